@@ -1,0 +1,209 @@
+/*
+ * midas_snps.h -- C-ABI of the MI355X-native MIDAS SNP pileup (libmidas_snps_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of snayfach/MIDAS: the pileup +
+ * allele-count stage of `run_midas.py snps`.  The reference has no FFI for it;
+ * the seam is Python (all citations are into /root/reference):
+ *
+ *   midas/run/snps.py:301      pysam_pileup(args, species, contigs)
+ *   midas/run/snps.py:194-199  bamfile.count_coverage(contig.id, start=0, end=contig.length,
+ *                                quality_threshold=args['baseq'], read_callback=keep_read)
+ *   midas/run/snps.py:141-162  keep_read(aln)                  (per-read filter + 2 counters)
+ *   midas/run/snps.py:201-213  per-site emit loop              (ref_allele, depth, 3 counters)
+ *   midas/run/snps.py:130-137  index_bam                       (samtools index)
+ *
+ * Every entry point below names the reference line(s) it replaces.  Only plain C
+ * types cross the boundary.  Ownership: the caller allocates and owns every host
+ * buffer it passes in or receives results in; the library never keeps a host
+ * pointer past the call that received it and never frees caller memory.  Device
+ * memory is owned by the context / batch objects and released by their destroy
+ * calls.  No global state; a context is bound to one GPU and may be used by one
+ * thread at a time (use one context per thread / per rank).
+ *
+ * Error convention: every call returns MIDAS_SNPS_OK (0) or a negative /
+ * positive status; midas_snps_last_error() returns a human-readable message for
+ * the last failing call on that context.  Nothing aborts or throws across the
+ * ABI.  The Python host turns a non-zero status into the reference's own
+ * convention, sys.exit("\nError: ...\n") (midas/utility.py:227-232).
+ *
+ * There is NO CPU fallback behind these symbols: if no gfx950 device is present
+ * midas_snps_create() fails with MIDAS_SNPS_ERR_NO_DEVICE.  The host-only
+ * helpers (pack / plan / version) work without a GPU.
+ */
+#ifndef MIDAS_SNPS_H
+#define MIDAS_SNPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIDAS_SNPS_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  MIDAS_SNPS_OK = 0,
+  /* Per-read conditions under which the reference raises inside the worker
+   * (numbering shared with oracle/pileup_oracle.py).  The offending read index
+   * (lowest one) is in the error string and in midas_snps_last_error_read(). */
+  MIDAS_SNPS_ERR_READ_NO_SEQ = 1,        /* len(aln.query_alignment_sequence) on None: TypeError  (snps.py:145) */
+  MIDAS_SNPS_ERR_READ_NO_NM = 2,         /* dict(aln.tags)['NM']: KeyError                         (snps.py:148) */
+  MIDAS_SNPS_ERR_READ_ZERO_ALIGN = 3,    /* /float(align_len) with align_len == 0: ZeroDivisionError (snps.py:148) */
+  MIDAS_SNPS_ERR_READ_NO_QUAL = 4,       /* np.mean(None): TypeError                               (snps.py:151) */
+  MIDAS_SNPS_ERR_READ_CIGAR_OVERRUN = 5, /* seq[qpos] past l_seq on a kept read: IndexError        (pysam count_coverage) */
+  MIDAS_SNPS_ERR_READ_BAD_CIGAR_OP = 6,  /* CIGAR op code > 8                                      */
+  /* Library / argument errors */
+  MIDAS_SNPS_ERR_INVALID_ARG = -1,
+  MIDAS_SNPS_ERR_NO_DEVICE = -2,         /* no HIP device / not gfx950 / HIP runtime failure at create */
+  MIDAS_SNPS_ERR_HIP = -3,               /* a HIP runtime call failed (message has hipGetErrorString) */
+  MIDAS_SNPS_ERR_OUT_OF_MEMORY = -4,
+  MIDAS_SNPS_ERR_UNSUPPORTED = -5,       /* l_seq > 1024, l_seq/n_cigar/NM > 65534, > 2^31-1 reads, zero-length contig */
+  MIDAS_SNPS_ERR_BAD_LAYOUT = -6         /* offsets out of range / not monotone, read_begin inconsistent */
+};
+
+/* ---- thresholds: the five `args[...]` values the path reads --------------
+ * scripts/run_midas.py:410-419 (defaults mapid 94.0, mapq 20, baseq 30, readq 20,
+ * aln_cov 0.75); consumed at midas/run/snps.py:148-157 and :198.               */
+typedef struct midas_snps_thresholds {
+  int32_t baseq;    /* count a base iff qual >= baseq (baseq <= 0: every base)   */
+  int32_t mapq;     /* keep read iff mapq >= mapq                                 */
+  int32_t readq;    /* keep read iff mean(qual over all l_seq bases) >= readq     */
+  int32_t reserved; /* must be 0                                                  */
+  double mapid;     /* keep read iff 100*(align_len-NM)/float(align_len) >= mapid */
+  double aln_cov;   /* keep read iff align_len/float(l_seq) >= aln_cov            */
+} midas_snps_thresholds;
+
+/* ---- inputs ---------------------------------------------------------------
+ * Alignment records in BAM-native encodings, struct-of-arrays, host memory,
+ * grouped by contig in the order of the contig table and (for speed, not for
+ * correctness) sorted by pos inside a contig -- i.e. the order of the
+ * coordinate-sorted snps/temp/genomes.bam (midas/run/snps.py:116-120).
+ *   seq4:  4-bit codes "=ACMGRSVTWYHKDBN", two per byte, first base in the high nibble
+ *   qual:  phred bytes, l_seq per read; qual[0]==0xFF means QUAL absent
+ *   cigar: u32 = len<<4 | op, op in MIDNSHP=X (0..8)
+ *   nm:    NM aux tag, or -1 when the record has none
+ *   *_off: CSR offsets, n_reads+1 entries each (seq_off/qual_off in bytes, cigar_off in u32 elements)
+ * `flag` is carried for completeness; the path never looks at it (with a callable
+ * read_callback pysam applies no flag filter), and it may be NULL.               */
+typedef struct midas_snps_reads {
+  int64_t n_reads;
+  const int32_t* pos;
+  const uint8_t* mapq;
+  const uint16_t* flag;
+  const int32_t* nm;
+  const int32_t* l_seq;
+  const int64_t* seq_off;
+  const int64_t* qual_off;
+  const int64_t* cigar_off;
+  const uint8_t* seq4;
+  const uint8_t* qual;
+  const uint32_t* cigar;
+} midas_snps_reads;
+
+/* Contig table: what initialize_contigs() builds (midas/run/snps.py:55-67), flattened.
+ * `ref` holds the FASTA letters of all contigs back to back in table order (any case;
+ * the library upper-cases ASCII a-z exactly like str.upper() at snps.py:62).
+ * Reads of contig c are read indices [read_begin[c], read_begin[c+1]).            */
+typedef struct midas_snps_contigs {
+  int32_t n_contigs;
+  int32_t n_species;
+  const int64_t* length;      /* [n_contigs]   > 0                                  */
+  const int32_t* species;     /* [n_contigs]   species index in [0, n_species)      */
+  const int64_t* read_begin;  /* [n_contigs+1] non-decreasing, last == n_reads      */
+  const uint8_t* ref;         /* [sum(length)]                                      */
+} midas_snps_contigs;
+
+/* Per-species counters, in this order (midas/run/snps.py:172-176, 211-213, 143, 161).
+ * genome_length is sum(length) and is left to the caller.                          */
+enum {
+  MIDAS_SNPS_STAT_ALIGNED_READS = 0,
+  MIDAS_SNPS_STAT_MAPPED_READS = 1,
+  MIDAS_SNPS_STAT_COVERED_BASES = 2,
+  MIDAS_SNPS_STAT_TOTAL_DEPTH = 3,
+  MIDAS_SNPS_NUM_STATS = 4
+};
+
+typedef struct midas_snps_ctx midas_snps_ctx;
+typedef struct midas_snps_batch midas_snps_batch;
+
+/* ---- library ------------------------------------------------------------ */
+int32_t midas_snps_abi_version(void);
+/* Static string for a status code (never NULL). */
+const char* midas_snps_status_string(int32_t status);
+
+/* ---- context: one per GPU ------------------------------------------------
+ * Replaces the per-worker-process module globals `aln_stats` / `global_args`
+ * (midas/run/snps.py:142,167-176) and the mp.Pool worker itself
+ * (midas/utility.py:81-107).                                                     */
+int32_t midas_snps_create(int32_t device_ordinal, midas_snps_ctx** out_ctx);
+void midas_snps_destroy(midas_snps_ctx* ctx);
+const char* midas_snps_last_error(const midas_snps_ctx* ctx);
+/* Lowest index of a read that made the last pileup fail with a MIDAS_SNPS_ERR_READ_* status, else -1. */
+int64_t midas_snps_last_error_read(const midas_snps_ctx* ctx);
+/* Launch on an existing HIP stream (hipStream_t as void*; e.g. torch's current stream) instead of
+ * the context's own.  NULL restores the context's stream.                                       */
+int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream);
+/* Device facts for logs: name (<=255 chars), compute units, HBM bytes. */
+int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes);
+
+/* ---- one-shot: host buffers in, host buffers out --------------------------
+ * Replaces, for every contig of the table at once, the call
+ *   bamfile.count_coverage(contig.id, 0, contig.length, args['baseq'], keep_read)
+ * (midas/run/snps.py:194-199) together with keep_read (:141-162) and the counter
+ * part of the emit loop (:204-213).
+ *   out_counts [sum(length) * 4] u32, per site A,C,G,T      (counts[0..3][i], :205-208)
+ *   out_allele [sum(length)]     u8, upper-cased ref letter  (contig.seq[i],   :203) -- may be NULL
+ *   out_stats  [n_species * 4]   i64, MIDAS_SNPS_STAT_* order
+ * On a MIDAS_SNPS_ERR_READ_* status the outputs are unspecified, as in the
+ * reference where the worker's exception discards them.                           */
+int32_t midas_snps_pileup(midas_snps_ctx* ctx, const midas_snps_thresholds* thr,
+                          const midas_snps_contigs* contigs, const midas_snps_reads* reads,
+                          uint32_t* out_counts, uint8_t* out_allele, int64_t* out_stats);
+
+/* ---- resident batches: upload once, run many ------------------------------
+ * A batch is the device-resident form of (contig table, reads): packed read
+ * records, the reference letters and the tile table.  Creating it replaces what
+ * `pysam.AlignmentFile(bampath)` + htslib's record decode do per worker
+ * (midas/run/snps.py:186); running it replaces index_bam (:130-137, the device
+ * builds its own per-tile read index each run) and the calls named above.      */
+int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
+                                const midas_snps_reads* reads, midas_snps_batch** out_batch);
+void midas_snps_batch_destroy(midas_snps_batch* batch);
+/* Enqueue one full pass (index + filter + pileup + per-species counters) on the context's stream;
+ * asynchronous.  Results stay on the device until midas_snps_batch_fetch().                    */
+int32_t midas_snps_batch_run(midas_snps_batch* batch, const midas_snps_thresholds* thr);
+/* Wait for the stream, then report the status of the last run (MIDAS_SNPS_ERR_READ_* possible). */
+int32_t midas_snps_batch_sync(midas_snps_batch* batch);
+/* sync + copy results to host.  Any of the three pointers may be NULL. */
+int32_t midas_snps_batch_fetch(midas_snps_batch* batch, uint32_t* out_counts, uint8_t* out_allele,
+                               int64_t* out_stats);
+/* Facts about a batch, for roofline accounting: */
+typedef struct midas_snps_batch_info {
+  int64_t n_reads;
+  int64_t n_sites;          /* sum(length)                                               */
+  int64_t n_tiles;
+  int64_t packed_bytes;     /* device bytes of packed records + payload                  */
+  int64_t algorithmic_bytes;/* sum(ceil(l/2)+l+4*n_cigar+16) + 17*n_sites  */
+  int32_t tile_sites;
+  int32_t lanes_per_read;
+} midas_snps_batch_info;
+int32_t midas_snps_batch_get_info(const midas_snps_batch* batch, midas_snps_batch_info* out);
+/* Device-side durations (ms, HIP events on the run's stream) of the last run's kernels:
+ * [0] index kernel, [1] pileup kernel, [2] whole run.  Recording is on only after
+ * midas_snps_batch_enable_timing(batch, 1).                                                    */
+int32_t midas_snps_batch_enable_timing(midas_snps_batch* batch, int32_t on);
+int32_t midas_snps_batch_last_timing(midas_snps_batch* batch, float out_ms[3]);
+
+/* ---- host-only helpers (no GPU needed) -------------------------------------
+ * The packer that batch_create() runs, exposed so that CPU-only tests can check
+ * the device layout: returns the number of payload bytes via *out_blob_bytes; if
+ * rec16/blob are non-NULL they receive n_reads*16 bytes of records and the payload. */
+int32_t midas_snps_pack_reads(const midas_snps_reads* reads, void* rec16, void* blob,
+                              int64_t blob_capacity, int64_t* out_blob_bytes,
+                              int32_t* out_max_l_seq, char* err256);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDAS_SNPS_H */

@@ -1,0 +1,337 @@
+"""ctypes binding of include/midas_snps.h (libmidas_snps_hip.so).
+
+There is no CPU fallback: if the library is missing, or no gfx950 GPU is visible,
+the calls raise.  Nothing under ``oracle/`` is imported from here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+ABI_VERSION = 1
+
+STAT_ALIGNED_READS, STAT_MAPPED_READS, STAT_COVERED_BASES, STAT_TOTAL_DEPTH = range(4)
+NUM_STATS = 4
+
+ERR_READ_NO_SEQ, ERR_READ_NO_NM, ERR_READ_ZERO_ALIGN, ERR_READ_NO_QUAL, ERR_READ_CIGAR_OVERRUN, \
+    ERR_READ_BAD_CIGAR_OP = range(1, 7)
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_BAD_LAYOUT = \
+    -1, -2, -3, -4, -5, -6
+
+
+class MidasSnpsError(RuntimeError):
+    def __init__(self, status: int, message: str, read_index: int = -1):
+        super().__init__("midas_snps status %d: %s" % (status, message))
+        self.status = status
+        self.message = message
+        self.read_index = read_index
+
+
+class Thresholds(C.Structure):
+    """scripts/run_midas.py:410-419 defaults."""
+    _fields_ = [("baseq", C.c_int32), ("mapq", C.c_int32), ("readq", C.c_int32), ("reserved", C.c_int32),
+                ("mapid", C.c_double), ("aln_cov", C.c_double)]
+
+    @classmethod
+    def from_args(cls, args: dict) -> "Thresholds":
+        return cls(int(args['baseq']), int(args['mapq']), int(args['readq']), 0,
+                   float(args['mapid']), float(args['aln_cov']))
+
+
+DEFAULT_ARGS = {'mapid': 94.0, 'mapq': 20, 'baseq': 30, 'readq': 20, 'aln_cov': 0.75}
+
+
+class _Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("pos", C.c_void_p), ("mapq", C.c_void_p), ("flag", C.c_void_p),
+                ("nm", C.c_void_p), ("l_seq", C.c_void_p), ("seq_off", C.c_void_p), ("qual_off", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("seq4", C.c_void_p), ("qual", C.c_void_p), ("cigar", C.c_void_p)]
+
+
+class _Contigs(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("n_species", C.c_int32), ("length", C.c_void_p),
+                ("species", C.c_void_p), ("read_begin", C.c_void_p), ("ref", C.c_void_p)]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_sites", C.c_int64), ("n_tiles", C.c_int64),
+                ("packed_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
+                ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32)]
+
+
+_SOA_DTYPES = {
+    'pos': np.int32, 'mapq': np.uint8, 'flag': np.uint16, 'nm': np.int32, 'l_seq': np.int32,
+    'seq_off': np.int64, 'qual_off': np.int64, 'cigar_off': np.int64,
+    'seq4': np.uint8, 'qual': np.uint8, 'cigar': np.uint32,
+}
+
+
+@dataclass
+class ReadsSoA:
+    """Alignment records in BAM-native encodings (see midas_snps_reads in the header)."""
+    pos: np.ndarray
+    mapq: np.ndarray
+    flag: np.ndarray
+    nm: np.ndarray
+    l_seq: np.ndarray
+    seq_off: np.ndarray
+    qual_off: np.ndarray
+    cigar_off: np.ndarray
+    seq4: np.ndarray
+    qual: np.ndarray
+    cigar: np.ndarray
+
+    def __post_init__(self):
+        for k, dt in _SOA_DTYPES.items():
+            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=dt))
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.pos.shape[0])
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k in _SOA_DTYPES}
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "ReadsSoA":
+        return cls(**{k: d[k] for k in _SOA_DTYPES})
+
+    @classmethod
+    def empty(cls) -> "ReadsSoA":
+        z = lambda dt, n=0: np.zeros(n, dtype=dt)
+        return cls(z(np.int32), z(np.uint8), z(np.uint16), z(np.int32), z(np.int32),
+                   z(np.int64, 1), z(np.int64, 1), z(np.int64, 1), z(np.uint8), z(np.uint8), z(np.uint32))
+
+    def _c(self) -> _Reads:
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        return _Reads(self.n_reads, p(self.pos), p(self.mapq), p(self.flag), p(self.nm), p(self.l_seq),
+                      self.seq_off.ctypes.data_as(C.c_void_p), self.qual_off.ctypes.data_as(C.c_void_p),
+                      self.cigar_off.ctypes.data_as(C.c_void_p), p(self.seq4), p(self.qual), p(self.cigar))
+
+
+@dataclass
+class ContigTable:
+    """Flattened `contigs` dict of midas/run/snps.py:55-67 (see midas_snps_contigs)."""
+    length: np.ndarray        # [n_contigs] int64
+    species: np.ndarray       # [n_contigs] int32 index into species ids
+    read_begin: np.ndarray    # [n_contigs+1] int64
+    ref: np.ndarray           # [sum(length)] uint8
+    n_species: int
+    ids: list = field(default_factory=list)           # contig ids, table order
+    species_ids: list = field(default_factory=list)   # species ids, index order
+
+    def __post_init__(self):
+        self.length = np.ascontiguousarray(self.length, dtype=np.int64)
+        self.species = np.ascontiguousarray(self.species, dtype=np.int32)
+        self.read_begin = np.ascontiguousarray(self.read_begin, dtype=np.int64)
+        self.ref = np.ascontiguousarray(self.ref, dtype=np.uint8)
+
+    @property
+    def n_contigs(self) -> int:
+        return int(self.length.shape[0])
+
+    @property
+    def n_sites(self) -> int:
+        return int(self.length.sum())
+
+    def site_offsets(self) -> np.ndarray:
+        out = np.zeros(self.n_contigs + 1, dtype=np.int64)
+        np.cumsum(self.length, out=out[1:])
+        return out
+
+    def _c(self) -> _Contigs:
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        return _Contigs(self.n_contigs, int(self.n_species), p(self.length), p(self.species),
+                        self.read_begin.ctypes.data_as(C.c_void_p), p(self.ref))
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen the in-tree libmidas_snps_hip.so; raises if it cannot be found or built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise MidasSnpsError(ERR_NO_DEVICE, "native library %s is missing (run `python -m midas_amd.build`)" % path)
+        _build.build_native()
+    lib = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    sig = {
+        'midas_snps_abi_version': (i32, []),
+        'midas_snps_status_string': (C.c_char_p, [i32]),
+        'midas_snps_create': (i32, [i32, C.POINTER(vp)]),
+        'midas_snps_destroy': (None, [vp]),
+        'midas_snps_last_error': (C.c_char_p, [vp]),
+        'midas_snps_last_error_read': (i64, [vp]),
+        'midas_snps_set_stream': (i32, [vp, vp]),
+        'midas_snps_device_info': (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i64)]),
+        'midas_snps_pileup': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Contigs), C.POINTER(_Reads), vp, vp, vp]),
+        'midas_snps_batch_create': (i32, [vp, C.POINTER(_Contigs), C.POINTER(_Reads), C.POINTER(vp)]),
+        'midas_snps_batch_destroy': (None, [vp]),
+        'midas_snps_batch_run': (i32, [vp, C.POINTER(Thresholds)]),
+        'midas_snps_batch_sync': (i32, [vp]),
+        'midas_snps_batch_fetch': (i32, [vp, vp, vp, vp]),
+        'midas_snps_batch_get_info': (i32, [vp, C.POINTER(BatchInfo)]),
+        'midas_snps_batch_enable_timing': (i32, [vp, i32]),
+        'midas_snps_batch_last_timing': (i32, [vp, C.POINTER(C.c_float)]),
+        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.midas_snps_abi_version() != ABI_VERSION:
+        raise MidasSnpsError(ERR_INVALID_ARG, "ABI version mismatch: library %d, binding %d"
+                             % (lib.midas_snps_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    'midas_snps_abi_version', 'midas_snps_status_string', 'midas_snps_create', 'midas_snps_destroy',
+    'midas_snps_last_error', 'midas_snps_last_error_read', 'midas_snps_set_stream', 'midas_snps_device_info',
+    'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
+    'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
+    'midas_snps_batch_enable_timing', 'midas_snps_batch_last_timing', 'midas_snps_pack_reads',
+]
+
+
+def pack_reads(reads: ReadsSoA):
+    """Host-only: run the packer and return (rec[n,16] uint8, blob uint8, max_l_seq)."""
+    lib = load_library()
+    r = reads._c()
+    nbytes = C.c_int64(0)
+    maxl = C.c_int32(0)
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_pack_reads(C.byref(r), None, None, 0, C.byref(nbytes), C.byref(maxl), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    rec = np.zeros((reads.n_reads, 16), dtype=np.uint8)
+    blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
+    st = lib.midas_snps_pack_reads(C.byref(r), rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
+                                   blob.size, C.byref(nbytes), C.byref(maxl), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    return rec, blob[:int(nbytes.value)], int(maxl.value)
+
+
+class Context:
+    """One GPU.  Replaces a `mp.Pool` worker and its module globals (midas/run/snps.py:142,167-176)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        st = self._lib.midas_snps_create(int(device), C.byref(h))
+        if st != 0:
+            raise MidasSnpsError(st, "midas_snps_create(device=%d): %s"
+                                 % (device, self._lib.midas_snps_status_string(st).decode()))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.midas_snps_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st: int):
+        if st != 0:
+            msg = self._lib.midas_snps_last_error(self._h).decode() or \
+                self._lib.midas_snps_status_string(st).decode()
+            raise MidasSnpsError(st, msg, int(self._lib.midas_snps_last_error_read(self._h)))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.midas_snps_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu = C.c_int32(0)
+        mem = C.c_int64(0)
+        self._check(self._lib.midas_snps_device_info(self._h, name, C.byref(ncu), C.byref(mem)))
+        return {'name': name.value.decode(), 'compute_units': ncu.value, 'hbm_bytes': mem.value}
+
+    def pileup(self, thr: Thresholds, contigs: ContigTable, reads: ReadsSoA, want_allele: bool = True):
+        """One-shot midas_snps_pileup(): returns (counts[n_sites,4] u32, allele[n_sites] u8 | None, stats[n_species,4] i64)."""
+        n = contigs.n_sites
+        counts = np.empty((n, 4), dtype=np.uint32)
+        allele = np.empty(n, dtype=np.uint8) if want_allele else None
+        stats = np.zeros((contigs.n_species, NUM_STATS), dtype=np.int64)
+        c, r = contigs._c(), reads._c()
+        st = self._lib.midas_snps_pileup(self._h, C.byref(thr), C.byref(c), C.byref(r),
+                                         counts.ctypes.data_as(C.c_void_p),
+                                         allele.ctypes.data_as(C.c_void_p) if want_allele else None,
+                                         stats.ctypes.data_as(C.c_void_p))
+        self._check(st)
+        return counts, allele, stats
+
+    def batch(self, contigs: ContigTable, reads: ReadsSoA) -> "Batch":
+        return Batch(self, contigs, reads)
+
+
+class Batch:
+    """Device-resident (contig table, reads): upload once, run many."""
+
+    def __init__(self, ctx: Context, contigs: ContigTable, reads: ReadsSoA):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.n_sites = contigs.n_sites
+        self.n_species = int(contigs.n_species)
+        h = C.c_void_p()
+        c, r = contigs._c(), reads._c()
+        ctx._check(self._lib.midas_snps_batch_create(ctx._h, C.byref(c), C.byref(r), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.midas_snps_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, thr: Thresholds):
+        self.ctx._check(self._lib.midas_snps_batch_run(self._h, C.byref(thr)))
+
+    def sync(self):
+        self.ctx._check(self._lib.midas_snps_batch_sync(self._h))
+
+    def fetch(self, counts: bool = True, allele: bool = True, stats: bool = True):
+        oc = np.empty((self.n_sites, 4), dtype=np.uint32) if counts else None
+        oa = np.empty(self.n_sites, dtype=np.uint8) if allele else None
+        os_ = np.zeros((self.n_species, NUM_STATS), dtype=np.int64) if stats else None
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.ctx._check(self._lib.midas_snps_batch_fetch(self._h, p(oc), p(oa), p(os_)))
+        return oc, oa, os_
+
+    def info(self) -> BatchInfo:
+        bi = BatchInfo()
+        self.ctx._check(self._lib.midas_snps_batch_get_info(self._h, C.byref(bi)))
+        return bi
+
+    def enable_timing(self, on: bool = True):
+        self.ctx._check(self._lib.midas_snps_batch_enable_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        ms = (C.c_float * 3)()
+        self.ctx._check(self._lib.midas_snps_batch_last_timing(self._h, ms))
+        return {'index_ms': ms[0], 'pileup_ms': ms[1], 'run_ms': ms[2]}

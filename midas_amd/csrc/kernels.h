@@ -1,0 +1,57 @@
+// Launch interface between the C-ABI runtime (snps_abi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+
+namespace midas {
+
+constexpr int kTileShift = 12;             // 4096 sites per tile: 4 planes x 4096 x u32 = 64 KiB of LDS
+constexpr int kTileSites = 1 << kTileShift;
+constexpr int kPileupBlock = 512;          // 8 waves; 2 workgroups per CU (LDS-limited)
+constexpr int kIndexBlock = 256;
+
+// Per-species counters, same order as MIDAS_SNPS_STAT_* in include/midas_snps.h.
+constexpr int MIDAS_STATS = 4;
+constexpr int MIDAS_STAT_ALIGNED = 0;
+constexpr int MIDAS_STAT_MAPPED = 1;
+constexpr int MIDAS_STAT_COVERED = 2;
+constexpr int MIDAS_STAT_DEPTH = 3;
+
+struct IndexParams {
+  const ReadRec* rec;
+  const uint8_t* blob;
+  const int32_t* contig_read_begin;  // [n_contigs + 1]
+  const int32_t* contig_tile_base;   // [n_contigs + 1]
+  const int32_t* contig_len;         // [n_contigs]
+  uint32_t* rbinv;                   // [n_tiles]  max over overlapping reads of (n_reads - index); 0 = none
+  uint32_t* rend;                    // [n_tiles]  max over overlapping reads of (index + 1)
+  int32_t n_reads;
+  int32_t n_contigs;
+};
+
+struct PileupParams {
+  const ReadRec* rec;
+  const uint8_t* blob;
+  const uint8_t* ref;
+  const Tile* tiles;
+  const uint32_t* rbinv;
+  const uint32_t* rend;
+  uint32_t* out_counts;              // [n_sites][4]
+  uint8_t* out_allele;               // [n_sites] or nullptr
+  unsigned long long* stats;         // [n_species][4]
+  unsigned long long* err;           // one word, atomicMin((read << 8) | kind)
+  int32_t n_tiles;
+  int32_t n_reads;
+  int32_t tiles_per_xcd;
+  int32_t lanes_per_read;            // ceil(max_l_seq / 16)
+  int32_t reads_per_wave;            // 64 / lanes_per_read
+  int32_t baseq, mapq, readq;
+  double mapid, aln_cov;
+};
+
+hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);
+hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream);
+
+}  // namespace midas

@@ -1,0 +1,62 @@
+// Device data layout of the MI355X SNP pileup, shared by the host packer and the kernels.
+//
+// HBM layout of one resident batch (all sizes for L=150, one CIGAR op):
+//
+//   rec   [n_reads]   16 B   fixed part of a BAM record (one dwordx4 load per read)
+//   blob  [...]       232 B  per read, 8-byte aligned, reads back to back in BAM order:
+//                              qual  l_seq bytes          -> padded to 4
+//                              seq4  ceil(l_seq/2) bytes  -> padded to 4
+//                              cigar n_cigar * u32        -> whole read padded to 8
+//                            coordinate-sorted input => the reads of a tile are one contiguous
+//                            byte range of `blob`, so a workgroup streams it with full lines.
+//   ref   [n_sites]   1 B    FASTA letters, contigs back to back
+//   tiles [n_tiles]   32 B   {contig, start, len, species, site_base}
+//   out counts [n_sites][4] u32 (A,C,G,T) ; out allele [n_sites] u8
+//
+// Algorithmic bytes: ceil(l/2) + l + 4*n_cigar + 16 per read, 17 per site.
+#pragma once
+#include <stdint.h>
+
+namespace midas {
+
+struct ReadRec {            // 16 bytes, 16-byte aligned
+  int32_t pos;              // BAM pos (0-based leftmost)
+  uint32_t blob_off8;       // payload offset in 8-byte units
+  uint16_t l_seq;           // stored query length (soft clips included)
+  uint16_t n_cigar;
+  uint16_t nm;              // NM tag; kNmAbsent when the record has none
+  uint8_t mapq;
+  uint8_t flags;            // kRecQualAbsent
+};
+static_assert(sizeof(ReadRec) == 16, "ReadRec must be 16 bytes");
+
+constexpr uint16_t kNmAbsent = 0xFFFF;
+constexpr uint8_t kRecQualAbsent = 1;
+
+constexpr int kMaxLSeq = 1024;      // 64 lanes x 16 bases: one wave row per read at most
+constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
+
+struct Tile {               // 32 bytes
+  int32_t contig;
+  int32_t start;            // first site of the tile, contig coordinates
+  int32_t len;              // sites in the tile (<= tile_sites)
+  int32_t species;
+  int64_t site_base;        // index of `start` in the concatenated site space
+  int32_t contig_len;
+  int32_t pad;
+};
+static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
+
+// Offsets of the three payload sections inside a read's blob.
+__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return (l_seq + 3u) & ~3u; }
+__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq) {
+  return blob_seq_off(l_seq) + ((((l_seq + 1u) >> 1) + 3u) & ~3u);
+}
+__host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar) {
+  return (blob_cigar_off(l_seq) + 4u * n_cigar + 7u) & ~7u;
+}
+
+// Error word written by the kernels: (read_index << 8) | kind, reduced with atomicMin.
+constexpr unsigned long long kNoError = ~0ull;
+
+}  // namespace midas

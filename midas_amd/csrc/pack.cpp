@@ -1,0 +1,193 @@
+// Host packer: BAM-native SoA records -> the device layout of layout.h.
+// Validates everything the kernels assume, so that malformed input is an error status, never UB.
+#include "pack.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace midas {
+
+namespace {
+
+int hw_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (n > 16) n = 16;
+  return (int)n;
+}
+
+template <class F>
+void parallel_ranges(int64_t n, F&& fn) {
+  int nt = hw_threads();
+  if (n < (int64_t)1 << 16) nt = 1;
+  if (nt == 1) {
+    fn(0, (int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    int64_t lo = t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([&fn, t, lo, hi] { fn(t, lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
+void set_err(char* err256, const char* fmt, long long a = 0, long long b = 0, long long c = 0) {
+  if (err256) snprintf(err256, 256, fmt, a, b, c);
+}
+
+}  // namespace
+
+int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64_t blob_capacity,
+                   PackSummary* out, char* err256) {
+  if (!r || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const int64_t n = r->n_reads;
+  *out = PackSummary{};
+  if (n < 0 || n > 2000000000LL) {
+    set_err(err256, "n_reads %lld out of range", (long long)n);
+    return n < 0 ? MIDAS_SNPS_ERR_INVALID_ARG : MIDAS_SNPS_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return MIDAS_SNPS_OK;
+  if (!r->pos || !r->mapq || !r->nm || !r->l_seq || !r->seq_off || !r->qual_off || !r->cigar_off ||
+      !r->seq4 || !r->qual || !r->cigar) {
+    set_err(err256, "NULL array in midas_snps_reads");
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  }
+
+  // Pass 1: validate + per-read payload size.
+  std::vector<uint32_t> bytes(n);
+  std::atomic<int32_t> status{MIDAS_SNPS_OK};
+  std::atomic<long long> bad_read{-1};
+  const int nt = hw_threads();
+  std::vector<int64_t> alg(nt, 0);
+  std::vector<int32_t> maxl(nt, 0);
+  auto fail = [&](int32_t st, int64_t i) {
+    int32_t ok = MIDAS_SNPS_OK;
+    if (status.compare_exchange_strong(ok, st)) bad_read = i;
+  };
+  parallel_ranges(n, [&](int t, int64_t lo, int64_t hi) {
+    int64_t a = 0;
+    int32_t ml = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t l = r->l_seq[i];
+      const int64_t nc = r->cigar_off[i + 1] - r->cigar_off[i];
+      const int64_t sb = r->seq_off[i + 1] - r->seq_off[i];
+      const int64_t qb = r->qual_off[i + 1] - r->qual_off[i];
+      if (l < 0 || nc < 0 || r->cigar_off[i] < 0 || r->seq_off[i] < 0 || r->qual_off[i] < 0 ||
+          sb < (l + 1) / 2 || qb < l) {
+        fail(MIDAS_SNPS_ERR_BAD_LAYOUT, i);
+        return;
+      }
+      if (l > kMaxLSeq || nc > kMaxField16 || r->nm[i] > kMaxField16) {
+        fail(MIDAS_SNPS_ERR_UNSUPPORTED, i);
+        return;
+      }
+      bytes[i] = blob_bytes((uint32_t)l, (uint32_t)nc);
+      a += (l + 1) / 2 + l + 4 * nc + 16;
+      ml = std::max<int32_t>(ml, (int32_t)l);
+    }
+    alg[t] += a;
+    maxl[t] = std::max(maxl[t], ml);
+  });
+  if (status != MIDAS_SNPS_OK) {
+    if (status == MIDAS_SNPS_ERR_UNSUPPORTED)
+      set_err(err256, "read %lld: l_seq > %lld or n_cigar/NM > %lld is not supported", bad_read.load(),
+              kMaxLSeq, kMaxField16);
+    else
+      set_err(err256, "read %lld: negative size or CSR offsets shorter than l_seq", bad_read.load());
+    return status;
+  }
+  int64_t total = 0;
+  for (int64_t i = 0; i < n; ++i) total += bytes[i];
+  out->blob_bytes = total;
+  for (int t = 0; t < nt; ++t) {
+    out->read_algorithmic_bytes += alg[t];
+    out->max_l_seq = std::max(out->max_l_seq, maxl[t]);
+  }
+  if ((uint64_t)total / 8 > 0xFFFFFFFFull) {
+    set_err(err256, "packed payload %lld bytes exceeds the 32 GiB a batch can address", (long long)total);
+    return MIDAS_SNPS_ERR_UNSUPPORTED;
+  }
+  if (!rec && !blob) return MIDAS_SNPS_OK;  // size query
+  if (!rec || !blob || blob_capacity < total) {
+    set_err(err256, "blob capacity %lld < %lld", (long long)blob_capacity, (long long)total);
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  }
+
+  // Pass 2: offsets (serial prefix sum over chunk totals), then copy in parallel.
+  std::vector<int64_t> off(n + 1);
+  off[0] = 0;
+  for (int64_t i = 0; i < n; ++i) off[i + 1] = off[i] + bytes[i];
+  parallel_ranges(n, [&](int, int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const uint32_t l = (uint32_t)r->l_seq[i];
+      const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+      uint8_t* b = blob + off[i];
+      const uint8_t* q = r->qual + r->qual_off[i];
+      memset(b, 0, bytes[i]);
+      memcpy(b, q, l);
+      memcpy(b + blob_seq_off(l), r->seq4 + r->seq_off[i], (l + 1) / 2);
+      memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
+      ReadRec rr;
+      rr.pos = r->pos[i];
+      rr.blob_off8 = (uint32_t)(off[i] >> 3);
+      rr.l_seq = (uint16_t)l;
+      rr.n_cigar = (uint16_t)nc;
+      rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
+      rr.mapq = r->mapq[i];
+      rr.flags = (l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0;
+      rec[i] = rr;
+    }
+  });
+  return MIDAS_SNPS_OK;
+}
+
+int32_t validate_contigs(const midas_snps_contigs* c, int64_t n_reads, int64_t* out_sites, char* err256) {
+  if (!c || c->n_contigs < 0 || c->n_species < 0) {
+    set_err(err256, "bad contig table header");
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  }
+  if (c->n_contigs > 0 && (!c->length || !c->species || !c->read_begin || !c->ref)) {
+    set_err(err256, "NULL array in midas_snps_contigs");
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  }
+  int64_t sites = 0;
+  for (int32_t i = 0; i < c->n_contigs; ++i) {
+    if (c->length[i] <= 0) {
+      // reference: pysam raises ValueError("interval of size 0") for an empty contig
+      set_err(err256, "contig %lld has length %lld (count_coverage: interval of size 0)", i, c->length[i]);
+      return MIDAS_SNPS_ERR_UNSUPPORTED;
+    }
+    if (c->length[i] > 0x7FFFFFFFLL) {
+      set_err(err256, "contig %lld longer than 2^31-1 (BAM limit)", i);
+      return MIDAS_SNPS_ERR_UNSUPPORTED;
+    }
+    if (c->species[i] < 0 || c->species[i] >= c->n_species) {
+      set_err(err256, "contig %lld: species index %lld out of range", i, c->species[i]);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+    if (c->read_begin[i] < 0 || c->read_begin[i + 1] < c->read_begin[i]) {
+      set_err(err256, "read_begin not monotone at contig %lld", i);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    sites += c->length[i];
+  }
+  if (c->n_contigs > 0 && (c->read_begin[0] != 0 || c->read_begin[c->n_contigs] != n_reads)) {
+    set_err(err256, "read_begin must start at 0 and end at n_reads (%lld)", (long long)n_reads);
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
+  if (c->n_contigs == 0 && n_reads != 0) {
+    set_err(err256, "reads without contigs");
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
+  *out_sites = sites;
+  return MIDAS_SNPS_OK;
+}
+
+}  // namespace midas

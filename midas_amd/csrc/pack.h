@@ -1,0 +1,20 @@
+#pragma once
+#include "../../include/midas_snps.h"
+#include "layout.h"
+
+namespace midas {
+
+struct PackSummary {
+  int64_t blob_bytes = 0;
+  int64_t read_algorithmic_bytes = 0;  // sum(ceil(l/2) + l + 4*n_cigar + 16)
+  int32_t max_l_seq = 0;
+};
+
+// rec == blob == nullptr: size query only.
+int32_t pack_reads(const midas_snps_reads* reads, ReadRec* rec, uint8_t* blob, int64_t blob_capacity,
+                   PackSummary* out, char* err256);
+
+int32_t validate_contigs(const midas_snps_contigs* contigs, int64_t n_reads, int64_t* out_sites,
+                         char* err256);
+
+}  // namespace midas

@@ -1,0 +1,454 @@
+// C-ABI runtime of libmidas_snps_hip.so: contexts, resident batches, launches.  See include/midas_snps.h
+// for the contract and the reference lines each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/midas_snps.h"
+#include "kernels.h"
+#include "layout.h"
+#include "pack.h"
+
+using namespace midas;
+
+struct midas_snps_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int64_t err_read = -1;
+  hipDeviceProp_t prop;
+};
+
+struct midas_snps_batch {
+  midas_snps_ctx* ctx = nullptr;
+  // device
+  ReadRec* d_rec = nullptr;
+  uint8_t* d_blob = nullptr;
+  uint8_t* d_ref = nullptr;
+  Tile* d_tiles = nullptr;
+  int32_t* d_contig_read_begin = nullptr;
+  int32_t* d_contig_tile_base = nullptr;
+  int32_t* d_contig_len = nullptr;
+  uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
+  size_t work_bytes = 0;
+  uint32_t* d_counts = nullptr;
+  uint8_t* d_allele = nullptr;
+  // facts
+  int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
+  int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool have_timing = false;
+  bool ran = false;
+};
+
+namespace {
+
+int32_t fail(midas_snps_ctx* ctx, int32_t st, const std::string& msg) {
+  if (ctx) {
+    ctx->err = msg;
+  }
+  return st;
+}
+
+int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  return fail(ctx, e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP, buf);
+}
+
+#define HIP_TRY(ctx, call)                                   \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+  } while (0)
+
+uint32_t* work_rbinv(midas_snps_batch* b) { return reinterpret_cast<uint32_t*>(b->d_work); }
+uint32_t* work_rend(midas_snps_batch* b) { return work_rbinv(b) + b->n_tiles; }
+unsigned long long* work_stats(midas_snps_batch* b) {
+  size_t off = ((size_t)b->n_tiles * 8 + 15) & ~(size_t)15;
+  return reinterpret_cast<unsigned long long*>(b->d_work + off);
+}
+unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
+
+const char* read_err_name(int32_t st) {
+  switch (st) {
+    case MIDAS_SNPS_ERR_READ_NO_SEQ: return "record has no SEQ (reference: TypeError in keep_read)";
+    case MIDAS_SNPS_ERR_READ_NO_NM: return "record has no NM tag (reference: KeyError 'NM' in keep_read)";
+    case MIDAS_SNPS_ERR_READ_ZERO_ALIGN: return "aligned length is 0 (reference: ZeroDivisionError in keep_read)";
+    case MIDAS_SNPS_ERR_READ_NO_QUAL: return "record has no QUAL (reference: TypeError in np.mean)";
+    case MIDAS_SNPS_ERR_READ_CIGAR_OVERRUN: return "CIGAR consumes more query than SEQ holds (reference: IndexError)";
+    case MIDAS_SNPS_ERR_READ_BAD_CIGAR_OP: return "bad CIGAR op";
+    default: return "unknown";
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t midas_snps_abi_version(void) { return MIDAS_SNPS_ABI_VERSION; }
+
+const char* midas_snps_status_string(int32_t st) {
+  switch (st) {
+    case MIDAS_SNPS_OK: return "ok";
+    case MIDAS_SNPS_ERR_INVALID_ARG: return "invalid argument";
+    case MIDAS_SNPS_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case MIDAS_SNPS_ERR_HIP: return "HIP runtime error";
+    case MIDAS_SNPS_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case MIDAS_SNPS_ERR_UNSUPPORTED: return "unsupported input";
+    case MIDAS_SNPS_ERR_BAD_LAYOUT: return "inconsistent input layout";
+    default: return (st >= 1 && st <= 6) ? read_err_name(st) : "unknown status";
+  }
+}
+
+int32_t midas_snps_create(int32_t device_ordinal, midas_snps_ctx** out_ctx) {
+  if (!out_ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return MIDAS_SNPS_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = new (std::nothrow) midas_snps_ctx();
+  if (!ctx) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess ||
+      hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    delete ctx;
+    return MIDAS_SNPS_ERR_NO_DEVICE;
+  }
+  // The kernels are built for gfx950 only; anything else cannot run them.
+  if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MIDAS_SNPS_ERR_NO_DEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  *out_ctx = ctx;
+  return MIDAS_SNPS_OK;
+}
+
+void midas_snps_destroy(midas_snps_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* midas_snps_last_error(const midas_snps_ctx* ctx) { return ctx ? ctx->err.c_str() : "NULL context"; }
+
+int64_t midas_snps_last_error_read(const midas_snps_ctx* ctx) { return ctx ? ctx->err_read : -1; }
+
+int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes) {
+  if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (name256) snprintf(name256, 256, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_pack_reads(const midas_snps_reads* reads, void* rec16, void* blob, int64_t blob_capacity,
+                              int64_t* out_blob_bytes, int32_t* out_max_l_seq, char* err256) {
+  PackSummary s;
+  int32_t st = pack_reads(reads, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
+                          blob_capacity, &s, err256);
+  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
+  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
+  return st;
+}
+
+void midas_snps_batch_destroy(midas_snps_batch* b) {
+  if (!b) return;
+  if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  (void)hipFree(b->d_rec);
+  (void)hipFree(b->d_blob);
+  (void)hipFree(b->d_ref);
+  (void)hipFree(b->d_tiles);
+  (void)hipFree(b->d_contig_read_begin);
+  (void)hipFree(b->d_contig_tile_base);
+  (void)hipFree(b->d_contig_len);
+  (void)hipFree(b->d_work);
+  (void)hipFree(b->d_counts);
+  (void)hipFree(b->d_allele);
+  for (auto& e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
+                                const midas_snps_reads* reads, midas_snps_batch** out_batch) {
+  if (!ctx || !contigs || !reads || !out_batch) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out_batch = nullptr;
+  ctx->err.clear();
+  ctx->err_read = -1;
+  char ebuf[256] = {0};
+  int64_t n_sites = 0;
+  int32_t st = validate_contigs(contigs, reads->n_reads, &n_sites, ebuf);
+  if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
+
+  PackSummary ps;
+  st = pack_reads(reads, nullptr, nullptr, 0, &ps, ebuf);
+  if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
+
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  midas_snps_batch* b = new (std::nothrow) midas_snps_batch();
+  if (!b) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->ctx = ctx;
+  b->n_reads = reads->n_reads;
+  b->n_sites = n_sites;
+  b->n_contigs = contigs->n_contigs;
+  b->n_species = contigs->n_species;
+  b->blob_bytes = ps.blob_bytes;
+  b->alg_bytes = ps.read_algorithmic_bytes + 17 * n_sites;
+  b->lanes_per_read = ps.max_l_seq <= 16 ? 1 : (ps.max_l_seq + 15) / 16;
+
+#define B_TRY(call)                              \
+  do {                                           \
+    hipError_t e__ = (call);                     \
+    if (e__ != hipSuccess) {                     \
+      int32_t s__ = hip_fail(ctx, e__, #call);   \
+      midas_snps_batch_destroy(b);               \
+      return s__;                                \
+    }                                            \
+  } while (0)
+
+  // ---- tile table -------------------------------------------------------------------------
+  std::vector<Tile> tiles;
+  std::vector<int32_t> tile_base(contigs->n_contigs + 1, 0), clen(contigs->n_contigs), rbeg(contigs->n_contigs + 1, 0);
+  {
+    int64_t site = 0;
+    for (int32_t c = 0; c < contigs->n_contigs; ++c) {
+      const int64_t len = contigs->length[c];
+      tile_base[c] = (int32_t)tiles.size();
+      clen[c] = (int32_t)len;
+      rbeg[c] = (int32_t)contigs->read_begin[c];
+      for (int64_t s = 0; s < len; s += kTileSites) {
+        Tile t;
+        t.contig = c;
+        t.start = (int32_t)s;
+        t.len = (int32_t)((len - s) < kTileSites ? (len - s) : kTileSites);
+        t.species = contigs->species[c];
+        t.site_base = site + s;
+        t.contig_len = (int32_t)len;
+        t.pad = 0;
+        tiles.push_back(t);
+      }
+      site += len;
+    }
+    tile_base[contigs->n_contigs] = (int32_t)tiles.size();
+    rbeg[contigs->n_contigs] = (int32_t)reads->n_reads;
+  }
+  b->n_tiles = (int64_t)tiles.size();
+
+  // ---- pack + upload reads ------------------------------------------------------------------
+  const size_t blob_alloc = (size_t)ps.blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
+  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_reads > 0 ? b->n_reads : 1) * sizeof(ReadRec)));
+  B_TRY(hipMalloc(&b->d_blob, blob_alloc));
+  if (b->n_reads > 0) {
+    ReadRec* h_rec = nullptr;
+    uint8_t* h_blob = nullptr;
+    B_TRY(hipHostMalloc(&h_rec, (size_t)b->n_reads * sizeof(ReadRec), hipHostMallocDefault));
+    hipError_t e = hipHostMalloc(&h_blob, blob_alloc, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      (void)hipHostFree(h_rec);
+      int32_t s = hip_fail(ctx, e, "hipHostMalloc(blob)");
+      midas_snps_batch_destroy(b);
+      return s;
+    }
+    memset(h_blob + ps.blob_bytes, 0, 64);
+    st = pack_reads(reads, h_rec, h_blob, (int64_t)blob_alloc, &ps, ebuf);
+    hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    if (st == MIDAS_SNPS_OK) {
+      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)b->n_reads * sizeof(ReadRec), hipMemcpyHostToDevice);
+      e2 = hipMemcpy(b->d_blob, h_blob, blob_alloc, hipMemcpyHostToDevice);
+    }
+    (void)hipHostFree(h_rec);
+    (void)hipHostFree(h_blob);
+    if (st != MIDAS_SNPS_OK) {
+      midas_snps_batch_destroy(b);
+      return fail(ctx, st, ebuf);
+    }
+    B_TRY(e1);
+    B_TRY(e2);
+  } else {
+    B_TRY(hipMemset(b->d_blob, 0, blob_alloc));
+  }
+
+  // ---- reference letters, tables, workspace, outputs -----------------------------------------
+  const size_t ns = (size_t)(n_sites > 0 ? n_sites : 1);
+  B_TRY(hipMalloc(&b->d_ref, ns));
+  if (n_sites > 0) B_TRY(hipMemcpy(b->d_ref, contigs->ref, (size_t)n_sites, hipMemcpyHostToDevice));
+  const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
+  B_TRY(hipMalloc(&b->d_tiles, nt * sizeof(Tile)));
+  if (b->n_tiles > 0) B_TRY(hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
+  const size_t nc1 = (size_t)contigs->n_contigs + 1;
+  B_TRY(hipMalloc(&b->d_contig_read_begin, nc1 * 4));
+  B_TRY(hipMalloc(&b->d_contig_tile_base, nc1 * 4));
+  B_TRY(hipMalloc(&b->d_contig_len, nc1 * 4));
+  B_TRY(hipMemcpy(b->d_contig_read_begin, rbeg.data(), nc1 * 4, hipMemcpyHostToDevice));
+  B_TRY(hipMemcpy(b->d_contig_tile_base, tile_base.data(), nc1 * 4, hipMemcpyHostToDevice));
+  if (contigs->n_contigs > 0)
+    B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
+  b->work_bytes = (((size_t)b->n_tiles * 8 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
+  B_TRY(hipMalloc(&b->d_work, b->work_bytes));
+  B_TRY(hipMalloc(&b->d_counts, ns * 16));
+  B_TRY(hipMalloc(&b->d_allele, ns));
+#undef B_TRY
+  *out_batch = b;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_enable_timing(midas_snps_batch* b, int32_t on) {
+  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (on) {
+    for (auto& e : b->ev)
+      if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+  }
+  b->timing = on != 0;
+  b->have_timing = false;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* thr) {
+  if (!b || !thr) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  if (thr->reserved != 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "thresholds.reserved must be 0");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
+  // rbinv / rend / stats zeroed, error word = "no error" (all ones)
+  HIP_TRY(ctx, hipMemsetAsync(b->d_work, 0, b->work_bytes - 8, s));
+  HIP_TRY(ctx, hipMemsetAsync(work_err(b), 0xFF, 8, s));
+
+  IndexParams ip;
+  ip.rec = b->d_rec;
+  ip.blob = b->d_blob;
+  ip.contig_read_begin = b->d_contig_read_begin;
+  ip.contig_tile_base = b->d_contig_tile_base;
+  ip.contig_len = b->d_contig_len;
+  ip.rbinv = work_rbinv(b);
+  ip.rend = work_rend(b);
+  ip.n_reads = (int32_t)b->n_reads;
+  ip.n_contigs = b->n_contigs;
+  HIP_TRY(ctx, launch_index_reads(ip, s));
+  if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));
+
+  PileupParams pp;
+  pp.rec = b->d_rec;
+  pp.blob = b->d_blob;
+  pp.ref = b->d_ref;
+  pp.tiles = b->d_tiles;
+  pp.rbinv = work_rbinv(b);
+  pp.rend = work_rend(b);
+  pp.out_counts = b->d_counts;
+  pp.out_allele = b->d_allele;
+  pp.stats = work_stats(b);
+  pp.err = work_err(b);
+  pp.n_tiles = (int32_t)b->n_tiles;
+  pp.n_reads = (int32_t)b->n_reads;
+  pp.tiles_per_xcd = (int32_t)((b->n_tiles + 7) / 8);
+  pp.lanes_per_read = b->lanes_per_read;
+  pp.reads_per_wave = 64 / b->lanes_per_read;
+  pp.baseq = thr->baseq;
+  pp.mapq = thr->mapq;
+  pp.readq = thr->readq;
+  pp.mapid = thr->mapid;
+  pp.aln_cov = thr->aln_cov;
+  HIP_TRY(ctx, launch_pileup_tiles(pp, s));
+  if (b->timing) {
+    HIP_TRY(ctx, hipEventRecord(b->ev[2], s));
+    b->have_timing = true;
+  }
+  b->ran = true;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_sync(midas_snps_batch* b) {
+  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!b->ran) return MIDAS_SNPS_OK;
+  unsigned long long e = kNoError;
+  HIP_TRY(ctx, hipMemcpy(&e, work_err(b), 8, hipMemcpyDeviceToHost));
+  if (e != kNoError) {
+    const int32_t kind = (int32_t)(e & 0xFF);
+    ctx->err_read = (int64_t)(e >> 8);
+    char buf[256];
+    snprintf(buf, sizeof buf, "read %lld: %s", (long long)ctx->err_read, read_err_name(kind));
+    return fail(ctx, kind, buf);
+  }
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_fetch(midas_snps_batch* b, uint32_t* out_counts, uint8_t* out_allele, int64_t* out_stats) {
+  int32_t st = midas_snps_batch_sync(b);
+  if (st != MIDAS_SNPS_OK) return st;
+  midas_snps_ctx* ctx = b->ctx;
+  if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_fetch before batch_run");
+  if (out_counts && b->n_sites > 0)
+    HIP_TRY(ctx, hipMemcpy(out_counts, b->d_counts, (size_t)b->n_sites * 16, hipMemcpyDeviceToHost));
+  if (out_allele && b->n_sites > 0)
+    HIP_TRY(ctx, hipMemcpy(out_allele, b->d_allele, (size_t)b->n_sites, hipMemcpyDeviceToHost));
+  if (out_stats && b->n_species > 0)
+    HIP_TRY(ctx, hipMemcpy(out_stats, work_stats(b), (size_t)b->n_species * MIDAS_STATS * 8, hipMemcpyDeviceToHost));
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_info* out) {
+  if (!b || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  out->n_reads = b->n_reads;
+  out->n_sites = b->n_sites;
+  out->n_tiles = b->n_tiles;
+  out->packed_bytes = b->blob_bytes + b->n_reads * (int64_t)sizeof(ReadRec);
+  out->algorithmic_bytes = b->alg_bytes;
+  out->tile_sites = kTileSites;
+  out->lanes_per_read = b->lanes_per_read;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_last_timing(midas_snps_batch* b, float out_ms[3]) {
+  if (!b || !out_ms) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  if (!b->have_timing) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "no timed run recorded");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(b->ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[2], b->ev[0], b->ev[2]));
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_pileup(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_contigs* contigs,
+                          const midas_snps_reads* reads, uint32_t* out_counts, uint8_t* out_allele,
+                          int64_t* out_stats) {
+  if (!ctx || !thr) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_batch* b = nullptr;
+  int32_t st = midas_snps_batch_create(ctx, contigs, reads, &b);
+  if (st != MIDAS_SNPS_OK) return st;
+  st = midas_snps_batch_run(b, thr);
+  if (st == MIDAS_SNPS_OK) st = midas_snps_batch_fetch(b, out_counts, out_allele, out_stats);
+  midas_snps_batch_destroy(b);
+  return st;
+}
+
+}  // extern "C"

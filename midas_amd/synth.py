@@ -1,0 +1,203 @@
+"""Seeded synthetic inputs for the pileup path (SURVEY.md 8d "Synthetic generator").
+
+There is no aligner and no MIDAS DB in the build image, so benchmark and parity
+inputs are generated directly in the form a coordinate-sorted bowtie2 BAM decodes
+to: per-contig, pos-sorted records with BAM-native SEQ/QUAL/CIGAR encodings.
+
+Distributions (thresholds bite at the CLI defaults):
+  reference   i.i.d. uniform ACGT, 0.01 % of sites turned to N in short runs
+  reads       start uniform over valid positions, L stored bases, forward strand
+  edits       1 % substitutions; 5 % of reads carry one I or D of length 1-3;
+              5 % carry a soft clip of 1-20 at one end; 0.1 % of read bases are N
+  NM          mismatches + inserted + deleted bases, plus an excess on 2 % of reads
+  QUAL        per base {70 %: 37-41, 20 %: 30-36, 10 %: 2-29}; 1 % of reads all 2-19
+  MAPQ        {80 %: 42, 10 %: 20-41, 10 %: 0-19}
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .abi import ContigTable, ReadsSoA
+
+BASE_SEED = 20260927
+_NT16 = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+_CODE_OF_ACGT = np.array([1, 2, 4, 8], dtype=np.uint8)   # BAM 4-bit codes of A,C,G,T
+_ASCII_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+OP_M, OP_I, OP_D, OP_N, OP_S, OP_H, OP_P, OP_EQ, OP_X = range(9)
+
+
+def make_reference(rng, n_contigs: int, contig_len: int, n_frac: float = 1e-4, lowercase_frac: float = 0.0):
+    """-> (ref ascii uint8 [n_contigs*contig_len], ref2bit int8 with -1 at N)"""
+    g = n_contigs * contig_len
+    two = rng.integers(0, 4, size=g, dtype=np.int8)
+    ref = _ASCII_ACGT[two]
+    n_runs = int(g * n_frac / 5) if n_frac > 0 else 0
+    if n_runs:
+        starts = rng.integers(0, max(1, g - 10), size=n_runs)
+        lens = rng.integers(1, 10, size=n_runs)
+        for s, ln in zip(starts, lens):
+            ref[s:s + ln] = ord('N')
+            two[s:s + ln] = -1
+    if lowercase_frac > 0:
+        lc = rng.random(g) < lowercase_frac
+        ref = np.where(lc, ref | 0x20, ref).astype(np.uint8)
+    return ref, two
+
+
+def make_dataset(n_species: int = 1, contigs_per_species: int = 4, contig_len: int = 20000,
+                 n_reads: int = 2000, read_len: int = 150, seed: int = BASE_SEED,
+                 var_len: bool = False, chunk: int = 1 << 17, lowercase_frac: float = 0.0):
+    """-> (ContigTable, ReadsSoA).  Contig ids are '<species>_c<k>' (k unpadded, so Python's
+    sorted() order differs from table order, as the reference's emit loop must be fed)."""
+    rng = np.random.default_rng(seed)
+    n_contigs = n_species * contigs_per_species
+    ref, two = make_reference(rng, n_contigs, contig_len, lowercase_frac=lowercase_frac)
+    species_ids = ["Species_%05d" % (s + 1) for s in range(n_species)]
+    ids, species = [], []
+    for s in range(n_species):
+        for k in range(contigs_per_species):
+            ids.append("%s_c%d" % (species_ids[s], k + 1))
+            species.append(s)
+    length = np.full(n_contigs, contig_len, dtype=np.int64)
+    L = read_len
+    if contig_len < L + 8:
+        raise ValueError("contig_len must exceed read_len + 8")
+
+    # reads per contig, then sorted starts
+    per = rng.multinomial(n_reads, np.full(n_contigs, 1.0 / n_contigs))
+    read_begin = np.zeros(n_contigs + 1, dtype=np.int64)
+    np.cumsum(per, out=read_begin[1:])
+    contig_of = np.repeat(np.arange(n_contigs, dtype=np.int64), per)
+
+    # per-read shape
+    u = rng.random(n_reads)
+    kind = np.zeros(n_reads, dtype=np.int8)            # 0 plain, 1 ins, 2 del, 3 lead clip, 4 trail clip
+    kind[u < 0.025] = 1
+    kind[(u >= 0.025) & (u < 0.05)] = 2
+    kind[(u >= 0.05) & (u < 0.075)] = 3
+    kind[(u >= 0.075) & (u < 0.10)] = 4
+    lens = np.full(n_reads, L, dtype=np.int32)
+    if var_len:
+        trim = rng.random(n_reads) < 0.3
+        lens[trim] = rng.integers(max(20, L // 3), L + 1, size=int(trim.sum()))
+    ev_len = np.zeros(n_reads, dtype=np.int32)
+    ev_len[(kind == 1) | (kind == 2)] = rng.integers(1, 4, size=int(((kind == 1) | (kind == 2)).sum()))
+    ev_len[kind >= 3] = rng.integers(1, 21, size=int((kind >= 3).sum()))
+    ev_len = np.minimum(ev_len, lens // 4)
+    kind[ev_len == 0] = 0
+    # indel offset a: bases before the event
+    a = (rng.random(n_reads) * (lens - ev_len - 20)).astype(np.int32) + 10
+    a = np.clip(a, 1, np.maximum(lens - ev_len - 1, 1))
+    ref_span = lens.astype(np.int64).copy()
+    ref_span[kind == 1] -= ev_len[kind == 1]
+    ref_span[kind == 2] += ev_len[kind == 2]
+    ref_span[kind >= 3] -= ev_len[kind >= 3]
+    pos = (rng.random(n_reads) * (contig_len - ref_span)).astype(np.int64)
+    # sort by (contig, pos); keep everything else aligned to the same permutation
+    order = np.lexsort((pos, contig_of))
+    pos, kind, lens, ev_len, a, ref_span = pos[order], kind[order], lens[order], ev_len[order], a[order], ref_span[order]
+
+    # CIGARs
+    n_cig = np.ones(n_reads, dtype=np.int64)
+    n_cig[(kind == 1) | (kind == 2)] = 3
+    n_cig[kind >= 3] = 2
+    cigar_off = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(n_cig, out=cigar_off[1:])
+    cigar = np.zeros(int(cigar_off[-1]), dtype=np.uint32)
+    c0 = cigar_off[:-1]
+    m = kind == 0
+    cigar[c0[m]] = (lens[m].astype(np.uint32) << 4) | OP_M
+    for kd, op in ((1, OP_I), (2, OP_D)):
+        m = kind == kd
+        rest = lens[m] - a[m] - (ev_len[m] if kd == 1 else 0)
+        cigar[c0[m]] = (a[m].astype(np.uint32) << 4) | OP_M
+        cigar[c0[m] + 1] = (ev_len[m].astype(np.uint32) << 4) | op
+        cigar[c0[m] + 2] = (rest.astype(np.uint32) << 4) | OP_M
+    m = kind == 3
+    cigar[c0[m]] = (ev_len[m].astype(np.uint32) << 4) | OP_S
+    cigar[c0[m] + 1] = ((lens[m] - ev_len[m]).astype(np.uint32) << 4) | OP_M
+    m = kind == 4
+    cigar[c0[m]] = ((lens[m] - ev_len[m]).astype(np.uint32) << 4) | OP_M
+    cigar[c0[m] + 1] = (ev_len[m].astype(np.uint32) << 4) | OP_S
+
+    seq_bytes = (lens.astype(np.int64) + 1) >> 1
+    seq_off = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(seq_bytes, out=seq_off[1:])
+    qual_off = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(lens.astype(np.int64), out=qual_off[1:])
+    seq4 = np.zeros(int(seq_off[-1]), dtype=np.uint8)
+    qual = np.zeros(int(qual_off[-1]), dtype=np.uint8)
+    nm = np.zeros(n_reads, dtype=np.int32)
+
+    contig_site0 = contig_of[order] * contig_len
+    j = np.arange(L, dtype=np.int64)[None, :]
+    for lo in range(0, n_reads, chunk):
+        hi = min(n_reads, lo + chunk)
+        k_, l_, e_, a_, p_ = kind[lo:hi, None], lens[lo:hi, None].astype(np.int64), \
+            ev_len[lo:hi, None].astype(np.int64), a[lo:hi, None].astype(np.int64), pos[lo:hi, None]
+        # reference offset (relative to pos) of query base j, or -1 when the base is not aligned
+        rel = np.broadcast_to(j, (hi - lo, L)).copy()
+        ins = k_ == 1
+        rel = np.where(ins & (j >= a_ + e_), j - e_, rel)
+        rel = np.where(ins & (j >= a_) & (j < a_ + e_), -1, rel)
+        rel = np.where((k_ == 2) & (j >= a_), j + e_, rel)
+        rel = np.where(k_ == 3, np.where(j < e_, -1, j - e_), rel)
+        rel = np.where((k_ == 4) & (j >= l_ - e_), -1, rel)
+        inread = j < l_
+        aligned = (rel >= 0) & inread
+        site = contig_site0[lo:hi, None] + p_ + np.where(aligned, rel, 0)
+        rb = two[site].astype(np.int16)                      # -1 at reference N
+        rnd = rng.integers(0, 4, size=rb.shape, dtype=np.int16)
+        sub = rng.random(rb.shape) < 0.01
+        shift = rng.integers(1, 4, size=rb.shape, dtype=np.int16)
+        base = np.where(aligned & (rb >= 0), np.where(sub, (rb + shift) & 3, rb), rnd)
+        mism = aligned & ((rb < 0) | sub)
+        code = _CODE_OF_ACGT[base]
+        isn = rng.random(rb.shape) < 0.001
+        code = np.where(isn, 15, code).astype(np.uint8)
+        mism |= aligned & isn
+        code = np.where(inread, code, 0).astype(np.uint8)
+        nm_c = mism.sum(axis=1).astype(np.int32)
+        kk = kind[lo:hi]
+        nm_c += np.where((kk == 1) | (kk == 2), ev_len[lo:hi], 0)
+        nm[lo:hi] = nm_c
+        # qualities
+        cat = rng.random(rb.shape)
+        q = np.where(cat < 0.7, rng.integers(37, 42, size=rb.shape),
+                     np.where(cat < 0.9, rng.integers(30, 37, size=rb.shape), rng.integers(2, 30, size=rb.shape)))
+        bad = rng.random(hi - lo) < 0.01
+        q = np.where(bad[:, None], rng.integers(2, 20, size=rb.shape), q).astype(np.uint8)
+        # scatter into the ragged arrays
+        flat_keep = inread.ravel()
+        qual[qual_off[lo]:qual_off[hi]] = q.ravel()[flat_keep]
+        Lp = L + (L & 1)
+        if Lp != L:
+            code = np.concatenate([code, np.zeros((hi - lo, 1), dtype=np.uint8)], axis=1)
+        packed = (code[:, 0::2] << 4) | code[:, 1::2]
+        nb = np.arange(Lp // 2)[None, :] < seq_bytes[lo:hi, None]
+        seq4[seq_off[lo]:seq_off[hi]] = packed.ravel()[nb.ravel()]
+    excess = rng.random(n_reads) < 0.02
+    nm[excess] += rng.integers(8, 20, size=int(excess.sum())).astype(np.int32)
+
+    mq_cat = rng.random(n_reads)
+    mapq = np.where(mq_cat < 0.8, 42, np.where(mq_cat < 0.9, rng.integers(20, 42, size=n_reads),
+                                               rng.integers(0, 20, size=n_reads))).astype(np.uint8)
+    flag = np.where(rng.random(n_reads) < 0.5, 16, 0).astype(np.uint16)
+
+    reads = ReadsSoA(pos=pos.astype(np.int32), mapq=mapq, flag=flag, nm=nm, l_seq=lens,
+                     seq_off=seq_off, qual_off=qual_off, cigar_off=cigar_off, seq4=seq4, qual=qual, cigar=cigar)
+    contigs = ContigTable(length=length, species=np.array(species, dtype=np.int32), read_begin=read_begin,
+                          ref=ref, n_species=n_species, ids=ids, species_ids=species_ids)
+    return contigs, reads
+
+
+# The workloads BASELINE.json / SURVEY.md 8d name.  C2 is the one the headline metric is quoted on.
+CONFIGS = {
+    'tiny': dict(n_species=1, contigs_per_species=4, contig_len=20000, n_reads=2000, seed=BASE_SEED + 1),
+    'c2': dict(n_species=1, contigs_per_species=60, contig_len=250000, n_reads=1000000, seed=BASE_SEED + 2),
+    'c3': dict(n_species=20, contigs_per_species=16, contig_len=250000, n_reads=10666667, seed=BASE_SEED + 3),
+    # one rank's share of C4 (100 species x 4 Mb, 80 M reads over 8 GPUs)
+    'c4_rank': dict(n_species=13, contigs_per_species=16, contig_len=250000, n_reads=10400000, seed=BASE_SEED + 4),
+}
