@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- genomic sites/sec of the MI355X SNP pileup (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one resident batch: the device builds its
+per-tile read index (the index_bam analogue), filters every read (keep_read), walks the
+CIGARs, tallies A/C/G/T per site, emits counts + ref allele and reduces the per-species
+counters; with N > 1 the per-species summary rows are then all-gathered over RCCL.  Inputs
+(packed reads, reference letters) are resident in HBM before the timed region starts.
+
+Workload: BASELINE.json configs[1] -- 1 species, 15 Mb, 1 M synthetic 150 bp reads (10x) per
+GPU.  Multi-GPU is species-sharded weak scaling: every rank owns its own species (own seed),
+no data-path collective, one all-gather of [n_species,4] int64 summary rows per pass.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def load_pmc_traffic(kernel, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d.get(workload, {}).get(kernel)
+        return float(e["hbm_bytes_per_launch"]) if e else None
+    except Exception:
+        return None
+
+
+def cpu_baseline(thr, contigs, reads, min_seconds):
+    """The C oracle ("port" of the reference semantics, 1 core) timed on this host; returns (dict, outputs)."""
+    from oracle import c_oracle
+    c_oracle.build()
+    t0 = time.perf_counter()
+    passes = 0
+    out = None
+    while True:
+        out = c_oracle.pileup(thr, contigs, reads)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds or passes >= 64:
+            break
+    sites = contigs.n_sites * passes
+    return ({"value": sites / el, "unit": "sites/s", "cores": 1, "kind": "port",
+             "sample": "%d pass(es) of the full workload (%d sites, %d reads) through oracle/pileup_oracle.c, %.1f s"
+                       % (passes, contigs.n_sites, reads.n_reads, el),
+             "host_cores_available": os.cpu_count()}, out)
+
+
+def python_shaped_estimate(contigs, reads, args, max_sites=250000):
+    """the pysam-shaped Python oracle (per-read callback, per-site Python emit + gzip-9
+    text) on the first contig only -- an ESTIMATE of what the reference's own loop costs, never 'the reference'."""
+    import gzip
+    import io
+    from oracle import pileup_oracle as po
+    n = int(contigs.read_begin[1])
+    length = min(int(contigs.length[0]), max_sites)
+    alns = po.alns_from_soa(reads.as_dict(), 0, n)
+    ref = bytes(contigs.ref[:length]).decode().upper()
+    oc = {"c": po.OContig(id="c", seq=ref, species_id="s")}
+    t0 = time.perf_counter()
+    text, _ = po.species_pileup(args, "s", oc, {"c": alns})
+    buf = io.BytesIO()
+    with io.TextIOWrapper(gzip.GzipFile(fileobj=buf, mode="w")) as f:
+        f.write(text)
+    el = time.perf_counter() - t0
+    return {"value": length / el, "unit": "sites/s", "cores": 1, "kind": "python-shaped estimate",
+            "sample": "first contig (%d sites, %d reads), Python per-read/per-site loops + gzip-9" % (length, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", help="workload from midas_amd.synth.CONFIGS (default c2 = BASELINE configs[1])")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from midas_amd import abi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        sys.exit("--gpus (%d) != WORLD_SIZE (%d)" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(synth.CONFIGS[a.config])
+    cfg["seed"] = cfg["seed"] + 1000 * rank       # every rank owns different species (weak scaling)
+    contigs, reads = synth.make_dataset(**cfg)
+    args = dict(abi.DEFAULT_ARGS)
+    thr = abi.Thresholds.from_args(args)
+
+    ctx = abi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)           # launch on torch's stream: torch events / RCCL see the kernels
+    batch = ctx.batch(contigs, reads)
+    info = batch.info()
+    n_sp = contigs.n_species
+    stats_dev = torch.zeros((n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
+    gathered = torch.zeros((world * n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def step():
+        batch.run(thr)
+        if world > 1:
+            batch.stats_to_device(stats_dev.data_ptr())
+            dist.all_gather_into_tensor(gathered, stats_dev)
+
+    for _ in range(a.warmup):
+        step()
+    batch.sync()
+    batch.enable_timing(a.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    batch.sync()   # surfaces MIDAS_SNPS_ERR_READ_* of the last run, if any
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    sites = torch.tensor([float(info.n_sites)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sites, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_sites = float(sites.item())
+
+    tm = [batch.timing(i) for i in range(a.steps)]
+    pile_ms = float(np.mean([t["pileup_ms"] for t in tm]))
+    index_ms = float(np.mean([t["index_ms"] for t in tm]))
+    run_ms = float(np.mean([t["run_ms"] for t in tm]))
+
+    if rank == 0:
+        kernel = "pileup_tiles_kernel"
+        achieved = info.algorithmic_bytes / (pile_ms * 1e-3) / 1e9
+        out = {
+            "metric": "genomic sites/sec pileup+allele-count",
+            "value": total_sites * a.steps / elapsed,
+            "unit": "sites/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32 integer tallies (fp64 only in the two keep_read ratio tests)",
+            "data": "synthetic (seeded generator midas_amd/synth.py; SURVEY 8d distributions)",
+            "config": {"workload": "configs[1]: 1 species rep-genome (60 contigs x 250 kb = 15 Mb), 1M synthetic "
+                                   "150 bp reads at 10x per GPU" if a.config == "c2" else a.config,
+                       "sites_per_gpu": int(info.n_sites), "reads_per_gpu": int(info.n_reads),
+                       "thresholds": args, "parallelism": "species-sharded x%d, RCCL all-gather of summary rows" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": load_pmc_traffic(kernel, a.config),
+                         "algorithmic_bytes_per_launch": int(info.algorithmic_bytes),
+                         "kernel_ms_avg": pile_ms, "index_kernel_ms_avg": index_ms, "device_ms_per_step": run_ms,
+                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+        }
+        if world == 1 and not a.no_cpu:
+            cb, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
+            out["cpu_baseline"] = cb
+            counts, allele, stats = batch.fetch()
+            st, _, oc, oa, os_ = ref
+            out["parity_vs_oracle"] = bool(st == 0 and np.array_equal(counts, oc) and np.array_equal(allele, oa)
+                                           and np.array_equal(stats, os_))
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            try:
+                out["cpu_python_shaped_estimate"] = python_shaped_estimate(contigs, reads, args)
+            except Exception as e:  # the estimate is a courtesy number; never fail the bench on it
+                out["cpu_python_shaped_estimate"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

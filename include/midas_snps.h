@@ -189,11 +189,17 @@ typedef struct midas_snps_batch_info {
   int32_t lanes_per_read;
 } midas_snps_batch_info;
 int32_t midas_snps_batch_get_info(const midas_snps_batch* batch, midas_snps_batch_info* out);
-/* Device-side durations (ms, HIP events on the run's stream) of the last run's kernels:
- * [0] index kernel, [1] pileup kernel, [2] whole run.  Recording is on only after
- * midas_snps_batch_enable_timing(batch, 1).                                                    */
-int32_t midas_snps_batch_enable_timing(midas_snps_batch* batch, int32_t on);
-int32_t midas_snps_batch_last_timing(midas_snps_batch* batch, float out_ms[3]);
+/* Device-side durations from HIP events recorded on the run's stream.  enable_timing(batch, n_slots)
+ * allocates n_slots event triples (0 = off); run number k (counted from enable) records into slot
+ * k % n_slots, so a caller can time K asynchronous runs and read all K after one sync.
+ * out_ms: [0] index kernel (+ workspace memsets), [1] pileup kernel, [2] whole run.              */
+int32_t midas_snps_batch_enable_timing(midas_snps_batch* batch, int32_t n_slots);
+int32_t midas_snps_batch_timing(midas_snps_batch* batch, int32_t slot, float out_ms[3]);
+/* Enqueue (same stream) a device-to-device copy of the per-species counters [n_species*4] i64 of the
+ * last run into caller-owned device memory -- e.g. a torch tensor that is then all-gathered over
+ * RCCL; the counters never round-trip through the host.  Replaces the pickled (species_id, aln_stats)
+ * tuples returned through the Pool pipe (midas/run/snps.py:216, 228).                             */
+int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_device_i64);
 
 /* ---- host-only helpers (no GPU needed) -------------------------------------
  * The packer that batch_create() runs, exposed so that CPU-only tests can check

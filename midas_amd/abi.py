@@ -187,7 +187,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_fetch': (i32, [vp, vp, vp, vp]),
         'midas_snps_batch_get_info': (i32, [vp, C.POINTER(BatchInfo)]),
         'midas_snps_batch_enable_timing': (i32, [vp, i32]),
-        'midas_snps_batch_last_timing': (i32, [vp, C.POINTER(C.c_float)]),
+        'midas_snps_batch_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
+        'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
     for name, (res, args) in sig.items():
@@ -206,7 +207,8 @@ EXPORTED_SYMBOLS = [
     'midas_snps_last_error', 'midas_snps_last_error_read', 'midas_snps_set_stream', 'midas_snps_device_info',
     'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
-    'midas_snps_batch_enable_timing', 'midas_snps_batch_last_timing', 'midas_snps_pack_reads',
+    'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_stats_to_device',
+    'midas_snps_pack_reads',
 ]
 
 
@@ -311,6 +313,8 @@ class Batch:
 
     def run(self, thr: Thresholds):
         self.ctx._check(self._lib.midas_snps_batch_run(self._h, C.byref(thr)))
+        if getattr(self, '_slots', 0):
+            self._timed += 1
 
     def sync(self):
         self.ctx._check(self._lib.midas_snps_batch_sync(self._h))
@@ -328,10 +332,20 @@ class Batch:
         self.ctx._check(self._lib.midas_snps_batch_get_info(self._h, C.byref(bi)))
         return bi
 
-    def enable_timing(self, on: bool = True):
-        self.ctx._check(self._lib.midas_snps_batch_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, n_slots: int = 1):
+        """n_slots event triples; run k records into slot k % n_slots (0 turns timing off)."""
+        self.ctx._check(self._lib.midas_snps_batch_enable_timing(self._h, int(n_slots)))
+        self._slots = int(n_slots)
+        self._timed = 0
+
+    def timing(self, slot: int = 0):
+        ms = (C.c_float * 3)()
+        self.ctx._check(self._lib.midas_snps_batch_timing(self._h, int(slot), ms))
+        return {'index_ms': ms[0], 'pileup_ms': ms[1], 'run_ms': ms[2]}
 
     def last_timing(self):
-        ms = (C.c_float * 3)()
-        self.ctx._check(self._lib.midas_snps_batch_last_timing(self._h, ms))
-        return {'index_ms': ms[0], 'pileup_ms': ms[1], 'run_ms': ms[2]}
+        return self.timing((self._timed - 1) % self._slots)
+
+    def stats_to_device(self, dst_device_ptr: int):
+        """Enqueue a D2D copy of the [n_species,4] int64 counters into caller-owned device memory."""
+        self.ctx._check(self._lib.midas_snps_batch_stats_to_device(self._h, C.c_void_p(dst_device_ptr)))

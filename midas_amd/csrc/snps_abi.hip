@@ -42,9 +42,9 @@ struct midas_snps_batch {
   int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
   int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1;
   // timing
-  bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool have_timing = false;
+  std::vector<hipEvent_t> ev;  // 3 per slot
+  int32_t timing_slots = 0;
+  int64_t timed_runs = 0;
   bool ran = false;
 };
 
@@ -315,16 +315,16 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   return MIDAS_SNPS_OK;
 }
 
-int32_t midas_snps_batch_enable_timing(midas_snps_batch* b, int32_t on) {
-  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+int32_t midas_snps_batch_enable_timing(midas_snps_batch* b, int32_t n_slots) {
+  if (!b || n_slots < 0 || n_slots > 65536) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (on) {
-    for (auto& e : b->ev)
-      if (!e) HIP_TRY(ctx, hipEventCreate(&e));
-  }
-  b->timing = on != 0;
-  b->have_timing = false;
+  for (auto& e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  b->ev.assign((size_t)n_slots * 3, nullptr);
+  for (auto& e : b->ev) HIP_TRY(ctx, hipEventCreate(&e));
+  b->timing_slots = n_slots;
+  b->timed_runs = 0;
   return MIDAS_SNPS_OK;
 }
 
@@ -334,7 +334,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   if (thr->reserved != 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "thresholds.reserved must be 0");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
+  hipEvent_t* ev = b->timing_slots > 0 ? &b->ev[(size_t)(b->timed_runs % b->timing_slots) * 3] : nullptr;
+  if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
   // rbinv / rend / stats zeroed, error word = "no error" (all ones)
   HIP_TRY(ctx, hipMemsetAsync(b->d_work, 0, b->work_bytes - 8, s));
   HIP_TRY(ctx, hipMemsetAsync(work_err(b), 0xFF, 8, s));
@@ -350,7 +351,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.n_reads = (int32_t)b->n_reads;
   ip.n_contigs = b->n_contigs;
   HIP_TRY(ctx, launch_index_reads(ip, s));
-  if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));
+  if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
 
   PileupParams pp;
   pp.rec = b->d_rec;
@@ -374,9 +375,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.mapid = thr->mapid;
   pp.aln_cov = thr->aln_cov;
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
-  if (b->timing) {
-    HIP_TRY(ctx, hipEventRecord(b->ev[2], s));
-    b->have_timing = true;
+  if (ev) {
+    HIP_TRY(ctx, hipEventRecord(ev[2], s));
+    b->timed_runs += 1;
   }
   b->ran = true;
   return MIDAS_SNPS_OK;
@@ -426,15 +427,28 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   return MIDAS_SNPS_OK;
 }
 
-int32_t midas_snps_batch_last_timing(midas_snps_batch* b, float out_ms[3]) {
+int32_t midas_snps_batch_timing(midas_snps_batch* b, int32_t slot, float out_ms[3]) {
   if (!b || !out_ms) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
-  if (!b->have_timing) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "no timed run recorded");
+  if (slot < 0 || slot >= b->timing_slots || slot >= b->timed_runs)
+    return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "no timed run recorded in that slot");
+  hipEvent_t* ev = &b->ev[(size_t)slot * 3];
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventSynchronize(b->ev[2]));
-  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
-  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
-  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[2], b->ev[0], b->ev[2]));
+  HIP_TRY(ctx, hipEventSynchronize(ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[0], ev[0], ev[1]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[1], ev[1], ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[2], ev[0], ev[2]));
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_stats_to_device(midas_snps_batch* b, void* dst) {
+  if (!b || !dst) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "stats_to_device before batch_run");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (b->n_species > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(dst, work_stats(b), (size_t)b->n_species * MIDAS_STATS * 8, hipMemcpyDeviceToDevice,
+                                ctx->stream));
   return MIDAS_SNPS_OK;
 }
 

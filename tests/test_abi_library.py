@@ -1,0 +1,119 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every symbol
+include/midas_snps.h declares; host-only entry points behave; there is no silent CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, build, synth
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "midas_snps.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(midas_snps_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_builds_for_gfx950_and_loads():
+    path = build.build_native()
+    assert os.path.exists(path)
+    lib = abi.load_library(build_if_missing=False)
+    assert lib.midas_snps_abi_version() == abi.ABI_VERSION
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    lib = C.CDLL(build.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), "header declares %s but the library does not export it" % sym
+    assert sorted(abi.EXPORTED_SYMBOLS) == declared, "python binding and header disagree"
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(build.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"pileup_tiles_kernel" in blob and b"index_reads_kernel" in blob
+
+
+def test_status_strings():
+    lib = abi.load_library()
+    assert lib.midas_snps_status_string(0) == b"ok"
+    assert b"NM" in lib.midas_snps_status_string(abi.ERR_READ_NO_NM)
+    assert lib.midas_snps_status_string(12345) == b"unknown status"
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this box has a GPU")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        abi.Context(0)
+    assert ei.value.status == abi.ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "midas_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "pileup_oracle" not in text, f
+    for f in ("scripts/run_midas.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            assert "oracle" not in open(p).read()
+
+
+# ---- the host packer (runs without a GPU) -----------------------------------------------------
+
+def test_pack_layout_matches_design():
+    reads = H.reads_from_dicts([
+        dict(pos=7, cigar="3S7M", seq="TTTACGTACG", qual=list(range(10)), nm=1, mapq=33, flag=16),
+        dict(pos=9, cigar="5M", seq="ACGTN", nm=None, mapq=0),
+        dict(pos=11, cigar="4M", seq="ACGT", qual="absent"),
+    ])
+    rec, blob, maxl = abi.pack_reads(reads)
+    assert maxl == 10 and rec.shape == (3, 16)
+    r = rec.view(np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
+                           ("mapq", "u1"), ("flags", "u1")])).reshape(3)
+    assert r["pos"].tolist() == [7, 9, 11] and r["l"].tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
+    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42] and r["flags"].tolist() == [0, 0, 1]
+    # read 0: qual 10 -> pad 12 | seq 5 -> pad 8 | cigar 8 -> 28 -> pad 32
+    assert r["off8"].tolist() == [0, 4, 6]   # read 1: 5->8 | 3->4 | 4 = 16 bytes
+    b0 = blob[:32]
+    assert b0[:10].tolist() == list(range(10))
+    assert bytes(b0[12:17]) == bytes(H.encode_seq4("TTTACGTACG"))
+    assert b0[20:28].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
+    assert blob.size == 32 + 16 + 16
+
+
+def test_pack_rejects_malformed_input_with_status():
+    ok = H.reads_from_dicts([dict(pos=0, cigar="4M", seq="ACGT")])
+    bad = abi.ReadsSoA(**{**ok.as_dict(), 'qual_off': np.array([0, 2], dtype=np.int64)})
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        abi.pack_reads(bad)
+    assert ei.value.status == abi.ERR_BAD_LAYOUT
+    long_read = H.reads_from_dicts([dict(pos=0, cigar="1025M", seq="A" * 1025)])
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        abi.pack_reads(long_read)
+    assert ei.value.status == abi.ERR_UNSUPPORTED
+
+
+def test_pack_round_trips_synthetic_reads():
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=9000, n_reads=3000,
+                                        seed=5, var_len=True)
+    rec, blob, maxl = abi.pack_reads(reads)
+    r = rec.view(np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
+                           ("mapq", "u1"), ("flags", "u1")])).reshape(-1)
+    np.testing.assert_array_equal(r["pos"], reads.pos)
+    np.testing.assert_array_equal(r["l"], reads.l_seq)
+    for i in (0, 17, 1234, reads.n_reads - 1):
+        l = int(reads.l_seq[i])
+        o = int(r["off8"][i]) * 8
+        np.testing.assert_array_equal(blob[o:o + l], reads.qual[reads.qual_off[i]:reads.qual_off[i] + l])
+        so = o + ((l + 3) & ~3)
+        np.testing.assert_array_equal(blob[so:so + (l + 1) // 2], reads.seq4[reads.seq_off[i]:reads.seq_off[i] + (l + 1) // 2])

@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle.
+
+Bit-exact bar (integer / byte work): per-site A,C,G,T, ref allele, and the four per-species
+counters must be IDENTICAL to the oracle's on the same seeded inputs.  The two floating-point
+expressions of the path (keep_read's mapid / aln_cov ratios) are IEEE fp64 divisions on both
+sides and only feed a comparison, so they are covered by the same bit-exact bar (tolerance 0).
+"""
+import numpy as np
+import pytest
+
+from midas_amd import abi, synth
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CASES = H.load_kat_cases()
+
+
+def _assert_same(ctx, thr, contigs, reads):
+    st, er, oc, oa, os_ = c_oracle.pileup(thr, contigs, reads)
+    assert st == 0, "oracle refused the input (%d at read %d)" % (st, er)
+    counts, allele, stats = ctx.pileup(thr, contigs, reads)
+    bad = np.nonzero((counts != oc).any(axis=1))[0]
+    assert bad.size == 0, "counts differ at %d sites, first %s: hip %s oracle %s" % (
+        bad.size, bad[:5], counts[bad[:5]].tolist(), oc[bad[:5]].tolist())
+    np.testing.assert_array_equal(allele, oa)
+    np.testing.assert_array_equal(stats, os_)
+    return counts, stats
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_hand_derived_cases_through_c_abi(hip_ctx, case):
+    contigs, reads, thr, _ = H.kat_inputs(case)
+    if "error" in case:
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            hip_ctx.pileup(thr, contigs, reads)
+        assert ei.value.status == case["error"]
+        assert ei.value.read_index == case.get("error_read", 0)
+        return
+    counts, allele, stats = hip_ctx.pileup(thr, contigs, reads)
+    np.testing.assert_array_equal(counts, H.kat_expected_counts(case))
+    np.testing.assert_array_equal(stats, H.kat_expected_stats(case))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_seeded_uniform_reads(hip_ctx, thr_default, seed):
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=40000, n_reads=30000, seed=seed)
+    _assert_same(hip_ctx, thr_default, contigs, reads)
+
+
+def test_ragged_lengths_lowercase_ref_tile_edges(hip_ctx, thr_default):
+    # contig length not a multiple of the 4096-site tile; trimmed reads; lower-case reference letters
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=5, contig_len=30011, n_reads=40000,
+                                        seed=7, var_len=True, lowercase_frac=0.1)
+    _assert_same(hip_ctx, thr_default, contigs, reads)
+
+
+def test_deep_hotspot_exceeds_u16(hip_ctx, thr_default):
+    # ~1000x on a small contig: several sites above 65 535? no -- but far above 255; u32 planes must hold
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=9000, n_reads=120000, seed=9)
+    counts, _ = _assert_same(hip_ctx, thr_default, contigs, reads)
+    assert counts.sum(axis=1).max() > 255
+
+
+@pytest.mark.parametrize("args", [
+    dict(baseq=0), dict(baseq=41), dict(mapq=0, readq=0, mapid=1.0, aln_cov=0.0),
+    dict(mapid=99.0), dict(aln_cov=1.0), dict(readq=38), dict(mapq=42),
+])
+def test_threshold_sweep(hip_ctx, args):
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=3, contig_len=20000, n_reads=15000, seed=11)
+    a = dict(abi.DEFAULT_ARGS)
+    a.update(args)
+    _assert_same(hip_ctx, abi.Thresholds.from_args(a), contigs, reads)
+
+
+def test_empty_inputs(hip_ctx, thr_default):
+    # a species with no reads at all: all-zero rows, counters 0
+    contigs = abi.ContigTable(length=[5000, 100], species=[0, 1], read_begin=[0, 0, 0],
+                              ref=np.frombuffer(b"acgtn" * 1020, dtype=np.uint8), n_species=2)
+    counts, allele, stats = hip_ctx.pileup(thr_default, contigs, abi.ReadsSoA.empty())
+    assert counts.shape == (5100, 4) and not counts.any()
+    assert bytes(allele[:10]) == b"ACGTNACGTN"
+    assert not stats.any()
+
+
+def test_one_site_contigs_and_many_small_contigs(hip_ctx, thr_default):
+    rng = np.random.default_rng(5)
+    reads = []
+    lengths = [1, 2, 3, 150, 151, 4095, 4096, 4097, 1]
+    read_begin = [0]
+    for ln in lengths:
+        n = 0
+        for _ in range(6):
+            l = int(rng.integers(1, 160))
+            pos = int(rng.integers(0, ln))
+            seq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=l))
+            reads.append(dict(pos=pos, cigar="%dM" % l, seq=seq))
+            n += 1
+        read_begin.append(read_begin[-1] + n)
+    soa = H.reads_from_dicts(reads)
+    g = sum(lengths)
+    contigs = abi.ContigTable(length=lengths, species=[0] * len(lengths), read_begin=read_begin,
+                              ref=np.frombuffer(b"A" * g, dtype=np.uint8), n_species=1)
+    _assert_same(hip_ctx, thr_default, contigs, soa)
+
+
+def test_long_deletions_refskips_and_clips_across_tiles(hip_ctx):
+    """Reads whose reference span crosses one or many tile borders; hard clips, pads, N-skips."""
+    rng = np.random.default_rng(3)
+    L = 20000
+    reads = []
+
+    def rs(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+    reads.append(dict(pos=4000, cigar="50M9000N50M", seq=rs(100), nm=0))        # spans 3 tiles, lands in #0 and #3
+    reads.append(dict(pos=4090, cigar="10M2D10M", seq=rs(20), nm=2))             # straddles the 4096 border
+    reads.append(dict(pos=4095, cigar="1M", seq="G"))
+    reads.append(dict(pos=4096, cigar="1M", seq="T"))
+    reads.append(dict(pos=8100, cigar="5H20S100M3I27M10S2H", seq=rs(160), nm=3))  # clips both ends, 160 bases
+    reads.append(dict(pos=8190, cigar="4M1P4M", seq=rs(8)))
+    reads.append(dict(pos=12000, cigar="30=5X30=", seq=rs(65), nm=5))
+    reads.append(dict(pos=19990, cigar="30M", seq=rs(30)))                        # hangs over the contig end
+    for _ in range(300):
+        l = int(rng.integers(30, 200))
+        a = int(rng.integers(5, l - 10))
+        d = int(rng.integers(1, 3000))
+        reads.append(dict(pos=int(rng.integers(0, L - 200)), cigar="%dM%dD%dM" % (a, d, l - a), seq=rs(l), nm=0))
+    reads.sort(key=lambda r: r["pos"])
+    soa = H.reads_from_dicts(reads)
+    contigs = H.single_contig(L, soa.n_reads, ref=rs(L))
+    a = dict(abi.DEFAULT_ARGS)
+    a.update(mapid=1.0)
+    _assert_same(hip_ctx, abi.Thresholds.from_args(a), contigs, soa)
+
+
+def test_unsorted_input_is_still_exact(hip_ctx, thr_default):
+    """Sortedness only tightens the per-tile read ranges; a shuffled contig must give the same table."""
+    from oracle import pileup_oracle as po
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=30000, n_reads=5000, seed=21)
+    perm = np.random.default_rng(0).permutation(reads.n_reads)
+    objs = po.alns_from_soa(reads.as_dict())
+    shuffled = [dict(pos=o.pos, cigar=o.cigar, seq=o.seq, qual=list(o.qual), nm=o.nm, mapq=o.mapq, flag=o.flag)
+                for o in (objs[j] for j in perm)]
+    soa = H.reads_from_dicts(shuffled)
+    c_sorted, _ = _assert_same(hip_ctx, thr_default, contigs, reads)
+    c_shuf, _ = _assert_same(hip_ctx, thr_default, contigs, soa)
+    np.testing.assert_array_equal(c_sorted, c_shuf)
+
+
+def test_batch_rerun_is_idempotent_and_thresholds_switch(hip_ctx):
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=2, contig_len=25000, n_reads=20000, seed=31)
+    b = hip_ctx.batch(contigs, reads)
+    t1 = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
+    a2 = dict(abi.DEFAULT_ARGS)
+    a2.update(baseq=10, mapq=0)
+    t2 = abi.Thresholds.from_args(a2)
+    b.run(t1)
+    c1, _, s1 = b.fetch()
+    b.run(t2)
+    c2, _, s2 = b.fetch()
+    b.run(t1)
+    c3, _, s3 = b.fetch()
+    np.testing.assert_array_equal(c1, c3)
+    np.testing.assert_array_equal(s1, s3)
+    assert c2.sum() > c1.sum()
+    for thr, c, s in ((t1, c1, s1), (t2, c2, s2)):
+        st, _, oc, _, os_ = c_oracle.pileup(thr, contigs, reads)
+        assert st == 0
+        np.testing.assert_array_equal(c, oc)
+        np.testing.assert_array_equal(s, os_)
+    b.close()
+
+
+def test_long_reads_up_to_1024(hip_ctx, thr_default):
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=50000, n_reads=3000,
+                                        read_len=1000, seed=41, var_len=True)
+    _assert_same(hip_ctx, thr_default, contigs, reads)
+
+
+@pytest.mark.parametrize("read_len,var_len", [(40, True), (16, False), (17, False), (33, False)])
+def test_short_reads(hip_ctx, thr_default, read_len, var_len):
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=5000, n_reads=4000,
+                                        read_len=read_len, seed=43, var_len=var_len)
+    _assert_same(hip_ctx, thr_default, contigs, reads)
+
+
+def test_unsupported_and_malformed_inputs_are_statuses_not_crashes(hip_ctx, thr_default):
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=5000, n_reads=100, seed=1)
+    bad = abi.ContigTable(length=contigs.length, species=contigs.species, read_begin=[0, 99], ref=contigs.ref, n_species=1)
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        hip_ctx.pileup(thr_default, bad, reads)
+    assert ei.value.status == abi.ERR_BAD_LAYOUT
+    zero = abi.ContigTable(length=[0], species=[0], read_begin=[0, 0], ref=np.zeros(0, np.uint8), n_species=1)
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        hip_ctx.pileup(thr_default, zero, abi.ReadsSoA.empty())
+    assert ei.value.status == abi.ERR_UNSUPPORTED
+    long_read = H.reads_from_dicts([dict(pos=0, cigar="2000M", seq="A" * 2000)])
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        hip_ctx.pileup(thr_default, H.single_contig(5000, 1), long_read)
+    assert ei.value.status == abi.ERR_UNSUPPORTED
+
+
+# ---- full-size properties (BASELINE configs[1]); the oracle also finishes it in ~1 s, so compare too -----
+
+@pytest.fixture(scope="module")
+def c2():
+    return synth.make_dataset(**synth.CONFIGS['c2'])
+
+
+def test_c2_full_size_bit_exact_and_conserved(hip_ctx, thr_default, c2):
+    contigs, reads = c2
+    counts, stats = _assert_same(hip_ctx, thr_default, contigs, reads)
+    depth = counts.sum(axis=1, dtype=np.int64)
+    # checksum of checksums: the per-species counters are the reduction of the per-site table
+    assert int(depth.sum()) == int(stats[0, abi.STAT_TOTAL_DEPTH])
+    assert int((depth > 0).sum()) == int(stats[0, abi.STAT_COVERED_BASES])
+    assert int(stats[0, abi.STAT_ALIGNED_READS]) == reads.n_reads
+    assert 0 < int(stats[0, abi.STAT_MAPPED_READS]) < reads.n_reads
+
+
+def test_c2_linearity_in_the_read_set(hip_ctx, thr_default, c2):
+    """counts(A u B) == counts(A) + counts(B): split the reads of every contig into even / odd halves."""
+    contigs, reads = c2
+    full, _, sfull = hip_ctx.pileup(thr_default, contigs, reads, want_allele=False)
+    acc = np.zeros_like(full)
+    sacc = np.zeros_like(sfull)
+    idx = np.arange(reads.n_reads)
+    contig_of = np.searchsorted(contigs.read_begin, idx, side='right') - 1
+    for par in (0, 1):
+        sel = idx[(idx & 1) == par]
+        sub = _subset(reads, sel)
+        rb = np.zeros(contigs.n_contigs + 1, dtype=np.int64)
+        np.cumsum(np.bincount(contig_of[sel], minlength=contigs.n_contigs), out=rb[1:])
+        sc = abi.ContigTable(length=contigs.length, species=contigs.species, read_begin=rb, ref=contigs.ref, n_species=1)
+        c, _, s = hip_ctx.pileup(thr_default, sc, sub, want_allele=False)
+        acc += c
+        sacc[:, :2] += s[:, :2]
+    np.testing.assert_array_equal(acc, full)
+    np.testing.assert_array_equal(sacc[:, :2], sfull[:, :2])
+
+
+def _subset(reads, sel):
+    """Sub-select records of a ReadsSoA (fixed-stride payloads not assumed)."""
+    def gather(data, off, per):
+        lens = (off[1:] - off[:-1])[sel]
+        new_off = np.zeros(sel.size + 1, dtype=np.int64)
+        np.cumsum(lens, out=new_off[1:])
+        starts = off[:-1][sel]
+        ix = np.repeat(starts - new_off[:-1], lens) + np.arange(new_off[-1])
+        return data[ix], new_off
+    seq4, seq_off = gather(reads.seq4, reads.seq_off, None)
+    qual, qual_off = gather(reads.qual, reads.qual_off, None)
+    cigar, cigar_off = gather(reads.cigar, reads.cigar_off, None)
+    return abi.ReadsSoA(pos=reads.pos[sel], mapq=reads.mapq[sel], flag=reads.flag[sel], nm=reads.nm[sel],
+                        l_seq=reads.l_seq[sel], seq_off=seq_off, qual_off=qual_off, cigar_off=cigar_off,
+                        seq4=seq4, qual=qual, cigar=cigar)

@@ -16,7 +16,7 @@ def check(name, contigs, reads, ctx, thr, steps=5):
     st, er, oc, oa, os_ = c_oracle.pileup(thr, contigs, reads)
     t_cpu = time.time() - t0
     b = ctx.batch(contigs, reads)
-    b.enable_timing(True)
+    b.enable_timing(1)
     b.run(thr)
     counts, allele, stats = b.fetch()
     ok_c = np.array_equal(counts, oc)
