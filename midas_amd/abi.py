@@ -109,7 +109,7 @@ class ReadsSoA:
                    z(np.int64, 1), z(np.int64, 1), z(np.int64, 1), z(np.uint8), z(np.uint8), z(np.uint32))
 
     def _c(self) -> _Reads:
-        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # zero-size arrays still have a valid address
         return _Reads(self.n_reads, p(self.pos), p(self.mapq), p(self.flag), p(self.nm), p(self.l_seq),
                       self.seq_off.ctypes.data_as(C.c_void_p), self.qual_off.ctypes.data_as(C.c_void_p),
                       self.cigar_off.ctypes.data_as(C.c_void_p), p(self.seq4), p(self.qual), p(self.cigar))
@@ -146,7 +146,7 @@ class ContigTable:
         return out
 
     def _c(self) -> _Contigs:
-        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
         return _Contigs(self.n_contigs, int(self.n_species), p(self.length), p(self.species),
                         self.read_begin.ctypes.data_as(C.c_void_p), p(self.ref))
 
