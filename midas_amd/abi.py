@@ -222,13 +222,13 @@ def pack_reads(reads: ReadsSoA):
     st = lib.midas_snps_pack_reads(C.byref(r), None, None, 0, C.byref(nbytes), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
-    rec = np.zeros((reads.n_reads, 16), dtype=np.uint8)
+    rec = np.zeros((reads.n_reads + 1, 16), dtype=np.uint8)   # + sentinel record
     blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
     st = lib.midas_snps_pack_reads(C.byref(r), rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
                                    blob.size, C.byref(nbytes), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
-    return rec, blob[:int(nbytes.value)], int(maxl.value)
+    return rec[:reads.n_reads], blob[:int(nbytes.value)], int(maxl.value)
 
 
 class Context:

@@ -7,7 +7,7 @@
 
 namespace midas {
 
-constexpr int kTileShift = 12;             // 4096 sites per tile: 4 planes x 4096 x u32 = 64 KiB of LDS
+constexpr int kTileShift = 12;             // 4096 sites per tile
 constexpr int kTileSites = 1 << kTileShift;
 constexpr int kPileupBlock = 512;          // 8 waves; 2 workgroups per CU (LDS-limited)
 constexpr int kIndexBlock = 256;
@@ -27,8 +27,20 @@ struct IndexParams {
   const int32_t* contig_len;         // [n_contigs]
   uint32_t* rbinv;                   // [n_tiles]  max over overlapping reads of (n_reads - index); 0 = none
   uint32_t* rend;                    // [n_tiles]  max over overlapping reads of (index + 1)
+  unsigned long long* stats;         // [n_species][4]  zeroed here, accumulated by the pileup kernel
+  unsigned long long* err;           // set to kNoError here
   int32_t n_reads;
   int32_t n_contigs;
+  int32_t n_stat_words;              // n_species * 4
+};
+
+// keep_read's two ratio tests as exact integer thresholds, built on the host per threshold set
+// (snps_abi.hip: build_filter_tables) by evaluating the reference's own fp64 expressions:
+//   min_match[a] = least x with !(100*x/float(a) < mapid)   -> keep iff (align_len - NM) >= min_match[align_len]
+//   min_align[l] = least a with !(a/float(l) < aln_cov)     -> keep iff align_len >= min_align[l_seq]
+struct FilterTables {
+  int32_t min_match[kMaxLSeq + 1];
+  int32_t min_align[kMaxLSeq + 1];
 };
 
 struct PileupParams {
@@ -36,8 +48,9 @@ struct PileupParams {
   const uint8_t* blob;
   const uint8_t* ref;
   const Tile* tiles;
-  const uint32_t* rbinv;
-  const uint32_t* rend;
+  uint32_t* rbinv;                   // consumed and reset to 0 by the tile's workgroup
+  uint32_t* rend;
+  const FilterTables* filt;
   uint32_t* out_counts;              // [n_sites][4]
   uint8_t* out_allele;               // [n_sites] or nullptr
   unsigned long long* stats;         // [n_species][4]
@@ -47,8 +60,8 @@ struct PileupParams {
   int32_t tiles_per_xcd;
   int32_t lanes_per_read;            // ceil(max_l_seq / 16)
   int32_t reads_per_wave;            // 64 / lanes_per_read
+  int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
-  double mapid, aln_cov;
 };
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);

@@ -2,10 +2,12 @@
 //
 // HBM layout of one resident batch (all sizes for L=150, one CIGAR op):
 //
-//   rec   [n_reads]   16 B   fixed part of a BAM record (one dwordx4 load per read)
+//   rec   [n_reads+1] 16 B   fixed part of a BAM record (one dwordx4 load per read); the extra
+//                            last record is a sentinel whose blob_off8 is the end of the payload
 //   blob  [...]       232 B  per read, 8-byte aligned, reads back to back in BAM order:
 //                              qual  l_seq bytes          -> padded to 4
-//                              seq4  ceil(l_seq/2) bytes  -> padded to 4
+//                              seq4  ceil(l_seq/2) bytes  -> padded to 4   (call codes: A,C,G,T = 0..3,
+//                                                                          every other BAM code = 8)
 //                              cigar n_cigar * u32        -> whole read padded to 8
 //                            coordinate-sorted input => the reads of a tile are one contiguous
 //                            byte range of `blob`, so a workgroup streams it with full lines.
@@ -26,12 +28,16 @@ struct ReadRec {            // 16 bytes, 16-byte aligned
   uint16_t n_cigar;
   uint16_t nm;              // NM tag; kNmAbsent when the record has none
   uint8_t mapq;
-  uint8_t flags;            // kRecQualAbsent
+  uint8_t flags;            // kRec* bits
 };
 static_assert(sizeof(ReadRec) == 16, "ReadRec must be 16 bytes");
 
 constexpr uint16_t kNmAbsent = 0xFFFF;
-constexpr uint8_t kRecQualAbsent = 1;
+// Record flag bits.  They are decode-time facts about the record, set by the packer:
+constexpr uint8_t kRecQualAbsent = 1;   // qual[0] == 0xFF (BAM: QUAL missing)
+constexpr uint8_t kRecSimple = 2;       // CIGAR is exactly one M/=/X op of length l_seq: the walk is the identity
+constexpr uint8_t kRecClipGeneric = 4;  // clip structure needs the general H/S loops (an H among the clips, or
+                                        // several S at one end); when clear: lead = (op0 == S), trail = (opLast == S)
 
 constexpr int kMaxLSeq = 1024;      // 64 lanes x 16 bases: one wave row per read at most
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record

@@ -38,6 +38,21 @@ void parallel_ranges(int64_t n, F&& fn) {
   for (auto& x : th) x.join();
 }
 
+// byte of two BAM base codes -> byte of two call codes
+struct CallCodeTable {
+  uint8_t v[256];
+  constexpr CallCodeTable() : v() {
+    for (int b = 0; b < 256; ++b) {
+      const int hi = b >> 4, lo = b & 15;
+      const int ch = hi == 1 ? 0 : hi == 2 ? 1 : hi == 4 ? 2 : hi == 8 ? 3 : 8;
+      const int cl = lo == 1 ? 0 : lo == 2 ? 1 : lo == 4 ? 2 : lo == 8 ? 3 : 8;
+      v[b] = (uint8_t)((ch << 4) | cl);
+    }
+  }
+  constexpr uint8_t operator[](uint8_t b) const { return v[b]; }
+};
+constexpr CallCodeTable kCallCodePair{};
+
 void set_err(char* err256, const char* fmt, long long a = 0, long long b = 0, long long c = 0) {
   if (err256) snprintf(err256, 256, fmt, a, b, c);
 }
@@ -132,7 +147,14 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
       const uint8_t* q = r->qual + r->qual_off[i];
       memset(b, 0, bytes[i]);
       memcpy(b, q, l);
-      memcpy(b + blob_seq_off(l), r->seq4 + r->seq_off[i], (l + 1) / 2);
+      {
+        // BAM 4-bit codes -> call codes (layout.h): A,C,G,T -> 0..3, anything else -> 8.  Still 4 bits per
+        // base, first base in the high nibble; the path only ever asks "is it exactly A/C/G/T, and which".
+        const uint8_t* s4 = r->seq4 + r->seq_off[i];
+        uint8_t* d4 = b + blob_seq_off(l);
+        const uint32_t nb = (l + 1) / 2;
+        for (uint32_t k = 0; k < nb; ++k) d4[k] = kCallCodePair[s4[k]];
+      }
       memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
       ReadRec rr;
       rr.pos = r->pos[i];
@@ -142,9 +164,31 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
       rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
       rr.mapq = r->mapq[i];
       rr.flags = (l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0;
+      // Decode-time facts about the CIGAR (fast-path hints; the walk itself runs on the device).
+      const uint32_t* cg = r->cigar + r->cigar_off[i];
+      auto opof = [&](uint32_t k) { return cg[k] & 15u; };
+      auto is_clip = [&](uint32_t k) { return opof(k) == 4u || opof(k) == 5u; };  // S, H
+      if (nc == 1 && (opof(0) == 0u || opof(0) == 7u || opof(0) == 8u) && (cg[0] >> 4) == l && l > 0) {
+        rr.flags |= kRecSimple;
+      } else if (nc > 0) {
+        // leading clip run: maximal prefix of {S,H}; trailing: maximal suffix of {S,H} within indices >= 1
+        uint32_t lead = 0;
+        while (lead < nc && is_clip(lead)) ++lead;
+        uint32_t trail = 0;
+        while (trail + 1 < nc && is_clip(nc - 1 - trail)) ++trail;
+        const bool lead_plain = lead == 0 || (lead == 1 && opof(0) == 4u);
+        const bool trail_plain = trail == 0 || (trail == 1 && opof(nc - 1) == 4u);
+        if (!lead_plain || !trail_plain) rr.flags |= kRecClipGeneric;
+      }
       rec[i] = rr;
     }
   });
+  {
+    ReadRec s;  // sentinel: where the payload ends
+    memset(&s, 0, sizeof s);
+    s.blob_off8 = (uint32_t)(off[n] >> 3);
+    rec[n] = s;
+  }
   return MIDAS_SNPS_OK;
 }
 

@@ -9,16 +9,21 @@
 //   index_bam                       midas/run/snps.py:130-137 (here: per-tile read ranges, built on device)
 //
 // Work decomposition.  The site space is cut into tiles of 4096 sites that never span contigs.  One
-// 512-thread workgroup owns a tile: its A/C/G/T tallies live in LDS as four planes (plane-major, so the
-// 16 consecutive sites a lane touches fall into 16 different banks), reads are streamed straight from
-// the packed HBM arrays, tallies are LDS atomics, and the tile is written out once, 16 B per site,
-// fully coalesced, with the per-species counters reduced by wave shuffles on the way out.
+// 512-thread workgroup owns a tile: its A/C/G/T tallies live in LDS as four skewed planes, reads are
+// streamed straight from the packed HBM arrays through a two-deep register prefetch pipeline, tallies
+// are LDS atomics, and the tile is written out once, 16 B per site, fully coalesced, with the
+// per-species counters reduced by wave shuffles on the way out.
 //
 // Lane mapping.  A lane owns 16 consecutive bases of one read: one 16-byte load of quals and one
-// 8-byte load of packed bases.  A read of l_seq bases therefore occupies ceil(l_seq/16) adjacent
-// lanes (10 for 150 bp; `lanes_per_read` is fixed per batch from the longest read), and a wave works
-// on floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
+// 8-byte load of packed bases.  A read of l_seq bases occupies ceil(l_seq/16) adjacent lanes (10 for
+// 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
+// floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
 // read: a segmented shuffle reduction over the read's lanes gives it without re-reading anything.
+//
+// LDS planes.  plane p, site i  ->  word p*TP + i + (i >> 4), TP = TILE + TILE/16.  The lanes of one
+// read touch sites 16 apart in the same instruction; the skew spreads them over 17-apart words, i.e.
+// distinct banks.  Bases that must not count (low quality, N/IUPAC, outside the CIGAR segment or the
+// tile) are not branched around: they add into a per-lane dump word, so every ds_add is unconditional.
 #include "kernels.h"
 
 namespace midas {
@@ -36,17 +41,34 @@ enum : uint32_t {
 };
 
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ bool consumes_both(uint32_t op) { return op == OP_M || op == OP_EQ || op == OP_X; }
 
+// Unpacked view of a 16-byte ReadRec held as a uint4.
+__device__ __forceinline__ int rec_pos(const uint4& r) { return (int)r.x; }
+__device__ __forceinline__ uint32_t rec_off8(const uint4& r) { return r.y; }
+__device__ __forceinline__ int rec_l(const uint4& r) { return (int)(r.z & 0xFFFFu); }
+__device__ __forceinline__ int rec_n(const uint4& r) { return (int)(r.z >> 16); }
+__device__ __forceinline__ uint32_t rec_nm(const uint4& r) { return r.w & 0xFFFFu; }
+__device__ __forceinline__ int rec_mapq(const uint4& r) { return (int)((r.w >> 16) & 0xFFu); }
+__device__ __forceinline__ uint32_t rec_flags(const uint4& r) { return r.w >> 24; }
+
 // ------------------------------------------------------------------------------------------------
-// Index kernel: one thread per read.  Walks the CIGAR for the reference span and records, for every
-// tile the read overlaps, the lowest and highest read index seen.  The pileup kernel scans exactly
-// [lowest, highest] per tile, so a long deletion in one read widens the scan of the tiles it really
-// crosses and of no other.  Sortedness of the input only affects how tight these ranges are.
+// Index kernel: one thread per read.  Finds the reference span (from the record alone for the
+// common single-match CIGAR, else by walking the CIGAR) and records, for every tile the read
+// overlaps, the lowest and highest read index seen.  The pileup kernel scans exactly that range per
+// tile, so a long deletion in one read widens the scan of the tiles it really crosses and of no
+// other.  Sortedness of the input only affects how tight these ranges are.  Block 0 also resets the
+// per-species counters and the error word for this run (the tile ranges reset themselves: each
+// pileup workgroup zeroes its own entry after reading it).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p) {
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < p.n_stat_words; i += kIndexBlock) p.stats[i] = 0ull;
+    if (threadIdx.x == 0) *p.err = kNoError;
+  }
   const int i = blockIdx.x * kIndexBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool valid = i < p.n_reads;
@@ -57,19 +79,23 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
       const int mid = (lo + hi) >> 1;
       if (p.contig_read_begin[mid] <= i) lo = mid; else hi = mid;
     }
-    const ReadRec r = p.rec[i];
-    const uint32_t* cig =
-        reinterpret_cast<const uint32_t*>(p.blob + (size_t)r.blob_off8 * 8 + blob_cigar_off(r.l_seq));
-    long long reflen = 0;
-    for (int k = 0; k < (int)r.n_cigar; ++k) {
-      const uint32_t v = cig[k];
-      const uint32_t op = v & 15u;
-      if (consumes_both(op) || op == OP_D || op == OP_N) reflen += (long long)(v >> 4);
+    const uint4 r = reinterpret_cast<const uint4*>(p.rec)[i];
+    long long reflen = rec_l(r);
+    if (!(rec_flags(r) & kRecSimple)) {
+      const uint32_t* cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(r) * 8 +
+                                                              blob_cigar_off((uint32_t)rec_l(r)));
+      reflen = 0;
+      const int n = rec_n(r);
+      for (int k = 0; k < n; ++k) {
+        const uint32_t v = cig[k];
+        const uint32_t op = v & 15u;
+        if (consumes_both(op) || op == OP_D || op == OP_N) reflen += (long long)(v >> 4);
+      }
     }
     const long long clen = p.contig_len[lo];
-    long long p0 = r.pos;
+    long long p0 = rec_pos(r);
     p0 = p0 < 0 ? 0 : (p0 > clen - 1 ? clen - 1 : p0);
-    long long p1 = (long long)r.pos + (reflen > 0 ? reflen : 1) - 1;
+    long long p1 = (long long)rec_pos(r) + (reflen > 0 ? reflen : 1) - 1;
     p1 = p1 < p0 ? p0 : (p1 > clen - 1 ? clen - 1 : p1);
     const int tb = p.contig_tile_base[lo];
     gt0 = tb + (int)(p0 >> kTileShift);
@@ -90,35 +116,28 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Tally 16 bases held in registers into the tile's LDS planes.
-//   qw[4]  : 16 quality bytes        sw[2] : 16 packed 4-bit base codes (first base in the high nibble)
-//   [jlo,jhi) : which of the 16 belong to the current CIGAR match segment
-//   local0 : tile-relative site of base 0 of the chunk (may be negative / past the tile)
-// ------------------------------------------------------------------------------------------------
-template <int TILE>
-__device__ __forceinline__ void tally16(uint32_t* cnt, const uint32_t (&qw)[4], const uint32_t (&sw)[2],
-                                        int jlo, int jhi, int local0, int tile_len, int baseq) {
-  const uint32_t span = (uint32_t)(jhi - jlo);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t q = (qw[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-    const uint32_t nb = (sw[j >> 3] >> (4 * ((j & 7) ^ 1))) & 0xFu;
-    const int loc = local0 + j;
-    const bool onehot = nb != 0u && (nb & (nb - 1u)) == 0u;  // exactly A(1) C(2) G(4) T(8)
-    const bool ok = (uint32_t)(j - jlo) < span && (uint32_t)loc < (uint32_t)tile_len && (int)q >= baseq && onehot;
-    if (ok) {
-      const int plane = __builtin_ctz(nb);
-      atomicAdd(&cnt[plane * TILE + loc], 1u);
-    }
-  }
+// Byte mask with bytes [lo, hi) of a 32-bit word set (lo, hi are clamped into 0..4 here).
+__device__ __forceinline__ uint32_t byte_range_mask(int lo, int hi) {
+  const uint32_t below_hi = hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
+  const uint32_t below_lo = lo >= 4 ? 0xFFFFFFFFu : (lo <= 0 ? 0u : ((1u << (8 * lo)) - 1u));
+  return below_hi & ~below_lo;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pileup kernel.  LDS tallies are [site][A,C,G,T] u32 (16 B per site), so the address of a tally is
+// (site << 4) | (call_code << 2): one OR per base.  Everything that decides WHETHER a base counts
+// (quality threshold, not-ACGT, tail of the read, CIGAR segment, tile edge) is folded, four bases per
+// instruction, into the quality byte itself (a base that must not count gets quality 0), so the
+// per-base work in the hot loop is one byte compare, one OR and one predicated ds_add.
+// ------------------------------------------------------------------------------------------------
 template <int TILE_SHIFT>
-__global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams p) {
+__global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
   constexpr int TILE = 1 << TILE_SHIFT;
-  __shared__ __attribute__((aligned(16))) uint32_t cnt[4 * TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
+  __shared__ int32_t s_min_match[kMaxLSeq + 1];
+  __shared__ int32_t s_min_align[kMaxLSeq + 1];
   __shared__ unsigned long long s_stats[MIDAS_STATS];
+  __shared__ int32_t s_range[2];
 
   // Consecutive tiles share their straddling reads: keep neighbours on one XCD (block b runs on XCD b % 8).
   const int t = (int)(blockIdx.x & 7u) * p.tiles_per_xcd + (int)(blockIdx.x >> 3);
@@ -129,14 +148,25 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
   const int wave = tid >> 6;
 
   {
-    uint4* z = reinterpret_cast<uint4*>(cnt);
+    uint4* z = reinterpret_cast<uint4*>(lds);
     for (int i = tid; i < TILE; i += kPileupBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < p.table_len; i += kPileupBlock) {
+      s_min_match[i] = p.filt->min_match[i];
+      s_min_align[i] = p.filt->min_align[i];
+    }
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
+    if (tid == 0) {
+      const uint32_t rbinv = p.rbinv[t];
+      const int re0 = (int)p.rend[t];
+      s_range[0] = rbinv ? p.n_reads - (int)rbinv : re0;
+      s_range[1] = re0;
+      p.rbinv[t] = 0u;   // leave the index clean for the next run
+      p.rend[t] = 0u;
+    }
   }
-  const uint32_t rbinv = p.rbinv[t];
-  const int re = (int)p.rend[t];
-  const int rb = rbinv ? p.n_reads - (int)rbinv : re;
   __syncthreads();
+  const int rb = s_range[0];
+  const int re = s_range[1];
 
   const int lpr = p.lanes_per_read;
   const int rpw = p.reads_per_wave;
@@ -144,68 +174,118 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
   const int c = lane - g * lpr;
   const bool lane_used = g < rpw;
   const int q0 = c * 16;
+  const int stride = (kPileupBlock / 64) * rpw;
+  const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
+  const int tile_len = tile.len;
+  const int tile_start = tile.start;
+  const int bq = p.baseq < 1 ? 1 : p.baseq;   // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
+  const bool count_all = p.baseq < 1;
   uint32_t w_aligned = 0, w_mapped = 0;
 
-  for (int base = rb + wave * rpw; base < re; base += (kPileupBlock / 64) * rpw) {
-    const int r = base + g;
-    bool act = lane_used && r < re;
-    ReadRec rr;
-    if (act) {
-      rr = p.rec[r];
-    } else {
-      rr.pos = 0; rr.blob_off8 = 0; rr.l_seq = 0; rr.n_cigar = 0; rr.nm = 0; rr.mapq = 0; rr.flags = 0;
-    }
-    const int l = rr.l_seq;
-    const int n = rr.n_cigar;
-    // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
-    int cpos = rr.pos < 0 ? 0 : rr.pos;
-    cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-    const bool owner = act && cpos >= tile.start && cpos < tile.start + tile.len;
-    // reads that start in an earlier tile and provably end before this one: nothing to do here
-    if (act && !owner && n == 1 && (long long)rr.pos + l <= (long long)tile.start) act = false;
-
-    const uint8_t* bp = p.blob + (size_t)rr.blob_off8 * 8;
-    const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
-    const bool has = act && q0 < l;
-    uint32_t qw[4] = {0u, 0u, 0u, 0u};
-    uint32_t sw[2] = {0u, 0u};
-    if (has) {
+  // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead -------------
+  auto fetch_rec = [&](int b) -> uint4 {
+    const int r = b + g;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (lane_used && r < re) v = recs[r];
+    return v;
+  };
+  struct Payload {
+    uint32_t qw[4];
+    uint32_t sw[2];
+    uint32_t cg[4];   // first four CIGAR ops (non-simple reads only)
+    uint32_t cl;      // last CIGAR op
+  };
+  auto fetch_payload = [&](const uint4& rv, int b, Payload& d) {
+    const int r = b + g;
+    const bool act = lane_used && r < re;
+    const int l = rec_l(rv);
+    const int n = rec_n(rv);
+    const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
+    d.qw[0] = d.qw[1] = d.qw[2] = d.qw[3] = 0u;
+    d.sw[0] = d.sw[1] = 0u;
+    d.cg[0] = d.cg[1] = d.cg[2] = d.cg[3] = 0u;
+    d.cl = 0u;
+    if (act && q0 < l) {
       const u32x4_a8 qv = *reinterpret_cast<const u32x4_a8*>(bp + q0);
       const u32x2_a4 sv = *reinterpret_cast<const u32x2_a4*>(bp + blob_seq_off((uint32_t)l) + (q0 >> 1));
-      qw[0] = qv.x; qw[1] = qv.y; qw[2] = qv.z; qw[3] = qv.w;
-      sw[0] = sv.x; sw[1] = sv.y;
+      d.qw[0] = qv.x; d.qw[1] = qv.y; d.qw[2] = qv.z; d.qw[3] = qv.w;
+      d.sw[0] = sv.x; d.sw[1] = sv.y;
     }
+    if (act && !(rec_flags(rv) & kRecSimple) && n > 0) {
+      const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
+      const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
+      d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
+      d.cl = n <= 4 ? (n == 1 ? cv.x : (n == 2 ? cv.y : (n == 3 ? cv.z : cv.w))) : cig[n - 1];
+    }
+  };
 
-    // ---- soft-clip trimming ([EXT] pysam getQueryStart / getQueryEnd) -------------------------
+  int base = rb + wave * rpw;
+  uint4 rec_cur = fetch_rec(base);
+  uint4 rec_nxt = fetch_rec(base + stride);
+  Payload cur;
+  fetch_payload(rec_cur, base, cur);
+
+  for (; base < re; base += stride) {
+    const uint4 rec_nn = fetch_rec(base + 2 * stride);
+    Payload nxt;
+    fetch_payload(rec_nxt, base + stride, nxt);
+
+    // ================= process (rec_cur, cur) =====================================================
+    const int r = base + g;
+    bool act = lane_used && r < re;
+    const int l = rec_l(rec_cur);
+    const int n = rec_n(rec_cur);
+    const int pos = rec_pos(rec_cur);
+    const uint32_t flags = rec_flags(rec_cur);
+    const bool simple = (flags & kRecSimple) != 0u;
+    // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
+    int cpos = pos < 0 ? 0 : pos;
+    cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
+    const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+    // reads that start in an earlier tile and provably end before this one: nothing to do here
+    if (act && !owner && n == 1 && (long long)pos + l <= (long long)tile_start) act = false;
+    const bool has = act && q0 < l;
+    const uint8_t* bp = p.blob + (size_t)rec_off8(rec_cur) * 8;
+    const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
+
+    // ---- soft-clip trimming ([EXT] pysam getQueryStart / getQueryEnd) -----------------------------
     int k0 = 0, lead_s = 0, trail_s = 0;
-    if (act) {
-      while (k0 < n) {
-        const uint32_t v = cig[k0];
-        const uint32_t op = v & 15u;
-        if (op == OP_H) { ++k0; }
-        else if (op == OP_S) { lead_s += (int)(v >> 4); ++k0; }
-        else break;
-      }
-      for (int k = n - 1; k >= 1; --k) {   // index 0 is never inspected by pysam's backward walk
-        const uint32_t v = cig[k];
-        const uint32_t op = v & 15u;
-        if (op == OP_H) continue;
-        if (op == OP_S) trail_s += (int)(v >> 4); else break;
+    if (act && !simple) {
+      if (!(flags & kRecClipGeneric)) {
+        if (n > 0 && (cur.cg[0] & 15u) == OP_S) { lead_s = (int)(cur.cg[0] >> 4); k0 = 1; }
+        if (n > 1 && (cur.cl & 15u) == OP_S) trail_s = (int)(cur.cl >> 4);
+      } else {
+        while (k0 < n) {
+          const uint32_t v = cig[k0];
+          const uint32_t op = v & 15u;
+          if (op == OP_H) { ++k0; }
+          else if (op == OP_S) { lead_s += (int)(v >> 4); ++k0; }
+          else break;
+        }
+        for (int k = n - 1; k >= 1; --k) {   // index 0 is never inspected by pysam's backward walk
+          const uint32_t v = cig[k];
+          const uint32_t op = v & 15u;
+          if (op == OP_H) continue;
+          if (op == OP_S) trail_s += (int)(v >> 4); else break;
+        }
       }
     }
     int align_len = (l - trail_s) - lead_s;
     align_len = align_len < 0 ? 0 : align_len;
+    // exact integer form of the two fp64 ratio tests (tables built by the host with the reference's expressions)
+    const int min_match = s_min_match[align_len < p.table_len ? align_len : 0];
+    const int min_align = s_min_align[l < p.table_len ? l : 0];
 
     // ---- quality sum of the whole read: per-lane partial, then a segmented reduction ------------
+    const int nvalid = has ? (l - q0 < 16 ? l - q0 : 16) : 0;
+    uint32_t qm[4];      // quality bytes of the chunk, zero beyond the end of the read
     int part = 0;
-    if (has) {
-      const int nvalid = l - q0;  // > 0
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int nb = nvalid - 4 * w;
-        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-        part = (int)__builtin_amdgcn_sad_u8(qw[w] & m, 0u, (uint32_t)part);
-      }
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t m = byte_range_mask(0, nvalid - 4 * w);
+      qm[w] = cur.qw[w] & m;
+      part = (int)__builtin_amdgcn_sad_u8(qm[w], 0u, (uint32_t)part);
+      if (count_all) qm[w] = m;
     }
     for (int d = 1; d < lpr; d <<= 1) {
       const int o = __shfl_down(part, d);
@@ -218,36 +298,59 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
     uint32_t err = 0;
     if (act) {
       if (l == 0) err = E_NO_SEQ;
-      else if (rr.nm == kNmAbsent) err = E_NO_NM;
+      else if (rec_nm(rec_cur) == kNmAbsent) err = E_NO_NM;
       else if (align_len == 0) err = E_ZERO_ALIGN;
-      else {
-        const double pid = (double)(100LL * (long long)(align_len - (int)rr.nm)) / (double)align_len;
-        if (pid < p.mapid) keep = false;
-        else if (rr.flags & kRecQualAbsent) err = E_NO_QUAL;
-        // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; quotient is >= 2^-16 away from readq)
-        else if ((long long)qsum < (long long)p.readq * (long long)l) keep = false;
-        else if ((int)rr.mapq < p.mapq) keep = false;
-        else if ((double)align_len / (double)l < p.aln_cov) keep = false;
-        else keep = true;
-      }
+      else if (align_len - (int)rec_nm(rec_cur) < min_match) keep = false;            // pid < mapid
+      else if (flags & kRecQualAbsent) err = E_NO_QUAL;
+      // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; the quotient is >= 2^-16 away from readq)
+      else if ((long long)qsum < (long long)p.readq * (long long)l) keep = false;
+      else if (rec_mapq(rec_cur) < p.mapq) keep = false;
+      else if (align_len < min_align) keep = false;                                     // aln_cov
+      else keep = true;
     }
 
-    // ---- CIGAR walk + tallies ([EXT] get_aligned_pairs(matches_only=True)) -------------------------
-    if (keep && has) {
-      long long qpos = lead_s;
-      long long rpos = rr.pos;
-      const int q1 = (q0 + 16 < l) ? q0 + 16 : l;
-      for (int k = k0; k < n; ++k) {
-        const uint32_t v = cig[k];
+    // ---- per-base call codes and validity, four bases per instruction ------------------------------
+    uint32_t qv[4];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
+    uint32_t cd[4];   // byte offset of the base's counter inside its site: call code * 4
+    bool walking = keep && has;
+    if (walking) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));        // seq bytes 2w, 2w+1: bases 4w .. 4w+3
+        const uint32_t t4 = __builtin_amdgcn_perm(0u, x16, 0x01010000u);   // [b0, b0, b1, b1]
+        const uint32_t nib = ((t4 >> 4) & 0x000F000Fu) | (t4 & 0x0F000F00u);  // one call code per byte
+        const uint32_t inv = nib & 0x08080808u;                       // not A/C/G/T
+        const uint32_t inv_ff = (inv << 5) - (inv >> 3);              // 0xFF in every such byte
+        qv[w] = qm[w] & ~inv_ff;
+        cd[w] = (nib & 0x03030303u) << 2;
+      }
+    } else {
+      qv[0] = qv[1] = qv[2] = qv[3] = 0u;
+      cd[0] = cd[1] = cd[2] = cd[3] = 0u;
+    }
+
+    // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -------
+    int k = k0;
+    long long qpos = lead_s;
+    long long rpos = pos;
+    const int q1 = q0 + nvalid;
+    int jlo = 0, jhi = 0, loc0 = 0;
+    auto next_segment = [&]() -> bool {
+      while (k < n) {
+        const uint32_t v = k < 4 ? (k == 0 ? cur.cg[0] : (k == 1 ? cur.cg[1] : (k == 2 ? cur.cg[2] : cur.cg[3]))) : cig[k];
+        ++k;
         const uint32_t op = v & 15u;
         const long long len = (long long)(v >> 4);
         if (consumes_both(op)) {
           const long long lo = qpos > q0 ? qpos : q0;
           const long long hi = (qpos + len) < q1 ? (qpos + len) : q1;
-          if (lo < hi) {
-            long long local0 = rpos + ((long long)q0 - qpos) - (long long)tile.start;
-            local0 = local0 < -(1LL << 30) ? -(1LL << 30) : (local0 > (1LL << 30) ? (1LL << 30) : local0);
-            tally16<TILE>(cnt, qw, sw, (int)(lo - q0), (int)(hi - q0), (int)local0, tile.len, p.baseq);
+          const bool found = lo < hi;
+          if (found) {
+            long long x = rpos + ((long long)q0 - qpos) - (long long)tile_start;
+            x = x < -(1LL << 24) ? -(1LL << 24) : (x > (1LL << 24) ? (1LL << 24) : x);
+            jlo = (int)(lo - q0);
+            jhi = (int)(hi - q0);
+            loc0 = (int)x;
           }
           if (qpos + len > l) {
             // query positions >= l_seq: pysam indexes past the end iff their refpos is inside the contig
@@ -257,12 +360,42 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
           }
           qpos += len;
           rpos += len;
+          if (found) return true;
         } else if (op == OP_I || op == OP_S) {
           qpos += len;
         } else if (op == OP_D || op == OP_N) {
           rpos += len;
         }  // H, P and anything else: no effect
       }
+      return false;
+    };
+    if (walking) {
+      if (simple) {
+        long long x = (long long)pos + q0 - (long long)tile_start;
+        x = x < -(1LL << 24) ? -(1LL << 24) : (x > (1LL << 24) ? (1LL << 24) : x);
+        jlo = 0; jhi = nvalid; loc0 = (int)x; k = n;
+      } else {
+        walking = next_segment();
+      }
+    }
+    while (walking) {
+      // bases of the chunk that belong to this segment AND lie inside the tile: [lo, hi)
+      uint32_t q4[4] = {qv[0], qv[1], qv[2], qv[3]};
+      const int lo = jlo > -loc0 ? jlo : -loc0;
+      const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
+      if (lo > 0 || hi < nvalid) {    // partial chunk (segment border or tile edge): mask the bytes outside
+#pragma unroll
+        for (int w = 0; w < 4; ++w) q4[w] &= byte_range_mask(lo - 4 * w, hi - 4 * w);
+      }
+      const uint32_t abase = (uint32_t)loc0 << 4;
+      char* const lds_bytes = reinterpret_cast<char*>(lds);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = (int)((q4[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+        const uint32_t code = (cd[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        if (q >= bq) atomicAdd(reinterpret_cast<uint32_t*>(lds_bytes + ((abase | code) + 16u * j)), 1u);
+      }
+      walking = (k < n) ? next_segment() : false;
     }
 
     // ---- per-species read counters: one ballot per wave -------------------------------------------
@@ -272,6 +405,10 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
     w_aligned += (uint32_t)__popcll(m_al);
     w_mapped += (uint32_t)__popcll(m_mp);
     if (head && err) atomicMin(p.err, ((unsigned long long)(uint32_t)r << 8) | err);
+
+    rec_cur = rec_nxt;
+    rec_nxt = rec_nn;
+    cur = nxt;
   }
 
   if (lane == 0) {
@@ -283,15 +420,16 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
   // ---- emit the tile: counts[site][A,C,G,T], upper-cased ref allele, covered/total-depth partials -
   unsigned long long covered = 0, depth_sum = 0;
   uint4* out = reinterpret_cast<uint4*>(p.out_counts) + tile.site_base;
-  for (int i = tid; i < tile.len; i += kPileupBlock) {
-    const uint32_t a = cnt[i], cc = cnt[TILE + i], gg = cnt[2 * TILE + i], tt = cnt[3 * TILE + i];
-    out[i] = make_uint4(a, cc, gg, tt);
+  const uint4* lds4 = reinterpret_cast<const uint4*>(lds);
+  for (int i = tid; i < tile_len; i += kPileupBlock) {
+    const uint4 v = lds4[i];
+    out[i] = v;
     if (p.out_allele) {
       uint32_t ch = p.ref[tile.site_base + i];
       if (ch >= 'a' && ch <= 'z') ch -= 32u;
       p.out_allele[tile.site_base + i] = (uint8_t)ch;
     }
-    const uint32_t d = a + cc + gg + tt;
+    const uint32_t d = v.x + v.y + v.z + v.w;
     covered += d > 0u ? 1ull : 0ull;
     depth_sum += d;
   }
@@ -310,8 +448,8 @@ __global__ __launch_bounds__(kPileupBlock) void pileup_tiles_kernel(PileupParams
 }  // namespace
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream) {
-  if (p.n_reads <= 0) return hipSuccess;
-  const int grid = (p.n_reads + kIndexBlock - 1) / kIndexBlock;
+  // always launched (even with no reads): block 0 resets the counters and the error word
+  const int grid = p.n_reads > 0 ? (p.n_reads + kIndexBlock - 1) / kIndexBlock : 1;
   hipLaunchKernelGGL(index_reads_kernel, dim3(grid), dim3(kIndexBlock), 0, stream, p);
   return hipGetLastError();
 }

@@ -35,6 +35,11 @@ struct midas_snps_batch {
   int32_t* d_contig_tile_base = nullptr;
   int32_t* d_contig_len = nullptr;
   uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
+  FilterTables* d_filt = nullptr;
+  FilterTables h_filt;
+  bool filt_valid = false;
+  double filt_mapid = 0, filt_aln_cov = 0;
+  int32_t max_l_seq = 0;
   size_t work_bytes = 0;
   uint32_t* d_counts = nullptr;
   uint8_t* d_allele = nullptr;
@@ -77,6 +82,49 @@ unsigned long long* work_stats(midas_snps_batch* b) {
   return reinterpret_cast<unsigned long long*>(b->d_work + off);
 }
 unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
+
+// The reference's own expressions (midas/run/snps.py:148, 157), evaluated in IEEE fp64 exactly as
+// Python does, tabulated over every length a batch can contain.  Both predicates are monotone in
+// the integer being tested, so the least passing value is found by bisection.
+//   min_match[a]: least x = align_len - NM in [-65535, a] with !(100*x/float(a) < mapid); a+1 if none
+//   min_align[l]: least a in [1, l] with !(a/float(l) < aln_cov);                          l+1 if none
+void build_filter_tables(double mapid, double aln_cov, int32_t max_l, FilterTables* t) {
+  t->min_match[0] = 0;
+  t->min_align[0] = 0;
+  for (int32_t a = 1; a <= max_l && a <= kMaxLSeq; ++a) {
+    auto pass_pid = [&](long long x) { return !((double)(100LL * x) / (double)a < mapid); };
+    long long lo = -65536, hi = (long long)a + 1;  // invariant: pass(hi) (virtually) true, pass(lo) false
+    if (pass_pid(-65535)) {
+      t->min_match[a] = -65535;
+    } else {
+      lo = -65535;
+      if (!pass_pid(a)) {
+        t->min_match[a] = a + 1;
+      } else {
+        hi = a;
+        while (hi - lo > 1) {
+          const long long mid = lo + (hi - lo) / 2;
+          if (pass_pid(mid)) hi = mid; else lo = mid;
+        }
+        t->min_match[a] = (int32_t)hi;
+      }
+    }
+    const int32_t l = a;
+    auto pass_cov = [&](long long x) { return !((double)x / (double)l < aln_cov); };
+    if (pass_cov(1)) {
+      t->min_align[l] = 1;
+    } else if (!pass_cov(l)) {
+      t->min_align[l] = l + 1;
+    } else {
+      long long lo2 = 1, hi2 = l;
+      while (hi2 - lo2 > 1) {
+        const long long mid = lo2 + (hi2 - lo2) / 2;
+        if (pass_cov(mid)) hi2 = mid; else lo2 = mid;
+      }
+      t->min_align[l] = (int32_t)hi2;
+    }
+  }
+}
 
 const char* read_err_name(int32_t st) {
   switch (st) {
@@ -185,6 +233,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   (void)hipFree(b->d_contig_tile_base);
   (void)hipFree(b->d_contig_len);
   (void)hipFree(b->d_work);
+  (void)hipFree(b->d_filt);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_allele);
   for (auto& e : b->ev)
@@ -259,12 +308,12 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
 
   // ---- pack + upload reads ------------------------------------------------------------------
   const size_t blob_alloc = (size_t)ps.blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
-  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_reads > 0 ? b->n_reads : 1) * sizeof(ReadRec)));
+  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec)));  // + sentinel
   B_TRY(hipMalloc(&b->d_blob, blob_alloc));
   if (b->n_reads > 0) {
     ReadRec* h_rec = nullptr;
     uint8_t* h_blob = nullptr;
-    B_TRY(hipHostMalloc(&h_rec, (size_t)b->n_reads * sizeof(ReadRec), hipHostMallocDefault));
+    B_TRY(hipHostMalloc(&h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipHostMallocDefault));
     hipError_t e = hipHostMalloc(&h_blob, blob_alloc, hipHostMallocDefault);
     if (e != hipSuccess) {
       (void)hipHostFree(h_rec);
@@ -276,7 +325,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     st = pack_reads(reads, h_rec, h_blob, (int64_t)blob_alloc, &ps, ebuf);
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
     if (st == MIDAS_SNPS_OK) {
-      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)b->n_reads * sizeof(ReadRec), hipMemcpyHostToDevice);
+      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
       e2 = hipMemcpy(b->d_blob, h_blob, blob_alloc, hipMemcpyHostToDevice);
     }
     (void)hipHostFree(h_rec);
@@ -289,6 +338,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     B_TRY(e2);
   } else {
     B_TRY(hipMemset(b->d_blob, 0, blob_alloc));
+    B_TRY(hipMemset(b->d_rec, 0, sizeof(ReadRec)));
   }
 
   // ---- reference letters, tables, workspace, outputs -----------------------------------------
@@ -308,6 +358,11 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
   b->work_bytes = (((size_t)b->n_tiles * 8 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
+  // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
+  // error word are reset by the index kernel at the start of each run: no per-run memsets
+  B_TRY(hipMemset(b->d_work, 0, b->work_bytes));
+  B_TRY(hipMalloc(&b->d_filt, sizeof(FilterTables)));
+  b->max_l_seq = ps.max_l_seq;
   B_TRY(hipMalloc(&b->d_counts, ns * 16));
   B_TRY(hipMalloc(&b->d_allele, ns));
 #undef B_TRY
@@ -337,8 +392,15 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   hipEvent_t* ev = b->timing_slots > 0 ? &b->ev[(size_t)(b->timed_runs % b->timing_slots) * 3] : nullptr;
   if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
   // rbinv / rend / stats zeroed, error word = "no error" (all ones)
-  HIP_TRY(ctx, hipMemsetAsync(b->d_work, 0, b->work_bytes - 8, s));
-  HIP_TRY(ctx, hipMemsetAsync(work_err(b), 0xFF, 8, s));
+  // keep_read's fp64 ratio tests as exact integer thresholds (rebuilt only when mapid / aln_cov change)
+  if (!b->filt_valid || memcmp(&b->filt_mapid, &thr->mapid, 8) != 0 || memcmp(&b->filt_aln_cov, &thr->aln_cov, 8) != 0) {
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // a previous run may still be reading the tables
+    build_filter_tables(thr->mapid, thr->aln_cov, b->max_l_seq, &b->h_filt);
+    HIP_TRY(ctx, hipMemcpy(b->d_filt, &b->h_filt, sizeof(FilterTables), hipMemcpyHostToDevice));
+    b->filt_mapid = thr->mapid;
+    b->filt_aln_cov = thr->aln_cov;
+    b->filt_valid = true;
+  }
 
   IndexParams ip;
   ip.rec = b->d_rec;
@@ -348,8 +410,11 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.contig_len = b->d_contig_len;
   ip.rbinv = work_rbinv(b);
   ip.rend = work_rend(b);
+  ip.stats = work_stats(b);
+  ip.err = work_err(b);
   ip.n_reads = (int32_t)b->n_reads;
   ip.n_contigs = b->n_contigs;
+  ip.n_stat_words = b->n_species * MIDAS_STATS;
   HIP_TRY(ctx, launch_index_reads(ip, s));
   if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
 
@@ -372,8 +437,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.baseq = thr->baseq;
   pp.mapq = thr->mapq;
   pp.readq = thr->readq;
-  pp.mapid = thr->mapid;
-  pp.aln_cov = thr->aln_cov;
+  pp.filt = b->d_filt;
+  pp.table_len = b->max_l_seq + 1;
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
   if (ev) {
     HIP_TRY(ctx, hipEventRecord(ev[2], s));

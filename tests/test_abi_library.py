@@ -81,7 +81,9 @@ def test_pack_layout_matches_design():
     r = rec.view(np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
                            ("mapq", "u1"), ("flags", "u1")])).reshape(3)
     assert r["pos"].tolist() == [7, 9, 11] and r["l"].tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
-    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42] and r["flags"].tolist() == [0, 0, 1]
+    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42] 
+    # flags: bit0 QUAL absent, bit1 "simple" (one M/=/X op spanning l_seq), bit2 generic clip structure
+    assert r["flags"].tolist() == [0, 2, 3]
     # read 0: qual 10 -> pad 12 | seq 5 -> pad 8 | cigar 8 -> 28 -> pad 32
     assert r["off8"].tolist() == [0, 4, 6]   # read 1: 5->8 | 3->4 | 4 = 16 bytes
     b0 = blob[:32]
@@ -89,6 +91,18 @@ def test_pack_layout_matches_design():
     assert bytes(b0[12:17]) == bytes(H.encode_seq4("TTTACGTACG"))
     assert b0[20:28].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
     assert blob.size == 32 + 16 + 16
+
+
+def test_pack_cigar_fast_path_flags():
+    """Decode-time CIGAR facts the kernels rely on (layout.h kRec*): they must be exact, not heuristics."""
+    cases = [("150M", 150, 2), ("150=", 150, 2), ("150X", 150, 2), ("149M", 150, 0), ("10S140M", 150, 0),
+             ("140M10S", 150, 0), ("10S130M10S", 150, 0), ("5H10S135M", 145, 4), ("135M10S5H", 145, 4),
+             ("5S5S140M", 150, 4), ("140M5S5S", 150, 4), ("2H148M", 148, 4), ("10S", 10, 0), ("5S5S", 10, 4),
+             ("75M2I73M", 150, 0), ("75M2D75M", 150, 0), ("150I", 150, 0)]
+    reads = H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l) for cg, l, _ in cases])
+    rec, _, _ = abi.pack_reads(reads)
+    flags = rec[:, 15].tolist()
+    assert flags == [f for _, _, f in cases], list(zip([c[0] for c in cases], flags))
 
 
 def test_pack_rejects_malformed_input_with_status():
