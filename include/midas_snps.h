@@ -205,9 +205,10 @@ int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_devi
  * The packer that batch_create() runs, exposed so that CPU-only tests can check
  * the device layout: returns the number of payload bytes via *out_blob_bytes; if
  * rec16/blob are non-NULL they receive (n_reads+1)*16 bytes of records (the last one a sentinel
- * holding the end of the payload) and the payload itself. */
-int32_t midas_snps_pack_reads(const midas_snps_reads* reads, void* rec16, void* blob,
-                              int64_t blob_capacity, int64_t* out_blob_bytes,
+ * holding the end of the payload) and the payload itself.  `contigs` may be NULL (then the
+ * "CIGAR reaches past SEQ inside the contig" record flag is computed against unbounded contigs). */
+int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs,
+                              void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
                               int32_t* out_max_l_seq, char* err256);
 
 #ifdef __cplusplus

@@ -189,7 +189,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_enable_timing': (i32, [vp, i32]),
         'midas_snps_batch_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
-        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
+        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
@@ -212,19 +212,21 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-def pack_reads(reads: ReadsSoA):
+def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):
     """Host-only: run the packer and return (rec[n,16] uint8, blob uint8, max_l_seq)."""
     lib = load_library()
     r = reads._c()
+    cc = contigs._c() if contigs is not None else None
+    cp = C.byref(cc) if cc is not None else None
     nbytes = C.c_int64(0)
     maxl = C.c_int32(0)
     err = C.create_string_buffer(256)
-    st = lib.midas_snps_pack_reads(C.byref(r), None, None, 0, C.byref(nbytes), C.byref(maxl), err)
+    st = lib.midas_snps_pack_reads(C.byref(r), cp, None, None, 0, C.byref(nbytes), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
     rec = np.zeros((reads.n_reads + 1, 16), dtype=np.uint8)   # + sentinel record
     blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
-    st = lib.midas_snps_pack_reads(C.byref(r), rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
+    st = lib.midas_snps_pack_reads(C.byref(r), cp, rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
                                    blob.size, C.byref(nbytes), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())

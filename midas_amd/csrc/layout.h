@@ -1,19 +1,25 @@
 // Device data layout of the MI355X SNP pileup, shared by the host packer and the kernels.
 //
-// HBM layout of one resident batch (all sizes for L=150, one CIGAR op):
+// HBM layout of one resident batch:
 //
 //   rec   [n_reads+1] 16 B   fixed part of a BAM record (one dwordx4 load per read); the extra
 //                            last record is a sentinel whose blob_off8 is the end of the payload
-//   blob  [...]       232 B  per read, 8-byte aligned, reads back to back in BAM order:
-//                              qual  l_seq bytes          -> padded to 4
-//                              seq4  ceil(l_seq/2) bytes  -> padded to 4   (call codes: A,C,G,T = 0..3,
-//                                                                          every other BAM code = 8)
-//                              cigar n_cigar * u32        -> whole read padded to 8
+//   blob  [...]              per read, 8-byte aligned, reads back to back in BAM order
+//                            (240 B for a 150 bp single-match read):
+//                              qual   l_seq bytes, zero-padded to a multiple of 32
+//                              calls  ceil(l_seq/2) bytes, zero-padded to a multiple of 16: one 4-bit
+//                                     call code per base, first base in the high nibble
+//                                     (A=0x0 C=0x4 G=0x8 T=0xC, every other BAM base code = 0x2)
+//                              cigar  n_cigar * u32 -- omitted when the record is kRecSimple
 //                            coordinate-sorted input => the reads of a tile are one contiguous
-//                            byte range of `blob`, so a workgroup streams it with full lines.
+//                            byte range of `blob`.
 //   ref   [n_sites]   1 B    FASTA letters, contigs back to back
 //   tiles [n_tiles]   32 B   {contig, start, len, species, site_base}
 //   out counts [n_sites][4] u32 (A,C,G,T) ; out allele [n_sites] u8
+//
+// A pileup lane owns kChunk = 32 consecutive bases of a read: 32 quality bytes (two dwordx4) and 16
+// bytes of call codes (one dwordx4).  The zero padding makes the last chunk of a read self-masking:
+// a padded base has quality 0, which never reaches a threshold >= 1.
 //
 // Algorithmic bytes: ceil(l/2) + l + 4*n_cigar + 16 per read, 17 per site.
 #pragma once
@@ -33,14 +39,20 @@ struct ReadRec {            // 16 bytes, 16-byte aligned
 static_assert(sizeof(ReadRec) == 16, "ReadRec must be 16 bytes");
 
 constexpr uint16_t kNmAbsent = 0xFFFF;
-// Record flag bits.  They are decode-time facts about the record, set by the packer:
+// Record flag bits: decode-time facts about the record, set by the packer.
 constexpr uint8_t kRecQualAbsent = 1;   // qual[0] == 0xFF (BAM: QUAL missing)
 constexpr uint8_t kRecSimple = 2;       // CIGAR is exactly one M/=/X op of length l_seq: the walk is the identity
 constexpr uint8_t kRecClipGeneric = 4;  // clip structure needs the general H/S loops (an H among the clips, or
                                         // several S at one end); when clear: lead = (op0 == S), trail = (opLast == S)
+constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >= l_seq onto a site inside the
+                                        // contig: pysam would index past SEQ (IndexError) if the read is kept
 
-constexpr int kMaxLSeq = 1024;      // 64 lanes x 16 bases: one wave row per read at most
+constexpr int kChunk = 32;          // bases per lane
+constexpr int kMaxLSeq = 1024;      // at most 32 lanes per read
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
+
+// 4-bit call codes (pre-shifted: code & 0xC is the byte offset of the base's counter inside its site)
+constexpr uint8_t kCallA = 0x0, kCallC = 0x4, kCallG = 0x8, kCallT = 0xC, kCallOther = 0x2;
 
 struct Tile {               // 32 bytes
   int32_t contig;
@@ -53,13 +65,13 @@ struct Tile {               // 32 bytes
 };
 static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 
-// Offsets of the three payload sections inside a read's blob.
-__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return (l_seq + 3u) & ~3u; }
+// Offsets of the payload sections inside a read's blob.
+__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return (l_seq + 31u) & ~31u; }
 __host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq) {
-  return blob_seq_off(l_seq) + ((((l_seq + 1u) >> 1) + 3u) & ~3u);
+  return blob_seq_off(l_seq) + ((((l_seq + 1u) >> 1) + 15u) & ~15u);
 }
-__host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar) {
-  return (blob_cigar_off(l_seq) + 4u * n_cigar + 7u) & ~7u;
+__host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_stored) {
+  return (blob_cigar_off(l_seq) + 4u * n_cigar_stored + 7u) & ~7u;
 }
 
 // Error word written by the kernels: (read_index << 8) | kind, reduced with atomicMin.

@@ -38,14 +38,14 @@ void parallel_ranges(int64_t n, F&& fn) {
   for (auto& x : th) x.join();
 }
 
-// byte of two BAM base codes -> byte of two call codes
+// byte of two BAM base codes ("=ACMGRSVTWYHKDBN") -> byte of two call codes (layout.h)
 struct CallCodeTable {
   uint8_t v[256];
   constexpr CallCodeTable() : v() {
     for (int b = 0; b < 256; ++b) {
       const int hi = b >> 4, lo = b & 15;
-      const int ch = hi == 1 ? 0 : hi == 2 ? 1 : hi == 4 ? 2 : hi == 8 ? 3 : 8;
-      const int cl = lo == 1 ? 0 : lo == 2 ? 1 : lo == 4 ? 2 : lo == 8 ? 3 : 8;
+      const int ch = hi == 1 ? kCallA : hi == 2 ? kCallC : hi == 4 ? kCallG : hi == 8 ? kCallT : kCallOther;
+      const int cl = lo == 1 ? kCallA : lo == 2 ? kCallC : lo == 4 ? kCallG : lo == 8 ? kCallT : kCallOther;
       v[b] = (uint8_t)((ch << 4) | cl);
     }
   }
@@ -57,10 +57,50 @@ void set_err(char* err256, const char* fmt, long long a = 0, long long b = 0, lo
   if (err256) snprintf(err256, 256, fmt, a, b, c);
 }
 
+inline bool op_match(uint32_t op) { return op == 0u || op == 7u || op == 8u; }  // M = X
+inline bool op_clip(uint32_t op) { return op == 4u || op == 5u; }              // S H
+
+// Decode-time facts about one record's CIGAR (layout.h kRec* bits).  The walk itself runs on the device;
+// these only say which of its fast paths applies, plus the one condition (kRecOverrun) under which the
+// reference would raise IndexError for a kept read.
+uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, int64_t contig_len) {
+  if (nc == 1 && op_match(cg[0] & 15u) && (cg[0] >> 4) == l && l > 0) return kRecSimple;
+  uint8_t f = 0;
+  if (nc > 0) {
+    // leading clip run: maximal prefix of {S,H}; trailing: maximal suffix of {S,H} within indices >= 1
+    uint32_t lead = 0;
+    while (lead < nc && op_clip(cg[lead] & 15u)) ++lead;
+    uint32_t trail = 0;
+    while (trail + 1 < nc && op_clip(cg[nc - 1 - trail] & 15u)) ++trail;
+    const bool lead_plain = lead == 0 || (lead == 1 && (cg[0] & 15u) == 4u);
+    const bool trail_plain = trail == 0 || (trail == 1 && (cg[nc - 1] & 15u) == 4u);
+    if (!lead_plain || !trail_plain) f |= kRecClipGeneric;
+  }
+  int64_t qpos = 0, rpos = pos;
+  for (uint32_t k = 0; k < nc; ++k) {
+    const uint32_t op = cg[k] & 15u;
+    const int64_t len = cg[k] >> 4;
+    if (op_match(op)) {
+      if (qpos + len > (int64_t)l) {
+        const int64_t qs = std::max<int64_t>(qpos, l);
+        const int64_t rs = rpos + (qs - qpos), rend = rpos + len;
+        if (rs < contig_len && rend > 0) f |= kRecOverrun;
+      }
+      qpos += len;
+      rpos += len;
+    } else if (op == 1u || op == 4u) {
+      qpos += len;
+    } else if (op == 2u || op == 3u) {
+      rpos += len;
+    }
+  }
+  return f;
+}
+
 }  // namespace
 
-int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64_t blob_capacity,
-                   PackSummary* out, char* err256) {
+int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, ReadRec* rec, uint8_t* blob,
+                   int64_t blob_capacity, PackSummary* out, char* err256) {
   if (!r || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   const int64_t n = r->n_reads;
   *out = PackSummary{};
@@ -68,15 +108,15 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
     set_err(err256, "n_reads %lld out of range", (long long)n);
     return n < 0 ? MIDAS_SNPS_ERR_INVALID_ARG : MIDAS_SNPS_ERR_UNSUPPORTED;
   }
-  if (n == 0) return MIDAS_SNPS_OK;
-  if (!r->pos || !r->mapq || !r->nm || !r->l_seq || !r->seq_off || !r->qual_off || !r->cigar_off ||
-      !r->seq4 || !r->qual || !r->cigar) {
+  if (n > 0 && (!r->pos || !r->mapq || !r->nm || !r->l_seq || !r->seq_off || !r->qual_off || !r->cigar_off ||
+                !r->seq4 || !r->qual || !r->cigar)) {
     set_err(err256, "NULL array in midas_snps_reads");
     return MIDAS_SNPS_ERR_INVALID_ARG;
   }
 
-  // Pass 1: validate + per-read payload size.
+  // Pass 1: validate, classify the CIGAR, per-read payload size.
   std::vector<uint32_t> bytes(n);
+  std::vector<uint8_t> cflags(n);
   std::atomic<int32_t> status{MIDAS_SNPS_OK};
   std::atomic<long long> bad_read{-1};
   const int nt = hw_threads();
@@ -89,6 +129,12 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
   parallel_ranges(n, [&](int t, int64_t lo, int64_t hi) {
     int64_t a = 0;
     int32_t ml = 0;
+    int32_t c = 0;  // contig of read i (reads are grouped by contig)
+    if (contigs && contigs->n_contigs > 0) {
+      c = (int32_t)(std::upper_bound(contigs->read_begin, contigs->read_begin + contigs->n_contigs + 1, lo) -
+                    contigs->read_begin) - 1;
+      c = std::max(0, std::min(c, contigs->n_contigs - 1));
+    }
     for (int64_t i = lo; i < hi; ++i) {
       const int64_t l = r->l_seq[i];
       const int64_t nc = r->cigar_off[i + 1] - r->cigar_off[i];
@@ -103,7 +149,14 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
         fail(MIDAS_SNPS_ERR_UNSUPPORTED, i);
         return;
       }
-      bytes[i] = blob_bytes((uint32_t)l, (uint32_t)nc);
+      int64_t clen = INT64_MAX;
+      if (contigs && contigs->n_contigs > 0) {
+        while (c + 1 < contigs->n_contigs && i >= contigs->read_begin[c + 1]) ++c;
+        clen = contigs->length[c];
+      }
+      const uint8_t f = cigar_flags(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->pos[i], clen);
+      cflags[i] = f;
+      bytes[i] = blob_bytes((uint32_t)l, (f & kRecSimple) ? 0u : (uint32_t)nc);
       a += (l + 1) / 2 + l + 4 * nc + 16;
       ml = std::max<int32_t>(ml, (int32_t)l);
     }
@@ -135,7 +188,7 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
     return MIDAS_SNPS_ERR_INVALID_ARG;
   }
 
-  // Pass 2: offsets (serial prefix sum over chunk totals), then copy in parallel.
+  // Pass 2: offsets (serial prefix sum), then copy in parallel.
   std::vector<int64_t> off(n + 1);
   off[0] = 0;
   for (int64_t i = 0; i < n; ++i) off[i + 1] = off[i] + bytes[i];
@@ -148,14 +201,13 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
       memset(b, 0, bytes[i]);
       memcpy(b, q, l);
       {
-        // BAM 4-bit codes -> call codes (layout.h): A,C,G,T -> 0..3, anything else -> 8.  Still 4 bits per
-        // base, first base in the high nibble; the path only ever asks "is it exactly A/C/G/T, and which".
+        // BAM 4-bit base codes -> call codes; the zero padding decodes as 'A' but carries quality 0
         const uint8_t* s4 = r->seq4 + r->seq_off[i];
         uint8_t* d4 = b + blob_seq_off(l);
         const uint32_t nb = (l + 1) / 2;
         for (uint32_t k = 0; k < nb; ++k) d4[k] = kCallCodePair[s4[k]];
       }
-      memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
+      if (!(cflags[i] & kRecSimple)) memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
       ReadRec rr;
       rr.pos = r->pos[i];
       rr.blob_off8 = (uint32_t)(off[i] >> 3);
@@ -163,23 +215,7 @@ int32_t pack_reads(const midas_snps_reads* r, ReadRec* rec, uint8_t* blob, int64
       rr.n_cigar = (uint16_t)nc;
       rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
       rr.mapq = r->mapq[i];
-      rr.flags = (l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0;
-      // Decode-time facts about the CIGAR (fast-path hints; the walk itself runs on the device).
-      const uint32_t* cg = r->cigar + r->cigar_off[i];
-      auto opof = [&](uint32_t k) { return cg[k] & 15u; };
-      auto is_clip = [&](uint32_t k) { return opof(k) == 4u || opof(k) == 5u; };  // S, H
-      if (nc == 1 && (opof(0) == 0u || opof(0) == 7u || opof(0) == 8u) && (cg[0] >> 4) == l && l > 0) {
-        rr.flags |= kRecSimple;
-      } else if (nc > 0) {
-        // leading clip run: maximal prefix of {S,H}; trailing: maximal suffix of {S,H} within indices >= 1
-        uint32_t lead = 0;
-        while (lead < nc && is_clip(lead)) ++lead;
-        uint32_t trail = 0;
-        while (trail + 1 < nc && is_clip(nc - 1 - trail)) ++trail;
-        const bool lead_plain = lead == 0 || (lead == 1 && opof(0) == 4u);
-        const bool trail_plain = trail == 0 || (trail == 1 && opof(nc - 1) == 4u);
-        if (!lead_plain || !trail_plain) rr.flags |= kRecClipGeneric;
-      }
+      rr.flags = (uint8_t)(cflags[i] | ((l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0));
       rec[i] = rr;
     }
   });

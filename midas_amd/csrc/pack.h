@@ -10,9 +10,11 @@ struct PackSummary {
   int32_t max_l_seq = 0;
 };
 
-// rec == blob == nullptr: size query only.
-int32_t pack_reads(const midas_snps_reads* reads, ReadRec* rec, uint8_t* blob, int64_t blob_capacity,
-                   PackSummary* out, char* err256);
+// rec == blob == nullptr: size query only.  rec must hold n_reads + 1 records (sentinel).
+// `contigs` (may be nullptr) supplies the contig lengths the kRecOverrun flag is defined against;
+// without it every contig is taken as unbounded.
+int32_t pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, ReadRec* rec, uint8_t* blob,
+                   int64_t blob_capacity, PackSummary* out, char* err256);
 
 int32_t validate_contigs(const midas_snps_contigs* contigs, int64_t n_reads, int64_t* out_sites,
                          char* err256);

@@ -9,21 +9,22 @@
 //   index_bam                       midas/run/snps.py:130-137 (here: per-tile read ranges, built on device)
 //
 // Work decomposition.  The site space is cut into tiles of 4096 sites that never span contigs.  One
-// 512-thread workgroup owns a tile: its A/C/G/T tallies live in LDS as four skewed planes, reads are
-// streamed straight from the packed HBM arrays through a two-deep register prefetch pipeline, tallies
-// are LDS atomics, and the tile is written out once, 16 B per site, fully coalesced, with the
-// per-species counters reduced by wave shuffles on the way out.
+// 512-thread workgroup owns a tile: its tallies live in LDS as [site][A,C,G,T] u32, reads are streamed
+// straight from the packed HBM arrays through a two-deep register prefetch pipeline, tallies are LDS
+// atomics, and the tile is written out once, 16 B per site, fully coalesced, with the per-species
+// counters reduced by wave shuffles on the way out.
 //
-// Lane mapping.  A lane owns 16 consecutive bases of one read: one 16-byte load of quals and one
-// 8-byte load of packed bases.  A read of l_seq bases occupies ceil(l_seq/16) adjacent lanes (10 for
-// 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
+// Lane mapping.  A lane owns kChunk = 32 consecutive bases of one read: two 16-byte loads of quals and
+// one 16-byte load of 4-bit call codes.  A read of l_seq bases occupies ceil(l_seq/32) adjacent lanes
+// (5 for 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
 // floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
 // read: a segmented shuffle reduction over the read's lanes gives it without re-reading anything.
 //
-// LDS planes.  plane p, site i  ->  word p*TP + i + (i >> 4), TP = TILE + TILE/16.  The lanes of one
-// read touch sites 16 apart in the same instruction; the skew spreads them over 17-apart words, i.e.
-// distinct banks.  Bases that must not count (low quality, N/IUPAC, outside the CIGAR segment or the
-// tile) are not branched around: they add into a per-lane dump word, so every ds_add is unconditional.
+// The kernel is VALU-issue bound, not HBM bound, until the per-base instruction count is tiny, so the
+// per-base work is arranged as: (1) SWAR, four bases per instruction -- everything that decides
+// WHETHER a base counts (not A/C/G/T, read tail, CIGAR segment, tile edge) is folded into the
+// quality byte itself (a base that must not count gets quality 0); (2) per base -- one byte compare
+// against baseq, one OR that forms the LDS address (site << 4 | call code), one predicated ds_add.
 #include "kernels.h"
 
 namespace midas {
@@ -42,7 +43,6 @@ enum : uint32_t {
 
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ bool consumes_both(uint32_t op) { return op == OP_M || op == OP_EQ || op == OP_X; }
 
@@ -116,23 +116,20 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
   }
 }
 
-// Byte mask with bytes [lo, hi) of a 32-bit word set (lo, hi are clamped into 0..4 here).
-__device__ __forceinline__ uint32_t byte_range_mask(int lo, int hi) {
-  const uint32_t below_hi = hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
-  const uint32_t below_lo = lo >= 4 ? 0xFFFFFFFFu : (lo <= 0 ? 0u : ((1u << (8 * lo)) - 1u));
-  return below_hi & ~below_lo;
+// Byte mask with bytes [0, hi) of a 32-bit word set.
+__device__ __forceinline__ uint32_t low_bytes_mask(int hi) {
+  return hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
+}
+// Four mask bits (bit k <-> byte k) -> 0xFF / 0x00 bytes.
+__device__ __forceinline__ uint32_t bits_to_bytes(uint32_t nib) {
+  const uint32_t b = (nib * 0x00204081u) & 0x01010101u;   // bit k -> bit 8k
+  return (b << 8) - b;                                      // 0x01 -> 0xFF in every byte (mod 2^32)
 }
 
-// ------------------------------------------------------------------------------------------------
-// Pileup kernel.  LDS tallies are [site][A,C,G,T] u32 (16 B per site), so the address of a tally is
-// (site << 4) | (call_code << 2): one OR per base.  Everything that decides WHETHER a base counts
-// (quality threshold, not-ACGT, tail of the read, CIGAR segment, tile edge) is folded, four bases per
-// instruction, into the quality byte itself (a base that must not count gets quality 0), so the
-// per-base work in the hot loop is one byte compare, one OR and one predicated ds_add.
-// ------------------------------------------------------------------------------------------------
 template <int TILE_SHIFT>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
   constexpr int TILE = 1 << TILE_SHIFT;
+  constexpr int NW = kChunk / 4;   // quality words per lane
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ int32_t s_min_match[kMaxLSeq + 1];
   __shared__ int32_t s_min_align[kMaxLSeq + 1];
@@ -173,13 +170,14 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   const int g = lane / lpr;
   const int c = lane - g * lpr;
   const bool lane_used = g < rpw;
-  const int q0 = c * 16;
+  const int q0 = c * kChunk;
   const int stride = (kPileupBlock / 64) * rpw;
   const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
   const int tile_len = tile.len;
   const int tile_start = tile.start;
   const int bq = p.baseq < 1 ? 1 : p.baseq;   // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
   const bool count_all = p.baseq < 1;
+  char* const lds_bytes = reinterpret_cast<char*>(lds);
   uint32_t w_aligned = 0, w_mapped = 0;
 
   // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead -------------
@@ -190,8 +188,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     return v;
   };
   struct Payload {
-    uint32_t qw[4];
-    uint32_t sw[2];
+    uint32_t qw[NW];  // 32 quality bytes (zero beyond the end of the read: the blob is padded)
+    uint32_t sw[4];   // 32 call codes
     uint32_t cg[4];   // first four CIGAR ops (non-simple reads only)
     uint32_t cl;      // last CIGAR op
   };
@@ -201,15 +199,18 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int l = rec_l(rv);
     const int n = rec_n(rv);
     const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
-    d.qw[0] = d.qw[1] = d.qw[2] = d.qw[3] = 0u;
-    d.sw[0] = d.sw[1] = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d.qw[w] = 0u;
+    d.sw[0] = d.sw[1] = d.sw[2] = d.sw[3] = 0u;
     d.cg[0] = d.cg[1] = d.cg[2] = d.cg[3] = 0u;
     d.cl = 0u;
     if (act && q0 < l) {
-      const u32x4_a8 qv = *reinterpret_cast<const u32x4_a8*>(bp + q0);
-      const u32x2_a4 sv = *reinterpret_cast<const u32x2_a4*>(bp + blob_seq_off((uint32_t)l) + (q0 >> 1));
-      d.qw[0] = qv.x; d.qw[1] = qv.y; d.qw[2] = qv.z; d.qw[3] = qv.w;
-      d.sw[0] = sv.x; d.sw[1] = sv.y;
+      const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + q0);
+      const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + q0 + 16);
+      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l) + (q0 >> 1));
+      d.qw[0] = qa.x; d.qw[1] = qa.y; d.qw[2] = qa.z; d.qw[3] = qa.w;
+      d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
+      d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
     if (act && !(rec_flags(rv) & kRecSimple) && n > 0) {
       const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
@@ -242,15 +243,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     int cpos = pos < 0 ? 0 : pos;
     cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
     const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+    // position of the read relative to the tile; a read that can never reach the tile is parked far right
+    // (reference positions only grow along a CIGAR, so "far right" stays far right)
+    const long long rel64 = (long long)pos - (long long)tile_start;
+    int rrel = (rel64 > (1LL << 25) || rel64 < -(1LL << 30)) ? (1 << 25) : (int)rel64;
     // reads that start in an earlier tile and provably end before this one: nothing to do here
-    if (act && !owner && n == 1 && (long long)pos + l <= (long long)tile_start) act = false;
+    if (act && !owner && n == 1 && rrel + l <= 0) act = false;
     const bool has = act && q0 < l;
-    const uint8_t* bp = p.blob + (size_t)rec_off8(rec_cur) * 8;
-    const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
 
     // ---- soft-clip trimming ([EXT] pysam getQueryStart / getQueryEnd) -----------------------------
     int k0 = 0, lead_s = 0, trail_s = 0;
+    const uint32_t* cig = nullptr;
     if (act && !simple) {
+      cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l));
       if (!(flags & kRecClipGeneric)) {
         if (n > 0 && (cur.cg[0] & 15u) == OP_S) { lead_s = (int)(cur.cg[0] >> 4); k0 = 1; }
         if (n > 1 && (cur.cl & 15u) == OP_S) trail_s = (int)(cur.cl >> 4);
@@ -277,21 +282,15 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int min_align = s_min_align[l < p.table_len ? l : 0];
 
     // ---- quality sum of the whole read: per-lane partial, then a segmented reduction ------------
-    const int nvalid = has ? (l - q0 < 16 ? l - q0 : 16) : 0;
-    uint32_t qm[4];      // quality bytes of the chunk, zero beyond the end of the read
-    int part = 0;
+    const int nvalid = has ? (l - q0 < kChunk ? l - q0 : kChunk) : 0;
+    uint32_t part = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t m = byte_range_mask(0, nvalid - 4 * w);
-      qm[w] = cur.qw[w] & m;
-      part = (int)__builtin_amdgcn_sad_u8(qm[w], 0u, (uint32_t)part);
-      if (count_all) qm[w] = m;
-    }
+    for (int w = 0; w < NW; ++w) part = __builtin_amdgcn_sad_u8(cur.qw[w], 0u, part);
     for (int d = 1; d < lpr; d <<= 1) {
-      const int o = __shfl_down(part, d);
+      const uint32_t o = __shfl_down(part, d);
       if (c + d < lpr) part += o;
     }
-    const int qsum = __shfl(part, lane - c);
+    const int qsum = (int)__shfl(part, lane - c);
 
     // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ------------------------
     bool keep = false;
@@ -306,33 +305,36 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       else if ((long long)qsum < (long long)p.readq * (long long)l) keep = false;
       else if (rec_mapq(rec_cur) < p.mapq) keep = false;
       else if (align_len < min_align) keep = false;                                     // aln_cov
+      else if (flags & kRecOverrun) err = E_CIGAR_OVERRUN;   // kept, and its CIGAR reaches past SEQ inside the contig
       else keep = true;
     }
 
     // ---- per-base call codes and validity, four bases per instruction ------------------------------
-    uint32_t qv[4];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
-    uint32_t cd[4];   // byte offset of the base's counter inside its site: call code * 4
+    uint32_t qv[NW];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
+    uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
     bool walking = keep && has;
     if (walking) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));        // seq bytes 2w, 2w+1: bases 4w .. 4w+3
-        const uint32_t t4 = __builtin_amdgcn_perm(0u, x16, 0x01010000u);   // [b0, b0, b1, b1]
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));               // call bytes 2w, 2w+1: bases 4w .. 4w+3
+        const uint32_t t4 = __builtin_amdgcn_perm(0u, x16, 0x01010000u);     // [b0, b0, b1, b1]
         const uint32_t nib = ((t4 >> 4) & 0x000F000Fu) | (t4 & 0x0F000F00u);  // one call code per byte
-        const uint32_t inv = nib & 0x08080808u;                       // not A/C/G/T
-        const uint32_t inv_ff = (inv << 5) - (inv >> 3);              // 0xFF in every such byte
-        qv[w] = qm[w] & ~inv_ff;
-        cd[w] = (nib & 0x03030303u) << 2;
+        const uint32_t inv = nib & 0x02020202u;                              // not A/C/G/T
+        const uint32_t inv_ff = (inv << 7) - (inv >> 1);                     // 0xFF in every such byte
+        const uint32_t q = count_all ? low_bytes_mask(nvalid - 4 * w) : cur.qw[w];
+        qv[w] = q & ~inv_ff;
+        cd[w] = nib & 0x0C0C0C0Cu;
       }
     } else {
-      qv[0] = qv[1] = qv[2] = qv[3] = 0u;
-      cd[0] = cd[1] = cd[2] = cd[3] = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { qv[w] = 0u; cd[w] = 0u; }
     }
 
     // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -------
+    // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative
+    // reference position only below 4096, and both only ever grow.
     int k = k0;
-    long long qpos = lead_s;
-    long long rpos = pos;
+    int qpos = lead_s;
     const int q1 = q0 + nvalid;
     int jlo = 0, jhi = 0, loc0 = 0;
     auto next_segment = [&]() -> bool {
@@ -340,60 +342,48 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         const uint32_t v = k < 4 ? (k == 0 ? cur.cg[0] : (k == 1 ? cur.cg[1] : (k == 2 ? cur.cg[2] : cur.cg[3]))) : cig[k];
         ++k;
         const uint32_t op = v & 15u;
-        const long long len = (long long)(v >> 4);
-        if (consumes_both(op)) {
-          const long long lo = qpos > q0 ? qpos : q0;
-          const long long hi = (qpos + len) < q1 ? (qpos + len) : q1;
-          const bool found = lo < hi;
-          if (found) {
-            long long x = rpos + ((long long)q0 - qpos) - (long long)tile_start;
-            x = x < -(1LL << 24) ? -(1LL << 24) : (x > (1LL << 24) ? (1LL << 24) : x);
-            jlo = (int)(lo - q0);
-            jhi = (int)(hi - q0);
-            loc0 = (int)x;
-          }
-          if (qpos + len > l) {
-            // query positions >= l_seq: pysam indexes past the end iff their refpos is inside the contig
-            const long long qs = qpos > l ? qpos : l;
-            const long long rs = rpos + (qs - qpos), rend = rpos + len;
-            if (rs < (long long)tile.contig_len && rend > 0) err = E_CIGAR_OVERRUN;
-          }
-          qpos += len;
-          rpos += len;
-          if (found) return true;
-        } else if (op == OP_I || op == OP_S) {
-          qpos += len;
-        } else if (op == OP_D || op == OP_N) {
-          rpos += len;
-        }  // H, P and anything else: no effect
+        const int len = (int)(v >> 4);
+        const bool m = consumes_both(op);
+        bool found = false;
+        if (m) {
+          const int lo = qpos > q0 ? qpos : q0;
+          const int hi = (qpos + len) < q1 ? (qpos + len) : q1;
+          found = lo < hi;
+          if (found) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + (q0 - qpos); }
+        }
+        if (m || op == OP_I || op == OP_S) { qpos += len; qpos = qpos > (1 << 29) ? (1 << 29) : qpos; }
+        if (m || op == OP_D || op == OP_N) { rrel += len; rrel = rrel > (1 << 29) ? (1 << 29) : rrel; }
+        if (found) return true;   // H, P and anything else: no effect
       }
       return false;
     };
     if (walking) {
       if (simple) {
-        long long x = (long long)pos + q0 - (long long)tile_start;
-        x = x < -(1LL << 24) ? -(1LL << 24) : (x > (1LL << 24) ? (1LL << 24) : x);
-        jlo = 0; jhi = nvalid; loc0 = (int)x; k = n;
+        jlo = 0; jhi = nvalid; loc0 = rrel + q0; k = n;
       } else {
         walking = next_segment();
       }
     }
     while (walking) {
       // bases of the chunk that belong to this segment AND lie inside the tile: [lo, hi)
-      uint32_t q4[4] = {qv[0], qv[1], qv[2], qv[3]};
+      uint32_t q4[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) q4[w] = qv[w];
       const int lo = jlo > -loc0 ? jlo : -loc0;
       const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
-      if (lo > 0 || hi < nvalid) {    // partial chunk (segment border or tile edge): mask the bytes outside
+      if (lo > 0 || hi < nvalid) {    // partial chunk (segment border or tile edge): zero the bytes outside
+        const uint32_t below_hi = hi >= 32 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+        const uint32_t below_lo = lo >= 32 ? 0xFFFFFFFFu : (lo <= 0 ? 0u : ((1u << lo) - 1u));
+        const uint32_t jm = below_hi & ~below_lo;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) q4[w] &= byte_range_mask(lo - 4 * w, hi - 4 * w);
+        for (int w = 0; w < NW; ++w) q4[w] &= bits_to_bytes((jm >> (4 * w)) & 0xFu);
       }
       const uint32_t abase = (uint32_t)loc0 << 4;
-      char* const lds_bytes = reinterpret_cast<char*>(lds);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int q = (int)((q4[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+      for (int j = 0; j < kChunk; ++j) {
+        const uint32_t q = (q4[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
         const uint32_t code = (cd[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-        if (q >= bq) atomicAdd(reinterpret_cast<uint32_t*>(lds_bytes + ((abase | code) + 16u * j)), 1u);
+        if (q >= (uint32_t)bq) atomicAdd(reinterpret_cast<uint32_t*>(lds_bytes + ((abase | code) + 16u * j)), 1u);
       }
       walking = (k < n) ? next_segment() : false;
     }

@@ -212,10 +212,10 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
   return MIDAS_SNPS_OK;
 }
 
-int32_t midas_snps_pack_reads(const midas_snps_reads* reads, void* rec16, void* blob, int64_t blob_capacity,
+int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob, int64_t blob_capacity,
                               int64_t* out_blob_bytes, int32_t* out_max_l_seq, char* err256) {
   PackSummary s;
-  int32_t st = pack_reads(reads, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
+  int32_t st = pack_reads(reads, contigs, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
                           blob_capacity, &s, err256);
   if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
   if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
@@ -253,7 +253,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   PackSummary ps;
-  st = pack_reads(reads, nullptr, nullptr, 0, &ps, ebuf);
+  st = pack_reads(reads, contigs, nullptr, nullptr, 0, &ps, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -266,7 +266,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   b->n_species = contigs->n_species;
   b->blob_bytes = ps.blob_bytes;
   b->alg_bytes = ps.read_algorithmic_bytes + 17 * n_sites;
-  b->lanes_per_read = ps.max_l_seq <= 16 ? 1 : (ps.max_l_seq + 15) / 16;
+  b->lanes_per_read = ps.max_l_seq <= kChunk ? 1 : (ps.max_l_seq + kChunk - 1) / kChunk;
 
 #define B_TRY(call)                              \
   do {                                           \
@@ -322,7 +322,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       return s;
     }
     memset(h_blob + ps.blob_bytes, 0, 64);
-    st = pack_reads(reads, h_rec, h_blob, (int64_t)blob_alloc, &ps, ebuf);
+    st = pack_reads(reads, contigs, h_rec, h_blob, (int64_t)blob_alloc, &ps, ebuf);
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
     if (st == MIDAS_SNPS_OK) {
       e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);

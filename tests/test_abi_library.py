@@ -70,6 +70,21 @@ def test_product_never_imports_the_oracle():
 
 # ---- the host packer (runs without a GPU) -----------------------------------------------------
 
+CALL = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
+
+
+def call_codes(seq):
+    """Expected device call-code bytes (layout.h): 4 bits per base, first base in the high nibble."""
+    codes = [CALL.get(ch, 0x2) for ch in seq.upper()]
+    if len(codes) & 1:
+        codes.append(0x2)      # BAM pads SEQ with code 0 ('='), which is "not A/C/G/T"
+    return bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+
+
+REC_DTYPE = np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
+                      ("mapq", "u1"), ("flags", "u1")])
+
+
 def test_pack_layout_matches_design():
     reads = H.reads_from_dicts([
         dict(pos=7, cigar="3S7M", seq="TTTACGTACG", qual=list(range(10)), nm=1, mapq=33, flag=16),
@@ -78,19 +93,29 @@ def test_pack_layout_matches_design():
     ])
     rec, blob, maxl = abi.pack_reads(reads)
     assert maxl == 10 and rec.shape == (3, 16)
-    r = rec.view(np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
-                           ("mapq", "u1"), ("flags", "u1")])).reshape(3)
+    r = rec.view(REC_DTYPE).reshape(3)
     assert r["pos"].tolist() == [7, 9, 11] and r["l"].tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
-    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42] 
-    # flags: bit0 QUAL absent, bit1 "simple" (one M/=/X op spanning l_seq), bit2 generic clip structure
+    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42]
+    # flags: bit0 QUAL absent, bit1 "simple" (one M/=/X op spanning l_seq), bit2 generic clips, bit3 overrun
     assert r["flags"].tolist() == [0, 2, 3]
-    # read 0: qual 10 -> pad 12 | seq 5 -> pad 8 | cigar 8 -> 28 -> pad 32
-    assert r["off8"].tolist() == [0, 4, 6]   # read 1: 5->8 | 3->4 | 4 = 16 bytes
-    b0 = blob[:32]
-    assert b0[:10].tolist() == list(range(10))
-    assert bytes(b0[12:17]) == bytes(H.encode_seq4("TTTACGTACG"))
-    assert b0[20:28].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
-    assert blob.size == 32 + 16 + 16
+    # read 0: qual 10 -> 32 | calls 5 -> 16 | cigar 8            = 56 bytes
+    # read 1: qual  5 -> 32 | calls 3 -> 16 | (simple: no cigar) = 48 bytes; read 2 likewise
+    assert r["off8"].tolist() == [0, 7, 13]
+    b0 = blob[:56]
+    assert b0[:10].tolist() == list(range(10)) and not b0[10:32].any()
+    assert bytes(b0[32:37]) == call_codes("TTTACGTACG") and not b0[37:48].any()
+    assert b0[48:56].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
+    assert bytes(blob[56 + 32:56 + 35]) == call_codes("ACGTN")
+    assert blob.size == 56 + 48 + 48
+
+
+def test_pack_overrun_flag_needs_the_contig_length():
+    reads = H.reads_from_dicts([dict(pos=0, cigar="12M", seq="ACGTACGTAC"),      # query 10..11 -> sites 10..11
+                                dict(pos=15, cigar="12M", seq="ACGTACGTAC")])    # query 10..11 -> sites 25..26
+    rec, _, _ = abi.pack_reads(reads, H.single_contig(20, 2))
+    assert (rec[:, 15] & 8).tolist() == [8, 0]      # the second read overruns only beyond the contig end
+    rec, _, _ = abi.pack_reads(reads, None)
+    assert (rec[:, 15] & 8).tolist() == [8, 8]
 
 
 def test_pack_cigar_fast_path_flags():
@@ -120,14 +145,17 @@ def test_pack_rejects_malformed_input_with_status():
 def test_pack_round_trips_synthetic_reads():
     contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=9000, n_reads=3000,
                                         seed=5, var_len=True)
-    rec, blob, maxl = abi.pack_reads(reads)
-    r = rec.view(np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
-                           ("mapq", "u1"), ("flags", "u1")])).reshape(-1)
+    rec, blob, maxl = abi.pack_reads(reads, contigs)
+    r = rec.view(REC_DTYPE).reshape(-1)
     np.testing.assert_array_equal(r["pos"], reads.pos)
     np.testing.assert_array_equal(r["l"], reads.l_seq)
     for i in (0, 17, 1234, reads.n_reads - 1):
         l = int(reads.l_seq[i])
         o = int(r["off8"][i]) * 8
         np.testing.assert_array_equal(blob[o:o + l], reads.qual[reads.qual_off[i]:reads.qual_off[i] + l])
-        so = o + ((l + 3) & ~3)
-        np.testing.assert_array_equal(blob[so:so + (l + 1) // 2], reads.seq4[reads.seq_off[i]:reads.seq_off[i] + (l + 1) // 2])
+        assert not blob[o + l:o + ((l + 31) & ~31)].any()            # zero padding = self-masking read tail
+        so = o + ((l + 31) & ~31)
+        nt16 = "=ACMGRSVTWYHKDBN"
+        s4 = reads.seq4[reads.seq_off[i]:reads.seq_off[i] + (l + 1) // 2]
+        seq = "".join(nt16[b >> 4] + nt16[b & 15] for b in s4)[:l]
+        assert bytes(blob[so:so + (l + 1) // 2]) == call_codes(seq)
