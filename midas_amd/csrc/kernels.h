@@ -7,9 +7,9 @@
 
 namespace midas {
 
-constexpr int kTileShift = 12;             // 4096 sites per tile
+constexpr int kTileShift = 12;             // 4096 sites per tile: 64 KiB of LDS tallies, 2 workgroups per CU
 constexpr int kTileSites = 1 << kTileShift;
-constexpr int kPileupBlock = 512;          // 8 waves; 2 workgroups per CU (LDS-limited)
+constexpr int kPileupBlock = 512;          // 8 waves
 constexpr int kIndexBlock = 256;
 
 // Per-species counters, same order as MIDAS_SNPS_STAT_* in include/midas_snps.h.

@@ -131,10 +131,9 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   constexpr int TILE = 1 << TILE_SHIFT;
   constexpr int NW = kChunk / 4;   // quality words per lane
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
-  __shared__ int32_t s_min_match[kMaxLSeq + 1];
-  __shared__ int32_t s_min_align[kMaxLSeq + 1];
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ int32_t s_range[2];
+  extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   // Consecutive tiles share their straddling reads: keep neighbours on one XCD (block b runs on XCD b % 8).
   const int t = (int)(blockIdx.x & 7u) * p.tiles_per_xcd + (int)(blockIdx.x >> 3);
@@ -148,8 +147,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     uint4* z = reinterpret_cast<uint4*>(lds);
     for (int i = tid; i < TILE; i += kPileupBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < p.table_len; i += kPileupBlock) {
-      s_min_match[i] = p.filt->min_match[i];
-      s_min_align[i] = p.filt->min_align[i];
+      s_tables[i] = p.filt->min_match[i];
+      s_tables[p.table_len + i] = p.filt->min_align[i];
     }
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
     if (tid == 0) {
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
       const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
       d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
-      d.cl = n <= 4 ? (n == 1 ? cv.x : (n == 2 ? cv.y : (n == 3 ? cv.z : cv.w))) : cig[n - 1];
+      if (n > 4) d.cl = cig[n - 1];   // n <= 4: the last op is one of cg[0..3]; picked at use, never here (a use would drain the prefetch)
     }
   };
 
@@ -258,7 +257,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l));
       if (!(flags & kRecClipGeneric)) {
         if (n > 0 && (cur.cg[0] & 15u) == OP_S) { lead_s = (int)(cur.cg[0] >> 4); k0 = 1; }
-        if (n > 1 && (cur.cl & 15u) == OP_S) trail_s = (int)(cur.cl >> 4);
+        const uint32_t last = n > 4 ? cur.cl : (n == 2 ? cur.cg[1] : (n == 3 ? cur.cg[2] : cur.cg[3]));
+        if (n > 1 && (last & 15u) == OP_S) trail_s = (int)(last >> 4);
       } else {
         while (k0 < n) {
           const uint32_t v = cig[k0];
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     int align_len = (l - trail_s) - lead_s;
     align_len = align_len < 0 ? 0 : align_len;
     // exact integer form of the two fp64 ratio tests (tables built by the host with the reference's expressions)
-    const int min_match = s_min_match[align_len < p.table_len ? align_len : 0];
-    const int min_align = s_min_align[l < p.table_len ? l : 0];
+    const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+    const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
 
     // ---- quality sum of the whole read: per-lane partial, then a segmented reduction ------------
     const int nvalid = has ? (l - q0 < kChunk ? l - q0 : kChunk) : 0;
@@ -447,7 +447,8 @@ hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream) {
 hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
   const int grid = p.tiles_per_xcd * 8;
-  hipLaunchKernelGGL(pileup_tiles_kernel<kTileShift>, dim3(grid), dim3(kPileupBlock), 0, stream, p);
+  const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
+  hipLaunchKernelGGL(pileup_tiles_kernel<kTileShift>, dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
   return hipGetLastError();
 }
 
