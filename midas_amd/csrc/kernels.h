@@ -27,11 +27,15 @@ struct IndexParams {
   const int32_t* contig_len;         // [n_contigs]
   uint32_t* rbinv;                   // [n_tiles]  max over overlapping reads of (n_reads - index); 0 = none
   uint32_t* rend;                    // [n_tiles]  max over overlapping reads of (index + 1)
+  uint32_t* rbinv_next;              // the other parity's ranges: zeroed here for the next run
+  uint32_t* rend_next;
+  int32_t n_tiles;
   unsigned long long* stats;         // [n_species][4]  zeroed here, accumulated by the pileup kernel
   unsigned long long* err;           // set to kNoError here
   int32_t n_reads;
   int32_t n_contigs;
   int32_t n_stat_words;              // n_species * 4
+  int32_t tile_len;                  // sites per tile of this batch (<= kTileSites)
 };
 
 // keep_read's two ratio tests as exact integer thresholds, built on the host per threshold set
@@ -48,8 +52,8 @@ struct PileupParams {
   const uint8_t* blob;
   const uint8_t* ref;
   const Tile* tiles;
-  uint32_t* rbinv;                   // consumed and reset to 0 by the tile's workgroup
-  uint32_t* rend;
+  const uint32_t* rbinv;             // this run's parity, read-only here
+  const uint32_t* rend;
   const FilterTables* filt;
   uint32_t* out_counts;              // [n_sites][4]
   uint8_t* out_allele;               // [n_sites] or nullptr
@@ -57,11 +61,12 @@ struct PileupParams {
   unsigned long long* err;           // one word, atomicMin((read << 8) | kind)
   int32_t n_tiles;
   int32_t n_reads;
-  int32_t tiles_per_xcd;
+  int32_t grid_blocks;               // persistent workgroups: 2 per CU
   int32_t lanes_per_read;            // ceil(max_l_seq / 16)
   int32_t reads_per_wave;            // 64 / lanes_per_read
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
+  int32_t debug;                     // developer ablation switches (MIDAS_SNPS_DEBUG), 0 in production
 };
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);

@@ -1,0 +1,463 @@
+// gfx950 (CDNA4) pileup kernel of the MIDAS SNP path.  Integer counting: no MFMA.
+//
+// Reference semantics implemented here (citations into /root/reference):
+//   keep_read                       midas/run/snps.py:141-162
+//   count_coverage call site        midas/run/snps.py:194-199  ([EXT] pysam: get_aligned_pairs(matches_only),
+//                                   qual >= quality_threshold, only 'A','C','G','T' counted)
+//   depth / covered / total_depth   midas/run/snps.py:204-213
+//   str(rec.seq).upper()            midas/run/snps.py:62
+//
+// Work decomposition.  The site space is cut into tiles of <= 4096 sites that never span contigs.  A
+// persistent 512-thread workgroup walks tiles blockIdx, blockIdx + grid, ...; a tile's tallies live in
+// LDS as [site][A,C,G,T] u32, reads are streamed straight from the packed HBM arrays through a
+// two-deep register prefetch pipeline, tallies are LDS atomics, and the tile is written out once,
+// 16 B per site, fully coalesced.  The loads of the NEXT tile are issued before the write-out of the
+// current one and the read-out re-zeroes LDS as it goes, so the memory-bound edges of a tile overlap
+// the compute-bound middle of its neighbours instead of every workgroup marching through
+// load -> compute -> store in lockstep (measured: those three phases used to simply add up).
+//
+// Lane mapping.  A lane owns kChunk = 32 consecutive bases of one read: two 16-byte loads of quals and
+// one 16-byte load of 4-bit call codes.  A read of l_seq bases occupies ceil(l_seq/32) adjacent lanes
+// (5 for 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
+// floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
+// read: a segmented shuffle reduction over the read's lanes gives it without re-reading anything.
+//
+// Instruction diet.  The loop is VALU-issue bound long before it is HBM bound, so the per-base work is
+// arranged as: (1) SWAR, four bases per instruction -- everything that decides WHETHER a base counts
+// (not A/C/G/T, read tail, CIGAR segment, tile edge) is folded into the quality byte itself (a base that
+// must not count gets quality 0); (2) per base -- one byte compare against baseq, one OR that forms the
+// LDS address (site << 4 | call code), one predicated returnless ds_add.
+#include "device_common.h"
+
+namespace midas {
+
+using namespace dev;
+
+namespace {
+
+// One base of the hot loop, hand-scheduled: byte compare (SDWA) -> exec mask -> address OR (SDWA) ->
+// returnless LDS atomic -> exec restore.  Written as asm because the compiler wraps every predicated
+// ds_add in an s_cbranch_execz skip branch (11.7 M branches per launch on the 1 M-read workload).
+//   q4/cd4: four quality / call-code bytes, BYTE selects the base; abase: LDS byte address of the chunk's
+//   first site (multiple of 16, so OR-ing the call code 0/4/8/12 selects the counter); OFF = 16 * j.
+template <int BYTE, int OFF>
+__device__ __forceinline__ void tally_base(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
+  uint32_t tmp;
+  unsigned long long save;
+#define MIDAS_TALLY_ASM(B)                                                                                   \
+  asm volatile("v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                        \
+               "s_and_saveexec_b64 %1, vcc\n\t"                                                               \
+               "v_or_b32_sdwa %0, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B \
+               "\n\t"                                                                                         \
+               "ds_add_u32 %0, %6 offset:%7\n\t"                                                              \
+               "s_mov_b64 exec, %1"                                                                           \
+               : "=&v"(tmp), "=&s"(save)                                                                      \
+               : "v"(q4), "s"(bq), "v"(cd4), "v"(abase), "v"(one), "n"(OFF)                                   \
+               : "vcc", "memory")
+  if constexpr (BYTE == 0) MIDAS_TALLY_ASM(0);
+  else if constexpr (BYTE == 1) MIDAS_TALLY_ASM(1);
+  else if constexpr (BYTE == 2) MIDAS_TALLY_ASM(2);
+  else MIDAS_TALLY_ASM(3);
+#undef MIDAS_TALLY_ASM
+}
+template <int W>
+__device__ __forceinline__ void tally_word(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
+  tally_base<0, 64 * W + 0>(q4, cd4, bq, abase, one);
+  tally_base<1, 64 * W + 16>(q4, cd4, bq, abase, one);
+  tally_base<2, 64 * W + 32>(q4, cd4, bq, abase, one);
+  tally_base<3, 64 * W + 48>(q4, cd4, bq, abase, one);
+}
+__device__ __forceinline__ void tally_chunk(const uint32_t (&q4)[kChunk / 4], const uint32_t (&cd)[kChunk / 4], uint32_t bq,
+                                            uint32_t abase, uint32_t one) {
+  static_assert(kChunk == 32, "tally_chunk is written for 8 words");
+  tally_word<0>(q4[0], cd[0], bq, abase, one);
+  tally_word<1>(q4[1], cd[1], bq, abase, one);
+  tally_word<2>(q4[2], cd[2], bq, abase, one);
+  tally_word<3>(q4[3], cd[3], bq, abase, one);
+  tally_word<4>(q4[4], cd[4], bq, abase, one);
+  tally_word<5>(q4[5], cd[5], bq, abase, one);
+  tally_word<6>(q4[6], cd[6], bq, abase, one);
+  tally_word<7>(q4[7], cd[7], bq, abase, one);
+}
+
+// Byte mask with bytes [0, hi) of a 32-bit word set.
+__device__ __forceinline__ uint32_t low_bytes_mask(int hi) {
+  return hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
+}
+// Four mask bits (bit k <-> byte k) -> 0xFF / 0x00 bytes.
+__device__ __forceinline__ uint32_t bits_to_bytes(uint32_t nib) {
+  const uint32_t b = (nib * 0x00204081u) & 0x01010101u;   // bit k -> bit 8k
+  return (b << 8) - b;                                      // 0x01 -> 0xFF in every byte (mod 2^32)
+}
+// str.upper() on four ASCII letters at once: bytes in 'a'..'z' lose bit 5, everything else is untouched.
+__device__ __forceinline__ uint32_t upper4(uint32_t x) {
+  const uint32_t t = x & 0x7F7F7F7Fu;
+  const uint32_t ge_a = t + 0x1F1F1F1Fu;   // bit 7 set iff t >= 0x61
+  const uint32_t gt_z = t + 0x05050505u;   // bit 7 set iff t >= 0x7B
+  const uint32_t lower = ge_a & ~gt_z & ~x & 0x80808080u;
+  return x - (lower >> 2);
+}
+
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+
+template <int TILE_SHIFT>
+__global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
+  constexpr int TILE = 1 << TILE_SHIFT;
+  constexpr int NW = kChunk / 4;                 // quality words per lane
+  constexpr int OUT_IT = TILE / kPileupBlock;    // read-out iterations per thread (8)
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
+  __shared__ unsigned long long s_stats[MIDAS_STATS];
+  extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int t = (int)blockIdx.x;
+  if (t >= p.n_tiles) return;
+
+  {
+    uint4* z = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < TILE; i += kPileupBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < p.table_len; i += kPileupBlock) {
+      s_tables[i] = p.filt->min_match[i];
+      s_tables[p.table_len + i] = p.filt->min_align[i];
+    }
+    if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
+  }
+
+  const int lpr = p.lanes_per_read;
+  const int rpw = p.reads_per_wave;
+  const int g = lane / lpr;
+  const int c = lane - g * lpr;
+  const bool lane_used = g < rpw;
+  const int q0 = c * kChunk;
+  const int stride = (kPileupBlock / 64) * rpw;
+  const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
+  const int bq = p.baseq < 1 ? 1 : p.baseq;   // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
+  const bool count_all = p.baseq < 1;
+  // LDS byte address of the tally array (LDS pointers are 32-bit offsets on amdgcn)
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
+
+  struct Payload {
+    uint32_t qw[NW];  // 32 quality bytes (zero beyond the end of the read: the blob is padded)
+    uint32_t sw[4];   // 32 call codes
+    uint32_t cg[4];   // first four CIGAR ops (non-simple reads only)
+    uint32_t cl;      // last CIGAR op when n_cigar > 4
+  };
+  // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead.  Nothing may be
+  // computed from a loaded value here: any use would make the compiler drain the loads at once.
+  auto fetch_rec = [&](int b, int re) -> uint4 {
+    const int r = b + g;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (lane_used && r < re) v = recs[r];
+    return v;
+  };
+  auto fetch_payload = [&](const uint4& rv, int b, int re, Payload& d) {
+    const int r = b + g;
+    const bool act = lane_used && r < re;
+    const int l = rec_l(rv);
+    const int n = rec_n(rv);
+    const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) d.qw[w] = 0u;
+    d.sw[0] = d.sw[1] = d.sw[2] = d.sw[3] = 0u;
+    d.cg[0] = d.cg[1] = d.cg[2] = d.cg[3] = 0u;
+    d.cl = 0u;
+    if (act && q0 < l) {
+      const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + q0);
+      const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + q0 + 16);
+      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l) + (q0 >> 1));
+      d.qw[0] = qa.x; d.qw[1] = qa.y; d.qw[2] = qa.z; d.qw[3] = qa.w;
+      d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
+      d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
+    }
+    if (act && !(rec_flags(rv) & kRecSimple) && n > 0) {
+      const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
+      const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
+      d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
+      if (n > 4) d.cl = cig[n - 1];   // n <= 4: the last op is one of cg[0..3], picked at use
+    }
+  };
+  auto tile_range = [&](int tt, int& rb, int& re) {
+    const uint32_t rbinv = p.rbinv[tt];
+    re = (int)p.rend[tt];
+    rb = rbinv ? p.n_reads - (int)rbinv : re;
+  };
+
+  Tile tile = p.tiles[t];
+  int rb, re;
+  tile_range(t, rb, re);
+  uint4 rec_cur = fetch_rec(rb + wave * rpw, re);
+  uint4 rec_nxt = fetch_rec(rb + wave * rpw + stride, re);
+  Payload cur;
+  fetch_payload(rec_cur, rb + wave * rpw, re, cur);
+  __syncthreads();   // LDS zeroed, tables in place
+
+  for (;;) {
+    const int tile_len = tile.len;
+    const int tile_start = tile.start;
+    uint32_t w_aligned = 0, w_mapped = 0;
+
+    for (int base = rb + wave * rpw; base < re; base += stride) {
+      const uint4 rec_nn = fetch_rec(base + 2 * stride, re);
+      Payload nxt;
+      fetch_payload(rec_nxt, base + stride, re, nxt);
+
+      // ================= process (rec_cur, cur) ===================================================
+      const int r = base + g;
+      bool act = lane_used && r < re;
+      const int l = rec_l(rec_cur);
+      const int n = rec_n(rec_cur);
+      const int pos = rec_pos(rec_cur);
+      const uint32_t flags = rec_flags(rec_cur);
+      const bool simple = (flags & kRecSimple) != 0u;
+      // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
+      int cpos = pos < 0 ? 0 : pos;
+      cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
+      const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+      // position of the read relative to the tile; a read that can never reach the tile is parked far right
+      // (reference positions only grow along a CIGAR, so "far right" stays far right)
+      const long long rel64 = (long long)pos - (long long)tile_start;
+      int rrel = (rel64 > (1LL << 25) || rel64 < -(1LL << 30)) ? (1 << 25) : (int)rel64;
+      // reads that start in an earlier tile and provably end before this one: nothing to do here
+      if (act && !owner && n == 1 && rrel + l <= 0) act = false;
+      const bool has = act && q0 < l;
+
+      // ---- soft-clip trimming ([EXT] pysam getQueryStart / getQueryEnd) ---------------------------
+      int k0 = 0, lead_s = 0, trail_s = 0;
+      const uint32_t* cig = nullptr;
+      if (act && !simple) {
+        cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l));
+        if (!(flags & kRecClipGeneric)) {
+          if (n > 0 && (cur.cg[0] & 15u) == OP_S) { lead_s = (int)(cur.cg[0] >> 4); k0 = 1; }
+          const uint32_t last = n > 4 ? cur.cl : (n == 2 ? cur.cg[1] : (n == 3 ? cur.cg[2] : cur.cg[3]));
+          if (n > 1 && (last & 15u) == OP_S) trail_s = (int)(last >> 4);
+        } else {
+          while (k0 < n) {
+            const uint32_t v = cig[k0];
+            const uint32_t op = v & 15u;
+            if (op == OP_H) { ++k0; }
+            else if (op == OP_S) { lead_s += (int)(v >> 4); ++k0; }
+            else break;
+          }
+          for (int k = n - 1; k >= 1; --k) {   // index 0 is never inspected by pysam's backward walk
+            const uint32_t v = cig[k];
+            const uint32_t op = v & 15u;
+            if (op == OP_H) continue;
+            if (op == OP_S) trail_s += (int)(v >> 4); else break;
+          }
+        }
+      }
+      int align_len = (l - trail_s) - lead_s;
+      align_len = align_len < 0 ? 0 : align_len;
+      // exact integer form of the two fp64 ratio tests (tables built by the host with the reference's expressions)
+      const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+      const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+
+      // ---- quality sum of the whole read: per-lane partial, then a segmented reduction ----------
+      const int nvalid = has ? (l - q0 < kChunk ? l - q0 : kChunk) : 0;
+      uint32_t part = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) part = __builtin_amdgcn_sad_u8(cur.qw[w], 0u, part);
+      for (int d = 1; d < lpr; d <<= 1) {
+        const uint32_t o = __shfl_down(part, d);
+        if (c + d < lpr) part += o;
+      }
+      const int qsum = (int)__shfl(part, lane - c);
+
+      // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
+      bool keep = false;
+      uint32_t err = 0;
+      if (act) {
+        if (l == 0) err = E_NO_SEQ;
+        else if (rec_nm(rec_cur) == kNmAbsent) err = E_NO_NM;
+        else if (align_len == 0) err = E_ZERO_ALIGN;
+        else if (align_len - (int)rec_nm(rec_cur) < min_match) keep = false;            // pid < mapid
+        else if (flags & kRecQualAbsent) err = E_NO_QUAL;
+        // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; the quotient is >= 2^-16 away from readq)
+        else if ((long long)qsum < (long long)p.readq * (long long)l) keep = false;
+        else if (rec_mapq(rec_cur) < p.mapq) keep = false;
+        else if (align_len < min_align) keep = false;                                     // aln_cov
+        else if (flags & kRecOverrun) err = E_CIGAR_OVERRUN;   // kept, and its CIGAR reaches past SEQ inside the contig
+        else keep = true;
+      }
+
+      // ---- per-base call codes and validity, four bases per instruction ----------------------------
+      uint32_t qv[NW];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
+      uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
+      bool walking = keep && has && !(p.debug & 4);
+      if (walking) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));               // call bytes 2w, 2w+1: bases 4w .. 4w+3
+          const uint32_t t4 = __builtin_amdgcn_perm(0u, x16, 0x01010000u);     // [b0, b0, b1, b1]
+          const uint32_t nib = ((t4 >> 4) & 0x000F000Fu) | (t4 & 0x0F000F00u);  // one call code per byte
+          const uint32_t inv = nib & 0x02020202u;                              // not A/C/G/T
+          const uint32_t inv_ff = (inv << 7) - (inv >> 1);                     // 0xFF in every such byte
+          const uint32_t q = count_all ? low_bytes_mask(nvalid - 4 * w) : cur.qw[w];
+          qv[w] = q & ~inv_ff;
+          cd[w] = nib & 0x0C0C0C0Cu;
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { qv[w] = 0u; cd[w] = 0u; }
+      }
+
+      // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -----
+      // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative
+      // reference position only below 4096, and both only ever grow.
+      int k = k0;
+      int qpos = lead_s;
+      const int q1 = q0 + nvalid;
+      int jlo = 0, jhi = 0, loc0 = 0;
+      auto next_segment = [&]() -> bool {
+        while (k < n) {
+          const uint32_t v = k < 4 ? (k == 0 ? cur.cg[0] : (k == 1 ? cur.cg[1] : (k == 2 ? cur.cg[2] : cur.cg[3]))) : cig[k];
+          ++k;
+          const uint32_t op = v & 15u;
+          const int len = (int)(v >> 4);
+          const bool m = consumes_both(op);
+          bool found = false;
+          if (m) {
+            const int lo = qpos > q0 ? qpos : q0;
+            const int hi = (qpos + len) < q1 ? (qpos + len) : q1;
+            found = lo < hi;
+            if (found) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + (q0 - qpos); }
+          }
+          if (m || op == OP_I || op == OP_S) { qpos += len; qpos = qpos > (1 << 29) ? (1 << 29) : qpos; }
+          if (m || op == OP_D || op == OP_N) { rrel += len; rrel = rrel > (1 << 29) ? (1 << 29) : rrel; }
+          if (found) return true;   // H, P and anything else: no effect
+        }
+        return false;
+      };
+      if (walking) {
+        if (simple) {
+          jlo = 0; jhi = nvalid; loc0 = rrel + q0; k = n;
+        } else {
+          walking = next_segment();
+        }
+      }
+      while (walking) {
+        // bases of the chunk that belong to this segment AND lie inside the tile: [lo, hi)
+        uint32_t q4[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) q4[w] = qv[w];
+        const int lo = jlo > -loc0 ? jlo : -loc0;
+        const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
+        if (lo > 0 || hi < nvalid) {    // partial chunk (segment border or tile edge): zero the bytes outside
+          const uint32_t below_hi = hi >= 32 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+          const uint32_t below_lo = lo >= 32 ? 0xFFFFFFFFu : (lo <= 0 ? 0u : ((1u << lo) - 1u));
+          const uint32_t jm = below_hi & ~below_lo;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) q4[w] &= bits_to_bytes((jm >> (4 * w)) & 0xFu);
+        }
+        const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
+        if (!(p.debug & 1)) tally_chunk(q4, cd, (uint32_t)bq, abase, 1u);
+        walking = (k < n) ? next_segment() : false;
+      }
+
+      // ---- per-species read counters: one ballot per wave -----------------------------------------
+      const bool head = owner && c == 0;
+      const unsigned long long m_al = __ballot(head);
+      const unsigned long long m_mp = __ballot(head && keep);
+      w_aligned += (uint32_t)__popcll(m_al);
+      w_mapped += (uint32_t)__popcll(m_mp);
+      if (head && err) atomicMin(p.err, ((unsigned long long)(uint32_t)r << 8) | err);
+
+      rec_cur = rec_nxt;
+      rec_nxt = rec_nn;
+      cur = nxt;
+    }
+
+    if (lane == 0) {
+      if (w_aligned) atomicAdd(&s_stats[MIDAS_STAT_ALIGNED], (unsigned long long)w_aligned);
+      if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
+    }
+    __syncthreads();   // every tally of this tile is in LDS
+
+    // ---- next tile: its first loads go out BEFORE this tile's stores ------------------------------------
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < p.n_tiles;
+    Tile ntile = tile;
+    int nrb = 0, nre = 0;
+    if (more) {
+      ntile = p.tiles[tn];
+      tile_range(tn, nrb, nre);
+      rec_cur = fetch_rec(nrb + wave * rpw, nre);
+      rec_nxt = fetch_rec(nrb + wave * rpw + stride, nre);
+    }
+
+    // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
+    unsigned long long covered = 0, depth_sum = 0;
+    {
+      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + tile.site_base;
+      uint4* lds4 = reinterpret_cast<uint4*>(lds);
+      const int lim = (p.debug & 2) ? 0 : tile_len;
+#pragma unroll
+      for (int it = 0; it < OUT_IT; ++it) {
+        const int i = tid + it * kPileupBlock;
+        if (i < lim) {
+          const uint4 v = lds4[i];
+          lds4[i] = make_uint4(0u, 0u, 0u, 0u);
+          out[i] = v;
+          const uint32_t d = v.x + v.y + v.z + v.w;
+          covered += d > 0u ? 1ull : 0ull;
+          depth_sum += d;
+        }
+      }
+    }
+    if (more) fetch_payload(rec_cur, nrb + wave * rpw, nre, cur);   // waits for the two record loads only
+
+    // ---- upper-cased ref allele, four sites per lane ---------------------------------------------------------
+    if (p.out_allele && !(p.debug & 2)) {
+      const uint8_t* ref = p.ref + tile.site_base;
+      uint8_t* al = p.out_allele + tile.site_base;
+#pragma unroll
+      for (int it = 0; it < TILE / (4 * kPileupBlock); ++it) {
+        const int i = 4 * (tid + it * kPileupBlock);
+        if (i + 4 <= tile_len) {
+          *reinterpret_cast<u32_a1*>(al + i) = upper4(*reinterpret_cast<const u32_a1*>(ref + i));
+        } else {
+          for (int j = i; j < tile_len; ++j) {
+            uint32_t ch = ref[j];
+            if (ch >= 'a' && ch <= 'z') ch -= 32u;
+            al[j] = (uint8_t)ch;
+          }
+        }
+      }
+    }
+
+    for (int d = 32; d >= 1; d >>= 1) {
+      covered += __shfl_down(covered, d);
+      depth_sum += __shfl_down(depth_sum, d);
+    }
+    if (lane == 0) {
+      if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
+      if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
+    }
+    __syncthreads();   // s_stats complete
+    if (tid < MIDAS_STATS) {
+      const unsigned long long v = s_stats[tid];
+      if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
+      s_stats[tid] = 0ull;
+    }
+    if (!more) break;
+    __syncthreads();   // LDS tallies re-zeroed and s_stats reset before the next tile's waves touch them
+    t = tn;
+    tile = ntile;
+    rb = nrb;
+    re = nre;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream) {
+  if (p.n_tiles <= 0) return hipSuccess;
+  const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
+  const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
+  hipLaunchKernelGGL(pileup_tiles_kernel<kTileShift>, dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace midas

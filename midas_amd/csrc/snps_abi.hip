@@ -2,7 +2,9 @@
 // for the contract and the reference lines each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,11 +47,12 @@ struct midas_snps_batch {
   uint8_t* d_allele = nullptr;
   // facts
   int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
-  int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1;
+  int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, tile_len = kTileSites;
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot
   int32_t timing_slots = 0;
   int64_t timed_runs = 0;
+  int64_t run_count = 0;
   bool ran = false;
 };
 
@@ -75,10 +78,11 @@ int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
     if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
   } while (0)
 
-uint32_t* work_rbinv(midas_snps_batch* b) { return reinterpret_cast<uint32_t*>(b->d_work); }
-uint32_t* work_rend(midas_snps_batch* b) { return work_rbinv(b) + b->n_tiles; }
+// tile ranges are double-buffered by run parity: [rbinv0][rend0][rbinv1][rend1]
+uint32_t* work_rbinv(midas_snps_batch* b, int par) { return reinterpret_cast<uint32_t*>(b->d_work) + (size_t)par * 2 * b->n_tiles; }
+uint32_t* work_rend(midas_snps_batch* b, int par) { return work_rbinv(b, par) + b->n_tiles; }
 unsigned long long* work_stats(midas_snps_batch* b) {
-  size_t off = ((size_t)b->n_tiles * 8 + 15) & ~(size_t)15;
+  size_t off = ((size_t)b->n_tiles * 16 + 15) & ~(size_t)15;
   return reinterpret_cast<unsigned long long*>(b->d_work + off);
 }
 unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
@@ -278,6 +282,34 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }                                            \
   } while (0)
 
+  // ---- tile length: a tile's reads are dealt to the workgroup's waves in rounds of `round_cap` reads, and a
+  // round costs the same whether it is full or nearly empty.  Pick the longest tile (<= kTileSites, the LDS
+  // budget) whose expected read count, plus two standard deviations, still fills a whole number of rounds.
+  {
+    const int64_t round_cap = (int64_t)(kPileupBlock / 64) * (64 / b->lanes_per_read);
+    const double rho = n_sites > 0 ? (double)reads->n_reads / (double)n_sites : 0.0;   // read starts per site
+    const double span = ps.max_l_seq;
+    int32_t best = kTileSites;
+    if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) {
+      best = atoi(e);
+    } else if (rho > 0.0) {
+      double best_eff = 0.0;
+      for (int k = 1; k <= 64; ++k) {
+        const double n_max = (double)(k * round_cap);
+        const double n_tgt = n_max - 2.0 * sqrt(n_max);
+        double tl = n_tgt / rho - span;
+        if (tl > kTileSites) tl = kTileSites;
+        if (tl < 256) continue;
+        const double eff = tl / k;               // sites retired per round
+        if (eff > best_eff * 1.001) { best_eff = eff; best = (int32_t)tl & ~15; }
+        if (tl >= kTileSites) break;
+      }
+    }
+    if (best < 64) best = 64;
+    if (best > kTileSites) best = kTileSites;
+    b->tile_len = best;
+  }
+  const int64_t tile_len = b->tile_len;
   // ---- tile table -------------------------------------------------------------------------
   std::vector<Tile> tiles;
   std::vector<int32_t> tile_base(contigs->n_contigs + 1, 0), clen(contigs->n_contigs), rbeg(contigs->n_contigs + 1, 0);
@@ -288,11 +320,11 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       tile_base[c] = (int32_t)tiles.size();
       clen[c] = (int32_t)len;
       rbeg[c] = (int32_t)contigs->read_begin[c];
-      for (int64_t s = 0; s < len; s += kTileSites) {
+      for (int64_t s = 0; s < len; s += tile_len) {
         Tile t;
         t.contig = c;
         t.start = (int32_t)s;
-        t.len = (int32_t)((len - s) < kTileSites ? (len - s) : kTileSites);
+        t.len = (int32_t)((len - s) < tile_len ? (len - s) : tile_len);
         t.species = contigs->species[c];
         t.site_base = site + s;
         t.contig_len = (int32_t)len;
@@ -356,7 +388,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemcpy(b->d_contig_tile_base, tile_base.data(), nc1 * 4, hipMemcpyHostToDevice));
   if (contigs->n_contigs > 0)
     B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
-  b->work_bytes = (((size_t)b->n_tiles * 8 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
+  b->work_bytes = (((size_t)b->n_tiles * 16 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
   // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
   // error word are reset by the index kernel at the start of each run: no per-run memsets
@@ -408,13 +440,18 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.contig_read_begin = b->d_contig_read_begin;
   ip.contig_tile_base = b->d_contig_tile_base;
   ip.contig_len = b->d_contig_len;
-  ip.rbinv = work_rbinv(b);
-  ip.rend = work_rend(b);
+  const int par = (int)(b->run_count & 1);
+  ip.rbinv = work_rbinv(b, par);
+  ip.rend = work_rend(b, par);
+  ip.rbinv_next = work_rbinv(b, par ^ 1);
+  ip.rend_next = work_rend(b, par ^ 1);
+  ip.n_tiles = (int32_t)b->n_tiles;
   ip.stats = work_stats(b);
   ip.err = work_err(b);
   ip.n_reads = (int32_t)b->n_reads;
   ip.n_contigs = b->n_contigs;
   ip.n_stat_words = b->n_species * MIDAS_STATS;
+  ip.tile_len = b->tile_len;
   HIP_TRY(ctx, launch_index_reads(ip, s));
   if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
 
@@ -423,15 +460,15 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.blob = b->d_blob;
   pp.ref = b->d_ref;
   pp.tiles = b->d_tiles;
-  pp.rbinv = work_rbinv(b);
-  pp.rend = work_rend(b);
+  pp.rbinv = work_rbinv(b, par);
+  pp.rend = work_rend(b, par);
   pp.out_counts = b->d_counts;
   pp.out_allele = b->d_allele;
   pp.stats = work_stats(b);
   pp.err = work_err(b);
   pp.n_tiles = (int32_t)b->n_tiles;
   pp.n_reads = (int32_t)b->n_reads;
-  pp.tiles_per_xcd = (int32_t)((b->n_tiles + 7) / 8);
+  pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
   pp.lanes_per_read = b->lanes_per_read;
   pp.reads_per_wave = 64 / b->lanes_per_read;
   pp.baseq = thr->baseq;
@@ -439,12 +476,14 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.readq = thr->readq;
   pp.filt = b->d_filt;
   pp.table_len = b->max_l_seq + 1;
+  pp.debug = getenv("MIDAS_SNPS_DEBUG") ? atoi(getenv("MIDAS_SNPS_DEBUG")) : 0;
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
   if (ev) {
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
     b->timed_runs += 1;
   }
   b->ran = true;
+  b->run_count += 1;
   return MIDAS_SNPS_OK;
 }
 
@@ -487,7 +526,7 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->n_tiles = b->n_tiles;
   out->packed_bytes = b->blob_bytes + b->n_reads * (int64_t)sizeof(ReadRec);
   out->algorithmic_bytes = b->alg_bytes;
-  out->tile_sites = kTileSites;
+  out->tile_sites = b->tile_len;
   out->lanes_per_read = b->lanes_per_read;
   return MIDAS_SNPS_OK;
 }
