@@ -98,6 +98,11 @@ __device__ __forceinline__ uint32_t upper4(uint32_t x) {
   return x - (lower >> 2);
 }
 
+// lane i <- lane i-1 (lane 0 <- 0), one VALU op (v_add_u32_dpp wave_shr:1 when fused with the add)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
+}
+
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 template <int TILE_SHIFT>
@@ -217,8 +222,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
       // position of the read relative to the tile; a read that can never reach the tile is parked far right
       // (reference positions only grow along a CIGAR, so "far right" stays far right)
-      const long long rel64 = (long long)pos - (long long)tile_start;
-      int rrel = (rel64 > (1LL << 25) || rel64 < -(1LL << 30)) ? (1 << 25) : (int)rel64;
+      const int rel = pos - tile_start;   // pos >= -1, tile_start >= 0: fits an int
+      int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;
       // reads that start in an earlier tile and provably end before this one: nothing to do here
       if (act && !owner && n == 1 && rrel + l <= 0) act = false;
       const bool has = act && q0 < l;
@@ -259,11 +264,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       uint32_t part = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) part = __builtin_amdgcn_sad_u8(cur.qw[w], 0u, part);
-      for (int d = 1; d < lpr; d <<= 1) {
-        const uint32_t o = __shfl_down(part, d);
-        if (c + d < lpr) part += o;
+      int qsum;
+      if (lpr <= 8) {
+        // running window sum: after lpr-1 steps lane i holds x[i] + ... + x[i-lpr+1]; the read's last lane has it all
+        uint32_t s = part;
+        for (int d = 1; d < lpr; ++d) s = part + wave_shr1(s);
+        qsum = (int)__shfl(s, lane - c + lpr - 1);
+      } else {
+        for (int d = 1; d < lpr; d <<= 1) {
+          const uint32_t o = __shfl_down(part, d);
+          if (c + d < lpr) part += o;
+        }
+        qsum = (int)__shfl(part, lane - c);
       }
-      const int qsum = (int)__shfl(part, lane - c);
 
       // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
       bool keep = false;
