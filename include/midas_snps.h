@@ -211,6 +211,35 @@ int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_co
                               void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
                               int32_t* out_max_l_seq, char* err256);
 
+/* ---- host I/O (no GPU needed) ------------------------------------------------
+ * BAM decode.  Replaces `pysam.AlignmentFile(bampath, 'rb')` and htslib's record decode
+ * (midas/run/snps.py:186): the whole coordinate-sorted snps/temp/genomes.bam is inflated (BGZF blocks in
+ * parallel) and every record with refID >= 0 -- everything fetch(contig, 0, length) can return -- is
+ * decoded into the BAM-native SoA of midas_snps_reads plus a refID per record.  No .bai is needed
+ * (index_bam, midas/run/snps.py:130-137, becomes a no-op: the device indexes).                     */
+typedef struct midas_bam midas_bam;
+int32_t midas_bam_open(const char* path, midas_bam** out, char* err256);
+void midas_bam_close(midas_bam* bam);
+int32_t midas_bam_n_refs(const midas_bam* bam);
+int32_t midas_bam_ref(const midas_bam* bam, int32_t i, const char** name, int64_t* length);
+/* Decode; returns the array sizes the caller must allocate for midas_bam_copy(). */
+int32_t midas_bam_load(midas_bam* bam, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                       int64_t* n_cigar, char* err256);
+/* Copy the decoded arrays out (any pointer may be NULL); *_off arrays have n_reads+1 entries. */
+int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8_t* mapq, uint16_t* flag,
+                       int32_t* nm, int32_t* l_seq, int64_t* seq_off, int64_t* qual_off, int64_t* cigar_off,
+                       uint8_t* seq4, uint8_t* qual, uint32_t* cigar);
+
+/* Row formatter + gzip writer for <outdir>/snps/output/<species>.snps.gz.  Replaces the per-site emit
+ * loop of midas/run/snps.py:201-210 and utility.iopen(...,'w') (midas/utility.py:194-206) for ONE contig:
+ * rows `ref_id \t i+1 \t allele[i] \t A+C+G+T \t A \t C \t G \t T \n` for i in [0, n_sites).
+ * append == 0 creates the file and writes the header line first; append != 0 appends gzip members
+ * (concatenated members are one valid gzip stream).  Rows are formatted and deflated by `threads`
+ * workers (0 = all cores) in 65 536-row members and written in order.                              */
+int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
+                              const uint8_t* allele, const uint32_t* counts, int32_t gz_level,
+                              int32_t threads, char* err256);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,15 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
+    sig.update({
+        'midas_bam_open': (i32, [C.c_char_p, C.POINTER(vp), C.c_char_p]),
+        'midas_bam_close': (None, [vp]),
+        'midas_bam_n_refs': (i32, [vp]),
+        'midas_bam_ref': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]),
+        'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_bam_copy': (i32, [vp] + [vp] * 12),
+        'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
+    })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
@@ -209,7 +218,62 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_stats_to_device',
     'midas_snps_pack_reads',
+    'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
+    'midas_snps_write_rows',
 ]
+
+
+def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts: np.ndarray,
+               gz_level: int = 6, threads: int = 0):
+    """Format + gzip the rows of ONE contig into <species>.snps.gz (midas_snps_write_rows)."""
+    lib = load_library()
+    allele = np.ascontiguousarray(allele, dtype=np.uint8)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    assert counts.shape == (allele.shape[0], 4)
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_write_rows(path.encode(), 1 if append else 0, ref_id.encode(), allele.shape[0],
+                                   allele.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                   int(gz_level), int(threads), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+
+
+def read_bam(path: str):
+    """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA)."""
+    lib = load_library()
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    st = lib.midas_bam_open(path.encode(), C.byref(h), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    try:
+        names, lens = [], []
+        for i in range(lib.midas_bam_n_refs(h)):
+            nm = C.c_char_p()
+            ln = C.c_int64()
+            lib.midas_bam_ref(h, i, C.byref(nm), C.byref(ln))
+            names.append(nm.value.decode())
+            lens.append(int(ln.value))
+        n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        st = lib.midas_bam_load(h, C.byref(n), C.byref(sb), C.byref(qb), C.byref(nc), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        n = int(n.value)
+        refid = np.empty(n, np.int32)
+        a = dict(pos=np.empty(n, np.int32), mapq=np.empty(n, np.uint8), flag=np.empty(n, np.uint16),
+                 nm=np.empty(n, np.int32), l_seq=np.empty(n, np.int32), seq_off=np.empty(n + 1, np.int64),
+                 qual_off=np.empty(n + 1, np.int64), cigar_off=np.empty(n + 1, np.int64),
+                 seq4=np.empty(int(sb.value), np.uint8), qual=np.empty(int(qb.value), np.uint8),
+                 cigar=np.empty(int(nc.value), np.uint32))
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        st = lib.midas_bam_copy(h, p(refid), p(a['pos']), p(a['mapq']), p(a['flag']), p(a['nm']), p(a['l_seq']),
+                                p(a['seq_off']), p(a['qual_off']), p(a['cigar_off']), p(a['seq4']), p(a['qual']),
+                                p(a['cigar']))
+        if st != 0:
+            raise MidasSnpsError(st, "midas_bam_copy failed")
+    finally:
+        lib.midas_bam_close(h)
+    return names, lens, refid, ReadsSoA(**a)
 
 
 def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):

@@ -1,0 +1,91 @@
+"""BAM helpers.  Reading goes through the native decoder (abi.read_bam); the small pure-Python writer below
+exists because no samtools/bowtie2/pysam is available in the build image: tests and the synthetic benchmark
+need a way to put `snps/temp/genomes.bam` on disk in the exact format a coordinate-sorted bowtie2 BAM has."""
+
+import struct
+import zlib
+
+import numpy as np
+
+_EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(data: bytes, level: int = 6) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    hdr = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord('B'), ord('C'), 2, bsize)
+    return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def write_bam(path, ref_names, ref_lengths, refid, reads, read_names=None, header_text=None, level=6):
+    """Write a BAM from SoA records (ReadsSoA) + a refID per record.  Records are written in the given order."""
+    if header_text is None:
+        header_text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join(
+            "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(ref_names, ref_lengths))
+    ht = header_text.encode()
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(ht)) + ht + struct.pack("<i", len(ref_names)))
+    for n, l in zip(ref_names, ref_lengths):
+        nb = n.encode() + b"\0"
+        out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    seq4 = reads.seq4.tobytes()
+    qual = reads.qual.tobytes()
+    cigar = reads.cigar.astype("<u4").tobytes()
+    chunks = [bytes(out)]
+    for i in range(reads.n_reads):
+        name = (read_names[i] if read_names is not None else "r%d" % i).encode() + b"\0"
+        l = int(reads.l_seq[i])
+        c0, c1 = int(reads.cigar_off[i]), int(reads.cigar_off[i + 1])
+        n_cig = c1 - c0
+        pos = int(reads.pos[i])
+        nm = int(reads.nm[i])
+        aux = b"" if nm < 0 else (b"NMC" + struct.pack("<B", nm) if nm < 256 else b"NMi" + struct.pack("<i", nm))
+        aux += b"YTZUU\0"
+        body = struct.pack("<iiBBHHHIiii", int(refid[i]), pos, len(name), int(reads.mapq[i]),
+                           4680, n_cig, int(reads.flag[i]), l, -1, -1, 0)
+        body += name + cigar[4 * c0:4 * c1]
+        body += seq4[int(reads.seq_off[i]):int(reads.seq_off[i]) + (l + 1) // 2]
+        body += qual[int(reads.qual_off[i]):int(reads.qual_off[i]) + l] + aux
+        chunks.append(struct.pack("<i", len(body)) + body)
+    stream = b"".join(chunks)
+    with open(path, "wb") as f:
+        for o in range(0, len(stream), 0xff00):
+            f.write(_bgzf_block(stream[o:o + 0xff00], level))
+        f.write(_EOF_BLOCK)
+
+
+def group_by_contig(ref_names, refid, reads, contig_ids):
+    """Records of a decoded BAM -> (ReadsSoA in contig-table order, read_begin) for the given contig ids.
+    A coordinate-sorted BAM is already grouped by refID; anything else is stably regrouped."""
+    from .abi import ReadsSoA
+    index_of = {n: i for i, n in enumerate(ref_names)}
+    want = np.array([index_of.get(c, -1) for c in contig_ids], dtype=np.int64)
+    rank = np.full(len(ref_names) + 1, -1, dtype=np.int64)
+    for k, r in enumerate(want):
+        if r >= 0:
+            rank[r] = k
+    key = rank[refid]
+    keep = key >= 0
+    order = np.nonzero(keep)[0]
+    k = key[order]
+    if k.size and np.any(k[1:] < k[:-1]):
+        order = order[np.argsort(k, kind='stable')]
+        k = key[order]
+    read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(k, minlength=len(contig_ids)), out=read_begin[1:])
+    if order.size == reads.n_reads and (order.size == 0 or np.all(order == np.arange(order.size))):
+        return reads, read_begin
+
+    def gather(data, off):
+        lens = (off[1:] - off[:-1])[order]
+        new_off = np.zeros(order.size + 1, dtype=np.int64)
+        np.cumsum(lens, out=new_off[1:])
+        ix = np.repeat(off[:-1][order] - new_off[:-1], lens) + np.arange(new_off[-1])
+        return data[ix], new_off
+    seq4, seq_off = gather(reads.seq4, reads.seq_off)
+    qual, qual_off = gather(reads.qual, reads.qual_off)
+    cigar, cigar_off = gather(reads.cigar, reads.cigar_off)
+    sub = ReadsSoA(pos=reads.pos[order], mapq=reads.mapq[order], flag=reads.flag[order], nm=reads.nm[order],
+                   l_seq=reads.l_seq[order], seq_off=seq_off, qual_off=qual_off, cigar_off=cigar_off,
+                   seq4=seq4, qual=qual, cigar=cigar)
+    return sub, read_begin

@@ -1,0 +1,406 @@
+// Host-side I/O of the pileup stage, native because it bounds the end-to-end time once the kernel is fast:
+//   * BAM (BGZF) decode into the BAM-native SoA the C-ABI takes      (reference: pysam.AlignmentFile + htslib
+//     record decode, midas/run/snps.py:186; `samtools index` is not needed: the device indexes)
+//   * <species>.snps.gz row formatter + multi-member gzip writer      (reference: midas/run/snps.py:179-182,
+//     201-210 and utility.iopen, midas/utility.py:194-206)
+// No GPU involved; exported through the same C-ABI library (include/midas_snps.h, "host I/O" section).
+#include "hostio.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct midas_bam {
+  std::string path;
+  std::vector<std::string> ref_names;
+  std::vector<int64_t> ref_lens;
+  std::vector<uint8_t> data;   // inflated stream
+  size_t rec_begin = 0;        // offset of the first alignment record
+  // decoded SoA
+  std::vector<int32_t> refid, pos, nm, l_seq;
+  std::vector<uint8_t> mapq, seq4, qual;
+  std::vector<uint16_t> flag;
+  std::vector<int64_t> seq_off, qual_off, cigar_off;
+  std::vector<uint32_t> cigar;
+  bool loaded = false;
+};
+
+namespace {
+
+void set_err(char* err256, const char* fmt, const char* a = "", long long b = 0) {
+  if (err256) snprintf(err256, 256, fmt, a, b);
+}
+
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+int hw_threads(int want) {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
+  if (n > 32) n = 32;
+  return (int)n;
+}
+
+// Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
+// are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
+int32_t bgzf_inflate_file(const std::string& path, std::vector<uint8_t>& out, char* err256) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  fseek(f, 0, SEEK_END);
+  const long fsz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> comp((size_t)fsz);
+  if (fsz > 0 && fread(comp.data(), 1, (size_t)fsz, f) != (size_t)fsz) {
+    fclose(f);
+    set_err(err256, "short read on %s", path.c_str());
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
+  fclose(f);
+  struct Blk { size_t cpos, clen, upos, ulen; };
+  std::vector<Blk> blocks;
+  size_t p = 0, upos = 0;
+  while (p < comp.size()) {
+    if (p + 18 > comp.size() || comp[p] != 0x1f || comp[p + 1] != 0x8b || comp[p + 2] != 8 || !(comp[p + 3] & 4)) {
+      set_err(err256, "%s: not a BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const size_t xlen = rd16(&comp[p + 10]);
+    size_t q = p + 12, xend = p + 12 + xlen;
+    size_t bsize = 0;
+    while (q + 4 <= xend) {
+      const uint16_t slen = rd16(&comp[q + 2]);
+      if (comp[q] == 'B' && comp[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&comp[q + 4]) + 1;
+      q += 4 + slen;
+    }
+    if (bsize == 0 || p + bsize > comp.size() || bsize < xlen + 20) {
+      set_err(err256, "%s: truncated BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const size_t isize = rd32(&comp[p + bsize - 4]);
+    blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize});
+    upos += isize;
+    p += bsize;
+  }
+  out.resize(upos);
+  std::atomic<size_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= blocks.size()) return;
+      const Blk& b = blocks[i];
+      if (b.ulen == 0) continue;
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+      zs.next_in = comp.data() + b.cpos;
+      zs.avail_in = (uInt)b.clen;
+      zs.next_out = out.data() + b.upos;
+      zs.avail_out = (uInt)b.ulen;
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+    }
+  };
+  const int nt = hw_threads(0);
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  if (bad) { set_err(err256, "%s: corrupt deflate data", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  return MIDAS_SNPS_OK;
+}
+
+// NM:i (any integer width) from the aux block, or -1.
+int32_t find_nm(const uint8_t* a, const uint8_t* end) {
+  while (a + 3 <= end) {
+    const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+    a += 3;
+    size_t sz = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(a, 0, (size_t)(end - a)); if (!z) return -1; sz = (size_t)(z - a) + 1; break; }
+      case 'B': {
+        if (a + 5 > end) return -1;
+        const char st = (char)a[0];
+        const size_t cnt = rd32(a + 1);
+        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        sz = 5 + cnt * es;
+        break;
+      }
+      default: return -1;
+    }
+    if (a + sz > end) return -1;
+    if (t0 == 'N' && t1 == 'M') {
+      switch (ty) {
+        case 'c': return (int8_t)a[0];
+        case 'C': return a[0];
+        case 's': return (int16_t)rd16(a);
+        case 'S': return rd16(a);
+        case 'i': return (int32_t)rd32(a);
+        case 'I': { const uint32_t v = rd32(a); return v > 0x7FFFFFFFu ? 0x7FFFFFFF : (int32_t)v; }
+        default: return -1;   // NM of a non-integer type: pysam would hand back a non-int; treat as absent
+      }
+    }
+    a += sz;
+  }
+  return -1;
+}
+
+// decimal formatting of a u32 into buf (returns new end)
+inline char* put_u32(char* p, uint32_t v) {
+  char tmp[10];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+inline char* put_u64(char* p, uint64_t v) {
+  char tmp[20];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  out.resize(deflateBound(&zs, (uLong)n) + 64);
+  zs.next_in = const_cast<Bytef*>(in);
+  zs.avail_in = (uInt)n;
+  zs.next_out = out.data();
+  zs.avail_out = (uInt)out.size();
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t produced = out.size() - zs.avail_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) return false;
+  out.resize(produced);
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) {
+  if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  midas_bam* b = new (std::nothrow) midas_bam();
+  if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  b->path = path;
+  int32_t st = bgzf_inflate_file(b->path, b->data, err256);
+  if (st != MIDAS_SNPS_OK) { delete b; return st; }
+  const std::vector<uint8_t>& d = b->data;
+  if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) {
+    set_err(err256, "%s: missing BAM magic", path);
+    delete b;
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
+  size_t p = 4;
+  const size_t l_text = rd32(&d[p]);
+  p += 4 + l_text;
+  if (p + 4 > d.size()) { set_err(err256, "%s: truncated BAM header", path); delete b; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  const uint32_t n_ref = rd32(&d[p]);
+  p += 4;
+  for (uint32_t i = 0; i < n_ref; ++i) {
+    if (p + 4 > d.size()) { set_err(err256, "%s: truncated BAM header", path); delete b; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    const uint32_t l_name = rd32(&d[p]);
+    p += 4;
+    if (p + l_name + 4 > d.size() || l_name == 0) { set_err(err256, "%s: truncated BAM header", path); delete b; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    b->ref_names.emplace_back(reinterpret_cast<const char*>(&d[p]), l_name - 1);
+    p += l_name;
+    b->ref_lens.push_back(rd32(&d[p]));
+    p += 4;
+  }
+  b->rec_begin = p;
+  *out = b;
+  return MIDAS_SNPS_OK;
+}
+
+void midas_bam_close(midas_bam* b) { delete b; }
+
+int32_t midas_bam_n_refs(const midas_bam* b) { return b ? (int32_t)b->ref_names.size() : 0; }
+
+int32_t midas_bam_ref(const midas_bam* b, int32_t i, const char** name, int64_t* length) {
+  if (!b || i < 0 || i >= (int32_t)b->ref_names.size()) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (name) *name = b->ref_names[i].c_str();
+  if (length) *length = b->ref_lens[i];
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar,
+                       char* err256) {
+  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (!b->loaded) {
+    const std::vector<uint8_t>& d = b->data;
+    // pass 1: record offsets (what fetch(contig, ...) can ever return: refID >= 0)
+    std::vector<size_t> offs;
+    size_t p = b->rec_begin;
+    while (p + 4 <= d.size()) {
+      const size_t bs = rd32(&d[p]);
+      if (bs < 32 || p + 4 + bs > d.size()) {
+        set_err(err256, "%s: truncated alignment record at byte %lld", b->path.c_str(), (long long)p);
+        return MIDAS_SNPS_ERR_BAD_LAYOUT;
+      }
+      if ((int32_t)rd32(&d[p + 4]) >= 0) offs.push_back(p);
+      p += 4 + bs;
+    }
+    const size_t n = offs.size();
+    b->refid.resize(n); b->pos.resize(n); b->nm.resize(n); b->l_seq.resize(n);
+    b->mapq.resize(n); b->flag.resize(n);
+    b->seq_off.assign(n + 1, 0); b->qual_off.assign(n + 1, 0); b->cigar_off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* r = &d[offs[i] + 4];
+      const uint32_t bs = rd32(&d[offs[i]]);
+      const uint32_t l_read_name = r[8];
+      const uint32_t n_cig = rd16(r + 12);
+      const uint32_t l = rd32(r + 16);
+      if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
+        set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)i);
+        return MIDAS_SNPS_ERR_BAD_LAYOUT;
+      }
+      b->cigar_off[i + 1] = b->cigar_off[i] + n_cig;
+      b->seq_off[i + 1] = b->seq_off[i] + (l + 1) / 2;
+      b->qual_off[i + 1] = b->qual_off[i] + l;
+    }
+    b->cigar.resize((size_t)b->cigar_off[n]);
+    b->seq4.resize((size_t)b->seq_off[n]);
+    b->qual.resize((size_t)b->qual_off[n]);
+    // pass 2: decode in parallel
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (;;) {
+        const size_t lo = next.fetch_add(4096);
+        if (lo >= n) return;
+        const size_t hi = std::min(n, lo + 4096);
+        for (size_t i = lo; i < hi; ++i) {
+          const uint8_t* r = &d[offs[i] + 4];
+          const uint32_t bs = rd32(&d[offs[i]]);
+          b->refid[i] = (int32_t)rd32(r);
+          b->pos[i] = (int32_t)rd32(r + 4);
+          const uint32_t l_read_name = r[8];
+          b->mapq[i] = r[9];
+          const uint32_t n_cig = rd16(r + 12);
+          b->flag[i] = rd16(r + 14);
+          const uint32_t l = rd32(r + 16);
+          b->l_seq[i] = (int32_t)l;
+          const uint8_t* q = r + 32 + l_read_name;
+          memcpy(b->cigar.data() + b->cigar_off[i], q, 4ull * n_cig);
+          q += 4ull * n_cig;
+          memcpy(b->seq4.data() + b->seq_off[i], q, (l + 1) / 2);
+          q += (l + 1) / 2;
+          memcpy(b->qual.data() + b->qual_off[i], q, l);
+          q += l;
+          b->nm[i] = find_nm(q, r + bs);
+        }
+      }
+    };
+    const int nt = hw_threads(0);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    b->loaded = true;
+    std::vector<uint8_t>().swap(b->data);   // the inflated stream is no longer needed
+  }
+  if (n_reads) *n_reads = (int64_t)b->pos.size();
+  if (seq_bytes) *seq_bytes = (int64_t)b->seq4.size();
+  if (qual_bytes) *qual_bytes = (int64_t)b->qual.size();
+  if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t* mapq, uint16_t* flag, int32_t* nm,
+                       int32_t* l_seq, int64_t* seq_off, int64_t* qual_off, int64_t* cigar_off, uint8_t* seq4,
+                       uint8_t* qual, uint32_t* cigar) {
+  if (!b || !b->loaded) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const size_t n = b->pos.size();
+  auto cp = [](void* dst, const void* src, size_t bytes) { if (dst && bytes) memcpy(dst, src, bytes); };
+  cp(refid, b->refid.data(), n * 4); cp(pos, b->pos.data(), n * 4); cp(mapq, b->mapq.data(), n);
+  cp(flag, b->flag.data(), n * 2); cp(nm, b->nm.data(), n * 4); cp(l_seq, b->l_seq.data(), n * 4);
+  cp(seq_off, b->seq_off.data(), (n + 1) * 8); cp(qual_off, b->qual_off.data(), (n + 1) * 8);
+  cp(cigar_off, b->cigar_off.data(), (n + 1) * 8);
+  cp(seq4, b->seq4.data(), b->seq4.size()); cp(qual, b->qual.data(), b->qual.size());
+  cp(cigar, b->cigar.data(), b->cigar.size() * 4);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
+                              const uint8_t* allele, const uint32_t* counts, int32_t gz_level, int32_t threads,
+                              char* err256) {
+  if (!path || (n_sites > 0 && (!ref_id || !allele || !counts)) || n_sites < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
+  FILE* f = fopen(path, append ? "ab" : "wb");
+  if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  if (gz_level < 0 || gz_level > 9) gz_level = 6;
+  bool ok = true;
+  if (!append) {
+    // header line of midas/run/snps.py:181-182
+    static const char hdr[] = "ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n";
+    std::vector<uint8_t> z;
+    ok = gz_member(reinterpret_cast<const uint8_t*>(hdr), sizeof(hdr) - 1, gz_level, z) &&
+         fwrite(z.data(), 1, z.size(), f) == z.size();
+  }
+  const size_t idlen = ref_id ? strlen(ref_id) : 0;
+  const int64_t kRows = 1 << 16;   // rows per gzip member
+  const int64_t n_chunks = (n_sites + kRows - 1) / kRows;
+  const int nt = hw_threads(threads > 0 ? threads : 0);
+  // chunks are produced by a pool and written strictly in order
+  std::vector<std::vector<uint8_t>> zbuf((size_t)n_chunks);
+  std::vector<std::atomic<int>> done((size_t)n_chunks);
+  for (auto& d : done) d = 0;
+  std::atomic<int64_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&] {
+    std::vector<char> text;
+    for (;;) {
+      const int64_t ci = next.fetch_add(1);
+      if (ci >= n_chunks) return;
+      const int64_t lo = ci * kRows, hi = std::min(n_sites, lo + kRows);
+      text.resize((size_t)(hi - lo) * (idlen + 80));
+      char* p = text.data();
+      for (int64_t i = lo; i < hi; ++i) {
+        // row = [contig.id, i+1, seq[i], depth, A, C, G, T] joined by tabs (midas/run/snps.py:202-210)
+        memcpy(p, ref_id, idlen); p += idlen;
+        *p++ = '\t'; p = put_u64(p, (uint64_t)(i + 1));
+        *p++ = '\t'; *p++ = (char)allele[i];
+        const uint32_t* c = counts + 4 * i;
+        *p++ = '\t'; p = put_u64(p, (uint64_t)c[0] + c[1] + c[2] + c[3]);
+        *p++ = '\t'; p = put_u32(p, c[0]);
+        *p++ = '\t'; p = put_u32(p, c[1]);
+        *p++ = '\t'; p = put_u32(p, c[2]);
+        *p++ = '\t'; p = put_u32(p, c[3]);
+        *p++ = '\n';
+      }
+      if (!gz_member(reinterpret_cast<const uint8_t*>(text.data()), (size_t)(p - text.data()), gz_level, zbuf[(size_t)ci]))
+        bad = 1;
+      done[(size_t)ci] = 1;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work);
+  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+    while (!done[(size_t)ci].load()) std::this_thread::yield();
+    if (bad) { ok = false; break; }
+    std::vector<uint8_t>& z = zbuf[(size_t)ci];
+    ok = fwrite(z.data(), 1, z.size(), f) == z.size();
+    std::vector<uint8_t>().swap(z);
+  }
+  if (!ok) next = n_chunks;   // stop the pool
+  for (auto& x : th) x.join();
+  if (fclose(f) != 0) ok = false;
+  if (!ok || bad) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  return MIDAS_SNPS_OK;
+}
+
+}  // extern "C"

@@ -201,3 +201,42 @@ CONFIGS = {
     # one rank's share of C4 (100 species x 4 Mb, 80 M reads over 8 GPUs)
     'c4_rank': dict(n_species=13, contigs_per_species=16, contig_len=250000, n_reads=10400000, seed=BASE_SEED + 4),
 }
+
+
+def write_sample(outdir, db_dir, contigs, reads, line_width=60, gz_fasta=False):
+    """Lay a synthetic dataset out on disk the way `run_midas.py snps --build_db --align` would leave it:
+    a minimal MIDAS DB (rep_genomes/<sp>/genome.fna + the files utility.check_database wants) and
+    <outdir>/snps/{species.txt,temp/genomes.fa,temp/genomes.bam}.  BAM @SQ order = contig-table order."""
+    import gzip
+    import os
+    from . import bam
+    os.makedirs(db_dir, exist_ok=True)
+    for d in ("marker_genes", "pan_genomes", "rep_genomes"):
+        os.makedirs(os.path.join(db_dir, d), exist_ok=True)
+    for f in ("species_info.txt", "genome_info.txt"):
+        with open(os.path.join(db_dir, f), "w") as h:
+            h.write("species_id\n" + "".join(s + "\n" for s in contigs.species_ids))
+    off = contigs.site_offsets()
+    for si, sp in enumerate(contigs.species_ids):
+        d = os.path.join(db_dir, "rep_genomes", sp)
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "genome.fna" + (".gz" if gz_fasta else ""))
+        opener = (lambda p: gzip.open(p, "wt")) if gz_fasta else (lambda p: open(p, "w"))
+        with opener(path) as h:
+            for k, cid in enumerate(contigs.ids):
+                if contigs.species[k] != si:
+                    continue
+                seq = bytes(contigs.ref[off[k]:off[k + 1]]).decode()
+                h.write(">%s synthetic contig %d\n" % (cid, k))
+                for o in range(0, len(seq), line_width):
+                    h.write(seq[o:o + line_width] + "\n")
+    os.makedirs(os.path.join(outdir, "snps", "temp"), exist_ok=True)
+    os.makedirs(os.path.join(outdir, "snps", "output"), exist_ok=True)
+    with open(os.path.join(outdir, "snps", "species.txt"), "w") as h:
+        h.write("".join(s + "\n" for s in contigs.species_ids))
+    with open(os.path.join(outdir, "snps", "temp", "genomes.fa"), "w") as h:
+        for k, cid in enumerate(contigs.ids):
+            h.write(">%s\n%s\n" % (cid, bytes(contigs.ref[off[k]:off[k + 1]]).decode().upper()))
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+    bam.write_bam(os.path.join(outdir, "snps", "temp", "genomes.bam"), contigs.ids,
+                  [int(x) for x in contigs.length], refid, reads)
