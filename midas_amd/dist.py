@@ -67,9 +67,9 @@ def all_gather_summary(rows):
     t = torch.from_numpy(rows)
     if on_gpu:
         t = t.cuda()
-    out = torch.empty((ws,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    return out.sum(dim=0).cpu().numpy()
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)     # rank-major concatenation along dim 0
+    return out.reshape((ws,) + tuple(t.shape)).sum(dim=0).cpu().numpy()
 
 
 def barrier():
