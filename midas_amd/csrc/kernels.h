@@ -25,8 +25,8 @@ struct IndexParams {
   const int32_t* contig_read_begin;  // [n_contigs + 1]
   const int32_t* contig_tile_base;   // [n_contigs + 1]
   const int32_t* contig_len;         // [n_contigs]
-  uint32_t* rbinv;                   // [n_tiles]  max over overlapping reads of (n_reads - index); 0 = none
-  uint32_t* rend;                    // [n_tiles]  max over overlapping reads of (index + 1)
+  uint32_t* rbinv;                   // [3*n_tiles] slots 3t (S), 3t+1 (G), 3t+2 (I), see index_reads.hip; max of (n_reads - index), 0 = none
+  uint32_t* rend;                    // [3*n_tiles] max of (index + 1)
   uint32_t* rbinv_next;              // the other parity's ranges: zeroed here for the next run
   uint32_t* rend_next;
   int32_t n_tiles;
@@ -55,6 +55,7 @@ struct PileupParams {
   const uint32_t* rbinv;             // this run's parity, read-only here
   const uint32_t* rend;
   const FilterTables* filt;
+  const uint32_t* orig;              // device record -> input index (read only when a record errs)
   uint32_t* out_counts;              // [n_sites][4]
   uint8_t* out_allele;               // [n_sites] or nullptr
   unsigned long long* stats;         // [n_species][4]

@@ -63,7 +63,8 @@ inline bool op_clip(uint32_t op) { return op == 4u || op == 5u; }              /
 // Decode-time facts about one record's CIGAR (layout.h kRec* bits).  The walk itself runs on the device;
 // these only say which of its fast paths applies, plus the one condition (kRecOverrun) under which the
 // reference would raise IndexError for a kept read.
-uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, int64_t contig_len) {
+uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, int64_t contig_len, int64_t* reflen) {
+  *reflen = l;
   if (nc == 1 && op_match(cg[0] & 15u) && (cg[0] >> 4) == l && l > 0) return kRecSimple;
   uint8_t f = 0;
   if (nc > 0) {
@@ -94,13 +95,14 @@ uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, in
       rpos += len;
     }
   }
+  *reflen = rpos - pos;
   return f;
 }
 
 }  // namespace
 
-int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, ReadRec* rec, uint8_t* blob,
-                   int64_t blob_capacity, PackSummary* out, char* err256) {
+int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
+                   uint8_t* blob, uint32_t* orig_index, int64_t blob_capacity, PackSummary* out, char* err256) {
   if (!r || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   const int64_t n = r->n_reads;
   *out = PackSummary{};
@@ -113,6 +115,18 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     set_err(err256, "NULL array in midas_snps_reads");
     return MIDAS_SNPS_ERR_INVALID_ARG;
   }
+
+  // Tiles (only when the caller asked for the tile-ordered device layout): first tile id of every contig.
+  const bool tiled = tile_len > 0 && contigs && contigs->n_contigs > 0;
+  std::vector<int64_t> tile_base;
+  if (tiled) {
+    tile_base.assign((size_t)contigs->n_contigs + 1, 0);
+    for (int32_t c = 0; c < contigs->n_contigs; ++c)
+      tile_base[c + 1] = tile_base[c] + (contigs->length[c] + tile_len - 1) / tile_len;
+  }
+  // 3 * owner tile + class: 0 = simple read inside one tile, 1 = any other read inside one tile,
+  // 2 = read reaching into a later tile ("straddler", either kind)
+  std::vector<uint32_t> key(tiled ? n : 0);
 
   // Pass 1: validate, classify the CIGAR, per-read payload size.
   std::vector<uint32_t> bytes(n);
@@ -154,8 +168,18 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         while (c + 1 < contigs->n_contigs && i >= contigs->read_begin[c + 1]) ++c;
         clen = contigs->length[c];
       }
-      const uint8_t f = cigar_flags(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->pos[i], clen);
+      int64_t reflen = 0;
+      const uint8_t f = cigar_flags(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->pos[i], clen, &reflen);
       cflags[i] = f;
+      if (tiled) {
+        int64_t pc = r->pos[i] < 0 ? 0 : r->pos[i];
+        pc = pc > clen - 1 ? clen - 1 : pc;
+        // same arithmetic as index_reads_kernel: first and last tile the record touches
+        int64_t pe = (int64_t)r->pos[i] + (reflen > 0 ? reflen : 1) - 1;
+        pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
+        const bool straddles = pe / tile_len != pc / tile_len;
+        key[i] = (uint32_t)(3 * (tile_base[c] + pc / tile_len) + (straddles ? 2 : ((f & kRecSimple) ? 0 : 1)));
+      }
       bytes[i] = blob_bytes((uint32_t)l, (f & kRecSimple) ? 0u : (uint32_t)nc);
       a += (l + 1) / 2 + l + 4 * nc + 16;
       ml = std::max<int32_t>(ml, (int32_t)l);
@@ -188,15 +212,31 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     return MIDAS_SNPS_ERR_INVALID_ARG;
   }
 
-  // Pass 2: offsets (serial prefix sum), then copy in parallel.
+  // Device order.  Within the window of every tile: the single-match ("simple") reads that stay inside the tile,
+  // then the other reads that stay inside it, then the reads that reach into a later tile -- each group in input
+  // order.  A wave of the pileup kernel then mostly works on reads of one kind, and the straddlers a later tile
+  // needs are one contiguous run at the end of the window.  A stable counting sort by (owner tile, class);
+  // reads never leave their contig because tiles do not span contigs.
+  std::vector<int64_t> order(n);
+  if (tiled) {
+    std::vector<int64_t> start((size_t)(3 * tile_base.back()) + 1, 0);
+    for (int64_t i = 0; i < n; ++i) start[key[i] + 1]++;
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    for (int64_t i = 0; i < n; ++i) order[start[key[i]]++] = i;
+  } else {
+    for (int64_t i = 0; i < n; ++i) order[i] = i;
+  }
+  // Pass 2: offsets (serial prefix sum in device order), then copy in parallel.
   std::vector<int64_t> off(n + 1);
   off[0] = 0;
-  for (int64_t i = 0; i < n; ++i) off[i + 1] = off[i] + bytes[i];
+  for (int64_t j = 0; j < n; ++j) off[j + 1] = off[j] + bytes[order[j]];
   parallel_ranges(n, [&](int, int64_t lo, int64_t hi) {
-    for (int64_t i = lo; i < hi; ++i) {
+    for (int64_t j = lo; j < hi; ++j) {
+      const int64_t i = order[j];
+      if (orig_index) orig_index[j] = (uint32_t)i;
       const uint32_t l = (uint32_t)r->l_seq[i];
       const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
-      uint8_t* b = blob + off[i];
+      uint8_t* b = blob + off[j];
       const uint8_t* q = r->qual + r->qual_off[i];
       memset(b, 0, bytes[i]);
       memcpy(b, q, l);
@@ -210,13 +250,13 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       if (!(cflags[i] & kRecSimple)) memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
       ReadRec rr;
       rr.pos = r->pos[i];
-      rr.blob_off8 = (uint32_t)(off[i] >> 3);
+      rr.blob_off8 = (uint32_t)(off[j] >> 3);
       rr.l_seq = (uint16_t)l;
       rr.n_cigar = (uint16_t)nc;
       rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
       rr.mapq = r->mapq[i];
       rr.flags = (uint8_t)(cflags[i] | ((l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0));
-      rec[i] = rr;
+      rec[j] = rr;
     }
   });
   {

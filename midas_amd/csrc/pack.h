@@ -13,8 +13,10 @@ struct PackSummary {
 // rec == blob == nullptr: size query only.  rec must hold n_reads + 1 records (sentinel).
 // `contigs` (may be nullptr) supplies the contig lengths the kRecOverrun flag is defined against;
 // without it every contig is taken as unbounded.
-int32_t pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, ReadRec* rec, uint8_t* blob,
-                   int64_t blob_capacity, PackSummary* out, char* err256);
+// tile_len > 0 (needs `contigs`): device order = per tile window [simple reads][other reads]; orig_index[j]
+// (nullable, n_reads entries) receives the input index of device record j.
+int32_t pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
+                   uint8_t* blob, uint32_t* orig_index, int64_t blob_capacity, PackSummary* out, char* err256);
 
 int32_t validate_contigs(const midas_snps_contigs* contigs, int64_t n_reads, int64_t* out_sites,
                          char* err256);

@@ -105,6 +105,9 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
 
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
+// the three read ranges of a tile as one virtual stream: range starts; |S|, |S|+|I|, |S|+|I|+|G|
+struct Ranges { int sb, ib, gb, ns, nsi, total; };
+
 template <int TILE_SHIFT>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
   constexpr int TILE = 1 << TILE_SHIFT;
@@ -151,15 +154,33 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   };
   // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead.  Nothing may be
   // computed from a loaded value here: any use would make the compiler drain the loads at once.
-  auto fetch_rec = [&](int b, int re) -> uint4 {
-    const int r = b + g;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (lane_used && r < re) v = recs[r];
-    return v;
+  // A tile's reads come as three index ranges (index_reads.hip): S = its simple reads that stay inside it,
+  // I = reads of earlier tiles reaching in, G = every other read that starts in it.  They are dealt to the waves
+  // as ONE virtual stream S, I, G: the leading wave-iterations are purely "simple", so the CIGAR-walk / clipping /
+  // segment-mask code is branched over (not masked through) for ~85 % of the reads, there is a single mixed
+  // iteration per tile, and the prefetch pipeline never restarts.
+  auto tile_ranges = [&](int tt) -> Ranges {
+    Ranges q;
+    const uint32_t vs = p.rbinv[3 * tt], vg = p.rbinv[3 * tt + 1], vi = p.rbinv[3 * tt + 2];
+    const int se = (int)p.rend[3 * tt], ge = (int)p.rend[3 * tt + 1], ie = (int)p.rend[3 * tt + 2];
+    q.sb = vs ? p.n_reads - (int)vs : se;
+    q.gb = vg ? p.n_reads - (int)vg : ge;
+    q.ib = vi ? p.n_reads - (int)vi : ie;
+    q.ns = se - q.sb;
+    q.nsi = q.ns + (ie - q.ib);
+    q.total = q.nsi + (ge - q.gb);
+    return q;
   };
-  auto fetch_payload = [&](const uint4& rv, int b, int re, Payload& d) {
-    const int r = b + g;
-    const bool act = lane_used && r < re;
+  // virtual stream position -> read index (n_reads = the sentinel record for positions past the end)
+  auto read_at = [&](const Ranges& q, int v) -> int {
+    const int r = v < q.ns ? q.sb + v : (v < q.nsi ? q.ib + (v - q.ns) : q.gb + (v - q.nsi));
+    return (lane_used && v < q.total) ? r : p.n_reads;
+  };
+  auto fetch_rec = [&](const Ranges& q, int it) -> uint4 { return recs[read_at(q, it * rpw + g)]; };
+
+  auto fetch_payload = [&](const uint4& rv, const Ranges& q, int it, Payload& d) {
+    const bool act = lane_used && it * rpw + g < q.total;
+    const bool pure_simple = (it + 1) * rpw <= q.ns;   // wave-uniform: no CIGAR to fetch
     const int l = rec_l(rv);
     const int n = rec_n(rv);
     const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
@@ -176,26 +197,20 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
       d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
-    if (act && !(rec_flags(rv) & kRecSimple) && n > 0) {
+    if (!pure_simple && act && !(rec_flags(rv) & kRecSimple) && n > 0) {
       const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
       const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
       d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
       if (n > 4) d.cl = cig[n - 1];   // n <= 4: the last op is one of cg[0..3], picked at use
     }
   };
-  auto tile_range = [&](int tt, int& rb, int& re) {
-    const uint32_t rbinv = p.rbinv[tt];
-    re = (int)p.rend[tt];
-    rb = rbinv ? p.n_reads - (int)rbinv : re;
-  };
-
+  constexpr int NWAVES = kPileupBlock / 64;
   Tile tile = p.tiles[t];
-  int rb, re;
-  tile_range(t, rb, re);
-  uint4 rec_cur = fetch_rec(rb + wave * rpw, re);
-  uint4 rec_nxt = fetch_rec(rb + wave * rpw + stride, re);
+  Ranges rg = tile_ranges(t);
+  uint4 rec_cur = fetch_rec(rg, wave);
+  uint4 rec_nxt = fetch_rec(rg, wave + NWAVES);
   Payload cur;
-  fetch_payload(rec_cur, rb + wave * rpw, re, cur);
+  fetch_payload(rec_cur, rg, wave, cur);
   __syncthreads();   // LDS zeroed, tables in place
 
   for (;;) {
@@ -203,14 +218,15 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int tile_start = tile.start;
     uint32_t w_aligned = 0, w_mapped = 0;
 
-    for (int base = rb + wave * rpw; base < re; base += stride) {
-      const uint4 rec_nn = fetch_rec(base + 2 * stride, re);
+    const int n_iter = (rg.total + rpw - 1) / rpw;
+    for (int it = wave; it < n_iter; it += NWAVES) {
+      const uint4 rec_nn = fetch_rec(rg, it + 2 * NWAVES);
       Payload nxt;
-      fetch_payload(rec_nxt, base + stride, re, nxt);
+      fetch_payload(rec_nxt, rg, it + NWAVES, nxt);
 
       // ================= process (rec_cur, cur) ===================================================
-      const int r = base + g;
-      bool act = lane_used && r < re;
+      const int r = read_at(rg, it * rpw + g);
+      bool act = r < p.n_reads;
       const int l = rec_l(rec_cur);
       const int n = rec_n(rec_cur);
       const int pos = rec_pos(rec_cur);
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const unsigned long long m_mp = __ballot(head && keep);
       w_aligned += (uint32_t)__popcll(m_al);
       w_mapped += (uint32_t)__popcll(m_mp);
-      if (head && err) atomicMin(p.err, ((unsigned long long)(uint32_t)r << 8) | err);
+      if (head && err) atomicMin(p.err, ((unsigned long long)p.orig[r] << 8) | err);   // input-order index of the record
 
       rec_cur = rec_nxt;
       rec_nxt = rec_nn;
@@ -392,12 +408,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int tn = t + (int)gridDim.x;
     const bool more = tn < p.n_tiles;
     Tile ntile = tile;
-    int nrb = 0, nre = 0;
+    Ranges nrg = rg;
     if (more) {
       ntile = p.tiles[tn];
-      tile_range(tn, nrb, nre);
-      rec_cur = fetch_rec(nrb + wave * rpw, nre);
-      rec_nxt = fetch_rec(nrb + wave * rpw + stride, nre);
+      nrg = tile_ranges(tn);
+      rec_cur = fetch_rec(nrg, wave);
+      rec_nxt = fetch_rec(nrg, wave + NWAVES);
     }
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         }
       }
     }
-    if (more) fetch_payload(rec_cur, nrb + wave * rpw, nre, cur);   // waits for the two record loads only
+    if (more) fetch_payload(rec_cur, nrg, wave, cur);   // waits for the two record loads only
 
     // ---- upper-cased ref allele, four sites per lane ---------------------------------------------------------
     if (p.out_allele && !(p.debug & 2)) {
@@ -458,8 +474,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     __syncthreads();   // LDS tallies re-zeroed and s_stats reset before the next tile's waves touch them
     t = tn;
     tile = ntile;
-    rb = nrb;
-    re = nre;
+    rg = nrg;
   }
 }
 

@@ -38,6 +38,7 @@ struct midas_snps_batch {
   int32_t* d_contig_len = nullptr;
   uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
   FilterTables* d_filt = nullptr;
+  uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
   FilterTables h_filt;
   bool filt_valid = false;
   double filt_mapid = 0, filt_aln_cov = 0;
@@ -79,10 +80,11 @@ int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
   } while (0)
 
 // tile ranges are double-buffered by run parity: [rbinv0][rend0][rbinv1][rend1]
-uint32_t* work_rbinv(midas_snps_batch* b, int par) { return reinterpret_cast<uint32_t*>(b->d_work) + (size_t)par * 2 * b->n_tiles; }
-uint32_t* work_rend(midas_snps_batch* b, int par) { return work_rbinv(b, par) + b->n_tiles; }
+// (each tile has three ranges, slots 3t..3t+2: see index_reads.hip)
+uint32_t* work_rbinv(midas_snps_batch* b, int par) { return reinterpret_cast<uint32_t*>(b->d_work) + (size_t)par * 6 * b->n_tiles; }
+uint32_t* work_rend(midas_snps_batch* b, int par) { return work_rbinv(b, par) + 3 * b->n_tiles; }
 unsigned long long* work_stats(midas_snps_batch* b) {
-  size_t off = ((size_t)b->n_tiles * 16 + 15) & ~(size_t)15;
+  size_t off = ((size_t)b->n_tiles * 48 + 15) & ~(size_t)15;
   return reinterpret_cast<unsigned long long*>(b->d_work + off);
 }
 unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
@@ -219,7 +221,7 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob, int64_t blob_capacity,
                               int64_t* out_blob_bytes, int32_t* out_max_l_seq, char* err256) {
   PackSummary s;
-  int32_t st = pack_reads(reads, contigs, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
+  int32_t st = pack_reads(reads, contigs, 0, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr,
                           blob_capacity, &s, err256);
   if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
   if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
@@ -238,6 +240,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   (void)hipFree(b->d_contig_len);
   (void)hipFree(b->d_work);
   (void)hipFree(b->d_filt);
+  (void)hipFree(b->d_orig);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_allele);
   for (auto& e : b->ev)
@@ -257,7 +260,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   PackSummary ps;
-  st = pack_reads(reads, contigs, nullptr, nullptr, 0, &ps, ebuf);
+  st = pack_reads(reads, contigs, 0, nullptr, nullptr, nullptr, 0, &ps, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -354,7 +357,13 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       return s;
     }
     memset(h_blob + ps.blob_bytes, 0, 64);
-    st = pack_reads(reads, contigs, h_rec, h_blob, (int64_t)blob_alloc, &ps, ebuf);
+    std::vector<uint32_t> h_orig((size_t)b->n_reads);
+    st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), (int64_t)blob_alloc, &ps, ebuf);
+    if (st == MIDAS_SNPS_OK) {
+      hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_reads * 4);
+      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
+      if (e0 != hipSuccess) { (void)hipHostFree(h_rec); (void)hipHostFree(h_blob); int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
+    }
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
     if (st == MIDAS_SNPS_OK) {
       e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
@@ -388,7 +397,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemcpy(b->d_contig_tile_base, tile_base.data(), nc1 * 4, hipMemcpyHostToDevice));
   if (contigs->n_contigs > 0)
     B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
-  b->work_bytes = (((size_t)b->n_tiles * 16 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
+  b->work_bytes = (((size_t)b->n_tiles * 48 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
   // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
   // error word are reset by the index kernel at the start of each run: no per-run memsets
@@ -475,6 +484,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.mapq = thr->mapq;
   pp.readq = thr->readq;
   pp.filt = b->d_filt;
+  pp.orig = b->d_orig;
   pp.table_len = b->max_l_seq + 1;
   pp.debug = getenv("MIDAS_SNPS_DEBUG") ? atoi(getenv("MIDAS_SNPS_DEBUG")) : 0;
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
