@@ -285,32 +285,16 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }                                            \
   } while (0)
 
-  // ---- tile length: a tile's reads are dealt to the workgroup's waves in rounds of `round_cap` reads, and a
-  // round costs the same whether it is full or nearly empty.  Pick the longest tile (<= kTileSites, the LDS
-  // budget) whose expected read count, plus two standard deviations, still fills a whole number of rounds.
+  // ---- tile length: the LDS budget (4096 sites x 16 B).  Shorter tiles were measured (configs[1], 10x): every
+  // tile pays fixed costs (two barriers, a pipeline restart, the halo re-read), and since a tile's reads are
+  // dealt to the waves as one stream the partly filled last round costs less than those.  MIDAS_SNPS_TILE_LEN
+  // overrides for experiments.
   {
-    const int64_t round_cap = (int64_t)(kPileupBlock / 64) * (64 / b->lanes_per_read);
-    const double rho = n_sites > 0 ? (double)reads->n_reads / (double)n_sites : 0.0;   // read starts per site
-    const double span = ps.max_l_seq;
     int32_t best = kTileSites;
-    if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) {
-      best = atoi(e);
-    } else if (rho > 0.0) {
-      double best_eff = 0.0;
-      for (int k = 1; k <= 64; ++k) {
-        const double n_max = (double)(k * round_cap);
-        const double n_tgt = n_max - 2.0 * sqrt(n_max);
-        double tl = n_tgt / rho - span;
-        if (tl > kTileSites) tl = kTileSites;
-        if (tl < 256) continue;
-        const double eff = tl / k;               // sites retired per round
-        if (eff > best_eff * 1.001) { best_eff = eff; best = (int32_t)tl & ~15; }
-        if (tl >= kTileSites) break;
-      }
-    }
+    if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) best = atoi(e);
     if (best < 64) best = 64;
     if (best > kTileSites) best = kTileSites;
-    b->tile_len = best;
+    b->tile_len = best & ~15;
   }
   const int64_t tile_len = b->tile_len;
   // ---- tile table -------------------------------------------------------------------------
