@@ -22,9 +22,8 @@ constexpr int MIDAS_STAT_DEPTH = 3;
 struct IndexParams {
   const ReadRec* rec;
   const uint8_t* blob;
-  const int32_t* contig_read_begin;  // [n_contigs + 1]
-  const int32_t* contig_tile_base;   // [n_contigs + 1]
-  const int32_t* contig_len;         // [n_contigs]
+  const uint32_t* key;               // [n_reads] tile << 7 | reach << 2 | class, from the packer
+  const Tile* tiles;
   uint32_t* rbinv;                   // [3*n_tiles] slots 3t (S), 3t+1 (G), 3t+2 (I), see index_reads.hip; max of (n_reads - index), 0 = none
   uint32_t* rend;                    // [3*n_tiles] max of (index + 1)
   uint32_t* rbinv_next;              // the other parity's ranges: zeroed here for the next run
@@ -33,7 +32,6 @@ struct IndexParams {
   unsigned long long* stats;         // [n_species][4]  zeroed here, accumulated by the pileup kernel
   unsigned long long* err;           // set to kNoError here
   int32_t n_reads;
-  int32_t n_contigs;
   int32_t n_stat_words;              // n_species * 4
   int32_t tile_len;                  // sites per tile of this batch (<= kTileSites)
 };

@@ -102,7 +102,8 @@ uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, in
 }  // namespace
 
 int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
-                   uint8_t* blob, uint32_t* orig_index, int64_t blob_capacity, PackSummary* out, char* err256) {
+                   uint8_t* blob, uint32_t* orig_index, uint32_t* key_out, int64_t blob_capacity, PackSummary* out,
+                   char* err256) {
   if (!r || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   const int64_t n = r->n_reads;
   *out = PackSummary{};
@@ -127,6 +128,8 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
   // 3 * owner tile + class: 0 = simple read inside one tile, 1 = any other read inside one tile,
   // 2 = read reaching into a later tile ("straddler", either kind)
   std::vector<uint32_t> key(tiled ? n : 0);
+  std::vector<uint32_t> tile_key_in(tiled && key_out ? n : 0);   // per input record; permuted into key_out below
+  uint32_t* const tile_key = tile_key_in.empty() ? nullptr : tile_key_in.data();
 
   // Pass 1: validate, classify the CIGAR, per-read payload size.
   std::vector<uint32_t> bytes(n);
@@ -177,8 +180,10 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         // same arithmetic as index_reads_kernel: first and last tile the record touches
         int64_t pe = (int64_t)r->pos[i] + (reflen > 0 ? reflen : 1) - 1;
         pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
-        const bool straddles = pe / tile_len != pc / tile_len;
-        key[i] = (uint32_t)(3 * (tile_base[c] + pc / tile_len) + (straddles ? 2 : ((f & kRecSimple) ? 0 : 1)));
+        const int64_t reach = pe / tile_len - pc / tile_len;
+        key[i] = (uint32_t)(3 * (tile_base[c] + pc / tile_len) + (reach > 0 ? 2 : ((f & kRecSimple) ? 0 : 1)));
+        if (tile_key) tile_key[i] = (uint32_t)(((tile_base[c] + pc / tile_len) << 7) | ((reach > 31 ? 31 : reach) << 2) |
+                                               (reach > 0 ? 2 : ((f & kRecSimple) ? 0 : 1)));
       }
       bytes[i] = blob_bytes((uint32_t)l, (f & kRecSimple) ? 0u : (uint32_t)nc);
       a += (l + 1) / 2 + l + 4 * nc + 16;
@@ -234,6 +239,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     for (int64_t j = lo; j < hi; ++j) {
       const int64_t i = order[j];
       if (orig_index) orig_index[j] = (uint32_t)i;
+      if (key_out && tile_key) key_out[j] = tile_key[i];
       const uint32_t l = (uint32_t)r->l_seq[i];
       const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
       uint8_t* b = blob + off[j];

@@ -14,9 +14,11 @@ struct PackSummary {
 // `contigs` (may be nullptr) supplies the contig lengths the kRecOverrun flag is defined against;
 // without it every contig is taken as unbounded.
 // tile_len > 0 (needs `contigs`): device order = per tile window [simple reads][other reads]; orig_index[j]
-// (nullable, n_reads entries) receives the input index of device record j.
+// (nullable, n_reads entries) receives the input index of device record j, key_out[j] (nullable) its index key
+// tile << 7 | min(reach, 31) << 2 | class (see index_reads.hip).
 int32_t pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
-                   uint8_t* blob, uint32_t* orig_index, int64_t blob_capacity, PackSummary* out, char* err256);
+                   uint8_t* blob, uint32_t* orig_index, uint32_t* key_out, int64_t blob_capacity, PackSummary* out,
+                   char* err256);
 
 int32_t validate_contigs(const midas_snps_contigs* contigs, int64_t n_reads, int64_t* out_sites,
                          char* err256);

@@ -39,6 +39,7 @@ struct midas_snps_batch {
   uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
   FilterTables* d_filt = nullptr;
   uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
+  uint32_t* d_key = nullptr;    // device record -> tile << 7 | reach << 2 | class (input of the index kernel)
   FilterTables h_filt;
   bool filt_valid = false;
   double filt_mapid = 0, filt_aln_cov = 0;
@@ -221,7 +222,7 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob, int64_t blob_capacity,
                               int64_t* out_blob_bytes, int32_t* out_max_l_seq, char* err256) {
   PackSummary s;
-  int32_t st = pack_reads(reads, contigs, 0, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr,
+  int32_t st = pack_reads(reads, contigs, 0, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr, nullptr,
                           blob_capacity, &s, err256);
   if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
   if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
@@ -241,6 +242,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   (void)hipFree(b->d_work);
   (void)hipFree(b->d_filt);
   (void)hipFree(b->d_orig);
+  (void)hipFree(b->d_key);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_allele);
   for (auto& e : b->ev)
@@ -260,7 +262,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   PackSummary ps;
-  st = pack_reads(reads, contigs, 0, nullptr, nullptr, nullptr, 0, &ps, ebuf);
+  st = pack_reads(reads, contigs, 0, nullptr, nullptr, nullptr, nullptr, 0, &ps, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -342,10 +344,13 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }
     memset(h_blob + ps.blob_bytes, 0, 64);
     std::vector<uint32_t> h_orig((size_t)b->n_reads);
-    st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), (int64_t)blob_alloc, &ps, ebuf);
+    std::vector<uint32_t> h_key((size_t)b->n_reads);
+    st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), h_key.data(), (int64_t)blob_alloc, &ps, ebuf);
     if (st == MIDAS_SNPS_OK) {
       hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_reads * 4);
       if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
+      if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_reads * 4);
+      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_key, h_key.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
       if (e0 != hipSuccess) { (void)hipHostFree(h_rec); (void)hipHostFree(h_blob); int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
     }
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
@@ -430,9 +435,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   IndexParams ip;
   ip.rec = b->d_rec;
   ip.blob = b->d_blob;
-  ip.contig_read_begin = b->d_contig_read_begin;
-  ip.contig_tile_base = b->d_contig_tile_base;
-  ip.contig_len = b->d_contig_len;
+  ip.key = b->d_key;
+  ip.tiles = b->d_tiles;
   const int par = (int)(b->run_count & 1);
   ip.rbinv = work_rbinv(b, par);
   ip.rend = work_rend(b, par);
@@ -442,7 +446,6 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.stats = work_stats(b);
   ip.err = work_err(b);
   ip.n_reads = (int32_t)b->n_reads;
-  ip.n_contigs = b->n_contigs;
   ip.n_stat_words = b->n_species * MIDAS_STATS;
   ip.tile_len = b->tile_len;
   HIP_TRY(ctx, launch_index_reads(ip, s));
