@@ -149,8 +149,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   struct Payload {
     uint32_t qw[NW];  // 32 quality bytes (zero beyond the end of the read: the blob is padded)
     uint32_t sw[4];   // 32 call codes
-    uint32_t cg[4];   // first four CIGAR ops (non-simple reads only)
-    uint32_t cl;      // last CIGAR op when n_cigar > 4
   };
   // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead.  Nothing may be
   // computed from a loaded value here: any use would make the compiler drain the loads at once.
@@ -187,8 +185,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
 #pragma unroll
     for (int w = 0; w < NW; ++w) d.qw[w] = 0u;
     d.sw[0] = d.sw[1] = d.sw[2] = d.sw[3] = 0u;
-    d.cg[0] = d.cg[1] = d.cg[2] = d.cg[3] = 0u;
-    d.cl = 0u;
     if (act && q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + q0);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + q0 + 16);
@@ -197,12 +193,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
       d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
-    if (!pure_simple && act && !(rec_flags(rv) & kRecSimple) && n > 0) {
-      const uint32_t* cig = reinterpret_cast<const uint32_t*>(bp + blob_cigar_off((uint32_t)l));
-      const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
-      d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
-      if (n > 4) d.cl = cig[n - 1];   // n <= 4: the last op is one of cg[0..3], picked at use
-    }
+    (void)pure_simple; (void)n;
   };
   constexpr int NWAVES = kPileupBlock / 64;
   Tile tile = p.tiles[t];
@@ -247,11 +238,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       // ---- soft-clip trimming ([EXT] pysam getQueryStart / getQueryEnd) ---------------------------
       int k0 = 0, lead_s = 0, trail_s = 0;
       const uint32_t* cig = nullptr;
+      uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u, cgl = 0u;   // first four CIGAR ops and the last one
       if (act && !simple) {
         cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l));
+        if (n > 0) {
+          // not prefetched (it would cost 10 VGPRs of the double-buffered payload): only the ~15 % mixed / general
+          // wave-iterations come here, the pure-simple ones branch over all of this
+          const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // may overhang into padding / next blob
+          cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
+          if (n > 4) cgl = cig[n - 1];
+        }
         if (!(flags & kRecClipGeneric)) {
-          if (n > 0 && (cur.cg[0] & 15u) == OP_S) { lead_s = (int)(cur.cg[0] >> 4); k0 = 1; }
-          const uint32_t last = n > 4 ? cur.cl : (n == 2 ? cur.cg[1] : (n == 3 ? cur.cg[2] : cur.cg[3]));
+          if (n > 0 && (cg0 & 15u) == OP_S) { lead_s = (int)(cg0 >> 4); k0 = 1; }
+          const uint32_t last = n > 4 ? cgl : (n == 2 ? cg1 : (n == 3 ? cg2 : cg3));
           if (n > 1 && (last & 15u) == OP_S) trail_s = (int)(last >> 4);
         } else {
           while (k0 < n) {
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       int jlo = 0, jhi = 0, loc0 = 0;
       auto next_segment = [&]() -> bool {
         while (k < n) {
-          const uint32_t v = k < 4 ? (k == 0 ? cur.cg[0] : (k == 1 ? cur.cg[1] : (k == 2 ? cur.cg[2] : cur.cg[3]))) : cig[k];
+          const uint32_t v = k < 4 ? (k == 0 ? cg0 : (k == 1 ? cg1 : (k == 2 ? cg2 : cg3))) : cig[k];
           ++k;
           const uint32_t op = v & 15u;
           const int len = (int)(v >> 4);
