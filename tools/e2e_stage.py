@@ -1,0 +1,48 @@
+"""Developer script (GPU box): end-to-end timing of the pileup STAGE (SURVEY 8d second timing):
+snps/temp/genomes.bam on disk -> <species>.snps.gz + summary.txt, phase by phase, through the same code
+`run_midas.py snps --pileup` runs.  usage: python tools/e2e_stage.py [config] [workdir]"""
+import gzip
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+from midas_amd import abi, synth  # noqa: E402
+from midas_amd.run import snps as msnps  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+work = sys.argv[2] if len(sys.argv) > 2 else '/tmp/midas_e2e'
+shutil.rmtree(work, ignore_errors=True)
+t0 = time.time()
+contigs, reads = synth.make_dataset(**synth.CONFIGS[cfg])
+out, db = os.path.join(work, 'sample'), os.path.join(work, 'db')
+synth.write_sample(out, db, contigs, reads)
+print("setup (generate + write FASTA/BAM, not part of the stage): %.1f s; BAM %.0f MB" % (
+    time.time() - t0, os.path.getsize(os.path.join(out, 'snps/temp/genomes.bam')) / 1e6), flush=True)
+
+args = dict(abi.DEFAULT_ARGS, outdir=out, db=db, build_db=False, threads=os.cpu_count(), gz_level=6,
+            log=open(os.devnull, 'w'))
+T = {}
+t = time.perf_counter(); species = msnps.initialize_species(args); cs = msnps.initialize_contigs(species); T['read FASTA'] = time.perf_counter() - t
+t = time.perf_counter(); decoded = abi.read_bam(os.path.join(out, 'snps/temp/genomes.bam')); T['BAM decode (native, parallel inflate)'] = time.perf_counter() - t
+ids = sorted(species)
+t = time.perf_counter(); table, sub = msnps._contig_table(ids, cs, *decoded); T['contig table + regroup'] = time.perf_counter() - t
+with abi.Context(0) as ctx:
+    thr = abi.Thresholds.from_args(args)
+    t = time.perf_counter(); b = ctx.batch(table, sub); T['pack + H2D (batch_create)'] = time.perf_counter() - t
+    t = time.perf_counter(); b.run(thr); b.sync(); T['device pass (index + pileup kernels)'] = time.perf_counter() - t
+    t = time.perf_counter(); counts, allele, stats = b.fetch(); T['D2H (counts, alleles, counters)'] = time.perf_counter() - t
+    b.close()
+t = time.perf_counter()
+for sp in ids:
+    msnps._write_species(args, sp, table, counts, allele)
+T['format + gzip rows (native, %d threads, level 6)' % args['threads']] = time.perf_counter() - t
+tot = sum(T.values())
+for k, v in T.items():
+    print("  %-52s %8.3f s  %5.1f %%" % (k, v, 100 * v / tot))
+print("  %-52s %8.3f s  -> %.3e sites/s end to end (%d sites, %d reads)" % ("TOTAL pileup stage", tot, contigs.n_sites / tot, contigs.n_sites, reads.n_reads))
+sz = sum(os.path.getsize(os.path.join(out, 'snps/output', f)) for f in os.listdir(os.path.join(out, 'snps/output')))
+print("  output: %.0f MB gz" % (sz / 1e6))
