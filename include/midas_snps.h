@@ -240,6 +240,43 @@ int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_
                               const uint8_t* allele, const uint32_t* counts, int32_t gz_level,
                               int32_t threads, char* err256);
 
+/* Parser of one sample's <species>.snps.gz: replaces read_run_midas_snps + the per-line split of
+ * build_temp_count_matrix (midas/merge/snps.py:236-271): per row the site key '|'.join(r[0:3]) and the counts
+ * r[-4:].  max_rows < 0 reads everything (args['max_sites']); want_keys == 0 skips the keys (only the first
+ * sample's are used, as in the reference).  key_off has rows+1 entries into the key bytes.            */
+typedef struct midas_snps_table midas_snps_table;
+int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_keys, midas_snps_table** out,
+                              char* err256);
+void midas_snps_table_close(midas_snps_table* table);
+int64_t midas_snps_table_rows(const midas_snps_table* table);
+int64_t midas_snps_table_key_bytes(const midas_snps_table* table);
+int32_t midas_snps_table_copy(const midas_snps_table* table, uint32_t* counts, char* keys, int64_t* key_off);
+
+/* ---- merge_midas.py snps: per-site cross-sample arithmetic (SURVEY 8f "next" #1) -------------------
+ * Replaces, for every genomic site of a species at once, GenomicSite.__init__/compute_pooled_counts,
+ * call_alleles, compute_per_sample_mafs, compute_prevalence and flag
+ * (midas/merge/snps.py:13-114, driven from build_sharded_tables :324-364).  Annotation (:116-174) and the
+ * text emission (:176-201) stay on the host.  Inputs are the samples' per-site count tables -- exactly what
+ * the pileup stage emits -- and each sample's mean_coverage (midas/merge/merge.py:18-21).          */
+typedef struct midas_merge_params {
+  double allele_freq;   /* args['allele_freq']: freq >= allele_freq counts an allele as present (0.01)   */
+  double site_ratio;    /* args['site_ratio']:  site_depth/mean_depth > site_ratio fails the sample (2.0) */
+  double site_prev;     /* args['site_prev']:   prevalence < site_prev flags the site (0.95)              */
+  int32_t site_depth;   /* args['site_depth']:  site_depth < site_depth fails the sample (1)              */
+  int32_t snp_types;    /* args['snp_type'] as a bit set: 1 any, 2 mono, 4 bi, 8 tri, 16 quad             */
+} midas_merge_params;
+#define MIDAS_MERGE_ERR_ZERO_MEAN_DEPTH 7 /* ZeroDivisionError in compute_prevalence (snps.py:99) */
+/* sample_counts[s] -> [n_sites*4] u32 (A,C,G,T per site) of sample s, host memory; mean_depth[s] = float(mean_coverage).
+ * Outputs (host, caller-owned): major/minor [n_sites] (0..3 = A,C,G,T, 255 = None), snp_type [n_sites]
+ * (0 None, 1 mono, 2 bi, 3 tri, 4 quad), flag [n_sites] (0 keep, 1 'min_prev', 2 'snp_type'),
+ * count_samples [n_sites], pooled [n_sites*4] u64, depth and minor_count [n_samples*n_sites] u32
+ * (sample_depths and the numerator of sample_mafs; maf = float(minor_count)/depth if depth > 0 else 0.0).
+ * out_kernel_ms (nullable): device time of the kernel(s), HIP events.                                */
+int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_params* params, int32_t n_samples, int64_t n_sites,
+                          const uint32_t* const* sample_counts, const double* mean_depth, uint8_t* out_major,
+                          uint8_t* out_minor, uint8_t* out_snp_type, uint8_t* out_flag, uint32_t* out_count_samples,
+                          uint64_t* out_pooled, uint32_t* out_depth, uint32_t* out_minor_count, float* out_kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,27 @@ class Thresholds(C.Structure):
 
 DEFAULT_ARGS = {'mapid': 94.0, 'mapq': 20, 'baseq': 30, 'readq': 20, 'aln_cov': 0.75}
 
+ERR_MERGE_ZERO_MEAN_DEPTH = 7
+SNP_TYPE_BITS = {'any': 1, 'mono': 2, 'bi': 4, 'tri': 8, 'quad': 16}
+SNP_TYPE_NAMES = [None, 'mono', 'bi', 'tri', 'quad']
+
+
+class MergeParams(C.Structure):
+    """scripts/merge_midas.py:229-252 (site filters) as the kernel takes them."""
+    _fields_ = [("allele_freq", C.c_double), ("site_ratio", C.c_double), ("site_prev", C.c_double),
+                ("site_depth", C.c_int32), ("snp_types", C.c_int32)]
+
+    @classmethod
+    def from_args(cls, args: dict) -> "MergeParams":
+        bits = 0
+        for t in args['snp_type']:
+            bits |= SNP_TYPE_BITS[t]
+        return cls(float(args['allele_freq']), float(args['site_ratio']), float(args['site_prev']),
+                   int(args['site_depth']), bits)
+
+
+DEFAULT_MERGE_ARGS = {'snp_type': ['bi'], 'allele_freq': 0.01, 'site_depth': 1, 'site_ratio': 2.0, 'site_prev': 0.95}
+
 
 class _Reads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("pos", C.c_void_p), ("mapq", C.c_void_p), ("flag", C.c_void_p),
@@ -199,6 +220,12 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
+        'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
+        'midas_snps_table_close': (None, [vp]),
+        'midas_snps_table_rows': (i64, [vp]),
+        'midas_snps_table_key_bytes': (i64, [vp]),
+        'midas_snps_table_copy': (i32, [vp, vp, vp, vp]),
+        'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 8 + [C.POINTER(C.c_float)]),
     })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
@@ -220,6 +247,8 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pack_reads',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
     'midas_snps_write_rows',
+    'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
+    'midas_snps_table_copy', 'midas_merge_sites',
 ]
 
 
@@ -236,6 +265,26 @@ def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts:
                                    int(gz_level), int(threads), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
+
+
+def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True):
+    """Parse one <species>.snps.gz with the native reader -> (counts[n,4] u32, keys bytes | None, key_off | None)."""
+    lib = load_library()
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_table_open(path.encode(), int(max_rows), 1 if want_keys else 0, C.byref(h), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    try:
+        n = int(lib.midas_snps_table_rows(h))
+        counts = np.empty((n, 4), np.uint32)
+        keys = np.empty(int(lib.midas_snps_table_key_bytes(h)), np.uint8) if want_keys else None
+        key_off = np.empty(n + 1, np.int64) if want_keys else None
+        p = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None
+        lib.midas_snps_table_copy(h, p(counts), p(keys), p(key_off))
+    finally:
+        lib.midas_snps_table_close(h)
+    return counts, (keys.tobytes() if want_keys else None), key_off
 
 
 def read_bam(path: str):
@@ -352,6 +401,27 @@ class Context:
                                          stats.ctypes.data_as(C.c_void_p))
         self._check(st)
         return counts, allele, stats
+
+    def merge_sites(self, prm: "MergeParams", sample_counts, mean_depth):
+        """midas_merge_sites(): sample_counts = list of [n_sites,4] uint32 arrays (one per sample).
+        -> dict(major, minor, snp_type, flag, count_samples, pooled[n,4] u64, depth[S,n] u32, minor_count[S,n] u32, kernel_ms)"""
+        S = len(sample_counts)
+        arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in sample_counts]
+        n = arrs[0].shape[0]
+        assert all(a.shape == (n, 4) for a in arrs)
+        ptrs = (C.c_void_p * S)(*[a.ctypes.data for a in arrs])
+        md = np.ascontiguousarray(mean_depth, dtype=np.float64)
+        out = dict(major=np.empty(n, np.uint8), minor=np.empty(n, np.uint8), snp_type=np.empty(n, np.uint8),
+                   flag=np.empty(n, np.uint8), count_samples=np.empty(n, np.uint32), pooled=np.empty((n, 4), np.uint64),
+                   depth=np.empty((S, n), np.uint32), minor_count=np.empty((S, n), np.uint32))
+        ms = C.c_float(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_merge_sites(self._h, C.byref(prm), S, n, ptrs, p(md), p(out['major']), p(out['minor']),
+                                         p(out['snp_type']), p(out['flag']), p(out['count_samples']), p(out['pooled']),
+                                         p(out['depth']), p(out['minor_count']), C.byref(ms))
+        self._check(st)
+        out['kernel_ms'] = float(ms.value)
+        return out
 
     def batch(self, contigs: ContigTable, reads: ReadsSoA) -> "Batch":
         return Batch(self, contigs, reads)

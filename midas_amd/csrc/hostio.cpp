@@ -31,6 +31,13 @@ struct midas_bam {
   bool loaded = false;
 };
 
+// One sample's <species>.snps.gz, parsed: what build_temp_count_matrix (midas/merge/snps.py:246-271) extracts.
+struct midas_snps_table {
+  std::vector<uint32_t> counts;    // [rows][4]   r[-4:]
+  std::string keys;                // 'ref_id|ref_pos|ref_allele' of every row, back to back
+  std::vector<int64_t> key_off;    // [rows + 1]
+};
+
 namespace {
 
 void set_err(char* err256, const char* fmt, const char* a = "", long long b = 0) {
@@ -333,6 +340,98 @@ int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t
   cp(cigar_off, b->cigar_off.data(), (n + 1) * 8);
   cp(seq4, b->seq4.data(), b->seq4.size()); cp(qual, b->qual.data(), b->qual.size());
   cp(cigar, b->cigar.data(), b->cigar.size() * 4);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_keys, midas_snps_table** out,
+                              char* err256) {
+  if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  gzFile f = gzopen(path, "rb");   // transparently reads concatenated gzip members
+  if (!f) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  gzbuffer(f, 1 << 20);
+  midas_snps_table* t = new (std::nothrow) midas_snps_table();
+  if (!t) { gzclose(f); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  t->key_off.push_back(0);
+  std::vector<char> buf(1 << 22);
+  std::string carry;
+  bool header = true;
+  int64_t rows = 0;
+  bool stop = (max_rows == 0);
+  auto parse_line = [&](const char* b, const char* e) -> bool {   // [b, e) without the newline
+    if (header) { header = false; return true; }
+    // fields: ref_id, ref_pos, ref_allele, depth, count_a, count_c, count_g, count_t (tab separated);
+    // the reference takes r[0:3] for the site key and r[-4:] for the counts
+    const char* tabs[16];
+    int nt = 0;
+    for (const char* q = b; q < e && nt < 16; ++q)
+      if (*q == '\t') tabs[nt++] = q;
+    if (nt < 7) return false;
+    if (want_keys) {
+      t->keys.append(b, tabs[0]);
+      t->keys.push_back('|');
+      t->keys.append(tabs[0] + 1, tabs[1]);
+      t->keys.push_back('|');
+      t->keys.append(tabs[1] + 1, tabs[2]);
+      t->key_off.push_back((int64_t)t->keys.size());
+    }
+    const char* starts[4] = {tabs[nt - 4] + 1, tabs[nt - 3] + 1, tabs[nt - 2] + 1, tabs[nt - 1] + 1};
+    const char* ends[4] = {tabs[nt - 3], tabs[nt - 2], tabs[nt - 1], e};
+    for (int k = 0; k < 4; ++k) {
+      uint64_t v = 0;
+      if (starts[k] >= ends[k]) return false;
+      for (const char* q = starts[k]; q < ends[k]; ++q) {
+        if (*q < '0' || *q > '9') return false;
+        v = v * 10 + (uint64_t)(*q - '0');
+        if (v > 0x7FFFFFFFull) return false;   // major + minor of one sample must fit 32 bits downstream
+      }
+      t->counts.push_back((uint32_t)v);
+    }
+    ++rows;
+    if (max_rows >= 0 && rows >= max_rows) stop = true;
+    return true;
+  };
+  bool ok = true;
+  while (!stop) {
+    const int n = gzread(f, buf.data(), (unsigned)buf.size());
+    if (n < 0) { ok = false; break; }
+    if (n == 0) break;
+    const char* b = buf.data();
+    const char* end = b + n;
+    while (b < end && !stop) {
+      const char* nl = (const char*)memchr(b, '\n', (size_t)(end - b));
+      if (!nl) { carry.append(b, end); b = end; break; }
+      if (!carry.empty()) {
+        carry.append(b, nl);
+        ok = parse_line(carry.data(), carry.data() + carry.size());
+        carry.clear();
+      } else {
+        ok = parse_line(b, nl);
+      }
+      if (!ok) break;
+      b = nl + 1;
+    }
+    if (!ok) break;
+  }
+  if (ok && !stop && !carry.empty()) ok = parse_line(carry.data(), carry.data() + carry.size());
+  gzclose(f);
+  if (!ok) {
+    set_err(err256, "%s: malformed row %lld", path, (long long)rows + 1);
+    delete t;
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
+  *out = t;
+  return MIDAS_SNPS_OK;
+}
+
+void midas_snps_table_close(midas_snps_table* t) { delete t; }
+int64_t midas_snps_table_rows(const midas_snps_table* t) { return t ? (int64_t)(t->counts.size() / 4) : 0; }
+int64_t midas_snps_table_key_bytes(const midas_snps_table* t) { return t ? (int64_t)t->keys.size() : 0; }
+int32_t midas_snps_table_copy(const midas_snps_table* t, uint32_t* counts, char* keys, int64_t* key_off) {
+  if (!t) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (counts && !t->counts.empty()) memcpy(counts, t->counts.data(), t->counts.size() * 4);
+  if (keys && !t->keys.empty()) memcpy(keys, t->keys.data(), t->keys.size());
+  if (key_off) memcpy(key_off, t->key_off.data(), t->key_off.size() * 8);
   return MIDAS_SNPS_OK;
 }
 

@@ -1,0 +1,203 @@
+// `merge_midas.py snps` on MI355X: the per-site cross-sample arithmetic of GenomicSite
+// (/root/reference/midas/merge/snps.py:13-114): pooled counts, major/minor allele call, snp_type,
+// per-sample depth / minor-allele count, prevalence and the site flag.  One thread per site, streaming over the
+// samples' count tables ([sample][site][A,C,G,T] u32, i.e. exactly what the pileup stage emits): HBM-bound,
+// 2 x 16 B read + 8 B written per (site, sample).  Annotation and text emission stay on the host.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../../include/midas_snps.h"
+#include "ctx_internal.h"
+
+namespace {
+
+struct MergeKParams {
+  const uint32_t* counts;     // [n_samples][n_sites][4]
+  const double* mean_depth;   // [n_samples]
+  uint8_t* major;             // [n_sites] 0..3 = A,C,G,T; 255 = None
+  uint8_t* minor;
+  uint8_t* snp_type;          // 0 None, 1 mono, 2 bi, 3 tri, 4 quad
+  uint8_t* flag;              // 0 keep, 1 min_prev, 2 snp_type
+  uint32_t* count_samples;
+  unsigned long long* pooled; // [n_sites][4]
+  uint32_t* depth;            // [n_samples][n_sites]  major + minor count
+  uint32_t* minor_count;      // [n_samples][n_sites]
+  unsigned long long* err;    // lowest site where the reference would raise ZeroDivisionError, else ~0
+  long long n_sites;
+  int n_samples;
+  int site_depth;
+  int snp_types;
+  double allele_freq, site_ratio, site_prev;
+};
+
+__global__ __launch_bounds__(256) void merge_sites_kernel(MergeKParams p) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n_sites; i += stride) {
+    const uint4* cnt = reinterpret_cast<const uint4*>(p.counts) + i;
+    unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
+    for (int s = 0; s < p.n_samples; ++s) {                      // compute_pooled_counts (:42-47)
+      const uint4 c = cnt[(size_t)s * p.n_sites];
+      pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
+    }
+    const unsigned long long pooled_depth = pc[0] + pc[1] + pc[2] + pc[3];
+    int major = 255, minor = 255, snp = 0;
+    if (pooled_depth > 0) {                                      // call_alleles (:49-76)
+      // stable descending sort of the four alleles by frequency; count/depth is strictly monotone in count, so
+      // sorting by count is the same order, and ties keep A,C,G,T order (Python's sorted is stable)
+      int ord[4] = {0, 1, 2, 3};
+#pragma unroll
+      for (int a = 1; a < 4; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+          if (pc[ord[b]] > pc[ord[b - 1]]) { const int t = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = t; }
+        }
+      }
+      const double d = (double)pooled_depth;
+      const double f0 = (double)pc[ord[0]] / d, f1 = (double)pc[ord[1]] / d, f2 = (double)pc[ord[2]] / d,
+                   f3 = (double)pc[ord[3]] / d;
+      if (f0 > 0) major = ord[0];
+      if (f1 > 0) minor = ord[1];
+      if (f3 >= p.allele_freq) snp = 4;
+      else if (f2 >= p.allele_freq) snp = 3;
+      else if (f1 >= p.allele_freq) snp = 2;
+      else if (f0 >= p.allele_freq) snp = 1;
+    }
+    // compute_per_sample_mafs (:78-91) + compute_prevalence (:93-104)
+    uint32_t pass = 0;
+    bool zero_div = false;
+    for (int s = 0; s < p.n_samples; ++s) {
+      const uint4 c = cnt[(size_t)s * p.n_sites];
+      const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+      unsigned long long sd = 0;
+      uint32_t mc = 0;
+      if (major != 255) {
+        sd = cc[major];
+        if (minor != 255) { mc = cc[minor]; sd += mc; }
+      }
+      p.depth[(size_t)s * p.n_sites + i] = (uint32_t)sd;
+      p.minor_count[(size_t)s * p.n_sites + i] = mc;
+      if ((long long)sd < (long long)p.site_depth) continue;
+      const double md = p.mean_depth[s];
+      if (md == 0.0) { zero_div = true; continue; }              // Python: ZeroDivisionError
+      if ((double)sd / md > p.site_ratio) continue;
+      ++pass;
+    }
+    const double prevalence = (double)pass / (double)p.n_samples;
+    int flag = 0;                                                // flag (:106-114)
+    if (prevalence < p.site_prev) flag = 1;
+    else if (!(p.snp_types & 1) && !(snp > 0 && (p.snp_types & (1 << snp)))) flag = 2;
+    p.major[i] = (uint8_t)major;
+    p.minor[i] = (uint8_t)minor;
+    p.snp_type[i] = (uint8_t)snp;
+    p.flag[i] = (uint8_t)flag;
+    p.count_samples[i] = pass;
+    reinterpret_cast<ulonglong2*>(p.pooled)[2 * i] = make_ulonglong2(pc[0], pc[1]);
+    reinterpret_cast<ulonglong2*>(p.pooled)[2 * i + 1] = make_ulonglong2(pc[2], pc[3]);
+    if (zero_div) atomicMin(p.err, (unsigned long long)i);
+  }
+}
+
+int32_t mfail(midas_snps_ctx* ctx, int32_t st, const char* what, hipError_t e) {
+  char buf[384];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  ctx->err = buf;
+  return st;
+}
+
+}  // namespace
+
+#define M_TRY(call)                                                                                             \
+  do {                                                                                                          \
+    hipError_t e__ = (call);                                                                                    \
+    if (e__ != hipSuccess) {                                                                                    \
+      for (void* q__ : dev) (void)hipFree(q__);                                                                 \
+      return mfail(ctx, e__ == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP, #call, e__); \
+    }                                                                                                           \
+  } while (0)
+
+extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_params* prm, int32_t n_samples,
+                                     int64_t n_sites, const uint32_t* const* sample_counts, const double* mean_depth,
+                                     uint8_t* out_major, uint8_t* out_minor, uint8_t* out_snp_type, uint8_t* out_flag,
+                                     uint32_t* out_count_samples, uint64_t* out_pooled, uint32_t* out_depth,
+                                     uint32_t* out_minor_count, float* out_kernel_ms) {
+  if (!ctx || !prm || n_samples <= 0 || n_sites < 0 || !sample_counts || !mean_depth || !out_major || !out_minor ||
+      !out_snp_type || !out_flag || !out_count_samples || !out_pooled || !out_depth || !out_minor_count)
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  ctx->err.clear();
+  ctx->err_read = -1;
+  if (out_kernel_ms) *out_kernel_ms = 0.f;
+  std::vector<void*> dev;
+  M_TRY(hipSetDevice(ctx->device));
+  // sites are processed in chunks so that any number of samples fits: <= ~4 GiB of count tables at a time
+  long long chunk = (long long)((4ull << 30) / (16ull * (unsigned long long)n_samples));
+  if (chunk < 1024) chunk = 1024;
+  if (chunk > n_sites) chunk = n_sites > 0 ? n_sites : 1;
+  uint32_t* d_counts = nullptr; double* d_md = nullptr; uint8_t* d_b = nullptr; uint32_t* d_cs = nullptr;
+  unsigned long long* d_pool = nullptr; uint32_t* d_depth = nullptr; uint32_t* d_mc = nullptr; unsigned long long* d_err = nullptr;
+  M_TRY(hipMalloc(&d_counts, (size_t)chunk * n_samples * 16)); dev.push_back(d_counts);
+  M_TRY(hipMalloc(&d_md, (size_t)n_samples * 8)); dev.push_back(d_md);
+  M_TRY(hipMalloc(&d_b, (size_t)chunk * 4)); dev.push_back(d_b);
+  M_TRY(hipMalloc(&d_cs, (size_t)chunk * 4)); dev.push_back(d_cs);
+  M_TRY(hipMalloc(&d_pool, (size_t)chunk * 32)); dev.push_back(d_pool);
+  M_TRY(hipMalloc(&d_depth, (size_t)chunk * n_samples * 4)); dev.push_back(d_depth);
+  M_TRY(hipMalloc(&d_mc, (size_t)chunk * n_samples * 4)); dev.push_back(d_mc);
+  M_TRY(hipMalloc(&d_err, 8)); dev.push_back(d_err);
+  M_TRY(hipMemcpy(d_md, mean_depth, (size_t)n_samples * 8, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  M_TRY(hipEventCreate(&e0));
+  M_TRY(hipEventCreate(&e1));
+  float total_ms = 0.f;
+  int32_t status = MIDAS_SNPS_OK;
+  for (long long lo = 0; lo < n_sites && status == MIDAS_SNPS_OK; lo += chunk) {
+    const long long m = (n_sites - lo) < chunk ? (n_sites - lo) : chunk;
+    for (int s = 0; s < n_samples; ++s)
+      M_TRY(hipMemcpyAsync(d_counts + (size_t)s * m * 4, sample_counts[s] + (size_t)lo * 4, (size_t)m * 16,
+                           hipMemcpyHostToDevice, ctx->stream));
+    M_TRY(hipMemsetAsync(d_err, 0xFF, 8, ctx->stream));
+    MergeKParams k;
+    k.counts = d_counts; k.mean_depth = d_md;
+    k.major = d_b; k.minor = d_b + m; k.snp_type = d_b + 2 * m; k.flag = d_b + 3 * m;
+    k.count_samples = d_cs; k.pooled = d_pool; k.depth = d_depth; k.minor_count = d_mc; k.err = d_err;
+    k.n_sites = m; k.n_samples = n_samples; k.site_depth = prm->site_depth; k.snp_types = prm->snp_types;
+    k.allele_freq = prm->allele_freq; k.site_ratio = prm->site_ratio; k.site_prev = prm->site_prev;
+    const int grid = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
+    M_TRY(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(merge_sites_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ctx->stream, k);
+    M_TRY(hipGetLastError());
+    M_TRY(hipEventRecord(e1, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_major + lo, k.major, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_minor + lo, k.minor, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_snp_type + lo, k.snp_type, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_flag + lo, k.flag, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_count_samples + lo, d_cs, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipMemcpyAsync(out_pooled + lo * 4, d_pool, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    for (int s = 0; s < n_samples; ++s) {
+      M_TRY(hipMemcpyAsync(out_depth + (size_t)s * n_sites + lo, d_depth + (size_t)s * m, (size_t)m * 4,
+                           hipMemcpyDeviceToHost, ctx->stream));
+      M_TRY(hipMemcpyAsync(out_minor_count + (size_t)s * n_sites + lo, d_mc + (size_t)s * m, (size_t)m * 4,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    }
+    unsigned long long err = ~0ull;
+    M_TRY(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    M_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    M_TRY(hipEventElapsedTime(&ms, e0, e1));
+    total_ms += ms;
+    if (err != ~0ull) {
+      char buf[200];
+      ctx->err_read = (int64_t)(lo + (long long)err);
+      snprintf(buf, sizeof buf, "site %lld: a sample with mean_coverage 0 reached site_depth/mean_depth "
+               "(reference: ZeroDivisionError in compute_prevalence)", (long long)ctx->err_read + 1);
+      ctx->err = buf;
+      status = MIDAS_MERGE_ERR_ZERO_MEAN_DEPTH;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (void* q : dev) (void)hipFree(q);
+  if (out_kernel_ms) *out_kernel_ms = total_ms;
+  return status;
+}

@@ -11,20 +11,12 @@
 #include <vector>
 
 #include "../../include/midas_snps.h"
+#include "ctx_internal.h"
 #include "kernels.h"
 #include "layout.h"
 #include "pack.h"
 
 using namespace midas;
-
-struct midas_snps_ctx {
-  int device = -1;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  std::string err;
-  int64_t err_read = -1;
-  hipDeviceProp_t prop;
-};
 
 struct midas_snps_batch {
   midas_snps_ctx* ctx = nullptr;

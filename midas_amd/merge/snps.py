@@ -1,0 +1,143 @@
+"""MI355X-native `merge_midas.py snps`: the host side (SURVEY.md 8f "next" #1).
+
+Mirrors /root/reference/midas/merge/snps.py: same outputs (<outdir>/<species>/snps_{info,freq,depth,summary}.txt,
+readme.txt), same site numbering and filters.  What changes underneath: the per-site cross-sample arithmetic of
+GenomicSite (pooled counts, allele calls, per-sample depth/MAF, prevalence, flag -- :13-114) runs on the GPU for all
+sites of a species at once (midas_merge_sites in include/midas_snps.h); the temporary acgt_counts matrices and the
+per-thread shard files of the reference are not needed.  Annotation (:116-174) and text emission (:176-201) stay on
+the host and touch only the sites that survive the filters.  No CPU fallback for the arithmetic.
+"""
+
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from midas_amd import abi, dist
+from midas_amd.merge import annotate, merge
+
+
+def replace_none(input_string, replace_string="NA"):
+    return input_string if input_string is not None else replace_string
+
+
+INFO_FIELDS = ['site_id', 'ref_id', 'ref_pos', 'ref_allele', 'major_allele', 'minor_allele', 'count_samples',
+               'count_a', 'count_c', 'count_g', 'count_t', 'locus_type', 'gene_id', 'snp_type', 'site_type', 'amino_acids']
+
+
+def write_merge_midas(species, args):
+    """Open output files for species, write headers -- midas/merge/snps.py:291-322"""
+    files = {}
+    for ftype in ['info', 'freq', 'depth']:
+        files[ftype] = open('%s/%s/snps_%s.txt' % (args['outdir'], species.id, ftype), 'w')
+    for ftype in ['freq', 'depth']:
+        record = ['site_id'] + [s.id for s in species.samples]
+        files[ftype].write('\t'.join(record) + '\n')
+    files['info'].write('\t'.join(INFO_FIELDS) + '\n')
+    return files
+
+
+def load_sample_tables(species, args):
+    """read_run_midas_snps + the zip of build_temp_count_matrix (midas/merge/snps.py:236-271), without the
+    temporary matrices: per sample the [n_sites,4] counts, plus the site keys of the first sample."""
+    max_rows = -1 if args['max_sites'] == float('Inf') else int(args['max_sites'])
+    paths = ['%s/snps/output/%s.snps.gz' % (s.dir, species.id) for s in species.samples]
+    nthreads = max(1, min(len(paths), int(args.get('threads', 1) or 1)))
+    with ThreadPoolExecutor(nthreads) as ex:
+        futs = [ex.submit(abi.read_snps_table, p, max_rows, i == 0) for i, p in enumerate(paths)]
+        tabs = [f.result() for f in futs]
+    n = min(t[0].shape[0] for t in tabs)     # the reference's zip stops at the shortest file
+    counts = [np.ascontiguousarray(t[0][:n]) for t in tabs]
+    return counts, tabs[0][1], tabs[0][2][:n + 1]
+
+
+def merge_species(species, args, ctx):
+    """build_sharded_tables + merge_sharded_tables (midas/merge/snps.py:324-420) for one species."""
+    counts, keys, key_off = load_sample_tables(species, args)
+    n = counts[0].shape[0]
+    prm = abi.MergeParams.from_args(args)
+    try:
+        res = ctx.merge_sites(prm, counts, species.sample_depth)
+    except abi.MidasSnpsError as e:
+        sys.exit("\nError: %s\n" % e.message)
+    files = write_merge_midas(species, args)
+    genes = annotate.GeneCursor.from_db(species.id, args['db'])
+    keep = np.nonzero(res['flag'] == 0)[0]
+    alle = 'ACGT'
+    depth = res['depth']
+    minor = res['minor_count']
+    for i in keep:
+        i = int(i)
+        key = keys[key_off[i]:key_off[i + 1]].decode()
+        ref_id, ref_pos, ref_allele = key.rsplit('|', 2)
+        site_id = str(i + 1)
+        mj, mn = int(res['major'][i]), int(res['minor'][i])
+        locus_type, gene_id, site_type, amino_acids = genes.lookup(ref_id, int(ref_pos))
+        pooled = res['pooled'][i]
+        info = [site_id, ref_id, str(int(ref_pos)), ref_allele,
+                alle[mj] if mj < 4 else None, alle[mn] if mn < 4 else None, str(int(res['count_samples'][i])),
+                str(int(pooled[0])), str(int(pooled[1])), str(int(pooled[2])), str(int(pooled[3])),
+                locus_type, gene_id, abi.SNP_TYPE_NAMES[int(res['snp_type'][i])], site_type, amino_acids]
+        files['info'].write('\t'.join([replace_none(_) for _ in info]) + '\n')
+        d = depth[:, i]
+        m = minor[:, i]
+        mafs = [float(m[s]) / int(d[s]) if (mn < 4 and d[s] > 0) else 0.0 for s in range(len(counts))]
+        files['freq'].write(site_id + '\t' + '\t'.join(['{0:.3g}'.format(f) for f in mafs]) + '\n')
+        files['depth'].write(site_id + '\t' + '\t'.join([str(int(x)) for x in d]) + '\n')
+    for f in files.values():
+        f.close()
+    return n, len(keep), res['kernel_ms']
+
+
+def write_snps_readme(args, sp):
+    """midas/merge/snps.py:422-468 (abridged to the file descriptions)"""
+    outfile = open('%s/%s/readme.txt' % (args['outdir'], sp.id), 'w')
+    outfile.write("""
+Description of output files and file formats from 'merge_midas.py snps'
+
+Output files
+############
+snps_freq.txt
+  frequency of minor allele per genomic site and per sample
+snps_depth.txt
+  number of reads mapped to genomic site per sample (major + minor allele)
+snps_info.txt
+  metadata for genomic site: site_id ref_id ref_pos ref_allele major_allele minor_allele count_samples
+  count_a count_c count_g count_t locus_type gene_id snp_type site_type amino_acids
+snps_summary.txt
+  alignment summary statistics per sample
+
+Additional information for species can be found in the reference database:
+ %s/rep_genomes/%s
+""" % (args['db'], sp.id))
+    outfile.close()
+
+
+def run_pipeline(args):
+    """midas/merge/snps.py:471-508"""
+    rank, ws = dist.init_from_env()
+    if rank == 0:
+        print("Identifying species and samples")
+    species_list = merge.select_species(args, dtype='snps')
+    if rank == 0:
+        for species in species_list:
+            print("  %s" % species.id)
+            print("    count samples: %s" % len(species.samples))
+        print("\nMerging snps")
+    try:
+        ctx = abi.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    except abi.MidasSnpsError as e:
+        sys.exit("\nError: %s\n" % e.message)
+    for k, species in enumerate(species_list):
+        if k % ws != rank:        # species are independent: one rank (GPU) per species, round robin
+            continue
+        print("  %s" % species.id)
+        print("    calling SNPs")
+        n, kept, ms = merge_species(species, args, ctx)
+        print("    %d sites, %d written (%.3f ms on the GPU)" % (n, kept, ms))
+        print("    finishing")
+        write_snps_readme(args, species)
+        species.write_sample_info(dtype='snps', outdir=args['outdir'])
+    ctx.close()
+    dist.barrier()

@@ -213,9 +213,7 @@ def write_sample(outdir, db_dir, contigs, reads, line_width=60, gz_fasta=False):
     os.makedirs(db_dir, exist_ok=True)
     for d in ("marker_genes", "pan_genomes", "rep_genomes"):
         os.makedirs(os.path.join(db_dir, d), exist_ok=True)
-    for f in ("species_info.txt", "genome_info.txt"):
-        with open(os.path.join(db_dir, f), "w") as h:
-            h.write("species_id\n" + "".join(s + "\n" for s in contigs.species_ids))
+    write_db_tables(db_dir, contigs.species_ids)
     off = contigs.site_offsets()
     for si, sp in enumerate(contigs.species_ids):
         d = os.path.join(db_dir, "rep_genomes", sp)
@@ -240,3 +238,128 @@ def write_sample(outdir, db_dir, contigs, reads, line_width=60, gz_fasta=False):
     refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
     bam.write_bam(os.path.join(outdir, "snps", "temp", "genomes.bam"), contigs.ids,
                   [int(x) for x in contigs.length], refid, reads)
+
+
+def write_db_tables(db_dir, species_ids):
+    """species_info.txt (species_id, rep_genome) and genome_info.txt (genome_id, ...) the way merge_midas.py reads
+    them (midas/merge/merge.py:88-102); the representative genome of species X is named X.rep."""
+    import os
+    os.makedirs(db_dir, exist_ok=True)
+    with open(os.path.join(db_dir, "species_info.txt"), "w") as h:
+        h.write("species_id\trep_genome\tcount_genomes\n")
+        h.write("".join("%s\t%s.rep\t1\n" % (s, s) for s in species_ids))
+    with open(os.path.join(db_dir, "genome_info.txt"), "w") as h:
+        h.write("genome_id\tspecies_id\trep_genome\n")
+        h.write("".join("%s.rep\t%s\t1\n" % (s, s) for s in species_ids))
+
+
+def make_genes(rng, contig_ids, contig_lengths, mean_gene=900, mean_gap=150):
+    """Non-overlapping genes over each contig, ~85% coding, both strands, lengths mostly multiples of 3 (a few are
+    not, and a few are non-CDS, to hit the reference's annotate() branches).  -> list of feature rows."""
+    genes = []
+    for cid, length in zip(contig_ids, contig_lengths):
+        pos = 1 + int(rng.integers(0, mean_gap))
+        k = 0
+        while True:
+            glen = 3 * int(rng.integers(mean_gene // 6, mean_gene // 2))
+            if rng.random() < 0.05:
+                glen += 1
+            if pos + glen - 1 > length:
+                break
+            k += 1
+            kind = "CDS" if rng.random() < 0.9 else ("tRNA" if rng.random() < 0.5 else "rRNA")
+            genes.append(dict(gene_id="%s_g%d" % (cid, k), scaffold_id=cid, start=pos, end=pos + glen - 1,
+                              strand="+" if rng.random() < 0.5 else "-", gene_type=kind))
+            pos += glen + int(rng.integers(0, 2 * mean_gap))
+    return genes
+
+
+def write_features(db_dir, species_id, genes):
+    import os
+    d = os.path.join(db_dir, "rep_genomes", species_id)
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "genome.features"), "w") as h:
+        h.write("gene_id\tscaffold_id\tstart\tend\tstrand\tgene_type\n")
+        for g in genes:
+            h.write("%s\t%s\t%d\t%d\t%s\t%s\n" % (g["gene_id"], g["scaffold_id"], g["start"], g["end"], g["strand"],
+                                                  g["gene_type"]))
+
+
+def make_merge_dataset(root, n_samples=4, n_sites=5000, n_contigs=3, species_id="sp1", seed=0, mean_depth=12.0,
+                       snp_rate=0.03, zero_depth_sample=False):
+    """Inputs of `merge_midas.py snps` without running the pileup: a DB (genome.fna, genome.features, info tables)
+    and n_samples run_midas-style sample dirs holding snps/output/<species>.snps.gz + snps/summary.txt.
+
+    Sites are a mix of uncovered, monomorphic, bi/tri/quad-allelic, tied and very deep ones, so every branch of the
+    reference's call_alleles / compute_prevalence / flag is exercised.  Returns a dict describing what was written.
+    """
+    import gzip
+    import os
+    rng = np.random.default_rng(seed)
+    db = os.path.join(root, "db")
+    for d in ("marker_genes", "pan_genomes", "rep_genomes"):
+        os.makedirs(os.path.join(db, d), exist_ok=True)
+    write_db_tables(db, [species_id])
+    lens = [n_sites // n_contigs + (1 if k < n_sites % n_contigs else 0) for k in range(n_contigs)]
+    ids = sorted("%s_contig_%d" % (species_id, k + 1) for k in range(n_contigs))
+    seqs = ["".join(rng.choice(list("ACGT"), size=l)) for l in lens]
+    gdir = os.path.join(db, "rep_genomes", species_id)
+    os.makedirs(gdir, exist_ok=True)
+    with open(os.path.join(gdir, "genome.fna"), "w") as h:
+        for cid, seq in zip(ids, seqs):
+            h.write(">%s\n" % cid)
+            for o in range(0, len(seq), 70):
+                h.write(seq[o:o + 70] + "\n")
+    write_features(db, species_id, make_genes(rng, ids, lens, mean_gene=240, mean_gap=60))
+    ref = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    ref_idx = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), ref)
+    n = len(ref)
+    kind = rng.random(n)
+    alt = (ref_idx + rng.integers(1, 4, n)) % 4
+    alt2 = (alt + rng.integers(1, 4, n)) % 4
+    samples, counts_all = [], []
+    for s in range(n_samples):
+        depth = rng.poisson(mean_depth, n).astype(np.int64)
+        depth[rng.random(n) < 0.04] = 0
+        deep = rng.random(n) < 0.01
+        depth[deep] *= 5
+        c = np.zeros((n, 4), np.int64)
+        af = np.where(kind < snp_rate, rng.random(n), 0.0)                 # polymorphic across samples
+        na = rng.binomial(depth, af)
+        np.add.at(c, (np.arange(n), ref_idx), depth - na)
+        np.add.at(c, (np.arange(n), alt), na)
+        third = (kind < snp_rate / 3) & (depth > 0)
+        n3 = np.where(third, rng.integers(0, 3, n), 0)
+        np.add.at(c, (np.arange(n), alt2), n3)
+        fourth = (kind < snp_rate / 6) & (depth > 0)                       # a fourth allele on a few sites
+        alt3 = 6 - ref_idx - alt - alt2
+        ok4 = fourth & (alt3 >= 0) & (alt3 < 4) & (alt3 != ref_idx) & (alt3 != alt) & (alt3 != alt2)
+        np.add.at(c, (np.arange(n)[ok4], alt3[ok4]), rng.integers(1, 4, int(ok4.sum())))
+        c[(kind > 0.5) & (kind < 0.51)] = 0                                 # sites no sample covers
+        tied = (kind > 0.995)                                               # exact ties between two alleles
+        c[tied] = 0
+        c[tied, ref_idx[tied]] = 3
+        c[tied, alt[tied]] = 3
+        if zero_depth_sample and s == n_samples - 1:
+            c[:] = 0
+        sdir = os.path.join(root, "samples", "sample_%d" % (s + 1))
+        os.makedirs(os.path.join(sdir, "snps", "output"), exist_ok=True)
+        tot = c.sum(1)
+        with gzip.open(os.path.join(sdir, "snps", "output", "%s.snps.gz" % species_id), "wt", compresslevel=1) as h:
+            h.write("ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n")
+            row = 0
+            for cid, seq in zip(ids, seqs):
+                for p, b in enumerate(seq):
+                    h.write("%s\t%d\t%s\t%d\t%d\t%d\t%d\t%d\n" % (cid, p + 1, b, tot[row], c[row, 0], c[row, 1],
+                                                                  c[row, 2], c[row, 3]))
+                    row += 1
+        cov = int((tot > 0).sum())
+        mean_cov = float(tot.sum()) / cov if cov else 0.0
+        with open(os.path.join(sdir, "snps", "summary.txt"), "w") as h:
+            h.write("species_id\tgenome_length\tcovered_bases\tfraction_covered\tmean_coverage\taligned_reads\tmapped_reads\n")
+            h.write("%s\t%d\t%d\t%s\t%s\t%d\t%d\n" % (species_id, n, cov, cov / float(n), mean_cov, 1000 + s, 900 + s))
+        samples.append(sdir)
+        counts_all.append(c)
+    keys = ["%s|%d|%s" % (cid, p + 1, b) for cid, seq in zip(ids, seqs) for p, b in enumerate(seq)]
+    return dict(db=db, samples=samples, species_id=species_id, keys=keys, counts=counts_all, contig_ids=ids,
+                contig_seqs=seqs)

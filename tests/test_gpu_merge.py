@@ -1,0 +1,230 @@
+"""`merge_midas.py snps` on the GPU box: midas_merge_sites (through the C-ABI) and the whole command against the
+restated reference arithmetic (oracle/merge_oracle.py), bit for bit / byte for byte."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, synth
+from oracle import merge_oracle as mo
+from tests.test_merge_host import oracle_genes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SNP_NAMES = [None, 'mono', 'bi', 'tri', 'quad']
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = abi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    return synth.make_merge_dataset(str(tmp_path_factory.mktemp("merge_gpu")), n_samples=5, n_sites=6000, seed=11)
+
+
+def oracle_fields(counts, mean, args):
+    """Per-site oracle outputs as arrays, same encodings as midas_merge_sites."""
+    S, n = len(counts), counts[0].shape[0]
+    o = dict(major=np.full(n, 255, np.uint8), minor=np.full(n, 255, np.uint8), snp_type=np.zeros(n, np.uint8),
+             flag=np.zeros(n, np.uint8), count_samples=np.zeros(n, np.uint32), pooled=np.zeros((n, 4), np.uint64),
+             depth=np.zeros((S, n), np.uint32), minor_count=np.zeros((S, n), np.uint32))
+    for i in range(n):
+        c = [[int(x) for x in counts[s][i]] for s in range(S)]
+        pooled = mo.pooled_counts(c)
+        major, minor, snp = mo.call_alleles(pooled, args['allele_freq'])
+        mafs, depths = mo.per_sample(c, major, minor)
+        cs, prev = mo.prevalence(mean, depths, args['site_depth'], args['site_ratio'])
+        why = mo.flag_reason(prev, snp, args['site_prev'], args['snp_type'])
+        o['major'][i] = 255 if major is None else major
+        o['minor'][i] = 255 if minor is None else minor
+        o['snp_type'][i] = SNP_NAMES.index(snp)
+        o['flag'][i] = {None: 0, 'min_prev': 1, 'snp_type': 2}[why]
+        o['count_samples'][i] = cs
+        o['pooled'][i] = pooled
+        o['depth'][:, i] = depths
+        if minor is not None:
+            o['minor_count'][:, i] = [x[minor] for x in c]
+    return o
+
+
+VARIANTS = [
+    dict(),                                                                   # --core_snps
+    dict(snp_type=['any'], site_prev=0.0),                                    # --all_sites
+    dict(snp_type=['mono', 'tri', 'quad'], allele_freq=0.05, site_prev=0.6),
+    dict(site_depth=15, site_ratio=1.1, site_prev=0.4, allele_freq=0.2),
+    dict(site_depth=0, site_ratio=0.0, site_prev=0.2, snp_type=['bi', 'tri']),
+]
+
+
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+def test_merge_sites_fields_match_oracle(ctx, dataset, variant):
+    args = dict(abi.DEFAULT_MERGE_ARGS, **VARIANTS[variant])
+    counts = [c.astype(np.uint32) for c in dataset['counts']]
+    mean = [12.3, 11.0, 13.75, 9.5, 12.0]
+    got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
+    exp = oracle_fields(counts, mean, args)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    if variant == 0:      # the dataset exercises every branch
+        assert set(exp['snp_type'].tolist()) == {0, 1, 2, 3, 4} and set(exp['flag'].tolist()) == {0, 1, 2}
+    assert got['kernel_ms'] > 0
+
+
+def test_merge_sites_edge_shapes(ctx):
+    prm = abi.MergeParams.from_args(abi.DEFAULT_MERGE_ARGS)
+    # no sites at all
+    r = ctx.merge_sites(prm, [np.zeros((0, 4), np.uint32)] * 2, [5.0, 5.0])
+    assert r['major'].shape == (0,) and r['depth'].shape == (2, 0)
+    # a single sample, a single site, large counts (pooled sums need 64 bits across samples)
+    big = np.array([[2**31 - 1, 2**31 - 1, 5, 0]], np.uint32)
+    r = ctx.merge_sites(abi.MergeParams.from_args(dict(abi.DEFAULT_MERGE_ARGS, site_ratio=1e18)), [big, big, big],
+                        [1.0, 1.0, 1.0])
+    assert r['pooled'][0].tolist() == [3 * (2**31 - 1), 3 * (2**31 - 1), 15, 0]
+    assert (r['major'][0], r['minor'][0], r['snp_type'][0]) == (0, 1, 2)     # tie -> A before C; G's 15/1.3e10 < 0.01
+    assert r['depth'][:, 0].tolist() == [2**32 - 2] * 3 and r['count_samples'][0] == 3
+    # ragged sample count vs grid: 3 samples x 100003 sites (grid-stride tail)
+    rng = np.random.default_rng(2)
+    counts = [rng.integers(0, 9, (100003, 4)).astype(np.uint32) for _ in range(3)]
+    args = dict(abi.DEFAULT_MERGE_ARGS, snp_type=['any'], site_prev=0.5)
+    got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, [4.0, 4.0, 4.0])
+    sel = np.r_[0:300, 99800:100003]
+    exp = oracle_fields([c[sel] for c in counts], [4.0, 4.0, 4.0], args)
+    for k in ('major', 'minor', 'snp_type', 'flag', 'count_samples'):
+        assert np.array_equal(got[k][sel], exp[k]), k
+    assert np.array_equal(got['depth'][:, sel], exp['depth']) and np.array_equal(got['pooled'][sel], exp['pooled'])
+
+
+def test_zero_mean_coverage_is_the_references_zero_division(ctx, dataset):
+    counts = [c.astype(np.uint32) for c in dataset['counts'][:2]]
+    prm = abi.MergeParams.from_args(abi.DEFAULT_MERGE_ARGS)
+    with pytest.raises(abi.MidasSnpsError) as e:
+        ctx.merge_sites(prm, counts, [10.0, 0.0])
+    assert e.value.status == abi.ERR_MERGE_ZERO_MEAN_DEPTH and "ZeroDivisionError" in e.value.message
+    # the oracle raises at the same site
+    first = None
+    for i in range(counts[0].shape[0]):
+        c = [[int(x) for x in counts[s][i]] for s in range(2)]
+        major, minor, _ = mo.call_alleles(mo.pooled_counts(c), 0.01)
+        try:
+            mo.prevalence([10.0, 0.0], mo.per_sample(c, major, minor)[1], 1, 2.0)
+        except ZeroDivisionError:
+            first = i
+            break
+    assert e.value.read_index == first
+    # a sample with zero depth everywhere never divides: site_depth < 1 short-circuits, as in the reference
+    z = [counts[0], np.zeros_like(counts[0])]
+    r = ctx.merge_sites(prm, z, [10.0, 0.0])
+    assert r['count_samples'].max() <= 1
+
+
+def oracle_text(dataset, args, samples=None, max_sites=None):
+    idx = list(range(len(dataset['samples']))) if samples is None else samples
+    n = len(dataset['keys']) if max_sites is None else max_sites
+    tabs = [[",".join(str(int(x)) for x in row) for row in dataset['counts'][s][:n]] for s in idx]
+    mean = []
+    for s in idx:
+        line = open(os.path.join(dataset['samples'][s], 'snps', 'summary.txt')).read().splitlines()[1].split('\t')
+        mean.append(float(line[4]))
+    return mo.merge_species(dataset['keys'][:n], tabs, mean, args, oracle_genes(dataset))
+
+
+INFO_HEADER = "site_id\tref_id\tref_pos\tref_allele\tmajor_allele\tminor_allele\tcount_samples\tcount_a\tcount_c\tcount_g\tcount_t\tlocus_type\tgene_id\tsnp_type\tsite_type\tamino_acids\n"
+
+
+def run_merge(outdir, dataset, *extra):
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'merge_midas.py'), 'snps', outdir,
+                           '-i', os.path.dirname(dataset['samples'][0]), '-t', 'dir', '-d', dataset['db']] + list(extra),
+                          capture_output=True, text=True, cwd=ROOT)
+
+
+@pytest.mark.parametrize("flags,args", [
+    ([], dict(abi.DEFAULT_MERGE_ARGS)),
+    (['--all_sites', '--threads', '3'], dict(abi.DEFAULT_MERGE_ARGS, snp_type=['any'], site_prev=0.0)),
+    (['--snp_type', 'bi', 'tri', '--site_prev', '0.5', '--allele_freq', '0.05', '--site_depth', '3', '--site_ratio', '1.5'],
+     dict(snp_type=['bi', 'tri'], site_prev=0.5, allele_freq=0.05, site_depth=3, site_ratio=1.5)),
+])
+def test_merge_midas_snps_files_match_reference_text(tmp_path, dataset, flags, args):
+    out = str(tmp_path / "merged")
+    r = run_merge(out, dataset, *flags)
+    assert r.returncode == 0, r.stderr + r.stdout
+    info, freq, depth = oracle_text(dataset, args)
+    assert len(info) > 20
+    ids = "\t".join("sample_%d" % (k + 1) for k in range(5))
+    d = os.path.join(out, 'sp1')
+    assert open(os.path.join(d, 'snps_info.txt')).read() == INFO_HEADER + "".join(info)
+    assert open(os.path.join(d, 'snps_freq.txt')).read() == "site_id\t" + ids + "\n" + "".join(freq)
+    assert open(os.path.join(d, 'snps_depth.txt')).read() == "site_id\t" + ids + "\n" + "".join(depth)
+    assert os.path.isfile(os.path.join(d, 'readme.txt'))
+    assert len(open(os.path.join(d, 'snps_summary.txt')).read().splitlines()) == 6
+
+
+def test_merge_midas_snps_max_sites_and_max_samples(tmp_path, dataset):
+    out = str(tmp_path / "merged")
+    r = run_merge(out, dataset, '--all_sites', '--max_sites', '777', '--max_samples', '3')
+    assert r.returncode == 0, r.stderr + r.stdout
+    args = dict(abi.DEFAULT_MERGE_ARGS, snp_type=['any'], site_prev=0.0)
+    info, freq, depth = oracle_text(dataset, args, samples=[0, 1, 2], max_sites=777)
+    d = os.path.join(out, 'sp1')
+    assert len(info) == 777
+    assert open(os.path.join(d, 'snps_info.txt')).read() == INFO_HEADER + "".join(info)
+    assert open(os.path.join(d, 'snps_freq.txt')).read().splitlines()[1:] == [l.rstrip('\n') for l in freq]
+    assert open(os.path.join(d, 'snps_depth.txt')).read().splitlines()[0] == "site_id\tsample_1\tsample_2\tsample_3"
+
+
+def test_run_midas_then_merge_midas_chain(tmp_path):
+    """Two samples through `run_midas.py snps --pileup`, then merged: merge's inputs are what the pileup stage wrote."""
+    db = str(tmp_path / "db")
+    sample_dirs = []
+    tables = []
+    for s in range(2):
+        contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=3, contig_len=5000, n_reads=6000 + 500 * s,
+                                            seed=3, var_len=True)
+        out = str(tmp_path / "samples" / ("s%d" % s))
+        synth.write_sample(out, db, contigs, reads)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_midas.py"), "snps", out, "--pileup", "-d", db],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        sample_dirs.append(out)
+    sp = contigs.species_ids[0]
+    rng = np.random.default_rng(0)
+    off = contigs.site_offsets()
+    cids = [contigs.ids[k] for k in range(contigs.n_contigs)]
+    synth.write_features(db, sp, synth.make_genes(rng, sorted(cids), [int(contigs.length[cids.index(c)]) for c in sorted(cids)],
+                                                  mean_gene=300, mean_gap=80))
+    out = str(tmp_path / "merged")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'merge_midas.py'), 'snps', out, '-i', ",".join(sample_dirs),
+                        '-t', 'list', '-d', db, '--all_sites', '--sample_depth', '0.5'], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout
+    # oracle over the tables on disk
+    keys, tabs, mean = None, [], []
+    for sd in sample_dirs:
+        rows = [l.split('\t') for l in gzip.open(os.path.join(sd, 'snps', 'output', sp + '.snps.gz'), 'rt').read().splitlines()[1:]]
+        if keys is None:
+            keys = ['|'.join(x[0:3]) for x in rows]
+        tabs.append([','.join(x[-4:]) for x in rows])
+        mean.append(float(open(os.path.join(sd, 'snps', 'summary.txt')).read().splitlines()[1].split('\t')[4]))
+    genome = {cid: bytes(contigs.ref[off[k]:off[k + 1]]).decode().upper() for k, cid in enumerate(contigs.ids)}
+    genes = []
+    with open(os.path.join(db, 'rep_genomes', sp, 'genome.features')) as h:
+        fields = next(h).rstrip('\n').split('\t')
+        for line in h:
+            g = dict(zip(fields, line.rstrip('\n').split('\t')))
+            if g['gene_type'] != 'CDS':
+                continue
+            g['start'], g['end'] = int(g['start']), int(g['end'])
+            g['seq'] = mo.gene_seq(g, genome[g['scaffold_id']])
+            genes.append(g)
+    args = dict(abi.DEFAULT_MERGE_ARGS, snp_type=['any'], site_prev=0.0)
+    info, freq, depth = mo.merge_species(keys, tabs, mean, args, mo.sort_genes(genes))
+    assert len(info) == 15000
+    d = os.path.join(out, sp)
+    assert open(os.path.join(d, 'snps_info.txt')).read() == INFO_HEADER + "".join(info)
+    assert open(os.path.join(d, 'snps_freq.txt')).read().splitlines()[1:] == [l.rstrip('\n') for l in freq]
+    assert open(os.path.join(d, 'snps_depth.txt')).read().splitlines()[1:] == [l.rstrip('\n') for l in depth]

@@ -1,0 +1,154 @@
+"""merge_midas.py snps, host side (no GPU): the native table reader, species/sample selection, annotation and CLI presets."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, synth
+from midas_amd.merge import annotate, merge
+from oracle import merge_oracle as mo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("merge"))
+    return synth.make_merge_dataset(root, n_samples=3, n_sites=4000, seed=5)
+
+
+def test_table_reader_matches_what_was_written(dataset):
+    path = os.path.join(dataset['samples'][1], 'snps', 'output', 'sp1.snps.gz')
+    counts, keys, off = abi.read_snps_table(path)
+    assert counts.shape == (4000, 4) and counts.dtype == np.uint32
+    assert np.array_equal(counts, dataset['counts'][1].astype(np.uint32))
+    got = [keys[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+    assert got == dataset['keys']
+    # max_rows (args['max_sites']) and keyless reads
+    c2, k2, o2 = abi.read_snps_table(path, 17, False)
+    assert c2.shape == (17, 4) and k2 is None and o2 is None and np.array_equal(c2, counts[:17])
+    c0, _, o0 = abi.read_snps_table(path, 0, True)
+    assert c0.shape == (0, 4) and list(o0) == [0]
+
+
+def test_table_reader_reads_tables_written_by_the_pileup_stage(tmp_path):
+    # multi-member gzip as midas_snps_write_rows produces it, 65536 rows per member
+    n = 70000
+    rng = np.random.default_rng(1)
+    allele = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n)
+    counts = rng.integers(0, 50, (n, 4)).astype(np.uint32)
+    path = str(tmp_path / "x.snps.gz")
+    abi.write_rows(path, False, "ctg|with|pipes", allele, counts)
+    got, keys, off = abi.read_snps_table(path)
+    assert np.array_equal(got, counts)
+    assert keys[off[0]:off[1]].decode() == "ctg|with|pipes|1|%s" % chr(allele[0])
+    assert keys[off[n - 1]:off[n]].decode() == "ctg|with|pipes|%d|%s" % (n, chr(allele[n - 1]))
+
+
+def test_table_reader_rejects_malformed_rows(tmp_path):
+    p = str(tmp_path / "bad.snps.gz")
+    with gzip.open(p, "wt") as h:
+        h.write("ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n")
+        h.write("c\t1\tA\t3\t1\t1\t1\t0\n")
+        h.write("c\t2\tA\t3\t1\tx\t1\t0\n")
+    with pytest.raises(abi.MidasSnpsError) as e:
+        abi.read_snps_table(p)
+    assert "row 2" in e.value.message
+    with pytest.raises(abi.MidasSnpsError):
+        abi.read_snps_table(str(tmp_path / "missing.snps.gz"))
+
+
+def base_args(dataset, outdir, **kw):
+    a = dict(outdir=outdir, db=dataset['db'], indirs=list(dataset['samples']), species_id=None, max_samples=None,
+             sample_depth=5.0, fract_cov=0.4, min_samples=1, max_species=None, threads=1, max_sites=float('Inf'),
+             **abi.DEFAULT_MERGE_ARGS)
+    a.update(kw)
+    return a
+
+
+def test_select_species_applies_the_pair_filters(dataset, tmp_path):
+    sp = merge.select_species(base_args(dataset, str(tmp_path)), 'snps')
+    assert [s.id for s in sp] == ['sp1'] and [x.id for x in sp[0].samples] == ['sample_1', 'sample_2', 'sample_3']
+    assert len(sp[0].sample_depth) == 3 and all(d > 5 for d in sp[0].sample_depth)
+    assert os.path.isdir(str(tmp_path / 'sp1'))
+    assert merge.select_species(base_args(dataset, str(tmp_path), sample_depth=1e6), 'snps') == []
+    assert merge.select_species(base_args(dataset, str(tmp_path), species_id='other'), 'snps') == []
+    assert merge.select_species(base_args(dataset, str(tmp_path), min_samples=4), 'snps') == []
+    two = merge.select_species(base_args(dataset, str(tmp_path), max_samples=2), 'snps')
+    assert [x.id for x in two[0].samples] == ['sample_1', 'sample_2']
+    # a directory without snps/summary.txt is not a sample
+    extra = base_args(dataset, str(tmp_path))
+    extra['indirs'] = extra['indirs'] + [str(tmp_path)]
+    assert len(merge.select_species(extra, 'snps')[0].samples) == 3
+    sp[0].write_sample_info('snps', str(tmp_path))
+    lines = open(str(tmp_path / 'sp1' / 'snps_summary.txt')).read().splitlines()
+    assert lines[0].split('\t') == ['sample_id', 'genome_length', 'covered_bases', 'fraction_covered', 'mean_coverage',
+                                    'aligned_reads', 'mapped_reads']
+    assert lines[1].split('\t')[0] == 'sample_1' and len(lines) == 4
+
+
+def oracle_genes(dataset):
+    """The oracle's gene list built independently of midas_amd.merge.annotate (plain parsing of the DB files)."""
+    genome = dict(zip(dataset['contig_ids'], dataset['contig_seqs']))
+    genes = []
+    with open(os.path.join(dataset['db'], 'rep_genomes', 'sp1', 'genome.features')) as h:
+        fields = next(h).rstrip('\n').split('\t')
+        for line in h:
+            g = dict(zip(fields, line.rstrip('\n').split('\t')))
+            if g['gene_type'] != 'CDS':
+                continue
+            g['start'], g['end'] = int(g['start']), int(g['end'])
+            g['seq'] = mo.gene_seq(g, genome[g['scaffold_id']])
+            genes.append(g)
+    return mo.sort_genes(genes)
+
+
+def test_gene_cursor_agrees_with_the_oracle_on_every_site(dataset):
+    cur = annotate.GeneCursor.from_db('sp1', dataset['db'])
+    genes = oracle_genes(dataset)
+    assert len(cur.genes) == len(genes['list']) > 5
+    kinds = set()
+    for key in dataset['keys'][::3]:
+        ref_id, pos, _ = key.rsplit('|', 2)
+        a = cur.lookup(ref_id, int(pos))
+        assert a == mo.annotate_site(ref_id, int(pos), genes)
+        kinds.add((a[0], a[2]))
+    assert ('IGR', None) in kinds and ('CDS', '1D') in kinds and ('CDS', '4D') in kinds and ('CDS', None) in kinds
+
+
+def run_cli(*argv):
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'merge_midas.py')] + list(argv),
+                          capture_output=True, text=True, cwd=ROOT)
+
+
+def test_cli_usage_and_argument_checks(dataset, tmp_path):
+    r = run_cli()
+    assert r.returncode == 0 and 'snps' in r.stdout
+    assert run_cli('genes', str(tmp_path)).returncode != 0
+    r = run_cli('snps', str(tmp_path / 'o'), '-i', str(tmp_path / 'nope'), '-t', 'dir', '-d', dataset['db'])
+    assert r.returncode != 0 and 'does not exist' in r.stderr
+    r = run_cli('snps', str(tmp_path / 'o'), '-i', ','.join(dataset['samples']), '-t', 'list', '-d', dataset['db'],
+                '--allele_freq', '0.7')
+    assert r.returncode != 0 and '--allele_freq' in r.stderr
+
+
+def test_cli_presets():
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    try:
+        import merge_midas
+    finally:
+        sys.path.pop(0)
+    base = dict(all_samples=False, all_sites=False, all_snps=False, core_sites=False, core_snps=False,
+                sample_depth=5.0, fract_cov=0.4, site_prev=0.3, snp_type=['tri'], site_depth=7, site_ratio=9.0)
+    a = merge_midas.add_snp_presets(dict(base, all_sites=True))
+    assert a['site_prev'] == 0.0 and a['snp_type'] == ['any'] and a['site_depth'] == 7
+    a = merge_midas.add_snp_presets(dict(base, core_snps=True, all_samples=True))
+    assert (a['site_depth'], a['site_ratio'], a['site_prev'], a['snp_type']) == (1, 2.0, 0.95, ['bi'])
+    assert a['sample_depth'] == 0.0 and a['fract_cov'] == 0.0
+    a = merge_midas.add_snp_presets(dict(base, core_sites=True))
+    assert a['snp_type'] == ['any'] and a['site_prev'] == 0.95
+    a = merge_midas.add_snp_presets(dict(base))
+    assert a['snp_type'] == ['tri'] and a['site_prev'] == 0.3
