@@ -267,15 +267,14 @@ typedef struct midas_merge_params {
 } midas_merge_params;
 #define MIDAS_MERGE_ERR_ZERO_MEAN_DEPTH 7 /* ZeroDivisionError in compute_prevalence (snps.py:99) */
 /* sample_counts[s] -> [n_sites*4] u32 (A,C,G,T per site) of sample s, host memory; mean_depth[s] = float(mean_coverage).
- * Outputs (host, caller-owned): major/minor [n_sites] (0..3 = A,C,G,T, 255 = None), snp_type [n_sites]
- * (0 None, 1 mono, 2 bi, 3 tri, 4 quad), flag [n_sites] (0 keep, 1 'min_prev', 2 'snp_type'),
+ * Outputs (host, caller-owned): calls [n_sites*4] = per site {major, minor, snp_type, flag}: major/minor 0..3 =
+ * A,C,G,T, 255 = None; snp_type 0 None, 1 mono, 2 bi, 3 tri, 4 quad; flag 0 keep, 1 'min_prev', 2 'snp_type';
  * count_samples [n_sites], pooled [n_sites*4] u64, depth and minor_count [n_samples*n_sites] u32
  * (sample_depths and the numerator of sample_mafs; maf = float(minor_count)/depth if depth > 0 else 0.0).
  * out_kernel_ms (nullable): device time of the kernel(s), HIP events.                                */
 int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_params* params, int32_t n_samples, int64_t n_sites,
-                          const uint32_t* const* sample_counts, const double* mean_depth, uint8_t* out_major,
-                          uint8_t* out_minor, uint8_t* out_snp_type, uint8_t* out_flag, uint32_t* out_count_samples,
-                          uint64_t* out_pooled, uint32_t* out_depth, uint32_t* out_minor_count, float* out_kernel_ms);
+                          const uint32_t* const* sample_counts, const double* mean_depth, uint8_t* out_calls,
+                          uint32_t* out_count_samples, uint64_t* out_pooled, uint32_t* out_depth, uint32_t* out_minor_count, float* out_kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -225,7 +225,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_table_rows': (i64, [vp]),
         'midas_snps_table_key_bytes': (i64, [vp]),
         'midas_snps_table_copy': (i32, [vp, vp, vp, vp]),
-        'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 8 + [C.POINTER(C.c_float)]),
+        'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 5 + [C.POINTER(C.c_float)]),
     })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
@@ -411,13 +411,14 @@ class Context:
         assert all(a.shape == (n, 4) for a in arrs)
         ptrs = (C.c_void_p * S)(*[a.ctypes.data for a in arrs])
         md = np.ascontiguousarray(mean_depth, dtype=np.float64)
-        out = dict(major=np.empty(n, np.uint8), minor=np.empty(n, np.uint8), snp_type=np.empty(n, np.uint8),
-                   flag=np.empty(n, np.uint8), count_samples=np.empty(n, np.uint32), pooled=np.empty((n, 4), np.uint64),
+        calls = np.empty((n, 4), np.uint8)
+        out = dict(major=calls[:, 0], minor=calls[:, 1], snp_type=calls[:, 2], flag=calls[:, 3],
+                   count_samples=np.empty(n, np.uint32), pooled=np.empty((n, 4), np.uint64),
                    depth=np.empty((S, n), np.uint32), minor_count=np.empty((S, n), np.uint32))
         ms = C.c_float(0)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        st = self._lib.midas_merge_sites(self._h, C.byref(prm), S, n, ptrs, p(md), p(out['major']), p(out['minor']),
-                                         p(out['snp_type']), p(out['flag']), p(out['count_samples']), p(out['pooled']),
+        st = self._lib.midas_merge_sites(self._h, C.byref(prm), S, n, ptrs, p(md), p(calls),
+                                         p(out['count_samples']), p(out['pooled']),
                                          p(out['depth']), p(out['minor_count']), C.byref(ms))
         self._check(st)
         out['kernel_ms'] = float(ms.value)

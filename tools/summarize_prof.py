@@ -28,9 +28,10 @@ def main():
     for db in sorted(glob.glob(os.path.join(root, "pmc_*", "pmc_results.db"))):
         cur = sqlite3.connect(db).cursor()
         q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-             "where kernel_name like '%midas%' group by kernel_name, counter_name")
+             "where kernel_name like '%midas%' or kernel_name like '%merge_sites%' group by kernel_name, counter_name")
         for k, c, v, n in cur.execute(q):
-            short = "pileup_tiles_kernel" if "pileup" in k else ("index_reads_kernel" if "index" in k else k[:40])
+            short = "pileup_tiles_kernel" if "pileup" in k else ("index_reads_kernel" if "index" in k else
+                                                                  ("merge_sites_kernel" if "merge_sites" in k else k[:40]))
             print("%-22s %-28s %18.1f  (n=%d)" % (short, c, v, n))
             out["pmc"].setdefault(short, {})[c] = v
     for k, d in out["pmc"].items():
