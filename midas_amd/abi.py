@@ -184,7 +184,7 @@ def load_library(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("MIDAS_SNPS_LIBRARY") or _build.LIB_PATH     # override: developer builds (tools/)
     if not os.path.exists(path):
         if not build_if_missing:
             raise MidasSnpsError(ERR_NO_DEVICE, "native library %s is missing (run `python -m midas_amd.build`)" % path)

@@ -7,9 +7,15 @@
 
 namespace midas {
 
-constexpr int kTileShift = 12;             // 4096 sites per tile: 64 KiB of LDS tallies, 2 workgroups per CU
+#ifndef MIDAS_TILE_SHIFT
+#define MIDAS_TILE_SHIFT 12
+#endif
+#ifndef MIDAS_PILEUP_BLOCK
+#define MIDAS_PILEUP_BLOCK 512
+#endif
+constexpr int kTileShift = MIDAS_TILE_SHIFT;             // 4096 sites per tile: 64 KiB of LDS tallies, 2 workgroups per CU
 constexpr int kTileSites = 1 << kTileShift;
-constexpr int kPileupBlock = 512;          // 8 waves
+constexpr int kPileupBlock = MIDAS_PILEUP_BLOCK;          // 8 waves
 constexpr int kIndexBlock = 256;
 
 // Per-species counters, same order as MIDAS_SNPS_STAT_* in include/midas_snps.h.
@@ -66,6 +72,7 @@ struct PileupParams {
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
   int32_t debug;                     // developer ablation switches (MIDAS_SNPS_DEBUG), 0 in production
+  unsigned long long* phase_clk;     // developer instrumentation (MIDAS_SNPS_PHASES): per-phase wave cycles, else null
 };
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);

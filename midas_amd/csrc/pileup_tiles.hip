@@ -107,6 +107,21 @@ typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 // the three read ranges of a tile as one virtual stream: range starts; |S|, |S|+|I|, |S|+|I|+|G|
 struct Ranges { int sb, ib, gb, ns, nsi, total; };
+// the six index words of a tile as loaded (index_reads.hip): rbinv / rend of S, G, I
+struct RawRanges { uint32_t vs, vg, vi, se, ge, ie; };
+
+// Per-tile tables are read through the constant address space: the tile index is workgroup-uniform, so these become
+// s_load (SGPR results, no VGPRs, tracked by lgkmcnt) and can be issued a whole tile ahead of their use.
+typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+__device__ __forceinline__ Tile load_tile(ConstWords tiles, int t) {
+  static_assert(sizeof(Tile) == 32, "eight words per tile");
+  const ConstWords w = tiles + 8 * (size_t)t;
+  Tile x;
+  x.contig = (int32_t)w[0]; x.start = (int32_t)w[1]; x.len = (int32_t)w[2]; x.species = (int32_t)w[3];
+  x.site_base = (int64_t)((unsigned long long)w[4] | ((unsigned long long)w[5] << 32));
+  x.contig_len = (int32_t)w[6]; x.pad = 0;
+  return x;
+}
 
 template <int TILE_SHIFT>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
@@ -157,13 +172,21 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   // as ONE virtual stream S, I, G: the leading wave-iterations are purely "simple", so the CIGAR-walk / clipping /
   // segment-mask code is branched over (not masked through) for ~85 % of the reads, there is a single mixed
   // iteration per tile, and the prefetch pipeline never restarts.
-  auto tile_ranges = [&](int tt) -> Ranges {
+  const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
+  const ConstWords c_rbinv = (ConstWords)(size_t)p.rbinv;
+  const ConstWords c_rend = (ConstWords)(size_t)p.rend;
+  auto load_ranges = [&](int tt) -> RawRanges {
+    RawRanges w;
+    w.vs = c_rbinv[3 * tt]; w.vg = c_rbinv[3 * tt + 1]; w.vi = c_rbinv[3 * tt + 2];
+    w.se = c_rend[3 * tt]; w.ge = c_rend[3 * tt + 1]; w.ie = c_rend[3 * tt + 2];
+    return w;
+  };
+  auto make_ranges = [&](const RawRanges& w) -> Ranges {
     Ranges q;
-    const uint32_t vs = p.rbinv[3 * tt], vg = p.rbinv[3 * tt + 1], vi = p.rbinv[3 * tt + 2];
-    const int se = (int)p.rend[3 * tt], ge = (int)p.rend[3 * tt + 1], ie = (int)p.rend[3 * tt + 2];
-    q.sb = vs ? p.n_reads - (int)vs : se;
-    q.gb = vg ? p.n_reads - (int)vg : ge;
-    q.ib = vi ? p.n_reads - (int)vi : ie;
+    const int se = (int)w.se, ge = (int)w.ge, ie = (int)w.ie;
+    q.sb = w.vs ? p.n_reads - (int)w.vs : se;
+    q.gb = w.vg ? p.n_reads - (int)w.vg : ge;
+    q.ib = w.vi ? p.n_reads - (int)w.vi : ie;
     q.ns = se - q.sb;
     q.nsi = q.ns + (ie - q.ib);
     q.total = q.nsi + (ge - q.gb);
@@ -196,18 +219,36 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     (void)pure_simple; (void)n;
   };
   constexpr int NWAVES = kPileupBlock / 64;
-  Tile tile = p.tiles[t];
-  Ranges rg = tile_ranges(t);
+  // developer instrumentation: per-phase cycle sums of every wave (lane-uniform values), see MIDAS_SNPS_PHASES
+#ifdef MIDAS_PHASE_PROFILE
+  const bool prof = p.phase_clk != nullptr;
+#else
+  constexpr bool prof = false;   // compiled out: build with MIDAS_HIPCC_EXTRA=-DMIDAS_PHASE_PROFILE to enable
+#endif
+  unsigned long long ph[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long clk = prof ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long clk_begin = clk;
+  auto mark = [&](int k) {
+    if (prof) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - clk; clk = now; }
+  };
+  Tile tile = load_tile(c_tiles, t);
+  Ranges rg = make_ranges(load_ranges(t));
   uint4 rec_cur = fetch_rec(rg, wave);
   uint4 rec_nxt = fetch_rec(rg, wave + NWAVES);
   Payload cur;
   fetch_payload(rec_cur, rg, wave, cur);
   __syncthreads();   // LDS zeroed, tables in place
+  mark(0);           // prologue
 
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
     uint32_t w_aligned = 0, w_mapped = 0;
+    // next tile's descriptor and index words: scalar loads issued now, consumed after this tile's reads
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < p.n_tiles;
+    const Tile ntile = load_tile(c_tiles, more ? tn : t);
+    const RawRanges nraw = load_ranges(more ? tn : t);
 
     const int n_iter = (rg.total + rpw - 1) / rpw;
     for (int it = wave; it < n_iter; it += NWAVES) {
@@ -216,6 +257,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       fetch_payload(rec_nxt, rg, it + NWAVES, nxt);
 
       // ================= process (rec_cur, cur) ===================================================
+      if (prof) { mark(1); __builtin_amdgcn_s_waitcnt(0x0F70); mark(2); }   // 1: issue of the prefetches, 2: vmcnt(0) wait
       const int r = read_at(rg, it * rpw + g);
       bool act = r < p.n_reads;
       const int l = rec_l(rec_cur);
@@ -395,25 +437,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       rec_cur = rec_nxt;
       rec_nxt = rec_nn;
       cur = nxt;
+      mark(3);   // processing of one wave-iteration
     }
+    mark(1);
 
     if (lane == 0) {
       if (w_aligned) atomicAdd(&s_stats[MIDAS_STAT_ALIGNED], (unsigned long long)w_aligned);
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
     }
-    __syncthreads();   // every tally of this tile is in LDS
-
-    // ---- next tile: its first loads go out BEFORE this tile's stores ------------------------------------
-    const int tn = t + (int)gridDim.x;
-    const bool more = tn < p.n_tiles;
-    Tile ntile = tile;
-    Ranges nrg = rg;
+    // ---- next tile: its record loads go out before the barrier, its payload loads before this tile's stores ----
+    const Ranges nrg = make_ranges(nraw);
     if (more) {
-      ntile = p.tiles[tn];
-      nrg = tile_ranges(tn);
       rec_cur = fetch_rec(nrg, wave);
       rec_nxt = fetch_rec(nrg, wave + NWAVES);
     }
+    __syncthreads();   // every tally of this tile is in LDS
+    mark(4);           // barrier: waiting for the slowest wave of the tile
+    if (more) fetch_payload(rec_cur, nrg, wave, cur);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
     unsigned long long covered = 0, depth_sum = 0;
@@ -434,8 +474,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         }
       }
     }
-    if (more) fetch_payload(rec_cur, nrg, wave, cur);   // waits for the two record loads only
-
     // ---- upper-cased ref allele, four sites per lane ---------------------------------------------------------
     if (p.out_allele && !(p.debug & 2)) {
       const uint8_t* ref = p.ref + tile.site_base;
@@ -463,6 +501,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
       if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
     }
+    mark(5);           // next tile's first loads, write-out, alleles, reductions
     __syncthreads();   // s_stats complete
     if (tid < MIDAS_STATS) {
       const unsigned long long v = s_stats[tid];
@@ -471,9 +510,15 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     }
     if (!more) break;
     __syncthreads();   // LDS tallies re-zeroed and s_stats reset before the next tile's waves touch them
+    mark(6);           // the two barriers after the write-out
     t = tn;
     tile = ntile;
     rg = nrg;
+  }
+  if (prof && lane == 0) {
+    for (int k = 0; k < 7; ++k) atomicAdd(&p.phase_clk[k], ph[k]);
+    atomicAdd(&p.phase_clk[7], __builtin_readcyclecounter() - clk_begin);   // whole wave
+    atomicAdd(&p.phase_clk[8], 1ull);                                       // waves
   }
 }
 

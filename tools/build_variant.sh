@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build a developer variant of the library next to the product one: tools/build_variant.sh <suffix> <extra hipcc flags...>
+# Use it with MIDAS_SNPS_LIBRARY=midas_amd/lib/libmidas_snps_hip_<suffix>.so (e.g. -DMIDAS_PHASE_PROFILE).
+set -e
+SUF=$1; shift
+cd "$(dirname "$0")/.."
+C=midas_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip "$@" $C/pack.cpp $C/hostio.cpp $C/index_reads.hip \
+  $C/pileup_tiles.hip $C/merge_sites.hip $C/snps_abi.hip -o midas_amd/lib/libmidas_snps_hip_$SUF.so -lz -lpthread
+echo built midas_amd/lib/libmidas_snps_hip_$SUF.so
