@@ -35,37 +35,43 @@ using namespace dev;
 
 namespace {
 
-// One base of the hot loop, hand-scheduled: byte compare (SDWA) -> exec mask -> address OR (SDWA) ->
-// returnless LDS atomic -> exec restore.  Written as asm because the compiler wraps every predicated
-// ds_add in an s_cbranch_execz skip branch (11.7 M branches per launch on the 1 M-read workload).
-//   q4/cd4: four quality / call-code bytes, BYTE selects the base; abase: LDS byte address of the chunk's
-//   first site (multiple of 16, so OR-ing the call code 0/4/8/12 selects the counter); OFF = 16 * j.
-template <int BYTE, int OFF>
-__device__ __forceinline__ void tally_base(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
-  uint32_t tmp;
-  unsigned long long save;
-#define MIDAS_TALLY_ASM(B)                                                                                   \
-  asm volatile("v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:BYTE_" #B " src1_sel:DWORD\n\t"                        \
-               "s_and_saveexec_b64 %1, vcc\n\t"                                                               \
-               "v_or_b32_sdwa %0, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B \
-               "\n\t"                                                                                         \
-               "ds_add_u32 %0, %6 offset:%7\n\t"                                                              \
-               "s_mov_b64 exec, %1"                                                                           \
-               : "=&v"(tmp), "=&s"(save)                                                                      \
-               : "v"(q4), "s"(bq), "v"(cd4), "v"(abase), "v"(one), "n"(OFF)                                   \
-               : "vcc", "memory")
-  if constexpr (BYTE == 0) MIDAS_TALLY_ASM(0);
-  else if constexpr (BYTE == 1) MIDAS_TALLY_ASM(1);
-  else if constexpr (BYTE == 2) MIDAS_TALLY_ASM(2);
-  else MIDAS_TALLY_ASM(3);
-#undef MIDAS_TALLY_ASM
+// Four bases of the hot loop, hand-scheduled.  Per base: byte compare against baseq (SDWA) -> lane mask in an SGPR
+// pair; address = chunk base | call code (SDWA OR); returnless LDS atomic under that mask.  The four address ORs and
+// the four compares are issued back to back (no dependency between them), then each atomic runs under its mask and
+// exec is restored once per word -- instead of compare -> saveexec -> OR -> atomic -> restore chained per base.
+// Written as asm because the compiler wraps every predicated ds_add in an s_cbranch_execz skip branch.
+//   q4/cd4: four quality / call-code bytes; abase: LDS byte address of the chunk's first site (multiple of 16, so
+//   OR-ing the call code 0/4/8/12 selects the counter); OFF = byte offset of the word's first site.
+template <int OFF>
+__device__ __forceinline__ void tally_word_at(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
+  uint32_t t0, t1, t2, t3;
+  unsigned long long m0, m1, m2, m3, save;
+  asm volatile(
+      "v_or_b32_sdwa %0, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+      "v_or_b32_sdwa %1, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+      "v_or_b32_sdwa %2, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_or_b32_sdwa %3, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+      "v_cmp_ge_u32_sdwa %4, %9, %12 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %5, %9, %12 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %6, %9, %12 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %7, %9, %12 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "s_mov_b64 %8, exec\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "ds_add_u32 %0, %13 offset:%14\n\t"
+      "s_mov_b64 exec, %5\n\t"
+      "ds_add_u32 %1, %13 offset:%14+16\n\t"
+      "s_mov_b64 exec, %6\n\t"
+      "ds_add_u32 %2, %13 offset:%14+32\n\t"
+      "s_mov_b64 exec, %7\n\t"
+      "ds_add_u32 %3, %13 offset:%14+48\n\t"
+      "s_mov_b64 exec, %8"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(save)
+      : "v"(q4), "v"(cd4), "v"(abase), "s"(bq), "v"(one), "n"(OFF)
+      : "memory");
 }
 template <int W>
 __device__ __forceinline__ void tally_word(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
-  tally_base<0, 64 * W + 0>(q4, cd4, bq, abase, one);
-  tally_base<1, 64 * W + 16>(q4, cd4, bq, abase, one);
-  tally_base<2, 64 * W + 32>(q4, cd4, bq, abase, one);
-  tally_base<3, 64 * W + 48>(q4, cd4, bq, abase, one);
+  tally_word_at<64 * W>(q4, cd4, bq, abase, one);
 }
 __device__ __forceinline__ void tally_chunk(const uint32_t (&q4)[kChunk / 4], const uint32_t (&cd)[kChunk / 4], uint32_t bq,
                                             uint32_t abase, uint32_t one) {
@@ -194,8 +200,11 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   };
   // virtual stream position -> read index (n_reads = the sentinel record for positions past the end)
   auto read_at = [&](const Ranges& q, int v) -> int {
-    const int r = v < q.ns ? q.sb + v : (v < q.nsi ? q.ib + (v - q.ns) : q.gb + (v - q.nsi));
-    return (lane_used && v < q.total) ? r : p.n_reads;
+    // selects, not branches: base index of the range that stream position v falls into
+    int base = q.gb - q.nsi;
+    base = v < q.nsi ? q.ib - q.ns : base;
+    base = v < q.ns ? q.sb : base;
+    return (lane_used && v < q.total) ? base + v : p.n_reads;
   };
   auto fetch_rec = [&](const Ranges& q, int it) -> uint4 { return recs[read_at(q, it * rpw + g)]; };
 
@@ -205,9 +214,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int l = rec_l(rv);
     const int n = rec_n(rv);
     const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) d.qw[w] = 0u;
-    d.sw[0] = d.sw[1] = d.sw[2] = d.sw[3] = 0u;
+    // lanes without a chunk load nothing and never look at their payload registers (`has` guards every use)
     if (act && q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + q0);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + q0 + 16);
@@ -244,11 +251,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const int tile_len = tile.len;
     const int tile_start = tile.start;
     uint32_t w_aligned = 0, w_mapped = 0;
-    // next tile's descriptor and index words: scalar loads issued now, consumed after this tile's reads
-    const int tn = t + (int)gridDim.x;
-    const bool more = tn < p.n_tiles;
-    const Tile ntile = load_tile(c_tiles, more ? tn : t);
-    const RawRanges nraw = load_ranges(more ? tn : t);
 
     const int n_iter = (rg.total + rpw - 1) / rpw;
     for (int it = wave; it < n_iter; it += NWAVES) {
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       uint32_t part = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) part = __builtin_amdgcn_sad_u8(cur.qw[w], 0u, part);
+      part = has ? part : 0u;
       int qsum;
       if (lpr <= 8) {
         // running window sum: after lpr-1 steps lane i holds x[i] + ... + x[i-lpr+1]; the read's last lane has it all
@@ -336,27 +339,41 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
 
       // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
-      bool keep = false;
-      uint32_t err = 0;
-      if (act) {
-        if (l == 0) err = E_NO_SEQ;
-        else if (rec_nm(rec_cur) == kNmAbsent) err = E_NO_NM;
-        else if (align_len == 0) err = E_ZERO_ALIGN;
-        else if (align_len - (int)rec_nm(rec_cur) < min_match) keep = false;            // pid < mapid
-        else if (flags & kRecQualAbsent) err = E_NO_QUAL;
-        // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; the quotient is >= 2^-16 away from readq)
-        else if ((long long)qsum < (long long)p.readq * (long long)l) keep = false;
-        else if (rec_mapq(rec_cur) < p.mapq) keep = false;
-        else if (align_len < min_align) keep = false;                                     // aln_cov
-        else if (flags & kRecOverrun) err = E_CIGAR_OVERRUN;   // kept, and its CIGAR reaches past SEQ inside the contig
-        else keep = true;
-      }
+      // Every test is evaluated (selects, no branches: the cascade used to cost seven exec-mask branches per
+      // iteration); the reference's order decides which outcome wins, lowest priority first.
+      const int nm = (int)rec_nm(rec_cur);
+      const bool t_noseq = l == 0;
+      const bool t_nonm = nm == (int)kNmAbsent;
+      const bool t_zero = align_len == 0;
+      const bool t_pid = align_len - nm < min_match;                                     // pid < mapid
+      const bool t_noqual = (flags & kRecQualAbsent) != 0u;
+      // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; the quotient is >= 2^-16 away from readq)
+      const bool t_drop = ((long long)qsum < (long long)p.readq * (long long)l) | (rec_mapq(rec_cur) < p.mapq) |
+                          (align_len < min_align);                                       // readq, mapq, aln_cov
+      const bool t_over = (flags & kRecOverrun) != 0u;   // kept, and its CIGAR reaches past SEQ inside the contig
+      uint32_t err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
+      err = t_drop ? 0u : err;
+      err = t_noqual ? (uint32_t)E_NO_QUAL : err;
+      err = t_pid ? 0u : err;
+      err = t_zero ? (uint32_t)E_ZERO_ALIGN : err;
+      err = t_nonm ? (uint32_t)E_NO_NM : err;
+      err = t_noseq ? (uint32_t)E_NO_SEQ : err;
+      err = act ? err : 0u;
+      const bool keep = act & !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
 
       // ---- per-base call codes and validity, four bases per instruction ----------------------------
       uint32_t qv[NW];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
       uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
       bool walking = keep && has && !(p.debug & 4);
-      if (walking) {
+      if (walking) {     // (qv, cd are only ever read under `walking`)
+        uint32_t qsrc[NW];
+        if (count_all) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) qsrc[w] = low_bytes_mask(nvalid - 4 * w);
+        } else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) qsrc[w] = cur.qw[w];
+        }
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));               // call bytes 2w, 2w+1: bases 4w .. 4w+3
@@ -364,13 +381,9 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
           const uint32_t nib = ((t4 >> 4) & 0x000F000Fu) | (t4 & 0x0F000F00u);  // one call code per byte
           const uint32_t inv = nib & 0x02020202u;                              // not A/C/G/T
           const uint32_t inv_ff = (inv << 7) - (inv >> 1);                     // 0xFF in every such byte
-          const uint32_t q = count_all ? low_bytes_mask(nvalid - 4 * w) : cur.qw[w];
-          qv[w] = q & ~inv_ff;
+          qv[w] = qsrc[w] & ~inv_ff;
           cd[w] = nib & 0x0C0C0C0Cu;
         }
-      } else {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { qv[w] = 0u; cd[w] = 0u; }
       }
 
       // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -----
@@ -446,7 +459,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
     }
     // ---- next tile: its record loads go out before the barrier, its payload loads before this tile's stores ----
-    const Ranges nrg = make_ranges(nraw);
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < p.n_tiles;
+    const Tile ntile = load_tile(c_tiles, more ? tn : t);            // scalar loads (constant address space)
+    const Ranges nrg = make_ranges(load_ranges(more ? tn : t));
     if (more) {
       rec_cur = fetch_rec(nrg, wave);
       rec_nxt = fetch_rec(nrg, wave + NWAVES);
