@@ -44,6 +44,7 @@ constexpr uint8_t kRecQualAbsent = 1;   // qual[0] == 0xFF (BAM: QUAL missing)
 constexpr uint8_t kRecSimple = 2;       // CIGAR is exactly one M/=/X op of length l_seq: the walk is the identity
 constexpr uint8_t kRecClipGeneric = 4;  // clip structure needs the general H/S loops (an H among the clips, or
                                         // several S at one end); when clear: lead = (op0 == S), trail = (opLast == S)
+constexpr uint8_t kRecSentinel = 0x80; // the record after the last read (l_seq 0): stream positions past a tile's reads
 constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >= l_seq onto a site inside the
                                         // contig: pysam would index past SEQ (IndexError) if the read is kept
 

@@ -269,6 +269,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     ReadRec s;  // sentinel: where the payload ends
     memset(&s, 0, sizeof s);
     s.blob_off8 = (uint32_t)(off[n] >> 3);
+    s.flags = kRecSentinel;
     rec[n] = s;
   }
   return MIDAS_SNPS_OK;

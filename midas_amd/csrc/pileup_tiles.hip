@@ -35,55 +35,65 @@ using namespace dev;
 
 namespace {
 
-// Four bases of the hot loop, hand-scheduled.  Per base: byte compare against baseq (SDWA) -> lane mask in an SGPR
-// pair; address = chunk base | call code (SDWA OR); returnless LDS atomic under that mask.  The four address ORs and
-// the four compares are issued back to back (no dependency between them), then each atomic runs under its mask and
-// exec is restored once per word -- instead of compare -> saveexec -> OR -> atomic -> restore chained per base.
-// Written as asm because the compiler wraps every predicated ds_add in an s_cbranch_execz skip branch.
-//   q4/cd4: four quality / call-code bytes; abase: LDS byte address of the chunk's first site (multiple of 16, so
-//   OR-ing the call code 0/4/8/12 selects the counter); OFF = byte offset of the word's first site.
+// Eight bases of the hot loop, hand-scheduled.  Per base: byte compare against baseq (SDWA) -> lane mask in an SGPR
+// pair; address = chunk base | call code (SDWA OR); returnless LDS atomic under that mask.  The eight address ORs and
+// the eight compares are issued back to back (no dependency between them), then each atomic runs under its mask and
+// exec is restored once -- instead of compare -> saveexec -> OR -> atomic -> restore chained per base (measured:
+// 156 -> 147 us).  Written as asm because the compiler wraps every predicated ds_add in an s_cbranch_execz skip branch.
+//   qa,qb / ca,cb: two words of four quality / call-code bytes; abase: LDS byte address of the chunk's first site
+//   (multiple of 16, so OR-ing the call code 0/4/8/12 selects the counter); OFF = byte offset of the first site.
 template <int OFF>
-__device__ __forceinline__ void tally_word_at(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
-  uint32_t t0, t1, t2, t3;
-  unsigned long long m0, m1, m2, m3, save;
+__device__ __forceinline__ void tally_pair_at(uint32_t qa, uint32_t qb, uint32_t ca, uint32_t cb, uint32_t bq, uint32_t abase,
+                                              uint32_t one) {
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, save;
   asm volatile(
-      "v_or_b32_sdwa %0, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-      "v_or_b32_sdwa %1, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-      "v_or_b32_sdwa %2, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
-      "v_or_b32_sdwa %3, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
-      "v_cmp_ge_u32_sdwa %4, %9, %12 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %5, %9, %12 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %6, %9, %12 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %7, %9, %12 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-      "s_mov_b64 %8, exec\n\t"
-      "s_mov_b64 exec, %4\n\t"
-      "ds_add_u32 %0, %13 offset:%14\n\t"
-      "s_mov_b64 exec, %5\n\t"
-      "ds_add_u32 %1, %13 offset:%14+16\n\t"
-      "s_mov_b64 exec, %6\n\t"
-      "ds_add_u32 %2, %13 offset:%14+32\n\t"
-      "s_mov_b64 exec, %7\n\t"
-      "ds_add_u32 %3, %13 offset:%14+48\n\t"
-      "s_mov_b64 exec, %8"
-      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(save)
-      : "v"(q4), "v"(cd4), "v"(abase), "s"(bq), "v"(one), "n"(OFF)
+      "v_or_b32_sdwa %0, %21, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+      "v_or_b32_sdwa %1, %21, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+      "v_or_b32_sdwa %2, %21, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_or_b32_sdwa %3, %21, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+      "v_or_b32_sdwa %4, %21, %20 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+      "v_or_b32_sdwa %5, %21, %20 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+      "v_or_b32_sdwa %6, %21, %20 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_or_b32_sdwa %7, %21, %20 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+      "v_cmp_ge_u32_sdwa %8, %17, %22 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %9, %17, %22 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %10, %17, %22 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %11, %17, %22 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %12, %18, %22 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %13, %18, %22 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %14, %18, %22 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %15, %18, %22 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "s_mov_b64 %16, exec\n\t"
+      "s_mov_b64 exec, %8\n\t"
+      "ds_add_u32 %0, %23 offset:%24\n\t"
+      "s_mov_b64 exec, %9\n\t"
+      "ds_add_u32 %1, %23 offset:%24+16\n\t"
+      "s_mov_b64 exec, %10\n\t"
+      "ds_add_u32 %2, %23 offset:%24+32\n\t"
+      "s_mov_b64 exec, %11\n\t"
+      "ds_add_u32 %3, %23 offset:%24+48\n\t"
+      "s_mov_b64 exec, %12\n\t"
+      "ds_add_u32 %4, %23 offset:%24+64\n\t"
+      "s_mov_b64 exec, %13\n\t"
+      "ds_add_u32 %5, %23 offset:%24+80\n\t"
+      "s_mov_b64 exec, %14\n\t"
+      "ds_add_u32 %6, %23 offset:%24+96\n\t"
+      "s_mov_b64 exec, %15\n\t"
+      "ds_add_u32 %7, %23 offset:%24+112\n\t"
+      "s_mov_b64 exec, %16"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&s"(m0), "=&s"(m1),
+        "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7), "=&s"(save)
+      : "v"(qa), "v"(qb), "v"(ca), "v"(cb), "v"(abase), "s"(bq), "v"(one), "n"(OFF)
       : "memory");
-}
-template <int W>
-__device__ __forceinline__ void tally_word(uint32_t q4, uint32_t cd4, uint32_t bq, uint32_t abase, uint32_t one) {
-  tally_word_at<64 * W>(q4, cd4, bq, abase, one);
 }
 __device__ __forceinline__ void tally_chunk(const uint32_t (&q4)[kChunk / 4], const uint32_t (&cd)[kChunk / 4], uint32_t bq,
                                             uint32_t abase, uint32_t one) {
   static_assert(kChunk == 32, "tally_chunk is written for 8 words");
-  tally_word<0>(q4[0], cd[0], bq, abase, one);
-  tally_word<1>(q4[1], cd[1], bq, abase, one);
-  tally_word<2>(q4[2], cd[2], bq, abase, one);
-  tally_word<3>(q4[3], cd[3], bq, abase, one);
-  tally_word<4>(q4[4], cd[4], bq, abase, one);
-  tally_word<5>(q4[5], cd[5], bq, abase, one);
-  tally_word<6>(q4[6], cd[6], bq, abase, one);
-  tally_word<7>(q4[7], cd[7], bq, abase, one);
+  tally_pair_at<0>(q4[0], q4[1], cd[0], cd[1], bq, abase, one);
+  tally_pair_at<128>(q4[2], q4[3], cd[2], cd[3], bq, abase, one);
+  tally_pair_at<256>(q4[4], q4[5], cd[4], cd[5], bq, abase, one);
+  tally_pair_at<384>(q4[6], q4[7], cd[6], cd[7], bq, abase, one);
 }
 
 // Byte mask with bytes [0, hi) of a 32-bit word set.
@@ -206,16 +216,15 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     base = v < q.ns ? q.sb : base;
     return (lane_used && v < q.total) ? base + v : p.n_reads;
   };
-  auto fetch_rec = [&](const Ranges& q, int it) -> uint4 { return recs[read_at(q, it * rpw + g)]; };
+  // v = stream position of this lane's read
+  auto fetch_rec = [&](const Ranges& q, int v) -> uint4 { return recs[read_at(q, v)]; };
 
-  auto fetch_payload = [&](const uint4& rv, const Ranges& q, int it, Payload& d) {
-    const bool act = lane_used && it * rpw + g < q.total;
-    const bool pure_simple = (it + 1) * rpw <= q.ns;   // wave-uniform: no CIGAR to fetch
+  auto fetch_payload = [&](const uint4& rv, Payload& d) {
+    // lanes without a chunk (the sentinel record has l_seq 0) load nothing and never look at their payload
+    // registers: `has` guards every use
     const int l = rec_l(rv);
-    const int n = rec_n(rv);
     const uint8_t* bp = p.blob + (size_t)rec_off8(rv) * 8;
-    // lanes without a chunk load nothing and never look at their payload registers (`has` guards every use)
-    if (act && q0 < l) {
+    if (q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + q0);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + q0 + 16);
       const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l) + (q0 >> 1));
@@ -223,7 +232,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
       d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
-    (void)pure_simple; (void)n;
   };
   constexpr int NWAVES = kPileupBlock / 64;
   // developer instrumentation: per-phase cycle sums of every wave (lane-uniform values), see MIDAS_SNPS_PHASES
@@ -240,10 +248,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   };
   Tile tile = load_tile(c_tiles, t);
   Ranges rg = make_ranges(load_ranges(t));
-  uint4 rec_cur = fetch_rec(rg, wave);
-  uint4 rec_nxt = fetch_rec(rg, wave + NWAVES);
+  const int vstep = NWAVES * rpw;                 // stream positions between a wave's consecutive iterations
+  const int v0 = wave * rpw + g;                  // this lane's stream position in the wave's first iteration
+  uint4 rec_cur = fetch_rec(rg, v0);
+  uint4 rec_nxt = fetch_rec(rg, v0 + vstep);
   Payload cur;
-  fetch_payload(rec_cur, rg, wave, cur);
+  fetch_payload(rec_cur, cur);
   __syncthreads();   // LDS zeroed, tables in place
   mark(0);           // prologue
 
@@ -253,19 +263,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     uint32_t w_aligned = 0, w_mapped = 0;
 
     const int n_iter = (rg.total + rpw - 1) / rpw;
-    for (int it = wave; it < n_iter; it += NWAVES) {
-      const uint4 rec_nn = fetch_rec(rg, it + 2 * NWAVES);
+    int vpos = v0;
+    for (int it = wave; it < n_iter; it += NWAVES, vpos += vstep) {
+      const uint4 rec_nn = fetch_rec(rg, vpos + 2 * vstep);
       Payload nxt;
-      fetch_payload(rec_nxt, rg, it + NWAVES, nxt);
+      fetch_payload(rec_nxt, nxt);
 
       // ================= process (rec_cur, cur) ===================================================
       if (prof) { mark(1); __builtin_amdgcn_s_waitcnt(0x0F70); mark(2); }   // 1: issue of the prefetches, 2: vmcnt(0) wait
-      const int r = read_at(rg, it * rpw + g);
-      bool act = r < p.n_reads;
       const int l = rec_l(rec_cur);
       const int n = rec_n(rec_cur);
       const int pos = rec_pos(rec_cur);
       const uint32_t flags = rec_flags(rec_cur);
+      bool act = (flags & kRecSentinel) == 0u;   // stream positions past the tile's reads fetched the sentinel
       const bool simple = (flags & kRecSimple) != 0u;
       // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
       int cpos = pos < 0 ? 0 : pos;
@@ -445,7 +455,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const unsigned long long m_mp = __ballot(head && keep);
       w_aligned += (uint32_t)__popcll(m_al);
       w_mapped += (uint32_t)__popcll(m_mp);
-      if (head && err) atomicMin(p.err, ((unsigned long long)p.orig[r] << 8) | err);   // input-order index of the record
+      if (head && err)   // input-order index of the record
+        atomicMin(p.err, ((unsigned long long)p.orig[read_at(rg, vpos)] << 8) | err);
 
       rec_cur = rec_nxt;
       rec_nxt = rec_nn;
@@ -464,12 +475,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const Tile ntile = load_tile(c_tiles, more ? tn : t);            // scalar loads (constant address space)
     const Ranges nrg = make_ranges(load_ranges(more ? tn : t));
     if (more) {
-      rec_cur = fetch_rec(nrg, wave);
-      rec_nxt = fetch_rec(nrg, wave + NWAVES);
+      rec_cur = fetch_rec(nrg, v0);
+      rec_nxt = fetch_rec(nrg, v0 + vstep);
     }
     __syncthreads();   // every tally of this tile is in LDS
     mark(4);           // barrier: waiting for the slowest wave of the tile
-    if (more) fetch_payload(rec_cur, nrg, wave, cur);
+    if (more) fetch_payload(rec_cur, cur);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
     unsigned long long covered = 0, depth_sum = 0;
