@@ -23,7 +23,8 @@ __device__ __forceinline__ bool consumes_both(uint32_t op) { return op == OP_M |
 // Unpacked view of a 16-byte ReadRec held as a uint4.
 __device__ __forceinline__ int rec_pos(const uint4& r) { return (int)r.x; }
 __device__ __forceinline__ uint32_t rec_off8(const uint4& r) { return r.y; }
-__device__ __forceinline__ int rec_l(const uint4& r) { return (int)(r.z & 0xFFFFu); }
+__device__ __forceinline__ int rec_l(const uint4& r) { return (int)(r.z & 0x7FFu); }
+__device__ __forceinline__ int rec_qmean(const uint4& r) { return (int)(((r.z >> 11) & 31u) | ((r.w >> 23) & 0xE0u)); }
 __device__ __forceinline__ int rec_n(const uint4& r) { return (int)(r.z >> 16); }
 __device__ __forceinline__ uint32_t rec_nm(const uint4& r) { return r.w & 0xFFFFu; }
 __device__ __forceinline__ int rec_mapq(const uint4& r) { return (int)((r.w >> 16) & 0xFFu); }

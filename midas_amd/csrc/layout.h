@@ -6,10 +6,13 @@
 //                            last record is a sentinel whose blob_off8 is the end of the payload
 //   blob  [...]              per read, 8-byte aligned, reads back to back in BAM order
 //                            (240 B for a 150 bp single-match read):
-//                              qual   l_seq bytes, zero-padded to a multiple of 32
-//                              calls  ceil(l_seq/2) bytes, zero-padded to a multiple of 16: one 4-bit
-//                                     call code per base, first base in the high nibble
-//                                     (A=0x0 C=0x4 G=0x8 T=0xC, every other BAM base code = 0x2)
+//                              qual   l_seq bytes, zero-padded to a multiple of 32; the byte of a base that
+//                                     is not A/C/G/T is stored as 0 (such a base can never count; the whole-read
+//                                     mean the readq filter needs travels in the record, see ReadRec)
+//                              calls  16 bytes per 32-base chunk: byte k holds the 4-bit call codes of bases k
+//                                     (low nibble) and k + 16 (high nibble) of the chunk, so a lane gets its
+//                                     32 byte-offsets with one AND per four bases
+//                                     (A=0x0 C=0x4 G=0x8 T=0xC, every other BAM base code and padding = 0x2)
 //                              cigar  n_cigar * u32 -- omitted when the record is kRecSimple
 //                            coordinate-sorted input => the reads of a tile are one contiguous
 //                            byte range of `blob`.
@@ -30,12 +33,16 @@ namespace midas {
 struct ReadRec {            // 16 bytes, 16-byte aligned
   int32_t pos;              // BAM pos (0-based leftmost)
   uint32_t blob_off8;       // payload offset in 8-byte units
-  uint16_t l_seq;           // stored query length (soft clips included)
+  uint16_t l_seq;           // bits 0-10: stored query length (soft clips included, <= kMaxLSeq);
+                            // bits 11-15: low five bits of qmean = floor(sum(qual) / l_seq)  (see rec_qmean)
   uint16_t n_cigar;
   uint16_t nm;              // NM tag; kNmAbsent when the record has none
   uint8_t mapq;
-  uint8_t flags;            // kRec* bits
+  uint8_t flags;            // kRec* bits; bits 4-6: high three bits of qmean
 };
+// qmean: `np.mean(query_qualities) < readq` (midas/run/snps.py:154) with an integer readq is exactly
+// floor(sum / l) < readq, so eight bits per read replace a reduction over its quality bytes on the device.
+constexpr int kRecLBits = 11;
 static_assert(sizeof(ReadRec) == 16, "ReadRec must be 16 bytes");
 
 constexpr uint16_t kNmAbsent = 0xFFFF;

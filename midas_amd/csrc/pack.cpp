@@ -38,20 +38,15 @@ void parallel_ranges(int64_t n, F&& fn) {
   for (auto& x : th) x.join();
 }
 
-// byte of two BAM base codes ("=ACMGRSVTWYHKDBN") -> byte of two call codes (layout.h)
+// BAM base code ("=ACMGRSVTWYHKDBN") -> call code (layout.h)
 struct CallCodeTable {
-  uint8_t v[256];
+  uint8_t v[16];
   constexpr CallCodeTable() : v() {
-    for (int b = 0; b < 256; ++b) {
-      const int hi = b >> 4, lo = b & 15;
-      const int ch = hi == 1 ? kCallA : hi == 2 ? kCallC : hi == 4 ? kCallG : hi == 8 ? kCallT : kCallOther;
-      const int cl = lo == 1 ? kCallA : lo == 2 ? kCallC : lo == 4 ? kCallG : lo == 8 ? kCallT : kCallOther;
-      v[b] = (uint8_t)((ch << 4) | cl);
-    }
+    for (int b = 0; b < 16; ++b) v[b] = b == 1 ? kCallA : b == 2 ? kCallC : b == 4 ? kCallG : b == 8 ? kCallT : kCallOther;
   }
   constexpr uint8_t operator[](uint8_t b) const { return v[b]; }
 };
-constexpr CallCodeTable kCallCodePair{};
+constexpr CallCodeTable kCallCode{};
 
 void set_err(char* err256, const char* fmt, long long a = 0, long long b = 0, long long c = 0) {
   if (err256) snprintf(err256, 256, fmt, a, b, c);
@@ -245,23 +240,41 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       uint8_t* b = blob + off[j];
       const uint8_t* q = r->qual + r->qual_off[i];
       memset(b, 0, bytes[i]);
-      memcpy(b, q, l);
+      uint64_t qsum = 0;
       {
-        // BAM 4-bit base codes -> call codes; the zero padding decodes as 'A' but carries quality 0
+        // qualities (0 for a base that is not A/C/G/T) and, per 32-base chunk, 16 bytes of call codes: byte k =
+        // code(base k) | code(base k + 16) << 4; bases past the end are kCallOther with quality 0
         const uint8_t* s4 = r->seq4 + r->seq_off[i];
         uint8_t* d4 = b + blob_seq_off(l);
-        const uint32_t nb = (l + 1) / 2;
-        for (uint32_t k = 0; k < nb; ++k) d4[k] = kCallCodePair[s4[k]];
+        const uint32_t n_chunks = (l + kChunk - 1) / kChunk;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+          for (uint32_t k = 0; k < 16; ++k) {
+            uint8_t code[2];
+            for (uint32_t h = 0; h < 2; ++h) {
+              const uint32_t j = c * kChunk + 16 * h + k;
+              if (j < l) {
+                const uint8_t bc = (uint8_t)((s4[j >> 1] >> ((~j & 1u) * 4)) & 15u);
+                code[h] = kCallCode[bc];
+                qsum += q[j];
+                b[j] = code[h] == kCallOther ? (uint8_t)0 : q[j];
+              } else {
+                code[h] = kCallOther;
+              }
+            }
+            d4[c * 16 + k] = (uint8_t)(code[0] | (code[1] << 4));
+          }
+        }
       }
       if (!(cflags[i] & kRecSimple)) memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
       ReadRec rr;
       rr.pos = r->pos[i];
       rr.blob_off8 = (uint32_t)(off[j] >> 3);
-      rr.l_seq = (uint16_t)l;
+      const uint32_t qmean = l > 0 ? (uint32_t)(qsum / l) : 0u;   // <= 255
+      rr.l_seq = (uint16_t)(l | ((qmean & 31u) << kRecLBits));
       rr.n_cigar = (uint16_t)nc;
       rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
       rr.mapq = r->mapq[i];
-      rr.flags = (uint8_t)(cflags[i] | ((l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0));
+      rr.flags = (uint8_t)(cflags[i] | ((l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0) | ((qmean >> 5) << 4));
       rec[j] = rr;
     }
   });

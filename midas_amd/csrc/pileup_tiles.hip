@@ -114,11 +114,6 @@ __device__ __forceinline__ uint32_t upper4(uint32_t x) {
   return x - (lower >> 2);
 }
 
-// lane i <- lane i-1 (lane 0 <- 0), one VALU op (v_add_u32_dpp wave_shr:1 when fused with the add)
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
-}
-
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 // the three read ranges of a tile as one virtual stream: range starts; |S|, |S|+|I|, |S|+|I|+|G|
@@ -328,25 +323,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
       const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
 
-      // ---- quality sum of the whole read: per-lane partial, then a segmented reduction ----------
       const int nvalid = has ? (l - q0 < kChunk ? l - q0 : kChunk) : 0;
-      uint32_t part = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) part = __builtin_amdgcn_sad_u8(cur.qw[w], 0u, part);
-      part = has ? part : 0u;
-      int qsum;
-      if (lpr <= 8) {
-        // running window sum: after lpr-1 steps lane i holds x[i] + ... + x[i-lpr+1]; the read's last lane has it all
-        uint32_t s = part;
-        for (int d = 1; d < lpr; ++d) s = part + wave_shr1(s);
-        qsum = (int)__shfl(s, lane - c + lpr - 1);
-      } else {
-        for (int d = 1; d < lpr; d <<= 1) {
-          const uint32_t o = __shfl_down(part, d);
-          if (c + d < lpr) part += o;
-        }
-        qsum = (int)__shfl(part, lane - c);
-      }
 
       // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
       // Every test is evaluated (selects, no branches: the cascade used to cost seven exec-mask branches per
@@ -357,8 +334,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const bool t_zero = align_len == 0;
       const bool t_pid = align_len - nm < min_match;                                     // pid < mapid
       const bool t_noqual = (flags & kRecQualAbsent) != 0u;
-      // np.mean(q) < readq  <=>  sum(q) < readq * n exactly (integers; the quotient is >= 2^-16 away from readq)
-      const bool t_drop = ((long long)qsum < (long long)p.readq * (long long)l) | (rec_mapq(rec_cur) < p.mapq) |
+      // np.mean(q) < readq  <=>  floor(sum(q) / l) < readq for an integer readq; the packer stored the quotient
+      const bool t_drop = (rec_qmean(rec_cur) < p.readq) | (rec_mapq(rec_cur) < p.mapq) |
                           (align_len < min_align);                                       // readq, mapq, aln_cov
       const bool t_over = (flags & kRecOverrun) != 0u;   // kept, and its CIGAR reaches past SEQ inside the contig
       uint32_t err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
@@ -376,23 +353,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
       bool walking = keep && has && !(p.debug & 4);
       if (walking) {     // (qv, cd are only ever read under `walking`)
-        uint32_t qsrc[NW];
-        if (count_all) {
+        // call codes arrive as byte k = code(base k) | code(base k + 16) << 4: one AND per four bases
 #pragma unroll
-          for (int w = 0; w < NW; ++w) qsrc[w] = low_bytes_mask(nvalid - 4 * w);
-        } else {
-#pragma unroll
-          for (int w = 0; w < NW; ++w) qsrc[w] = cur.qw[w];
+        for (int w = 0; w < NW / 2; ++w) {
+          cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
+          cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
         }
+        if (count_all) {   // baseq <= 0: every A/C/G/T base of the read counts, whatever its quality
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          const uint32_t x16 = cur.sw[w >> 1] >> (16 * (w & 1));               // call bytes 2w, 2w+1: bases 4w .. 4w+3
-          const uint32_t t4 = __builtin_amdgcn_perm(0u, x16, 0x01010000u);     // [b0, b0, b1, b1]
-          const uint32_t nib = ((t4 >> 4) & 0x000F000Fu) | (t4 & 0x0F000F00u);  // one call code per byte
-          const uint32_t inv = nib & 0x02020202u;                              // not A/C/G/T
-          const uint32_t inv_ff = (inv << 7) - (inv >> 1);                     // 0xFF in every such byte
-          qv[w] = qsrc[w] & ~inv_ff;
-          cd[w] = nib & 0x0C0C0C0Cu;
+          for (int w = 0; w < NW; ++w) {
+            const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
+            const uint32_t inv = nib & 0x02020202u;                    // not A/C/G/T
+            const uint32_t inv_ff = (inv << 7) - (inv >> 1);           // 0xFF in every such byte
+            qv[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
+          }
+        } else {           // the packer zeroed the quality of every base that is not A/C/G/T
+#pragma unroll
+          for (int w = 0; w < NW; ++w) qv[w] = cur.qw[w];
         }
       }
 

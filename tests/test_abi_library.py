@@ -74,11 +74,14 @@ CALL = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
 
 
 def call_codes(seq):
-    """Expected device call-code bytes (layout.h): 4 bits per base, first base in the high nibble."""
-    codes = [CALL.get(ch, 0x2) for ch in seq.upper()]
-    if len(codes) & 1:
-        codes.append(0x2)      # BAM pads SEQ with code 0 ('='), which is "not A/C/G/T"
-    return bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+    """layout.h: 16 bytes per 32-base chunk; byte k = code(base k) | code(base k + 16) << 4; padding = 0x2"""
+    code = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
+    out = bytearray()
+    for c0 in range(0, max(len(seq), 1), 32):
+        chunk = [code.get(ch, 0x2) for ch in seq[c0:c0 + 32]]
+        chunk += [0x2] * (32 - len(chunk))
+        out += bytes(chunk[k] | (chunk[k + 16] << 4) for k in range(16))
+    return bytes(out)
 
 
 REC_DTYPE = np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
@@ -94,19 +97,26 @@ def test_pack_layout_matches_design():
     rec, blob, maxl = abi.pack_reads(reads)
     assert maxl == 10 and rec.shape == (3, 16)
     r = rec.view(REC_DTYPE).reshape(3)
-    assert r["pos"].tolist() == [7, 9, 11] and r["l"].tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
+    assert r["pos"].tolist() == [7, 9, 11] and (r["l"] & 0x7FF).tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
     assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42]
     # flags: bit0 QUAL absent, bit1 "simple" (one M/=/X op spanning l_seq), bit2 generic clips, bit3 overrun
-    assert r["flags"].tolist() == [0, 2, 3]
-    # read 0: qual 10 -> 32 | calls 5 -> 16 | cigar 8            = 56 bytes
-    # read 1: qual  5 -> 32 | calls 3 -> 16 | (simple: no cigar) = 48 bytes; read 2 likewise
+    assert (r["flags"] & 0x8F).tolist() == [0, 2, 3]
+    # qmean = floor(sum(qual) / l): low five bits above l_seq, high three bits in flags 4-6
+    qmean = ((r["l"] >> 11) | ((r["flags"].astype(int) >> 4) & 7) << 5).tolist()
+    assert qmean == [45 // 10, 40, 255]           # 0..9 ; default quality 40 ; absent = 0xFF bytes
+    # read 0: qual 10 -> 32 | calls 16 | cigar 8            = 56 bytes
+    # read 1: qual  5 -> 32 | calls 16 | (simple: no cigar) = 48 bytes; read 2 likewise
     assert r["off8"].tolist() == [0, 7, 13]
     b0 = blob[:56]
     assert b0[:10].tolist() == list(range(10)) and not b0[10:32].any()
-    assert bytes(b0[32:37]) == call_codes("TTTACGTACG") and not b0[37:48].any()
+    assert bytes(b0[32:48]) == call_codes("TTTACGTACG")
     assert b0[48:56].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
-    assert bytes(blob[56 + 32:56 + 35]) == call_codes("ACGTN")
+    b1 = blob[56:104]
+    assert b1[:5].tolist() == [40, 40, 40, 40, 0]    # the N's quality is stored as 0: it can never count
+    assert bytes(b1[32:48]) == call_codes("ACGTN")
     assert blob.size == 56 + 48 + 48
+    # the sentinel record after the last read carries its own flag
+    assert rec.shape[0] == 3
 
 
 def test_pack_overrun_flag_needs_the_contig_length():
@@ -126,7 +136,7 @@ def test_pack_cigar_fast_path_flags():
              ("75M2I73M", 150, 0), ("75M2D75M", 150, 0), ("150I", 150, 0)]
     reads = H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l) for cg, l, _ in cases])
     rec, _, _ = abi.pack_reads(reads)
-    flags = rec[:, 15].tolist()
+    flags = (rec[:, 15] & 0x8F).tolist()       # bits 4-6 carry qmean
     assert flags == [f for _, _, f in cases], list(zip([c[0] for c in cases], flags))
 
 
@@ -148,14 +158,20 @@ def test_pack_round_trips_synthetic_reads():
     rec, blob, maxl = abi.pack_reads(reads, contigs)
     r = rec.view(REC_DTYPE).reshape(-1)
     np.testing.assert_array_equal(r["pos"], reads.pos)
-    np.testing.assert_array_equal(r["l"], reads.l_seq)
+    np.testing.assert_array_equal(r["l"] & 0x7FF, reads.l_seq)
+    qmean = (r["l"] >> 11).astype(int) | (((r["flags"].astype(int) >> 4) & 7) << 5)
+    saw_n = False
     for i in (0, 17, 1234, reads.n_reads - 1):
         l = int(reads.l_seq[i])
         o = int(r["off8"][i]) * 8
-        np.testing.assert_array_equal(blob[o:o + l], reads.qual[reads.qual_off[i]:reads.qual_off[i] + l])
-        assert not blob[o + l:o + ((l + 31) & ~31)].any()            # zero padding = self-masking read tail
-        so = o + ((l + 31) & ~31)
         nt16 = "=ACMGRSVTWYHKDBN"
         s4 = reads.seq4[reads.seq_off[i]:reads.seq_off[i] + (l + 1) // 2]
         seq = "".join(nt16[b >> 4] + nt16[b & 15] for b in s4)[:l]
-        assert bytes(blob[so:so + (l + 1) // 2]) == call_codes(seq)
+        q = reads.qual[reads.qual_off[i]:reads.qual_off[i] + l].astype(int)
+        assert qmean[i] == int(q.sum()) // l
+        acgt = np.array([ch in "ACGT" for ch in seq])
+        saw_n |= bool((~acgt).any())
+        np.testing.assert_array_equal(blob[o:o + l], np.where(acgt, q, 0))   # non-ACGT bases carry quality 0
+        assert not blob[o + l:o + ((l + 31) & ~31)].any()            # zero padding = self-masking read tail
+        so = o + ((l + 31) & ~31)
+        assert bytes(blob[so:so + 16 * ((l + 31) // 32)]) == call_codes(seq)
