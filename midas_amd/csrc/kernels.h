@@ -72,7 +72,6 @@ struct PileupParams {
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
   int32_t debug;                     // developer ablation switches (MIDAS_SNPS_DEBUG), 0 in production
-  unsigned long long* phase_clk;     // developer instrumentation (MIDAS_SNPS_PHASES): per-phase wave cycles, else null
 };
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);

@@ -229,18 +229,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     }
   };
   constexpr int NWAVES = kPileupBlock / 64;
-  // developer instrumentation: per-phase cycle sums of every wave (lane-uniform values), see MIDAS_SNPS_PHASES
-#ifdef MIDAS_PHASE_PROFILE
-  const bool prof = p.phase_clk != nullptr;
-#else
-  constexpr bool prof = false;   // compiled out: build with MIDAS_HIPCC_EXTRA=-DMIDAS_PHASE_PROFILE to enable
-#endif
-  unsigned long long ph[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-  unsigned long long clk = prof ? __builtin_readcyclecounter() : 0ull;
-  const unsigned long long clk_begin = clk;
-  auto mark = [&](int k) {
-    if (prof) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - clk; clk = now; }
-  };
   Tile tile = load_tile(c_tiles, t);
   Ranges rg = make_ranges(load_ranges(t));
   const int vstep = NWAVES * rpw;                 // stream positions between a wave's consecutive iterations
@@ -250,12 +238,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   Payload cur;
   fetch_payload(rec_cur, cur);
   __syncthreads();   // LDS zeroed, tables in place
-  mark(0);           // prologue
 
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
     uint32_t w_aligned = 0, w_mapped = 0;
+    // the tile's reference letters are fetched now and written (upper-cased) with the tile's counts: loading them
+    // in the write-out put a full HBM round trip on every wave's critical path, once per tile
+    constexpr int REF_IT = TILE / (4 * kPileupBlock);
+    uint32_t refw[REF_IT];
+    if (p.out_allele) {
+      const uint8_t* ref = p.ref + tile.site_base;
+#pragma unroll
+      for (int it = 0; it < REF_IT; ++it) {
+        const int i = 4 * (tid + it * kPileupBlock);
+        if (i + 4 <= tile_len) refw[it] = *reinterpret_cast<const u32_a1*>(ref + i);
+      }
+    }
 
     const int n_iter = (rg.total + rpw - 1) / rpw;
     int vpos = v0;
@@ -265,7 +264,58 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       fetch_payload(rec_nxt, nxt);
 
       // ================= process (rec_cur, cur) ===================================================
-      if (prof) { mark(1); __builtin_amdgcn_s_waitcnt(0x0F70); mark(2); }   // 1: issue of the prefetches, 2: vmcnt(0) wait
+      // Fast path: every read of this wave-iteration comes from the tile's S range (single-match reads that start
+      // AND end inside the tile, ~85 % of the iterations at 150 bp / 4096 sites).  Nothing of the CIGAR walk,
+      // clipping, tile-edge or ownership logic applies: align_len = l, one segment, sites = pos + query index.
+      // The general code below stays the reference for everything else (and for any S read that does not lie
+      // inside the tile after all -- checked, not assumed).
+      bool fast = (it + 1) * rpw <= rg.ns && !(p.debug & 4);
+      if (fast) {
+        const int fl = rec_l(rec_cur);
+        const int frel = rec_pos(rec_cur) - tile_start;
+        const bool fact = (rec_cur.w >> 31) == 0u;                       // not the sentinel
+        const bool inside = frel >= 0 && frel + fl <= tile_len && fl > 0 && (rec_cur.w & ((uint32_t)kRecSimple << 24));
+        fast = __ballot(fact && !inside) == 0ull;
+        if (fast) {
+          const int fnm = (int)rec_nm(rec_cur);
+          const int min_match = s_tables[fl];                            // fl <= max l_seq of the batch < table_len
+          const int min_align = s_tables[p.table_len + fl];
+          const bool t_nonm = fnm == (int)kNmAbsent;
+          const bool t_pid = fl - fnm < min_match;
+          const bool t_noqual = (rec_cur.w & ((uint32_t)kRecQualAbsent << 24)) != 0u;
+          const bool t_drop = (rec_qmean(rec_cur) < p.readq) | (rec_mapq(rec_cur) < p.mapq) | (fl < min_align);
+          uint32_t err = t_noqual ? (uint32_t)E_NO_QUAL : 0u;            // same precedence as the general cascade
+          err = t_pid ? 0u : err;
+          err = t_nonm ? (uint32_t)E_NO_NM : err;
+          err = fact ? err : 0u;
+          const bool keep = fact & !(t_nonm | t_pid | t_noqual | t_drop);
+          if (keep && q0 < fl) {
+            uint32_t cd[NW];
+#pragma unroll
+            for (int w = 0; w < NW / 2; ++w) {
+              cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
+              cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
+            }
+            if (count_all) {
+              const int nvalid = fl - q0 < kChunk ? fl - q0 : kChunk;
+#pragma unroll
+              for (int w = 0; w < NW; ++w) {
+                const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
+                const uint32_t inv = nib & 0x02020202u;
+                const uint32_t inv_ff = (inv << 7) - (inv >> 1);
+                cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
+              }
+            }
+            const uint32_t abase = ((uint32_t)(frel + q0) << 4) + lds_base;
+            if (!(p.debug & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
+          }
+          const bool head = fact && c == 0;                              // S reads start in this tile: it owns them
+          w_aligned += (uint32_t)__popcll(__ballot(head));
+          w_mapped += (uint32_t)__popcll(__ballot(head && keep));
+          if (head && err) atomicMin(p.err, ((unsigned long long)p.orig[read_at(rg, vpos)] << 8) | err);
+        }
+      }
+      if (!fast) {
       const int l = rec_l(rec_cur);
       const int n = rec_n(rec_cur);
       const int pos = rec_pos(rec_cur);
@@ -349,27 +399,24 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const bool keep = act & !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
 
       // ---- per-base call codes and validity, four bases per instruction ----------------------------
-      uint32_t qv[NW];   // quality byte if the base may count (is A/C/G/T, inside the read), else 0
+      // cur.qw: quality byte if the base may count (the packer zeroed the bases that are not A/C/G/T), else 0
       uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
       bool walking = keep && has && !(p.debug & 4);
-      if (walking) {     // (qv, cd are only ever read under `walking`)
+      if (walking) {     // (cd is only ever read under `walking`)
         // call codes arrive as byte k = code(base k) | code(base k + 16) << 4: one AND per four bases
 #pragma unroll
         for (int w = 0; w < NW / 2; ++w) {
           cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
           cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
         }
-        if (count_all) {   // baseq <= 0: every A/C/G/T base of the read counts, whatever its quality
+        if (count_all) {   // baseq <= 0: every A/C/G/T base of the read counts, whatever its quality (bq is 1)
 #pragma unroll
           for (int w = 0; w < NW; ++w) {
             const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
             const uint32_t inv = nib & 0x02020202u;                    // not A/C/G/T
             const uint32_t inv_ff = (inv << 7) - (inv >> 1);           // 0xFF in every such byte
-            qv[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
+            cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
           }
-        } else {           // the packer zeroed the quality of every base that is not A/C/G/T
-#pragma unroll
-          for (int w = 0; w < NW; ++w) qv[w] = cur.qw[w];
         }
       }
 
@@ -411,7 +458,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         // bases of the chunk that belong to this segment AND lie inside the tile: [lo, hi)
         uint32_t q4[NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) q4[w] = qv[w];
+        for (int w = 0; w < NW; ++w) q4[w] = cur.qw[w];
         const int lo = jlo > -loc0 ? jlo : -loc0;
         const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
         if (lo > 0 || hi < nvalid) {    // partial chunk (segment border or tile edge): zero the bytes outside
@@ -434,13 +481,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       w_mapped += (uint32_t)__popcll(m_mp);
       if (head && err)   // input-order index of the record
         atomicMin(p.err, ((unsigned long long)p.orig[read_at(rg, vpos)] << 8) | err);
+      }   // general path
 
       rec_cur = rec_nxt;
       rec_nxt = rec_nn;
       cur = nxt;
-      mark(3);   // processing of one wave-iteration
     }
-    mark(1);
 
     if (lane == 0) {
       if (w_aligned) atomicAdd(&s_stats[MIDAS_STAT_ALIGNED], (unsigned long long)w_aligned);
@@ -456,7 +502,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       rec_nxt = fetch_rec(nrg, v0 + vstep);
     }
     __syncthreads();   // every tally of this tile is in LDS
-    mark(4);           // barrier: waiting for the slowest wave of the tile
     if (more) fetch_payload(rec_cur, cur);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
@@ -483,10 +528,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const uint8_t* ref = p.ref + tile.site_base;
       uint8_t* al = p.out_allele + tile.site_base;
 #pragma unroll
-      for (int it = 0; it < TILE / (4 * kPileupBlock); ++it) {
+      for (int it = 0; it < REF_IT; ++it) {
         const int i = 4 * (tid + it * kPileupBlock);
         if (i + 4 <= tile_len) {
-          *reinterpret_cast<u32_a1*>(al + i) = upper4(*reinterpret_cast<const u32_a1*>(ref + i));
+          *reinterpret_cast<u32_a1*>(al + i) = upper4(refw[it]);
         } else {
           for (int j = i; j < tile_len; ++j) {
             uint32_t ch = ref[j];
@@ -505,24 +550,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
       if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
     }
-    mark(5);           // next tile's first loads, write-out, alleles, reductions
-    __syncthreads();   // s_stats complete
-    if (tid < MIDAS_STATS) {
-      const unsigned long long v = s_stats[tid];
-      if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
-      s_stats[tid] = 0ull;
+    // One barrier per tile after the write-out: tallies re-zeroed (and this tile's s_stats additions done) before
+    // the next tile's waves touch LDS.  The workgroup's counters go to the species row only when the next tile
+    // belongs to another species or there is no next tile: they are additive, so tiles of one species share them.
+    __syncthreads();
+    const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
+    if (flush) {
+      if (tid < MIDAS_STATS) {
+        const unsigned long long v = s_stats[tid];
+        if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
+        s_stats[tid] = 0ull;
+      }
+      if (!more) break;
+      __syncthreads();   // s_stats reset before the next tile adds to it
     }
-    if (!more) break;
-    __syncthreads();   // LDS tallies re-zeroed and s_stats reset before the next tile's waves touch them
-    mark(6);           // the two barriers after the write-out
     t = tn;
     tile = ntile;
     rg = nrg;
-  }
-  if (prof && lane == 0) {
-    for (int k = 0; k < 7; ++k) atomicAdd(&p.phase_clk[k], ph[k]);
-    atomicAdd(&p.phase_clk[7], __builtin_readcyclecounter() - clk_begin);   // whole wave
-    atomicAdd(&p.phase_clk[8], 1ull);                                       // waves
   }
 }
 

@@ -28,7 +28,6 @@ struct midas_snps_batch {
   int32_t* d_contig_read_begin = nullptr;
   int32_t* d_contig_tile_base = nullptr;
   int32_t* d_contig_len = nullptr;
-  unsigned long long* d_phase = nullptr;   // MIDAS_SNPS_PHASES instrumentation
   uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
   FilterTables* d_filt = nullptr;
   uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
@@ -233,7 +232,6 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   (void)hipFree(b->d_contig_tile_base);
   (void)hipFree(b->d_contig_len);
   (void)hipFree(b->d_work);
-  if (b->d_phase) (void)hipFree(b->d_phase);
   (void)hipFree(b->d_filt);
   (void)hipFree(b->d_orig);
   (void)hipFree(b->d_key);
@@ -469,12 +467,6 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.orig = b->d_orig;
   pp.table_len = b->max_l_seq + 1;
   pp.debug = getenv("MIDAS_SNPS_DEBUG") ? atoi(getenv("MIDAS_SNPS_DEBUG")) : 0;
-  pp.phase_clk = nullptr;
-  if (getenv("MIDAS_SNPS_PHASES")) {
-    if (!b->d_phase) HIP_TRY(ctx, hipMalloc(&b->d_phase, 16 * 8));
-    HIP_TRY(ctx, hipMemsetAsync(b->d_phase, 0, 16 * 8, s));
-    pp.phase_clk = b->d_phase;
-  }
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
   if (ev) {
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
@@ -491,13 +483,6 @@ int32_t midas_snps_batch_sync(midas_snps_batch* b) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (!b->ran) return MIDAS_SNPS_OK;
-  if (b->d_phase) {
-    unsigned long long ph[16];
-    HIP_TRY(ctx, hipMemcpy(ph, b->d_phase, sizeof ph, hipMemcpyDeviceToHost));
-    fprintf(stderr, "PHASES (wave-cycles summed over waves):");
-    for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", ph[i]);
-    fprintf(stderr, "\n");
-  }
   unsigned long long e = kNoError;
   HIP_TRY(ctx, hipMemcpy(&e, work_err(b), 8, hipMemcpyDeviceToHost));
   if (e != kNoError) {
