@@ -239,6 +239,12 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
 int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
                               const uint8_t* allele, const uint32_t* counts, int32_t gz_level,
                               int32_t threads, char* err256);
+/* All contigs of one species in ONE call (header + rows, same text as repeated midas_snps_write_rows calls):
+ * the emit loop of species_pileup over sorted(contigs) (midas/run/snps.py:183-213).  ref_ids[k], n_sites[k],
+ * allele[k], counts[k] describe contig k in output order; the formatter/deflater pool works across contigs.  */
+int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* const* ref_ids,
+                               const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
+                               int32_t gz_level, int32_t threads, char* err256);
 
 /* Parser of one sample's <species>.snps.gz: replaces read_run_midas_snps + the per-line split of
  * build_temp_count_matrix (midas/merge/snps.py:236-271): per row the site key '|'.join(r[0:3]) and the counts

@@ -220,6 +220,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
+        'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
         'midas_snps_table_close': (None, [vp]),
         'midas_snps_table_rows': (i64, [vp]),
@@ -246,7 +247,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_stats_to_device',
     'midas_snps_pack_reads',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
-    'midas_snps_write_rows',
+    'midas_snps_write_rows', 'midas_snps_write_table',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites',
 ]
@@ -263,6 +264,24 @@ def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts:
     st = lib.midas_snps_write_rows(path.encode(), 1 if append else 0, ref_id.encode(), allele.shape[0],
                                    allele.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
                                    int(gz_level), int(threads), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+
+
+def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads: int = 0):
+    """Header + the rows of every contig of one species in one call (midas_snps_write_table): ref_ids[k],
+    alleles[k] (u8[n_k]) and counts[k] (u32[n_k,4]) describe contig k in output order."""
+    lib = load_library()
+    n = len(ref_ids)
+    al = [np.ascontiguousarray(a, dtype=np.uint8) for a in alleles]
+    cn = [np.ascontiguousarray(c, dtype=np.uint32) for c in counts]
+    assert all(c.shape == (a.shape[0], 4) for a, c in zip(al, cn))
+    ids = (C.c_char_p * max(n, 1))(*[r.encode() for r in ref_ids])
+    ns = (C.c_int64 * max(n, 1))(*[a.shape[0] for a in al])
+    pa = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in al])
+    pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in cn])
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_write_table(path.encode(), n, ids, ns, pa, pc, int(gz_level), int(threads), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
 

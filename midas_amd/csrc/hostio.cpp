@@ -51,7 +51,16 @@ int hw_threads(int want) {
   unsigned n = std::thread::hardware_concurrency();
   if (n == 0) n = 1;
   if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
-  if (n > 32) n = 32;
+  if (n > 128) n = 128;
+  return (int)n;
+}
+
+// Threads of the row writer: the caller's --threads when given, else every core (capped at 128).
+int writer_threads(int want) {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
+  if (n > 128) n = 128;
   return (int)n;
 }
 
@@ -435,10 +444,11 @@ int32_t midas_snps_table_copy(const midas_snps_table* t, uint32_t* counts, char*
   return MIDAS_SNPS_OK;
 }
 
-int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
-                              const uint8_t* allele, const uint32_t* counts, int32_t gz_level, int32_t threads,
-                              char* err256) {
-  if (!path || (n_sites > 0 && (!ref_id || !allele || !counts)) || n_sites < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
+namespace {
+// Rows of any number of contigs -> gzip members of kRows rows, formatted and deflated by a pool, written in order.
+int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const char* const* ref_ids,
+                      const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
+                      int32_t gz_level, int32_t threads, char* err256) {
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   if (gz_level < 0 || gz_level > 9) gz_level = 6;
@@ -450,11 +460,17 @@ int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_
     ok = gz_member(reinterpret_cast<const uint8_t*>(hdr), sizeof(hdr) - 1, gz_level, z) &&
          fwrite(z.data(), 1, z.size(), f) == z.size();
   }
-  const size_t idlen = ref_id ? strlen(ref_id) : 0;
-  const int64_t kRows = 1 << 16;   // rows per gzip member
-  const int64_t n_chunks = (n_sites + kRows - 1) / kRows;
-  const int nt = hw_threads(threads > 0 ? threads : 0);
-  // chunks are produced by a pool and written strictly in order
+  const int64_t kRows = 1 << 14;   // rows per gzip member: enough members to keep every core busy on one species
+  struct Chunk { int32_t contig; int64_t lo, hi; };
+  std::vector<Chunk> chunks;
+  std::vector<size_t> idlen((size_t)n_contigs);
+  for (int32_t k = 0; k < n_contigs; ++k) {
+    idlen[(size_t)k] = strlen(ref_ids[k]);
+    for (int64_t lo = 0; lo < n_sites[k]; lo += kRows) chunks.push_back({k, lo, std::min(n_sites[k], lo + kRows)});
+  }
+  const int64_t n_chunks = (int64_t)chunks.size();
+  int nt = writer_threads(threads);
+  if ((int64_t)nt > n_chunks) nt = (int)std::max<int64_t>(1, n_chunks);
   std::vector<std::vector<uint8_t>> zbuf((size_t)n_chunks);
   std::vector<std::atomic<int>> done((size_t)n_chunks);
   for (auto& d : done) d = 0;
@@ -465,15 +481,19 @@ int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_
     for (;;) {
       const int64_t ci = next.fetch_add(1);
       if (ci >= n_chunks) return;
-      const int64_t lo = ci * kRows, hi = std::min(n_sites, lo + kRows);
-      text.resize((size_t)(hi - lo) * (idlen + 80));
+      const Chunk& ch = chunks[(size_t)ci];
+      const char* id = ref_ids[ch.contig];
+      const size_t il = idlen[(size_t)ch.contig];
+      const uint8_t* al = allele[ch.contig];
+      const uint32_t* cn = counts[ch.contig];
+      text.resize((size_t)(ch.hi - ch.lo) * (il + 80));
       char* p = text.data();
-      for (int64_t i = lo; i < hi; ++i) {
+      for (int64_t i = ch.lo; i < ch.hi; ++i) {
         // row = [contig.id, i+1, seq[i], depth, A, C, G, T] joined by tabs (midas/run/snps.py:202-210)
-        memcpy(p, ref_id, idlen); p += idlen;
+        memcpy(p, id, il); p += il;
         *p++ = '\t'; p = put_u64(p, (uint64_t)(i + 1));
-        *p++ = '\t'; *p++ = (char)allele[i];
-        const uint32_t* c = counts + 4 * i;
+        *p++ = '\t'; *p++ = (char)al[i];
+        const uint32_t* c = cn + 4 * i;
         *p++ = '\t'; p = put_u64(p, (uint64_t)c[0] + c[1] + c[2] + c[3]);
         *p++ = '\t'; p = put_u32(p, c[0]);
         *p++ = '\t'; p = put_u32(p, c[1]);
@@ -500,6 +520,25 @@ int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_
   if (fclose(f) != 0) ok = false;
   if (!ok || bad) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   return MIDAS_SNPS_OK;
+}
+}  // namespace
+
+int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
+                              const uint8_t* allele, const uint32_t* counts, int32_t gz_level, int32_t threads,
+                              char* err256) {
+  if (!path || (n_sites > 0 && (!ref_id || !allele || !counts)) || n_sites < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const char* id = ref_id ? ref_id : "";
+  return write_contigs(path, append != 0, n_sites > 0 ? 1 : 0, &id, &n_sites, &allele, &counts, gz_level, threads, err256);
+}
+
+int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
+                               const uint8_t* const* allele, const uint32_t* const* counts, int32_t gz_level,
+                               int32_t threads, char* err256) {
+  if (!path || n_contigs < 0 || (n_contigs > 0 && (!ref_ids || !n_sites || !allele || !counts)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  for (int32_t k = 0; k < n_contigs; ++k)
+    if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k]))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256);
 }
 
 }  // extern "C"

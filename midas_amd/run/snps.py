@@ -235,16 +235,11 @@ def _write_species(args, species_id, table, counts, allele):
     out_path = '%s/snps/output/%s.snps.gz' % (args['outdir'], species_id)
     off = table.site_offsets()
     sp = table.species_ids.index(species_id)
-    first = True
-    for cid in sorted(table.ids):
-        k = table.ids.index(cid)
-        if table.species[k] != sp:
-            continue
-        abi.write_rows(out_path, not first, cid, allele[off[k]:off[k + 1]], counts[off[k]:off[k + 1]],
-                       gz_level=int(args.get('gz_level', 6)), threads=int(args.get('threads', 1) or 1))
-        first = False
-    if first:   # a species without contigs still gets its header-only file
-        abi.write_rows(out_path, False, "", np.zeros(0, np.uint8), np.zeros((0, 4), np.uint32))
+    ks = [table.ids.index(cid) for cid in sorted(table.ids)]
+    ks = [k for k in ks if table.species[k] == sp]         # a species without contigs still gets its header-only file
+    abi.write_table(out_path, [table.ids[k] for k in ks], [allele[off[k]:off[k + 1]] for k in ks],
+                    [counts[off[k]:off[k + 1]] for k in ks], gz_level=int(args.get('gz_level', 6)),
+                    threads=int(args.get('threads', 1) or 1))
 
 
 def _pileup_species_set(args, species_ids, contigs, decoded, ctx):

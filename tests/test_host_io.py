@@ -89,12 +89,20 @@ def test_row_writer_reproduces_reference_text(tmp_path):
     got = gzip.open(out, "rt").read()
     exp, exp_stats = _oracle_text(contigs, reads, args)[contigs.species_ids[0]]
     assert got == exp
+    # the one-call table writer (what the host uses) produces the same text
+    out2 = str(tmp_path / "sp2.snps.gz")
+    ks = [contigs.ids.index(cid) for cid in sorted(contigs.ids)]
+    abi.write_table(out2, [contigs.ids[k] for k in ks], [allele[off[k]:off[k + 1]] for k in ks],
+                    [counts[off[k]:off[k + 1]] for k in ks], threads=5)
+    assert gzip.open(out2, "rt").read() == exp
+    abi.write_table(out2, [], [], [])            # a species without contigs: header only
+    assert gzip.open(out2, "rt").read() == exp.splitlines(keepends=True)[0]
     assert [l.split("\t")[0] for l in got.splitlines()[1::3000]] == ["C_1", "a|b", "c_10"]
     assert exp_stats['total_depth'] == int(stats[0, abi.STAT_TOTAL_DEPTH])
 
 
 def test_row_writer_large_counts_and_many_members(tmp_path):
-    n = 200000   # > 3 gzip members of 65 536 rows
+    n = 200000   # 13 gzip members of 16 384 rows
     counts = np.zeros((n, 4), dtype=np.uint32)
     counts[:, 0] = np.arange(n)
     counts[7] = [4000000000, 4000000000, 4000000000, 4000000000]   # depth needs 64-bit

@@ -35,7 +35,7 @@ def test_table_reader_matches_what_was_written(dataset):
 
 
 def test_table_reader_reads_tables_written_by_the_pileup_stage(tmp_path):
-    # multi-member gzip as midas_snps_write_rows produces it, 65536 rows per member
+    # multi-member gzip as midas_snps_write_rows produces it, 16384 rows per member
     n = 70000
     rng = np.random.default_rng(1)
     allele = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n)
