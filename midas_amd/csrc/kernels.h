@@ -64,6 +64,11 @@ struct PileupParams {
   uint8_t* out_allele;               // [n_sites] or nullptr
   unsigned long long* stats;         // [n_species][4]
   unsigned long long* err;           // one word, atomicMin((read << 8) | kind)
+  const uint32_t* items;             // [n_items][4] work items {tile, part, n_parts, 0}: a tile whose reads were split
+                                     // into n_parts > 1 slices (hot spots) is accumulated with global atomics
+  uint32_t* split_ticket;            // [n_tiles] arrival counter of a split tile's parts (self-resetting)
+  int32_t n_items;
+  int32_t n_whole_items;             // items [0, n_whole_items) are whole tiles (n_parts == 1), the rest parts of split tiles
   int32_t n_tiles;
   int32_t n_reads;
   int32_t grid_blocks;               // persistent workgroups: 2 per CU

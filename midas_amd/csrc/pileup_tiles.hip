@@ -134,20 +134,29 @@ __device__ __forceinline__ Tile load_tile(ConstWords tiles, int t) {
   return x;
 }
 
-template <int TILE_SHIFT>
+// SPLIT = false: whole tiles, plain stores (the common case); SPLIT = true: the parts of split tiles (hot spots),
+// launched separately so that the common case carries none of that code or its registers.
+template <int TILE_SHIFT, bool SPLIT>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
   constexpr int TILE = 1 << TILE_SHIFT;
   constexpr int NW = kChunk / 4;                 // quality words per lane
   constexpr int OUT_IT = TILE / kPileupBlock;    // read-out iterations per thread (8)
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ unsigned long long s_stats[MIDAS_STATS];
+  __shared__ uint32_t s_last_part;
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
-  int t = (int)blockIdx.x;
-  if (t >= p.n_tiles) return;
+  // Work items: one per tile, except that a tile holding very many reads (a coverage hot spot) comes as n_parts
+  // items, each taking a slice of the tile's wave-iterations and adding its tallies to the output with atomics.
+  const int w_end = SPLIT ? p.n_items : p.n_whole_items;      // items [0, n_whole) are whole tiles, the rest are parts
+  int w = (SPLIT ? p.n_whole_items : 0) + (int)blockIdx.x;
+  if (w >= w_end) return;
+  const ConstWords c_items = (ConstWords)(size_t)p.items;
+  int t = (!SPLIT && p.n_whole_items == p.n_tiles) ? w : (int)c_items[4 * w];
+  int part = SPLIT ? (int)c_items[4 * w + 1] : 0, nparts = SPLIT ? (int)c_items[4 * w + 2] : 1;
 
   {
     uint4* z = reinterpret_cast<uint4*>(lds);
@@ -232,7 +241,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   Tile tile = load_tile(c_tiles, t);
   Ranges rg = make_ranges(load_ranges(t));
   const int vstep = NWAVES * rpw;                 // stream positions between a wave's consecutive iterations
-  const int v0 = wave * rpw + g;                  // this lane's stream position in the wave's first iteration
+  // iterations [it_lo, it_hi) of the tile belong to this item (all of them unless the tile was split)
+  auto first_iter = [&](const Ranges& q, int pt, int np) -> int { return (int)(((long long)((q.total + rpw - 1) / rpw) * pt) / np); };
+  int it_lo = first_iter(rg, part, nparts), it_hi = first_iter(rg, part + 1, nparts);
+  int v0 = (it_lo + wave) * rpw + g;              // this lane's stream position in the wave's first iteration
   uint4 rec_cur = fetch_rec(rg, v0);
   uint4 rec_nxt = fetch_rec(rg, v0 + vstep);
   Payload cur;
@@ -256,9 +268,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
     }
 
-    const int n_iter = (rg.total + rpw - 1) / rpw;
     int vpos = v0;
-    for (int it = wave; it < n_iter; it += NWAVES, vpos += vstep) {
+    for (int it = it_lo + wave; it < it_hi; it += NWAVES, vpos += vstep) {
       const uint4 rec_nn = fetch_rec(rg, vpos + 2 * vstep);
       Payload nxt;
       fetch_payload(rec_nxt, nxt);
@@ -493,13 +504,20 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
     }
     // ---- next tile: its record loads go out before the barrier, its payload loads before this tile's stores ----
-    const int tn = t + (int)gridDim.x;
-    const bool more = tn < p.n_tiles;
-    const Tile ntile = load_tile(c_tiles, more ? tn : t);            // scalar loads (constant address space)
-    const Ranges nrg = make_ranges(load_ranges(more ? tn : t));
+    const int wn = w + (int)gridDim.x;
+    const bool more = wn < w_end;
+    // whole-tile items are the identity list unless some tile of the batch was split: no dependent load then
+    const bool ident = !SPLIT && p.n_whole_items == p.n_tiles;
+    const int tn = more ? (ident ? wn : (int)c_items[4 * wn]) : t;   // scalar loads (constant address space)
+    const int npart = (SPLIT && more) ? (int)c_items[4 * wn + 1] : (SPLIT ? part : 0);
+    const int nnparts = (SPLIT && more) ? (int)c_items[4 * wn + 2] : (SPLIT ? nparts : 1);
+    const Tile ntile = load_tile(c_tiles, tn);
+    const Ranges nrg = make_ranges(load_ranges(tn));
+    const int nit_lo = first_iter(nrg, npart, nnparts), nit_hi = first_iter(nrg, npart + 1, nnparts);
+    const int nv0 = (nit_lo + wave) * rpw + g;
     if (more) {
-      rec_cur = fetch_rec(nrg, v0);
-      rec_nxt = fetch_rec(nrg, v0 + vstep);
+      rec_cur = fetch_rec(nrg, nv0);
+      rec_nxt = fetch_rec(nrg, nv0 + vstep);
     }
     __syncthreads();   // every tally of this tile is in LDS
     if (more) fetch_payload(rec_cur, cur);
@@ -510,21 +528,40 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       uint4* out = reinterpret_cast<uint4*>(p.out_counts) + tile.site_base;
       uint4* lds4 = reinterpret_cast<uint4*>(lds);
       const int lim = (p.debug & 2) ? 0 : tile_len;
+      if constexpr (!SPLIT) {
 #pragma unroll
-      for (int it = 0; it < OUT_IT; ++it) {
-        const int i = tid + it * kPileupBlock;
-        if (i < lim) {
-          const uint4 v = lds4[i];
-          lds4[i] = make_uint4(0u, 0u, 0u, 0u);
-          out[i] = v;
-          const uint32_t d = v.x + v.y + v.z + v.w;
-          covered += d > 0u ? 1ull : 0ull;
-          depth_sum += d;
+        for (int it = 0; it < OUT_IT; ++it) {
+          const int i = tid + it * kPileupBlock;
+          if (i < lim) {
+            const uint4 v = lds4[i];
+            lds4[i] = make_uint4(0u, 0u, 0u, 0u);
+            out[i] = v;
+            const uint32_t d = v.x + v.y + v.z + v.w;
+            covered += d > 0u ? 1ull : 0ull;
+            depth_sum += d;
+          }
         }
+      } else {
+        // one slice of a split tile: the output was zeroed before the launch, every part adds to it; the part that
+        // arrives last counts the covered sites from the finished counts (below)
+        uint32_t* outw = p.out_counts + 4 * tile.site_base;
+        for (int it = 0; it < OUT_IT; ++it) {
+          const int i = tid + it * kPileupBlock;
+          if (i < lim) {
+            const uint4 v = lds4[i];
+            lds4[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (v.x) atomicAdd(&outw[4 * (size_t)i + 0], v.x);
+            if (v.y) atomicAdd(&outw[4 * (size_t)i + 1], v.y);
+            if (v.z) atomicAdd(&outw[4 * (size_t)i + 2], v.z);
+            if (v.w) atomicAdd(&outw[4 * (size_t)i + 3], v.w);
+            depth_sum += (unsigned long long)v.x + v.y + v.z + v.w;
+          }
+        }
+        __threadfence();   // this thread's additions are visible device-wide before the workgroup takes its ticket
       }
     }
     // ---- upper-cased ref allele, four sites per lane ---------------------------------------------------------
-    if (p.out_allele && !(p.debug & 2)) {
+    if (p.out_allele && !(p.debug & 2) && part == 0) {
       const uint8_t* ref = p.ref + tile.site_base;
       uint8_t* al = p.out_allele + tile.site_base;
 #pragma unroll
@@ -554,6 +591,29 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     // the next tile's waves touch LDS.  The workgroup's counters go to the species row only when the next tile
     // belongs to another species or there is no next tile: they are additive, so tiles of one species share them.
     __syncthreads();
+    if constexpr (SPLIT) {
+      if (tid == 0) {
+        const uint32_t ticket = atomicAdd(&p.split_ticket[t], 1u);
+        s_last_part = ticket == (uint32_t)(nparts - 1) ? 1u : 0u;
+        if (s_last_part) p.split_ticket[t] = 0u;   // every part has arrived: ready for the next run
+      }
+      __syncthreads();
+      if (s_last_part) {   // all parts' additions are in: covered sites of the finished tile
+        __threadfence();
+        const uint32_t* outw = p.out_counts + 4 * tile.site_base;
+        unsigned long long cov = 0;
+        for (int i = tid; i < tile_len; i += kPileupBlock) {
+          const uint32_t a = __hip_atomic_load(&outw[4 * (size_t)i + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t b = __hip_atomic_load(&outw[4 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t cc = __hip_atomic_load(&outw[4 * (size_t)i + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t d = __hip_atomic_load(&outw[4 * (size_t)i + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cov += (a | b | cc | d) ? 1ull : 0ull;
+        }
+        for (int d = 32; d >= 1; d >>= 1) cov += __shfl_down(cov, d);
+        if (lane == 0 && cov) atomicAdd(&s_stats[MIDAS_STAT_COVERED], cov);
+      }
+      __syncthreads();
+    }
     const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
     if (flush) {
       if (tid < MIDAS_STATS) {
@@ -564,6 +624,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (!more) break;
       __syncthreads();   // s_stats reset before the next tile adds to it
     }
+    w = wn;
+    part = npart;
+    nparts = nnparts;
+    it_lo = nit_lo;
+    it_hi = nit_hi;
+    v0 = nv0;
     t = tn;
     tile = ntile;
     rg = nrg;
@@ -573,10 +639,16 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
 }  // namespace
 
 hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream) {
-  if (p.n_tiles <= 0) return hipSuccess;
-  const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
   const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
-  hipLaunchKernelGGL(pileup_tiles_kernel<kTileShift>, dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+  if (p.n_whole_items > 0) {
+    const int grid = p.n_whole_items < p.grid_blocks ? p.n_whole_items : p.grid_blocks;
+    hipLaunchKernelGGL((pileup_tiles_kernel<kTileShift, false>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+  }
+  const int n_parts = p.n_items - p.n_whole_items;
+  if (n_parts > 0) {   // hot spots: the parts of split tiles, merged with atomics
+    const int grid = n_parts < p.grid_blocks ? n_parts : p.grid_blocks;
+    hipLaunchKernelGGL((pileup_tiles_kernel<kTileShift, true>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+  }
   return hipGetLastError();
 }
 

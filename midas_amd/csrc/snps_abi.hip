@@ -32,6 +32,10 @@ struct midas_snps_batch {
   FilterTables* d_filt = nullptr;
   uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
   uint32_t* d_key = nullptr;    // device record -> tile << 7 | reach << 2 | class (input of the index kernel)
+  uint32_t* d_items = nullptr;  // [n_items][4] work items {tile, part, n_parts, 0} of the pileup kernel
+  uint32_t* d_ticket = nullptr; // [n_tiles] arrival counters of split tiles
+  int64_t n_items = 0, n_whole_items = 0;
+  std::vector<std::pair<size_t, size_t>> zero_ranges;   // (first site, sites) of split tiles: counts zeroed before a run
   FilterTables h_filt;
   bool filt_valid = false;
   double filt_mapid = 0, filt_aln_cov = 0;
@@ -232,6 +236,8 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   (void)hipFree(b->d_contig_tile_base);
   (void)hipFree(b->d_contig_len);
   (void)hipFree(b->d_work);
+  (void)hipFree(b->d_items);
+  (void)hipFree(b->d_ticket);
   (void)hipFree(b->d_filt);
   (void)hipFree(b->d_orig);
   (void)hipFree(b->d_key);
@@ -318,6 +324,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     rbeg[contigs->n_contigs] = (int32_t)reads->n_reads;
   }
   b->n_tiles = (int64_t)tiles.size();
+  std::vector<int64_t> tile_reads(tiles.size(), 0);
 
   // ---- pack + upload reads ------------------------------------------------------------------
   const size_t blob_alloc = (size_t)ps.blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
@@ -339,6 +346,12 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     std::vector<uint32_t> h_key((size_t)b->n_reads);
     st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), h_key.data(), (int64_t)blob_alloc, &ps, ebuf);
     if (st == MIDAS_SNPS_OK) {
+      // reads a tile will see = those that start in it + those of earlier tiles reaching in (key: tile << 7 | reach << 2 | class)
+      for (int64_t i = 0; i < b->n_reads; ++i) {
+        const uint32_t k = h_key[(size_t)i];
+        const size_t t0 = k >> 7, reach = (k >> 2) & 31u;
+        for (size_t r = 0; r <= reach && t0 + r < tile_reads.size(); ++r) tile_reads[t0 + r] += 1;
+      }
       hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_reads * 4);
       if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
       if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_reads * 4);
@@ -378,6 +391,40 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemcpy(b->d_contig_tile_base, tile_base.data(), nc1 * 4, hipMemcpyHostToDevice));
   if (contigs->n_contigs > 0)
     B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
+  // ---- work items: one per tile; a tile with very many reads (coverage hot spot) is cut into parts that different
+  // workgroups process concurrently and merge with atomics -- otherwise one workgroup would walk it alone while the
+  // rest of the chip idles.  Whole tiles and parts are launched as two instantiations of the kernel.
+  {
+    // split only what would otherwise leave the chip idle: a tile holding more than twice a workgroup's fair share
+    // of all reads (and at least 2048), cut into parts of about one fair share (at least 1024 reads)
+    int64_t total_reads = 0;
+    for (int64_t x : tile_reads) total_reads += x;
+    const int64_t fair = total_reads / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
+    int64_t split_reads = std::max<int64_t>(2048, 2 * fair), part_reads = std::max<int64_t>(1024, fair);
+    if (const char* e = getenv("MIDAS_SNPS_SPLIT_READS")) { split_reads = atoll(e); part_reads = split_reads > 1 ? split_reads / 2 : 1; }
+    std::vector<uint32_t> items;
+    items.reserve(tiles.size() * 4 + 64);
+    std::vector<char> is_split(tiles.size(), 0);
+    for (size_t t = 0; t < tiles.size(); ++t) {     // whole tiles first ...
+      if (tile_reads[t] > split_reads) { is_split[t] = 1; continue; }
+      items.push_back((uint32_t)t); items.push_back(0u); items.push_back(1u); items.push_back(0u);
+    }
+    b->n_whole_items = (int64_t)(items.size() / 4);
+    for (size_t t = 0; t < tiles.size(); ++t) {     // ... then the parts of split tiles
+      if (!is_split[t]) continue;
+      int64_t np = (tile_reads[t] + part_reads - 1) / part_reads;
+      if (np > 4096) np = 4096;
+      for (int64_t j = 0; j < np; ++j) { items.push_back((uint32_t)t); items.push_back((uint32_t)j); items.push_back((uint32_t)np); items.push_back(0u); }
+      const size_t first = (size_t)tiles[t].site_base, cnt = (size_t)tiles[t].len;
+      if (!b->zero_ranges.empty() && b->zero_ranges.back().first + b->zero_ranges.back().second == first) b->zero_ranges.back().second += cnt;
+      else b->zero_ranges.emplace_back(first, cnt);
+    }
+    b->n_items = (int64_t)(items.size() / 4);
+    B_TRY(hipMalloc(&b->d_items, (items.empty() ? 1 : items.size()) * 4));
+    if (!items.empty()) B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
+    B_TRY(hipMalloc(&b->d_ticket, nt * 4));
+    B_TRY(hipMemset(b->d_ticket, 0, nt * 4));
+  }
   b->work_bytes = (((size_t)b->n_tiles * 48 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
   // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
@@ -455,6 +502,10 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.stats = work_stats(b);
   pp.err = work_err(b);
   pp.n_tiles = (int32_t)b->n_tiles;
+  pp.items = b->d_items;
+  pp.split_ticket = b->d_ticket;
+  pp.n_items = (int32_t)b->n_items;
+  pp.n_whole_items = (int32_t)b->n_whole_items;
   pp.n_reads = (int32_t)b->n_reads;
   pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
   if (const char* e = getenv("MIDAS_SNPS_GRID")) pp.grid_blocks = atoi(e) > 0 ? atoi(e) : pp.grid_blocks;   // experiments only
@@ -467,6 +518,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.orig = b->d_orig;
   pp.table_len = b->max_l_seq + 1;
   pp.debug = getenv("MIDAS_SNPS_DEBUG") ? atoi(getenv("MIDAS_SNPS_DEBUG")) : 0;
+  for (const auto& zr : b->zero_ranges)   // split tiles accumulate with atomics: their counts start from zero
+    HIP_TRY(ctx, hipMemsetAsync(b->d_counts + 4 * zr.first, 0, zr.second * 16, s));
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
   if (ev) {
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
