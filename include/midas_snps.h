@@ -187,6 +187,7 @@ typedef struct midas_snps_batch_info {
   int64_t algorithmic_bytes;/* sum(ceil(l/2)+l+4*n_cigar+16) + 17*n_sites  */
   int32_t tile_sites;
   int32_t lanes_per_read;
+  int64_t n_work_items;     /* >= n_tiles: a tile holding a coverage hot spot is processed as several parts */
 } midas_snps_batch_info;
 int32_t midas_snps_batch_get_info(const midas_snps_batch* batch, midas_snps_batch_info* out);
 /* Device-side durations from HIP events recorded on the run's stream.  enable_timing(batch, n_slots)

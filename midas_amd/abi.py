@@ -83,7 +83,7 @@ class _Contigs(C.Structure):
 class BatchInfo(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_sites", C.c_int64), ("n_tiles", C.c_int64),
                 ("packed_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
-                ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32)]
+                ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32), ("n_work_items", C.c_int64)]
 
 
 _SOA_DTYPES = {

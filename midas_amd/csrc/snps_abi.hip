@@ -571,6 +571,7 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->algorithmic_bytes = b->alg_bytes;
   out->tile_sites = b->tile_len;
   out->lanes_per_read = b->lanes_per_read;
+  out->n_work_items = b->n_items;
   return MIDAS_SNPS_OK;
 }
 

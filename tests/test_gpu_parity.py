@@ -63,6 +63,53 @@ def test_deep_hotspot_exceeds_u16(hip_ctx, thr_default):
     assert counts.sum(axis=1).max() > 255
 
 
+def test_hot_spot_among_ordinary_tiles_is_split_and_stays_exact(hip_ctx, thr_default):
+    # one 3 kb window at ~2500x inside an otherwise 8x genome: its tiles hold far more than a workgroup's fair share
+    # of the reads and are processed as parts merged with atomics -- counts, alleles, covered bases and depth must not
+    # notice, run after run (the part counters and the zeroed outputs reset themselves)
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=40000, n_reads=13000, seed=23,
+                                        var_len=True)
+    hot_c, hot_r = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=3000, n_reads=50000, seed=24)
+    # graft the hot reads onto contig 1 at offset 17000 (BAM order: by contig, then position)
+    shift = 17000
+    d, h = reads.as_dict(), hot_r.as_dict()
+    lo, hi = int(contigs.read_begin[1]), int(contigs.read_begin[2])
+    pos = np.concatenate([d['pos'][lo:hi], h['pos'] + shift])
+    order = np.argsort(pos, kind='stable')
+    def splice(key, off_key=None):
+        if off_key is None:
+            mid = np.concatenate([d[key][lo:hi], h[key] + (shift if key == 'pos' else 0)])[order]
+            return np.concatenate([d[key][:lo], mid, d[key][hi:]])
+    def ragged(key, off_key):
+        a = [d[key][d[off_key][i]:d[off_key][i + 1]] for i in range(len(d['pos']))]
+        b = [h[key][h[off_key][i]:h[off_key][i + 1]] for i in range(len(h['pos']))]
+        mid = [(a[lo:hi] + b)[j] for j in order]
+        seqs = a[:lo] + mid + a[hi:]
+        offs = np.zeros(len(seqs) + 1, np.int64)
+        offs[1:] = np.cumsum([len(x) for x in seqs])
+        return np.concatenate(seqs), offs
+    new = {k: splice(k) for k in ('pos', 'mapq', 'flag', 'nm', 'l_seq')}
+    new['seq4'], new['seq_off'] = ragged('seq4', 'seq_off')
+    new['qual'], new['qual_off'] = ragged('qual', 'qual_off')
+    new['cigar'], new['cigar_off'] = ragged('cigar', 'cigar_off')
+    merged = abi.ReadsSoA(**new)
+    rb = contigs.read_begin.copy()
+    rb[2:] += len(h['pos'])
+    contigs.read_begin = rb
+    b = hip_ctx.batch(contigs, merged)
+    info = b.info()
+    assert info.n_work_items > info.n_tiles          # the hot tiles were split
+    from oracle import c_oracle
+    st, _, oc, oa, os_ = c_oracle.pileup(thr_default, contigs, merged)
+    assert st == 0
+    for _ in range(3):
+        b.run(thr_default)
+        counts, allele, stats = b.fetch()
+        assert np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)
+    assert counts.sum(axis=1).max() > 1500
+    b.close()
+
+
 @pytest.mark.parametrize("args", [
     dict(baseq=0), dict(baseq=41), dict(mapq=0, readq=0, mapid=1.0, aln_cov=0.0),
     dict(mapid=99.0), dict(aln_cov=1.0), dict(readq=38), dict(mapq=42),
