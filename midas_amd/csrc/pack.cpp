@@ -16,7 +16,7 @@ namespace {
 int hw_threads() {
   unsigned n = std::thread::hardware_concurrency();
   if (n == 0) n = 1;
-  if (n > 16) n = 16;
+  if (n > 64) n = 64;
   return (int)n;
 }
 

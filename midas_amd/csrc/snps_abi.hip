@@ -2,6 +2,9 @@
 // for the contract and the reference lines each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <thread>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -194,6 +197,11 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->stage_rec || ctx->stage_blob) {   // unmapping large staging buffers is slow: not on the caller's time
+    void* a = ctx->stage_rec;
+    void* c = ctx->stage_blob;
+    std::thread([a, c] { free(a); free(c); }).detach();
+  }
   delete ctx;
 }
 
@@ -256,12 +264,22 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   ctx->err_read = -1;
   char ebuf[256] = {0};
   int64_t n_sites = 0;
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;   // developer: where batch_create spends its time
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_prev = now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = now();
+    fprintf(stderr, "[batch_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   int32_t st = validate_contigs(contigs, reads->n_reads, &n_sites, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
   PackSummary ps;
   st = pack_reads(reads, contigs, 0, nullptr, nullptr, nullptr, nullptr, 0, &ps, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
+  lap("validate + size query");
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   midas_snps_batch* b = new (std::nothrow) midas_snps_batch();
@@ -331,20 +349,31 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec)));  // + sentinel
   B_TRY(hipMalloc(&b->d_blob, blob_alloc));
   if (b->n_reads > 0) {
-    ReadRec* h_rec = nullptr;
-    uint8_t* h_blob = nullptr;
-    B_TRY(hipHostMalloc(&h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipHostMallocDefault));
-    hipError_t e = hipHostMalloc(&h_blob, blob_alloc, hipHostMallocDefault);
-    if (e != hipSuccess) {
-      (void)hipHostFree(h_rec);
-      int32_t s = hip_fail(ctx, e, "hipHostMalloc(blob)");
+    // staging in ordinary (pageable) memory owned by the context: pinning and unpinning ~0.25 GB costs ~70 ms on this
+    // platform, and even unmapping it ~30 ms -- several times the pack and the copy themselves (MIDAS_SNPS_TRACE)
+    const size_t rec_bytes = (size_t)(b->n_reads + 1) * sizeof(ReadRec);
+    if (ctx->stage_rec_cap < rec_bytes) {
+      free(ctx->stage_rec);
+      ctx->stage_rec = malloc(rec_bytes);
+      ctx->stage_rec_cap = ctx->stage_rec ? rec_bytes : 0;
+    }
+    if (ctx->stage_blob_cap < blob_alloc) {
+      free(ctx->stage_blob);
+      ctx->stage_blob = malloc(blob_alloc);
+      ctx->stage_blob_cap = ctx->stage_blob ? blob_alloc : 0;
+    }
+    ReadRec* h_rec = static_cast<ReadRec*>(ctx->stage_rec);
+    uint8_t* h_blob = static_cast<uint8_t*>(ctx->stage_blob);
+    if (!h_rec || !h_blob) {
       midas_snps_batch_destroy(b);
-      return s;
+      return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host staging allocation failed");
     }
     memset(h_blob + ps.blob_bytes, 0, 64);
+    lap("device + staging allocations");
     std::vector<uint32_t> h_orig((size_t)b->n_reads);
     std::vector<uint32_t> h_key((size_t)b->n_reads);
     st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), h_key.data(), (int64_t)blob_alloc, &ps, ebuf);
+    lap("pack_reads");
     if (st == MIDAS_SNPS_OK) {
       // reads a tile will see = those that start in it + those of earlier tiles reaching in (key: tile << 7 | reach << 2 | class)
       for (int64_t i = 0; i < b->n_reads; ++i) {
@@ -356,15 +385,15 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
       if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_reads * 4);
       if (e0 == hipSuccess) e0 = hipMemcpy(b->d_key, h_key.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
-      if (e0 != hipSuccess) { (void)hipHostFree(h_rec); (void)hipHostFree(h_blob); int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
+      if (e0 != hipSuccess) { int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
     }
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
     if (st == MIDAS_SNPS_OK) {
       e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
       e2 = hipMemcpy(b->d_blob, h_blob, blob_alloc, hipMemcpyHostToDevice);
     }
-    (void)hipHostFree(h_rec);
-    (void)hipHostFree(h_blob);
+    lap("H2D records + payload");
+
     if (st != MIDAS_SNPS_OK) {
       midas_snps_batch_destroy(b);
       return fail(ctx, st, ebuf);
@@ -435,6 +464,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMalloc(&b->d_counts, ns * 16));
   B_TRY(hipMalloc(&b->d_allele, ns));
 #undef B_TRY
+  lap("tables, items, outputs");
   *out_batch = b;
   return MIDAS_SNPS_OK;
 }
