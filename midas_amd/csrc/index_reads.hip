@@ -63,14 +63,23 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
     }
   }
   // Records are in (tile, class) order, so a wave mostly sees runs of one slot: only the first lane of a run
-  // publishes the low bound and only the last one the high bound.
+  // publishes the low bound and only the last one the high bound.  The same holds for the reads that reach into
+  // the next tile (class 2 of one tile is one run): their bounds on that tile's incoming slot are published by the
+  // run's first and last lane; only tiles further away (reach >= 2) are updated by every read.
   const int prev = __shfl_up(slot, 1);
   const int next = __shfl_down(slot, 1);
+  const int reaching = (valid && reach >= 1) ? t0 : -1;     // run key of the straddlers of tile t0
+  const int rprev = __shfl_up(reaching, 1);
+  const int rnext = __shfl_down(reaching, 1);
   if (valid) {
     const uint32_t inv = (uint32_t)(p.n_reads - i);
     if (lane == 0 || prev != slot) atomicMax(&p.rbinv[slot], inv);
     if (lane == 63 || next != slot) atomicMax(&p.rend[slot], (uint32_t)(i + 1));
-    for (int k = 1; k <= reach; ++k) {   // incoming slot of every later tile touched
+    if (reach >= 1) {
+      if (lane == 0 || rprev != reaching) atomicMax(&p.rbinv[3 * (t0 + 1) + 2], inv);
+      if (lane == 63 || rnext != reaching) atomicMax(&p.rend[3 * (t0 + 1) + 2], (uint32_t)(i + 1));
+    }
+    for (int k = 2; k <= reach; ++k) {   // incoming slot of every further tile touched
       atomicMax(&p.rbinv[3 * (t0 + k) + 2], inv);
       atomicMax(&p.rend[3 * (t0 + k) + 2], (uint32_t)(i + 1));
     }
