@@ -283,6 +283,14 @@ int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_params* params,
                           const uint32_t* const* sample_counts, const double* mean_depth, uint8_t* out_calls,
                           uint32_t* out_count_samples, uint64_t* out_pooled, uint32_t* out_depth, uint32_t* out_minor_count, float* out_kernel_ms);
 
+/* snps_freq.txt / snps_depth.txt of merge_midas.py snps (GenomicSite.write, midas/merge/snps.py:196-201): header_line,
+ * then one line per kept site `site_id \t v[sample 0] \t ...` with site_id = keep[r] + 1.  depth / minor_count are
+ * the [n_samples * n_sites] outputs of midas_merge_sites.  minor_count == NULL prints str(depth); otherwise
+ * '{0:.3g}'.format(float(minor_count) / depth if depth > 0 else 0.0).  Host only, formatted by a thread pool.  */
+int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
+                                 int32_t n_samples, int64_t n_sites, const uint32_t* depth,
+                                 const uint32_t* minor_count, int32_t threads, char* err256);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
+        'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
         'midas_snps_table_close': (None, [vp]),
@@ -249,7 +250,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
     'midas_snps_write_rows', 'midas_snps_write_table',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
-    'midas_snps_table_copy', 'midas_merge_sites',
+    'midas_snps_table_copy', 'midas_merge_sites', 'midas_merge_write_matrix',
 ]
 
 
@@ -286,8 +287,28 @@ def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads:
         raise MidasSnpsError(st, err.value.decode())
 
 
+def write_merge_matrix(path: str, header_line: str, keep: np.ndarray, depth: np.ndarray, minor_count=None, threads: int = 0):
+    """snps_depth.txt (minor_count None) / snps_freq.txt of merge_midas.py snps for the kept sites (midas_merge_write_matrix).
+    depth, minor_count: [n_samples, n_sites] uint32 as returned by Context.merge_sites."""
+    lib = load_library()
+    keep = np.ascontiguousarray(keep, dtype=np.int64)
+    depth = np.ascontiguousarray(depth, dtype=np.uint32)
+    S, n = depth.shape
+    mc = None
+    if minor_count is not None:
+        mc = np.ascontiguousarray(minor_count, dtype=np.uint32)
+        assert mc.shape == depth.shape
+    err = C.create_string_buffer(256)
+    st = lib.midas_merge_write_matrix(path.encode(), header_line.encode(), keep.shape[0], keep.ctypes.data_as(C.c_void_p),
+                                      S, n, depth.ctypes.data_as(C.c_void_p),
+                                      mc.ctypes.data_as(C.c_void_p) if mc is not None else None, int(threads), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+
+
 def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True):
-    """Parse one <species>.snps.gz with the native reader -> (counts[n,4] u32, keys bytes | None, key_off | None)."""
+    """Parse one <species>.snps.gz with the native reader -> (counts[n,4] u32, keys | None, key_off | None);
+    keys is a byte buffer, row i's 'ref_id|ref_pos|ref_allele' is bytes(keys[key_off[i]:key_off[i + 1]])."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
@@ -303,7 +324,7 @@ def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True):
         lib.midas_snps_table_copy(h, p(counts), p(keys), p(key_off))
     finally:
         lib.midas_snps_table_close(h)
-    return counts, (keys.tobytes() if want_keys else None), key_off
+    return counts, (memoryview(keys) if want_keys else None), key_off
 
 
 def read_bam(path: str):

@@ -32,10 +32,21 @@ struct midas_bam {
 };
 
 // One sample's <species>.snps.gz, parsed: what build_temp_count_matrix (midas/merge/snps.py:246-271) extracts.
+struct ParsedRows {
+  std::vector<uint32_t> counts;   // 4 per row: r[-4:]
+  std::string keys;               // 'ref_id|ref_pos|ref_allele' back to back
+  std::vector<int64_t> key_end;   // per row, end offset within `keys`
+  int64_t rows = 0;
+  int64_t bad_row = -1;           // first malformed row of the piece (0-based within the piece), or -1
+};
+
 struct midas_snps_table {
-  std::vector<uint32_t> counts;    // [rows][4]   r[-4:]
-  std::string keys;                // 'ref_id|ref_pos|ref_allele' of every row, back to back
-  std::vector<int64_t> key_off;    // [rows + 1]
+  // the table as parsed pieces (parallel parse), plus where each piece lands in the caller's arrays
+  std::vector<ParsedRows> pieces;
+  std::vector<int64_t> take;       // rows used of each piece (max_rows may cut the last one)
+  std::vector<int64_t> row_base;   // first row of each piece
+  std::vector<int64_t> key_base;   // first key byte of each piece
+  int64_t rows = 0, key_bytes = 0;
 };
 
 namespace {
@@ -188,21 +199,98 @@ inline char* put_u64(char* p, uint64_t v) {
   return p;
 }
 
+// One gzip member around a raw deflate stream.  The header carries an extra subfield 'M','S' with the member's
+// total size in bytes (the BGZF idea): any gzip reader skips it, ours uses it to find the members of a table without
+// inflating them, so that members are inflated and parsed in parallel (midas_snps_table_open).
+constexpr size_t kGzHeader = 20;   // 10 fixed + XLEN(2) + 'M','S',len(2) + u32
 bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out) {
   z_stream zs;
   memset(&zs, 0, sizeof zs);
-  if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-  out.resize(deflateBound(&zs, (uLong)n) + 64);
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  out.resize(kGzHeader + deflateBound(&zs, (uLong)n) + 64);
   zs.next_in = const_cast<Bytef*>(in);
   zs.avail_in = (uInt)n;
-  zs.next_out = out.data();
-  zs.avail_out = (uInt)out.size();
+  zs.next_out = out.data() + kGzHeader;
+  zs.avail_out = (uInt)(out.size() - kGzHeader - 8);
   const int rc = deflate(&zs, Z_FINISH);
-  const size_t produced = out.size() - zs.avail_out;
+  const size_t produced = (out.size() - kGzHeader - 8) - zs.avail_out;
   deflateEnd(&zs);
   if (rc != Z_STREAM_END) return false;
-  out.resize(produced);
+  const size_t total = kGzHeader + produced + 8;
+  if (total > 0xFFFFFFFFull) return false;
+  static const uint8_t fixed[10] = {0x1f, 0x8b, 8, 4 /* FEXTRA */, 0, 0, 0, 0, 0, 255};
+  memcpy(out.data(), fixed, 10);
+  const uint8_t extra[10] = {8, 0, 'M', 'S', 4, 0, (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16),
+                             (uint8_t)(total >> 24)};
+  memcpy(out.data() + 10, extra, 10);
+  const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n);
+  const uint32_t isize = (uint32_t)n;
+  memcpy(out.data() + kGzHeader + produced, &crc, 4);
+  memcpy(out.data() + kGzHeader + produced + 4, &isize, 4);
+  out.resize(total);
   return true;
+}
+
+// fields: ref_id, ref_pos, ref_allele, depth, count_a, count_c, count_g, count_t (tab separated); the reference takes
+// r[0:3] for the site key and r[-4:] for the counts (midas/merge/snps.py:262-270)
+void parse_rows(const char* b, const char* end, bool want_keys, bool skip_first_line, ParsedRows& out) {
+  if (skip_first_line) {
+    const char* nl = (const char*)memchr(b, '\n', (size_t)(end - b));
+    b = nl ? nl + 1 : end;
+  }
+  while (b < end) {
+    const char* nl = (const char*)memchr(b, '\n', (size_t)(end - b));
+    const char* e = nl ? nl : end;
+    const char* tabs[16];
+    int nt = 0;
+    for (const char* q = b; q < e && nt < 16; ++q)
+      if (*q == '\t') tabs[nt++] = q;
+    bool ok = nt >= 7;
+    uint32_t v4[4] = {0, 0, 0, 0};
+    if (ok) {
+      const char* starts[4] = {tabs[nt - 4] + 1, tabs[nt - 3] + 1, tabs[nt - 2] + 1, tabs[nt - 1] + 1};
+      const char* ends[4] = {tabs[nt - 3], tabs[nt - 2], tabs[nt - 1], e};
+      for (int k = 0; k < 4 && ok; ++k) {
+        uint64_t v = 0;
+        if (starts[k] >= ends[k]) ok = false;
+        for (const char* q = starts[k]; q < ends[k] && ok; ++q) {
+          if (*q < '0' || *q > '9') { ok = false; break; }
+          v = v * 10 + (uint64_t)(*q - '0');
+          if (v > 0x7FFFFFFFull) ok = false;   // major + minor of one sample must fit 32 bits downstream
+        }
+        v4[k] = (uint32_t)v;
+      }
+    }
+    if (!ok) { out.bad_row = out.rows; return; }
+    if (want_keys) {
+      out.keys.append(b, tabs[0]);
+      out.keys.push_back('|');
+      out.keys.append(tabs[0] + 1, tabs[1]);
+      out.keys.push_back('|');
+      out.keys.append(tabs[1] + 1, tabs[2]);
+      out.key_end.push_back((int64_t)out.keys.size());
+    }
+    out.counts.insert(out.counts.end(), v4, v4 + 4);
+    ++out.rows;
+    b = nl ? nl + 1 : end;
+  }
+}
+
+template <class F>
+void run_pool(int nt, size_t n_tasks, F&& fn) {
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n_tasks) return;
+      fn(i);
+    }
+  };
+  if ((size_t)nt > n_tasks) nt = (int)std::max<size_t>(1, n_tasks);
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
 }
 
 }  // namespace
@@ -356,91 +444,145 @@ int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_k
                               char* err256) {
   if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
-  gzFile f = gzopen(path, "rb");   // transparently reads concatenated gzip members
-  if (!f) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
-  gzbuffer(f, 1 << 20);
-  midas_snps_table* t = new (std::nothrow) midas_snps_table();
-  if (!t) { gzclose(f); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  t->key_off.push_back(0);
-  std::vector<char> buf(1 << 22);
-  std::string carry;
-  bool header = true;
-  int64_t rows = 0;
-  bool stop = (max_rows == 0);
-  auto parse_line = [&](const char* b, const char* e) -> bool {   // [b, e) without the newline
-    if (header) { header = false; return true; }
-    // fields: ref_id, ref_pos, ref_allele, depth, count_a, count_c, count_g, count_t (tab separated);
-    // the reference takes r[0:3] for the site key and r[-4:] for the counts
-    const char* tabs[16];
-    int nt = 0;
-    for (const char* q = b; q < e && nt < 16; ++q)
-      if (*q == '\t') tabs[nt++] = q;
-    if (nt < 7) return false;
-    if (want_keys) {
-      t->keys.append(b, tabs[0]);
-      t->keys.push_back('|');
-      t->keys.append(tabs[0] + 1, tabs[1]);
-      t->keys.push_back('|');
-      t->keys.append(tabs[1] + 1, tabs[2]);
-      t->key_off.push_back((int64_t)t->keys.size());
-    }
-    const char* starts[4] = {tabs[nt - 4] + 1, tabs[nt - 3] + 1, tabs[nt - 2] + 1, tabs[nt - 1] + 1};
-    const char* ends[4] = {tabs[nt - 3], tabs[nt - 2], tabs[nt - 1], e};
-    for (int k = 0; k < 4; ++k) {
-      uint64_t v = 0;
-      if (starts[k] >= ends[k]) return false;
-      for (const char* q = starts[k]; q < ends[k]; ++q) {
-        if (*q < '0' || *q > '9') return false;
-        v = v * 10 + (uint64_t)(*q - '0');
-        if (v > 0x7FFFFFFFull) return false;   // major + minor of one sample must fit 32 bits downstream
-      }
-      t->counts.push_back((uint32_t)v);
-    }
-    ++rows;
-    if (max_rows >= 0 && rows >= max_rows) stop = true;
-    return true;
-  };
-  bool ok = true;
-  while (!stop) {
-    const int n = gzread(f, buf.data(), (unsigned)buf.size());
-    if (n < 0) { ok = false; break; }
-    if (n == 0) break;
-    const char* b = buf.data();
-    const char* end = b + n;
-    while (b < end && !stop) {
-      const char* nl = (const char*)memchr(b, '\n', (size_t)(end - b));
-      if (!nl) { carry.append(b, end); b = end; break; }
-      if (!carry.empty()) {
-        carry.append(b, nl);
-        ok = parse_line(carry.data(), carry.data() + carry.size());
-        carry.clear();
-      } else {
-        ok = parse_line(b, nl);
-      }
-      if (!ok) break;
-      b = nl + 1;
-    }
-    if (!ok) break;
+  // ---- the text of the table, as line-aligned pieces ------------------------------------------------------
+  std::vector<std::vector<char>> pieces;
+  std::vector<uint8_t> file;
+  {
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+    fseek(f, 0, SEEK_END);
+    const long fsz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    file.resize((size_t)(fsz > 0 ? fsz : 0));
+    const bool rd = file.empty() || fread(file.data(), 1, file.size(), f) == file.size();
+    fclose(f);
+    if (!rd) { set_err(err256, "short read on %s", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   }
-  if (ok && !stop && !carry.empty()) ok = parse_line(carry.data(), carry.data() + carry.size());
-  gzclose(f);
-  if (!ok) {
-    set_err(err256, "%s: malformed row %lld", path, (long long)rows + 1);
-    delete t;
-    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  // members written by midas_snps_write_rows/_table announce their size: walk them without inflating
+  struct Member { size_t data, clen, ulen; };
+  std::vector<Member> members;
+  {
+    size_t p = 0;
+    bool sized = !file.empty();
+    while (sized && p < file.size()) {
+      const uint8_t* h = file.data() + p;
+      if (p + kGzHeader + 8 > file.size() || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || rd16(h + 10) != 8 ||
+          h[12] != 'M' || h[13] != 'S' || rd16(h + 14) != 4) { sized = false; break; }
+      const size_t total = rd32(h + 16);
+      if (total < kGzHeader + 8 || p + total > file.size()) { sized = false; break; }
+      members.push_back({p + kGzHeader, total - kGzHeader - 8, (size_t)rd32(h + total - 4)});
+      p += total;
+    }
+    if (!sized) members.clear();
   }
-  *out = t;
+  const int nt = hw_threads(0);
+  if (!members.empty()) {
+    pieces.resize(members.size());
+    std::atomic<int> bad{0};
+    run_pool(nt, members.size(), [&](size_t i) {
+      const Member& m = members[i];
+      pieces[i].resize(m.ulen);
+      if (m.ulen == 0) return;
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+      zs.next_in = file.data() + m.data;
+      zs.avail_in = (uInt)m.clen;
+      zs.next_out = reinterpret_cast<Bytef*>(pieces[i].data());
+      zs.avail_out = (uInt)m.ulen;
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+    });
+    if (bad) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  } else {
+    // any other gzip file (e.g. written by the reference): one serial inflate, then line-aligned pieces
+    std::vector<uint8_t>().swap(file);
+    gzFile f = gzopen(path, "rb");   // transparently reads concatenated gzip members
+    if (!f) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+    gzbuffer(f, 1 << 20);
+    const size_t kPiece = (size_t)4 << 20;
+    std::vector<char> cur;
+    cur.reserve(kPiece + (1 << 16));
+    std::vector<char> buf(1 << 20);
+    bool ok = true;
+    for (;;) {
+      const int n = gzread(f, buf.data(), (unsigned)buf.size());
+      if (n < 0) { ok = false; break; }
+      if (n == 0) break;
+      cur.insert(cur.end(), buf.data(), buf.data() + n);
+      if (cur.size() >= kPiece) {   // cut after the last complete line
+        size_t cut = cur.size();
+        while (cut > 0 && cur[cut - 1] != '\n') --cut;
+        if (cut > 0) {
+          std::vector<char> rest(cur.begin() + (long)cut, cur.end());
+          cur.resize(cut);
+          pieces.push_back(std::move(cur));
+          cur = std::move(rest);
+          cur.reserve(kPiece + (1 << 16));
+        }
+      }
+    }
+    gzclose(f);
+    if (!ok) { set_err(err256, "%s: corrupt gzip data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    if (!cur.empty()) pieces.push_back(std::move(cur));
+  }
+  std::vector<uint8_t>().swap(file);
+  // ---- parse the pieces in parallel (the first line of the file is the header) --------------------------------
+  size_t first_piece = 0;
+  while (first_piece < pieces.size() && pieces[first_piece].empty()) ++first_piece;
+  std::vector<ParsedRows> parsed(pieces.size());
+  run_pool(nt, pieces.size(), [&](size_t i) {
+    const std::vector<char>& t = pieces[i];
+    if (t.empty()) return;
+    parse_rows(t.data(), t.data() + t.size(), want_keys != 0, i == first_piece, parsed[i]);
+    std::vector<char>().swap(pieces[i]);
+  });
+  midas_snps_table* tab = new (std::nothrow) midas_snps_table();
+  if (!tab) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  tab->take.assign(parsed.size(), 0);
+  tab->row_base.assign(parsed.size(), 0);
+  tab->key_base.assign(parsed.size(), 0);
+  int64_t rows = 0, kbytes = 0;
+  for (size_t i = 0; i < parsed.size(); ++i) {
+    ParsedRows& pr = parsed[i];
+    int64_t take = pr.rows;
+    if (max_rows >= 0 && rows + take > max_rows) take = max_rows - rows;
+    if (pr.bad_row >= 0 && (max_rows < 0 || rows + pr.bad_row < max_rows)) {
+      // a malformed row inside what would be read (the reference would fail converting it)
+      set_err(err256, "%s: malformed row %lld", path, (long long)(rows + pr.bad_row + 1));
+      delete tab;
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    tab->take[i] = take;
+    tab->row_base[i] = rows;
+    tab->key_base[i] = kbytes;
+    rows += take;
+    if (want_keys && take > 0) kbytes += pr.key_end[(size_t)take - 1];
+    if (max_rows >= 0 && rows >= max_rows) break;
+  }
+  tab->rows = rows;
+  tab->key_bytes = kbytes;
+  tab->pieces = std::move(parsed);
+  *out = tab;
   return MIDAS_SNPS_OK;
 }
 
 void midas_snps_table_close(midas_snps_table* t) { delete t; }
-int64_t midas_snps_table_rows(const midas_snps_table* t) { return t ? (int64_t)(t->counts.size() / 4) : 0; }
-int64_t midas_snps_table_key_bytes(const midas_snps_table* t) { return t ? (int64_t)t->keys.size() : 0; }
+int64_t midas_snps_table_rows(const midas_snps_table* t) { return t ? t->rows : 0; }
+int64_t midas_snps_table_key_bytes(const midas_snps_table* t) { return t ? t->key_bytes : 0; }
 int32_t midas_snps_table_copy(const midas_snps_table* t, uint32_t* counts, char* keys, int64_t* key_off) {
   if (!t) return MIDAS_SNPS_ERR_INVALID_ARG;
-  if (counts && !t->counts.empty()) memcpy(counts, t->counts.data(), t->counts.size() * 4);
-  if (keys && !t->keys.empty()) memcpy(keys, t->keys.data(), t->keys.size());
-  if (key_off) memcpy(key_off, t->key_off.data(), t->key_off.size() * 8);
+  if (key_off) key_off[0] = 0;
+  run_pool(hw_threads(0), t->pieces.size(), [&](size_t i) {   // every piece lands at its own offsets
+    const int64_t take = t->take[i];
+    if (take <= 0) return;
+    const ParsedRows& pr = t->pieces[i];
+    if (counts) memcpy(counts + 4 * t->row_base[i], pr.counts.data(), (size_t)take * 16);
+    if (keys && !pr.key_end.empty()) memcpy(keys + t->key_base[i], pr.keys.data(), (size_t)pr.key_end[(size_t)take - 1]);
+    if (key_off && !pr.key_end.empty())
+      for (int64_t r = 0; r < take; ++r) key_off[t->row_base[i] + r + 1] = t->key_base[i] + pr.key_end[(size_t)r];
+  });
   return MIDAS_SNPS_OK;
 }
 
@@ -539,6 +681,66 @@ int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* 
   for (int32_t k = 0; k < n_contigs; ++k)
     if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k]))) return MIDAS_SNPS_ERR_INVALID_ARG;
   return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256);
+}
+
+int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
+                                 int32_t n_samples, int64_t n_sites, const uint32_t* depth, const uint32_t* minor_count,
+                                 int32_t threads, char* err256) {
+  if (!path || !header_line || n_keep < 0 || n_samples <= 0 || n_sites < 0 || (n_keep > 0 && (!keep || !depth)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  bool ok = fwrite(header_line, 1, strlen(header_line), f) == strlen(header_line);
+  const int64_t kRows = 1 << 13;
+  const int64_t n_chunks = (n_keep + kRows - 1) / kRows;
+  int nt = writer_threads(threads);
+  if ((int64_t)nt > n_chunks) nt = (int)std::max<int64_t>(1, n_chunks);
+  std::vector<std::vector<char>> text((size_t)n_chunks);
+  std::vector<std::atomic<int>> done((size_t)n_chunks);
+  for (auto& d : done) d = 0;
+  std::atomic<int64_t> next{0};
+  auto work = [&] {
+    for (;;) {
+      const int64_t ci = next.fetch_add(1);
+      if (ci >= n_chunks) return;
+      const int64_t lo = ci * kRows, hi = std::min(n_keep, lo + kRows);
+      std::vector<char>& t = text[(size_t)ci];
+      t.resize((size_t)(hi - lo) * (24 + 16 * (size_t)n_samples));
+      char* p = t.data();
+      for (int64_t r = lo; r < hi; ++r) {
+        const int64_t i = keep[r];
+        p = put_u64(p, (uint64_t)(i + 1));                                   // site_id = 1-based table row
+        for (int32_t s = 0; s < n_samples; ++s) {
+          *p++ = '\t';
+          const uint32_t d = depth[(size_t)s * (size_t)n_sites + (size_t)i];
+          if (!minor_count) {
+            p = put_u32(p, d);                                               // str(depth)
+          } else {
+            // '{0:.3g}'.format(float(minor) / depth if depth > 0 else 0.0)  (midas/merge/snps.py:88-90, 197)
+            const uint32_t m = minor_count[(size_t)s * (size_t)n_sites + (size_t)i];
+            if (d == 0 || m == 0) *p++ = '0';
+            else p += snprintf(p, 16, "%.3g", (double)m / (double)d);
+          }
+        }
+        *p++ = '\n';
+      }
+      t.resize((size_t)(p - t.data()));
+      done[(size_t)ci] = 1;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work);
+  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+    while (!done[(size_t)ci].load()) std::this_thread::yield();
+    std::vector<char>& t = text[(size_t)ci];
+    ok = fwrite(t.data(), 1, t.size(), f) == t.size();
+    std::vector<char>().swap(t);
+  }
+  if (!ok) next = n_chunks;
+  for (auto& x : th) x.join();
+  if (fclose(f) != 0) ok = false;
+  if (!ok) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  return MIDAS_SNPS_OK;
 }
 
 }  // extern "C"

@@ -26,18 +26,6 @@ INFO_FIELDS = ['site_id', 'ref_id', 'ref_pos', 'ref_allele', 'major_allele', 'mi
                'count_a', 'count_c', 'count_g', 'count_t', 'locus_type', 'gene_id', 'snp_type', 'site_type', 'amino_acids']
 
 
-def write_merge_midas(species, args):
-    """Open output files for species, write headers -- midas/merge/snps.py:291-322"""
-    files = {}
-    for ftype in ['info', 'freq', 'depth']:
-        files[ftype] = open('%s/%s/snps_%s.txt' % (args['outdir'], species.id, ftype), 'w')
-    for ftype in ['freq', 'depth']:
-        record = ['site_id'] + [s.id for s in species.samples]
-        files[ftype].write('\t'.join(record) + '\n')
-    files['info'].write('\t'.join(INFO_FIELDS) + '\n')
-    return files
-
-
 def load_sample_tables(species, args):
     """read_run_midas_snps + the zip of build_temp_count_matrix (midas/merge/snps.py:236-271), without the
     temporary matrices: per sample the [n_sites,4] counts, plus the site keys of the first sample."""
@@ -61,32 +49,34 @@ def merge_species(species, args, ctx):
         res = ctx.merge_sites(prm, counts, species.sample_depth)
     except abi.MidasSnpsError as e:
         sys.exit("\nError: %s\n" % e.message)
-    files = write_merge_midas(species, args)
     genes = annotate.GeneCursor.from_db(species.id, args['db'])
     keep = np.nonzero(res['flag'] == 0)[0]
-    alle = 'ACGT'
-    depth = res['depth']
-    minor = res['minor_count']
-    for i in keep:
-        i = int(i)
-        key = keys[key_off[i]:key_off[i + 1]].decode()
+    outdir = '%s/%s' % (args['outdir'], species.id)
+    # snps_freq.txt / snps_depth.txt: one number per (kept site, sample) -- formatted natively
+    header = '\t'.join(['site_id'] + [s.id for s in species.samples]) + '\n'
+    threads = int(args.get('threads', 1) or 1)
+    abi.write_merge_matrix(outdir + '/snps_freq.txt', header, keep, res['depth'], res['minor_count'], threads=threads)
+    abi.write_merge_matrix(outdir + '/snps_depth.txt', header, keep, res['depth'], None, threads=threads)
+    # snps_info.txt: annotation of the kept sites (forward cursor over the sorted genes) + the per-site calls
+    alle = ('A', 'C', 'G', 'T')
+    major, minor, snp_type = res['major'], res['minor'], res['snp_type']
+    count_samples, pooled = res['count_samples'], res['pooled']
+    lines = []
+    for i in keep.tolist():
+        key = bytes(keys[key_off[i]:key_off[i + 1]]).decode()
         ref_id, ref_pos, ref_allele = key.rsplit('|', 2)
-        site_id = str(i + 1)
-        mj, mn = int(res['major'][i]), int(res['minor'][i])
+        mj, mn = int(major[i]), int(minor[i])
         locus_type, gene_id, site_type, amino_acids = genes.lookup(ref_id, int(ref_pos))
-        pooled = res['pooled'][i]
-        info = [site_id, ref_id, str(int(ref_pos)), ref_allele,
-                alle[mj] if mj < 4 else None, alle[mn] if mn < 4 else None, str(int(res['count_samples'][i])),
-                str(int(pooled[0])), str(int(pooled[1])), str(int(pooled[2])), str(int(pooled[3])),
-                locus_type, gene_id, abi.SNP_TYPE_NAMES[int(res['snp_type'][i])], site_type, amino_acids]
-        files['info'].write('\t'.join([replace_none(_) for _ in info]) + '\n')
-        d = depth[:, i]
-        m = minor[:, i]
-        mafs = [float(m[s]) / int(d[s]) if (mn < 4 and d[s] > 0) else 0.0 for s in range(len(counts))]
-        files['freq'].write(site_id + '\t' + '\t'.join(['{0:.3g}'.format(f) for f in mafs]) + '\n')
-        files['depth'].write(site_id + '\t' + '\t'.join([str(int(x)) for x in d]) + '\n')
-    for f in files.values():
-        f.close()
+        pc = pooled[i]
+        lines.append('\t'.join((str(i + 1), ref_id, str(int(ref_pos)), ref_allele,
+                                alle[mj] if mj < 4 else 'NA', alle[mn] if mn < 4 else 'NA', str(int(count_samples[i])),
+                                str(int(pc[0])), str(int(pc[1])), str(int(pc[2])), str(int(pc[3])),
+                                locus_type, replace_none(gene_id), replace_none(abi.SNP_TYPE_NAMES[int(snp_type[i])]),
+                                replace_none(site_type), replace_none(amino_acids))))
+    with open(outdir + '/snps_info.txt', 'w') as f:
+        f.write('\t'.join(INFO_FIELDS) + '\n')
+        if lines:
+            f.write('\n'.join(lines) + '\n')
     return n, len(keep), res['kernel_ms']
 
 

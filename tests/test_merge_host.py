@@ -25,7 +25,7 @@ def test_table_reader_matches_what_was_written(dataset):
     counts, keys, off = abi.read_snps_table(path)
     assert counts.shape == (4000, 4) and counts.dtype == np.uint32
     assert np.array_equal(counts, dataset['counts'][1].astype(np.uint32))
-    got = [keys[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+    got = [bytes(keys[off[i]:off[i + 1]]).decode() for i in range(len(off) - 1)]
     assert got == dataset['keys']
     # max_rows (args['max_sites']) and keyless reads
     c2, k2, o2 = abi.read_snps_table(path, 17, False)
@@ -44,8 +44,8 @@ def test_table_reader_reads_tables_written_by_the_pileup_stage(tmp_path):
     abi.write_rows(path, False, "ctg|with|pipes", allele, counts)
     got, keys, off = abi.read_snps_table(path)
     assert np.array_equal(got, counts)
-    assert keys[off[0]:off[1]].decode() == "ctg|with|pipes|1|%s" % chr(allele[0])
-    assert keys[off[n - 1]:off[n]].decode() == "ctg|with|pipes|%d|%s" % (n, chr(allele[n - 1]))
+    assert bytes(keys[off[0]:off[1]]).decode() == "ctg|with|pipes|1|%s" % chr(allele[0])
+    assert bytes(keys[off[n - 1]:off[n]]).decode() == "ctg|with|pipes|%d|%s" % (n, chr(allele[n - 1]))
 
 
 def test_table_reader_rejects_malformed_rows(tmp_path):
@@ -152,3 +152,56 @@ def test_cli_presets():
     assert a['snp_type'] == ['any'] and a['site_prev'] == 0.95
     a = merge_midas.add_snp_presets(dict(base))
     assert a['snp_type'] == ['tri'] and a['site_prev'] == 0.3
+
+
+def test_matrix_writer_formats_like_python(tmp_path):
+    rng = np.random.default_rng(3)
+    S, n = 5, 30000
+    depth = rng.integers(0, 2000, (S, n)).astype(np.uint32)
+    minor = (depth * rng.random((S, n))).astype(np.uint32)
+    depth[:, 7] = 0
+    minor[:, 7] = 0
+    minor[0, 9], depth[0, 9] = 1, 100000          # 1e-05
+    minor[1, 9], depth[1, 9] = 1, 3               # 0.333
+    minor[2, 9], depth[2, 9] = 2, 3               # 0.667
+    minor[3, 9], depth[3, 9] = 5, 5               # 1
+    keep = np.sort(rng.choice(n, 12000, replace=False))
+    keep[:3] = [7, 8, 9]
+    keep = np.unique(keep)
+    header = "site_id\ta\tb\tc\td\te\n"
+    fp, dp = str(tmp_path / "freq.txt"), str(tmp_path / "depth.txt")
+    abi.write_merge_matrix(fp, header, keep, depth, minor, threads=4)
+    abi.write_merge_matrix(dp, header, keep, depth, None, threads=4)
+    exp_f = [header] + ["%d\t%s\n" % (i + 1, "\t".join('{0:.3g}'.format(float(minor[s, i]) / depth[s, i] if depth[s, i] > 0 else 0.0)
+                                                       for s in range(S))) for i in keep]
+    exp_d = [header] + ["%d\t%s\n" % (i + 1, "\t".join(str(int(depth[s, i])) for s in range(S))) for i in keep]
+    assert open(fp).read() == "".join(exp_f)
+    assert open(dp).read() == "".join(exp_d)
+    abi.write_merge_matrix(fp, header, np.zeros(0, np.int64), depth, minor)
+    assert open(fp).read() == header
+
+
+def test_table_reader_foreign_gzip_and_row_limits(tmp_path):
+    # a single-member gzip as Python's gzip (the reference's writer) produces it: serial inflate, parallel parse
+    n = 300000
+    rng = np.random.default_rng(8)
+    counts = rng.integers(0, 99, (n, 4))
+    p = str(tmp_path / "ref_style.snps.gz")
+    with gzip.open(p, "wt", compresslevel=1) as h:
+        h.write("ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n")
+        h.write("".join("ctg\t%d\tA\t%d\t%d\t%d\t%d\t%d\n" % (i + 1, counts[i].sum(), *counts[i]) for i in range(n)))
+    got, keys, off = abi.read_snps_table(p)
+    assert np.array_equal(got, counts.astype(np.uint32)) and len(off) == n + 1
+    assert bytes(keys[off[n - 1]:off[n]]).decode() == "ctg|%d|A" % n
+    got2, _, _ = abi.read_snps_table(p, 123457, False)
+    assert np.array_equal(got2, counts[:123457].astype(np.uint32))
+    # a malformed row beyond max_rows is never looked at (the reference stops reading at max_sites)
+    q = str(tmp_path / "late_garbage.snps.gz")
+    with gzip.open(q, "wt") as h:
+        h.write("ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n")
+        h.write("c\t1\tA\t3\t1\t1\t1\t0\nc\t2\tA\t3\t1\t1\t1\t0\nc\t3\tA\tgarbage\n")
+    ok, _, _ = abi.read_snps_table(q, 2, False)
+    assert ok.tolist() == [[1, 1, 1, 0], [1, 1, 1, 0]]
+    with pytest.raises(abi.MidasSnpsError) as e:
+        abi.read_snps_table(q, 3, False)
+    assert "row 3" in e.value.message
