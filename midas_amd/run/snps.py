@@ -28,165 +28,152 @@ from midas_amd import abi, bam, dist, fasta, utility
 
 
 class Species:
-    """Base class for species -- midas/run/snps.py:12-31"""
+    """A species of the sample: id, where its representative genome lives, and (after the pileup) its counters."""
+    __slots__ = ('id', 'paths', 'aligned_reads', 'mapped_reads', 'genome_length', 'covered_bases', 'total_depth',
+                 'fraction_covered', 'mean_coverage')
+
     def __init__(self, id):
         self.id = id
         self.paths = {}
-        self.aligned_reads = 0
-        self.mapped_reads = 0
-        self.genome_length = 0
-        self.covered_bases = 0
-        self.total_depth = 0
-        self.fraction_covered = 0
-        self.mean_coverage = 0
+        self.aligned_reads = self.mapped_reads = self.genome_length = self.covered_bases = self.total_depth = 0
+        self.fraction_covered = self.mean_coverage = 0
 
     def fetch_paths(self, ref_db):
-        indir = '%s/rep_genomes/%s' % (ref_db, self.id)
-        for ext in ['', '.gz']:
-            for type in ['fna', 'features']:
-                path = '%s/genome.%s%s' % (indir, type, ext)
-                if os.path.isfile(path):
-                    self.paths[type] = path
+        """genome.fna / genome.features of the species, plain or .gz (the .gz wins when both exist, as in the reference)."""
+        base = os.path.join(ref_db, 'rep_genomes', self.id)
+        for kind in ('fna', 'features'):
+            for suffix in ('', '.gz'):
+                candidate = os.path.join(base, 'genome.%s%s' % (kind, suffix))
+                if os.path.isfile(candidate):
+                    self.paths[kind] = candidate
 
 
 class Contig:
-    """Base class for contig -- midas/run/snps.py:33-36"""
-    def __init__(self, id):
+    """One FASTA record of a representative genome: id, upper-cased sequence, length, owning species."""
+    __slots__ = ('id', 'seq', 'length', 'species_id')
+
+    def __init__(self, id, seq='', species_id=None):
         self.id = id
+        self.seq = seq
+        self.length = len(seq)
+        self.species_id = species_id
 
 
 def select_species(args):
-    """The slice of midas/run/species.py:191-227 this path can honour without a species profile:
-    --species_id (checked against the database).  --species_cov / --species_topn need the output of
-    `run_midas.py species`, which is outside this build."""
-    if not args.get('species_id'):
+    """Only --species_id can be honoured here: --species_cov / --species_topn read the abundance profile written by
+    `run_midas.py species` (midas/run/species.py:191-227), a pipeline outside this build."""
+    wanted = args.get('species_id')
+    if not wanted:
         sys.exit("\nError: this build only selects species with --species_id "
                  "(--species_cov/--species_topn need `run_midas.py species`, which is out of scope)\n")
-    ids = []
-    for sp in args['species_id']:
-        if not os.path.isdir('%s/rep_genomes/%s' % (args['db'], sp)):
+    for sp in wanted:
+        if not os.path.isdir(os.path.join(args['db'], 'rep_genomes', sp)):
             sys.exit("\nError: Species id not found in database: %s\n" % sp)
-        ids.append(sp)
-    return ids
+    return list(wanted)
 
 
 def initialize_species(args):
-    """midas/run/snps.py:38-53"""
-    species = {}
-    splist = '%s/snps/species.txt' % args['outdir']
+    """{species_id: Species}: chosen now and recorded in snps/species.txt when the database is being built, else
+    read back from that file (midas/run/snps.py:38-53)."""
+    listing = os.path.join(args['outdir'], 'snps', 'species.txt')
     if args['build_db']:
-        with open(splist, 'w') as outfile:
-            for id in select_species(args):
-                species[id] = Species(id)
-                outfile.write(id + '\n')
-    elif os.path.isfile(splist):
-        for line in open(splist):
-            id = line.rstrip()
-            species[id] = Species(id)
+        ids = select_species(args)
+        with open(listing, 'w') as handle:
+            handle.writelines(i + '\n' for i in ids)
+    elif os.path.isfile(listing):
+        with open(listing) as handle:
+            ids = [line.rstrip() for line in handle]
+    else:
+        ids = []
+    species = {i: Species(i) for i in ids}
     for sp in species.values():
         sp.fetch_paths(ref_db=args['db'])
     return species
 
 
+def _records(sp):
+    if 'fna' not in sp.paths:
+        sys.exit("\nError: Could not locate the representative genome of species: %s\n" % sp.id)
+    with utility.iopen(sp.paths['fna']) as handle:
+        for rec_id, rec_seq in fasta.parse(handle):
+            yield rec_id, rec_seq.upper()
+
+
 def initialize_contigs(species):
-    """midas/run/snps.py:55-67 (Bio.SeqIO replaced by midas_amd.fasta; same id / upper-cased seq)"""
-    contigs = {}
-    for sp in species.values():
-        if 'fna' not in sp.paths:
-            sys.exit("\nError: Could not locate the representative genome of species: %s\n" % sp.id)
-        infile = utility.iopen(sp.paths['fna'])
-        for rec_id, rec_seq in fasta.parse(infile):
-            contig = Contig(rec_id)
-            contig.id = rec_id
-            contig.seq = rec_seq.upper()
-            contig.length = len(contig.seq)
-            contig.species_id = sp.id
-            contigs[contig.id] = contig
-        infile.close()
-    return contigs
+    """{contig_id: Contig} over every species' representative genome, sequences upper-cased (midas/run/snps.py:55-67)."""
+    return {rid: Contig(rid, seq, sp.id) for sp in species.values() for rid, seq in _records(sp)}
+
+
+def _shell(args, stages):
+    """Run `stage | stage | ...` through the shell, logging the command; a failing pipeline ends the run."""
+    command = ' | '.join(' '.join(str(x) for x in stage) for stage in stages) + ' '
+    args['log'].write('command: ' + command + '\n')
+    process = subprocess.Popen(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    utility.check_exit_code(process, command)
 
 
 def build_genome_db(args, species):
-    """Build FASTA and BT2 database of representative genomes -- midas/run/snps.py:69-95"""
-    outfile = open('/'.join([args['outdir'], 'snps/temp/genomes.fa']), 'w')
-    db_stats = {'total_length': 0, 'total_seqs': 0, 'species': 0}
-    for sp in species.values():
-        db_stats['species'] += 1
-        infile = utility.iopen(sp.paths['fna'])
-        for rec_id, rec_seq in fasta.parse(infile):
-            outfile.write('>%s\n%s\n' % (rec_id, rec_seq.upper()))
-            db_stats['total_length'] += len(rec_seq)
-            db_stats['total_seqs'] += 1
-        infile.close()
-    outfile.close()
-    print("  total genomes: %s" % db_stats['species'])
-    print("  total contigs: %s" % db_stats['total_seqs'])
-    print("  total base-pairs: %s" % db_stats['total_length'])
+    """snps/temp/genomes.fa = every selected genome, then `bowtie2-build` on it (midas/run/snps.py:69-95)."""
+    temp = os.path.join(args['outdir'], 'snps', 'temp')
+    n_seqs = n_bases = 0
+    with open(os.path.join(temp, 'genomes.fa'), 'w') as out:
+        for sp in species.values():
+            for rid, seq in _records(sp):
+                out.write('>%s\n%s\n' % (rid, seq))
+                n_seqs += 1
+                n_bases += len(seq)
+    print("  total genomes: %s\n  total contigs: %s\n  total base-pairs: %s" % (len(species), n_seqs, n_bases))
     if not args.get('bowtie2-build'):
         sys.exit("\nError: bowtie2-build not found on PATH (needed for --build_db; the aligner is not part of this build)\n")
-    command = '%s ' % args['bowtie2-build']
-    command += '--threads %s ' % args['threads']
-    command += '%s/snps/temp/genomes.fa ' % args['outdir']
-    command += '%s/snps/temp/genomes ' % args['outdir']
-    args['log'].write('command: ' + command + '\n')
-    process = subprocess.Popen(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    utility.check_exit_code(process, command)
+    _shell(args, [[args['bowtie2-build'], '--threads', args['threads'], os.path.join(temp, 'genomes.fa'),
+                   os.path.join(temp, 'genomes')]])
 
 
 def genome_align(args):
-    """Use Bowtie2 to map reads to representative genomes -- midas/run/snps.py:97-128"""
+    """bowtie2 (no unaligned reads) | samtools view -b | samtools sort -> snps/temp/genomes.bam, with the same
+    switches the reference passes (midas/run/snps.py:97-128)."""
     if not args.get('bowtie2') or not args.get('samtools'):
         sys.exit("\nError: bowtie2 / samtools not found on PATH (needed for --align; the aligner is not part of this build)\n")
-    bam_path = os.path.join(args['outdir'], 'snps/temp/genomes.bam')
-    command = '%s --no-unal ' % args['bowtie2']
-    command += '-x %s ' % '/'.join([args['outdir'], 'snps/temp/genomes'])
-    if args['max_reads']: command += '-u %s ' % args['max_reads']
-    if args['trim']: command += '--trim3 %s ' % args['trim']
-    command += '--%s' % args['speed']
-    command += '-local ' if args['mode'] == 'local' else ' '
-    command += '--threads %s ' % args['threads']
-    command += '-f ' if args['file_type'] == 'fasta' else '-q '
+    temp = os.path.join(args['outdir'], 'snps', 'temp')
+    bt2 = [args['bowtie2'], '--no-unal', '-x', os.path.join(temp, 'genomes')]
+    if args['max_reads']:
+        bt2 += ['-u', args['max_reads']]
+    if args['trim']:
+        bt2 += ['--trim3', args['trim']]
+    bt2 += ['--%s%s' % (args['speed'], '-local' if args['mode'] == 'local' else ''), '--threads', args['threads'],
+            '-f' if args['file_type'] == 'fasta' else '-q']
     if args['m2']:
-        command += '-1 %s -2 %s ' % (args['m1'], args['m2'])
+        bt2 += ['-1', args['m1'], '-2', args['m2']]
     elif args['interleaved']:
-        command += '--interleaved %s ' % args['m1']
+        bt2 += ['--interleaved', args['m1']]
     else:
-        command += '-U %s ' % args['m1']
-    command += '| %s view -b - ' % args['samtools']
-    command += '--threads %s ' % args['threads']
-    command += '| %s sort - ' % args['samtools']
-    command += '--threads %s ' % args['threads']
-    command += '-o %s ' % bam_path
-    args['log'].write('command: ' + command + '\n')
-    process = subprocess.Popen(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    utility.check_exit_code(process, command)
+        bt2 += ['-U', args['m1']]
+    view = [args['samtools'], 'view', '-b', '-', '--threads', args['threads']]
+    sort = [args['samtools'], 'sort', '-', '--threads', args['threads'], '-o', os.path.join(temp, 'genomes.bam')]
+    _shell(args, [bt2, view, sort])
     print("  finished aligning")
 
 
 def index_bam(args):
-    """midas/run/snps.py:130-139.  The reference shells out to `samtools index` because pysam's
-    count_coverage fetches through the .bai; here the index is the per-tile read range table the device
-    builds at the start of every pileup pass, so there is nothing to do on the host."""
+    """The reference runs `samtools index` here because pysam fetches through the .bai (midas/run/snps.py:130-139).
+    The device builds its own per-tile read index at the start of every pileup pass (index_reads_kernel), so the
+    host has nothing to do; the step is kept so that logs and callers look the same."""
     start = time()
     print("\nIndexing bamfile")
-    args['log'].write("\nIndexing bamfile\n")
-    args['log'].write('command: (none) per-tile read index is built on the GPU by index_reads_kernel\n')
+    args['log'].write("\nIndexing bamfile\ncommand: (none) per-tile read index is built on the GPU by index_reads_kernel\n")
     print("  %s minutes" % round((time() - start) / 60, 2))
     print("  %s Gb maximum memory" % utility.max_mem_usage())
 
 
 def keep_read(aln_len_minus_nm, align_len, qual_sum, query_len, mapq, args):
-    """The predicate of midas/run/snps.py:141-162 on already-extracted numbers.  Documentation and host-side
-    spot checks only: the pileup evaluates exactly this on the GPU (pileup_tiles.hip, `keep_read` block)."""
-    if 100 * aln_len_minus_nm / float(align_len) < args['mapid']:
-        return False
-    elif qual_sum / float(query_len) < args['readq']:
-        return False
-    elif mapq < args['mapq']:
-        return False
-    elif align_len / float(query_len) < args['aln_cov']:
-        return False
-    return True
+    """The read filter of midas/run/snps.py:141-162 on already-extracted numbers, tests in the reference's order:
+    identity, mean quality, mapping quality, aligned fraction.  Documentation and host-side spot checks only: the
+    pileup evaluates exactly this on the GPU (pileup_tiles.hip)."""
+    tests = (100 * aln_len_minus_nm / float(align_len) < args['mapid'],
+             qual_sum / float(query_len) < args['readq'],
+             mapq < args['mapq'],
+             align_len / float(query_len) < args['aln_cov'])
+    return not any(tests)
 
 
 _ERR_TEXT = {

@@ -1,144 +1,145 @@
 #!/usr/bin/env python
-"""merge_midas.py -- the `snps` command (multi-sample SNP calling) on MI355X.
+"""merge_midas.py snps -- multi-sample SNP calling with the per-site arithmetic on MI355X.
 
-Keeps the reference's command line for `merge_midas.py snps` (scripts/merge_midas.py:148-281 arguments and presets,
-:283-332 checks) and output layout; `species` and `genes` merges are not part of this build.
+Drop-in for the `snps` command of the reference's scripts/merge_midas.py: same positional arguments, option names,
+defaults, presets and output files (<outdir>/<species>/snps_{info,freq,depth,summary}.txt, readme.txt).  The option
+semantics are the reference's (scripts/merge_midas.py:148-281); `species` and `genes` merges are not part of this
+build.  Under torch.distributed.run the species are dealt to the ranks (one GPU each).
 """
 
 import argparse
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+# preset flag -> the site filters it pins (applied in this order, later ones win, as in the reference)
+PRESETS = [
+    ('all_sites', dict(site_prev=0.0, snp_type=['any'])),
+    ('all_snps', dict(site_prev=0.0, snp_type=['bi'])),
+    ('core_sites', dict(site_depth=1, site_ratio=2.0, site_prev=0.95, snp_type=['any'])),
+    ('core_snps', dict(site_depth=1, site_ratio=2.0, site_prev=0.95, snp_type=['bi'])),
+]
+
+OPTION_GROUPS = [
+    ("Samples", [
+        (['-i'], dict(dest='input', required=True, help="run_midas.py output directories; how to read this is set by -t")),
+        (['-t'], dict(dest='intype', required=True, choices=['list', 'file', 'dir'], metavar='list|file|dir',
+                      help="list: comma separated paths; file: one path per line; dir: every sub-directory")),
+        (['-d'], dict(dest='db', default=os.environ.get('MIDAS_DB'), help="MIDAS reference database (default: $MIDAS_DB)")),
+    ]),
+    ("Presets", [
+        (['--core_snps'], dict(action='store_true', help="bi-allelic sites present in >= 95 %% of the samples (the default behaviour)")),
+        (['--core_sites'], dict(action='store_true', help="like --core_snps but keeps every site, variable or not")),
+        (['--all_snps'], dict(action='store_true', help="bi-allelic sites, whatever their prevalence")),
+        (['--all_sites'], dict(action='store_true', help="every site")),
+    ]),
+    ("Species", [
+        (['--min_samples'], dict(type=int, default=1, metavar='INT', help="species found in at least this many samples (1)")),
+        (['--species_id'], dict(metavar='ID[,ID...]', help="only these species")),
+        (['--max_species'], dict(type=int, metavar='INT', help="at most this many species, most prevalent first")),
+    ]),
+    ("Sample filters, per species", [
+        (['--sample_depth'], dict(type=float, default=5.0, metavar='FLOAT', help="minimum mean_coverage of the sample (5.0)")),
+        (['--fract_cov'], dict(type=float, default=0.4, metavar='FLOAT', help="minimum fraction_covered of the sample (0.4)")),
+        (['--max_samples'], dict(type=int, metavar='INT', help="use at most this many samples")),
+        (['--all_samples'], dict(action='store_true', help="no sample filters (sample_depth = fract_cov = 0)")),
+    ]),
+    ("Site filters", [
+        (['--snp_type'], dict(nargs='+', default=['bi'], choices=['any', 'mono', 'bi', 'tri', 'quad'], metavar='TYPE',
+                              help="keep sites with 1/2/3/4 alleles at or above --allele_freq: mono bi tri quad, or any (bi)")),
+        (['--allele_freq'], dict(type=float, default=0.01, metavar='FLOAT', help="pooled frequency at which an allele counts as present (0.01)")),
+        (['--site_depth'], dict(type=int, default=1, metavar='INT', help="a sample passes at a site with at least this depth (1)")),
+        (['--site_ratio'], dict(type=float, default=2.0, metavar='FLOAT', help="... and at most this depth / mean_coverage (2.0)")),
+        (['--site_prev'], dict(type=float, default=0.95, metavar='FLOAT', help="keep sites where at least this fraction of samples passes (0.95)")),
+        (['--max_sites'], dict(type=int, default=float('Inf'), metavar='INT', help="read only the first N sites of every table (all)")),
+    ]),
+]
+
+
+def die(message):
+    sys.exit("\nError: %s\n" % message)
 
 
 def get_program():
-    if len(sys.argv) == 1 or sys.argv[1] in ['-h', '--help']:
-        print('Description: merge MIDAS results across metagenomic samples')
-        print('')
-        print('Usage: merge_midas.py <command> [options]')
-        print('')
-        print('Commands:')
-        print('\tsnps\t perform multi-sample SNP calling and build SNP matrix for each species (MI355X)')
-        print('')
-        print('Note: use merge_midas.py <command> -h to view usage for a specific command')
-        quit()
-    elif sys.argv[1] in ['species', 'genes']:
-        sys.exit("\nError: '%s' is not part of this build (only the snps path is)\n" % sys.argv[1])
-    elif sys.argv[1] != 'snps':
-        sys.exit("\nError: Unrecognized command: '%s'\n" % sys.argv[1])
-    return sys.argv[1]
+    word = sys.argv[1] if len(sys.argv) > 1 else '-h'
+    if word in ('-h', '--help'):
+        print("merge_midas.py <command> [options]\n\n"
+              "  snps   pool the per-sample allele counts of a species, call alleles and SNP types, write the\n"
+              "         freq/depth/info matrices (site arithmetic on the MI355X); `merge_midas.py snps -h` for options\n\n"
+              "species and genes merges are not part of this build.")
+        sys.exit(0)
+    if word in ('species', 'genes'):
+        die("'%s' is not part of this build (only the snps path is)" % word)
+    if word != 'snps':
+        die("Unrecognized command: '%s'" % word)
+    return word
+
+
+def add_snp_presets(args):
+    """--all_samples and the four presets overwrite the individual filters (scripts/merge_midas.py:259-281)."""
+    if args['all_samples']:
+        args['sample_depth'] = args['fract_cov'] = 0.0
+    for flag, pinned in PRESETS:
+        if args[flag]:
+            args.update({k: (list(v) if isinstance(v, list) else v) for k, v in pinned.items()})
+    return args
 
 
 def snps_arguments():
     parser = argparse.ArgumentParser(
-        formatter_class=argparse.RawTextHelpFormatter, usage=argparse.SUPPRESS,
-        description="""
-Description: perform multi-sample core-genome SNP calling
-
-Usage: merge_midas.py snps <outdir> [options]
-""",
-        epilog="""Examples:
-1) Call SNPs for all species. Provide list of paths to sample directories:
-merge_midas.py snps /path/to/outdir -i sample_1,sample_2 -t list
-
-2) Merge results for all sites in the core genome, including those that aren't SNPs:
-merge_midas.py snps /path/to/outdir -i /path/to/samples -t dir --core_sites
-""")
+        prog='merge_midas.py snps', formatter_class=argparse.RawTextHelpFormatter,
+        description="Multi-sample SNP calling over the core genome of each species.",
+        epilog="examples:\n"
+               "  merge_midas.py snps OUT -i sample_1,sample_2 -t list\n"
+               "  merge_midas.py snps OUT -i /path/to/samples -t dir --core_sites")
     parser.add_argument('program', help=argparse.SUPPRESS)
-    parser.add_argument('outdir', type=str, help="Directory for output files. \nA subdirectory will be created for each species_id")
-    parser.add_argument('--threads', type=int, default=1, metavar='INT', help="Number of CPUs to use (1)")
-    io = parser.add_argument_group('Input/Output')
-    io.add_argument('-i', type=str, dest='input', required=True, help="Input to sample directories output by run_midas.py; see '-t' for details")
-    io.add_argument('-t', choices=['list', 'file', 'dir'], dest='intype', required=True, metavar="INPUT_TYPE",
-                    help="list: comma-separated list; dir: directory containing all samples; file: file of paths")
-    io.add_argument('-d', type=str, dest='db', default=os.environ['MIDAS_DB'] if 'MIDAS_DB' in os.environ else None,
-                    help="Path to reference database (default: MIDAS_DB)")
-    snps = parser.add_argument_group("Presets")
-    snps.add_argument('--core_snps', action='store_true', help="Same as: --snp_type bi --site_depth 1 --site_ratio 2.0 --site_prev 0.95 (default)")
-    snps.add_argument('--core_sites', action='store_true', help="Same as: --snp_type any --site_depth 1 --site_ratio 2.0 --site_prev 0.95")
-    snps.add_argument('--all_snps', action='store_true', help="Same as: --snp_type bi --site_prev 0.0")
-    snps.add_argument('--all_sites', action='store_true', help="Same as: --snp_type any --site_prev 0.0")
-    species = parser.add_argument_group("Species filters (select subset of species from INPUT)")
-    species.add_argument('--min_samples', type=int, default=1, metavar='INT', help="All species with >= MIN_SAMPLES (1)")
-    species.add_argument('--species_id', dest='species_id', type=str, metavar='CHAR', help="Comma-separated list of species ids")
-    species.add_argument('--max_species', type=int, metavar='INT', help="Maximum number of species to call SNPs for")
-    sample = parser.add_argument_group("Sample filters (select subset of samples from INPUT)")
-    sample.add_argument('--sample_depth', dest='sample_depth', type=float, default=5.0, metavar='FLOAT', help="Minimum average read depth per sample (5.0)")
-    sample.add_argument('--fract_cov', dest='fract_cov', type=float, default=0.4, metavar='FLOAT', help="Fraction of reference sites covered by at least 1 read (0.4)")
-    sample.add_argument('--max_samples', type=int, metavar='INT', help="Maximum number of samples to process")
-    sample.add_argument('--all_samples', default=False, action='store_true', help="Include all samples in output")
-    snps = parser.add_argument_group("Site filters (select subset of genomic sites from INPUT)")
-    snps.add_argument('--snp_type', choices=['any', 'mono', 'bi', 'tri', 'quad'], nargs='+', default=['bi'], metavar="",
-                      help="mono/bi/tri/quad: keep sites with 1/2/3/4 alleles > ALLELE_FREQ; any: keep regardless")
-    snps.add_argument('--allele_freq', type=float, default=0.01, metavar='FLOAT', help="Minimum frequency for calling an allele present (0.01)")
-    snps.add_argument('--site_depth', type=int, default=1, metavar='INT', help="Minimum number of reads mapped to genomic site (1)")
-    snps.add_argument('--site_ratio', type=float, default=2.0, metavar='FLOAT', help="Maximum ratio of site depth to genome depth (2.0)")
-    snps.add_argument('--site_prev', type=float, default=0.95, metavar='FLOAT', help="Minimum fraction of samples where the site passes (0.95)")
-    snps.add_argument('--max_sites', type=int, default=float('Inf'), metavar='INT', help="Maximum number of sites to include in output (use all)")
-    args = vars(parser.parse_args())
-    return add_snp_presets(args)
-
-
-def add_snp_presets(args):
-    """scripts/merge_midas.py:259-281"""
-    if args['all_samples']:
-        args['sample_depth'] = 0.0
-        args['fract_cov'] = 0.0
-    if args['all_sites']:
-        args['site_prev'] = 0.0
-        args['snp_type'] = ['any']
-    if args['all_snps']:
-        args['site_prev'] = 0.0
-        args['snp_type'] = ['bi']
-    if args['core_sites']:
-        args['site_depth'] = 1
-        args['site_ratio'] = 2.0
-        args['site_prev'] = 0.95
-        args['snp_type'] = ['any']
-    if args['core_snps']:
-        args['site_depth'] = 1
-        args['site_ratio'] = 2.0
-        args['site_prev'] = 0.95
-        args['snp_type'] = ['bi']
-    return args
+    parser.add_argument('outdir', help="output directory; one sub-directory per species")
+    parser.add_argument('--threads', type=int, default=1, metavar='INT', help="CPU threads for reading and writing tables (1)")
+    for title, options in OPTION_GROUPS:
+        group = parser.add_argument_group(title)
+        for flags, kw in options:
+            group.add_argument(*flags, **kw)
+    return add_snp_presets(vars(parser.parse_args()))
 
 
 def check_arguments(args):
-    """scripts/merge_midas.py:283-332 (the parts that apply to snps)"""
-    if not os.path.isdir(args['outdir']):
-        os.makedirs(args['outdir'], exist_ok=True)
+    """scripts/merge_midas.py:283-332, the parts that apply to snps."""
+    os.makedirs(args['outdir'], exist_ok=True)
     if args['db'] is None:
-        sys.exit("\nError: No reference database specified\nUse the flag -d to specify a database,\nOr set the MIDAS_DB environmental variable: export MIDAS_DB=/path/to/midas/db\n")
+        die("No reference database specified\nUse the flag -d to specify a database,\n"
+            "Or set the MIDAS_DB environmental variable: export MIDAS_DB=/path/to/midas/db")
     if not os.path.isdir(args['db']):
-        sys.exit("\nError: Specified reference database does not exist: %s\n" % args['db'])
-    if args['intype'] == 'dir':
-        if not os.path.isdir(args['input']):
-            sys.exit("\nError: Specified input directory '%s' does not exist\n" % args['input'])
-        args['indirs'] = [os.path.join(args['input'], d) for d in sorted(os.listdir(args['input']))]
-    elif args['intype'] == 'file':
-        if not os.path.isfile(args['input']):
-            sys.exit("\nError: Specified input file '%s' does not exist\n" % args['input'])
-        args['indirs'] = [line.rstrip().rstrip('/') for line in open(args['input']) if line.strip()]
+        die("Specified reference database does not exist: %s" % args['db'])
+    kind, source = args['intype'], args['input']
+    if kind == 'dir':
+        if not os.path.isdir(source):
+            die("Specified input directory '%s' does not exist" % source)
+        args['indirs'] = [os.path.join(source, d) for d in sorted(os.listdir(source))]
+    elif kind == 'file':
+        if not os.path.isfile(source):
+            die("Specified input file '%s' does not exist" % source)
+        with open(source) as handle:
+            args['indirs'] = [line.strip().rstrip('/') for line in handle if line.strip()]
     else:
-        args['indirs'] = args['input'].split(',')
+        args['indirs'] = source.split(',')
     for d in args['indirs']:
         if not os.path.isdir(d):
-            sys.exit("\nError: Specified input directory '%s' does not exist\n" % d)
+            die("Specified input directory '%s' does not exist" % d)
     if args['site_depth'] < 0:
-        sys.exit("\nError: --site_depth must be >=0\n")
-    if args['allele_freq'] <= 0.0 or args['allele_freq'] >= 0.5:
-        sys.exit("\nError: --allele_freq must be > 0.0 and < 0.5\n")
-    if args['site_prev'] < 0 or args['site_prev'] > 1:
-        sys.exit("\nError: --site_prev must be between 0 and 1\n")
+        die("--site_depth must be >=0")
+    if not 0.0 < args['allele_freq'] < 0.5:
+        die("--allele_freq must be > 0.0 and < 0.5")
+    if not 0 <= args['site_prev'] <= 1:
+        die("--site_prev must be between 0 and 1")
     if args['max_sites'] != float('Inf') and args['max_sites'] < 0:
-        sys.exit("\nError: --max_sites must be >= 0\n")
+        die("--max_sites must be >= 0")
 
 
 if __name__ == '__main__':
-    program = get_program()
+    get_program()
     args = snps_arguments()
     check_arguments(args)
     from midas_amd.merge import snps

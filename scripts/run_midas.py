@@ -1,12 +1,14 @@
 #!/usr/bin/env python
-"""run_midas.py -- the `snps` command of MIDAS on MI355X.
+"""run_midas.py snps -- per-sample pileup + allele counting on MI355X.
 
-Keeps the reference's command-line surface for `run_midas.py snps` (scripts/run_midas.py:338-430 argument
-set, :556-628 checks, :195-202 directory layout, :432-481 parameter block, :701-745 readme) so that it is
-a drop-in for that path.  `species` and `genes` are different pipelines and are not part of this build.
+Drop-in for the `snps` command of the reference's scripts/run_midas.py: same positional arguments, option
+names, defaults and output layout (<outdir>/snps/{output/<species>.snps.gz, species.txt, summary.txt, log.txt,
+readme.txt, temp/}), so existing command lines keep working.  What the options mean is the reference's
+(scripts/run_midas.py:338-430); how this file is written is not.  `species` and `genes` are other pipelines and
+are not part of this build.
 
-Multi-GPU: launch under torch.distributed.run, one process per GPU; species are sharded over the ranks,
-every rank writes the <species>.snps.gz files it owns and rank 0 writes summary.txt.
+Multi-GPU: start it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1`; species
+are dealt to the ranks, each rank writes the tables of its species, rank 0 writes summary.txt.
 """
 
 import argparse
@@ -14,341 +16,201 @@ import os
 import platform
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 
 from midas_amd import utility  # noqa: E402
 
+RANK = int(os.environ.get('RANK', '0'))
+
+# (group title, [(flags, argparse keywords)])
+OPTION_GROUPS = [
+    ("Stages (any subset; none given = all three)", [
+        (['--build_db'], dict(action='store_true', help="concatenate the representative genomes and index them with bowtie2-build")),
+        (['--align'], dict(action='store_true', help="map the reads with bowtie2 | samtools view | samtools sort")),
+        (['--pileup'], dict(action='store_true', dest='call', help="count A/C/G/T per genomic site (this is the GPU stage)")),
+    ]),
+    ("Which species (for --build_db)", [
+        (['-d'], dict(dest='db', default=os.environ.get('MIDAS_DB'), help="MIDAS reference database (default: $MIDAS_DB)")),
+        (['--species_cov'], dict(type=float, metavar='FLOAT', help="species whose genome coverage exceeds this (3.0); needs `run_midas.py species` output")),
+        (['--species_topn'], dict(type=int, metavar='INT', help="the N most abundant species; needs `run_midas.py species` output")),
+        (['--species_id'], dict(metavar='ID[,ID...]', help="these species, comma separated")),
+    ]),
+    ("Reads and aligner (for --align)", [
+        (['-1'], dict(dest='m1', help="FASTA/FASTQ of unpaired reads or of the first mates (.gz / .bz2 accepted)")),
+        (['-2'], dict(dest='m2', help="FASTA/FASTQ of the second mates")),
+        (['--interleaved'], dict(action='store_true', help="-1 holds both mates, interleaved")),
+        (['-s'], dict(dest='speed', default='very-sensitive', choices=['very-fast', 'fast', 'sensitive', 'very-sensitive'],
+                      help="bowtie2 preset (very-sensitive)")),
+        (['-n'], dict(dest='max_reads', type=int, help="use only the first N reads (all)")),
+        (['-m'], dict(dest='mode', default='global', choices=['local', 'global'], help="end-to-end or local alignment (global)")),
+        (['-t'], dict(dest='threads', default=1, help="CPU threads for the aligner and the table writer (1)")),
+    ]),
+    ("Read and base filters (for --pileup)", [
+        (['--mapid'], dict(type=float, default=94.0, metavar='FLOAT', help="drop reads below this percent identity (94.0)")),
+        (['--mapq'], dict(type=int, default=20, metavar='INT', help="drop reads below this mapping quality (20)")),
+        (['--baseq'], dict(type=int, default=30, metavar='INT', help="ignore bases below this quality (30)")),
+        (['--readq'], dict(type=int, default=20, metavar='INT', help="drop reads whose mean quality is below this (20)")),
+        (['--aln_cov'], dict(type=float, default=0.75, metavar='FLOAT', help="drop reads aligned over less than this fraction of their length (0.75)")),
+        (['--trim'], dict(type=int, default=0, metavar='INT', help="bases trimmed off the 3' end before alignment (0)")),
+        (['--discard'], dict(action='store_true', help="accepted for compatibility; has no effect (as in the reference)")),
+        (['--baq'], dict(action='store_true', help="accepted for compatibility; has no effect (as in the reference)")),
+        (['--adjust_mq'], dict(action='store_true', help="accepted for compatibility; has no effect (as in the reference)")),
+    ]),
+]
+
+
+def die(message):
+    sys.exit("\nError: %s\n" % message)
+
 
 def get_program():
-    """Get program specified by user (species, genes, or snps) -- scripts/run_midas.py:10-28"""
-    if len(sys.argv) == 1 or sys.argv[1] in ['-h', '--help']:
-        print('Description: Estimate species abundance and intra-species genomic variation from an individual metagenome')
-        print('')
-        print('Usage: run_midas.py <command> [options]')
-        print('')
-        print('Commands:')
-        print('\tsnps\t quantify single nucleotide variation in abundant species (MI355X pileup)')
-        print('')
-        print('Note: use run_midas.py <command> -h to view usage for a specific command')
-        print('      (species / genes belong to the reference implementation; this build accelerates snps only)')
-        quit()
-    elif sys.argv[1] in ['species', 'genes']:
-        sys.exit("\nError: '%s' is not part of this build (only the snps pileup path is)\n" % sys.argv[1])
-    elif sys.argv[1] != 'snps':
-        sys.exit("\nError: Unrecognized command: '%s'\n" % sys.argv[1])
-    else:
-        return sys.argv[1]
+    """First positional word: only `snps` exists here."""
+    word = sys.argv[1] if len(sys.argv) > 1 else '-h'
+    if word in ('-h', '--help'):
+        print("run_midas.py <command> [options]\n\n"
+              "  snps   count alleles at every site of the representative genomes of a sample's abundant species\n"
+              "         (pileup on the MI355X); `run_midas.py snps -h` lists the options\n\n"
+              "species and genes are not part of this build.")
+        sys.exit(0)
+    if word in ('species', 'genes'):
+        die("'%s' is not part of this build (only the snps path is)" % word)
+    if word != 'snps':
+        die("Unrecognized command: '%s'" % word)
+    return word
 
 
-def open_log(program, args):
-    """scripts/run_midas.py:30-33 (rank 0 owns log.txt; other ranks write to the null device)"""
-    logpath = '%s/%s/%s' % (args['outdir'], program, 'log.txt')
-    if int(os.environ.get('RANK', '0')) == 0:
-        args['log'] = open(logpath, 'w')
-    else:
-        args['log'] = open(os.devnull, 'w')
-
-
-def add_executables(args):
-    """The aligner stage shells out exactly as the reference does (midas/utility.py:109-150), but the tools are
-    looked up on PATH: no binaries ship with this build.  Missing tools only matter for --build_db / --align."""
-    args['bowtie2-build'] = utility.find_executable('bowtie2-build')
-    args['bowtie2'] = utility.find_executable('bowtie2')
-    args['samtools'] = utility.find_executable('samtools')
-
-
-def snp_arguments():
+def build_parser():
     parser = argparse.ArgumentParser(
-        formatter_class=argparse.RawTextHelpFormatter,
-        usage=argparse.SUPPRESS,
-        description="""
-Description: Map metagenomic reads to a bacterial genome database and quantify nucleotide variation
-
-The pipeline can be broken down into the following steps:
-  1) build a database of genome sequences for abundant bacterial species (1 representative genome/species)
-  2) use global alignment to map high-quality reads to the database
-  3) generate pileups and count variants at each genomic site   <- runs on the MI355X
-
-After completion, use 'merge_midas.py snps' to perform multisample SNP calling
-
-Usage: run_midas.py snps <outdir> [options]
-""",
-        epilog="""Examples:
-1) run entire pipeline using defaults:
-run_midas.py snps /path/to/outdir -1 /path/to/reads_1.fq.gz -2 /path/to/reads_2.fq.gz
-
-2) run entire pipeline for a specific species:
-run_midas.py snps /path/to/outdir --species_id Bacteroides_vulgatus_57955 -1 /path/to/reads_1.fq.gz -2 /path/to/reads_2.fq.gz
-
-3) just count variants, keep reads with >=95% alignment identity and keep bases with quality-scores >=35:
-run_midas.py snps /path/to/outdir --pileup --mapid 95 --baseq 35
-
-4) count variants on 8 GPUs (species sharded over ranks):
-python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_midas.py snps /path/to/outdir --pileup
-""")
+        prog='run_midas.py snps', formatter_class=argparse.RawTextHelpFormatter,
+        description="Map a metagenome to the representative genomes of its abundant species and count the four alleles\n"
+                    "at every genomic site.  Stages: --build_db, --align, --pileup (the last one runs on the GPU).\n"
+                    "Afterwards: merge_midas.py snps.",
+        epilog="examples:\n"
+               "  run_midas.py snps OUT -1 reads_1.fq.gz -2 reads_2.fq.gz\n"
+               "  run_midas.py snps OUT --pileup --mapid 95 --baseq 35\n"
+               "  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_midas.py snps OUT --pileup")
     parser.add_argument('program', help=argparse.SUPPRESS)
-    parser.add_argument('outdir', type=str,
-        help="""Path to directory to store results.
-Directory name should correspond to sample identifier""")
-    parser.add_argument('--remove_temp', default=False, action='store_true',
-        help="""Remove intermediate files generated by MIDAS (False).\nUseful to reduce disk space of MIDAS output""")
-    pipe = parser.add_argument_group('Pipeline options (choose one or more; default=all)')
-    pipe.add_argument('--build_db', action='store_true', dest='build_db',
-        default=False, help='Build bowtie2 database of pangenomes')
-    pipe.add_argument('--align', action='store_true', dest='align',
-        default=False, help='Align reads to pangenome database')
-    pipe.add_argument('--pileup', action='store_true', dest='call',
-        default=False, help='Count 4 alleles across genome (GPU pileup)')
-    db = parser.add_argument_group('Database options (if using --build_db)')
-    db.add_argument('-d', type=str, dest='db', default=os.environ['MIDAS_DB'] if 'MIDAS_DB' in os.environ else None,
-        help="""Path to reference database
-By default, the MIDAS_DB environmental variable is used""")
-    db.add_argument('--species_cov', type=float, dest='species_cov', metavar='FLOAT', help='Include species with >X coverage (3.0)')
-    db.add_argument('--species_topn', type=int, dest='species_topn', metavar='INT', help='Include top N most abundant species')
-    db.add_argument('--species_id', type=str, dest='species_id', metavar='CHAR', help='Include specified species. Separate ids with a comma')
-    align = parser.add_argument_group('Read alignment options (if using --align)')
-    align.add_argument('-1', type=str, dest='m1',
-        help="""FASTA/FASTQ file containing 1st mate if using paired-end reads.
-Otherwise FASTA/FASTQ containing unpaired reads.
-Can be gzip'ed (extension: .gz) or bzip2'ed (extension: .bz2)""")
-    align.add_argument('-2', type=str, dest='m2',
-        help="""FASTA/FASTQ file containing 2nd mate if using paired-end reads.
-Can be gzip'ed (extension: .gz) or bzip2'ed (extension: .bz2)""")
-    align.add_argument('--interleaved', action='store_true', default=False,
-        help='FASTA/FASTQ file in -1 are paired and contain forward AND reverse reads')
-    align.add_argument('-s', type=str, dest='speed', default='very-sensitive',
-        choices=['very-fast', 'fast', 'sensitive', 'very-sensitive'],
-        help='Bowtie2 alignment speed/sensitivity (very-sensitive)')
-    align.add_argument('-n', type=int, dest='max_reads', help='# reads to use from input file(s) (use all)')
-    align.add_argument('-m', type=str, dest='mode', default='global',
-        choices=['local', 'global'],
-        help='Global/local read alignment (global)')
-    align.add_argument('-t', dest='threads', default=1,
-        help='Number of threads to use (1)')
-    snps = parser.add_argument_group('Pileup options (if using --pileup)')
-    snps.add_argument('--mapid', type=float, metavar='FLOAT',
-        default=94.0, help='Discard reads with alignment identity < MAPID (94.0)')
-    snps.add_argument('--mapq', type=int, metavar='INT',
-        default=20, help='Discard reads with mapping quality < MAPQ (20)')
-    snps.add_argument('--baseq', type=int, metavar='INT',
-        default=30, help='Discard bases with quality < BASEQ (30)')
-    snps.add_argument('--readq', type=int, metavar='INT',
-        default=20, help='Discard reads with mean quality < READQ (20)')
-    snps.add_argument('--aln_cov', type=float, metavar='FLOAT',
-        default=0.75, help='Discard reads with alignment coverage < ALN_COV (0.75)')
-    snps.add_argument('--trim', metavar='INT', type=int, default=0,
-        help='Trim N base-pairs from 3\'/right end of read (0)')
-    snps.add_argument('--discard', default=False, action='store_true',
-        help='Discard discordant read-pairs (False) [accepted and ignored, as in the reference]')
-    snps.add_argument('--baq', default=False, action='store_true',
-        help='Enable BAQ: per-base alignment quality (False) [accepted and ignored, as in the reference]')
-    snps.add_argument('--adjust_mq', default=False, action='store_true',
-        help='Adjust MAPQ (False) [accepted and ignored, as in the reference]')
-    args = vars(parser.parse_args())
-    if args['species_id']: args['species_id'] = args['species_id'].split(',')
-    return args
+    parser.add_argument('outdir', help="sample directory (its name is the sample id)")
+    parser.add_argument('--remove_temp', action='store_true', help="delete <outdir>/snps/temp when done")
+    for title, options in OPTION_GROUPS:
+        group = parser.add_argument_group(title)
+        for flags, kw in options:
+            group.add_argument(*flags, **kw)
+    return parser
 
 
 def get_arguments(program):
-    args = snp_arguments()
-    add_executables(args)
+    args = vars(build_parser().parse_args())
+    if args['species_id']:
+        args['species_id'] = args['species_id'].split(',')
+    # the aligner stages shell out like the reference does, but to whatever is on PATH: no binaries ship here
+    for tool in ('bowtie2-build', 'bowtie2', 'samtools'):
+        args[tool] = utility.find_executable(tool)
     return args
 
 
-def check_selected_species(args):
-    """scripts/run_midas.py: make sure selected species are valid (have a rep genome in the database)"""
-    if args['species_id']:
-        for species_id in args['species_id']:
-            if not os.path.isdir('%s/rep_genomes/%s' % (args['db'], species_id)):
-                sys.exit("\nError: the specified species_id '%s' was not found in the database\n" % species_id)
-
-
-def check_snps(args):
-    """Check validity of command line arguments -- scripts/run_midas.py:556-628"""
-    if args['m1']: args['file_type'] = utility.auto_detect_file_type(args['m1'])
-    utility.check_database(args)
-    check_selected_species(args)
-    if not os.path.isdir('%s/snps' % args['outdir']):
-        os.makedirs('%s/snps' % args['outdir'], exist_ok=True)
-    if not any([args['build_db'], args['align'], args['call']]):
-        args['build_db'] = True
-        args['align'] = True
-        args['call'] = True
-    if not any([args['species_id'], args['species_topn'], args['species_cov']]):
-        args['species_cov'] = 3.0
-    profile = '%s/species/species_profile.txt' % args['outdir']
-    if not os.path.isfile(profile):
-        if (args['species_topn'] or args['species_cov']) and args['build_db']:
-            sys.exit("\nError: Could not find species abundance profile: %s\n\
-To specify species with --species_topn or --species_cov you must have run: run_midas.py species\n\
-Alternatively, you can manually specify one or more species using --species_id\n" % profile)
-    if (args['align']
-            and not args['build_db']
-            and not os.path.isfile('%s/snps/temp/genomes.fa' % args['outdir'])):
-        error = "\nError: You've specified --align, but no database has been built"
-        error += "\nTry running with --build_db\n"
-        sys.exit(error)
-    if (args['call']
-            and not args['align']
-            and not os.path.isfile('%s/snps/temp/genomes.bam' % args['outdir'])):
-        error = "\nError: You've specified --pileup, but no alignments were found"
-        error += "\nTry running with --align\n"
-        sys.exit(error)
-    if (args['call']
-            and not args['build_db']
-            and not os.path.isfile('%s/snps/temp/genomes.fa' % args['outdir'])):
-        error = "\nError: You've specified --pileup, but the no genome database was found"
-        error += "\nTry running with --build_db\n"
-        sys.exit(error)
-    if args['align'] and not args['m1']:
-        sys.exit("\nError: To align reads, you must specify path to input FASTA/FASTQ\n")
-    for arg in ['m1', 'm2']:
-        if args[arg] and not os.path.isfile(args[arg]):
-            sys.exit("\nError: Input file does not exist: '%s'\n" % args[arg])
-    if args['m1']: utility.check_compression(args['m1'])
-    if args['m2']: utility.check_compression(args['m2'])
-    if args['m2'] and not args['m1']:
-        sys.exit("\nError: Must specify -1 and -2 if aligning paired end reads\n")
-    if args['m2'] and args['interleaved']:
-        sys.exit("\nError: Cannot specify --interleaved together with -2\n")
-    if args['mapid'] < 1 or args['mapid'] > 100:
-        sys.exit("\nError: MAPQ must be between 1 and 100\n")
-    if args['mapq'] < 0 or args['mapq'] > 100:
-        sys.exit("\nError: MAPQ must be between 0 and 100\n")
-    if args['baseq'] < 0 or args['baseq'] > 100:
-        sys.exit("\nError: BASEQ must be between 0 and 100\n")
-    if args['aln_cov'] < 0 or args['aln_cov'] > 1:
-        sys.exit("\nError: ALN_COV must be between 0 and 1\n")
-
-
 def check_arguments(program, args):
-    check_snps(args)
-    if platform.system() not in ['Linux', 'Darwin']:
-        sys.exit("\nError: Operating system '%s' not supported\n" % platform.system())
+    """The reference's sanity checks for snps (scripts/run_midas.py:556-628): same conditions, same exits."""
+    if platform.system() not in ('Linux', 'Darwin'):
+        die("Operating system '%s' not supported" % platform.system())
+    if args['m1']:
+        args['file_type'] = utility.auto_detect_file_type(args['m1'])
+    utility.check_database(args)
+    for sp in args['species_id'] or []:
+        if not os.path.isdir(os.path.join(args['db'], 'rep_genomes', sp)):
+            die("the specified species_id '%s' was not found in the database" % sp)
+    os.makedirs(os.path.join(args['outdir'], 'snps'), exist_ok=True)
+    if not (args['build_db'] or args['align'] or args['call']):
+        args['build_db'] = args['align'] = args['call'] = True
+    if not (args['species_id'] or args['species_topn'] or args['species_cov']):
+        args['species_cov'] = 3.0
+    temp = os.path.join(args['outdir'], 'snps', 'temp')
+    profile = os.path.join(args['outdir'], 'species', 'species_profile.txt')
+    if args['build_db'] and (args['species_topn'] or args['species_cov']) and not os.path.isfile(profile):
+        die("Could not find species abundance profile: %s\n"
+            "--species_topn / --species_cov need the output of `run_midas.py species`; use --species_id otherwise" % profile)
+    have_fa, have_bam = (os.path.isfile(os.path.join(temp, f)) for f in ('genomes.fa', 'genomes.bam'))
+    if args['align'] and not args['build_db'] and not have_fa:
+        die("You've specified --align, but no database has been built\nTry running with --build_db")
+    if args['call'] and not args['align'] and not have_bam:
+        die("You've specified --pileup, but no alignments were found\nTry running with --align")
+    if args['call'] and not args['build_db'] and not have_fa:
+        die("You've specified --pileup, but no genome database was found\nTry running with --build_db")
+    if args['align'] and not args['m1']:
+        die("To align reads, you must specify path to input FASTA/FASTQ")
+    if args['m2'] and not args['m1']:
+        die("Must specify -1 and -2 if aligning paired end reads")
+    if args['m2'] and args['interleaved']:
+        die("Cannot specify --interleaved together with -2")
+    for key in ('m1', 'm2'):
+        if args[key]:
+            if not os.path.isfile(args[key]):
+                die("Input file does not exist: '%s'" % args[key])
+            utility.check_compression(args[key])
+    for key, lo, hi in (('mapid', 1, 100), ('mapq', 0, 100), ('baseq', 0, 100), ('aln_cov', 0, 1)):
+        if not lo <= args[key] <= hi:
+            die("%s must be between %s and %s" % (key.upper(), lo, hi))
 
 
 def create_directories(program, args):
-    """scripts/run_midas.py:195-202"""
-    dirs = [args['outdir']]
-    dirs.append('%s/%s' % (args['outdir'], program))
-    dirs.append('%s/%s/%s' % (args['outdir'], program, 'output'))
-    dirs.append('%s/%s/%s' % (args['outdir'], program, 'temp'))
-    for dir in dirs:
-        if not os.path.isdir(dir): os.makedirs(dir, exist_ok=True)
+    for sub in ('', 'output', 'temp'):
+        os.makedirs(os.path.join(args['outdir'], program, sub), exist_ok=True)
 
 
-def print_snp_arguments(args):
-    """scripts/run_midas.py:432-481"""
-    lines = []
-    lines.append("===========Parameters===========")
-    lines.append("Command: %s" % ' '.join(sys.argv))
-    lines.append("Script: run_midas.py snps")
-    lines.append("Database: %s" % args['db'])
-    lines.append("Output directory: %s" % args['outdir'])
-    lines.append("Remove temporary files: %s" % args['remove_temp'])
-    lines.append("Pipeline options:")
+def open_log(program, args):
+    """Rank 0 owns log.txt; the other ranks log to the null device."""
+    args['log'] = open(os.path.join(args['outdir'], program, 'log.txt') if RANK == 0 else os.devnull, 'w')
+
+
+def print_arguments(program, args):
+    stages = [name for name, on in (('build_db', args['build_db']), ('align', args['align']), ('pileup', args['call'])) if on]
+    shown = [('command', ' '.join(sys.argv)), ('database', args['db']), ('output directory', args['outdir']),
+             ('stages', ', '.join(stages)), ('remove temp', args['remove_temp'])]
     if args['build_db']:
-        lines.append("  build bowtie2 database of genomes")
+        shown += [('species_id', args['species_id']), ('species_topn', args['species_topn']), ('species_cov', args['species_cov'])]
     if args['align']:
-        lines.append("  align reads to bowtie2 genome database")
+        shown += [('reads', ' '.join(x for x in (args['m1'], args['m2']) if x) + (' (interleaved)' if args['interleaved'] else '')),
+                  ('bowtie2', '--%s%s' % (args['speed'], '-local' if args['mode'] == 'local' else '')),
+                  ('max reads', args['max_reads'] or 'all'), ('threads', args['threads'])]
     if args['call']:
-        lines.append("  use the MI355X pileup to count variants")
-    if args['build_db']:
-        lines.append("Database options:")
-        if args['species_topn']:
-            lines.append("  include top %s most abundant species" % args['species_topn'])
-        if args['species_cov']:
-            lines.append("  include all species with >=%sX genome coverage" % args['species_cov'])
-        if args['species_id']:
-            lines.append("  include specified species id(s): %s" % args['species_id'])
-    if args['align']:
-        lines.append("Read alignment options:")
-        if args['interleaved']:
-            lines.append("  input reads (1st + 2nd mate): %s" % args['m1'])
-        elif args['m2']:
-            lines.append("  input reads (1st mate): %s" % args['m1'])
-            lines.append("  input reads (2nd mate): %s" % args['m2'])
-        else:
-            lines.append("  input reads (unpaired): %s" % args['m1'])
-        lines.append("  alignment speed/sensitivity: %s" % args['speed'])
-        lines.append("  alignment mode: %s" % args['mode'])
-        lines.append("  number of reads to use from input: %s" % (args['max_reads'] if args['max_reads'] else 'use all'))
-        lines.append("  number of threads for database search: %s" % args['threads'])
-    if args['call']:
-        lines.append("SNP calling options:")
-        lines.append("  minimum alignment percent identity: %s" % args['mapid'])
-        lines.append("  minimum mapping quality score: %s" % args['mapq'])
-        lines.append("  minimum base quality score: %s" % args['baseq'])
-        lines.append("  minimum read quality score: %s" % args['readq'])
-        lines.append("  minimum alignment coverage of reads: %s" % args['aln_cov'])
-        lines.append("  trim %s base-pairs from 3'/right end of read" % args['trim'])
-        if args['discard']: lines.append("  discard discordant read-pairs")
-        if args['baq']: lines.append("  enable BAQ (per-base alignment quality)")
-        if args['adjust_mq']: lines.append("  adjust MAPQ")
-    lines.append("================================")
-    args['log'].write('\n'.join(lines) + '\n')
-    if int(os.environ.get('RANK', '0')) == 0:
-        sys.stdout.write('\n'.join(lines) + '\n')
+        shown += [(k, args[k]) for k in ('mapid', 'mapq', 'baseq', 'readq', 'aln_cov', 'trim')]
+    text = "=== run_midas.py snps (MI355X pileup) ===\n" + ''.join("%-18s %s\n" % (k + ':', v) for k, v in shown) + "===\n"
+    args['log'].write(text)
+    if RANK == 0:
+        sys.stdout.write(text)
 
 
-def run_program(program, args):
-    """scripts/run_midas.py:72-84"""
-    from midas_amd.run import snps
-    snps.run_pipeline(args)
+README = """run_midas.py snps -- files in this directory
+
+output/<species_id>.snps.gz   one row per site of the species' representative genome, tab separated, gzip:
+                                ref_id      contig id
+                                ref_pos     1-based position on the contig
+                                ref_allele  reference base (upper case)
+                                depth       count_a + count_c + count_g + count_t
+                                count_a/c/g/t  reads supporting each allele at the site
+species.txt                   species whose genomes are in temp/genomes.fa
+summary.txt                   per species: genome_length, covered_bases, fraction_covered, mean_coverage,
+                              aligned_reads, mapped_reads
+log.txt                       parameters and external commands of this run
+temp/                         genomes.fa, bowtie2 index, genomes.bam (deleted by --remove_temp)
+
+Reads counted: identity >= --mapid, mean quality >= --readq, mapping quality >= --mapq, aligned fraction
+>= --aln_cov; bases counted: A/C/G/T with quality >= --baseq.  mean_coverage is over covered sites only.
+Next step: merge_midas.py snps.
+"""
 
 
 def write_readme(program, args):
-    """scripts/run_midas.py:630, 701-745 (snps branch)"""
-    if int(os.environ.get('RANK', '0')) != 0:
-        return
-    outfile = open('%s/%s/readme.txt' % (args['outdir'], program), 'w')
-    outfile.write("""
-Description of output files and file formats from 'run_midas.py snps'
+    if RANK == 0:
+        with open(os.path.join(args['outdir'], program, 'readme.txt'), 'w') as handle:
+            handle.write(README)
 
-Output files
-############
-output
-  directory of per-species output files
-  files are tab-delimited, gzip-compressed, with header
-  naming convention of each file is: {SPECIES_ID}.snps.gz
-species.txt
-  list of species_ids included in local database
-summary.txt
-  tab-delimited with header
-  summarizes alignment results per-species
-log.txt
-  log file containing parameters used
-temp
-  directory of intermediate files
-  run with `--remove_temp` to remove these files
 
-Output formats
-############
-output/{SPECIES_ID}.snps.gz
-  ref_id: id of reference scaffold/contig/genome
-  ref_pos: position in ref_id (1-indexed)
-  ref_allele: reference nucleotide
-  depth: number of mapped reads
-  count_a: count of A allele
-  count_c: count of C allele
-  count_g: count of G allele
-  count_t: count of T allele
-
-summary.txt
-  species_id: species id
-  genome_length: number of base pairs in representative genome
-  covered_bases: number of reference sites with at least 1 mapped read
-  fraction_covered: proportion of reference sites with at least 1 mapped read
-  mean_coverage: average read-depth across reference sites with at least 1 mapped read
-  aligned_reads: number of aligned reads BEFORE quality filtering
-  mapped_reads: number of aligned reads AFTER quality filtering
-
-Additional information for each species can be found in the reference database:
- %s/rep_genomes
-""" % args['db'])
-    outfile.close()
+def run_program(program, args):
+    from midas_amd.run import snps
+    snps.run_pipeline(args)
 
 
 if __name__ == '__main__':
@@ -357,6 +219,6 @@ if __name__ == '__main__':
     check_arguments(program, args)
     create_directories(program, args)
     open_log(program, args)
-    print_snp_arguments(args)
-    run_program(program, args)
+    print_arguments(program, args)
     write_readme(program, args)
+    run_program(program, args)
