@@ -80,28 +80,24 @@ def merge_species(species, args, ctx):
     return n, len(keep), res['kernel_ms']
 
 
+README = """merge_midas.py snps -- files in this directory (species %s)
+
+snps_info.txt     one row per kept site: site_id (row number in the per-sample tables), ref_id, ref_pos, ref_allele,
+                  major_allele, minor_allele (by pooled count over the samples), count_samples (samples that pass the
+                  depth filters at the site), count_a/c/g/t (pooled), locus_type / gene_id / site_type / amino_acids
+                  (annotation from the species' genome.features: CDS, degeneracy 1D-4D, the four possible residues),
+                  snp_type (mono, bi, tri, quad)
+snps_freq.txt     site_id, then per sample the minor-allele frequency minor / (major + minor), 0 when uncovered
+snps_depth.txt    site_id, then per sample the reads on the major + minor allele
+snps_summary.txt  the samples' own summary rows for this species (from run_midas.py snps)
+
+Genome and gene annotation of the species: %s/rep_genomes/%s
+"""
+
+
 def write_snps_readme(args, sp):
-    """midas/merge/snps.py:422-468 (abridged to the file descriptions)"""
-    outfile = open('%s/%s/readme.txt' % (args['outdir'], sp.id), 'w')
-    outfile.write("""
-Description of output files and file formats from 'merge_midas.py snps'
-
-Output files
-############
-snps_freq.txt
-  frequency of minor allele per genomic site and per sample
-snps_depth.txt
-  number of reads mapped to genomic site per sample (major + minor allele)
-snps_info.txt
-  metadata for genomic site: site_id ref_id ref_pos ref_allele major_allele minor_allele count_samples
-  count_a count_c count_g count_t locus_type gene_id snp_type site_type amino_acids
-snps_summary.txt
-  alignment summary statistics per sample
-
-Additional information for species can be found in the reference database:
- %s/rep_genomes/%s
-""" % (args['db'], sp.id))
-    outfile.close()
+    with open('%s/%s/readme.txt' % (args['outdir'], sp.id), 'w') as handle:
+        handle.write(README % (sp.id, args['db'], sp.id))
 
 
 def run_pipeline(args):
