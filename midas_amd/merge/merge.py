@@ -111,3 +111,9 @@ def filter_species(species, args):
 
 def select_species(args, dtype):
     return filter_species(init_species(init_samples(args['indirs'], dtype), args, dtype), args)
+
+
+def species_for_rank(species_list, rank, world_size):
+    """Species are independent units of a merge: rank r of N takes species r, r + N, ... of the (prevalence-sorted)
+    list and writes their output directories itself; no data-path collective is needed."""
+    return [sp for k, sp in enumerate(species_list) if k % world_size == rank]

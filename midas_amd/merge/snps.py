@@ -115,9 +115,7 @@ def run_pipeline(args):
         ctx = abi.Context(int(os.environ.get("LOCAL_RANK", "0")))
     except abi.MidasSnpsError as e:
         sys.exit("\nError: %s\n" % e.message)
-    for k, species in enumerate(species_list):
-        if k % ws != rank:        # species are independent: one rank (GPU) per species, round robin
-            continue
+    for species in merge.species_for_rank(species_list, rank, ws):
         print("  %s" % species.id)
         print("    calling SNPs")
         n, kept, ms = merge_species(species, args, ctx)

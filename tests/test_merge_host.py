@@ -205,3 +205,10 @@ def test_table_reader_foreign_gzip_and_row_limits(tmp_path):
     with pytest.raises(abi.MidasSnpsError) as e:
         abi.read_snps_table(q, 3, False)
     assert "row 3" in e.value.message
+
+
+def test_species_are_dealt_round_robin_to_ranks():
+    sp = ["s%d" % i for i in range(7)]
+    parts = [merge.species_for_rank(sp, r, 3) for r in range(3)]
+    assert parts == [["s0", "s3", "s6"], ["s1", "s4"], ["s2", "s5"]]
+    assert sorted(sum(parts, [])) == sp and merge.species_for_rank(sp, 0, 1) == sp
