@@ -525,7 +525,9 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
     unsigned long long covered = 0, depth_sum = 0;
     {
-      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + tile.site_base;
+      // debug bit 8 (timing experiment only, results wrong): every tile's counts land on the first tile's sites, so
+      // the stores stay in L2 and cost no HBM write bandwidth
+      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((p.debug & 8) ? 0 : tile.site_base);
       uint4* lds4 = reinterpret_cast<uint4*>(lds);
       const int lim = (p.debug & 2) ? 0 : tile_len;
       if constexpr (!SPLIT) {

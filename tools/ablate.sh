@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: pileup kernel time on configs[1] with parts of the kernel switched off (MIDAS_SNPS_DEBUG bits:
-# 1 = no LDS tallies, 2 = no tile write-out, 4 = no per-base work at all).  Results are WRONG for bits != 0.
+# 1 = no LDS tallies, 2 = no tile write-out, 4 = no per-base work at all, 8 = write-out lands on the first tile only,
+# i.e. stays in L2).  Results are WRONG for bits != 0.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 for D in ${*:-0 1 4 2 6 7}; do
   echo -n "debug=$D grid=${GRID:-512} "
