@@ -48,7 +48,8 @@ def make_reference(rng, n_contigs: int, contig_len: int, n_frac: float = 1e-4, l
 
 def make_dataset(n_species: int = 1, contigs_per_species: int = 4, contig_len: int = 20000,
                  n_reads: int = 2000, read_len: int = 150, seed: int = BASE_SEED,
-                 var_len: bool = False, chunk: int = 1 << 17, lowercase_frac: float = 0.0):
+                 var_len: bool = False, chunk: int = 1 << 17, lowercase_frac: float = 0.0,
+                 plain_only: bool = False):
     """-> (ContigTable, ReadsSoA).  Contig ids are '<species>_c<k>' (k unpadded, so Python's
     sorted() order differs from table order, as the reference's emit loop must be fed)."""
     rng = np.random.default_rng(seed)
@@ -78,6 +79,8 @@ def make_dataset(n_species: int = 1, contigs_per_species: int = 4, contig_len: i
     kind[(u >= 0.025) & (u < 0.05)] = 2
     kind[(u >= 0.05) & (u < 0.075)] = 3
     kind[(u >= 0.075) & (u < 0.10)] = 4
+    if plain_only:          # every read a single full-length match (kernel fast path only; developer measurements)
+        kind[:] = 0
     lens = np.full(n_reads, L, dtype=np.int32)
     if var_len:
         trim = rng.random(n_reads) < 0.3

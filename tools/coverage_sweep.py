@@ -12,6 +12,8 @@ def main():
     for cov in covs:
         cfg = dict(base)
         cfg['n_reads'] = int(round(base['n_reads'] * cov / 10.0))
+        if os.environ.get('PLAIN_ONLY'):
+            cfg['plain_only'] = True
         contigs, reads = synth.make_dataset(**cfg)
         b = ctx.batch(contigs, reads)
         b.enable_timing(1)
