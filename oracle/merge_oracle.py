@@ -2,11 +2,15 @@
 
 TEST INFRASTRUCTURE ONLY -- never imported from midas_amd/ or scripts/.
 
-PARITY UNPINNED by reference fixtures: the reference's tests hold no values for this path (test/test_midas.py:116-120
-asserts an exit code only).  The arithmetic in the reference is plain Python, so it is restated here function by
-function (each cites the lines of /root/reference/midas/merge/snps.py or midas/utility.py it follows) with the same
-operations in the same order -- float division, `sorted(..., reverse=True)` stability, '{0:.3g}' formatting -- and
-pinned by the hand-derived cases of tests/test_merge_oracle.py.  Bio.SeqIO is not needed: genes arrive as dicts.
+PINNED AGAINST THE REFERENCE ITSELF: the reference's tests hold no values for this path (test/test_midas.py:116-120
+asserts an exit code only), but its arithmetic is plain Python, so tests/golden/make_merge_vectors.py executes the
+reference's own GenomicSite class and codon helpers (in the build container, from /root/reference) on seeded inputs
+and commits inputs + outputs as tests/golden/merge_vectors.json (4 800 site evaluations: every snp_type / flag /
+annotation branch, floats compared bit for bit, the three output texts byte for byte); tests/test_merge_golden.py
+holds this oracle, the product's annotation code and -- on the GPU box -- midas_merge_sites to those vectors.  Hand
+derived cases (tests/test_merge_oracle.py) cover the corner semantics by reasoning.  The restatement below keeps the
+reference's operations in the reference's order (float division, stable `sorted(..., reverse=True)`, '{0:.3g}'); each
+function cites the lines of /root/reference/midas/merge/snps.py or midas/utility.py it follows.
 """
 
 ALLELES = 'ACGT'
