@@ -4,14 +4,22 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``midas_amd/`` may import this module:
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg use it, and only as the checker.
 
-PARITY UNPINNED.  The arithmetic of this path lives in a third-party dependency
-that is absent from /root/reference and from this image: ``pysam >= 0.8.1``
-(unpinned: reference ``setup.py:15``), i.e. ``AlignmentFile.count_coverage`` and
-the ``AlignedSegment`` accessors, wrapping htslib.  The reference's own tests
-(``test/test_midas.py:98-102``) assert exit codes only, so there is no golden
-vector to pin against.  This file therefore *restates* the published pysam /
-SAM-spec semantics at the reference's call sites and is itself checked against
-hand-derived known-answer cases (``tests/golden/kat_cases.json``).
+PARITY UNPINNED for pysam, PINNED for the reference's own code.  The per-base
+arithmetic of this path lives in a third-party dependency that is absent from
+/root/reference and from this image: ``pysam >= 0.8.1`` (unpinned: reference
+``setup.py:15``), i.e. ``AlignmentFile.count_coverage`` and the
+``AlignedSegment`` accessors, wrapping htslib.  The reference's own tests
+(``test/test_midas.py:98-102``) assert exit codes only, so nothing pins pysam's
+behaviour: the [EXT] functions below *restate* the published pysam / SAM-spec
+semantics at the reference's call sites and are checked against hand-derived
+known-answer cases (``tests/golden/kat_cases.json``).  Everything the
+reference's OWN code decides around that one pysam call IS pinned against the
+reference itself: ``tests/golden/make_keep_read_vectors.py`` and
+``make_emit_vectors.py`` execute the reference's ``keep_read``,
+``species_pileup`` and ``snps_summary`` (text taken from /root/reference at
+generation time, in the build container) and commit inputs + outputs as data;
+``tests/test_keep_read_golden.py`` and ``test_emit_golden.py`` hold this oracle
+-- and, on the GPU box, the product through the C-ABI -- to them.
 
 What is restated, and from where (paths relative to /root/reference):
 
