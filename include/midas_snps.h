@@ -203,14 +203,15 @@ int32_t midas_snps_batch_timing(midas_snps_batch* batch, int32_t slot, float out
 int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_device_i64);
 
 /* ---- host-only helpers (no GPU needed) -------------------------------------
- * The packer that batch_create() runs, exposed so that CPU-only tests can check
- * the device layout: returns the number of payload bytes via *out_blob_bytes; if
- * rec16/blob are non-NULL they receive (n_reads+1)*16 bytes of records (the last one a sentinel
- * holding the end of the payload) and the payload itself.  `contigs` may be NULL (then the
- * "CIGAR reaches past SEQ inside the contig" record flag is computed against unbounded contigs). */
+ * The packer that batch_create() runs, exposed so that CPU-only tests can check the device layout.  A read whose
+ * CIGAR is clips at the ends around M/=/X/I/D/N ops becomes one device record per gap-free match segment; any other
+ * read becomes one record that keeps its CIGAR.  *out_blob_bytes and *out_n_records always receive the payload size
+ * and the record count; if rec16/blob are non-NULL they receive (n_records+1)*16 bytes of records (the last one a
+ * sentinel holding the end of the payload) and the payload itself.  `contigs` may be NULL (then the "CIGAR reaches
+ * past SEQ inside the contig" record flag is computed against unbounded contigs).                                   */
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs,
                               void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
-                              int32_t* out_max_l_seq, char* err256);
+                              int64_t* out_n_records, int32_t* out_max_l_seq, char* err256);
 
 /* ---- host I/O (no GPU needed) ------------------------------------------------
  * BAM decode.  Replaces `pysam.AlignmentFile(bampath, 'rb')` and htslib's record decode

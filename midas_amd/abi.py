@@ -210,7 +210,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_enable_timing': (i32, [vp, i32]),
         'midas_snps_batch_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
-        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
+        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
     sig.update({
         'midas_bam_open': (i32, [C.c_char_p, C.POINTER(vp), C.c_char_p]),
@@ -366,24 +366,27 @@ def read_bam(path: str):
 
 
 def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):
-    """Host-only: run the packer and return (rec[n,16] uint8, blob uint8, max_l_seq)."""
+    """Host-only: run the packer and return (rec[n_records,16] uint8, blob uint8, max_l_seq).  n_records >= n_reads:
+    a read with indels or clips is served as one record per match segment (layout.h)."""
     lib = load_library()
     r = reads._c()
     cc = contigs._c() if contigs is not None else None
     cp = C.byref(cc) if cc is not None else None
     nbytes = C.c_int64(0)
+    nrec = C.c_int64(0)
     maxl = C.c_int32(0)
     err = C.create_string_buffer(256)
-    st = lib.midas_snps_pack_reads(C.byref(r), cp, None, None, 0, C.byref(nbytes), C.byref(maxl), err)
+    st = lib.midas_snps_pack_reads(C.byref(r), cp, None, None, 0, C.byref(nbytes), C.byref(nrec), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
-    rec = np.zeros((reads.n_reads + 1, 16), dtype=np.uint8)   # + sentinel record
+    n = int(nrec.value)
+    rec = np.zeros((n + 1, 16), dtype=np.uint8)   # + sentinel record
     blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
     st = lib.midas_snps_pack_reads(C.byref(r), cp, rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
-                                   blob.size, C.byref(nbytes), C.byref(maxl), err)
+                                   blob.size, C.byref(nbytes), C.byref(nrec), C.byref(maxl), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
-    return rec[:reads.n_reads], blob[:int(nbytes.value)], int(maxl.value)
+    return rec[:n], blob[:int(nbytes.value)], int(maxl.value)
 
 
 class Context:

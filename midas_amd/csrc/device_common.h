@@ -24,6 +24,12 @@ __device__ __forceinline__ bool consumes_both(uint32_t op) { return op == OP_M |
 __device__ __forceinline__ int rec_pos(const uint4& r) { return (int)r.x; }
 __device__ __forceinline__ uint32_t rec_off8(const uint4& r) { return r.y; }
 __device__ __forceinline__ int rec_l(const uint4& r) { return (int)(r.z & 0x7FFu); }
+// A kRecSimple record is one match segment of its read; the read-level numbers of the filter ride in the n_cigar / nm
+// fields (layout.h): l_seq of the read, its aligned length, NM, and whether this is the read's first segment.
+__device__ __forceinline__ int seg_read_l(const uint4& r) { return (int)((r.z >> 16) & 0x3FFu); }
+__device__ __forceinline__ int seg_align_len(const uint4& r) { return (int)((((r.z >> 26) & 0xFu) << 6) | ((r.w >> 10) & 0x3Fu)); }
+__device__ __forceinline__ int seg_nm(const uint4& r) { return (int)(r.w & 0x3FFu); }
+__device__ __forceinline__ bool seg_first(const uint4& r) { return ((r.z >> 30) & 1u) != 0u; }
 __device__ __forceinline__ int rec_qmean(const uint4& r) { return (int)(((r.z >> 11) & 31u) | ((r.w >> 23) & 0xE0u)); }
 __device__ __forceinline__ int rec_n(const uint4& r) { return (int)(r.z >> 16); }
 __device__ __forceinline__ uint32_t rec_nm(const uint4& r) { return r.w & 0xFFFFu; }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
     reach = (int)((key >> 2) & 31u);
     t0 = (int)(key >> 7);
     slot = 3 * t0 + (cls == 0 ? 0 : 1);
-    if (reach == 31) {
+    if (reach == 31 && !(rec_flags(reinterpret_cast<const uint4*>(p.rec)[i]) & kRecSimple)) {
       // exact last tile of a very long record: walk its CIGAR (contig from the tile table)
       const uint4 r = reinterpret_cast<const uint4*>(p.rec)[i];
       const uint32_t* cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(r) * 8 +

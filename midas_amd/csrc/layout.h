@@ -35,8 +35,11 @@ struct ReadRec {            // 16 bytes, 16-byte aligned
   uint32_t blob_off8;       // payload offset in 8-byte units
   uint16_t l_seq;           // bits 0-10: stored query length (soft clips included, <= kMaxLSeq);
                             // bits 11-15: low five bits of qmean = floor(sum(qual) / l_seq)  (see rec_qmean)
-  uint16_t n_cigar;
-  uint16_t nm;              // NM tag; kNmAbsent when the record has none
+  uint16_t n_cigar;         // record with a CIGAR: number of ops.  kRecSimple record (a match segment): bits 0-9 the
+                            // read's l_seq, bits 10-13 the high four bits of its aligned length, bit 14 "first segment
+                            // of its read" (the one that counts the read and reports its errors)
+  uint16_t nm;              // record with a CIGAR: NM tag, kNmAbsent when the record has none.  kRecSimple record:
+                            // bits 0-9 NM, bits 10-15 the low six bits of the read's aligned length
   uint8_t mapq;
   uint8_t flags;            // kRec* bits; bits 4-6: high three bits of qmean
 };
@@ -48,7 +51,8 @@ static_assert(sizeof(ReadRec) == 16, "ReadRec must be 16 bytes");
 constexpr uint16_t kNmAbsent = 0xFFFF;
 // Record flag bits: decode-time facts about the record, set by the packer.
 constexpr uint8_t kRecQualAbsent = 1;   // qual[0] == 0xFF (BAM: QUAL missing)
-constexpr uint8_t kRecSimple = 2;       // CIGAR is exactly one M/=/X op of length l_seq: the walk is the identity
+constexpr uint8_t kRecSimple = 2;       // the record is ONE gap-free match segment of its read (pos = the segment's first
+                                        // site, l_seq = its length, payload = its bases): the walk is the identity
 constexpr uint8_t kRecClipGeneric = 4;  // clip structure needs the general H/S loops (an H among the clips, or
                                         // several S at one end); when clear: lead = (op0 == S), trail = (opLast == S)
 constexpr uint8_t kRecSentinel = 0x80; // the record after the last read (l_seq 0): stream positions past a tile's reads
@@ -58,6 +62,8 @@ constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >
 constexpr int kChunk = 32;          // bases per lane
 constexpr int kMaxLSeq = 1024;      // at most 32 lanes per read
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
+constexpr int kMaxSegments = 6;     // match segments a read may be served as (more: it keeps its CIGAR)
+constexpr int kMaxSegField = 1023;  // l_seq / aligned length / NM representable in a segment record (10 bits each)
 
 // 4-bit call codes (pre-shifted: code & 0xC is the byte offset of the base's counter inside its site)
 constexpr uint8_t kCallA = 0x0, kCallC = 0x4, kCallG = 0x8, kCallT = 0xC, kCallOther = 0x2;

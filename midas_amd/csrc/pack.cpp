@@ -55,12 +55,10 @@ void set_err(char* err256, const char* fmt, long long a = 0, long long b = 0, lo
 inline bool op_match(uint32_t op) { return op == 0u || op == 7u || op == 8u; }  // M = X
 inline bool op_clip(uint32_t op) { return op == 4u || op == 5u; }              // S H
 
-// Decode-time facts about one record's CIGAR (layout.h kRec* bits).  The walk itself runs on the device;
-// these only say which of its fast paths applies, plus the one condition (kRecOverrun) under which the
-// reference would raise IndexError for a kept read.
+// Decode-time facts about one record's CIGAR (layout.h kRec* bits) for a record that keeps its CIGAR: which clip
+// path applies, plus the one condition (kRecOverrun) under which the reference would raise IndexError for a kept read.
 uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, int64_t contig_len, int64_t* reflen) {
   *reflen = l;
-  if (nc == 1 && op_match(cg[0] & 15u) && (cg[0] >> 4) == l && l > 0) return kRecSimple;
   uint8_t f = 0;
   if (nc > 0) {
     // leading clip run: maximal prefix of {S,H}; trailing: maximal suffix of {S,H} within indices >= 1
@@ -94,6 +92,62 @@ uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, in
   return f;
 }
 
+// A read whose CIGAR is `H* S? (M|=|X|I|D|N)+ S? H*` with every length >= 1, consuming exactly l_seq query bases, is
+// served to the device as its match segments: records that are each one gap-free run of aligned bases ("simple").
+// Clipped and inserted bases are in no segment (they are never tallied); the read-level numbers the filter needs
+// travel in every segment's record (layout.h).  Returns the number of segments (1..kMaxSegments) or 0 when the read
+// keeps its CIGAR and takes the device's general path (anything else: P/B ops, clips elsewhere, several S at one
+// end, zero-length ops, a query length that does not add up, absent or large NM, l_seq = 1024, negative pos, or more
+// segments than kMaxSegments).
+struct Segment { int32_t qoff; int64_t roff; int32_t len; };
+int segment_plan(const uint32_t* cg, uint32_t nc, uint32_t l, int32_t nm, int64_t pos, Segment* segs, uint32_t* align_total) {
+  if (l < 1 || l > kMaxSegField || nm < 0 || nm > kMaxSegField || pos < 0 || nc == 0) return 0;
+  uint32_t k = 0;
+  while (k < nc && (cg[k] & 15u) == 5u) { if ((cg[k] >> 4) == 0) return 0; ++k; }              // H*
+  uint32_t lead = 0, trail = 0;
+  if (k < nc && (cg[k] & 15u) == 4u) { lead = cg[k] >> 4; if (lead == 0) return 0; ++k; }        // S?
+  uint32_t e = nc;
+  while (e > k && (cg[e - 1] & 15u) == 5u) { if ((cg[e - 1] >> 4) == 0) return 0; --e; }         // H* at the end
+  if (e > k && (cg[e - 1] & 15u) == 4u) { trail = cg[e - 1] >> 4; if (trail == 0) return 0; --e; }
+  if (e <= k) return 0;
+  // pysam's backward walk never inspects op 0: a trailing clip at index 0 cannot happen here (e > k >= 0 and the
+  // ops in [k, e) are not clips), so lead/trail are exactly what getQueryStart/getQueryEnd return
+  int64_t q = lead, r = 0;
+  int n = 0;
+  bool prev_match = false;
+  for (uint32_t i = k; i < e; ++i) {
+    const uint32_t op = cg[i] & 15u;
+    const int64_t len = cg[i] >> 4;
+    if (len == 0) return 0;
+    if (op_match(op)) {
+      if (prev_match) {
+        segs[n - 1].len += (int32_t)len;          // "10=1X20=": one gap-free run
+      } else {
+        if (n == kMaxSegments) return 0;
+        segs[n].qoff = (int32_t)q;
+        segs[n].roff = r;
+        segs[n].len = (int32_t)len;
+        ++n;
+      }
+      q += len;
+      r += len;
+      prev_match = true;
+    } else if (op == 1u) {        // I
+      q += len;
+      prev_match = false;
+    } else if (op == 2u || op == 3u) {   // D N
+      r += len;
+      prev_match = false;
+    } else {
+      return 0;                   // S/H in the middle, P, B, unknown
+    }
+    if (q > (int64_t)l || r > 0x7FFFFFFFll) return 0;
+  }
+  if (n == 0 || q + trail != (int64_t)l) return 0;
+  *align_total = l - lead - trail;
+  return n;
+}
+
 }  // namespace
 
 int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
@@ -120,15 +174,12 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     for (int32_t c = 0; c < contigs->n_contigs; ++c)
       tile_base[c + 1] = tile_base[c] + (contigs->length[c] + tile_len - 1) / tile_len;
   }
-  // 3 * owner tile + class: 0 = simple read inside one tile, 1 = any other read inside one tile,
-  // 2 = read reaching into a later tile ("straddler", either kind)
-  std::vector<uint32_t> key(tiled ? n : 0);
-  std::vector<uint32_t> tile_key_in(tiled && key_out ? n : 0);   // per input record; permuted into key_out below
-  uint32_t* const tile_key = tile_key_in.empty() ? nullptr : tile_key_in.data();
 
-  // Pass 1: validate, classify the CIGAR, per-read payload size.
-  std::vector<uint32_t> bytes(n);
-  std::vector<uint8_t> cflags(n);
+  // Pass 1: validate every read, decide how many device records it becomes (its match segments, or one record that
+  // keeps the CIGAR).
+  std::vector<uint8_t> nseg(n);       // 0: one general record; k >= 1: k segment records
+  const bool have_contigs = contigs && contigs->n_contigs > 0;
+  std::vector<int32_t> contig_of(have_contigs ? n : 0);
   std::atomic<int32_t> status{MIDAS_SNPS_OK};
   std::atomic<long long> bad_read{-1};
   const int nt = hw_threads();
@@ -147,6 +198,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
                     contigs->read_begin) - 1;
       c = std::max(0, std::min(c, contigs->n_contigs - 1));
     }
+    Segment segs[kMaxSegments];
     for (int64_t i = lo; i < hi; ++i) {
       const int64_t l = r->l_seq[i];
       const int64_t nc = r->cigar_off[i + 1] - r->cigar_off[i];
@@ -161,26 +213,12 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         fail(MIDAS_SNPS_ERR_UNSUPPORTED, i);
         return;
       }
-      int64_t clen = INT64_MAX;
       if (contigs && contigs->n_contigs > 0) {
         while (c + 1 < contigs->n_contigs && i >= contigs->read_begin[c + 1]) ++c;
-        clen = contigs->length[c];
+        contig_of[i] = c;
       }
-      int64_t reflen = 0;
-      const uint8_t f = cigar_flags(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->pos[i], clen, &reflen);
-      cflags[i] = f;
-      if (tiled) {
-        int64_t pc = r->pos[i] < 0 ? 0 : r->pos[i];
-        pc = pc > clen - 1 ? clen - 1 : pc;
-        // same arithmetic as index_reads_kernel: first and last tile the record touches
-        int64_t pe = (int64_t)r->pos[i] + (reflen > 0 ? reflen : 1) - 1;
-        pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
-        const int64_t reach = pe / tile_len - pc / tile_len;
-        key[i] = (uint32_t)(3 * (tile_base[c] + pc / tile_len) + (reach > 0 ? 2 : ((f & kRecSimple) ? 0 : 1)));
-        if (tile_key) tile_key[i] = (uint32_t)(((tile_base[c] + pc / tile_len) << 7) | ((reach > 31 ? 31 : reach) << 2) |
-                                               (reach > 0 ? 2 : ((f & kRecSimple) ? 0 : 1)));
-      }
-      bytes[i] = blob_bytes((uint32_t)l, (f & kRecSimple) ? 0u : (uint32_t)nc);
+      uint32_t at = 0;
+      nseg[i] = (uint8_t)segment_plan(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->nm[i], r->pos[i], segs, &at);
       a += (l + 1) / 2 + l + 4 * nc + 16;
       ml = std::max<int32_t>(ml, (int32_t)l);
     }
@@ -195,13 +233,75 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       set_err(err256, "read %lld: negative size or CSR offsets shorter than l_seq", bad_read.load());
     return status;
   }
-  int64_t total = 0;
-  for (int64_t i = 0; i < n; ++i) total += bytes[i];
-  out->blob_bytes = total;
   for (int t = 0; t < nt; ++t) {
     out->read_algorithmic_bytes += alg[t];
     out->max_l_seq = std::max(out->max_l_seq, maxl[t]);
   }
+  // records in input order: read i owns records [first[i], first[i + 1])
+  std::vector<int64_t> first(n + 1);
+  first[0] = 0;
+  for (int64_t i = 0; i < n; ++i) first[i + 1] = first[i] + (nseg[i] ? nseg[i] : 1);
+  const int64_t m = first[n];
+  if (m > 2000000000LL) {
+    set_err(err256, "%lld device records exceed the supported range", (long long)m);
+    return MIDAS_SNPS_ERR_UNSUPPORTED;
+  }
+  out->n_records = m;
+
+  // Pass 1b: per record -- payload size, sort key (3 * owner tile + class: 0 = segment inside one tile, 1 = record with
+  // a CIGAR inside one tile, 2 = record reaching into a later tile), index key for the device.
+  std::vector<uint32_t> rec_read(m);
+  std::vector<uint8_t> rec_seg(m);
+  std::vector<uint32_t> bytes(m);
+  std::vector<uint8_t> cflags(m);
+  std::vector<uint32_t> key(tiled ? m : 0);
+  std::vector<uint32_t> tile_key_in(tiled && key_out ? m : 0);
+  uint32_t* const tile_key = tile_key_in.empty() ? nullptr : tile_key_in.data();
+  parallel_ranges(n, [&](int, int64_t lo, int64_t hi) {
+    Segment segs[kMaxSegments];
+    for (int64_t i = lo; i < hi; ++i) {
+      const uint32_t l = (uint32_t)r->l_seq[i];
+      const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+      const uint32_t* cg = r->cigar + r->cigar_off[i];
+      const int64_t clen = have_contigs ? contigs->length[contig_of[i]] : INT64_MAX;
+      const int64_t tb = tiled ? tile_base[contig_of[i]] : 0;
+      auto set_keys = [&](int64_t j, int64_t start, int64_t reflen, bool simple) {
+        if (!tiled) return;
+        int64_t pc = start < 0 ? 0 : start;
+        pc = pc > clen - 1 ? clen - 1 : pc;
+        // same arithmetic as index_reads_kernel: first and last tile the record touches
+        int64_t pe = start + (reflen > 0 ? reflen : 1) - 1;
+        pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
+        const int64_t reach = pe / tile_len - pc / tile_len;
+        const uint32_t cls = reach > 0 ? 2u : (simple ? 0u : 1u);
+        key[j] = (uint32_t)(3 * (tb + pc / tile_len)) + cls;
+        if (tile_key) tile_key[j] = (uint32_t)(((tb + pc / tile_len) << 7) | ((reach > 31 ? 31 : reach) << 2) | cls);
+      };
+      if (nseg[i] == 0) {
+        const int64_t j = first[i];
+        int64_t reflen = 0;
+        cflags[j] = cigar_flags(cg, nc, l, r->pos[i], clen, &reflen);
+        rec_read[j] = (uint32_t)i;
+        rec_seg[j] = 0;
+        bytes[j] = blob_bytes(l, nc);
+        set_keys(j, r->pos[i], reflen, false);
+      } else {
+        uint32_t at = 0;
+        const int k = segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at);
+        for (int s = 0; s < k; ++s) {
+          const int64_t j = first[i] + s;
+          cflags[j] = kRecSimple;
+          rec_read[j] = (uint32_t)i;
+          rec_seg[j] = (uint8_t)s;
+          bytes[j] = blob_bytes((uint32_t)segs[s].len, 0u);
+          set_keys(j, (int64_t)r->pos[i] + segs[s].roff, segs[s].len, true);
+        }
+      }
+    }
+  });
+  int64_t total = 0;
+  for (int64_t j = 0; j < m; ++j) total += bytes[j];
+  out->blob_bytes = total;
   if ((uint64_t)total / 8 > 0xFFFFFFFFull) {
     set_err(err256, "packed payload %lld bytes exceeds the 32 GiB a batch can address", (long long)total);
     return MIDAS_SNPS_ERR_UNSUPPORTED;
@@ -212,78 +312,102 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     return MIDAS_SNPS_ERR_INVALID_ARG;
   }
 
-  // Device order.  Within the window of every tile: the single-match ("simple") reads that stay inside the tile,
-  // then the other reads that stay inside it, then the reads that reach into a later tile -- each group in input
-  // order.  A wave of the pileup kernel then mostly works on reads of one kind, and the straddlers a later tile
-  // needs are one contiguous run at the end of the window.  A stable counting sort by (owner tile, class);
-  // reads never leave their contig because tiles do not span contigs.
-  std::vector<int64_t> order(n);
+  // Device order.  Within the window of every tile: the segments that stay inside the tile, then the records with a
+  // CIGAR that stay inside it, then the records that reach into a later tile -- each group in input order.  A wave of
+  // the pileup kernel then mostly works on records of one kind, and the straddlers a later tile needs are one
+  // contiguous run at the end of the window.  A stable counting sort by (owner tile, class); records never leave
+  // their contig because tiles do not span contigs.
+  std::vector<int64_t> order(m);
   if (tiled) {
     std::vector<int64_t> start((size_t)(3 * tile_base.back()) + 1, 0);
-    for (int64_t i = 0; i < n; ++i) start[key[i] + 1]++;
+    for (int64_t j = 0; j < m; ++j) start[key[j] + 1]++;
     for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
-    for (int64_t i = 0; i < n; ++i) order[start[key[i]]++] = i;
+    for (int64_t j = 0; j < m; ++j) order[start[key[j]]++] = j;
   } else {
-    for (int64_t i = 0; i < n; ++i) order[i] = i;
+    for (int64_t j = 0; j < m; ++j) order[j] = j;
   }
   // Pass 2: offsets (serial prefix sum in device order), then copy in parallel.
-  std::vector<int64_t> off(n + 1);
+  std::vector<int64_t> off(m + 1);
   off[0] = 0;
-  for (int64_t j = 0; j < n; ++j) off[j + 1] = off[j] + bytes[order[j]];
-  parallel_ranges(n, [&](int, int64_t lo, int64_t hi) {
-    for (int64_t j = lo; j < hi; ++j) {
-      const int64_t i = order[j];
-      if (orig_index) orig_index[j] = (uint32_t)i;
-      if (key_out && tile_key) key_out[j] = tile_key[i];
+  for (int64_t d = 0; d < m; ++d) off[d + 1] = off[d] + bytes[order[d]];
+  parallel_ranges(m, [&](int, int64_t lo, int64_t hi) {
+    Segment segs[kMaxSegments];
+    for (int64_t d = lo; d < hi; ++d) {
+      const int64_t j = order[d];
+      const int64_t i = rec_read[j];
+      if (orig_index) orig_index[d] = (uint32_t)i;
+      if (key_out && tile_key) key_out[d] = tile_key[j];
       const uint32_t l = (uint32_t)r->l_seq[i];
       const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
-      uint8_t* b = blob + off[j];
+      const uint32_t* cg = r->cigar + r->cigar_off[i];
       const uint8_t* q = r->qual + r->qual_off[i];
-      memset(b, 0, bytes[i]);
+      const uint8_t* s4 = r->seq4 + r->seq_off[i];
+      uint8_t* b = blob + off[d];
+      memset(b, 0, bytes[j]);
       uint64_t qsum = 0;
+      for (uint32_t x = 0; x < l; ++x) qsum += q[x];
+      const uint32_t qmean = l > 0 ? (uint32_t)(qsum / l) : 0u;   // <= 255, over the WHOLE read (clips included)
+      // the bases this record carries: the whole read, or one match segment of it
+      uint32_t q0 = 0, len = l;
+      int64_t pos = r->pos[i];
+      uint32_t at = 0;
+      int k = 0;
+      if (cflags[j] & kRecSimple) {
+        k = segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at);
+        const Segment& sg = segs[rec_seg[j]];
+        q0 = (uint32_t)sg.qoff;
+        len = (uint32_t)sg.len;
+        pos += sg.roff;
+      }
       {
         // qualities (0 for a base that is not A/C/G/T) and, per 32-base chunk, 16 bytes of call codes: byte k =
         // code(base k) | code(base k + 16) << 4; bases past the end are kCallOther with quality 0
-        const uint8_t* s4 = r->seq4 + r->seq_off[i];
-        uint8_t* d4 = b + blob_seq_off(l);
-        const uint32_t n_chunks = (l + kChunk - 1) / kChunk;
+        uint8_t* d4 = b + blob_seq_off(len);
+        const uint32_t n_chunks = (len + kChunk - 1) / kChunk;
         for (uint32_t c = 0; c < n_chunks; ++c) {
-          for (uint32_t k = 0; k < 16; ++k) {
+          for (uint32_t kk = 0; kk < 16; ++kk) {
             uint8_t code[2];
             for (uint32_t h = 0; h < 2; ++h) {
-              const uint32_t j = c * kChunk + 16 * h + k;
-              if (j < l) {
-                const uint8_t bc = (uint8_t)((s4[j >> 1] >> ((~j & 1u) * 4)) & 15u);
+              const uint32_t x = c * kChunk + 16 * h + kk;    // base of the record
+              if (x < len) {
+                const uint32_t y = q0 + x;                      // base of the read
+                const uint8_t bc = (uint8_t)((s4[y >> 1] >> ((~y & 1u) * 4)) & 15u);
                 code[h] = kCallCode[bc];
-                qsum += q[j];
-                b[j] = code[h] == kCallOther ? (uint8_t)0 : q[j];
+                b[x] = code[h] == kCallOther ? (uint8_t)0 : q[y];
               } else {
                 code[h] = kCallOther;
               }
             }
-            d4[c * 16 + k] = (uint8_t)(code[0] | (code[1] << 4));
+            d4[c * 16 + kk] = (uint8_t)(code[0] | (code[1] << 4));
           }
         }
       }
-      if (!(cflags[i] & kRecSimple)) memcpy(b + blob_cigar_off(l), r->cigar + r->cigar_off[i], 4ull * nc);
       ReadRec rr;
-      rr.pos = r->pos[i];
-      rr.blob_off8 = (uint32_t)(off[j] >> 3);
-      const uint32_t qmean = l > 0 ? (uint32_t)(qsum / l) : 0u;   // <= 255
-      rr.l_seq = (uint16_t)(l | ((qmean & 31u) << kRecLBits));
-      rr.n_cigar = (uint16_t)nc;
-      rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
+      rr.pos = (int32_t)pos;
+      rr.blob_off8 = (uint32_t)(off[d] >> 3);
+      rr.l_seq = (uint16_t)(len | ((qmean & 31u) << kRecLBits));
       rr.mapq = r->mapq[i];
-      rr.flags = (uint8_t)(cflags[i] | ((l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0) | ((qmean >> 5) << 4));
-      rec[j] = rr;
+      const uint8_t qflag = (l > 0 && q[0] == 0xFF) ? kRecQualAbsent : 0;
+      if (cflags[j] & kRecSimple) {
+        // read-level numbers of the filter, in every segment (layout.h): l_seq, aligned length, NM, "first segment"
+        rr.n_cigar = (uint16_t)(l | ((at >> 6) << 10) | ((rec_seg[j] == 0 ? 1u : 0u) << 14));
+        rr.nm = (uint16_t)((uint32_t)r->nm[i] | ((at & 63u) << 10));
+        (void)k;
+      } else {
+        memcpy(b + blob_cigar_off(l), cg, 4ull * nc);
+        rr.n_cigar = (uint16_t)nc;
+        rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
+      }
+      rr.flags = (uint8_t)(cflags[j] | qflag | ((qmean >> 5) << 4));
+      rec[d] = rr;
     }
   });
   {
     ReadRec s;  // sentinel: where the payload ends
     memset(&s, 0, sizeof s);
-    s.blob_off8 = (uint32_t)(off[n] >> 3);
+    s.blob_off8 = (uint32_t)(off[m] >> 3);
     s.flags = kRecSentinel;
-    rec[n] = s;
+    rec[m] = s;
   }
   return MIDAS_SNPS_OK;
 }

@@ -6,11 +6,13 @@ namespace midas {
 
 struct PackSummary {
   int64_t blob_bytes = 0;
+  int64_t n_records = 0;               // device records: one per match segment, or one per read that keeps its CIGAR
   int64_t read_algorithmic_bytes = 0;  // sum(ceil(l/2) + l + 4*n_cigar + 16)
   int32_t max_l_seq = 0;
 };
 
-// rec == blob == nullptr: size query only.  rec must hold n_reads + 1 records (sentinel).
+// rec == blob == nullptr: size query only (blob_bytes, n_records).  rec must hold n_records + 1 records (sentinel);
+// orig_index / key_out n_records entries.
 // `contigs` (may be nullptr) supplies the contig lengths the kRecOverrun flag is defined against;
 // without it every contig is taken as unbounded.
 // tile_len > 0 (needs `contigs`): device order = per tile window [simple reads][other reads]; orig_index[j]

@@ -288,18 +288,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         const bool inside = frel >= 0 && frel + fl <= tile_len && fl > 0 && (rec_cur.w & ((uint32_t)kRecSimple << 24));
         fast = __ballot(fact && !inside) == 0ull;
         if (fast) {
-          const int fnm = (int)rec_nm(rec_cur);
-          const int min_match = s_tables[fl];                            // fl <= max l_seq of the batch < table_len
-          const int min_align = s_tables[p.table_len + fl];
-          const bool t_nonm = fnm == (int)kNmAbsent;
-          const bool t_pid = fl - fnm < min_match;
+          // read-level numbers of the filter travel in the segment's record
+          const int fnm = seg_nm(rec_cur);
+          const int a_tot = seg_align_len(rec_cur);                      // aligned length of the whole read
+          const int l_read = seg_read_l(rec_cur);                        // its l_seq
+          const int min_match = s_tables[a_tot];                         // both <= max l_seq of the batch < table_len
+          const int min_align = s_tables[p.table_len + l_read];
+          const bool t_pid = a_tot - fnm < min_match;
           const bool t_noqual = (rec_cur.w & ((uint32_t)kRecQualAbsent << 24)) != 0u;
-          const bool t_drop = (rec_qmean(rec_cur) < p.readq) | (rec_mapq(rec_cur) < p.mapq) | (fl < min_align);
+          const bool t_drop = (rec_qmean(rec_cur) < p.readq) | (rec_mapq(rec_cur) < p.mapq) | (a_tot < min_align);
           uint32_t err = t_noqual ? (uint32_t)E_NO_QUAL : 0u;            // same precedence as the general cascade
           err = t_pid ? 0u : err;
-          err = t_nonm ? (uint32_t)E_NO_NM : err;
           err = fact ? err : 0u;
-          const bool keep = fact & !(t_nonm | t_pid | t_noqual | t_drop);
+          const bool keep = fact & !(t_pid | t_noqual | t_drop);
           if (keep && q0 < fl) {
             uint32_t cd[NW];
 #pragma unroll
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
             const uint32_t abase = ((uint32_t)(frel + q0) << 4) + lds_base;
             if (!(p.debug & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
           }
-          const bool head = fact && c == 0;                              // S reads start in this tile: it owns them
+          const bool head = fact && c == 0 && seg_first(rec_cur);        // S records start in this tile: it owns them;
+                                                                         // a read is counted by its first segment
           w_aligned += (uint32_t)__popcll(__ballot(head));
           w_mapped += (uint32_t)__popcll(__ballot(head && keep));
           if (head && err) atomicMin(p.err, ((unsigned long long)p.orig[read_at(rg, vpos)] << 8) | err);
@@ -328,11 +330,11 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
       if (!fast) {
       const int l = rec_l(rec_cur);
-      const int n = rec_n(rec_cur);
       const int pos = rec_pos(rec_cur);
       const uint32_t flags = rec_flags(rec_cur);
       bool act = (flags & kRecSentinel) == 0u;   // stream positions past the tile's reads fetched the sentinel
-      const bool simple = (flags & kRecSimple) != 0u;
+      const bool simple = (flags & kRecSimple) != 0u;   // a match segment: no CIGAR, read-level numbers in n / nm
+      const int n = simple ? 1 : rec_n(rec_cur);
       // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
       int cpos = pos < 0 ? 0 : pos;
       cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
@@ -380,18 +382,20 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
       int align_len = (l - trail_s) - lead_s;
       align_len = align_len < 0 ? 0 : align_len;
+      align_len = simple ? seg_align_len(rec_cur) : align_len;   // of the whole read
+      const int l_read = simple ? seg_read_l(rec_cur) : l;
       // exact integer form of the two fp64 ratio tests (tables built by the host with the reference's expressions)
       const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
-      const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+      const int min_align = s_tables[p.table_len + (l_read < p.table_len ? l_read : 0)];
 
       const int nvalid = has ? (l - q0 < kChunk ? l - q0 : kChunk) : 0;
 
       // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
       // Every test is evaluated (selects, no branches: the cascade used to cost seven exec-mask branches per
       // iteration); the reference's order decides which outcome wins, lowest priority first.
-      const int nm = (int)rec_nm(rec_cur);
+      const int nm = simple ? seg_nm(rec_cur) : (int)rec_nm(rec_cur);
       const bool t_noseq = l == 0;
-      const bool t_nonm = nm == (int)kNmAbsent;
+      const bool t_nonm = !simple && nm == (int)kNmAbsent;
       const bool t_zero = align_len == 0;
       const bool t_pid = align_len - nm < min_match;                                     // pid < mapid
       const bool t_noqual = (flags & kRecQualAbsent) != 0u;
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
 
       // ---- per-species read counters: one ballot per wave -----------------------------------------
-      const bool head = owner && c == 0;
+      const bool head = owner && c == 0 && (!simple || seg_first(rec_cur));   // a read is counted by its first segment
       const unsigned long long m_al = __ballot(head);
       const unsigned long long m_mp = __ballot(head && keep);
       w_aligned += (uint32_t)__popcll(m_al);

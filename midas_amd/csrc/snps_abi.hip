@@ -48,6 +48,7 @@ struct midas_snps_batch {
   uint8_t* d_allele = nullptr;
   // facts
   int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
+  int64_t n_records = 0;   // device records (match segments + reads that keep their CIGAR) >= n_reads
   int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, tile_len = kTileSites;
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot
@@ -224,11 +225,12 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
 }
 
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob, int64_t blob_capacity,
-                              int64_t* out_blob_bytes, int32_t* out_max_l_seq, char* err256) {
+                              int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
   PackSummary s;
   int32_t st = pack_reads(reads, contigs, 0, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr, nullptr,
                           blob_capacity, &s, err256);
   if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
+  if (out_n_records) *out_n_records = s.n_records;
   if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
   return st;
 }
@@ -286,6 +288,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   if (!b) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host allocation failed");
   b->ctx = ctx;
   b->n_reads = reads->n_reads;
+  b->n_records = ps.n_records;
   b->n_sites = n_sites;
   b->n_contigs = contigs->n_contigs;
   b->n_species = contigs->n_species;
@@ -346,12 +349,12 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
 
   // ---- pack + upload reads ------------------------------------------------------------------
   const size_t blob_alloc = (size_t)ps.blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
-  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec)));  // + sentinel
+  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_records + 1) * sizeof(ReadRec)));  // + sentinel
   B_TRY(hipMalloc(&b->d_blob, blob_alloc));
   if (b->n_reads > 0) {
     // staging in ordinary (pageable) memory owned by the context: pinning and unpinning ~0.25 GB costs ~70 ms on this
     // platform, and even unmapping it ~30 ms -- several times the pack and the copy themselves (MIDAS_SNPS_TRACE)
-    const size_t rec_bytes = (size_t)(b->n_reads + 1) * sizeof(ReadRec);
+    const size_t rec_bytes = (size_t)(b->n_records + 1) * sizeof(ReadRec);
     if (ctx->stage_rec_cap < rec_bytes) {
       free(ctx->stage_rec);
       ctx->stage_rec = malloc(rec_bytes);
@@ -370,26 +373,26 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }
     memset(h_blob + ps.blob_bytes, 0, 64);
     lap("device + staging allocations");
-    std::vector<uint32_t> h_orig((size_t)b->n_reads);
-    std::vector<uint32_t> h_key((size_t)b->n_reads);
+    std::vector<uint32_t> h_orig((size_t)b->n_records);
+    std::vector<uint32_t> h_key((size_t)b->n_records);
     st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), h_key.data(), (int64_t)blob_alloc, &ps, ebuf);
     lap("pack_reads");
     if (st == MIDAS_SNPS_OK) {
       // reads a tile will see = those that start in it + those of earlier tiles reaching in (key: tile << 7 | reach << 2 | class)
-      for (int64_t i = 0; i < b->n_reads; ++i) {
+      for (int64_t i = 0; i < b->n_records; ++i) {
         const uint32_t k = h_key[(size_t)i];
         const size_t t0 = k >> 7, reach = (k >> 2) & 31u;
         for (size_t r = 0; r <= reach && t0 + r < tile_reads.size(); ++r) tile_reads[t0 + r] += 1;
       }
-      hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_reads * 4);
-      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
-      if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_reads * 4);
-      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_key, h_key.data(), (size_t)b->n_reads * 4, hipMemcpyHostToDevice);
+      hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_records * 4);
+      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_records * 4, hipMemcpyHostToDevice);
+      if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_records * 4);
+      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_key, h_key.data(), (size_t)b->n_records * 4, hipMemcpyHostToDevice);
       if (e0 != hipSuccess) { int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
     }
     hipError_t e1 = hipSuccess, e2 = hipSuccess;
     if (st == MIDAS_SNPS_OK) {
-      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_reads + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
+      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_records + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
       e2 = hipMemcpy(b->d_blob, h_blob, blob_alloc, hipMemcpyHostToDevice);
     }
     lap("H2D records + payload");
@@ -514,7 +517,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.n_tiles = (int32_t)b->n_tiles;
   ip.stats = work_stats(b);
   ip.err = work_err(b);
-  ip.n_reads = (int32_t)b->n_reads;
+  ip.n_reads = (int32_t)b->n_records;
   ip.n_stat_words = b->n_species * MIDAS_STATS;
   ip.tile_len = b->tile_len;
   HIP_TRY(ctx, launch_index_reads(ip, s));
@@ -536,7 +539,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.split_ticket = b->d_ticket;
   pp.n_items = (int32_t)b->n_items;
   pp.n_whole_items = (int32_t)b->n_whole_items;
-  pp.n_reads = (int32_t)b->n_reads;
+  pp.n_reads = (int32_t)b->n_records;
   pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
   if (const char* e = getenv("MIDAS_SNPS_GRID")) pp.grid_blocks = atoi(e) > 0 ? atoi(e) : pp.grid_blocks;   // experiments only
   pp.lanes_per_read = b->lanes_per_read;
@@ -597,7 +600,7 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->n_reads = b->n_reads;
   out->n_sites = b->n_sites;
   out->n_tiles = b->n_tiles;
-  out->packed_bytes = b->blob_bytes + b->n_reads * (int64_t)sizeof(ReadRec);
+  out->packed_bytes = b->blob_bytes + b->n_records * (int64_t)sizeof(ReadRec);
   out->algorithmic_bytes = b->alg_bytes;
   out->tile_sites = b->tile_len;
   out->lanes_per_read = b->lanes_per_read;

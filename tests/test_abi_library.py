@@ -88,6 +88,16 @@ REC_DTYPE = np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"
                       ("mapq", "u1"), ("flags", "u1")])
 
 
+def seg_fields(r):
+    """Read-level numbers a segment record carries (layout.h): (l_seq of the read, aligned length, NM, first?)."""
+    n, nm = r["n"].astype(int), r["nm"].astype(int)
+    return (n & 0x3FF).tolist(), ((((n >> 10) & 0xF) << 6) | (nm >> 10)).tolist(), (nm & 0x3FF).tolist(), ((n >> 14) & 1).tolist()
+
+
+def qmean_of(r):
+    return ((r["l"] >> 11).astype(int) | (((r["flags"].astype(int) >> 4) & 7) << 5)).tolist()
+
+
 def test_pack_layout_matches_design():
     reads = H.reads_from_dicts([
         dict(pos=7, cigar="3S7M", seq="TTTACGTACG", qual=list(range(10)), nm=1, mapq=33, flag=16),
@@ -97,26 +107,75 @@ def test_pack_layout_matches_design():
     rec, blob, maxl = abi.pack_reads(reads)
     assert maxl == 10 and rec.shape == (3, 16)
     r = rec.view(REC_DTYPE).reshape(3)
-    assert r["pos"].tolist() == [7, 9, 11] and (r["l"] & 0x7FF).tolist() == [10, 5, 4] and r["n"].tolist() == [2, 1, 1]
-    assert r["nm"].tolist() == [1, 0xFFFF, 0] and r["mapq"].tolist() == [33, 0, 42]
-    # flags: bit0 QUAL absent, bit1 "simple" (one M/=/X op spanning l_seq), bit2 generic clips, bit3 overrun
-    assert (r["flags"] & 0x8F).tolist() == [0, 2, 3]
-    # qmean = floor(sum(qual) / l): low five bits above l_seq, high three bits in flags 4-6
-    qmean = ((r["l"] >> 11) | ((r["flags"].astype(int) >> 4) & 7) << 5).tolist()
-    assert qmean == [45 // 10, 40, 255]           # 0..9 ; default quality 40 ; absent = 0xFF bytes
-    # read 0: qual 10 -> 32 | calls 16 | cigar 8            = 56 bytes
-    # read 1: qual  5 -> 32 | calls 16 | (simple: no cigar) = 48 bytes; read 2 likewise
-    assert r["off8"].tolist() == [0, 7, 13]
-    b0 = blob[:56]
-    assert b0[:10].tolist() == list(range(10)) and not b0[10:32].any()
-    assert bytes(b0[32:48]) == call_codes("TTTACGTACG")
-    assert b0[48:56].view("<u4").tolist() == [(3 << 4) | 4, (7 << 4) | 0]
-    b1 = blob[56:104]
+    # read 0 is served as its one match segment: the 7 aligned bases at pos 7 (the soft clip is in no record);
+    # read 1 has no NM tag, so it keeps its CIGAR (the device's general path raises the reference's KeyError);
+    # read 2 is a plain single match
+    assert r["pos"].tolist() == [7, 9, 11] and (r["l"] & 0x7FF).tolist() == [7, 5, 4]
+    # flags: bit0 QUAL absent, bit1 "simple" (one gap-free match segment), bit2 generic clips, bit3 overrun
+    assert (r["flags"] & 0x8F).tolist() == [2, 0, 3]
+    assert r["mapq"].tolist() == [33, 0, 42]
+    lr, al, nm, first = seg_fields(r[[0, 2]])
+    assert (lr, al, nm, first) == ([10, 4], [7, 4], [1, 0], [1, 1])
+    assert r["n"][1] == 1 and r["nm"][1] == 0xFFFF
+    # qmean = floor(sum(qual) / l) over the WHOLE read: low five bits above l_seq, high three bits in flags 4-6
+    assert qmean_of(r) == [45 // 10, 40, 255]           # 0..9 ; default quality 40 ; absent = 0xFF bytes
+    # read 0: qual 7 -> 32 | calls 16                = 48 bytes
+    # read 1: qual 5 -> 32 | calls 16 | cigar 4 -> 8 = 56 bytes; read 2 like read 0
+    assert r["off8"].tolist() == [0, 6, 13]
+    b0 = blob[:48]
+    assert b0[:7].tolist() == list(range(3, 10)) and not b0[7:32].any()
+    assert bytes(b0[32:48]) == call_codes("ACGTACG")
+    b1 = blob[48:104]
     assert b1[:5].tolist() == [40, 40, 40, 40, 0]    # the N's quality is stored as 0: it can never count
     assert bytes(b1[32:48]) == call_codes("ACGTN")
-    assert blob.size == 56 + 48 + 48
-    # the sentinel record after the last read carries its own flag
-    assert rec.shape[0] == 3
+    assert b1[48:52].view("<u4").tolist() == [(5 << 4) | 0]
+    assert blob.size == 48 + 56 + 48
+
+
+def test_pack_serves_reads_as_match_segments():
+    """CIGAR -> records: one per gap-free run of aligned bases; clipped and inserted bases are in no record."""
+    seq = "".join("ACGT"[(7 * i) % 4] for i in range(150))
+    reads = H.reads_from_dicts([
+        dict(pos=100, cigar="75M2I73M", seq=seq, nm=3),          # -> (100, bases 0..74), (175, bases 77..149)
+        dict(pos=300, cigar="5S70M2D75M", seq=seq, nm=2),        # -> (300, 5..74), (372, 75..149)
+        dict(pos=500, cigar="10=1X20=119S", seq=seq, nm=1),      # -> one segment of 31
+        dict(pos=700, cigar="2H10S30M5N40M3D60M10S4H", seq=seq, nm=3),   # three segments
+    ])
+    rec, blob, _ = abi.pack_reads(reads)
+    r = rec.view(REC_DTYPE).reshape(-1)
+    assert r["pos"].tolist() == [100, 175, 300, 372, 500, 700, 735, 778]
+    assert (r["l"] & 0x7FF).tolist() == [75, 73, 70, 75, 31, 30, 40, 60]
+    assert (r["flags"] & 0x8F).tolist() == [2] * 8
+    lr, al, nm, first = seg_fields(r)
+    assert lr == [150] * 8 and nm == [3, 3, 2, 2, 1, 3, 3, 3]
+    assert al == [150, 150, 145, 145, 31, 130, 130, 130]          # l_seq minus the soft clips (insertions count)
+    assert first == [1, 0, 1, 0, 1, 1, 0, 0]
+    # payload of the second record of read 0: read bases 77..149
+    o = int(r["off8"][1]) * 8
+    assert bytes(blob[o + 96:o + 96 + 48]) == call_codes(seq[77:150])
+    assert blob[o:o + 73].tolist() == [40] * 73 and not blob[o + 73:o + 96].any()
+
+
+def test_pack_keeps_the_cigar_of_reads_it_cannot_segment():
+    seq = "A" * 60
+    cases = [("10S", 10, "no aligned base"), ("5S5S50M", 60, "two clips at one end"), ("30M2P30M", 60, "pad op"),
+             ("20M5S35M", 60, "clip in the middle"), ("50M", 60, "query length does not add up"),
+             ("70M", 60, "CIGAR longer than SEQ"), ("60I", 60, "no match op")]
+    reads = H.reads_from_dicts([dict(pos=0, cigar=cg, seq=seq[:l]) for cg, l, _ in cases] +
+                               [dict(pos=0, cigar="60M", seq=seq, nm=None), dict(pos=0, cigar="60M", seq=seq, nm=1024),
+                                dict(pos=-1, cigar="60M", seq=seq)])
+    rec, _, _ = abi.pack_reads(reads)
+    r = rec.view(REC_DTYPE).reshape(-1)
+    assert rec.shape[0] == len(cases) + 3
+    assert ((r["flags"] & 2) == 0).all()                        # none of them is "simple"
+    assert r["n"].tolist() == [1, 3, 3, 3, 1, 1, 1, 1, 1, 1]    # the op counts, i.e. the CIGARs are stored
+    # seven match ops separated by insertions: more segments than a read may be served as
+    many = H.reads_from_dicts([dict(pos=0, cigar="5M1I" * 6 + "5M", seq="A" * 41, nm=6)])
+    rec, _, _ = abi.pack_reads(many)
+    assert rec.shape[0] == 1 and not (rec[0, 15] & 2)
+    six = H.reads_from_dicts([dict(pos=0, cigar="5M1I" * 5 + "5M", seq="A" * 35, nm=5)])
+    rec, _, _ = abi.pack_reads(six)
+    assert rec.shape[0] == 6 and all(rec[:, 15] & 2)
 
 
 def test_pack_overrun_flag_needs_the_contig_length():
@@ -129,15 +188,15 @@ def test_pack_overrun_flag_needs_the_contig_length():
 
 
 def test_pack_cigar_fast_path_flags():
-    """Decode-time CIGAR facts the kernels rely on (layout.h kRec*): they must be exact, not heuristics."""
-    cases = [("150M", 150, 2), ("150=", 150, 2), ("150X", 150, 2), ("149M", 150, 0), ("10S140M", 150, 0),
-             ("140M10S", 150, 0), ("10S130M10S", 150, 0), ("5H10S135M", 145, 4), ("135M10S5H", 145, 4),
-             ("5S5S140M", 150, 4), ("140M5S5S", 150, 4), ("2H148M", 148, 4), ("10S", 10, 0), ("5S5S", 10, 4),
-             ("75M2I73M", 150, 0), ("75M2D75M", 150, 0), ("150I", 150, 0)]
-    reads = H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l) for cg, l, _ in cases])
-    rec, _, _ = abi.pack_reads(reads)
-    flags = (rec[:, 15] & 0x8F).tolist()       # bits 4-6 carry qmean
-    assert flags == [f for _, _, f in cases], list(zip([c[0] for c in cases], flags))
+    """Decode-time CIGAR facts the kernels rely on (layout.h kRec*): they must be exact, not heuristics.
+    (cigar, l_seq, flags of the first record & 0x0F, number of records)"""
+    cases = [("150M", 150, 2, 1), ("150=", 150, 2, 1), ("150X", 150, 2, 1), ("149M", 150, 0, 1), ("10S140M", 150, 2, 1),
+             ("140M10S", 150, 2, 1), ("10S130M10S", 150, 2, 1), ("5H10S135M", 145, 2, 1), ("135M10S5H", 145, 2, 1),
+             ("5S5S140M", 150, 4, 1), ("140M5S5S", 150, 4, 1), ("2H148M", 148, 2, 1), ("10S", 10, 0, 1), ("5S5S", 10, 4, 1),
+             ("75M2I73M", 150, 2, 2), ("75M2D75M", 150, 2, 2), ("150I", 150, 0, 1)]
+    for cg, l, f, k in cases:
+        rec, _, _ = abi.pack_reads(H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l)]))
+        assert rec.shape[0] == k and (rec[0, 15] & 0x0F) == f, (cg, rec.shape[0], rec[0, 15] & 0x0F)
 
 
 def test_pack_rejects_malformed_input_with_status():
@@ -157,21 +216,37 @@ def test_pack_round_trips_synthetic_reads():
                                         seed=5, var_len=True)
     rec, blob, maxl = abi.pack_reads(reads, contigs)
     r = rec.view(REC_DTYPE).reshape(-1)
-    np.testing.assert_array_equal(r["pos"], reads.pos)
-    np.testing.assert_array_equal(r["l"] & 0x7FF, reads.l_seq)
-    qmean = (r["l"] >> 11).astype(int) | (((r["flags"].astype(int) >> 4) & 7) << 5)
-    saw_n = False
-    for i in (0, 17, 1234, reads.n_reads - 1):
+    nt16 = "=ACMGRSVTWYHKDBN"
+    # walk the records in input order (no tile order without a tile length): read i owns k_i consecutive records
+    j = 0
+    multi = 0
+    for i in range(reads.n_reads):
         l = int(reads.l_seq[i])
-        o = int(r["off8"][i]) * 8
-        nt16 = "=ACMGRSVTWYHKDBN"
         s4 = reads.seq4[reads.seq_off[i]:reads.seq_off[i] + (l + 1) // 2]
         seq = "".join(nt16[b >> 4] + nt16[b & 15] for b in s4)[:l]
         q = reads.qual[reads.qual_off[i]:reads.qual_off[i] + l].astype(int)
-        assert qmean[i] == int(q.sum()) // l
-        acgt = np.array([ch in "ACGT" for ch in seq])
-        saw_n |= bool((~acgt).any())
-        np.testing.assert_array_equal(blob[o:o + l], np.where(acgt, q, 0))   # non-ACGT bases carry quality 0
-        assert not blob[o + l:o + ((l + 31) & ~31)].any()            # zero padding = self-masking read tail
-        so = o + ((l + 31) & ~31)
-        assert bytes(blob[so:so + 16 * ((l + 31) // 32)]) == call_codes(seq)
+        cig = [(int(v) & 15, int(v) >> 4) for v in reads.cigar[reads.cigar_off[i]:reads.cigar_off[i + 1]]]
+        # match segments by the textbook walk
+        segs, qp, rp = [], 0, int(reads.pos[i])
+        for op, ln in cig:
+            if op in (0, 7, 8):
+                segs.append((qp, rp, ln)); qp += ln; rp += ln
+            elif op in (1, 4):
+                qp += ln
+            elif op in (2, 3):
+                rp += ln
+        multi += len(segs) > 1
+        for s, (qs, rs, ln) in enumerate(segs):
+            assert r["flags"][j] & 2 and int(r["pos"][j]) == rs and int(r["l"][j]) & 0x7FF == ln, (i, s)
+            assert qmean_of(r[j:j + 1])[0] == int(q.sum()) // l
+            o = int(r["off8"][j]) * 8
+            acgt = np.array([ch in "ACGT" for ch in seq[qs:qs + ln]])
+            np.testing.assert_array_equal(blob[o:o + ln], np.where(acgt, q[qs:qs + ln], 0))   # non-ACGT bases carry quality 0
+            assert not blob[o + ln:o + ((ln + 31) & ~31)].any()        # zero padding = self-masking tail
+            so = o + ((ln + 31) & ~31)
+            assert bytes(blob[so:so + 16 * ((ln + 31) // 32)]) == call_codes(seq[qs:qs + ln])
+            lr, al, nm, first = seg_fields(r[j:j + 1])
+            clips = sum(ln2 for op, ln2 in cig if op == 4)
+            assert (lr[0], al[0], nm[0], first[0]) == (l, l - clips, int(reads.nm[i]), int(s == 0))
+            j += 1
+    assert j == rec.shape[0] and multi > 50
