@@ -63,6 +63,7 @@ constexpr int kChunk = 32;          // bases per lane
 constexpr int kMaxLSeq = 1024;      // at most 32 lanes per read
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
 constexpr int kMaxSegments = 6;     // match segments a read may be served as (more: it keeps its CIGAR)
+constexpr int kMaxPieces = 12;      // device records of one read: its segments, each cut at the tile boundaries it crosses
 constexpr int kMaxSegField = 1023;  // l_seq / aligned length / NM representable in a segment record (10 bits each)
 
 // 4-bit call codes (pre-shifted: code & 0xC is the byte offset of the base's counter inside its site)

@@ -148,6 +148,38 @@ int segment_plan(const uint32_t* cg, uint32_t nc, uint32_t l, int32_t nm, int64_
   return n;
 }
 
+// The device records of a segmentable read: its match segments, each cut where it crosses a tile boundary (tile_len > 0)
+// and clipped to [0, contig_len) -- sites outside the contig are never counted.  A record then lies inside exactly
+// one tile, so no segment is ever processed by two tiles or needs an edge mask on the device.  Returns the number of
+// pieces, 0 when the read keeps its CIGAR after all (too many pieces, or its first segment has no base inside the
+// contig).
+int piece_plan(const Segment* segs, int k, int64_t pos, int64_t contig_len, int32_t tile_len, Segment* out) {
+  int n = 0;
+  for (int s = 0; s < k; ++s) {
+    int64_t qo = segs[s].qoff, ro = segs[s].roff, len = segs[s].len;
+    int64_t start = pos + ro;
+    // clip to the contig
+    if (start + len > contig_len) len = contig_len - start;
+    if (len <= 0) {
+      if (s == 0) return 0;   // the read's first record must exist (it counts the read): leave this one to the general path
+      continue;
+    }
+    if (tile_len > 0) {
+      while (len > 0) {
+        const int64_t room = tile_len - (start % tile_len);
+        const int64_t take = len < room ? len : room;
+        if (n == kMaxPieces) return 0;
+        out[n++] = Segment{(int32_t)qo, ro, (int32_t)take};
+        qo += take; ro += take; start += take; len -= take;
+      }
+    } else {
+      if (n == kMaxPieces) return 0;
+      out[n++] = Segment{(int32_t)qo, ro, (int32_t)len};
+    }
+  }
+  return n;
+}
+
 }  // namespace
 
 int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
@@ -198,7 +230,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
                     contigs->read_begin) - 1;
       c = std::max(0, std::min(c, contigs->n_contigs - 1));
     }
-    Segment segs[kMaxSegments];
+    Segment segs[kMaxSegments], pieces[kMaxPieces];
     for (int64_t i = lo; i < hi; ++i) {
       const int64_t l = r->l_seq[i];
       const int64_t nc = r->cigar_off[i + 1] - r->cigar_off[i];
@@ -218,7 +250,9 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         contig_of[i] = c;
       }
       uint32_t at = 0;
-      nseg[i] = (uint8_t)segment_plan(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->nm[i], r->pos[i], segs, &at);
+      const int k = segment_plan(r->cigar + r->cigar_off[i], (uint32_t)nc, (uint32_t)l, r->nm[i], r->pos[i], segs, &at);
+      const int64_t clen1 = have_contigs ? contigs->length[c] : INT64_MAX;
+      nseg[i] = (uint8_t)(k > 0 && r->pos[i] < clen1 ? piece_plan(segs, k, r->pos[i], clen1, tiled ? tile_len : 0, pieces) : 0);
       a += (l + 1) / 2 + l + 4 * nc + 16;
       ml = std::max<int32_t>(ml, (int32_t)l);
     }
@@ -258,7 +292,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
   std::vector<uint32_t> tile_key_in(tiled && key_out ? m : 0);
   uint32_t* const tile_key = tile_key_in.empty() ? nullptr : tile_key_in.data();
   parallel_ranges(n, [&](int, int64_t lo, int64_t hi) {
-    Segment segs[kMaxSegments];
+    Segment segs[kMaxSegments], pieces[kMaxPieces];
     for (int64_t i = lo; i < hi; ++i) {
       const uint32_t l = (uint32_t)r->l_seq[i];
       const uint32_t nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
@@ -287,14 +321,15 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         set_keys(j, r->pos[i], reflen, false);
       } else {
         uint32_t at = 0;
-        const int k = segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at);
+        const int k = piece_plan(segs, segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at), r->pos[i], clen,
+                                 tiled ? tile_len : 0, pieces);
         for (int s = 0; s < k; ++s) {
           const int64_t j = first[i] + s;
           cflags[j] = kRecSimple;
           rec_read[j] = (uint32_t)i;
           rec_seg[j] = (uint8_t)s;
-          bytes[j] = blob_bytes((uint32_t)segs[s].len, 0u);
-          set_keys(j, (int64_t)r->pos[i] + segs[s].roff, segs[s].len, true);
+          bytes[j] = blob_bytes((uint32_t)pieces[s].len, 0u);
+          set_keys(j, (int64_t)r->pos[i] + pieces[s].roff, pieces[s].len, true);
         }
       }
     }
@@ -331,7 +366,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
   off[0] = 0;
   for (int64_t d = 0; d < m; ++d) off[d + 1] = off[d] + bytes[order[d]];
   parallel_ranges(m, [&](int, int64_t lo, int64_t hi) {
-    Segment segs[kMaxSegments];
+    Segment segs[kMaxSegments], pieces[kMaxPieces];
     for (int64_t d = lo; d < hi; ++d) {
       const int64_t j = order[d];
       const int64_t i = rec_read[j];
@@ -353,8 +388,10 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       uint32_t at = 0;
       int k = 0;
       if (cflags[j] & kRecSimple) {
-        k = segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at);
-        const Segment& sg = segs[rec_seg[j]];
+        const int64_t clen = have_contigs ? contigs->length[contig_of[i]] : INT64_MAX;
+        k = piece_plan(segs, segment_plan(cg, nc, l, r->nm[i], r->pos[i], segs, &at), r->pos[i], clen,
+                       tiled ? tile_len : 0, pieces);
+        const Segment& sg = pieces[rec_seg[j]];
         q0 = (uint32_t)sg.qoff;
         len = (uint32_t)sg.len;
         pos += sg.roff;

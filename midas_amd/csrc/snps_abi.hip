@@ -278,8 +278,15 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   int32_t st = validate_contigs(contigs, reads->n_reads, &n_sites, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
 
+  // tile length: the LDS budget (4096 sites x 16 B); shorter tiles were measured and are slower.  MIDAS_SNPS_TILE_LEN
+  // overrides for experiments.  Known before the size query: the packer cuts records at tile boundaries.
+  int32_t chosen_tile_len = kTileSites;
+  if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) chosen_tile_len = atoi(e);
+  if (chosen_tile_len < 64) chosen_tile_len = 64;
+  if (chosen_tile_len > kTileSites) chosen_tile_len = kTileSites;
+  chosen_tile_len &= ~15;
   PackSummary ps;
-  st = pack_reads(reads, contigs, 0, nullptr, nullptr, nullptr, nullptr, 0, &ps, ebuf);
+  st = pack_reads(reads, contigs, chosen_tile_len, nullptr, nullptr, nullptr, nullptr, 0, &ps, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
   lap("validate + size query");
 
@@ -306,17 +313,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }                                            \
   } while (0)
 
-  // ---- tile length: the LDS budget (4096 sites x 16 B).  Shorter tiles were measured (configs[1], 10x): every
-  // tile pays fixed costs (two barriers, a pipeline restart, the halo re-read), and since a tile's reads are
-  // dealt to the waves as one stream the partly filled last round costs less than those.  MIDAS_SNPS_TILE_LEN
-  // overrides for experiments.
-  {
-    int32_t best = kTileSites;
-    if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) best = atoi(e);
-    if (best < 64) best = 64;
-    if (best > kTileSites) best = kTileSites;
-    b->tile_len = best & ~15;
-  }
+  b->tile_len = chosen_tile_len;
   const int64_t tile_len = b->tile_len;
   // ---- tile table -------------------------------------------------------------------------
   std::vector<Tile> tiles;
