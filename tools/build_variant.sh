@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a developer variant of the library next to the product one: tools/build_variant.sh <suffix> <extra hipcc flags...>
-# Use it with MIDAS_SNPS_LIBRARY=midas_amd/lib/libmidas_snps_hip_<suffix>.so (e.g. -DMIDAS_PHASE_PROFILE).
+# Use it with MIDAS_SNPS_LIBRARY=midas_amd/lib/libmidas_snps_hip_<suffix>.so (e.g. -DMIDAS_TILE_SHIFT=11 -DMIDAS_PILEUP_BLOCK=256).
 set -e
 SUF=$1; shift
 cd "$(dirname "$0")/.."
