@@ -292,6 +292,27 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
                                  int32_t n_samples, int64_t n_sites, const uint32_t* depth,
                                  const uint32_t* minor_count, int32_t threads, char* err256);
 
+/* snps_info.txt of merge_midas.py snps: GenomicSite.annotate + fetch_ref_codon + the info line of GenomicSite.write
+ * (midas/merge/snps.py:116-195) with utility.translate / index_replace (midas/utility.py:306-332) for the kept sites.
+ * keys / key_off: 'ref_id|ref_pos|ref_allele' of every table row (midas_snps_table_copy); calls / count_samples /
+ * pooled: outputs of midas_merge_sites; genes: the species' genes in the reference's order (scaffold_id, start, -end) --
+ * scaffold ids, 1-based inclusive start/end, strand '+'/'-', gene_type and gene_id strings, and the gene sequence
+ * oriented start to stop (get_gene_seq).  A site takes the first gene in that order that is not entirely behind it.  */
+typedef struct midas_merge_genes {
+  int64_t n_genes;
+  const char* const* scaffold_id;
+  const int64_t* start;
+  const int64_t* end;
+  const char* strand;          /* n_genes chars */
+  const char* const* gene_type;
+  const char* const* gene_id;
+  const char* const* seq;
+} midas_merge_genes;
+int32_t midas_merge_write_info(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
+                               const char* keys, const int64_t* key_off, const uint8_t* calls,
+                               const uint32_t* count_samples, const uint64_t* pooled, const midas_merge_genes* genes,
+                               int32_t threads, char* err256);
+
 #ifdef __cplusplus
 }
 #endif

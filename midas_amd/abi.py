@@ -220,6 +220,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
+        'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_char_p]),
         'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
@@ -250,7 +251,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
     'midas_snps_write_rows', 'midas_snps_write_table',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
-    'midas_snps_table_copy', 'midas_merge_sites', 'midas_merge_write_matrix',
+    'midas_snps_table_copy', 'midas_merge_sites', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
 
 
@@ -283,6 +284,43 @@ def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads:
     pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in cn])
     err = C.create_string_buffer(256)
     st = lib.midas_snps_write_table(path.encode(), n, ids, ns, pa, pc, int(gz_level), int(threads), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+
+
+class _Genes(C.Structure):
+    _fields_ = [("n_genes", C.c_int64), ("scaffold_id", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p),
+                ("strand", C.c_char_p), ("gene_type", C.c_void_p), ("gene_id", C.c_void_p), ("seq", C.c_void_p)]
+
+
+def write_merge_info(path: str, header_line: str, keep: np.ndarray, keys, key_off: np.ndarray, res: dict, genes: list,
+                     threads: int = 0):
+    """snps_info.txt for the kept sites (midas_merge_write_info): annotation + the per-site calls.  keys / key_off as
+    returned by read_snps_table, res = Context.merge_sites(...), genes = the species' genes in the reference's order
+    (dicts with scaffold_id, start, end, strand, gene_type, gene_id, seq)."""
+    lib = load_library()
+    keep = np.ascontiguousarray(keep, dtype=np.int64)
+    key_off = np.ascontiguousarray(key_off, dtype=np.int64)
+    kb = np.frombuffer(keys, dtype=np.uint8) if not isinstance(keys, np.ndarray) else keys
+    calls = res['major'].base if res['major'].base is not None else np.stack([res['major'], res['minor'], res['snp_type'], res['flag']], 1)
+    calls = np.ascontiguousarray(calls, dtype=np.uint8)
+    cs = np.ascontiguousarray(res['count_samples'], dtype=np.uint32)
+    pooled = np.ascontiguousarray(res['pooled'], dtype=np.uint64)
+    n = len(genes)
+
+    def strs(field):
+        vals = [str(g[field]).encode() for g in genes]
+        return (C.c_char_p * max(n, 1))(*vals)
+    sid, gty, gid, seq = strs('scaffold_id'), strs('gene_type'), strs('gene_id'), strs('seq')
+    start = np.array([g['start'] for g in genes], dtype=np.int64)
+    end = np.array([g['end'] for g in genes], dtype=np.int64)
+    strand = "".join(str(g['strand'])[:1] or '+' for g in genes).encode()
+    gs = _Genes(n, C.cast(sid, C.c_void_p), start.ctypes.data_as(C.c_void_p), end.ctypes.data_as(C.c_void_p), strand,
+                C.cast(gty, C.c_void_p), C.cast(gid, C.c_void_p), C.cast(seq, C.c_void_p))
+    err = C.create_string_buffer(256)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = lib.midas_merge_write_info(path.encode(), header_line.encode(), keep.shape[0], p(keep), p(kb), p(key_off), p(calls),
+                                    p(cs), p(pooled), C.byref(gs), int(threads), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
 

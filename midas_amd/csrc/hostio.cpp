@@ -743,4 +743,145 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
   return MIDAS_SNPS_OK;
 }
 
+namespace {
+// the standard genetic code in the reference's spelling (stop = '_'), indexed by 16*b0 + 4*b1 + b2 with T,C,A,G = 0..3
+const char kAmino[65] = "FFLLSSSSYY__CC_WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+inline int base_index(char b) { return b == 'T' ? 0 : b == 'C' ? 1 : b == 'A' ? 2 : b == 'G' ? 3 : -1; }
+inline char complement_base(char b) { return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'G' ? 'C' : b == 'C' ? 'G' : b; }
+}  // namespace
+
+int32_t midas_merge_write_info(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
+                               const char* keys, const int64_t* key_off, const uint8_t* calls,
+                               const uint32_t* count_samples, const uint64_t* pooled, const midas_merge_genes* genes,
+                               int32_t threads, char* err256) {
+  if (!path || !header_line || n_keep < 0 || !genes || genes->n_genes < 0 ||
+      (n_keep > 0 && (!keep || !keys || !key_off || !calls || !count_samples || !pooled)) ||
+      (genes->n_genes > 0 && (!genes->scaffold_id || !genes->start || !genes->end || !genes->strand || !genes->gene_type ||
+                              !genes->gene_id || !genes->seq)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  bool ok = fwrite(header_line, 1, strlen(header_line), f) == strlen(header_line);
+  const int64_t ng = genes->n_genes;
+  std::vector<size_t> seq_len((size_t)ng), sid_len((size_t)ng);
+  std::vector<char> is_cds((size_t)ng);
+  for (int64_t g = 0; g < ng; ++g) {
+    seq_len[(size_t)g] = strlen(genes->seq[g]);
+    sid_len[(size_t)g] = strlen(genes->scaffold_id[g]);
+    is_cds[(size_t)g] = strcmp(genes->gene_type[g], "CDS") == 0;
+  }
+  // Python's str comparison (code points) is byte order for the ASCII ids of a MIDAS database
+  auto cmp_id = [&](const char* a, size_t la, int64_t g) {
+    const size_t lb = sid_len[(size_t)g];
+    const int c = memcmp(a, genes->scaffold_id[g], la < lb ? la : lb);
+    return c != 0 ? c : (la < lb ? -1 : (la > lb ? 1 : 0));
+  };
+  const int64_t kRows = 1 << 13;
+  const int64_t n_chunks = (n_keep + kRows - 1) / kRows;
+  int nt = writer_threads(threads);
+  if ((int64_t)nt > n_chunks) nt = (int)std::max<int64_t>(1, n_chunks);
+  std::vector<std::string> text((size_t)n_chunks);
+  std::vector<std::atomic<int>> done((size_t)n_chunks);
+  for (auto& d : done) d = 0;
+  std::atomic<int64_t> next{0};
+  static const char* kSnpType[5] = {"NA", "mono", "bi", "tri", "quad"};
+  auto work = [&] {
+    char num[24];
+    for (;;) {
+      const int64_t ci = next.fetch_add(1);
+      if (ci >= n_chunks) return;
+      const int64_t lo = ci * kRows, hi = std::min(n_keep, lo + kRows);
+      std::string& t = text[(size_t)ci];
+      t.reserve((size_t)(hi - lo) * 96);
+      int64_t cursor = 0;   // the reference's forward cursor: a gene behind a site is behind every later site, so the
+                            // cursor before a site is simply the first gene not behind it -- chunks can start from 0
+      for (int64_t r = lo; r < hi; ++r) {
+        const int64_t i = keep[r];
+        const char* key = keys + key_off[i];
+        const size_t klen = (size_t)(key_off[i + 1] - key_off[i]);
+        // rsplit('|', 2)
+        size_t p2 = klen;
+        while (p2 > 0 && key[p2 - 1] != '|') --p2;
+        size_t p1 = p2 > 0 ? p2 - 1 : 0;
+        while (p1 > 0 && key[p1 - 1] != '|') --p1;
+        if (p2 == 0 || p1 == 0) { t.append("malformed key\n"); continue; }
+        const char* ref_id = key;
+        const size_t id_len = p1 - 1;
+        long long ref_pos = 0;
+        for (size_t q = p1; q + 1 < p2; ++q) ref_pos = ref_pos * 10 + (key[q] - '0');
+        // ---- annotate -----------------------------------------------------------------------------------
+        const char* locus = "IGR";
+        const char* gene_id = "NA";
+        char site_type[4] = "NA";
+        char aas[8] = "NA";
+        while (cursor < ng) {
+          const int c = cmp_id(ref_id, id_len, cursor);
+          if (c < 0 || (c == 0 && ref_pos < genes->start[cursor])) break;             // upstream of the next gene
+          if (c > 0 || (c == 0 && ref_pos > genes->end[cursor])) { ++cursor; continue; }   // gene is behind the site
+          locus = genes->gene_type[cursor];
+          gene_id = genes->gene_id[cursor];
+          if (is_cds[(size_t)cursor] && seq_len[(size_t)cursor] % 3 == 0) {
+            const bool plus = genes->strand[cursor] == '+';
+            const long long gpos = plus ? ref_pos - genes->start[cursor] : genes->end[cursor] - ref_pos;
+            const long long cpos = gpos % 3;
+            const long long c0 = gpos - cpos;
+            const char* sq = genes->seq[cursor];
+            if (c0 >= 0 && (size_t)(c0 + 3) <= seq_len[(size_t)cursor]) {
+              int b[3] = {base_index(sq[c0]), base_index(sq[c0 + 1]), base_index(sq[c0 + 2])};
+              if (b[0] >= 0 && b[1] >= 0 && b[2] >= 0) {
+                char aa[4];
+                int distinct = 0;
+                for (int a = 0; a < 4; ++a) {
+                  const char allele = "ACGT"[a];
+                  int bb[3] = {b[0], b[1], b[2]};
+                  bb[cpos] = base_index(plus ? allele : complement_base(allele));
+                  aa[a] = kAmino[16 * bb[0] + 4 * bb[1] + bb[2]];
+                  bool seen = false;
+                  for (int x = 0; x < a; ++x) seen |= aa[x] == aa[a];
+                  distinct += !seen;
+                }
+                snprintf(site_type, sizeof site_type, "%dD", 5 - distinct);
+                snprintf(aas, sizeof aas, "%c,%c,%c,%c", aa[0], aa[1], aa[2], aa[3]);
+              }
+            }
+          }
+          break;
+        }
+        // ---- the line -----------------------------------------------------------------------------------
+        const uint8_t* cl = calls + 4 * i;
+        auto put = [&](uint64_t v) { char* e = put_u64(num, v); t.append(num, (size_t)(e - num)); };
+        put((uint64_t)(i + 1)); t.push_back('\t');
+        t.append(ref_id, id_len); t.push_back('\t');
+        put((uint64_t)ref_pos); t.push_back('\t');
+        t.append(key + p2, klen - p2); t.push_back('\t');
+        if (cl[0] < 4) t.push_back("ACGT"[cl[0]]); else t.append("NA");
+        t.push_back('\t');
+        if (cl[1] < 4) t.push_back("ACGT"[cl[1]]); else t.append("NA");
+        t.push_back('\t');
+        put(count_samples[i]); t.push_back('\t');
+        for (int a = 0; a < 4; ++a) { put(pooled[4 * i + a]); t.push_back('\t'); }
+        t.append(locus); t.push_back('\t');
+        t.append(gene_id); t.push_back('\t');
+        t.append(kSnpType[cl[2] < 5 ? cl[2] : 0]); t.push_back('\t');
+        t.append(site_type); t.push_back('\t');
+        t.append(aas); t.push_back('\n');
+      }
+      done[(size_t)ci] = 1;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(work);
+  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+    while (!done[(size_t)ci].load()) std::this_thread::yield();
+    std::string& t = text[(size_t)ci];
+    ok = fwrite(t.data(), 1, t.size(), f) == t.size();
+    std::string().swap(t);
+  }
+  if (!ok) next = n_chunks;
+  for (auto& x : th) x.join();
+  if (fclose(f) != 0) ok = false;
+  if (!ok) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  return MIDAS_SNPS_OK;
+}
+
 }  // extern "C"

@@ -57,26 +57,10 @@ def merge_species(species, args, ctx):
     threads = int(args.get('threads', 1) or 1)
     abi.write_merge_matrix(outdir + '/snps_freq.txt', header, keep, res['depth'], res['minor_count'], threads=threads)
     abi.write_merge_matrix(outdir + '/snps_depth.txt', header, keep, res['depth'], None, threads=threads)
-    # snps_info.txt: annotation of the kept sites (forward cursor over the sorted genes) + the per-site calls
-    alle = ('A', 'C', 'G', 'T')
-    major, minor, snp_type = res['major'], res['minor'], res['snp_type']
-    count_samples, pooled = res['count_samples'], res['pooled']
-    lines = []
-    for i in keep.tolist():
-        key = bytes(keys[key_off[i]:key_off[i + 1]]).decode()
-        ref_id, ref_pos, ref_allele = key.rsplit('|', 2)
-        mj, mn = int(major[i]), int(minor[i])
-        locus_type, gene_id, site_type, amino_acids = genes.lookup(ref_id, int(ref_pos))
-        pc = pooled[i]
-        lines.append('\t'.join((str(i + 1), ref_id, str(int(ref_pos)), ref_allele,
-                                alle[mj] if mj < 4 else 'NA', alle[mn] if mn < 4 else 'NA', str(int(count_samples[i])),
-                                str(int(pc[0])), str(int(pc[1])), str(int(pc[2])), str(int(pc[3])),
-                                locus_type, replace_none(gene_id), replace_none(abi.SNP_TYPE_NAMES[int(snp_type[i])]),
-                                replace_none(site_type), replace_none(amino_acids))))
-    with open(outdir + '/snps_info.txt', 'w') as f:
-        f.write('\t'.join(INFO_FIELDS) + '\n')
-        if lines:
-            f.write('\n'.join(lines) + '\n')
+    # snps_info.txt: annotation of the kept sites (the reference's forward cursor over the sorted genes, codon
+    # degeneracy) + the per-site calls, formatted natively
+    abi.write_merge_info(outdir + '/snps_info.txt', '\t'.join(INFO_FIELDS) + '\n', keep, keys, key_off, res, genes.genes,
+                         threads=threads)
     return n, len(keep), res['kernel_ms']
 
 

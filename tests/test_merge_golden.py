@@ -98,3 +98,24 @@ def test_device_merge_matches_the_reference_vectors(vectors):
                     assert mafs == ref[4]
                     assert int(res['count_samples'][i]) == ref[5]
                     assert [None, 'min_prev', 'snp_type'][int(res['flag'][i])] == (None if ref[7] == 'keep' else ref[7])
+
+
+def test_native_info_writer_matches_the_reference_text(vectors, tmp_path):
+    """midas_merge_write_info (host C++: annotation + info lines) against the reference's own snps_info text."""
+    import numpy as np
+    from midas_amd import abi
+    code = {None: 255, 'A': 0, 'C': 1, 'G': 2, 'T': 3}
+    types = [None, 'mono', 'bi', 'tri', 'quad']
+    for gi, g in enumerate(vectors['groups']):
+        keys = "".join(g['keys']).encode()
+        key_off = np.zeros(len(g['keys']) + 1, np.int64)
+        key_off[1:] = np.cumsum([len(k.encode()) for k in g['keys']])
+        pooled = np.array([[sum(site[s][a] for s in range(g['n_samples'])) for a in range(4)] for site in g['counts']], np.uint64)
+        for vi, v in enumerate(g['variants']):
+            calls = np.array([[code[s[0]], code[s[1]], types.index(s[2]), 0 if s[7] == 'keep' else 1] for s in v['sites']], np.uint8)
+            res = dict(major=calls[:, 0], minor=calls[:, 1], snp_type=calls[:, 2], flag=calls[:, 3],
+                       count_samples=np.array([s[5] for s in v['sites']], np.uint32), pooled=pooled)
+            keep = np.nonzero(calls[:, 3] == 0)[0]
+            out = str(tmp_path / ("info_%d_%d.txt" % (gi, vi)))
+            abi.write_merge_info(out, "H\n", keep, keys, key_off, res, g['genes'], threads=3)
+            assert open(out).read() == "H\n" + v['info']
