@@ -303,3 +303,89 @@ def _subset(reads, sel):
     return abi.ReadsSoA(pos=reads.pos[sel], mapq=reads.mapq[sel], flag=reads.flag[sel], nm=reads.nm[sel],
                         l_seq=reads.l_seq[sel], seq_off=seq_off, qual_off=qual_off, cigar_off=cigar_off,
                         seq4=seq4, qual=qual, cigar=cigar)
+
+
+def _random_cigar(rng, l):
+    """A CIGAR for a query of l bases drawn from a grammar that covers what the packer must tell apart: regular
+    (clips at the ends around M/=/X/I/D/N), and irregular in every way it knows (P ops, several clips at one end, a clip
+    in the middle, hard clips, zero-length ops, a query length shorter than l_seq, more segments than it serves)."""
+    kind = rng.random()
+    ops = []
+    q = 0
+
+    def match(n):
+        nonlocal q
+        ops.append((rng.choice([0, 0, 0, 7, 8]), n))
+        q += n
+    lead = rng.randint(0, l // 5) if rng.random() < 0.3 else 0
+    trail = rng.randint(0, l // 5) if rng.random() < 0.3 else 0
+    if rng.random() < 0.1:
+        ops.append((5, rng.randint(1, 9)))                       # H
+    if lead:
+        if kind > 0.97:
+            a = rng.randint(0, lead)
+            ops += [(4, a), (4, lead - a)]                       # two S at one end (maybe zero-length)
+        else:
+            ops.append((4, lead))
+        q += lead
+    body = l - lead - trail
+    n_events = rng.choice([0, 0, 0, 1, 1, 2, 3, 8]) if kind < 0.9 else rng.choice([1, 2])
+    cuts = sorted(rng.sample(range(1, body), min(n_events, max(0, body - 1)))) if body > 1 else []
+    prev = 0
+    for c in cuts + [body]:
+        if c - prev > 0:
+            match(c - prev)
+        prev = c
+        if c != body:
+            ev = rng.random()
+            if ev < 0.35:
+                ins = min(rng.randint(1, 4), body - c - 1) if body - c > 1 else 0
+                if ins > 0:
+                    ops.append((1, ins)); q += ins; prev = c + ins
+            elif ev < 0.7:
+                ops.append((2, rng.randint(1, 6)))
+            elif ev < 0.85:
+                ops.append((3, rng.choice([1, 50, 4000, 9000])))     # N skip, possibly across tiles
+            elif ev < 0.92:
+                ops.append((6, rng.randint(1, 3)))                    # P
+            elif ev < 0.96:
+                ops.append((4, 0) if rng.random() < 0.5 else (5, 2))  # a clip in the middle (zero-length S, or H)
+            else:
+                ops.append((2, 0))                                    # zero-length D
+    # the walk above may have consumed fewer query bases than planned when insertions were clipped
+    if trail:
+        ops.append((4, trail)); q += trail
+    if rng.random() < 0.1:
+        ops.append((5, rng.randint(1, 9)))
+    if q < l:
+        if kind > 0.94 and kind <= 0.97:
+            pass                                                      # a CIGAR that covers fewer bases than l_seq
+        else:
+            ops.insert(len(ops) - (1 if trail else 0) - (1 if ops and ops[-1][0] == 5 else 0), (0, l - q))
+    return [(op, n) for op, n in ops], sum(n for op, n in ops if op in (0, 1, 4, 7, 8))
+
+
+@pytest.mark.parametrize("seed", [99, 7, 2026])
+def test_random_cigar_grammar_matches_oracle(hip_ctx, seed):
+    import random
+    rng = random.Random(seed)
+    L = 30000
+    reads = []
+    for _ in range(6000):
+        l = rng.choice([150, 150, 150, 100, 60, 33, rng.randint(20, 400)])
+        while True:
+            cigar, qlen = _random_cigar(rng, l)
+            if qlen <= l and any(op in (0, 7, 8) and n > 0 for op, n in cigar):
+                break
+        pos = rng.choice([rng.randint(0, L - 1), rng.randint(4000, 4200), rng.randint(L - 300, L - 1), rng.randint(8100, 8250)])
+        seq = "".join(rng.choice("ACGTACGTACGTN") for _ in range(l))
+        qual = [rng.choice([40, 38, 35, 31, 30, 29, 12, 2]) for _ in range(l)]
+        reads.append(dict(pos=pos, cigar=cigar, seq=seq, qual=qual, nm=rng.choice([0, 1, 2, 5, 9, 30, 1023, 1024, 3000]),
+                          mapq=rng.choice([42, 42, 30, 20, 19, 3])))
+    reads.sort(key=lambda r: r['pos'])
+    soa = H.reads_from_dicts(reads)
+    ref = "".join(rng.choice("ACGTacgtN") for _ in range(L))
+    contig = H.single_contig(L, len(reads), ref)
+    for args in (dict(abi.DEFAULT_ARGS), dict(abi.DEFAULT_ARGS, baseq=0, mapid=80.0, aln_cov=0.3, readq=10, mapq=0)):
+        counts, stats = _assert_same(hip_ctx, abi.Thresholds.from_args(args), contig, soa)
+        assert int(stats[0, abi.STAT_MAPPED_READS]) > 500
