@@ -313,6 +313,19 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
                                const uint32_t* count_samples, const uint64_t* pooled, const midas_merge_genes* genes,
                                int32_t threads, char* err256);
 
+/* ---- run_midas.py genes: reads per pangenome gene (SURVEY 8f "next" #4) -----------------------------------------
+ * Replaces count_mapped_bp's pass over the BAM (midas/run/genes.py:165-180) for every gene at once: per gene the number
+ * of alignments (aligned_reads), of alignments passing keep_read (genes.py:148-163 -- the same predicate as the snps
+ * path, thresholds mapid / readq / mapq / aln_cov of `thr`; baseq unused) and depth = the sum, IN BAM ORDER, of
+ * len(query_alignment_sequence) / float(gene_length) over the kept ones (fp64, bit-identical to the reference's
+ * running sum).  reads: the alignments in BAM order (seq4 may be NULL: only l_seq, CIGAR, NM, QUAL and MAPQ are read);
+ * ref_id[i]: index of read i's gene in gene_length.  A record the reference would raise on returns
+ * MIDAS_SNPS_ERR_READ_NO_SEQ / _NO_NM / _ZERO_ALIGN / _NO_QUAL with the lowest offending read in
+ * midas_snps_last_error_read.  out_kernel_ms (nullable): device time of the kernel.                                  */
+int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads,
+                          const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length, int64_t* out_aligned,
+                          int64_t* out_mapped, double* out_depth, float* out_kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,6 +228,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_table_rows': (i64, [vp]),
         'midas_snps_table_key_bytes': (i64, [vp]),
         'midas_snps_table_copy': (i32, [vp, vp, vp, vp]),
+        'midas_genes_count': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Reads), vp, i64, vp, vp, vp, vp, C.POINTER(C.c_float)]),
         'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 5 + [C.POINTER(C.c_float)]),
     })
     for name, (res, args) in sig.items():
@@ -251,7 +252,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
     'midas_snps_write_rows', 'midas_snps_write_table',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
-    'midas_snps_table_copy', 'midas_merge_sites', 'midas_merge_write_info', 'midas_merge_write_matrix',
+    'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
 
 
@@ -482,6 +483,20 @@ class Context:
                                          stats.ctypes.data_as(C.c_void_p))
         self._check(st)
         return counts, allele, stats
+
+    def genes_count(self, thr: Thresholds, reads: "ReadsSoA", ref_id, gene_length):
+        """midas_genes_count(): per gene (aligned_reads i64, mapped_reads i64, depth f64, kernel_ms)."""
+        rid = np.ascontiguousarray(ref_id, dtype=np.int32)
+        gl = np.ascontiguousarray(gene_length, dtype=np.int64)
+        n = gl.shape[0]
+        aligned, mapped, depth = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float64)
+        ms = C.c_float(0)
+        r = reads._c()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_genes_count(self._h, C.byref(thr), C.byref(r), p(rid), n, p(gl), p(aligned), p(mapped), p(depth),
+                                         C.byref(ms))
+        self._check(st)
+        return aligned, mapped, depth, float(ms.value)
 
     def merge_sites(self, prm: "MergeParams", sample_counts, mean_depth):
         """midas_merge_sites(): sample_counts = list of [n_sites,4] uint32 arrays (one per sample).

@@ -51,6 +51,9 @@ struct FilterTables {
   int32_t min_align[kMaxLSeq + 1];
 };
 
+// host: tabulate the two thresholds for lengths 1..max_l (snps_abi.hip)
+void build_filter_tables(double mapid, double aln_cov, int32_t max_l, FilterTables* t);
+
 struct PileupParams {
   const ReadRec* rec;
   const uint8_t* blob;

@@ -58,38 +58,7 @@ struct midas_snps_batch {
   bool ran = false;
 };
 
-namespace {
-
-int32_t fail(midas_snps_ctx* ctx, int32_t st, const std::string& msg) {
-  if (ctx) {
-    ctx->err = msg;
-  }
-  return st;
-}
-
-int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
-  char buf[512];
-  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-  (void)hipGetLastError();
-  return fail(ctx, e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP, buf);
-}
-
-#define HIP_TRY(ctx, call)                                   \
-  do {                                                       \
-    hipError_t e__ = (call);                                 \
-    if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
-  } while (0)
-
-// tile ranges are double-buffered by run parity: [rbinv0][rend0][rbinv1][rend1]
-// (each tile has three ranges, slots 3t..3t+2: see index_reads.hip)
-uint32_t* work_rbinv(midas_snps_batch* b, int par) { return reinterpret_cast<uint32_t*>(b->d_work) + (size_t)par * 6 * b->n_tiles; }
-uint32_t* work_rend(midas_snps_batch* b, int par) { return work_rbinv(b, par) + 3 * b->n_tiles; }
-unsigned long long* work_stats(midas_snps_batch* b) {
-  size_t off = ((size_t)b->n_tiles * 48 + 15) & ~(size_t)15;
-  return reinterpret_cast<unsigned long long*>(b->d_work + off);
-}
-unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
-
+namespace midas {
 // The reference's own expressions (midas/run/snps.py:148, 157), evaluated in IEEE fp64 exactly as
 // Python does, tabulated over every length a batch can contain.  Both predicates are monotone in
 // the integer being tested, so the least passing value is found by bisection.
@@ -132,6 +101,40 @@ void build_filter_tables(double mapid, double aln_cov, int32_t max_l, FilterTabl
     }
   }
 }
+
+}  // namespace midas
+
+namespace {
+
+int32_t fail(midas_snps_ctx* ctx, int32_t st, const std::string& msg) {
+  if (ctx) {
+    ctx->err = msg;
+  }
+  return st;
+}
+
+int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  return fail(ctx, e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP, buf);
+}
+
+#define HIP_TRY(ctx, call)                                   \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+  } while (0)
+
+// tile ranges are double-buffered by run parity: [rbinv0][rend0][rbinv1][rend1]
+// (each tile has three ranges, slots 3t..3t+2: see index_reads.hip)
+uint32_t* work_rbinv(midas_snps_batch* b, int par) { return reinterpret_cast<uint32_t*>(b->d_work) + (size_t)par * 6 * b->n_tiles; }
+uint32_t* work_rend(midas_snps_batch* b, int par) { return work_rbinv(b, par) + 3 * b->n_tiles; }
+unsigned long long* work_stats(midas_snps_batch* b) {
+  size_t off = ((size_t)b->n_tiles * 48 + 15) & ~(size_t)15;
+  return reinterpret_cast<unsigned long long*>(b->d_work + off);
+}
+unsigned long long* work_err(midas_snps_batch* b) { return work_stats(b) + (size_t)b->n_species * MIDAS_STATS; }
 
 const char* read_err_name(int32_t st) {
   switch (st) {

@@ -1,0 +1,268 @@
+"""MI355X-native `run_midas.py genes` pipeline: the host side (SURVEY.md 8f "next" #4).
+
+Same steps, files and numbers as /root/reference/midas/run/genes.py -- pangenome database from the species' centroid
+genes, bowtie2 alignment, then per gene: aligned reads, reads passing the read filter, depth, copy number relative to
+the median depth of the species' marker genes -- with the pass over the BAM (count_mapped_bp, :165-180) done by the
+device through the C-ABI (midas_genes_count): every read of a gene is filtered and its aligned length / gene length
+added to the gene's depth in BAM order, so the fp64 sums are the reference's bit for bit.  No CPU fallback for it.
+"""
+
+import csv
+import os
+import shutil
+import subprocess
+import sys
+from collections import defaultdict
+from time import time
+
+import numpy as np
+
+from midas_amd import abi, fasta, utility
+from midas_amd.run.snps import select_species
+
+
+class Species:
+    """A species of the sample: its pangenome files and, after the pass, its summary numbers."""
+
+    def __init__(self, id):
+        self.id = id
+        self.paths = {}
+        self.genes = []                      # depth of every gene, in pangenome order
+        self.pangenome_size = 0
+        self.aligned_reads = 0
+        self.mapped_reads = 0
+        self.markers = defaultdict(float)    # marker family -> summed depth of its genes
+        self.covered_genes = 0
+        self.mean_coverage = 0
+        self.fraction_covered = 0
+        self.marker_coverage = 0
+
+    def init_ref_db(self, ref_db):
+        """centroids.ffn / cluster_info.txt / gene_info.txt of the species, plain or .gz (the .gz wins when both exist)."""
+        self.dir = os.path.join(ref_db, 'pan_genomes', self.id)
+        for name in ('centroids.ffn', 'cluster_info.txt', 'gene_info.txt'):
+            for suffix in ('', '.gz'):
+                candidate = os.path.join(self.dir, name + suffix)
+                if os.path.isfile(candidate):
+                    self.paths[name] = candidate
+
+
+class Gene:
+    """A centroid gene of a pangenome."""
+    __slots__ = ('id', 'species_id', 'length', 'aligned_reads', 'mapped_reads', 'depth', 'copies', 'marker_id')
+
+    def __init__(self, id, species_id=None, length=0):
+        self.id = id
+        self.species_id = species_id
+        self.length = length
+        self.aligned_reads = self.mapped_reads = 0
+        self.depth = self.copies = 0.0
+        self.marker_id = None
+
+
+def initialize_species(args):
+    """{species_id: Species}: chosen now (and written to genes/species.txt) when the database is being built, else read
+    back from that file (genes.py:33-50)."""
+    listing = os.path.join(args['outdir'], 'genes', 'species.txt')
+    if args['build_db']:
+        ids = select_species(args, 'pan_genomes')
+        with open(listing, 'w') as handle:
+            handle.writelines(i + '\n' for i in ids)
+    elif os.path.isfile(listing):
+        with open(listing) as handle:
+            ids = [line.rstrip() for line in handle]
+    else:
+        ids = []
+    species = {i: Species(i) for i in ids}
+    for sp in species.values():
+        sp.init_ref_db(args['db'])
+    return species
+
+
+def _centroids(sp):
+    if 'centroids.ffn' not in sp.paths:
+        sys.exit("\nError: Could not locate the pangenome of species: %s\n" % sp.id)
+    with utility.iopen(sp.paths['centroids.ffn']) as handle:
+        for rec_id, rec_seq in fasta.parse(handle):
+            yield rec_id, rec_seq
+
+
+def initialize_genes(args, species):
+    """{gene_id: Gene} in pangenome order (species by species, genes in FASTA order), with lengths and -- from
+    marker_genes/phyeco.map -- the marker family of the genes that are universal single-copy markers (genes.py:63-85)."""
+    genes = {}
+    for sp in species.values():
+        for gid, seq in _centroids(sp):
+            genes[gid] = Gene(gid, sp.id, len(seq))
+            sp.pangenome_size += 1
+    with utility.iopen(os.path.join(args['db'], 'marker_genes', 'phyeco.map')) as handle:
+        for row in csv.DictReader(handle, delimiter='\t'):
+            gene = genes.get(row['gene_id'])
+            if gene is not None:
+                gene.marker_id = row['marker_id']
+    return genes
+
+
+def _shell(args, command):
+    args['log'].write('command: ' + command + '\n')
+    process = subprocess.Popen(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    utility.check_exit_code(process, command)
+
+
+def build_pangenome_db(args, species):
+    """genes/temp/pangenomes.fa (+ .map: gene -> species) from the centroid genes, then `bowtie2-build` (genes.py:87-116)."""
+    temp = os.path.join(args['outdir'], 'genes', 'temp')
+    n_seqs = n_bases = 0
+    with open(os.path.join(temp, 'pangenomes.fa'), 'w') as fa, open(os.path.join(temp, 'pangenomes.map'), 'w') as mp:
+        for sp in species.values():
+            for gid, seq in _centroids(sp):
+                fa.write('>%s\n%s\n' % (gid, seq.upper()))
+                mp.write('%s\t%s\n' % (gid, sp.id))
+                n_seqs += 1
+                n_bases += len(seq)
+    print("  total species: %s\n  total genes: %s\n  total base-pairs: %s" % (len(species), n_seqs, n_bases))
+    if not args.get('bowtie2-build'):
+        sys.exit("\nError: bowtie2-build not found on PATH (needed for --build_db; the aligner is not part of this build)\n")
+    _shell(args, ' '.join(str(x) for x in (args['bowtie2-build'], '--threads', args['threads'],
+                                           os.path.join(temp, 'pangenomes.fa'), os.path.join(temp, 'pangenomes'))) + ' ')
+
+
+def pangenome_align(args):
+    """bowtie2 (no unaligned reads) | samtools view -b > genes/temp/pangenomes.bam, unsorted, with the reference's
+    switches (genes.py:118-146)."""
+    if not args.get('bowtie2') or not args.get('samtools'):
+        sys.exit("\nError: bowtie2 / samtools not found on PATH (needed for --align; the aligner is not part of this build)\n")
+    temp = os.path.join(args['outdir'], 'genes', 'temp')
+    bt2 = [args['bowtie2'], '--no-unal', '-x', os.path.join(temp, 'pangenomes')]
+    if args['max_reads']:
+        bt2 += ['-u', args['max_reads']]
+    if args['trim']:
+        bt2 += ['--trim3', args['trim']]
+    bt2 += ['--%s%s' % (args['speed'], '-local' if args['mode'] == 'local' else ''), '--threads', args['threads'],
+            '-f' if args['file_type'] == 'fasta' else '-q']
+    if args['m2']:
+        bt2 += ['-1', args['m1'], '-2', args['m2']]
+    elif args['interleaved']:
+        bt2 += ['--interleaved', args['m1']]
+    else:
+        bt2 += ['-U', args['m1']]
+    view = [args['samtools'], 'view', '--threads', args['threads'], '-b', '-', '>', os.path.join(temp, 'pangenomes.bam')]
+    _shell(args, ' '.join(str(x) for x in bt2) + ' | ' + ' '.join(str(x) for x in view))
+    print("  finished aligning")
+
+
+def fold_counts(species, genes, gene_ids, aligned, mapped, depth):
+    """The per-gene device results into Gene / Species, then the species summaries of genes.py:182-199: covered genes,
+    mean depth over the covered ones (np.mean over the depths in pangenome order, like the reference), fraction covered."""
+    for k, gid in enumerate(gene_ids):
+        gene = genes[gid]
+        gene.aligned_reads, gene.mapped_reads, gene.depth = int(aligned[k]), int(mapped[k]), float(depth[k])
+        sp = species[gene.species_id]
+        sp.aligned_reads += gene.aligned_reads
+        sp.mapped_reads += gene.mapped_reads
+    for gene in genes.values():
+        species[gene.species_id].genes.append(gene.depth)
+    for sp in species.values():
+        covered = [d for d in sp.genes if d > 0]
+        sp.covered_genes = len(covered)
+        sp.mean_coverage = np.mean(covered) if covered else 0
+        sp.fraction_covered = sp.covered_genes / float(sp.pangenome_size)
+
+
+def count_mapped_bp(args, species, genes, ctx):
+    """genes.py:165-199 with the BAM pass on the device: native BAM decode, one midas_genes_count call."""
+    bam_path = os.path.join(args['outdir'], 'genes', 'temp', 'pangenomes.bam')
+    try:
+        ref_names, ref_lens, refid, reads = abi.read_bam(bam_path)
+    except abi.MidasSnpsError as e:
+        sys.exit("\nError: could not read %s\n%s\n" % (bam_path, e.message))
+    missing = [n for n in ref_names if n not in genes]
+    if missing:    # the reference: KeyError in genes[bamfile.getrname(...)] at the first read of such a gene
+        used = set(np.unique(refid).tolist())
+        bad = [n for i, n in enumerate(ref_names) if n not in genes and i in used]
+        if bad:
+            sys.exit("\nError: gene '%s' of the BAM header is not in the pangenome database\n" % bad[0])
+    gene_ids = list(ref_names)
+    lengths = np.array([genes[n].length if n in genes else ref_lens[i] for i, n in enumerate(ref_names)], dtype=np.int64)
+    try:
+        aligned, mapped, depth, ms = ctx.genes_count(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **{
+            k: args[k] for k in ('mapid', 'readq', 'mapq', 'aln_cov')})), reads, refid, lengths)
+    except abi.MidasSnpsError as e:
+        where = " [read %d of the BAM]" % e.read_index if e.read_index >= 0 else ""
+        sys.exit("\nError: %s%s\n" % (e.message, where))
+    known = [k for k, n in enumerate(gene_ids) if n in genes]
+    fold_counts(species, genes, [gene_ids[k] for k in known], aligned[known], mapped[known], depth[known])
+    print("  total aligned reads: %s" % sum(sp.aligned_reads for sp in species.values()))
+    print("  total mapped reads: %s" % sum(sp.mapped_reads for sp in species.values()))
+    return ms
+
+
+def normalize(args, species, genes):
+    """Copy number of a gene = its depth over the median depth of the species' marker families (genes.py:201-215)."""
+    for gene in genes.values():
+        if gene.marker_id is not None:
+            species[gene.species_id].markers[gene.marker_id] += gene.depth
+    for sp in species.values():
+        sp.marker_coverage = np.median(list(sp.markers.values()))      # nan (with numpy's warning) when there are none
+    for gene in genes.values():
+        mc = species[gene.species_id].marker_coverage
+        if mc > 0:
+            gene.copies = gene.depth / mc
+
+
+def write_results(args, species, genes):
+    """genes/output/<species>.genes.gz (genes in sorted id order) and genes/summary.txt (genes.py:217-244)."""
+    handles = {}
+    for sp in species.values():
+        handles[sp.id] = utility.iopen(os.path.join(args['outdir'], 'genes', 'output', '%s.genes.gz' % sp.id), 'w')
+        handles[sp.id].write('gene_id\tcount_reads\tcoverage\tcopy_number\n')
+    for gid in sorted(genes):
+        gene = genes[gid]
+        handles[gene.species_id].write('%s\t%s\t%s\t%s\n' % (gene.id, gene.mapped_reads, gene.depth, gene.copies))
+    for handle in handles.values():
+        handle.close()
+    fields = ('pangenome_size', 'covered_genes', 'fraction_covered', 'mean_coverage', 'marker_coverage', 'aligned_reads',
+              'mapped_reads')
+    with open(os.path.join(args['outdir'], 'genes', 'summary.txt'), 'w') as handle:
+        handle.write('\t'.join(('species_id',) + fields) + '\n')
+        for sp in species.values():
+            handle.write('\t'.join([sp.id] + [str(getattr(sp, f)) for f in fields]) + '\n')
+
+
+def pangenome_coverage(args, species, genes):
+    try:
+        with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
+            ms = count_mapped_bp(args, species, genes, ctx)
+    except abi.MidasSnpsError as e:
+        sys.exit("\nError: %s\n" % e.message)
+    normalize(args, species, genes)
+    write_results(args, species, genes)
+    return ms
+
+
+def remove_tmp(args):
+    shutil.rmtree(os.path.join(args['outdir'], 'genes', 'temp'))
+
+
+def run_pipeline(args):
+    def timed(title, log_title, fn, *a):
+        start = time()
+        print("\n" + title)
+        if log_title:
+            args['log'].write("\n" + log_title + "\n")
+        out = fn(*a)
+        print("  %s minutes" % round((time() - start) / 60, 2))
+        print("  %s Gb maximum memory" % utility.max_mem_usage())
+        return out
+
+    species = timed("Reading reference data", None, initialize_species, args)
+    genes = initialize_genes(args, species)
+    if args['build_db']:
+        timed("Building pangenome database", "Building pangenome database", build_pangenome_db, args, species)
+    if args['align']:
+        args['file_type'] = utility.auto_detect_file_type(args['m1'])
+        timed("Aligning reads to pangenomes", "Aligning reads to pangenomes", pangenome_align, args)
+    if args['cov']:
+        timed("Computing coverage of pangenomes", "Computing coverage of pangenomes", pangenome_coverage, args, species, genes)
+    if args['remove_temp']:
+        remove_tmp(args)

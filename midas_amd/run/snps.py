@@ -59,7 +59,7 @@ class Contig:
         self.species_id = species_id
 
 
-def select_species(args):
+def select_species(args, per_species='rep_genomes'):
     """Only --species_id can be honoured here: --species_cov / --species_topn read the abundance profile written by
     `run_midas.py species` (midas/run/species.py:191-227), a pipeline outside this build."""
     wanted = args.get('species_id')
@@ -67,7 +67,7 @@ def select_species(args):
         sys.exit("\nError: this build only selects species with --species_id "
                  "(--species_cov/--species_topn need `run_midas.py species`, which is out of scope)\n")
     for sp in wanted:
-        if not os.path.isdir(os.path.join(args['db'], 'rep_genomes', sp)):
+        if not os.path.isdir(os.path.join(args['db'], per_species, sp)):
             sys.exit("\nError: Species id not found in database: %s\n" % sp)
     return list(wanted)
 

@@ -366,3 +366,121 @@ def make_merge_dataset(root, n_samples=4, n_sites=5000, n_contigs=3, species_id=
     keys = ["%s|%d|%s" % (cid, p + 1, b) for cid, seq in zip(ids, seqs) for p, b in enumerate(seq)]
     return dict(db=db, samples=samples, species_id=species_id, keys=keys, counts=counts_all, contig_ids=ids,
                 contig_seqs=seqs)
+
+
+def take_reads(reads, order):
+    """The reads `order` picks, in that order (ragged columns regathered)."""
+    order = np.asarray(order, dtype=np.int64)
+
+    def ragged(data, off):
+        n = (off[1:] - off[:-1])[order]
+        new_off = np.zeros(order.size + 1, dtype=np.int64)
+        np.cumsum(n, out=new_off[1:])
+        src = np.repeat(off[:-1][order] - new_off[:-1], n) + np.arange(new_off[-1])
+        return data[src], new_off
+    seq4, seq_off = ragged(reads.seq4, reads.seq_off)
+    qual, qual_off = ragged(reads.qual, reads.qual_off)
+    cigar, cigar_off = ragged(reads.cigar, reads.cigar_off)
+    return ReadsSoA(pos=reads.pos[order], mapq=reads.mapq[order], flag=reads.flag[order], nm=reads.nm[order],
+                    l_seq=reads.l_seq[order], seq_off=seq_off, qual_off=qual_off, cigar_off=cigar_off,
+                    seq4=seq4, qual=qual, cigar=cigar)
+
+
+def concat_reads(parts):
+    def offsets(name):
+        sizes = np.concatenate([np.diff(getattr(p, name)) for p in parts]) if parts else np.zeros(0, np.int64)
+        off = np.zeros(sizes.size + 1, dtype=np.int64)
+        np.cumsum(sizes, out=off[1:])
+        return off
+    cat = lambda name: np.concatenate([getattr(p, name) for p in parts])
+    return ReadsSoA(pos=cat('pos'), mapq=cat('mapq'), flag=cat('flag'), nm=cat('nm'), l_seq=cat('l_seq'),
+                    seq_off=offsets('seq_off'), qual_off=offsets('qual_off'), cigar_off=offsets('cigar_off'),
+                    seq4=cat('seq4'), qual=cat('qual'), cigar=cat('cigar'))
+
+
+N_MARKER_FAMILIES = 15
+
+
+def make_pangenome_dataset(n_species=3, genes_per_species=120, n_reads=20000, read_len=150, seed=BASE_SEED + 9,
+                           gene_lengths=(420, 900, 1500, 3000), var_len=True, silent_fraction=0.15):
+    """What `run_midas.py genes --build_db --align` leaves for --call_genes, in memory: pangenomes of n_species species
+    (centroid genes of a few lengths; ids sort differently from pangenome order), 15 marker families per species (one
+    family with two genes), reads over the genes in aligner (= random) order, a share of the genes without reads.
+    -> dict(species_ids, gene_ids, gene_species, gene_seq, marker, refid, reads)."""
+    rng = np.random.default_rng(seed)
+    per_class = max(1, genes_per_species // len(gene_lengths))
+    species_ids = ["Species_%05d" % (s + 1) for s in range(n_species)]
+    gene_ids, gene_species, gene_seq = [], [], []
+    first = {}                                        # (species, class) -> global index of its first gene
+    sets = []
+    for c, glen in enumerate(gene_lengths):
+        contigs, reads = make_dataset(n_species=n_species, contigs_per_species=per_class, contig_len=int(glen),
+                                      n_reads=max(1, n_reads // len(gene_lengths)), read_len=min(read_len, int(glen) - 9),
+                                      seed=seed + 31 * (c + 1), var_len=var_len)
+        sets.append((contigs, reads))
+    for s in range(n_species):
+        for c, (contigs, _) in enumerate(sets):
+            first[(s, c)] = len(gene_ids)
+            off = contigs.site_offsets()
+            for k in range(per_class):
+                j = s * per_class + k
+                gene_ids.append("%s.peg.%d" % (species_ids[s][-5:], len(gene_ids) - first[(s, 0)] + 1))
+                gene_species.append(species_ids[s])
+                gene_seq.append(bytes(contigs.ref[off[j]:off[j + 1]]).decode())
+    parts, refids = [], []
+    for c, (contigs, reads) in enumerate(sets):
+        local = np.repeat(np.arange(contigs.n_contigs, dtype=np.int64), np.diff(contigs.read_begin))
+        base = np.array([first[(j // per_class, c)] + j % per_class for j in range(contigs.n_contigs)], dtype=np.int64)
+        parts.append(reads)
+        refids.append(base[local])
+    reads, refid = concat_reads(parts), np.concatenate(refids)
+    silent = rng.random(len(gene_ids)) < silent_fraction
+    order = rng.permutation(refid.size)
+    order = order[~silent[refid[order]]]
+    reads, refid = take_reads(reads, order), refid[order].astype(np.int32)
+    marker = {}
+    for s in range(n_species):
+        mine = [g for g, sp in zip(gene_ids, gene_species) if sp == species_ids[s]]
+        picks = rng.choice(len(mine), size=min(len(mine), N_MARKER_FAMILIES + 1), replace=False)
+        for m, g in enumerate(picks):
+            marker[mine[int(g)]] = "B%06d" % (min(m, N_MARKER_FAMILIES - 1) + 1)
+    return dict(species_ids=species_ids, gene_ids=gene_ids, gene_species=gene_species, gene_seq=gene_seq,
+                marker=marker, refid=refid, reads=reads)
+
+
+def write_pangenome_sample(outdir, db_dir, ds, line_width=70, gz=True):
+    """Lay a make_pangenome_dataset() out on disk: the database side (pan_genomes/<species>/centroids.ffn[.gz],
+    marker_genes/phyeco.map with rows of other species mixed in, the files utility.check_database wants) and the
+    sample side (<outdir>/genes/{species.txt, temp/pangenomes.fa, temp/pangenomes.bam}); BAM @SQ order = pangenome
+    order, records in aligner order (not sorted), as `samtools view -b` of bowtie2's output is."""
+    import gzip
+    import os
+    from . import bam
+    for d in ("marker_genes", "pan_genomes", "rep_genomes"):
+        os.makedirs(os.path.join(db_dir, d), exist_ok=True)
+    write_db_tables(db_dir, ds['species_ids'])
+    for sp in ds['species_ids']:
+        d = os.path.join(db_dir, "pan_genomes", sp)
+        os.makedirs(d, exist_ok=True)
+        opener = (lambda p: gzip.open(p + ".gz", "wt")) if gz else (lambda p: open(p, "w"))
+        with opener(os.path.join(d, "centroids.ffn")) as h:
+            for gid, gsp, seq in zip(ds['gene_ids'], ds['gene_species'], ds['gene_seq']):
+                if gsp == sp:
+                    h.write(">%s\n" % gid)
+                    for o in range(0, len(seq), line_width):
+                        h.write(seq[o:o + line_width] + "\n")
+    with open(os.path.join(db_dir, "marker_genes", "phyeco.map"), "w") as h:
+        h.write("species_id\tgenome_id\tgene_id\tgene_length\tmarker_id\n")
+        h.write("Species_99999\tSpecies_99999.rep\t99999.peg.1\t800\tB000001\n")
+        for gid, gsp, seq in zip(ds['gene_ids'], ds['gene_species'], ds['gene_seq']):
+            if gid in ds['marker']:
+                h.write("%s\t%s.rep\t%s\t%d\t%s\n" % (gsp, gsp, gid, len(seq), ds['marker'][gid]))
+    os.makedirs(os.path.join(outdir, "genes", "temp"), exist_ok=True)
+    os.makedirs(os.path.join(outdir, "genes", "output"), exist_ok=True)
+    with open(os.path.join(outdir, "genes", "species.txt"), "w") as h:
+        h.write("".join(s + "\n" for s in ds['species_ids']))
+    with open(os.path.join(outdir, "genes", "temp", "pangenomes.fa"), "w") as h:
+        for gid, seq in zip(ds['gene_ids'], ds['gene_seq']):
+            h.write(">%s\n%s\n" % (gid, seq.upper()))
+    bam.write_bam(os.path.join(outdir, "genes", "temp", "pangenomes.bam"), ds['gene_ids'],
+                  [len(s) for s in ds['gene_seq']], ds['refid'], ds['reads'])

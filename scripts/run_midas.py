@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""run_midas.py snps -- per-sample pileup + allele counting on MI355X.
+"""run_midas.py snps | genes -- per-sample pileup + allele counting, and pangenome gene coverage, on MI355X.
 
 Drop-in for the `snps` command of the reference's scripts/run_midas.py: same positional arguments, option
 names, defaults and output layout (<outdir>/snps/{output/<species>.snps.gz, species.txt, summary.txt, log.txt,
 readme.txt, temp/}), so existing command lines keep working.  What the options mean is the reference's
-(scripts/run_midas.py:338-430); how this file is written is not.  `species` and `genes` are other pipelines and
-are not part of this build.
+(scripts/run_midas.py:338-430); how this file is written is not.  `genes` (gene coverage over the species'
+pangenomes, reference options :205-336) is served the same way; `species` is another pipeline and not part of
+this build.
 
 Multi-GPU: start it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1`; species
 are dealt to the ranks, each rank writes the tables of its species, rank 0 writes summary.txt.
@@ -61,24 +62,72 @@ OPTION_GROUPS = [
 ]
 
 
+GENES_OPTION_GROUPS = [
+    ("Stages (any subset; none given = all three)", [
+        (['--build_db'], dict(action='store_true', help="concatenate the species' centroid genes and index them with bowtie2-build")),
+        (['--align'], dict(action='store_true', help="map the reads with bowtie2 | samtools view")),
+        (['--call_genes'], dict(action='store_true', dest='cov', help="reads, depth and copy number per gene (this is the GPU stage)")),
+    ]),
+    OPTION_GROUPS[1],
+    ("Reads and aligner (for --align)", [
+        (['-1'], dict(dest='m1', required=True, help="FASTA/FASTQ of unpaired reads or of the first mates (.gz / .bz2 accepted)")),
+        (['-2'], dict(dest='m2', help="FASTA/FASTQ of the second mates")),
+        (['--interleaved'], dict(action='store_true', help="-1 holds both mates, interleaved")),
+        (['-s'], dict(dest='speed', default='very-sensitive', choices=['very-fast', 'fast', 'sensitive', 'very-sensitive'],
+                      help="bowtie2 preset (very-sensitive)")),
+        (['-m'], dict(dest='mode', default='local', choices=['local', 'global'], help="local or end-to-end alignment (local)")),
+        (['-n'], dict(dest='max_reads', type=int, help="use only the first N reads (all)")),
+        (['-t'], dict(dest='threads', default=1, help="CPU threads for the aligner (1)")),
+    ]),
+    ("Read filters (for --call_genes)", [
+        (['--readq'], dict(type=int, default=20, metavar='INT', help="drop reads whose mean quality is below this (20)")),
+        (['--mapid'], dict(type=float, default=94.0, metavar='FLOAT', help="drop reads below this percent identity (94.0)")),
+        (['--mapq'], dict(type=int, default=0, metavar='INT', help=argparse.SUPPRESS)),
+        (['--aln_cov'], dict(type=float, default=0.75, metavar='FLOAT', help="drop reads aligned over less than this fraction of their length (0.75)")),
+        (['--trim'], dict(type=int, default=0, metavar='INT', help="bases trimmed off the 3' end before alignment (0)")),
+    ]),
+]
+
+
 def die(message):
     sys.exit("\nError: %s\n" % message)
 
 
 def get_program():
-    """First positional word: only `snps` exists here."""
+    """First positional word: `snps` or `genes`."""
     word = sys.argv[1] if len(sys.argv) > 1 else '-h'
     if word in ('-h', '--help'):
         print("run_midas.py <command> [options]\n\n"
               "  snps   count alleles at every site of the representative genomes of a sample's abundant species\n"
-              "         (pileup on the MI355X); `run_midas.py snps -h` lists the options\n\n"
-              "species and genes are not part of this build.")
+              "         (pileup on the MI355X); `run_midas.py snps -h` lists the options\n"
+              "  genes  reads, depth and copy number of every gene of the species' pangenomes (read filter and per-gene\n"
+              "         sums on the MI355X); `run_midas.py genes -h` lists the options\n\n"
+              "species is not part of this build.")
         sys.exit(0)
-    if word in ('species', 'genes'):
-        die("'%s' is not part of this build (only the snps path is)" % word)
-    if word != 'snps':
+    if word == 'species':
+        die("'%s' is not part of this build (only the snps and genes paths are)" % word)
+    if word not in ('snps', 'genes'):
         die("Unrecognized command: '%s'" % word)
     return word
+
+
+def build_genes_parser():
+    parser = argparse.ArgumentParser(
+        prog='run_midas.py genes', formatter_class=argparse.RawTextHelpFormatter,
+        description="Map a metagenome to the pangenomes (centroid genes) of its abundant species and report, per gene, the\n"
+                    "reads that pass the filter, the depth and the copy number relative to the species' marker genes.\n"
+                    "Stages: --build_db, --align, --call_genes (the last one runs on the GPU).",
+        epilog="examples:\n"
+               "  run_midas.py genes OUT -1 reads_1.fq.gz -2 reads_2.fq.gz\n"
+               "  run_midas.py genes OUT -1 reads.fq.gz --call_genes --mapid 96")
+    parser.add_argument('program', help=argparse.SUPPRESS)
+    parser.add_argument('outdir', help="sample directory (its name is the sample id)")
+    parser.add_argument('--remove_temp', action='store_true', help="delete <outdir>/genes/temp when done")
+    for title, options in GENES_OPTION_GROUPS:
+        group = parser.add_argument_group(title)
+        for flags, kw in options:
+            group.add_argument(*flags, **kw)
+    return parser
 
 
 def build_parser():
@@ -102,7 +151,7 @@ def build_parser():
 
 
 def get_arguments(program):
-    args = vars(build_parser().parse_args())
+    args = vars((build_genes_parser() if program == 'genes' else build_parser()).parse_args())
     if args['species_id']:
         args['species_id'] = args['species_id'].split(',')
     # the aligner stages shell out like the reference does, but to whatever is on PATH: no binaries ship here
@@ -112,31 +161,35 @@ def get_arguments(program):
 
 
 def check_arguments(program, args):
-    """The reference's sanity checks for snps (scripts/run_midas.py:556-628): same conditions, same exits."""
+    """The reference's sanity checks (scripts/run_midas.py:556-628 snps, :484-554 genes): same conditions, same exits."""
     if platform.system() not in ('Linux', 'Darwin'):
         die("Operating system '%s' not supported" % platform.system())
     if args['m1']:
         args['file_type'] = utility.auto_detect_file_type(args['m1'])
     utility.check_database(args)
+    per_species = 'rep_genomes' if program == 'snps' else 'pan_genomes'
     for sp in args['species_id'] or []:
-        if not os.path.isdir(os.path.join(args['db'], 'rep_genomes', sp)):
+        if not os.path.isdir(os.path.join(args['db'], per_species, sp)):
             die("the specified species_id '%s' was not found in the database" % sp)
-    os.makedirs(os.path.join(args['outdir'], 'snps'), exist_ok=True)
-    if not (args['build_db'] or args['align'] or args['call']):
-        args['build_db'] = args['align'] = args['call'] = True
+    os.makedirs(os.path.join(args['outdir'], program), exist_ok=True)
+    last = 'call' if program == 'snps' else 'cov'       # the stage after alignment
+    if not (args['build_db'] or args['align'] or args[last]):
+        args['build_db'] = args['align'] = args[last] = True
     if not (args['species_id'] or args['species_topn'] or args['species_cov']):
         args['species_cov'] = 3.0
-    temp = os.path.join(args['outdir'], 'snps', 'temp')
+    temp = os.path.join(args['outdir'], program, 'temp')
+    fa_name, bam_name, flag = ('genomes.fa', 'genomes.bam', '--pileup') if program == 'snps' else \
+        ('pangenomes.fa', 'pangenomes.bam', '--call_genes')
     profile = os.path.join(args['outdir'], 'species', 'species_profile.txt')
     if args['build_db'] and (args['species_topn'] or args['species_cov']) and not os.path.isfile(profile):
         die("Could not find species abundance profile: %s\n"
             "--species_topn / --species_cov need the output of `run_midas.py species`; use --species_id otherwise" % profile)
-    have_fa, have_bam = (os.path.isfile(os.path.join(temp, f)) for f in ('genomes.fa', 'genomes.bam'))
+    have_fa, have_bam = (os.path.isfile(os.path.join(temp, f)) for f in (fa_name, bam_name))
     if args['align'] and not args['build_db'] and not have_fa:
         die("You've specified --align, but no database has been built\nTry running with --build_db")
-    if args['call'] and not args['align'] and not have_bam:
-        die("You've specified --pileup, but no alignments were found\nTry running with --align")
-    if args['call'] and not args['build_db'] and not have_fa:
+    if args[last] and not args['align'] and not have_bam:
+        die("You've specified %s, but no alignments were found\nTry running with --align" % flag)
+    if program == 'snps' and args['call'] and not args['build_db'] and not have_fa:
         die("You've specified --pileup, but no genome database was found\nTry running with --build_db")
     if args['align'] and not args['m1']:
         die("To align reads, you must specify path to input FASTA/FASTQ")
@@ -150,7 +203,7 @@ def check_arguments(program, args):
                 die("Input file does not exist: '%s'" % args[key])
             utility.check_compression(args[key])
     for key, lo, hi in (('mapid', 1, 100), ('mapq', 0, 100), ('baseq', 0, 100), ('aln_cov', 0, 1)):
-        if not lo <= args[key] <= hi:
+        if key in args and not lo <= args[key] <= hi:
             die("%s must be between %s and %s" % (key.upper(), lo, hi))
 
 
@@ -165,7 +218,8 @@ def open_log(program, args):
 
 
 def print_arguments(program, args):
-    stages = [name for name, on in (('build_db', args['build_db']), ('align', args['align']), ('pileup', args['call'])) if on]
+    last = ('pileup', args.get('call')) if program == 'snps' else ('call_genes', args.get('cov'))
+    stages = [name for name, on in (('build_db', args['build_db']), ('align', args['align']), last) if on]
     shown = [('command', ' '.join(sys.argv)), ('database', args['db']), ('output directory', args['outdir']),
              ('stages', ', '.join(stages)), ('remove temp', args['remove_temp'])]
     if args['build_db']:
@@ -174,9 +228,9 @@ def print_arguments(program, args):
         shown += [('reads', ' '.join(x for x in (args['m1'], args['m2']) if x) + (' (interleaved)' if args['interleaved'] else '')),
                   ('bowtie2', '--%s%s' % (args['speed'], '-local' if args['mode'] == 'local' else '')),
                   ('max reads', args['max_reads'] or 'all'), ('threads', args['threads'])]
-    if args['call']:
-        shown += [(k, args[k]) for k in ('mapid', 'mapq', 'baseq', 'readq', 'aln_cov', 'trim')]
-    text = "=== run_midas.py snps (MI355X pileup) ===\n" + ''.join("%-18s %s\n" % (k + ':', v) for k, v in shown) + "===\n"
+    if last[1]:
+        shown += [(k, args[k]) for k in ('mapid', 'mapq', 'baseq', 'readq', 'aln_cov', 'trim') if k in args]
+    text = "=== run_midas.py %s (MI355X) ===\n" % program + ''.join("%-18s %s\n" % (k + ':', v) for k, v in shown) + "===\n"
     args['log'].write(text)
     if RANK == 0:
         sys.stdout.write(text)
@@ -202,15 +256,37 @@ Next step: merge_midas.py snps.
 """
 
 
+GENES_README = """run_midas.py genes -- files in this directory
+
+output/<species_id>.genes.gz  one row per gene of the species' pangenome, tab separated, gzip:
+                                gene_id       centroid gene id
+                                count_reads   reads that passed the filter on this gene
+                                coverage      sum over those reads of aligned bases / gene length
+                                copy_number   coverage / median coverage of the species' 15 marker genes
+species.txt                   species whose pangenomes are in temp/pangenomes.fa
+summary.txt                   per species: pangenome_size, covered_genes, fraction_covered, mean_coverage (over covered
+                              genes), marker_coverage, aligned_reads, mapped_reads
+log.txt                       parameters and external commands of this run
+temp/                         pangenomes.fa, bowtie2 index, pangenomes.bam (deleted by --remove_temp)
+
+Reads counted: identity >= --mapid, mean quality >= --readq, mapping quality >= --mapq, aligned fraction >= --aln_cov.
+Next step: merge_midas.py genes.
+"""
+
+
 def write_readme(program, args):
     if RANK == 0:
         with open(os.path.join(args['outdir'], program, 'readme.txt'), 'w') as handle:
-            handle.write(README)
+            handle.write(README if program == 'snps' else GENES_README)
 
 
 def run_program(program, args):
-    from midas_amd.run import snps
-    snps.run_pipeline(args)
+    if program == 'genes':
+        from midas_amd.run import genes
+        genes.run_pipeline(args)
+    else:
+        from midas_amd.run import snps
+        snps.run_pipeline(args)
 
 
 if __name__ == '__main__':

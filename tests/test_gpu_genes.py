@@ -1,0 +1,159 @@
+"""`run_midas.py genes` on the GPU box: midas_genes_count through the C-ABI and the whole --call_genes stage through the
+command line, against oracle/genes_oracle.py (pinned to the reference's own functions by tests/test_genes_golden.py).
+Bit-exact: the per-gene fp64 depth is the reference's running sum in BAM order, compared by repr()."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, synth
+from oracle import genes_oracle as go
+from oracle import pileup_oracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GENES_ARGS = dict(mapid=94.0, readq=20, mapq=0, aln_cov=0.75)
+
+
+def _oracle_records(reads, refid):
+    recs = []
+    for aln, rid in zip(po.alns_from_soa(reads.as_dict()), refid):
+        if aln.seq is None:
+            raise TypeError("no SEQ")
+        a = max(0, po.query_alignment_end(aln) - po.query_alignment_start(aln))
+        recs.append((int(rid), a, len(aln.seq), aln.nm, aln.qual, aln.mapq))
+    return recs
+
+
+def _oracle(ds, args):
+    lengths = [len(s) for s in ds['gene_seq']]
+    marker = [ds['marker'].get(g) for g in ds['gene_ids']]
+    aligned, mapped, depth, species = go.count_mapped_bp(args, _oracle_records(ds['reads'], ds['refid']), ds['gene_ids'],
+                                                         ds['gene_species'], lengths)
+    copies = go.normalize(depth, ds['gene_species'], marker, species)
+    tables, summary = go.write_results(ds['gene_ids'], ds['gene_species'], mapped, depth, copies, species)
+    return aligned, mapped, depth, tables, summary
+
+
+@pytest.mark.parametrize("args", [GENES_ARGS, dict(mapid=97.0, readq=32, mapq=25, aln_cov=0.95),
+                                  dict(mapid=1.0, readq=0, mapq=0, aln_cov=0.0)])
+def test_per_gene_counts_match_the_oracle(args):
+    ds = synth.make_pangenome_dataset(n_species=3, genes_per_species=80, n_reads=24000, seed=101)
+    lengths = [len(s) for s in ds['gene_seq']]
+    exp_aligned, exp_mapped, exp_depth, _, _ = _oracle(ds, args)
+    with abi.Context(0) as ctx:
+        thr = abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **args))
+        aligned, mapped, depth, ms = ctx.genes_count(thr, ds['reads'], ds['refid'], lengths)
+        assert aligned.tolist() == exp_aligned and mapped.tolist() == exp_mapped
+        assert [repr(float(x)) for x in depth] == [repr(float(x)) for x in exp_depth]
+        assert ms > 0
+        # a second call on the same context gives the same answer (no state carried over)
+        again = ctx.genes_count(thr, ds['reads'], ds['refid'], lengths)
+        assert np.array_equal(again[2], depth) and np.array_equal(again[1], mapped)
+
+
+def test_one_hot_gene_keeps_bam_order():
+    """All reads on one gene: the depth is one long sequential fp64 sum; any reordering would show in the last bits."""
+    ds = synth.make_pangenome_dataset(n_species=1, genes_per_species=8, n_reads=30000, seed=7, silent_fraction=0.0)
+    refid = np.full_like(ds['refid'], 3)
+    lengths = [len(s) for s in ds['gene_seq']]
+    recs = [(3,) + r[1:] for r in _oracle_records(ds['reads'], refid)]
+    _, exp_mapped, exp_depth, _ = go.count_mapped_bp(GENES_ARGS, recs, ds['gene_ids'], ds['gene_species'], lengths)
+    with abi.Context(0) as ctx:
+        _, mapped, depth, _ = ctx.genes_count(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **GENES_ARGS)), ds['reads'],
+                                              refid, lengths)
+    assert mapped.tolist() == exp_mapped and [repr(float(x)) for x in depth] == [repr(float(x)) for x in exp_depth]
+    assert exp_mapped[3] > 20000
+
+
+def test_no_reads_and_no_genes():
+    with abi.Context(0) as ctx:
+        thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
+        aligned, mapped, depth, _ = ctx.genes_count(thr, abi.ReadsSoA.empty(), np.zeros(0, np.int32), [900, 1200, 30])
+        assert aligned.tolist() == [0, 0, 0] and mapped.tolist() == [0, 0, 0] and depth.tolist() == [0.0, 0.0, 0.0]
+        aligned, mapped, depth, _ = ctx.genes_count(thr, abi.ReadsSoA.empty(), np.zeros(0, np.int32), [])
+        assert aligned.size == 0 and depth.size == 0
+
+
+@pytest.mark.parametrize("what,status", [("seq", 1), ("nm", 2), ("align", 3), ("qual", 4)])
+def test_reference_exceptions_are_statuses_with_the_first_bad_read(what, status):
+    ds = synth.make_pangenome_dataset(n_species=1, genes_per_species=12, n_reads=4000, seed=11)
+    reads, refid = ds['reads'], ds['refid']
+    lengths = [len(s) for s in ds['gene_seq']]
+    victims = (901, 2345)
+    for v in victims:
+        if what == "nm":
+            reads.nm[v] = -1
+        elif what == "qual":
+            reads.qual[int(reads.qual_off[v]):int(reads.qual_off[v + 1])] = 0xFF
+        elif what == "align":      # everything soft-clipped: query_alignment_sequence is ''
+            c0 = int(reads.cigar_off[v])
+            reads.cigar[c0:int(reads.cigar_off[v + 1])] = 0
+            reads.cigar[c0] = (int(reads.l_seq[v]) << 4) | 4
+    if what == "seq":              # SEQ '*': l_seq 0 and nothing in the ragged columns
+        l_seq = reads.l_seq.copy()
+        l_seq[list(victims)] = 0
+        keep_q = np.repeat(l_seq > 0, np.diff(reads.qual_off))
+        keep_s = np.repeat(l_seq > 0, np.diff(reads.seq_off))
+        q_off = np.zeros(reads.n_reads + 1, np.int64)
+        np.cumsum(l_seq.astype(np.int64), out=q_off[1:])
+        s_off = np.zeros(reads.n_reads + 1, np.int64)
+        np.cumsum((l_seq.astype(np.int64) + 1) >> 1, out=s_off[1:])
+        reads = abi.ReadsSoA(pos=reads.pos, mapq=reads.mapq, flag=reads.flag, nm=reads.nm, l_seq=l_seq, seq_off=s_off,
+                             qual_off=q_off, cigar_off=reads.cigar_off, seq4=reads.seq4[keep_s], qual=reads.qual[keep_q],
+                             cigar=reads.cigar)
+    with abi.Context(0) as ctx:
+        thr = abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, mapid=1.0, readq=0, mapq=0, aln_cov=0.0))
+        with pytest.raises(abi.MidasSnpsError) as e:
+            ctx.genes_count(thr, reads, refid, lengths)
+        assert e.value.status == status and e.value.read_index == victims[0]
+
+
+def test_bad_reference_index_is_rejected():
+    ds = synth.make_pangenome_dataset(n_species=1, genes_per_species=12, n_reads=500, seed=12)
+    refid = ds['refid'].copy()
+    refid[77] = len(ds['gene_ids'])
+    with abi.Context(0) as ctx:
+        with pytest.raises(abi.MidasSnpsError) as e:
+            ctx.genes_count(abi.Thresholds.from_args(abi.DEFAULT_ARGS), ds['reads'], refid, [len(s) for s in ds['gene_seq']])
+        assert e.value.status < 0
+
+
+def _run_cli(out, db, fq, extra=()):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_midas.py"), "genes", out, "--call_genes",
+                           "-d", db, "-1", fq] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+@pytest.mark.parametrize("extra", [[], ["--mapid", "96", "--readq", "30", "--mapq", "20", "--aln_cov", "0.9"]])
+def test_run_midas_genes_call_genes_matches_reference_text(tmp_path, extra):
+    ds = synth.make_pangenome_dataset(n_species=3, genes_per_species=60, n_reads=15000, seed=23)
+    out, db, fq = str(tmp_path / "sample"), str(tmp_path / "db"), str(tmp_path / "reads.fq")
+    synth.write_pangenome_sample(out, db, ds)
+    with open(fq, "w") as h:
+        h.write("@r1\nACGT\n+\nIIII\n")
+    r = _run_cli(out, db, fq, extra)
+    assert r.returncode == 0, r.stderr
+    assert "Computing coverage of pangenomes" in r.stdout
+    args = dict(GENES_ARGS)
+    for k, v in zip(extra[0::2], extra[1::2]):
+        args[k[2:]] = float(v) if k in ("--mapid", "--aln_cov") else int(v)
+    _, _, _, tables, summary = _oracle(ds, args)
+    for sp in ds['species_ids']:
+        assert gzip.open(os.path.join(out, "genes", "output", sp + ".genes.gz"), "rt").read() == tables[sp], sp
+    assert open(os.path.join(out, "genes", "summary.txt")).read() == summary
+    assert os.path.isfile(os.path.join(out, "genes", "readme.txt")) and os.path.isfile(os.path.join(out, "genes", "log.txt"))
+
+
+def test_run_midas_genes_error_exit(tmp_path):
+    ds = synth.make_pangenome_dataset(n_species=1, genes_per_species=12, n_reads=600, seed=29)
+    ds['reads'].nm[41] = -1
+    out, db, fq = str(tmp_path / "sample"), str(tmp_path / "db"), str(tmp_path / "reads.fq")
+    synth.write_pangenome_sample(out, db, ds)
+    with open(fq, "w") as h:
+        h.write("@r1\nACGT\n+\nIIII\n")
+    r = _run_cli(out, db, fq)
+    assert r.returncode == 1
+    assert "NM" in r.stderr and "read 41" in r.stderr
