@@ -3,16 +3,24 @@
 // the gene's depth = sum over kept reads of len(query_alignment_sequence) / float(gene.length).
 //
 // The reference walks the (unsorted) BAM once and accumulates `gene.depth += align_len / float(gene.length)` read by
-// read.  fp64 addition is not associative, so the sum is reproduced in exactly that order: the host groups the reads
-// by gene with a stable sort (BAM order inside a gene is kept) and one device thread per gene adds its reads' terms
-// one after the other.  Genes are independent, so the device parallelism is over genes (10^5 - 10^6 per sample).
-// Per read the kernel needs 12 bytes: aligned length, l_seq, NM, floor(mean quality), mapq and three "absent" flags,
-// all derived on the host from the BAM record with pysam's rules (query_alignment_start/end from the CIGAR clips).
+// read.  fp64 addition is not associative, so the sum has to be reproduced in exactly that order:
+//   host    per read, 8 bytes: aligned length (pysam's clip rules), l_seq, NM, floor(mean quality), mapq, three
+//           "absent" flags -- a pass over the quality bytes and CIGARs on all host cores;
+//   filter  one thread per read, BAM order: keep_read with the exceptions the reference would raise (lowest read
+//           index wins), and the read's term  align_len / float(gene.length)  (+0.0 for a read that is dropped:
+//           adding it leaves the running sum unchanged bit for bit);
+//   sort    stable LSD radix sort of (gene, term) pairs by gene (hipCUB): BAM order survives inside a gene;
+//   bounds  first sorted position of every gene;
+//   sum     one thread per gene (one wave for a gene with many reads) adds its terms one after the other.
+// Genes are independent, so the device parallelism of the last step is over genes (10^5 - 10^6 per sample).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/midas_snps.h"
@@ -23,69 +31,130 @@
 namespace midas {
 namespace {
 
-struct GeneRead {            // 12 bytes per read, in gene order
-  uint32_t orig;             // index of the read in the caller's arrays (BAM order), for error reports
-  uint16_t align_len;        // len(aln.query_alignment_sequence)
-  uint16_t l_seq;            // aln.query_length
-  uint16_t nm;               // NM tag
-  uint8_t qmean;             // floor(mean(query_qualities)): np.mean(q) < readq  <=>  qmean < readq for an integer readq
-  uint8_t mapq_flags;        // unused
-};
-static_assert(sizeof(GeneRead) == 12, "GeneRead must be 12 bytes");
-struct GeneReadAux { uint8_t mapq; uint8_t flags; };   // flags: 1 no SEQ, 2 no NM, 4 no QUAL
-constexpr uint8_t kNoSeq = 1, kNoNm = 2, kNoQual = 4;
+// word 0: align_len (11) | l_seq (11) << 11 | flags (3) << 22      word 1: NM (16) | qmean (8) << 16 | mapq (8) << 24
+// qmean = floor(mean(query_qualities)): np.mean(q) < readq  <=>  qmean < readq for an integer readq
+constexpr uint32_t kNoSeq = 1, kNoNm = 2, kNoQual = 4;
+constexpr int kHeavyGene = 2048;       // reads; genes above it are summed by a whole wave
 
-struct GenesKParams {
-  const GeneRead* reads;
-  const GeneReadAux* aux;
-  const int64_t* gene_begin;     // [n_genes + 1] into reads
+struct FilterKParams {
+  const uint2* rec;              // [n] BAM order
+  const uint32_t* gene;          // [n] reference id = gene index
   const int64_t* gene_len;       // [n_genes]
   const FilterTables* filt;
-  long long* aligned;            // [n_genes]
-  long long* mapped;
-  double* depth;
-  unsigned long long* err;       // atomicMin((orig << 8) | kind)
-  long long n_genes;
+  double* term;                  // [n] out
+  unsigned long long* err;       // atomicMin((read << 8) | kind)
+  long long n;
   int mapq, readq;
 };
 
-__global__ __launch_bounds__(256) void genes_count_kernel(GenesKParams p) {
+__global__ __launch_bounds__(256) void genes_filter_kernel(FilterKParams p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const uint2 r = p.rec[i];
+  const int align_len = (int)(r.x & 2047u), l_seq = (int)((r.x >> 11) & 2047u);
+  const uint32_t flags = r.x >> 22;
+  const int nm = (int)(r.y & 0xFFFFu), qmean = (int)((r.y >> 16) & 0xFFu), mapq = (int)(r.y >> 24);
+  // keep_read (genes.py:148-163): identity, mean quality, mapping quality, aligned fraction -- in that order, with
+  // the exceptions the reference would raise in the order it would raise them
+  uint32_t err = 0;
+  bool keep = false;
+  if (flags & kNoSeq) err = dev::E_NO_SEQ;                           // len(None)
+  else if (flags & kNoNm) err = dev::E_NO_NM;                        // dict(aln.tags)['NM']
+  else if (align_len == 0) err = dev::E_ZERO_ALIGN;                  // / float(0)
+  else if (align_len - nm < p.filt->min_match[align_len]) keep = false;
+  else if (flags & kNoQual) err = dev::E_NO_QUAL;                    // np.mean(None)
+  else if (qmean < p.readq) keep = false;
+  else if (mapq < p.mapq) keep = false;
+  else if (align_len < p.filt->min_align[l_seq]) keep = false;
+  else keep = true;
+  if (err) atomicMin(p.err, ((unsigned long long)i << 8) | err);
+  // the reference's own expression; a dropped read contributes +0.0
+  p.term[i] = keep ? (double)align_len / (double)p.gene_len[p.gene[i]] : 0.0;
+}
+
+// first sorted position of every gene: begin[g] = lowest i with key[i] >= g; begin[n_genes] = n
+__global__ __launch_bounds__(256) void genes_bounds_kernel(const uint32_t* key, long long n, long long n_genes, long long* begin) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  const long long prev = i == 0 ? -1 : (long long)key[i - 1];
+  const long long cur = i == n ? n_genes : (long long)key[i];
+  for (long long g = prev + 1; g <= cur; ++g) begin[g] = i;
+}
+
+struct SumKParams {
+  const double* term;            // [n] gene order, BAM order inside a gene
+  const long long* begin;        // [n_genes + 1]
+  long long* aligned;            // [n_genes]
+  long long* mapped;
+  double* depth;
+  unsigned int* heavy_count;
+  unsigned int* heavy;           // [n_genes] genes left to the wave kernel
+  long long n_genes;
+};
+
+__global__ __launch_bounds__(256) void genes_sum_kernel(SumKParams p) {
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   if (g >= p.n_genes) return;
-  const long long lo = p.gene_begin[g], hi = p.gene_begin[g + 1];
-  const double glen = (double)p.gene_len[g];
+  const long long lo = p.begin[g], hi = p.begin[g + 1];
+  p.aligned[g] = hi - lo;
+  if (hi - lo > kHeavyGene) {
+    p.heavy[atomicAdd(p.heavy_count, 1u)] = (unsigned int)g;
+    return;
+  }
   long long mapped = 0;
   double depth = 0.0;
   for (long long i = lo; i < hi; ++i) {
-    const GeneRead r = p.reads[i];
-    const GeneReadAux x = p.aux[i];
-    // keep_read (genes.py:148-163): identity, mean quality, mapping quality, aligned fraction -- in that order,
-    // with the exceptions the reference would raise in the order it would raise them
-    uint32_t err = 0;
-    bool keep = false;
-    if (x.flags & kNoSeq) err = dev::E_NO_SEQ;                         // len(None)
-    else if (x.flags & kNoNm) err = dev::E_NO_NM;                      // dict(aln.tags)['NM']
-    else if (r.align_len == 0) err = dev::E_ZERO_ALIGN;                // / float(0)
-    else if ((int)r.align_len - (int)r.nm < p.filt->min_match[r.align_len]) keep = false;
-    else if (x.flags & kNoQual) err = dev::E_NO_QUAL;                  // np.mean(None)
-    else if ((int)r.qmean < p.readq) keep = false;
-    else if ((int)x.mapq < p.mapq) keep = false;
-    else if ((int)r.align_len < p.filt->min_align[r.l_seq]) keep = false;
-    else keep = true;
-    if (err) { atomicMin(p.err, ((unsigned long long)r.orig << 8) | err); continue; }
-    if (keep) {
-      ++mapped;
-      depth += (double)r.align_len / glen;       // the reference's own expression, accumulated in BAM order
-    }
+    const double t = p.term[i];
+    mapped += t > 0.0;
+    depth += t;
   }
-  p.aligned[g] = hi - lo;
   p.mapped[g] = mapped;
   p.depth[g] = depth;
+}
+
+// One wave per heavy gene: 64 terms are fetched at once (coalesced), then added in lane order by every lane alike
+// (v_readlane broadcasts), so the sequence of additions is the thread-per-gene one.
+__global__ __launch_bounds__(64) void genes_sum_heavy_kernel(SumKParams p) {
+  if (blockIdx.x >= *p.heavy_count) return;
+  const long long g = p.heavy[blockIdx.x];
+  const long long lo = p.begin[g], hi = p.begin[g + 1];
+  const int lane = threadIdx.x;
+  long long mapped = 0;
+  double depth = 0.0;
+  for (long long base = lo; base < hi; base += 64) {
+    const long long i = base + lane;
+    const double t = i < hi ? p.term[i] : 0.0;
+    mapped += __popcll(__ballot(t > 0.0));
+    const int t_lo = __double2loint(t), t_hi = __double2hiint(t);
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+      depth += __hiloint2double(__builtin_amdgcn_readlane(t_hi, k), __builtin_amdgcn_readlane(t_lo, k));
+  }
+  if (lane == 0) {
+    p.mapped[g] = mapped;
+    p.depth[g] = depth;
+  }
 }
 
 int32_t gfail(midas_snps_ctx* ctx, int32_t st, const char* msg) {
   ctx->err = msg;
   return st;
+}
+
+template <class F>
+void host_ranges(int64_t n, F&& fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1, 64);
+  if (n < (int64_t)1 << 15) nt = 1;
+  if (nt == 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t lo = t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
 }
 
 }  // namespace
@@ -116,107 +185,133 @@ extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thres
   ctx->err_read = -1;
   if (out_kernel_ms) *out_kernel_ms = 0.f;
   const int64_t n = reads->n_reads;
-  // ---- host: per read, the numbers keep_read looks at; reads grouped by gene, BAM order kept inside a gene ------------
-  std::vector<int64_t> begin((size_t)n_genes + 1, 0);
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t g = ref_id[i];
-    if (g < 0 || g >= n_genes) {
-      char buf[160];
-      snprintf(buf, sizeof buf, "read %lld: reference id %lld is not a gene of the pangenome (the reference fails in getrname / genes[...])",
-               (long long)i, (long long)g);
-      ctx->err_read = i;
-      return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, buf);
+  if (n > 0x7FFFFFFFll || n_genes > 0x7FFFFFFFll) return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "more than 2^31-1 reads or genes");
+  // ---- host: per read, the numbers keep_read looks at (all cores) ------------------------------------------------
+  std::vector<uint2> recs((size_t)n);
+  std::atomic<int64_t> bad_ref{INT64_MAX}, bad_layout{INT64_MAX}, bad_size{INT64_MAX};
+  std::atomic<int32_t> max_l_all{0};
+  auto lower = [](std::atomic<int64_t>& a, int64_t v) {
+    int64_t cur = a.load();
+    while (v < cur && !a.compare_exchange_weak(cur, v)) {}
+  };
+  host_ranges(n, [&](int64_t lo, int64_t hi) {
+    int32_t max_l = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t g = ref_id[i];
+      if (g < 0 || g >= n_genes) { lower(bad_ref, i); continue; }
+      const int64_t l = reads->l_seq[i];
+      const int64_t nc = reads->cigar_off[i + 1] - reads->cigar_off[i];
+      if (l < 0 || nc < 0 || reads->qual_off[i + 1] - reads->qual_off[i] < l) { lower(bad_layout, i); continue; }
+      if (l > kMaxLSeq || reads->nm[i] > kMaxField16) { lower(bad_size, i); continue; }
+      const uint32_t* cg = reads->cigar + reads->cigar_off[i];
+      // [EXT] pysam query_alignment_start / _end: leading S run (hopping over H); trailing S run found by a backward
+      // walk over ops n-1 .. 1 (op 0 is never inspected)
+      int64_t qs = 0;
+      for (int64_t k = 0; k < nc; ++k) {
+        const uint32_t op = cg[k] & 15u;
+        if (op == 5u) continue;
+        if (op == 4u) qs += cg[k] >> 4; else break;
+      }
+      int64_t qe = l;
+      for (int64_t k = nc - 1; k >= 1; --k) {
+        const uint32_t op = cg[k] & 15u;
+        if (op == 5u) continue;
+        if (op == 4u) qe -= cg[k] >> 4; else break;
+      }
+      int64_t al = qe - qs > 0 ? qe - qs : 0;
+      if (al > l) al = l;                       // (clips shorter than the read: cannot exceed it)
+      const uint8_t* q = reads->qual + reads->qual_off[i];
+      uint32_t qsum = 0;
+      for (int64_t x = 0; x < l; ++x) qsum += q[x];
+      const uint32_t flags = (l == 0 ? kNoSeq : 0u) | (reads->nm[i] < 0 ? kNoNm : 0u) | ((l > 0 && q[0] == 0xFF) ? kNoQual : 0u);
+      const uint32_t nm = (uint32_t)(reads->nm[i] < 0 ? 0 : reads->nm[i]);
+      const uint32_t qmean = l > 0 ? qsum / (uint32_t)l : 0u;
+      recs[(size_t)i] = make_uint2((uint32_t)al | ((uint32_t)l << 11) | (flags << 22), nm | (qmean << 16) | ((uint32_t)reads->mapq[i] << 24));
+      max_l = std::max<int32_t>(max_l, (int32_t)l);
     }
-    begin[(size_t)g + 1]++;
-  }
-  for (int64_t g = 0; g < n_genes; ++g) begin[(size_t)g + 1] += begin[(size_t)g];
-  std::vector<int64_t> cursor(begin.begin(), begin.end() - 1);
-  std::vector<GeneRead> recs((size_t)n);
-  std::vector<GeneReadAux> aux((size_t)n);
-  int32_t max_l = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t l = reads->l_seq[i];
-    const int64_t nc = reads->cigar_off[i + 1] - reads->cigar_off[i];
-    if (l < 0 || nc < 0 || reads->qual_off[i + 1] - reads->qual_off[i] < l) {
-      ctx->err_read = i;
-      return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative size or CSR offsets shorter than l_seq");
-    }
-    if (l > kMaxLSeq || reads->nm[i] > kMaxField16) {
-      ctx->err_read = i;
+    int32_t cur = max_l_all.load();
+    while (max_l > cur && !max_l_all.compare_exchange_weak(cur, max_l)) {}
+  });
+  {
+    // the first malformed read in BAM order decides, as a single forward pass would
+    const int64_t first = std::min(bad_ref.load(), std::min(bad_layout.load(), bad_size.load()));
+    if (first != INT64_MAX) {
+      ctx->err_read = first;
+      char buf[200];
+      if (first == bad_ref.load()) {
+        snprintf(buf, sizeof buf, "read %lld: reference id %lld is not a gene of the pangenome (the reference fails in getrname / genes[...])",
+                 (long long)first, (long long)ref_id[first]);
+        return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, buf);
+      }
+      if (first == bad_layout.load()) return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative size or CSR offsets shorter than l_seq");
       return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "l_seq > 1024 or NM > 65534 is not supported");
     }
-    const uint32_t* cg = reads->cigar + reads->cigar_off[i];
-    // [EXT] pysam query_alignment_start / _end: leading S run (hopping over H); trailing S run found by a backward
-    // walk over ops n-1 .. 1 (op 0 is never inspected)
-    int64_t qs = 0;
-    for (int64_t k = 0; k < nc; ++k) {
-      const uint32_t op = cg[k] & 15u;
-      if (op == 5u) continue;
-      if (op == 4u) qs += cg[k] >> 4; else break;
-    }
-    int64_t qe = l;
-    for (int64_t k = nc - 1; k >= 1; --k) {
-      const uint32_t op = cg[k] & 15u;
-      if (op == 5u) continue;
-      if (op == 4u) qe -= cg[k] >> 4; else break;
-    }
-    const int64_t al = qe - qs > 0 ? qe - qs : 0;
-    const uint8_t* q = reads->qual + reads->qual_off[i];
-    uint64_t qsum = 0;
-    for (int64_t x = 0; x < l; ++x) qsum += q[x];
-    GeneRead r;
-    r.orig = (uint32_t)i;
-    r.align_len = (uint16_t)(al > 65535 ? 65535 : al);
-    r.l_seq = (uint16_t)l;
-    r.nm = (uint16_t)(reads->nm[i] < 0 ? 0 : reads->nm[i]);
-    r.qmean = (uint8_t)(l > 0 ? qsum / (uint64_t)l : 0);
-    r.mapq_flags = 0;
-    GeneReadAux a;
-    a.mapq = reads->mapq[i];
-    a.flags = (uint8_t)((l == 0 ? kNoSeq : 0) | (reads->nm[i] < 0 ? kNoNm : 0) | ((l > 0 && q[0] == 0xFF) ? kNoQual : 0));
-    const int64_t d = cursor[(size_t)ref_id[i]]++;
-    recs[(size_t)d] = r;
-    aux[(size_t)d] = a;
-    max_l = std::max<int32_t>(max_l, (int32_t)l);
   }
   FilterTables ft;
   memset(&ft, 0, sizeof ft);
-  build_filter_tables(thr->mapid, thr->aln_cov, max_l, &ft);
+  build_filter_tables(thr->mapid, thr->aln_cov, max_l_all.load(), &ft);
   // ---- device ------------------------------------------------------------------------------------------------------
   std::vector<void*> dev_ptrs;
   G_TRY(hipSetDevice(ctx->device));
-  GeneRead* d_recs = nullptr; GeneReadAux* d_aux = nullptr; int64_t* d_begin = nullptr; int64_t* d_len = nullptr;
-  FilterTables* d_ft = nullptr; long long* d_al = nullptr; long long* d_mp = nullptr; double* d_dp = nullptr; unsigned long long* d_err = nullptr;
+  hipStream_t s = ctx->stream;
   const size_t ng = (size_t)(n_genes > 0 ? n_genes : 1), nr = (size_t)(n > 0 ? n : 1);
-  G_TRY(hipMalloc(&d_recs, nr * sizeof(GeneRead))); dev_ptrs.push_back(d_recs);
-  G_TRY(hipMalloc(&d_aux, nr * sizeof(GeneReadAux))); dev_ptrs.push_back(d_aux);
-  G_TRY(hipMalloc(&d_begin, (ng + 1) * 8)); dev_ptrs.push_back(d_begin);
+  uint2* d_recs = nullptr; uint32_t* d_key = nullptr; uint32_t* d_key_sorted = nullptr; double* d_term = nullptr; double* d_term_sorted = nullptr;
+  int64_t* d_len = nullptr; FilterTables* d_ft = nullptr; long long* d_begin = nullptr; long long* d_al = nullptr; long long* d_mp = nullptr;
+  double* d_dp = nullptr; unsigned long long* d_err = nullptr; unsigned int* d_heavy = nullptr; void* d_tmp = nullptr;
+  G_TRY(hipMalloc(&d_recs, nr * sizeof(uint2))); dev_ptrs.push_back(d_recs);
+  G_TRY(hipMalloc(&d_key, nr * 4)); dev_ptrs.push_back(d_key);
+  G_TRY(hipMalloc(&d_key_sorted, nr * 4)); dev_ptrs.push_back(d_key_sorted);
+  G_TRY(hipMalloc(&d_term, nr * 8)); dev_ptrs.push_back(d_term);
+  G_TRY(hipMalloc(&d_term_sorted, nr * 8)); dev_ptrs.push_back(d_term_sorted);
   G_TRY(hipMalloc(&d_len, ng * 8)); dev_ptrs.push_back(d_len);
   G_TRY(hipMalloc(&d_ft, sizeof(FilterTables))); dev_ptrs.push_back(d_ft);
+  G_TRY(hipMalloc(&d_begin, (ng + 1) * 8)); dev_ptrs.push_back(d_begin);
   G_TRY(hipMalloc(&d_al, ng * 8)); dev_ptrs.push_back(d_al);
   G_TRY(hipMalloc(&d_mp, ng * 8)); dev_ptrs.push_back(d_mp);
   G_TRY(hipMalloc(&d_dp, ng * 8)); dev_ptrs.push_back(d_dp);
-  G_TRY(hipMalloc(&d_err, 8)); dev_ptrs.push_back(d_err);
-  hipStream_t s = ctx->stream;
+  G_TRY(hipMalloc(&d_err, 16)); dev_ptrs.push_back(d_err);
+  G_TRY(hipMalloc(&d_heavy, (ng + 1) * 4)); dev_ptrs.push_back(d_heavy);
+  int key_bits = 1;
+  while (key_bits < 32 && ((int64_t)1 << key_bits) < n_genes) ++key_bits;
+  size_t tmp_bytes = 0;
+  G_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key_sorted, d_term, d_term_sorted, (int)n, 0, key_bits, s));
+  G_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16)); dev_ptrs.push_back(d_tmp);
   if (n > 0) {
-    G_TRY(hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(GeneRead), hipMemcpyHostToDevice, s));
-    G_TRY(hipMemcpyAsync(d_aux, aux.data(), (size_t)n * sizeof(GeneReadAux), hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_key, ref_id, (size_t)n * 4, hipMemcpyHostToDevice, s));
   }
-  G_TRY(hipMemcpyAsync(d_begin, begin.data(), ((size_t)n_genes + 1) * 8, hipMemcpyHostToDevice, s));
   if (n_genes > 0) G_TRY(hipMemcpyAsync(d_len, gene_length, (size_t)n_genes * 8, hipMemcpyHostToDevice, s));
   G_TRY(hipMemcpyAsync(d_ft, &ft, sizeof ft, hipMemcpyHostToDevice, s));
   G_TRY(hipMemsetAsync(d_err, 0xFF, 8, s));
+  G_TRY(hipMemsetAsync(d_heavy, 0, 4, s));
   hipEvent_t e0, e1;
   G_TRY(hipEventCreate(&e0));
   G_TRY(hipEventCreate(&e1));
   unsigned long long err = ~0ull;
   if (n_genes > 0) {
-    GenesKParams k;
-    k.reads = d_recs; k.aux = d_aux; k.gene_begin = d_begin; k.gene_len = d_len; k.filt = d_ft;
-    k.aligned = d_al; k.mapped = d_mp; k.depth = d_dp; k.err = d_err; k.n_genes = n_genes; k.mapq = thr->mapq; k.readq = thr->readq;
     G_TRY(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(genes_count_kernel, dim3((unsigned)((n_genes + 255) / 256)), dim3(256), 0, s, k);
+    if (n > 0) {
+      FilterKParams f;
+      f.rec = d_recs; f.gene = d_key; f.gene_len = d_len; f.filt = d_ft; f.term = d_term; f.err = d_err; f.n = n;
+      f.mapq = thr->mapq; f.readq = thr->readq;
+      hipLaunchKernelGGL(genes_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f);
+      G_TRY(hipGetLastError());
+      G_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key_sorted, d_term, d_term_sorted, (int)n, 0, key_bits, s));
+    }
+    hipLaunchKernelGGL(genes_bounds_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_key_sorted, (long long)n,
+                       (long long)n_genes, d_begin);
     G_TRY(hipGetLastError());
+    SumKParams k;
+    k.term = d_term_sorted; k.begin = d_begin; k.aligned = d_al; k.mapped = d_mp; k.depth = d_dp;
+    k.heavy_count = d_heavy; k.heavy = d_heavy + 1; k.n_genes = n_genes;
+    hipLaunchKernelGGL(genes_sum_kernel, dim3((unsigned)((n_genes + 255) / 256)), dim3(256), 0, s, k);
+    G_TRY(hipGetLastError());
+    // at most n / kHeavyGene genes are heavy; idle waves leave at once
+    const long long max_heavy = std::min<long long>(n_genes, n / kHeavyGene);
+    if (max_heavy > 0) {
+      hipLaunchKernelGGL(genes_sum_heavy_kernel, dim3((unsigned)max_heavy), dim3(64), 0, s, k);
+      G_TRY(hipGetLastError());
+    }
     G_TRY(hipEventRecord(e1, s));
     G_TRY(hipMemcpyAsync(out_aligned, d_al, (size_t)n_genes * 8, hipMemcpyDeviceToHost, s));
     G_TRY(hipMemcpyAsync(out_mapped, d_mp, (size_t)n_genes * 8, hipMemcpyDeviceToHost, s));

@@ -83,7 +83,7 @@ def test_reference_exceptions_are_statuses_with_the_first_bad_read(what, status)
     ds = synth.make_pangenome_dataset(n_species=1, genes_per_species=12, n_reads=4000, seed=11)
     reads, refid = ds['reads'], ds['refid']
     lengths = [len(s) for s in ds['gene_seq']]
-    victims = (901, 2345)
+    victims = (901, 1745)
     for v in victims:
         if what == "nm":
             reads.nm[v] = -1
