@@ -40,7 +40,10 @@ def build_native(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + \
+    # The atomic optimizer turns a one-lane atomicAdd into mbcnt/readfirstlane and waits for the result at once; the
+    # pileup kernel fetches its next work item that way and must not stall on it (pileup_tiles.hip, dynamic items).
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+           "-amdgpu-atomic-optimizer-strategy=None", "-x", "hip"] + srcs + \
           ["-o", tmp, "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -54,6 +54,9 @@ struct FilterTables {
 // host: tabulate the two thresholds for lengths 1..max_l (snps_abi.hip)
 void build_filter_tables(double mapid, double aln_cov, int32_t max_l, FilterTables* t);
 
+constexpr int kSchedGroups = 8;                      // XCDs
+constexpr int kSchedWords = 32 * (kSchedGroups + 1);
+
 struct PileupParams {
   const ReadRec* rec;
   const uint8_t* blob;
@@ -69,7 +72,9 @@ struct PileupParams {
   unsigned long long* err;           // one word, atomicMin((read << 8) | kind)
   const uint32_t* items;             // [n_items][4] work items {tile, part, n_parts, 0}: a tile whose reads were split
                                      // into n_parts > 1 slices (hot spots) is accumulated with global atomics
-  uint32_t* split_ticket;            // [n_tiles] arrival counter of a split tile's parts (self-resetting)
+  uint32_t* split_ticket;            // [n_tiles] arrival counter of a split tile's parts (self-resetting), then twice
+                                     // kSchedWords: {8 item counters, workgroups done}, one cache line each, of the
+                                     // whole-tile and of the parts launch
   int32_t n_items;
   int32_t n_whole_items;             // items [0, n_whole_items) are whole tiles (n_parts == 1), the rest parts of split tiles
   int32_t n_tiles;

@@ -136,6 +136,17 @@ __device__ __forceinline__ Tile load_tile(ConstWords tiles, int t) {
 
 // SPLIT = false: whole tiles, plain stores (the common case); SPLIT = true: the parts of split tiles (hot spots),
 // launched separately so that the common case carries none of that code or its registers.
+// Barrier between the phases of a tile.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: every wave would
+// sit out the acknowledgement of its own write-out stores and the arrival of the next tile's prefetched records and
+// payload before it may even wait for the others.  What the phases exchange lives in LDS only (tallies, counters), so
+// the whole-tile kernel waits for LDS traffic alone; prefetched registers are guarded by the compiler's own counters.
+// The parts kernel keeps the full fence (its global atomics are ordered against the tile's arrival ticket).
+template <bool SPLIT>
+__device__ __forceinline__ void tile_barrier(int debug) {
+  if (SPLIT || (debug & 64)) __syncthreads();
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int TILE_SHIFT, bool SPLIT>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupParams p) {
   constexpr int TILE = 1 << TILE_SHIFT;
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_last_part;
+  __shared__ uint32_t s_next_ticket;
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   const int tid = threadIdx.x;
@@ -152,8 +164,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   // Work items: one per tile, except that a tile holding very many reads (a coverage hot spot) comes as n_parts
   // items, each taking a slice of the tile's wave-iterations and adding its tallies to the output with atomics.
   const int w_end = SPLIT ? p.n_items : p.n_whole_items;      // items [0, n_whole) are whole tiles, the rest are parts
-  int w = (SPLIT ? p.n_whole_items : 0) + (int)blockIdx.x;
-  if (w >= w_end) return;
+  // Items are handed out dynamically: the first two of a workgroup are blockIdx and blockIdx + grid, every further one
+  // comes from a device counter (fetched two tiles ahead, so the atomic's round trip is never waited for).  With ~7
+  // tiles per workgroup a static round-robin leaves the chip waiting for the workgroups that drew one tile more.
+  // One counter per XCD (workgroups are dispatched round-robin over the 8 XCDs, so blockIdx % 8 names the XCD): it
+  // hands out the items congruent to it modulo 8 and its cache line stays in that XCD's L2.  A single counter
+  // bounces between the eight L2s and costs more than the balance gains (measured: 129 us against 108 us static).
+  const int w_base = SPLIT ? p.n_whole_items : 0;
+  const bool dynamic = !(p.debug & 16) && (gridDim.x % kSchedGroups) == 0;
+  const int sched_group = (int)(blockIdx.x % kSchedGroups);
+  uint32_t* const sched = p.split_ticket + p.n_tiles + (SPLIT ? kSchedWords : 0);   // [8 counters, 32 words apart][done]
+  int w = w_base + (int)blockIdx.x;
+  if (w >= w_end) return;          // (never: the grid is at most the number of items)
+  int w_next = w + (int)gridDim.x;
   const ConstWords c_items = (ConstWords)(size_t)p.items;
   int t = (!SPLIT && p.n_whole_items == p.n_tiles) ? w : (int)c_items[4 * w];
   int part = SPLIT ? (int)c_items[4 * w + 1] : 0, nparts = SPLIT ? (int)c_items[4 * w + 2] : 1;
@@ -509,7 +532,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
     }
     // ---- next tile: its record loads go out before the barrier, its payload loads before this tile's stores ----
-    const int wn = w + (int)gridDim.x;
+    const int wn = w_next;
     const bool more = wn < w_end;
     // whole-tile items are the identity list unless some tile of the batch was split: no dependent load then
     const bool ident = !SPLIT && p.n_whole_items == p.n_tiles;
@@ -524,8 +547,13 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       rec_cur = fetch_rec(nrg, nv0);
       rec_nxt = fetch_rec(nrg, nv0 + vstep);
     }
-    __syncthreads();   // every tally of this tile is in LDS
+    tile_barrier<SPLIT>(p.debug);   // every tally of this tile is in LDS
+    // the item after the next one: the counter is asked here, behind the next tile's record loads and ahead of its
+    // payload loads, whose first use is a whole write-out away (loads and returning atomics come back in order: an
+    // atomic issued ahead of the stream loop held back every load of the tile's first iterations)
     if (more) fetch_payload(rec_cur, cur);
+    uint32_t ticket = 0;
+    if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered/total-depth partials ----------
     unsigned long long covered = 0, depth_sum = 0;
@@ -594,10 +622,11 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
       if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
     }
+    if (dynamic && more && tid == 0) s_next_ticket = ticket;
     // One barrier per tile after the write-out: tallies re-zeroed (and this tile's s_stats additions done) before
     // the next tile's waves touch LDS.  The workgroup's counters go to the species row only when the next tile
     // belongs to another species or there is no next tile: they are additive, so tiles of one species share them.
-    __syncthreads();
+    tile_barrier<SPLIT>(p.debug);
     if constexpr (SPLIT) {
       if (tid == 0) {
         const uint32_t ticket = atomicAdd(&p.split_ticket[t], 1u);
@@ -621,6 +650,11 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
       __syncthreads();
     }
+    if (more) {
+      const long long nn = (dynamic && !(p.debug & 32)) ? (long long)w_base + 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
+                                                        : (long long)wn + (long long)gridDim.x;
+      w_next = __builtin_amdgcn_readfirstlane((int)(nn < (long long)w_end ? nn : (long long)w_end));
+    }
     const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
     if (flush) {
       if (tid < MIDAS_STATS) {
@@ -628,8 +662,17 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
         s_stats[tid] = 0ull;
       }
-      if (!more) break;
-      __syncthreads();   // s_stats reset before the next tile adds to it
+      if (!more) {
+        if (dynamic && tid == 0) {   // the last workgroup to leave rewinds the counters for the next launch (every
+          // ticket this workgroup drew has come back and been used by now, so its arrival is ordered behind them; no
+          // fence: an agent-scope fence here writes back and invalidates the XCD's whole L2, once per workgroup)
+          if (atomicAdd(&sched[32 * kSchedGroups], 1u) == gridDim.x - 1u) {
+            for (int k = 0; k <= kSchedGroups; ++k) sched[32 * k] = 0u;
+          }
+        }
+        break;
+      }
+      tile_barrier<SPLIT>(p.debug);   // s_stats reset before the next tile adds to it
     }
     w = wn;
     part = npart;

@@ -454,8 +454,8 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     b->n_items = (int64_t)(items.size() / 4);
     B_TRY(hipMalloc(&b->d_items, (items.empty() ? 1 : items.size()) * 4));
     if (!items.empty()) B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
-    B_TRY(hipMalloc(&b->d_ticket, nt * 4));
-    B_TRY(hipMemset(b->d_ticket, 0, nt * 4));
+    B_TRY(hipMalloc(&b->d_ticket, (nt + 2 * kSchedWords) * 4));     // + the two launches' dynamic-schedule words
+    B_TRY(hipMemset(b->d_ticket, 0, (nt + 2 * kSchedWords) * 4));
   }
   b->work_bytes = (((size_t)b->n_tiles * 48 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
