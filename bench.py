@@ -8,12 +8,13 @@
 A "step" is one full pass of the hot path over one resident batch: the device builds its
 per-tile read index (the index_bam analogue), filters every read (keep_read), walks the
 CIGARs, tallies A/C/G/T per site, emits counts + ref allele and reduces the per-species
-counters; with N > 1 the per-species summary rows are then all-gathered over RCCL.  Inputs
+counters.  With N > 1 a rank's K steps are its share of the job and the job's one exchange -- the
+all-gather of every rank's per-species summary rows over RCCL -- follows them, inside the timed region.  Inputs
 (packed reads, reference letters) are resident in HBM before the timed region starts.
 
 Workload: BASELINE.json configs[1] -- 1 species, 15 Mb, 1 M synthetic 150 bp reads (10x) per
 GPU.  Multi-GPU is species-sharded weak scaling: every rank owns its own species (own seed),
-no data-path collective, one all-gather of [n_species,4] int64 summary rows per pass.
+no data-path collective, one all-gather of [K, n_species, 4] int64 summary rows per job.
 """
 import argparse
 import json
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--config", default="c2", help="workload from midas_amd.synth.CONFIGS (default c2 = BASELINE configs[1])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the summary all-gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     a = ap.parse_args()
 
     import torch
@@ -106,8 +109,14 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or a.force_collective
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = dict(synth.CONFIGS[a.config])
@@ -122,34 +131,41 @@ def main():
     batch = ctx.batch(contigs, reads)
     info = batch.info()
     n_sp = contigs.n_species
-    stats_dev = torch.zeros((n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
-    gathered = torch.zeros((world * n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda") if world > 1 else None
+    # N > 1: a rank's K steps are its share of the job (K species batches); the job's one exchange -- the all-gather of
+    # every rank's summary rows, what snps_summary needs to write summary.txt -- follows the last step, inside the timed
+    # region, exactly as midas_amd/run/snps.py does it (all of a rank's species, then one all-gather).
+    rows = torch.zeros((max(a.steps, a.warmup, 1), n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
+    gathered = torch.zeros((world,) + tuple(rows.shape), dtype=torch.int64, device="cuda") if collective else None
 
-    def step():
-        batch.run(thr)
-        if world > 1:
-            batch.stats_to_device(stats_dev.data_ptr())
-            dist.all_gather_into_tensor(gathered, stats_dev)
+    def job(n):
+        for i in range(n):
+            batch.run(thr)
+            if collective:
+                batch.stats_to_device(rows[i].data_ptr())
+        if collective and n > 0:
+            dist.all_gather_into_tensor(gathered, rows)
 
-    for _ in range(a.warmup):
-        step()
+    job(a.warmup)
     batch.sync()
+    torch.cuda.synchronize()
     batch.enable_timing(a.steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    job(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     batch.sync()   # surfaces MIDAS_SNPS_ERR_READ_* of the last run, if any
+    if collective:      # the gathered table holds this rank's rows where they belong
+        if not torch.equal(gathered[rank], rows):
+            sys.exit("bench.py: all-gathered summary rows differ from this rank's rows")
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     sites = torch.tensor([float(info.n_sites)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if collective:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(sites, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
@@ -160,6 +176,7 @@ def main():
     index_ms = float(np.mean([t["index_ms"] for t in tm]))
     run_ms = float(np.mean([t["run_ms"] for t in tm]))
 
+    out = None
     if rank == 0:
         kernel = "pileup_tiles_kernel"
         achieved = info.algorithmic_bytes / (pile_ms * 1e-3) / 1e9
@@ -175,7 +192,7 @@ def main():
             "config": {"workload": "configs[1]: 1 species rep-genome (60 contigs x 250 kb = 15 Mb), 1M synthetic "
                                    "150 bp reads at 10x per GPU" if a.config == "c2" else a.config,
                        "sites_per_gpu": int(info.n_sites), "reads_per_gpu": int(info.n_reads),
-                       "thresholds": args, "parallelism": "species-sharded x%d, RCCL all-gather of summary rows" % world
+                       "thresholds": args, "parallelism": "species-sharded x%d, one RCCL all-gather of the summary rows per job" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
@@ -196,11 +213,15 @@ def main():
                 out["cpu_python_shaped_estimate"] = python_shaped_estimate(contigs, reads, args)
             except Exception as e:  # the estimate is a courtesy number; never fail the bench on it
                 out["cpu_python_shaped_estimate"] = {"error": str(e)}
-        print(json.dumps(out), flush=True)
     batch.close()
     ctx.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+    if rank == 0:       # the JSON line is the last thing on stdout: push out what RCCL left in the C stdio buffer first
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
