@@ -11,7 +11,8 @@
 //           adding it leaves the running sum unchanged bit for bit);
 //   sort    stable LSD radix sort of (gene, term) pairs by gene (hipCUB): BAM order survives inside a gene;
 //   bounds  first sorted position of every gene;
-//   sum     one thread per gene (one wave for a gene with many reads) adds its terms one after the other.
+//   sum     one thread per gene adds its terms one after the other (a gene with many reads: one wave stages 512
+//           terms at a time in LDS and adds them in the same order).
 // Genes are independent, so the device parallelism of the last step is over genes (10^5 - 10^6 per sample).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -112,23 +113,44 @@ __global__ __launch_bounds__(256) void genes_sum_kernel(SumKParams p) {
   p.depth[g] = depth;
 }
 
-// One wave per heavy gene: 64 terms are fetched at once (coalesced), then added in lane order by every lane alike
-// (v_readlane broadcasts), so the sequence of additions is the thread-per-gene one.
+// One wave per heavy gene: 512 terms are fetched at once (coalesced, eight loads in flight per lane) and parked in LDS;
+// then every lane alike reads them back in order (same address in all lanes: a broadcast, two terms per ds_read_b128)
+// and adds them one after the other, so the sequence of additions is the thread-per-gene one while the memory latency
+// is paid once per 512 terms instead of once per term.
 __global__ __launch_bounds__(64) void genes_sum_heavy_kernel(SumKParams p) {
+  constexpr int kBatch = 8;
+  __shared__ __attribute__((aligned(16))) double buf[64 * kBatch];
   if (blockIdx.x >= *p.heavy_count) return;
   const long long g = p.heavy[blockIdx.x];
   const long long lo = p.begin[g], hi = p.begin[g + 1];
   const int lane = threadIdx.x;
   long long mapped = 0;
   double depth = 0.0;
-  for (long long base = lo; base < hi; base += 64) {
-    const long long i = base + lane;
-    const double t = i < hi ? p.term[i] : 0.0;
-    mapped += __popcll(__ballot(t > 0.0));
-    const int t_lo = __double2loint(t), t_hi = __double2hiint(t);
+  for (long long base = lo; base < hi; base += 64 * kBatch) {
+    double t[kBatch];
 #pragma unroll
-    for (int k = 0; k < 64; ++k)
-      depth += __hiloint2double(__builtin_amdgcn_readlane(t_hi, k), __builtin_amdgcn_readlane(t_lo, k));
+    for (int j = 0; j < kBatch; ++j) {
+      const long long i = base + j * 64 + lane;
+      t[j] = i < hi ? p.term[i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      mapped += __popcll(__ballot(t[j] > 0.0));
+      buf[j * 64 + lane] = t[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long left = hi - base;
+    const int n = left < 64 * kBatch ? (int)left : 64 * kBatch;
+    const double2* pairs = reinterpret_cast<const double2*>(buf);
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {       // (terms past the end of the gene are +0.0, but stay out of the sum anyway)
+      const double2 a = pairs[k / 2], b = pairs[k / 2 + 1], c = pairs[k / 2 + 2], d = pairs[k / 2 + 3];
+      depth += a.x; depth += a.y; depth += b.x; depth += b.y;
+      depth += c.x; depth += c.y; depth += d.x; depth += d.y;
+    }
+    for (; k < n; ++k) depth += buf[k];
+    __builtin_amdgcn_wave_barrier();    // the next batch overwrites buf
   }
   if (lane == 0) {
     p.mapped[g] = mapped;
