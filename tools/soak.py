@@ -1,0 +1,77 @@
+"""Developer soak (GPU box): random dataset shapes against the C oracle, every batch run three times (the self-resetting
+device counters -- split tickets, dynamic work items -- must leave no state behind).  usage: python tools/soak.py [seconds] [seed] [big]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from midas_amd import abi, synth  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+
+def hot_spot(contigs, reads, rng, share):
+    """Move `share` of the reads of the first contig into a 600-site window (keeps them sorted)."""
+    n0 = int(contigs.read_begin[1])
+    if n0 < 50:
+        return
+    pick = rng.random(n0) < share
+    span = max(1, min(600, int(contigs.length[0]) - int(reads.l_seq.max()) - 40))
+    pos = reads.pos[:n0].copy()
+    pos[pick] = 10 + (rng.random(int(pick.sum())) * span).astype(np.int32)
+    order = np.argsort(pos, kind='stable')
+    sub = synth.take_reads(reads, np.concatenate([order, np.arange(n0, reads.n_reads)]))
+    sub.pos[:n0] = pos[order]
+    return sub
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    ctx = abi.Context(0)
+    t_end = time.time() + budget
+    n = bad = 0
+    while time.time() < t_end:
+        read_len = int(rng.choice([36, 75, 100, 125, 150, 151, 250]))
+        big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # > 1024 tiles: the dynamic work-item path
+        contig_len = int(rng.integers(400000, 900000)) if big else int(rng.integers(read_len + 40, 120000))
+        ncontig = int(rng.integers(4, 12)) if big else int(rng.integers(1, 12))
+        nsp = int(rng.integers(1, 4))
+        cov = float(rng.choice([0.0, 0.3, 2, 8, 25, 60]))
+        n_reads = int(min(2500000 if big else 400000, cov * contig_len * ncontig * nsp / read_len))
+        kw = dict(n_species=nsp, contigs_per_species=ncontig, contig_len=contig_len, n_reads=max(n_reads, 0), read_len=read_len,
+                  seed=int(rng.integers(1, 1 << 30)), var_len=bool(rng.random() < 0.5), lowercase_frac=0.05)
+        contigs, reads = synth.make_dataset(**kw)
+        tag = ''
+        if reads.n_reads > 3000 and rng.random() < 0.4:
+            moved = hot_spot(contigs, reads, rng, float(rng.choice([0.3, 0.9])))
+            if moved is not None:
+                reads, tag = moved, ' hot'
+        args = dict(abi.DEFAULT_ARGS)
+        if rng.random() < 0.3:
+            args.update(baseq=int(rng.choice([0, 20, 41])), mapq=int(rng.choice([0, 30])), mapid=float(rng.choice([90.0, 97.5])),
+                        aln_cov=float(rng.choice([0.5, 0.95])), readq=int(rng.choice([0, 30])))
+        thr = abi.Thresholds.from_args(args)
+        st, er, oc, oa, os_ = c_oracle.pileup(thr, contigs, reads)
+        b = ctx.batch(contigs, reads)
+        ok = True
+        for rep in range(3):
+            b.run(thr)
+            counts, allele, stats = b.fetch()
+            ok = ok and np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)
+        info = b.info()
+        b.close()
+        n += 1
+        if not ok:
+            bad += 1
+            print("MISMATCH", kw, tag, args, flush=True)
+        elif n % 10 == 0:
+            print("%d cases ok (last: %d sites, %d reads, %d tiles, %d items%s)" % (n, info.n_sites, info.n_reads, info.n_tiles,
+                                                                                   info.n_work_items, tag), flush=True)
+    print("soak: %d cases, %d mismatches" % (n, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
