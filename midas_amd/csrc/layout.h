@@ -20,9 +20,9 @@
 //   tiles [n_tiles]   32 B   {contig, start, len, species, site_base}
 //   out counts [n_sites][4] u32 (A,C,G,T) ; out allele [n_sites] u8
 //
-// A pileup lane owns kChunk = 32 consecutive bases of a read: 32 quality bytes (two dwordx4) and 16
-// bytes of call codes (one dwordx4).  The zero padding makes the last chunk of a read self-masking:
-// a padded base has quality 0, which never reaches a threshold >= 1.
+// A pileup lane owns kBases = 31 consecutive bases of a read in kChunk = 32 slots: 32 quality bytes (two dwordx4) and
+// 16 bytes of call codes (one dwordx4); slot 31 and the slots past the end of the read are padding.  The zero padding
+// is self-masking: a padded slot has quality 0, which never reaches a threshold >= 1.
 //
 // Algorithmic bytes: ceil(l/2) + l + 4*n_cigar + 16 per read, 17 per site.
 #pragma once
@@ -59,7 +59,17 @@ constexpr uint8_t kRecSentinel = 0x80; // the record after the last read (l_seq 
 constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >= l_seq onto a site inside the
                                         // contig: pysam would index past SEQ (IndexError) if the read is kept
 
-constexpr int kChunk = 32;          // bases per lane
+constexpr int kChunk = 32;          // payload slots per lane: 32 quality bytes, 16 bytes of call codes
+#ifndef MIDAS_LANE_BASES
+#define MIDAS_LANE_BASES 31
+#endif
+// Bases per lane.  31, not 32: the last slot of every lane is padding (quality 0, never counted).  The lanes of a read
+// then start 31 sites apart, i.e. 124 dwords apart in the [site][A,C,G,T] tallies -- 4 banks short of a multiple of the
+// bank count -- so their LDS atomics fall into different banks; 32 sites apart they all hit the same four banks
+// (measured with 32: 57 % of the LDS cycles were bank conflicts).  A 150 bp read takes 5 lanes either way.
+constexpr int kBases = MIDAS_LANE_BASES;
+static_assert(kBases == 31 || kBases == 32, "a lane carries 31 or 32 bases");
+__host__ __device__ inline uint32_t blob_chunks(uint32_t l_seq) { return (l_seq + (uint32_t)kBases - 1u) / (uint32_t)kBases; }
 constexpr int kMaxLSeq = 1024;      // at most 32 lanes per read
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
 constexpr int kMaxSegments = 6;     // match segments a read may be served as (more: it keeps its CIGAR)
@@ -81,10 +91,8 @@ struct Tile {               // 32 bytes
 static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 
 // Offsets of the payload sections inside a read's blob.
-__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return (l_seq + 31u) & ~31u; }
-__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq) {
-  return blob_seq_off(l_seq) + ((((l_seq + 1u) >> 1) + 15u) & ~15u);
-}
+__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return blob_chunks(l_seq) * 32u; }
+__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq) { return blob_chunks(l_seq) * 48u; }
 __host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_stored) {
   return (blob_cigar_off(l_seq) + 4u * n_cigar_stored + 7u) & ~7u;
 }

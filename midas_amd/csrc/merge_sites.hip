@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/midas_snps.h"
@@ -161,7 +162,8 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
     const int grid = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
     M_TRY(hipEventRecord(e0, ctx->stream));
     const dim3 g(grid > 0 ? grid : 1), b(256);
-    hipLaunchKernelGGL(merge_sites_kernel, g, b, 0, ctx->stream, k);
+    const size_t dyn_lds = getenv("MIDAS_MERGE_LDS") ? (size_t)atoi(getenv("MIDAS_MERGE_LDS")) : 0;   // experiment: cap occupancy
+    hipLaunchKernelGGL(merge_sites_kernel, g, b, dyn_lds, ctx->stream, k);
     M_TRY(hipGetLastError());
     M_TRY(hipEventRecord(e1, ctx->stream));
     M_TRY(hipMemcpyAsync(out_calls + lo * 4, d_b, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -400,17 +400,18 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         // qualities (0 for a base that is not A/C/G/T) and, per 32-base chunk, 16 bytes of call codes: byte k =
         // code(base k) | code(base k + 16) << 4; bases past the end are kCallOther with quality 0
         uint8_t* d4 = b + blob_seq_off(len);
-        const uint32_t n_chunks = (len + kChunk - 1) / kChunk;
+        const uint32_t n_chunks = blob_chunks(len);
         for (uint32_t c = 0; c < n_chunks; ++c) {
           for (uint32_t kk = 0; kk < 16; ++kk) {
             uint8_t code[2];
             for (uint32_t h = 0; h < 2; ++h) {
-              const uint32_t x = c * kChunk + 16 * h + kk;    // base of the record
-              if (x < len) {
+              const uint32_t slot = 16 * h + kk;               // slot of the lane
+              const uint32_t x = c * kBases + slot;            // base of the record
+              if (slot < (uint32_t)kBases && x < len) {
                 const uint32_t y = q0 + x;                      // base of the read
                 const uint8_t bc = (uint8_t)((s4[y >> 1] >> ((~y & 1u) * 4)) & 15u);
                 code[h] = kCallCode[bc];
-                b[x] = code[h] == kCallOther ? (uint8_t)0 : q[y];
+                b[c * kChunk + slot] = code[h] == kCallOther ? (uint8_t)0 : q[y];
               } else {
                 code[h] = kCallOther;
               }

@@ -304,7 +304,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   b->n_species = contigs->n_species;
   b->blob_bytes = ps.blob_bytes;
   b->alg_bytes = ps.read_algorithmic_bytes + 17 * n_sites;
-  b->lanes_per_read = ps.max_l_seq <= kChunk ? 1 : (ps.max_l_seq + kChunk - 1) / kChunk;
+  b->lanes_per_read = ps.max_l_seq <= kBases ? 1 : (ps.max_l_seq + kBases - 1) / kBases;
 
 #define B_TRY(call)                              \
   do {                                           \

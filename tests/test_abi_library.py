@@ -73,15 +73,31 @@ def test_product_never_imports_the_oracle():
 CALL = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
 
 
+LANE_BASES = 31      # layout.h kBases: a lane carries 31 bases in 32 payload slots, the last slot is padding
+
+
+def n_lanes(n_bases):
+    return (n_bases + LANE_BASES - 1) // LANE_BASES
+
+
 def call_codes(seq):
-    """layout.h: 16 bytes per 32-base chunk; byte k = code(base k) | code(base k + 16) << 4; padding = 0x2"""
+    """layout.h: 16 bytes per lane (31 bases + one padding slot); byte k = code(slot k) | code(slot k + 16) << 4; padding = 0x2"""
     code = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
     out = bytearray()
-    for c0 in range(0, max(len(seq), 1), 32):
-        chunk = [code.get(ch, 0x2) for ch in seq[c0:c0 + 32]]
+    for c0 in range(0, len(seq), LANE_BASES):
+        chunk = [code.get(ch, 0x2) for ch in seq[c0:c0 + LANE_BASES]]
         chunk += [0x2] * (32 - len(chunk))
         out += bytes(chunk[k] | (chunk[k + 16] << 4) for k in range(16))
     return bytes(out)
+
+
+def lane_quals(quals):
+    """layout.h: 32 quality bytes per lane, the 31 bases then a zero; zeros past the end of the record"""
+    out = []
+    for c0 in range(0, len(quals), LANE_BASES):
+        lane = list(quals[c0:c0 + LANE_BASES])
+        out += lane + [0] * (32 - len(lane))
+    return out
 
 
 REC_DTYPE = np.dtype([("pos", "<i4"), ("off8", "<u4"), ("l", "<u2"), ("n", "<u2"), ("nm", "<u2"),
@@ -152,8 +168,8 @@ def test_pack_serves_reads_as_match_segments():
     assert first == [1, 0, 1, 0, 1, 1, 0, 0]
     # payload of the second record of read 0: read bases 77..149
     o = int(r["off8"][1]) * 8
-    assert bytes(blob[o + 96:o + 96 + 48]) == call_codes(seq[77:150])
-    assert blob[o:o + 73].tolist() == [40] * 73 and not blob[o + 73:o + 96].any()
+    assert bytes(blob[o + 96:o + 96 + 48]) == call_codes(seq[77:150])               # 73 bases: three lanes
+    assert blob[o:o + 96].tolist() == lane_quals([40] * 73)
 
 
 def test_pack_keeps_the_cigar_of_reads_it_cannot_segment():
@@ -241,10 +257,10 @@ def test_pack_round_trips_synthetic_reads():
             assert qmean_of(r[j:j + 1])[0] == int(q.sum()) // l
             o = int(r["off8"][j]) * 8
             acgt = np.array([ch in "ACGT" for ch in seq[qs:qs + ln]])
-            np.testing.assert_array_equal(blob[o:o + ln], np.where(acgt, q[qs:qs + ln], 0))   # non-ACGT bases carry quality 0
-            assert not blob[o + ln:o + ((ln + 31) & ~31)].any()        # zero padding = self-masking tail
-            so = o + ((ln + 31) & ~31)
-            assert bytes(blob[so:so + 16 * ((ln + 31) // 32)]) == call_codes(seq[qs:qs + ln])
+            # non-ACGT bases carry quality 0; so do the padding slots (the self-masking tail)
+            assert blob[o:o + 32 * n_lanes(ln)].tolist() == lane_quals(np.where(acgt, q[qs:qs + ln], 0).tolist())
+            so = o + 32 * n_lanes(ln)
+            assert bytes(blob[so:so + 16 * n_lanes(ln)]) == call_codes(seq[qs:qs + ln])
             lr, al, nm, first = seg_fields(r[j:j + 1])
             clips = sum(ln2 for op, ln2 in cig if op == 4)
             assert (lr[0], al[0], nm[0], first[0]) == (l, l - clips, int(reads.nm[i]), int(s == 0))
