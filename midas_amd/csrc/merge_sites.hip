@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
-#include <cstdlib>
 #include <vector>
 
 #include "../../include/midas_snps.h"
@@ -40,6 +39,7 @@ __global__ __launch_bounds__(256) void merge_sites_kernel(MergeKParams p) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n_sites; i += stride) {
     const u32x4* cnt = reinterpret_cast<const u32x4*>(p.counts) + i;
     unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll 8                                                 // eight independent row loads in flight per thread
     for (int s = 0; s < p.n_samples; ++s) {                      // compute_pooled_counts (:38-43)
       const u32x4 c = cnt[(size_t)s * p.n_sites];
       pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void merge_sites_kernel(MergeKParams p) {
       if ((double)sd / md > p.site_ratio) return;
       ++pass;
     };
+#pragma unroll 8
     for (int s = 0; s < p.n_samples; ++s) sample(s, cnt[(size_t)s * p.n_sites]);
     const double prevalence = (double)pass / (double)p.n_samples;
     int flag = 0;                                                // flag (:106-114)
@@ -162,8 +163,7 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
     const int grid = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
     M_TRY(hipEventRecord(e0, ctx->stream));
     const dim3 g(grid > 0 ? grid : 1), b(256);
-    const size_t dyn_lds = getenv("MIDAS_MERGE_LDS") ? (size_t)atoi(getenv("MIDAS_MERGE_LDS")) : 0;   // experiment: cap occupancy
-    hipLaunchKernelGGL(merge_sites_kernel, g, b, dyn_lds, ctx->stream, k);
+    hipLaunchKernelGGL(merge_sites_kernel, g, b, 0, ctx->stream, k);
     M_TRY(hipGetLastError());
     M_TRY(hipEventRecord(e1, ctx->stream));
     M_TRY(hipMemcpyAsync(out_calls + lo * 4, d_b, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
