@@ -77,6 +77,35 @@ def test_merge_sites_fields_match_oracle(ctx, dataset, variant):
     assert got['kernel_ms'] > 0
 
 
+@pytest.mark.parametrize("n_samples", [19, 20, 24, 33, 50, 64, 65])
+def test_many_samples(ctx, n_samples):
+    """Dozens of samples (BASELINE config 5 merges 50), counts on both sides of a byte, against the oracle."""
+    rng = np.random.default_rng(100 + n_samples)
+    n = 700
+    counts = []
+    for s in range(n_samples):
+        depth = rng.poisson(9.0, n)
+        c = np.zeros((n, 4), np.int64)
+        ref = rng.integers(0, 4, n)
+        alt = (ref + 1 + rng.integers(0, 3, n)) % 4
+        na = np.where(rng.random(n) < 0.2, rng.binomial(depth, 0.4), 0)
+        c[np.arange(n), ref] = depth - na
+        c[np.arange(n), alt] += na
+        counts.append(c)
+    # every 9th site: one sample with a count that does not fit a byte (255 itself still does: sites 4, 13, ...)
+    for i in range(0, n, 9):
+        counts[i % n_samples][i, i % 4] = 256 + 37 * i
+    for i in range(4, n, 9):
+        counts[(i + 1) % n_samples][i, (i + 1) % 4] = 255
+    counts = [c.astype(np.uint32) for c in counts]
+    mean = [9.0 + 0.1 * s for s in range(n_samples)]
+    args = dict(abi.DEFAULT_MERGE_ARGS, site_prev=0.5, snp_type=['bi', 'tri'])
+    got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
+    exp = oracle_fields(counts, mean, args)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+
+
 def test_merge_sites_edge_shapes(ctx):
     prm = abi.MergeParams.from_args(abi.DEFAULT_MERGE_ARGS)
     # no sites at all
