@@ -16,18 +16,44 @@
 #include <thread>
 #include <vector>
 
+// A byte/word buffer that is NOT zero-filled when it grows: the BAM stream, its inflated form and the decoded SEQ / QUAL /
+// CIGAR columns are hundreds of MB that get overwritten in full right away (std::vector::resize would memset them on one
+// core first: a third of the decode time).
+template <class T>
+struct RawBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  ~RawBuf() { free(p); }
+  bool resize(size_t m) {
+    free(p);
+    p = m ? static_cast<T*>(malloc(m * sizeof(T))) : nullptr;
+    n = p ? m : 0;
+    return m == 0 || p != nullptr;
+  }
+  void release() { free(p); p = nullptr; n = 0; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct midas_bam {
   std::string path;
   std::vector<std::string> ref_names;
   std::vector<int64_t> ref_lens;
-  std::vector<uint8_t> data;   // inflated stream
+  RawBuf<uint8_t> data;        // inflated stream
   size_t rec_begin = 0;        // offset of the first alignment record
   // decoded SoA
   std::vector<int32_t> refid, pos, nm, l_seq;
-  std::vector<uint8_t> mapq, seq4, qual;
+  std::vector<uint8_t> mapq;
+  RawBuf<uint8_t> seq4, qual;
   std::vector<uint16_t> flag;
   std::vector<int64_t> seq_off, qual_off, cigar_off;
-  std::vector<uint32_t> cigar;
+  RawBuf<uint32_t> cigar;
   bool loaded = false;
 };
 
@@ -77,13 +103,14 @@ int writer_threads(int want) {
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
-int32_t bgzf_inflate_file(const std::string& path, std::vector<uint8_t>& out, char* err256) {
+int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
   fseek(f, 0, SEEK_END);
   const long fsz = ftell(f);
   fseek(f, 0, SEEK_SET);
-  std::vector<uint8_t> comp((size_t)fsz);
+  RawBuf<uint8_t> comp;
+  if (!comp.resize((size_t)fsz)) { fclose(f); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   if (fsz > 0 && fread(comp.data(), 1, (size_t)fsz, f) != (size_t)fsz) {
     fclose(f);
     set_err(err256, "short read on %s", path.c_str());
@@ -115,7 +142,7 @@ int32_t bgzf_inflate_file(const std::string& path, std::vector<uint8_t>& out, ch
     upos += isize;
     p += bsize;
   }
-  out.resize(upos);
+  if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   std::atomic<size_t> next{0};
   std::atomic<int> bad{0};
   auto work = [&] {
@@ -305,7 +332,7 @@ int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) {
   b->path = path;
   int32_t st = bgzf_inflate_file(b->path, b->data, err256);
   if (st != MIDAS_SNPS_OK) { delete b; return st; }
-  const std::vector<uint8_t>& d = b->data;
+  const RawBuf<uint8_t>& d = b->data;
   if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) {
     set_err(err256, "%s: missing BAM magic", path);
     delete b;
@@ -347,7 +374,7 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
                        char* err256) {
   if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
   if (!b->loaded) {
-    const std::vector<uint8_t>& d = b->data;
+    const RawBuf<uint8_t>& d = b->data;
     // pass 1: record offsets (what fetch(contig, ...) can ever return: refID >= 0)
     std::vector<size_t> offs;
     size_t p = b->rec_begin;
@@ -378,9 +405,10 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
       b->seq_off[i + 1] = b->seq_off[i] + (l + 1) / 2;
       b->qual_off[i + 1] = b->qual_off[i] + l;
     }
-    b->cigar.resize((size_t)b->cigar_off[n]);
-    b->seq4.resize((size_t)b->seq_off[n]);
-    b->qual.resize((size_t)b->qual_off[n]);
+    if (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n])) {
+      set_err(err256, "out of memory decoding %s", b->path.c_str());
+      return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+    }
     // pass 2: decode in parallel
     std::atomic<size_t> next{0};
     auto work = [&] {
@@ -416,7 +444,7 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
     work();
     for (auto& x : th) x.join();
     b->loaded = true;
-    std::vector<uint8_t>().swap(b->data);   // the inflated stream is no longer needed
+    b->data.release();   // the inflated stream is no longer needed
   }
   if (n_reads) *n_reads = (int64_t)b->pos.size();
   if (seq_bytes) *seq_bytes = (int64_t)b->seq4.size();
@@ -430,7 +458,17 @@ int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t
                        uint8_t* qual, uint32_t* cigar) {
   if (!b || !b->loaded) return MIDAS_SNPS_ERR_INVALID_ARG;
   const size_t n = b->pos.size();
-  auto cp = [](void* dst, const void* src, size_t bytes) { if (dst && bytes) memcpy(dst, src, bytes); };
+  // the three big columns are copied by all cores (a single memcpy of ~250 MB is 60 ms of the stage)
+  auto cp = [](void* dst, const void* src, size_t bytes) {
+    if (!dst || !bytes) return;
+    const size_t piece = (size_t)4 << 20;
+    if (bytes < 4 * piece) { memcpy(dst, src, bytes); return; }
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    run_pool(hw_threads(0), n_pieces, [&](size_t i) {
+      const size_t lo = i * piece, len = std::min(piece, bytes - lo);
+      memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(src) + lo, len);
+    });
+  };
   cp(refid, b->refid.data(), n * 4); cp(pos, b->pos.data(), n * 4); cp(mapq, b->mapq.data(), n);
   cp(flag, b->flag.data(), n * 2); cp(nm, b->nm.data(), n * 4); cp(l_seq, b->l_seq.data(), n * 4);
   cp(seq_off, b->seq_off.data(), (n + 1) * 8); cp(qual_off, b->qual_off.data(), (n + 1) * 8);
