@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kIndexBlock) void index_reads_kernel(IndexParams p)
       // exact last tile of a very long record: walk its CIGAR (contig from the tile table)
       const uint4 r = reinterpret_cast<const uint4*>(p.rec)[i];
       const uint32_t* cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(r) * 8 +
-                                                              blob_cigar_off((uint32_t)rec_l(r)));
+                                                              blob_cigar_off((uint32_t)rec_l(r), (uint32_t)p.lane_bases));
       long long reflen = 0;
       const int n = rec_n(r);
       for (int k = 0; k < n; ++k) {

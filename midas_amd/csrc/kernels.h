@@ -40,6 +40,7 @@ struct IndexParams {
   int32_t n_reads;
   int32_t n_stat_words;              // n_species * 4
   int32_t tile_len;                  // sites per tile of this batch (<= kTileSites)
+  int32_t lane_bases;                // bases per lane of the blob layout (31 or 32)
 };
 
 // keep_read's two ratio tests as exact integer thresholds, built on the host per threshold set
@@ -80,7 +81,8 @@ struct PileupParams {
   int32_t n_tiles;
   int32_t n_reads;
   int32_t grid_blocks;               // persistent workgroups: 2 per CU
-  int32_t lanes_per_read;            // ceil(max_l_seq / 16)
+  int32_t lanes_per_read;            // ceil(max_l_seq / lane_bases)
+  int32_t lane_bases;                // bases per lane of the blob layout (31 or 32, layout.h)
   int32_t reads_per_wave;            // 64 / lanes_per_read
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;

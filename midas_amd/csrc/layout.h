@@ -20,7 +20,7 @@
 //   tiles [n_tiles]   32 B   {contig, start, len, species, site_base}
 //   out counts [n_sites][4] u32 (A,C,G,T) ; out allele [n_sites] u8
 //
-// A pileup lane owns kBases = 31 consecutive bases of a read in kChunk = 32 slots: 32 quality bytes (two dwordx4) and
+// A pileup lane owns 31 (or 32, see lane_bases_for) consecutive bases of a read in kChunk = 32 slots: 32 quality bytes (two dwordx4) and
 // 16 bytes of call codes (one dwordx4); slot 31 and the slots past the end of the read are padding.  The zero padding
 // is self-masking: a padded slot has quality 0, which never reaches a threshold >= 1.
 //
@@ -60,16 +60,20 @@ constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >
                                         // contig: pysam would index past SEQ (IndexError) if the read is kept
 
 constexpr int kChunk = 32;          // payload slots per lane: 32 quality bytes, 16 bytes of call codes
-#ifndef MIDAS_LANE_BASES
-#define MIDAS_LANE_BASES 31
-#endif
-// Bases per lane.  31, not 32: the last slot of every lane is padding (quality 0, never counted).  The lanes of a read
-// then start 31 sites apart, i.e. 124 dwords apart in the [site][A,C,G,T] tallies -- 4 banks short of a multiple of the
-// bank count -- so their LDS atomics fall into different banks; 32 sites apart they all hit the same four banks
-// (measured with 32: 57 % of the LDS cycles were bank conflicts).  A 150 bp read takes 5 lanes either way.
-constexpr int kBases = MIDAS_LANE_BASES;
-static_assert(kBases == 31 || kBases == 32, "a lane carries 31 or 32 bases");
-__host__ __device__ inline uint32_t blob_chunks(uint32_t l_seq) { return (l_seq + (uint32_t)kBases - 1u) / (uint32_t)kBases; }
+// Bases per lane: 31 or 32, fixed per batch (lane_bases_for).  31: the last slot of every lane is padding (quality 0,
+// never counted).  The lanes of a read then start 31 sites apart, i.e. 124 dwords apart in the [site][A,C,G,T] tallies
+// -- 4 banks short of a multiple of the bank count -- so their LDS atomics fall into different banks; 32 sites apart
+// they all hit the same four banks (measured with 32 on 150 bp reads: 57 % of the LDS cycles were bank conflicts, kernel
+// +6 %).  32 is kept for the read lengths where it saves a whole lane per read and a read has few lanes to collide
+// (125 bp: 4 lanes instead of 5, measured 9 % faster; 250 bp: 8 instead of 9, measured 5 % slower, so 31 there).
+__host__ __device__ inline uint32_t blob_chunks(uint32_t l_seq, uint32_t bases) {
+  return bases == 32u ? (l_seq + 31u) >> 5 : (l_seq + 30u) / 31u;
+}
+inline int lane_bases_for(int32_t max_l_seq) {
+  const uint32_t l = max_l_seq > 0 ? (uint32_t)max_l_seq : 1u;
+  const uint32_t n32 = blob_chunks(l, 32u), n31 = blob_chunks(l, 31u);
+  return (n32 < n31 && n32 <= 5u) ? 32 : 31;
+}
 constexpr int kMaxLSeq = 1024;      // at most 32 lanes per read
 constexpr int kMaxField16 = 65534;  // l_seq / n_cigar / NM representable in the record
 constexpr int kMaxSegments = 6;     // match segments a read may be served as (more: it keeps its CIGAR)
@@ -91,10 +95,10 @@ struct Tile {               // 32 bytes
 static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 
 // Offsets of the payload sections inside a read's blob.
-__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq) { return blob_chunks(l_seq) * 32u; }
-__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq) { return blob_chunks(l_seq) * 48u; }
-__host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_stored) {
-  return (blob_cigar_off(l_seq) + 4u * n_cigar_stored + 7u) & ~7u;
+__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq, uint32_t bases) { return blob_chunks(l_seq, bases) * 32u; }
+__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq, uint32_t bases) { return blob_chunks(l_seq, bases) * 48u; }
+__host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_stored, uint32_t bases) {
+  return (blob_cigar_off(l_seq, bases) + 4u * n_cigar_stored + 7u) & ~7u;
 }
 
 // Error word written by the kernels: (read_index << 8) | kind, reduced with atomicMin.

@@ -271,6 +271,8 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     out->read_algorithmic_bytes += alg[t];
     out->max_l_seq = std::max(out->max_l_seq, maxl[t]);
   }
+  out->lane_bases = lane_bases_for(out->max_l_seq);
+  const uint32_t lane_bases = (uint32_t)out->lane_bases;
   // records in input order: read i owns records [first[i], first[i + 1])
   std::vector<int64_t> first(n + 1);
   first[0] = 0;
@@ -317,7 +319,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         cflags[j] = cigar_flags(cg, nc, l, r->pos[i], clen, &reflen);
         rec_read[j] = (uint32_t)i;
         rec_seg[j] = 0;
-        bytes[j] = blob_bytes(l, nc);
+        bytes[j] = blob_bytes(l, nc, lane_bases);
         set_keys(j, r->pos[i], reflen, false);
       } else {
         uint32_t at = 0;
@@ -328,7 +330,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
           cflags[j] = kRecSimple;
           rec_read[j] = (uint32_t)i;
           rec_seg[j] = (uint8_t)s;
-          bytes[j] = blob_bytes((uint32_t)pieces[s].len, 0u);
+          bytes[j] = blob_bytes((uint32_t)pieces[s].len, 0u, lane_bases);
           set_keys(j, (int64_t)r->pos[i] + pieces[s].roff, pieces[s].len, true);
         }
       }
@@ -399,15 +401,15 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       {
         // qualities (0 for a base that is not A/C/G/T) and, per 32-base chunk, 16 bytes of call codes: byte k =
         // code(base k) | code(base k + 16) << 4; bases past the end are kCallOther with quality 0
-        uint8_t* d4 = b + blob_seq_off(len);
-        const uint32_t n_chunks = blob_chunks(len);
+        uint8_t* d4 = b + blob_seq_off(len, lane_bases);
+        const uint32_t n_chunks = blob_chunks(len, lane_bases);
         for (uint32_t c = 0; c < n_chunks; ++c) {
           for (uint32_t kk = 0; kk < 16; ++kk) {
             uint8_t code[2];
             for (uint32_t h = 0; h < 2; ++h) {
               const uint32_t slot = 16 * h + kk;               // slot of the lane
-              const uint32_t x = c * kBases + slot;            // base of the record
-              if (slot < (uint32_t)kBases && x < len) {
+              const uint32_t x = c * lane_bases + slot;        // base of the record
+              if (slot < lane_bases && x < len) {
                 const uint32_t y = q0 + x;                      // base of the read
                 const uint8_t bc = (uint8_t)((s4[y >> 1] >> ((~y & 1u) * 4)) & 15u);
                 code[h] = kCallCode[bc];
@@ -432,7 +434,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         rr.nm = (uint16_t)((uint32_t)r->nm[i] | ((at & 63u) << 10));
         (void)k;
       } else {
-        memcpy(b + blob_cigar_off(l), cg, 4ull * nc);
+        memcpy(b + blob_cigar_off(l, lane_bases), cg, 4ull * nc);
         rr.n_cigar = (uint16_t)nc;
         rr.nm = r->nm[i] < 0 ? kNmAbsent : (uint16_t)r->nm[i];
       }

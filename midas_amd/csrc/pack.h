@@ -9,6 +9,7 @@ struct PackSummary {
   int64_t n_records = 0;               // device records: one per match segment, or one per read that keeps its CIGAR
   int64_t read_algorithmic_bytes = 0;  // sum(ceil(l/2) + l + 4*n_cigar + 16)
   int32_t max_l_seq = 0;
+  int32_t lane_bases = 31;             // bases per lane of this batch's blob layout (layout.h lane_bases_for)
 };
 
 // rec == blob == nullptr: size query only (blob_bytes, n_records).  rec must hold n_records + 1 records (sentinel);

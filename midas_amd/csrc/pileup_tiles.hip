@@ -16,8 +16,8 @@
 // the compute-bound middle of its neighbours instead of every workgroup marching through
 // load -> compute -> store in lockstep (measured: those three phases used to simply add up).
 //
-// Lane mapping.  A lane owns kBases = 31 consecutive bases of one read (32 payload slots, the last one padding:
-// layout.h says why 31): two 16-byte loads of quals and one 16-byte load of 4-bit call codes.  A read of l_seq
+// Lane mapping.  A lane owns 31 consecutive bases of one read (32 payload slots, the last one padding: layout.h says
+// why 31, and when a batch uses all 32 instead): two 16-byte loads of quals and one 16-byte load of 4-bit call codes.  A read of l_seq
 // bases occupies ceil(l_seq/31) adjacent lanes (5 for 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
 // floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
 // read: a segmented shuffle reduction over the read's lanes gives it without re-reading anything.
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   const int g = lane / lpr;
   const int c = lane - g * lpr;
   const bool lane_used = g < rpw;
-  const int q0 = c * kBases;                     // first base of the lane; its payload sits in slot block c
+  const int lane_bases = p.lane_bases;           // 31 or 32 (layout.h), uniform
+  const int q0 = c * lane_bases;                 // first base of the lane; its payload sits in slot block c
   const int stride = (kPileupBlock / 64) * rpw;
   const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
   const int bq = p.baseq < 1 ? 1 : p.baseq;   // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     if (q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk + 16);
-      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l) + c * (kChunk / 2));
+      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l, (uint32_t)lane_bases) + c * (kChunk / 2));
       d.qw[0] = qa.x; d.qw[1] = qa.y; d.qw[2] = qa.z; d.qw[3] = qa.w;
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
       d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
               cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
             }
             if (count_all) {
-              const int nvalid = fl - q0 < kBases ? fl - q0 : kBases;
+              const int nvalid = fl - q0 < lane_bases ? fl - q0 : lane_bases;
 #pragma unroll
               for (int w = 0; w < NW; ++w) {
                 const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const uint32_t* cig = nullptr;
       uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u, cgl = 0u;   // first four CIGAR ops and the last one
       if (act && !simple) {
-        cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l));
+        cig = reinterpret_cast<const uint32_t*>(p.blob + (size_t)rec_off8(rec_cur) * 8 + blob_cigar_off((uint32_t)l, (uint32_t)lane_bases));
         if (n > 0) {
           // not prefetched (it would cost 10 VGPRs of the double-buffered payload): only the ~15 % mixed / general
           // wave-iterations come here, the pure-simple ones branch over all of this
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
       const int min_align = s_tables[p.table_len + (l_read < p.table_len ? l_read : 0)];
 
-      const int nvalid = has ? (l - q0 < kBases ? l - q0 : kBases) : 0;
+      const int nvalid = has ? (l - q0 < lane_bases ? l - q0 : lane_bases) : 0;
 
       // ---- keep_read (midas/run/snps.py:141-162), same order of evaluation ----------------------
       // Every test is evaluated (selects, no branches: the cascade used to cost seven exec-mask branches per

@@ -49,7 +49,7 @@ struct midas_snps_batch {
   // facts
   int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
   int64_t n_records = 0;   // device records (match segments + reads that keep their CIGAR) >= n_reads
-  int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, tile_len = kTileSites;
+  int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, lane_bases = 31, tile_len = kTileSites;
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot
   int32_t timing_slots = 0;
@@ -304,7 +304,8 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   b->n_species = contigs->n_species;
   b->blob_bytes = ps.blob_bytes;
   b->alg_bytes = ps.read_algorithmic_bytes + 17 * n_sites;
-  b->lanes_per_read = ps.max_l_seq <= kBases ? 1 : (ps.max_l_seq + kBases - 1) / kBases;
+  b->lane_bases = ps.lane_bases;
+  b->lanes_per_read = ps.max_l_seq <= b->lane_bases ? 1 : (ps.max_l_seq + b->lane_bases - 1) / b->lane_bases;
 
 #define B_TRY(call)                              \
   do {                                           \
@@ -520,6 +521,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   ip.n_reads = (int32_t)b->n_records;
   ip.n_stat_words = b->n_species * MIDAS_STATS;
   ip.tile_len = b->tile_len;
+  ip.lane_bases = b->lane_bases;
   HIP_TRY(ctx, launch_index_reads(ip, s));
   if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
 
@@ -543,6 +545,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
   if (const char* e = getenv("MIDAS_SNPS_GRID")) pp.grid_blocks = atoi(e) > 0 ? atoi(e) : pp.grid_blocks;   // experiments only
   pp.lanes_per_read = b->lanes_per_read;
+  pp.lane_bases = b->lane_bases;
   pp.reads_per_wave = 64 / b->lanes_per_read;
   pp.baseq = thr->baseq;
   pp.mapq = thr->mapq;

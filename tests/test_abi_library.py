@@ -172,6 +172,21 @@ def test_pack_serves_reads_as_match_segments():
     assert blob[o:o + 96].tolist() == lane_quals([40] * 73)
 
 
+def test_pack_uses_all_32_slots_where_that_saves_a_lane():
+    """layout.h lane_bases_for: 125 bp reads pack 32 bases per lane (4 lanes, no padding slot), 150 bp reads 31 (5 lanes)."""
+    seq = "".join("ACGT"[(5 * i) % 4] for i in range(125))
+    reads = H.reads_from_dicts([dict(pos=10, cigar="125M", seq=seq, nm=0, qual=[30 + (i % 10) for i in range(125)])])
+    rec, blob, maxl = abi.pack_reads(reads)
+    assert maxl == 125 and blob.size == 128 + 64
+    assert blob[:125].tolist() == [30 + (i % 10) for i in range(125)] and not blob[125:128].any()
+    code = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
+    exp = bytearray()
+    for c0 in range(0, 125, 32):
+        chunk = [code[ch] for ch in seq[c0:c0 + 32]] + [0x2] * max(0, c0 + 32 - 125)
+        exp += bytes(chunk[k] | (chunk[k + 16] << 4) for k in range(16))
+    assert bytes(blob[128:192]) == bytes(exp)
+
+
 def test_pack_keeps_the_cigar_of_reads_it_cannot_segment():
     seq = "A" * 60
     cases = [("10S", 10, "no aligned base"), ("5S5S50M", 60, "two clips at one end"), ("30M2P30M", 60, "pad op"),

@@ -233,6 +233,19 @@ def test_short_reads(hip_ctx, thr_default, read_len, var_len):
     _assert_same(hip_ctx, thr_default, contigs, reads)
 
 
+@pytest.mark.parametrize("read_len", [32, 64, 96, 125, 128, 151, 160, 250])
+def test_read_lengths_on_both_sides_of_the_lane_size(hip_ctx, thr_default, read_len):
+    """A batch packs 31 bases per lane, or 32 where that saves a lane per read (32, 64, 96, 125, 128, 160 here): both
+    layouts, reads straddling tiles, indels and clips included."""
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=2, contig_len=9000, n_reads=5000,
+                                        read_len=read_len, seed=47 + read_len, var_len=False)
+    _assert_same(hip_ctx, thr_default, contigs, reads)
+    info_lanes = {32: 1, 64: 2, 96: 3, 125: 4, 128: 4, 151: 5, 160: 5, 250: 9}[read_len]
+    b = hip_ctx.batch(contigs, reads)
+    assert b.info().lanes_per_read == info_lanes
+    b.close()
+
+
 def test_unsupported_and_malformed_inputs_are_statuses_not_crashes(hip_ctx, thr_default):
     contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=5000, n_reads=100, seed=1)
     bad = abi.ContigTable(length=contigs.length, species=contigs.species, read_begin=[0, 99], ref=contigs.ref, n_species=1)
