@@ -72,6 +72,23 @@ def all_gather_summary(rows):
     return out.reshape((ws,) + tuple(t.shape)).sum(dim=0).cpu().numpy()
 
 
+def all_gather_rows_f64(rows):
+    """Like all_gather_summary for float64 rows (the genes summary has means and medians): rows are zero outside the
+    species this rank owns, so the sum over ranks is the owner's row (nan stays nan)."""
+    import torch
+    import torch.distributed as dist
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    rank, ws = world()
+    if ws == 1:
+        return rows.copy()
+    t = torch.from_numpy(rows)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.reshape((ws,) + tuple(t.shape)).sum(dim=0).cpu().numpy()
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -17,7 +17,7 @@ from time import time
 
 import numpy as np
 
-from midas_amd import abi, fasta, utility
+from midas_amd import abi, bam, dist, fasta, utility
 from midas_amd.run.snps import select_species
 
 
@@ -169,8 +169,9 @@ def fold_counts(species, genes, gene_ids, aligned, mapped, depth):
         sp.fraction_covered = sp.covered_genes / float(sp.pangenome_size)
 
 
-def count_mapped_bp(args, species, genes, ctx):
-    """genes.py:165-199 with the BAM pass on the device: native BAM decode, one midas_genes_count call."""
+def count_mapped_bp(args, species, genes, ctx, mine=None):
+    """genes.py:165-199 with the BAM pass on the device: native BAM decode, one midas_genes_count call.  `mine` (N > 1):
+    the species this rank owns -- only reads on their genes are counted here."""
     bam_path = os.path.join(args['outdir'], 'genes', 'temp', 'pangenomes.bam')
     try:
         ref_names, ref_lens, refid, reads = abi.read_bam(bam_path)
@@ -183,7 +184,12 @@ def count_mapped_bp(args, species, genes, ctx):
         if bad:
             sys.exit("\nError: gene '%s' of the BAM header is not in the pangenome database\n" % bad[0])
     gene_ids = list(ref_names)
-    lengths = np.array([genes[n].length if n in genes else ref_lens[i] for i, n in enumerate(ref_names)], dtype=np.int64)
+    if mine is not None:     # this rank's genes, and the reads on them (BAM order inside a gene is kept)
+        gene_ids = [n for n in ref_names if n in genes and genes[n].species_id in mine]
+        reads, begin = bam.group_by_contig(ref_names, refid, reads, gene_ids)
+        refid = np.repeat(np.arange(len(gene_ids), dtype=np.int32), np.diff(begin))
+        ref_lens = [genes[n].length for n in gene_ids]
+    lengths = np.array([genes[n].length if n in genes else ref_lens[i] for i, n in enumerate(gene_ids)], dtype=np.int64)
     try:
         aligned, mapped, depth, ms = ctx.genes_count(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **{
             k: args[k] for k in ('mapid', 'readq', 'mapq', 'aln_cov')})), reads, refid, lengths)
@@ -210,8 +216,15 @@ def normalize(args, species, genes):
             gene.copies = gene.depth / mc
 
 
-def write_results(args, species, genes):
-    """genes/output/<species>.genes.gz (genes in sorted id order) and genes/summary.txt (genes.py:217-244)."""
+SUMMARY_FIELDS = ('pangenome_size', 'covered_genes', 'fraction_covered', 'mean_coverage', 'marker_coverage', 'aligned_reads',
+                  'mapped_reads')
+
+
+def write_results(args, species, genes, mine=None):
+    """genes/output/<species>.genes.gz (genes in sorted id order) and genes/summary.txt (genes.py:217-244).  N > 1: a rank
+    writes the tables of its own species (`mine`), the summary rows are all-gathered and rank 0 writes summary.txt."""
+    if mine is not None:
+        return _write_results_sharded(args, species, genes, mine)
     handles = {}
     for sp in species.values():
         handles[sp.id] = utility.iopen(os.path.join(args['outdir'], 'genes', 'output', '%s.genes.gz' % sp.id), 'w')
@@ -221,22 +234,61 @@ def write_results(args, species, genes):
         handles[gene.species_id].write('%s\t%s\t%s\t%s\n' % (gene.id, gene.mapped_reads, gene.depth, gene.copies))
     for handle in handles.values():
         handle.close()
-    fields = ('pangenome_size', 'covered_genes', 'fraction_covered', 'mean_coverage', 'marker_coverage', 'aligned_reads',
-              'mapped_reads')
     with open(os.path.join(args['outdir'], 'genes', 'summary.txt'), 'w') as handle:
-        handle.write('\t'.join(('species_id',) + fields) + '\n')
+        handle.write('\t'.join(('species_id',) + SUMMARY_FIELDS) + '\n')
         for sp in species.values():
-            handle.write('\t'.join([sp.id] + [str(getattr(sp, f)) for f in fields]) + '\n')
+            handle.write('\t'.join([sp.id] + [str(getattr(sp, f)) for f in SUMMARY_FIELDS]) + '\n')
 
 
-def pangenome_coverage(args, species, genes):
+def _write_results_sharded(args, species, genes, mine):
+    handles = {}
+    for sp in species.values():
+        if sp.id in mine:
+            handles[sp.id] = utility.iopen(os.path.join(args['outdir'], 'genes', 'output', '%s.genes.gz' % sp.id), 'w')
+            handles[sp.id].write('gene_id\tcount_reads\tcoverage\tcopy_number\n')
+    for gid in sorted(genes):
+        gene = genes[gid]
+        if gene.species_id in mine:
+            handles[gene.species_id].write('%s\t%s\t%s\t%s\n' % (gene.id, gene.mapped_reads, gene.depth, gene.copies))
+    for handle in handles.values():
+        handle.close()
+    # one row per species, zero outside this rank's: the owner's numbers survive the sum over ranks
+    rows = np.zeros((len(species), len(SUMMARY_FIELDS)), dtype=np.float64)
+    for k, sp in enumerate(species.values()):
+        if sp.id in mine:
+            rows[k] = [float(getattr(sp, f)) for f in SUMMARY_FIELDS]
+    rows = dist.all_gather_rows_f64(rows)
+    if dist.world()[0] != 0:
+        return
+    ints = ('pangenome_size', 'covered_genes', 'aligned_reads', 'mapped_reads')
+    with open(os.path.join(args['outdir'], 'genes', 'summary.txt'), 'w') as handle:
+        handle.write('\t'.join(('species_id',) + SUMMARY_FIELDS) + '\n')
+        for k, sp in enumerate(species.values()):
+            cells = []
+            for f, v in zip(SUMMARY_FIELDS, rows[k]):
+                if f in ints or (f == 'mean_coverage' and rows[k][1] == 0):   # the reference's mean of no genes is the int 0
+                    cells.append(str(int(v)))
+                else:
+                    cells.append(str(np.float64(v)) if f != 'fraction_covered' else str(float(v)))
+            handle.write('\t'.join([sp.id] + cells) + '\n')
+
+
+def pangenome_coverage(args, species, genes, make_context=None):
+    """N > 1 (torchrun): species are dealt to the ranks by pangenome size; a rank counts the reads on its species' genes,
+    writes their tables, and one all-gather of the summary rows lets rank 0 write summary.txt."""
+    rank, ws = dist.world()
+    mine = None
+    if ws > 1:
+        owner = dist.shard_species({sp.id: float(sp.pangenome_size) for sp in species.values()}, ws)
+        mine = {sp for sp, r in owner.items() if r == rank}
+    make_context = make_context or (lambda: abi.Context(int(os.environ.get("LOCAL_RANK", "0"))))
     try:
-        with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
-            ms = count_mapped_bp(args, species, genes, ctx)
+        with make_context() as ctx:
+            ms = count_mapped_bp(args, species, genes, ctx, mine)
     except abi.MidasSnpsError as e:
         sys.exit("\nError: %s\n" % e.message)
     normalize(args, species, genes)
-    write_results(args, species, genes)
+    write_results(args, species, genes, mine)
     return ms
 
 
@@ -255,14 +307,17 @@ def run_pipeline(args):
         print("  %s Gb maximum memory" % utility.max_mem_usage())
         return out
 
+    rank, ws = dist.init_from_env()
     species = timed("Reading reference data", None, initialize_species, args)
     genes = initialize_genes(args, species)
-    if args['build_db']:
+    if args['build_db'] and rank == 0:
         timed("Building pangenome database", "Building pangenome database", build_pangenome_db, args, species)
-    if args['align']:
+    if args['align'] and rank == 0:
         args['file_type'] = utility.auto_detect_file_type(args['m1'])
         timed("Aligning reads to pangenomes", "Aligning reads to pangenomes", pangenome_align, args)
+    dist.barrier()
     if args['cov']:
         timed("Computing coverage of pangenomes", "Computing coverage of pangenomes", pangenome_coverage, args, species, genes)
-    if args['remove_temp']:
+    dist.barrier()
+    if args['remove_temp'] and rank == 0:
         remove_tmp(args)

@@ -78,3 +78,72 @@ def test_two_ranks_gloo_all_gather_of_summary_rows(tmp_path):
     for i, sp in enumerate(ids):
         r = outs[0]["owner"][sp]
         assert outs[0]["tot"][i] == [1000 + i, 10 * i, 100 * i, 7 * i + r, i]
+
+
+GENES_WORKER = r'''
+import io, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from midas_amd import abi, dist
+from midas_amd.run import genes as mgenes
+from oracle import genes_oracle as go
+from oracle import pileup_oracle as po
+
+
+class OracleContext:
+    """Stands in for the device in this CPU test: midas_genes_count's contract, computed by the oracle."""
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def genes_count(self, thr, reads, ref_id, gene_length):
+        args = dict(mapid=thr.mapid, readq=thr.readq, mapq=thr.mapq, aln_cov=thr.aln_cov)
+        recs = []
+        for aln, rid in zip(po.alns_from_soa(reads.as_dict()), ref_id):
+            a = max(0, po.query_alignment_end(aln) - po.query_alignment_start(aln))
+            recs.append((int(rid), a, len(aln.seq), aln.nm, aln.qual, aln.mapq))
+        n = len(gene_length)
+        al, mp, dp, _ = go.count_mapped_bp(args, recs, list(range(n)), ["x"] * n, [int(x) for x in gene_length])
+        return np.array(al, np.int64), np.array(mp, np.int64), np.array(dp, np.float64), 0.0
+
+
+out, db = sys.argv[1], sys.argv[2]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    dist.init_from_env("gloo")
+args = dict(outdir=out, db=db, build_db=False, align=False, cov=True, species_id=None, threads=1, log=io.StringIO(),
+            mapid=94.0, readq=20, mapq=0, aln_cov=0.75)
+species = mgenes.initialize_species(args)
+genes = mgenes.initialize_genes(args, species)
+mgenes.pangenome_coverage(args, species, genes, make_context=OracleContext)
+dist.barrier()
+'''
+
+
+def test_two_ranks_gloo_genes_outputs_equal_the_single_process_ones(tmp_path):
+    """run_midas.py genes with N = 2: species dealt to the ranks, each writes its own tables, summary rows gathered --
+    the files are the single-process files (the device call is played by the oracle here; the GPU tests cover it)."""
+    import gzip
+    import shutil
+    from midas_amd import synth
+    ds = synth.make_pangenome_dataset(n_species=3, genes_per_species=20, n_reads=1500, seed=5)
+    one, two, db = str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "db")
+    synth.write_pangenome_sample(one, db, ds)
+    shutil.copytree(one, two)
+    script = tmp_path / "genes_worker.py"
+    script.write_text(GENES_WORKER % {"root": ROOT})
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script), one, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=env1, timeout=300)
+    assert r.returncode == 0, r.stderr
+    port = _free_port()
+    procs = []
+    for k in range(2):
+        env = dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), two, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e
+    assert open(os.path.join(two, "genes", "summary.txt")).read() == open(os.path.join(one, "genes", "summary.txt")).read()
+    for sp in ds['species_ids']:
+        a = gzip.open(os.path.join(one, "genes", "output", sp + ".genes.gz"), "rt").read()
+        b = gzip.open(os.path.join(two, "genes", "output", sp + ".genes.gz"), "rt").read()
+        assert a == b and a.count("\n") == 21
