@@ -8,21 +8,23 @@
 //   str(rec.seq).upper()            midas/run/snps.py:62
 //
 // Work decomposition.  The site space is cut into tiles of <= 4096 sites that never span contigs.  A
-// persistent 512-thread workgroup walks tiles blockIdx, blockIdx + grid, ...; a tile's tallies live in
+// persistent 512-thread workgroup takes tiles blockIdx, blockIdx + grid, then whatever a per-XCD counter hands it
+// (a hot-spot tile comes as several parts, accumulated with global atomics by a second instantiation); a tile's tallies live in
 // LDS as [site][A,C,G,T] u32, reads are streamed straight from the packed HBM arrays through a
 // two-deep register prefetch pipeline, tallies are LDS atomics, and the tile is written out once,
 // 16 B per site, fully coalesced.  The loads of the NEXT tile are issued before the write-out of the
 // current one and the read-out re-zeroes LDS as it goes, so the memory-bound edges of a tile overlap
 // the compute-bound middle of its neighbours instead of every workgroup marching through
-// load -> compute -> store in lockstep (measured: those three phases used to simply add up).
+// load -> compute -> store in lockstep (measured: those three phases used to simply add up).  The counts and
+// alleles leave as non-temporal stores; the barriers between the phases wait for LDS traffic only.
 //
 // Lane mapping.  A lane owns 31 consecutive bases of one read (32 payload slots, the last one padding: layout.h says
 // why 31, and when a batch uses all 32 instead): two 16-byte loads of quals and one 16-byte load of 4-bit call codes.  A read of l_seq
 // bases occupies ceil(l_seq/31) adjacent lanes (5 for 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
-// floor(64 / lanes_per_read) reads at a time.  The read filter needs the quality sum of the whole
-// read: a segmented shuffle reduction over the read's lanes gives it without re-reading anything.
+// floor(64 / lanes_per_read) reads at a time.  The read filter's numbers (aligned length, NM, floor of the mean
+// quality) come with the record: the packer computed them once per read.
 //
-// Instruction diet.  The loop is VALU-issue bound long before it is HBM bound, so the per-base work is
+// Instruction diet.  The loop is instruction-issue and LDS bound long before it is HBM bound, so the per-base work is
 // arranged as: (1) SWAR, four bases per instruction -- everything that decides WHETHER a base counts
 // (not A/C/G/T, read tail, CIGAR segment, tile edge) is folded into the quality byte itself (a base that
 // must not count gets quality 0); (2) per base -- one byte compare against baseq, one OR that forms the
