@@ -193,8 +193,11 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* batch, midas_snps_batc
 /* Device-side durations from HIP events recorded on the run's stream.  enable_timing(batch, n_slots)
  * allocates n_slots event triples (0 = off); run number k (counted from enable) records into slot
  * k % n_slots, so a caller can time K asynchronous runs and read all K after one sync.
- * out_ms: [0] index kernel (+ workspace memsets), [1] pileup kernel, [2] whole run.              */
+ * out_ms: [0] index kernel (+ workspace memsets), [1] pileup kernel, [2] whole run.
+ * time_pileup_only(batch, 1): runs record only the two events around the pileup kernel (each event record takes
+ * ~4 us of stream time); out_ms[0] is then 0 and out_ms[2] == out_ms[1].                              */
 int32_t midas_snps_batch_enable_timing(midas_snps_batch* batch, int32_t n_slots);
+int32_t midas_snps_batch_time_pileup_only(midas_snps_batch* batch, int32_t on);
 int32_t midas_snps_batch_timing(midas_snps_batch* batch, int32_t slot, float out_ms[3]);
 /* Enqueue (same stream) a device-to-device copy of the per-species counters [n_species*4] i64 of the
  * last run into caller-owned device memory -- e.g. a torch tensor that is then all-gathered over

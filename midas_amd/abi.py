@@ -209,6 +209,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_get_info': (i32, [vp, C.POINTER(BatchInfo)]),
         'midas_snps_batch_enable_timing': (i32, [vp, i32]),
         'midas_snps_batch_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
+        'midas_snps_batch_time_pileup_only': (i32, [vp, i32]),
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
@@ -247,7 +248,8 @@ EXPORTED_SYMBOLS = [
     'midas_snps_last_error', 'midas_snps_last_error_read', 'midas_snps_set_stream', 'midas_snps_device_info',
     'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
-    'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_stats_to_device',
+    'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
+    'midas_snps_batch_stats_to_device',
     'midas_snps_pack_reads',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
     'midas_snps_write_rows', 'midas_snps_write_table',
@@ -570,6 +572,10 @@ class Batch:
         self.ctx._check(self._lib.midas_snps_batch_enable_timing(self._h, int(n_slots)))
         self._slots = int(n_slots)
         self._timed = 0
+
+    def time_pileup_only(self, on: bool = True):
+        """Timed runs record only the two events around the pileup kernel (index_ms reads 0, run_ms == pileup_ms)."""
+        self.ctx._check(self._lib.midas_snps_batch_time_pileup_only(self._h, 1 if on else 0))
 
     def timing(self, slot: int = 0):
         ms = (C.c_float * 3)()
