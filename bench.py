@@ -155,6 +155,8 @@ def main():
     index_ms = float(np.median([batch.timing(i)["index_ms"] for i in range(a.warmup)])) if a.warmup > 0 else None
     batch.enable_timing(a.steps)
     batch.time_pileup_only(True)
+    if collective:      # RCCL builds its communicator and channels on first use: never inside the timed region
+        dist.all_gather_into_tensor(gathered, rows)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
