@@ -290,6 +290,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
   std::vector<uint8_t> rec_seg(m);
   std::vector<uint32_t> bytes(m);
   std::vector<uint8_t> cflags(m);
+  std::vector<uint8_t> phase(tiled ? m : 0);   // first site of the record modulo 8: its LDS bank phase (see below)
   std::vector<uint32_t> key(tiled ? m : 0);
   std::vector<uint32_t> tile_key_in(tiled && key_out ? m : 0);
   uint32_t* const tile_key = tile_key_in.empty() ? nullptr : tile_key_in.data();
@@ -311,6 +312,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         const int64_t reach = pe / tile_len - pc / tile_len;
         const uint32_t cls = reach > 0 ? 2u : (simple ? 0u : 1u);
         key[j] = (uint32_t)(3 * (tb + pc / tile_len)) + cls;
+        phase[j] = (uint8_t)(pc & 7);
         if (tile_key) tile_key[j] = (uint32_t)(((tb + pc / tile_len) << 7) | ((reach > 31 ? 31 : reach) << 2) | cls);
       };
       if (nseg[i] == 0) {
@@ -360,6 +362,29 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     for (int64_t j = 0; j < m; ++j) start[key[j] + 1]++;
     for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
     for (int64_t j = 0; j < m; ++j) order[start[key[j]]++] = j;
+    // Inside a tile's run of segment records the order is free (tallies commute).  Deal them so that consecutive
+    // records -- the reads one wave tallies together -- start at different sites modulo 8: a read's lanes occupy five of
+    // the eight 4-bank groups of the [site][A,C,G,T] tallies, starting at group (first site mod 8), and reads with the
+    // same phase collide bank for bank.
+    // (measured: 97.5 -> 95.5 us.)
+    {
+      std::vector<int64_t> bucket[8];
+      int64_t d0 = 0;
+      while (d0 < m) {
+        const uint32_t k = key[order[d0]];
+        int64_t d1 = d0 + 1;
+        while (d1 < m && key[order[d1]] == k) ++d1;
+        if (k % 3 == 0 && d1 - d0 > 2) {
+          for (auto& b : bucket) b.clear();
+          for (int64_t d = d0; d < d1; ++d) bucket[phase[order[d]]].push_back(order[d]);
+          int64_t d = d0;
+          for (size_t round = 0; d < d1; ++round)
+            for (int ph = 0; ph < 8; ++ph)
+              if (round < bucket[ph].size()) order[d++] = bucket[ph][round];
+        }
+        d0 = d1;
+      }
+    }
   } else {
     for (int64_t j = 0; j < m; ++j) order[j] = j;
   }
