@@ -307,7 +307,11 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       // query index, the read-level numbers of the filter come out of the record.  The general code below is for
       // everything else: records reaching into the next tile, reads that keep their CIGAR (and any S record that does
       // not lie inside the tile after all -- checked, not assumed).
-      bool fast = (it + 1) * rpw <= rg.ns && !(p.debug & 4);
+      // ... including the iteration that holds the last few S records: the stream positions behind them carry I / G
+      // records (never "simple and inside": the ballot below sends the iteration down the general path) or, when the
+      // tile has none, the sentinel.  (That last, partial iteration used to take the general path in every tile, and the
+      // seven other waves waited for it at the barrier: -2 %.)
+      bool fast = it * rpw < rg.ns && !(p.debug & 4);
       if (fast) {
         const int fl = rec_l(rec_cur);
         const int frel = rec_pos(rec_cur) - tile_start;
