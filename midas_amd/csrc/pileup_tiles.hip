@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   fetch_payload(rec_cur, cur);
   __syncthreads();   // LDS zeroed, tables in place
 
+  unsigned long long acc_cov = 0ull, acc_depth = 0ull;   // covered sites / depth of this thread's sites since the last flush
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
@@ -625,13 +626,20 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
     }
 
-    for (int d = 32; d >= 1; d >>= 1) {
-      covered += __shfl_down(covered, d);
-      depth_sum += __shfl_down(depth_sum, d);
-    }
-    if (lane == 0) {
-      if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
-      if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
+    if constexpr (!SPLIT) {
+      // covered sites / depth stay in the thread until the species row is flushed: the wave reduction and the LDS
+      // atomics would sit between the write-out and the barrier of every tile
+      acc_cov += covered;
+      acc_depth += depth_sum;
+    } else {
+      for (int d = 32; d >= 1; d >>= 1) {
+        covered += __shfl_down(covered, d);
+        depth_sum += __shfl_down(depth_sum, d);
+      }
+      if (lane == 0) {
+        if (covered) atomicAdd(&s_stats[MIDAS_STAT_COVERED], covered);
+        if (depth_sum) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], depth_sum);
+      }
     }
     if (dynamic && more && tid == 0) s_next_ticket = ticket;
     // One barrier per tile after the write-out: tallies re-zeroed (and this tile's s_stats additions done) before
@@ -668,6 +676,19 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     }
     const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
     if (flush) {
+      if constexpr (!SPLIT) {
+        for (int d = 32; d >= 1; d >>= 1) {
+          acc_cov += __shfl_down(acc_cov, d);
+          acc_depth += __shfl_down(acc_depth, d);
+        }
+        if (lane == 0) {
+          if (acc_cov) atomicAdd(&s_stats[MIDAS_STAT_COVERED], acc_cov);
+          if (acc_depth) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], acc_depth);
+        }
+        acc_cov = 0ull;
+        acc_depth = 0ull;
+        tile_barrier<SPLIT>(p.debug);
+      }
       if (tid < MIDAS_STATS) {
         const unsigned long long v = s_stats[tid];
         if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
