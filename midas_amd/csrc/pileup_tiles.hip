@@ -296,8 +296,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     }
 
     int vpos = v0;
+    // The record/payload prefetch runs across the tile boundary: a wave's last two iterations fetch the records of its
+    // first two iterations of the NEXT tile where the stream of this one has nothing left, so that nothing is loaded
+    // -- or waited for -- between the stream loop and the write-out.  Only the two record indices are kept (the next
+    // tile's tables are read here, early, and again after the loop, by then from the scalar cache).
+    const int n_w = it_hi > it_lo + wave ? (it_hi - (it_lo + wave) + NWAVES - 1) / NWAVES : 0;
+    const bool xt = !SPLIT && p.n_whole_items == p.n_tiles && w_next < w_end && n_w >= 2;
+    int xidx0 = p.n_reads, xidx1 = p.n_reads;
+    if (xt) {
+      const Ranges xr = make_ranges(load_ranges(w_next));
+      const int xv0 = (first_iter(xr, 0, 1) + wave) * rpw + g;
+      xidx0 = read_at(xr, xv0);
+      xidx1 = read_at(xr, xv0 + vstep);
+    }
     for (int it = it_lo + wave; it < it_hi; it += NWAVES, vpos += vstep) {
-      const uint4 rec_nn = fetch_rec(rg, vpos + 2 * vstep);
+      int nn_idx = read_at(rg, vpos + 2 * vstep);
+      if (xt && it + 2 * NWAVES >= it_hi) nn_idx = (it + NWAVES < it_hi) ? xidx0 : xidx1;
+      const uint4 rec_nn = recs[nn_idx];
       Payload nxt;
       fetch_payload(rec_nxt, nxt);
 
@@ -551,7 +566,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     const Ranges nrg = make_ranges(load_ranges(tn));
     const int nit_lo = first_iter(nrg, npart, nnparts), nit_hi = first_iter(nrg, npart + 1, nnparts);
     const int nv0 = (nit_lo + wave) * rpw + g;
-    if (more) {
+    if (more && !xt) {   // (with xt the pipeline already holds the next tile's first two records and first payload)
       rec_cur = fetch_rec(nrg, nv0);
       rec_nxt = fetch_rec(nrg, nv0 + vstep);
     }
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     // the item after the next one: the counter is asked here, behind the next tile's record loads and ahead of its
     // payload loads, whose first use is a whole write-out away (loads and returning atomics come back in order: an
     // atomic issued ahead of the stream loop held back every load of the tile's first iterations)
-    if (more) fetch_payload(rec_cur, cur);
+    if (more && !xt) fetch_payload(rec_cur, cur);
     uint32_t ticket = 0;
     if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
