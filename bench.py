@@ -8,13 +8,17 @@
 A "step" is one full pass of the hot path over one resident batch: the device builds its
 per-tile read index (the index_bam analogue), filters every read (keep_read), walks the
 CIGARs, tallies A/C/G/T per site, emits counts + ref allele and reduces the per-species
-counters.  With N > 1 a rank's K steps are its share of the job and the job's one exchange -- the
+counters.  A second timed region (`value_incl_pack`) puts the device packer in front of every step: from the
+BAM-native arrays resident in HBM (pos, mapq, NM, l_seq, CSR offsets, 4-bit SEQ, QUAL, CIGAR) -- CIGAR -> match
+segments, mean quality by wave reduction, N-mask, tile order (radix sort), records + payload -- to the counts.  With N > 1 a rank's K steps are its share of the job and the job's one exchange -- the
 all-gather of every rank's per-species summary rows over RCCL -- follows them, inside the timed region.  Inputs
 (packed reads, reference letters) are resident in HBM before the timed region starts.
 
-Workload: BASELINE.json configs[1] -- 1 species, 15 Mb, 1 M synthetic 150 bp reads (10x) per
-GPU.  Multi-GPU is species-sharded weak scaling: every rank owns its own species (own seed),
-no data-path collective, one all-gather of [K, n_species, 4] int64 summary rows per job.
+Workload (default): BASELINE.json configs[2], the largest single-GPU configuration -- 20 species, 80 Mb,
+10 666 667 aligned synthetic 150 bp reads (20x) per GPU (`--config c2` = configs[1]: 1 species, 15 Mb, 1 M reads,
+10x; `--config c4_rank` = one rank's share of configs[3]).  Multi-GPU is species-sharded weak scaling: every rank
+owns its own species (own seed), no data-path collective, one all-gather of [K, n_species, 4] int64 summary rows
+per job.
 """
 import argparse
 import json
@@ -30,20 +34,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+WORKLOADS = {
+    "c2": "configs[1]: 1 species rep-genome (60 contigs x 250 kb = 15 Mb), 1M synthetic 150 bp reads at 10x per GPU",
+    "c3": "configs[2]: 20 species (320 contigs x 250 kb = 80 Mb), 10 666 667 aligned synthetic 150 bp reads at 20x per GPU",
+    "c4_rank": "one rank's share of configs[3]: 13 species (52 Mb), 10.4M aligned synthetic 150 bp reads at 30x",
+}
+
+
 def load_pmc_traffic(kernel, workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, or None."""
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from) -- PMC counters cannot be read
+    inside a plain run, so the figure is the one of the committed rocprofv3 --pmc passes of this same command."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
         e = d.get(workload, {}).get(kernel)
-        return float(e["hbm_bytes_per_launch"]) if e else None
+        if not e:
+            return None, None
+        return float(e["hbm_bytes_per_launch"]), "committed profile: %s" % e.get("source", "profiles/pmc_traffic.json")
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(thr, contigs, reads, min_seconds):
-    """The C oracle ("port" of the reference semantics, 1 core) timed on this host; returns (dict, outputs)."""
+    """The C oracle ("port" of the reference semantics) timed on this host: 1 core, then all cores with one task per
+    contig, then the reference's own grain (one worker per species, midas/run/snps.py:225-228).
+    Returns (1-core dict, all-cores dict, species-grain dict, outputs of the 1-core pass)."""
     from oracle import c_oracle
     c_oracle.build()
     t0 = time.perf_counter()
@@ -56,10 +72,27 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
         if el >= min_seconds or passes >= 64:
             break
     sites = contigs.n_sites * passes
-    return ({"value": sites / el, "unit": "sites/s", "cores": 1, "kind": "port",
-             "sample": "%d pass(es) of the full workload (%d sites, %d reads) through oracle/pileup_oracle.c, %.1f s"
-                       % (passes, contigs.n_sites, reads.n_reads, el),
-             "host_cores_available": os.cpu_count()}, out)
+    one = {"value": sites / el, "unit": "sites/s", "cores": 1, "kind": "port",
+           "sample": "%d pass(es) of the full workload (%d sites, %d reads) through oracle/pileup_oracle.c, %.1f s"
+                     % (passes, contigs.n_sites, reads.n_reads, el),
+           "host_cores_available": os.cpu_count()}
+    ncpu = os.cpu_count() or 1
+    more = []
+    for grain, workers in (("contig", min(ncpu, contigs.n_contigs)), ("species", min(ncpu, contigs.n_species))):
+        t0 = time.perf_counter()
+        passes = 0
+        ok = True
+        while True:
+            st, c, s = c_oracle.pileup_parallel(thr, contigs, reads, workers, grain)
+            ok = ok and st == 0 and np.array_equal(c, out[2]) and np.array_equal(s, out[4])
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= min_seconds / 2 or passes >= 64:
+                break
+        more.append({"value": contigs.n_sites * passes / el, "unit": "sites/s", "cores": int(workers), "kind": "port",
+                     "grain": "one task per %s" % grain, "equals_1core_output": bool(ok),
+                     "sample": "%d pass(es) of the full workload over %d threads, %.1f s" % (passes, workers, el)})
+    return one, more[0], more[1], out
 
 
 def python_shaped_estimate(contigs, reads, args, max_sites=250000):
@@ -86,11 +119,13 @@ def python_shaped_estimate(contigs, reads, args, max_sites=250000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", help="workload from midas_amd.synth.CONFIGS (default c2 = BASELINE configs[1])")
+    ap.add_argument("--config", default="c3", help="workload from midas_amd.synth.CONFIGS (default c3 = BASELINE configs[2], "
+                                                  "the largest single-GPU configuration; c2 = configs[1])")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pack-steps", type=int, default=20, help="steps of the second region (device packer + step)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the summary all-gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     a = ap.parse_args()
@@ -183,10 +218,36 @@ def main():
     pile_ms = float(np.mean([t["pileup_ms"] for t in tm]))
     run_ms = pile_ms + index_ms if index_ms is not None else None
 
+    # ---- second region: the device packer in front of every step (raw BAM-native arrays resident in HBM -> counts) ----
+    kp = max(1, min(a.steps, a.pack_steps))
+    batch.enable_timing(kp)
+    batch.time_pileup_only(True)
+    batch.pack()
+    batch.run(thr)
+    batch.sync()
+    batch.enable_timing(kp)
+    batch.time_pileup_only(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(kp):
+        batch.pack()
+        batch.run(thr)
+    torch.cuda.synchronize()
+    elapsed_pack = time.perf_counter() - t0
+    batch.sync()
+    ptm = [batch.pack_timing(i) for i in range(kp)]
+    pack_ms = float(np.mean([t["pack_ms"] for t in ptm]))
+    scatter_ms = float(np.mean([t["scatter_ms"] for t in ptm]))
+    elp = torch.tensor([elapsed_pack], dtype=torch.float64, device="cuda")
+    if collective:
+        dist.all_reduce(elp, op=dist.ReduceOp.MAX)
+    elapsed_pack = float(elp.item())
+
     out = None
     if rank == 0:
         kernel = "pileup_tiles_kernel"
         achieved = info.algorithmic_bytes / (pile_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_pmc_traffic(kernel, a.config)
         out = {
             "metric": "genomic sites/sec pileup+allele-count",
             "value": total_sites * a.steps / elapsed,
@@ -196,26 +257,41 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer tallies (fp64 only in the two keep_read ratio tests)",
             "data": "synthetic (seeded generator midas_amd/synth.py; SURVEY 8d distributions)",
-            "config": {"workload": "configs[1]: 1 species rep-genome (60 contigs x 250 kb = 15 Mb), 1M synthetic "
-                                   "150 bp reads at 10x per GPU" if a.config == "c2" else a.config,
+            "config": {"workload": WORKLOADS.get(a.config, a.config),
                        "sites_per_gpu": int(info.n_sites), "reads_per_gpu": int(info.n_reads),
                        "thresholds": args, "parallelism": "species-sharded x%d, one RCCL all-gather of the summary rows per job" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": load_pmc_traffic(kernel, a.config),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(info.algorithmic_bytes),
                          "kernel_ms_avg": pile_ms, "index_kernel_ms_warmup_median": index_ms, "kernels_ms_per_step": run_ms,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
+        # pack + index + pileup from the resident raw arrays; the packer's dominant kernel reads the raw read
+        # (SURVEY 8d's per-read figure) and writes its records + payload
+        read_alg = int(info.algorithmic_bytes) - 17 * int(info.n_sites)
+        pack_alg = read_alg + int(info.packed_bytes)
+        pack_ach = pack_alg / (scatter_ms * 1e-3) / 1e9
+        out["value_incl_pack"] = total_sites * kp / elapsed_pack
+        out["ms_per_step_incl_pack"] = elapsed_pack / kp * 1e3
+        out["steps_incl_pack"] = kp
+        out["roofline_pack"] = {"bound": "hbm", "kernel": "pack_scatter_kernel", "achieved": pack_ach, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": pack_ach / HBM_PEAK_GBPS, "traffic": None,
+                                "algorithmic_bytes_per_launch": pack_alg,
+                                "algorithmic_bytes_note": "raw reads in (sum(ceil(l/2) + l + 4*n_cigar + 16)) + records and payload out",
+                                "kernel_ms_avg": scatter_ms, "pack_ms_avg_all_kernels": pack_ms}
         if world == 1 and not a.no_cpu:
-            cb, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
+            cb, cb_all, cb_species, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
             out["cpu_baseline"] = cb
+            out["cpu_baseline_all_cores"] = cb_all
+            out["cpu_baseline_reference_grain"] = cb_species
             counts, allele, stats = batch.fetch()
             st, _, oc, oa, os_ = ref
             out["parity_vs_oracle"] = bool(st == 0 and np.array_equal(counts, oc) and np.array_equal(allele, oa)
                                            and np.array_equal(stats, os_))
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            out["speedup_vs_cpu_all_cores"] = out["value"] / cb_all["value"]
             try:
                 out["cpu_python_shaped_estimate"] = python_shaped_estimate(contigs, reads, args)
             except Exception as e:  # the estimate is a courtesy number; never fail the bench on it

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MIDAS_SNPS_ABI_VERSION 1
+#define MIDAS_SNPS_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -162,14 +162,31 @@ int32_t midas_snps_pileup(midas_snps_ctx* ctx, const midas_snps_thresholds* thr,
                           uint32_t* out_counts, uint8_t* out_allele, int64_t* out_stats);
 
 /* ---- resident batches: upload once, run many ------------------------------
- * A batch is the device-resident form of (contig table, reads): packed read
- * records, the reference letters and the tile table.  Creating it replaces what
- * `pysam.AlignmentFile(bampath)` + htslib's record decode do per worker
+ * A batch is the device-resident form of (contig table, reads): the caller's BAM-native arrays
+ * are uploaded as they are and packed ON THE DEVICE (midas_snps_batch_pack below) into read
+ * records + payload in tile order, next to the reference letters and the tile table.
+ * Creating it replaces what `pysam.AlignmentFile(bampath)` + htslib's record decode do per worker
  * (midas/run/snps.py:186); running it replaces index_bam (:130-137, the device
  * builds its own per-tile read index each run) and the calls named above.      */
 int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
                                 const midas_snps_reads* reads, midas_snps_batch** out_batch);
 void midas_snps_batch_destroy(midas_snps_batch* batch);
+/* Re-run the device packer over the batch's resident BAM-native arrays (the arrays batch_create uploaded, unchanged):
+ * per read the CIGAR walk into gap-free match segments (pysam get_aligned_pairs(matches_only=True), reached from
+ * midas/run/snps.py:194-199), the clip structure (query_alignment_sequence, :145), floor(mean(query_qualities))
+ * (:151, a wave reduction), the 'A','C','G','T'-only rule folded into the quality bytes, and the tile order the
+ * index kernel expects (:130-137).  batch_create already ran it once; this entry exists so that a caller can time
+ * "raw reads resident in HBM -> counts" (pack + run).  Returns after the pack has finished (the hot-spot plan needs
+ * the per-tile read counts on the host).                                                                          */
+int32_t midas_snps_batch_pack(midas_snps_batch* batch);
+/* Copy the packed device layout back (tests: it must equal midas_snps_pack_reads' host mirror bit for bit).
+ * rec16 [(n_records+1)*16], blob [blob_bytes], orig_index / key [n_records]; any pointer may be NULL; the two sizes
+ * are always returned.                                                                                            */
+int32_t midas_snps_batch_fetch_packed(midas_snps_batch* batch, void* rec16, void* blob, uint32_t* orig_index,
+                                      uint32_t* key, int64_t* out_n_records, int64_t* out_blob_bytes);
+/* Device-side durations of a timed pack (enable_timing slots, like batch_timing): [0] whole pack, [1] its scatter
+ * kernel (the dominant one: raw reads in, records + payload out).                                                 */
+int32_t midas_snps_batch_pack_timing(midas_snps_batch* batch, int32_t slot, float out_ms[2]);
 /* Enqueue one full pass (index + filter + pileup + per-species counters) on the context's stream;
  * asynchronous.  Results stay on the device until midas_snps_batch_fetch().                    */
 int32_t midas_snps_batch_run(midas_snps_batch* batch, const midas_snps_thresholds* thr);
@@ -206,7 +223,8 @@ int32_t midas_snps_batch_timing(midas_snps_batch* batch, int32_t slot, float out
 int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_device_i64);
 
 /* ---- host-only helpers (no GPU needed) -------------------------------------
- * The packer that batch_create() runs, exposed so that CPU-only tests can check the device layout.  A read whose
+ * The host mirror of the device packer (batch_create packs on the GPU; this is the same layout computed on the CPU),
+ * exposed so that CPU-only tests can pin the device layout and GPU tests can hold the device packer to it.  A read whose
  * CIGAR is clips at the ends around M/=/X/I/D/N ops becomes one device record per gap-free match segment; any other
  * read becomes one record that keeps its CIGAR.  *out_blob_bytes and *out_n_records always receive the payload size
  * and the record count; if rec16/blob are non-NULL they receive (n_records+1)*16 bytes of records (the last one a
@@ -215,6 +233,15 @@ int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_devi
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs,
                               void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
                               int64_t* out_n_records, int32_t* out_max_l_seq, char* err256);
+
+/* The same mirror in the tile order of a batch (4096-site tiles; `contigs` required): what batch_create's device packer
+ * must produce bit for bit -- records and payload in device order, orig_index[d] = input index of device record d,
+ * key[d] = its index key (tile << 7 | reach << 2 | class).  orig_index / key may be NULL; rec16 == blob == NULL is a
+ * size query.                                                                                                       */
+int32_t midas_snps_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16,
+                                    void* blob, int64_t blob_capacity, uint32_t* orig_index, uint32_t* key,
+                                    int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq,
+                                    char* err256);
 
 /* ---- host I/O (no GPU needed) ------------------------------------------------
  * BAM decode.  Replaces `pysam.AlignmentFile(bampath, 'rb')` and htslib's record decode
@@ -250,6 +277,15 @@ int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_
 int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* const* ref_ids,
                                const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
                                int32_t gz_level, int32_t threads, char* err256);
+
+/* A PART of a species' table: the rows of some of its contigs (consecutive in the sorted-contig order of the emit
+ * loop), with or without the header member in front.  When a species' contigs are spread over several GPUs every
+ * rank writes the parts it owns and the parts are concatenated in sorted-contig order: gzip members concatenate into
+ * one valid gzip stream, and because a member never spans two contigs the concatenation is byte for byte the file
+ * one midas_snps_write_table call would have written (midas/run/snps.py:183-213).                                */
+int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
+                              const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
+                              int32_t gz_level, int32_t threads, char* err256);
 
 /* Parser of one sample's <species>.snps.gz: replaces read_run_midas_snps + the per-line split of
  * build_temp_count_matrix (midas/merge/snps.py:236-271): per row the site key '|'.join(r[0:3]) and the counts

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STAT_ALIGNED_READS, STAT_MAPPED_READS, STAT_COVERED_BASES, STAT_TOTAL_DEPTH = range(4)
 NUM_STATS = 4
@@ -211,8 +211,13 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_batch_time_pileup_only': (i32, [vp, i32]),
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
+        'midas_snps_batch_pack': (i32, [vp]),
+        'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+        'midas_snps_batch_pack_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
+    sig['midas_snps_pack_reads_tiled'] = (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, vp, vp, C.POINTER(i64),
+                                                 C.POINTER(i64), C.POINTER(i32), C.c_char_p])
     sig.update({
         'midas_bam_open': (i32, [C.c_char_p, C.POINTER(vp), C.c_char_p]),
         'midas_bam_close': (None, [vp]),
@@ -224,6 +229,7 @@ def load_library(build_if_missing: bool = True):
         'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_char_p]),
         'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
+        'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
         'midas_snps_table_close': (None, [vp]),
         'midas_snps_table_rows': (i64, [vp]),
@@ -249,10 +255,11 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
-    'midas_snps_batch_stats_to_device',
-    'midas_snps_pack_reads',
+    'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
+    'midas_snps_batch_pack_timing',
+    'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
-    'midas_snps_write_rows', 'midas_snps_write_table',
+    'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
@@ -273,9 +280,10 @@ def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts:
         raise MidasSnpsError(st, err.value.decode())
 
 
-def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads: int = 0):
+def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads: int = 0, header=None):
     """Header + the rows of every contig of one species in one call (midas_snps_write_table): ref_ids[k],
-    alleles[k] (u8[n_k]) and counts[k] (u32[n_k,4]) describe contig k in output order."""
+    alleles[k] (u8[n_k]) and counts[k] (u32[n_k,4]) describe contig k in output order.  header = True / False writes a
+    PART of a species' table instead (midas_snps_write_part): with or without the header member in front."""
     lib = load_library()
     n = len(ref_ids)
     al = [np.ascontiguousarray(a, dtype=np.uint8) for a in alleles]
@@ -286,7 +294,10 @@ def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads:
     pa = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in al])
     pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in cn])
     err = C.create_string_buffer(256)
-    st = lib.midas_snps_write_table(path.encode(), n, ids, ns, pa, pc, int(gz_level), int(threads), err)
+    if header is None:
+        st = lib.midas_snps_write_table(path.encode(), n, ids, ns, pa, pc, int(gz_level), int(threads), err)
+    else:
+        st = lib.midas_snps_write_part(path.encode(), 1 if header else 0, n, ids, ns, pa, pc, int(gz_level), int(threads), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
 
@@ -428,6 +439,29 @@ def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
     return rec[:n], blob[:int(nbytes.value)], int(maxl.value)
+
+
+def pack_reads_tiled(reads: ReadsSoA, contigs: "ContigTable"):
+    """Host mirror of the device packer in a batch's tile order -> (rec[n+1,16] u8 incl. sentinel, blob, orig u32, key u32)."""
+    lib = load_library()
+    r, cc = reads._c(), contigs._c()
+    nbytes, nrec, maxl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_pack_reads_tiled(C.byref(r), C.byref(cc), None, None, 0, None, None, C.byref(nbytes), C.byref(nrec),
+                                         C.byref(maxl), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    n = int(nrec.value)
+    rec = np.zeros((n + 1, 16), dtype=np.uint8)
+    blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
+    orig = np.zeros(max(n, 1), np.uint32)
+    key = np.zeros(max(n, 1), np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = lib.midas_snps_pack_reads_tiled(C.byref(r), C.byref(cc), p(rec), p(blob), blob.size, p(orig), p(key), C.byref(nbytes),
+                                         C.byref(nrec), C.byref(maxl), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    return rec, blob[:int(nbytes.value)], orig[:n], key[:n]
 
 
 class Context:
@@ -572,6 +606,7 @@ class Batch:
         self.ctx._check(self._lib.midas_snps_batch_enable_timing(self._h, int(n_slots)))
         self._slots = int(n_slots)
         self._timed = 0
+        self._packs = 0
 
     def time_pileup_only(self, on: bool = True):
         """Timed runs record only the two events around the pileup kernel (index_ms reads 0, run_ms == pileup_ms)."""
@@ -584,6 +619,29 @@ class Batch:
 
     def last_timing(self):
         return self.timing((self._timed - 1) % self._slots)
+
+    def pack(self):
+        """Re-run the device packer over the resident raw reads (midas_snps_batch_pack)."""
+        self.ctx._check(self._lib.midas_snps_batch_pack(self._h))
+        if getattr(self, '_slots', 0):
+            self._packs += 1
+
+    def pack_timing(self, slot: int = 0):
+        ms = (C.c_float * 2)()
+        self.ctx._check(self._lib.midas_snps_batch_pack_timing(self._h, int(slot), ms))
+        return {'pack_ms': ms[0], 'scatter_ms': ms[1]}
+
+    def fetch_packed(self):
+        """The device-packed layout: (rec[n_records+1,16] u8 incl. the sentinel, blob u8, orig u32, key u32)."""
+        n, nb = C.c_int64(0), C.c_int64(0)
+        self.ctx._check(self._lib.midas_snps_batch_fetch_packed(self._h, None, None, None, None, C.byref(n), C.byref(nb)))
+        rec = np.zeros((n.value + 1, 16), np.uint8)
+        blob = np.zeros(max(nb.value, 1), np.uint8)
+        orig = np.zeros(max(n.value, 1), np.uint32)
+        key = np.zeros(max(n.value, 1), np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.ctx._check(self._lib.midas_snps_batch_fetch_packed(self._h, p(rec), p(blob), p(orig), p(key), C.byref(n), C.byref(nb)))
+        return rec, blob[:nb.value], orig[:n.value], key[:n.value]
 
     def stats_to_device(self, dst_device_ptr: int):
         """Enqueue a D2D copy of the [n_species,4] int64 counters into caller-owned device memory."""

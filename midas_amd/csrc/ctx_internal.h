@@ -11,9 +11,4 @@ struct midas_snps_ctx {
   std::string err;
   int64_t err_read = -1;
   hipDeviceProp_t prop;
-  // host staging of batch_create (packed records / payload), kept between batches: allocating, pinning or
-  // unmapping a quarter of a gigabyte per batch costs more than packing and copying it
-  void* stage_rec = nullptr;
-  void* stage_blob = nullptr;
-  size_t stage_rec_cap = 0, stage_blob_cap = 0;
 };

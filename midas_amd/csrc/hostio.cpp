@@ -628,12 +628,12 @@ namespace {
 // Rows of any number of contigs -> gzip members of kRows rows, formatted and deflated by a pool, written in order.
 int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const char* const* ref_ids,
                       const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
-                      int32_t gz_level, int32_t threads, char* err256) {
+                      int32_t gz_level, int32_t threads, char* err256, bool header = true) {
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   if (gz_level < 0 || gz_level > 9) gz_level = 6;
   bool ok = true;
-  if (!append) {
+  if (!append && header) {
     // header line of midas/run/snps.py:181-182
     static const char hdr[] = "ref_id\tref_pos\tref_allele\tdepth\tcount_a\tcount_c\tcount_g\tcount_t\n";
     std::vector<uint8_t> z;
@@ -719,6 +719,16 @@ int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* 
   for (int32_t k = 0; k < n_contigs; ++k)
     if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k]))) return MIDAS_SNPS_ERR_INVALID_ARG;
   return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256);
+}
+
+int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
+                              const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
+                              int32_t gz_level, int32_t threads, char* err256) {
+  if (!path || n_contigs < 0 || (n_contigs > 0 && (!ref_ids || !n_sites || !allele || !counts)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  for (int32_t k = 0; k < n_contigs; ++k)
+    if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k]))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256, with_header != 0);
 }
 
 int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,

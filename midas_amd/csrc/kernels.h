@@ -86,8 +86,58 @@ struct PileupParams {
   int32_t reads_per_wave;            // 64 / lanes_per_read
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
-  int32_t debug;                     // developer ablation switches (MIDAS_SNPS_DEBUG), 0 in production
 };
+
+// ---- device packer (pack_reads.hip): BAM-native SoA resident in HBM -> rec / blob / orig / key of layout.h -----------
+constexpr int kPackBinsPerTile = 10;     // sort bins of a tile: segment records by first site mod 8, then records with a
+                                         // CIGAR that stay inside the tile, then records reaching into a later tile
+constexpr unsigned kPackBadLayout = 1, kPackUnsupported = 2;   // low byte of PackFacts::status
+
+struct PackFacts {                       // reductions of one pack, device resident (zeroed by launch_pack_plan)
+  unsigned long long status;             // min((read << 8) | kPack*), kNoError when every read is well-formed
+  unsigned long long alg_bytes;          // sum(ceil(l/2) + l + 4*n_cigar + 16)
+  unsigned long long blob_bytes;         // payload bytes of all records
+  unsigned long long n_records;          // device records of all reads (the u32 scan behind it may have wrapped: checked)
+  uint32_t max_l;                        // longest read
+  uint32_t pad;
+};
+
+struct PackParams {
+  // the ABI's midas_snps_reads, uploaded as it is
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
+  const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
+  int64_t seq_bytes, qual_bytes, n_cigar;   // array sizes (the last CSR offsets)
+  int32_t n_reads;
+  // contig / tile geometry
+  const int32_t* contig_read_begin;      // [n_contigs + 1]
+  const int32_t* contig_tile_base;       // [n_contigs + 1]
+  const int32_t* contig_len;             // [n_contigs]
+  int32_t n_contigs, n_tiles, tile_len;
+  int32_t lane_bases, lanes_per_read;    // known after the plan step (longest read)
+  // per read
+  uint8_t* nseg;                         // [n_reads] 0 = one record that keeps its CIGAR, k = k segment records
+  uint32_t* cnt;                         // [n_reads + 1] records per read
+  uint32_t* first;                       // [n_reads + 1] first record of a read (input order), [n_reads] = n_records
+  // per record, input order
+  uint32_t* sort_key; uint32_t* sort_val; uint32_t* bytes8; uint32_t* dest;
+  // per record, sorted / device order
+  uint32_t* key_sorted; uint32_t* val_sorted;
+  uint32_t* bin_start;                   // [n_tiles * kPackBinsPerTile + 1]
+  uint32_t* bytes8_dev; uint32_t* off8;  // [n_records + 1]
+  uint32_t* tile_extra; uint32_t* tile_reads;   // [n_tiles] records reaching in / all records a tile will see
+  PackFacts* facts;
+  int32_t n_records;
+  // outputs
+  ReadRec* rec; uint8_t* blob; uint32_t* orig; uint32_t* key_out;
+};
+
+size_t pack_sort_temp_bytes(int64_t max_records, int key_bits);
+int pack_key_bits(int32_t n_tiles);
+hipError_t launch_pack_plan(const PackParams& p, void* tmp, size_t tmp_bytes, hipStream_t s);      // nseg, first, facts
+hipError_t launch_pack_keys(const PackParams& p, hipStream_t s);                                   // sort keys, sizes
+hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, int key_bits, hipStream_t s);   // dest, off8, tile_reads
+hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);                                // rec, blob, orig, key
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);
 hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream);

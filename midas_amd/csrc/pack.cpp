@@ -374,7 +374,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         const uint32_t k = key[order[d0]];
         int64_t d1 = d0 + 1;
         while (d1 < m && key[order[d1]] == k) ++d1;
-        if (k % 3 == 0 && d1 - d0 > 2) {
+        if (k % 3 == 0) {
           for (auto& b : bucket) b.clear();
           for (int64_t d = d0; d < d1; ++d) bucket[phase[order[d]]].push_back(order[d]);
           int64_t d = d0;

@@ -1,0 +1,616 @@
+// gfx950 device packer of the MIDAS SNP pileup: BAM-native SoA resident in HBM -> the device layout of layout.h.
+//
+// What it stands for in the reference (citations into /root/reference):
+//   midas/run/snps.py:145       aln.query_alignment_sequence      (clip structure of the CIGAR, [EXT] pysam)
+//   midas/run/snps.py:151,154   np.mean(aln.query_qualities)      (whole-read quality reduction, one wave reduction here)
+//   midas/run/snps.py:194-199   count_coverage -> get_aligned_pairs(matches_only=True): the CIGAR walk that turns a
+//                               read into gap-free match segments; only 'A','C','G','T' are counted
+//   midas/run/snps.py:130-137   samtools index (the records are laid out in tile order for the index kernel)
+//
+// The layout produced is bit for bit the one of the host packer (pack.cpp), which stays as the CPU test mirror:
+// tests/test_gpu_pack.py compares records, payload, input-order map and index keys of both.
+//
+// Pipeline (all on one stream, no host round trip in between once the buffers exist):
+//   pack_plan_kernel     1 thread / read   validate, CIGAR -> number of device records (match segments cut at tile
+//                                          boundaries, or one record that keeps its CIGAR); algorithmic bytes, longest read
+//   [scan]                                 first device record of every read (hipCUB exclusive sum)
+//   pack_keys_kernel     1 thread / read   per record: sort key (tile, class, bank phase), payload size
+//   [radix sort]                           stable sort of (key, record) -- input order survives inside a key (hipCUB)
+//   pack_bounds_kernel   1 thread / record first sorted position of every key
+//   pack_dest_kernel     1 thread / record device position of every record: a tile's segment records are dealt round-robin
+//                                          over their eight bank phases (layout.h), everything else keeps the sorted order
+//   [scan]                                 payload offsets in device order
+//   pack_scatter_kernel  5 lanes / read    sum(qual) by wave reduction, 4-bit SEQ -> call codes (SWAR on nibbles), N-mask
+//                                          folded into the quality bytes, records + payload + keys written in place
+//
+// HBM roofline of the scatter kernel (the dominant one): it reads the raw read (ceil(l/2) + l + 4 n_cigar + 29 B of
+// fixed fields and offsets) and writes 48 B per 31 bases + 16 B of record + 8 B of keys.
+#include <hipcub/hipcub.hpp>
+
+#include "device_common.h"
+
+namespace midas {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kPlanBlock = 256;
+constexpr int kScatterBlock = 256;
+
+__device__ __forceinline__ bool op_is_match(uint32_t op) { return op == OP_M || op == OP_EQ || op == OP_X; }
+__device__ __forceinline__ bool op_is_clip(uint32_t op) { return op == OP_S || op == OP_H; }
+
+// contig of read i: the last contig whose first read is <= i (empty contigs share their begin with the next one)
+__device__ __forceinline__ int contig_of_read(const PackParams& p, int i) {
+  int lo = 0, hi = p.n_contigs;   // first index in (0, n_contigs] with read_begin[idx] > i
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (p.contig_read_begin[mid] > i) hi = mid; else lo = mid + 1;
+  }
+  int c = lo - 1;
+  c = c < 0 ? 0 : c;
+  return c > p.n_contigs - 1 ? p.n_contigs - 1 : c;
+}
+
+struct ReadView {
+  long long pos;
+  uint32_t l, nc;
+  int nm;
+  const uint32_t* cg;
+  long long clen;
+  int tile_len;
+};
+
+// Number of device records of a read served as match segments (1..kMaxPieces), or 0 when it keeps its CIGAR.
+// Same rules as pack.cpp segment_plan + piece_plan: `H* S? (M|=|X|I|D|N)+ S? H*`, every length >= 1, the query length
+// adding up, NM present and small, at most kMaxSegments gap-free runs, the first of them with a base inside the contig,
+// at most kMaxPieces pieces after cutting at the tile boundaries.
+__device__ int plan_read(const ReadView& r, uint32_t* align_total) {
+  if (r.l < 1u || r.l > (uint32_t)kMaxSegField || r.nm < 0 || r.nm > kMaxSegField || r.pos < 0 || r.nc == 0u) return 0;
+  if (!(r.pos < r.clen)) return 0;
+  uint32_t k = 0;
+  while (k < r.nc && (r.cg[k] & 15u) == OP_H) { if ((r.cg[k] >> 4) == 0u) return 0; ++k; }
+  uint32_t lead = 0, trail = 0;
+  if (k < r.nc && (r.cg[k] & 15u) == OP_S) { lead = r.cg[k] >> 4; if (lead == 0u) return 0; ++k; }
+  uint32_t e = r.nc;
+  while (e > k && (r.cg[e - 1] & 15u) == OP_H) { if ((r.cg[e - 1] >> 4) == 0u) return 0; --e; }
+  if (e > k && (r.cg[e - 1] & 15u) == OP_S) { trail = r.cg[e - 1] >> 4; if (trail == 0u) return 0; --e; }
+  if (e <= k) return 0;
+  long long q = lead, rr = 0;
+  int nsegs = 0, npieces = 0;
+  bool prev_match = false, bad = false;
+  long long seg_r = 0, seg_len = 0;
+  auto flush = [&]() {   // pieces of the finished segment
+    long long start = r.pos + seg_r, len = seg_len;
+    if (start + len > r.clen) len = r.clen - start;
+    if (len <= 0) { if (nsegs == 1) bad = true; return; }
+    // 0 <= start < start + len <= clen < 2^31: 32-bit divisions
+    npieces += (int)((uint32_t)(start + len - 1) / (uint32_t)r.tile_len - (uint32_t)start / (uint32_t)r.tile_len) + 1;
+  };
+  for (uint32_t i = k; i < e; ++i) {
+    const uint32_t op = r.cg[i] & 15u;
+    const long long len = r.cg[i] >> 4;
+    if (len == 0) return 0;
+    if (op_is_match(op)) {
+      if (prev_match) {
+        seg_len += len;
+      } else {
+        if (nsegs > 0) flush();
+        if (nsegs == kMaxSegments) return 0;
+        ++nsegs;
+        seg_r = rr;
+        seg_len = len;
+      }
+      q += len;
+      rr += len;
+      prev_match = true;
+    } else if (op == OP_I) {
+      q += len;
+      prev_match = false;
+    } else if (op == OP_D || op == OP_N) {
+      rr += len;
+      prev_match = false;
+    } else {
+      return 0;
+    }
+    if (q > (long long)r.l || rr > 0x7FFFFFFFll) return 0;
+  }
+  if (nsegs == 0 || q + trail != (long long)r.l) return 0;
+  flush();
+  if (bad || npieces > kMaxPieces || npieces == 0) return 0;
+  *align_total = r.l - lead - trail;
+  return npieces;
+}
+
+// The pieces of a read plan_read accepted, one after the other: its match segments (adjacent match ops merged), clipped
+// to the contig and cut at the tile boundaries.
+struct PieceIter {
+  const uint32_t* cg;
+  uint32_t k, e;
+  long long q, rr;       // query / reference offset of the op at k
+  long long sq, sr, sl;  // what is left of the current segment
+  long long pos, clen;
+  int tile_len;
+  __device__ void init(const ReadView& r) {
+    cg = r.cg; pos = r.pos; clen = r.clen; tile_len = r.tile_len;
+    k = 0;
+    while (k < r.nc && (cg[k] & 15u) == OP_H) ++k;
+    q = 0;
+    if (k < r.nc && (cg[k] & 15u) == OP_S) { q = cg[k] >> 4; ++k; }
+    e = r.nc;
+    while (e > k && (cg[e - 1] & 15u) == OP_H) --e;
+    if (e > k && (cg[e - 1] & 15u) == OP_S) --e;
+    rr = 0; sq = sr = sl = 0;
+  }
+  __device__ bool next(int* qoff, long long* roff, int* len) {
+    for (;;) {
+      if (sl > 0) {
+        const long long start = pos + sr;
+        const long long room = tile_len - (int)((uint32_t)start % (uint32_t)tile_len);   // 0 <= start < clen < 2^31
+        const long long take = sl < room ? sl : room;
+        *qoff = (int)sq; *roff = sr; *len = (int)take;
+        sq += take; sr += take; sl -= take;
+        return true;
+      }
+      while (k < e && !op_is_match(cg[k] & 15u)) {
+        const uint32_t op = cg[k] & 15u;
+        const long long len = cg[k] >> 4;
+        if (op == OP_I) q += len; else rr += len;   // D / N (nothing else can be here: plan_read accepted the read)
+        ++k;
+      }
+      if (k >= e) return false;
+      const long long q0 = q, r0 = rr;
+      long long len = 0;
+      while (k < e && op_is_match(cg[k] & 15u)) { len += cg[k] >> 4; ++k; }
+      q += len; rr += len;
+      const long long start = pos + r0;
+      if (start + len > clen) len = clen - start;
+      if (len <= 0) continue;
+      sq = q0; sr = r0; sl = len;
+    }
+  }
+};
+
+// Facts about a record that keeps its CIGAR (layout.h kRec* bits): clip structure, the one condition under which the
+// reference would raise IndexError for a kept read, and its reference length.  pack.cpp cigar_flags.
+__device__ uint32_t general_flags(const ReadView& r, long long* reflen) {
+  uint32_t f = 0;
+  if (r.nc > 0u) {
+    uint32_t lead = 0;
+    while (lead < r.nc && op_is_clip(r.cg[lead] & 15u)) ++lead;
+    uint32_t trail = 0;
+    while (trail + 1 < r.nc && op_is_clip(r.cg[r.nc - 1 - trail] & 15u)) ++trail;
+    const bool lead_plain = lead == 0u || (lead == 1u && (r.cg[0] & 15u) == OP_S);
+    const bool trail_plain = trail == 0u || (trail == 1u && (r.cg[r.nc - 1] & 15u) == OP_S);
+    if (!lead_plain || !trail_plain) f |= kRecClipGeneric;
+  }
+  long long qpos = 0, rpos = r.pos;
+  for (uint32_t k = 0; k < r.nc; ++k) {
+    const uint32_t op = r.cg[k] & 15u;
+    const long long len = r.cg[k] >> 4;
+    if (op_is_match(op)) {
+      if (qpos + len > (long long)r.l) {
+        const long long qs = qpos > (long long)r.l ? qpos : (long long)r.l;
+        const long long rs = rpos + (qs - qpos), rend = rpos + len;
+        if (rs < r.clen && rend > 0) f |= kRecOverrun;
+      }
+      qpos += len;
+      rpos += len;
+    } else if (op == OP_I || op == OP_S) {
+      qpos += len;
+    } else if (op == OP_D || op == OP_N) {
+      rpos += len;
+    }
+  }
+  *reflen = rpos - r.pos;
+  return f;
+}
+
+// Sort key and index key of a record (pack.cpp set_keys; index_reads.hip reads the index key).
+struct RecKeys { uint32_t sort_key, tile_key; int tile, reach; };
+__device__ __forceinline__ RecKeys record_keys(long long start, long long reflen, bool simple, long long clen, int tile_len, int tile_base) {
+  long long pc = start < 0 ? 0 : start;
+  pc = pc > clen - 1 ? clen - 1 : pc;
+  long long pe = start + (reflen > 0 ? reflen : 1) - 1;
+  pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
+  const uint32_t t0 = (uint32_t)pc / (uint32_t)tile_len;   // 0 <= pc <= pe < clen < 2^31: 32-bit divisions
+  const long long reach = (long long)((uint32_t)pe / (uint32_t)tile_len) - (long long)t0;
+  const uint32_t cls = reach > 0 ? 2u : (simple ? 0u : 1u);
+  RecKeys k;
+  k.tile = tile_base + (int)t0;
+  k.reach = (int)(reach > 31 ? 31 : reach);
+  k.sort_key = (uint32_t)k.tile * (uint32_t)kPackBinsPerTile + (cls == 0u ? (uint32_t)(pc & 7) : 7u + cls);
+  k.tile_key = ((uint32_t)k.tile << 7) | ((uint32_t)k.reach << 2) | cls;
+  return k;
+}
+
+__device__ __forceinline__ bool load_read(const PackParams& p, int i, ReadView* r, int* contig) {
+  const int c = contig_of_read(p, i);
+  *contig = c;
+  r->pos = p.pos[i];
+  r->l = (uint32_t)p.l_seq[i];
+  r->nm = p.nm[i];
+  const long long co = p.cigar_off[i];
+  r->nc = (uint32_t)(p.cigar_off[i + 1] - co);
+  r->cg = p.cigar + co;
+  r->clen = p.contig_len[c];
+  r->tile_len = p.tile_len;
+  return true;
+}
+
+// ---- 1. validate + count --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPlanBlock) void pack_plan_kernel(PackParams p) {
+  const int i = blockIdx.x * kPlanBlock + threadIdx.x;
+  unsigned long long alg = 0, recs = 0;
+  uint32_t maxl = 0;
+  if (i < p.n_reads) {
+    const long long l = p.l_seq[i];
+    const long long so = p.seq_off[i], qo = p.qual_off[i], co = p.cigar_off[i];
+    const long long so1 = p.seq_off[i + 1], qo1 = p.qual_off[i + 1], co1 = p.cigar_off[i + 1];
+    const long long nc = co1 - co;
+    uint32_t cnt = 1;
+    uint8_t ns = 0;
+    if (l < 0 || nc < 0 || co < 0 || so < 0 || qo < 0 || so1 - so < (l + 1) / 2 || qo1 - qo < l || so1 > p.seq_bytes ||
+        qo1 > p.qual_bytes || co1 > p.n_cigar) {
+      atomicMin(&p.facts->status, ((unsigned long long)i << 8) | kPackBadLayout);
+    } else if (l > kMaxLSeq || nc > kMaxField16 || p.nm[i] > kMaxField16) {
+      atomicMin(&p.facts->status, ((unsigned long long)i << 8) | kPackUnsupported);
+    } else {
+      ReadView r;
+      int c;
+      load_read(p, i, &r, &c);
+      uint32_t at = 0;
+      ns = (uint8_t)plan_read(r, &at);
+      cnt = ns ? ns : 1u;
+      alg = (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
+      maxl = (uint32_t)l;
+    }
+    p.nseg[i] = ns;
+    p.cnt[i] = cnt;
+    recs = cnt;
+  }
+  // block reductions -> three atomics per wave
+  for (int d = 32; d >= 1; d >>= 1) {
+    alg += __shfl_down(alg, d);
+    recs += __shfl_down(recs, d);
+    const uint32_t o = __shfl_down(maxl, d);
+    maxl = o > maxl ? o : maxl;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (alg) atomicAdd(&p.facts->alg_bytes, alg);
+    if (recs) atomicAdd(&p.facts->n_records, recs);
+    if (maxl) atomicMax(&p.facts->max_l, maxl);
+  }
+  if (i == 0) p.cnt[p.n_reads] = 0u;
+}
+
+// ---- 2. per record: sort key, payload size --------------------------------------------------------------------------
+__global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
+  const int i = blockIdx.x * kPlanBlock + threadIdx.x;
+  unsigned long long bytes_sum = 0;
+  if (i < p.n_reads) {
+    ReadView r;
+    int c;
+    load_read(p, i, &r, &c);
+    const int tb = p.contig_tile_base[c];
+    const uint32_t j0 = p.first[i];
+    const int ns = p.nseg[i];
+    auto emit = [&](uint32_t j, const RecKeys& k, uint32_t bytes) {
+      p.sort_key[j] = k.sort_key;
+      p.sort_val[j] = j;
+      p.bytes8[j] = bytes >> 3;
+      bytes_sum += bytes;
+      for (int t = 1; t <= k.reach; ++t)    // reads a later tile will see as well (hot-spot planning)
+        if (k.tile + t < p.n_tiles) atomicAdd(&p.tile_extra[k.tile + t], 1u);
+    };
+    if (ns == 0) {
+      long long reflen = 0;
+      (void)general_flags(r, &reflen);
+      emit(j0, record_keys(r.pos, reflen, false, r.clen, p.tile_len, tb), blob_bytes(r.l, r.nc, (uint32_t)p.lane_bases));
+    } else {
+      PieceIter it;
+      it.init(r);
+      int qoff, len;
+      long long roff;
+      for (int s = 0; s < ns && it.next(&qoff, &roff, &len); ++s)
+        emit(j0 + (uint32_t)s, record_keys(r.pos + roff, len, true, r.clen, p.tile_len, tb),
+             blob_bytes((uint32_t)len, 0u, (uint32_t)p.lane_bases));
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) bytes_sum += __shfl_down(bytes_sum, d);
+  if ((threadIdx.x & 63) == 0 && bytes_sum) atomicAdd(&p.facts->blob_bytes, bytes_sum);
+}
+
+// ---- 3. first sorted position of every key ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPlanBlock) void pack_bounds_kernel(PackParams p) {
+  const int d = blockIdx.x * kPlanBlock + threadIdx.x;
+  const int m = p.n_records;
+  const int nbins = p.n_tiles * kPackBinsPerTile;
+  if (m == 0) {
+    for (int b = d; b <= nbins; b += gridDim.x * kPlanBlock) p.bin_start[b] = 0u;
+    return;
+  }
+  if (d >= m) return;
+  const long long k = p.key_sorted[d];
+  const long long kp = d > 0 ? (long long)p.key_sorted[d - 1] : -1ll;
+  for (long long b = kp + 1; b <= k; ++b) p.bin_start[b] = (uint32_t)d;
+  if (d == m - 1)
+    for (long long b = k + 1; b <= nbins; ++b) p.bin_start[b] = (uint32_t)m;
+}
+
+// ---- 4. device position of every record -----------------------------------------------------------------------------
+// A tile's segment records (bins 0..7 = first site modulo 8) are dealt round-robin over their phases, so that the reads
+// one pileup wave tallies together start in different LDS bank groups (layout.h / pack.cpp): the record with rank r in
+// phase ph lands behind the first min(count, r) records of every phase and behind the rank-r records of the phases
+// before its own.
+__global__ __launch_bounds__(kPlanBlock) void pack_dest_kernel(PackParams p) {
+  const int d = blockIdx.x * kPlanBlock + threadIdx.x;
+  if (d < p.n_tiles) p.tile_reads[d] = p.tile_extra[d] + (p.bin_start[(d + 1) * kPackBinsPerTile] - p.bin_start[d * kPackBinsPerTile]);
+  if (d >= p.n_records) return;
+  const uint32_t key = p.key_sorted[d];
+  const uint32_t j = p.val_sorted[d];
+  const uint32_t tile = key / (uint32_t)kPackBinsPerTile, sub = key - tile * (uint32_t)kPackBinsPerTile;
+  uint32_t dpos = (uint32_t)d;
+  if (sub < 8u) {
+    const uint32_t* bs = p.bin_start + (size_t)tile * kPackBinsPerTile;
+    const uint32_t rank = (uint32_t)d - bs[sub];
+    uint32_t before = 0;
+    uint32_t prev = bs[0];
+#pragma unroll
+    for (uint32_t ph = 0; ph < 8u; ++ph) {
+      const uint32_t nxt = bs[ph + 1];
+      const uint32_t cnt = nxt - prev;
+      before += cnt < rank ? cnt : rank;
+      before += (ph < sub && cnt > rank) ? 1u : 0u;
+      prev = nxt;
+    }
+    dpos = bs[0] + before;
+  }
+  p.dest[j] = dpos;
+  p.bytes8_dev[dpos] = p.bytes8[j];
+  if (d == 0) p.bytes8_dev[p.n_records] = 0u;
+}
+
+// ---- 5. scatter: records + payload -----------------------------------------------------------------------------------
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+
+__device__ __forceinline__ uint32_t low_bytes_mask(int hi) {
+  return hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
+}
+
+// Eight 4-bit BAM base codes ("=ACMGRSVTWYHKDBN") -> eight call codes in the same nibbles:
+// A (1) -> 0x0, C (2) -> 0x4, G (4) -> 0x8, T (8) -> 0xC, anything else -> kCallOther (0x2).
+__device__ __forceinline__ uint32_t call_codes8(uint32_t x) {
+  const uint32_t pair = (x & 0x55555555u) + ((x >> 1) & 0x55555555u);
+  const uint32_t pop = (pair & 0x33333333u) + ((pair >> 2) & 0x33333333u);   // bits set per nibble
+  const uint32_t z = pop ^ 0x11111111u;                                       // 0 where exactly one bit is set
+  const uint32_t nz = (z | (z >> 1) | (z >> 2) | (z >> 3)) & 0x11111111u;
+  const uint32_t valid = (nz ^ 0x11111111u) * 15u;                            // 0xF in the nibbles of A/C/G/T
+  const uint32_t hi = ((x >> 3) | (x >> 2)) & 0x11111111u;                    // G or T
+  const uint32_t lo = ((x >> 3) | (x >> 1)) & 0x11111111u;                    // C or T
+  const uint32_t code = (hi << 3) | (lo << 2);
+  return (code & valid) | (0x22222222u & ~valid);
+}
+// Two bytes (four nibbles: byte0.hi, byte0.lo, byte1.hi, byte1.lo in base order) -> four bytes, one nibble each.
+// HALF 0: bytes 0,1 of x; HALF 1: bytes 2,3.
+template <int HALF>
+__device__ __forceinline__ uint32_t spread_nibbles(uint32_t x) {
+  const uint32_t pp = __builtin_amdgcn_perm(x, x, HALF ? 0x03030202u : 0x01010000u);
+  return ((pp >> 4) & 0x000F000Fu) | (pp & 0x0F000F00u);
+}
+
+__global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams p) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = p.lanes_per_read, rpw = 64 / lpr;
+  const int g = lane / lpr, c = lane - g * lpr;
+  const long long wave_id = (long long)blockIdx.x * (kScatterBlock / 64) + (threadIdx.x >> 6);
+  const long long ii = wave_id * rpw + g;
+  const bool valid = g < rpw && ii < (long long)p.n_reads;
+  const int i = valid ? (int)ii : 0;
+  const uint32_t lb = (uint32_t)p.lane_bases;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the sentinel record: where the payload ends
+    uint4 s = make_uint4(0u, p.off8[p.n_records], 0u, (uint32_t)kRecSentinel << 24);
+    reinterpret_cast<uint4*>(p.rec)[p.n_records] = s;
+  }
+  if (p.n_reads == 0) return;
+
+  ReadView r;
+  int contig = 0;
+  load_read(p, i, &r, &contig);
+  const int tb = p.contig_tile_base[contig];
+  const uint8_t* qsrc = p.qual + p.qual_off[i];
+  const uint8_t* ssrc = p.seq4 + p.seq_off[i];
+  const int l = valid ? (int)r.l : 0;
+
+  // ---- floor(mean quality) of the whole read (clipped bases included): one pass over its bytes, reduced over the
+  // read's lanes (np.mean(aln.query_qualities), midas/run/snps.py:151) -----------------------------------------------
+  uint32_t part = 0;
+  if (32 * c < l) {
+    const u32x4_a1 a = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c);
+    const u32x4_a1 b = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c + 16);
+    const int nb = l - 32 * c;
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(w[k] & low_bytes_mask(nb - 4 * k), 0u, part);
+    if (c == 0) part |= ((a.x & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+  }
+  uint32_t qsum = 0;
+  for (int cc = 0; cc < lpr; ++cc) qsum += __shfl(part, g * lpr + cc);
+  const uint32_t qflag = (qsum >> 31) ? (uint32_t)kRecQualAbsent : 0u;
+  qsum &= 0x7FFFFFFFu;
+  const uint32_t qmean = l > 0 ? qsum / (uint32_t)l : 0u;
+
+  const int ns = valid ? (int)p.nseg[i] : 0;
+  const int np = valid ? (ns ? ns : 1) : 0;
+  const uint32_t j0 = p.first[i];
+  uint32_t at = 0;
+  PieceIter it;
+  if (ns) {
+    (void)plan_read(r, &at);   // aligned length of the whole read
+    it.init(r);
+  }
+  for (int s = 0; __any(s < np); ++s) {
+    if (s >= np) continue;
+    int pq = 0, plen = l;
+    long long pr = 0;
+    uint32_t flags = 0;
+    long long reflen = 0;
+    if (ns) {
+      it.next(&pq, &pr, &plen);
+      flags = kRecSimple;
+      reflen = plen;
+    } else {
+      flags = general_flags(r, &reflen);
+    }
+    const uint32_t d = p.dest[j0 + (uint32_t)s];
+    const uint32_t o8 = p.off8[d];
+    uint8_t* const b = p.blob + (size_t)o8 * 8;
+    const uint32_t chunks = blob_chunks((uint32_t)plen, lb);
+    if ((uint32_t)c < chunks) {
+      // ---- this lane's 32 payload slots: bases [y0, y0 + nvalid) of the read -----------------------------------
+      const int x0 = c * (int)lb;
+      const int nvalid = plen - x0 < (int)lb ? plen - x0 : (int)lb;
+      const int y0 = pq + x0;
+      const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qsrc + y0);
+      const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qsrc + y0 + 16);
+      const uint8_t* sp = ssrc + (y0 >> 1);
+      const u32x4_a1 sa = *reinterpret_cast<const u32x4_a1*>(sp);
+      const uint32_t s4 = *reinterpret_cast<const u32_a1*>(sp + 16);
+      uint32_t cw[4] = {sa.x, sa.y, sa.z, sa.w};
+      if (y0 & 1) {   // the first base is a low nibble: shift the nibble stream by one
+        const uint32_t nx[4] = {sa.y, sa.z, sa.w, s4};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t x = __builtin_amdgcn_alignbyte(nx[k], cw[k], 1);   // bytes 1..4 of {cw[k], nx[k]}
+          cw[k] = ((cw[k] & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cw[k] = call_codes8(cw[k]);
+      // out byte k = code(slot k) | code(slot k + 16) << 4
+      uint32_t out[4];
+      out[0] = spread_nibbles<0>(cw[0]) | (spread_nibbles<0>(cw[2]) << 4);
+      out[1] = spread_nibbles<1>(cw[0]) | (spread_nibbles<1>(cw[2]) << 4);
+      out[2] = spread_nibbles<0>(cw[1]) | (spread_nibbles<0>(cw[3]) << 4);
+      out[3] = spread_nibbles<1>(cw[1]) | (spread_nibbles<1>(cw[3]) << 4);
+      uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // slots past the end of the record (and the padding slot of a 31-base lane) are kCallOther with quality 0
+        const uint32_t keep = (low_bytes_mask(nvalid - 4 * k) & 0x0F0F0F0Fu) | (low_bytes_mask(nvalid - 16 - 4 * k) & 0xF0F0F0F0u);
+        out[k] = (out[k] & keep) | (0x22222222u & ~keep);
+        const uint32_t inv_lo = out[k] & 0x02020202u, inv_hi = (out[k] >> 4) & 0x02020202u;
+        qw[k] &= ~((inv_lo << 7) - (inv_lo >> 1));           // a base that is not A/C/G/T carries quality 0
+        qw[k + 4] &= ~((inv_hi << 7) - (inv_hi >> 1));
+      }
+      u32x4_a8 v0, v1, v2;
+      v0.x = qw[0]; v0.y = qw[1]; v0.z = qw[2]; v0.w = qw[3];
+      v1.x = qw[4]; v1.y = qw[5]; v1.z = qw[6]; v1.w = qw[7];
+      v2.x = out[0]; v2.y = out[1]; v2.z = out[2]; v2.w = out[3];
+      *reinterpret_cast<u32x4_a8*>(b + c * kChunk) = v0;
+      *reinterpret_cast<u32x4_a8*>(b + c * kChunk + 16) = v1;
+      *reinterpret_cast<u32x4_a8*>(b + chunks * 32u + c * (kChunk / 2)) = v2;
+    }
+    if (!ns) {   // the record keeps its CIGAR behind the payload (zero padding to 8 bytes)
+      uint32_t* cd = reinterpret_cast<uint32_t*>(b + blob_cigar_off((uint32_t)l, lb));
+      for (uint32_t k = (uint32_t)c; k < r.nc; k += (uint32_t)lpr) cd[k] = r.cg[k];
+      if (c == 0 && (r.nc & 1u)) cd[r.nc] = 0u;
+    }
+    if (c == 0) {
+      const RecKeys keys = record_keys(r.pos + pr, reflen, ns != 0, r.clen, p.tile_len, tb);
+      uint32_t n16, nm16;
+      if (ns) {   // read-level numbers of the filter, in every segment (layout.h)
+        n16 = (uint32_t)l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14);
+        nm16 = (uint32_t)r.nm | ((at & 63u) << 10);
+      } else {
+        n16 = r.nc;
+        nm16 = r.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)r.nm;
+      }
+      uint4 rec;
+      rec.x = (uint32_t)(int32_t)(r.pos + pr);
+      rec.y = o8;
+      rec.z = ((uint32_t)plen | ((qmean & 31u) << kRecLBits)) | (n16 << 16);
+      rec.w = (nm16 & 0xFFFFu) | ((uint32_t)p.mapq[i] << 16) | ((flags | qflag | ((qmean >> 5) << 4)) << 24);
+      reinterpret_cast<uint4*>(p.rec)[d] = rec;
+      p.orig[d] = (uint32_t)i;
+      p.key_out[d] = keys.tile_key;
+    }
+  }
+}
+
+}  // namespace
+
+size_t pack_sort_temp_bytes(int64_t max_records, int key_bits) {
+  size_t a = 0, b = 0, c = 0;
+  uint32_t* nil = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, nil, nil, nil, nil, (int)max_records, 0, key_bits, nullptr);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, nil, nil, (int)max_records + 1, nullptr);
+  c = a > b ? a : b;
+  return c + 256;
+}
+
+int pack_key_bits(int32_t n_tiles) {
+  unsigned long long nbins = (unsigned long long)(n_tiles > 0 ? n_tiles : 1) * kPackBinsPerTile;
+  int bits = 1;
+  while ((1ull << bits) < nbins) ++bits;
+  return bits;
+}
+
+hipError_t launch_pack_plan(const PackParams& p, void* tmp, size_t tmp_bytes, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(p.facts, 0, sizeof(PackFacts), s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(&p.facts->status, 0xFF, 8, s);
+  if (e != hipSuccess) return e;
+  if (p.n_reads > 0) {
+    hipLaunchKernelGGL(pack_plan_kernel, dim3((p.n_reads + kPlanBlock - 1) / kPlanBlock), dim3(kPlanBlock), 0, s, p);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, p.cnt, p.first, p.n_reads + 1, s);
+    if (e != hipSuccess) return e;
+  } else {
+    e = hipMemsetAsync(p.first, 0, 4, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_keys(const PackParams& p, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(p.tile_extra, 0, (size_t)(p.n_tiles > 0 ? p.n_tiles : 1) * 4, s);
+  if (e != hipSuccess) return e;
+  if (p.n_reads > 0)
+    hipLaunchKernelGGL(pack_keys_kernel, dim3((p.n_reads + kPlanBlock - 1) / kPlanBlock), dim3(kPlanBlock), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, int key_bits, hipStream_t s) {
+  const int m = p.n_records;
+  hipError_t e = hipSuccess;
+  if (m > 0) {
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, p.sort_key, p.key_sorted, p.sort_val, p.val_sorted, m, 0, key_bits, s);
+    if (e != hipSuccess) return e;
+  }
+  const int nbins = p.n_tiles * kPackBinsPerTile;
+  const int gb = m > 0 ? (m + kPlanBlock - 1) / kPlanBlock : (nbins + kPlanBlock) / kPlanBlock;
+  hipLaunchKernelGGL(pack_bounds_kernel, dim3(gb > 0 ? gb : 1), dim3(kPlanBlock), 0, s, p);
+  const int nd = m > p.n_tiles ? m : p.n_tiles;
+  if (nd > 0) hipLaunchKernelGGL(pack_dest_kernel, dim3((nd + kPlanBlock - 1) / kPlanBlock), dim3(kPlanBlock), 0, s, p);
+  if (m == 0) {
+    e = hipMemsetAsync(p.off8, 0, 4, s);
+    if (e != hipSuccess) return e;
+  } else {
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, p.bytes8_dev, p.off8, m + 1, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s) {
+  const int rpw = 64 / p.lanes_per_read;
+  const long long waves = ((long long)p.n_reads + rpw - 1) / rpw;
+  long long blocks = (waves + (kScatterBlock / 64) - 1) / (kScatterBlock / 64);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pack_scatter_kernel, dim3((unsigned)blocks), dim3(kScatterBlock), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace midas

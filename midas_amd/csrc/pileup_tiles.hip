@@ -37,6 +37,14 @@ using namespace dev;
 
 namespace {
 
+// Developer ablation switches (tools/ablate.sh builds variants with -DMIDAS_SNPS_DEBUG_BITS=<bits>; several of the bits make
+// the kernel produce wrong counts on purpose, for timing only).  A compile-time constant: the shipped library is built
+// with 0 and carries none of that code, and nothing in the environment can switch it on.
+#ifndef MIDAS_SNPS_DEBUG_BITS
+#define MIDAS_SNPS_DEBUG_BITS 0
+#endif
+constexpr int kDebug = MIDAS_SNPS_DEBUG_BITS;
+
 // Eight bases of the hot loop, hand-scheduled.  Per base: byte compare against baseq (SDWA) -> lane mask in an SGPR
 // pair; address = chunk base | call code (SDWA OR); returnless LDS atomic under that mask.  The eight address ORs and
 // the eight compares are issued back to back (no dependency between them), then each atomic runs under its mask and
@@ -144,8 +152,8 @@ __device__ __forceinline__ Tile load_tile(ConstWords tiles, int t) {
 // the whole-tile kernel waits for LDS traffic alone; prefetched registers are guarded by the compiler's own counters.
 // The parts kernel keeps the full fence (its global atomics are ordered against the tile's arrival ticket).
 template <bool SPLIT>
-__device__ __forceinline__ void tile_barrier(int debug) {
-  if (SPLIT || (debug & 64)) __syncthreads();
+__device__ __forceinline__ void tile_barrier() {
+  if (SPLIT || (kDebug & 64)) __syncthreads();
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   // hands out the items congruent to it modulo 8 and its cache line stays in that XCD's L2.  A single counter
   // bounces between the eight L2s and costs more than the balance gains (measured: 129 us against 108 us static).
   const int w_base = SPLIT ? p.n_whole_items : 0;
-  const bool dynamic = !(p.debug & 16) && (gridDim.x % kSchedGroups) == 0;
+  const bool dynamic = !(kDebug & 16) && (gridDim.x % kSchedGroups) == 0;
   const int sched_group = (int)(blockIdx.x % kSchedGroups);
   uint32_t* const sched = p.split_ticket + p.n_tiles + (SPLIT ? kSchedWords : 0);   // [8 counters, 32 words apart][done]
   int w = w_base + (int)blockIdx.x;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       // records (never "simple and inside": the ballot below sends the iteration down the general path) or, when the
       // tile has none, the sentinel.  (That last, partial iteration used to take the general path in every tile, and the
       // seven other waves waited for it at the barrier: -2 %.)
-      bool fast = it * rpw < rg.ns && !(p.debug & 4);
+      bool fast = it * rpw < rg.ns && !(kDebug & 4);
       if (fast) {
         const int fl = rec_l(rec_cur);
         const int frel = rec_pos(rec_cur) - tile_start;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
               }
             }
             const uint32_t abase = ((uint32_t)(frel + q0) << 4) + lds_base;
-            if (!(p.debug & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
+            if (!(kDebug & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
           }
           const bool head = fact && c == 0 && seg_first(rec_cur);        // S records start in this tile: it owns them;
                                                                          // a read is counted by its first segment
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       // ---- per-base call codes and validity, four bases per instruction ----------------------------
       // cur.qw: quality byte if the base may count (the packer zeroed the bases that are not A/C/G/T), else 0
       uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
-      bool walking = keep && has && !(p.debug & 4);
+      bool walking = keep && has && !(kDebug & 4);
       if (walking) {     // (cd is only ever read under `walking`)
         // call codes arrive as byte k = code(base k) | code(base k + 16) << 4: one AND per four bases
 #pragma unroll
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
           for (int w = 0; w < NW; ++w) q4[w] &= bits_to_bytes((jm >> (4 * w)) & 0xFu);
         }
         const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
-        if (!(p.debug & 1)) tally_chunk(q4, cd, (uint32_t)bq, abase, 1u);
+        if (!(kDebug & 1)) tally_chunk(q4, cd, (uint32_t)bq, abase, 1u);
         walking = (k < n) ? next_segment() : false;
       }
 
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       rec_cur = fetch_rec(nrg, nv0);
       rec_nxt = fetch_rec(nrg, nv0 + vstep);
     }
-    tile_barrier<SPLIT>(p.debug);   // every tally of this tile is in LDS
+    tile_barrier<SPLIT>();   // every tally of this tile is in LDS
     // the item after the next one: the counter is asked here, behind the next tile's record loads and ahead of its
     // payload loads, whose first use is a whole write-out away (loads and returning atomics come back in order: an
     // atomic issued ahead of the stream loop held back every load of the tile's first iterations)
@@ -583,9 +591,9 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     {
       // debug bit 8 (timing experiment only, results wrong): every tile's counts land on the first tile's sites, so
       // the stores stay in L2 and cost no HBM write bandwidth
-      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((p.debug & 8) ? 0 : tile.site_base);
+      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((kDebug & 8) ? 0 : tile.site_base);
       uint4* lds4 = reinterpret_cast<uint4*>(lds);
-      const int lim = (p.debug & 2) ? 0 : tile_len;
+      const int lim = (kDebug & 2) ? 0 : tile_len;
       if constexpr (!SPLIT) {
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       }
     }
     // ---- upper-cased ref allele, four sites per lane ---------------------------------------------------------
-    if (p.out_allele && !(p.debug & 2) && part == 0) {
+    if (p.out_allele && !(kDebug & 2) && part == 0) {
       const uint8_t* ref = p.ref + tile.site_base;
       uint8_t* al = p.out_allele + tile.site_base;
 #pragma unroll
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     // One barrier per tile after the write-out: tallies re-zeroed (and this tile's s_stats additions done) before
     // the next tile's waves touch LDS.  The workgroup's counters go to the species row only when the next tile
     // belongs to another species or there is no next tile: they are additive, so tiles of one species share them.
-    tile_barrier<SPLIT>(p.debug);
+    tile_barrier<SPLIT>();
     if constexpr (SPLIT) {
       if (tid == 0) {
         const uint32_t ticket = atomicAdd(&p.split_ticket[t], 1u);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       __syncthreads();
     }
     if (more) {
-      const long long nn = (dynamic && !(p.debug & 32)) ? (long long)w_base + 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
+      const long long nn = (dynamic && !(kDebug & 32)) ? (long long)w_base + 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
                                                         : (long long)wn + (long long)gridDim.x;
       w_next = __builtin_amdgcn_readfirstlane((int)(nn < (long long)w_end ? nn : (long long)w_end));
     }
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         }
         acc_cov = 0ull;
         acc_depth = 0ull;
-        tile_barrier<SPLIT>(p.debug);
+        tile_barrier<SPLIT>();
       }
       if (tid < MIDAS_STATS) {
         const unsigned long long v = s_stats[tid];
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
         }
         break;
       }
-      tile_barrier<SPLIT>(p.debug);   // s_stats reset before the next tile adds to it
+      tile_barrier<SPLIT>();   // s_stats reset before the next tile adds to it
     }
     w = wn;
     part = npart;

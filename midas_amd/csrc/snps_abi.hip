@@ -19,11 +19,35 @@
 #include "layout.h"
 #include "pack.h"
 
+#include <algorithm>
+
 using namespace midas;
 
 struct midas_snps_batch {
   midas_snps_ctx* ctx = nullptr;
-  // device
+  // device: the caller's BAM-native SoA, uploaded as it is (the device packer's input)
+  int32_t* d_pos = nullptr;
+  uint8_t* d_mapq = nullptr;
+  int32_t* d_nm = nullptr;
+  int32_t* d_lseq = nullptr;
+  int64_t* d_seq_off = nullptr;
+  int64_t* d_qual_off = nullptr;
+  int64_t* d_cigar_off = nullptr;
+  uint8_t* d_seq4 = nullptr;
+  uint8_t* d_qual = nullptr;
+  uint32_t* d_cigar = nullptr;
+  int64_t seq_bytes = 0, qual_bytes = 0, n_cigar = 0;
+  // device: scratch of the packer (one slab each: per read, per record)
+  uint8_t* d_pack_reads = nullptr;    // nseg, cnt, first, facts, bin_start, tile_extra, tile_reads
+  uint8_t* d_pack_recs = nullptr;     // sort keys / values (in + out), bytes8, dest, bytes8_dev, off8
+  void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int key_bits = 1;
+  PackParams pk;                      // every pointer of a pack, filled once the buffers exist
+  uint32_t* h_tile_reads = nullptr;   // pinned: reads every tile will see, fetched once per pack for the hot-spot plan
+  std::vector<uint32_t> h_items;      // the work items last uploaded
+  int64_t pack_count = 0;
+  // device: the packed layout (layout.h)
   ReadRec* d_rec = nullptr;
   uint8_t* d_blob = nullptr;
   uint8_t* d_ref = nullptr;
@@ -36,6 +60,7 @@ struct midas_snps_batch {
   uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
   uint32_t* d_key = nullptr;    // device record -> tile << 7 | reach << 2 | class (input of the index kernel)
   uint32_t* d_items = nullptr;  // [n_items][4] work items {tile, part, n_parts, 0} of the pileup kernel
+  size_t items_cap = 0;         // words d_items can hold
   uint32_t* d_ticket = nullptr; // [n_tiles] arrival counters of split tiles
   int64_t n_items = 0, n_whole_items = 0;
   std::vector<std::pair<size_t, size_t>> zero_ranges;   // (first site, sites) of split tiles: counts zeroed before a run
@@ -51,10 +76,11 @@ struct midas_snps_batch {
   int64_t n_records = 0;   // device records (match segments + reads that keep their CIGAR) >= n_reads
   int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, lane_bases = 31, tile_len = kTileSites;
   // timing
-  std::vector<hipEvent_t> ev;  // 3 per slot
+  std::vector<hipEvent_t> ev;  // 3 per slot: before the index kernel, before and after the pileup kernel
+  std::vector<hipEvent_t> pev; // 3 per slot: before the pack, before and after its scatter kernel
   int32_t timing_slots = 0;
   bool timing_pileup_only = false;
-  int64_t timed_runs = 0;
+  int64_t timed_runs = 0, timed_packs = 0;
   int64_t run_count = 0;
   bool ran = false;
 };
@@ -202,11 +228,6 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-  if (ctx->stage_rec || ctx->stage_blob) {   // unmapping large staging buffers is slow: not on the caller's time
-    void* a = ctx->stage_rec;
-    void* c = ctx->stage_blob;
-    std::thread([a, c] { free(a); free(c); }).detach();
-  }
   delete ctx;
 }
 
@@ -239,28 +260,140 @@ int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_co
   return st;
 }
 
+int32_t midas_snps_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob,
+                                    int64_t blob_capacity, uint32_t* orig_index, uint32_t* key, int64_t* out_blob_bytes,
+                                    int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
+  PackSummary s;
+  if (!contigs) return MIDAS_SNPS_ERR_INVALID_ARG;
+  int32_t st = pack_reads(reads, contigs, kTileSites, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
+                          orig_index, key, blob_capacity, &s, err256);
+  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
+  if (out_n_records) *out_n_records = s.n_records;
+  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
+  return st;
+}
+
 void midas_snps_batch_destroy(midas_snps_batch* b) {
   if (!b) return;
   if (b->ctx) (void)hipSetDevice(b->ctx->device);
-  (void)hipFree(b->d_rec);
-  (void)hipFree(b->d_blob);
-  (void)hipFree(b->d_ref);
-  (void)hipFree(b->d_tiles);
-  (void)hipFree(b->d_contig_read_begin);
-  (void)hipFree(b->d_contig_tile_base);
-  (void)hipFree(b->d_contig_len);
-  (void)hipFree(b->d_work);
-  (void)hipFree(b->d_items);
-  (void)hipFree(b->d_ticket);
-  (void)hipFree(b->d_filt);
-  (void)hipFree(b->d_orig);
-  (void)hipFree(b->d_key);
-  (void)hipFree(b->d_counts);
-  (void)hipFree(b->d_allele);
+  void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
+                 b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
+                 b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
+                 b->d_orig, b->d_key, b->d_counts, b->d_allele};
+  for (void* q : dev) (void)hipFree(q);
+  if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
   for (auto& e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->pev)
     if (e) (void)hipEventDestroy(e);
   delete b;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Work items of the pileup kernel from the reads every tile will see: one per tile; a tile with very many reads (a
+// coverage hot spot) is cut into parts that different workgroups process concurrently and merge with atomics -- otherwise
+// one workgroup would walk it alone while the rest of the chip idles.  Whole tiles and parts are launched as two
+// instantiations of the kernel.  Uploaded only when the plan differs from the one on the device.
+int32_t plan_work_items(midas_snps_batch* b, const uint32_t* tile_reads) {
+  midas_snps_ctx* ctx = b->ctx;
+  // split only what would otherwise leave the chip idle: a tile holding more than twice a workgroup's fair share
+  // of all reads (and at least 2048), cut into parts of about one fair share (at least 1024 reads)
+  const size_t nt = (size_t)b->n_tiles;
+  int64_t total_reads = 0;
+  for (size_t t = 0; t < nt; ++t) total_reads += tile_reads[t];
+  const int64_t fair = total_reads / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
+  int64_t split_reads = std::max<int64_t>(2048, 2 * fair), part_reads = std::max<int64_t>(1024, fair);
+#ifdef MIDAS_SNPS_SPLIT_READS   // developer variants only (tools/build_variant.sh)
+  split_reads = MIDAS_SNPS_SPLIT_READS;
+  part_reads = split_reads > 1 ? split_reads / 2 : 1;
+#endif
+  std::vector<uint32_t> items;
+  items.reserve(nt * 4 + 64);
+  std::vector<std::pair<size_t, size_t>> zero_ranges;
+  size_t n_split = 0;
+  for (size_t t = 0; t < nt; ++t) {     // whole tiles first ...
+    if ((int64_t)tile_reads[t] > split_reads) { ++n_split; continue; }
+    items.push_back((uint32_t)t); items.push_back(0u); items.push_back(1u); items.push_back(0u);
+  }
+  const int64_t n_whole = (int64_t)(items.size() / 4);
+  if (n_split) {
+    std::vector<Tile> tiles(nt);
+    HIP_TRY(ctx, hipMemcpy(tiles.data(), b->d_tiles, nt * sizeof(Tile), hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < nt; ++t) {     // ... then the parts of split tiles
+      if ((int64_t)tile_reads[t] <= split_reads) continue;
+      int64_t np = ((int64_t)tile_reads[t] + part_reads - 1) / part_reads;
+      if (np > 4096) np = 4096;
+      for (int64_t j = 0; j < np; ++j) { items.push_back((uint32_t)t); items.push_back((uint32_t)j); items.push_back((uint32_t)np); items.push_back(0u); }
+      const size_t first = (size_t)tiles[t].site_base, cnt = (size_t)tiles[t].len;
+      if (!zero_ranges.empty() && zero_ranges.back().first + zero_ranges.back().second == first) zero_ranges.back().second += cnt;
+      else zero_ranges.emplace_back(first, cnt);
+    }
+  }
+  b->n_whole_items = n_whole;
+  b->n_items = (int64_t)(items.size() / 4);
+  b->zero_ranges.swap(zero_ranges);
+  // with no split tile the list is the identity and the kernel never reads it
+  const bool need_upload = n_split > 0 && items != b->h_items;
+  if (need_upload) {
+    if (b->items_cap < items.size()) {
+      (void)hipFree(b->d_items);
+      b->d_items = nullptr;
+      b->items_cap = 0;
+      HIP_TRY(ctx, hipMalloc(&b->d_items, items.size() * 4));
+      b->items_cap = items.size();
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->h_items.swap(items);
+  }
+  return MIDAS_SNPS_OK;
+}
+
+template <class T>
+T* carve(uint8_t*& cur, size_t n) {
+  T* r = reinterpret_cast<T*>(cur);
+  cur += (n * sizeof(T) + 255) & ~(size_t)255;
+  return r;
+}
+size_t carved(size_t n, size_t elem) { return (n * elem + 255) & ~(size_t)255; }
+
+int32_t pack_status_to_error(midas_snps_ctx* ctx, unsigned long long st) {
+  const long long rd = (long long)(st >> 8);
+  char buf[256];
+  ctx->err_read = rd;
+  if ((st & 0xFF) == kPackUnsupported) {
+    snprintf(buf, sizeof buf, "read %lld: l_seq > %d or n_cigar/NM > %d is not supported", rd, kMaxLSeq, kMaxField16);
+    return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, buf);
+  }
+  snprintf(buf, sizeof buf, "read %lld: negative size or CSR offsets shorter than l_seq", rd);
+  return fail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, buf);
+}
+
+// The device packer over the resident raw reads, once the buffers exist: plan, keys, order, scatter on the context's stream.
+// The per-tile read counts come back over a pinned buffer while the scatter kernel runs; the host derives the hot-spot
+// plan from them (identical for identical input: nothing is uploaded then).
+int32_t run_pack(midas_snps_batch* b, hipEvent_t* ev) {
+  midas_snps_ctx* ctx = b->ctx;
+  hipStream_t s = ctx->stream;
+  if (ev) HIP_TRY(ctx, hipEventRecord(ev[0], s));
+  HIP_TRY(ctx, launch_pack_plan(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, s));
+  HIP_TRY(ctx, launch_pack_keys(b->pk, s));
+  HIP_TRY(ctx, launch_pack_order(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, b->key_bits, s));
+  if (b->n_tiles > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
+  if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
+  HIP_TRY(ctx, launch_pack_scatter(b->pk, s));
+  if (ev) HIP_TRY(ctx, hipEventRecord(ev[2], s));
+  b->pack_count += 1;
+  return MIDAS_SNPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
                                 const midas_snps_reads* reads, midas_snps_batch** out_batch) {
@@ -270,7 +403,11 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   ctx->err_read = -1;
   char ebuf[256] = {0};
   int64_t n_sites = 0;
-  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;   // developer: where batch_create spends its time
+#ifdef MIDAS_SNPS_TRACE   // developer variants only: where batch_create spends its time
+  const bool trace = true;
+#else
+  const bool trace = false;
+#endif
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t_prev = now();
   auto lap = [&](const char* what) {
@@ -281,32 +418,32 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   };
   int32_t st = validate_contigs(contigs, reads->n_reads, &n_sites, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
-
-  // tile length: the LDS budget (4096 sites x 16 B); shorter tiles were measured and are slower.  MIDAS_SNPS_TILE_LEN
-  // overrides for experiments.  Known before the size query: the packer cuts records at tile boundaries.
-  int32_t chosen_tile_len = kTileSites;
-  if (const char* e = getenv("MIDAS_SNPS_TILE_LEN")) chosen_tile_len = atoi(e);
-  if (chosen_tile_len < 64) chosen_tile_len = 64;
-  if (chosen_tile_len > kTileSites) chosen_tile_len = kTileSites;
-  chosen_tile_len &= ~15;
-  PackSummary ps;
-  st = pack_reads(reads, contigs, chosen_tile_len, nullptr, nullptr, nullptr, nullptr, 0, &ps, ebuf);
-  if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
-  lap("validate + size query");
+  const int64_t n = reads->n_reads;
+  if (n < 0 || n > 2000000000LL) {
+    snprintf(ebuf, sizeof ebuf, "n_reads %lld out of range", (long long)n);
+    return fail(ctx, n < 0 ? MIDAS_SNPS_ERR_INVALID_ARG : MIDAS_SNPS_ERR_UNSUPPORTED, ebuf);
+  }
+  if (n > 0 && (!reads->pos || !reads->mapq || !reads->nm || !reads->l_seq || !reads->seq_off || !reads->qual_off ||
+                !reads->cigar_off || !reads->seq4 || !reads->qual || !reads->cigar))
+    return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "NULL array in midas_snps_reads");
+  // the CSR offsets' last entries are the array sizes (the device checks every read against them)
+  const int64_t seq_bytes = n > 0 ? reads->seq_off[n] : 0, qual_bytes = n > 0 ? reads->qual_off[n] : 0,
+                n_cigar = n > 0 ? reads->cigar_off[n] : 0;
+  if (seq_bytes < 0 || qual_bytes < 0 || n_cigar < 0 || (n > 0 && (reads->seq_off[0] < 0 || reads->qual_off[0] < 0 || reads->cigar_off[0] < 0)))
+    return fail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative CSR offset in midas_snps_reads");
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
   midas_snps_batch* b = new (std::nothrow) midas_snps_batch();
   if (!b) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host allocation failed");
   b->ctx = ctx;
-  b->n_reads = reads->n_reads;
-  b->n_records = ps.n_records;
+  b->n_reads = n;
   b->n_sites = n_sites;
   b->n_contigs = contigs->n_contigs;
   b->n_species = contigs->n_species;
-  b->blob_bytes = ps.blob_bytes;
-  b->alg_bytes = ps.read_algorithmic_bytes + 17 * n_sites;
-  b->lane_bases = ps.lane_bases;
-  b->lanes_per_read = ps.max_l_seq <= b->lane_bases ? 1 : (ps.max_l_seq + b->lane_bases - 1) / b->lane_bases;
+  b->seq_bytes = seq_bytes;
+  b->qual_bytes = qual_bytes;
+  b->n_cigar = n_cigar;
 
 #define B_TRY(call)                              \
   do {                                           \
@@ -317,8 +454,17 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       return s__;                                \
     }                                            \
   } while (0)
+#define B_ST(expr)                               \
+  do {                                           \
+    int32_t s__ = (expr);                        \
+    if (s__ != MIDAS_SNPS_OK) {                  \
+      midas_snps_batch_destroy(b);               \
+      return s__;                                \
+    }                                            \
+  } while (0)
 
-  b->tile_len = chosen_tile_len;
+  // tile length: the LDS budget (4096 sites x 16 B); shorter tiles were measured and are slower
+  b->tile_len = kTileSites;
   const int64_t tile_len = b->tile_len;
   // ---- tile table -------------------------------------------------------------------------
   std::vector<Tile> tiles;
@@ -330,13 +476,13 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       tile_base[c] = (int32_t)tiles.size();
       clen[c] = (int32_t)len;
       rbeg[c] = (int32_t)contigs->read_begin[c];
-      for (int64_t s = 0; s < len; s += tile_len) {
+      for (int64_t x = 0; x < len; x += tile_len) {
         Tile t;
         t.contig = c;
-        t.start = (int32_t)s;
-        t.len = (int32_t)((len - s) < tile_len ? (len - s) : tile_len);
+        t.start = (int32_t)x;
+        t.len = (int32_t)((len - x) < tile_len ? (len - x) : tile_len);
         t.species = contigs->species[c];
-        t.site_base = site + s;
+        t.site_base = site + x;
         t.contig_len = (int32_t)len;
         t.pad = 0;
         tiles.push_back(t);
@@ -344,76 +490,9 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
       site += len;
     }
     tile_base[contigs->n_contigs] = (int32_t)tiles.size();
-    rbeg[contigs->n_contigs] = (int32_t)reads->n_reads;
+    rbeg[contigs->n_contigs] = (int32_t)n;
   }
   b->n_tiles = (int64_t)tiles.size();
-  std::vector<int64_t> tile_reads(tiles.size(), 0);
-
-  // ---- pack + upload reads ------------------------------------------------------------------
-  const size_t blob_alloc = (size_t)ps.blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
-  B_TRY(hipMalloc(&b->d_rec, (size_t)(b->n_records + 1) * sizeof(ReadRec)));  // + sentinel
-  B_TRY(hipMalloc(&b->d_blob, blob_alloc));
-  if (b->n_reads > 0) {
-    // staging in ordinary (pageable) memory owned by the context: pinning and unpinning ~0.25 GB costs ~70 ms on this
-    // platform, and even unmapping it ~30 ms -- several times the pack and the copy themselves (MIDAS_SNPS_TRACE)
-    const size_t rec_bytes = (size_t)(b->n_records + 1) * sizeof(ReadRec);
-    if (ctx->stage_rec_cap < rec_bytes) {
-      free(ctx->stage_rec);
-      ctx->stage_rec = malloc(rec_bytes);
-      ctx->stage_rec_cap = ctx->stage_rec ? rec_bytes : 0;
-    }
-    if (ctx->stage_blob_cap < blob_alloc) {
-      free(ctx->stage_blob);
-      ctx->stage_blob = malloc(blob_alloc);
-      ctx->stage_blob_cap = ctx->stage_blob ? blob_alloc : 0;
-    }
-    ReadRec* h_rec = static_cast<ReadRec*>(ctx->stage_rec);
-    uint8_t* h_blob = static_cast<uint8_t*>(ctx->stage_blob);
-    if (!h_rec || !h_blob) {
-      midas_snps_batch_destroy(b);
-      return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host staging allocation failed");
-    }
-    memset(h_blob + ps.blob_bytes, 0, 64);
-    lap("device + staging allocations");
-    std::vector<uint32_t> h_orig((size_t)b->n_records);
-    std::vector<uint32_t> h_key((size_t)b->n_records);
-    st = pack_reads(reads, contigs, b->tile_len, h_rec, h_blob, h_orig.data(), h_key.data(), (int64_t)blob_alloc, &ps, ebuf);
-    lap("pack_reads");
-    if (st == MIDAS_SNPS_OK) {
-      // reads a tile will see = those that start in it + those of earlier tiles reaching in (key: tile << 7 | reach << 2 | class)
-      for (int64_t i = 0; i < b->n_records; ++i) {
-        const uint32_t k = h_key[(size_t)i];
-        const size_t t0 = k >> 7, reach = (k >> 2) & 31u;
-        for (size_t r = 0; r <= reach && t0 + r < tile_reads.size(); ++r) tile_reads[t0 + r] += 1;
-      }
-      hipError_t e0 = hipMalloc(&b->d_orig, (size_t)b->n_records * 4);
-      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_orig, h_orig.data(), (size_t)b->n_records * 4, hipMemcpyHostToDevice);
-      if (e0 == hipSuccess) e0 = hipMalloc(&b->d_key, (size_t)b->n_records * 4);
-      if (e0 == hipSuccess) e0 = hipMemcpy(b->d_key, h_key.data(), (size_t)b->n_records * 4, hipMemcpyHostToDevice);
-      if (e0 != hipSuccess) { int32_t s2 = hip_fail(ctx, e0, "upload of the input-order map"); midas_snps_batch_destroy(b); return s2; }
-    }
-    hipError_t e1 = hipSuccess, e2 = hipSuccess;
-    if (st == MIDAS_SNPS_OK) {
-      e1 = hipMemcpy(b->d_rec, h_rec, (size_t)(b->n_records + 1) * sizeof(ReadRec), hipMemcpyHostToDevice);
-      e2 = hipMemcpy(b->d_blob, h_blob, blob_alloc, hipMemcpyHostToDevice);
-    }
-    lap("H2D records + payload");
-
-    if (st != MIDAS_SNPS_OK) {
-      midas_snps_batch_destroy(b);
-      return fail(ctx, st, ebuf);
-    }
-    B_TRY(e1);
-    B_TRY(e2);
-  } else {
-    B_TRY(hipMemset(b->d_blob, 0, blob_alloc));
-    B_TRY(hipMemset(b->d_rec, 0, sizeof(ReadRec)));
-  }
-
-  // ---- reference letters, tables, workspace, outputs -----------------------------------------
-  const size_t ns = (size_t)(n_sites > 0 ? n_sites : 1);
-  B_TRY(hipMalloc(&b->d_ref, ns));
-  if (n_sites > 0) B_TRY(hipMemcpy(b->d_ref, contigs->ref, (size_t)n_sites, hipMemcpyHostToDevice));
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
   B_TRY(hipMalloc(&b->d_tiles, nt * sizeof(Tile)));
   if (b->n_tiles > 0) B_TRY(hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
@@ -425,52 +504,186 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemcpy(b->d_contig_tile_base, tile_base.data(), nc1 * 4, hipMemcpyHostToDevice));
   if (contigs->n_contigs > 0)
     B_TRY(hipMemcpy(b->d_contig_len, clen.data(), (size_t)contigs->n_contigs * 4, hipMemcpyHostToDevice));
-  // ---- work items: one per tile; a tile with very many reads (coverage hot spot) is cut into parts that different
-  // workgroups process concurrently and merge with atomics -- otherwise one workgroup would walk it alone while the
-  // rest of the chip idles.  Whole tiles and parts are launched as two instantiations of the kernel.
-  {
-    // split only what would otherwise leave the chip idle: a tile holding more than twice a workgroup's fair share
-    // of all reads (and at least 2048), cut into parts of about one fair share (at least 1024 reads)
-    int64_t total_reads = 0;
-    for (int64_t x : tile_reads) total_reads += x;
-    const int64_t fair = total_reads / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
-    int64_t split_reads = std::max<int64_t>(2048, 2 * fair), part_reads = std::max<int64_t>(1024, fair);
-    if (const char* e = getenv("MIDAS_SNPS_SPLIT_READS")) { split_reads = atoll(e); part_reads = split_reads > 1 ? split_reads / 2 : 1; }
-    std::vector<uint32_t> items;
-    items.reserve(tiles.size() * 4 + 64);
-    std::vector<char> is_split(tiles.size(), 0);
-    for (size_t t = 0; t < tiles.size(); ++t) {     // whole tiles first ...
-      if (tile_reads[t] > split_reads) { is_split[t] = 1; continue; }
-      items.push_back((uint32_t)t); items.push_back(0u); items.push_back(1u); items.push_back(0u);
-    }
-    b->n_whole_items = (int64_t)(items.size() / 4);
-    for (size_t t = 0; t < tiles.size(); ++t) {     // ... then the parts of split tiles
-      if (!is_split[t]) continue;
-      int64_t np = (tile_reads[t] + part_reads - 1) / part_reads;
-      if (np > 4096) np = 4096;
-      for (int64_t j = 0; j < np; ++j) { items.push_back((uint32_t)t); items.push_back((uint32_t)j); items.push_back((uint32_t)np); items.push_back(0u); }
-      const size_t first = (size_t)tiles[t].site_base, cnt = (size_t)tiles[t].len;
-      if (!b->zero_ranges.empty() && b->zero_ranges.back().first + b->zero_ranges.back().second == first) b->zero_ranges.back().second += cnt;
-      else b->zero_ranges.emplace_back(first, cnt);
-    }
-    b->n_items = (int64_t)(items.size() / 4);
-    B_TRY(hipMalloc(&b->d_items, (items.empty() ? 1 : items.size()) * 4));
-    if (!items.empty()) B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
-    B_TRY(hipMalloc(&b->d_ticket, (nt + 2 * kSchedWords) * 4));     // + the two launches' dynamic-schedule words
-    B_TRY(hipMemset(b->d_ticket, 0, (nt + 2 * kSchedWords) * 4));
+  lap("validate + tile table");
+
+  // ---- upload the reads as they are: the packer runs on the device -----------------------------------------------
+  // (64 bytes of slack behind the byte arrays: the packer's 16-byte loads may overhang the last read)
+  const size_t n1 = (size_t)(n > 0 ? n : 1);
+  B_TRY(hipMalloc(&b->d_pos, n1 * 4));
+  B_TRY(hipMalloc(&b->d_mapq, n1));
+  B_TRY(hipMalloc(&b->d_nm, n1 * 4));
+  B_TRY(hipMalloc(&b->d_lseq, n1 * 4));
+  B_TRY(hipMalloc(&b->d_seq_off, (n1 + 1) * 8));
+  B_TRY(hipMalloc(&b->d_qual_off, (n1 + 1) * 8));
+  B_TRY(hipMalloc(&b->d_cigar_off, (n1 + 1) * 8));
+  B_TRY(hipMalloc(&b->d_seq4, (size_t)seq_bytes + 64));
+  B_TRY(hipMalloc(&b->d_qual, (size_t)qual_bytes + 64));
+  B_TRY(hipMalloc(&b->d_cigar, ((size_t)n_cigar + 16) * 4));
+  if (n > 0) {
+    B_TRY(hipMemcpyAsync(b->d_pos, reads->pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_mapq, reads->mapq, (size_t)n, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_nm, reads->nm, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_lseq, reads->l_seq, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_seq_off, reads->seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_qual_off, reads->qual_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    B_TRY(hipMemcpyAsync(b->d_cigar_off, reads->cigar_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (seq_bytes > 0) B_TRY(hipMemcpyAsync(b->d_seq4, reads->seq4, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
+    if (qual_bytes > 0) B_TRY(hipMemcpyAsync(b->d_qual, reads->qual, (size_t)qual_bytes, hipMemcpyHostToDevice, s));
+    if (n_cigar > 0) B_TRY(hipMemcpyAsync(b->d_cigar, reads->cigar, (size_t)n_cigar * 4, hipMemcpyHostToDevice, s));
   }
+  B_TRY(hipMemsetAsync(b->d_seq4 + seq_bytes, 0, 64, s));
+  B_TRY(hipMemsetAsync(b->d_qual + qual_bytes, 0, 64, s));
+  B_TRY(hipMemsetAsync(b->d_cigar + n_cigar, 0, 64, s));
+  lap("H2D raw reads");
+
+  // ---- packer, step 1: plan (validates every read on the device; the sizes come back) ----------------------------
+  const size_t nbins = (size_t)b->n_tiles * kPackBinsPerTile + 1;
+  {
+    const size_t bytes = carved(n1, 1) + 2 * carved(n1 + 1, 4) + carved(1, sizeof(PackFacts)) + carved(nbins, 4) + 2 * carved(nt, 4);
+    B_TRY(hipMalloc(&b->d_pack_reads, bytes));
+    uint8_t* cur = b->d_pack_reads;
+    PackParams& k = b->pk;
+    memset(&k, 0, sizeof k);
+    k.nseg = carve<uint8_t>(cur, n1);
+    k.cnt = carve<uint32_t>(cur, n1 + 1);
+    k.first = carve<uint32_t>(cur, n1 + 1);
+    k.facts = carve<PackFacts>(cur, 1);
+    k.bin_start = carve<uint32_t>(cur, nbins);
+    k.tile_extra = carve<uint32_t>(cur, nt);
+    k.tile_reads = carve<uint32_t>(cur, nt);
+    k.pos = b->d_pos; k.mapq = b->d_mapq; k.nm = b->d_nm; k.l_seq = b->d_lseq;
+    k.seq_off = b->d_seq_off; k.qual_off = b->d_qual_off; k.cigar_off = b->d_cigar_off;
+    k.seq4 = b->d_seq4; k.qual = b->d_qual; k.cigar = b->d_cigar;
+    k.seq_bytes = seq_bytes; k.qual_bytes = qual_bytes; k.n_cigar = n_cigar;
+    k.n_reads = (int32_t)n;
+    k.contig_read_begin = b->d_contig_read_begin; k.contig_tile_base = b->d_contig_tile_base; k.contig_len = b->d_contig_len;
+    k.n_contigs = contigs->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len;
+  }
+  b->key_bits = pack_key_bits((int32_t)b->n_tiles);
+  // the first scan needs scratch before the record count is known: size it for the reads, regrow below for the records
+  b->sort_tmp_bytes = pack_sort_temp_bytes((int64_t)n1 + 1, b->key_bits);
+  B_TRY(hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes));
+  B_TRY(launch_pack_plan(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, s));
+  PackFacts facts;
+  B_TRY(hipMemcpyAsync(&facts, b->pk.facts, sizeof facts, hipMemcpyDeviceToHost, s));
+  B_TRY(hipStreamSynchronize(s));
+  lap("pack: plan");
+  if (facts.status != kNoError) B_ST(pack_status_to_error(ctx, facts.status));
+  if (facts.n_records > 2000000000ull) {
+    snprintf(ebuf, sizeof ebuf, "%llu device records exceed the supported range", facts.n_records);
+    B_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
+  }
+  const int64_t m = (int64_t)facts.n_records;
+  b->n_records = m;
+  b->max_l_seq = (int32_t)facts.max_l;
+  b->alg_bytes = (int64_t)facts.alg_bytes + 17 * n_sites;
+  b->lane_bases = lane_bases_for(b->max_l_seq);
+  b->lanes_per_read = b->max_l_seq <= b->lane_bases ? 1 : (b->max_l_seq + b->lane_bases - 1) / b->lane_bases;
+
+  // ---- packer, step 2: keys + sizes ------------------------------------------------------------------------------
+  const size_t m1 = (size_t)(m > 0 ? m : 1);
+  {
+    const size_t bytes = 6 * carved(m1, 4) + 2 * carved(m1 + 1, 4);
+    B_TRY(hipMalloc(&b->d_pack_recs, bytes));
+    uint8_t* cur = b->d_pack_recs;
+    PackParams& k = b->pk;
+    k.sort_key = carve<uint32_t>(cur, m1);
+    k.sort_val = carve<uint32_t>(cur, m1);
+    k.key_sorted = carve<uint32_t>(cur, m1);
+    k.val_sorted = carve<uint32_t>(cur, m1);
+    k.bytes8 = carve<uint32_t>(cur, m1);
+    k.dest = carve<uint32_t>(cur, m1);
+    k.bytes8_dev = carve<uint32_t>(cur, m1 + 1);
+    k.off8 = carve<uint32_t>(cur, m1 + 1);
+    k.n_records = (int32_t)m;
+    k.lane_bases = b->lane_bases;
+    k.lanes_per_read = b->lanes_per_read;
+  }
+  {
+    const size_t need = pack_sort_temp_bytes((int64_t)std::max(m1, n1) + 1, b->key_bits);
+    if (need > b->sort_tmp_bytes) {
+      (void)hipFree(b->d_sort_tmp);
+      b->d_sort_tmp = nullptr;
+      B_TRY(hipMalloc(&b->d_sort_tmp, need));
+      b->sort_tmp_bytes = need;
+    }
+  }
+  B_TRY(launch_pack_keys(b->pk, s));
+  B_TRY(hipMemcpyAsync(&facts, b->pk.facts, sizeof facts, hipMemcpyDeviceToHost, s));
+  B_TRY(hipStreamSynchronize(s));
+  lap("pack: keys");
+  b->blob_bytes = (int64_t)facts.blob_bytes;
+  if (facts.blob_bytes / 8 > 0xFFFFFFFFull) {
+    snprintf(ebuf, sizeof ebuf, "packed payload %llu bytes exceeds the 32 GiB a batch can address", facts.blob_bytes);
+    B_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
+  }
+
+  // ---- packer, steps 3 + 4: device order, then records + payload ---------------------------------------------------
+  const size_t blob_alloc = (size_t)b->blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
+  B_TRY(hipMalloc(&b->d_rec, (size_t)(m + 1) * sizeof(ReadRec)));  // + sentinel
+  B_TRY(hipMalloc(&b->d_blob, blob_alloc));
+  B_TRY(hipMalloc(&b->d_orig, m1 * 4));
+  B_TRY(hipMalloc(&b->d_key, m1 * 4));
+  B_TRY(hipMemsetAsync(b->d_blob + b->blob_bytes, 0, 64, s));
+  b->pk.rec = b->d_rec; b->pk.blob = b->d_blob; b->pk.orig = b->d_orig; b->pk.key_out = b->d_key;
+  B_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_tile_reads), nt * 4, hipHostMallocDefault));
+  B_TRY(launch_pack_order(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, b->key_bits, s));
+  if (b->n_tiles > 0)
+    B_TRY(hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
+  B_TRY(launch_pack_scatter(b->pk, s));
+  B_TRY(hipStreamSynchronize(s));
+  b->pack_count = 1;
+  lap("pack: order + scatter");
+  B_TRY(hipMalloc(&b->d_items, 4));
+  b->items_cap = 1;
+  B_ST(plan_work_items(b, b->h_tile_reads));
+  B_TRY(hipMalloc(&b->d_ticket, (nt + 2 * kSchedWords) * 4));     // + the two launches' dynamic-schedule words
+  B_TRY(hipMemset(b->d_ticket, 0, (nt + 2 * kSchedWords) * 4));
+
+  // ---- reference letters, workspace, outputs --------------------------------------------------------------------
+  const size_t ns = (size_t)(n_sites > 0 ? n_sites : 1);
+  B_TRY(hipMalloc(&b->d_ref, ns));
+  if (n_sites > 0) B_TRY(hipMemcpy(b->d_ref, contigs->ref, (size_t)n_sites, hipMemcpyHostToDevice));
   b->work_bytes = (((size_t)b->n_tiles * 48 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
   // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
   // error word are reset by the index kernel at the start of each run: no per-run memsets
   B_TRY(hipMemset(b->d_work, 0, b->work_bytes));
   B_TRY(hipMalloc(&b->d_filt, sizeof(FilterTables)));
-  b->max_l_seq = ps.max_l_seq;
   B_TRY(hipMalloc(&b->d_counts, ns * 16));
   B_TRY(hipMalloc(&b->d_allele, ns));
 #undef B_TRY
-  lap("tables, items, outputs");
+#undef B_ST
+  lap("ref, workspace, outputs");
   *out_batch = b;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_pack(midas_snps_batch* b) {
+  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipEvent_t* ev = b->timing_slots > 0 ? &b->pev[(size_t)(b->timed_packs % b->timing_slots) * 3] : nullptr;
+  int32_t st = run_pack(b, ev);
+  if (st != MIDAS_SNPS_OK) return st;
+  if (ev) b->timed_packs += 1;
+  // the hot-spot plan needs the per-tile read counts on the host: one wait per pack (the scatter kernel is part of it)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return plan_work_items(b, b->h_tile_reads);
+}
+
+int32_t midas_snps_batch_fetch_packed(midas_snps_batch* b, void* rec16, void* blob, uint32_t* orig_index, uint32_t* key,
+                                      int64_t* out_n_records, int64_t* out_blob_bytes) {
+  if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_n_records) *out_n_records = b->n_records;
+  if (out_blob_bytes) *out_blob_bytes = b->blob_bytes;
+  if (rec16) HIP_TRY(ctx, hipMemcpy(rec16, b->d_rec, (size_t)(b->n_records + 1) * sizeof(ReadRec), hipMemcpyDeviceToHost));
+  if (blob && b->blob_bytes > 0) HIP_TRY(ctx, hipMemcpy(blob, b->d_blob, (size_t)b->blob_bytes, hipMemcpyDeviceToHost));
+  if (orig_index && b->n_records > 0) HIP_TRY(ctx, hipMemcpy(orig_index, b->d_orig, (size_t)b->n_records * 4, hipMemcpyDeviceToHost));
+  if (key && b->n_records > 0) HIP_TRY(ctx, hipMemcpy(key, b->d_key, (size_t)b->n_records * 4, hipMemcpyDeviceToHost));
   return MIDAS_SNPS_OK;
 }
 
@@ -480,10 +693,15 @@ int32_t midas_snps_batch_enable_timing(midas_snps_batch* b, int32_t n_slots) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (auto& e : b->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->pev)
+    if (e) (void)hipEventDestroy(e);
   b->ev.assign((size_t)n_slots * 3, nullptr);
+  b->pev.assign((size_t)n_slots * 3, nullptr);
   for (auto& e : b->ev) HIP_TRY(ctx, hipEventCreate(&e));
+  for (auto& e : b->pev) HIP_TRY(ctx, hipEventCreate(&e));
   b->timing_slots = n_slots;
   b->timed_runs = 0;
+  b->timed_packs = 0;
   return MIDAS_SNPS_OK;
 }
 
@@ -552,7 +770,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.n_whole_items = (int32_t)b->n_whole_items;
   pp.n_reads = (int32_t)b->n_records;
   pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
-  if (const char* e = getenv("MIDAS_SNPS_GRID")) pp.grid_blocks = atoi(e) > 0 ? atoi(e) : pp.grid_blocks;   // experiments only
+#ifdef MIDAS_SNPS_GRID_BLOCKS   // developer variants only (tools/build_variant.sh)
+  pp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
+#endif
   pp.lanes_per_read = b->lanes_per_read;
   pp.lane_bases = b->lane_bases;
   pp.reads_per_wave = 64 / b->lanes_per_read;
@@ -562,7 +782,6 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.filt = b->d_filt;
   pp.orig = b->d_orig;
   pp.table_len = b->max_l_seq + 1;
-  pp.debug = getenv("MIDAS_SNPS_DEBUG") ? atoi(getenv("MIDAS_SNPS_DEBUG")) : 0;
   for (const auto& zr : b->zero_ranges)   // split tiles accumulate with atomics: their counts start from zero
     HIP_TRY(ctx, hipMemsetAsync(b->d_counts + 4 * zr.first, 0, zr.second * 16, s));
   HIP_TRY(ctx, launch_pileup_tiles(pp, s));
@@ -636,6 +855,19 @@ int32_t midas_snps_batch_timing(midas_snps_batch* b, int32_t slot, float out_ms[
     HIP_TRY(ctx, hipEventElapsedTime(&out_ms[0], ev[0], ev[1]));
     HIP_TRY(ctx, hipEventElapsedTime(&out_ms[2], ev[0], ev[2]));
   }
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_pack_timing(midas_snps_batch* b, int32_t slot, float out_ms[2]) {
+  if (!b || !out_ms) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  if (slot < 0 || slot >= b->timing_slots || slot >= b->timed_packs)
+    return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "no timed pack recorded in that slot");
+  hipEvent_t* ev = &b->pev[(size_t)slot * 3];
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[0], ev[0], ev[2]));
+  HIP_TRY(ctx, hipEventElapsedTime(&out_ms[1], ev[1], ev[2]));
   return MIDAS_SNPS_OK;
 }
 

@@ -1,13 +1,17 @@
-"""Multi-GPU plumbing for the pileup stage: one process per GPU, species sharded over ranks, and a single
+"""Multi-GPU plumbing for the pileup stage: one process per GPU, contigs sharded over ranks, and a single
 all-gather of the per-species summary rows (RCCL over xGMI when the backend is "nccl", gloo in CPU tests).
 
 The reference's only parallelism is `mp.Pool(threads)` with one task per species whose return value,
 (species_id, aln_stats), is pickled back through a pipe (midas/run/snps.py:225-228, midas/utility.py:81-107).
-Here a species lives on exactly one rank, per-site output never leaves its rank (the owner writes the
-<species>.snps.gz), and only [n_species, 5] int64 counters are exchanged.
+Here the unit of work is the contig -- the unit `count_coverage` is called on (midas/run/snps.py:187-199) -- so one
+species keeps every GPU busy; per-site output never leaves its rank (the owner writes its contigs' part of
+<species>.snps.gz, parts are concatenated in sorted-contig order), and only [n_species, 5] int64 counters (partial sums
+per rank) are exchanged.
 """
 
+import datetime
 import os
+import sys
 
 import numpy as np
 
@@ -19,6 +23,11 @@ def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+# Rank 0 builds the bowtie2 database and aligns (tens of minutes to hours) while the other ranks wait at a barrier: the
+# default collective timeout (10 min with nccl) would let the watchdog kill the job before the pileup starts.
+COLLECTIVE_TIMEOUT = datetime.timedelta(hours=48)
 
 
 def init_from_env(device_backend=None):
@@ -33,18 +42,44 @@ def init_from_env(device_backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=COLLECTIVE_TIMEOUT)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=COLLECTIVE_TIMEOUT)
     return world()
 
 
-def shard_species(weights, n_ranks):
-    """Longest-processing-time bin packing of species onto ranks.
+def agree_or_exit(error_message=None):
+    """Every rank calls this in front of a collective with its own error (None = fine).  If any rank failed, ALL ranks
+    leave together -- the failing ones with their message, as the reference's sys.exit("\nError: ...") would, the others
+    naming the failed ranks -- instead of one rank exiting and its peers blocking in the collective until the
+    watchdog kills them."""
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        if error_message is not None:
+            sys.exit(error_message)
+        return
+    flag = torch.tensor([1 if error_message is not None else 0], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    flags = torch.zeros(ws, dtype=torch.int64, device=flag.device)
+    dist.all_gather_into_tensor(flags, flag)
+    failed = [r for r, f in enumerate(flags.cpu().tolist()) if f]
+    if not failed:
+        return
+    if error_message is not None:
+        sys.exit(error_message)
+    sys.exit("\nError: rank(s) %s failed, see their message; rank %d stops with them\n" % (failed, rank))
 
-    weights: {species_id: cost} (aligned reads + genome length is a good proxy).  Deterministic: ties are
-    broken by species id, so every rank computes the same assignment without talking.
-    Returns {species_id: rank}."""
+
+def shard_species(weights, n_ranks):
+    """Longest-processing-time bin packing of work items (contigs for the snps pileup, species for genes / merge) onto
+    ranks.
+
+    weights: {item: cost} (bytes of aligned reads + sites is a good proxy).  Deterministic: ties are
+    broken by item id, so every rank computes the same assignment without talking.
+    Returns {item: rank}."""
     load = [0.0] * n_ranks
     owner = {}
     for sp in sorted(weights, key=lambda s: (-weights[s], s)):
@@ -52,6 +87,9 @@ def shard_species(weights, n_ranks):
         owner[sp] = r
         load[r] += weights[sp]
     return owner
+
+
+shard_items = shard_species
 
 
 def all_gather_summary(rows):

@@ -1,7 +1,7 @@
 """MI355X-native `run_midas.py snps` pipeline: the host side.
 
 Mirrors /root/reference/midas/run/snps.py name for name (Species, Contig, initialize_species,
-initialize_contigs, build_genome_db, genome_align, index_bam, keep_read, species_pileup, pysam_pileup,
+initialize_contigs, build_genome_db, genome_align, index_bam, species_pileup, pysam_pileup,
 snps_summary, remove_tmp, run_pipeline) so that scripts/run_midas.py can call it exactly as the
 reference's CLI calls the original, and so that the tests read like the reference's own.
 
@@ -11,7 +11,7 @@ What is different underneath:
     let the native formatter write <species>.snps.gz.  There is NO CPU fallback: without the library
     or a gfx950 GPU the stage exits with an error.
   * index_bam does not run `samtools index`: the device builds its own per-tile read index.
-  * the pileup is one task per *rank* (torch.distributed, one process per GPU), species sharded over
+  * the pileup is one task per *rank* (torch.distributed, one process per GPU), contigs sharded over
     ranks, not one mp.Pool task per species (which is also what breaks the reference on python3:
     args['log'] is not picklable).
 """
@@ -165,17 +165,6 @@ def index_bam(args):
     print("  %s Gb maximum memory" % utility.max_mem_usage())
 
 
-def keep_read(aln_len_minus_nm, align_len, qual_sum, query_len, mapq, args):
-    """The read filter of midas/run/snps.py:141-162 on already-extracted numbers, tests in the reference's order:
-    identity, mean quality, mapping quality, aligned fraction.  Documentation and host-side spot checks only: the
-    pileup evaluates exactly this on the GPU (pileup_tiles.hip)."""
-    tests = (100 * aln_len_minus_nm / float(align_len) < args['mapid'],
-             qual_sum / float(query_len) < args['readq'],
-             mapq < args['mapq'],
-             align_len / float(query_len) < args['aln_cov'])
-    return not any(tests)
-
-
 _ERR_TEXT = {
     abi.ERR_READ_NO_SEQ: "an alignment has no SEQ (the reference raises TypeError in keep_read)",
     abi.ERR_READ_NO_NM: "an alignment has no NM tag (the reference raises KeyError: 'NM' in keep_read)",
@@ -185,24 +174,28 @@ _ERR_TEXT = {
 }
 
 
+def _error_text(e):
+    """The reference's convention for a failed stage: sys.exit("\\nError: ...") (midas/utility.py:227-232)."""
+    msg = _ERR_TEXT.get(e.status, e.message)
+    where = " [read %d of the rank's records]" % e.read_index if e.read_index >= 0 else ""
+    return "\nError: %s%s\n%s\n" % (msg, where, e.message)
+
+
 def _exit_on(e):
     if isinstance(e, abi.MidasSnpsError):
-        msg = _ERR_TEXT.get(e.status, e.message)
-        where = " [read %d of the species' records]" % e.read_index if e.read_index >= 0 else ""
-        sys.exit("\nError: %s%s\n%s\n" % (msg, where, e.message))
+        sys.exit(_error_text(e))
     raise e
 
 
-def _contig_table(species_ids, contigs, ref_names, ref_lens, refid, reads):
-    """(ContigTable, ReadsSoA) for the given species: contigs in BAM header order, reads regrouped to match."""
+def _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads):
+    """(ContigTable, ReadsSoA) for the given Contig objects: contigs in BAM header order, reads regrouped to match."""
     sp_index = {s: i for i, s in enumerate(species_ids)}
     order = {n: i for i, n in enumerate(ref_names)}
-    mine = [c for c in contigs.values() if c.species_id in sp_index]
     missing = [c.id for c in mine if c.id not in order]
     # a contig that is not in the BAM header: pysam would raise on count_coverage(contig.id, ...)
     if missing:
         sys.exit("\nError: contig '%s' is not in the BAM header (was the genome database rebuilt after alignment?)\n" % missing[0])
-    mine.sort(key=lambda c: order[c.id])
+    mine = sorted(mine, key=lambda c: order[c.id])
     for c in mine:
         if ref_lens[order[c.id]] != c.length:
             sys.exit("\nError: contig '%s' has length %d in the BAM header but %d in the FASTA\n"
@@ -216,54 +209,111 @@ def _contig_table(species_ids, contigs, ref_names, ref_lens, refid, reads):
     return table, sub
 
 
-def _write_species(args, species_id, table, counts, allele):
-    """<outdir>/snps/output/<species>.snps.gz -- header + rows in sorted(contig id) order
-    (midas/run/snps.py:179-182, 187-192, 201-210), formatted and gzipped by the native writer."""
-    out_path = '%s/snps/output/%s.snps.gz' % (args['outdir'], species_id)
-    off = table.site_offsets()
-    sp = table.species_ids.index(species_id)
-    ks = [table.ids.index(cid) for cid in sorted(table.ids)]
-    ks = [k for k in ks if table.species[k] == sp]         # a species without contigs still gets its header-only file
-    abi.write_table(out_path, [table.ids[k] for k in ks], [allele[off[k]:off[k + 1]] for k in ks],
-                    [counts[off[k]:off[k + 1]] for k in ks], gz_level=int(args.get('gz_level', 6)),
-                    threads=int(args.get('threads', 1) or 1))
+def _species_contig_order(species_ids, contigs):
+    """{species_id: its contig ids in the order the reference emits them}: sorted(contigs.keys()) filtered by species
+    (midas/run/snps.py:187-192)."""
+    out = {sp: [] for sp in species_ids}
+    for cid in sorted(contigs):
+        sp = contigs[cid].species_id
+        if sp in out:
+            out[sp].append(cid)
+    return out
 
 
-def _pileup_species_set(args, species_ids, contigs, decoded, ctx):
-    """count_coverage + keep_read + emit for a set of species on one GPU -> {species_id: aln_stats}"""
+def _part_path(args, species_id, k):
+    return '%s/snps/output/%s.snps.gz.part%06d' % (args['outdir'], species_id, k)
+
+
+def _write_rows(args, path, table, pos, cids, counts, allele, off, header):
+    ks = [pos[cid] for cid in cids]
+    abi.write_table(path, cids, [allele[off[k]:off[k + 1]] for k in ks], [counts[off[k]:off[k + 1]] for k in ks],
+                    gz_level=int(args.get('gz_level', 6)), threads=int(args.get('threads', 1) or 1), header=header)
+
+
+def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
+    """count_coverage + keep_read + emit for the contigs `mine` on one GPU.  Returns {species_id: partial aln_stats}
+    (sums over this rank's contigs).  Writes <species>.snps.gz directly when this rank owns every contig of the
+    species, else one part file per run of consecutive (sorted order) contigs it owns."""
     ref_names, ref_lens, refid, reads = decoded
-    table, sub = _contig_table(species_ids, contigs, ref_names, ref_lens, refid, reads)
+    table, sub = _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads)
     thr = abi.Thresholds.from_args(args)
-    try:
+    if mine:
         counts, allele, stats = ctx.pileup(thr, table, sub)
-    except abi.MidasSnpsError as e:
-        _exit_on(e)
+    else:       # more ranks than contigs: nothing to do here
+        counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
+        stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)
+    rank, _ = dist.world()
     genome_length = np.bincount(table.species, weights=table.length, minlength=len(species_ids)).astype(np.int64)
+    pos = {cid: k for k, cid in enumerate(table.ids)}
+    off = table.site_offsets()
     out = {}
     for i, sp in enumerate(species_ids):
-        _write_species(args, sp, table, counts, allele)
-        out[sp] = {'genome_length': int(genome_length[i]),
-                   'total_depth': int(stats[i, abi.STAT_TOTAL_DEPTH]),
-                   'covered_bases': int(stats[i, abi.STAT_COVERED_BASES]),
-                   'aligned_reads': int(stats[i, abi.STAT_ALIGNED_READS]),
-                   'mapped_reads': int(stats[i, abi.STAT_MAPPED_READS])}
+        cids = order[sp]
+        owned = [owner.get(cid, 0) == rank for cid in cids]
+        if all(owned):       # (a species without contigs still gets its header-only file, from rank 0)
+            if cids or rank == 0:
+                _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], sp), table, pos, cids, counts, allele, off, None)
+        else:
+            k = 0
+            while k < len(cids):     # maximal runs of consecutive contigs this rank owns; part k starts at sorted index k
+                if not owned[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < len(cids) and owned[e]:
+                    e += 1
+                _write_rows(args, _part_path(args, sp, k), table, pos, cids[k:e], counts, allele, off, k == 0)
+                k = e
+        if any(owned) or (not cids and rank == 0):
+            out[sp] = {'genome_length': int(genome_length[i]),
+                       'total_depth': int(stats[i, abi.STAT_TOTAL_DEPTH]),
+                       'covered_bases': int(stats[i, abi.STAT_COVERED_BASES]),
+                       'aligned_reads': int(stats[i, abi.STAT_ALIGNED_READS]),
+                       'mapped_reads': int(stats[i, abi.STAT_MAPPED_READS])}
     return out
+
+
+def _join_parts(args, species_ids, order, owner, rank):
+    """Species whose contigs were spread over ranks: concatenate the parts in sorted-contig order into
+    <species>.snps.gz.  Done by the rank that owns the species' first contig (it wrote the header)."""
+    for sp in species_ids:
+        cids = order[sp]
+        if not cids or len({owner.get(c, 0) for c in cids}) <= 1 or owner.get(cids[0], 0) != rank:
+            continue
+        starts = [k for k in range(len(cids)) if k == 0 or owner.get(cids[k], 0) != owner.get(cids[k - 1], 0)]
+        final = '%s/snps/output/%s.snps.gz' % (args['outdir'], sp)
+        with open(final + '.tmp', 'wb') as dst:
+            for k in starts:
+                with open(_part_path(args, sp, k), 'rb') as src:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+        os.replace(final + '.tmp', final)
+        for k in starts:
+            os.remove(_part_path(args, sp, k))
 
 
 def species_pileup(args, species_id, contigs):
     """midas/run/snps.py:164-216 for ONE species on GPU 0: writes <species>.snps.gz, returns (species_id, aln_stats)."""
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
+    order = _species_contig_order([species_id], contigs)
+    mine = [contigs[c] for c in order[species_id]]
     try:
         decoded = abi.read_bam(bampath)
         with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
-            stats = _pileup_species_set(args, [species_id], contigs, decoded, ctx)
+            stats = _pileup_contigs(args, [species_id], mine, order, {}, decoded, ctx)
     except abi.MidasSnpsError as e:
         _exit_on(e)
     return (species_id, stats[species_id])
 
 
-def pysam_pileup(args, species, contigs):
-    """midas/run/snps.py:219-244.  Name kept for drop-in; there is no pysam underneath."""
+def _device_context():
+    return abi.Context(int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def pysam_pileup(args, species, contigs, make_context=_device_context):
+    """midas/run/snps.py:219-244.  Name kept for drop-in; there is no pysam underneath.
+    N ranks: contigs are the work items (the unit count_coverage is called on, :187-199), dealt to the ranks by
+    longest-processing-time over bytes of aligned reads + sites; a rank piles up its contigs, writes their rows, and one
+    all-gather of [n_species, 5] partial counters follows.  make_context: tests substitute a CPU double of the device."""
     start = time()
     rank, ws = dist.world()
     if rank == 0:
@@ -271,38 +321,43 @@ def pysam_pileup(args, species, contigs):
         args['log'].write("\nCounting alleles\n")
 
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
+    error = None
+    decoded = None
     try:
         decoded = abi.read_bam(bampath)
     except abi.MidasSnpsError as e:
-        sys.exit("\nError: could not read %s\n%s\n" % (bampath, e.message))
+        error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+    dist.agree_or_exit(error)
     ref_names, ref_lens, refid, reads = decoded
 
-    # species -> rank, by aligned reads + genome length (every rank computes the same assignment)
+    # contig -> rank by bytes of aligned reads + sites (every rank computes the same assignment from the same BAM)
     all_ids = sorted(species)
-    reads_per_ref = np.bincount(refid, minlength=len(ref_names)) if refid.size else np.zeros(len(ref_names), np.int64)
+    order = _species_contig_order(all_ids, contigs)
+    read_bytes = np.bincount(refid, weights=reads.l_seq, minlength=len(ref_names)) if refid.size else np.zeros(len(ref_names))
     ref_index = {n: i for i, n in enumerate(ref_names)}
-    weight = {sp: 0.0 for sp in all_ids}
-    for c in contigs.values():
-        if c.species_id in weight:
-            weight[c.species_id] += 150.0 * float(reads_per_ref[ref_index[c.id]] if c.id in ref_index else 0) + c.length
-    owner = dist.shard_species(weight, ws)
-    mine = [sp for sp in all_ids if owner[sp] == rank]
-
+    weight = {cid: 1.6 * float(read_bytes[ref_index[cid]] if cid in ref_index else 0.0) + 17.0 * contigs[cid].length
+              for sp in all_ids for cid in order[sp]}      # ~1.63 B per aligned base, 17 B per site
+    owner = dist.shard_items(weight, ws)
+    mine = [contigs[cid] for sp in all_ids for cid in order[sp] if owner[cid] == rank]
     local = {}
-    if mine:
-        try:
-            with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
-                local = _pileup_species_set(args, mine, contigs, decoded, ctx)
-        except abi.MidasSnpsError as e:
-            _exit_on(e)
+    try:
+        with make_context() as ctx:
+            local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx)
+    except abi.MidasSnpsError as e:
+        error = _error_text(e)
+    except SystemExit as e:
+        error = str(e.code)
+    dist.agree_or_exit(error)
 
-    # one all-gather of the per-species summary rows; per-site output stays on its rank
+    # one all-gather of the per-species partial counters; per-site output stays on its rank
     rows = np.zeros((len(all_ids), 5), dtype=np.int64)
     for i, sp in enumerate(all_ids):
         if sp in local:
             st = local[sp]
             rows[i] = [st['genome_length'], st['covered_bases'], st['total_depth'], st['aligned_reads'], st['mapped_reads']]
     rows = dist.all_gather_summary(rows)
+    if ws > 1:       # the all-gather is also the "every part is on disk" point
+        _join_parts(args, all_ids, order, owner, rank)
 
     # update alignment stats for species objects -- midas/run/snps.py:230-241
     for i, species_id in enumerate(all_ids):

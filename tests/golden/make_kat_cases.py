@@ -163,6 +163,52 @@ cases.append(dict(name="e06_error_read_index", contig_len=20, args={},
                   reads=[read(0, "4M", "ACGT"), read(1, "4M", "ACGT", nm=None), read(2, "4M", "ACGT", nm=None)],
                   error=2, error_read=1))
 
+# ---- the worked example of the SAM v1 specification, section 1.1 (a PUBLISHED vector for the [EXT] semantics) -------------
+# The specification prints the alignment column by column:
+#
+#   Coor     12345678901234  5678901234567890123456789012345
+#   ref      AGCATGTTAGATAA**GATAGCTGTGCTAGTAGGCAGTCAGCGCCAT
+#   +r001/1        TTAGATAAAGGATA*CTG
+#   +r002         aaaAGATAA*GGATA
+#   +r003       gcctaAGCTAA
+#   +r004                     ATAGCT..............TCAGC
+#   -r003                            ttagctTAGGC
+#   -r001/2                                        CAGCGGCAT
+#
+# and the records  r001 pos 7 8M2I4M1D3M TTAGATAAAGGATACTG | r002 pos 9 3S6M1P1I4M AAAAGATAAGGATA | r003 pos 9 5S6M
+# GCCTAAGCTAA | r004 pos 16 6M14N5M ATAGCTTCAGC | r003 (supplementary, flag 2064) pos 29 6H5M TAGGC | r001 pos 37 9M
+# CAGCGGCAT.  The expected counts below are read off the PRINTED columns (1-based column c = site c - 1), not derived from
+# any CIGAR walk of ours: inserted and soft-clipped (lower-case) bases stand over no reference column, the deleted column
+# 19 of r001 and the skipped columns 22-35 of r004 carry no base, the pad of r002 is silent.  The example has QUAL '*' and
+# NM only on the last record; the path needs both (keep_read), so every read gets Q40 and the NM its printed alignment
+# implies (inserted + deleted + mismatched bases: 3, 1, 1, 0, 0, 1).
+SAM_REF = "AGCATGTTAGATAAGATAGCTGTGCTAGTAGGCAGTCAGCGCCAT"
+SAM_READS = [read(6, "8M2I4M1D3M", "TTAGATAAAGGATACTG", nm=3, mapq=30, flag=99),
+             read(8, "3S6M1P1I4M", "AAAAGATAAGGATA", nm=1, mapq=30, flag=0),
+             read(8, "5S6M", "GCCTAAGCTAA", nm=1, mapq=30, flag=0),
+             read(15, "6M14N5M", "ATAGCTTCAGC", nm=0, mapq=30, flag=0),
+             read(28, "6H5M", "TAGGC", nm=0, mapq=17, flag=2064),
+             read(36, "9M", "CAGCGGCAT", nm=1, mapq=30, flag=147)]
+SAM_COLUMNS = {   # read -> (first 1-based column, printed upper-case bases; '*' / '.' = no base over that column)
+    "r001/1": (7, "TTAGATAA" + "GATA*CTG"),      # the two inserted bases AG stand over the ** of the padded reference
+    "r002": (9, "AGATAA" + "GATA"),              # aaa clipped; the inserted G stands over the padded reference
+    "r003": (9, "AGCTAA"),
+    "r004": (16, "ATAGCT" + "." * 14 + "TCAGC"),
+    "r003s": (29, "TAGGC"),
+    "r001/2": (37, "CAGCGGCAT"),
+}
+sam_all = add(*[run(bases.replace("*", "-").replace(".", "-"), col - 1) for col, bases in SAM_COLUMNS.values()])
+cases.append(dict(name="s01_sam_spec_example_all_reads_kept", contig_len=45, ref=SAM_REF,
+                  args={"mapid": 0.0, "aln_cov": 0.0, "mapq": 0, "readq": 0},
+                  reads=SAM_READS, counts=sam_all, aligned_reads=6, mapped_reads=6,
+                  covered_bases=len(sam_all), total_depth=sum(sum(v) for v in sam_all.values())))
+# at the CLI defaults only r004 survives keep_read: identities 14/17 = 82.4 % (r001/1), 10/11 = 90.9 % (r002: aligned
+# length 14 - 3 clipped), 5/6 = 83.3 % (r003), 8/9 = 88.9 % (r001/2) are below mapid 94; the supplementary r003
+# (5/5 = 100 %) has MAPQ 17 < 20; r004 is 11/11 = 100 %, MAPQ 30, aligned fraction 11/11
+sam_r004 = run(SAM_COLUMNS["r004"][1].replace(".", "-"), SAM_COLUMNS["r004"][0] - 1)
+cases.append(dict(name="s02_sam_spec_example_default_thresholds", contig_len=45, ref=SAM_REF, args={},
+                  reads=SAM_READS, counts=sam_r004, aligned_reads=6, mapped_reads=1, covered_bases=11, total_depth=11))
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_cases.json")
 with open(out, "w") as f:
     json.dump({"comment": "hand-derived; written by make_kat_cases.py; do not regenerate from the oracle",

@@ -147,3 +147,106 @@ def test_two_ranks_gloo_genes_outputs_equal_the_single_process_ones(tmp_path):
         a = gzip.open(os.path.join(one, "genes", "output", sp + ".genes.gz"), "rt").read()
         b = gzip.open(os.path.join(two, "genes", "output", sp + ".genes.gz"), "rt").read()
         assert a == b and a.count("\n") == 21
+
+
+SNPS_WORKER = r'''
+import io, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from midas_amd import abi, dist
+from midas_amd.run import snps as msnps
+from oracle import c_oracle
+
+
+class OracleContext:
+    """Stands in for the device in this CPU test: midas_snps_pileup's contract, computed by the C oracle."""
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def pileup(self, thr, table, reads):
+        st, bad, counts, allele, stats = c_oracle.pileup(thr, table, reads)
+        if st != 0:
+            raise abi.MidasSnpsError(st, "oracle status %%d" %% st, bad)
+        return counts, allele, stats
+
+
+out, db = sys.argv[1], sys.argv[2]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    dist.init_from_env("gloo")
+rank, ws = dist.world()
+args = dict(outdir=out, db=db, build_db=False, align=False, call=True, species_id=None, threads=2, log=io.StringIO(),
+            mapid=94.0, readq=20, mapq=20, baseq=30, aln_cov=0.75, remove_temp=False)
+species = msnps.initialize_species(args)
+contigs = msnps.initialize_contigs(species)
+msnps.pysam_pileup(args, species, contigs, make_context=OracleContext)
+if rank == 0:
+    msnps.snps_summary(args, species)
+dist.barrier()
+'''
+
+
+def _run_snps_workers(tmp_path, script, outdir, db, n_ranks):
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if n_ranks == 1:
+        r = subprocess.run([sys.executable, str(script), outdir, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=env1, timeout=300)
+        return [(r.returncode, r.stdout, r.stderr)]
+    port = _free_port()
+    procs = []
+    for k in range(n_ranks):
+        env = dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), outdir, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    res = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        res.append((p.returncode, o, e))
+    return res
+
+
+def test_two_ranks_snps_outputs_equal_single(tmp_path):
+    """run_midas.py snps with N = 2 and 3: the contigs are dealt to the ranks, so even the ONE-species sample is split
+    (its .snps.gz is the concatenation of the ranks' gzip parts in sorted-contig order) -- every <species>.snps.gz and
+    summary.txt is byte for byte the single-process file.  (The device call is played by the C oracle here; the GPU
+    tests cover it.)"""
+    import shutil
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    for tag, kw in (("one_species", dict(n_species=1, contigs_per_species=5, contig_len=20011, n_reads=6000, seed=11, var_len=True)),
+                    ("three_species", dict(n_species=3, contigs_per_species=3, contig_len=17000, n_reads=9000, seed=12))):
+        contigs, reads = synth.make_dataset(**kw)
+        db = str(tmp_path / (tag + "_db"))
+        one = str(tmp_path / (tag + "_n1"))
+        synth.write_sample(one, db, contigs, reads)
+        (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+        assert rc == 0, e
+        for n in (2, 3):
+            many = str(tmp_path / ("%s_n%d" % (tag, n)))
+            shutil.copytree(one, many, ignore=shutil.ignore_patterns("output"))
+            os.makedirs(os.path.join(many, "snps", "output"))
+            for rc, o, e in _run_snps_workers(tmp_path, script, many, db, n):
+                assert rc == 0, e
+            assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
+            files = sorted(os.listdir(os.path.join(one, "snps", "output")))
+            assert sorted(os.listdir(os.path.join(many, "snps", "output"))) == files       # no part file left behind
+            assert len(files) == contigs.n_species
+            for f in files:
+                a = open(os.path.join(one, "snps", "output", f), "rb").read()
+                b = open(os.path.join(many, "snps", "output", f), "rb").read()
+                assert a == b, "%s differs between 1 and %d ranks" % (f, n)
+
+
+def test_a_failing_rank_takes_every_rank_down_with_its_message(tmp_path):
+    """A read the reference would raise on (no NM tag) sits on one rank's contig: both ranks exit non-zero, promptly, and
+    the failing one says why -- nobody is left blocking in the all-gather."""
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=4, contig_len=9000, n_reads=2000, seed=13)
+    reads.nm[5] = -1
+    db, out = str(tmp_path / "db"), str(tmp_path / "out")
+    synth.write_sample(out, db, contigs, reads)
+    res = _run_snps_workers(tmp_path, script, out, db, 2)
+    assert all(rc != 0 for rc, _, _ in res)
+    assert sum("NM tag" in e for _, _, e in res) == 1
+    assert sum("stops with them" in e for _, _, e in res) == 1

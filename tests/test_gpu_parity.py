@@ -301,6 +301,31 @@ def test_c2_linearity_in_the_read_set(hip_ctx, thr_default, c2):
     np.testing.assert_array_equal(sacc[:, :2], sfull[:, :2])
 
 
+# ---- the two larger single-GPU workloads: BASELINE configs[2] and one rank's share of configs[3] -------------------
+# (20 species / 80 Mb / 10.67 M reads at 20x, and 13 species / 52 Mb / 10.4 M reads at 30x; the C oracle needs ~8 s)
+
+@pytest.mark.parametrize("name", ["c3", "c4_rank"])
+def test_full_size_configs_bit_exact_and_conserved(hip_ctx, thr_default, name):
+    contigs, reads = synth.make_dataset(**synth.CONFIGS[name])
+    counts, stats = _assert_same(hip_ctx, thr_default, contigs, reads)
+    # checksum of checksums per species: the counters are the reduction of that species' rows of the per-site table
+    off = contigs.site_offsets()
+    depth = counts.sum(axis=1, dtype=np.int64)
+    sp_depth = np.zeros(contigs.n_species, np.int64)
+    sp_cov = np.zeros(contigs.n_species, np.int64)
+    sp_reads = np.zeros(contigs.n_species, np.int64)
+    for k in range(contigs.n_contigs):
+        s = int(contigs.species[k])
+        d = depth[off[k]:off[k + 1]]
+        sp_depth[s] += int(d.sum())
+        sp_cov[s] += int((d > 0).sum())
+        sp_reads[s] += int(contigs.read_begin[k + 1] - contigs.read_begin[k])
+    np.testing.assert_array_equal(stats[:, abi.STAT_TOTAL_DEPTH], sp_depth)
+    np.testing.assert_array_equal(stats[:, abi.STAT_COVERED_BASES], sp_cov)
+    np.testing.assert_array_equal(stats[:, abi.STAT_ALIGNED_READS], sp_reads)
+    assert (stats[:, abi.STAT_MAPPED_READS] > 0).all() and (stats[:, abi.STAT_MAPPED_READS] < sp_reads).all()
+
+
 def _subset(reads, sel):
     """Sub-select records of a ReadsSoA (fixed-stride payloads not assumed)."""
     def gather(data, off, per):
