@@ -93,7 +93,9 @@ constexpr int kPackBinsPerTile = 10;     // sort bins of a tile: segment records
                                          // CIGAR that stay inside the tile, then records reaching into a later tile
 constexpr unsigned kPackBadLayout = 1, kPackUnsupported = 2;   // low byte of PackFacts::status
 
-struct PackFacts {                       // reductions of one pack, device resident (zeroed by launch_pack_plan)
+constexpr int kPackFactSlots = 64;       // workgroup b adds to slot b % 64 (own cache line each): 4096 atomics on ONE word take
+                                         // ~50 us, the kernels they sit in ~100; the host adds the slots up
+struct alignas(128) PackFacts {          // reductions of one pack, device resident (zeroed by launch_pack_plan)
   unsigned long long status;             // min((read << 8) | kPack*), kNoError when every read is well-formed
   unsigned long long alg_bytes;          // sum(ceil(l/2) + l + 4*n_cigar + 16)
   unsigned long long blob_bytes;         // payload bytes of all records
@@ -113,7 +115,7 @@ struct PackParams {
   const int32_t* contig_read_begin;      // [n_contigs + 1]
   const int32_t* contig_tile_base;       // [n_contigs + 1]
   const int32_t* contig_len;             // [n_contigs]
-  int32_t n_contigs, n_tiles, tile_len;
+  int32_t n_contigs, n_tiles, tile_len, tile_shift;   // tile_len == 1 << tile_shift
   int32_t lane_bases, lanes_per_read;    // known after the plan step (longest read)
   // per read
   uint8_t* nseg;                         // [n_reads] 0 = one record that keeps its CIGAR, k = k segment records
@@ -121,12 +123,13 @@ struct PackParams {
   uint32_t* first;                       // [n_reads + 1] first record of a read (input order), [n_reads] = n_records
   // per record, input order
   uint32_t* sort_key; uint32_t* sort_val; uint32_t* bytes8; uint32_t* dest;
+  uint4* desc;                           // 32-byte record descriptor, two words of 16 (pack_reads.hip make_desc)
   // per record, sorted / device order
   uint32_t* key_sorted; uint32_t* val_sorted;
   uint32_t* bin_start;                   // [n_tiles * kPackBinsPerTile + 1]
   uint32_t* bytes8_dev; uint32_t* off8;  // [n_records + 1]
   uint32_t* tile_extra; uint32_t* tile_reads;   // [n_tiles] records reaching in / all records a tile will see
-  PackFacts* facts;
+  PackFacts* facts;                      // [kPackFactSlots]
   int32_t n_records;
   // outputs
   ReadRec* rec; uint8_t* blob; uint32_t* orig; uint32_t* key_out;

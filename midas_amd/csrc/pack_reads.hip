@@ -14,17 +14,21 @@
 //   pack_plan_kernel     1 thread / read   validate, CIGAR -> number of device records (match segments cut at tile
 //                                          boundaries, or one record that keeps its CIGAR); algorithmic bytes, longest read
 //   [scan]                                 first device record of every read (hipCUB exclusive sum)
-//   pack_keys_kernel     1 thread / read   per record: sort key (tile, class, bank phase), payload size
+//   pack_keys_kernel     1 thread / read   per record: sort key (tile, class, bank phase), payload size, index key and a
+//                                          16-byte descriptor (position, read, query offset, length, the filter's numbers)
 //   [radix sort]                           stable sort of (key, record) -- input order survives inside a key (hipCUB)
 //   pack_bounds_kernel   1 thread / record first sorted position of every key
 //   pack_dest_kernel     1 thread / record device position of every record: a tile's segment records are dealt round-robin
-//                                          over their eight bank phases (layout.h), everything else keeps the sorted order
+//                                          over their eight bank phases (layout.h), everything else keeps the sorted order;
+//                                          index keys and the input-order map land in device order
 //   [scan]                                 payload offsets in device order
-//   pack_scatter_kernel  5 lanes / read    sum(qual) by wave reduction, 4-bit SEQ -> call codes (SWAR on nibbles), N-mask
-//                                          folded into the quality bytes, records + payload + keys written in place
+//   pack_scatter_kernel  5 lanes / record  sum(qual) of the record's read by wave reduction, 4-bit SEQ -> call codes (SWAR on
+//                                          nibbles), N-mask folded into the quality bytes, record + payload written in place
+// Everything that is per READ and branchy (CIGAR grammar, clipping, tile cuts) runs one thread per read, 64 reads per
+// wave; the scatter kernel is uniform data movement, one lane per 31 bases.
 //
-// HBM roofline of the scatter kernel (the dominant one): it reads the raw read (ceil(l/2) + l + 4 n_cigar + 29 B of
-// fixed fields and offsets) and writes 48 B per 31 bases + 16 B of record + 8 B of keys.
+// HBM roofline of the scatter kernel (the dominant one): it reads the raw read (ceil(l/2) + l + 4 n_cigar + 16 B of
+// fixed fields) and writes 48 B per 31 bases + 16 B of record.
 #include <hipcub/hipcub.hpp>
 
 #include "device_common.h"
@@ -53,13 +57,28 @@ __device__ __forceinline__ int contig_of_read(const PackParams& p, int i) {
   return c > p.n_contigs - 1 ? p.n_contigs - 1 : c;
 }
 
+// A read's CIGAR: the first four ops arrive with one 16-byte load (nearly every CIGAR is that short), the rest on demand.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+struct CigarView {
+  uint32_t c0, c1, c2, c3;
+  const uint32_t* p;
+  __device__ __forceinline__ void load(const uint32_t* q) {   // (the array has 64 bytes of slack behind its last op)
+    p = q;
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(q);
+    c0 = v.x; c1 = v.y; c2 = v.z; c3 = v.w;
+  }
+  __device__ __forceinline__ uint32_t operator[](uint32_t k) const {
+    return k < 4u ? (k < 2u ? (k == 0u ? c0 : c1) : (k == 2u ? c2 : c3)) : p[k];
+  }
+};
+
 struct ReadView {
   long long pos;
   uint32_t l, nc;
   int nm;
-  const uint32_t* cg;
+  CigarView cg;
   long long clen;
-  int tile_len;
+  int tile_len, tile_shift;   // tile_len == 1 << tile_shift
 };
 
 // Number of device records of a read served as match segments (1..kMaxPieces), or 0 when it keeps its CIGAR.
@@ -85,8 +104,7 @@ __device__ int plan_read(const ReadView& r, uint32_t* align_total) {
     long long start = r.pos + seg_r, len = seg_len;
     if (start + len > r.clen) len = r.clen - start;
     if (len <= 0) { if (nsegs == 1) bad = true; return; }
-    // 0 <= start < start + len <= clen < 2^31: 32-bit divisions
-    npieces += (int)((uint32_t)(start + len - 1) / (uint32_t)r.tile_len - (uint32_t)start / (uint32_t)r.tile_len) + 1;
+    npieces += (int)(((start + len - 1) >> r.tile_shift) - (start >> r.tile_shift)) + 1;   // 0 <= start: shifts divide
   };
   for (uint32_t i = k; i < e; ++i) {
     const uint32_t op = r.cg[i] & 15u;
@@ -126,7 +144,7 @@ __device__ int plan_read(const ReadView& r, uint32_t* align_total) {
 // The pieces of a read plan_read accepted, one after the other: its match segments (adjacent match ops merged), clipped
 // to the contig and cut at the tile boundaries.
 struct PieceIter {
-  const uint32_t* cg;
+  CigarView cg;
   uint32_t k, e;
   long long q, rr;       // query / reference offset of the op at k
   long long sq, sr, sl;  // what is left of the current segment
@@ -147,7 +165,7 @@ struct PieceIter {
     for (;;) {
       if (sl > 0) {
         const long long start = pos + sr;
-        const long long room = tile_len - (int)((uint32_t)start % (uint32_t)tile_len);   // 0 <= start < clen < 2^31
+        const long long room = tile_len - (start & (long long)(tile_len - 1));   // tile_len is a power of two, start >= 0
         const long long take = sl < room ? sl : room;
         *qoff = (int)sq; *roff = sr; *len = (int)take;
         sq += take; sr += take; sl -= take;
@@ -209,13 +227,13 @@ __device__ uint32_t general_flags(const ReadView& r, long long* reflen) {
 
 // Sort key and index key of a record (pack.cpp set_keys; index_reads.hip reads the index key).
 struct RecKeys { uint32_t sort_key, tile_key; int tile, reach; };
-__device__ __forceinline__ RecKeys record_keys(long long start, long long reflen, bool simple, long long clen, int tile_len, int tile_base) {
+__device__ __forceinline__ RecKeys record_keys(long long start, long long reflen, bool simple, long long clen, int tile_shift, int tile_base) {
   long long pc = start < 0 ? 0 : start;
   pc = pc > clen - 1 ? clen - 1 : pc;
   long long pe = start + (reflen > 0 ? reflen : 1) - 1;
   pe = pe < pc ? pc : (pe > clen - 1 ? clen - 1 : pe);
-  const uint32_t t0 = (uint32_t)pc / (uint32_t)tile_len;   // 0 <= pc <= pe < clen < 2^31: 32-bit divisions
-  const long long reach = (long long)((uint32_t)pe / (uint32_t)tile_len) - (long long)t0;
+  const uint32_t t0 = (uint32_t)(pc >> tile_shift);         // 0 <= pc <= pe < clen < 2^31
+  const long long reach = (pe >> tile_shift) - (long long)t0;
   const uint32_t cls = reach > 0 ? 2u : (simple ? 0u : 1u);
   RecKeys k;
   k.tile = tile_base + (int)t0;
@@ -225,26 +243,76 @@ __device__ __forceinline__ RecKeys record_keys(long long start, long long reflen
   return k;
 }
 
-__device__ __forceinline__ bool load_read(const PackParams& p, int i, ReadView* r, int* contig) {
-  const int c = contig_of_read(p, i);
-  *contig = c;
+// The fixed fields of read i; its contig is tracked by the caller (ContigCursor).
+__device__ __forceinline__ void load_read(const PackParams& p, int i, long long clen, ReadView* r) {
   r->pos = p.pos[i];
   r->l = (uint32_t)p.l_seq[i];
   r->nm = p.nm[i];
   const long long co = p.cigar_off[i];
   r->nc = (uint32_t)(p.cigar_off[i + 1] - co);
-  r->cg = p.cigar + co;
-  r->clen = p.contig_len[c];
+  r->cg.load(p.cigar + co);
+  r->clen = clen;
   r->tile_len = p.tile_len;
-  return true;
+  r->tile_shift = p.tile_shift;
+}
+
+// Contig of the reads a thread walks in increasing order: one binary search at the start, then a forward walk (reads are
+// grouped by contig, so the walk almost never moves) -- no search on the critical path of every read.
+struct ContigCursor {
+  int c;
+  int next_begin;     // read_begin[c + 1]
+  long long clen;
+  int tile_base;
+  __device__ __forceinline__ void seek(const PackParams& p, int i) {
+    c = contig_of_read(p, i);
+    fetch(p);
+  }
+  __device__ __forceinline__ void fetch(const PackParams& p) {
+    next_begin = p.contig_read_begin[c + 1];
+    clen = p.contig_len[c];
+    tile_base = p.contig_tile_base[c];
+  }
+  __device__ __forceinline__ void advance(const PackParams& p, int i) {
+    if (i < next_begin || c + 1 >= p.n_contigs) return;
+    while (c + 1 < p.n_contigs && i >= p.contig_read_begin[c + 1]) ++c;
+    fetch(p);
+  }
+};
+
+// Sum over the block, result in thread 0 (4 waves: shuffles, then four words of LDS).
+__device__ __forceinline__ unsigned long long block_sum(unsigned long long v, unsigned long long* lds4) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__device__ __forceinline__ unsigned long long block_max(unsigned long long v, unsigned long long* lds4) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_down(v, d);
+    v = o > v ? o : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const unsigned long long a = lds4[0] > lds4[1] ? lds4[0] : lds4[1], b = lds4[2] > lds4[3] ? lds4[2] : lds4[3];
+  return a > b ? a : b;
 }
 
 // ---- 1. validate + count --------------------------------------------------------------------------------------------
+// Grid-stride over the reads: a few thousand workgroups, so that the batch-wide sums cost one atomic per workgroup
+// (one per wave -- 170 k same-address atomics on configs[2] -- took 5.9 ms; the kernel itself takes ~0.1).
 __global__ __launch_bounds__(kPlanBlock) void pack_plan_kernel(PackParams p) {
-  const int i = blockIdx.x * kPlanBlock + threadIdx.x;
+  __shared__ unsigned long long red[4];
   unsigned long long alg = 0, recs = 0;
   uint32_t maxl = 0;
-  if (i < p.n_reads) {
+  const long long per = ((long long)p.n_reads + gridDim.x - 1) / gridDim.x;   // a workgroup owns a contiguous run of reads
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < (long long)p.n_reads ? lo + per : (long long)p.n_reads;
+  ContigCursor cur;
+  if (lo + threadIdx.x < hi) cur.seek(p, (int)(lo + threadIdx.x));
+  for (long long ii = lo + threadIdx.x; ii < hi; ii += kPlanBlock) {
+    const int i = (int)ii;
     const long long l = p.l_seq[i];
     const long long so = p.seq_off[i], qo = p.qual_off[i], co = p.cigar_off[i];
     const long long so1 = p.seq_off[i + 1], qo1 = p.qual_off[i + 1], co1 = p.cigar_off[i + 1];
@@ -258,68 +326,100 @@ __global__ __launch_bounds__(kPlanBlock) void pack_plan_kernel(PackParams p) {
       atomicMin(&p.facts->status, ((unsigned long long)i << 8) | kPackUnsupported);
     } else {
       ReadView r;
-      int c;
-      load_read(p, i, &r, &c);
+      cur.advance(p, i);
+      load_read(p, i, cur.clen, &r);
       uint32_t at = 0;
       ns = (uint8_t)plan_read(r, &at);
       cnt = ns ? ns : 1u;
-      alg = (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
-      maxl = (uint32_t)l;
+      alg += (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
+      maxl = (uint32_t)l > maxl ? (uint32_t)l : maxl;
     }
     p.nseg[i] = ns;
     p.cnt[i] = cnt;
-    recs = cnt;
+    recs += cnt;
   }
-  // block reductions -> three atomics per wave
-  for (int d = 32; d >= 1; d >>= 1) {
-    alg += __shfl_down(alg, d);
-    recs += __shfl_down(recs, d);
-    const uint32_t o = __shfl_down(maxl, d);
-    maxl = o > maxl ? o : maxl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.cnt[p.n_reads] = 0u;
+  alg = block_sum(alg, red);
+  recs = block_sum(recs, red);
+  const unsigned long long bmax = block_max((unsigned long long)maxl, red);
+  if (threadIdx.x == 0) {
+    PackFacts* f = p.facts + (blockIdx.x % kPackFactSlots);
+    if (alg) atomicAdd(&f->alg_bytes, alg);
+    if (recs) atomicAdd(&f->n_records, recs);
+    if (bmax) atomicMax(&f->max_l, (uint32_t)bmax);
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (alg) atomicAdd(&p.facts->alg_bytes, alg);
-    if (recs) atomicAdd(&p.facts->n_records, recs);
-    if (maxl) atomicMax(&p.facts->max_l, maxl);
-  }
-  if (i == 0) p.cnt[p.n_reads] = 0u;
 }
 
-// ---- 2. per record: sort key, payload size --------------------------------------------------------------------------
+// Record descriptor, 32 bytes per device record in input order: everything the scatter kernel needs to start loading
+// the record's bytes at once -- no per-read lookups on its critical path.
+//   d0.x  position of the record's first base on the contig        d0.y  index of its read
+//   d0.z  bases in the record | n_cigar field << 16                 d0.w  nm field | mapq << 16 | kRec* flags << 24
+//         (ReadRec words 2 and 3 as they will be stored, still without the read's mean quality / "QUAL absent")
+//   d1.x / d1.y  low words of the read's byte offsets into qual / seq4
+//   d1.z  bits 0-7 / 8-15 their bits 32-39, bits 16-26 the record's first base in the read (query offset)
+//   d1.w  index key of the record (tile << 7 | reach << 2 | class)
+struct Desc { uint4 d0, d1; };
+__device__ __forceinline__ Desc make_desc(long long pos, int read, int len, int qoff, uint32_t flags, uint32_t n16, uint32_t nm16,
+                                          uint32_t mapq, long long qual_off, long long seq_off, uint32_t tile_key) {
+  Desc d;
+  d.d0 = make_uint4((uint32_t)(int32_t)pos, (uint32_t)read, (uint32_t)len | ((n16 & 0xFFFFu) << 16),
+                    (nm16 & 0xFFFFu) | (mapq << 16) | (flags << 24));
+  d.d1 = make_uint4((uint32_t)qual_off, (uint32_t)seq_off,
+                    (uint32_t)((qual_off >> 32) & 0xFF) | ((uint32_t)((seq_off >> 32) & 0xFF) << 8) | ((uint32_t)qoff << 16), tile_key);
+  return d;
+}
+
+// ---- 2. per record: sort key, payload size, index key, descriptor ------------------------------------------------------
 __global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
-  const int i = blockIdx.x * kPlanBlock + threadIdx.x;
+  __shared__ unsigned long long red[4];
   unsigned long long bytes_sum = 0;
-  if (i < p.n_reads) {
+  const long long per = ((long long)p.n_reads + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < (long long)p.n_reads ? lo + per : (long long)p.n_reads;
+  ContigCursor cur;
+  if (lo + threadIdx.x < hi) cur.seek(p, (int)(lo + threadIdx.x));
+  for (long long ii = lo + threadIdx.x; ii < hi; ii += kPlanBlock) {
+    const int i = (int)ii;
     ReadView r;
-    int c;
-    load_read(p, i, &r, &c);
-    const int tb = p.contig_tile_base[c];
+    cur.advance(p, i);
+    load_read(p, i, cur.clen, &r);
+    const int tb = cur.tile_base;
     const uint32_t j0 = p.first[i];
     const int ns = p.nseg[i];
-    auto emit = [&](uint32_t j, const RecKeys& k, uint32_t bytes) {
+    const uint32_t mapq = p.mapq[i];
+    const long long qo = p.qual_off[i], so = p.seq_off[i];
+    auto emit = [&](uint32_t j, const RecKeys& k, uint32_t bytes, long long pos, int len, int qoff, uint32_t flags, uint32_t n16,
+                    uint32_t nm16) {
       p.sort_key[j] = k.sort_key;
       p.sort_val[j] = j;
       p.bytes8[j] = bytes >> 3;
+      const Desc d = make_desc(pos, i, len, qoff, flags, n16, nm16, mapq, qo, so, k.tile_key);
+      p.desc[2 * (size_t)j] = d.d0;
+      p.desc[2 * (size_t)j + 1] = d.d1;
       bytes_sum += bytes;
       for (int t = 1; t <= k.reach; ++t)    // reads a later tile will see as well (hot-spot planning)
         if (k.tile + t < p.n_tiles) atomicAdd(&p.tile_extra[k.tile + t], 1u);
     };
     if (ns == 0) {
       long long reflen = 0;
-      (void)general_flags(r, &reflen);
-      emit(j0, record_keys(r.pos, reflen, false, r.clen, p.tile_len, tb), blob_bytes(r.l, r.nc, (uint32_t)p.lane_bases));
+      const uint32_t flags = general_flags(r, &reflen);
+      emit(j0, record_keys(r.pos, reflen, false, r.clen, p.tile_shift, tb), blob_bytes(r.l, r.nc, (uint32_t)p.lane_bases),
+           r.pos, (int)r.l, 0, flags, r.nc, r.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)r.nm);
     } else {
+      uint32_t at = 0;
+      (void)plan_read(r, &at);   // aligned length of the whole read
       PieceIter it;
       it.init(r);
       int qoff, len;
       long long roff;
       for (int s = 0; s < ns && it.next(&qoff, &roff, &len); ++s)
-        emit(j0 + (uint32_t)s, record_keys(r.pos + roff, len, true, r.clen, p.tile_len, tb),
-             blob_bytes((uint32_t)len, 0u, (uint32_t)p.lane_bases));
+        // read-level numbers of the filter, in every segment (layout.h): l_seq, aligned length, NM, "first segment"
+        emit(j0 + (uint32_t)s, record_keys(r.pos + roff, len, true, r.clen, p.tile_shift, tb),
+             blob_bytes((uint32_t)len, 0u, (uint32_t)p.lane_bases), r.pos + roff, len, qoff, (uint32_t)kRecSimple,
+             r.l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14), (uint32_t)r.nm | ((at & 63u) << 10));
     }
   }
-  for (int d = 32; d >= 1; d >>= 1) bytes_sum += __shfl_down(bytes_sum, d);
-  if ((threadIdx.x & 63) == 0 && bytes_sum) atomicAdd(&p.facts->blob_bytes, bytes_sum);
+  bytes_sum = block_sum(bytes_sum, red);
+  if (threadIdx.x == 0 && bytes_sum) atomicAdd(&p.facts[blockIdx.x % kPackFactSlots].blob_bytes, bytes_sum);
 }
 
 // ---- 3. first sorted position of every key ---------------------------------------------------------------------------
@@ -401,83 +501,81 @@ __device__ __forceinline__ uint32_t spread_nibbles(uint32_t x) {
   return ((pp >> 4) & 0x000F000Fu) | (pp & 0x0F000F00u);
 }
 
+// One group of `lanes_per_read` lanes per device record (input order), lane c = payload chunk c: 31 (32) bases.
+// Uniform work: every per-read decision was taken by pack_keys_kernel and travels in the 32-byte descriptor, byte offsets of
+// the read included, so a wave waits for two rounds of loads (descriptor, bytes).  One batch of records per wave and as
+// many waves as there are batches: persistent waves with a software prefetch of the next descriptors measured 20 % slower
+// (fewer waves in flight), the hardware's own wave switching hides the latency better.
 __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams p) {
   const int lane = threadIdx.x & 63;
   const int lpr = p.lanes_per_read, rpw = 64 / lpr;
   const int g = lane / lpr, c = lane - g * lpr;
-  const long long wave_id = (long long)blockIdx.x * (kScatterBlock / 64) + (threadIdx.x >> 6);
-  const long long ii = wave_id * rpw + g;
-  const bool valid = g < rpw && ii < (long long)p.n_reads;
-  const int i = valid ? (int)ii : 0;
   const uint32_t lb = (uint32_t)p.lane_bases;
+  const long long m = p.n_records;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the sentinel record: where the payload ends
     uint4 s = make_uint4(0u, p.off8[p.n_records], 0u, (uint32_t)kRecSentinel << 24);
     reinterpret_cast<uint4*>(p.rec)[p.n_records] = s;
   }
-  if (p.n_reads == 0) return;
-
-  ReadView r;
-  int contig = 0;
-  load_read(p, i, &r, &contig);
-  const int tb = p.contig_tile_base[contig];
-  const uint8_t* qsrc = p.qual + p.qual_off[i];
-  const uint8_t* ssrc = p.seq4 + p.seq_off[i];
-  const int l = valid ? (int)r.l : 0;
-
-  // ---- floor(mean quality) of the whole read (clipped bases included): one pass over its bytes, reduced over the
-  // read's lanes (np.mean(aln.query_qualities), midas/run/snps.py:151) -----------------------------------------------
-  uint32_t part = 0;
-  if (32 * c < l) {
-    const u32x4_a1 a = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c);
-    const u32x4_a1 b = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c + 16);
-    const int nb = l - 32 * c;
-    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(w[k] & low_bytes_mask(nb - 4 * k), 0u, part);
-    if (c == 0) part |= ((a.x & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+  const long long batch = (long long)blockIdx.x * (kScatterBlock / 64) + (threadIdx.x >> 6);
+  if (batch * rpw >= m) return;
+  struct Head { uint4 d0, d1; uint32_t dest; };
+  Head cur;
+  {
+    const long long jj = batch * rpw + g;
+    const size_t j = (g < rpw && jj < m) ? (size_t)jj : 0;
+    cur.d0 = p.desc[2 * j];
+    cur.d1 = p.desc[2 * j + 1];
+    cur.dest = p.dest[j];
   }
-  uint32_t qsum = 0;
-  for (int cc = 0; cc < lpr; ++cc) qsum += __shfl(part, g * lpr + cc);
-  const uint32_t qflag = (qsum >> 31) ? (uint32_t)kRecQualAbsent : 0u;
-  qsum &= 0x7FFFFFFFu;
-  const uint32_t qmean = l > 0 ? qsum / (uint32_t)l : 0u;
-
-  const int ns = valid ? (int)p.nseg[i] : 0;
-  const int np = valid ? (ns ? ns : 1) : 0;
-  const uint32_t j0 = p.first[i];
-  uint32_t at = 0;
-  PieceIter it;
-  if (ns) {
-    (void)plan_read(r, &at);   // aligned length of the whole read
-    it.init(r);
-  }
-  for (int s = 0; __any(s < np); ++s) {
-    if (s >= np) continue;
-    int pq = 0, plen = l;
-    long long pr = 0;
-    uint32_t flags = 0;
-    long long reflen = 0;
-    if (ns) {
-      it.next(&pq, &pr, &plen);
-      flags = kRecSimple;
-      reflen = plen;
-    } else {
-      flags = general_flags(r, &reflen);
-    }
-    const uint32_t d = p.dest[j0 + (uint32_t)s];
+  {
+    const bool valid = g < rpw && batch * rpw + g < m;
+    const uint32_t d = cur.dest;
     const uint32_t o8 = p.off8[d];
+    const uint32_t flags = (cur.d0.w >> 24) & 0xFu;
+    const bool simple = (flags & kRecSimple) != 0u;
+    const int plen = valid ? (int)(cur.d0.z & 0xFFFFu) : 0;
+    const int pq = (int)((cur.d1.z >> 16) & 0x7FFu);
+    const int l = valid ? (simple ? (int)((cur.d0.z >> 16) & 0x3FFu) : plen) : 0;   // a segment carries its read's l_seq
+    const uint8_t* qsrc = p.qual + ((size_t)cur.d1.x | ((size_t)(cur.d1.z & 0xFFu) << 32));
+    const uint8_t* ssrc = p.seq4 + ((size_t)cur.d1.y | ((size_t)((cur.d1.z >> 8) & 0xFFu) << 32));
+    const bool whole = pq == 0 && plen == l;   // the record is its whole read: the payload's quality bytes are the read's
+
+    // ---- this lane's 32 payload slots: bases [y0, y0 + nvalid) of the read ---------------------------------------------
     uint8_t* const b = p.blob + (size_t)o8 * 8;
     const uint32_t chunks = blob_chunks((uint32_t)plen, lb);
-    if ((uint32_t)c < chunks) {
-      // ---- this lane's 32 payload slots: bases [y0, y0 + nvalid) of the read -----------------------------------
-      const int x0 = c * (int)lb;
-      const int nvalid = plen - x0 < (int)lb ? plen - x0 : (int)lb;
-      const int y0 = pq + x0;
-      const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qsrc + y0);
-      const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qsrc + y0 + 16);
+    const bool has = (uint32_t)c < chunks;
+    const int x0 = c * (int)lb;
+    const int nvalid = plen - x0 < (int)lb ? plen - x0 : (int)lb;
+    const int y0 = pq + x0;
+    u32x4_a1 qa, qb, sa;
+    uint32_t s4 = 0;
+    if (has) {
+      qa = *reinterpret_cast<const u32x4_a1*>(qsrc + y0);
+      qb = *reinterpret_cast<const u32x4_a1*>(qsrc + y0 + 16);
       const uint8_t* sp = ssrc + (y0 >> 1);
-      const u32x4_a1 sa = *reinterpret_cast<const u32x4_a1*>(sp);
-      const uint32_t s4 = *reinterpret_cast<const u32_a1*>(sp + 16);
+      sa = *reinterpret_cast<const u32x4_a1*>(sp);
+      s4 = *reinterpret_cast<const u32_a1*>(sp + 16);
+    }
+    // ---- floor(mean quality) of the whole read (clipped bases included; np.mean(aln.query_qualities),
+    // midas/run/snps.py:151): from the payload's own bytes when the record is the whole read, else one more pass over
+    // the read's bytes; reduced over the group's lanes -----------------------------------------------------------------
+    uint32_t part = 0;
+    if (!whole && 32 * c < l) {
+      const u32x4_a1 a = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c);
+      const u32x4_a1 bb = *reinterpret_cast<const u32x4_a1*>(qsrc + 32 * c + 16);
+      const int nb = l - 32 * c;
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(w[k] & low_bytes_mask(nb - 4 * k), 0u, part);
+      if (c == 0) part |= ((a.x & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+    }
+    if (has) {
+      uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+      if (whole) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(qw[k] & low_bytes_mask(nvalid - 4 * k), 0u, part);
+        if (c == 0) part |= ((qa.x & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;
+      }
       uint32_t cw[4] = {sa.x, sa.y, sa.z, sa.w};
       if (y0 & 1) {   // the first base is a low nibble: shift the nibble stream by one
         const uint32_t nx[4] = {sa.y, sa.z, sa.w, s4};
@@ -495,7 +593,6 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
       out[1] = spread_nibbles<1>(cw[0]) | (spread_nibbles<1>(cw[2]) << 4);
       out[2] = spread_nibbles<0>(cw[1]) | (spread_nibbles<0>(cw[3]) << 4);
       out[3] = spread_nibbles<1>(cw[1]) | (spread_nibbles<1>(cw[3]) << 4);
-      uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         // slots past the end of the record (and the padding slot of a 31-base lane) are kCallOther with quality 0
@@ -513,29 +610,27 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
       *reinterpret_cast<u32x4_a8*>(b + c * kChunk + 16) = v1;
       *reinterpret_cast<u32x4_a8*>(b + chunks * 32u + c * (kChunk / 2)) = v2;
     }
-    if (!ns) {   // the record keeps its CIGAR behind the payload (zero padding to 8 bytes)
+    if (valid && !simple) {   // the record keeps its CIGAR behind the payload (zero padding to 8 bytes)
+      const uint32_t nc = cur.d0.z >> 16;
+      const uint32_t* cg = p.cigar + p.cigar_off[cur.d0.y];
       uint32_t* cd = reinterpret_cast<uint32_t*>(b + blob_cigar_off((uint32_t)l, lb));
-      for (uint32_t k = (uint32_t)c; k < r.nc; k += (uint32_t)lpr) cd[k] = r.cg[k];
-      if (c == 0 && (r.nc & 1u)) cd[r.nc] = 0u;
+      for (uint32_t k = (uint32_t)c; k < nc; k += (uint32_t)lpr) cd[k] = cg[k];
+      if (c == 0 && (nc & 1u)) cd[nc] = 0u;
     }
-    if (c == 0) {
-      const RecKeys keys = record_keys(r.pos + pr, reflen, ns != 0, r.clen, p.tile_len, tb);
-      uint32_t n16, nm16;
-      if (ns) {   // read-level numbers of the filter, in every segment (layout.h)
-        n16 = (uint32_t)l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14);
-        nm16 = (uint32_t)r.nm | ((at & 63u) << 10);
-      } else {
-        n16 = r.nc;
-        nm16 = r.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)r.nm;
-      }
+    uint32_t qsum = 0;
+    for (int cc = 0; cc < lpr; ++cc) qsum += __shfl(part, g * lpr + cc);
+    if (valid && c == 0) {
+      const uint32_t qflag = (qsum >> 31) ? (uint32_t)kRecQualAbsent : 0u;
+      qsum &= 0x7FFFFFFFu;
+      const uint32_t qmean = l > 0 ? qsum / (uint32_t)l : 0u;
       uint4 rec;
-      rec.x = (uint32_t)(int32_t)(r.pos + pr);
+      rec.x = cur.d0.x;
       rec.y = o8;
-      rec.z = ((uint32_t)plen | ((qmean & 31u) << kRecLBits)) | (n16 << 16);
-      rec.w = (nm16 & 0xFFFFu) | ((uint32_t)p.mapq[i] << 16) | ((flags | qflag | ((qmean >> 5) << 4)) << 24);
+      rec.z = cur.d0.z | ((qmean & 31u) << kRecLBits);
+      rec.w = cur.d0.w | ((qflag | ((qmean >> 5) << 4)) << 24);
       reinterpret_cast<uint4*>(p.rec)[d] = rec;
-      p.orig[d] = (uint32_t)i;
-      p.key_out[d] = keys.tile_key;
+      p.orig[d] = cur.d0.y;
+      p.key_out[d] = cur.d1.w;
     }
   }
 }
@@ -558,13 +653,18 @@ int pack_key_bits(int32_t n_tiles) {
   return bits;
 }
 
+static int plan_grid(int n_reads) {   // grid-stride: enough workgroups to fill the chip, few enough for one atomic each
+  const int need = (n_reads + kPlanBlock - 1) / kPlanBlock;
+  return need < 1 ? 1 : (need > 4096 ? 4096 : need);
+}
+
 hipError_t launch_pack_plan(const PackParams& p, void* tmp, size_t tmp_bytes, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(p.facts, 0, sizeof(PackFacts), s);
+  hipError_t e = hipMemsetAsync(p.facts, 0, sizeof(PackFacts) * kPackFactSlots, s);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(&p.facts->status, 0xFF, 8, s);
+  e = hipMemsetAsync(&p.facts->status, 0xFF, 8, s);   // (the status word of slot 0 is the batch's: errors are rare)
   if (e != hipSuccess) return e;
   if (p.n_reads > 0) {
-    hipLaunchKernelGGL(pack_plan_kernel, dim3((p.n_reads + kPlanBlock - 1) / kPlanBlock), dim3(kPlanBlock), 0, s, p);
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(plan_grid(p.n_reads)), dim3(kPlanBlock), 0, s, p);
     e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, p.cnt, p.first, p.n_reads + 1, s);
     if (e != hipSuccess) return e;
   } else {
@@ -578,7 +678,7 @@ hipError_t launch_pack_keys(const PackParams& p, hipStream_t s) {
   hipError_t e = hipMemsetAsync(p.tile_extra, 0, (size_t)(p.n_tiles > 0 ? p.n_tiles : 1) * 4, s);
   if (e != hipSuccess) return e;
   if (p.n_reads > 0)
-    hipLaunchKernelGGL(pack_keys_kernel, dim3((p.n_reads + kPlanBlock - 1) / kPlanBlock), dim3(kPlanBlock), 0, s, p);
+    hipLaunchKernelGGL(pack_keys_kernel, dim3(plan_grid(p.n_reads)), dim3(kPlanBlock), 0, s, p);
   return hipGetLastError();
 }
 
@@ -606,8 +706,8 @@ hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, i
 
 hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s) {
   const int rpw = 64 / p.lanes_per_read;
-  const long long waves = ((long long)p.n_reads + rpw - 1) / rpw;
-  long long blocks = (waves + (kScatterBlock / 64) - 1) / (kScatterBlock / 64);
+  const long long batches = ((long long)p.n_records + rpw - 1) / rpw;
+  long long blocks = (batches + (kScatterBlock / 64) - 1) / (kScatterBlock / 64);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(pack_scatter_kernel, dim3((unsigned)blocks), dim3(kScatterBlock), 0, s, p);
   return hipGetLastError();

@@ -539,7 +539,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   // ---- packer, step 1: plan (validates every read on the device; the sizes come back) ----------------------------
   const size_t nbins = (size_t)b->n_tiles * kPackBinsPerTile + 1;
   {
-    const size_t bytes = carved(n1, 1) + 2 * carved(n1 + 1, 4) + carved(1, sizeof(PackFacts)) + carved(nbins, 4) + 2 * carved(nt, 4);
+    const size_t bytes = carved(n1, 1) + 2 * carved(n1 + 1, 4) + carved(kPackFactSlots, sizeof(PackFacts)) + carved(nbins, 4) + 2 * carved(nt, 4);
     B_TRY(hipMalloc(&b->d_pack_reads, bytes));
     uint8_t* cur = b->d_pack_reads;
     PackParams& k = b->pk;
@@ -547,7 +547,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     k.nseg = carve<uint8_t>(cur, n1);
     k.cnt = carve<uint32_t>(cur, n1 + 1);
     k.first = carve<uint32_t>(cur, n1 + 1);
-    k.facts = carve<PackFacts>(cur, 1);
+    k.facts = carve<PackFacts>(cur, kPackFactSlots);
     k.bin_start = carve<uint32_t>(cur, nbins);
     k.tile_extra = carve<uint32_t>(cur, nt);
     k.tile_reads = carve<uint32_t>(cur, nt);
@@ -557,7 +557,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     k.seq_bytes = seq_bytes; k.qual_bytes = qual_bytes; k.n_cigar = n_cigar;
     k.n_reads = (int32_t)n;
     k.contig_read_begin = b->d_contig_read_begin; k.contig_tile_base = b->d_contig_tile_base; k.contig_len = b->d_contig_len;
-    k.n_contigs = contigs->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len;
+    k.n_contigs = contigs->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len; k.tile_shift = kTileShift;
   }
   b->key_bits = pack_key_bits((int32_t)b->n_tiles);
   // the first scan needs scratch before the record count is known: size it for the reads, regrow below for the records
@@ -565,8 +565,20 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes));
   B_TRY(launch_pack_plan(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, s));
   PackFacts facts;
-  B_TRY(hipMemcpyAsync(&facts, b->pk.facts, sizeof facts, hipMemcpyDeviceToHost, s));
-  B_TRY(hipStreamSynchronize(s));
+  std::vector<PackFacts> slots(kPackFactSlots);
+  auto fetch_facts = [&]() -> hipError_t {   // the workgroups' partial sums, one slot per cache line
+    hipError_t e = hipMemcpyAsync(slots.data(), b->pk.facts, sizeof(PackFacts) * kPackFactSlots, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    facts = slots[0];
+    for (int k = 1; k < kPackFactSlots; ++k) {
+      facts.alg_bytes += slots[k].alg_bytes;
+      facts.blob_bytes += slots[k].blob_bytes;
+      facts.n_records += slots[k].n_records;
+      facts.max_l = std::max(facts.max_l, slots[k].max_l);
+    }
+    return e;
+  };
+  B_TRY(fetch_facts());
   lap("pack: plan");
   if (facts.status != kNoError) B_ST(pack_status_to_error(ctx, facts.status));
   if (facts.n_records > 2000000000ull) {
@@ -583,7 +595,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   // ---- packer, step 2: keys + sizes ------------------------------------------------------------------------------
   const size_t m1 = (size_t)(m > 0 ? m : 1);
   {
-    const size_t bytes = 6 * carved(m1, 4) + 2 * carved(m1 + 1, 4);
+    const size_t bytes = 6 * carved(m1, 4) + 2 * carved(m1 + 1, 4) + carved(m1, 32);
     B_TRY(hipMalloc(&b->d_pack_recs, bytes));
     uint8_t* cur = b->d_pack_recs;
     PackParams& k = b->pk;
@@ -593,6 +605,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     k.val_sorted = carve<uint32_t>(cur, m1);
     k.bytes8 = carve<uint32_t>(cur, m1);
     k.dest = carve<uint32_t>(cur, m1);
+    k.desc = carve<uint4>(cur, 2 * m1);
     k.bytes8_dev = carve<uint32_t>(cur, m1 + 1);
     k.off8 = carve<uint32_t>(cur, m1 + 1);
     k.n_records = (int32_t)m;
@@ -609,8 +622,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }
   }
   B_TRY(launch_pack_keys(b->pk, s));
-  B_TRY(hipMemcpyAsync(&facts, b->pk.facts, sizeof facts, hipMemcpyDeviceToHost, s));
-  B_TRY(hipStreamSynchronize(s));
+  B_TRY(fetch_facts());
   lap("pack: keys");
   b->blob_bytes = (int64_t)facts.blob_bytes;
   if (facts.blob_bytes / 8 > 0xFFFFFFFFull) {
