@@ -147,6 +147,12 @@ int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream);
 /* Device facts for logs: name (<=255 chars), compute units, HBM bytes. */
 int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes);
 
+/* Page-locked host memory (hipHostMalloc).  Optional: every entry point takes ordinary memory; result buffers that come
+ * from here are filled by one DMA instead of through the context's staging ring, and a caller that keeps them for the
+ * lifetime of its context pays the pinning once.  NULL when no device / out of memory.                            */
+void* midas_snps_host_alloc(int64_t bytes);
+void midas_snps_host_free(void* ptr);
+
 /* ---- one-shot: host buffers in, host buffers out --------------------------
  * Replaces, for every contig of the table at once, the call
  *   bamfile.count_coverage(contig.id, 0, contig.length, args['baseq'], keep_read)

@@ -200,6 +200,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_last_error_read': (i64, [vp]),
         'midas_snps_set_stream': (i32, [vp, vp]),
         'midas_snps_device_info': (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i64)]),
+        'midas_snps_host_alloc': (vp, [i64]),
+        'midas_snps_host_free': (None, [vp]),
         'midas_snps_pileup': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Contigs), C.POINTER(_Reads), vp, vp, vp]),
         'midas_snps_batch_create': (i32, [vp, C.POINTER(_Contigs), C.POINTER(_Reads), C.POINTER(vp)]),
         'midas_snps_batch_destroy': (None, [vp]),
@@ -252,6 +254,7 @@ def load_library(build_if_missing: bool = True):
 EXPORTED_SYMBOLS = [
     'midas_snps_abi_version', 'midas_snps_status_string', 'midas_snps_create', 'midas_snps_destroy',
     'midas_snps_last_error', 'midas_snps_last_error_read', 'midas_snps_set_stream', 'midas_snps_device_info',
+    'midas_snps_host_alloc', 'midas_snps_host_free',
     'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
@@ -464,11 +467,41 @@ def pack_reads_tiled(reads: ReadsSoA, contigs: "ContigTable"):
     return rec, blob[:int(nbytes.value)], orig[:n], key[:n]
 
 
+class PinnedPool:
+    """Page-locked result buffers of a Context (midas_snps_host_alloc): grown on demand and REUSED across calls -- pinning
+    a quarter of a gigabyte costs more than the copy it speeds up.  An array handed out under a key is overwritten by the
+    next request for that key."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._bufs = {}
+
+    def array(self, key, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = max(1, int(np.prod(shape)) * dtype.itemsize)
+        ptr, cap = self._bufs.get(key, (None, 0))
+        if cap < nbytes:
+            if ptr:
+                self._lib.midas_snps_host_free(C.c_void_p(ptr))
+            ptr = self._lib.midas_snps_host_alloc(nbytes)
+            if not ptr:
+                self._bufs.pop(key, None)
+                return np.empty(shape, dtype)          # no pinned memory: an ordinary array (staged copy)
+            self._bufs[key] = (ptr, nbytes)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        for ptr, _ in self._bufs.values():
+            self._lib.midas_snps_host_free(C.c_void_p(ptr))
+        self._bufs = {}
+
+
 class Context:
     """One GPU.  Replaces a `mp.Pool` worker and its module globals (midas/run/snps.py:142,167-176)."""
 
     def __init__(self, device: int = 0):
         self._lib = load_library()
+        self._pool = None
         h = C.c_void_p()
         st = self._lib.midas_snps_create(int(device), C.byref(h))
         if st != 0:
@@ -478,6 +511,9 @@ class Context:
         self.device = int(device)
 
     def close(self):
+        if getattr(self, '_pool', None):
+            self._pool.close()
+            self._pool = None
         if getattr(self, '_h', None):
             self._lib.midas_snps_destroy(self._h)
             self._h = None
@@ -489,6 +525,12 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def pinned(self, key, shape, dtype):
+        """A page-locked array owned by the context (see PinnedPool): valid until the same key is asked for again."""
+        if self._pool is None:
+            self._pool = PinnedPool(self._lib)
+        return self._pool.array(key, shape, dtype)
 
     def _check(self, st: int):
         if st != 0:
@@ -506,11 +548,17 @@ class Context:
         self._check(self._lib.midas_snps_device_info(self._h, name, C.byref(ncu), C.byref(mem)))
         return {'name': name.value.decode(), 'compute_units': ncu.value, 'hbm_bytes': mem.value}
 
-    def pileup(self, thr: Thresholds, contigs: ContigTable, reads: ReadsSoA, want_allele: bool = True):
-        """One-shot midas_snps_pileup(): returns (counts[n_sites,4] u32, allele[n_sites] u8 | None, stats[n_species,4] i64)."""
+    def pileup(self, thr: Thresholds, contigs: ContigTable, reads: ReadsSoA, want_allele: bool = True, pinned_slot=None):
+        """One-shot midas_snps_pileup(): returns (counts[n_sites,4] u32, allele[n_sites] u8 | None, stats[n_species,4] i64).
+        pinned_slot: the per-site results land in the context's page-locked buffers of that name (one DMA, no staging)
+        and stay valid until the next call with the same slot."""
         n = contigs.n_sites
-        counts = np.empty((n, 4), dtype=np.uint32)
-        allele = np.empty(n, dtype=np.uint8) if want_allele else None
+        if pinned_slot is None:
+            counts = np.empty((n, 4), dtype=np.uint32)
+            allele = np.empty(n, dtype=np.uint8) if want_allele else None
+        else:
+            counts = self.pinned(('counts', pinned_slot), (n, 4), np.uint32)
+            allele = self.pinned(('allele', pinned_slot), (n,), np.uint8) if want_allele else None
         stats = np.zeros((contigs.n_species, NUM_STATS), dtype=np.int64)
         c, r = contigs._c(), reads._c()
         st = self._lib.midas_snps_pileup(self._h, C.byref(thr), C.byref(c), C.byref(r),

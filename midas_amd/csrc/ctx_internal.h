@@ -11,4 +11,10 @@ struct midas_snps_ctx {
   std::string err;
   int64_t err_read = -1;
   hipDeviceProp_t prop;
+  // pinned staging ring for device -> pageable host copies, allocated on first use and kept for the context's lifetime
+  // (pinning and unpinning a quarter of a gigabyte per batch costs more than the copy it would speed up)
+  static constexpr int kStageSlots = 2;
+  static constexpr size_t kStageBytes = (size_t)32 << 20;
+  void* stage[kStageSlots] = {nullptr, nullptr};
+  hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr};
 };

@@ -95,17 +95,20 @@ def run_pipeline(args):
             print("  %s" % species.id)
             print("    count samples: %s" % len(species.samples))
         print("\nMerging snps")
-    try:
+    error = None
+    try:        # a rank that fails takes the others down with it at the end, instead of leaving them at the barrier
         ctx = abi.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        for species in merge.species_for_rank(species_list, rank, ws):
+            print("  %s" % species.id)
+            print("    calling SNPs")
+            n, kept, ms = merge_species(species, args, ctx)
+            print("    %d sites, %d written (%.3f ms on the GPU)" % (n, kept, ms))
+            print("    finishing")
+            write_snps_readme(args, species)
+            species.write_sample_info(dtype='snps', outdir=args['outdir'])
+        ctx.close()
     except abi.MidasSnpsError as e:
-        sys.exit("\nError: %s\n" % e.message)
-    for species in merge.species_for_rank(species_list, rank, ws):
-        print("  %s" % species.id)
-        print("    calling SNPs")
-        n, kept, ms = merge_species(species, args, ctx)
-        print("    %d sites, %d written (%.3f ms on the GPU)" % (n, kept, ms))
-        print("    finishing")
-        write_snps_readme(args, species)
-        species.write_sample_info(dtype='snps', outdir=args['outdir'])
-    ctx.close()
-    dist.barrier()
+        error = "\nError: %s\n" % e.message
+    except SystemExit as e:
+        error = str(e.code)
+    dist.agree_or_exit(error)

@@ -282,11 +282,15 @@ def pangenome_coverage(args, species, genes, make_context=None):
         owner = dist.shard_species({sp.id: float(sp.pangenome_size) for sp in species.values()}, ws)
         mine = {sp for sp, r in owner.items() if r == rank}
     make_context = make_context or (lambda: abi.Context(int(os.environ.get("LOCAL_RANK", "0"))))
+    error, ms = None, 0.0
     try:
         with make_context() as ctx:
             ms = count_mapped_bp(args, species, genes, ctx, mine)
     except abi.MidasSnpsError as e:
-        sys.exit("\nError: %s\n" % e.message)
+        error = "\nError: %s\n" % e.message
+    except SystemExit as e:
+        error = str(e.code)
+    dist.agree_or_exit(error)       # every rank leaves with the failing one, in front of the summary all-gather
     normalize(args, species, genes)
     write_results(args, species, genes, mine)
     return ms

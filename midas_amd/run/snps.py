@@ -230,6 +230,16 @@ def _write_rows(args, path, table, pos, cids, counts, allele, off, header):
                     gz_level=int(args.get('gz_level', 6)), threads=int(args.get('threads', 1) or 1), header=header)
 
 
+def _write_species(args, species_id, table, counts, allele):
+    """<outdir>/snps/output/<species>.snps.gz of ONE species whose contigs are all in `table` -- header + rows in
+    sorted(contig id) order (midas/run/snps.py:179-182, 187-192, 201-210), formatted and gzipped by the native writer."""
+    sp = table.species_ids.index(species_id)
+    pos = {cid: k for k, cid in enumerate(table.ids)}
+    cids = sorted(cid for cid, k in pos.items() if table.species[k] == sp)   # (a species without contigs: header only)
+    _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], species_id), table, pos, cids, counts, allele,
+                table.site_offsets(), None)
+
+
 def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
     """count_coverage + keep_read + emit for the contigs `mine` on one GPU.  Returns {species_id: partial aln_stats}
     (sums over this rank's contigs).  Writes <species>.snps.gz directly when this rank owns every contig of the
@@ -238,7 +248,10 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
     table, sub = _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads)
     thr = abi.Thresholds.from_args(args)
     if mine:
-        counts, allele, stats = ctx.pileup(thr, table, sub)
+        try:        # the rows are formatted straight from the context's page-locked result buffers
+            counts, allele, stats = ctx.pileup(thr, table, sub, pinned_slot=0)
+        except TypeError:       # (a test double of the device without that option)
+            counts, allele, stats = ctx.pileup(thr, table, sub)
     else:       # more ranks than contigs: nothing to do here
         counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
         stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)

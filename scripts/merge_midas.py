@@ -117,23 +117,26 @@ def check_arguments(args):
     if kind == 'dir':
         if not os.path.isdir(source):
             die("Specified input directory '%s' does not exist" % source)
+        # every entry is taken, as in the reference (a stray README or tarball among the samples is dropped later,
+        # when it turns out to have no snps/summary.txt); sorted, so that the sample columns do not depend on the
+        # file system's listing order
         args['indirs'] = [os.path.join(source, d) for d in sorted(os.listdir(source))]
-    elif kind == 'file':
-        if not os.path.isfile(source):
-            die("Specified input file '%s' does not exist" % source)
-        with open(source) as handle:
-            args['indirs'] = [line.strip().rstrip('/') for line in handle if line.strip()]
     else:
-        args['indirs'] = source.split(',')
-    for d in args['indirs']:
-        if not os.path.isdir(d):
-            die("Specified input directory '%s' does not exist" % d)
+        if kind == 'file':
+            if not os.path.isfile(source):
+                die("Specified input file '%s' does not exist" % source)
+            with open(source) as handle:
+                args['indirs'] = [line.strip().rstrip('/') for line in handle if line.strip()]
+        else:
+            args['indirs'] = source.split(',')
+        for d in args['indirs']:      # only listed directories are checked (scripts/merge_midas.py:320-331)
+            if not os.path.isdir(d):
+                die("Specified input directory '%s' does not exist" % d)
     if args['site_depth'] < 0:
         die("--site_depth must be >=0")
-    if not 0.0 < args['allele_freq'] < 0.5:
-        die("--allele_freq must be > 0.0 and < 0.5")
-    if not 0 <= args['site_prev'] <= 1:
-        die("--site_prev must be between 0 and 1")
+    for name in ('allele_freq', 'fract_cov', 'site_prev'):      # scripts/merge_midas.py:291-293
+        if args.get(name) and not 0.0 <= args[name] <= 1.0:
+            die("--%s must be between 0.0 and 1.0" % name)
     if args['max_sites'] != float('Inf') and args['max_sites'] < 0:
         die("--max_sites must be >= 0")
 

@@ -130,9 +130,25 @@ def test_cli_usage_and_argument_checks(dataset, tmp_path):
     assert run_cli('genes', str(tmp_path)).returncode != 0
     r = run_cli('snps', str(tmp_path / 'o'), '-i', str(tmp_path / 'nope'), '-t', 'dir', '-d', dataset['db'])
     assert r.returncode != 0 and 'does not exist' in r.stderr
+    # the reference accepts any frequency in [0, 1] (scripts/merge_midas.py:291-293): 1.7 is an error, 0.7 is not
     r = run_cli('snps', str(tmp_path / 'o'), '-i', ','.join(dataset['samples']), '-t', 'list', '-d', dataset['db'],
-                '--allele_freq', '0.7')
+                '--allele_freq', '1.7')
     assert r.returncode != 0 and '--allele_freq' in r.stderr
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    try:
+        import merge_midas
+    finally:
+        sys.path.pop(0)
+    base = dict(outdir=str(tmp_path / 'o2'), db=dataset['db'], site_depth=1, max_sites=float('Inf'), site_prev=0.95, fract_cov=0.4)
+    merge_midas.check_arguments(dict(base, intype='list', input=','.join(dataset['samples']), allele_freq=0.7))
+    merge_midas.check_arguments(dict(base, intype='list', input=','.join(dataset['samples']), allele_freq=0.0))
+    # -t dir takes every entry of the directory, samples or not (they are dropped later for want of a summary.txt)
+    d = tmp_path / 'samples_dir'
+    d.mkdir()
+    (d / 'README.txt').write_text('not a sample\n')
+    a = dict(base, intype='dir', input=str(d), allele_freq=0.01)
+    merge_midas.check_arguments(a)
+    assert [os.path.basename(x) for x in a['indirs']] == ['README.txt']
 
 
 def test_cli_presets():
