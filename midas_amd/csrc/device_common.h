@@ -17,6 +17,7 @@ enum : uint32_t {
 
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
 __device__ __forceinline__ bool consumes_both(uint32_t op) { return op == OP_M || op == OP_EQ || op == OP_X; }
 

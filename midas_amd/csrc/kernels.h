@@ -76,6 +76,10 @@ struct PileupParams {
   uint32_t* split_ticket;            // [n_tiles] arrival counter of a split tile's parts (self-resetting), then twice
                                      // kSchedWords: {8 item counters, workgroups done}, one cache line each, of the
                                      // whole-tile and of the parts launch
+  // streaming kernel (pileup_stream.hip, developer variant): workgroup b owns tiles [wg_begin[b], wg_begin[b + 1])
+  const uint32_t* wg_begin;          // [n_stream_wgs + 1]
+  const uint8_t* tile_split;         // [n_tiles] 1 = the tile is processed as parts by the phased kernel; nullptr = none is
+  int32_t n_stream_wgs;              // one per CU
   int32_t n_items;
   int32_t n_whole_items;             // items [0, n_whole_items) are whole tiles (n_parts == 1), the rest parts of split tiles
   int32_t n_tiles;
@@ -143,6 +147,7 @@ hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, i
 hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);                                // rec, blob, orig, key
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);
-hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream);
+hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream, bool whole_tiles, bool parts);   // barrier-phased
+hipError_t launch_pileup_stream(const PileupParams& p, hipStream_t stream);   // whole tiles, barrier-free
 
 }  // namespace midas

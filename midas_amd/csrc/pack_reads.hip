@@ -58,7 +58,6 @@ __device__ __forceinline__ int contig_of_read(const PackParams& p, int i) {
 }
 
 // A read's CIGAR: the first four ops arrive with one 16-byte load (nearly every CIGAR is that short), the rest on demand.
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 struct CigarView {
   uint32_t c0, c1, c2, c3;
   const uint32_t* p;
@@ -473,7 +472,6 @@ __global__ __launch_bounds__(kPlanBlock) void pack_dest_kernel(PackParams p) {
 }
 
 // ---- 5. scatter: records + payload -----------------------------------------------------------------------------------
-typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 __device__ __forceinline__ uint32_t low_bytes_mask(int hi) {

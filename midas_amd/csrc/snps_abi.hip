@@ -62,6 +62,11 @@ struct midas_snps_batch {
   uint32_t* d_items = nullptr;  // [n_items][4] work items {tile, part, n_parts, 0} of the pileup kernel
   size_t items_cap = 0;         // words d_items can hold
   uint32_t* d_ticket = nullptr; // [n_tiles] arrival counters of split tiles
+  uint32_t* d_wg_begin = nullptr;   // [n_stream_wgs + 1] first tile of every workgroup of the streaming kernel
+  uint8_t* d_tile_split = nullptr;  // [n_tiles] 1 = processed as parts (only allocated when a tile is split)
+  std::vector<uint32_t> h_wg_begin;
+  std::vector<uint8_t> h_tile_split;
+  bool any_split = false;
   int64_t n_items = 0, n_whole_items = 0;
   std::vector<std::pair<size_t, size_t>> zero_ranges;   // (first site, sites) of split tiles: counts zeroed before a run
   FilterTables h_filt;
@@ -347,6 +352,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
+                 b->d_wg_begin, b->d_tile_split,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -403,6 +409,42 @@ int32_t plan_work_items(midas_snps_batch* b, const uint32_t* tile_reads) {
   b->n_whole_items = n_whole;
   b->n_items = (int64_t)(items.size() / 4);
   b->zero_ranges.swap(zero_ranges);
+#ifdef MIDAS_SNPS_STREAM_KERNEL
+  // Runs of whole tiles for the streaming kernel: one workgroup per CU, cuts where the cumulative cost (bytes of the
+  // reads a tile will see + bytes of its rows) crosses a multiple of the fair share.  Split tiles cost nothing there.
+  {
+    const int n_wg = ctx->prop.multiProcessorCount;
+    std::vector<uint8_t> split(nt, 0);
+    std::vector<double> cost(nt);
+    double total = 0;
+    for (size_t t = 0; t < nt; ++t) {
+      split[t] = (int64_t)tile_reads[t] > split_reads ? 1 : 0;
+      cost[t] = split[t] ? 0.0 : 245.0 * (double)tile_reads[t] + 17.0 * (double)b->tile_len + 2000.0;
+      total += cost[t];
+    }
+    std::vector<uint32_t> wg(n_wg + 1, (uint32_t)nt);
+    wg[0] = 0;
+    double acc = 0;
+    int k = 1;
+    for (size_t t = 0; t < nt && k < n_wg; ++t) {
+      acc += cost[t];
+      while (k < n_wg && acc >= total * k / n_wg) wg[k++] = (uint32_t)(t + 1);
+    }
+    if (wg != b->h_wg_begin) {
+      if (!b->d_wg_begin) HIP_TRY(ctx, hipMalloc(&b->d_wg_begin, wg.size() * 4));
+      HIP_TRY(ctx, hipMemcpyAsync(b->d_wg_begin, wg.data(), wg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      b->h_wg_begin.swap(wg);
+    }
+    b->any_split = n_split > 0;
+    if (n_split > 0 && split != b->h_tile_split) {
+      if (!b->d_tile_split) HIP_TRY(ctx, hipMalloc(&b->d_tile_split, nt));
+      HIP_TRY(ctx, hipMemcpyAsync(b->d_tile_split, split.data(), nt, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      b->h_tile_split.swap(split);
+    }
+  }
+#endif
   // with no split tile the list is the identity and the kernel never reads it
   const bool need_upload = n_split > 0 && items != b->h_items;
   if (need_upload) {
@@ -864,7 +906,16 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.table_len = b->max_l_seq + 1;
   for (const auto& zr : b->zero_ranges)   // split tiles accumulate with atomics: their counts start from zero
     HIP_TRY(ctx, hipMemsetAsync(b->d_counts + 4 * zr.first, 0, zr.second * 16, s));
-  HIP_TRY(ctx, launch_pileup_tiles(pp, s));
+  pp.wg_begin = b->d_wg_begin;
+  pp.tile_split = b->any_split ? b->d_tile_split : nullptr;
+  pp.n_stream_wgs = (int32_t)b->h_wg_begin.size() - 1;
+#ifdef MIDAS_SNPS_STREAM_KERNEL   // developer variants only: whole tiles through the barrier-free streaming kernel
+  // (pileup_stream.hip: correct, bit-exact, and 8-15 % slower than the barrier-phased kernel -- DESIGN.md section 3.3)
+  HIP_TRY(ctx, launch_pileup_stream(pp, s));
+  HIP_TRY(ctx, launch_pileup_tiles(pp, s, false, true));
+#else
+  HIP_TRY(ctx, launch_pileup_tiles(pp, s, true, true));
+#endif
   if (ev) {
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
     b->timed_runs += 1;
