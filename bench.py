@@ -95,6 +95,22 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
     return one, more[0], more[1], out
 
 
+def copy_ceiling_gbps(torch, nbytes=1 << 30, reps=10):
+    """What a plain device-to-device copy reaches on THIS box right now (bytes read + bytes written per second): the
+    practical HBM ceiling the guide quotes as ~6.3 TB/s, measured live because boxes of the pool differ by a few percent."""
+    src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").random_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def python_shaped_estimate(contigs, reads, args, max_sites=250000):
     """the pysam-shaped Python oracle (per-read callback, per-site Python emit + gzip-9
     text) on the first contig only -- an ESTIMATE of what the reference's own loop costs, never 'the reference'."""
@@ -268,6 +284,16 @@ def main():
                          "kernel_ms_avg": pile_ms, "index_kernel_ms_warmup_median": index_ms, "kernels_ms_per_step": run_ms,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
+        if world == 1:
+            try:      # the practical ceiling of this box, measured the same minute
+                ceil = copy_ceiling_gbps(torch)
+                out["roofline"]["copy_ceiling_GBps_this_box"] = ceil
+                out["roofline"]["frac_of_copy_ceiling_this_box"] = achieved / ceil
+                if traffic:
+                    out["roofline"]["hbm_traffic_GBps"] = traffic / (pile_ms * 1e-3) / 1e9
+                    out["roofline"]["hbm_traffic_frac_of_copy_ceiling_this_box"] = traffic / (pile_ms * 1e-3) / 1e9 / ceil
+            except Exception as e:
+                out["roofline"]["copy_ceiling_error"] = str(e)
         # pack + index + pileup from the resident raw arrays; the packer's dominant kernel reads the raw read
         # (SURVEY 8d's per-read figure) and writes its records + payload
         read_alg = int(info.algorithmic_bytes) - 17 * int(info.n_sites)
