@@ -268,6 +268,28 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
                        int32_t* nm, int32_t* l_seq, int64_t* seq_off, int64_t* qual_off, int64_t* cigar_off,
                        uint8_t* seq4, uint8_t* qual, uint32_t* cigar);
 
+/* Rank-local decode (N GPUs, one process each): a rank must not inflate the whole BAM to use an eighth of it.
+ *   midas_bam_open_slice   maps the file, reads the BGZF block table and the header, and walks the records that START in
+ *                          this rank's share of the file's bytes (slice of n_slices).  A slice that does not begin at
+ *                          the header's end has to GUESS its first record boundary (32 plausible records in a row);
+ *   midas_bam_slice_facts  hands back what the walk found -- out7 = {first record offset, offset behind the slice's last
+ *                          record, coordinate-sorted so far (0/1), first and last refID seen, offset of the file's first
+ *                          record, uncompressed size}; per reference: records, sum(l_seq), offset of its first record
+ *                          (-1 = none in this slice).  All offsets are into the uncompressed stream.  The caller
+ *                          exchanges these few numbers between the ranks and TRUSTS a guessed start only when the slice
+ *                          before it ended on exactly that offset (the chain starts at the header's end, which is
+ *                          exact): guesses are verified, never believed;
+ *   midas_bam_load_ranges  inflates only the blocks that hold the given record ranges [begin, end) (e.g. the contigs
+ *                          this rank owns: from a reference's first record to the next reference's) and decodes them;
+ *                          midas_bam_copy then hands the columns out as after midas_bam_load.
+ * Replaces the same `pysam.AlignmentFile` + `fetch(contig, ...)` of midas/run/snps.py:186, 194-199 (which goes through
+ * the .bai the reference builds at :130-137; no index file is needed here).                                           */
+int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256);
+int32_t midas_bam_slice_facts(const midas_bam* bam, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases,
+                              int64_t* ref_first);
+int32_t midas_bam_load_ranges(midas_bam* bam, int32_t n_ranges, const int64_t* range_begin, const int64_t* range_end,
+                              int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+
 /* Row formatter + gzip writer for <outdir>/snps/output/<species>.snps.gz.  Replaces the per-site emit
  * loop of midas/run/snps.py:201-210 and utility.iopen(...,'w') (midas/utility.py:194-206) for ONE contig:
  * rows `ref_id \t i+1 \t allele[i] \t A+C+G+T \t A \t C \t G \t T \n` for i in [0, n_sites).

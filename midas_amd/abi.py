@@ -227,6 +227,9 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_ref': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]),
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
+        'midas_bam_open_slice': (i32, [C.c_char_p, i32, i32, C.POINTER(vp), C.c_char_p]),
+        'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
+        'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
         'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_char_p]),
         'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, C.c_char_p]),
@@ -262,6 +265,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
+    'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
@@ -418,6 +422,72 @@ def read_bam(path: str):
     finally:
         lib.midas_bam_close(h)
     return names, lens, refid, ReadsSoA(**a)
+
+
+def _bam_refs(lib, h):
+    names, lens = [], []
+    for i in range(lib.midas_bam_n_refs(h)):
+        nm = C.c_char_p()
+        ln = C.c_int64()
+        lib.midas_bam_ref(h, i, C.byref(nm), C.byref(ln))
+        names.append(nm.value.decode())
+        lens.append(int(ln.value))
+    return names, lens
+
+
+def _bam_columns(lib, h, n, sb, qb, nc):
+    refid = np.empty(n, np.int32)
+    a = dict(pos=np.empty(n, np.int32), mapq=np.empty(n, np.uint8), flag=np.empty(n, np.uint16),
+             nm=np.empty(n, np.int32), l_seq=np.empty(n, np.int32), seq_off=np.empty(n + 1, np.int64),
+             qual_off=np.empty(n + 1, np.int64), cigar_off=np.empty(n + 1, np.int64),
+             seq4=np.empty(sb, np.uint8), qual=np.empty(qb, np.uint8), cigar=np.empty(nc, np.uint32))
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    st = lib.midas_bam_copy(h, p(refid), p(a['pos']), p(a['mapq']), p(a['flag']), p(a['nm']), p(a['l_seq']),
+                            p(a['seq_off']), p(a['qual_off']), p(a['cigar_off']), p(a['seq4']), p(a['qual']), p(a['cigar']))
+    if st != 0:
+        raise MidasSnpsError(st, "midas_bam_copy failed")
+    return refid, ReadsSoA(**a)
+
+
+class BamSlice:
+    """Rank-local view of a BAM (midas_bam_open_slice): this rank's share of the file walked, facts to exchange with the
+    other ranks, then only the record ranges this rank owns decoded (midas_bam_load_ranges)."""
+
+    def __init__(self, path: str, slice_index: int, n_slices: int):
+        self._lib = load_library()
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        st = self._lib.midas_bam_open_slice(path.encode(), int(slice_index), int(n_slices), C.byref(h), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        self._h = h
+        self.ref_names, self.ref_lens = _bam_refs(self._lib, h)
+        n = len(self.ref_names)
+        out7 = np.zeros(7, np.int64)
+        self.ref_reads, self.ref_bases, self.ref_first = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._lib.midas_bam_slice_facts(h, p(out7), p(self.ref_reads), p(self.ref_bases), p(self.ref_first))
+        (self.first, self.end, self.sorted, self.first_ref, self.last_ref, self.rec_begin, self.total) = (int(x) for x in out7)
+
+    def load_ranges(self, ranges):
+        """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order."""
+        rb = np.array([r[0] for r in ranges], np.int64)
+        re_ = np.array([r[1] for r in ranges], np.int64)
+        n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        err = C.create_string_buffer(256)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_bam_load_ranges(self._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(sb), C.byref(qb),
+                                             C.byref(nc), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.midas_bam_close(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):

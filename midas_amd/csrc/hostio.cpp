@@ -6,9 +6,14 @@
 // No GPU involved; exported through the same C-ABI library (include/midas_snps.h, "host I/O" section).
 #include "hostio.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -41,7 +46,26 @@ struct RawBuf {
   const T& operator[](size_t i) const { return p[i]; }
 };
 
+// A BAM file mapped read-only with its BGZF block table (rank-local decode: a rank inflates only the blocks it needs).
+struct BgzfMap {
+  const uint8_t* base = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  struct Blk { size_t cpos, clen; uint64_t upos; uint32_t ulen; size_t fpos; };
+  std::vector<Blk> blocks;
+  uint64_t total = 0;          // uncompressed bytes
+  ~BgzfMap() {
+    if (base && size) munmap(const_cast<uint8_t*>(base), size);
+    if (fd >= 0) close(fd);
+  }
+};
+
 struct midas_bam {
+  // rank-local mode (midas_bam_open_slice): the mapped file and what the walk over this rank's slice found
+  std::unique_ptr<BgzfMap> map;
+  int64_t slice_first = -1, slice_end = -1;   // uncompressed offsets: first record starting in the slice / first one behind it
+  int32_t slice_sorted = 1, slice_first_ref = -1, slice_last_ref = -1;
+  std::vector<int64_t> ref_reads, ref_bases, ref_first;
   std::string path;
   std::vector<std::string> ref_names;
   std::vector<int64_t> ref_lens;
@@ -320,6 +344,227 @@ void run_pool(int nt, size_t n_tasks, F&& fn) {
   for (auto& x : th) x.join();
 }
 
+// ---- rank-local BAM decode: block table, slice walk with verified record-boundary guessing, range loads -------------------
+int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256) {
+  m.fd = open(path.c_str(), O_RDONLY);
+  if (m.fd < 0) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  struct stat st;
+  if (fstat(m.fd, &st) != 0) { set_err(err256, "cannot stat %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  m.size = (size_t)st.st_size;
+  if (m.size == 0) { set_err(err256, "%s is empty", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
+  if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  m.base = static_cast<const uint8_t*>(a);
+  size_t p = 0;
+  uint64_t upos = 0;
+  while (p < m.size) {
+    const uint8_t* c = m.base;
+    if (p + 18 > m.size || c[p] != 0x1f || c[p + 1] != 0x8b || c[p + 2] != 8 || !(c[p + 3] & 4)) {
+      set_err(err256, "%s: not a BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const size_t xlen = rd16(&c[p + 10]);
+    size_t q = p + 12, xend = p + 12 + xlen, bsize = 0;
+    while (q + 4 <= xend && xend <= m.size) {
+      const uint16_t slen = rd16(&c[q + 2]);
+      if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&c[q + 4]) + 1;
+      q += 4 + slen;
+    }
+    if (bsize == 0 || p + bsize > m.size || bsize < xlen + 20) {
+      set_err(err256, "%s: truncated BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const uint32_t isize = rd32(&c[p + bsize - 4]);
+    m.blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize, p});
+    upos += isize;
+    p += bsize;
+  }
+  m.total = upos;
+  return MIDAS_SNPS_OK;
+}
+
+// Inflated bytes of the consecutive blocks [b_lo, b_hi) of a mapped BAM; grows at the far end on demand.
+struct BamWindow {
+  const BgzfMap* m = nullptr;
+  size_t b_lo = 0, b_hi = 0;
+  std::vector<uint8_t> buf;
+  uint64_t u_lo() const { return b_lo < m->blocks.size() ? m->blocks[b_lo].upos : m->total; }
+  uint64_t u_hi() const { return u_lo() + buf.size(); }
+  bool extend(size_t new_hi) {   // inflate blocks [b_hi, new_hi) behind what is there
+    if (new_hi > m->blocks.size()) new_hi = m->blocks.size();
+    if (new_hi <= b_hi) return true;
+    size_t add = 0;
+    for (size_t i = b_hi; i < new_hi; ++i) add += m->blocks[i].ulen;
+    const size_t old = buf.size();
+    buf.resize(old + add);
+    std::vector<size_t> at(new_hi - b_hi);
+    size_t o = old;
+    for (size_t i = b_hi; i < new_hi; ++i) { at[i - b_hi] = o; o += m->blocks[i].ulen; }
+    std::atomic<int> bad{0};
+    const size_t first = b_hi;
+    run_pool(hw_threads(0), new_hi - b_hi, [&](size_t k) {
+      const BgzfMap::Blk& b = m->blocks[first + k];
+      if (b.ulen == 0) return;
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+      zs.next_in = const_cast<Bytef*>(m->base + b.cpos);
+      zs.avail_in = (uInt)b.clen;
+      zs.next_out = buf.data() + at[k];
+      zs.avail_out = (uInt)b.ulen;
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+    });
+    b_hi = new_hi;
+    return bad == 0;
+  }
+  // make bytes [u, u + n) available (n bytes from uncompressed offset u >= u_lo()); false at end of file / bad data
+  bool need(uint64_t u, size_t n) {
+    while (u + n > u_hi()) {
+      if (b_hi >= m->blocks.size()) return false;
+      if (!extend(b_hi + 4)) return false;
+    }
+    return true;
+  }
+  const uint8_t* at(uint64_t u) const { return buf.data() + (u - u_lo()); }
+};
+
+// Could an alignment record start at uncompressed offset u?  Every fixed field must be plausible and the variable parts
+// must fit the record's own block_size.  (A guess that passes here is only ever TRUSTED after the walk of the slice before
+// it has ended on exactly this offset: midas_amd/run/snps.py checks that across ranks.)
+bool plausible_record(BamWindow& w, uint64_t u, const std::vector<int64_t>& ref_lens, uint32_t* block_size) {
+  if (!w.need(u, 36)) return false;
+  const uint8_t* r = w.at(u);
+  const uint32_t bs = rd32(r);
+  if (bs < 32 || bs > (1u << 26)) return false;
+  const int32_t refid = (int32_t)rd32(r + 4), pos = (int32_t)rd32(r + 8);
+  const uint32_t lrn = r[12], n_cig = rd16(r + 16), l = rd32(r + 20);
+  const int32_t nref = (int32_t)rd32(r + 24), npos = (int32_t)rd32(r + 28);
+  const int32_t n_ref = (int32_t)ref_lens.size();
+  if (refid < -1 || refid >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1) return false;
+  if (refid >= 0 && pos > ref_lens[refid]) return false;
+  if (lrn < 1 || l > (1u << 26)) return false;
+  if ((uint64_t)32 + lrn + 4ull * n_cig + (l + 1) / 2 + l > bs) return false;
+  if (!w.need(u, 4 + 32 + lrn + 4ull * n_cig)) return false;
+  r = w.at(u);
+  const uint8_t* name = r + 36;
+  if (name[lrn - 1] != 0) return false;
+  for (uint32_t k = 0; k + 1 < lrn; ++k)
+    if (name[k] < 33 || name[k] > 126) return false;
+  const uint8_t* cg = name + lrn;
+  for (uint32_t k = 0; k < n_cig && k < 64; ++k)
+    if ((rd32(cg + 4 * k) & 15u) > 8u) return false;
+  *block_size = bs;
+  return true;
+}
+
+// The first offset >= from where `chain` records in a row are plausible (or the file ends exactly behind fewer).
+int64_t guess_record_start(BamWindow& w, uint64_t from, const std::vector<int64_t>& ref_lens, int chain) {
+  const uint64_t total = w.m->total;
+  for (uint64_t u = from; u + 36 <= total; ++u) {
+    uint64_t v = u;
+    int ok = 0;
+    while (ok < chain) {
+      if (v == total) break;                       // the file ends on a record boundary: as good as a full chain
+      uint32_t bs = 0;
+      if (!plausible_record(w, v, ref_lens, &bs)) { ok = -1; break; }
+      v += 4ull + bs;
+      if (v > total) { ok = -1; break; }
+      ++ok;
+    }
+    if (ok >= 0) return (int64_t)u;
+  }
+  return (int64_t)total;
+}
+
+// records [offs] of the inflated bytes d -> the SoA columns of b (what fetch(contig, ...) can return: refID >= 0)
+int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>& offs, char* err256) {
+  const size_t n = offs.size();
+  b->refid.resize(n); b->pos.resize(n); b->nm.resize(n); b->l_seq.resize(n);
+  b->mapq.resize(n); b->flag.resize(n);
+  b->seq_off.assign(n + 1, 0); b->qual_off.assign(n + 1, 0); b->cigar_off.assign(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t* r = &d[offs[i] + 4];
+    const uint32_t bs = rd32(&d[offs[i]]);
+    const uint32_t l_read_name = r[8];
+    const uint32_t n_cig = rd16(r + 12);
+    const uint32_t l = rd32(r + 16);
+    if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
+      set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)i);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    b->cigar_off[i + 1] = b->cigar_off[i] + n_cig;
+    b->seq_off[i + 1] = b->seq_off[i] + (l + 1) / 2;
+    b->qual_off[i + 1] = b->qual_off[i] + l;
+  }
+  if (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n])) {
+    set_err(err256, "out of memory decoding %s", b->path.c_str());
+    return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  }
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (;;) {
+      const size_t lo = next.fetch_add(4096);
+      if (lo >= n) return;
+      const size_t hi = std::min(n, lo + 4096);
+      for (size_t i = lo; i < hi; ++i) {
+        const uint8_t* r = &d[offs[i] + 4];
+        const uint32_t bs = rd32(&d[offs[i]]);
+        b->refid[i] = (int32_t)rd32(r);
+        b->pos[i] = (int32_t)rd32(r + 4);
+        const uint32_t l_read_name = r[8];
+        b->mapq[i] = r[9];
+        const uint32_t n_cig = rd16(r + 12);
+        b->flag[i] = rd16(r + 14);
+        const uint32_t l = rd32(r + 16);
+        b->l_seq[i] = (int32_t)l;
+        const uint8_t* q = r + 32 + l_read_name;
+        memcpy(b->cigar.data() + b->cigar_off[i], q, 4ull * n_cig);
+        q += 4ull * n_cig;
+        memcpy(b->seq4.data() + b->seq_off[i], q, (l + 1) / 2);
+        q += (l + 1) / 2;
+        memcpy(b->qual.data() + b->qual_off[i], q, l);
+        q += l;
+        b->nm[i] = find_nm(q, r + bs);
+      }
+    }
+  };
+  const int nt = hw_threads(0);
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  b->loaded = true;
+  return MIDAS_SNPS_OK;
+}
+
+// BAM header (magic, text, reference table) out of inflated bytes; returns the offset of the first record, 0 = truncated
+size_t parse_bam_header(const uint8_t* d, size_t n, midas_bam* b, bool* bad_magic) {
+  *bad_magic = false;
+  if (n < 12) return 0;
+  if (memcmp(d, "BAM\1", 4) != 0) { *bad_magic = true; return 0; }
+  size_t p = 4;
+  const size_t l_text = rd32(&d[p]);
+  p += 4 + l_text;
+  if (p + 4 > n) return 0;
+  const uint32_t n_ref = rd32(&d[p]);
+  p += 4;
+  b->ref_names.clear();
+  b->ref_lens.clear();
+  for (uint32_t i = 0; i < n_ref; ++i) {
+    if (p + 4 > n) return 0;
+    const uint32_t l_name = rd32(&d[p]);
+    p += 4;
+    if (l_name == 0 || p + l_name + 4 > n) return 0;
+    b->ref_names.emplace_back(reinterpret_cast<const char*>(&d[p]), l_name - 1);
+    p += l_name;
+    b->ref_lens.push_back(rd32(&d[p]));
+    p += 4;
+  }
+  return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -387,63 +632,8 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
       if ((int32_t)rd32(&d[p + 4]) >= 0) offs.push_back(p);
       p += 4 + bs;
     }
-    const size_t n = offs.size();
-    b->refid.resize(n); b->pos.resize(n); b->nm.resize(n); b->l_seq.resize(n);
-    b->mapq.resize(n); b->flag.resize(n);
-    b->seq_off.assign(n + 1, 0); b->qual_off.assign(n + 1, 0); b->cigar_off.assign(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) {
-      const uint8_t* r = &d[offs[i] + 4];
-      const uint32_t bs = rd32(&d[offs[i]]);
-      const uint32_t l_read_name = r[8];
-      const uint32_t n_cig = rd16(r + 12);
-      const uint32_t l = rd32(r + 16);
-      if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
-        set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)i);
-        return MIDAS_SNPS_ERR_BAD_LAYOUT;
-      }
-      b->cigar_off[i + 1] = b->cigar_off[i] + n_cig;
-      b->seq_off[i + 1] = b->seq_off[i] + (l + 1) / 2;
-      b->qual_off[i + 1] = b->qual_off[i] + l;
-    }
-    if (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n])) {
-      set_err(err256, "out of memory decoding %s", b->path.c_str());
-      return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
-    }
-    // pass 2: decode in parallel
-    std::atomic<size_t> next{0};
-    auto work = [&] {
-      for (;;) {
-        const size_t lo = next.fetch_add(4096);
-        if (lo >= n) return;
-        const size_t hi = std::min(n, lo + 4096);
-        for (size_t i = lo; i < hi; ++i) {
-          const uint8_t* r = &d[offs[i] + 4];
-          const uint32_t bs = rd32(&d[offs[i]]);
-          b->refid[i] = (int32_t)rd32(r);
-          b->pos[i] = (int32_t)rd32(r + 4);
-          const uint32_t l_read_name = r[8];
-          b->mapq[i] = r[9];
-          const uint32_t n_cig = rd16(r + 12);
-          b->flag[i] = rd16(r + 14);
-          const uint32_t l = rd32(r + 16);
-          b->l_seq[i] = (int32_t)l;
-          const uint8_t* q = r + 32 + l_read_name;
-          memcpy(b->cigar.data() + b->cigar_off[i], q, 4ull * n_cig);
-          q += 4ull * n_cig;
-          memcpy(b->seq4.data() + b->seq_off[i], q, (l + 1) / 2);
-          q += (l + 1) / 2;
-          memcpy(b->qual.data() + b->qual_off[i], q, l);
-          q += l;
-          b->nm[i] = find_nm(q, r + bs);
-        }
-      }
-    };
-    const int nt = hw_threads(0);
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
-    b->loaded = true;
+    const int32_t st = decode_records(b, d.data(), offs, err256);
+    if (st != MIDAS_SNPS_OK) return st;
     b->data.release();   // the inflated stream is no longer needed
   }
   if (n_reads) *n_reads = (int64_t)b->pos.size();
@@ -475,6 +665,168 @@ int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t
   cp(cigar_off, b->cigar_off.data(), (n + 1) * 8);
   cp(seq4, b->seq4.data(), b->seq4.size()); cp(qual, b->qual.data(), b->qual.size());
   cp(cigar, b->cigar.data(), b->cigar.size() * 4);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256) {
+  if (!path || !out || n_slices < 1 || slice < 0 || slice >= n_slices) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
+  if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  b->path = path;
+  b->map.reset(new BgzfMap());
+  int32_t st = bgzf_map_file(b->path, *b->map, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  const BgzfMap& m = *b->map;
+  const size_t nb = m.blocks.size();
+  // header: the first blocks, as many as it takes
+  size_t rec_begin = 0;
+  {
+    BamWindow w;
+    w.m = &m;
+    size_t k = 1;
+    for (;;) {
+      if (!w.extend(std::min(nb, k))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      bool bad_magic = false;
+      rec_begin = parse_bam_header(w.buf.data(), w.buf.size(), b.get(), &bad_magic);
+      if (bad_magic) { set_err(err256, "%s: missing BAM magic", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      if (rec_begin) break;
+      if (k >= nb) { set_err(err256, "%s: truncated BAM header", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      k *= 2;
+    }
+  }
+  b->rec_begin = rec_begin;
+  const size_t n_ref = b->ref_lens.size();
+  b->ref_reads.assign(n_ref, 0);
+  b->ref_bases.assign(n_ref, 0);
+  b->ref_first.assign(n_ref, -1);
+  // this slice's blocks: those whose file offset falls into its share of the file's bytes
+  auto first_block_at = [&](size_t fpos) {
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].fpos < fpos) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const size_t b_lo = slice == 0 ? 0 : first_block_at((size_t)((unsigned __int128)m.size * slice / n_slices));
+  const size_t b_hi = slice + 1 == n_slices ? nb : first_block_at((size_t)((unsigned __int128)m.size * (slice + 1) / n_slices));
+  const uint64_t u_lo = std::max<uint64_t>(b_lo < nb ? m.blocks[b_lo].upos : m.total, rec_begin);
+  const uint64_t u_hi = std::max<uint64_t>(b_hi < nb ? m.blocks[b_hi].upos : m.total, rec_begin);
+  BamWindow w;
+  w.m = &m;
+  {   // start the window at the block holding u_lo
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u_lo) lo = mid + 1; else hi = mid; }
+    w.b_lo = w.b_hi = lo;
+  }
+  if (!w.extend(std::max(b_hi, w.b_lo + 1))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  // The first record that starts in the slice: known exactly when the slice begins at the header's end, else guessed
+  // (32 plausible records in a row) -- and verified by the caller against the end of the slice before.
+  uint64_t u = u_lo == rec_begin ? rec_begin : (uint64_t)guess_record_start(w, u_lo, b->ref_lens, 32);
+  b->slice_first = (int64_t)u;
+  int32_t prev_ref = -1;
+  bool seen_unmapped = false;
+  while (u < u_hi && u < m.total) {
+    uint32_t bs = 0;
+    if (!plausible_record(w, u, b->ref_lens, &bs) || !w.need(u, 4ull + bs)) {
+      set_err(err256, "%s: malformed alignment record at uncompressed byte %lld", path, (long long)u);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const uint8_t* r = w.at(u);
+    const int32_t refid = (int32_t)rd32(r + 4);
+    if (refid >= 0) {
+      if (seen_unmapped || refid < prev_ref) b->slice_sorted = 0;
+      if (b->slice_first_ref < 0) b->slice_first_ref = refid;
+      b->slice_last_ref = refid;
+      prev_ref = refid;
+      b->ref_reads[refid] += 1;
+      b->ref_bases[refid] += (int64_t)rd32(r + 20);
+      if (b->ref_first[refid] < 0) b->ref_first[refid] = (int64_t)u;
+    } else {
+      seen_unmapped = true;
+    }
+    u += 4ull + bs;
+  }
+  b->slice_end = (int64_t)u;
+  *out = b.release();
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_slice_facts(const midas_bam* b, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases, int64_t* ref_first) {
+  if (!b || !b->map || !out7) return MIDAS_SNPS_ERR_INVALID_ARG;
+  out7[0] = b->slice_first; out7[1] = b->slice_end; out7[2] = b->slice_sorted; out7[3] = b->slice_first_ref;
+  out7[4] = b->slice_last_ref; out7[5] = (int64_t)b->rec_begin; out7[6] = (int64_t)b->map->total;
+  const size_t n = b->ref_lens.size();
+  if (ref_reads) memcpy(ref_reads, b->ref_reads.data(), n * 8);
+  if (ref_bases) memcpy(ref_bases, b->ref_bases.data(), n * 8);
+  if (ref_first) memcpy(ref_first, b->ref_first.data(), n * 8);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* range_begin, const int64_t* range_end,
+                              int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  if (!b || !b->map || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const BgzfMap& m = *b->map;
+  const size_t nb = m.blocks.size();
+  auto block_of = [&](uint64_t u) {   // the block holding uncompressed offset u (u < total)
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  // the blocks the ranges touch, in file order, inflated back to back into one buffer
+  std::vector<char> needed(nb, 0);
+  for (int32_t k = 0; k < n_ranges; ++k) {
+    if (range_begin[k] < (int64_t)b->rec_begin || range_end[k] < range_begin[k] || (uint64_t)range_end[k] > m.total) {
+      set_err(err256, "%s: record range %lld outside the file", b->path.c_str(), (long long)k);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+    if (range_end[k] == range_begin[k]) continue;
+    for (size_t i = block_of((uint64_t)range_begin[k]), e = block_of((uint64_t)range_end[k] - 1); i <= e; ++i) needed[i] = 1;
+  }
+  std::vector<size_t> at(nb, 0), list;
+  size_t bytes = 0;
+  for (size_t i = 0; i < nb; ++i)
+    if (needed[i]) { at[i] = bytes; bytes += m.blocks[i].ulen; list.push_back(i); }
+  RawBuf<uint8_t> buf;
+  if (!buf.resize(bytes)) { set_err(err256, "out of memory inflating %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  std::atomic<int> bad{0};
+  run_pool(hw_threads(0), list.size(), [&](size_t k) {
+    const BgzfMap::Blk& blk = m.blocks[list[k]];
+    if (blk.ulen == 0) return;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+    zs.next_in = const_cast<Bytef*>(m.base + blk.cpos);
+    zs.avail_in = (uInt)blk.clen;
+    zs.next_out = buf.data() + at[list[k]];
+    zs.avail_out = (uInt)blk.ulen;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+  });
+  if (bad) { set_err(err256, "%s: corrupt deflate data", b->path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  // walk every range from its first record to exactly its end (a range's blocks are consecutive in the buffer)
+  std::vector<size_t> offs;
+  for (int32_t k = 0; k < n_ranges; ++k) {
+    if (range_end[k] == range_begin[k]) continue;
+    const size_t b0 = block_of((uint64_t)range_begin[k]);
+    const size_t base = at[b0] - 0;
+    const uint64_t ubase = m.blocks[b0].upos;
+    uint64_t u = (uint64_t)range_begin[k];
+    const uint64_t ue = (uint64_t)range_end[k];
+    while (u < ue) {
+      const size_t p = base + (size_t)(u - ubase);
+      if (u + 36 > ue) { set_err(err256, "%s: record range ends inside a record at byte %lld", b->path.c_str(), (long long)u); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      const uint32_t bs = rd32(&buf[p]);
+      if (bs < 32 || u + 4ull + bs > ue) { set_err(err256, "%s: record range ends inside a record at byte %lld", b->path.c_str(), (long long)u); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      if ((int32_t)rd32(&buf[p + 4]) >= 0) offs.push_back(p);
+      u += 4ull + bs;
+    }
+  }
+  const int32_t st = decode_records(b, buf.data(), offs, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  if (n_reads) *n_reads = (int64_t)b->pos.size();
+  if (seq_bytes) *seq_bytes = (int64_t)b->seq4.size();
+  if (qual_bytes) *qual_bytes = (int64_t)b->qual.size();
+  if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
   return MIDAS_SNPS_OK;
 }
 

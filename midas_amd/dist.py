@@ -110,6 +110,22 @@ def all_gather_summary(rows):
     return out.reshape((ws,) + tuple(t.shape)).sum(dim=0).cpu().numpy()
 
 
+def all_gather_i64(values):
+    """values: int64 array of the same length on every rank -> [world, len] (rank-major)."""
+    import torch
+    import torch.distributed as dist
+    v = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
+    rank, ws = world()
+    if ws == 1:
+        return v.reshape(1, -1).copy()
+    t = torch.from_numpy(v)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = torch.empty(ws * t.shape[0], dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.reshape(ws, -1).cpu().numpy()
+
+
 def all_gather_rows_f64(rows):
     """Like all_gather_summary for float64 rows (the genes summary has means and medians): rows are zero outside the
     species this rank owns, so the sum over ranks is the owner's row (nan stays nan)."""

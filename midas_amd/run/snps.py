@@ -318,6 +318,63 @@ def species_pileup(args, species_id, contigs):
     return (species_id, stats[species_id])
 
 
+def _rank_local_plan(bampath, rank, ws):
+    """Phase 1 of the rank-local decode (include/midas_snps.h, midas_bam_open_slice): walk this rank's share of the BAM,
+    all-gather {first record, end, sorted, first/last refID} and the per-reference {reads, bases, first record offset} of
+    every slice, and accept the slices only if they chain: slice 0 starts at the header's end, every slice ends where the
+    next one starts (so every GUESSED record boundary is confirmed by a walk that began at an exact one), the last ends at
+    the end of the file, and the references never go backwards.  Returns None when they do not (the caller then decodes
+    the whole file, as a single rank does), else what the assignment and the range loads need."""
+    error, sl = None, None
+    try:
+        sl = abi.BamSlice(bampath, rank, ws)
+    except abi.MidasSnpsError as e:
+        error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+    dist.agree_or_exit(error)
+    n_ref = len(sl.ref_names)
+    mine = np.concatenate([np.array([sl.first, sl.end, sl.sorted, sl.first_ref, sl.last_ref, sl.rec_begin, sl.total, n_ref], np.int64),
+                           sl.ref_reads, sl.ref_bases, sl.ref_first])
+    allv = dist.all_gather_i64(mine)
+    head = allv[:, :8]
+    ok = bool((head[:, 7] == n_ref).all() and (head[:, 2] == 1).all() and head[0, 0] == head[0, 5] and head[-1, 1] == head[0, 6])
+    last_ref = -1
+    for r in range(ws):
+        if r + 1 < ws and head[r, 1] != head[r + 1, 0]:
+            ok = False
+        if head[r, 3] >= 0:
+            if head[r, 3] < last_ref:
+                ok = False
+            last_ref = head[r, 4]
+    if not ok:
+        sl.close()
+        return None
+    reads_per = allv[:, 8:8 + n_ref].sum(axis=0)
+    bases_per = allv[:, 8 + n_ref:8 + 2 * n_ref].sum(axis=0)
+    firsts = allv[:, 8 + 2 * n_ref:8 + 3 * n_ref]
+    ref_first = np.where(firsts >= 0, firsts, np.iinfo(np.int64).max).min(axis=0)
+    ref_first[reads_per == 0] = -1
+    return dict(slice=sl, ref_names=sl.ref_names, ref_lens=sl.ref_lens, ref_reads=reads_per, ref_bases=bases_per.astype(np.float64),
+                ref_first=ref_first, total=int(head[0, 6]))
+
+
+def _record_ranges(plan, ref_ids):
+    """Uncompressed [begin, end) record ranges of the given references: from a reference's first record to the first
+    record of the next reference that has any (the file is coordinate-sorted: _rank_local_plan checked), merged."""
+    first = plan['ref_first']
+    have = np.nonzero(first >= 0)[0]
+    nxt = {}
+    for k, r in enumerate(have):
+        nxt[int(r)] = int(first[have[k + 1]]) if k + 1 < len(have) else plan['total']
+    ranges = sorted((int(first[r]), nxt[int(r)]) for r in ref_ids if first[r] >= 0)
+    merged = []
+    for b, e in ranges:
+        if merged and merged[-1][1] == b:
+            merged[-1] = (merged[-1][0], e)
+        else:
+            merged.append((b, e))
+    return merged
+
+
 def _device_context():
     return abi.Context(int(os.environ.get("LOCAL_RANK", "0")))
 
@@ -334,24 +391,41 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         args['log'].write("\nCounting alleles\n")
 
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
+    # N ranks: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and each
+    # decodes only the records of the contigs it ends up owning.  One rank (or a BAM the slices cannot vouch for:
+    # not coordinate-sorted, or a guessed record boundary that the neighbouring slice does not confirm): decode it whole.
+    plan = _rank_local_plan(bampath, rank, ws) if ws > 1 else None
     error = None
     decoded = None
-    try:
-        decoded = abi.read_bam(bampath)
-    except abi.MidasSnpsError as e:
-        error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
-    dist.agree_or_exit(error)
-    ref_names, ref_lens, refid, reads = decoded
+    if plan is None:
+        try:
+            decoded = abi.read_bam(bampath)
+        except abi.MidasSnpsError as e:
+            error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+        dist.agree_or_exit(error)
+        ref_names, ref_lens, refid, reads = decoded
+        read_bytes = np.bincount(refid, weights=reads.l_seq, minlength=len(ref_names)) if refid.size else np.zeros(len(ref_names))
+    else:
+        ref_names, ref_lens, read_bytes = plan['ref_names'], plan['ref_lens'], plan['ref_bases']
+        if rank == 0:
+            args['log'].write("rank-local BAM decode: %d slices chained, %d records\n" % (ws, int(plan['ref_reads'].sum())))
 
-    # contig -> rank by bytes of aligned reads + sites (every rank computes the same assignment from the same BAM)
+    # contig -> rank by bytes of aligned reads + sites (every rank computes the same assignment from the same numbers)
     all_ids = sorted(species)
     order = _species_contig_order(all_ids, contigs)
-    read_bytes = np.bincount(refid, weights=reads.l_seq, minlength=len(ref_names)) if refid.size else np.zeros(len(ref_names))
     ref_index = {n: i for i, n in enumerate(ref_names)}
     weight = {cid: 1.6 * float(read_bytes[ref_index[cid]] if cid in ref_index else 0.0) + 17.0 * contigs[cid].length
               for sp in all_ids for cid in order[sp]}      # ~1.63 B per aligned base, 17 B per site
     owner = dist.shard_items(weight, ws)
     mine = [contigs[cid] for sp in all_ids for cid in order[sp] if owner[cid] == rank]
+    if plan is not None:
+        try:
+            refid, reads = plan['slice'].load_ranges(_record_ranges(plan, [ref_index[c.id] for c in mine if c.id in ref_index]))
+            decoded = (ref_names, ref_lens, refid, reads)
+        except abi.MidasSnpsError as e:
+            error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+        dist.agree_or_exit(error)
+
     local = {}
     try:
         with make_context() as ctx:

@@ -180,6 +180,7 @@ contigs = msnps.initialize_contigs(species)
 msnps.pysam_pileup(args, species, contigs, make_context=OracleContext)
 if rank == 0:
     msnps.snps_summary(args, species)
+    print("LOG:" + args['log'].getvalue().replace("\n", "|"))
 dist.barrier()
 '''
 
@@ -224,8 +225,10 @@ def test_two_ranks_snps_outputs_equal_single(tmp_path):
             many = str(tmp_path / ("%s_n%d" % (tag, n)))
             shutil.copytree(one, many, ignore=shutil.ignore_patterns("output"))
             os.makedirs(os.path.join(many, "snps", "output"))
-            for rc, o, e in _run_snps_workers(tmp_path, script, many, db, n):
+            res = _run_snps_workers(tmp_path, script, many, db, n)
+            for rc, o, e in res:
                 assert rc == 0, e
+            assert any("rank-local BAM decode: %d slices chained" % n in o for _, o, _ in res)   # nobody decoded the whole file
             assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
             files = sorted(os.listdir(os.path.join(one, "snps", "output")))
             assert sorted(os.listdir(os.path.join(many, "snps", "output"))) == files       # no part file left behind
@@ -234,6 +237,35 @@ def test_two_ranks_snps_outputs_equal_single(tmp_path):
                 a = open(os.path.join(one, "snps", "output", f), "rb").read()
                 b = open(os.path.join(many, "snps", "output", f), "rb").read()
                 assert a == b, "%s differs between 1 and %d ranks" % (f, n)
+
+
+def test_two_ranks_on_a_bam_that_is_not_coordinate_sorted_fall_back_to_the_whole_decode(tmp_path):
+    """Contigs written to the BAM in reverse order of the header: the slices cannot vouch for record ranges per contig, so
+    every rank decodes the whole file (as one rank does) -- same files again."""
+    import shutil
+    from midas_amd import bam, synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=2, contig_len=15000, n_reads=6000, seed=21)
+    db, one, two = str(tmp_path / "db"), str(tmp_path / "n1"), str(tmp_path / "n2")
+    synth.write_sample(one, db, contigs, reads)
+    # rewrite the BAM with the records of the contigs in reverse contig order (within a contig still by position)
+    from tests.test_gpu_parity import _subset
+    rb = contigs.read_begin
+    order = np.concatenate([np.arange(rb[c], rb[c + 1]) for c in reversed(range(contigs.n_contigs))])
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(rb))[order]
+    bam.write_bam(os.path.join(one, "snps", "temp", "genomes.bam"), contigs.ids, [int(x) for x in contigs.length], refid,
+                  _subset(reads, order))
+    shutil.copytree(one, two)
+    (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+    assert rc == 0, e
+    res = _run_snps_workers(tmp_path, script, two, db, 2)
+    for rc, o, e in res:
+        assert rc == 0, e
+    assert not any("rank-local BAM decode" in o for _, o, _ in res)
+    for f in sorted(os.listdir(os.path.join(one, "snps", "output"))):
+        assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(two, "snps", "output", f), "rb").read()
+    assert open(os.path.join(one, "snps", "summary.txt")).read() == open(os.path.join(two, "snps", "summary.txt")).read()
 
 
 def test_a_failing_rank_takes_every_rank_down_with_its_message(tmp_path):
