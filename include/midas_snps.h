@@ -263,6 +263,10 @@ int32_t midas_bam_ref(const midas_bam* bam, int32_t i, const char** name, int64_
 /* Decode; returns the array sizes the caller must allocate for midas_bam_copy(). */
 int32_t midas_bam_load(midas_bam* bam, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                        int64_t* n_cigar, char* err256);
+/* The decoded columns where they are, without a copy: out12 = {refid, pos, mapq, flag, nm, l_seq, seq_off, qual_off,
+ * cigar_off, seq4, qual, cigar} (types as in midas_bam_copy).  They belong to `bam` and are valid until midas_bam_close:
+ * the caller keeps the handle for as long as it uses them (the Python host wraps them as numpy arrays that do).      */
+int32_t midas_bam_columns(const midas_bam* bam, const void** out12);
 /* Copy the decoded arrays out (any pointer may be NULL); *_off arrays have n_reads+1 entries. */
 int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8_t* mapq, uint16_t* flag,
                        int32_t* nm, int32_t* l_seq, int64_t* seq_off, int64_t* qual_off, int64_t* cigar_off,

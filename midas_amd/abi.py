@@ -227,6 +227,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_ref': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]),
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_copy': (i32, [vp] + [vp] * 12),
+        'midas_bam_columns': (i32, [vp, vp]),
         'midas_bam_open_slice': (i32, [C.c_char_p, i32, i32, C.POINTER(vp), C.c_char_p]),
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
@@ -264,7 +265,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
-    'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy',
+    'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part',
     'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
@@ -387,41 +388,22 @@ def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True):
 
 
 def read_bam(path: str):
-    """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA)."""
+    """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA).  The arrays are views of
+    the decoder's own buffers (no copy); the native handle lives as long as any of them does."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
     st = lib.midas_bam_open(path.encode(), C.byref(h), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
-    try:
-        names, lens = [], []
-        for i in range(lib.midas_bam_n_refs(h)):
-            nm = C.c_char_p()
-            ln = C.c_int64()
-            lib.midas_bam_ref(h, i, C.byref(nm), C.byref(ln))
-            names.append(nm.value.decode())
-            lens.append(int(ln.value))
-        n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        st = lib.midas_bam_load(h, C.byref(n), C.byref(sb), C.byref(qb), C.byref(nc), err)
-        if st != 0:
-            raise MidasSnpsError(st, err.value.decode())
-        n = int(n.value)
-        refid = np.empty(n, np.int32)
-        a = dict(pos=np.empty(n, np.int32), mapq=np.empty(n, np.uint8), flag=np.empty(n, np.uint16),
-                 nm=np.empty(n, np.int32), l_seq=np.empty(n, np.int32), seq_off=np.empty(n + 1, np.int64),
-                 qual_off=np.empty(n + 1, np.int64), cigar_off=np.empty(n + 1, np.int64),
-                 seq4=np.empty(int(sb.value), np.uint8), qual=np.empty(int(qb.value), np.uint8),
-                 cigar=np.empty(int(nc.value), np.uint32))
-        p = lambda x: x.ctypes.data_as(C.c_void_p)
-        st = lib.midas_bam_copy(h, p(refid), p(a['pos']), p(a['mapq']), p(a['flag']), p(a['nm']), p(a['l_seq']),
-                                p(a['seq_off']), p(a['qual_off']), p(a['cigar_off']), p(a['seq4']), p(a['qual']),
-                                p(a['cigar']))
-        if st != 0:
-            raise MidasSnpsError(st, "midas_bam_copy failed")
-    finally:
-        lib.midas_bam_close(h)
-    return names, lens, refid, ReadsSoA(**a)
+    owner = _BamOwner(lib, h)
+    names, lens = _bam_refs(lib, h)
+    n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    st = lib.midas_bam_load(h, C.byref(n), C.byref(sb), C.byref(qb), C.byref(nc), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    refid, reads = _bam_columns(lib, h, int(n.value), int(sb.value), int(qb.value), int(nc.value), owner)
+    return names, lens, refid, reads
 
 
 def _bam_refs(lib, h):
@@ -435,17 +417,39 @@ def _bam_refs(lib, h):
     return names, lens
 
 
-def _bam_columns(lib, h, n, sb, qb, nc):
-    refid = np.empty(n, np.int32)
-    a = dict(pos=np.empty(n, np.int32), mapq=np.empty(n, np.uint8), flag=np.empty(n, np.uint16),
-             nm=np.empty(n, np.int32), l_seq=np.empty(n, np.int32), seq_off=np.empty(n + 1, np.int64),
-             qual_off=np.empty(n + 1, np.int64), cigar_off=np.empty(n + 1, np.int64),
-             seq4=np.empty(sb, np.uint8), qual=np.empty(qb, np.uint8), cigar=np.empty(nc, np.uint32))
-    p = lambda x: x.ctypes.data_as(C.c_void_p)
-    st = lib.midas_bam_copy(h, p(refid), p(a['pos']), p(a['mapq']), p(a['flag']), p(a['nm']), p(a['l_seq']),
-                            p(a['seq_off']), p(a['qual_off']), p(a['cigar_off']), p(a['seq4']), p(a['qual']), p(a['cigar']))
+class _BamOwner:
+    """Keeps a decoded BAM alive for as long as a numpy view of one of its columns is (midas_bam_columns: no copies)."""
+
+    def __init__(self, lib, h):
+        self._lib, self._h = lib, h
+
+    def __del__(self):
+        if self._h:
+            self._lib.midas_bam_close(self._h)
+            self._h = None
+
+
+class _Column:
+    def __init__(self, owner, ptr, n, dtype):
+        self._owner = owner
+        dt = np.dtype(dtype)
+        self.__array_interface__ = {'shape': (int(n),), 'typestr': dt.str, 'data': (int(ptr) if n else 0, True), 'version': 3} \
+            if n else np.empty(0, dt).__array_interface__
+
+
+def _bam_columns(lib, h, n, sb, qb, nc, owner=None):
+    """(refid, ReadsSoA) over the decoder's own buffers.  `owner` (a _BamOwner) is kept alive by every array."""
+    ptrs = (C.c_void_p * 12)()
+    st = lib.midas_bam_columns(h, ptrs)
     if st != 0:
-        raise MidasSnpsError(st, "midas_bam_copy failed")
+        raise MidasSnpsError(st, "midas_bam_columns failed")
+    if owner is None:
+        owner = _BamOwner(lib, None)      # (the caller keeps the handle itself)
+    spec = [('refid', np.int32, n), ('pos', np.int32, n), ('mapq', np.uint8, n), ('flag', np.uint16, n), ('nm', np.int32, n),
+            ('l_seq', np.int32, n), ('seq_off', np.int64, n + 1), ('qual_off', np.int64, n + 1), ('cigar_off', np.int64, n + 1),
+            ('seq4', np.uint8, sb), ('qual', np.uint8, qb), ('cigar', np.uint32, nc)]
+    a = {name: np.asarray(_Column(owner, ptrs[k] or 0, cnt, dt)) for k, (name, dt, cnt) in enumerate(spec)}
+    refid = a.pop('refid')
     return refid, ReadsSoA(**a)
 
 
@@ -480,7 +484,9 @@ class BamSlice:
                                              C.byref(nc), err)
         if st != 0:
             raise MidasSnpsError(st, err.value.decode())
-        return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value))
+        keeper = _BamOwner(self._lib, None)
+        keeper._slice = self                # the arrays keep this object (and with it the native handle) alive
+        return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value), keeper)
 
     def close(self):
         if getattr(self, '_h', None):

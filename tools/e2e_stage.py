@@ -23,7 +23,7 @@ synth.write_sample(out, db, contigs, reads)
 print("setup (generate + write FASTA/BAM, not part of the stage): %.1f s; BAM %.0f MB" % (
     time.time() - t0, os.path.getsize(os.path.join(out, 'snps/temp/genomes.bam')) / 1e6), flush=True)
 
-args = dict(abi.DEFAULT_ARGS, outdir=out, db=db, build_db=False, threads=os.cpu_count(), gz_level=6,
+args = dict(abi.DEFAULT_ARGS, outdir=out, db=db, build_db=False, threads=os.cpu_count(),
             log=open(os.devnull, 'w'))
 T = {}
 t = time.perf_counter(); species = msnps.initialize_species(args); cs = msnps.initialize_contigs(species); T['read FASTA'] = time.perf_counter() - t
@@ -44,7 +44,7 @@ with abi.Context(0) as ctx:
     t = time.perf_counter()
     for sp in ids:
         msnps._write_rows(args, '%s/snps/output/%s.snps.gz' % (out, sp), table, pos, order[sp], counts, allele, off, None)
-    T['format + gzip rows (native, %d threads, level 6)' % args['threads']] = time.perf_counter() - t
+    T['format + gzip rows (native, %d threads, level %d)' % (args['threads'], msnps.GZ_LEVEL)] = time.perf_counter() - t
 tot = sum(T.values())
 for k, v in T.items():
     print("  %-52s %8.3f s  %5.1f %%" % (k, v, 100 * v / tot))
