@@ -326,6 +326,14 @@ int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_c
 typedef struct midas_snps_table midas_snps_table;
 int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_keys, midas_snps_table** out,
                               char* err256);
+/* The same for the table rows [row_begin, row_end) only (row_end < 0: to the end) -- what one rank of a site-sharded
+ * merge reads (the reference shards build_sharded_tables by line range, midas/merge/snps.py:366-386).  Tables written by
+ * this library say in every gzip member how many rows it holds, so only the members that hold the range are inflated;
+ * any other file is read whole and cut.  midas_snps_table_count_rows: the table's rows without inflating anything, or
+ * -1 when the file does not say (a table written by the reference or by round 1 of this library).                    */
+int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t row_end, int32_t want_keys,
+                                    midas_snps_table** out, char* err256);
+int32_t midas_snps_table_count_rows(const char* path, int64_t* out_rows, char* err256);
 void midas_snps_table_close(midas_snps_table* table);
 int64_t midas_snps_table_rows(const midas_snps_table* table);
 int64_t midas_snps_table_key_bytes(const midas_snps_table* table);
@@ -356,12 +364,13 @@ int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_params* params,
                           uint32_t* out_count_samples, uint64_t* out_pooled, uint32_t* out_depth, uint32_t* out_minor_count, float* out_kernel_ms);
 
 /* snps_freq.txt / snps_depth.txt of merge_midas.py snps (GenomicSite.write, midas/merge/snps.py:196-201): header_line,
- * then one line per kept site `site_id \t v[sample 0] \t ...` with site_id = keep[r] + 1.  depth / minor_count are
+ * then one line per kept site `site_id \t v[sample 0] \t ...` with site_id = site_id_base + keep[r] + 1 (site_id_base: the
+ * table row of the arrays' first site -- 0 unless the caller holds a row range of the table; header_line may be "").  depth / minor_count are
  * the [n_samples * n_sites] outputs of midas_merge_sites.  minor_count == NULL prints str(depth); otherwise
  * '{0:.3g}'.format(float(minor_count) / depth if depth > 0 else 0.0).  Host only, formatted by a thread pool.  */
 int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
                                  int32_t n_samples, int64_t n_sites, const uint32_t* depth,
-                                 const uint32_t* minor_count, int32_t threads, char* err256);
+                                 const uint32_t* minor_count, int32_t threads, int64_t site_id_base, char* err256);
 
 /* snps_info.txt of merge_midas.py snps: GenomicSite.annotate + fetch_ref_codon + the info line of GenomicSite.write
  * (midas/merge/snps.py:116-195) with utility.translate / index_replace (midas/utility.py:306-332) for the kept sites.
@@ -382,7 +391,7 @@ typedef struct midas_merge_genes {
 int32_t midas_merge_write_info(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
                                const char* keys, const int64_t* key_off, const uint8_t* calls,
                                const uint32_t* count_samples, const uint64_t* pooled, const midas_merge_genes* genes,
-                               int32_t threads, char* err256);
+                               int32_t threads, int64_t site_id_base, char* err256);
 
 /* ---- run_midas.py genes: reads per pangenome gene (SURVEY 8f "next" #4) -----------------------------------------
  * Replaces count_mapped_bp's pass over the BAM (midas/run/genes.py:165-180) for every gene at once: per gene the number

@@ -232,8 +232,10 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
-        'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_char_p]),
-        'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, C.c_char_p]),
+        'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, C.c_char_p]),
+        'midas_merge_write_matrix': (i32, [C.c_char_p, C.c_char_p, i64, vp, i32, i64, vp, vp, i32, i64, C.c_char_p]),
+        'midas_snps_table_open_range': (i32, [C.c_char_p, i64, i64, i32, C.POINTER(vp), C.c_char_p]),
+        'midas_snps_table_count_rows': (i32, [C.c_char_p, C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
@@ -268,7 +270,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part',
-    'midas_snps_table_open', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
+    'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
 
@@ -316,7 +318,7 @@ class _Genes(C.Structure):
 
 
 def write_merge_info(path: str, header_line: str, keep: np.ndarray, keys, key_off: np.ndarray, res: dict, genes: list,
-                     threads: int = 0):
+                     threads: int = 0, site_id_base: int = 0):
     """snps_info.txt for the kept sites (midas_merge_write_info): annotation + the per-site calls.  keys / key_off as
     returned by read_snps_table, res = Context.merge_sites(...), genes = the species' genes in the reference's order
     (dicts with scaffold_id, start, end, strand, gene_type, gene_id, seq)."""
@@ -342,12 +344,13 @@ def write_merge_info(path: str, header_line: str, keep: np.ndarray, keys, key_of
     err = C.create_string_buffer(256)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     st = lib.midas_merge_write_info(path.encode(), header_line.encode(), keep.shape[0], p(keep), p(kb), p(key_off), p(calls),
-                                    p(cs), p(pooled), C.byref(gs), int(threads), err)
+                                    p(cs), p(pooled), C.byref(gs), int(threads), int(site_id_base), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
 
 
-def write_merge_matrix(path: str, header_line: str, keep: np.ndarray, depth: np.ndarray, minor_count=None, threads: int = 0):
+def write_merge_matrix(path: str, header_line: str, keep: np.ndarray, depth: np.ndarray, minor_count=None, threads: int = 0,
+                       site_id_base: int = 0):
     """snps_depth.txt (minor_count None) / snps_freq.txt of merge_midas.py snps for the kept sites (midas_merge_write_matrix).
     depth, minor_count: [n_samples, n_sites] uint32 as returned by Context.merge_sites."""
     lib = load_library()
@@ -361,18 +364,30 @@ def write_merge_matrix(path: str, header_line: str, keep: np.ndarray, depth: np.
     err = C.create_string_buffer(256)
     st = lib.midas_merge_write_matrix(path.encode(), header_line.encode(), keep.shape[0], keep.ctypes.data_as(C.c_void_p),
                                       S, n, depth.ctypes.data_as(C.c_void_p),
-                                      mc.ctypes.data_as(C.c_void_p) if mc is not None else None, int(threads), err)
+                                      mc.ctypes.data_as(C.c_void_p) if mc is not None else None, int(threads), int(site_id_base), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
 
 
-def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True):
+def count_snps_rows(path: str) -> int:
+    """Rows of a <species>.snps.gz without inflating it, or -1 when the file does not say (midas_snps_table_count_rows)."""
+    lib = load_library()
+    n = C.c_int64(-1)
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_table_count_rows(path.encode(), C.byref(n), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    return int(n.value)
+
+
+def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True, row_begin: int = 0):
     """Parse one <species>.snps.gz with the native reader -> (counts[n,4] u32, keys | None, key_off | None);
-    keys is a byte buffer, row i's 'ref_id|ref_pos|ref_allele' is bytes(keys[key_off[i]:key_off[i + 1]])."""
+    keys is a byte buffer, row i's 'ref_id|ref_pos|ref_allele' is bytes(keys[key_off[i]:key_off[i + 1]]).
+    Rows [row_begin, max_rows) of the table (max_rows < 0: to the end)."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
-    st = lib.midas_snps_table_open(path.encode(), int(max_rows), 1 if want_keys else 0, C.byref(h), err)
+    st = lib.midas_snps_table_open_range(path.encode(), int(row_begin), int(max_rows), 1 if want_keys else 0, C.byref(h), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
     try:

@@ -106,7 +106,8 @@ struct ParsedRows {
 struct midas_snps_table {
   // the table as parsed pieces (parallel parse), plus where each piece lands in the caller's arrays
   std::vector<ParsedRows> pieces;
-  std::vector<int64_t> take;       // rows used of each piece (max_rows may cut the last one)
+  std::vector<int64_t> skip;       // rows of each piece in front of the wanted range
+  std::vector<int64_t> take;       // rows used of each piece (the range may cut the first and the last one)
   std::vector<int64_t> row_base;   // first row of each piece
   std::vector<int64_t> key_base;   // first key byte of each piece
   int64_t rows = 0, key_bytes = 0;
@@ -266,12 +267,18 @@ inline char* put_u64(char* p, uint64_t v) {
 // One gzip member around a raw deflate stream.  The header carries an extra subfield 'M','S' with the member's
 // total size in bytes (the BGZF idea): any gzip reader skips it, ours uses it to find the members of a table without
 // inflating them, so that members are inflated and parsed in parallel (midas_snps_table_open).
-constexpr size_t kGzHeader = 20;   // 10 fixed + XLEN(2) + 'M','S',len(2) + u32
-bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out) {
+constexpr size_t kGzHeaderOld = 20;   // round-1 files: 10 fixed + XLEN(2) + 'M','S',len(2) + u32
+constexpr size_t kGzHeader = 28;      // + 'M','R',len(2) + u32: the member's table rows (a rank of a sharded merge reads
+                                      // only the members that hold its row range)
+// `out` is sized to the member; the deflate runs into a scratch buffer the calling thread keeps (sizing `out` to
+// deflateBound first would zero-fill and page-fault as many bytes as the text itself, once per member).
+bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& result, uint32_t rows = 0) {
   z_stream zs;
   memset(&zs, 0, sizeof zs);
   if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-  out.resize(kGzHeader + deflateBound(&zs, (uLong)n) + 64);
+  static thread_local std::vector<uint8_t> out;
+  const size_t cap = kGzHeader + deflateBound(&zs, (uLong)n) + 64;
+  if (out.size() < cap) out.resize(cap);
   zs.next_in = const_cast<Bytef*>(in);
   zs.avail_in = (uInt)n;
   zs.next_out = out.data() + kGzHeader;
@@ -284,14 +291,15 @@ bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& out
   if (total > 0xFFFFFFFFull) return false;
   static const uint8_t fixed[10] = {0x1f, 0x8b, 8, 4 /* FEXTRA */, 0, 0, 0, 0, 0, 255};
   memcpy(out.data(), fixed, 10);
-  const uint8_t extra[10] = {8, 0, 'M', 'S', 4, 0, (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16),
-                             (uint8_t)(total >> 24)};
-  memcpy(out.data() + 10, extra, 10);
+  const uint8_t extra[18] = {16, 0, 'M', 'S', 4, 0, (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16),
+                             (uint8_t)(total >> 24), 'M', 'R', 4, 0, (uint8_t)rows, (uint8_t)(rows >> 8),
+                             (uint8_t)(rows >> 16), (uint8_t)(rows >> 24)};
+  memcpy(out.data() + 10, extra, 18);
   const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n);
   const uint32_t isize = (uint32_t)n;
   memcpy(out.data() + kGzHeader + produced, &crc, 4);
   memcpy(out.data() + kGzHeader + produced + 4, &isize, 4);
-  out.resize(total);
+  result.assign(out.begin(), out.begin() + (ptrdiff_t)total);
   return true;
 }
 
@@ -857,47 +865,94 @@ int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* ran
   return MIDAS_SNPS_OK;
 }
 
-int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_keys, midas_snps_table** out,
-                              char* err256) {
-  if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+namespace {
+// The gzip members of a table written by this library, found without inflating anything: {data offset, compressed bytes,
+// uncompressed bytes, table rows (-1: a round-1 file that does not say)}.  Empty when the file is any other gzip file.
+struct TableMember { size_t data, clen, ulen; int64_t rows; };
+std::vector<TableMember> table_members(const std::vector<uint8_t>& file) {
+  std::vector<TableMember> members;
+  size_t p = 0;
+  while (p < file.size()) {
+    const uint8_t* h = file.data() + p;
+    if (p + kGzHeaderOld + 8 > file.size() || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[12] != 'M' ||
+        h[13] != 'S' || rd16(h + 14) != 4) return {};
+    const size_t xlen = rd16(h + 10);
+    int64_t rows = -1;
+    if (xlen == 16 && p + kGzHeader + 8 <= file.size() && h[20] == 'M' && h[21] == 'R' && rd16(h + 22) == 4) rows = rd32(h + 24);
+    else if (xlen != 8) return {};
+    const size_t hdr = 12 + xlen, total = rd32(h + 16);
+    if (total < hdr + 8 || p + total > file.size()) return {};
+    members.push_back({p + hdr, total - hdr - 8, (size_t)rd32(h + total - 4), rows});
+    p += total;
+  }
+  return members;
+}
+
+bool read_file(const char* path, std::vector<uint8_t>& file, char* err256) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { set_err(err256, "cannot open %s", path); return false; }
+  fseek(f, 0, SEEK_END);
+  const long fsz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  file.resize((size_t)(fsz > 0 ? fsz : 0));
+  const bool rd = file.empty() || fread(file.data(), 1, file.size(), f) == file.size();
+  fclose(f);
+  if (!rd) set_err(err256, "short read on %s", path);
+  return rd;
+}
+}  // namespace
+
+int32_t midas_snps_table_count_rows(const char* path, int64_t* out_rows, char* err256) {
+  if (!path || !out_rows) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out_rows = -1;
+  std::vector<uint8_t> file;
+  if (!read_file(path, file, err256)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const std::vector<TableMember> members = table_members(file);
+  if (members.empty()) return MIDAS_SNPS_OK;      // not one of ours: unknown without reading it
+  int64_t rows = 0;
+  for (const TableMember& m : members) {
+    if (m.rows < 0) return MIDAS_SNPS_OK;          // a round-1 file
+    rows += m.rows;
+  }
+  *out_rows = rows;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t row_end, int32_t want_keys,
+                                    midas_snps_table** out, char* err256) {
+  if (!path || !out || row_begin < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
   // ---- the text of the table, as line-aligned pieces ------------------------------------------------------
   std::vector<std::vector<char>> pieces;
   std::vector<uint8_t> file;
-  {
-    FILE* f = fopen(path, "rb");
-    if (!f) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
-    fseek(f, 0, SEEK_END);
-    const long fsz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    file.resize((size_t)(fsz > 0 ? fsz : 0));
-    const bool rd = file.empty() || fread(file.data(), 1, file.size(), f) == file.size();
-    fclose(f);
-    if (!rd) { set_err(err256, "short read on %s", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
-  }
-  // members written by midas_snps_write_rows/_table announce their size: walk them without inflating
-  struct Member { size_t data, clen, ulen; };
-  std::vector<Member> members;
-  {
-    size_t p = 0;
-    bool sized = !file.empty();
-    while (sized && p < file.size()) {
-      const uint8_t* h = file.data() + p;
-      if (p + kGzHeader + 8 > file.size() || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || rd16(h + 10) != 8 ||
-          h[12] != 'M' || h[13] != 'S' || rd16(h + 14) != 4) { sized = false; break; }
-      const size_t total = rd32(h + 16);
-      if (total < kGzHeader + 8 || p + total > file.size()) { sized = false; break; }
-      members.push_back({p + kGzHeader, total - kGzHeader - 8, (size_t)rd32(h + total - 4)});
-      p += total;
-    }
-    if (!sized) members.clear();
-  }
+  if (!read_file(path, file, err256)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  // members written by midas_snps_write_rows/_table/_part announce their size (and rows): walk them without inflating
+  std::vector<TableMember> members = table_members(file);
+  int64_t first_row = 0;           // table row of the first row that will be parsed
+  size_t header_piece = 0;         // the piece whose first line is the header line (SIZE_MAX: not among the pieces)
   const int nt = hw_threads(0);
   if (!members.empty()) {
+    bool counted = true;
+    for (const TableMember& m : members) counted = counted && m.rows >= 0;
+    if (counted) {                 // only the members that hold rows [row_begin, row_end)
+      std::vector<TableMember> wanted;
+      int64_t at = 0;
+      bool first = true;
+      header_piece = (size_t)-1;
+      for (size_t i = 0; i < members.size(); ++i) {
+        const int64_t lo = at, hi = at + members[i].rows;
+        at = hi;
+        if (members[i].rows == 0 || hi <= row_begin || (row_end >= 0 && lo >= row_end)) continue;
+        if (first) { first_row = lo; first = false; }
+        wanted.push_back(members[i]);
+      }
+      if (first) first_row = row_begin;
+      members.swap(wanted);
+    }
     pieces.resize(members.size());
     std::atomic<int> bad{0};
     run_pool(nt, members.size(), [&](size_t i) {
-      const Member& m = members[i];
+      const TableMember& m = members[i];
       pieces[i].resize(m.ulen);
       if (m.ulen == 0) return;
       z_stream zs;
@@ -946,43 +1001,53 @@ int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_k
   }
   std::vector<uint8_t>().swap(file);
   // ---- parse the pieces in parallel (the first line of the file is the header) --------------------------------
-  size_t first_piece = 0;
-  while (first_piece < pieces.size() && pieces[first_piece].empty()) ++first_piece;
+  if (header_piece != (size_t)-1) {
+    header_piece = 0;
+    while (header_piece < pieces.size() && pieces[header_piece].empty()) ++header_piece;
+  }
   std::vector<ParsedRows> parsed(pieces.size());
   run_pool(nt, pieces.size(), [&](size_t i) {
     const std::vector<char>& t = pieces[i];
     if (t.empty()) return;
-    parse_rows(t.data(), t.data() + t.size(), want_keys != 0, i == first_piece, parsed[i]);
+    parse_rows(t.data(), t.data() + t.size(), want_keys != 0, i == header_piece, parsed[i]);
     std::vector<char>().swap(pieces[i]);
   });
   midas_snps_table* tab = new (std::nothrow) midas_snps_table();
   if (!tab) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  tab->skip.assign(parsed.size(), 0);
   tab->take.assign(parsed.size(), 0);
   tab->row_base.assign(parsed.size(), 0);
   tab->key_base.assign(parsed.size(), 0);
-  int64_t rows = 0, kbytes = 0;
+  int64_t rows = 0, kbytes = 0, at = first_row;
   for (size_t i = 0; i < parsed.size(); ++i) {
     ParsedRows& pr = parsed[i];
-    int64_t take = pr.rows;
-    if (max_rows >= 0 && rows + take > max_rows) take = max_rows - rows;
-    if (pr.bad_row >= 0 && (max_rows < 0 || rows + pr.bad_row < max_rows)) {
+    const int64_t lo = at, hi = at + pr.rows;     // table rows of this piece
+    at = hi;
+    const int64_t use_lo = std::max(lo, row_begin), use_hi = row_end >= 0 ? std::min(hi, row_end) : hi;
+    if (pr.bad_row >= 0 && lo + pr.bad_row >= row_begin && (row_end < 0 || lo + pr.bad_row < row_end)) {
       // a malformed row inside what would be read (the reference would fail converting it)
-      set_err(err256, "%s: malformed row %lld", path, (long long)(rows + pr.bad_row + 1));
+      set_err(err256, "%s: malformed row %lld", path, (long long)(lo + pr.bad_row + 1));
       delete tab;
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
-    tab->take[i] = take;
+    if (use_hi <= use_lo) { if (row_end >= 0 && lo >= row_end) break; continue; }
+    tab->skip[i] = use_lo - lo;
+    tab->take[i] = use_hi - use_lo;
     tab->row_base[i] = rows;
     tab->key_base[i] = kbytes;
-    rows += take;
-    if (want_keys && take > 0) kbytes += pr.key_end[(size_t)take - 1];
-    if (max_rows >= 0 && rows >= max_rows) break;
+    rows += use_hi - use_lo;
+    if (want_keys) kbytes += pr.key_end[(size_t)(use_hi - lo) - 1] - (use_lo > lo ? pr.key_end[(size_t)(use_lo - lo) - 1] : 0);
   }
   tab->rows = rows;
   tab->key_bytes = kbytes;
   tab->pieces = std::move(parsed);
   *out = tab;
   return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_table_open(const char* path, int64_t max_rows, int32_t want_keys, midas_snps_table** out,
+                              char* err256) {
+  return midas_snps_table_open_range(path, 0, max_rows < 0 ? -1 : max_rows, want_keys, out, err256);
 }
 
 void midas_snps_table_close(midas_snps_table* t) { delete t; }
@@ -992,13 +1057,16 @@ int32_t midas_snps_table_copy(const midas_snps_table* t, uint32_t* counts, char*
   if (!t) return MIDAS_SNPS_ERR_INVALID_ARG;
   if (key_off) key_off[0] = 0;
   run_pool(hw_threads(0), t->pieces.size(), [&](size_t i) {   // every piece lands at its own offsets
-    const int64_t take = t->take[i];
+    const int64_t take = t->take[i], skip = t->skip[i];
     if (take <= 0) return;
     const ParsedRows& pr = t->pieces[i];
-    if (counts) memcpy(counts + 4 * t->row_base[i], pr.counts.data(), (size_t)take * 16);
-    if (keys && !pr.key_end.empty()) memcpy(keys + t->key_base[i], pr.keys.data(), (size_t)pr.key_end[(size_t)take - 1]);
-    if (key_off && !pr.key_end.empty())
-      for (int64_t r = 0; r < take; ++r) key_off[t->row_base[i] + r + 1] = t->key_base[i] + pr.key_end[(size_t)r];
+    if (counts) memcpy(counts + 4 * t->row_base[i], pr.counts.data() + 4 * skip, (size_t)take * 16);
+    if (!pr.key_end.empty()) {
+      const int64_t k0 = skip > 0 ? pr.key_end[(size_t)skip - 1] : 0;     // key bytes in front of the wanted rows
+      if (keys) memcpy(keys + t->key_base[i], pr.keys.data() + k0, (size_t)(pr.key_end[(size_t)(skip + take) - 1] - k0));
+      if (key_off)
+        for (int64_t r = 0; r < take; ++r) key_off[t->row_base[i] + r + 1] = t->key_base[i] + pr.key_end[(size_t)(skip + r)] - k0;
+    }
   });
   return MIDAS_SNPS_OK;
 }
@@ -1060,7 +1128,8 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
         *p++ = '\t'; p = put_u32(p, c[3]);
         *p++ = '\n';
       }
-      if (!gz_member(reinterpret_cast<const uint8_t*>(text.data()), (size_t)(p - text.data()), gz_level, zbuf[(size_t)ci]))
+      if (!gz_member(reinterpret_cast<const uint8_t*>(text.data()), (size_t)(p - text.data()), gz_level, zbuf[(size_t)ci],
+                     (uint32_t)(ch.hi - ch.lo)))
         bad = 1;
       done[(size_t)ci] = 1;
     }
@@ -1112,7 +1181,7 @@ int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_c
 
 int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
                                  int32_t n_samples, int64_t n_sites, const uint32_t* depth, const uint32_t* minor_count,
-                                 int32_t threads, char* err256) {
+                                 int32_t threads, int64_t site_id_base, char* err256) {
   if (!path || !header_line || n_keep < 0 || n_samples <= 0 || n_sites < 0 || (n_keep > 0 && (!keep || !depth)))
     return MIDAS_SNPS_ERR_INVALID_ARG;
   FILE* f = fopen(path, "wb");
@@ -1136,7 +1205,7 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
       char* p = t.data();
       for (int64_t r = lo; r < hi; ++r) {
         const int64_t i = keep[r];
-        p = put_u64(p, (uint64_t)(i + 1));                                   // site_id = 1-based table row
+        p = put_u64(p, (uint64_t)(site_id_base + i + 1));                    // site_id = 1-based table row
         for (int32_t s = 0; s < n_samples; ++s) {
           *p++ = '\t';
           const uint32_t d = depth[(size_t)s * (size_t)n_sites + (size_t)i];
@@ -1180,7 +1249,7 @@ inline char complement_base(char b) { return b == 'A' ? 'T' : b == 'T' ? 'A' : b
 int32_t midas_merge_write_info(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,
                                const char* keys, const int64_t* key_off, const uint8_t* calls,
                                const uint32_t* count_samples, const uint64_t* pooled, const midas_merge_genes* genes,
-                               int32_t threads, char* err256) {
+                               int32_t threads, int64_t site_id_base, char* err256) {
   if (!path || !header_line || n_keep < 0 || !genes || genes->n_genes < 0 ||
       (n_keep > 0 && (!keep || !keys || !key_off || !calls || !count_samples || !pooled)) ||
       (genes->n_genes > 0 && (!genes->scaffold_id || !genes->start || !genes->end || !genes->strand || !genes->gene_type ||
@@ -1277,7 +1346,7 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
         // ---- the line -----------------------------------------------------------------------------------
         const uint8_t* cl = calls + 4 * i;
         auto put = [&](uint64_t v) { char* e = put_u64(num, v); t.append(num, (size_t)(e - num)); };
-        put((uint64_t)(i + 1)); t.push_back('\t');
+        put((uint64_t)(site_id_base + i + 1)); t.push_back('\t');
         t.append(ref_id, id_len); t.push_back('\t');
         put((uint64_t)ref_pos); t.push_back('\t');
         t.append(key + p2, klen - p2); t.push_back('\t');

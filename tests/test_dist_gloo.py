@@ -282,3 +282,96 @@ def test_a_failing_rank_takes_every_rank_down_with_its_message(tmp_path):
     assert all(rc != 0 for rc, _, _ in res)
     assert sum("NM tag" in e for _, _, e in res) == 1
     assert sum("stops with them" in e for _, _, e in res) == 1
+
+
+MERGE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "scripts"))
+from midas_amd import abi, dist
+from midas_amd.merge import snps as msnps
+from tests.test_gpu_merge import oracle_fields
+import merge_midas
+
+
+class OracleContext:
+    """Stands in for the device in this CPU test: midas_merge_sites' contract, computed by the restated reference."""
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def merge_sites(self, prm, counts, mean_depth):
+        names = [t for t, bit in abi.SNP_TYPE_BITS.items() if prm.snp_types & bit]
+        args = dict(allele_freq=prm.allele_freq, site_depth=prm.site_depth, site_ratio=prm.site_ratio, site_prev=prm.site_prev,
+                    snp_type=names)
+        out = oracle_fields([np.asarray(c) for c in counts], [float(x) for x in mean_depth], args)
+        out['kernel_ms'] = 0.0
+        return out
+
+
+sys.argv = ['merge_midas.py'] + sys.argv[1:]
+merge_midas.get_program()
+args = merge_midas.snps_arguments()
+merge_midas.check_arguments(args)
+msnps.run_pipeline(args, make_context=OracleContext)
+'''
+
+
+def test_ranks_share_one_species_merge_by_site_range(tmp_path):
+    """merge_midas.py snps with N = 2 and 3 on ONE species: the sample tables (written by this library's writer) say how
+    many rows every gzip member holds, so rank r reads, merges and writes rows [n r / N, n (r+1) / N) only and the parts are
+    concatenated -- snps_info / snps_freq / snps_depth are byte for byte the single-process files.  Tables that do not
+    say (written like the reference writes them) make the species go whole to one rank: same files again."""
+    import shutil
+    from midas_amd import abi, synth
+    script = tmp_path / "merge_worker.py"
+    script.write_text(MERGE_WORKER % {"root": ROOT})
+    ds = synth.make_merge_dataset(str(tmp_path / "ds"), n_samples=3, n_sites=50000, n_contigs=2, seed=5)
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    samples_dir = os.path.dirname(ds['samples'][0])
+
+    def run(out, n_ranks):
+        argv = [sys.executable, str(script), 'snps', out, '-i', samples_dir, '-t', 'dir', '-d', ds['db'], '--all_snps', '--threads', '2']
+        if n_ranks == 1:
+            r = subprocess.run(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env1, timeout=600)
+            assert r.returncode == 0, r.stderr
+            return r.stdout
+        port = _free_port()
+        procs = [subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                                           MASTER_PORT=str(port))) for k in range(n_ranks)]
+        outs = []
+        for p in procs:
+            o, e = p.communicate(timeout=600)
+            assert p.returncode == 0, e
+            outs.append(o)
+        return "".join(outs)
+
+    def same(a, b):
+        names = sorted(os.listdir(os.path.join(a, ds['species_id'])))
+        assert sorted(os.listdir(os.path.join(b, ds['species_id']))) == names and 'snps_info.txt' in names
+        for f in names:
+            assert open(os.path.join(a, ds['species_id'], f), 'rb').read() == open(os.path.join(b, ds['species_id'], f), 'rb').read(), f
+
+    # (1) tables as the reference writes them: one gzip stream, no row counts -> the species goes whole to one rank
+    one = str(tmp_path / "ref_n1")
+    run(one, 1)
+    two = str(tmp_path / "ref_n2")
+    assert "rows " not in run(two, 2)
+    same(one, two)
+    # (2) the same tables written by this library's writer (25 000-row contigs: two members each)
+    off = 0
+    for sdir, c in zip(ds['samples'], ds['counts']):
+        alleles, counts = [], []
+        off = 0
+        for seq in ds['contig_seqs']:
+            alleles.append(np.frombuffer(seq.encode(), np.uint8))
+            counts.append(np.ascontiguousarray(c[off:off + len(seq)], np.uint32))
+            off += len(seq)
+        path = os.path.join(sdir, 'snps', 'output', ds['species_id'] + '.snps.gz')
+        abi.write_table(path, ds['contig_ids'], alleles, counts, gz_level=1, threads=2)
+        assert abi.count_snps_rows(path) == 50000
+    for n in (2, 3):
+        many = str(tmp_path / ("own_n%d" % n))
+        log = run(many, n)
+        assert log.count("rows ") == n          # every rank took its range of the one species
+        same(one, many)

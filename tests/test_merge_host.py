@@ -228,3 +228,33 @@ def test_species_are_dealt_round_robin_to_ranks():
     parts = [merge.species_for_rank(sp, r, 3) for r in range(3)]
     assert parts == [["s0", "s3", "s6"], ["s1", "s4"], ["s2", "s5"]]
     assert sorted(sum(parts, [])) == sp and merge.species_for_rank(sp, 0, 1) == sp
+
+
+def test_row_ranges_of_a_table_equal_slices_of_the_whole(tmp_path):
+    """midas_snps_table_open_range: a rank of a site-sharded merge reads rows [lo, hi) only -- from a table that says how
+    many rows its gzip members hold (only those members are inflated) and from one that does not (read whole, then cut)."""
+    import gzip
+    rng = np.random.default_rng(2)
+    lens = [20000, 7, 33000]
+    ids = ["c_a", "c_b", "c_c"]
+    n = sum(lens)
+    counts = rng.integers(0, 50, size=(n, 4)).astype(np.uint32)
+    allele = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n)
+    own = str(tmp_path / "own.snps.gz")
+    o = np.cumsum([0] + lens)
+    abi.write_table(own, ids, [allele[o[k]:o[k + 1]] for k in range(3)], [counts[o[k]:o[k + 1]] for k in range(3)], gz_level=1, threads=3)
+    assert abi.count_snps_rows(own) == n
+    plain = str(tmp_path / "plain.snps.gz")
+    with gzip.open(plain, "wb") as h:
+        h.write(gzip.open(own, "rb").read())
+    assert abi.count_snps_rows(plain) == -1
+    full_c, full_k, full_o = abi.read_snps_table(own)
+    assert np.array_equal(full_c, counts)
+    for path in (own, plain):
+        for lo, hi in [(0, n), (0, 1), (16383, 16385), (19999, 20008), (20007, 53007), (n - 1, n), (5000, 5000), (40000, n + 10)]:
+            c, k, ko = abi.read_snps_table(path, hi, True, lo)
+            e = min(hi, n)
+            assert np.array_equal(c, counts[lo:e]), (path, lo, hi)
+            assert ko[0] == 0 and len(ko) == e - lo + 1
+            assert bytes(k) == bytes(full_k[full_o[lo]:full_o[e]])
+            assert np.array_equal(ko, full_o[lo:e + 1] - full_o[lo])
