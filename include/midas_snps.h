@@ -58,7 +58,8 @@ enum {
   MIDAS_SNPS_ERR_NO_DEVICE = -2,         /* no HIP device / not gfx950 / HIP runtime failure at create */
   MIDAS_SNPS_ERR_HIP = -3,               /* a HIP runtime call failed (message has hipGetErrorString) */
   MIDAS_SNPS_ERR_OUT_OF_MEMORY = -4,
-  MIDAS_SNPS_ERR_UNSUPPORTED = -5,       /* l_seq > 1024, l_seq/n_cigar/NM > 65534, > 2^31-1 reads, zero-length contig */
+  MIDAS_SNPS_ERR_UNSUPPORTED = -5,       /* l_seq > 1024, l_seq/n_cigar/NM > 65534, > 2^31-1 reads, zero-length contig,
+                                            baseq > 62 on a batch that holds base qualities above 62 */
   MIDAS_SNPS_ERR_BAD_LAYOUT = -6         /* offsets out of range / not monotone, read_begin inconsistent */
 };
 

@@ -105,7 +105,7 @@ struct alignas(128) PackFacts {          // reductions of one pack, device resid
   unsigned long long blob_bytes;         // payload bytes of all records
   unsigned long long n_records;          // device records of all reads (the u32 scan behind it may have wrapped: checked)
   uint32_t max_l;                        // longest read
-  uint32_t pad;
+  uint32_t high_qual;                    // a record holds a quality above kMaxPackedQual (set by the scatter kernel, slot 0)
 };
 
 struct PackParams {

@@ -4,15 +4,15 @@
 //
 //   rec   [n_reads+1] 16 B   fixed part of a BAM record (one dwordx4 load per read); the extra
 //                            last record is a sentinel whose blob_off8 is the end of the payload
-//   blob  [...]              per read, 8-byte aligned, reads back to back in BAM order
-//                            (240 B for a 150 bp single-match read):
-//                              qual   l_seq bytes, zero-padded to a multiple of 32; the byte of a base that
-//                                     is not A/C/G/T is stored as 0 (such a base can never count; the whole-read
-//                                     mean the readq filter needs travels in the record, see ReadRec)
-//                              calls  16 bytes per 32-base chunk: byte k holds the 4-bit call codes of bases k
-//                                     (low nibble) and k + 16 (high nibble) of the chunk, so a lane gets its
-//                                     32 byte-offsets with one AND per four bases
-//                                     (A=0x0 C=0x4 G=0x8 T=0xC, every other BAM base code and padding = 0x2)
+//   blob  [...]              per record, 8-byte aligned, records back to back in device order
+//                            (160 B for a 150 bp single-match read):
+//                              bases  ONE byte per base, 32 per lane chunk: (min(qual, 62) + 1) << 2 | code with
+//                                     code A=0 C=1 G=2 T=3; a base that is not A/C/G/T, the padding slot of a 31-base
+//                                     lane and the slots past the end of the record are 0.  A base counts iff its byte
+//                                     is >= 4 * (baseq + 1) -- ONE unsigned byte compare, exact for every baseq <= 62
+//                                     (a batch that holds a quality above 62 refuses a baseq above 62: kMaxPackedQual);
+//                                     baseq <= 0 compares against 4: every A/C/G/T base, none of the zeros.
+//                                     (the whole-read mean the readq filter needs travels in the record, see ReadRec)
 //                              cigar  n_cigar * u32 -- omitted when the record is kRecSimple
 //                            coordinate-sorted input => the reads of a tile are one contiguous
 //                            byte range of `blob`.
@@ -20,9 +20,11 @@
 //   tiles [n_tiles]   32 B   {contig, start, len, species, site_base}
 //   out counts [n_sites][4] u32 (A,C,G,T) ; out allele [n_sites] u8
 //
-// A pileup lane owns 31 (or 32, see lane_bases_for) consecutive bases of a read in kChunk = 32 slots: 32 quality bytes (two dwordx4) and
-// 16 bytes of call codes (one dwordx4); slot 31 and the slots past the end of the read are padding.  The zero padding
-// is self-masking: a padded slot has quality 0, which never reaches a threshold >= 1.
+// A pileup lane owns 31 (or 32, see lane_bases_for) consecutive bases of a read in kChunk = 32 slots of one byte (two
+// dwordx4); slot 31 and the slots past the end of the record are padding.  The zero padding is self-masking: a zero byte
+// never reaches a threshold >= 4.  (Round 1 and the first half of round 2 kept 32 quality bytes + 16 bytes of 4-bit call
+// codes per lane: 48 B.  The kernel is HBM-bound and its reads are two thirds of its traffic, so a third less payload
+// is worth more than the shift-and-mask per four bases that recovers the counter offsets.)
 //
 // Algorithmic bytes: ceil(l/2) + l + 4*n_cigar + 16 per read, 17 per site.
 #pragma once
@@ -59,7 +61,8 @@ constexpr uint8_t kRecSentinel = 0x80; // the record after the last read (l_seq 
 constexpr uint8_t kRecOverrun = 8;      // some match op maps a query position >= l_seq onto a site inside the
                                         // contig: pysam would index past SEQ (IndexError) if the read is kept
 
-constexpr int kChunk = 32;          // payload slots per lane: 32 quality bytes, 16 bytes of call codes
+constexpr int kChunk = 32;          // payload slots (= bytes) per lane
+constexpr int kMaxPackedQual = 62;  // qualities above it are stored as 62: exact for every base-quality threshold <= 62
 // Bases per lane: 31 or 32, fixed per batch (lane_bases_for).  31: the last slot of every lane is padding (quality 0,
 // never counted).  The lanes of a read then start 31 sites apart, i.e. 124 dwords apart in the [site][A,C,G,T] tallies
 // -- 4 banks short of a multiple of the bank count -- so their LDS atomics fall into different banks; 32 sites apart
@@ -80,8 +83,15 @@ constexpr int kMaxSegments = 6;     // match segments a read may be served as (m
 constexpr int kMaxPieces = 12;      // device records of one read: its segments, each cut at the tile boundaries it crosses
 constexpr int kMaxSegField = 1023;  // l_seq / aligned length / NM representable in a segment record (10 bits each)
 
-// 4-bit call codes (pre-shifted: code & 0xC is the byte offset of the base's counter inside its site)
-constexpr uint8_t kCallA = 0x0, kCallC = 0x4, kCallG = 0x8, kCallT = 0xC, kCallOther = 0x2;
+// payload byte of one base (0 = does not count at any threshold)
+__host__ __device__ inline uint8_t base_byte(uint32_t qual, uint32_t code2) {
+  const uint32_t q = qual > (uint32_t)kMaxPackedQual ? (uint32_t)kMaxPackedQual : qual;
+  return (uint8_t)(((q + 1u) << 2) | code2);
+}
+// the byte threshold of a base-quality threshold: a base counts iff byte >= it (256: none does)
+__host__ __device__ inline uint32_t base_threshold(int32_t baseq) {
+  return baseq < 1 ? 4u : (baseq <= kMaxPackedQual ? 4u * ((uint32_t)baseq + 1u) : 256u);
+}
 
 struct Tile {               // 32 bytes
   int32_t contig;
@@ -95,8 +105,7 @@ struct Tile {               // 32 bytes
 static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 
 // Offsets of the payload sections inside a read's blob.
-__host__ __device__ inline uint32_t blob_seq_off(uint32_t l_seq, uint32_t bases) { return blob_chunks(l_seq, bases) * 32u; }
-__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq, uint32_t bases) { return blob_chunks(l_seq, bases) * 48u; }
+__host__ __device__ inline uint32_t blob_cigar_off(uint32_t l_seq, uint32_t bases) { return blob_chunks(l_seq, bases) * 32u; }
 __host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_stored, uint32_t bases) {
   return (blob_cigar_off(l_seq, bases) + 4u * n_cigar_stored + 7u) & ~7u;
 }

@@ -38,11 +38,11 @@ void parallel_ranges(int64_t n, F&& fn) {
   for (auto& x : th) x.join();
 }
 
-// BAM base code ("=ACMGRSVTWYHKDBN") -> call code (layout.h)
+// BAM base code ("=ACMGRSVTWYHKDBN") -> 2-bit code A,C,G,T = 0..3, 4 for anything else (layout.h)
 struct CallCodeTable {
   uint8_t v[16];
   constexpr CallCodeTable() : v() {
-    for (int b = 0; b < 16; ++b) v[b] = b == 1 ? kCallA : b == 2 ? kCallC : b == 4 ? kCallG : b == 8 ? kCallT : kCallOther;
+    for (int b = 0; b < 16; ++b) v[b] = b == 1 ? 0 : b == 2 ? 1 : b == 4 ? 2 : b == 8 ? 3 : 4;
   }
   constexpr uint8_t operator[](uint8_t b) const { return v[b]; }
 };
@@ -389,6 +389,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
     for (int64_t j = 0; j < m; ++j) order[j] = j;
   }
   // Pass 2: offsets (serial prefix sum in device order), then copy in parallel.
+  std::atomic<int> any_high{0};
   std::vector<int64_t> off(m + 1);
   off[0] = 0;
   for (int64_t d = 0; d < m; ++d) off[d + 1] = off[d] + bytes[order[d]];
@@ -407,7 +408,9 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       uint8_t* b = blob + off[d];
       memset(b, 0, bytes[j]);
       uint64_t qsum = 0;
-      for (uint32_t x = 0; x < l; ++x) qsum += q[x];
+      bool high = false;
+      for (uint32_t x = 0; x < l; ++x) { qsum += q[x]; high |= q[x] > (uint8_t)kMaxPackedQual; }
+      if (high && !(l > 0 && q[0] == 0xFF)) any_high.store(1, std::memory_order_relaxed);
       const uint32_t qmean = l > 0 ? (uint32_t)(qsum / l) : 0u;   // <= 255, over the WHOLE read (clips included)
       // the bases this record carries: the whole read, or one match segment of it
       uint32_t q0 = 0, len = l;
@@ -424,26 +427,16 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
         pos += sg.roff;
       }
       {
-        // qualities (0 for a base that is not A/C/G/T) and, per 32-base chunk, 16 bytes of call codes: byte k =
-        // code(base k) | code(base k + 16) << 4; bases past the end are kCallOther with quality 0
-        uint8_t* d4 = b + blob_seq_off(len, lane_bases);
+        // one byte per base (layout.h base_byte), 32 slots per lane chunk; 0 for a base that is not A/C/G/T, for the
+        // padding slot of a 31-base lane and past the end of the record (the memset above)
         const uint32_t n_chunks = blob_chunks(len, lane_bases);
         for (uint32_t c = 0; c < n_chunks; ++c) {
-          for (uint32_t kk = 0; kk < 16; ++kk) {
-            uint8_t code[2];
-            for (uint32_t h = 0; h < 2; ++h) {
-              const uint32_t slot = 16 * h + kk;               // slot of the lane
-              const uint32_t x = c * lane_bases + slot;        // base of the record
-              if (slot < lane_bases && x < len) {
-                const uint32_t y = q0 + x;                      // base of the read
-                const uint8_t bc = (uint8_t)((s4[y >> 1] >> ((~y & 1u) * 4)) & 15u);
-                code[h] = kCallCode[bc];
-                b[c * kChunk + slot] = code[h] == kCallOther ? (uint8_t)0 : q[y];
-              } else {
-                code[h] = kCallOther;
-              }
-            }
-            d4[c * 16 + kk] = (uint8_t)(code[0] | (code[1] << 4));
+          for (uint32_t slot = 0; slot < lane_bases; ++slot) {
+            const uint32_t x = c * lane_bases + slot;        // base of the record
+            if (x >= len) break;
+            const uint32_t y = q0 + x;                        // base of the read
+            const uint8_t code = kCallCode[(uint8_t)((s4[y >> 1] >> ((~y & 1u) * 4)) & 15u)];
+            b[c * kChunk + slot] = code < 4 ? base_byte(q[y], code) : (uint8_t)0;
           }
         }
       }
@@ -467,6 +460,7 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
       rec[d] = rr;
     }
   });
+  out->has_high_qual = any_high.load();
   {
     ReadRec s;  // sentinel: where the payload ends
     memset(&s, 0, sizeof s);

@@ -10,6 +10,7 @@ struct PackSummary {
   int64_t read_algorithmic_bytes = 0;  // sum(ceil(l/2) + l + 4*n_cigar + 16)
   int32_t max_l_seq = 0;
   int32_t lane_bases = 31;             // bases per lane of this batch's blob layout (layout.h lane_bases_for)
+  int32_t has_high_qual = 0;           // a read with QUAL present holds a quality above kMaxPackedQual
 };
 
 // rec == blob == nullptr: size query only (blob_bytes, n_records).  rec must hold n_records + 1 records (sentinel);

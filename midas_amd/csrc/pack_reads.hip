@@ -28,7 +28,7 @@
 // wave; the scatter kernel is uniform data movement, one lane per 31 bases.
 //
 // HBM roofline of the scatter kernel (the dominant one): it reads the raw read (ceil(l/2) + l + 4 n_cigar + 16 B of
-// fixed fields) and writes 48 B per 31 bases + 16 B of record.
+// fixed fields) and writes 32 B per 31 bases + 16 B of record.
 #include <hipcub/hipcub.hpp>
 
 #include "device_common.h"
@@ -478,18 +478,17 @@ __device__ __forceinline__ uint32_t low_bytes_mask(int hi) {
   return hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : ((1u << (8 * hi)) - 1u));
 }
 
-// Eight 4-bit BAM base codes ("=ACMGRSVTWYHKDBN") -> eight call codes in the same nibbles:
-// A (1) -> 0x0, C (2) -> 0x4, G (4) -> 0x8, T (8) -> 0xC, anything else -> kCallOther (0x2).
+// Eight 4-bit BAM base codes ("=ACMGRSVTWYHKDBN") -> eight nibbles 4 | code (A, C, G, T = 0..3) for A (1), C (2), G (4),
+// T (8) and 0 for anything else: bit 2 of a nibble says "counts", bits 0-1 are the counter of the base.
 __device__ __forceinline__ uint32_t call_codes8(uint32_t x) {
   const uint32_t pair = (x & 0x55555555u) + ((x >> 1) & 0x55555555u);
   const uint32_t pop = (pair & 0x33333333u) + ((pair >> 2) & 0x33333333u);   // bits set per nibble
   const uint32_t z = pop ^ 0x11111111u;                                       // 0 where exactly one bit is set
   const uint32_t nz = (z | (z >> 1) | (z >> 2) | (z >> 3)) & 0x11111111u;
-  const uint32_t valid = (nz ^ 0x11111111u) * 15u;                            // 0xF in the nibbles of A/C/G/T
+  const uint32_t valid = nz ^ 0x11111111u;                                    // bit 0 of the nibbles of A/C/G/T
   const uint32_t hi = ((x >> 3) | (x >> 2)) & 0x11111111u;                    // G or T
   const uint32_t lo = ((x >> 3) | (x >> 1)) & 0x11111111u;                    // C or T
-  const uint32_t code = (hi << 3) | (lo << 2);
-  return (code & valid) | (0x22222222u & ~valid);
+  return ((valid << 2) | (hi << 1) | lo) & (valid * 7u);
 }
 // Two bytes (four nibbles: byte0.hi, byte0.lo, byte1.hi, byte1.lo in base order) -> four bytes, one nibble each.
 // HALF 0: bytes 0,1 of x; HALF 1: bytes 2,3.
@@ -585,28 +584,29 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) cw[k] = call_codes8(cw[k]);
-      // out byte k = code(slot k) | code(slot k + 16) << 4
-      uint32_t out[4];
-      out[0] = spread_nibbles<0>(cw[0]) | (spread_nibbles<0>(cw[2]) << 4);
-      out[1] = spread_nibbles<1>(cw[0]) | (spread_nibbles<1>(cw[2]) << 4);
-      out[2] = spread_nibbles<0>(cw[1]) | (spread_nibbles<0>(cw[3]) << 4);
-      out[3] = spread_nibbles<1>(cw[1]) | (spread_nibbles<1>(cw[3]) << 4);
+      // one byte per slot: {valid << 2 | code} of slots 4k .. 4k + 3 in word k
+      const uint32_t cb[8] = {spread_nibbles<0>(cw[0]), spread_nibbles<1>(cw[0]), spread_nibbles<0>(cw[1]), spread_nibbles<1>(cw[1]),
+                              spread_nibbles<0>(cw[2]), spread_nibbles<1>(cw[2]), spread_nibbles<0>(cw[3]), spread_nibbles<1>(cw[3])};
+      uint32_t high = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // slots past the end of the record (and the padding slot of a 31-base lane) are kCallOther with quality 0
-        const uint32_t keep = (low_bytes_mask(nvalid - 4 * k) & 0x0F0F0F0Fu) | (low_bytes_mask(nvalid - 16 - 4 * k) & 0xF0F0F0F0u);
-        out[k] = (out[k] & keep) | (0x22222222u & ~keep);
-        const uint32_t inv_lo = out[k] & 0x02020202u, inv_hi = (out[k] >> 4) & 0x02020202u;
-        qw[k] &= ~((inv_lo << 7) - (inv_lo >> 1));           // a base that is not A/C/G/T carries quality 0
-        qw[k + 4] &= ~((inv_hi << 7) - (inv_hi >> 1));
+      for (int k = 0; k < 8; ++k) {
+        // layout.h base_byte, four bases at a time: (min(q, 62) + 1) << 2 | code where the base is A/C/G/T and inside the
+        // record, 0 elsewhere (padding slot, tail, other letters)
+        const uint32_t q = qw[k];
+        const uint32_t over = (((q & 0x7F7F7F7Fu) + 0x41414141u) | q) & 0x80808080u;    // bit 7 of the bytes above 62
+        const uint32_t om = (over >> 7) * 0xFFu;
+        const uint32_t qq = ((q & ~om) | (0x3E3E3E3Eu & om)) + 0x01010101u;
+        const uint32_t keep = ((cb[k] >> 2) & 0x01010101u) * 0xFFu & low_bytes_mask(nvalid - 4 * k);
+        high |= over & low_bytes_mask(nvalid - 4 * k);
+        qw[k] = ((qq << 2) | (cb[k] & 0x03030303u)) & keep;
       }
-      u32x4_a8 v0, v1, v2;
+      // a quality above 62 among the record's bases (QUAL present): the batch will refuse a baseq above 62
+      if (high && qsrc[0] != 0xFFu) atomicOr(&p.facts->high_qual, 1u);
+      u32x4_a8 v0, v1;
       v0.x = qw[0]; v0.y = qw[1]; v0.z = qw[2]; v0.w = qw[3];
       v1.x = qw[4]; v1.y = qw[5]; v1.z = qw[6]; v1.w = qw[7];
-      v2.x = out[0]; v2.y = out[1]; v2.z = out[2]; v2.w = out[3];
       *reinterpret_cast<u32x4_a8*>(b + c * kChunk) = v0;
       *reinterpret_cast<u32x4_a8*>(b + c * kChunk + 16) = v1;
-      *reinterpret_cast<u32x4_a8*>(b + chunks * 32u + c * (kChunk / 2)) = v2;
     }
     if (valid && !simple) {   // the record keeps its CIGAR behind the payload (zero padding to 8 bytes)
       const uint32_t nc = cur.d0.z >> 16;

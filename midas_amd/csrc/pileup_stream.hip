@@ -96,8 +96,7 @@ __global__ __launch_bounds__(kStreamBlock, 4) void pileup_stream_kernel(PileupPa
   const int lane_bases = p.lane_bases;           // 31 or 32 (layout.h), uniform
   const int q0 = c * lane_bases;                 // first base of the lane; its payload sits in slot block c
   const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
-  const int bq = p.baseq < 1 ? 1 : p.baseq;      // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
-  const bool count_all = p.baseq < 1;
+  const int bq = (int)base_threshold(p.baseq);   // a base counts iff its payload byte >= this (layout.h)
   const uint32_t lds_base0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0][0];
 
   // ---- once: LDS clean, filter tables in place -----------------------------------------------------------------------------
@@ -167,8 +166,7 @@ __global__ __launch_bounds__(kStreamBlock, 4) void pileup_stream_kernel(PileupPa
   const uint32_t n_units = s_units;
 
   struct Payload {
-    uint32_t qw[NW];  // 32 quality bytes (zero beyond the end of the read: the blob is padded)
-    uint32_t sw[4];   // 32 call codes
+    uint32_t qw[NW];  // 32 base bytes: (min(qual, 62) + 1) << 2 | code, 0 = never counts (layout.h)
   };
   // word k of tile t's info record
   auto info = [&](int t, int k) -> uint4 { return s_info[4 * (t - seg_begin) + k]; };
@@ -207,10 +205,8 @@ __global__ __launch_bounds__(kStreamBlock, 4) void pileup_stream_kernel(PileupPa
     if (q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk + 16);
-      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l, (uint32_t)lane_bases) + c * (kChunk / 2));
       d.qw[0] = qa.x; d.qw[1] = qa.y; d.qw[2] = qa.z; d.qw[3] = qa.w;
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
-      d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
   };
 
@@ -398,20 +394,7 @@ __global__ __launch_bounds__(kStreamBlock, 4) void pileup_stream_kernel(PileupPa
         if (keep && q0 < fl) {
           uint32_t cd[NW];
 #pragma unroll
-          for (int w = 0; w < NW / 2; ++w) {
-            cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
-            cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
-          }
-          if (count_all) {
-            const int nvalid = fl - q0 < lane_bases ? fl - q0 : lane_bases;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
-              const uint32_t inv = nib & 0x02020202u;
-              const uint32_t inv_ff = (inv << 7) - (inv >> 1);
-              cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
-            }
-          }
+          for (int w = 0; w < NW; ++w) cd[w] = (cur.qw[w] << 2) & 0x0C0C0C0Cu;   // code << 2: the counter's byte offset
           const uint32_t abase = ((uint32_t)(frel + q0) << 4) + lds_base;
           if (!(kAblate & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
         }
@@ -500,19 +483,7 @@ __global__ __launch_bounds__(kStreamBlock, 4) void pileup_stream_kernel(PileupPa
       bool walking = keep && has;
       if (walking) {
 #pragma unroll
-        for (int w = 0; w < NW / 2; ++w) {
-          cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
-          cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
-        }
-        if (count_all) {   // baseq <= 0: every A/C/G/T base of the read counts, whatever its quality (bq is 1)
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
-            const uint32_t inv = nib & 0x02020202u;                    // not A/C/G/T
-            const uint32_t inv_ff = (inv << 7) - (inv >> 1);           // 0xFF in every such byte
-            cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
-          }
-        }
+        for (int w = 0; w < NW; ++w) cd[w] = (cur.qw[w] << 2) & 0x0C0C0C0Cu;   // code << 2: the counter's byte offset
       }
 
       // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -----

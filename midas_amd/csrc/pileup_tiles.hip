@@ -18,8 +18,8 @@
 // load -> compute -> store in lockstep (measured: those three phases used to simply add up).  The counts and
 // alleles leave as non-temporal stores; the barriers between the phases wait for LDS traffic only.
 //
-// Lane mapping.  A lane owns 31 consecutive bases of one read (32 payload slots, the last one padding: layout.h says
-// why 31, and when a batch uses all 32 instead): two 16-byte loads of quals and one 16-byte load of 4-bit call codes.  A read of l_seq
+// Lane mapping.  A lane owns 31 consecutive bases of one read (32 payload slots of one byte, the last one padding: layout.h
+// says why 31, and when a batch uses all 32 instead): two 16-byte loads, quality and base code in the same byte.  A read of l_seq
 // bases occupies ceil(l_seq/31) adjacent lanes (5 for 150 bp; `lanes_per_read` is fixed per batch from the longest read) and a wave works on
 // floor(64 / lanes_per_read) reads at a time.  The read filter's numbers (aligned length, NM, floor of the mean
 // quality) come with the record: the packer computed them once per read.
@@ -104,14 +104,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
   const int q0 = c * lane_bases;                 // first base of the lane; its payload sits in slot block c
   const int stride = (kPileupBlock / 64) * rpw;
   const uint4* recs = reinterpret_cast<const uint4*>(p.rec);
-  const int bq = p.baseq < 1 ? 1 : p.baseq;   // baseq <= 0 counts every base: validity bytes become 0xFF >= 1
-  const bool count_all = p.baseq < 1;
+  const int bq = (int)base_threshold(p.baseq);   // a base counts iff its payload byte >= this (layout.h)
   // LDS byte address of the tally array (LDS pointers are 32-bit offsets on amdgcn)
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
 
   struct Payload {
-    uint32_t qw[NW];  // 32 quality bytes (zero beyond the end of the read: the blob is padded)
-    uint32_t sw[4];   // 32 call codes
+    uint32_t qw[NW];  // 32 base bytes: (min(qual, 62) + 1) << 2 | code, 0 = never counts (layout.h)
   };
   // ---- two-deep prefetch: records two iterations ahead, payload one iteration ahead.  Nothing may be
   // computed from a loaded value here: any use would make the compiler drain the loads at once.
@@ -159,10 +157,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
     if (q0 < l) {
       const u32x4_a8 qa = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk);
       const u32x4_a8 qb = *reinterpret_cast<const u32x4_a8*>(bp + c * kChunk + 16);
-      const u32x4_a8 sv = *reinterpret_cast<const u32x4_a8*>(bp + blob_seq_off((uint32_t)l, (uint32_t)lane_bases) + c * (kChunk / 2));
       d.qw[0] = qa.x; d.qw[1] = qa.y; d.qw[2] = qa.z; d.qw[3] = qa.w;
       d.qw[4] = qb.x; d.qw[5] = qb.y; d.qw[6] = qb.z; d.qw[7] = qb.w;
-      d.sw[0] = sv.x; d.sw[1] = sv.y; d.sw[2] = sv.z; d.sw[3] = sv.w;
     }
   };
   constexpr int NWAVES = kPileupBlock / 64;
@@ -253,20 +249,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
           if (keep && q0 < fl) {
             uint32_t cd[NW];
 #pragma unroll
-            for (int w = 0; w < NW / 2; ++w) {
-              cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
-              cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
-            }
-            if (count_all) {
-              const int nvalid = fl - q0 < lane_bases ? fl - q0 : lane_bases;
-#pragma unroll
-              for (int w = 0; w < NW; ++w) {
-                const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
-                const uint32_t inv = nib & 0x02020202u;
-                const uint32_t inv_ff = (inv << 7) - (inv >> 1);
-                cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
-              }
-            }
+            for (int w = 0; w < NW; ++w) cd[w] = (cur.qw[w] << 2) & 0x0C0C0C0Cu;   // code << 2: the counter's byte offset
             const uint32_t abase = ((uint32_t)(frel + q0) << 4) + lds_base;
             if (!(kDebug & 1)) tally_chunk(cur.qw, cd, (uint32_t)bq, abase, 1u);
           }
@@ -363,25 +346,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const bool keep = act & !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
 
       // ---- per-base call codes and validity, four bases per instruction ----------------------------
-      // cur.qw: quality byte if the base may count (the packer zeroed the bases that are not A/C/G/T), else 0
+      // cur.qw: one byte per base, quality above the code; 0 = never counts (not A/C/G/T, padding, past the record)
       uint32_t cd[NW];   // byte offset of the base's counter inside its site (call code & 0xC)
       bool walking = keep && has && !(kDebug & 4);
       if (walking) {     // (cd is only ever read under `walking`)
-        // call codes arrive as byte k = code(base k) | code(base k + 16) << 4: one AND per four bases
 #pragma unroll
-        for (int w = 0; w < NW / 2; ++w) {
-          cd[w] = cur.sw[w] & 0x0C0C0C0Cu;
-          cd[w + NW / 2] = (cur.sw[w] >> 4) & 0x0C0C0C0Cu;
-        }
-        if (count_all) {   // baseq <= 0: every A/C/G/T base of the read counts, whatever its quality (bq is 1)
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            const uint32_t nib = w < NW / 2 ? cur.sw[w] : (cur.sw[w - NW / 2] >> 4);
-            const uint32_t inv = nib & 0x02020202u;                    // not A/C/G/T
-            const uint32_t inv_ff = (inv << 7) - (inv >> 1);           // 0xFF in every such byte
-            cur.qw[w] = low_bytes_mask(nvalid - 4 * w) & ~inv_ff;
-          }
-        }
+        for (int w = 0; w < NW; ++w) cd[w] = (cur.qw[w] << 2) & 0x0C0C0C0Cu;   // code << 2: the counter's byte offset
       }
 
       // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -----

@@ -67,6 +67,7 @@ struct midas_snps_batch {
   std::vector<uint32_t> h_wg_begin;
   std::vector<uint8_t> h_tile_split;
   bool any_split = false;
+  bool has_high_qual = false;   // the payload holds a quality above kMaxPackedQual: a baseq above it cannot be served
   int64_t n_items = 0, n_whole_items = 0;
   std::vector<std::pair<size_t, size_t>> zero_ranges;   // (first site, sites) of split tiles: counts zeroed before a run
   FilterTables h_filt;
@@ -753,7 +754,8 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   if (b->n_tiles > 0)
     B_TRY(hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
   B_TRY(launch_pack_scatter(b->pk, s));
-  B_TRY(hipStreamSynchronize(s));
+  B_TRY(fetch_facts());
+  b->has_high_qual = slots[0].high_qual != 0;
   b->pack_count = 1;
   lap("pack: order + scatter");
   B_TRY(hipMalloc(&b->d_items, 4));
@@ -837,6 +839,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   if (!b || !thr) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   if (thr->reserved != 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "thresholds.reserved must be 0");
+  if (thr->baseq > kMaxPackedQual && b->has_high_qual)   // (Illumina tops out in the forties; BAM allows 93)
+    return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "baseq above 62 on reads that hold base qualities above 62 is not supported "
+                                                  "(qualities are kept in six bits)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   hipEvent_t* ev = b->timing_slots > 0 ? &b->ev[(size_t)(b->timed_runs % b->timing_slots) * 3] : nullptr;

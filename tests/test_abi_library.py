@@ -70,32 +70,20 @@ def test_product_never_imports_the_oracle():
 
 # ---- the host packer (runs without a GPU) -----------------------------------------------------
 
-CALL = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
-
-
-LANE_BASES = 31      # layout.h kBases: a lane carries 31 bases in 32 payload slots, the last slot is padding
+LANE_BASES = 31      # layout.h: a lane carries 31 bases in 32 payload slots of one byte, the last slot is padding
 
 
 def n_lanes(n_bases):
     return (n_bases + LANE_BASES - 1) // LANE_BASES
 
 
-def call_codes(seq):
-    """layout.h: 16 bytes per lane (31 bases + one padding slot); byte k = code(slot k) | code(slot k + 16) << 4; padding = 0x2"""
-    code = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
-    out = bytearray()
-    for c0 in range(0, len(seq), LANE_BASES):
-        chunk = [code.get(ch, 0x2) for ch in seq[c0:c0 + LANE_BASES]]
-        chunk += [0x2] * (32 - len(chunk))
-        out += bytes(chunk[k] | (chunk[k + 16] << 4) for k in range(16))
-    return bytes(out)
-
-
-def lane_quals(quals):
-    """layout.h: 32 quality bytes per lane, the 31 bases then a zero; zeros past the end of the record"""
+def base_bytes(seq, quals, lane_bases=LANE_BASES):
+    """layout.h: one byte per base, (min(qual, 62) + 1) << 2 | code with A, C, G, T = 0..3; 0 for any other letter, for the
+    padding slot of a 31-base lane and past the end of the record; 32 slots per lane."""
     out = []
-    for c0 in range(0, len(quals), LANE_BASES):
-        lane = list(quals[c0:c0 + LANE_BASES])
+    for c0 in range(0, len(seq), lane_bases):
+        lane = [((min(q, 62) + 1) << 2) | "ACGT".index(ch) if ch in "ACGT" else 0
+                for ch, q in zip(seq[c0:c0 + lane_bases], quals[c0:c0 + lane_bases])]
         out += lane + [0] * (32 - len(lane))
     return out
 
@@ -135,17 +123,16 @@ def test_pack_layout_matches_design():
     assert r["n"][1] == 1 and r["nm"][1] == 0xFFFF
     # qmean = floor(sum(qual) / l) over the WHOLE read: low five bits above l_seq, high three bits in flags 4-6
     assert qmean_of(r) == [45 // 10, 40, 255]           # 0..9 ; default quality 40 ; absent = 0xFF bytes
-    # read 0: qual 7 -> 32 | calls 16                = 48 bytes
-    # read 1: qual 5 -> 32 | calls 16 | cigar 4 -> 8 = 56 bytes; read 2 like read 0
-    assert r["off8"].tolist() == [0, 6, 13]
-    b0 = blob[:48]
-    assert b0[:7].tolist() == list(range(3, 10)) and not b0[7:32].any()
-    assert bytes(b0[32:48]) == call_codes("ACGTACG")
-    b1 = blob[48:104]
-    assert b1[:5].tolist() == [40, 40, 40, 40, 0]    # the N's quality is stored as 0: it can never count
-    assert bytes(b1[32:48]) == call_codes("ACGTN")
-    assert b1[48:52].view("<u4").tolist() == [(5 << 4) | 0]
-    assert blob.size == 48 + 56 + 48
+    # read 0: 7 bases -> 32 bytes; read 1: 5 bases -> 32 | cigar 4 -> 8 = 40 bytes; read 2 like read 0
+    assert r["off8"].tolist() == [0, 4, 9]
+    b0 = blob[:32]
+    assert b0.tolist() == base_bytes("ACGTACG", list(range(3, 10)))        # quality 3..9 above codes 0,1,2,3,0,1,2
+    assert b0[:7].tolist() == [(q + 1) << 2 | k % 4 for k, q in enumerate(range(3, 10))] and not b0[7:32].any()
+    b1 = blob[32:72]
+    assert b1[:5].tolist() == [41 << 2 | 0, 41 << 2 | 1, 41 << 2 | 2, 41 << 2 | 3, 0]    # the N is stored as 0: it can never count
+    assert b1[:32].tolist() == base_bytes("ACGTN", [40] * 5)
+    assert b1[32:36].view("<u4").tolist() == [(5 << 4) | 0]
+    assert blob.size == 32 + 40 + 32
 
 
 def test_pack_serves_reads_as_match_segments():
@@ -168,23 +155,27 @@ def test_pack_serves_reads_as_match_segments():
     assert first == [1, 0, 1, 0, 1, 1, 0, 0]
     # payload of the second record of read 0: read bases 77..149
     o = int(r["off8"][1]) * 8
-    assert bytes(blob[o + 96:o + 96 + 48]) == call_codes(seq[77:150])               # 73 bases: three lanes
-    assert blob[o:o + 96].tolist() == lane_quals([40] * 73)
+    assert blob[o:o + 96].tolist() == base_bytes(seq[77:150], [40] * 73)              # 73 bases: three lanes
 
 
 def test_pack_uses_all_32_slots_where_that_saves_a_lane():
     """layout.h lane_bases_for: 125 bp reads pack 32 bases per lane (4 lanes, no padding slot), 150 bp reads 31 (5 lanes)."""
     seq = "".join("ACGT"[(5 * i) % 4] for i in range(125))
-    reads = H.reads_from_dicts([dict(pos=10, cigar="125M", seq=seq, nm=0, qual=[30 + (i % 10) for i in range(125)])])
+    quals = [30 + (i % 10) for i in range(125)]
+    reads = H.reads_from_dicts([dict(pos=10, cigar="125M", seq=seq, nm=0, qual=quals)])
     rec, blob, maxl = abi.pack_reads(reads)
-    assert maxl == 125 and blob.size == 128 + 64
-    assert blob[:125].tolist() == [30 + (i % 10) for i in range(125)] and not blob[125:128].any()
-    code = {"A": 0x0, "C": 0x4, "G": 0x8, "T": 0xC}
-    exp = bytearray()
-    for c0 in range(0, 125, 32):
-        chunk = [code[ch] for ch in seq[c0:c0 + 32]] + [0x2] * max(0, c0 + 32 - 125)
-        exp += bytes(chunk[k] | (chunk[k + 16] << 4) for k in range(16))
-    assert bytes(blob[128:192]) == bytes(exp)
+    assert maxl == 125 and blob.size == 128
+    assert blob.tolist() == base_bytes(seq, quals, lane_bases=32)
+    assert not blob[125:128].any()
+
+
+def test_pack_keeps_qualities_in_six_bits():
+    """Qualities above 62 are stored as 62 (exact for every baseq <= 62, layout.h); 0xFF bytes (QUAL absent) too."""
+    reads = H.reads_from_dicts([dict(pos=0, cigar="6M", seq="ACGTAC", qual=[0, 1, 61, 62, 63, 93]),
+                                dict(pos=0, cigar="4M", seq="ACGT", qual="absent")])
+    rec, blob, _ = abi.pack_reads(reads)
+    assert blob[:6].tolist() == [1 << 2 | 0, 2 << 2 | 1, 62 << 2 | 2, 63 << 2 | 3, 63 << 2 | 0, 63 << 2 | 1]
+    assert blob[32:36].tolist() == [63 << 2 | 0, 63 << 2 | 1, 63 << 2 | 2, 63 << 2 | 3]
 
 
 def test_pack_keeps_the_cigar_of_reads_it_cannot_segment():
@@ -271,11 +262,8 @@ def test_pack_round_trips_synthetic_reads():
             assert r["flags"][j] & 2 and int(r["pos"][j]) == rs and int(r["l"][j]) & 0x7FF == ln, (i, s)
             assert qmean_of(r[j:j + 1])[0] == int(q.sum()) // l
             o = int(r["off8"][j]) * 8
-            acgt = np.array([ch in "ACGT" for ch in seq[qs:qs + ln]])
             # non-ACGT bases carry quality 0; so do the padding slots (the self-masking tail)
-            assert blob[o:o + 32 * n_lanes(ln)].tolist() == lane_quals(np.where(acgt, q[qs:qs + ln], 0).tolist())
-            so = o + 32 * n_lanes(ln)
-            assert bytes(blob[so:so + 16 * n_lanes(ln)]) == call_codes(seq[qs:qs + ln])
+            assert blob[o:o + 32 * n_lanes(ln)].tolist() == base_bytes(seq[qs:qs + ln], q[qs:qs + ln].tolist())
             lr, al, nm, first = seg_fields(r[j:j + 1])
             clips = sum(ln2 for op, ln2 in cig if op == 4)
             assert (lr[0], al[0], nm[0], first[0]) == (l, l - clips, int(reads.nm[i]), int(s == 0))
