@@ -262,6 +262,32 @@ def test_unsupported_and_malformed_inputs_are_statuses_not_crashes(hip_ctx, thr_
     assert ei.value.status == abi.ERR_UNSUPPORTED
 
 
+def test_qualities_above_62_are_exact_up_to_baseq_62_and_refused_beyond(hip_ctx):
+    """The device keeps a base's quality in six bits (layout.h): Phred 63..93 are stored as 62, which changes no comparison
+    with a baseq <= 62; a baseq above 62 on such a batch is a status, not a wrong table.  Batches without such qualities take
+    any baseq (nothing passes above their maximum, as in the reference)."""
+    rng = np.random.default_rng(5)
+    L = 6000
+    reads = []
+    for k in range(800):
+        l = int(rng.integers(30, 151))
+        reads.append(dict(pos=int(rng.integers(0, L - 160)), cigar="%dM" % l, seq="".join("ACGT"[i] for i in rng.integers(0, 4, l)),
+                          qual=[int(x) for x in rng.choice([0, 1, 30, 40, 61, 62, 63, 64, 70, 93], size=l)], nm=0))
+    reads.sort(key=lambda r: r['pos'])
+    soa = H.reads_from_dicts(reads)
+    contig = H.single_contig(L, len(reads), "".join("ACGT"[i] for i in rng.integers(0, 4, L)))
+    for bq in (0, 1, 41, 61, 62):
+        _assert_same(hip_ctx, abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, soa)
+    for bq in (63, 64, 94):
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            hip_ctx.pileup(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, soa)
+        assert ei.value.status == abi.ERR_UNSUPPORTED
+    low = H.reads_from_dicts([dict(r, qual=[min(q, 62) for q in r['qual']]) for r in reads])
+    for bq in (62, 63, 200):
+        counts, _ = _assert_same(hip_ctx, abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, low)
+        assert (counts.sum() > 0) == (bq == 62)
+
+
 # ---- full-size properties (BASELINE configs[1]); the oracle also finishes it in ~1 s, so compare too -----
 
 @pytest.fixture(scope="module")
