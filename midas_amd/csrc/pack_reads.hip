@@ -488,7 +488,7 @@ __device__ __forceinline__ uint32_t call_codes8(uint32_t x) {
   const uint32_t valid = nz ^ 0x11111111u;                                    // bit 0 of the nibbles of A/C/G/T
   const uint32_t hi = ((x >> 3) | (x >> 2)) & 0x11111111u;                    // G or T
   const uint32_t lo = ((x >> 3) | (x >> 1)) & 0x11111111u;                    // C or T
-  return ((valid << 2) | (hi << 1) | lo) & (valid * 7u);
+  return ((valid << 2) | (hi << 1) | lo) & ((valid << 3) - valid);            // (x << 3) - x = 7 x: no integer multiply
 }
 // Two bytes (four nibbles: byte0.hi, byte0.lo, byte1.hi, byte1.lo in base order) -> four bytes, one nibble each.
 // HALF 0: bytes 0,1 of x; HALF 1: bytes 2,3.
@@ -568,9 +568,12 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
     }
     if (has) {
       uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+      uint32_t tm[8];   // byte masks of the slots that hold bases of the record (the last lane of a record is partial)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tm[k] = low_bytes_mask(nvalid - 4 * k);
       if (whole) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(qw[k] & low_bytes_mask(nvalid - 4 * k), 0u, part);
+        for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(qw[k] & tm[k], 0u, part);
         if (c == 0) part |= ((qa.x & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;
       }
       uint32_t cw[4] = {sa.x, sa.y, sa.z, sa.w};
@@ -587,18 +590,25 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
       // one byte per slot: {valid << 2 | code} of slots 4k .. 4k + 3 in word k
       const uint32_t cb[8] = {spread_nibbles<0>(cw[0]), spread_nibbles<1>(cw[0]), spread_nibbles<0>(cw[1]), spread_nibbles<1>(cw[1]),
                               spread_nibbles<0>(cw[2]), spread_nibbles<1>(cw[2]), spread_nibbles<0>(cw[3]), spread_nibbles<1>(cw[3])};
+      // qualities above 62 (bit 7 of `over` in their bytes): rare enough that the clamp is a branch the wave usually skips
       uint32_t high = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) high |= (((qw[k] & 0x7F7F7F7Fu) + 0x41414141u) | qw[k]) & 0x80808080u & tm[k];
+      if (__builtin_expect(high != 0u, 0)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t over = (((qw[k] & 0x7F7F7F7Fu) + 0x41414141u) | qw[k]) & 0x80808080u;
+          const uint32_t om = (over << 1) - (over >> 7);                       // 0xFF in the bytes above 62
+          qw[k] = (qw[k] & ~om) | (0x3E3E3E3Eu & om);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         // layout.h base_byte, four bases at a time: (min(q, 62) + 1) << 2 | code where the base is A/C/G/T and inside the
         // record, 0 elsewhere (padding slot, tail, other letters)
-        const uint32_t q = qw[k];
-        const uint32_t over = (((q & 0x7F7F7F7Fu) + 0x41414141u) | q) & 0x80808080u;    // bit 7 of the bytes above 62
-        const uint32_t om = (over >> 7) * 0xFFu;
-        const uint32_t qq = ((q & ~om) | (0x3E3E3E3Eu & om)) + 0x01010101u;
-        const uint32_t keep = ((cb[k] >> 2) & 0x01010101u) * 0xFFu & low_bytes_mask(nvalid - 4 * k);
-        high |= over & low_bytes_mask(nvalid - 4 * k);
-        qw[k] = ((qq << 2) | (cb[k] & 0x03030303u)) & keep;
+        const uint32_t vb = (cb[k] >> 2) & 0x01010101u;
+        const uint32_t keep = ((vb << 8) - vb) & tm[k];                        // 0xFF where the slot holds an A/C/G/T base
+        qw[k] = (((qw[k] + 0x01010101u) << 2) | (cb[k] & 0x03030303u)) & keep;
       }
       // a quality above 62 among the record's bases (QUAL present): the batch will refuse a baseq above 62
       if (high && qsrc[0] != 0xFFu) atomicOr(&p.facts->high_qual, 1u);
