@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include "../../include/midas_snps.h"
@@ -13,9 +14,13 @@
 
 namespace {
 
+// A sample's part in compute_prevalence (:93-104), folded into integer limits on the host (sample_limits below): the
+// site passes for the sample iff lo <= depth <= hi; it raises ZeroDivisionError iff zero_on and depth >= zero_from.
+struct SampleLimit { uint32_t lo, hi, zero_from, zero_on; };
+
 struct MergeKParams {
   const uint32_t* counts;     // [n_samples][n_sites][4]
-  const double* mean_depth;   // [n_samples]
+  const SampleLimit* limit;   // [n_samples]
   uint32_t* calls;            // [n_sites] bytes {major, minor, snp_type, flag}: 0..3 = A,C,G,T, 255 = None;
                               // snp_type 0 None, 1 mono, 2 bi, 3 tri, 4 quad; flag 0 keep, 1 min_prev, 2 snp_type
   uint32_t* count_samples;
@@ -23,11 +28,10 @@ struct MergeKParams {
   uint32_t* depth;            // [n_samples][n_sites]  major + minor count
   uint32_t* minor_count;      // [n_samples][n_sites]
   unsigned long long* err;    // lowest site where the reference would raise ZeroDivisionError, else ~0
-  long long n_sites;
+  uint32_t n_sites;           // sites of this chunk: < 2^26, so that every per-site byte offset fits 32 bits
   int n_samples;
-  int site_depth;
   int snp_types;
-  double allele_freq, site_ratio, site_prev;
+  double allele_freq, site_prev;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -35,8 +39,24 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define MIDAS_MERGE_SPLIT_FROM 28
 #endif
 constexpr int kSplitFrom = MIDAS_MERGE_SPLIT_FROM;   // samples from which several waves share a site group
+#ifndef MIDAS_MERGE_REGS_UP_TO
+#define MIDAS_MERGE_REGS_UP_TO 64
+#endif
+constexpr int kRegsUpTo = MIDAS_MERGE_REGS_UP_TO;    // samples up to which a site's rows stay in registers (one pass)
+constexpr long long kMaxChunkSites = 1ll << 26;
 
-// ---- per-site arithmetic shared by the two kernel forms ---------------------------------------------------------
+// Addressing: (uniform 64-bit base of the sample's row) + (32-bit byte offset of the site).  That is the form the
+// global_load / global_store "saddr + voffset" encoding takes: no 64-bit address arithmetic in vector registers.
+__device__ __forceinline__ u32x4 load_row(const MergeKParams& p, int s, uint32_t site) {
+  const char* base = reinterpret_cast<const char*>(p.counts + (size_t)s * p.n_sites * 4);
+  return *reinterpret_cast<const u32x4*>(base + (site * 16u));
+}
+__device__ __forceinline__ void store_u32(uint32_t* table, const MergeKParams& p, int s, uint32_t site, uint32_t v) {
+  char* base = reinterpret_cast<char*>(table + (size_t)s * p.n_sites);
+  __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(base + (site * 4u)));
+}
+
+// ---- per-site arithmetic shared by the kernel forms --------------------------------------------------------------
 // call_alleles (:49-76) from the pooled counts
 struct SiteCall { int major, minor, snp; };
 __device__ __forceinline__ SiteCall call_site(const unsigned long long (&pc)[4], double allele_freq) {
@@ -67,24 +87,25 @@ __device__ __forceinline__ SiteCall call_site(const unsigned long long (&pc)[4],
 }
 
 // compute_per_sample_mafs (:78-91) + compute_prevalence (:93-104) for one sample's row of the site
-struct SampleAcc { uint32_t pass = 0; bool zero_div = false; };
-__device__ __forceinline__ void sample_row(const MergeKParams& p, long long i, int s, const u32x4 c, const SiteCall& sc,
+struct SampleAcc { uint32_t pass = 0; uint32_t zero_div = 0; };
+__device__ __forceinline__ void sample_row(const MergeKParams& p, uint32_t i, int s, const u32x4 c, const SiteCall& sc,
                                            SampleAcc& acc) {
   // counts of the major / minor allele without indexing a register array by a runtime value
   const uint32_t cmaj = sc.major == 0 ? c.x : sc.major == 1 ? c.y : sc.major == 2 ? c.z : sc.major == 3 ? c.w : 0u;
   const uint32_t mc = sc.minor == 0 ? c.x : sc.minor == 1 ? c.y : sc.minor == 2 ? c.z : sc.minor == 3 ? c.w : 0u;
   const uint32_t sd = cmaj + mc;                             // the table reader bounds counts to 31 bits
-  __builtin_nontemporal_store(sd, &p.depth[(size_t)s * p.n_sites + i]);
-  __builtin_nontemporal_store(mc, &p.minor_count[(size_t)s * p.n_sites + i]);
-  if ((long long)sd < (long long)p.site_depth) return;
-  const double md = p.mean_depth[s];
-  if (md == 0.0) { acc.zero_div = true; return; }            // Python: ZeroDivisionError
-  if ((double)sd / md > p.site_ratio) return;
-  ++acc.pass;
+  store_u32(p.depth, p, s, i, sd);
+  store_u32(p.minor_count, p, s, i, mc);
+  // uniform, and read through the constant address space: scalar loads, not one vector load per thread
+  typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+  const ConstWords lw = (ConstWords)(uintptr_t)p.limit + 4 * s;
+  const SampleLimit l{lw[0], lw[1], lw[2], lw[3]};
+  acc.pass += (sd >= l.lo && sd <= l.hi) ? 1u : 0u;
+  acc.zero_div |= (l.zero_on && sd >= l.zero_from) ? 1u : 0u;
 }
 
 // flag (:106-114) and the per-site outputs
-__device__ __forceinline__ void finish_site(const MergeKParams& p, long long i, const unsigned long long (&pc)[4],
+__device__ __forceinline__ void finish_site(const MergeKParams& p, uint32_t i, const unsigned long long (&pc)[4],
                                             const SiteCall& sc, uint32_t pass, bool zero_div) {
   const double prevalence = (double)pass / (double)p.n_samples;
   int flag = 0;
@@ -92,29 +113,116 @@ __device__ __forceinline__ void finish_site(const MergeKParams& p, long long i, 
   else if (!(p.snp_types & 1) && !(sc.snp > 0 && (p.snp_types & (1 << sc.snp)))) flag = 2;
   p.calls[i] = (uint32_t)sc.major | ((uint32_t)sc.minor << 8) | ((uint32_t)sc.snp << 16) | ((uint32_t)flag << 24);
   p.count_samples[i] = pass;
-  reinterpret_cast<ulonglong2*>(p.pooled)[2 * i] = make_ulonglong2(pc[0], pc[1]);
-  reinterpret_cast<ulonglong2*>(p.pooled)[2 * i + 1] = make_ulonglong2(pc[2], pc[3]);
+  char* pool = reinterpret_cast<char*>(p.pooled) + (i * 32u);
+  reinterpret_cast<ulonglong2*>(pool)[0] = make_ulonglong2(pc[0], pc[1]);
+  reinterpret_cast<ulonglong2*>(pool)[1] = make_ulonglong2(pc[2], pc[3]);
   if (zero_div) atomicMin(p.err, (unsigned long long)i);
 }
 
 // Thread-per-site form: two passes over the site's count rows -- pooling, then per-sample depth.  The second pass hits
 // L2 / Infinity Cache while the rows of all resident threads fit there (up to a couple of dozen samples).
 __global__ __launch_bounds__(256) void merge_sites_kernel(MergeKParams p) {
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.n_sites; i += stride) {
-    const u32x4* cnt = reinterpret_cast<const u32x4*>(p.counts) + i;
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n_sites; i += stride) {
     unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll 8                                                 // eight independent row loads in flight per thread
     for (int s = 0; s < p.n_samples; ++s) {                      // compute_pooled_counts (:38-43)
-      const u32x4 c = cnt[(size_t)s * p.n_sites];
+      const u32x4 c = load_row(p, s, i);
       pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
     }
     const SiteCall sc = call_site(pc, p.allele_freq);
     SampleAcc acc;
 #pragma unroll 8
-    for (int s = 0; s < p.n_samples; ++s) sample_row(p, i, s, cnt[(size_t)s * p.n_sites], sc, acc);
-    finish_site(p, i, pc, sc, acc.pass, acc.zero_div);
+    for (int s = 0; s < p.n_samples; ++s) sample_row(p, i, s, load_row(p, s, i), sc, acc);
+    finish_site(p, i, pc, sc, acc.pass, acc.zero_div != 0u);
   }
+}
+
+// One-pass form: the site's rows stay in registers between the pooling and the per-sample pass, so every count row is
+// read from HBM exactly once (the two-pass form above re-reads them, and with a quarter of a million sites in flight
+// the second pass mostly misses L2: PMC 1.77 x the algorithmic reads at 8 samples).  What makes it fit: rows are packed
+// as they arrive -- up to 8 samples as they are (4 registers a row), above that two counts per register -- and a site
+// whose counts do not fit the packing (any count >= 2^16) takes the two-pass route for itself.  Loads go out eight rows
+// at a time.  The number of samples S is a template parameter: the rows are named registers, not an indexed array, and
+// the loads of a batch are straight-line code (with a run-time bound every load sat in its own branch behind an
+// s_waitcnt vmcnt(0): one row in flight per thread).
+template <int S>
+__global__ __launch_bounds__(256, S <= 40 ? 4 : (S <= 60 ? 3 : 2))   // <= 128 / 170 / 256 registers
+void merge_sites_regs_kernel(MergeKParams p) {
+  constexpr int BITS = S <= 8 ? 32 : 16;
+  constexpr int W = BITS == 32 ? 4 : 2;                         // registers per row
+  constexpr int LOADS = 8;
+  // counts below this bound take the fast route: they fit the packing, and S of them sum below 2^32, so the pooled
+  // counts are plain 32-bit adds (a 64-bit add is two instructions and a register pair per allele)
+  constexpr int kSmallBits = BITS == 32 ? 28 : 16;
+  static_assert(S <= 64 && ((unsigned long long)S << kSmallBits) <= (1ull << 32), "32-bit pooled sums");
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n_sites; i += stride) {
+    uint32_t sum[4] = {0u, 0u, 0u, 0u};
+    uint32_t row[S][W];
+    uint32_t big = 0u;
+#pragma unroll
+    for (int s0 = 0; s0 < S; s0 += LOADS) {
+      constexpr int kMaxBatch = LOADS < S ? LOADS : S;
+      u32x4 c[kMaxBatch];
+#pragma unroll
+      for (int k = 0; k < kMaxBatch; ++k)
+        if (s0 + k < S) c[k] = load_row(p, s0 + k, i);
+#pragma unroll
+      for (int k = 0; k < kMaxBatch; ++k) {
+        if (s0 + k < S) {
+          const int s = s0 + k;
+          sum[0] += c[k].x; sum[1] += c[k].y; sum[2] += c[k].z; sum[3] += c[k].w;  // compute_pooled_counts (:38-43)
+          big |= c[k].x | c[k].y | c[k].z | c[k].w;
+          if (BITS == 32) {
+            row[s][0] = c[k].x; row[s][1] = c[k].y; row[s][W > 2 ? 2 : 0] = c[k].z; row[s][W > 3 ? 3 : 0] = c[k].w;
+          } else {
+            row[s][0] = c[k].x | (c[k].y << 16);
+            row[s][1] = c[k].z | (c[k].w << 16);
+            // packed HERE: left alone, the compiler sinks the packing into the branch that uses it and keeps the raw
+            // rows (twice the registers) alive until then
+            asm volatile("" : "+v"(row[s][0]), "+v"(row[s][1]));
+          }
+        }
+      }
+      asm volatile("" : "+v"(big), "+v"(sum[0]), "+v"(sum[1]), "+v"(sum[2]), "+v"(sum[3]));
+      // the next loads go out behind this batch's packing, not in front of it: hoisting them all (what the scheduler
+      // does on its own) needs every raw row live at once
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned long long pc[4] = {sum[0], sum[1], sum[2], sum[3]};
+    SampleAcc acc;
+    if (big >> kSmallBits) {     // a large count: this site takes the two-pass route, with 64-bit sums
+      pc[0] = pc[1] = pc[2] = pc[3] = 0ull;
+#pragma unroll 1
+      for (int s = 0; s < S; ++s) {
+        const u32x4 c = load_row(p, s, i);
+        pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
+      }
+      const SiteCall sc = call_site(pc, p.allele_freq);
+#pragma unroll 1
+      for (int s = 0; s < S; ++s) sample_row(p, i, s, load_row(p, s, i), sc, acc);
+      finish_site(p, i, pc, sc, acc.pass, acc.zero_div != 0u);
+      continue;
+    }
+    const SiteCall sc = call_site(pc, p.allele_freq);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      u32x4 c;
+      if (BITS == 32) c = u32x4{row[s][0], row[s][1], row[s][W > 2 ? 2 : 0], row[s][W > 3 ? 3 : 0]};
+      else c = u32x4{row[s][0] & 0xFFFFu, row[s][0] >> 16, row[s][1] & 0xFFFFu, row[s][1] >> 16};
+      sample_row(p, i, s, c, sc, acc);
+    }
+    finish_site(p, i, pc, sc, acc.pass, acc.zero_div != 0u);
+  }
+}
+
+typedef void (*MergeKernel)(MergeKParams);
+template <int... S>
+constexpr MergeKernel regs_kernel_for(int n_samples, std::integer_sequence<int, S...>) {
+  MergeKernel k = nullptr;
+  (void)((n_samples == S + 1 ? (k = merge_sites_regs_kernel<S + 1>, true) : false) || ...);
+  return k;
 }
 
 // Several-threads-per-site form for many samples (BASELINE config 5 merges 50).  With dozens of samples the rows that all
@@ -130,7 +238,7 @@ __global__ __launch_bounds__(64 * G) void merge_sites_split_kernel(MergeKParams 
   __shared__ unsigned long long s_pool[2][4][T];
   __shared__ uint32_t s_pass[2][T], s_zero[2][T], s_call[T];
   const int tid = threadIdx.x, site_l = tid % T, g = tid / T;
-  const long long n_tiles = (p.n_sites + T - 1) / T;
+  const uint32_t n_tiles = (p.n_sites + T - 1) / T;
   if (tid < T) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -141,15 +249,15 @@ __global__ __launch_bounds__(64 * G) void merge_sites_split_kernel(MergeKParams 
   }
   __syncthreads();
   int par = 0;
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
-    const long long i = tile * T + site_l;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+    const uint32_t i = tile * T + site_l;
     const bool valid = i < p.n_sites;
-    const u32x4* cnt = reinterpret_cast<const u32x4*>(p.counts) + (valid ? i : 0);
+    const uint32_t ia = valid ? i : 0u;
     if (valid) {                                                 // compute_pooled_counts (:38-43), this wave's samples
       unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll 8
       for (int s = g; s < p.n_samples; s += G) {
-        const u32x4 c = cnt[(size_t)s * p.n_sites];
+        const u32x4 c = load_row(p, s, ia);
         pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
       }
       atomicAdd(&s_pool[par][0][site_l], pc[0]); atomicAdd(&s_pool[par][1][site_l], pc[1]);
@@ -168,7 +276,7 @@ __global__ __launch_bounds__(64 * G) void merge_sites_split_kernel(MergeKParams 
     if (valid) {                                                 // second pass over this wave's samples
       SampleAcc acc;
 #pragma unroll 8
-      for (int s = g; s < p.n_samples; s += G) sample_row(p, i, s, cnt[(size_t)s * p.n_sites], sc, acc);
+      for (int s = g; s < p.n_samples; s += G) sample_row(p, i, s, load_row(p, s, ia), sc, acc);
       if (acc.pass) atomicAdd(&s_pass[par][site_l], acc.pass);
       if (acc.zero_div) s_zero[par][site_l] = 1u;
     }
@@ -185,6 +293,34 @@ __global__ __launch_bounds__(64 * G) void merge_sites_split_kernel(MergeKParams 
       s_zero[par][site_l] = 0u;
     }
   }
+}
+
+// compute_prevalence (:93-104) keeps a sample's site when depth >= site_depth and depth / mean_depth <= site_ratio, and
+// divides by a mean depth of zero when one gets that far.  IEEE division is monotone in its numerator, so for a given
+// sample the depths that pass form one interval of integers: found here by bisection with the very expression the
+// reference evaluates (double division, then the comparison), which keeps the kernel free of 64-bit divisions and
+// the result identical for every depth, NaN and negative means included.
+SampleLimit sample_limits(double mean_depth, double site_ratio, int site_depth) {
+  const uint32_t kMax = 0xFFFFFFFFu;
+  const uint32_t from = site_depth > 0 ? (uint32_t)site_depth : 0u;
+  SampleLimit l{1u, 0u, 0u, 0u};                    // lo > hi: nothing passes
+  if (mean_depth == 0.0) { l.zero_on = 1u; l.zero_from = from; return l; }
+  auto keeps = [&](uint32_t depth) { return !((double)depth / mean_depth > site_ratio); };
+  const bool k0 = keeps(0u), k1 = keeps(kMax);
+  uint32_t lo = 0u, hi = kMax;
+  if (!k0 && !k1) return l;
+  if (k0 && !k1) {                                  // true on a prefix: the last depth that is kept
+    uint32_t a = 0u, b = kMax;                      // keeps(a), !keeps(b)
+    while (b - a > 1u) { const uint32_t m = a + (b - a) / 2u; (keeps(m) ? a : b) = m; }
+    hi = a;
+  } else if (!k0 && k1) {                           // true on a suffix (a negative mean): the first depth that is kept
+    uint32_t a = 0u, b = kMax;                      // !keeps(a), keeps(b)
+    while (b - a > 1u) { const uint32_t m = a + (b - a) / 2u; (keeps(m) ? b : a) = m; }
+    lo = b;
+  }
+  if (lo < from) lo = from;
+  l.lo = lo; l.hi = hi;
+  return l;
 }
 
 int32_t mfail(midas_snps_ctx* ctx, int32_t st, const char* what, hipError_t e) {
@@ -221,18 +357,21 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
   // sites are processed in chunks so that any number of samples fits: <= ~4 GiB of count tables at a time
   long long chunk = (long long)((4ull << 30) / (16ull * (unsigned long long)n_samples));
   if (chunk < 1024) chunk = 1024;
+  if (chunk > kMaxChunkSites) chunk = kMaxChunkSites;
   if (chunk > n_sites) chunk = n_sites > 0 ? n_sites : 1;
-  uint32_t* d_counts = nullptr; double* d_md = nullptr; uint32_t* d_b = nullptr; uint32_t* d_cs = nullptr;
+  std::vector<SampleLimit> limits((size_t)n_samples);
+  for (int s = 0; s < n_samples; ++s) limits[(size_t)s] = sample_limits(mean_depth[s], prm->site_ratio, prm->site_depth);
+  uint32_t* d_counts = nullptr; SampleLimit* d_md = nullptr; uint32_t* d_b = nullptr; uint32_t* d_cs = nullptr;
   unsigned long long* d_pool = nullptr; uint32_t* d_depth = nullptr; uint32_t* d_mc = nullptr; unsigned long long* d_err = nullptr;
   M_TRY(hipMalloc(&d_counts, (size_t)chunk * n_samples * 16)); dev.push_back(d_counts);
-  M_TRY(hipMalloc(&d_md, (size_t)n_samples * 8)); dev.push_back(d_md);
+  M_TRY(hipMalloc(&d_md, (size_t)n_samples * sizeof(SampleLimit))); dev.push_back(d_md);
   M_TRY(hipMalloc(&d_b, (size_t)chunk * 4)); dev.push_back(d_b);
   M_TRY(hipMalloc(&d_cs, (size_t)chunk * 4)); dev.push_back(d_cs);
   M_TRY(hipMalloc(&d_pool, (size_t)chunk * 32)); dev.push_back(d_pool);
   M_TRY(hipMalloc(&d_depth, (size_t)chunk * n_samples * 4)); dev.push_back(d_depth);
   M_TRY(hipMalloc(&d_mc, (size_t)chunk * n_samples * 4)); dev.push_back(d_mc);
   M_TRY(hipMalloc(&d_err, 8)); dev.push_back(d_err);
-  M_TRY(hipMemcpy(d_md, mean_depth, (size_t)n_samples * 8, hipMemcpyHostToDevice));
+  M_TRY(hipMemcpy(d_md, limits.data(), (size_t)n_samples * sizeof(SampleLimit), hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   M_TRY(hipEventCreate(&e0));
   M_TRY(hipEventCreate(&e1));
@@ -245,14 +384,19 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
                            hipMemcpyHostToDevice, ctx->stream));
     M_TRY(hipMemsetAsync(d_err, 0xFF, 8, ctx->stream));
     MergeKParams k;
-    k.counts = d_counts; k.mean_depth = d_md;
+    k.counts = d_counts; k.limit = d_md;
     k.calls = d_b;
     k.count_samples = d_cs; k.pooled = d_pool; k.depth = d_depth; k.minor_count = d_mc; k.err = d_err;
-    k.n_sites = m; k.n_samples = n_samples; k.site_depth = prm->site_depth; k.snp_types = prm->snp_types;
-    k.allele_freq = prm->allele_freq; k.site_ratio = prm->site_ratio; k.site_prev = prm->site_prev;
+    k.n_sites = (uint32_t)m; k.n_samples = n_samples; k.snp_types = prm->snp_types;
+    k.allele_freq = prm->allele_freq; k.site_prev = prm->site_prev;
     const int grid = (int)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096);
     M_TRY(hipEventRecord(e0, ctx->stream));
     const dim3 g(grid > 0 ? grid : 1), b(256);
+#ifndef MIDAS_MERGE_TWO_PASS
+    if (n_samples <= kRegsUpTo) {     // rows in registers: every count row is read once
+      hipLaunchKernelGGL(regs_kernel_for(n_samples, std::make_integer_sequence<int, kRegsUpTo>{}), g, b, 0, ctx->stream, k);
+    } else {
+#endif
     if (n_samples >= kSplitFrom) {
       // waves per site group: enough that the rows resident between the passes stay below ~100 MB
       const long long n_tiles = (m + 63) / 64;
@@ -263,6 +407,9 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
     } else {
       hipLaunchKernelGGL(merge_sites_kernel, g, b, 0, ctx->stream, k);
     }
+#ifndef MIDAS_MERGE_TWO_PASS   // (developer variants: the round-1 kernels, for A/B runs)
+    }
+#endif
     M_TRY(hipGetLastError());
     M_TRY(hipEventRecord(e1, ctx->stream));
     M_TRY(hipMemcpyAsync(out_calls + lo * 4, d_b, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -106,6 +106,51 @@ def test_many_samples(ctx, n_samples):
         assert np.array_equal(got[k], exp[k]), k
 
 
+@pytest.mark.parametrize("n_samples", [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 36, 40, 41, 60, 61, 64])
+def test_rows_held_in_registers(ctx, n_samples):
+    """Up to 64 samples the kernel keeps a site's rows in registers (as they are up to 8 samples, two counts per
+    register above), with 32-bit pooled sums; a site with a count past what that holds (2^28 / 2^16) goes the long way
+    round.  Counts on both sides of each bound, per sample count, against the oracle."""
+    rng = np.random.default_rng(500 + n_samples)
+    n = 1500
+    counts = [rng.poisson(6.0, (n, 4)).astype(np.int64) * (rng.random((n, 4)) < 0.5) for _ in range(n_samples)]
+    edge = [65535, 65536, 65537, 2**28 - 1, 2**28, 2**31 - 1, 255, 256]
+    for j, i in enumerate(range(0, n, 7)):
+        counts[(3 * j) % n_samples][i, j % 4] = edge[j % len(edge)]
+    for i in range(3, n, 50):          # every sample large at once: the pooled sums pass 2^32
+        for s in range(n_samples):
+            counts[s][i, 1] = 2**31 - 1 - s
+    counts = [c.astype(np.uint32) for c in counts]
+    mean = [5.0 + 0.37 * s for s in range(n_samples)]
+    args = dict(abi.DEFAULT_MERGE_ARGS, site_prev=0.3, site_ratio=3.0, snp_type=['bi', 'tri', 'quad'])
+    got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
+    exp = oracle_fields(counts, mean, args)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+
+
+@pytest.mark.parametrize("site_ratio", [2.0, 0.0, -1.0, 1e-9, 0.3333333333333333, 1e18, float('inf')])
+def test_depth_ratio_limits(ctx, site_ratio):
+    """compute_prevalence compares depth / mean_depth with site_ratio in floating point; the library turns that into
+    integer limits per sample before the launch.  Depths on both sides of every limit, means that make the quotient land
+    exactly on the ratio, tiny and huge means."""
+    mean = [2.5, 3.7, 0.1, 7.0 / 3.0, 1e-300, 1e300, 12.0, 1.0, 4.999999999999999, 5.000000000000001]
+    S = len(mean)
+    depth = np.r_[0:64, 2**31 - 64:2**31].astype(np.int64)
+    n = depth.size
+    counts = []
+    for s in range(S):
+        c = np.zeros((n, 4), np.int64)
+        c[:, 0] = np.roll(depth, s)          # A is the major allele everywhere, no minor allele: sample depth = c[:, 0]
+        counts.append(c.astype(np.uint32))
+    for site_depth in (0, 1, 5):
+        args = dict(abi.DEFAULT_MERGE_ARGS, site_ratio=site_ratio, site_depth=site_depth, site_prev=0.0, snp_type=['any'])
+        got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
+        exp = oracle_fields(counts, mean, args)
+        for k in exp:
+            assert np.array_equal(got[k], exp[k]), (k, site_depth)
+
+
 def test_merge_sites_edge_shapes(ctx):
     prm = abi.MergeParams.from_args(abi.DEFAULT_MERGE_ARGS)
     # no sites at all
