@@ -146,16 +146,21 @@ __global__ __launch_bounds__(256) void merge_sites_kernel(MergeKParams p) {
 // at a time.  The number of samples S is a template parameter: the rows are named registers, not an indexed array, and
 // the loads of a batch are straight-line code (with a run-time bound every load sat in its own branch behind an
 // s_waitcnt vmcnt(0): one row in flight per thread).
-template <int S>
+template <int S, bool PADDED>
 __global__ __launch_bounds__(256, S <= 40 ? 4 : (S <= 60 ? 3 : 2))   // <= 128 / 170 / 256 registers
 void merge_sites_regs_kernel(MergeKParams p) {
-  constexpr int BITS = S <= 8 ? 32 : 16;
-  constexpr int W = BITS == 32 ? 4 : 2;                         // registers per row
+  // registers per row and what a count must stay below for its site to take the fast route: the counts fit the packing,
+  // and S of them sum below 2^32, so the pooled counts are plain 32-bit adds (a 64-bit add is two instructions and a
+  // register pair per allele)
+  constexpr int BITS = S <= 8 ? 32 : (S <= 64 ? 16 : 8);
+  constexpr int W = BITS == 32 ? 4 : (BITS == 16 ? 2 : 1);
+  constexpr int kSmallBits = BITS == 32 ? 28 : BITS;
   constexpr int LOADS = 8;
-  // counts below this bound take the fast route: they fit the packing, and S of them sum below 2^32, so the pooled
-  // counts are plain 32-bit adds (a 64-bit add is two instructions and a register pair per allele)
-  constexpr int kSmallBits = BITS == 32 ? 28 : 16;
-  static_assert(S <= 64 && ((unsigned long long)S << kSmallBits) <= (1ull << 32), "32-bit pooled sums");
+  static_assert(S <= 128 && ((unsigned long long)S << kSmallBits) <= (1ull << 32), "32-bit pooled sums");
+  // PADDED: S is the sample count rounded up to a multiple of eight (one instantiation serves eight counts).  The rows
+  // past the last sample are read from sample 0's first site and multiplied away -- a load under `if (s < n_samples)`
+  // would sit in its own branch behind an s_waitcnt vmcnt(0), one row in flight per thread.
+  const int n_real = PADDED ? p.n_samples : S;
   const uint32_t stride = gridDim.x * 256u;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.n_sites; i += stride) {
     uint32_t sum[4] = {0u, 0u, 0u, 0u};
@@ -166,22 +171,33 @@ void merge_sites_regs_kernel(MergeKParams p) {
       constexpr int kMaxBatch = LOADS < S ? LOADS : S;
       u32x4 c[kMaxBatch];
 #pragma unroll
-      for (int k = 0; k < kMaxBatch; ++k)
-        if (s0 + k < S) c[k] = load_row(p, s0 + k, i);
+      for (int k = 0; k < kMaxBatch; ++k) {
+        if (s0 + k < S) {
+          const bool real = !PADDED || s0 + k < n_real;
+          c[k] = load_row(p, real ? s0 + k : 0, real ? i : 0u);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < kMaxBatch; ++k) {
         if (s0 + k < S) {
           const int s = s0 + k;
+          if (PADDED) {
+            const uint32_t keep = s < n_real ? 0xFFFFFFFFu : 0u;
+            c[k].x &= keep; c[k].y &= keep; c[k].z &= keep; c[k].w &= keep;
+          }
           sum[0] += c[k].x; sum[1] += c[k].y; sum[2] += c[k].z; sum[3] += c[k].w;  // compute_pooled_counts (:38-43)
           big |= c[k].x | c[k].y | c[k].z | c[k].w;
           if (BITS == 32) {
-            row[s][0] = c[k].x; row[s][1] = c[k].y; row[s][W > 2 ? 2 : 0] = c[k].z; row[s][W > 3 ? 3 : 0] = c[k].w;
-          } else {
+            row[s][0] = c[k].x; row[s][W > 1 ? 1 : 0] = c[k].y; row[s][W > 2 ? 2 : 0] = c[k].z; row[s][W > 3 ? 3 : 0] = c[k].w;
+          } else if (BITS == 16) {
             row[s][0] = c[k].x | (c[k].y << 16);
-            row[s][1] = c[k].z | (c[k].w << 16);
+            row[s][W > 1 ? 1 : 0] = c[k].z | (c[k].w << 16);
             // packed HERE: left alone, the compiler sinks the packing into the branch that uses it and keeps the raw
             // rows (twice the registers) alive until then
-            asm volatile("" : "+v"(row[s][0]), "+v"(row[s][1]));
+            asm volatile("" : "+v"(row[s][0]), "+v"(row[s][W > 1 ? 1 : 0]));
+          } else {
+            row[s][0] = c[k].x | (c[k].y << 8) | (c[k].z << 16) | (c[k].w << 24);
+            asm volatile("" : "+v"(row[s][0]));
           }
         }
       }
@@ -195,23 +211,26 @@ void merge_sites_regs_kernel(MergeKParams p) {
     if (big >> kSmallBits) {     // a large count: this site takes the two-pass route, with 64-bit sums
       pc[0] = pc[1] = pc[2] = pc[3] = 0ull;
 #pragma unroll 1
-      for (int s = 0; s < S; ++s) {
+      for (int s = 0; s < n_real; ++s) {
         const u32x4 c = load_row(p, s, i);
         pc[0] += c.x; pc[1] += c.y; pc[2] += c.z; pc[3] += c.w;
       }
       const SiteCall sc = call_site(pc, p.allele_freq);
 #pragma unroll 1
-      for (int s = 0; s < S; ++s) sample_row(p, i, s, load_row(p, s, i), sc, acc);
+      for (int s = 0; s < n_real; ++s) sample_row(p, i, s, load_row(p, s, i), sc, acc);
       finish_site(p, i, pc, sc, acc.pass, acc.zero_div != 0u);
       continue;
     }
     const SiteCall sc = call_site(pc, p.allele_freq);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      u32x4 c;
-      if (BITS == 32) c = u32x4{row[s][0], row[s][1], row[s][W > 2 ? 2 : 0], row[s][W > 3 ? 3 : 0]};
-      else c = u32x4{row[s][0] & 0xFFFFu, row[s][0] >> 16, row[s][1] & 0xFFFFu, row[s][1] >> 16};
-      sample_row(p, i, s, c, sc, acc);
+      if (!PADDED || s < n_real) {
+        u32x4 c;
+        if (BITS == 32) c = u32x4{row[s][0], row[s][W > 1 ? 1 : 0], row[s][W > 2 ? 2 : 0], row[s][W > 3 ? 3 : 0]};
+        else if (BITS == 16) c = u32x4{row[s][0] & 0xFFFFu, row[s][0] >> 16, row[s][W > 1 ? 1 : 0] & 0xFFFFu, row[s][W > 1 ? 1 : 0] >> 16};
+        else c = u32x4{row[s][0] & 0xFFu, (row[s][0] >> 8) & 0xFFu, (row[s][0] >> 16) & 0xFFu, row[s][0] >> 24};
+        sample_row(p, i, s, c, sc, acc);
+      }
     }
     finish_site(p, i, pc, sc, acc.pass, acc.zero_div != 0u);
   }
@@ -221,7 +240,14 @@ typedef void (*MergeKernel)(MergeKParams);
 template <int... S>
 constexpr MergeKernel regs_kernel_for(int n_samples, std::integer_sequence<int, S...>) {
   MergeKernel k = nullptr;
-  (void)((n_samples == S + 1 ? (k = merge_sites_regs_kernel<S + 1>, true) : false) || ...);
+  (void)((n_samples == S + 1 ? (k = merge_sites_regs_kernel<S + 1, false>, true) : false) || ...);
+  return k;
+}
+// 65..128 samples: one instantiation per eight counts, a byte per count
+template <int... E>
+constexpr MergeKernel bytes_kernel_for(int n_samples, std::integer_sequence<int, E...>) {
+  MergeKernel k = nullptr;
+  (void)(((n_samples + 7) / 8 == 9 + E ? (k = merge_sites_regs_kernel<8 * (9 + E), true>, true) : false) || ...);
   return k;
 }
 
@@ -359,6 +385,10 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
   if (chunk < 1024) chunk = 1024;
   if (chunk > kMaxChunkSites) chunk = kMaxChunkSites;
   if (chunk > n_sites) chunk = n_sites > 0 ? n_sites : 1;
+  // 65..128 samples: a byte per count holds a site's rows when the samples are shallow (a site with a count >= 256 takes
+  // the long way round by itself, which only pays while such sites are rare: mean depths well below 256)
+  bool shallow = true;
+  for (int s = 0; s < n_samples; ++s) shallow = shallow && mean_depth[s] <= 64.0;
   std::vector<SampleLimit> limits((size_t)n_samples);
   for (int s = 0; s < n_samples; ++s) limits[(size_t)s] = sample_limits(mean_depth[s], prm->site_ratio, prm->site_depth);
   uint32_t* d_counts = nullptr; SampleLimit* d_md = nullptr; uint32_t* d_b = nullptr; uint32_t* d_cs = nullptr;
@@ -395,6 +425,8 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
 #ifndef MIDAS_MERGE_TWO_PASS
     if (n_samples <= kRegsUpTo) {     // rows in registers: every count row is read once
       hipLaunchKernelGGL(regs_kernel_for(n_samples, std::make_integer_sequence<int, kRegsUpTo>{}), g, b, 0, ctx->stream, k);
+    } else if (n_samples <= 128 && kRegsUpTo >= 64 && shallow) {   // the same with a byte per count
+      hipLaunchKernelGGL(bytes_kernel_for(n_samples, std::make_integer_sequence<int, 8>{}), g, b, 0, ctx->stream, k);
     } else {
 #endif
     if (n_samples >= kSplitFrom) {

@@ -106,11 +106,12 @@ def test_many_samples(ctx, n_samples):
         assert np.array_equal(got[k], exp[k]), k
 
 
-@pytest.mark.parametrize("n_samples", [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 36, 40, 41, 60, 61, 64])
+@pytest.mark.parametrize("n_samples", [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 36, 40, 41, 60, 61, 64, 65, 72, 73, 100, 127, 128, 129])
 def test_rows_held_in_registers(ctx, n_samples):
-    """Up to 64 samples the kernel keeps a site's rows in registers (as they are up to 8 samples, two counts per
-    register above), with 32-bit pooled sums; a site with a count past what that holds (2^28 / 2^16) goes the long way
-    round.  Counts on both sides of each bound, per sample count, against the oracle."""
+    """Up to 128 samples the kernel keeps a site's rows in registers (as they are up to 8 samples, two counts per
+    register up to 64, four above -- shallow samples only), with 32-bit pooled sums; a site with a count past what that
+    holds (2^28 / 2^16 / 2^8) goes the long way round.  Counts on both sides of each bound, per sample count, against
+    the oracle.  (129 samples: the several-waves-per-site kernel.)"""
     rng = np.random.default_rng(500 + n_samples)
     n = 1500
     counts = [rng.poisson(6.0, (n, 4)).astype(np.int64) * (rng.random((n, 4)) < 0.5) for _ in range(n_samples)]
@@ -121,7 +122,7 @@ def test_rows_held_in_registers(ctx, n_samples):
         for s in range(n_samples):
             counts[s][i, 1] = 2**31 - 1 - s
     counts = [c.astype(np.uint32) for c in counts]
-    mean = [5.0 + 0.37 * s for s in range(n_samples)]
+    mean = [5.0 + 0.37 * (s % 64) for s in range(n_samples)]
     args = dict(abi.DEFAULT_MERGE_ARGS, site_prev=0.3, site_ratio=3.0, snp_type=['bi', 'tri', 'quad'])
     got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
     exp = oracle_fields(counts, mean, args)
@@ -149,6 +150,27 @@ def test_depth_ratio_limits(ctx, site_ratio):
         exp = oracle_fields(counts, mean, args)
         for k in exp:
             assert np.array_equal(got[k], exp[k]), (k, site_depth)
+
+
+def test_many_deep_samples(ctx):
+    """100 samples at 100x: past what a byte per count holds, so the several-waves-per-site kernel takes them."""
+    rng = np.random.default_rng(77)
+    n, S = 900, 100
+    counts = []
+    for s in range(S):
+        c = np.zeros((n, 4), np.int64)
+        depth = rng.poisson(100.0, n)
+        ref = rng.integers(0, 4, n)
+        na = np.where(rng.random(n) < 0.3, rng.binomial(depth, 0.25), 0)
+        c[np.arange(n), ref] = depth - na
+        c[np.arange(n), (ref + 1 + rng.integers(0, 3, n)) % 4] += na
+        counts.append(c.astype(np.uint32))
+    mean = [100.0 + s for s in range(S)]
+    args = dict(abi.DEFAULT_MERGE_ARGS, site_prev=0.5)
+    got = ctx.merge_sites(abi.MergeParams.from_args(args), counts, mean)
+    exp = oracle_fields(counts, mean, args)
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
 
 
 def test_merge_sites_edge_shapes(ctx):

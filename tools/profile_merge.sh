@@ -14,3 +14,4 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_p2 -o pmc -- $CMD > $OUT/p
 cd $REPO
 { echo "# $CMD"; grep RESULT $OUT/trace.log; python tools/summarize_prof.py $OUT | grep -v "^JSON"; } > $OUT/summary.txt
 cat $OUT/summary.txt
+rm -rf $OUT/trace $OUT/pmc_p1 $OUT/pmc_p2      # the rocpd databases are tens of MiB each; gpurun_out/ carries 64 MiB back
