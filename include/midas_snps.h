@@ -300,7 +300,9 @@ int32_t midas_bam_load_ranges(midas_bam* bam, int32_t n_ranges, const int64_t* r
  * rows `ref_id \t i+1 \t allele[i] \t A+C+G+T \t A \t C \t G \t T \n` for i in [0, n_sites).
  * append == 0 creates the file and writes the header line first; append != 0 appends gzip members
  * (concatenated members are one valid gzip stream).  Rows are formatted and deflated by `threads`
- * workers (0 = all cores) in 65 536-row members and written in order.                              */
+ * workers (0 = all hardware threads) in 16 384-row members and written in order.  gz_level 1-5: the library's row
+ * coder (midas_snps_deflate_rows below: smaller than zlib level 6 on these tables, several times faster);
+ * 6-9: zlib at that level; 0: stored.                                                              */
 int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
                               const uint8_t* allele, const uint32_t* counts, int32_t gz_level,
                               int32_t threads, char* err256);
@@ -319,6 +321,16 @@ int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* 
 int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
                               const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
                               int32_t gz_level, int32_t threads, char* err256);
+
+/* The row coder behind gz_level 1-5 of the writers above, on its own (tests and tools reach it here): a raw DEFLATE
+ * stream (RFC 1951, one final dynamic-Huffman block) for text[0, n) whose rows start at row_begin[k] and whose row
+ * tails -- the part that tends to repeat an earlier row: from the tab before ref_allele on -- start at tail_begin[k]
+ * (row_begin[k] <= tail_begin[k] < row_begin[k + 1], the last row ends at n).  One table lookup per row instead of
+ * zlib's hash chains: what utility.iopen's gzip.open(..., 'w') costs the reference (midas/utility.py:194-206,
+ * midas/run/snps.py:179-210).  Any inflater reads the result.  Returns the stream's bytes in out[0, *out_len);
+ * MIDAS_SNPS_ERR_INVALID_ARG when out_cap is too small (n + n/8 + 4096 always suffices).                          */
+int32_t midas_snps_deflate_rows(const uint8_t* text, int64_t n, const uint32_t* row_begin, const uint32_t* tail_begin,
+                                int64_t n_rows, uint8_t* out, int64_t out_cap, int64_t* out_len);
 
 /* Parser of one sample's <species>.snps.gz: replaces read_run_midas_snps + the per-line split of
  * build_temp_count_matrix (midas/merge/snps.py:236-271): per row the site key '|'.join(r[0:3]) and the counts

@@ -238,6 +238,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_table_count_rows': (i32, [C.c_char_p, C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
+        'midas_snps_deflate_rows': (i32, [vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
         'midas_snps_table_close': (None, [vp]),
         'midas_snps_table_rows': (i64, [vp]),
@@ -269,10 +270,25 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
-    'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part',
+    'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_deflate_rows',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
+
+
+def deflate_rows(text: bytes, row_begin, tail_begin) -> bytes:
+    """Raw DEFLATE stream of row-structured text by the library's row coder (midas_snps_deflate_rows)."""
+    lib = load_library()
+    buf = np.frombuffer(text, dtype=np.uint8)
+    rb = np.ascontiguousarray(row_begin, dtype=np.uint32)
+    tb = np.ascontiguousarray(tail_begin, dtype=np.uint32)
+    out = np.empty(len(text) + len(text) // 8 + 4096, dtype=np.uint8)
+    n_out = C.c_int64(0)
+    st = lib.midas_snps_deflate_rows(buf.ctypes.data, len(text), rb.ctypes.data, tb.ctypes.data, rb.size, out.ctypes.data,
+                                     out.size, C.byref(n_out))
+    if st != 0:
+        raise MidasSnpsError(st, "midas_snps_deflate_rows: bad row offsets or output too small")
+    return out[:n_out.value].tobytes()
 
 
 def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts: np.ndarray,

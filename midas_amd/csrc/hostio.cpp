@@ -5,6 +5,8 @@
 //     201-210 and utility.iopen, midas/utility.py:194-206)
 // No GPU involved; exported through the same C-ABI library (include/midas_snps.h, "host I/O" section).
 #include "hostio.h"
+#include "row_deflate.h"
+#include "workers.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -15,8 +17,12 @@
 #include <algorithm>
 #include <memory>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,6 +37,7 @@ struct RawBuf {
   RawBuf() = default;
   RawBuf(const RawBuf&) = delete;
   RawBuf& operator=(const RawBuf&) = delete;
+  RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
   ~RawBuf() { free(p); }
   bool resize(size_t m) {
     free(p);
@@ -115,6 +122,8 @@ struct midas_snps_table {
 
 namespace {
 
+using midas::Workers;
+
 void set_err(char* err256, const char* fmt, const char* a = "", long long b = 0) {
   if (err256) snprintf(err256, 256, fmt, a, b);
 }
@@ -130,14 +139,35 @@ int hw_threads(int want) {
   return (int)n;
 }
 
-// Threads of the row writer: the caller's --threads when given, else every core (capped at 128).
+// Threads of the row writer: the caller's --threads when given, else every core (capped at 128; 256 SMT threads
+// measured no faster on a 128-core host, 0.21 vs 0.23-0.29 s with zlib).
+#ifndef MIDAS_WRITER_MAX_THREADS
+#define MIDAS_WRITER_MAX_THREADS 128
+#endif
 int writer_threads(int want) {
   unsigned n = std::thread::hardware_concurrency();
   if (n == 0) n = 1;
   if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
-  if (n > 128) n = 128;
+  if (n > MIDAS_WRITER_MAX_THREADS) n = MIDAS_WRITER_MAX_THREADS;
   return (int)n;
 }
+
+// Developer variants (-DMIDAS_HOSTIO_TRACE): where the host stages spend their time, on stderr.
+struct Lap {
+#ifdef MIDAS_HOSTIO_TRACE
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  const char* who;
+  explicit Lap(const char* w) : who(w) {}
+  void operator()(const char* what) {
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[%s] %-34s %8.2f ms\n", who, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+#else
+  explicit Lap(const char*) {}
+  void operator()(const char*) {}
+#endif
+};
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
@@ -147,14 +177,31 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
   fseek(f, 0, SEEK_END);
   const long fsz = ftell(f);
   fseek(f, 0, SEEK_SET);
+  Lap lap("bam inflate");
   RawBuf<uint8_t> comp;
   if (!comp.resize((size_t)fsz)) { fclose(f); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  if (fsz > 0 && fread(comp.data(), 1, (size_t)fsz, f) != (size_t)fsz) {
+  {   // the file comes in through several threads: one core copies ~4 GB/s out of the page cache, a BAM is 100s of MB
+    const int fd = fileno(f);
+    const size_t piece = (size_t)8 << 20, n_pieces = ((size_t)fsz + piece - 1) / piece;
+    std::atomic<size_t> nextp{0};
+    std::atomic<int> short_read{0};
+    Workers::run((int)std::min<size_t>(n_pieces, 16), [&] {
+      for (;;) {
+        const size_t k = nextp.fetch_add(1);
+        if (k >= n_pieces) return;
+        size_t off = k * piece;
+        const size_t end = std::min((size_t)fsz, off + piece);
+        while (off < end) {
+          const ssize_t got = pread(fd, comp.data() + off, end - off, (off_t)off);
+          if (got <= 0) { short_read = 1; return; }
+          off += (size_t)got;
+        }
+      }
+    });
     fclose(f);
-    set_err(err256, "short read on %s", path.c_str());
-    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    if (short_read) { set_err(err256, "short read on %s", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   }
-  fclose(f);
+  lap("read file");
   struct Blk { size_t cpos, clen, upos, ulen; };
   std::vector<Blk> blocks;
   size_t p = 0, upos = 0;
@@ -181,6 +228,7 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     p += bsize;
   }
   if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  lap("block table");
   std::atomic<size_t> next{0};
   std::atomic<int> bad{0};
   auto work = [&] {
@@ -202,10 +250,8 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     }
   };
   const int nt = hw_threads(0);
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto& x : th) x.join();
+  Workers::run(nt, work);
+  lap("inflate blocks");
   if (bad) { set_err(err256, "%s: corrupt deflate data", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   return MIDAS_SNPS_OK;
 }
@@ -303,6 +349,32 @@ bool gz_member(const uint8_t* in, size_t n, int level, std::vector<uint8_t>& res
   return true;
 }
 
+// The same member around the row coder's stream (row_deflate.h): for table rows, whose structure the formatter knows.
+bool gz_member_rows(const uint8_t* in, size_t n, const uint32_t* row_begin, const uint32_t* tail_begin, size_t n_rows,
+                    std::vector<uint8_t>& result, uint32_t rows) {
+  static thread_local midas::RowDeflate coder;
+  static thread_local std::vector<uint8_t> out;
+  out.clear();
+  out.resize(kGzHeader);
+  coder.compress(in, n, row_begin, tail_begin, n_rows, out);
+  const size_t total = out.size() + 8;
+  if (total > 0xFFFFFFFFull) return false;
+  static const uint8_t fixed[10] = {0x1f, 0x8b, 8, 4 /* FEXTRA */, 0, 0, 0, 0, 0, 255};
+  memcpy(out.data(), fixed, 10);
+  const uint8_t extra[18] = {16, 0, 'M', 'S', 4, 0, (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16),
+                             (uint8_t)(total >> 24), 'M', 'R', 4, 0, (uint8_t)rows, (uint8_t)(rows >> 8),
+                             (uint8_t)(rows >> 16), (uint8_t)(rows >> 24)};
+  memcpy(out.data() + 10, extra, 18);
+  const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n);
+  const uint32_t isize = (uint32_t)n;
+  uint8_t tail[8];
+  memcpy(tail, &crc, 4);
+  memcpy(tail + 4, &isize, 4);
+  out.insert(out.end(), tail, tail + 8);
+  result.assign(out.begin(), out.end());
+  return true;
+}
+
 // fields: ref_id, ref_pos, ref_allele, depth, count_a, count_c, count_g, count_t (tab separated); the reference takes
 // r[0:3] for the site key and r[-4:] for the counts (midas/merge/snps.py:262-270)
 void parse_rows(const char* b, const char* end, bool want_keys, bool skip_first_line, ParsedRows& out) {
@@ -359,10 +431,7 @@ void run_pool(int nt, size_t n_tasks, F&& fn) {
     }
   };
   if ((size_t)nt > n_tasks) nt = (int)std::max<size_t>(1, n_tasks);
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto& x : th) x.join();
+  Workers::run(nt, work);
 }
 
 // ---- rank-local BAM decode: block table, slice walk with verified record-boundary guessing, range loads -------------------
@@ -454,21 +523,25 @@ struct BamWindow {
 // Could an alignment record start at uncompressed offset u?  Every fixed field must be plausible and the variable parts
 // must fit the record's own block_size.  (A guess that passes here is only ever TRUSTED after the walk of the slice before
 // it has ended on exactly this offset: midas_amd/run/snps.py checks that across ranks.)
-bool plausible_record(BamWindow& w, uint64_t u, const std::vector<int64_t>& ref_lens, uint32_t* block_size) {
-  if (!w.need(u, 36)) return false;
-  const uint8_t* r = w.at(u);
+// (r: the bytes from the candidate offset on, avail of them readable; *need: how many the full check wants, when
+// more than avail are needed the answer is "false" with *need set so that the caller can map more and ask again)
+bool plausible_bytes(const uint8_t* r, uint64_t avail, const std::vector<int64_t>& ref_lens, uint32_t* block_size, uint64_t* need) {
+  *need = 36;
+  if (avail < 36) return false;
   const uint32_t bs = rd32(r);
-  if (bs < 32 || bs > (1u << 26)) return false;
+  if (bs < 32 || bs > (1u << 26)) { *need = 0; return false; }
   const int32_t refid = (int32_t)rd32(r + 4), pos = (int32_t)rd32(r + 8);
   const uint32_t lrn = r[12], n_cig = rd16(r + 16), l = rd32(r + 20);
   const int32_t nref = (int32_t)rd32(r + 24), npos = (int32_t)rd32(r + 28);
   const int32_t n_ref = (int32_t)ref_lens.size();
+  *need = 0;
   if (refid < -1 || refid >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1) return false;
   if (refid >= 0 && pos > ref_lens[refid]) return false;
   if (lrn < 1 || l > (1u << 26)) return false;
   if ((uint64_t)32 + lrn + 4ull * n_cig + (l + 1) / 2 + l > bs) return false;
-  if (!w.need(u, 4 + 32 + lrn + 4ull * n_cig)) return false;
-  r = w.at(u);
+  *need = 4ull + 32 + lrn + 4ull * n_cig;
+  if (avail < *need) return false;
+  *need = 0;
   const uint8_t* name = r + 36;
   if (name[lrn - 1] != 0) return false;
   for (uint32_t k = 0; k + 1 < lrn; ++k)
@@ -478,6 +551,13 @@ bool plausible_record(BamWindow& w, uint64_t u, const std::vector<int64_t>& ref_
     if ((rd32(cg + 4 * k) & 15u) > 8u) return false;
   *block_size = bs;
   return true;
+}
+bool plausible_record(BamWindow& w, uint64_t u, const std::vector<int64_t>& ref_lens, uint32_t* block_size) {
+  if (!w.need(u, 36)) return false;
+  uint64_t need = 0;
+  if (plausible_bytes(w.at(u), 36, ref_lens, block_size, &need)) return true;
+  if (need <= 36 || !w.need(u, need)) return false;
+  return plausible_bytes(w.at(u), need, ref_lens, block_size, &need);
 }
 
 // The first offset >= from where `chain` records in a row are plausible (or the file ends exactly behind fewer).
@@ -509,21 +589,49 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
     set_err(err256, "out of memory decoding %s", b->path.c_str());
     return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   }
+  Lap lap("bam decode");
+  // sizes first, by all threads (every record header is a cache miss), then three running sums over contiguous arrays
   b->seq_off[0] = b->qual_off[0] = b->cigar_off[0] = 0;
-  for (size_t i = 0; i < n; ++i) {
-    const uint8_t* r = &d[offs[i] + 4];
-    const uint32_t bs = rd32(&d[offs[i]]);
-    const uint32_t l_read_name = r[8];
-    const uint32_t n_cig = rd16(r + 12);
-    const uint32_t l = rd32(r + 16);
-    if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
-      set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)i);
+  {
+    std::atomic<size_t> nexts{0};
+    std::atomic<long long> overrun{-1};
+    Workers::run(hw_threads(0), [&] {
+      for (;;) {
+        const size_t lo = nexts.fetch_add(8192);
+        if (lo >= n) return;
+        const size_t hi = std::min(n, lo + 8192);
+        for (size_t i = lo; i < hi; ++i) {
+          const uint8_t* r = &d[offs[i] + 4];
+          const uint32_t bs = rd32(&d[offs[i]]);
+          const uint32_t l_read_name = r[8];
+          const uint32_t n_cig = rd16(r + 12);
+          const uint32_t l = rd32(r + 16);
+          if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
+            long long none = -1;
+            overrun.compare_exchange_strong(none, (long long)i);
+          }
+          b->cigar_off[i + 1] = n_cig;
+          b->seq_off[i + 1] = (l + 1) / 2;
+          b->qual_off[i + 1] = l;
+        }
+      }
+    });
+    if (overrun.load() >= 0) {
+      long long first = overrun.load();      // report the lowest one, as a serial walk would
+      for (size_t i = 0; i < (size_t)first; ++i) {
+        const uint8_t* r = &d[offs[i] + 4];
+        if ((uint64_t)32 + r[8] + 4ull * rd16(r + 12) + (rd32(r + 16) + 1) / 2 + rd32(r + 16) > rd32(&d[offs[i]])) { first = (long long)i; break; }
+      }
+      set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), first);
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
-    b->cigar_off[i + 1] = b->cigar_off[i] + n_cig;
-    b->seq_off[i + 1] = b->seq_off[i] + (l + 1) / 2;
-    b->qual_off[i + 1] = b->qual_off[i] + l;
+    for (size_t i = 0; i < n; ++i) {
+      b->cigar_off[i + 1] += b->cigar_off[i];
+      b->seq_off[i + 1] += b->seq_off[i];
+      b->qual_off[i + 1] += b->qual_off[i];
+    }
   }
+  lap("record sizes + offsets");
   if (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n])) {
     set_err(err256, "out of memory decoding %s", b->path.c_str());
     return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
@@ -557,11 +665,108 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
     }
   };
   const int nt = hw_threads(0);
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(work);
-  work();
-  for (auto& x : th) x.join();
+  Workers::run(nt, work);
+  lap("columns");
   b->loaded = true;
+  return MIDAS_SNPS_OK;
+}
+
+// Offsets of the alignment records with refID >= 0 in an inflated BAM stream.  The records form a chain (each one's
+// block_size leads to the next), a million dependent cache misses when one core walks it.  Here every thread guesses a
+// record boundary inside its piece of the stream (the first offset where eight plausible records follow one another),
+// walks from there to the next piece's guess, and the pieces are then stitched IN ORDER: a piece's walk counts only if
+// the chain that started at the true first record ended on exactly its guess -- then the guess was a true boundary and
+// the walk is the one a single core would have made.  A piece whose guess the chain does not hit is walked again from
+// where the chain stands (nothing is ever taken on plausibility alone).
+int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std::vector<int64_t>& ref_lens,
+                     std::vector<size_t>& offs, const char* path, char* err256) {
+  struct Piece { size_t start = 0, end = 0, bad_at = 0; bool bad = false; std::vector<size_t> offs; };
+  auto walk = [&](size_t p, size_t stop, Piece& pc) {     // records starting in [p, stop); pc.end = first start >= stop
+    while (p + 4 <= total && p < stop) {
+      const size_t bs = rd32(&d[p]);
+      if (bs < 32 || p + 4 + bs > total) { pc.bad = true; pc.bad_at = p; break; }
+      if ((int32_t)rd32(&d[p + 4]) >= 0) pc.offs.push_back(p);
+      p += 4 + bs;
+    }
+    pc.end = p;
+  };
+  const int nt = hw_threads(0);
+  const size_t span = total > rec_begin ? total - rec_begin : 0;
+  size_t n_pieces = std::min<size_t>((size_t)nt * 4, span / ((size_t)1 << 20));
+  if (n_pieces < 2) {
+    Piece all;
+    walk(rec_begin, total, all);
+    if (all.bad) { set_err(err256, "%s: truncated alignment record at byte %lld", path, (long long)all.bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    offs.swap(all.offs);
+    return MIDAS_SNPS_OK;
+  }
+  const size_t per = span / n_pieces;
+  std::vector<size_t> guess(n_pieces);
+  std::atomic<size_t> next{0};
+  Workers::run(nt, [&] {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= n_pieces) return;
+      if (k == 0) { guess[0] = rec_begin; continue; }
+      size_t u = rec_begin + k * per;
+      const size_t limit = std::min(total, u + per);      // a piece without a boundary of its own joins the one before
+      size_t found = total;
+      for (; u < limit; ++u) {
+        size_t v = u;
+        int ok = 0;
+        while (ok < 8 && v != total) {
+          uint32_t bs = 0;
+          uint64_t need = 0;
+          if (!plausible_bytes(d + v, total - v, ref_lens, &bs, &need) || v + 4ull + bs > total) { ok = -1; break; }
+          v += 4ull + bs;
+          ++ok;
+        }
+        if (ok >= 0) { found = u; break; }
+      }
+      guess[k] = found;
+    }
+  });
+  std::vector<Piece> pieces;
+  for (size_t k = 0; k < n_pieces; ++k)
+    if (guess[k] < total && (pieces.empty() || guess[k] > pieces.back().start)) { pieces.emplace_back(); pieces.back().start = guess[k]; }
+  next = 0;
+  Workers::run(nt, [&] {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= pieces.size()) return;
+      pieces[k].offs.reserve(per / 200);
+      walk(pieces[k].start, k + 1 < pieces.size() ? pieces[k + 1].start : total, pieces[k]);
+    }
+  });
+  size_t cur = rec_begin, n_total = 0;
+  std::vector<Piece> redo(pieces.size());
+  std::vector<const Piece*> use(pieces.size(), nullptr);
+  for (size_t k = 0; k < pieces.size(); ++k) {
+    const Piece* pc = &pieces[k];
+    if (cur != pc->start) {                 // the chain did not arrive on this piece's guess: walk it from the chain's position
+      const size_t stop = k + 1 < pieces.size() ? pieces[k + 1].start : total;
+      if (cur < stop) walk(cur, stop, redo[k]); else redo[k].end = cur;
+      pc = &redo[k];
+#ifdef MIDAS_HOSTIO_TRACE
+      fprintf(stderr, "[bam load] piece %zu of %zu walked again: guess %zu, chain at %zu\n", k, pieces.size(), pieces[k].start, cur);
+#endif
+    }
+    if (pc->bad) { set_err(err256, "%s: truncated alignment record at byte %lld", path, (long long)pc->bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    use[k] = pc;
+    n_total += pc->offs.size();
+    cur = pc->end;
+  }
+  offs.resize(n_total);
+  std::vector<size_t> at(pieces.size() + 1, 0);
+  for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + use[k]->offs.size();
+  next = 0;
+  Workers::run(nt, [&] {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= pieces.size()) return;
+      if (!use[k]->offs.empty()) memcpy(offs.data() + at[k], use[k]->offs.data(), use[k]->offs.size() * sizeof(size_t));
+    }
+  });
   return MIDAS_SNPS_OK;
 }
 
@@ -647,20 +852,17 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
   if (!b->loaded) {
     const RawBuf<uint8_t>& d = b->data;
     // pass 1: record offsets (what fetch(contig, ...) can ever return: refID >= 0)
+    Lap lap("bam load");
     std::vector<size_t> offs;
-    size_t p = b->rec_begin;
-    while (p + 4 <= d.size()) {
-      const size_t bs = rd32(&d[p]);
-      if (bs < 32 || p + 4 + bs > d.size()) {
-        set_err(err256, "%s: truncated alignment record at byte %lld", b->path.c_str(), (long long)p);
-        return MIDAS_SNPS_ERR_BAD_LAYOUT;
-      }
-      if ((int32_t)rd32(&d[p + 4]) >= 0) offs.push_back(p);
-      p += 4 + bs;
-    }
+    const int32_t wst = walk_records(d.data(), d.size(), b->rec_begin, b->ref_lens, offs, b->path.c_str(), err256);
+    if (wst != MIDAS_SNPS_OK) return wst;
+    lap("record walk");
     const int32_t st = decode_records(b, d.data(), offs, err256);
     if (st != MIDAS_SNPS_OK) return st;
-    b->data.release();   // the inflated stream is no longer needed
+    lap("decode_records");
+    // the inflated stream is no longer needed; unmapping hundreds of MB takes ~10 ms, which nobody has to wait for
+    std::thread([](RawBuf<uint8_t> gone) { gone.release(); }, std::move(b->data)).detach();
+    lap("release");
   }
   if (n_reads) *n_reads = (int64_t)b->n_records;
   if (seq_bytes) *seq_bytes = (int64_t)b->seq4.size();
@@ -1076,6 +1278,7 @@ namespace {
 int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const char* const* ref_ids,
                       const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
                       int32_t gz_level, int32_t threads, char* err256, bool header = true) {
+  Lap lap("write rows");
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   if (gz_level < 0 || gz_level > 9) gz_level = 6;
@@ -1103,8 +1306,12 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
   for (auto& d : done) d = 0;
   std::atomic<int64_t> next{0};
   std::atomic<int> bad{0};
+  // levels 1-5: the row coder (row_deflate.h: one table lookup per row, about zlib level 4's size at a fraction of its
+  // time); 6-9: zlib at that level; 0: zlib, stored
+  const bool row_coder = gz_level >= 1 && gz_level <= 5;
   auto work = [&] {
     std::vector<char> text;
+    std::vector<uint32_t> row_at, tail_at;
     for (;;) {
       const int64_t ci = next.fetch_add(1);
       if (ci >= n_chunks) return;
@@ -1114,11 +1321,15 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       const uint8_t* al = allele[ch.contig];
       const uint32_t* cn = counts[ch.contig];
       text.resize((size_t)(ch.hi - ch.lo) * (il + 80));
+      row_at.resize((size_t)(ch.hi - ch.lo));
+      tail_at.resize((size_t)(ch.hi - ch.lo));
       char* p = text.data();
       for (int64_t i = ch.lo; i < ch.hi; ++i) {
         // row = [contig.id, i+1, seq[i], depth, A, C, G, T] joined by tabs (midas/run/snps.py:202-210)
+        row_at[(size_t)(i - ch.lo)] = (uint32_t)(p - text.data());
         memcpy(p, id, il); p += il;
         *p++ = '\t'; p = put_u64(p, (uint64_t)(i + 1));
+        tail_at[(size_t)(i - ch.lo)] = (uint32_t)(p - text.data());
         *p++ = '\t'; *p++ = (char)al[i];
         const uint32_t* c = cn + 4 * i;
         *p++ = '\t'; p = put_u64(p, (uint64_t)c[0] + c[1] + c[2] + c[3]);
@@ -1128,28 +1339,53 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
         *p++ = '\t'; p = put_u32(p, c[3]);
         *p++ = '\n';
       }
-      if (!gz_member(reinterpret_cast<const uint8_t*>(text.data()), (size_t)(p - text.data()), gz_level, zbuf[(size_t)ci],
-                     (uint32_t)(ch.hi - ch.lo)))
-        bad = 1;
+      const uint8_t* t8 = reinterpret_cast<const uint8_t*>(text.data());
+      const size_t tn = (size_t)(p - text.data());
+      const bool done_ok = row_coder ? gz_member_rows(t8, tn, row_at.data(), tail_at.data(), row_at.size(), zbuf[(size_t)ci], (uint32_t)(ch.hi - ch.lo))
+                                     : gz_member(t8, tn, gz_level, zbuf[(size_t)ci], (uint32_t)(ch.hi - ch.lo));
+      if (!done_ok) bad = 1;
       done[(size_t)ci] = 1;
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back(work);
-  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-    while (!done[(size_t)ci].load()) std::this_thread::yield();
-    if (bad) { ok = false; break; }
-    std::vector<uint8_t>& z = zbuf[(size_t)ci];
-    ok = fwrite(z.data(), 1, z.size(), f) == z.size();
-    std::vector<uint8_t>().swap(z);
-  }
-  if (!ok) next = n_chunks;   // stop the pool
-  for (auto& x : th) x.join();
+  // one thread writes the finished chunks in order while the others format / compress the next ones
+  auto drain = [&] {
+    for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      if (bad) { ok = false; break; }
+      std::vector<uint8_t>& z = zbuf[(size_t)ci];
+      ok = fwrite(z.data(), 1, z.size(), f) == z.size();
+      std::vector<uint8_t>().swap(z);
+    }
+    if (!ok) next = n_chunks;   // stop the pool
+  };
+  std::atomic<int> role{0};
+  lap("setup");
+  Workers::run(nt + 1, [&] { if (role.fetch_add(1) == 0) drain(); else work(); });
+  lap("format + gzip + write");
   if (fclose(f) != 0) ok = false;
+  lap("fclose");
   if (!ok || bad) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   return MIDAS_SNPS_OK;
 }
 }  // namespace
+
+int32_t midas_snps_deflate_rows(const uint8_t* text, int64_t n, const uint32_t* row_begin, const uint32_t* tail_begin,
+                                int64_t n_rows, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+  if (!text || n <= 0 || n > 0x7FFFFFFFll || n_rows < 0 || (n_rows > 0 && (!row_begin || !tail_begin)) || !out || !out_len)
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  for (int64_t k = 0; k < n_rows; ++k) {
+    const int64_t end = k + 1 < n_rows ? (int64_t)row_begin[k + 1] : n;
+    if ((k == 0 ? 0 : (int64_t)row_begin[k - 1]) > (int64_t)row_begin[k] || row_begin[k] > tail_begin[k] || (int64_t)tail_begin[k] >= end)
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+  }
+  std::vector<uint8_t> z;
+  midas::RowDeflate coder;
+  coder.compress(text, (size_t)n, row_begin, tail_begin, (size_t)n_rows, z);
+  if ((int64_t)z.size() > out_cap) return MIDAS_SNPS_ERR_INVALID_ARG;
+  memcpy(out, z.data(), z.size());
+  *out_len = (int64_t)z.size();
+  return MIDAS_SNPS_OK;
+}
 
 int32_t midas_snps_write_rows(const char* path, int32_t append, const char* ref_id, int64_t n_sites,
                               const uint8_t* allele, const uint32_t* counts, int32_t gz_level, int32_t threads,
@@ -1224,16 +1460,18 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
       done[(size_t)ci] = 1;
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back(work);
-  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-    while (!done[(size_t)ci].load()) std::this_thread::yield();
-    std::vector<char>& t = text[(size_t)ci];
-    ok = fwrite(t.data(), 1, t.size(), f) == t.size();
-    std::vector<char>().swap(t);
-  }
-  if (!ok) next = n_chunks;
-  for (auto& x : th) x.join();
+  // one thread writes the finished chunks in order while the others format / compress the next ones
+  auto drain = [&] {
+    for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      std::vector<char>& t = text[(size_t)ci];
+      ok = fwrite(t.data(), 1, t.size(), f) == t.size();
+      std::vector<char>().swap(t);
+    }
+    if (!ok) next = n_chunks;
+  };
+  std::atomic<int> role{0};
+  Workers::run(nt + 1, [&] { if (role.fetch_add(1) == 0) drain(); else work(); });
   if (fclose(f) != 0) ok = false;
   if (!ok) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   return MIDAS_SNPS_OK;
@@ -1365,16 +1603,18 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
       done[(size_t)ci] = 1;
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back(work);
-  for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-    while (!done[(size_t)ci].load()) std::this_thread::yield();
-    std::string& t = text[(size_t)ci];
-    ok = fwrite(t.data(), 1, t.size(), f) == t.size();
-    std::string().swap(t);
-  }
-  if (!ok) next = n_chunks;
-  for (auto& x : th) x.join();
+  // one thread writes the finished chunks in order while the others format / compress the next ones
+  auto drain = [&] {
+    for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
+      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      std::string& t = text[(size_t)ci];
+      ok = fwrite(t.data(), 1, t.size(), f) == t.size();
+      std::string().swap(t);
+    }
+    if (!ok) next = n_chunks;
+  };
+  std::atomic<int> role{0};
+  Workers::run(nt + 1, [&] { if (role.fetch_add(1) == 0) drain(); else work(); });
   if (fclose(f) != 0) ok = false;
   if (!ok) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   return MIDAS_SNPS_OK;

@@ -2,6 +2,7 @@
 // for the contract and the reference lines each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -18,6 +19,7 @@
 #include "kernels.h"
 #include "layout.h"
 #include "pack.h"
+#include "workers.h"
 
 #include <algorithm>
 
@@ -167,14 +169,15 @@ void parallel_copy(uint8_t* dst, const uint8_t* src, size_t n) {
   size_t nt = hw >= 32 ? 12 : (hw >= 8 ? 4 : 1);
   if (n < ((size_t)4 << 20)) nt = 1;
   if (nt == 1) { memcpy(dst, src, n); return; }
-  std::vector<std::thread> th;
   const size_t per = ((n + nt - 1) / nt + 63) & ~(size_t)63;
-  for (size_t t = 0; t < nt; ++t) {
-    const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
-    if (lo >= hi) break;
-    th.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
-  }
-  for (auto& x : th) x.join();
+  std::atomic<size_t> next{0};
+  midas::Workers::run((int)nt, [&] {
+    for (;;) {
+      const size_t lo = next.fetch_add(1) * per, hi = lo + per < n ? lo + per : n;
+      if (lo >= hi) return;
+      memcpy(dst + lo, src + lo, hi - lo);
+    }
+  });
 }
 
 int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t bytes) {

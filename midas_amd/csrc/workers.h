@@ -1,0 +1,93 @@
+// Worker threads shared by the host-side parallel regions of the library (hostio.cpp, snps_abi.hip).
+#pragma once
+#include <unistd.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace midas {
+
+// The library's worker threads.  Every parallel region of the host code (inflate, record decode, row formatting + gzip, table
+// parsing) used to start its own std::threads and join them: on a 256-thread host that is ~130 thread starts per region,
+// several regions per species.  Here the threads are started once and parked on a condition variable between regions.
+// One region runs at a time; a caller that finds the pool taken (another Python thread inside the library) starts
+// threads of its own, as before.  The pool is never torn down (the parked threads end with the process) and is rebuilt in
+// a forked child, where the parent's threads do not exist.
+class Workers {
+ public:
+  // work() runs on nt threads in all (the caller is one of them); returns when every one of them has returned
+  static void run(int nt, const std::function<void()>& work) {
+    if (nt <= 1) { work(); return; }
+    Workers* w = instance();
+    std::unique_lock<std::mutex> region(w->region_, std::try_to_lock);
+    if (!region.owns_lock()) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t) th.emplace_back(work);
+      work();
+      for (auto& x : th) x.join();
+      return;
+    }
+    w->start(nt - 1, &work);
+    work();
+    w->finish();
+  }
+
+ private:
+  static Workers* instance() {
+    static std::mutex make;
+    std::lock_guard<std::mutex> g(make);
+    static Workers* self = nullptr;
+    if (!self || self->pid_ != getpid()) self = new Workers();   // (a forked child leaks the parent's object)
+    return self;
+  }
+  Workers() : pid_(getpid()) {}
+  void start(int n, const std::function<void()>* job) {
+    std::unique_lock<std::mutex> g(m_);
+    while ((int)th_.size() < n) {
+      const int id = (int)th_.size();
+      th_.emplace_back([this, id] { loop(id); });
+      th_.back().detach();
+    }
+    job_ = job;
+    want_ = n;
+    left_ = n;
+    ++gen_;
+    g.unlock();
+    wake_.notify_all();
+  }
+  void finish() {
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+  void loop(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void()>* job;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        wake_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (id >= want_) continue;
+        job = job_;
+      }
+      (*job)();
+      std::lock_guard<std::mutex> g(m_);
+      if (--left_ == 0) done_.notify_one();
+    }
+  }
+  const pid_t pid_;
+  std::mutex region_, m_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void()>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int want_ = 0, left_ = 0;
+};
+
+
+}  // namespace midas

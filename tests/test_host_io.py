@@ -32,6 +32,95 @@ def test_bam_round_trip_through_native_decoder(tmp_path):
         np.testing.assert_array_equal(getattr(got, k), getattr(reads, k), err_msg=k)
 
 
+def _rewrite_bgzf(src, dst, edit):
+    """inflate a BAM, let `edit` change the byte stream, write it back as BGZF blocks"""
+    import gzip
+    raw = bytearray(gzip.open(src, 'rb').read())
+    raw = edit(raw)
+    with open(dst, 'wb') as f:
+        for lo in range(0, len(raw), 60000):
+            f.write(bam._bgzf_block(bytes(raw[lo:lo + 60000])))
+        f.write(bam._bgzf_block(b""))
+
+
+def test_large_bam_goes_through_the_parallel_record_walk(tmp_path):
+    """Above a few MB of inflated records the decoder finds record boundaries inside the stream and walks the pieces on
+    all cores, stitched in order (hostio.cpp walk_records): the result must be the serial walk's, i.e. what was written --
+    also when bytes that look like a run of records sit inside a read's qualities, and when the stream is cut short."""
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=40000, n_reads=50000, seed=21, var_len=True)
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+    names = ["r%d%s" % (i, "x" * (i % 23)) for i in range(reads.n_reads)]       # record sizes differ read to read
+    path = str(tmp_path / "big.bam")
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, read_names=names)
+    _, _, rid, got = abi.read_bam(path)
+    np.testing.assert_array_equal(rid, refid)
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(got, k), getattr(reads, k), err_msg=k)
+
+    cut = str(tmp_path / "cut.bam")
+    _rewrite_bgzf(path, cut, lambda raw: raw[:len(raw) - 11])
+    with pytest.raises(abi.MidasSnpsError) as e:
+        abi.read_bam(cut)
+    assert "truncated alignment record" in e.value.message
+
+
+def test_record_walk_is_not_fooled_by_bytes_that_look_like_records(tmp_path):
+    """White box: walk_records cuts the inflated stream into min(4 x threads, MiB) pieces and scans forward from every cut
+    for eight plausible records in a row.  Here the QUAL bytes of the reads that straddle those cuts spell eight
+    well-formed tiny records, so the scans find them before the next true record; the stitching must notice that the
+    true chain does not arrive there and walk those pieces again."""
+    import gzip
+    import os
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=3, contig_len=60000, n_reads=30000, read_len=320,
+                                        seed=22, var_len=False)
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+    path = str(tmp_path / "plain.bam")
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads)
+    raw = gzip.open(path, 'rb').read()
+    # header: magic, l_text, text, n_ref, then per reference l_name, name, l_ref
+    p = 8 + int(np.frombuffer(raw, '<i4', 1, 4)[0])
+    n_ref = int(np.frombuffer(raw, '<i4', 1, p)[0]); p += 4
+    for _ in range(n_ref):
+        p += 4 + int(np.frombuffer(raw, '<i4', 1, p)[0]) + 4
+    rec_begin, total = p, len(raw)
+    starts = []
+    while p < total:
+        starts.append(p)
+        p += 4 + int(np.frombuffer(raw, '<i4', 1, p)[0])
+    starts = np.array(starts)
+    nt = min(os.cpu_count() or 1, 128)
+    span = total - rec_begin
+    n_pieces = min(nt * 4, span >> 20)
+    assert n_pieces >= 8
+    per = span // n_pieces
+    fake = bytearray()
+    for k in range(8):
+        rec = bytearray(33)
+        rec[0:4] = np.int32(0).tobytes(); rec[4:8] = np.int32(5 + k).tobytes()       # refID 0, pos
+        rec[8] = 1; rec[9] = 30                                                      # l_read_name 1 (just the NUL), mapq
+        rec[20:24] = np.int32(-1).tobytes(); rec[24:28] = np.int32(-1).tobytes()     # next refID, next pos
+        fake += np.int32(len(rec)).tobytes() + rec
+    placed = 0
+    qual = reads.qual.copy()
+    for k in range(1, n_pieces):
+        u = rec_begin + k * per
+        i = int(np.searchsorted(starts, u, side='right')) - 1      # the record this cut falls into
+        qual_at = int(starts[i]) + 4 + 32 + raw[int(starts[i]) + 12] + 4 * int(np.frombuffer(raw, '<u2', 1, int(starts[i]) + 16)[0]) + 160
+        if u <= qual_at:                                           # the scan from u reaches this read's QUAL first
+            q0 = int(reads.qual_off[i])
+            qual[q0:q0 + len(fake)] = np.frombuffer(bytes(fake), np.uint8)
+            placed += 1
+    assert placed >= 2
+    decoyed = abi.ReadsSoA(**{**reads.as_dict(), 'qual': qual})
+    path2 = str(tmp_path / "decoy.bam")
+    bam.write_bam(path2, contigs.ids, [int(x) for x in contigs.length], refid, decoyed)
+    assert len(gzip.open(path2, 'rb').read()) == total
+    _, _, rid, got = abi.read_bam(path2)
+    np.testing.assert_array_equal(rid, refid)
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(got, k), getattr(decoyed, k), err_msg=k)
+
+
 def test_bam_decoder_rejects_garbage(tmp_path):
     p = tmp_path / "bad.bam"
     p.write_bytes(b"this is not a bam file at all")

@@ -7,6 +7,6 @@ set -e
 SUF=$1; shift
 cd "$(dirname "$0")/.."
 C=midas_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-atomic-optimizer-strategy=None -x hip "$@" $C/pack.cpp $C/hostio.cpp $C/pack_reads.hip $C/index_reads.hip \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-atomic-optimizer-strategy=None -x hip "$@" $C/pack.cpp $C/hostio.cpp $C/row_deflate.cpp $C/pack_reads.hip $C/index_reads.hip \
   $C/pileup_tiles.hip $C/pileup_stream.hip $C/merge_sites.hip $C/genes_count.hip $C/snps_abi.hip -o midas_amd/lib/libmidas_snps_hip_$SUF.so -lz -lpthread
 echo built midas_amd/lib/libmidas_snps_hip_$SUF.so
