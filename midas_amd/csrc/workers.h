@@ -19,7 +19,10 @@ namespace midas {
 // a forked child, where the parent's threads do not exist.
 class Workers {
  public:
-  // work() runs on nt threads in all (the caller is one of them); returns when every one of them has returned
+  // work() runs on up to nt threads (the caller is one of them) and must be written as "claim the next item until none
+  // is left": the region ends when the caller's own work() has returned and every pool thread that started on it has
+  // returned too.  A pool thread the host was slow to wake (a busy machine can take tens of milliseconds) finds the
+  // region closed and goes back to sleep -- nobody waits for a thread that has nothing left to do.
   static void run(int nt, const std::function<void()>& work) {
     if (nt <= 1) { work(); return; }
     Workers* w = instance();
@@ -31,9 +34,9 @@ class Workers {
       for (auto& x : th) x.join();
       return;
     }
-    w->start(nt - 1, &work);
+    w->open(nt - 1, &work);
     work();
-    w->finish();
+    w->close();
   }
 
  private:
@@ -45,7 +48,7 @@ class Workers {
     return self;
   }
   Workers() : pid_(getpid()) {}
-  void start(int n, const std::function<void()>* job) {
+  void open(int n, const std::function<void()>* job) {
     std::unique_lock<std::mutex> g(m_);
     while ((int)th_.size() < n) {
       const int id = (int)th_.size();
@@ -54,14 +57,16 @@ class Workers {
     }
     job_ = job;
     want_ = n;
-    left_ = n;
+    inside_ = 0;
+    is_open_ = true;
     ++gen_;
     g.unlock();
     wake_.notify_all();
   }
-  void finish() {
+  void close() {
     std::unique_lock<std::mutex> g(m_);
-    done_.wait(g, [this] { return left_ == 0; });
+    is_open_ = false;                                   // late wakers stay out from here on
+    done_.wait(g, [this] { return inside_ == 0; });
     job_ = nullptr;
   }
   void loop(int id) {
@@ -72,12 +77,13 @@ class Workers {
         std::unique_lock<std::mutex> g(m_);
         wake_.wait(g, [&] { return gen_ != seen; });
         seen = gen_;
-        if (id >= want_) continue;
+        if (id >= want_ || !is_open_) continue;
         job = job_;
+        ++inside_;
       }
       (*job)();
       std::lock_guard<std::mutex> g(m_);
-      if (--left_ == 0) done_.notify_one();
+      if (--inside_ == 0) done_.notify_one();
     }
   }
   const pid_t pid_;
@@ -86,8 +92,8 @@ class Workers {
   std::vector<std::thread> th_;
   const std::function<void()>* job_ = nullptr;
   uint64_t gen_ = 0;
-  int want_ = 0, left_ = 0;
+  int want_ = 0, inside_ = 0;
+  bool is_open_ = false;
 };
-
 
 }  // namespace midas
