@@ -302,8 +302,10 @@ def main():
         out["value_incl_pack"] = total_sites * kp / elapsed_pack
         out["ms_per_step_incl_pack"] = elapsed_pack / kp * 1e3
         out["steps_incl_pack"] = kp
+        pack_traffic, pack_traffic_src = load_pmc_traffic("pack_scatter_kernel", a.config)
         out["roofline_pack"] = {"bound": "hbm", "kernel": "pack_scatter_kernel", "achieved": pack_ach, "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": pack_ach / HBM_PEAK_GBPS, "traffic": None,
+                                "unit": "GB/s", "frac": pack_ach / HBM_PEAK_GBPS, "traffic": pack_traffic,
+                                "traffic_source": pack_traffic_src,
                                 "algorithmic_bytes_per_launch": pack_alg,
                                 "algorithmic_bytes_note": "raw reads in (sum(ceil(l/2) + l + 4*n_cigar + 16)) + records and payload out",
                                 "kernel_ms_avg": scatter_ms, "pack_ms_avg_all_kernels": pack_ms}

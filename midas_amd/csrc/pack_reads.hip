@@ -87,6 +87,17 @@ struct ReadView {
 __device__ int plan_read(const ReadView& r, uint32_t* align_total) {
   if (r.l < 1u || r.l > (uint32_t)kMaxSegField || r.nm < 0 || r.nm > kMaxSegField || r.pos < 0 || r.nc == 0u) return 0;
   if (!(r.pos < r.clen)) return 0;
+  if (r.nc == 1u) {      // "<l>M", most of what an end-to-end aligner writes: the same answer without the walk, in 32 bits
+    const uint32_t op = r.cg.c0 & 15u, len = r.cg.c0 >> 4;
+    if (op_is_match(op) && len == r.l) {
+      const uint32_t start = (uint32_t)r.pos, room = (uint32_t)r.clen - start;      // 0 <= pos < clen < 2^31
+      const uint32_t ln = len < room ? len : room;
+      const int np = (int)(((start + ln - 1u) >> r.tile_shift) - (start >> r.tile_shift)) + 1;
+      if (np > kMaxPieces) return 0;
+      *align_total = r.l;
+      return np;
+    }
+  }
   uint32_t k = 0;
   while (k < r.nc && (r.cg[k] & 15u) == OP_H) { if ((r.cg[k] >> 4) == 0u) return 0; ++k; }
   uint32_t lead = 0, trail = 0;
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(kPlanBlock) void pack_plan_kernel(PackParams p) {
   }
 }
 
-// Record descriptor, 32 bytes per device record in input order: everything the scatter kernel needs to start loading
+// Record descriptor, 32 bytes per device record in input order (d0 of all records, then d1 of all records): everything the scatter kernel needs to start loading
 // the record's bytes at once -- no per-read lookups on its critical path.
 //   d0.x  position of the record's first base on the contig        d0.y  index of its read
 //   d0.z  bases in the record | n_cigar field << 16                 d0.w  nm field | mapq << 16 | kRec* flags << 24
@@ -392,8 +403,8 @@ __global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
       p.sort_val[j] = j;
       p.bytes8[j] = bytes >> 3;
       const Desc d = make_desc(pos, i, len, qoff, flags, n16, nm16, mapq, qo, so, k.tile_key);
-      p.desc[2 * (size_t)j] = d.d0;
-      p.desc[2 * (size_t)j + 1] = d.d1;
+      p.desc[j] = d.d0;                                  // two arrays of 16-byte halves: neighbouring threads write
+      p.desc[(size_t)p.n_records + j] = d.d1;            // neighbouring 16 bytes (interleaved halves: PMC 916 MB written for 510)
       bytes_sum += bytes;
       for (int t = 1; t <= k.reach; ++t)    // reads a later tile will see as well (hot-spot planning)
         if (k.tile + t < p.n_tiles) atomicAdd(&p.tile_extra[k.tile + t], 1u);
@@ -403,6 +414,18 @@ __global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
       const uint32_t flags = general_flags(r, &reflen);
       emit(j0, record_keys(r.pos, reflen, false, r.clen, p.tile_shift, tb), blob_bytes(r.l, r.nc, (uint32_t)p.lane_bases),
            r.pos, (int)r.l, 0, flags, r.nc, r.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)r.nm);
+    } else if (r.nc == 1u) {     // "<l>M" (plan_read's short cut took it): the pieces are the read cut at the tile boundaries
+      const uint32_t at = r.l;
+      uint32_t start = (uint32_t)r.pos, left = (uint32_t)r.clen - start, q = 0;
+      left = r.l < left ? r.l : left;
+      for (int s = 0; s < ns; ++s) {
+        const uint32_t room = (uint32_t)p.tile_len - (start & (uint32_t)(p.tile_len - 1));
+        const uint32_t take = left < room ? left : room;
+        emit(j0 + (uint32_t)s, record_keys((long long)start, (long long)take, true, r.clen, p.tile_shift, tb), blob_bytes(take, 0u, (uint32_t)p.lane_bases),
+             (long long)start, (int)take, (int)q, (uint32_t)kRecSimple, r.l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14),
+             (uint32_t)r.nm | ((at & 63u) << 10));
+        start += take; q += take; left -= take;
+      }
     } else {
       uint32_t at = 0;
       (void)plan_read(r, &at);   // aligned length of the whole read
@@ -520,8 +543,8 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
   {
     const long long jj = batch * rpw + g;
     const size_t j = (g < rpw && jj < m) ? (size_t)jj : 0;
-    cur.d0 = p.desc[2 * j];
-    cur.d1 = p.desc[2 * j + 1];
+    cur.d0 = p.desc[j];
+    cur.d1 = p.desc[(size_t)m + j];
     cur.dest = p.dest[j];
   }
   {

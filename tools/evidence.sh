@@ -25,7 +25,7 @@ prof() {   # prof <name> <bench args...>
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_2 -o pmc -- python $REPO/bench.py --no-cpu --steps 10 --warmup 2 --pack-steps 3 "$@" > $out/pmc_2.log 2>&1 )
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu $*   (then --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command with --steps 10 --pack-steps 3)"
     grep '^{' $out/trace.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('# bench line of the profiled run: value %.4g %s, ms_per_step %.4f, kernel_ms_avg %.4f, frac %.3f' % (d['value'], d['unit'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac']))" 2>/dev/null
-    python tools/summarize_prof.py $out; } > $EV/${TAG}_${name}_rocprofv3_stats_pmc.txt 2>&1
+    python tools/summarize_prof.py $out | grep -v "^JSON"; } > $EV/${TAG}_${name}_rocprofv3_stats_pmc.txt 2>&1
   rm -rf $out
 }
 prof c3
