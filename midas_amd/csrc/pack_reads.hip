@@ -638,7 +638,10 @@ __device__ __forceinline__ uint32_t call_codes8(uint32_t x) {
   const uint32_t valid = nz ^ 0x11111111u;                                    // bit 0 of the nibbles of A/C/G/T
   const uint32_t hi = ((x >> 3) | (x >> 2)) & 0x11111111u;                    // G or T
   const uint32_t lo = ((x >> 3) | (x >> 1)) & 0x11111111u;                    // C or T
-  return ((valid << 2) | (hi << 1) | lo) & ((valid << 3) - valid);            // (x << 3) - x = 7 x: no integer multiply
+  // 7 in the nibbles of A/C/G/T.  (valid << 3) - valid would do, but the compiler turns that into v_mul_lo_u32 by 7:
+  // a quarter-rate instruction; two shift-ors stay full rate
+  const uint32_t seven = valid | (valid << 1) | (valid << 2);
+  return ((valid << 2) | (hi << 1) | lo) & seven;
 }
 // Two bytes (four nibbles: byte0.hi, byte0.lo, byte1.hi, byte1.lo in base order) -> four bytes, one nibble each.
 // HALF 0: bytes 0,1 of x; HALF 1: bytes 2,3.
@@ -758,7 +761,9 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
         // layout.h base_byte, four bases at a time: (min(q, 62) + 1) << 2 | code where the base is A/C/G/T and inside the
         // record, 0 elsewhere (padding slot, tail, other letters)
         const uint32_t vb = (cb[k] >> 2) & 0x01010101u;
-        const uint32_t keep = ((vb << 8) - vb) & tm[k];                        // 0xFF where the slot holds an A/C/G/T base
+        // 0xFF where the slot holds an A/C/G/T base: (vb << 8) - vb, with the shift spelt as a byte alignment so that the
+        // compiler does not fold the pair into a quarter-rate multiply by 255
+        const uint32_t keep = (__builtin_amdgcn_alignbyte(vb, 0u, 3u) - vb) & tm[k];
         qw[k] = (((qw[k] + 0x01010101u) << 2) | (cb[k] & 0x03030303u)) & keep;
       }
       // a quality above 62 among the record's bases (QUAL present): the batch will refuse a baseq above 62
