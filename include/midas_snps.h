@@ -322,6 +322,20 @@ int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_c
                               const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
                               int32_t gz_level, int32_t threads, char* err256);
 
+/* The count columns of SEVERAL samples' tables in one go: what the lock-step zip over the samples' files does in
+ * build_temp_count_matrix (midas/merge/snps.py:236-271, one r[-4:] per sample and row).  _open reads all files (in
+ * parallel) and walks their gzip members' headers; rows_each[t] is table t's row count, or -1 for a file that does not
+ * announce it (written by the reference): such a table is read with midas_snps_table_open instead.  _read_counts fills
+ * out_counts[t][4 * n_rows] with rows [row_begin, row_begin + n_rows) of every table t whose pointer is not NULL: every
+ * gzip member of every table is one task of a single parallel region (inflate, then the last four fields of each line
+ * straight into the caller's array) -- no per-table thread pools, no intermediate copies.                          */
+typedef struct midas_snps_tableset midas_snps_tableset;
+int32_t midas_snps_tableset_open(int32_t n_tables, const char* const* paths, midas_snps_tableset** out, int64_t* rows_each,
+                                 char* err256);
+int32_t midas_snps_tableset_read_counts(midas_snps_tableset* ts, int64_t row_begin, int64_t n_rows,
+                                        uint32_t* const* out_counts, char* err256);
+void midas_snps_tableset_close(midas_snps_tableset* ts);
+
 /* The row coder behind gz_level 1-5 of the writers above, on its own (tests and tools reach it here): a raw DEFLATE
  * stream (RFC 1951, one final dynamic-Huffman block) for text[0, n) whose rows start at row_begin[k] and whose row
  * tails -- the part that tends to repeat an earlier row: from the tab before ref_allele on -- start at tail_begin[k]

@@ -239,6 +239,9 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_deflate_rows': (i32, [vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]),
+        'midas_snps_tableset_open': (i32, [i32, vp, C.POINTER(vp), vp, C.c_char_p]),
+        'midas_snps_tableset_read_counts': (i32, [vp, i64, i64, vp, C.c_char_p]),
+        'midas_snps_tableset_close': (None, [vp]),
         'midas_snps_table_open': (i32, [C.c_char_p, i64, i32, C.POINTER(vp), C.c_char_p]),
         'midas_snps_table_close': (None, [vp]),
         'midas_snps_table_rows': (i64, [vp]),
@@ -271,6 +274,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_deflate_rows',
+    'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
@@ -292,7 +296,7 @@ def deflate_rows(text: bytes, row_begin, tail_begin) -> bytes:
 
 
 def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts: np.ndarray,
-               gz_level: int = 6, threads: int = 0):
+               gz_level: int = 4, threads: int = 0):
     """Format + gzip the rows of ONE contig into <species>.snps.gz (midas_snps_write_rows)."""
     lib = load_library()
     allele = np.ascontiguousarray(allele, dtype=np.uint8)
@@ -306,7 +310,7 @@ def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts:
         raise MidasSnpsError(st, err.value.decode())
 
 
-def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 6, threads: int = 0, header=None):
+def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 4, threads: int = 0, header=None):
     """Header + the rows of every contig of one species in one call (midas_snps_write_table): ref_ids[k],
     alleles[k] (u8[n_k]) and counts[k] (u32[n_k,4]) describe contig k in output order.  header = True / False writes a
     PART of a species' table instead (midas_snps_write_part): with or without the header member in front."""
@@ -416,6 +420,35 @@ def read_snps_table(path: str, max_rows: int = -1, want_keys: bool = True, row_b
     finally:
         lib.midas_snps_table_close(h)
     return counts, (memoryview(keys) if want_keys else None), key_off
+
+
+def read_snps_counts(paths, row_begin: int = 0, max_rows: int = -1):
+    """The count columns of several samples' <species>.snps.gz in one parallel region (midas_snps_tableset_*):
+    -> list of counts[n,4] u32, one per path, n = rows [row_begin, max_rows) of the SHORTEST table (max_rows < 0: its
+    end) -- the reference's zip over the samples' files stops there too.  None when one of the files does not announce
+    its rows (written by the reference): read those with read_snps_table."""
+    lib = load_library()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    rows = np.empty(n, np.int64)
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    st = lib.midas_snps_tableset_open(n, arr, C.byref(h), rows.ctypes.data_as(C.c_void_p), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
+    try:
+        if (rows < 0).any():
+            return None
+        hi = int(rows.min()) if max_rows < 0 else min(int(rows.min()), int(max_rows))
+        m = max(0, hi - int(row_begin))
+        out = [np.empty((m, 4), np.uint32) for _ in range(n)]
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in out])
+        st = lib.midas_snps_tableset_read_counts(h, int(row_begin), m, ptrs, err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        return out
+    finally:
+        lib.midas_snps_tableset_close(h)
 
 
 def read_bam(path: str):

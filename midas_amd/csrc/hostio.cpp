@@ -120,6 +120,14 @@ struct midas_snps_table {
   int64_t rows = 0, key_bytes = 0;
 };
 
+struct TableSetMember { size_t data, clen, ulen; int64_t row0, rows; };   // row0: table row of the member's first row
+struct midas_snps_tableset {
+  std::vector<std::string> paths;
+  std::vector<RawBuf<uint8_t>> files;
+  std::vector<std::vector<TableSetMember>> members;    // per table, the members that hold rows
+  std::vector<int64_t> rows;                            // per table, -1 = the file does not announce its rows
+};
+
 namespace {
 
 using midas::Workers;
@@ -1071,7 +1079,8 @@ namespace {
 // The gzip members of a table written by this library, found without inflating anything: {data offset, compressed bytes,
 // uncompressed bytes, table rows (-1: a round-1 file that does not say)}.  Empty when the file is any other gzip file.
 struct TableMember { size_t data, clen, ulen; int64_t rows; };
-std::vector<TableMember> table_members(const std::vector<uint8_t>& file) {
+std::vector<TableMember> table_members_of(const uint8_t* bytes, size_t n_bytes) {
+  struct Span { const uint8_t* d; size_t n; size_t size() const { return n; } const uint8_t* data() const { return d; } } file{bytes, n_bytes};
   std::vector<TableMember> members;
   size_t p = 0;
   while (p < file.size()) {
@@ -1089,6 +1098,8 @@ std::vector<TableMember> table_members(const std::vector<uint8_t>& file) {
   }
   return members;
 }
+
+std::vector<TableMember> table_members(const std::vector<uint8_t>& file) { return table_members_of(file.data(), file.size()); }
 
 bool read_file(const char* path, std::vector<uint8_t>& file, char* err256) {
   FILE* f = fopen(path, "rb");
@@ -1244,6 +1255,145 @@ int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t
   tab->key_bytes = kbytes;
   tab->pieces = std::move(parsed);
   *out = tab;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_tableset_open(int32_t n_tables, const char* const* paths, midas_snps_tableset** out, int64_t* rows_each,
+                                 char* err256) {
+  if (n_tables <= 0 || !paths || !out || !rows_each) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_ptr<midas_snps_tableset> ts(new (std::nothrow) midas_snps_tableset());
+  if (!ts) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  const size_t n = (size_t)n_tables;
+  ts->paths.resize(n);
+  ts->files.resize(n);
+  ts->members.resize(n);
+  ts->rows.assign(n, -1);
+  // every file in 8 MiB pieces, all pieces of all files in one parallel region
+  struct Piece { size_t table, off, len; };
+  std::vector<Piece> pieces;
+  std::vector<int> fds(n, -1);
+  int32_t st = MIDAS_SNPS_OK;
+  for (size_t t = 0; t < n && st == MIDAS_SNPS_OK; ++t) {
+    if (!paths[t]) { st = MIDAS_SNPS_ERR_INVALID_ARG; break; }
+    ts->paths[t] = paths[t];
+    fds[t] = open(paths[t], O_RDONLY);
+    struct stat sb;
+    if (fds[t] < 0 || fstat(fds[t], &sb) != 0) { set_err(err256, "cannot open %s", paths[t]); st = MIDAS_SNPS_ERR_INVALID_ARG; break; }
+    if (!ts->files[t].resize((size_t)sb.st_size)) { set_err(err256, "out of memory reading %s", paths[t]); st = MIDAS_SNPS_ERR_OUT_OF_MEMORY; break; }
+    for (size_t off = 0; off < (size_t)sb.st_size; off += (size_t)8 << 20)
+      pieces.push_back({t, off, std::min((size_t)8 << 20, (size_t)sb.st_size - off)});
+  }
+  std::atomic<int> short_read{-1};
+  if (st == MIDAS_SNPS_OK)
+    run_pool(hw_threads(0), pieces.size(), [&](size_t k) {
+      const Piece& pc = pieces[k];
+      size_t done = 0;
+      while (done < pc.len) {
+        const ssize_t got = pread(fds[pc.table], ts->files[pc.table].data() + pc.off + done, pc.len - done, (off_t)(pc.off + done));
+        if (got <= 0) { short_read = (int)pc.table; return; }
+        done += (size_t)got;
+      }
+    });
+  for (int fd : fds) if (fd >= 0) close(fd);
+  if (st != MIDAS_SNPS_OK) return st;
+  if (short_read >= 0) { set_err(err256, "short read on %s", paths[short_read.load()]); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  for (size_t t = 0; t < n; ++t) {
+    const std::vector<TableMember> all = table_members_of(ts->files[t].data(), ts->files[t].size());
+    bool counted = !all.empty();
+    for (const TableMember& m : all) counted = counted && m.rows >= 0;
+    if (!counted) continue;                      // written by the reference (or round 1): the caller reads it the other way
+    int64_t at = 0;
+    for (const TableMember& m : all) {
+      if (m.rows > 0) ts->members[t].push_back({m.data, m.clen, m.ulen, at, m.rows});
+      at += m.rows;
+    }
+    ts->rows[t] = at;
+  }
+  memcpy(rows_each, ts->rows.data(), n * sizeof(int64_t));
+  *out = ts.release();
+  return MIDAS_SNPS_OK;
+}
+
+void midas_snps_tableset_close(midas_snps_tableset* ts) { delete ts; }
+
+int32_t midas_snps_tableset_read_counts(midas_snps_tableset* ts, int64_t row_begin, int64_t n_rows, uint32_t* const* out_counts,
+                                        char* err256) {
+  if (!ts || row_begin < 0 || n_rows < 0 || !out_counts) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const int64_t row_end = row_begin + n_rows;
+  struct Task { size_t table, member; };
+  std::vector<Task> tasks;
+  for (size_t t = 0; t < ts->files.size(); ++t) {
+    if (!out_counts[t]) continue;                // a table the caller reads some other way
+    if (ts->rows[t] < row_end) {
+      set_err(err256, "%s: rows up to %lld asked of a table that holds fewer (or does not say)", ts->paths[t].c_str(), (long long)row_end);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+    for (size_t k = 0; k < ts->members[t].size(); ++k) {
+      const TableSetMember& m = ts->members[t][k];
+      if (m.row0 + m.rows > row_begin && m.row0 < row_end) tasks.push_back({t, k});
+    }
+  }
+  std::atomic<long long> bad_row{-1};
+  std::atomic<int> bad_table{-1}, corrupt{-1};
+  run_pool(hw_threads(0), tasks.size(), [&](size_t i) {
+    static thread_local std::vector<char> text;
+    const Task& tk = tasks[i];
+    const TableSetMember& m = ts->members[tk.table][tk.member];
+    if (text.size() < m.ulen + 1) text.resize(m.ulen + 1);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { corrupt = (int)tk.table; return; }
+    zs.next_in = ts->files[tk.table].data() + m.data;
+    zs.avail_in = (uInt)m.clen;
+    zs.next_out = reinterpret_cast<Bytef*>(text.data());
+    zs.avail_out = (uInt)m.ulen;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) { corrupt = (int)tk.table; return; }
+    // rows of the member straight into the caller's array: the last four fields of every line (r[-4:],
+    // midas/merge/snps.py:262-270), same checks as parse_rows
+    const char* b = text.data();
+    const char* const end = b + m.ulen;
+    uint32_t* const dst = out_counts[tk.table];
+    int64_t row = m.row0;
+    while (b < end) {
+      const char* nl = (const char*)memchr(b, '\n', (size_t)(end - b));
+      const char* e = nl ? nl : end;
+      if (row >= row_begin && row < row_end) {
+        int n_tabs = 0;
+        for (const char* q = b; q < e; ++q) n_tabs += *q == '\t';
+        bool ok = n_tabs >= 7;
+        uint32_t v4[4] = {0, 0, 0, 0};
+        const char* q = e;
+        for (int k = 3; k >= 0 && ok; --k) {      // backwards from the line's end: digits, then the tab in front of them
+          uint64_t v = 0, scale = 1;
+          const char* stop = q;
+          while (q > b && q[-1] >= '0' && q[-1] <= '9') { v += (uint64_t)(q[-1] - '0') * scale; scale *= 10; --q; if (stop - q > 10) break; }
+          if (q == stop || stop - q > 10 || v > 0x7FFFFFFFull || q == b || q[-1] != '\t') ok = false;
+          v4[k] = (uint32_t)v;
+          --q;
+        }
+        if (!ok) {
+          long long none = -1;
+          if (bad_row.compare_exchange_strong(none, (long long)row)) bad_table = (int)tk.table;
+          return;
+        }
+        memcpy(dst + 4 * (row - row_begin), v4, 16);
+      }
+      ++row;
+      b = nl ? nl + 1 : end;
+    }
+    if (row != m.row0 + m.rows) {               // the member holds another number of rows than it announces
+      long long none = -1;
+      if (bad_row.compare_exchange_strong(none, (long long)row)) bad_table = (int)tk.table;
+    }
+  });
+  if (corrupt >= 0) { set_err(err256, "%s: corrupt deflate data", ts->paths[(size_t)corrupt.load()].c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  if (bad_row >= 0) {
+    set_err(err256, "%s: malformed row %lld", ts->paths[(size_t)bad_table.load()].c_str(), bad_row.load() + 1);
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
+  }
   return MIDAS_SNPS_OK;
 }
 

@@ -37,6 +37,13 @@ def load_sample_tables(species, args, row_range=None):
     max_rows = -1 if args['max_sites'] == float('Inf') else int(args['max_sites'])
     lo, hi = row_range if row_range is not None else (0, max_rows)
     paths = _table_paths(species)
+    # tables written by this library announce their rows: every gzip member of every sample is one task of a single
+    # parallel region; the site keys come from the first sample's table alone, as in the reference
+    counts = abi.read_snps_counts(paths, lo, hi)
+    if counts is not None:
+        n = counts[0].shape[0]
+        _, keys, key_off = abi.read_snps_table(paths[0], lo + n, True, lo)
+        return counts, keys, key_off[:n + 1]
     nthreads = max(1, min(len(paths), int(args.get('threads', 1) or 1)))
     with ThreadPoolExecutor(nthreads) as ex:
         futs = [ex.submit(abi.read_snps_table, p, hi, i == 0, lo) for i, p in enumerate(paths)]

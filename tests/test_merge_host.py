@@ -258,3 +258,67 @@ def test_row_ranges_of_a_table_equal_slices_of_the_whole(tmp_path):
             assert ko[0] == 0 and len(ko) == e - lo + 1
             assert bytes(k) == bytes(full_k[full_o[lo]:full_o[e]])
             assert np.array_equal(ko, full_o[lo:e + 1] - full_o[lo])
+
+
+def test_several_tables_in_one_region(tmp_path):
+    """midas_snps_tableset_*: the count columns of several samples' tables, every gzip member one task of a single
+    parallel region.  Equal to reading the tables one by one; the shortest table bounds the rows (the reference's zip
+    over the files); row ranges cut members; a table that does not announce its rows sends the caller the other way;
+    malformed rows are named."""
+    import gzip
+    rng = np.random.default_rng(5)
+    ids = ["c_a", "c_b", "c_c"]
+    paths, tables = [], []
+    for s, lens in enumerate([[20000, 7, 33000], [20000, 7, 33000], [20000, 7, 21000]]):     # the third sample's table is shorter
+        n = sum(lens)
+        counts = rng.integers(0, 2**31 - 1 if s == 1 else 60, size=(n, 4)).astype(np.uint32)
+        allele = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n)
+        o = np.cumsum([0] + lens)
+        p = str(tmp_path / ("s%d.snps.gz" % s))
+        abi.write_table(p, ids, [allele[o[k]:o[k + 1]] for k in range(3)], [counts[o[k]:o[k + 1]] for k in range(3)],
+                        gz_level=[4, 6, 1][s], threads=3)
+        paths.append(p)
+        tables.append(counts)
+    shortest = min(t.shape[0] for t in tables)
+    got = abi.read_snps_counts(paths)
+    assert [g.shape for g in got] == [(shortest, 4)] * 3
+    for g, t in zip(got, tables):
+        assert np.array_equal(g, t[:shortest])
+    for lo, hi in [(0, 1), (16383, 16385), (19999, 20008), (20007, 40000), (shortest - 1, shortest + 50), (300, 300), (41000, -1)]:
+        got = abi.read_snps_counts(paths, lo, hi)
+        e = shortest if hi < 0 else min(hi, shortest)
+        for g, t in zip(got, tables):
+            assert np.array_equal(g, t[lo:e]), (lo, hi)
+    # a table as the reference writes it (one gzip member, no row counts): not for this reader
+    plain = str(tmp_path / "plain.snps.gz")
+    with gzip.open(plain, "wb") as h:
+        h.write(gzip.open(paths[0], "rb").read())
+    assert abi.read_snps_counts([paths[0], plain]) is None
+    with pytest.raises(abi.MidasSnpsError):
+        abi.read_snps_counts([paths[0], str(tmp_path / "missing.snps.gz")])
+    # a row that is not a row, inside a member that announces its rows: rewrite one member's text
+    raw = bytearray(open(paths[0], "rb").read())
+    import zlib
+    text = gzip.open(paths[0], "rb").read()
+    lines = text.split(b"\n")
+    lines[25001] = b"c_b\t1\tA\t3\t1\tx\t1\t0"
+    bad = str(tmp_path / "bad.snps.gz")
+    # same member structure: compress line groups the way the writer cut them (header, then <= 16384 rows per member and contig)
+    def member(payload, rows):
+        z = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = z.compress(payload) + z.flush()
+        total = 28 + len(body) + 8
+        head = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 255, 16, 0]) + b"MS" + (4).to_bytes(2, "little") + total.to_bytes(4, "little") \
+            + b"MR" + (4).to_bytes(2, "little") + rows.to_bytes(4, "little")
+        return head + body + zlib.crc32(payload).to_bytes(4, "little") + (len(payload) & 0xFFFFFFFF).to_bytes(4, "little")
+    with open(bad, "wb") as h:
+        h.write(member(lines[0] + b"\n", 0))
+        for lo in range(1, len(lines) - 1, 10000):
+            chunk = lines[lo:min(lo + 10000, len(lines) - 1)]
+            h.write(member(b"\n".join(chunk) + b"\n", len(chunk)))
+    assert gzip.open(bad, "rb").read() == b"\n".join(lines)
+    with pytest.raises(abi.MidasSnpsError) as e:
+        abi.read_snps_counts([paths[1], bad])
+    assert "row 25001" in e.value.message and "bad.snps.gz" in e.value.message
+    ok = abi.read_snps_counts([paths[1], bad], 0, 25000)          # the bad row is outside what is read
+    assert np.array_equal(ok[1], tables[0][:25000])
