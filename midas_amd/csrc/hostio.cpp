@@ -1137,6 +1137,8 @@ int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t
   *out = nullptr;
   // ---- the text of the table, as line-aligned pieces ------------------------------------------------------
   std::vector<std::vector<char>> pieces;
+  std::vector<ParsedRows> fused;       // members of one of our own files: inflated and parsed in one task each
+  bool have_fused = false;
   std::vector<uint8_t> file;
   if (!read_file(path, file, err256)) return MIDAS_SNPS_ERR_INVALID_ARG;
   // members written by midas_snps_write_rows/_table/_part announce their size (and rows): walk them without inflating
@@ -1162,24 +1164,39 @@ int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t
       if (first) first_row = row_begin;
       members.swap(wanted);
     }
-    pieces.resize(members.size());
+    // inflate and parse in one task per member: the text lives in a buffer the thread keeps (a vector per member would
+    // be zero-filled and page-faulted once per member: as many bytes again as the text itself)
+    size_t header_member = (size_t)-1;
+    if (header_piece != (size_t)-1) {
+      header_member = 0;
+      while (header_member < members.size() && members[header_member].ulen == 0) ++header_member;
+    }
+    fused.resize(members.size());
     std::atomic<int> bad{0};
     run_pool(nt, members.size(), [&](size_t i) {
+      static thread_local std::vector<char> text;
       const TableMember& m = members[i];
-      pieces[i].resize(m.ulen);
       if (m.ulen == 0) return;
+      if (text.size() < m.ulen) text.resize(m.ulen);
       z_stream zs;
       memset(&zs, 0, sizeof zs);
       if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
       zs.next_in = file.data() + m.data;
       zs.avail_in = (uInt)m.clen;
-      zs.next_out = reinterpret_cast<Bytef*>(pieces[i].data());
+      zs.next_out = reinterpret_cast<Bytef*>(text.data());
       zs.avail_out = (uInt)m.ulen;
       const int rc = inflate(&zs, Z_FINISH);
       inflateEnd(&zs);
-      if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+      if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+      ParsedRows& pr = fused[i];
+      if (m.rows > 0) {
+        pr.counts.reserve((size_t)m.rows * 4);
+        if (want_keys) { pr.key_end.reserve((size_t)m.rows); pr.keys.reserve((size_t)m.rows * 24); }
+      }
+      parse_rows(text.data(), text.data() + m.ulen, want_keys != 0, i == header_member, pr);
     });
     if (bad) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    have_fused = true;
   } else {
     // any other gzip file (e.g. written by the reference): one serial inflate, then line-aligned pieces
     std::vector<uint8_t>().swap(file);
@@ -1218,13 +1235,18 @@ int32_t midas_snps_table_open_range(const char* path, int64_t row_begin, int64_t
     header_piece = 0;
     while (header_piece < pieces.size() && pieces[header_piece].empty()) ++header_piece;
   }
-  std::vector<ParsedRows> parsed(pieces.size());
-  run_pool(nt, pieces.size(), [&](size_t i) {
-    const std::vector<char>& t = pieces[i];
-    if (t.empty()) return;
-    parse_rows(t.data(), t.data() + t.size(), want_keys != 0, i == header_piece, parsed[i]);
-    std::vector<char>().swap(pieces[i]);
-  });
+  std::vector<ParsedRows> parsed;
+  if (have_fused) {
+    parsed.swap(fused);
+  } else {
+    parsed.resize(pieces.size());
+    run_pool(nt, pieces.size(), [&](size_t i) {
+      const std::vector<char>& t = pieces[i];
+      if (t.empty()) return;
+      parse_rows(t.data(), t.data() + t.size(), want_keys != 0, i == header_piece, parsed[i]);
+      std::vector<char>().swap(pieces[i]);
+    });
+  }
   midas_snps_table* tab = new (std::nothrow) midas_snps_table();
   if (!tab) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   tab->skip.assign(parsed.size(), 0);

@@ -19,8 +19,11 @@ CODONTABLE = {x + y + z: _AMINO[16 * i + 4 * j + k]
               for i, x in enumerate(_ORDER) for j, y in enumerate(_ORDER) for k, z in enumerate(_ORDER)}
 
 
+_COMPLEMENT = str.maketrans(_PAIR)      # A<->T, C<->G; every other character stays what it is
+
+
 def rev_comp(seq):
-    return ''.join(_PAIR.get(b, b) for b in reversed(seq))
+    return seq[::-1].translate(_COMPLEMENT)
 
 
 def _db_file(db, species_id, name):

@@ -39,15 +39,18 @@ def load_sample_tables(species, args, row_range=None):
     paths = _table_paths(species)
     # tables written by this library announce their rows: every gzip member of every sample is one task of a single
     # parallel region; the site keys come from the first sample's table alone, as in the reference
-    counts = abi.read_snps_counts(paths, lo, hi)
-    if counts is not None:
-        n = counts[0].shape[0]
-        _, keys, key_off = abi.read_snps_table(paths[0], lo + n, True, lo)
-        return counts, keys, key_off[:n + 1]
+    with ThreadPoolExecutor(1) as ex:      # the first sample's table (keys + counts) beside the others' counts
+        first = ex.submit(abi.read_snps_table, paths[0], hi, True, lo)
+        rest = abi.read_snps_counts(paths[1:], lo, hi) if len(paths) > 1 else []
+        c0, keys, key_off = first.result()
+    if rest is not None:
+        n = min([c0.shape[0]] + [c.shape[0] for c in rest])
+        return [np.ascontiguousarray(c[:n]) for c in [c0] + rest], keys, key_off[:n + 1]
+    # a table written by the reference among them: one table per thread, each read whole
     nthreads = max(1, min(len(paths), int(args.get('threads', 1) or 1)))
     with ThreadPoolExecutor(nthreads) as ex:
-        futs = [ex.submit(abi.read_snps_table, p, hi, i == 0, lo) for i, p in enumerate(paths)]
-        tabs = [f.result() for f in futs]
+        futs = [ex.submit(abi.read_snps_table, p, hi, False, lo) for p in paths[1:]]
+        tabs = [(c0, keys, key_off)] + [f.result() for f in futs]
     n = min(t[0].shape[0] for t in tabs)     # the reference's zip stops at the shortest file
     counts = [np.ascontiguousarray(t[0][:n]) for t in tabs]
     return counts, tabs[0][1], tabs[0][2][:n + 1]
@@ -67,7 +70,10 @@ def merge_species(species, args, ctx, row_range=None, part=None):
             with open('%s/%s%s' % (outdir, name, suffix), 'w') as handle:
                 handle.write(h)
         return 0, 0, 0.0
-    counts, keys, key_off = load_sample_tables(species, args, row_range)
+    with ThreadPoolExecutor(1) as ex:      # the gene table is Python work: it runs while the native reader has the cores
+        genes_job = ex.submit(annotate.GeneCursor.from_db, species.id, args['db'])
+        counts, keys, key_off = load_sample_tables(species, args, row_range)
+        genes = genes_job.result()
     n = counts[0].shape[0]
     prm = abi.MergeParams.from_args(args)
     try:
@@ -76,7 +82,6 @@ def merge_species(species, args, ctx, row_range=None, part=None):
         if e.status == abi.ERR_MERGE_ZERO_MEAN_DEPTH and e.read_index >= 0 and base:
             sys.exit("\nError: %s [row %d of the species' tables]\n" % (e.message, base + e.read_index + 1))
         sys.exit("\nError: %s\n" % e.message)
-    genes = annotate.GeneCursor.from_db(species.id, args['db'])
     keep = np.nonzero(res['flag'] == 0)[0]
     # snps_freq.txt / snps_depth.txt: one number per (kept site, sample) -- formatted natively
     threads = int(args.get('threads', 1) or 1)

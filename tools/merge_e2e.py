@@ -69,7 +69,36 @@ def main():
     t = time.perf_counter(); counts, keys, key_off = msnps.load_sample_tables(sp, args); T['read %d sample tables (native, threads)' % S] = time.perf_counter() - t
     t = time.perf_counter(); res = ctx.merge_sites(abi.MergeParams.from_args(args), counts, sp.sample_depth); T['device arithmetic incl. H2D/D2H'] = time.perf_counter() - t
     kms = res['kernel_ms']
-    t = time.perf_counter(); nn, kept, _ = msnps.merge_species(sp, args, ctx); T['whole merge_species (again: read + device + annotate + write)'] = time.perf_counter() - t
+    from midas_amd.merge import annotate
+    outdir = '%s/%s' % (args['outdir'], sp.id)
+    os.makedirs(outdir, exist_ok=True)
+    t = time.perf_counter(); genes = annotate.GeneCursor.from_db(sp.id, args['db']); T['gene table + genome (GeneCursor.from_db)'] = time.perf_counter() - t
+    t = time.perf_counter(); keep = np.nonzero(res['flag'] == 0)[0]; T['kept sites'] = time.perf_counter() - t
+    hdr = '\t'.join(['site_id'] + [x.id for x in sp.samples]) + '\n'
+    t = time.perf_counter()
+    abi.write_merge_matrix(outdir + '/f.txt', hdr, keep, res['depth'], res['minor_count'], threads=64)
+    abi.write_merge_matrix(outdir + '/d.txt', hdr, keep, res['depth'], None, threads=64)
+    T['snps_freq + snps_depth (native)'] = time.perf_counter() - t
+    t = time.perf_counter(); abi.write_merge_info(outdir + '/i.txt', 'x\n', keep, keys, key_off, res, genes.genes, threads=64); T['snps_info (native)'] = time.perf_counter() - t
+    calls = []
+
+    def timed(mod, name):
+        f = getattr(mod, name)
+
+        def g(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                calls.append((name, t0 - t_start, time.perf_counter() - t0))
+        setattr(mod, name, g)
+    for name in ('read_snps_counts', 'read_snps_table', 'write_merge_matrix', 'write_merge_info'):
+        timed(abi, name)
+    timed(annotate.GeneCursor, 'from_db')
+    timed(type(ctx), 'merge_sites')
+    t_start = t = time.perf_counter(); nn, kept, _ = msnps.merge_species(sp, args, ctx); T['whole merge_species (again: read + device + annotate + write)'] = time.perf_counter() - t
+    for name, at, dur in calls:
+        print("      inside merge_species: %-22s starts %6.3f s  takes %6.3f s" % (name, at, dur))
     total = T['select species/samples'] + T['whole merge_species (again: read + device + annotate + write)']
     for k, v in T.items():
         print("  %-62s %8.3f s" % (k, v))
