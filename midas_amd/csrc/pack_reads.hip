@@ -523,10 +523,15 @@ __global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
       for (int s = 0; s < ns; ++s) {
         const uint32_t room = (uint32_t)p.tile_len - (start & (uint32_t)(p.tile_len - 1));
         const uint32_t take = left < room ? left : room;
-        out.emit(i, f0.mapq, f0.qo, f0.so, f0.first + (uint32_t)s,
-                 record_keys((long long)start, (long long)take, true, cur.clen, p.tile_shift, cur.tile_base),
-                 blob_bytes(take, 0u, (uint32_t)p.lane_bases), (long long)start, (int)take, (int)q, (uint32_t)kRecSimple,
-                 l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14), (uint32_t)f0.nm | ((at & 63u) << 10));
+        // a piece lies inside one tile and one contig: record_keys in 32 bits, reach 0, class 0
+        RecKeys rk;
+        rk.tile = cur.tile_base + (int)(start >> p.tile_shift);
+        rk.reach = 0;
+        rk.sort_key = (uint32_t)rk.tile * (uint32_t)kPackBinsPerTile + (start & 7u);
+        rk.tile_key = (uint32_t)rk.tile << 7;
+        out.emit(i, f0.mapq, f0.qo, f0.so, f0.first + (uint32_t)s, rk, blob_bytes(take, 0u, (uint32_t)p.lane_bases), (long long)start,
+                 (int)take, (int)q, (uint32_t)kRecSimple, l | ((at >> 6) << 10) | ((s == 0 ? 1u : 0u) << 14),
+                 (uint32_t)f0.nm | ((at & 63u) << 10));
         start += take; q += take; left -= take;
       }
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -26,8 +27,7 @@ class Workers {
   static void run(int nt, const std::function<void()>& work) {
     if (nt <= 1) { work(); return; }
     Workers* w = instance();
-    std::unique_lock<std::mutex> region(w->region_, std::try_to_lock);
-    if (!region.owns_lock()) {
+    if (w->taken_.exchange(true, std::memory_order_acquire)) {     // another region is running (or this is a nested one)
       std::vector<std::thread> th;
       for (int t = 1; t < nt; ++t) th.emplace_back(work);
       work();
@@ -37,6 +37,7 @@ class Workers {
     w->open(nt - 1, &work);
     work();
     w->close();
+    w->taken_.store(false, std::memory_order_release);
   }
 
  private:
@@ -87,7 +88,8 @@ class Workers {
     }
   }
   const pid_t pid_;
-  std::mutex region_, m_;
+  std::atomic<bool> taken_{false};
+  std::mutex m_;
   std::condition_variable wake_, done_;
   std::vector<std::thread> th_;
   const std::function<void()>* job_ = nullptr;
