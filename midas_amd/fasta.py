@@ -3,16 +3,12 @@
 
 
 def parse(handle):
-    """Yield (id, seq) per record."""
-    rec_id, chunks = None, []
-    for line in handle:
-        if line.startswith('>'):
-            if rec_id is not None:
-                yield rec_id, ''.join(chunks)
-            header = line[1:].strip()
-            rec_id = header.split()[0] if header else ''
-            chunks = []
-        elif rec_id is not None:
-            chunks.append(''.join(line.split()))
-    if rec_id is not None:
-        yield rec_id, ''.join(chunks)
+    """Yield (id, seq) per record.  The file is taken in one read and cut at the '>' that start a line: one split/join
+    per record instead of one per line."""
+    text = handle.read()
+    if text.startswith('>'):
+        text = '\n' + text
+    for part in text.split('\n>')[1:]:       # (whatever precedes the first header is not a record)
+        header, _, body = part.partition('\n')
+        header = header.strip()
+        yield (header.split()[0] if header else ''), ''.join(body.split())

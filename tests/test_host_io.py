@@ -143,6 +143,34 @@ def test_fasta_parser_matches_biopython_conventions():
     text = ">c1 description here\nacgt\nNNAC\n\n>c2\nGG\n>c3\tx\n"
     recs = list(fasta.parse(io.StringIO(text)))
     assert recs == [("c1", "acgtNNAC"), ("c2", "GG"), ("c3", "")]
+    # text before the first header is not a record; '>' only starts a record at the start of a line; CR LF files (text
+    # mode has turned them into LF by the time the parser sees them) and blanks inside sequence lines; an empty header
+    text = "stray line\n>a\nAC>GT \tN\n\n>\nTT\n> \nGG\n>b x y\n"
+    assert list(fasta.parse(io.StringIO(text))) == [("a", "AC>GTN"), ("", "TT"), ("", "GG"), ("b", "")]
+    assert list(fasta.parse(io.StringIO(""))) == [] and list(fasta.parse(io.StringIO("no header at all\n"))) == []
+    import random
+    rng = random.Random(4)
+    for _ in range(50):       # against the line-by-line reading of the same text
+        lines = []
+        for _ in range(rng.randint(0, 12)):
+            kind = rng.random()
+            if kind < 0.3:
+                lines.append(">" + "".join(rng.choice("ab \t|.") for _ in range(rng.randint(0, 6))))
+            else:
+                lines.append("".join(rng.choice("ACGTn >\t") for _ in range(rng.randint(0, 9))))
+        text = "\n".join(lines) + ("\n" if rng.random() < 0.7 else "")
+        want, rid, chunks = [], None, []
+        for line in io.StringIO(text):
+            if line.startswith(">"):
+                if rid is not None:
+                    want.append((rid, "".join(chunks)))
+                h = line[1:].strip()
+                rid, chunks = (h.split()[0] if h else ""), []
+            elif rid is not None:
+                chunks.append("".join(line.split()))
+        if rid is not None:
+            want.append((rid, "".join(chunks)))
+        assert list(fasta.parse(io.StringIO(text))) == want, repr(text)
 
 
 def _oracle_text(contigs, reads, args):
