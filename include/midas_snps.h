@@ -336,6 +336,15 @@ int32_t midas_snps_tableset_read_counts(midas_snps_tableset* ts, int64_t row_beg
                                         uint32_t* const* out_counts, char* err256);
 void midas_snps_tableset_close(midas_snps_tableset* ts);
 
+/* The same rows as midas_snps_write_part, taken from a batch's results WHERE THEY ARE -- on the device -- for the
+ * contigs contig_index[k] (indices into the batch's contig table, in output order) under the names ref_ids[k]: the
+ * emit loop of species_pileup (midas/run/snps.py:183-213) without a host copy of the counts.  The formatter's
+ * threads work on one slab of sites in the context's page-locked ring while the next slab crosses the link; the file
+ * is byte for byte what batch_fetch + midas_snps_write_part write.  After midas_snps_batch_run.                  */
+int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32_t with_header, int32_t n_contigs,
+                                    const int32_t* contig_index, const char* const* ref_ids, int32_t gz_level,
+                                    int32_t threads);
+
 /* The row coder behind gz_level 1-5 of the writers above, on its own (tests and tools reach it here): a raw DEFLATE
  * stream (RFC 1951, one final dynamic-Huffman block) for text[0, n) whose rows start at row_begin[k] and whose row
  * tails -- the part that tends to repeat an earlier row: from the tab before ref_allele on -- start at tail_begin[k]

@@ -239,6 +239,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_deflate_rows': (i32, [vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]),
+        'midas_snps_batch_write_part': (i32, [vp, C.c_char_p, i32, i32, vp, vp, i32, i32]),
         'midas_snps_tableset_open': (i32, [i32, vp, C.POINTER(vp), vp, C.c_char_p]),
         'midas_snps_tableset_read_counts': (i32, [vp, i64, i64, vp, C.c_char_p]),
         'midas_snps_tableset_close': (None, [vp]),
@@ -274,7 +275,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_deflate_rows',
-    'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close',
+    'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
 ]
@@ -783,6 +784,15 @@ class Batch:
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         self.ctx._check(self._lib.midas_snps_batch_fetch(self._h, p(oc), p(oa), p(os_)))
         return oc, oa, os_
+
+    def write_part(self, path: str, contig_index, ref_ids, header: bool = True, gz_level: int = 4, threads: int = 0):
+        """Rows of the contigs contig_index (indices into the batch's contig table, output order) straight from the device
+        results into a gzip table or part of one (midas_snps_batch_write_part)."""
+        n = len(contig_index)
+        idx = np.ascontiguousarray(contig_index, dtype=np.int32)
+        ids = (C.c_char_p * max(n, 1))(*[r.encode() for r in ref_ids])
+        self.ctx._check(self._lib.midas_snps_batch_write_part(self._h, path.encode(), 1 if header else 0, n,
+                                                              idx.ctypes.data_as(C.c_void_p), ids, int(gz_level), int(threads)))
 
     def info(self) -> BatchInfo:
         bi = BatchInfo()

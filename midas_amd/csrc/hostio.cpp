@@ -1449,7 +1449,7 @@ namespace {
 // Rows of any number of contigs -> gzip members of kRows rows, formatted and deflated by a pool, written in order.
 int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const char* const* ref_ids,
                       const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
-                      int32_t gz_level, int32_t threads, char* err256, bool header = true) {
+                      int32_t gz_level, int32_t threads, char* err256, bool header = true, const midas::RowFeed* feed = nullptr) {
   Lap lap("write rows");
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
@@ -1462,15 +1462,35 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
     ok = gz_member(reinterpret_cast<const uint8_t*>(hdr), sizeof(hdr) - 1, gz_level, z) &&
          fwrite(z.data(), 1, z.size(), f) == z.size();
   }
-  const int64_t kRows = 1 << 14;   // rows per gzip member: enough members to keep every core busy on one species
-  struct Chunk { int32_t contig; int64_t lo, hi; };
+  const int64_t kRows = midas::kRowsPerMember;   // rows per gzip member: enough members to keep every core busy on one species
+  struct Chunk { int32_t contig; int64_t lo, hi; int32_t slab; int64_t in_slab; };
   std::vector<Chunk> chunks;
   std::vector<size_t> idlen((size_t)n_contigs);
+  // With a feed the sites are not in host memory yet: they arrive slab by slab (a run of sites that is contiguous at the
+  // source, whole members only) in a ring of the feed's slots, fetched by one thread while the others work on the
+  // slab before.
+  struct Slab { int64_t src_lo, n; int32_t chunks; const uint8_t* allele; const uint32_t* counts; };
+  std::vector<Slab> slabs;
   for (int32_t k = 0; k < n_contigs; ++k) {
     idlen[(size_t)k] = strlen(ref_ids[k]);
-    for (int64_t lo = 0; lo < n_sites[k]; lo += kRows) chunks.push_back({k, lo, std::min(n_sites[k], lo + kRows)});
+    for (int64_t lo = 0; lo < n_sites[k]; lo += kRows) {
+      const int64_t hi = std::min(n_sites[k], lo + kRows);
+      Chunk ch{k, lo, hi, -1, 0};
+      if (feed) {
+        const int64_t src = feed->source_site[k] + lo;
+        if (slabs.empty() || slabs.back().src_lo + slabs.back().n != src || slabs.back().n + (hi - lo) > feed->slab_sites)
+          slabs.push_back({src, 0, 0, nullptr, nullptr});
+        ch.slab = (int32_t)slabs.size() - 1;
+        ch.in_slab = slabs.back().n;
+        slabs.back().n += hi - lo;
+        slabs.back().chunks += 1;
+      }
+      chunks.push_back(ch);
+    }
   }
   const int64_t n_chunks = (int64_t)chunks.size();
+  std::vector<std::atomic<int>> slab_ready(slabs.size()), slab_left(slabs.size());
+  for (size_t k = 0; k < slabs.size(); ++k) { slab_ready[k] = 0; slab_left[k] = slabs[k].chunks; }
   int nt = writer_threads(threads);
   if ((int64_t)nt > n_chunks) nt = (int)std::max<int64_t>(1, n_chunks);
   std::vector<std::vector<uint8_t>> zbuf((size_t)n_chunks);
@@ -1490,8 +1510,17 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       const Chunk& ch = chunks[(size_t)ci];
       const char* id = ref_ids[ch.contig];
       const size_t il = idlen[(size_t)ch.contig];
-      const uint8_t* al = allele[ch.contig];
-      const uint32_t* cn = counts[ch.contig];
+      const uint8_t* al;
+      const uint32_t* cn;
+      if (feed) {          // (pointers biased so that site i of the contig is al[i] / cn[4 i], as below)
+        while (!slab_ready[(size_t)ch.slab].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (bad) return;
+        al = slabs[(size_t)ch.slab].allele + ch.in_slab - ch.lo;
+        cn = slabs[(size_t)ch.slab].counts + 4 * (ch.in_slab - ch.lo);
+      } else {
+        al = allele[ch.contig];
+        cn = counts[ch.contig];
+      }
       text.resize((size_t)(ch.hi - ch.lo) * (il + 80));
       row_at.resize((size_t)(ch.hi - ch.lo));
       tail_at.resize((size_t)(ch.hi - ch.lo));
@@ -1516,7 +1545,22 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       const bool done_ok = row_coder ? gz_member_rows(t8, tn, row_at.data(), tail_at.data(), row_at.size(), zbuf[(size_t)ci], (uint32_t)(ch.hi - ch.lo))
                                      : gz_member(t8, tn, gz_level, zbuf[(size_t)ci], (uint32_t)(ch.hi - ch.lo));
       if (!done_ok) bad = 1;
+      if (feed) slab_left[(size_t)ch.slab].fetch_sub(1, std::memory_order_release);
       done[(size_t)ci] = 1;
+    }
+  };
+  // (with a feed) one thread brings the slabs in, a ring slot being reused once every chunk of its previous slab is done
+  auto fetch = [&] {
+    for (size_t k = 0; k < slabs.size(); ++k) {
+      if (k >= (size_t)feed->n_slots)
+        while (slab_left[k - (size_t)feed->n_slots].load(std::memory_order_acquire) > 0 && !bad) std::this_thread::yield();
+      if (!bad && !feed->fetch(feed->user, (int)(k % (size_t)feed->n_slots), slabs[k].src_lo, slabs[k].n, &slabs[k].allele, &slabs[k].counts)) bad = 1;
+      if (bad) {          // let everybody out
+        for (size_t j = k; j < slabs.size(); ++j) slab_ready[j].store(1, std::memory_order_release);
+        for (auto& d : done) d = 1;
+        return;
+      }
+      slab_ready[k].store(1, std::memory_order_release);
     }
   };
   // one thread writes the finished chunks in order while the others format / compress the next ones
@@ -1532,7 +1576,13 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
   };
   std::atomic<int> role{0};
   lap("setup");
-  Workers::run(nt + 1, [&] { if (role.fetch_add(1) == 0) drain(); else work(); });
+  const int extra = feed && !slabs.empty() ? 2 : 1;
+  Workers::run(nt + extra, [&] {
+    const int r = role.fetch_add(1);
+    if (r == 0) drain();
+    else if (r == 1 && extra == 2) fetch();
+    else work();
+  });
   lap("format + gzip + write");
   if (fclose(f) != 0) ok = false;
   lap("fclose");
@@ -1540,6 +1590,15 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
   return MIDAS_SNPS_OK;
 }
 }  // namespace
+
+}  // extern "C"
+namespace midas {
+int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
+                       int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256) {
+  return write_contigs(path, false, n_contigs, ref_ids, n_sites, nullptr, nullptr, gz_level, threads, err256, with_header, &feed);
+}
+}  // namespace midas
+extern "C" {
 
 int32_t midas_snps_deflate_rows(const uint8_t* text, int64_t n, const uint32_t* row_begin, const uint32_t* tail_begin,
                                 int64_t n_rows, uint8_t* out, int64_t out_cap, int64_t* out_len) {

@@ -18,6 +18,7 @@
 #include "ctx_internal.h"
 #include "kernels.h"
 #include "layout.h"
+#include "hostio.h"
 #include "pack.h"
 #include "workers.h"
 
@@ -47,6 +48,7 @@ struct midas_snps_batch {
   int key_bits = 1;
   PackParams pk;                      // every pointer of a pack, filled once the buffers exist
   uint32_t* h_tile_reads = nullptr;   // pinned: reads every tile will see, fetched once per pack for the hot-spot plan
+  std::vector<int64_t> h_contig_site; // [n_contigs + 1] first site of every contig in d_counts / d_allele
   std::vector<uint32_t> h_items;      // the work items last uploaded
   int64_t pack_count = 0;
   // device: the packed layout (layout.h)
@@ -643,6 +645,8 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     }
     tile_base[contigs->n_contigs] = (int32_t)tiles.size();
     rbeg[contigs->n_contigs] = (int32_t)n;
+    b->h_contig_site.assign((size_t)contigs->n_contigs + 1, 0);
+    for (int32_t c = 0; c < contigs->n_contigs; ++c) b->h_contig_site[(size_t)c + 1] = b->h_contig_site[(size_t)c] + contigs->length[c];
   }
   b->n_tiles = (int64_t)tiles.size();
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
@@ -1004,6 +1008,69 @@ int32_t midas_snps_batch_fetch(midas_snps_batch* b, uint32_t* out_counts, uint8_
   }
   if (out_stats && b->n_species > 0)
     HIP_TRY(ctx, hipMemcpy(out_stats, work_stats(b), (size_t)b->n_species * MIDAS_STATS * 8, hipMemcpyDeviceToHost));
+  return MIDAS_SNPS_OK;
+}
+
+// Rows of a table straight from the batch's device results: the formatter's threads work on one slab of sites in the
+// context's pinned ring while the next one crosses the link, so neither a host copy of the whole result nor the time of
+// its transfer is ever paid on its own.
+namespace {
+struct BatchFeed {
+  midas_snps_batch* b;
+  int64_t slab_sites;
+  hipError_t err = hipSuccess;
+};
+bool batch_feed_fetch(void* user, int slot, int64_t src_lo, int64_t n, const uint8_t** allele, const uint32_t** counts) {
+  BatchFeed* f = static_cast<BatchFeed*>(user);
+  midas_snps_batch* b = f->b;
+  midas_snps_ctx* ctx = b->ctx;
+  hipStream_t s = ctx->stream;
+  hipError_t e = hipSetDevice(ctx->device);     // (called from one of the library's worker threads)
+  uint8_t* base = static_cast<uint8_t*>(ctx->stage[slot]);
+  uint8_t* al = base + (size_t)f->slab_sites * 16;
+  if (e == hipSuccess && n > 0) {
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, base, 0) == hipSuccess && mapped) {
+      hipLaunchKernelGGL(copy_out_kernel, dim3(1024), dim3(256), 0, s, static_cast<copy_u32x4*>(mapped),
+                         reinterpret_cast<const copy_u32x4*>(b->d_counts + 4 * src_lo), (size_t)n);
+      e = hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+      e = hipMemcpyAsync(base, b->d_counts + 4 * src_lo, (size_t)n * 16, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(al, b->d_allele + src_lo, (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) { f->err = e; return false; }
+  *allele = al;
+  *counts = reinterpret_cast<const uint32_t*>(base);
+  return true;
+}
+}  // namespace
+
+int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32_t with_header, int32_t n_contigs,
+                                    const int32_t* contig_index, const char* const* ref_ids, int32_t gz_level, int32_t threads) {
+  if (!b || !path || n_contigs < 0 || (n_contigs > 0 && (!contig_index || !ref_ids))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  int32_t st = midas_snps_batch_sync(b);
+  if (st != MIDAS_SNPS_OK) return st;
+  if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part before batch_run");
+  std::vector<int64_t> n_sites((size_t)n_contigs), src((size_t)n_contigs);
+  for (int32_t k = 0; k < n_contigs; ++k) {
+    const int32_t c = contig_index[k];
+    if (c < 0 || c >= b->n_contigs || !ref_ids[k]) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part: contig index out of range");
+    src[(size_t)k] = b->h_contig_site[(size_t)c];
+    n_sites[(size_t)k] = b->h_contig_site[(size_t)c + 1] - b->h_contig_site[(size_t)c];
+  }
+  constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
+  for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
+    if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, hipHostMallocDefault));
+  BatchFeed user{b, (int64_t)(kChunk / 17 / (size_t)kRowsPerMember) * kRowsPerMember};
+  RowFeed feed{src.data(), user.slab_sites, midas_snps_ctx::kStageSlots, &user, batch_feed_fetch};
+  char err[256] = {0};
+  st = write_rows_fed(path, with_header != 0, n_contigs, ref_ids, n_sites.data(), gz_level, threads, feed, err);
+  if (user.err != hipSuccess) return hip_fail(ctx, user.err, "batch_write_part: results to host");
+  if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
   return MIDAS_SNPS_OK;
 }
 

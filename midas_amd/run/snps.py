@@ -231,10 +231,14 @@ def _part_path(args, species_id, k):
     return '%s/snps/output/%s.snps.gz.part%06d' % (args['outdir'], species_id, k)
 
 
-def _write_rows(args, path, table, pos, cids, counts, allele, off, header):
+def _write_rows(args, path, table, pos, cids, counts, allele, off, header, batch=None):
     ks = [pos[cid] for cid in cids]
+    level, threads = int(args.get('gz_level', GZ_LEVEL)), int(args.get('threads', 1) or 1)
+    if batch is not None:
+        batch.write_part(path, ks, cids, header=header is None or bool(header), gz_level=level, threads=threads)
+        return
     abi.write_table(path, cids, [allele[off[k]:off[k + 1]] for k in ks], [counts[off[k]:off[k + 1]] for k in ks],
-                    gz_level=int(args.get('gz_level', GZ_LEVEL)), threads=int(args.get('threads', 1) or 1), header=header)
+                    gz_level=level, threads=threads, header=header)
 
 
 def _write_species(args, species_id, table, counts, allele):
@@ -254,14 +258,32 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
     ref_names, ref_lens, refid, reads = decoded
     table, sub = _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads)
     thr = abi.Thresholds.from_args(args)
-    if mine:
-        try:        # the rows are formatted straight from the context's page-locked result buffers
-            counts, allele, stats = ctx.pileup(thr, table, sub, pinned_slot=0)
-        except TypeError:       # (a test double of the device without that option)
-            counts, allele, stats = ctx.pileup(thr, table, sub)
+    batch = None
+    if mine and hasattr(ctx, 'batch'):
+        # the results stay on the device: the row writer takes them slab by slab through the context's page-locked ring
+        # (midas_snps_batch_write_part), formatting one slab while the next crosses the link
+        batch = ctx.batch(table, sub)
+        try:
+            batch.run(thr)
+            _, _, stats = batch.fetch(counts=False, allele=False)
+        except BaseException:
+            batch.close()
+            raise
+        counts = allele = None
+    elif mine:      # (a test double of the device: one-shot call, host arrays)
+        counts, allele, stats = ctx.pileup(thr, table, sub)
     else:       # more ranks than contigs: nothing to do here
         counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
         stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)
+    try:
+        return _emit_contigs(args, species_ids, table, order, owner, counts, allele, stats, batch)
+    finally:
+        if batch is not None:
+            batch.close()
+
+
+def _emit_contigs(args, species_ids, table, order, owner, counts, allele, stats, batch):
+    """The rows and the partial counters of _pileup_contigs, from host arrays or (batch) from the device results."""
     rank, _ = dist.world()
     genome_length = np.bincount(table.species, weights=table.length, minlength=len(species_ids)).astype(np.int64)
     pos = {cid: k for k, cid in enumerate(table.ids)}
@@ -272,7 +294,7 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
         owned = [owner.get(cid, 0) == rank for cid in cids]
         if all(owned):       # (a species without contigs still gets its header-only file, from rank 0)
             if cids or rank == 0:
-                _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], sp), table, pos, cids, counts, allele, off, None)
+                _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], sp), table, pos, cids, counts, allele, off, None, batch)
         else:
             k = 0
             while k < len(cids):     # maximal runs of consecutive contigs this rank owns; part k starts at sorted index k
@@ -282,7 +304,7 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
                 e = k
                 while e < len(cids) and owned[e]:
                     e += 1
-                _write_rows(args, _part_path(args, sp, k), table, pos, cids[k:e], counts, allele, off, k == 0)
+                _write_rows(args, _part_path(args, sp, k), table, pos, cids[k:e], counts, allele, off, k == 0, batch)
                 k = e
         if any(owned) or (not cids and rank == 0):
             out[sp] = {'genome_length': int(genome_length[i]),

@@ -63,3 +63,38 @@ def test_reference_exceptions_become_error_exits(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1
     assert "NM" in r.stderr and "read 17" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rows_streamed_from_the_device_are_the_bytes_of_the_host_writer(tmp_path):
+    """midas_snps_batch_write_part: the rows leave the device slab by slab through the pinned ring while the formatter
+    works -- the file must be byte for byte what batch_fetch + midas_snps_write_part write, for whole tables, parts, contig
+    subsets in any order, a contig longer than a ring slot, and at both kinds of gzip level."""
+    from midas_amd import abi, synth
+    import numpy as np
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=30011, n_reads=30000, seed=17, var_len=True)
+    long_contigs, long_reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=2_500_000, n_reads=20000, seed=18)
+    thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
+    with abi.Context(0) as ctx:
+        for tag, (tab, rd) in {"small": (contigs, reads), "long": (long_contigs, long_reads)}.items():
+            b = ctx.batch(tab, rd)
+            try:
+                b.run(thr)
+                counts, allele, _ = b.fetch()
+                off = tab.site_offsets()
+                nc = tab.n_contigs
+                picks = [list(range(nc)), list(range(nc))[::-1], [nc - 1], [], [1, 0] if nc > 1 else [0]]
+                for k, pick in enumerate(picks):
+                    names = ["ctg_%s_%d" % (tag, c) for c in pick]
+                    for header in (True, False):
+                        for level in (4, 6):
+                            a = str(tmp_path / ("dev_%s_%d_%d_%d.gz" % (tag, k, header, level)))
+                            h = str(tmp_path / ("host_%s_%d_%d_%d.gz" % (tag, k, header, level)))
+                            b.write_part(a, pick, names, header=header, gz_level=level, threads=7)
+                            abi.write_table(h, names, [allele[off[c]:off[c + 1]] for c in pick],
+                                            [counts[off[c]:off[c + 1]] for c in pick], gz_level=level, threads=5, header=header)
+                            assert open(a, "rb").read() == open(h, "rb").read(), (tag, pick, header, level)
+                with pytest.raises(abi.MidasSnpsError):
+                    b.write_part(str(tmp_path / "bad.gz"), [nc], ["x"])
+            finally:
+                b.close()
