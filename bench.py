@@ -60,6 +60,7 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
     """The C oracle ("port" of the reference semantics) timed on this host: 1 core, then all cores with one task per
     contig, then the reference's own grain (one worker per species, midas/run/snps.py:225-228).
     Returns (1-core dict, all-cores dict, species-grain dict, outputs of the 1-core pass)."""
+    from midas_amd import utility
     from oracle import c_oracle
     c_oracle.build()
     t0 = time.perf_counter()
@@ -75,8 +76,10 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
     one = {"value": sites / el, "unit": "sites/s", "cores": 1, "kind": "port",
            "sample": "%d pass(es) of the full workload (%d sites, %d reads) through oracle/pileup_oracle.c, %.1f s"
                      % (passes, contigs.n_sites, reads.n_reads, el),
-           "host_cores_available": os.cpu_count()}
-    ncpu = os.cpu_count() or 1
+           "host_hardware_threads": os.cpu_count(), "host_cpu_budget": utility.cpu_budget()}
+    # all the CPUs this process may use: the hardware threads, or the cgroup's quota when that is less (a container that
+    # shows 256 threads under a 16-CPU quota gets 16 CPUs' worth of work per second however many threads it starts)
+    ncpu = utility.cpu_budget()
     more = []
     for grain, workers in (("contig", min(ncpu, contigs.n_contigs)), ("species", min(ncpu, contigs.n_species))):
         t0 = time.perf_counter()
@@ -91,6 +94,7 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
                 break
         more.append({"value": contigs.n_sites * passes / el, "unit": "sites/s", "cores": int(workers), "kind": "port",
                      "grain": "one task per %s" % grain, "equals_1core_output": bool(ok),
+                     "host_hardware_threads": os.cpu_count(), "host_cpu_budget": ncpu,
                      "sample": "%d pass(es) of the full workload over %d threads, %.1f s" % (passes, workers, el)})
     return one, more[0], more[1], out
 

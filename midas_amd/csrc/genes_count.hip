@@ -26,6 +26,7 @@
 
 #include "../../include/midas_snps.h"
 #include "ctx_internal.h"
+#include "workers.h"
 #include "device_common.h"
 #include "kernels.h"
 
@@ -165,8 +166,7 @@ int32_t gfail(midas_snps_ctx* ctx, int32_t st, const char* msg) {
 
 template <class F>
 void host_ranges(int64_t n, F&& fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1, 64);
+  int nt = std::min(midas::cpu_budget(), 64);
   if (n < (int64_t)1 << 15) nt = 1;
   if (nt == 1) { fn((int64_t)0, n); return; }
   std::vector<std::thread> th;

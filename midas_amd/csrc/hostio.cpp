@@ -140,8 +140,7 @@ inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v;
 inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 
 int hw_threads(int want) {
-  unsigned n = std::thread::hardware_concurrency();
-  if (n == 0) n = 1;
+  unsigned n = (unsigned)midas::cpu_budget();      // hardware threads, or the cgroup's CPU quota when that is less
   if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
   if (n > 128) n = 128;
   return (int)n;
@@ -153,8 +152,7 @@ int hw_threads(int want) {
 #define MIDAS_WRITER_MAX_THREADS 128
 #endif
 int writer_threads(int want) {
-  unsigned n = std::thread::hardware_concurrency();
-  if (n == 0) n = 1;
+  unsigned n = (unsigned)midas::cpu_budget();
   if (want > 0) n = std::min<unsigned>(n, (unsigned)want);
   if (n > MIDAS_WRITER_MAX_THREADS) n = MIDAS_WRITER_MAX_THREADS;
   return (int)n;
@@ -1497,6 +1495,7 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
   std::vector<std::atomic<int>> done((size_t)n_chunks);
   for (auto& d : done) d = 0;
   std::atomic<int64_t> next{0};
+  midas::Events events;      // chunk done / slab ready / slot free: the waits below sleep on it
   std::atomic<int> bad{0};
   // levels 1-5: the row coder (row_deflate.h: one table lookup per row, about zlib level 4's size at a fraction of its
   // time); 6-9: zlib at that level; 0: zlib, stored
@@ -1513,7 +1512,7 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       const uint8_t* al;
       const uint32_t* cn;
       if (feed) {          // (pointers biased so that site i of the contig is al[i] / cn[4 i], as below)
-        while (!slab_ready[(size_t)ch.slab].load(std::memory_order_acquire)) std::this_thread::yield();
+        events.wait([&] { return slab_ready[(size_t)ch.slab].load(std::memory_order_acquire) != 0; });
         if (bad) return;
         al = slabs[(size_t)ch.slab].allele + ch.in_slab - ch.lo;
         cn = slabs[(size_t)ch.slab].counts + 4 * (ch.in_slab - ch.lo);
@@ -1547,32 +1546,46 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       if (!done_ok) bad = 1;
       if (feed) slab_left[(size_t)ch.slab].fetch_sub(1, std::memory_order_release);
       done[(size_t)ci] = 1;
+      events.signal();
     }
   };
   // (with a feed) one thread brings the slabs in, a ring slot being reused once every chunk of its previous slab is done
+#ifdef MIDAS_HOSTIO_TRACE
+  const auto t_begin = std::chrono::steady_clock::now();
+#endif
   auto fetch = [&] {
     for (size_t k = 0; k < slabs.size(); ++k) {
       if (k >= (size_t)feed->n_slots)
-        while (slab_left[k - (size_t)feed->n_slots].load(std::memory_order_acquire) > 0 && !bad) std::this_thread::yield();
+        events.wait([&] { return slab_left[k - (size_t)feed->n_slots].load(std::memory_order_acquire) <= 0 || bad; });
+#ifdef MIDAS_HOSTIO_TRACE
+      const auto t0 = std::chrono::steady_clock::now();
+#endif
       if (!bad && !feed->fetch(feed->user, (int)(k % (size_t)feed->n_slots), slabs[k].src_lo, slabs[k].n, &slabs[k].allele, &slabs[k].counts)) bad = 1;
+#ifdef MIDAS_HOSTIO_TRACE
+      fprintf(stderr, "[write rows] slab %zu of %zu: %lld sites, %d members, fetched in %.2f ms (waited for the slot until %.2f ms)\n", k, slabs.size(),
+              (long long)slabs[k].n, slabs[k].chunks, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+              std::chrono::duration<double, std::milli>(t0 - t_begin).count());
+#endif
       if (bad) {          // let everybody out
         for (size_t j = k; j < slabs.size(); ++j) slab_ready[j].store(1, std::memory_order_release);
         for (auto& d : done) d = 1;
+        events.signal();
         return;
       }
       slab_ready[k].store(1, std::memory_order_release);
+      events.signal();
     }
   };
   // one thread writes the finished chunks in order while the others format / compress the next ones
   auto drain = [&] {
     for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      events.wait([&] { return done[(size_t)ci].load() != 0; });
       if (bad) { ok = false; break; }
       std::vector<uint8_t>& z = zbuf[(size_t)ci];
       ok = fwrite(z.data(), 1, z.size(), f) == z.size();
       std::vector<uint8_t>().swap(z);
     }
-    if (!ok) next = n_chunks;   // stop the pool
+    if (!ok) { next = n_chunks; bad = 1; events.signal(); }   // stop the pool (and the slab feeder)
   };
   std::atomic<int> role{0};
   lap("setup");
@@ -1662,6 +1675,7 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
   std::vector<std::atomic<int>> done((size_t)n_chunks);
   for (auto& d : done) d = 0;
   std::atomic<int64_t> next{0};
+  midas::Events events;      // chunk done / slab ready / slot free: the waits below sleep on it
   auto work = [&] {
     for (;;) {
       const int64_t ci = next.fetch_add(1);
@@ -1689,12 +1703,13 @@ int32_t midas_merge_write_matrix(const char* path, const char* header_line, int6
       }
       t.resize((size_t)(p - t.data()));
       done[(size_t)ci] = 1;
+      events.signal();
     }
   };
   // one thread writes the finished chunks in order while the others format / compress the next ones
   auto drain = [&] {
     for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      events.wait([&] { return done[(size_t)ci].load() != 0; });
       std::vector<char>& t = text[(size_t)ci];
       ok = fwrite(t.data(), 1, t.size(), f) == t.size();
       std::vector<char>().swap(t);
@@ -1749,6 +1764,7 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
   std::vector<std::atomic<int>> done((size_t)n_chunks);
   for (auto& d : done) d = 0;
   std::atomic<int64_t> next{0};
+  midas::Events events;      // chunk done / slab ready / slot free: the waits below sleep on it
   static const char* kSnpType[5] = {"NA", "mono", "bi", "tri", "quad"};
   auto work = [&] {
     char num[24];
@@ -1832,12 +1848,13 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
         t.append(aas); t.push_back('\n');
       }
       done[(size_t)ci] = 1;
+      events.signal();
     }
   };
   // one thread writes the finished chunks in order while the others format / compress the next ones
   auto drain = [&] {
     for (int64_t ci = 0; ci < n_chunks && ok; ++ci) {
-      while (!done[(size_t)ci].load()) std::this_thread::yield();
+      events.wait([&] { return done[(size_t)ci].load() != 0; });
       std::string& t = text[(size_t)ci];
       ok = fwrite(t.data(), 1, t.size(), f) == t.size();
       std::string().swap(t);

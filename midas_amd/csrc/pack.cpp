@@ -9,13 +9,14 @@
 #include <thread>
 #include <vector>
 
+#include "workers.h"
+
 namespace midas {
 
 namespace {
 
 int hw_threads() {
-  unsigned n = std::thread::hardware_concurrency();
-  if (n == 0) n = 1;
+  unsigned n = (unsigned)cpu_budget();
   if (n > 64) n = 64;
   return (int)n;
 }

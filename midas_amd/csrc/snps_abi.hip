@@ -26,6 +26,15 @@
 
 using namespace midas;
 
+// Page-locked host memory the device writes and host threads read: non-coherent (coarse-grained) allocations are ordinary
+// cached memory to the CPU -- the device's writes are visible once the stream has been synchronised, which every user
+// here does -- where the default, coherent kind is mapped uncached on these hosts: the row formatter read its input
+// 20 x slower from it (68 ms for 16 gzip members).
+#ifndef MIDAS_SNPS_HOST_ALLOC_FLAGS
+#define MIDAS_SNPS_HOST_ALLOC_FLAGS hipHostMallocNonCoherent
+#endif
+constexpr unsigned int kHostAllocFlags = MIDAS_SNPS_HOST_ALLOC_FLAGS;
+
 struct midas_snps_batch {
   midas_snps_ctx* ctx = nullptr;
   // device: the caller's BAM-native SoA, uploaded as it is (the device packer's input)
@@ -167,7 +176,7 @@ int32_t hip_fail(midas_snps_ctx* ctx, hipError_t e, const char* what) {
 // with HIP) take one DMA; pageable ones go through the context's pinned ring, 32 MiB at a time, the DMA of chunk k + 1
 // running while host threads move chunk k out (HIP's own pageable path reaches ~12 GB/s here, this one ~3x that).
 void parallel_copy(uint8_t* dst, const uint8_t* src, size_t n) {
-  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned hw = (unsigned)midas::cpu_budget();
   size_t nt = hw >= 32 ? 12 : (hw >= 8 ? 4 : 1);
   if (n < ((size_t)4 << 20)) nt = 1;
   if (nt == 1) { memcpy(dst, src, n); return; }
@@ -218,7 +227,7 @@ int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t byt
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
-    if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, hipHostMallocDefault));
+    if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
     if (!ctx->stage_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
   }
   const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
@@ -337,7 +346,7 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
 
 void* midas_snps_host_alloc(int64_t bytes) {
   void* p = nullptr;
-  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, kHostAllocFlags) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -794,7 +803,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMalloc(&b->d_key, m1 * 4));
   B_TRY(hipMemsetAsync(b->d_blob + b->blob_bytes, 0, 64, s));
   b->pk.rec = b->d_rec; b->pk.blob = b->d_blob; b->pk.orig = b->d_orig; b->pk.key_out = b->d_key;
-  B_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_tile_reads), nt * 4, hipHostMallocDefault));
+  B_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_tile_reads), nt * 4, kHostAllocFlags));
   B_TRY(launch_pack_order(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, b->key_bits, s));
   if (b->n_tiles > 0)
     B_TRY(hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
@@ -1015,6 +1024,12 @@ int32_t midas_snps_batch_fetch(midas_snps_batch* b, uint32_t* out_counts, uint8_
 // context's pinned ring while the next one crosses the link, so neither a host copy of the whole result nor the time of
 // its transfer is ever paid on its own.
 namespace {
+// The ring: the context's two 32 MiB staging buffers cut into 16 slots of 4 MiB (15 gzip members each).  Many small
+// slabs, not two large ones: a slot is reused only when every member of its previous slab is done, so with two slabs of
+// ~125 members each and ~128 formatter threads the whole pool moved in lock step at the pace of its slowest thread
+// (measured on a shared host: three rounds of ~86 ms).  With 240 members in flight a straggler holds up nobody.
+constexpr int kFeedSlotsPerStage = 8;
+constexpr size_t kFeedSlotBytes = midas_snps_ctx::kStageBytes / kFeedSlotsPerStage;
 struct BatchFeed {
   midas_snps_batch* b;
   int64_t slab_sites;
@@ -1026,7 +1041,7 @@ bool batch_feed_fetch(void* user, int slot, int64_t src_lo, int64_t n, const uin
   midas_snps_ctx* ctx = b->ctx;
   hipStream_t s = ctx->stream;
   hipError_t e = hipSetDevice(ctx->device);     // (called from one of the library's worker threads)
-  uint8_t* base = static_cast<uint8_t*>(ctx->stage[slot]);
+  uint8_t* base = static_cast<uint8_t*>(ctx->stage[slot / kFeedSlotsPerStage]) + (size_t)(slot % kFeedSlotsPerStage) * kFeedSlotBytes;
   uint8_t* al = base + (size_t)f->slab_sites * 16;
   if (e == hipSuccess && n > 0) {
     void* mapped = nullptr;
@@ -1064,9 +1079,9 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
-    if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, hipHostMallocDefault));
-  BatchFeed user{b, (int64_t)(kChunk / 17 / (size_t)kRowsPerMember) * kRowsPerMember};
-  RowFeed feed{src.data(), user.slab_sites, midas_snps_ctx::kStageSlots, &user, batch_feed_fetch};
+    if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
+  BatchFeed user{b, (int64_t)(kFeedSlotBytes / 17 / (size_t)kRowsPerMember) * kRowsPerMember};
+  RowFeed feed{src.data(), user.slab_sites, midas_snps_ctx::kStageSlots * kFeedSlotsPerStage, &user, batch_feed_fetch};
   char err[256] = {0};
   st = write_rows_fed(path, with_header != 0, n_contigs, ref_ids, n_sites.data(), gz_level, threads, feed, err);
   if (user.err != hipSuccess) return hip_fail(ctx, user.err, "batch_write_part: results to host");

@@ -4,6 +4,8 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <functional>
 #include <mutex>
@@ -11,6 +13,57 @@
 #include <vector>
 
 namespace midas {
+
+// CPUs this process may actually use: the hardware threads, or fewer when a cgroup CPU quota (cpu.max of cgroup v2,
+// cpu.cfs_quota_us / cpu.cfs_period_us of v1) says so.  A container that shows 256 hardware threads under a quota of
+// 16 CPUs runs 128 busy threads for an eighth of every 100 ms period and is throttled for the rest of it: more threads
+// than the quota buy nothing and turn every wait into a stall of most of a period.
+inline int cpu_budget() {
+  static const int budget = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    double quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64] = {0};
+      double p = 0;
+      if (fscanf(f, "%63s %lf", q, &p) == 2 && q[0] != 'm' && p > 0) { quota = atof(q); period = p; }
+      fclose(f);
+    } else {
+      FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+      FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      if (fq && fp && fscanf(fq, "%lf", &quota) == 1 && fscanf(fp, "%lf", &period) == 1) { /* read */ } else { quota = -1; }
+      if (fq) fclose(fq);
+      if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) {
+      const unsigned cap = (unsigned)((quota + period - 1) / period);
+      if (cap >= 1 && cap < hw) hw = cap;
+    }
+    return (int)hw;
+  }();
+  return budget;
+}
+
+// Waiting for another thread's progress without spinning (a yield loop burns the CPU quota of everybody else in the
+// cgroup): the waiter sleeps on a condition variable until the predicate holds; whoever changes what a predicate reads
+// calls signal() afterwards.
+class Events {
+ public:
+  template <class P>
+  void wait(P&& pred) {
+    if (pred()) return;
+    std::unique_lock<std::mutex> g(m_);
+    cv_.wait(g, pred);
+  }
+  void signal() {
+    { std::lock_guard<std::mutex> g(m_); }      // (a waiter is either before its check or already asleep)
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+};
 
 // The library's worker threads.  Every parallel region of the host code (inflate, record decode, row formatting + gzip, table
 // parsing) used to start its own std::threads and join them: on a 256-thread host that is ~130 thread starts per region,

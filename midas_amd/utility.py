@@ -71,3 +71,30 @@ def find_executable(name):
     """bowtie2 / samtools for --build_db and --align come from PATH (the reference ships its own binaries; this
     build ships none).  None when absent: only those two stages need them."""
     return shutil.which(name)
+
+
+def cpu_budget():
+    """CPUs this process may use: os.cpu_count(), or fewer under a cgroup CPU quota (cpu.max of cgroup v2,
+    cpu.cfs_quota_us / cpu.cfs_period_us of v1) -- the same rule as the native library's midas::cpu_budget()."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = period = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()[:2]
+            if q != 'max':
+                quota, period = float(q), float(p)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fq, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fp:
+                quota, period = float(fq.read()), float(fp.read())
+        except (OSError, ValueError):
+            pass
+    if quota and period and quota > 0 and period > 0:
+        n = max(1, min(n, int(math.ceil(quota / period))))
+    return n
