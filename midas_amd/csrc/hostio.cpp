@@ -1589,12 +1589,19 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
   };
   std::atomic<int> role{0};
   lap("setup");
-  const int extra = feed && !slabs.empty() ? 2 : 1;
-  Workers::run(nt + extra, [&] {
-    const int r = role.fetch_add(1);
-    if (r == 0) drain();
-    else if (r == 1 && extra == 2) fetch();
-    else work();
+  // roles: with a feed the calling thread brings the slabs in (it is the one thread that has already talked to the
+  // device -- a pool thread's first HIP call costs ~13 ms of per-thread set-up) and joins the formatters afterwards; the
+  // first of the others writes, the rest format
+  const bool feeding = feed && !slabs.empty();
+  const std::thread::id caller = std::this_thread::get_id();
+  Workers::run(nt + (feeding ? 2 : 1), [&] {
+    if (feeding && std::this_thread::get_id() == caller) {
+      fetch();
+      work();
+      if (role.fetch_add(1) == 0) drain();     // (no other thread has arrived yet: a tiny table on a slow-to-wake pool)
+      return;
+    }
+    if (role.fetch_add(1) == 0) drain(); else work();
   });
   lap("format + gzip + write");
   if (fclose(f) != 0) ok = false;
