@@ -1,3 +1,5 @@
+"""Developer script (GPU box): how fast host threads read the library's page-locked memory (midas_snps_host_alloc) compared
+with ordinary memory -- the row formatter reads its input from such buffers.  usage: python tools/pinned_read_rate.py"""
 import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, '.')
