@@ -300,3 +300,30 @@ def test_cli_argument_checks_follow_the_reference(tmp_path):
     # dead flags of the reference are accepted
     r = _cli("snps", str(tmp_path / "out"), "--pileup", "-d", db, "--discard", "--baq", "--adjust_mq", "--baseq", "101")
     assert r.returncode == 1 and "BASEQ" in r.stderr
+
+
+def test_cpu_budget_is_the_quota_or_the_hardware(monkeypatch, tmp_path):
+    """utility.cpu_budget: hardware threads, or the cgroup's CPU quota when that is smaller (the native library applies
+    the same rule to its thread counts)."""
+    import builtins
+    from midas_amd import utility
+    n = utility.cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake(limit):
+        def opener(path, *a, **k):
+            if path == '/sys/fs/cgroup/cpu.max':
+                return io.StringIO(limit)
+            return real_open(path, *a, **k)
+        return opener
+    monkeypatch.setattr(os, 'cpu_count', lambda: 64)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(64)), raising=False)
+    monkeypatch.setattr(builtins, 'open', fake("1600000 100000\n"))
+    assert utility.cpu_budget() == 16
+    monkeypatch.setattr(builtins, 'open', fake("150000 100000\n"))
+    assert utility.cpu_budget() == 2                      # a fraction of a CPU counts as one more thread
+    monkeypatch.setattr(builtins, 'open', fake("max 100000\n"))
+    assert utility.cpu_budget() == 64
+    monkeypatch.setattr(builtins, 'open', fake("99900000 100000\n"))
+    assert utility.cpu_budget() == 64                     # a quota above the hardware changes nothing
