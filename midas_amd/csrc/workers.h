@@ -17,7 +17,8 @@ namespace midas {
 // CPUs this process may actually use: the hardware threads, or fewer when a cgroup CPU quota (cpu.max of cgroup v2,
 // cpu.cfs_quota_us / cpu.cfs_period_us of v1) says so.  A container that shows 256 hardware threads under a quota of
 // 16 CPUs runs 128 busy threads for an eighth of every 100 ms period and is throttled for the rest of it: more threads
-// than the quota buy nothing and turn every wait into a stall of most of a period.
+// than the quota buy nothing and turn every wait into a stall of most of a period.  Under torchrun the budget is the
+// rank's share of the node (LOCAL_WORLD_SIZE ranks run side by side).
 inline int cpu_budget() {
   static const int budget = [] {
     unsigned hw = std::thread::hardware_concurrency();
@@ -38,6 +39,11 @@ inline int cpu_budget() {
     if (quota > 0 && period > 0) {
       const unsigned cap = (unsigned)((quota + period - 1) / period);
       if (cap >= 1 && cap < hw) hw = cap;
+    }
+    // one process per GPU under torchrun: the node's CPUs are shared by LOCAL_WORLD_SIZE ranks
+    if (const char* lws = getenv("LOCAL_WORLD_SIZE")) {
+      const long ranks = atol(lws);
+      if (ranks > 1) hw = hw / (unsigned)ranks > 0 ? hw / (unsigned)ranks : 1u;
     }
     return (int)hw;
   }();

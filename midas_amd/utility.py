@@ -97,4 +97,10 @@ def cpu_budget():
             pass
     if quota and period and quota > 0 and period > 0:
         n = max(1, min(n, int(math.ceil(quota / period))))
+    try:        # one process per GPU under torchrun: the node's CPUs are shared by LOCAL_WORLD_SIZE ranks
+        ranks = int(os.environ.get('LOCAL_WORLD_SIZE', '1'))
+    except ValueError:
+        ranks = 1
+    if ranks > 1:
+        n = max(1, n // ranks)
     return n

@@ -327,3 +327,7 @@ def test_cpu_budget_is_the_quota_or_the_hardware(monkeypatch, tmp_path):
     assert utility.cpu_budget() == 64
     monkeypatch.setattr(builtins, 'open', fake("99900000 100000\n"))
     assert utility.cpu_budget() == 64                     # a quota above the hardware changes nothing
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')           # torchrun: eight ranks share the node
+    assert utility.cpu_budget() == 8
+    monkeypatch.setattr(builtins, 'open', fake("400000 100000\n"))
+    assert utility.cpu_budget() == 1
