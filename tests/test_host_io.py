@@ -88,7 +88,8 @@ def test_record_walk_is_not_fooled_by_bytes_that_look_like_records(tmp_path):
         starts.append(p)
         p += 4 + int(np.frombuffer(raw, '<i4', 1, p)[0])
     starts = np.array(starts)
-    nt = min(os.cpu_count() or 1, 128)
+    from midas_amd import utility
+    nt = min(utility.cpu_budget(), 128)            # the library's own thread budget (hostio.cpp hw_threads)
     span = total - rec_begin
     n_pieces = min(nt * 4, span >> 20)
     assert n_pieces >= 8
