@@ -15,7 +15,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 STAT_ALIGNED_READS, STAT_MAPPED_READS, STAT_COVERED_BASES, STAT_TOTAL_DEPTH = range(4)
 NUM_STATS = 4
@@ -83,7 +83,14 @@ class _Contigs(C.Structure):
 class BatchInfo(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_sites", C.c_int64), ("n_tiles", C.c_int64),
                 ("packed_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
-                ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32), ("n_work_items", C.c_int64)]
+                ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32), ("n_work_items", C.c_int64),
+                ("path", C.c_int32), ("path_auto", C.c_int32), ("lane_bases", C.c_int32), ("reserved0", C.c_int32),
+                ("direct_general_reads", C.c_int64), ("direct_general_entries", C.c_int64),
+                ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64)]
+
+
+PATH_AUTO, PATH_DIRECT, PATH_PACKED = 0, 1, 2
+PATH_NAMES = {PATH_AUTO: "auto", PATH_DIRECT: "direct", PATH_PACKED: "packed"}
 
 
 _SOA_DTYPES = {
@@ -214,6 +221,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_time_pileup_only': (i32, [vp, i32]),
         'midas_snps_batch_stats_to_device': (i32, [vp, vp]),
         'midas_snps_batch_pack': (i32, [vp]),
+        'midas_snps_batch_select_path': (i32, [vp, i32]),
+        'midas_snps_set_default_path': (i32, [vp, i32]),
         'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
         'midas_snps_batch_pack_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
@@ -270,6 +279,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
+    'midas_snps_batch_select_path', 'midas_snps_set_default_path',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
@@ -682,6 +692,10 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         self._check(self._lib.midas_snps_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
+    def set_default_path(self, path: int):
+        """The path of every batch created on this context from now on (PATH_AUTO: each batch's own choice)."""
+        self._check(self._lib.midas_snps_set_default_path(self._h, int(path)))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         ncu = C.c_int32(0)
@@ -817,6 +831,11 @@ class Batch:
 
     def last_timing(self):
         return self.timing((self._timed - 1) % self._slots)
+
+    def select_path(self, path: int):
+        """PATH_DIRECT: the pileup kernel reads the raw arrays; PATH_PACKED: tile-ordered records + payload; PATH_AUTO: the
+        batch's own choice (midas_snps_batch_select_path)."""
+        self.ctx._check(self._lib.midas_snps_batch_select_path(self._h, int(path)))
 
     def pack(self):
         """Re-run the device packer over the resident raw reads (midas_snps_batch_pack)."""

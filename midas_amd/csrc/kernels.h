@@ -146,6 +146,82 @@ hipError_t launch_pack_keys(const PackParams& p, hipStream_t s);                
 hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, int key_bits, hipStream_t s);   // dest, off8, tile_reads
 hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);                                // rec, blob, orig, key
 
+
+// ---- direct path (index_direct.hip + pileup_direct.hip): the pileup kernel reads the BAM-native arrays themselves ------
+// Coordinate-sorted input needs no packed payload: a classify pass (one thread per read) sorts the reads into
+//   class 0  `H* S? (M|=|X)+ S? H*`, lengths adding up, inside its contig, NM present: ONE gap-free match segment.  The
+//            pileup kernel finds these by position -- per tile the lowest and highest read index touching it
+//            (atomicMin / atomicMax; reads are position-sorted, so that is a contiguous range) -- and takes everything
+//            else it needs (clip lengths, aligned length) from one word per read, `info`;
+//   general  everything else (indels, skips, pads, odd clips, reads without NM / SEQ, positions outside the contig ...):
+//            gathered per tile into 48-byte descriptors (count -> scan -> fill), walked op by op on the device.
+// Unsorted input only widens the ranges (slower, never wrong); the host falls back to the packed path when the ranges of a
+// batch add up to much more than its reads.
+constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0; else lead | alen << 10 | trail << 21
+constexpr int kInfoAlenShift = 10, kInfoTrailShift = 21;
+constexpr int kGenDescWords = 12;                 // 48 bytes per (general read, tile) entry
+
+// gdesc flag bits
+constexpr uint32_t kGenQualUnused = 0;            // (QUAL absence is read from the quality bytes themselves)
+constexpr uint32_t kGenOverrun = 1;               // a match op maps a query position >= l_seq into the contig (IndexError if kept)
+constexpr uint32_t kGenNoNm = 2;                  // record has no NM tag
+
+constexpr int kDirectFactSlots = 64;
+struct alignas(128) DirectFacts {                 // per-slot partial sums of one classify pass (slot 0 also holds the status)
+  unsigned long long status;                      // min((read << 8) | kPack*), kNoError when every read is well-formed
+  unsigned long long alg_bytes;                   // sum(ceil(l/2) + l + 4*n_cigar + 16)
+  unsigned long long n_entries;                   // (general read, tile) entries
+  uint32_t n_general;                             // general reads (slot 0 only: it is the append cursor of gen_reads)
+  uint32_t max_l;                                 // longest read
+};
+struct DirectTotals {                             // the slots added up by the scan kernel (one per run, host reads it at create)
+  unsigned long long status, alg_bytes, n_entries;
+  uint32_t n_general, max_l;
+};
+
+struct DirectIndexParams {
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
+  const uint32_t* cigar;
+  int64_t seq_bytes, qual_bytes, n_cigar;
+  int32_t n_reads;
+  const int32_t* contig_read_begin; const int32_t* contig_tile_base; const int32_t* contig_len;
+  int32_t n_contigs, n_tiles, tile_shift;
+  uint32_t* info;                                 // [n_reads]
+  uint32_t* tbegin; uint32_t* tend;               // [n_tiles] this run's parity: min index / max index + 1 of the class-0 reads touching a tile
+  uint32_t* tbegin_next; uint32_t* tend_next;     // the other parity, reset here for the next run
+  uint32_t* gcount;                               // [n_tiles + 1] general entries per tile (zero on entry; the fill kernel counts it back to zero)
+  uint32_t* goff;                                 // [n_tiles + 1] exclusive scan of gcount
+  uint32_t* gen_reads;                            // [n_reads] the general reads, in no particular order
+  uint32_t* gdesc;                                // [n_entries][kGenDescWords]
+  int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)
+  DirectFacts* facts;                             // [kDirectFactSlots]
+  DirectTotals* totals;
+  unsigned long long* stats; unsigned long long* err;
+  int32_t n_stat_words;
+};
+
+struct DirectParams {
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm;
+  const int64_t* seq_off; const int64_t* qual_off;
+  const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
+  const uint32_t* info;
+  const uint32_t* tbegin; const uint32_t* tend; const uint32_t* goff; const uint32_t* gdesc;
+  const uint8_t* ref;
+  const Tile* tiles;
+  const FilterTables* filt;
+  uint32_t* out_counts; uint8_t* out_allele;
+  unsigned long long* stats; unsigned long long* err;
+  uint32_t* sched;                                // kSchedWords: {8 item counters, workgroups done}
+  int32_t n_tiles, n_reads, grid_blocks;
+  int32_t lanes_per_read, reads_per_wave, table_len;
+  int32_t baseq, mapq_min, readq;
+};
+
+hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
+hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
+int direct_lane_bases(int32_t max_l_seq);
+
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);
 hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream, bool whole_tiles, bool parts);   // barrier-phased
 hipError_t launch_pileup_stream(const PileupParams& p, hipStream_t stream);   // whole tiles, barrier-free

@@ -94,6 +94,24 @@ struct midas_snps_batch {
   int64_t n_reads = 0, n_sites = 0, n_tiles = 0, blob_bytes = 0, alg_bytes = 0;
   int64_t n_records = 0;   // device records (match segments + reads that keep their CIGAR) >= n_reads
   int32_t n_contigs = 0, n_species = 0, lanes_per_read = 1, lane_bases = 31, tile_len = kTileSites;
+  // ---- direct path (index_direct.hip + pileup_direct.hip): the pileup kernel reads the raw arrays above -----------------
+  int path = MIDAS_SNPS_PATH_DIRECT;   // the path batch_run takes
+  int path_auto = MIDAS_SNPS_PATH_DIRECT;   // what the batch's own numbers recommend
+  bool packed_built = false;    // rec / blob / orig / key exist (the packed path's layout is built on first use)
+  uint32_t* d_info = nullptr;   // [n_reads] class-0 info words
+  uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
+  uint32_t* d_gcount = nullptr; // [n_tiles + 1]
+  uint32_t* d_goff = nullptr;   // [n_tiles + 1]
+  uint32_t* d_gen_reads = nullptr;   // [n_reads]
+  uint32_t* d_gdesc = nullptr;  // [gdesc_capacity][kGenDescWords]
+  int64_t gdesc_capacity = 0;
+  DirectFacts* d_dfacts = nullptr;
+  DirectTotals* d_dtotals = nullptr;
+  DirectTotals h_dtotals{};
+  int32_t direct_lane_bases = 30, direct_lanes_per_read = 1;
+  int64_t direct_stream_reads = 0;   // sum over tiles of the positions their streams hold (>= n_reads: straddlers twice)
+  int64_t direct_max_tile_reads = 0;
+  int64_t direct_run_count = 0;
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot: before the index kernel, before and after the pileup kernel
   std::vector<hipEvent_t> pev; // 3 per slot: before the pack, before and after its scatter kernel
@@ -367,6 +385,12 @@ int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream) {
   return MIDAS_SNPS_OK;
 }
 
+int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path) {
+  if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  ctx->default_path = path;
+  return MIDAS_SNPS_OK;
+}
+
 int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes) {
   if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
   if (name256) snprintf(name256, 256, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
@@ -405,7 +429,8 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split,
+                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gdesc,
+                 b->d_dfacts, b->d_dtotals,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -554,6 +579,232 @@ int32_t run_pack(midas_snps_batch* b, hipEvent_t* ev) {
   return MIDAS_SNPS_OK;
 }
 
+
+uint32_t* trange_begin(midas_snps_batch* b, int par) { return b->d_trange + (size_t)par * 2 * (b->n_tiles > 0 ? b->n_tiles : 1); }
+uint32_t* trange_end(midas_snps_batch* b, int par) { return trange_begin(b, par) + (b->n_tiles > 0 ? b->n_tiles : 1); }
+
+void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
+  const int par = (int)(b->direct_run_count & 1);
+  ip->pos = b->d_pos; ip->mapq = b->d_mapq; ip->nm = b->d_nm; ip->l_seq = b->d_lseq;
+  ip->seq_off = b->d_seq_off; ip->qual_off = b->d_qual_off; ip->cigar_off = b->d_cigar_off;
+  ip->cigar = b->d_cigar;
+  ip->seq_bytes = b->seq_bytes; ip->qual_bytes = b->qual_bytes; ip->n_cigar = b->n_cigar;
+  ip->n_reads = (int32_t)b->n_reads;
+  ip->contig_read_begin = b->d_contig_read_begin; ip->contig_tile_base = b->d_contig_tile_base; ip->contig_len = b->d_contig_len;
+  ip->n_contigs = b->n_contigs; ip->n_tiles = (int32_t)b->n_tiles; ip->tile_shift = kTileShift;
+  ip->info = b->d_info;
+  ip->tbegin = trange_begin(b, par); ip->tend = trange_end(b, par);
+  ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
+  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads;
+  ip->gdesc = b->d_gdesc; ip->gdesc_capacity = b->gdesc_capacity;
+  ip->facts = b->d_dfacts; ip->totals = b->d_dtotals;
+  ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
+  ip->n_stat_words = b->d_work ? b->n_species * MIDAS_STATS : 0;
+}
+
+// Buffers of the direct path, and its index pass run once: every read validated on the device (the statuses of the packer),
+// the batch's totals, the descriptors of the general reads sized -- and the numbers the choice of path rests on.
+int32_t direct_prepare(midas_snps_batch* b) {
+  midas_snps_ctx* ctx = b->ctx;
+  hipStream_t s = ctx->stream;
+  const size_t n1 = (size_t)(b->n_reads > 0 ? b->n_reads : 1);
+  const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
+  HIP_TRY(ctx, hipMalloc(&b->d_info, n1 * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_gen_reads, n1 * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_trange, nt * 4 * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_gcount, (nt + 1) * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_goff, (nt + 1) * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots));
+  HIP_TRY(ctx, hipMalloc(&b->d_dtotals, sizeof(DirectTotals)));
+  HIP_TRY(ctx, hipMalloc(&b->d_gdesc, 64));
+  // tile bounds start clean (every pass resets the other parity's); counters at zero; status words at "no error"
+  HIP_TRY(ctx, hipMemsetAsync(b->d_trange, 0, nt * 16, s));
+  HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 0), 0xFF, nt * 4, s));
+  HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 1), 0xFF, nt * 4, s));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_gcount, 0, (nt + 1) * 4, s));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_goff, 0, (nt + 1) * 4, s));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_dfacts, 0, sizeof(DirectFacts) * kDirectFactSlots, s));
+  HIP_TRY(ctx, hipMemsetAsync(&b->d_dfacts->status, 0xFF, 8, s));
+  DirectIndexParams ip;
+  fill_direct_index(b, &ip);
+  HIP_TRY(ctx, launch_direct_index(ip, s));
+  HIP_TRY(ctx, hipMemcpyAsync(&b->h_dtotals, b->d_dtotals, sizeof(DirectTotals), hipMemcpyDeviceToHost, s));
+  std::vector<uint32_t> tb(nt), te(nt), go(nt + 1);
+  HIP_TRY(ctx, hipMemcpyAsync(tb.data(), ip.tbegin, nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(te.data(), ip.tend, nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(go.data(), b->d_goff, (nt + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  b->direct_run_count += 1;
+  const DirectTotals& t = b->h_dtotals;
+  if (t.status != kNoError) return pack_status_to_error(ctx, t.status);
+  b->max_l_seq = (int32_t)t.max_l;
+  b->alg_bytes = (int64_t)t.alg_bytes + 17 * b->n_sites;
+  b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
+  b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;
+  if (t.n_entries > 0) {
+    (void)hipFree(b->d_gdesc);
+    b->d_gdesc = nullptr;
+    HIP_TRY(ctx, hipMalloc(&b->d_gdesc, (size_t)t.n_entries * kGenDescWords * 4));
+    b->gdesc_capacity = (int64_t)t.n_entries;
+  }
+  // how well the reads are ordered: a tile's stream holds every read between the first and the last class-0 read touching it
+  int64_t stream = 0, worst = 0;
+  for (size_t k = 0; k < (size_t)b->n_tiles; ++k) {
+    const int64_t n0 = te[k] > tb[k] ? (int64_t)te[k] - (int64_t)tb[k] : 0, m = (int64_t)go[k + 1] - (int64_t)go[k];
+    stream += n0 + m;
+    worst = std::max(worst, n0 + m);
+  }
+  b->direct_stream_reads = stream;
+  b->direct_max_tile_reads = worst;
+  // Coordinate-sorted input makes the streams add up to the reads plus the few that straddle a tile border.  Much more than
+  // that (unsorted input), or one tile holding far more than a workgroup's fair share (a coverage hot spot: the packed path
+  // cuts such a tile into parts), and the packed path is the faster one.
+  const int64_t fair = stream / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
+  const bool ordered = stream <= b->n_reads + b->n_reads / 2 + 4096;
+  const bool hot = worst > std::max<int64_t>(2048, 2 * fair);
+  b->path_auto = (ordered && !hot) ? MIDAS_SNPS_PATH_DIRECT : MIDAS_SNPS_PATH_PACKED;
+  b->path = ctx->default_path == MIDAS_SNPS_PATH_AUTO ? b->path_auto : ctx->default_path;
+  return MIDAS_SNPS_OK;
+}
+
+// The packed path's device layout (layout.h), built on first use: plan, keys, order, scatter over the resident raw reads.
+int32_t ensure_packed(midas_snps_batch* b) {
+  if (b->packed_built) return MIDAS_SNPS_OK;
+  midas_snps_ctx* ctx = b->ctx;
+  hipStream_t s = ctx->stream;
+  char ebuf[256] = {0};
+  const int64_t n = b->n_reads, n_sites = b->n_sites;
+  const size_t n1 = (size_t)(n > 0 ? n : 1);
+  const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
+  const int64_t seq_bytes = b->seq_bytes, qual_bytes = b->qual_bytes, n_cigar = b->n_cigar;
+  auto lap = [](const char*) {};
+#define P_TRY(call)                                          \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+  } while (0)
+#define P_ST(expr)                          \
+  do {                                      \
+    int32_t s__ = (expr);                   \
+    if (s__ != MIDAS_SNPS_OK) return s__;   \
+  } while (0)
+  // ---- packer, step 1: plan (validates every read on the device; the sizes come back) ----------------------------
+  const size_t nbins = (size_t)b->n_tiles * kPackBinsPerTile + 1;
+  {
+    const size_t bytes = carved(n1, 1) + 2 * carved(n1 + 1, 4) + carved(kPackFactSlots, sizeof(PackFacts)) + carved(nbins, 4) + 2 * carved(nt, 4);
+    P_TRY(hipMalloc(&b->d_pack_reads, bytes));
+    uint8_t* cur = b->d_pack_reads;
+    PackParams& k = b->pk;
+    memset(&k, 0, sizeof k);
+    k.nseg = carve<uint8_t>(cur, n1);
+    k.cnt = carve<uint32_t>(cur, n1 + 1);
+    k.first = carve<uint32_t>(cur, n1 + 1);
+    k.facts = carve<PackFacts>(cur, kPackFactSlots);
+    k.bin_start = carve<uint32_t>(cur, nbins);
+    k.tile_extra = carve<uint32_t>(cur, nt);
+    k.tile_reads = carve<uint32_t>(cur, nt);
+    k.pos = b->d_pos; k.mapq = b->d_mapq; k.nm = b->d_nm; k.l_seq = b->d_lseq;
+    k.seq_off = b->d_seq_off; k.qual_off = b->d_qual_off; k.cigar_off = b->d_cigar_off;
+    k.seq4 = b->d_seq4; k.qual = b->d_qual; k.cigar = b->d_cigar;
+    k.seq_bytes = seq_bytes; k.qual_bytes = qual_bytes; k.n_cigar = n_cigar;
+    k.n_reads = (int32_t)n;
+    k.contig_read_begin = b->d_contig_read_begin; k.contig_tile_base = b->d_contig_tile_base; k.contig_len = b->d_contig_len;
+    k.n_contigs = b->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len; k.tile_shift = kTileShift;
+  }
+  b->key_bits = pack_key_bits((int32_t)b->n_tiles);
+  // the first scan needs scratch before the record count is known: size it for the reads, regrow below for the records
+  b->sort_tmp_bytes = pack_sort_temp_bytes((int64_t)n1 + 1, b->key_bits);
+  P_TRY(hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes));
+  P_TRY(launch_pack_plan(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, s));
+  PackFacts facts;
+  std::vector<PackFacts> slots(kPackFactSlots);
+  auto fetch_facts = [&]() -> hipError_t {   // the workgroups' partial sums, one slot per cache line
+    hipError_t e = hipMemcpyAsync(slots.data(), b->pk.facts, sizeof(PackFacts) * kPackFactSlots, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    facts = slots[0];
+    for (int k = 1; k < kPackFactSlots; ++k) {
+      facts.alg_bytes += slots[k].alg_bytes;
+      facts.blob_bytes += slots[k].blob_bytes;
+      facts.n_records += slots[k].n_records;
+      facts.max_l = std::max(facts.max_l, slots[k].max_l);
+    }
+    return e;
+  };
+  P_TRY(fetch_facts());
+  lap("pack: plan");
+  if (facts.status != kNoError) P_ST(pack_status_to_error(ctx, facts.status));
+  if (facts.n_records > 2000000000ull) {
+    snprintf(ebuf, sizeof ebuf, "%llu device records exceed the supported range", facts.n_records);
+    P_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
+  }
+  const int64_t m = (int64_t)facts.n_records;
+  b->n_records = m;
+  b->max_l_seq = (int32_t)facts.max_l;
+  b->alg_bytes = (int64_t)facts.alg_bytes + 17 * n_sites;
+  b->lane_bases = lane_bases_for(b->max_l_seq);
+  b->lanes_per_read = b->max_l_seq <= b->lane_bases ? 1 : (b->max_l_seq + b->lane_bases - 1) / b->lane_bases;
+
+  // ---- packer, step 2: keys + sizes ------------------------------------------------------------------------------
+  const size_t m1 = (size_t)(m > 0 ? m : 1);
+  {
+    const size_t bytes = 6 * carved(m1, 4) + 2 * carved(m1 + 1, 4) + carved(m1, 32);
+    P_TRY(hipMalloc(&b->d_pack_recs, bytes));
+    uint8_t* cur = b->d_pack_recs;
+    PackParams& k = b->pk;
+    k.sort_key = carve<uint32_t>(cur, m1);
+    k.sort_val = carve<uint32_t>(cur, m1);
+    k.key_sorted = carve<uint32_t>(cur, m1);
+    k.val_sorted = carve<uint32_t>(cur, m1);
+    k.bytes8 = carve<uint32_t>(cur, m1);
+    k.dest = carve<uint32_t>(cur, m1);
+    k.desc = carve<uint4>(cur, 2 * m1);
+    k.bytes8_dev = carve<uint32_t>(cur, m1 + 1);
+    k.off8 = carve<uint32_t>(cur, m1 + 1);
+    k.n_records = (int32_t)m;
+    k.lane_bases = b->lane_bases;
+    k.lanes_per_read = b->lanes_per_read;
+  }
+  {
+    const size_t need = pack_sort_temp_bytes((int64_t)std::max(m1, n1) + 1, b->key_bits);
+    if (need > b->sort_tmp_bytes) {
+      (void)hipFree(b->d_sort_tmp);
+      b->d_sort_tmp = nullptr;
+      P_TRY(hipMalloc(&b->d_sort_tmp, need));
+      b->sort_tmp_bytes = need;
+    }
+  }
+  P_TRY(launch_pack_keys(b->pk, s));
+  P_TRY(fetch_facts());
+  lap("pack: keys");
+  b->blob_bytes = (int64_t)facts.blob_bytes;
+  if (facts.blob_bytes / 8 > 0xFFFFFFFFull) {
+    snprintf(ebuf, sizeof ebuf, "packed payload %llu bytes exceeds the 32 GiB a batch can address", facts.blob_bytes);
+    P_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
+  }
+
+  // ---- packer, steps 3 + 4: device order, then records + payload ---------------------------------------------------
+  const size_t blob_alloc = (size_t)b->blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
+  P_TRY(hipMalloc(&b->d_rec, (size_t)(m + 1) * sizeof(ReadRec)));  // + sentinel
+  P_TRY(hipMalloc(&b->d_blob, blob_alloc));
+  P_TRY(hipMalloc(&b->d_orig, m1 * 4));
+  P_TRY(hipMalloc(&b->d_key, m1 * 4));
+  P_TRY(hipMemsetAsync(b->d_blob + b->blob_bytes, 0, 64, s));
+  b->pk.rec = b->d_rec; b->pk.blob = b->d_blob; b->pk.orig = b->d_orig; b->pk.key_out = b->d_key;
+  P_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_tile_reads), nt * 4, kHostAllocFlags));
+  P_TRY(launch_pack_order(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, b->key_bits, s));
+  if (b->n_tiles > 0)
+    P_TRY(hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
+  P_TRY(launch_pack_scatter(b->pk, s));
+  P_TRY(fetch_facts());
+  b->has_high_qual = slots[0].high_qual != 0;
+  b->pack_count = 1;
+  lap("pack: order + scatter");
+  P_ST(plan_work_items(b, b->h_tile_reads));
+  b->packed_built = true;
+#undef P_TRY
+#undef P_ST
+  return MIDAS_SNPS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -701,139 +952,42 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemsetAsync(b->d_cigar + n_cigar, 0, 64, s));
   lap("H2D raw reads");
 
-  // ---- packer, step 1: plan (validates every read on the device; the sizes come back) ----------------------------
-  const size_t nbins = (size_t)b->n_tiles * kPackBinsPerTile + 1;
-  {
-    const size_t bytes = carved(n1, 1) + 2 * carved(n1 + 1, 4) + carved(kPackFactSlots, sizeof(PackFacts)) + carved(nbins, 4) + 2 * carved(nt, 4);
-    B_TRY(hipMalloc(&b->d_pack_reads, bytes));
-    uint8_t* cur = b->d_pack_reads;
-    PackParams& k = b->pk;
-    memset(&k, 0, sizeof k);
-    k.nseg = carve<uint8_t>(cur, n1);
-    k.cnt = carve<uint32_t>(cur, n1 + 1);
-    k.first = carve<uint32_t>(cur, n1 + 1);
-    k.facts = carve<PackFacts>(cur, kPackFactSlots);
-    k.bin_start = carve<uint32_t>(cur, nbins);
-    k.tile_extra = carve<uint32_t>(cur, nt);
-    k.tile_reads = carve<uint32_t>(cur, nt);
-    k.pos = b->d_pos; k.mapq = b->d_mapq; k.nm = b->d_nm; k.l_seq = b->d_lseq;
-    k.seq_off = b->d_seq_off; k.qual_off = b->d_qual_off; k.cigar_off = b->d_cigar_off;
-    k.seq4 = b->d_seq4; k.qual = b->d_qual; k.cigar = b->d_cigar;
-    k.seq_bytes = seq_bytes; k.qual_bytes = qual_bytes; k.n_cigar = n_cigar;
-    k.n_reads = (int32_t)n;
-    k.contig_read_begin = b->d_contig_read_begin; k.contig_tile_base = b->d_contig_tile_base; k.contig_len = b->d_contig_len;
-    k.n_contigs = contigs->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len; k.tile_shift = kTileShift;
-  }
-  b->key_bits = pack_key_bits((int32_t)b->n_tiles);
-  // the first scan needs scratch before the record count is known: size it for the reads, regrow below for the records
-  b->sort_tmp_bytes = pack_sort_temp_bytes((int64_t)n1 + 1, b->key_bits);
-  B_TRY(hipMalloc(&b->d_sort_tmp, b->sort_tmp_bytes));
-  B_TRY(launch_pack_plan(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, s));
-  PackFacts facts;
-  std::vector<PackFacts> slots(kPackFactSlots);
-  auto fetch_facts = [&]() -> hipError_t {   // the workgroups' partial sums, one slot per cache line
-    hipError_t e = hipMemcpyAsync(slots.data(), b->pk.facts, sizeof(PackFacts) * kPackFactSlots, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    facts = slots[0];
-    for (int k = 1; k < kPackFactSlots; ++k) {
-      facts.alg_bytes += slots[k].alg_bytes;
-      facts.blob_bytes += slots[k].blob_bytes;
-      facts.n_records += slots[k].n_records;
-      facts.max_l = std::max(facts.max_l, slots[k].max_l);
-    }
-    return e;
-  };
-  B_TRY(fetch_facts());
-  lap("pack: plan");
-  if (facts.status != kNoError) B_ST(pack_status_to_error(ctx, facts.status));
-  if (facts.n_records > 2000000000ull) {
-    snprintf(ebuf, sizeof ebuf, "%llu device records exceed the supported range", facts.n_records);
-    B_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
-  }
-  const int64_t m = (int64_t)facts.n_records;
-  b->n_records = m;
-  b->max_l_seq = (int32_t)facts.max_l;
-  b->alg_bytes = (int64_t)facts.alg_bytes + 17 * n_sites;
-  b->lane_bases = lane_bases_for(b->max_l_seq);
-  b->lanes_per_read = b->max_l_seq <= b->lane_bases ? 1 : (b->max_l_seq + b->lane_bases - 1) / b->lane_bases;
-
-  // ---- packer, step 2: keys + sizes ------------------------------------------------------------------------------
-  const size_t m1 = (size_t)(m > 0 ? m : 1);
-  {
-    const size_t bytes = 6 * carved(m1, 4) + 2 * carved(m1 + 1, 4) + carved(m1, 32);
-    B_TRY(hipMalloc(&b->d_pack_recs, bytes));
-    uint8_t* cur = b->d_pack_recs;
-    PackParams& k = b->pk;
-    k.sort_key = carve<uint32_t>(cur, m1);
-    k.sort_val = carve<uint32_t>(cur, m1);
-    k.key_sorted = carve<uint32_t>(cur, m1);
-    k.val_sorted = carve<uint32_t>(cur, m1);
-    k.bytes8 = carve<uint32_t>(cur, m1);
-    k.dest = carve<uint32_t>(cur, m1);
-    k.desc = carve<uint4>(cur, 2 * m1);
-    k.bytes8_dev = carve<uint32_t>(cur, m1 + 1);
-    k.off8 = carve<uint32_t>(cur, m1 + 1);
-    k.n_records = (int32_t)m;
-    k.lane_bases = b->lane_bases;
-    k.lanes_per_read = b->lanes_per_read;
-  }
-  {
-    const size_t need = pack_sort_temp_bytes((int64_t)std::max(m1, n1) + 1, b->key_bits);
-    if (need > b->sort_tmp_bytes) {
-      (void)hipFree(b->d_sort_tmp);
-      b->d_sort_tmp = nullptr;
-      B_TRY(hipMalloc(&b->d_sort_tmp, need));
-      b->sort_tmp_bytes = need;
-    }
-  }
-  B_TRY(launch_pack_keys(b->pk, s));
-  B_TRY(fetch_facts());
-  lap("pack: keys");
-  b->blob_bytes = (int64_t)facts.blob_bytes;
-  if (facts.blob_bytes / 8 > 0xFFFFFFFFull) {
-    snprintf(ebuf, sizeof ebuf, "packed payload %llu bytes exceeds the 32 GiB a batch can address", facts.blob_bytes);
-    B_ST(fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, ebuf));
-  }
-
-  // ---- packer, steps 3 + 4: device order, then records + payload ---------------------------------------------------
-  const size_t blob_alloc = (size_t)b->blob_bytes + 64;  // slack: the last lane's 16-byte load may overhang
-  B_TRY(hipMalloc(&b->d_rec, (size_t)(m + 1) * sizeof(ReadRec)));  // + sentinel
-  B_TRY(hipMalloc(&b->d_blob, blob_alloc));
-  B_TRY(hipMalloc(&b->d_orig, m1 * 4));
-  B_TRY(hipMalloc(&b->d_key, m1 * 4));
-  B_TRY(hipMemsetAsync(b->d_blob + b->blob_bytes, 0, 64, s));
-  b->pk.rec = b->d_rec; b->pk.blob = b->d_blob; b->pk.orig = b->d_orig; b->pk.key_out = b->d_key;
-  B_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_tile_reads), nt * 4, kHostAllocFlags));
-  B_TRY(launch_pack_order(b->pk, b->d_sort_tmp, b->sort_tmp_bytes, b->key_bits, s));
-  if (b->n_tiles > 0)
-    B_TRY(hipMemcpyAsync(b->h_tile_reads, b->pk.tile_reads, (size_t)b->n_tiles * 4, hipMemcpyDeviceToHost, s));
-  B_TRY(launch_pack_scatter(b->pk, s));
-  B_TRY(fetch_facts());
-  b->has_high_qual = slots[0].high_qual != 0;
-  b->pack_count = 1;
-  lap("pack: order + scatter");
-  B_TRY(hipMalloc(&b->d_items, 4));
-  b->items_cap = 1;
-  B_ST(plan_work_items(b, b->h_tile_reads));
-  B_TRY(hipMalloc(&b->d_ticket, (nt + 2 * kSchedWords) * 4));     // + the two launches' dynamic-schedule words
-  B_TRY(hipMemset(b->d_ticket, 0, (nt + 2 * kSchedWords) * 4));
-
   // ---- reference letters, workspace, outputs --------------------------------------------------------------------
   const size_t ns = (size_t)(n_sites > 0 ? n_sites : 1);
   B_TRY(hipMalloc(&b->d_ref, ns));
-  if (n_sites > 0) B_TRY(hipMemcpy(b->d_ref, contigs->ref, (size_t)n_sites, hipMemcpyHostToDevice));
+  if (n_sites > 0) B_TRY(hipMemcpyAsync(b->d_ref, contigs->ref, (size_t)n_sites, hipMemcpyHostToDevice, s));
   b->work_bytes = (((size_t)b->n_tiles * 48 + 15) & ~(size_t)15) + ((size_t)b->n_species * MIDAS_STATS + 1) * 8;
   B_TRY(hipMalloc(&b->d_work, b->work_bytes));
   // tile ranges start clean and every pileup workgroup re-zeroes its own entry; the counters and the
   // error word are reset by the index kernel at the start of each run: no per-run memsets
-  B_TRY(hipMemset(b->d_work, 0, b->work_bytes));
+  B_TRY(hipMemsetAsync(b->d_work, 0, b->work_bytes, s));
   B_TRY(hipMalloc(&b->d_filt, sizeof(FilterTables)));
   B_TRY(hipMalloc(&b->d_counts, ns * 16));
   B_TRY(hipMalloc(&b->d_allele, ns));
+  B_TRY(hipMalloc(&b->d_ticket, (nt + 2 * kSchedWords) * 4));     // + the two launches' dynamic-schedule words
+  B_TRY(hipMemsetAsync(b->d_ticket, 0, (nt + 2 * kSchedWords) * 4, s));
+  B_TRY(hipMalloc(&b->d_items, 4));
+  b->items_cap = 1;
+  lap("ref, workspace, outputs");
+
+  // ---- the direct path's index pass, once: validates every read on the device, sizes the general reads' descriptors,
+  // and tells how well the reads are ordered (the path is chosen from that) -------------------------------------------
+  B_ST(direct_prepare(b));
+  lap("direct index (sizing run)");
+  if (b->path == MIDAS_SNPS_PATH_PACKED) B_ST(ensure_packed(b));
 #undef B_TRY
 #undef B_ST
-  lap("ref, workspace, outputs");
+  lap("packed layout");
   *out_batch = b;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_batch_select_path(midas_snps_batch* b, int32_t path) {
+  if (!b || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas_snps_ctx* ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  b->path = path == MIDAS_SNPS_PATH_AUTO ? b->path_auto : path;
+  if (b->path == MIDAS_SNPS_PATH_PACKED) return ensure_packed(b);
   return MIDAS_SNPS_OK;
 }
 
@@ -841,6 +995,7 @@ int32_t midas_snps_batch_pack(midas_snps_batch* b) {
   if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!b->packed_built) return ensure_packed(b);      // (building the layout IS a pack)
   hipEvent_t* ev = b->timing_slots > 0 ? &b->pev[(size_t)(b->timed_packs % b->timing_slots) * 3] : nullptr;
   int32_t st = run_pack(b, ev);
   if (st != MIDAS_SNPS_OK) return st;
@@ -855,6 +1010,10 @@ int32_t midas_snps_batch_fetch_packed(midas_snps_batch* b, void* rec16, void* bl
   if (!b) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int32_t pst = ensure_packed(b);
+    if (pst != MIDAS_SNPS_OK) return pst;
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (out_n_records) *out_n_records = b->n_records;
   if (out_blob_bytes) *out_blob_bytes = b->blob_bytes;
@@ -893,7 +1052,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   if (!b || !thr) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   if (thr->reserved != 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "thresholds.reserved must be 0");
-  if (thr->baseq > kMaxPackedQual && b->has_high_qual)   // (Illumina tops out in the forties; BAM allows 93)
+  if (b->path != MIDAS_SNPS_PATH_DIRECT && thr->baseq > kMaxPackedQual && (b->packed_built ? b->has_high_qual : true) &&
+      ensure_packed(b) == MIDAS_SNPS_OK && b->has_high_qual)   // (Illumina tops out in the forties; BAM allows 93)
     return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "baseq above 62 on reads that hold base qualities above 62 is not supported "
                                                   "(qualities are kept in six bits)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -911,6 +1071,48 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     b->filt_mapid = thr->mapid;
     b->filt_aln_cov = thr->aln_cov;
     b->filt_valid = true;
+  }
+
+  if (b->path == MIDAS_SNPS_PATH_DIRECT) {
+    // ---- direct path: classify + scan + fill, then the pileup kernel over the raw arrays -------------------------------
+    DirectIndexParams dip;
+    fill_direct_index(b, &dip);
+    HIP_TRY(ctx, launch_direct_index(dip, s));
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
+    DirectParams dp;
+    dp.pos = b->d_pos; dp.mapq = b->d_mapq; dp.nm = b->d_nm;
+    dp.seq_off = b->d_seq_off; dp.qual_off = b->d_qual_off;
+    dp.seq4 = b->d_seq4; dp.qual = b->d_qual; dp.cigar = b->d_cigar;
+    dp.info = b->d_info;
+    dp.tbegin = dip.tbegin; dp.tend = dip.tend; dp.goff = b->d_goff; dp.gdesc = b->d_gdesc;
+    dp.ref = b->d_ref;
+    dp.tiles = b->d_tiles;
+    dp.filt = b->d_filt;
+    dp.out_counts = b->d_counts; dp.out_allele = b->d_allele;
+    dp.stats = work_stats(b); dp.err = work_err(b);
+    dp.sched = b->d_ticket + b->n_tiles;
+    dp.n_tiles = (int32_t)b->n_tiles; dp.n_reads = (int32_t)b->n_reads;
+    dp.grid_blocks = ctx->prop.multiProcessorCount * 2;
+#ifdef MIDAS_SNPS_GRID_BLOCKS
+    dp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
+#endif
+    dp.lanes_per_read = b->direct_lanes_per_read;
+    dp.reads_per_wave = 64 / b->direct_lanes_per_read;
+    dp.table_len = b->max_l_seq + 1;
+    dp.baseq = thr->baseq; dp.mapq_min = thr->mapq; dp.readq = thr->readq;
+    HIP_TRY(ctx, launch_pileup_direct(dp, b->direct_lane_bases, s));
+    if (ev) {
+      HIP_TRY(ctx, hipEventRecord(ev[2], s));
+      b->timed_runs += 1;
+    }
+    b->ran = true;
+    b->run_count += 1;
+    b->direct_run_count += 1;
+    return MIDAS_SNPS_OK;
+  }
+  {
+    const int32_t pst = ensure_packed(b);
+    if (pst != MIDAS_SNPS_OK) return pst;
   }
 
   IndexParams ip;
@@ -1094,11 +1296,19 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->n_reads = b->n_reads;
   out->n_sites = b->n_sites;
   out->n_tiles = b->n_tiles;
-  out->packed_bytes = b->blob_bytes + b->n_records * (int64_t)sizeof(ReadRec);
+  out->packed_bytes = b->packed_built ? b->blob_bytes + b->n_records * (int64_t)sizeof(ReadRec) : 0;
   out->algorithmic_bytes = b->alg_bytes;
   out->tile_sites = b->tile_len;
-  out->lanes_per_read = b->lanes_per_read;
-  out->n_work_items = b->n_items;
+  out->lanes_per_read = b->path == MIDAS_SNPS_PATH_DIRECT ? b->direct_lanes_per_read : b->lanes_per_read;
+  out->n_work_items = b->path == MIDAS_SNPS_PATH_DIRECT ? b->n_tiles : b->n_items;
+  out->path = b->path;
+  out->path_auto = b->path_auto;
+  out->lane_bases = b->path == MIDAS_SNPS_PATH_DIRECT ? b->direct_lane_bases : b->lane_bases;
+  out->reserved0 = 0;
+  out->direct_general_reads = (int64_t)b->h_dtotals.n_general;
+  out->direct_general_entries = (int64_t)b->h_dtotals.n_entries;
+  out->direct_stream_reads = b->direct_stream_reads;
+  out->direct_max_tile_reads = b->direct_max_tile_reads;
   return MIDAS_SNPS_OK;
 }
 

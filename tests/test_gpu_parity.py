@@ -240,9 +240,13 @@ def test_read_lengths_on_both_sides_of_the_lane_size(hip_ctx, thr_default, read_
     contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=2, contig_len=9000, n_reads=5000,
                                         read_len=read_len, seed=47 + read_len, var_len=False)
     _assert_same(hip_ctx, thr_default, contigs, reads)
-    info_lanes = {32: 1, 64: 2, 96: 3, 125: 4, 128: 4, 151: 5, 160: 5, 250: 9}[read_len]
     b = hip_ctx.batch(contigs, reads)
-    assert b.info().lanes_per_read == info_lanes
+    # packed path: 31 bases per lane, or 32 where that saves a lane; direct path: 30, or 32 where that saves a lane
+    b.select_path(abi.PATH_PACKED)
+    assert b.info().lanes_per_read == {32: 1, 64: 2, 96: 3, 125: 4, 128: 4, 151: 5, 160: 5, 250: 9}[read_len]
+    b.select_path(abi.PATH_DIRECT)
+    assert b.info().lanes_per_read == {32: 1, 64: 2, 96: 3, 125: 4, 128: 4, 151: 5, 160: 5, 250: 8}[read_len]
+    assert b.info().lane_bases == 32
     b.close()
 
 
@@ -263,9 +267,18 @@ def test_unsupported_and_malformed_inputs_are_statuses_not_crashes(hip_ctx, thr_
 
 
 def test_qualities_above_62_are_exact_up_to_baseq_62_and_refused_beyond(hip_ctx):
-    """The device keeps a base's quality in six bits (layout.h): Phred 63..93 are stored as 62, which changes no comparison
+    """The PACKED path keeps a base's quality in six bits (layout.h): Phred 63..93 are stored as 62, which changes no comparison
     with a baseq <= 62; a baseq above 62 on such a batch is a status, not a wrong table.  Batches without such qualities take
-    any baseq (nothing passes above their maximum, as in the reference)."""
+    any baseq (nothing passes above their maximum, as in the reference).  The DIRECT path compares the quality bytes
+    themselves and takes every baseq (tests/test_gpu_direct.py)."""
+    hip_ctx.set_default_path(abi.PATH_PACKED)
+    try:
+        _packed_quality_limits(hip_ctx)
+    finally:
+        hip_ctx.set_default_path(abi.PATH_AUTO)
+
+
+def _packed_quality_limits(hip_ctx):
     rng = np.random.default_rng(5)
     L = 6000
     reads = []
