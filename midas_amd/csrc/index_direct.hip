@@ -22,7 +22,8 @@ using namespace direct;
 namespace {
 
 constexpr int kClsBlock = 256;
-constexpr int kClsRun = 4096;        // reads per workgroup (the list of its not-so-simple reads lives in LDS)
+constexpr int kClsU = 4;            // reads a thread has in flight in phase A
+constexpr int kClsRun = 2048;        // reads per workgroup (the list of its not-so-simple reads lives in LDS)
 
 // contig of read i: the last contig whose first read is <= i (empty contigs share their begin with the next one)
 __device__ __forceinline__ int contig_of_read(const DirectIndexParams& p, int i) {
@@ -36,12 +37,14 @@ __device__ __forceinline__ int contig_of_read(const DirectIndexParams& p, int i)
   return c > p.n_contigs - 1 ? p.n_contigs - 1 : c;
 }
 struct ContigCursor {
-  int c, next_begin, tile_base;
+  int c, begin, next_begin, tile_base, tile_end;
   long long clen;
   __device__ __forceinline__ void fetch(const DirectIndexParams& p) {
+    begin = p.contig_read_begin[c];
     next_begin = p.contig_read_begin[c + 1];
     clen = p.contig_len[c];
     tile_base = p.contig_tile_base[c];
+    tile_end = p.contig_tile_base[c + 1];
   }
   __device__ __forceinline__ void seek(const DirectIndexParams& p, int i) { c = contig_of_read(p, i); fetch(p); }
   __device__ __forceinline__ void advance(const DirectIndexParams& p, int i) {
@@ -153,13 +156,27 @@ __device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t*
 
 // ---- 1. classify -------------------------------------------------------------------------------------------------------
 // Two phases, like the packer's per-read kernels: phase A settles in a few dozen instructions the reads whose CIGAR is one
-// match op of the read's length (most of what an end-to-end aligner writes) -- `info`, and the tile bounds published once
-// per run of consecutive reads in the same tile; everything else goes onto the workgroup's list (LDS) and is taken by phase
-// B with all lanes busy on the CIGAR grammar.
+// match op of the read's length (most of what an end-to-end aligner writes); everything else goes onto the workgroup's
+// list (LDS) and is taken by phase B with all lanes busy on the CIGAR grammar.
+//
+// The per-tile ranges.  SORTED (the batch's first pass found every contig's reads in position order): no atomics at all --
+// read i compares the tile of its start and the tile of `start + reach` (reach = the longest read of the batch: no class-0
+// read is longer) with those of read i - 1 and, where they differ, writes the index i into the tiles in between:
+//   tend[t]   = first read that starts behind tile t          tbegin[t] = first read whose start + reach gets to tile t
+// so [tbegin, tend) holds every class-0 read touching t (and the few that end just short of it).  !SORTED: the lowest / highest
+// index of the class-0 reads touching a tile by atomicMin / atomicMax, one pair per run of consecutive reads in a tile --
+// exact in any order, but a device-scope atomic is a trip to the memory side of the fabric: 1.3 M of them were 0.25 ms of
+// this kernel's 0.35 on configs[2].
+constexpr int kGenWin = 64;          // tiles (from the workgroup's first) whose general entries are counted in LDS first
+
+template <bool SORTED>
 __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexParams p) {
   __shared__ unsigned long long red[4];
   __shared__ uint32_t s_later[kClsRun];
-  __shared__ uint32_t s_nlater;
+  __shared__ uint32_t s_nlater, s_ngen, s_gen_base;
+  __shared__ uint32_t s_hist[kGenWin];
+  __shared__ int s_crange[2];
+  __shared__ int s_tile0;
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < p.n_stat_words; i += kClsBlock) p.stats[i] = 0ull;
     if (threadIdx.x == 0) *p.err = kNoError;
@@ -168,58 +185,113 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
     p.tbegin_next[i] = 0xFFFFFFFFu;
     p.tend_next[i] = 0u;
   }
-  if (threadIdx.x == 0) s_nlater = 0u;
-  __syncthreads();
   const long long lo = (long long)blockIdx.x * kClsRun;
   const long long hi = lo + kClsRun < (long long)p.n_reads ? lo + kClsRun : (long long)p.n_reads;
+  if (threadIdx.x == 0) { s_nlater = 0u; s_ngen = 0u; }
+  if (threadIdx.x < kGenWin) s_hist[threadIdx.x] = 0u;
+  // the contigs this workgroup's reads lie in (one binary search each, not one per read: nine dependent loads)
+  if (threadIdx.x == 64 && lo < hi) s_crange[0] = contig_of_read(p, (int)lo);
+  if (threadIdx.x == 128 && lo < hi) s_crange[1] = contig_of_read(p, (int)(hi - 1));
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   unsigned long long alg = 0, entries = 0;
-  uint32_t maxl = 0;
+  uint32_t maxl = 0, unsorted = 0;
   ContigCursor cur;
-  if (lo + threadIdx.x < hi) cur.seek(p, (int)(lo + threadIdx.x));
-  for (long long base = lo; base < hi; base += kClsBlock) {       // phase A
-    const long long ii = base + threadIdx.x;
-    const bool valid = ii < hi;
-    bool quick = false;
-    uint32_t key = 0xFFFFFFFEu;
-    int t1 = -1;
-    if (valid) {
-      const int i = (int)ii;
-      const Fields f = load_fields(p, ii);
-      cur.advance(p, i);
-      const bool bad = bad_layout(p, f);
-      const uint32_t c0 = bad ? 0u : p.cigar[f.co < p.n_cigar ? f.co : 0];
-      const uint32_t l = (uint32_t)f.l;
-      quick = !bad && f.co1 - f.co == 1 && l - 1u < (uint32_t)kMaxLSeq && f.nm >= 0 && f.nm <= kMaxField16 && f.pos >= 0 &&
-              (long long)f.pos < cur.clen && op_is_match(c0 & 15u) && (c0 >> 4) == l;
-      if (quick) {
-        p.info[i] = l << kInfoAlenShift;
-        const uint32_t start = (uint32_t)f.pos, room = (uint32_t)cur.clen - start;
-        const uint32_t ln = l < room ? l : room;
-        key = (uint32_t)cur.tile_base + (start >> p.tile_shift);
-        const int te = cur.tile_base + (int)((start + ln - 1u) >> p.tile_shift);
-        t1 = te != (int)key ? te : -1;
-        alg += (unsigned long long)((l + 1u) / 2u + l + 4u + 16u);
-        maxl = l > maxl ? l : maxl;
-      }
+  if (lo + threadIdx.x < hi) {
+    cur.c = s_crange[0];
+    cur.fetch(p);
+    cur.advance(p, (int)(lo + threadIdx.x));
+  }
+  if (threadIdx.x == 0 && lo < hi) {       // first tile of the workgroup's reads: the window of the LDS entry counts
+    long long pc = p.pos[lo];
+    pc = pc < 0 ? 0 : (pc > cur.clen - 1 ? cur.clen - 1 : pc);
+    s_tile0 = cur.tile_base + (int)(pc >> p.tile_shift);
+  }
+  // phase A, four reads per thread at a time: all their columns are requested first, then the first CIGAR word of each,
+  // then they are settled one after the other (written the obvious way a read cost two dependent trips to memory, and
+  // those trips -- not bandwidth -- were the kernel's duration)
+  for (long long base = lo; base < hi; base += kClsBlock * kClsU) {
+    Fields f[kClsU];
+    uint32_t c0[kClsU];
+    int32_t pos_before[kClsU];
+    bool bad[kClsU];
+#pragma unroll
+    for (int u = 0; u < kClsU; ++u) {
+      const long long ii = base + (long long)u * kClsBlock + threadIdx.x;
+      const long long ic = ii < hi ? ii : hi - 1;
+      f[u] = load_fields(p, ic);
+      pos_before[u] = p.pos[ic > 0 ? ic - 1 : 0];
     }
-    // reads are position-sorted, so consecutive reads mostly share a tile: the first read of a run publishes the low bound,
-    // the last one the high bound (read indices grow with the lane whatever the positions do: unsorted input makes more
-    // runs, never a wrong bound)
-    const uint32_t key_before = __shfl_up(key, 1), key_after = __shfl_down(key, 1);
-    if (quick) {
-      const uint32_t i = (uint32_t)ii;
-      if (lane == 0 || key_before != key) atomicMin(&p.tbegin[key], i);
-      if (lane == 63 || key_after != key) atomicMax(&p.tend[key], i + 1u);
-      if (t1 >= 0) {       // it reaches into the next tile (at most one: a read is no longer than a tile)
-        atomicMin(&p.tbegin[t1], i);
-        atomicMax(&p.tend[t1], i + 1u);
-      }
+#pragma unroll
+    for (int u = 0; u < kClsU; ++u) {
+      bad[u] = bad_layout(p, f[u]);
+      c0[u] = p.cigar[(!bad[u] && f[u].co < p.n_cigar) ? f[u].co : 0];
     }
-    wave_append(valid && !quick, (uint32_t)ii, &s_nlater, s_later);
+#pragma unroll
+    for (int u = 0; u < kClsU; ++u) {
+      const long long ii = base + (long long)u * kClsBlock + threadIdx.x;
+      const bool valid = ii < hi;
+      bool quick = false;
+      uint32_t key = 0xFFFFFFFEu;
+      int t1 = -1;
+      if (valid) {
+        const int i = (int)ii;
+        cur.advance(p, i);
+        const uint32_t l = (uint32_t)f[u].l;
+        quick = !bad[u] && f[u].co1 - f[u].co == 1 && l - 1u < (uint32_t)kMaxLSeq && f[u].nm >= 0 && f[u].nm <= kMaxField16 &&
+                f[u].pos >= 0 && (long long)f[u].pos < cur.clen && op_is_match(c0[u] & 15u) && (c0[u] >> 4) == l;
+        if (quick) {
+          p.info[i] = l << kInfoAlenShift;
+          alg += (unsigned long long)((l + 1u) / 2u + l + 4u + 16u);
+          maxl = l > maxl ? l : maxl;
+        }
+        // the tiles of the read's (clamped) start and of start + reach, and those of the read before it
+        const long long last = cur.clen - 1;
+        long long pc = f[u].pos;
+        pc = pc < 0 ? 0 : (pc > last ? last : pc);
+        const int ka = cur.tile_base + (int)(pc >> p.tile_shift);
+        const bool first_of_contig = i == cur.begin;
+        long long pb = pos_before[u];
+        pb = pb < 0 ? 0 : (pb > last ? last : pb);
+        if (!first_of_contig && pb > pc) unsorted = 1u;
+        if (SORTED) {
+          const long long pr = pc + p.reach < last ? pc + p.reach : last;
+          const int kb = cur.tile_base + (int)(pr >> p.tile_shift);
+          const long long pbr = pb + p.reach < last ? pb + p.reach : last;
+          const int ka0 = first_of_contig ? cur.tile_base : cur.tile_base + (int)(pb >> p.tile_shift);
+          const int kb0 = first_of_contig ? cur.tile_base - 1 : cur.tile_base + (int)(pbr >> p.tile_shift);
+          for (int t = ka0; t < ka; ++t) p.tend[t] = (uint32_t)i;            // the first read that starts behind tile t
+          for (int t = kb0 + 1; t <= kb; ++t) p.tbegin[t] = (uint32_t)i;     // the first read that can reach tile t
+          if (i == cur.next_begin - 1)                                        // the contig's last read: every tile from its own on ends here
+            for (int t = ka; t < cur.tile_end; ++t) p.tend[t] = (uint32_t)i + 1u;
+        } else if (quick) {
+          const uint32_t start = (uint32_t)f[u].pos, room = (uint32_t)cur.clen - start;
+          const uint32_t ln = l < room ? l : room;
+          key = (uint32_t)ka;
+          const int te = cur.tile_base + (int)((start + ln - 1u) >> p.tile_shift);
+          t1 = te != ka ? te : -1;
+        }
+      }
+      if (!SORTED) {
+        // consecutive reads mostly share a tile: the first read of a run publishes the low bound, the last one the high
+        // bound (read indices grow with the lane whatever the positions do: unsorted input makes more runs, never a wrong bound)
+        const uint32_t key_before = __shfl_up(key, 1), key_after = __shfl_down(key, 1);
+        if (quick) {
+          const uint32_t i = (uint32_t)ii;
+          if (lane == 0 || key_before != key) atomicMin(&p.tbegin[key], i);
+          if (lane == 63 || key_after != key) atomicMax(&p.tend[key], i + 1u);
+          if (t1 >= 0) {       // it reaches into the next tile (at most one: a read is no longer than a tile)
+            atomicMin(&p.tbegin[t1], i);
+            atomicMax(&p.tend[t1], i + 1u);
+          }
+        }
+      }
+      wave_append(valid && !quick, (uint32_t)ii, &s_nlater, s_later);
+    }
   }
   __syncthreads();
   const uint32_t n_later = s_nlater;
+  const int tile0 = s_tile0;
   for (uint32_t k0 = 0; k0 < n_later; k0 += kClsBlock) {      // phase B
     const uint32_t k = k0 + threadIdx.x;
     bool general = false;
@@ -239,41 +311,77 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
         CigarView cg;
         cg.load(p.cigar + f.co);
         ContigCursor at;
-        at.seek(p, i);
+        at.c = s_crange[0];
+        while (at.c < s_crange[1] && i >= p.contig_read_begin[at.c + 1]) ++at.c;
+        at.fetch(p);
         uint32_t info = 0;
         alg += (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
         maxl = (uint32_t)l > maxl ? (uint32_t)l : maxl;
         if (class0_info(f, cg, at.clen, &info)) {
           p.info[i] = info;
-          const uint32_t alen = (info >> kInfoAlenShift) & 2047u;
-          const uint32_t start = (uint32_t)f.pos, room = (uint32_t)at.clen - start;
-          const uint32_t ln = alen < room ? alen : room;
-          const int ta = at.tile_base + (int)(start >> p.tile_shift), tz = at.tile_base + (int)((start + ln - 1u) >> p.tile_shift);
-          atomicMin(&p.tbegin[ta], (uint32_t)i);
-          atomicMax(&p.tend[ta], (uint32_t)i + 1u);
-          if (tz != ta) {
-            atomicMin(&p.tbegin[tz], (uint32_t)i);
-            atomicMax(&p.tend[tz], (uint32_t)i + 1u);
+          if (!SORTED) {
+            const uint32_t alen = (info >> kInfoAlenShift) & 2047u;
+            const uint32_t start = (uint32_t)f.pos, room = (uint32_t)at.clen - start;
+            const uint32_t ln = alen < room ? alen : room;
+            const int ta = at.tile_base + (int)(start >> p.tile_shift), tz = at.tile_base + (int)((start + ln - 1u) >> p.tile_shift);
+            atomicMin(&p.tbegin[ta], (uint32_t)i);
+            atomicMax(&p.tend[ta], (uint32_t)i + 1u);
+            if (tz != ta) {
+              atomicMin(&p.tbegin[tz], (uint32_t)i);
+              atomicMax(&p.tend[tz], (uint32_t)i + 1u);
+            }
           }
         } else {
-          p.info[i] = kInfoGeneral;
+          p.info[i] = kInfoGeneral | (uint32_t)at.c;      // (the fill kernel takes the contig from here)
           general = true;
           unsigned long long n = 0;
-          general_tiles(f.pos, (uint32_t)nc, cg, at.clen, p.tile_shift, at.tile_base, [&](int t) { atomicAdd(&p.gcount[t], 1u); ++n; });
+          // entries per tile: counted in LDS for the tiles near the workgroup's reads, one global atomic per tile afterwards
+          general_tiles(f.pos, (uint32_t)nc, cg, at.clen, p.tile_shift, at.tile_base, [&](int t) {
+            const unsigned w = (unsigned)(t - tile0);
+            if (w < (unsigned)kGenWin) atomicAdd(&s_hist[w], 1u); else atomicAdd(&p.gcount[t], 1u);
+            ++n;
+          });
           entries += n;
         }
       }
     }
-    wave_append(general, gi, &p.facts->n_general, p.gen_reads);
+    // the workgroup's general reads, compacted over the list that has been consumed up to here
+    {
+      const unsigned long long mask = __ballot(general);
+      if (mask != 0ull) {
+        const int leader = __ffsll((long long)mask) - 1;
+        uint32_t b0 = 0;
+        if (lane == leader) b0 = atomicAdd(&s_ngen, (uint32_t)__popcll(mask));
+        b0 = __shfl(b0, leader);
+        // (slot b0 + rank <= k0 + rank: entries at or below the ones being read in this round are only overwritten by the
+        // waves that have already read theirs -- write after the round's reads)
+        const uint32_t slot = b0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (general) s_later[slot] = gi;
+      } else {
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const uint32_t n_gen = s_ngen;
+    if (threadIdx.x == 0 && n_gen) s_gen_base = atomicAdd(&p.facts->n_general, n_gen);     // one atomic per workgroup
+    if (threadIdx.x < kGenWin && s_hist[threadIdx.x] && tile0 + (int)threadIdx.x <= p.n_tiles)
+      atomicAdd(&p.gcount[tile0 + threadIdx.x], s_hist[threadIdx.x]);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_gen; k += kClsBlock) p.gen_reads[s_gen_base + k] = s_later[k];
   }
   alg = block_sum(alg, red);
   entries = block_sum(entries, red);
   const unsigned long long bmax = block_max((unsigned long long)maxl, red);
+  const unsigned long long any_unsorted = block_max((unsigned long long)unsorted, red);
   if (threadIdx.x == 0) {
     DirectFacts* f = p.facts + (blockIdx.x % kDirectFactSlots);
     if (alg) atomicAdd(&f->alg_bytes, alg);
     if (entries) atomicAdd(&f->n_entries, entries);
     if (bmax) atomicMax(&f->max_l, (uint32_t)bmax);
+    if (any_unsorted) atomicOr(&f->unsorted, 1u);
   }
 }
 
@@ -287,6 +395,7 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   const int per = (n + kScanBlock - 1) / kScanBlock;
   const int a = tid * per, b = a + per < n ? a + per : n;
   unsigned long long sum = 0;
+#pragma unroll 8
   for (int i = a; i < b; ++i) sum += p.gcount[i];
   unsigned long long incl = sum;                      // inclusive scan over the wave
   for (int d = 1; d < 64; d <<= 1) {
@@ -301,6 +410,7 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   }
   __syncthreads();
   unsigned long long run = s_base[wave] + incl - sum;
+#pragma unroll 8
   for (int i = a; i < b; ++i) {
     p.goff[i] = (uint32_t)run;
     run += p.gcount[i];
@@ -308,12 +418,13 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   // the pass's totals: the slots added up, then cleared for the next pass
   if (tid < kDirectFactSlots) {
     DirectFacts* f = p.facts + tid;
-    unsigned long long alg = f->alg_bytes, ent = f->n_entries, mx = f->max_l;
+    unsigned long long alg = f->alg_bytes, ent = f->n_entries, mx = f->max_l, uns = f->unsorted;
     for (int d = 32; d >= 1; d >>= 1) {
       alg += __shfl_down(alg, d);
       ent += __shfl_down(ent, d);
       const unsigned long long o = __shfl_down(mx, d);
       mx = o > mx ? o : mx;
+      uns |= __shfl_down(uns, d);
     }
     if (tid == 0) {
       p.totals->status = f->status;
@@ -321,44 +432,59 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
       p.totals->n_entries = ent;
       p.totals->n_general = f->n_general;
       p.totals->max_l = (uint32_t)mx;
+      p.totals->unsorted = (uint32_t)uns;
       f->status = kNoError;
       f->n_general = 0u;
     }
     f->alg_bytes = 0ull;
     f->n_entries = 0ull;
     f->max_l = 0u;
+    f->unsorted = 0u;
   }
 }
 
 // ---- 3. fill: the descriptors of the general reads, tile by tile -------------------------------------------------------
+// A workgroup takes 256 consecutive entries of the general-read list (reads of one neighbourhood: the classify kernel
+// appends a workgroup's reads together), ranks their tile entries in LDS, reserves the slots of a tile with ONE returning
+// atomic per tile and workgroup, and writes the descriptors.  (One returning atomic per entry, 0.55 M of them, took 0.12 ms.)
+constexpr int kFillKeep = 4;         // tile entries of a read ranked through LDS (a read has one or two; more go the direct way)
 __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParams p) {
+  __shared__ uint32_t s_cnt[kGenWin], s_base[kGenWin];
+  __shared__ int s_tile0;
   const uint32_t n_gen = p.totals->n_general;
-  for (uint32_t k = blockIdx.x * kClsBlock + threadIdx.x; k < n_gen; k += gridDim.x * kClsBlock) {
-    const int i = (int)p.gen_reads[k];
-    const Fields f = load_fields(p, i);
-    const uint32_t nc = (uint32_t)(f.co1 - f.co);
-    CigarView cg;
-    cg.load(p.cigar + f.co);
-    const int c = contig_of_read(p, i);
-    const long long clen = p.contig_len[c];
-    GenDesc d;
-    d.idx = (uint32_t)i;
-    d.pos = f.pos;
-    d.l = (uint32_t)f.l;
-    d.nc = nc;
-    d.nm16 = f.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)f.nm;
-    d.mapq = p.mapq[i];
-    d.so = (unsigned long long)f.so; d.qo = (unsigned long long)f.qo; d.co = (unsigned long long)f.co;
-    // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
-    const long long qs = query_start(cg, nc), qe = query_end(cg, nc, f.l);
-    long long al = qe - qs;
-    al = al < 0 ? 0 : al;
-    d.align_len = (uint32_t)(al > 0xFFFF ? 0xFFFF : al);
-    d.lead = (uint32_t)(qs > 0xFFFF ? 0xFFFF : qs);
-    // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position
-    // >= l_seq onto a site inside the contig
-    uint32_t flags = f.nm < 0 ? kGenNoNm : 0u;
-    {
+  for (uint32_t chunk = blockIdx.x * kClsBlock; chunk < n_gen; chunk += gridDim.x * kClsBlock) {
+    const uint32_t k = chunk + threadIdx.x;
+    const bool act = k < n_gen;
+    if (threadIdx.x < kGenWin) s_cnt[threadIdx.x] = 0u;
+    GenDesc d{};
+    CigarView cg{};
+    uint32_t nc = 0;
+    long long clen = 1;
+    int tile_base = 0;
+    if (act) {
+      const int i = (int)p.gen_reads[k];
+      const Fields f = load_fields(p, i);
+      nc = (uint32_t)(f.co1 - f.co);
+      cg.load(p.cigar + f.co);
+      const int c = (int)(p.info[i] & ~kInfoGeneral);      // its contig, left there by the classify kernel
+      clen = p.contig_len[c];
+      tile_base = p.contig_tile_base[c];
+      d.idx = (uint32_t)i;
+      d.pos = f.pos;
+      d.l = (uint32_t)f.l;
+      d.nc = nc;
+      d.nm16 = f.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)f.nm;
+      d.mapq = p.mapq[i];
+      d.so = (unsigned long long)f.so; d.qo = (unsigned long long)f.qo; d.co = (unsigned long long)f.co;
+      // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
+      const long long qs = query_start(cg, nc), qe = query_end(cg, nc, f.l);
+      long long al = qe - qs;
+      al = al < 0 ? 0 : al;
+      d.align_len = (uint32_t)(al > 0xFFFF ? 0xFFFF : al);
+      d.lead = (uint32_t)(qs > 0xFFFF ? 0xFFFF : qs);
+      // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position
+      // >= l_seq onto a site inside the contig
+      uint32_t flags = f.nm < 0 ? kGenNoNm : 0u;
       long long qpos = 0, rpos = f.pos;
       for (uint32_t j = 0; j < nc; ++j) {
         const uint32_t v = cg[j], op = v & 15u;
@@ -377,13 +503,46 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
           rpos += len;
         }
       }
+      d.flags = flags;
+      if (threadIdx.x == 0) {
+        long long pc = f.pos < 0 ? 0 : f.pos;
+        pc = pc > clen - 1 ? clen - 1 : pc;
+        s_tile0 = tile_base + (int)(pc >> p.tile_shift);
+      }
     }
-    d.flags = flags;
-    general_tiles(f.pos, nc, cg, clen, p.tile_shift, p.contig_tile_base[c], [&](int t) {
-      const uint32_t left = atomicSub(&p.gcount[t], 1u);        // counts the tile's entries back to zero: ready for the next pass
-      const long long slot = (long long)p.goff[t] + (long long)left - 1;
+    __syncthreads();
+    const int tile0 = s_tile0;
+    // the first entries of the read: rank inside the workgroup (LDS); anything else takes its slot directly
+    int kept_tile[kFillKeep];
+    uint32_t kept_rank[kFillKeep];
+    int n_kept = 0, ord = 0;
+    if (act) {
+      general_tiles(d.pos, nc, cg, clen, p.tile_shift, tile_base, [&](int t) {
+        const unsigned w = (unsigned)(t - tile0);
+        if (ord < kFillKeep && w < (unsigned)kGenWin) {
+          kept_tile[n_kept] = t;
+          kept_rank[n_kept] = atomicAdd(&s_cnt[w], 1u);
+          ++n_kept;
+        } else {
+          const uint32_t left = atomicSub(&p.gcount[t], 1u);
+          const long long slot = (long long)p.goff[t] + (long long)left - 1;
+          if (slot >= 0 && slot < p.gdesc_capacity) gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d);
+        }
+        ++ord;
+      });
+    }
+    __syncthreads();
+    if (threadIdx.x < kGenWin && s_cnt[threadIdx.x]) {       // counts a tile's entries back towards zero: ready for the next pass
+      const uint32_t n = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = atomicSub(&p.gcount[tile0 + threadIdx.x], n) - n;
+    }
+    __syncthreads();
+    for (int e = 0; e < n_kept; ++e) {
+      const int t = kept_tile[e];
+      const long long slot = (long long)p.goff[t] + (long long)s_base[t - tile0] + (long long)kept_rank[e];
       if (slot >= 0 && slot < p.gdesc_capacity) gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d);
-    });
+    }
+    __syncthreads();      // s_cnt / s_tile0 are rewritten by the next chunk
   }
 }
 
@@ -392,9 +551,12 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s) {
   // always launched (even with no reads): block 0 resets the counters and the error word, the scan publishes the totals
   const int grid = p.n_reads > 0 ? (int)(((long long)p.n_reads + kClsRun - 1) / kClsRun) : 1;
-  hipLaunchKernelGGL(direct_classify_kernel, dim3(grid), dim3(kClsBlock), 0, s, p);
+  if (p.sorted) hipLaunchKernelGGL(direct_classify_kernel<true>, dim3(grid), dim3(kClsBlock), 0, s, p);
+  else hipLaunchKernelGGL(direct_classify_kernel<false>, dim3(grid), dim3(kClsBlock), 0, s, p);
   hipLaunchKernelGGL(direct_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, p);
-  hipLaunchKernelGGL(direct_fill_kernel, dim3(256), dim3(kClsBlock), 0, s, p);
+  // (the grid follows the count the batch's first pass found: the batch never changes; the kernel itself reads the device's)
+  const long long fg = (p.n_general_hint + kClsBlock - 1) / kClsBlock;
+  hipLaunchKernelGGL(direct_fill_kernel, dim3((unsigned)(fg < 256 ? 256 : fg)), dim3(kClsBlock), 0, s, p);
   return hipGetLastError();
 }
 

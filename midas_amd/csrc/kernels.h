@@ -157,7 +157,7 @@ hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);             
 //            gathered per tile into 48-byte descriptors (count -> scan -> fill), walked op by op on the device.
 // Unsorted input only widens the ranges (slower, never wrong); the host falls back to the packed path when the ranges of a
 // batch add up to much more than its reads.
-constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0; else lead | alen << 10 | trail << 21
+constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0 (then bits 0-30: its contig); else lead | alen << 10 | trail << 21
 constexpr int kInfoAlenShift = 10, kInfoTrailShift = 21;
 constexpr int kGenDescWords = 12;                 // 48 bytes per (general read, tile) entry
 
@@ -173,10 +173,11 @@ struct alignas(128) DirectFacts {                 // per-slot partial sums of on
   unsigned long long n_entries;                   // (general read, tile) entries
   uint32_t n_general;                             // general reads (slot 0 only: it is the append cursor of gen_reads)
   uint32_t max_l;                                 // longest read
+  uint32_t unsorted;                              // some contig's reads are not in position order
 };
 struct DirectTotals {                             // the slots added up by the scan kernel (one per run, host reads it at create)
   unsigned long long status, alg_bytes, n_entries;
-  uint32_t n_general, max_l;
+  uint32_t n_general, max_l, unsorted;
 };
 
 struct DirectIndexParams {
@@ -195,6 +196,9 @@ struct DirectIndexParams {
   uint32_t* gen_reads;                            // [n_reads] the general reads, in no particular order
   uint32_t* gdesc;                                // [n_entries][kGenDescWords]
   int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)
+  int32_t sorted;                                 // the batch's first pass found every contig's reads in position order
+  int32_t reach;                                  // the longest read of the batch: no class-0 read spans more sites
+  int64_t n_general_hint;                         // general reads found by the batch's first pass (sizes the fill kernel's grid)
   DirectFacts* facts;                             // [kDirectFactSlots]
   DirectTotals* totals;
   unsigned long long* stats; unsigned long long* err;

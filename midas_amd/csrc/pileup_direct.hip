@@ -34,6 +34,8 @@
 #include "direct_common.h"
 #include "pileup_common.h"
 
+#include <type_traits>
+
 namespace midas {
 
 using namespace dev;
@@ -130,30 +132,15 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
   }
 }
 
-template <int LB>
-__device__ __forceinline__ void tally_lane(const uint32_t (&q)[8], const uint32_t (&th)[8], const uint32_t (&cd)[8], uint32_t abase,
-                                           uint32_t one) {
-  tally_group<0, 8>(q[0], q[1], th[0], th[1], cd[0], cd[1], abase, one);
-  tally_group<128, 8>(q[2], q[3], th[2], th[3], cd[2], cd[3], abase, one);
-  tally_group<256, 8>(q[4], q[5], th[4], th[5], cd[4], cd[5], abase, one);
-  tally_group<384, (LB == 32 ? 8 : 6)>(q[6], q[7], th[6], th[7], cd[6], cd[7], abase, one);
+// The per-tile stream: the read indices rb .. rb + n0 (class 0; a general read in the range is skipped there), then the
+// tile's general descriptors gb .. gb + ng.
+struct Stream { int rb, n0, gb, ng; };
+
+// 32-bit byte offsets from a uniform base: the loads take the `saddr + voffset` form (no 64-bit address arithmetic per lane)
+template <class T>
+__device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
 }
-
-// The per-tile stream: positions [0, n0) are the read indices rb .. rb + n0 (class 0; a general read in the range is
-// skipped there), positions [n0, total) the tile's general descriptors gb ...
-struct Stream { int rb, n0, gb, total; };
-
-// What is carried of a read from the arrival of its columns to its processing.
-//   misc: mapq | gen flags << 8 | kind << 16 (kind 0 nothing to do, 1 class 0, 2 general; two bits)
-struct Rd {
-  uint32_t a;        // class 0: info (lead | alen << 10 | trail << 21); general: aligned length | leading clip << 16
-  int32_t pos;
-  uint32_t nm;       // general: 0xFFFF = absent
-  uint32_t misc;     // ... | bits 24-31: bits 32-39 of the general read's CIGAR offset
-  uint32_t l_nc;     // l_seq | n_cigar << 16
-  uint32_t co_lo;    // general: element offset of its CIGAR, low word
-};
-constexpr uint32_t kKindC0 = 1u << 16, kKindGen = 2u << 16;
 
 template <int LB, bool BQ0>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectParams p) {
@@ -163,6 +150,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_mhi[33 * 8];   // [h][w]: 0xFF in the bytes of the bases j >= h
   __shared__ __attribute__((aligned(16))) uint32_t s_mlo[33 * 8];   // [l][w]: 0xFF in the bytes of the bases j <  l
+  __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
@@ -196,6 +184,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       s_mhi[i] = mh;
       s_mlo[i] = ml;
     }
+    s_qsum[tid] = 0u;
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
   }
 
@@ -207,11 +196,13 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const int q0 = c * LB;                           // first base of the lane in the read's stored query
   const int vstep = NWAVES * rpw;
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t qsum_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_qsum + wave * 64 + g);
   // v_perm_b32 tables (slots 0, 1, 3, 7 = A, C, G, T): threshold bytes and counter offsets
   const uint32_t thr = BQ0 ? 0u : (uint32_t)(p.baseq > 256 ? 255 : p.baseq - 1);
   const uint32_t th_lo = thr | (thr << 8) | 0x00FF0000u | (thr << 24), th_hi = 0x00FFFFFFu | (thr << 24);
   const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
+  const uint32_t one = 1u;
 
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
@@ -223,81 +214,112 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     s.rb = e > b ? (int)b : 0;
     s.n0 = e > b ? (int)(e - b) : 0;
     s.gb = (int)g0;
-    s.total = s.n0 + (int)(g1 - g0);
+    s.ng = (int)(g1 - g0);
     return s;
   };
 
-  // ---- stage F: the per-read columns of stream position v (raw loads; nothing is computed from them here) -------------
-  struct Raw { uint32_t r0, r1, r2, r3, r4, r5, r6, r7, r8; int kind; };    // kind: 0 none, 1 range position, 2 descriptor
-  auto fetch_raw = [&](const Stream& st, int v) -> Raw {
-    Raw f;
-    f.kind = (lane_used && v < st.total) ? (v < st.n0 ? 1 : 2) : 0;
-    if (f.kind == 1) {
-      const size_t i = (size_t)(st.rb + v);
-      f.r0 = p.info[i];
-      f.r1 = (uint32_t)p.pos[i];
-      f.r2 = (uint32_t)p.nm[i];
-      f.r3 = p.mapq[i];
-      const unsigned long long so = (unsigned long long)p.seq_off[i], qo = (unsigned long long)p.qual_off[i];
-      f.r4 = (uint32_t)so; f.r5 = (uint32_t)(so >> 32);
-      f.r6 = (uint32_t)qo; f.r7 = (uint32_t)(qo >> 32);
-      f.r8 = 0u;
-    } else if (f.kind == 2) {
-      const uint4* gd = reinterpret_cast<const uint4*>(p.gdesc) + (size_t)(st.gb + (v - st.n0)) * 3;
-      const uint4 a = gd[0], b = gd[1];
-      f.r0 = a.x; f.r1 = a.y; f.r2 = a.z; f.r3 = a.w;
-      f.r4 = b.x; f.r5 = b.y; f.r6 = b.z; f.r7 = b.w;
-      f.r8 = gd[2].x;
+  // Sum of a read's quality bytes over its lanes (np.mean(aln.query_qualities), midas/run/snps.py:151): every lane adds its
+  // part to the read's LDS slot, reads the slot back and clears it -- three LDS operations of one wave, executed in
+  // order, instead of a shuffle per lane of the read.  Bit 31: QUAL absent.
+  auto read_sum = [&](uint32_t part) -> uint32_t {
+    uint32_t tot;
+    asm volatile("ds_add_u32 %1, %2\n\tds_read_b32 %0, %1\n\tds_write_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(tot) : "v"(qsum_addr), "v"(part), "v"(0u) : "memory");
+    return tot;
+  };
+  auto lane_qsum = [&](const uint32_t (&q)[8], int nb) -> uint32_t {
+    uint32_t part = 0;
+    if (nb == LB) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) part = __builtin_amdgcn_sad_u8(q[k], 0u, part);
+      part = __builtin_amdgcn_sad_u8(LB == 32 ? q[7] : (q[7] & 0x0000FFFFu), 0u, part);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
+    }
+    return part;
+  };
+  // Threshold bytes and counter offsets of eight bases from their 4-bit codes (one dword of SEQ): the even and the odd
+  // nibbles become v_perm_b32 selectors by (n + 7) ^ 8 -- A, C, G, T (1, 2, 4, 8) select table slots 0, 1, 3, 7, every
+  // other code a slot or a selector constant that reads 0xFF.
+  // The lanes `go` tally bases [lo, hi) of their 30 / 32, the first of the lane at tile-relative site loc0.  Group by group
+  // (decode eight bases, tally them), so that only one group's looked-up bytes are alive at a time.
+  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4]) {
+    const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
+    const bool masked = __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
+    if (!go) return;                                                    // outside [lo, hi) (a row of each table, LDS)
+    const uint32_t* mh = s_mhi + 8 * (hi > 32 ? 32 : hi);
+    const uint32_t* ml = s_mlo + 8 * (lo < 0 ? 0 : lo);
+    auto group = [&](auto sidx, auto off, auto nbases) {
+      constexpr int S = decltype(sidx)::value;
+      const uint32_t x = sq[S];
+      const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
+      const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
+      uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
+      const uint32_t ce = __builtin_amdgcn_perm(cd_hi, cd_lo, se), co = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
+      if (masked) {
+        const uint2 h = *reinterpret_cast<const uint2*>(mh + 2 * S), l = *reinterpret_cast<const uint2*>(ml + 2 * S);
+        te |= h.x | l.x;
+        to |= h.y | l.y;
+      }
+      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
+    };
+    using std::integral_constant;
+    group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 1>{}, integral_constant<int, 128>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 2>{}, integral_constant<int, 256>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
+  };
+
+  // ---- class 0, stage F: the columns of range position v (raw loads; nothing is computed from them here) -----------------
+  struct RawA { uint32_t info, pos, nm, mapq, so_lo, so_hi, qo_lo, qo_hi; };
+  auto fetch_a = [&](const Stream& st, int v) -> RawA {
+    RawA f;
+    f.info = kInfoGeneral;
+    if (lane_used && v < st.n0) {
+      const uint32_t i = (uint32_t)(st.rb + v);
+      f.info = ld_off<uint32_t>(p.info, i * 4u);
+      f.pos = ld_off<uint32_t>(p.pos, i * 4u);
+      f.nm = ld_off<uint32_t>(p.nm, i * 4u);
+      f.mapq = ld_off<uint8_t>(p.mapq, i);
+      const uint2 so = ld_off<uint2>(p.seq_off, i * 8u), qo = ld_off<uint2>(p.qual_off, i * 8u);
+      f.so_lo = so.x; f.so_hi = so.y; f.qo_lo = qo.x; f.qo_hi = qo.y;
     }
     return f;
   };
-  // ---- stage D: the lane's bases (two 16-byte loads of QUAL, one of SEQ; a general read's first four CIGAR ops) ---------
+  // ---- stage D: the lane's bases (two 16-byte loads of QUAL, one of SEQ) --------------------------------------------------
+  struct RdA { uint32_t info, pos, nm, mapq; };
   struct Dat { uint32_t q[8]; uint32_t s[4]; };
-  auto settle = [&](const Raw& f, Rd& r, Dat& d) {
-    // the columns have arrived: fold them into what the read's processing needs, and issue the loads of its bases
-    r.a = 0u; r.pos = 0; r.nm = 0u; r.misc = 0u; r.l_nc = 0u; r.co_lo = 0u;
-    unsigned long long so = 0, qo = 0;
-    int l = 0;
-    if (f.kind == 1) {
-      if (!(f.r0 & kInfoGeneral)) {
-        r.a = f.r0; r.pos = (int32_t)f.r1; r.nm = f.r2; r.misc = (f.r3 & 0xFFu) | kKindC0;
-        l = (int)((f.r0 & 1023u) + ((f.r0 >> kInfoAlenShift) & 2047u) + (f.r0 >> kInfoTrailShift));
-        r.l_nc = (uint32_t)l;
-        so = (unsigned long long)f.r4 | ((unsigned long long)f.r5 << 32);
-        qo = (unsigned long long)f.r6 | ((unsigned long long)f.r7 << 32);
-      }
-    } else if (f.kind == 2) {
-      r.pos = (int32_t)f.r1; r.l_nc = f.r2; r.nm = f.r3 & 0xFFFFu;
-      r.misc = ((f.r3 >> 16) & 0xFFu) | (((f.r3 >> 24) & 0xFFu) << 8) | kKindGen | (((f.r8 >> 16) & 0xFFu) << 24);
-      r.a = f.r4;
-      l = (int)(f.r2 & 0xFFFFu);
-      so = (unsigned long long)f.r5 | ((unsigned long long)(f.r8 & 0xFFu) << 32);
-      qo = (unsigned long long)f.r6 | ((unsigned long long)((f.r8 >> 8) & 0xFFu) << 32);
-      r.co_lo = f.r7;
-    }
-    if (r.misc != 0u && q0 < l) {
-      const uint8_t* qp = p.qual + qo + (size_t)q0;
-      const uint8_t* sp = p.seq4 + so + (size_t)(q0 >> 1);
-      const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
-      const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
-      const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
-      d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
-      d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
-      d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
-    }
+  const uint8_t* const q_lane = p.qual + q0;            // (one 64-bit addition per pointer and read, not three)
+  const uint8_t* const s_lane = p.seq4 + (q0 >> 1);
+  auto load_bases = [&](unsigned long long so, unsigned long long qo, Dat& d) {
+    const uint8_t* qp = q_lane + qo;
+    const uint8_t* sp = s_lane + so;
+    const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
+    const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
+    const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
+    d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
+    d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
+    d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
+  };
+  auto settle_a = [&](const RawA& f, RdA& r, Dat& d) {
+    r.info = f.info; r.pos = f.pos; r.nm = f.nm; r.mapq = f.mapq;
+    const int l = (int)((f.info & 1023u) + ((f.info >> kInfoAlenShift) & 2047u) + ((f.info >> kInfoTrailShift) & 1023u));
+    if (!(f.info & kInfoGeneral) && q0 < l)
+      load_bases((unsigned long long)f.so_lo | ((unsigned long long)f.so_hi << 32), (unsigned long long)f.qo_lo | ((unsigned long long)f.qo_hi << 32), d);
   };
 
   Tile tile = load_tile(c_tiles, w);
   Stream st = load_stream(w);
-  auto n_iters = [&](const Stream& s) -> int { return (s.total + rpw - 1) / rpw; };
-  int it_hi = n_iters(st);
-  int v0 = wave * rpw + g;
-  Raw raw_n = fetch_raw(st, v0 + vstep);
-  Rd rd_cur;
+  auto n_iters = [&](int n) -> int { return (n + rpw - 1) / rpw; };
+  int it_hi = n_iters(st.n0);
+  const int v0 = wave * rpw + g;
+  RawA raw_n = fetch_a(st, v0 + vstep);
+  RdA rd_cur;
   Dat dat_cur;
   {
-    const Raw raw_c = fetch_raw(st, v0);
-    settle(raw_c, rd_cur, dat_cur);
+    const RawA raw_c = fetch_a(st, v0);
+    settle_a(raw_c, rd_cur, dat_cur);
   }
   __syncthreads();   // LDS zeroed, tables in place
 
@@ -318,6 +340,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       }
     }
 
+    // ======================= class 0: the reads of the tile's range, one gap-free match segment each =========================
     int vpos = v0;
     // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
     // the columns of its first two iterations of the NEXT tile
@@ -326,58 +349,105 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     Stream xs = st;
     if (xt) xs = load_stream(w_next);
     for (int it = wave; it < it_hi; it += NWAVES, vpos += vstep) {
-      Rd rd_n;
+      RdA rd_n;
       Dat dat_n;
-      settle(raw_n, rd_n, dat_n);       // (the columns of the next iteration have arrived: its bases are requested ...)
-      if (xt && it + 2 * NWAVES >= it_hi) raw_n = fetch_raw(xs, (it + NWAVES < it_hi) ? v0 : v0 + vstep);   // ... then the
-      else raw_n = fetch_raw(st, vpos + 2 * vstep);                                                          // columns after it
+      settle_a(raw_n, rd_n, dat_n);       // (the columns of the next iteration have arrived: its bases are requested ...)
+      if (xt && it + 2 * NWAVES >= it_hi) raw_n = fetch_a(xs, (it + NWAVES < it_hi) ? v0 : v0 + vstep);   // ... then the
+      else raw_n = fetch_a(st, vpos + 2 * vstep);                                                          // columns after it
 
-      // ================= process (rd_cur, dat_cur) =========================================================================
-      const uint32_t kind = (rd_cur.misc >> 16) & 3u;
-      const unsigned long long m_any = __ballot(kind != 0u);
-      if (m_any != 0ull) {
-        const bool is_gen = kind == 2u;
-        const int l = (int)(rd_cur.l_nc & 0xFFFFu);
-        const int pos = rd_cur.pos;
-        const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
-        const bool has = kind != 0u && nb > 0;
-        // ---- sum of the read's quality bytes (np.mean(aln.query_qualities), clipped bases included) -----------------
+      const bool act = !(rd_cur.info & kInfoGeneral);
+      const int lead = (int)(rd_cur.info & 1023u);
+      const int align_len = (int)((rd_cur.info >> kInfoAlenShift) & 2047u);
+      const int l = act ? lead + align_len + (int)((rd_cur.info >> kInfoTrailShift) & 1023u) : 0;
+      const int pos = (int)rd_cur.pos;
+      const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
+      const bool has = nb > 0;
+      uint32_t part = 0;
+      if (has) {
+        part = lane_qsum(dat_cur.q, nb);
+        if (c == 0) part |= ((dat_cur.q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+      }
+      uint32_t qsum = read_sum(part);
+      const bool t_noqual = (qsum >> 31) != 0u;
+      qsum &= 0x7FFFFFFFu;
+      // ---- keep_read (midas/run/snps.py:141-162): a class-0 read has SEQ, NM and a non-empty aligned part --------------------
+      const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+      const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+      const bool t_pid = align_len - (int)rd_cur.nm < min_match;                                            // pid < mapid
+      const bool t_drop = ((int)qsum < rq * l) | ((int)rd_cur.mapq < p.mapq_min) | (align_len < min_align);   // readq, mapq, aln_cov
+      const uint32_t err = (act && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
+      const bool keep = act && !(t_pid | t_noqual | t_drop);
+      const int rel = pos - tile_start;            // 0 <= pos < contig length: no wrap
+      const bool owner = act && rel >= 0 && rel < tile_len;
+      // the one segment: query [lead, lead + align_len) at sites pos ...; this lane's part of it, clipped to the tile
+      const int loc0 = rel + (q0 - lead);
+      int lo = lead - q0;
+      lo = lo > -loc0 ? lo : -loc0;
+      lo = lo > 0 ? lo : 0;
+      int hi = lead + align_len - q0;
+      hi = hi < tile_len - loc0 ? hi : tile_len - loc0;
+      hi = hi < nb ? hi : nb;
+      const bool go = keep && lo < hi;
+      if (__ballot(go) != 0ull) {
+        uint32_t qv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
+        tally_range(go, lo, hi, loc0, qv, dat_cur.s);
+      }
+      const bool head = owner && c == 0;
+      w_aligned += (uint32_t)__popcll(__ballot(head));
+      w_mapped += (uint32_t)__popcll(__ballot(head && keep));
+      if (head && err) atomicMin(p.err, ((unsigned long long)(uint32_t)(st.rb + vpos) << 8) | err);
+
+      rd_cur = rd_n;
+      dat_cur = dat_n;
+    }
+
+    // ======================= general reads: descriptors, walked op by op (the few per tile; not pipelined) ===================
+    {
+      const int nb_it = n_iters(st.ng);
+      for (int j = NWAVES - 1 - wave; j < nb_it; j += NWAVES) {      // (dealt from the last wave down: those have fewer range iterations)
+        const int e = j * rpw + g;
+        const bool act = lane_used && e < st.ng;
+        uint4 da = make_uint4(0u, 0u, 0u, 0u), db = da;
+        uint32_t dc = 0;
+        if (act) {
+          const uint4* gd = reinterpret_cast<const uint4*>(p.gdesc) + (size_t)(st.gb + e) * 3;
+          da = gd[0]; db = gd[1]; dc = gd[2].x;
+        }
+        const int l = (int)(da.z & 0xFFFFu), nc = (int)(da.z >> 16);
+        const int pos = (int)da.y;
+        const uint32_t nm16 = da.w & 0xFFFFu, gflags = da.w >> 24;
+        const int mapq = (int)((da.w >> 16) & 0xFFu);
+        const int align_len = (int)(db.x & 0xFFFFu);
+        const uint32_t* cig = p.cigar + ((size_t)db.w | ((size_t)((dc >> 16) & 0xFFu) << 32));
+        const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;
+        const bool has = act && nb > 0;
+        Dat d;
+        uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u;
+        if (act && nc > 0) {
+          const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // (may overhang into the array's slack)
+          cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
+        }
+        if (has) load_bases((unsigned long long)db.y | ((unsigned long long)(dc & 0xFFu) << 32),
+                            (unsigned long long)db.z | ((unsigned long long)((dc >> 8) & 0xFFu) << 32), d);
         uint32_t part = 0;
         if (has) {
-          if (nb == LB) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) part = __builtin_amdgcn_sad_u8(dat_cur.q[k], 0u, part);
-            part = __builtin_amdgcn_sad_u8(LB == 32 ? dat_cur.q[7] : (dat_cur.q[7] & 0x0000FFFFu), 0u, part);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(dat_cur.q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
-          }
-          if (c == 0) part |= ((dat_cur.q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+          part = lane_qsum(d.q, nb);
+          if (c == 0) part |= ((d.q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;
         }
-        uint32_t qsum = 0;
-        for (int cc = 0; cc < lpr; ++cc) qsum += __shfl(part, g * lpr + cc);
+        uint32_t qsum = read_sum(part);
         const bool t_noqual = (qsum >> 31) != 0u;
         qsum &= 0x7FFFFFFFu;
-
-        // ---- keep_read (midas/run/snps.py:141-162), every test evaluated, the reference's order decides -------------------
-        int align_len, lead;
-        if (!is_gen) {
-          lead = (int)(rd_cur.a & 1023u);
-          align_len = (int)((rd_cur.a >> kInfoAlenShift) & 2047u);
-        } else {
-          align_len = (int)(rd_cur.a & 0xFFFFu);
-          lead = (int)(rd_cur.a >> 16);
-        }
-        const uint32_t gflags = (rd_cur.misc >> 8) & 0xFFu;
-        const int mapq = (int)(rd_cur.misc & 0xFFu);
+        // ---- keep_read, every test evaluated, the reference's order decides which outcome wins ---------------------------
         const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
         const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
         const bool t_noseq = l == 0;
-        const bool t_nonm = is_gen && (gflags & kGenNoNm) != 0u;
+        const bool t_nonm = (gflags & kGenNoNm) != 0u;
         const bool t_zero = align_len == 0;
-        const bool t_pid = align_len - (int)rd_cur.nm < min_match;                                  // pid < mapid
-        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);   // readq, mapq, aln_cov
-        const bool t_over = is_gen && (gflags & kGenOverrun) != 0u;
+        const bool t_pid = align_len - (int)nm16 < min_match;
+        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);
+        const bool t_over = (gflags & kGenOverrun) != 0u;
         uint32_t err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
         err = t_drop ? 0u : err;
         err = t_noqual ? (uint32_t)E_NO_QUAL : err;
@@ -385,46 +455,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         err = t_zero ? (uint32_t)E_ZERO_ALIGN : err;
         err = t_nonm ? (uint32_t)E_NO_NM : err;
         err = t_noseq ? (uint32_t)E_NO_SEQ : err;
-        err = kind != 0u ? err : 0u;
-        const bool keep = kind != 0u && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
-
+        err = act ? err : 0u;
+        const bool keep = act && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
         // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
         int cpos = pos < 0 ? 0 : pos;
         cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-        const bool owner = kind != 0u && cpos >= tile_start && cpos < tile_start + tile_len;
-        const int rel = pos - tile_start;                                  // pos >= -2^31, tile_start >= 0: may wrap for
-        int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // absurd positions -> parked far right
+        const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+        const int rel = pos - tile_start;                                     // may wrap for absurd positions:
+        int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // those are parked far right
 
-        // ---- per-base threshold bytes and counter offsets from the 4-bit codes ------------------------------------------
-        uint32_t th[8], cd[8];
-        bool walking = keep && has;
-        if (walking) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const uint32_t x = dat_cur.s[s];
-            const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
-            const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
-            th[2 * s] = __builtin_amdgcn_perm(th_hi, th_lo, se);
-            th[2 * s + 1] = __builtin_amdgcn_perm(th_hi, th_lo, so);
-            cd[2 * s] = __builtin_amdgcn_perm(cd_hi, cd_lo, se);
-            cd[2 * s + 1] = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
-          }
-        }
         uint32_t qv[8];
+        bool walking = keep && has;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
-
-        // ---- the read's match segments, one at a time: bases [jlo, jhi) of the lane, the first of them at site loc0 --------
+        for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : d.q[k];
+        // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time ------------------------
+        // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative reference
+        // position only below 4096, and both only ever grow.
         int k = 0, qpos = 0, jlo = 0, jhi = 0, loc0 = 0;
-        const int nc = (int)(rd_cur.l_nc >> 16);
-        // a general read's CIGAR is not prefetched (it would cost eight registers of the double-buffered bases): only the
-        // iterations at the end of a tile's stream come here
-        const uint32_t* cig = p.cigar + ((size_t)rd_cur.co_lo | ((size_t)(rd_cur.misc >> 24) << 32));
-        uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u;
-        if (is_gen && nc > 0) {
-          const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // (may overhang into the array's slack)
-          cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
-        }
         const int q1 = q0 + nb;
         auto next_segment = [&]() -> bool {
           while (k < nc) {
@@ -446,50 +493,18 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
           }
           return false;
         };
-        if (walking) {
-          if (!is_gen) {       // class 0: the one segment is query [lead, lead + align_len) at sites pos ...
-            const int lo = lead > q0 ? lead : q0;
-            const int hi = lead + align_len < q1 ? lead + align_len : q1;
-            jlo = lo - q0; jhi = hi - q0; loc0 = rrel + (q0 - lead);
-            walking = lo < hi;
-          } else {
-            walking = next_segment();
-          }
-        }
-        const uint32_t one = 1u;
+        if (walking) walking = next_segment();
         while (__ballot(walking) != 0ull) {
-          // bases of the lane that belong to this segment AND lie inside the tile: [lo, hi)
           const int lo = jlo > -loc0 ? jlo : -loc0;
           const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
-          const bool go = walking && lo < hi;
-          const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
-          if (__ballot(go && (lo > 0 || hi < LB)) == 0ull) {
-            if (go) tally_lane<LB>(qv, th, cd, abase, one);
-          } else if (go) {
-            // partial lanes: 0xFF into the threshold bytes outside [lo, hi) (a row of each table, LDS)
-            const uint4* mh = reinterpret_cast<const uint4*>(s_mhi) + 2 * (hi > 32 ? 32 : hi);
-            const uint4* ml = reinterpret_cast<const uint4*>(s_mlo) + 2 * (lo < 0 ? 0 : lo);
-            const uint4 h0 = mh[0], h1 = mh[1], l0 = ml[0], l1 = ml[1];
-            uint32_t tm[8];
-            tm[0] = th[0] | h0.x | l0.x; tm[1] = th[1] | h0.y | l0.y; tm[2] = th[2] | h0.z | l0.z; tm[3] = th[3] | h0.w | l0.w;
-            tm[4] = th[4] | h1.x | l1.x; tm[5] = th[5] | h1.y | l1.y; tm[6] = th[6] | h1.z | l1.z; tm[7] = th[7] | h1.w | l1.w;
-            tally_lane<LB>(qv, tm, cd, abase, one);
-          }
-          walking = (walking && is_gen && k < nc) ? next_segment() : false;
+          tally_range(walking && lo < hi, lo, hi, loc0, qv, d.s);
+          walking = (walking && k < nc) ? next_segment() : false;
         }
-
-        // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
         const bool head = owner && c == 0;
         w_aligned += (uint32_t)__popcll(__ballot(head));
         w_mapped += (uint32_t)__popcll(__ballot(head && keep));
-        if (head && err) {   // (the read's index: its stream position, or the first word of its descriptor)
-          const uint32_t idx = is_gen ? p.gdesc[(size_t)(st.gb + (vpos - st.n0)) * kGenDescWords] : (uint32_t)(st.rb + vpos);
-          atomicMin(p.err, ((unsigned long long)idx << 8) | err);
-        }
+        if (head && err) atomicMin(p.err, ((unsigned long long)da.x << 8) | err);
       }
-
-      rd_cur = rd_n;
-      dat_cur = dat_n;
     }
 
     if (lane == 0) {
@@ -502,14 +517,14 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     const int tn = more ? wn : t;
     const Tile ntile = load_tile(c_tiles, tn);
     const Stream nst = load_stream(tn);
-    const int nit_hi = n_iters(nst);
-    Raw raw_c;
+    const int nit_hi = n_iters(nst.n0);
+    RawA raw_c;
     if (more && !xt) {   // (with xt the pipeline already holds the next tile's first two iterations)
-      raw_c = fetch_raw(nst, v0);
-      raw_n = fetch_raw(nst, v0 + vstep);
+      raw_c = fetch_a(nst, v0);
+      raw_n = fetch_a(nst, v0 + vstep);
     }
     lds_barrier();       // every tally of this tile is in LDS
-    if (more && !xt) settle(raw_c, rd_cur, dat_cur);
+    if (more && !xt) settle_a(raw_c, rd_cur, dat_cur);
     uint32_t ticket = 0;
     if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 

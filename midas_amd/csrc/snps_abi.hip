@@ -112,6 +112,7 @@ struct midas_snps_batch {
   int64_t direct_stream_reads = 0;   // sum over tiles of the positions their streams hold (>= n_reads: straddlers twice)
   int64_t direct_max_tile_reads = 0;
   int64_t direct_run_count = 0;
+  bool direct_sorted = false;   // every contig's reads in position order (found by the first index pass): tile ranges need no atomics
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot: before the index kernel, before and after the pileup kernel
   std::vector<hipEvent_t> pev; // 3 per slot: before the pack, before and after its scatter kernel
@@ -597,6 +598,9 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
   ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads;
   ip->gdesc = b->d_gdesc; ip->gdesc_capacity = b->gdesc_capacity;
+  ip->n_general_hint = b->direct_run_count > 0 ? (int64_t)b->h_dtotals.n_general : b->n_reads;
+  ip->sorted = b->direct_sorted ? 1 : 0;
+  ip->reach = b->max_l_seq;
   ip->facts = b->d_dfacts; ip->totals = b->d_dtotals;
   ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
   ip->n_stat_words = b->d_work ? b->n_species * MIDAS_STATS : 0;
@@ -638,6 +642,7 @@ int32_t direct_prepare(midas_snps_batch* b) {
   const DirectTotals& t = b->h_dtotals;
   if (t.status != kNoError) return pack_status_to_error(ctx, t.status);
   b->max_l_seq = (int32_t)t.max_l;
+  b->direct_sorted = t.unsorted == 0;
   b->alg_bytes = (int64_t)t.alg_bytes + 17 * b->n_sites;
   b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
   b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;

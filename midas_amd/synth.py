@@ -203,6 +203,8 @@ CONFIGS = {
     'c3': dict(n_species=20, contigs_per_species=16, contig_len=250000, n_reads=10666667, seed=BASE_SEED + 3),
     # one rank's share of C4 (100 species x 4 Mb, 80 M reads over 8 GPUs)
     'c4_rank': dict(n_species=13, contigs_per_species=16, contig_len=250000, n_reads=10400000, seed=BASE_SEED + 4),
+    # developer measurements: configs[2] with every read a full-length match (no clips, no indels)
+    'c3_plain': dict(n_species=20, contigs_per_species=16, contig_len=250000, n_reads=10666667, seed=BASE_SEED + 3, plain_only=True),
 }
 
 

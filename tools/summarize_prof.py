@@ -2,6 +2,7 @@
 usage: python tools/summarize_prof.py gpurun_out/prof_<tag> > profiles/<name>.txt
 """
 import glob
+import re
 import json
 import os
 import sqlite3
@@ -30,8 +31,8 @@ def main():
         q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
              "where kernel_name like '%midas%' or kernel_name like '%merge_sites%' group by kernel_name, counter_name")
         for k, c, v, n in cur.execute(q):
-            short = "pileup_tiles_kernel" if "pileup" in k else ("index_reads_kernel" if "index" in k else
-                                                                  ("merge_sites_kernel" if "merge_sites" in k else k[:40]))
+            m = re.search(r"(\w+_kernel)", k)
+            short = m.group(1) if m else k[:40]
             print("%-22s %-28s %18.1f  (n=%d)" % (short, c, v, n))
             out["pmc"].setdefault(short, {})[c] = v
     for k, d in out["pmc"].items():
