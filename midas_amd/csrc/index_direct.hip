@@ -3,12 +3,12 @@
 //
 // Three launches on one stream, every pass (they are inside the timed step):
 //   direct_classify_kernel  one thread per read: validates the read's CSR extents (status + lowest read, as the packer
-//                           does), decides its class (kernels.h), writes the one-word `info` of a class-0 read (leading
+//                           does), decides its class (kernels.h), writes the 20-byte index record of a class-0 read (leading
 //                           clip, aligned length, trailing clip -- what query_alignment_sequence, midas/run/snps.py:145,
-//                           needs of the CIGAR), publishes the lowest / highest class-0 read index touching every tile,
+//                           needs of the CIGAR --, position, NM, mapq, byte offsets of its SEQ and QUAL), publishes the lowest / highest class-0 read index touching every tile,
 //                           counts the (general read, tile) entries per tile and appends the general reads to a list
 //   direct_scan_kernel      one workgroup: entry offsets per tile (exclusive scan), the pass's totals
-//   direct_fill_kernel      one thread per general read: its 48-byte descriptor into every tile it touches (the tile of its
+//   direct_fill_kernel      one thread per general read: its 32-byte descriptor into every tile it touches (the tile of its
 //                           clamped start, which counts it, and every tile holding one of its aligned bases), with the
 //                           clip lengths by pysam's rules and the IndexError condition of count_coverage precomputed
 // No sort, no payload: the pileup kernel reads SEQ / QUAL / CIGAR where they are.
@@ -74,25 +74,25 @@ __device__ __forceinline__ bool bad_layout(const DirectIndexParams& p, const Fie
 }
 
 // Class 0 or not: `H* S? (M|=|X)+ S? H*`, every length >= 1, the query length adding up, NM present, the read's start inside
-// its contig.  On success *info = leading clip | aligned length << 10 | trailing clip << 21.
+// its contig.  On success *info = leading clip | aligned length << 10 | trailing clip << 21.  One forward pass:
+// stage 0 leading hard clips, 1 behind the leading soft clip, 2 in the matches, 3 behind the trailing soft clip, 4 trailing
+// hard clips.
 __device__ bool class0_info(const Fields& f, const CigarView& cg, long long clen, uint32_t* info) {
   const uint32_t nc = (uint32_t)(f.co1 - f.co);
   if (f.l < 1 || f.l > kMaxLSeq || f.nm < 0 || f.pos < 0 || !((long long)f.pos < clen) || nc == 0u) return false;
-  uint32_t k = 0;
-  while (k < nc && (cg[k] & 15u) == OP_H) { if ((cg[k] >> 4) == 0u) return false; ++k; }
-  uint32_t lead = 0, trail = 0;
-  if (k < nc && (cg[k] & 15u) == OP_S) { lead = cg[k] >> 4; if (lead == 0u) return false; ++k; }
-  uint32_t e = nc;
-  while (e > k && (cg[e - 1] & 15u) == OP_H) { if ((cg[e - 1] >> 4) == 0u) return false; --e; }
-  if (e > k && (cg[e - 1] & 15u) == OP_S) { trail = cg[e - 1] >> 4; if (trail == 0u) return false; --e; }
-  if (e <= k) return false;
+  uint32_t stage = 0, lead = 0, trail = 0;
   unsigned long long m = 0;
-  for (uint32_t i = k; i < e; ++i) {
-    const uint32_t v = cg[i];
-    if (!op_is_match(v & 15u) || (v >> 4) == 0u) return false;
-    m += v >> 4;
-  }
-  if ((unsigned long long)lead + m + trail != (unsigned long long)f.l) return false;
+  bool ok = true;
+  for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
+    const uint32_t op = v & 15u, len = v >> 4;
+    if (len == 0u) ok = false;
+    else if (op == OP_H) { if (stage == 2u || stage == 3u) stage = 4u; else if (stage != 0u && stage != 4u) ok = false; }
+    else if (op == OP_S) { if (stage == 0u) { lead = len; stage = 1u; } else if (stage == 2u) { trail = len; stage = 3u; } else ok = false; }
+    else if (op_is_match(op)) { if (stage <= 2u) { m += len; stage = 2u; } else ok = false; }
+    else ok = false;
+    return ok;
+  });
+  if (!ok || stage < 2u || (unsigned long long)lead + m + trail != (unsigned long long)f.l) return false;
   *info = lead | ((uint32_t)m << kInfoAlenShift) | (trail << kInfoTrailShift);
   return true;
 }
@@ -106,8 +106,8 @@ __device__ void general_tiles(long long pos, uint32_t nc, const CigarView& cg, l
   long long last = pc >> tile_shift;
   emit(tile_base + (int)last);
   long long r = pos;
-  for (uint32_t k = 0; k < nc; ++k) {
-    const uint32_t v = cg[k], op = v & 15u;
+  for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
+    const uint32_t op = v & 15u;
     const long long len = (long long)(v >> 4);
     if (op_is_match(op)) {
       const long long a = r < 0 ? 0 : r, b = r + len < clen ? r + len : clen;
@@ -120,7 +120,8 @@ __device__ void general_tiles(long long pos, uint32_t nc, const CigarView& cg, l
     } else if (op == OP_D || op == OP_N) {
       r += len;
     }
-  }
+    return true;
+  });
 }
 
 __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, unsigned long long* lds4) {
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
   __shared__ int s_tile0;
   if (blockIdx.x == 0) {
     for (int i = threadIdx.x; i < p.n_stat_words; i += kClsBlock) p.stats[i] = 0ull;
-    if (threadIdx.x == 0) *p.err = kNoError;
+    if (threadIdx.x == 0) {
+      *p.err = kNoError;
+      idxrec_store_idle(p.rec, (size_t)p.n_reads, 0u);      // the sentinels: what a lane without a read / an entry fetches
+      if (p.gdesc) gdesc_store_idle(p.gdesc + (size_t)p.gdesc_capacity * kGenDescWords);
+    }
   }
   for (int i = blockIdx.x * kClsBlock + threadIdx.x; i < p.n_tiles; i += gridDim.x * kClsBlock) {
     p.tbegin_next[i] = 0xFFFFFFFFu;
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
     Fields f[kClsU];
     uint32_t c0[kClsU];
     int32_t pos_before[kClsU];
+    uint32_t mapq[kClsU];
     bool bad[kClsU];
 #pragma unroll
     for (int u = 0; u < kClsU; ++u) {
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
       const long long ic = ii < hi ? ii : hi - 1;
       f[u] = load_fields(p, ic);
       pos_before[u] = p.pos[ic > 0 ? ic - 1 : 0];
+      mapq[u] = p.mapq[ic];
     }
 #pragma unroll
     for (int u = 0; u < kClsU; ++u) {
@@ -238,10 +245,11 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
         const int i = (int)ii;
         cur.advance(p, i);
         const uint32_t l = (uint32_t)f[u].l;
-        quick = !bad[u] && f[u].co1 - f[u].co == 1 && l - 1u < (uint32_t)kMaxLSeq && f[u].nm >= 0 && f[u].nm <= kMaxField16 &&
+        quick = !bad[u] && f[u].co1 - f[u].co == 1 && l - 1u < (uint32_t)kMaxLSeq && idxrec_fits(f[u].nm, (unsigned long long)f[u].so) &&
                 f[u].pos >= 0 && (long long)f[u].pos < cur.clen && op_is_match(c0[u] & 15u) && (c0[u] >> 4) == l;
         if (quick) {
-          p.info[i] = l << kInfoAlenShift;
+          idxrec_store(p.rec, (size_t)i, l << kInfoAlenShift, f[u].pos, (uint32_t)f[u].nm, mapq[u], (unsigned long long)f[u].so,
+                       (unsigned long long)f[u].qo);
           alg += (unsigned long long)((l + 1u) / 2u + l + 4u + 16u);
           maxl = l > maxl ? l : maxl;
         }
@@ -303,10 +311,10 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
       const long long l = f.l, nc = f.co1 - f.co;
       if (bad_layout(p, f)) {
         atomicMin(&p.facts->status, ((unsigned long long)i << 8) | kPackBadLayout);
-        p.info[i] = kInfoGeneral;     // (the run fails: nothing reads it)
+        idxrec_store_idle(p.rec, (size_t)i, 0u);     // (the run fails: nothing reads it)
       } else if (l > kMaxLSeq || nc > kMaxField16 || f.nm > kMaxField16) {
         atomicMin(&p.facts->status, ((unsigned long long)i << 8) | kPackUnsupported);
-        p.info[i] = kInfoGeneral;
+        idxrec_store_idle(p.rec, (size_t)i, 0u);
       } else {
         CigarView cg;
         cg.load(p.cigar + f.co);
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
         uint32_t info = 0;
         alg += (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
         maxl = (uint32_t)l > maxl ? (uint32_t)l : maxl;
-        if (class0_info(f, cg, at.clen, &info)) {
-          p.info[i] = info;
+        if (idxrec_fits(f.nm, (unsigned long long)f.so) && class0_info(f, cg, at.clen, &info)) {
+          idxrec_store(p.rec, (size_t)i, info, f.pos, (uint32_t)f.nm, p.mapq[i], (unsigned long long)f.so, (unsigned long long)f.qo);
           if (!SORTED) {
             const uint32_t alen = (info >> kInfoAlenShift) & 2047u;
             const uint32_t start = (uint32_t)f.pos, room = (uint32_t)at.clen - start;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
             }
           }
         } else {
-          p.info[i] = kInfoGeneral | (uint32_t)at.c;      // (the fill kernel takes the contig from here)
+          idxrec_store_idle(p.rec, (size_t)i, (uint32_t)at.c);      // (the fill kernel takes the contig from here)
           general = true;
           unsigned long long n = 0;
           // entries per tile: counted in LDS for the tiles near the workgroup's reads, one global atomic per tile afterwards
@@ -366,7 +374,13 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
   }
   {
     const uint32_t n_gen = s_ngen;
-    if (threadIdx.x == 0 && n_gen) s_gen_base = atomicAdd(&p.facts->n_general, n_gen);     // one atomic per workgroup
+    // the workgroup's general reads go to ITS stretch of the list (the fill kernel takes it workgroup by workgroup: reads of
+    // one neighbourhood, so that their tiles fall into one LDS window there too)
+    if (threadIdx.x == 0) {
+      s_gen_base = (uint32_t)lo;
+      p.gen_count[blockIdx.x] = n_gen;
+      if (n_gen) atomicAdd(&p.facts[blockIdx.x % kDirectFactSlots].n_general, n_gen);
+    }
     if (threadIdx.x < kGenWin && s_hist[threadIdx.x] && tile0 + (int)threadIdx.x <= p.n_tiles)
       atomicAdd(&p.gcount[tile0 + threadIdx.x], s_hist[threadIdx.x]);
     __syncthreads();
@@ -418,10 +432,11 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   // the pass's totals: the slots added up, then cleared for the next pass
   if (tid < kDirectFactSlots) {
     DirectFacts* f = p.facts + tid;
-    unsigned long long alg = f->alg_bytes, ent = f->n_entries, mx = f->max_l, uns = f->unsorted;
+    unsigned long long alg = f->alg_bytes, ent = f->n_entries, mx = f->max_l, uns = f->unsorted, ngen = f->n_general;
     for (int d = 32; d >= 1; d >>= 1) {
       alg += __shfl_down(alg, d);
       ent += __shfl_down(ent, d);
+      ngen += __shfl_down(ngen, d);
       const unsigned long long o = __shfl_down(mx, d);
       mx = o > mx ? o : mx;
       uns |= __shfl_down(uns, d);
@@ -451,8 +466,9 @@ constexpr int kFillKeep = 4;         // tile entries of a read ranked through LD
 __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParams p) {
   __shared__ uint32_t s_cnt[kGenWin], s_base[kGenWin];
   __shared__ int s_tile0;
-  const uint32_t n_gen = p.totals->n_general;
-  for (uint32_t chunk = blockIdx.x * kClsBlock; chunk < n_gen; chunk += gridDim.x * kClsBlock) {
+  const uint32_t n_gen = p.gen_count[blockIdx.x];            // the general reads of classify workgroup blockIdx.x ...
+  const uint32_t list0 = blockIdx.x * (uint32_t)kClsRun;     // ... lie at the start of its stretch of the list
+  for (uint32_t chunk = 0; chunk < n_gen; chunk += kClsBlock) {
     const uint32_t k = chunk + threadIdx.x;
     const bool act = k < n_gen;
     if (threadIdx.x < kGenWin) s_cnt[threadIdx.x] = 0u;
@@ -462,11 +478,11 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
     long long clen = 1;
     int tile_base = 0;
     if (act) {
-      const int i = (int)p.gen_reads[k];
+      const int i = (int)p.gen_reads[list0 + k];
       const Fields f = load_fields(p, i);
       nc = (uint32_t)(f.co1 - f.co);
       cg.load(p.cigar + f.co);
-      const int c = (int)(p.info[i] & ~kInfoGeneral);      // its contig, left there by the classify kernel
+      const int c = (int)(*reinterpret_cast<const uint32_t*>(p.rec + (size_t)i * kIdxRecBytes) & ~kInfoGeneral);   // its contig, left there by the classify kernel
       clen = p.contig_len[c];
       tile_base = p.contig_tile_base[c];
       d.idx = (uint32_t)i;
@@ -477,17 +493,18 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
       d.mapq = p.mapq[i];
       d.so = (unsigned long long)f.so; d.qo = (unsigned long long)f.qo; d.co = (unsigned long long)f.co;
       // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
-      const long long qs = query_start(cg, nc), qe = query_end(cg, nc, f.l);
+      long long qs = 0, qe = 0;
+      query_bounds(cg, nc, f.l, &qs, &qe);
       long long al = qe - qs;
       al = al < 0 ? 0 : al;
-      d.align_len = (uint32_t)(al > 0xFFFF ? 0xFFFF : al);
-      d.lead = (uint32_t)(qs > 0xFFFF ? 0xFFFF : qs);
+      d.align_len = (uint32_t)(al > 2047 ? 2047 : al);      // (l_seq <= 1024)
+      d.lead = (uint32_t)(qs > 2047 ? 2047 : qs);
       // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position
       // >= l_seq onto a site inside the contig
       uint32_t flags = f.nm < 0 ? kGenNoNm : 0u;
       long long qpos = 0, rpos = f.pos;
-      for (uint32_t j = 0; j < nc; ++j) {
-        const uint32_t v = cg[j], op = v & 15u;
+      for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
+        const uint32_t op = v & 15u;
         const long long len = (long long)(v >> 4);
         if (op_is_match(op)) {
           if (qpos + len > (long long)f.l) {
@@ -502,7 +519,8 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
         } else if (op == OP_D || op == OP_N) {
           rpos += len;
         }
-      }
+        return true;
+      });
       d.flags = flags;
       if (threadIdx.x == 0) {
         long long pc = f.pos < 0 ? 0 : f.pos;
@@ -526,7 +544,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
         } else {
           const uint32_t left = atomicSub(&p.gcount[t], 1u);
           const long long slot = (long long)p.goff[t] + (long long)left - 1;
-          if (slot >= 0 && slot < p.gdesc_capacity) gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d);
+          if (slot >= 0 && slot < p.gdesc_capacity) { gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d); p.gidx[slot] = d.idx; }
         }
         ++ord;
       });
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
     for (int e = 0; e < n_kept; ++e) {
       const int t = kept_tile[e];
       const long long slot = (long long)p.goff[t] + (long long)s_base[t - tile0] + (long long)kept_rank[e];
-      if (slot >= 0 && slot < p.gdesc_capacity) gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d);
+      if (slot >= 0 && slot < p.gdesc_capacity) { gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d); p.gidx[slot] = d.idx; }
     }
     __syncthreads();      // s_cnt / s_tile0 are rewritten by the next chunk
   }
@@ -548,15 +566,15 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
 
 }  // namespace
 
+int direct_index_blocks(int64_t n_reads) { return n_reads > 0 ? (int)((n_reads + kClsRun - 1) / kClsRun) : 1; }
+
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s) {
   // always launched (even with no reads): block 0 resets the counters and the error word, the scan publishes the totals
   const int grid = p.n_reads > 0 ? (int)(((long long)p.n_reads + kClsRun - 1) / kClsRun) : 1;
   if (p.sorted) hipLaunchKernelGGL(direct_classify_kernel<true>, dim3(grid), dim3(kClsBlock), 0, s, p);
   else hipLaunchKernelGGL(direct_classify_kernel<false>, dim3(grid), dim3(kClsBlock), 0, s, p);
   hipLaunchKernelGGL(direct_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, p);
-  // (the grid follows the count the batch's first pass found: the batch never changes; the kernel itself reads the device's)
-  const long long fg = (p.n_general_hint + kClsBlock - 1) / kClsBlock;
-  hipLaunchKernelGGL(direct_fill_kernel, dim3((unsigned)(fg < 256 ? 256 : fg)), dim3(kClsBlock), 0, s, p);
+  hipLaunchKernelGGL(direct_fill_kernel, dim3(grid), dim3(kClsBlock), 0, s, p);       // one workgroup per classify workgroup
   return hipGetLastError();
 }
 

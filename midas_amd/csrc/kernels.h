@@ -159,19 +159,19 @@ hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);             
 // batch add up to much more than its reads.
 constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0 (then bits 0-30: its contig); else lead | alen << 10 | trail << 21
 constexpr int kInfoAlenShift = 10, kInfoTrailShift = 21;
-constexpr int kGenDescWords = 12;                 // 48 bytes per (general read, tile) entry
+constexpr int kGenDescWords = 8;                  // 32 bytes per (general read, tile) entry
 
 // gdesc flag bits
-constexpr uint32_t kGenQualUnused = 0;            // (QUAL absence is read from the quality bytes themselves)
 constexpr uint32_t kGenOverrun = 1;               // a match op maps a query position >= l_seq into the contig (IndexError if kept)
 constexpr uint32_t kGenNoNm = 2;                  // record has no NM tag
+constexpr uint32_t kGenIdle = 0x80;               // the sentinel descriptor [gdesc_capacity]: what a lane without an entry fetches
 
 constexpr int kDirectFactSlots = 64;
 struct alignas(128) DirectFacts {                 // per-slot partial sums of one classify pass (slot 0 also holds the status)
   unsigned long long status;                      // min((read << 8) | kPack*), kNoError when every read is well-formed
   unsigned long long alg_bytes;                   // sum(ceil(l/2) + l + 4*n_cigar + 16)
   unsigned long long n_entries;                   // (general read, tile) entries
-  uint32_t n_general;                             // general reads (slot 0 only: it is the append cursor of gen_reads)
+  uint32_t n_general;                             // general reads
   uint32_t max_l;                                 // longest read
   uint32_t unsorted;                              // some contig's reads are not in position order
 };
@@ -188,13 +188,15 @@ struct DirectIndexParams {
   int32_t n_reads;
   const int32_t* contig_read_begin; const int32_t* contig_tile_base; const int32_t* contig_len;
   int32_t n_contigs, n_tiles, tile_shift;
-  uint32_t* info;                                 // [n_reads]
+  uint8_t* rec;                                   // [n_reads + 1] 20-byte index records (direct_common.h), the last one a sentinel
   uint32_t* tbegin; uint32_t* tend;               // [n_tiles] this run's parity: min index / max index + 1 of the class-0 reads touching a tile
   uint32_t* tbegin_next; uint32_t* tend_next;     // the other parity, reset here for the next run
   uint32_t* gcount;                               // [n_tiles + 1] general entries per tile (zero on entry; the fill kernel counts it back to zero)
   uint32_t* goff;                                 // [n_tiles + 1] exclusive scan of gcount
-  uint32_t* gen_reads;                            // [n_reads] the general reads, in no particular order
+  uint32_t* gen_reads;                            // [n_reads] the general reads: every classify workgroup fills the start of its own stretch
+  uint32_t* gen_count;                            // [direct_index_blocks(n_reads)] how many it put there
   uint32_t* gdesc;                                // [n_entries][kGenDescWords]
+  uint32_t* gidx;                                 // [n_entries] read index of an entry (error reports)
   int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)
   int32_t sorted;                                 // the batch's first pass found every contig's reads in position order
   int32_t reach;                                  // the longest read of the batch: no class-0 read spans more sites
@@ -206,11 +208,10 @@ struct DirectIndexParams {
 };
 
 struct DirectParams {
-  const int32_t* pos; const uint8_t* mapq; const int32_t* nm;
-  const int64_t* seq_off; const int64_t* qual_off;
   const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
-  const uint32_t* info;
-  const uint32_t* tbegin; const uint32_t* tend; const uint32_t* goff; const uint32_t* gdesc;
+  const uint8_t* rec;                             // index records, written by the classify kernel
+  const uint32_t* tbegin; const uint32_t* tend; const uint32_t* goff; const uint32_t* gdesc; const uint32_t* gidx;
+  int64_t gdesc_capacity;                         // entries; the sentinel descriptor sits behind them
   const uint8_t* ref;
   const Tile* tiles;
   const FilterTables* filt;
@@ -225,6 +226,7 @@ struct DirectParams {
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);
+int direct_index_blocks(int64_t n_reads);
 
 hipError_t launch_index_reads(const IndexParams& p, hipStream_t stream);
 hipError_t launch_pileup_tiles(const PileupParams& p, hipStream_t stream, bool whole_tiles, bool parts);   // barrier-phased

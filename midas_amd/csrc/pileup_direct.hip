@@ -132,15 +132,9 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
   }
 }
 
-// The per-tile stream: the read indices rb .. rb + n0 (class 0; a general read in the range is skipped there), then the
-// tile's general descriptors gb .. gb + ng.
-struct Stream { int rb, n0, gb, ng; };
-
-// 32-bit byte offsets from a uniform base: the loads take the `saddr + voffset` form (no 64-bit address arithmetic per lane)
-template <class T>
-__device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off) {
-  return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
-}
+// The per-tile stream: the index records rb .. rb + n0 (class 0; a general read in the range is skipped there), then the
+// tile's general descriptors gb .. gb + ng -- as wave-iterations: na of the first kind, then ng_it of the second.
+struct Stream { int rb, n0, gb, ng, na, total; };
 
 template <int LB, bool BQ0>
 __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectParams p) {
@@ -194,7 +188,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const int c = lane - g * lpr;
   const bool lane_used = g < rpw;
   const int q0 = c * LB;                           // first base of the lane in the read's stored query
-  const int vstep = NWAVES * rpw;
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
   const uint32_t qsum_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_qsum + wave * 64 + g);
   // v_perm_b32 tables (slots 0, 1, 3, 7 = A, C, G, T): threshold bytes and counter offsets
@@ -203,6 +196,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
   const uint32_t one = 1u;
+  const uint8_t* const q_lane = p.qual + q0;            // (one 64-bit addition per pointer and read)
+  const uint8_t* const s_lane = p.seq4 + (q0 >> 1);
 
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
@@ -215,6 +210,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     s.n0 = e > b ? (int)(e - b) : 0;
     s.gb = (int)g0;
     s.ng = (int)(g1 - g0);
+    s.na = (s.n0 + rpw - 1) / rpw;
+    s.total = s.na + (s.ng + rpw - 1) / rpw;
     return s;
   };
 
@@ -237,6 +234,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
 #pragma unroll
       for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
     }
+    if (c == 0) part |= ((q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
     return part;
   };
   // Threshold bytes and counter offsets of eight bases from their 4-bit codes (one dword of SEQ): the even and the odd
@@ -271,30 +269,57 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
   };
 
-  // ---- class 0, stage F: the columns of range position v (raw loads; nothing is computed from them here) -----------------
-  struct RawA { uint32_t info, pos, nm, mapq, so_lo, so_hi, qo_lo, qo_hi; };
-  auto fetch_a = [&](const Stream& st, int v) -> RawA {
-    RawA f;
-    f.info = kInfoGeneral;
-    if (lane_used && v < st.n0) {
-      const uint32_t i = (uint32_t)(st.rb + v);
-      f.info = ld_off<uint32_t>(p.info, i * 4u);
-      f.pos = ld_off<uint32_t>(p.pos, i * 4u);
-      f.nm = ld_off<uint32_t>(p.nm, i * 4u);
-      f.mapq = ld_off<uint8_t>(p.mapq, i);
-      const uint2 so = ld_off<uint2>(p.seq_off, i * 8u), qo = ld_off<uint2>(p.qual_off, i * 8u);
-      f.so_lo = so.x; f.so_hi = so.y; f.qo_lo = qo.x; f.qo_hi = qo.y;
-    }
+  // ---- stage F: the record / descriptor of this lane's read in wave-iteration `it` of a tile's stream.  Raw loads: nothing is
+  // computed from them here, and NO load sits in a branch -- a lane without a read fetches the sentinel record, a lane
+  // without bases the first bytes of the arrays -- so that the compiler can count the loads in flight (a load in a branch
+  // makes it wait for every outstanding load, vmcnt(0), before the first use of any of them: the prefetch of the next
+  // iteration's bases would be waited for at once).
+  struct Raw { uint4 a, b; };
+  const uint8_t* const gd_base = reinterpret_cast<const uint8_t*>(p.gdesc);
+  const uint8_t* const idle_rec = p.rec + (size_t)p.n_reads * kIdxRecBytes;       // the two sentinels
+  const uint8_t* const idle_gd = gd_base + (size_t)p.gdesc_capacity * (kGenDescWords * 4);
+  auto fetch = [&](const Stream& st, int it) -> Raw {
+    const bool gen = it >= st.na;                                   // (wave-uniform)
+    const int v = (gen ? it - st.na : it) * rpw + g;
+    const bool act = lane_used && it < st.total && v < (gen ? st.ng : st.n0);
+    const uint8_t* src = gen ? gd_base + (size_t)(uint32_t)(st.gb + v) * (kGenDescWords * 4) : p.rec + (size_t)(uint32_t)(st.rb + v) * kIdxRecBytes;
+    src = act ? src : (gen ? idle_gd : idle_rec);
+    Raw f;
+    const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src);
+    const u32x4_a4 b = *reinterpret_cast<const u32x4_a4*>(src + 16);      // (of a 20-byte record: its last word and the next record's head)
+    f.a = make_uint4(a.x, a.y, a.z, a.w);
+    f.b = make_uint4(b.x, b.y, b.z, b.w);
     return f;
   };
-  // ---- stage D: the lane's bases (two 16-byte loads of QUAL, one of SEQ) --------------------------------------------------
-  struct RdA { uint32_t info, pos, nm, mapq; };
+  // ---- stage D: what the read's processing needs of its record, and the lane's bases (two 16-byte loads of QUAL, one of SEQ)
+  //   a: class 0 the info word; general: aligned length | leading clip << 11 | CIGAR offset bits 32-39 << 22
+  //   nmq: NM | mapq << 16 | kGen* flags << 24 (kGenIdle: nothing to do)        l_nc: l_seq | n_cigar << 16
+  struct Rd { uint32_t a, pos, nmq, l_nc, co_lo; };
   struct Dat { uint32_t q[8]; uint32_t s[4]; };
-  const uint8_t* const q_lane = p.qual + q0;            // (one 64-bit addition per pointer and read, not three)
-  const uint8_t* const s_lane = p.seq4 + (q0 >> 1);
-  auto load_bases = [&](unsigned long long so, unsigned long long qo, Dat& d) {
-    const uint8_t* qp = q_lane + qo;
-    const uint8_t* sp = s_lane + so;
+  auto settle = [&](const Raw& f, bool gen, Rd& r, Dat& d) {
+    unsigned long long so, qo;
+    int l;
+    r.a = f.a.x; r.pos = f.a.y;
+    if (!gen) {       // (wave-uniform; no load in here)
+      const bool act = !(f.a.x >> 31);
+      l = (int)((f.a.x & 1023u) + ((f.a.x >> kInfoAlenShift) & 2047u) + ((f.a.x >> kInfoTrailShift) & 1023u));
+      l = act ? l : 0;
+      r.nmq = (f.a.w & 2047u) | (((f.a.w >> 11) & 0xFFu) << 16) | (act ? 0u : (uint32_t)kGenIdle << 24);
+      r.l_nc = (uint32_t)l;
+      r.co_lo = 0u;
+      qo = (unsigned long long)f.a.z | ((unsigned long long)((f.a.w >> 19) & 0xFFu) << 32);
+      so = (unsigned long long)f.b.x | ((unsigned long long)(f.a.w >> 27) << 32);
+    } else {
+      l = (int)(f.b.w & 0xFFFFu);                                    // (0 in the sentinel)
+      r.nmq = (f.a.z & 0x00FFFFFFu) | (((f.b.y >> 8) & 0xFFu) << 24);
+      r.l_nc = f.b.w;
+      r.co_lo = f.b.z;
+      qo = (unsigned long long)f.b.x | ((unsigned long long)(f.b.y & 0xFFu) << 32);
+      so = (unsigned long long)f.a.w | ((unsigned long long)(f.a.z >> 24) << 32);
+    }
+    const bool has = q0 < l && !(kDebug & 128);
+    const uint8_t* qp = has ? q_lane + qo : p.qual;
+    const uint8_t* sp = has ? s_lane + so : p.seq4;
     const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
     const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
     const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
@@ -302,24 +327,16 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
     d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
   };
-  auto settle_a = [&](const RawA& f, RdA& r, Dat& d) {
-    r.info = f.info; r.pos = f.pos; r.nm = f.nm; r.mapq = f.mapq;
-    const int l = (int)((f.info & 1023u) + ((f.info >> kInfoAlenShift) & 2047u) + ((f.info >> kInfoTrailShift) & 1023u));
-    if (!(f.info & kInfoGeneral) && q0 < l)
-      load_bases((unsigned long long)f.so_lo | ((unsigned long long)f.so_hi << 32), (unsigned long long)f.qo_lo | ((unsigned long long)f.qo_hi << 32), d);
-  };
 
   Tile tile = load_tile(c_tiles, w);
   Stream st = load_stream(w);
-  auto n_iters = [&](int n) -> int { return (n + rpw - 1) / rpw; };
-  int it_hi = n_iters(st.n0);
-  const int v0 = wave * rpw + g;
-  RawA raw_n = fetch_a(st, v0 + vstep);
-  RdA rd_cur;
+  Raw raw_n = fetch(st, wave + NWAVES);
+  bool gen_n = wave + NWAVES >= st.na;       // kind of the iteration raw_n belongs to (wave-uniform)
+  Rd rd_cur;
   Dat dat_cur;
   {
-    const RawA raw_c = fetch_a(st, v0);
-    settle_a(raw_c, rd_cur, dat_cur);
+    const Raw raw_c = fetch(st, wave);
+    settle(raw_c, wave >= st.na, rd_cur, dat_cur);
   }
   __syncthreads();   // LDS zeroed, tables in place
 
@@ -328,6 +345,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
+    const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
     constexpr int REF_IT = TILE / (4 * kPileupBlock);
     uint32_t refw[REF_IT];
@@ -340,115 +358,93 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       }
     }
 
-    // ======================= class 0: the reads of the tile's range, one gap-free match segment each =========================
-    int vpos = v0;
-    // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
-    // the columns of its first two iterations of the NEXT tile
+    // the record / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
+    // the records of its first two iterations of the NEXT tile
     const int n_w = it_hi > wave ? (it_hi - wave + NWAVES - 1) / NWAVES : 0;
     const bool xt = w_next < w_end && n_w >= 2;
     Stream xs = st;
     if (xt) xs = load_stream(w_next);
-    for (int it = wave; it < it_hi; it += NWAVES, vpos += vstep) {
-      RdA rd_n;
+    for (int it = wave; it < it_hi; it += NWAVES) {
+      Rd rd_n;
       Dat dat_n;
-      settle_a(raw_n, rd_n, dat_n);       // (the columns of the next iteration have arrived: its bases are requested ...)
-      if (xt && it + 2 * NWAVES >= it_hi) raw_n = fetch_a(xs, (it + NWAVES < it_hi) ? v0 : v0 + vstep);   // ... then the
-      else raw_n = fetch_a(st, vpos + 2 * vstep);                                                          // columns after it
+      settle(raw_n, gen_n, rd_n, dat_n);       // (the record of the next iteration has arrived: its bases are requested ...)
+      {                                        // ... then the record of the one after it
+        const bool over = xt && it + 2 * NWAVES >= it_hi;
+        Stream fs;
+        fs.rb = over ? xs.rb : st.rb; fs.n0 = over ? xs.n0 : st.n0; fs.gb = over ? xs.gb : st.gb; fs.ng = over ? xs.ng : st.ng;
+        fs.na = over ? xs.na : st.na; fs.total = over ? xs.total : st.total;
+        const int fi = over ? ((it + NWAVES < it_hi) ? wave : wave + NWAVES) : it + 2 * NWAVES;
+        raw_n = fetch(fs, fi);
+        gen_n = fi >= fs.na;
+      }
+      const bool gen_cur = it >= st.na;        // (wave-uniform) a general-descriptor iteration
 
-      const bool act = !(rd_cur.info & kInfoGeneral);
-      const int lead = (int)(rd_cur.info & 1023u);
-      const int align_len = (int)((rd_cur.info >> kInfoAlenShift) & 2047u);
-      const int l = act ? lead + align_len + (int)((rd_cur.info >> kInfoTrailShift) & 1023u) : 0;
+      if (kDebug & 4) {          // (developer timing variant: the stream of loads only)
+        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(rd_cur.a));
+        rd_cur = rd_n; dat_cur = dat_n;
+        continue;
+      }
       const int pos = (int)rd_cur.pos;
+      const int l = (int)(rd_cur.l_nc & 0xFFFFu);
       const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
       const bool has = nb > 0;
-      uint32_t part = 0;
-      if (has) {
-        part = lane_qsum(dat_cur.q, nb);
-        if (c == 0) part |= ((dat_cur.q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
-      }
-      uint32_t qsum = read_sum(part);
+      uint32_t qsum = read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
       const bool t_noqual = (qsum >> 31) != 0u;
       qsum &= 0x7FFFFFFFu;
-      // ---- keep_read (midas/run/snps.py:141-162): a class-0 read has SEQ, NM and a non-empty aligned part --------------------
-      const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
-      const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
-      const bool t_pid = align_len - (int)rd_cur.nm < min_match;                                            // pid < mapid
-      const bool t_drop = ((int)qsum < rq * l) | ((int)rd_cur.mapq < p.mapq_min) | (align_len < min_align);   // readq, mapq, aln_cov
-      const uint32_t err = (act && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
-      const bool keep = act && !(t_pid | t_noqual | t_drop);
-      const int rel = pos - tile_start;            // 0 <= pos < contig length: no wrap
-      const bool owner = act && rel >= 0 && rel < tile_len;
-      // the one segment: query [lead, lead + align_len) at sites pos ...; this lane's part of it, clipped to the tile
-      const int loc0 = rel + (q0 - lead);
-      int lo = lead - q0;
-      lo = lo > -loc0 ? lo : -loc0;
-      lo = lo > 0 ? lo : 0;
-      int hi = lead + align_len - q0;
-      hi = hi < tile_len - loc0 ? hi : tile_len - loc0;
-      hi = hi < nb ? hi : nb;
-      const bool go = keep && lo < hi;
-      if (__ballot(go) != 0ull) {
-        uint32_t qv[8];
+      const int nm = (int)(rd_cur.nmq & 0xFFFFu), mapq = (int)((rd_cur.nmq >> 16) & 0xFFu);
+      uint32_t qv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
-        tally_range(go, lo, hi, loc0, qv, dat_cur.s);
-      }
-      const bool head = owner && c == 0;
-      w_aligned += (uint32_t)__popcll(__ballot(head));
-      w_mapped += (uint32_t)__popcll(__ballot(head && keep));
-      if (head && err) atomicMin(p.err, ((unsigned long long)(uint32_t)(st.rb + vpos) << 8) | err);
-
-      rd_cur = rd_n;
-      dat_cur = dat_n;
-    }
-
-    // ======================= general reads: descriptors, walked op by op (the few per tile; not pipelined) ===================
-    {
-      const int nb_it = n_iters(st.ng);
-      for (int j = NWAVES - 1 - wave; j < nb_it; j += NWAVES) {      // (dealt from the last wave down: those have fewer range iterations)
-        const int e = j * rpw + g;
-        const bool act = lane_used && e < st.ng;
-        uint4 da = make_uint4(0u, 0u, 0u, 0u), db = da;
-        uint32_t dc = 0;
-        if (act) {
-          const uint4* gd = reinterpret_cast<const uint4*>(p.gdesc) + (size_t)(st.gb + e) * 3;
-          da = gd[0]; db = gd[1]; dc = gd[2].x;
-        }
-        const int l = (int)(da.z & 0xFFFFu), nc = (int)(da.z >> 16);
-        const int pos = (int)da.y;
-        const uint32_t nm16 = da.w & 0xFFFFu, gflags = da.w >> 24;
-        const int mapq = (int)((da.w >> 16) & 0xFFu);
-        const int align_len = (int)(db.x & 0xFFFFu);
-        const uint32_t* cig = p.cigar + ((size_t)db.w | ((size_t)((dc >> 16) & 0xFFu) << 32));
-        const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;
-        const bool has = act && nb > 0;
-        Dat d;
+      for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
+      bool keep, owner;
+      uint32_t err;
+      if (!gen_cur) {
+        // ======================= class 0: one gap-free match segment ============================================================
+        const bool act = !((rd_cur.nmq >> 24) & kGenIdle);
+        const int lead = (int)(rd_cur.a & 1023u);
+        const int align_len = (int)((rd_cur.a >> kInfoAlenShift) & 2047u);
+        // ---- keep_read (midas/run/snps.py:141-162): a class-0 read has SEQ, NM and a non-empty aligned part -----------------
+        const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+        const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+        const bool t_pid = align_len - nm < min_match;                                                       // pid < mapid
+        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);             // readq, mapq, aln_cov
+        err = (act && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
+        keep = act && !(t_pid | t_noqual | t_drop);
+        const int rel = pos - tile_start;            // 0 <= pos < contig length: no wrap
+        owner = act && rel >= 0 && rel < tile_len;
+        // the segment: query [lead, lead + align_len) at sites pos ...; this lane's part of it, clipped to the tile
+        const int loc0 = rel + (q0 - lead);
+        int lo = lead - q0;
+        lo = lo > -loc0 ? lo : -loc0;
+        lo = lo > 0 ? lo : 0;
+        int hi = lead + align_len - q0;
+        hi = hi < tile_len - loc0 ? hi : tile_len - loc0;
+        hi = hi < nb ? hi : nb;
+        const bool go = keep && lo < hi;
+        if (!(kDebug & 1) && __ballot(go) != 0ull) tally_range(go, lo, hi, loc0, qv, dat_cur.s);
+      } else {
+        // ======================= general reads: descriptors, walked op by op =================================================
+        const uint32_t gflags = rd_cur.nmq >> 24;
+        const bool act = !(gflags & kGenIdle);
+        const int nc = (int)(rd_cur.l_nc >> 16);
+        const int align_len = (int)(rd_cur.a & 2047u);
+        const uint32_t* cig = p.cigar + ((size_t)rd_cur.co_lo | ((size_t)((rd_cur.a >> 22) & 0xFFu) << 32));
+        // the CIGAR is not prefetched (it would cost eight registers of the double-buffered bases): only the few iterations at
+        // the end of a tile's stream come here
         uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u;
         if (act && nc > 0) {
           const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // (may overhang into the array's slack)
           cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
         }
-        if (has) load_bases((unsigned long long)db.y | ((unsigned long long)(dc & 0xFFu) << 32),
-                            (unsigned long long)db.z | ((unsigned long long)((dc >> 8) & 0xFFu) << 32), d);
-        uint32_t part = 0;
-        if (has) {
-          part = lane_qsum(d.q, nb);
-          if (c == 0) part |= ((d.q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;
-        }
-        uint32_t qsum = read_sum(part);
-        const bool t_noqual = (qsum >> 31) != 0u;
-        qsum &= 0x7FFFFFFFu;
         // ---- keep_read, every test evaluated, the reference's order decides which outcome wins ---------------------------
         const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
         const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
         const bool t_noseq = l == 0;
         const bool t_nonm = (gflags & kGenNoNm) != 0u;
         const bool t_zero = align_len == 0;
-        const bool t_pid = align_len - (int)nm16 < min_match;
+        const bool t_pid = align_len - nm < min_match;
         const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);
         const bool t_over = (gflags & kGenOverrun) != 0u;
-        uint32_t err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
+        err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
         err = t_drop ? 0u : err;
         err = t_noqual ? (uint32_t)E_NO_QUAL : err;
         err = t_pid ? 0u : err;
@@ -456,18 +452,13 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         err = t_nonm ? (uint32_t)E_NO_NM : err;
         err = t_noseq ? (uint32_t)E_NO_SEQ : err;
         err = act ? err : 0u;
-        const bool keep = act && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
+        keep = act && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
         // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
         int cpos = pos < 0 ? 0 : pos;
         cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-        const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+        owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
         const int rel = pos - tile_start;                                     // may wrap for absurd positions:
         int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // those are parked far right
-
-        uint32_t qv[8];
-        bool walking = keep && has;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : d.q[k];
         // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time ------------------------
         // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative reference
         // position only below 4096, and both only ever grow.
@@ -493,18 +484,26 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
           }
           return false;
         };
+        bool walking = keep && has;
         if (walking) walking = next_segment();
         while (__ballot(walking) != 0ull) {
           const int lo = jlo > -loc0 ? jlo : -loc0;
           const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
-          tally_range(walking && lo < hi, lo, hi, loc0, qv, d.s);
+          tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s);
           walking = (walking && k < nc) ? next_segment() : false;
         }
-        const bool head = owner && c == 0;
-        w_aligned += (uint32_t)__popcll(__ballot(head));
-        w_mapped += (uint32_t)__popcll(__ballot(head && keep));
-        if (head && err) atomicMin(p.err, ((unsigned long long)da.x << 8) | err);
       }
+      // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
+      const bool head = owner && c == 0;
+      w_aligned += (uint32_t)__popcll(__ballot(head));
+      w_mapped += (uint32_t)__popcll(__ballot(head && keep));
+      if (head && err) {     // (the read's index: its place in the range, or the entry's word of gidx)
+        const uint32_t idx = gen_cur ? p.gidx[(size_t)(st.gb + (it - st.na) * rpw + g)] : (uint32_t)(st.rb + it * rpw + g);
+        atomicMin(p.err, ((unsigned long long)idx << 8) | err);
+      }
+
+      rd_cur = rd_n;
+      dat_cur = dat_n;
     }
 
     if (lane == 0) {
@@ -517,25 +516,26 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     const int tn = more ? wn : t;
     const Tile ntile = load_tile(c_tiles, tn);
     const Stream nst = load_stream(tn);
-    const int nit_hi = n_iters(nst.n0);
-    RawA raw_c;
+    Raw raw_c;
     if (more && !xt) {   // (with xt the pipeline already holds the next tile's first two iterations)
-      raw_c = fetch_a(nst, v0);
-      raw_n = fetch_a(nst, v0 + vstep);
+      raw_c = fetch(nst, wave);
+      raw_n = fetch(nst, wave + NWAVES);
+      gen_n = wave + NWAVES >= nst.na;
     }
     lds_barrier();       // every tally of this tile is in LDS
-    if (more && !xt) settle_a(raw_c, rd_cur, dat_cur);
+    if (more && !xt) settle(raw_c, wave >= nst.na, rd_cur, dat_cur);
     uint32_t ticket = 0;
     if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered / total-depth partials ---------------------------
     {
-      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + tile.site_base;
+      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((kDebug & 8) ? 0 : tile.site_base);
       uint4* lds4 = reinterpret_cast<uint4*>(lds);
+      const int lim = (kDebug & 2) ? 0 : tile_len;
 #pragma unroll
       for (int it = 0; it < OUT_IT; ++it) {
         const int i = tid + it * kPileupBlock;
-        if (i < tile_len) {
+        if (i < lim) {
           const uint4 v = lds4[i];
           lds4[i] = make_uint4(0u, 0u, 0u, 0u);
           u32x4_a8 nv; nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         }
       }
     }
-    if (p.out_allele) {
+    if (p.out_allele && !(kDebug & 2)) {
       const uint8_t* ref = p.ref + tile.site_base;
       uint8_t* al = p.out_allele + tile.site_base;
 #pragma unroll
@@ -600,7 +600,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     }
     w = wn;
     t = tn;
-    it_hi = nit_hi;
     tile = ntile;
     st = nst;
   }

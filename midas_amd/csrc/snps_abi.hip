@@ -98,11 +98,13 @@ struct midas_snps_batch {
   int path = MIDAS_SNPS_PATH_DIRECT;   // the path batch_run takes
   int path_auto = MIDAS_SNPS_PATH_DIRECT;   // what the batch's own numbers recommend
   bool packed_built = false;    // rec / blob / orig / key exist (the packed path's layout is built on first use)
-  uint32_t* d_info = nullptr;   // [n_reads] class-0 info words
+  uint8_t* d_info = nullptr;    // [n_reads + 1] 20-byte index records of the direct path (+ slack)
+  uint32_t* d_gidx = nullptr;   // [gdesc_capacity] read index of a general entry
   uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
   uint32_t* d_gcount = nullptr; // [n_tiles + 1]
   uint32_t* d_goff = nullptr;   // [n_tiles + 1]
   uint32_t* d_gen_reads = nullptr;   // [n_reads]
+  uint32_t* d_gen_count = nullptr;   // [classify workgroups]
   uint32_t* d_gdesc = nullptr;  // [gdesc_capacity][kGenDescWords]
   int64_t gdesc_capacity = 0;
   DirectFacts* d_dfacts = nullptr;
@@ -430,7 +432,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gdesc,
+                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_gidx, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gen_count, b->d_gdesc,
                  b->d_dfacts, b->d_dtotals,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
@@ -593,11 +595,11 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->n_reads = (int32_t)b->n_reads;
   ip->contig_read_begin = b->d_contig_read_begin; ip->contig_tile_base = b->d_contig_tile_base; ip->contig_len = b->d_contig_len;
   ip->n_contigs = b->n_contigs; ip->n_tiles = (int32_t)b->n_tiles; ip->tile_shift = kTileShift;
-  ip->info = b->d_info;
+  ip->rec = b->d_info;
   ip->tbegin = trange_begin(b, par); ip->tend = trange_end(b, par);
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
-  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads;
-  ip->gdesc = b->d_gdesc; ip->gdesc_capacity = b->gdesc_capacity;
+  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads; ip->gen_count = b->d_gen_count;
+  ip->gdesc = b->d_gdesc; ip->gidx = b->d_gidx; ip->gdesc_capacity = b->gdesc_capacity;
   ip->n_general_hint = b->direct_run_count > 0 ? (int64_t)b->h_dtotals.n_general : b->n_reads;
   ip->sorted = b->direct_sorted ? 1 : 0;
   ip->reach = b->max_l_seq;
@@ -613,14 +615,16 @@ int32_t direct_prepare(midas_snps_batch* b) {
   hipStream_t s = ctx->stream;
   const size_t n1 = (size_t)(b->n_reads > 0 ? b->n_reads : 1);
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
-  HIP_TRY(ctx, hipMalloc(&b->d_info, n1 * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_info, (n1 + 1) * 20 + 64));
   HIP_TRY(ctx, hipMalloc(&b->d_gen_reads, n1 * 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_gen_count, (size_t)direct_index_blocks(b->n_reads) * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_trange, nt * 4 * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_gcount, (nt + 1) * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_goff, (nt + 1) * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots));
   HIP_TRY(ctx, hipMalloc(&b->d_dtotals, sizeof(DirectTotals)));
-  HIP_TRY(ctx, hipMalloc(&b->d_gdesc, 64));
+  HIP_TRY(ctx, hipMalloc(&b->d_gdesc, 64));      // (room for the sentinel descriptor)
+  HIP_TRY(ctx, hipMalloc(&b->d_gidx, 64));
   // tile bounds start clean (every pass resets the other parity's); counters at zero; status words at "no error"
   HIP_TRY(ctx, hipMemsetAsync(b->d_trange, 0, nt * 16, s));
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 0), 0xFF, nt * 4, s));
@@ -649,7 +653,10 @@ int32_t direct_prepare(midas_snps_batch* b) {
   if (t.n_entries > 0) {
     (void)hipFree(b->d_gdesc);
     b->d_gdesc = nullptr;
-    HIP_TRY(ctx, hipMalloc(&b->d_gdesc, (size_t)t.n_entries * kGenDescWords * 4));
+    HIP_TRY(ctx, hipMalloc(&b->d_gdesc, ((size_t)t.n_entries + 1) * kGenDescWords * 4));
+    (void)hipFree(b->d_gidx);
+    b->d_gidx = nullptr;
+    HIP_TRY(ctx, hipMalloc(&b->d_gidx, (size_t)t.n_entries * 4));
     b->gdesc_capacity = (int64_t)t.n_entries;
   }
   // how well the reads are ordered: a tile's stream holds every read between the first and the last class-0 read touching it
@@ -1085,11 +1092,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     HIP_TRY(ctx, launch_direct_index(dip, s));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     DirectParams dp;
-    dp.pos = b->d_pos; dp.mapq = b->d_mapq; dp.nm = b->d_nm;
-    dp.seq_off = b->d_seq_off; dp.qual_off = b->d_qual_off;
     dp.seq4 = b->d_seq4; dp.qual = b->d_qual; dp.cigar = b->d_cigar;
-    dp.info = b->d_info;
-    dp.tbegin = dip.tbegin; dp.tend = dip.tend; dp.goff = b->d_goff; dp.gdesc = b->d_gdesc;
+    dp.rec = b->d_info;
+    dp.tbegin = dip.tbegin; dp.tend = dip.tend; dp.goff = b->d_goff; dp.gdesc = b->d_gdesc; dp.gidx = b->d_gidx; dp.gdesc_capacity = b->gdesc_capacity;
     dp.ref = b->d_ref;
     dp.tiles = b->d_tiles;
     dp.filt = b->d_filt;

@@ -18,7 +18,19 @@ def main():
     print(ctx.device_info(), flush=True)
     thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
     t0 = time.time()
-    contigs, reads = synth.make_dataset(**synth.CONFIGS[name])
+    cache = os.path.join(os.environ.get('DIRECT_CHECK_CACHE', '/tmp'), 'direct_check_%s.npz' % name)
+    if os.path.exists(cache):        # (several variants in one GPU call: generate once)
+        z = np.load(cache, allow_pickle=True)
+        reads = abi.ReadsSoA(**{k[2:]: z[k] for k in z.files if k.startswith('r_')})
+        contigs = abi.ContigTable(length=z['c_length'], species=z['c_species'], read_begin=z['c_read_begin'], ref=z['c_ref'],
+                                  n_species=int(z['c_n_species']))
+    else:
+        contigs, reads = synth.make_dataset(**synth.CONFIGS[name])
+        try:
+            np.savez(cache, c_length=contigs.length, c_species=contigs.species, c_read_begin=contigs.read_begin, c_ref=contigs.ref,
+                     c_n_species=contigs.n_species, **{'r_' + k: v for k, v in reads.as_dict().items()})
+        except Exception as e:
+            print("cache not written:", e)
     print("dataset %s: %.1f s" % (name, time.time() - t0), flush=True)
     t0 = time.time()
     b = ctx.batch(contigs, reads)
