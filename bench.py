@@ -5,25 +5,32 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full pass of the hot path over one resident batch: the device builds its
-per-tile read index (the index_bam analogue), filters every read (keep_read), walks the
-CIGARs, tallies A/C/G/T per site, emits counts + ref allele and reduces the per-species
-counters.  A second timed region (`value_incl_pack`) puts the device packer in front of every step: from the
-BAM-native arrays resident in HBM (pos, mapq, NM, l_seq, CSR offsets, 4-bit SEQ, QUAL, CIGAR) -- CIGAR -> match
-segments, mean quality by wave reduction, N-mask, tile order (radix sort), records + payload -- to the counts.  With N > 1 a rank's K steps are its share of the job and the job's one exchange -- the
-all-gather of every rank's per-species summary rows over RCCL -- follows them, inside the timed region.  Inputs
-(packed reads, reference letters) are resident in HBM before the timed region starts.
+A "step" is one full pass of the hot path FROM THE BAM-NATIVE ARRAYS resident in HBM (pos, mapq, NM, l_seq, CSR offsets,
+4-bit SEQ, QUAL, CIGAR -- what the BAM decoder hands over) to the per-site counts: the device's index pass (one thread per
+read: validation, CIGAR class, per-tile read ranges -- the index_bam analogue), then the pileup kernel, which reads SEQ /
+QUAL / CIGAR where they are: read filter (keep_read), CIGAR walk, mean-quality reduction, A/C/G/T tallies per site, counts
++ ref allele emission and the per-species counters.  Nothing is sorted, packed or cached between steps.  With N > 1 a rank's
+K steps are its share of the job and the job's one exchange -- the all-gather of every rank's per-species summary rows over
+RCCL -- follows them, inside the timed region.
 
-Workload (default): BASELINE.json configs[2], the largest single-GPU configuration -- 20 species, 80 Mb,
-10 666 667 aligned synthetic 150 bp reads (20x) per GPU (`--config c2` = configs[1]: 1 species, 15 Mb, 1 M reads,
-10x; `--config c4_rank` = one rank's share of configs[3]).  Multi-GPU is species-sharded weak scaling: every rank
-owns its own species (own seed), no data-path collective, one all-gather of [K, n_species, 4] int64 summary rows
-per job.
+Workload (default): BASELINE.json configs[2], the largest single-GPU configuration -- 20 species, 80 Mb, 10 666 667 aligned
+synthetic 150 bp reads (20x) per GPU (`--config c2` = configs[1]; `--config c4_rank` = one rank's share of configs[3]).
+Multi-GPU default is weak scaling: every rank owns its own configs[2]-sized set of species.  `--config c4` is
+BASELINE.json configs[3] itself -- 100 species, 400 Mb, 80 M aligned reads -- dealt to the N ranks contig by contig with the
+product's partitioner (midas_amd.dist.shard_items, the weights of midas_amd/run/snps.py): strong scaling, no data-path
+collective, one all-gather of the summary rows.
+
+Secondary figures in the same JSON line: the step over a resident PACKED batch (`value_resident_packed`: the tile-ordered
+records + one byte per base of pack_reads.hip, built once, outside the region), the device copy rate of this box, the CPU
+baselines, and -- when rocprofv3 is on PATH -- the HBM traffic of the step's kernels measured on this box.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,22 +40,23 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-
 WORKLOADS = {
     "c2": "configs[1]: 1 species rep-genome (60 contigs x 250 kb = 15 Mb), 1M synthetic 150 bp reads at 10x per GPU",
     "c3": "configs[2]: 20 species (320 contigs x 250 kb = 80 Mb), 10 666 667 aligned synthetic 150 bp reads at 20x per GPU",
     "c4_rank": "one rank's share of configs[3]: 13 species (52 Mb), 10.4M aligned synthetic 150 bp reads at 30x",
+    "c4": "configs[3]: 100 species (1600 contigs x 250 kb = 400 Mb), 80M aligned synthetic 150 bp reads (30x on average, "
+          "log-normal abundances), contig-sharded over the ranks by midas_amd.dist.shard_items",
 }
+STEP_KERNELS = ["direct_classify_kernel", "direct_scan_kernel", "direct_fill_kernel", "pileup_direct_kernel"]
 
 
-def load_pmc_traffic(kernel, workload):
-    """(HBM bytes per launch of the dominant kernel, where the figure comes from) -- PMC counters cannot be read
-    inside a plain run, so the figure is the one of the committed rocprofv3 --pmc passes of this same command."""
+def load_pmc_traffic(key, workload):
+    """(HBM bytes per launch, where the figure comes from): the committed rocprofv3 --pmc passes of this same command."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        e = d.get(workload, {}).get(kernel)
+        e = d.get(workload, {}).get(key)
         if not e:
             return None, None
         return float(e["hbm_bytes_per_launch"]), "committed profile: %s" % e.get("source", "profiles/pmc_traffic.json")
@@ -77,8 +85,6 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
            "sample": "%d pass(es) of the full workload (%d sites, %d reads) through oracle/pileup_oracle.c, %.1f s"
                      % (passes, contigs.n_sites, reads.n_reads, el),
            "host_hardware_threads": os.cpu_count(), "host_cpu_budget": utility.cpu_budget()}
-    # all the CPUs this process may use: the hardware threads, or the cgroup's quota when that is less (a container that
-    # shows 256 threads under a 16-CPU quota gets 16 CPUs' worth of work per second however many threads it starts)
     ncpu = utility.cpu_budget()
     more = []
     for grain, workers in (("contig", min(ncpu, contigs.n_contigs)), ("species", min(ncpu, contigs.n_species))):
@@ -97,22 +103,6 @@ def cpu_baseline(thr, contigs, reads, min_seconds):
                      "host_hardware_threads": os.cpu_count(), "host_cpu_budget": ncpu,
                      "sample": "%d pass(es) of the full workload over %d threads, %.1f s" % (passes, workers, el)})
     return one, more[0], more[1], out
-
-
-def copy_ceiling_gbps(torch, nbytes=1 << 30, reps=10):
-    """What a plain device-to-device copy reaches on THIS box right now (bytes read + bytes written per second): the
-    practical HBM ceiling the guide quotes as ~6.3 TB/s, measured live because boxes of the pool differ by a few percent."""
-    src = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").random_()
-    dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def python_shaped_estimate(contigs, reads, args, max_sites=250000):
@@ -136,19 +126,105 @@ def python_shaped_estimate(contigs, reads, args, max_sites=250000):
             "sample": "first contig (%d sites, %d reads), Python per-read/per-site loops + gzip-9" % (length, n)}
 
 
+# ---- HBM traffic of the step's kernels on THIS box: rocprofv3 --pmc around a child that runs a few steps ----------------------
+def save_dataset(path, contigs, reads):
+    np.savez(path, c_length=contigs.length, c_species=contigs.species, c_read_begin=contigs.read_begin, c_ref=contigs.ref,
+             c_n_species=contigs.n_species, **{"r_" + k: v for k, v in reads.as_dict().items()})
+
+
+def load_dataset(path):
+    from midas_amd import abi
+    z = np.load(path)
+    reads = abi.ReadsSoA(**{k[2:]: z[k] for k in z.files if k.startswith("r_")})
+    contigs = abi.ContigTable(length=z["c_length"], species=z["c_species"], read_begin=z["c_read_begin"], ref=z["c_ref"],
+                              n_species=int(z["c_n_species"]))
+    return contigs, reads
+
+
+def pmc_child(path, steps):
+    """(run under rocprofv3 by measure_traffic) a few steps over the saved dataset, nothing else."""
+    from midas_amd import abi
+    contigs, reads = load_dataset(path)
+    ctx = abi.Context(0)
+    b = ctx.batch(contigs, reads)
+    thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
+    for _ in range(steps):
+        b.run(thr)
+    b.sync()
+    b.close()
+    ctx.close()
+
+
+def measure_traffic(contigs, reads, steps=6):
+    """FETCH_SIZE / WRITE_SIZE of the step's kernels, separate rocprofv3 --pmc passes with --kernel-trace only, corrected as
+    MI355X_MICROARCH.md prescribes (KiB * 1024; FETCH_SIZE doubled on gfx950).  Returns a dict or None."""
+    import sqlite3
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    tmp = tempfile.mkdtemp(prefix="midas_pmc_", dir="/tmp")
+    try:
+        data = os.path.join(tmp, "dataset.npz")
+        save_dataset(data, contigs, reads)
+        per = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", data, "--steps", str(steps)]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
+            if res.returncode != 0 or not dbs:
+                return {"error": "rocprofv3 --pmc %s failed (rc %d)" % (counter, res.returncode)}
+            cur = sqlite3.connect(dbs[0]).cursor()
+            q = "select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name"
+            rows_ = list(cur.execute(q, (counter,)))
+            sorted_variant = any("direct_classify_kernel<true>" in r[0] for r in rows_)
+            for name, v, n in rows_:
+                if sorted_variant and "direct_classify_kernel<false>" in name:
+                    continue        # (the batch's creation runs the classify kernel's atomic variant once: not part of a step)
+                for k in STEP_KERNELS:
+                    if k in name:
+                        e = per.setdefault(k, {})
+                        e[counter] = float(v)
+                        e[counter + "_launches"] = int(n)
+        total_r = total_w = 0.0
+        for k, e in per.items():
+            rd = e.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+            wr = e.get("WRITE_SIZE", 0.0) * 1024.0
+            e["hbm_read_bytes_corrected"] = rd
+            e["hbm_write_bytes"] = wr
+            total_r += rd
+            total_w += wr
+        return {"per_kernel": per, "hbm_bytes_per_step": total_r + total_w, "hbm_read_bytes": total_r, "hbm_write_bytes": total_w,
+                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this box; bytes = KiB*1024, "
+                          "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads; narrow column loads are "
+                          "over-corrected by that), WRITE_SIZE uncorrected"}
+    except Exception as e:  # a courtesy measurement: never fail the bench on it
+        return {"error": str(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c3", help="workload from midas_amd.synth.CONFIGS (default c3 = BASELINE configs[2], "
-                                                  "the largest single-GPU configuration; c2 = configs[1])")
+    ap.add_argument("--config", default="c3", help="workload (default c3 = BASELINE configs[2], the largest single-GPU "
+                                                  "configuration; c2 = configs[1]; c4 = configs[3] sharded over the ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pack-steps", type=int, default=20, help="steps of the second region (device packer + step)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 traffic measurement")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="untimed back-to-back steps in front of the timed region (the driver's GPU-busy sampler sees them)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the summary all-gather even with one rank (exercises the N>1 step on a 1-GPU box)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.pmc_child:
+        pmc_child(a.pmc_child, a.steps)
+        return
 
     import torch
     import torch.distributed as dist
@@ -174,21 +250,25 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = dict(synth.CONFIGS[a.config])
-    cfg["seed"] = cfg["seed"] + 1000 * rank       # every rank owns different species (weak scaling)
-    contigs, reads = synth.make_dataset(**cfg)
+    share = None
+    if a.config == "c4":        # configs[3]: this rank's contigs of the one 400 Mb sample (strong scaling)
+        contigs, reads, share = synth.c4_share(rank, world)
+    else:
+        cfg = dict(synth.CONFIGS[a.config])
+        cfg["seed"] = cfg["seed"] + 1000 * rank       # every rank owns different species (weak scaling)
+        contigs, reads = synth.make_dataset(**cfg)
     args = dict(abi.DEFAULT_ARGS)
     thr = abi.Thresholds.from_args(args)
 
     ctx = abi.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)           # launch on torch's stream: torch events / RCCL see the kernels
-    batch = ctx.batch(contigs, reads)
+    batch = ctx.batch(contigs, reads)            # uploads the BAM-native arrays as they are; picks the path
     info = batch.info()
     n_sp = contigs.n_species
-    # N > 1: a rank's K steps are its share of the job (K species batches); the job's one exchange -- the all-gather of
-    # every rank's summary rows, what snps_summary needs to write summary.txt -- follows the last step, inside the timed
-    # region, exactly as midas_amd/run/snps.py does it (all of a rank's species, then one all-gather).
+    # N > 1: a rank's K steps are its share of the job; the job's one exchange -- the all-gather of every rank's summary
+    # rows, what snps_summary needs to write summary.txt -- follows the last step, inside the timed region, exactly as
+    # midas_amd/run/snps.py does it (all of a rank's contigs, then one all-gather).
     rows = torch.zeros((max(a.steps, a.warmup, 1), n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
     gathered = torch.zeros((world,) + tuple(rows.shape), dtype=torch.int64, device="cuda") if collective else None
 
@@ -200,16 +280,19 @@ def main():
         if collective and n > 0:
             dist.all_gather_into_tensor(gathered, rows)
 
-    # warm-up runs are timed with all three events (index kernel, pileup kernel); the timed region records only the two
-    # around the pileup kernel, whose average feeds `roofline` -- every event record takes ~4 us of stream time
-    if a.warmup > 0:
-        batch.enable_timing(a.warmup)
     job(a.warmup)
     batch.sync()
+    # sustain: the same step, back to back, untimed -- the timed region below is a few dozen milliseconds, too short for a
+    # once-a-second GPU-busy sampler to notice
+    sustain_steps = 0
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < a.sustain_seconds:
+        for _ in range(50):
+            batch.run(thr)
+        batch.sync()
+        sustain_steps += 50
     torch.cuda.synchronize()
-    index_ms = float(np.median([batch.timing(i)["index_ms"] for i in range(a.warmup)])) if a.warmup > 0 else None
-    batch.enable_timing(a.steps)
-    batch.time_pileup_only(True)
+    batch.enable_timing(a.steps)                 # HIP events on the step's stream: before the index pass, between it and the
     if collective:      # RCCL builds its communicator and channels on first use: never inside the timed region
         dist.all_gather_into_tensor(gathered, rows)
     if world > 1:
@@ -222,102 +305,128 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     batch.sync()   # surfaces MIDAS_SNPS_ERR_READ_* of the last run, if any
-    if collective:      # the gathered table holds this rank's rows where they belong
-        if not torch.equal(gathered[rank], rows):
-            sys.exit("bench.py: all-gathered summary rows differ from this rank's rows")
+    if collective and not torch.equal(gathered[rank], rows):      # the gathered table holds this rank's rows where they belong
+        sys.exit("bench.py: all-gathered summary rows differ from this rank's rows")
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     sites = torch.tensor([float(info.n_sites)], dtype=torch.float64, device="cuda")
+    el_all = None
     if collective:
+        el_all = torch.zeros(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(el_all, el)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(sites, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     total_sites = float(sites.item())
 
     tm = [batch.timing(i) for i in range(a.steps)]
+    index_ms = float(np.mean([t["index_ms"] for t in tm]))
     pile_ms = float(np.mean([t["pileup_ms"] for t in tm]))
-    run_ms = pile_ms + index_ms if index_ms is not None else None
+    step_kernels_ms = index_ms + pile_ms
+    path = abi.PATH_NAMES[info.path]
 
-    # ---- second region: the device packer in front of every step (raw BAM-native arrays resident in HBM -> counts) ----
-    kp = max(1, min(a.steps, a.pack_steps))
-    batch.enable_timing(kp)
-    batch.time_pileup_only(True)
-    batch.pack()
-    batch.run(thr)
-    batch.sync()
-    batch.enable_timing(kp)
-    batch.time_pileup_only(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(kp):
-        batch.pack()
-        batch.run(thr)
-    torch.cuda.synchronize()
-    elapsed_pack = time.perf_counter() - t0
-    batch.sync()
-    ptm = [batch.pack_timing(i) for i in range(kp)]
-    pack_ms = float(np.mean([t["pack_ms"] for t in ptm]))
-    scatter_ms = float(np.mean([t["scatter_ms"] for t in ptm]))
-    elp = torch.tensor([elapsed_pack], dtype=torch.float64, device="cuda")
-    if collective:
-        dist.all_reduce(elp, op=dist.ReduceOp.MAX)
-    elapsed_pack = float(elp.item())
+    # ---- secondary region: the step over a resident PACKED batch (the layout is built once, outside the region) ----------
+    packed = None
+    if world == 1:
+        try:
+            batch.select_path(abi.PATH_PACKED)
+            kp = max(1, a.steps)
+            for _ in range(3):
+                batch.run(thr)
+            batch.sync()
+            batch.enable_timing(kp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kp):
+                batch.run(thr)
+            torch.cuda.synchronize()
+            el_p = time.perf_counter() - t0
+            batch.sync()
+            ptm = [batch.timing(i) for i in range(kp)]
+            p_idx = float(np.mean([t["index_ms"] for t in ptm]))
+            p_pil = float(np.mean([t["pileup_ms"] for t in ptm]))
+            packed = {"value": info.n_sites * kp / el_p, "ms_per_step": el_p / kp * 1e3, "steps": kp,
+                      "index_kernel_ms": p_idx, "pileup_tiles_kernel_ms": p_pil,
+                      "pileup_tiles_kernel_achieved_GBps": info.algorithmic_bytes / (p_pil * 1e-3) / 1e9,
+                      "note": "index + pileup over the packed records and one-byte-per-base payload of pack_reads.hip, which is "
+                              "built ONCE outside this region (3.3 ms per pack on this workload): not the path's figure"}
+        finally:
+            batch.select_path(abi.PATH_AUTO)
 
     out = None
     if rank == 0:
-        kernel = "pileup_tiles_kernel"
-        achieved = info.algorithmic_bytes / (pile_ms * 1e-3) / 1e9
-        traffic, traffic_src = load_pmc_traffic(kernel, a.config)
+        achieved = info.algorithmic_bytes / (step_kernels_ms * 1e-3) / 1e9
+        pile_ach = info.algorithmic_bytes / (pile_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_pmc_traffic("direct_step" if path == "direct" else "pileup_tiles_kernel", a.config)
         out = {
             "metric": "genomic sites/sec pileup+allele-count",
             "value": total_sites * a.steps / elapsed,
             "unit": "sites/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.config == "c4" else "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer tallies (fp64 only in the two keep_read ratio tests)",
             "data": "synthetic (seeded generator midas_amd/synth.py; SURVEY 8d distributions)",
             "config": {"workload": WORKLOADS.get(a.config, a.config),
+                       "step": "BAM-native arrays resident in HBM -> per-site counts, alleles and per-species counters "
+                               "(device index pass + pileup kernel; path: %s)" % path,
                        "sites_per_gpu": int(info.n_sites), "reads_per_gpu": int(info.n_reads),
-                       "thresholds": args, "parallelism": "species-sharded x%d, one RCCL all-gather of the summary rows per job" % world
+                       "thresholds": args,
+                       "parallelism": ("contig-sharded x%d (dist.shard_items), " % world if a.config == "c4" else
+                                       "species-sharded x%d, " % world) + "one RCCL all-gather of the summary rows per job"
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm",
+                         "kernel": "the step's kernels: direct_classify_kernel + direct_scan_kernel + direct_fill_kernel (index "
+                                   "pass) + pileup_direct_kernel" if path == "direct" else "index_reads_kernel + pileup_tiles_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(info.algorithmic_bytes),
-                         "kernel_ms_avg": pile_ms, "index_kernel_ms_warmup_median": index_ms, "kernels_ms_per_step": run_ms,
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+                         "kernels_ms_avg": step_kernels_ms, "index_pass_ms_avg": index_ms, "pileup_kernel_ms_avg": pile_ms,
+                         "timing": "HIP events on the step's stream around the index pass and around the pileup kernel, every "
+                                   "timed step",
+                         "dominant_kernel": {"name": "pileup_direct_kernel" if path == "direct" else "pileup_tiles_kernel",
+                                             "ms_avg": pile_ms, "achieved": pile_ach, "frac": pile_ach / HBM_PEAK_GBPS}},
+            "sustain": {"steps": sustain_steps, "seconds": a.sustain_seconds,
+                        "note": "untimed back-to-back steps in front of the timed region (same work)"},
+            "path": {"taken": path, "general_reads": int(info.direct_general_reads),
+                     "general_entries": int(info.direct_general_entries), "stream_reads": int(info.direct_stream_reads),
+                     "lanes_per_read": int(info.lanes_per_read), "lane_bases": int(info.lane_bases)},
         }
+        if share is not None:
+            out["config"]["sharding"] = {"items": share["n_items"], "imbalance_max_over_mean": share["imbalance"],
+                                         "total_sites": share["total_sites"], "total_reads": share["total_reads"]}
+        if el_all is not None:
+            per = [float(x) / a.steps * 1e3 for x in el_all.cpu().tolist()]
+            out["per_rank_ms_per_step"] = per
+            out["rank_time_max_over_mean"] = max(per) / (sum(per) / len(per))
+        if packed is not None:
+            out["value_resident_packed"] = packed["value"]
+            out["resident_packed"] = packed
         if world == 1:
-            try:      # the practical ceiling of this box, measured the same minute
-                ceil = copy_ceiling_gbps(torch)
+            try:      # the practical ceiling of this box: the library's own 16-bytes-per-lane copy kernel, the same minute
+                ceil = ctx.copy_rate(1 << 30, 10)
                 out["roofline"]["copy_ceiling_GBps_this_box"] = ceil
+                out["roofline"]["copy_ceiling_method"] = "midas_snps_copy_rate: 10 passes of a 16-bytes-per-lane copy kernel over 1 GiB"
                 out["roofline"]["frac_of_copy_ceiling_this_box"] = achieved / ceil
-                if traffic:
-                    out["roofline"]["hbm_traffic_GBps"] = traffic / (pile_ms * 1e-3) / 1e9
-                    out["roofline"]["hbm_traffic_frac_of_copy_ceiling_this_box"] = traffic / (pile_ms * 1e-3) / 1e9 / ceil
             except Exception as e:
                 out["roofline"]["copy_ceiling_error"] = str(e)
-        # pack + index + pileup from the resident raw arrays; the packer's dominant kernel reads the raw read
-        # (SURVEY 8d's per-read figure) and writes its records + payload
-        read_alg = int(info.algorithmic_bytes) - 17 * int(info.n_sites)
-        pack_alg = read_alg + int(info.packed_bytes)
-        pack_ach = pack_alg / (scatter_ms * 1e-3) / 1e9
-        out["value_incl_pack"] = total_sites * kp / elapsed_pack
-        out["ms_per_step_incl_pack"] = elapsed_pack / kp * 1e3
-        out["steps_incl_pack"] = kp
-        pack_traffic, pack_traffic_src = load_pmc_traffic("pack_scatter_kernel", a.config)
-        out["roofline_pack"] = {"bound": "hbm", "kernel": "pack_scatter_kernel", "achieved": pack_ach, "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": pack_ach / HBM_PEAK_GBPS, "traffic": pack_traffic,
-                                "traffic_source": pack_traffic_src,
-                                "algorithmic_bytes_per_launch": pack_alg,
-                                "algorithmic_bytes_note": "raw reads in (sum(ceil(l/2) + l + 4*n_cigar + 16)) + records and payload out",
-                                "kernel_ms_avg": scatter_ms, "pack_ms_avg_all_kernels": pack_ms}
+            if not a.no_pmc:
+                live = measure_traffic(contigs, reads)
+                if live is not None:
+                    out["roofline"]["traffic_this_box"] = live
+                    if live.get("hbm_bytes_per_step"):
+                        out["roofline"]["traffic"] = live["hbm_bytes_per_step"]
+                        out["roofline"]["traffic_source"] = "rocprofv3 --pmc on this box (roofline.traffic_this_box)"
+                        out["roofline"]["traffic_over_algorithmic"] = live["hbm_bytes_per_step"] / info.algorithmic_bytes
+                        if "copy_ceiling_GBps_this_box" in out["roofline"]:
+                            out["roofline"]["hbm_traffic_frac_of_copy_ceiling_this_box"] = \
+                                live["hbm_bytes_per_step"] / (step_kernels_ms * 1e-3) / 1e9 / out["roofline"]["copy_ceiling_GBps_this_box"]
         if world == 1 and not a.no_cpu:
             cb, cb_all, cb_species, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
             out["cpu_baseline"] = cb
             out["cpu_baseline_all_cores"] = cb_all
             out["cpu_baseline_reference_grain"] = cb_species
+            batch.run(thr)
             counts, allele, stats = batch.fetch()
             st, _, oc, oa, os_ = ref
             out["parity_vs_oracle"] = bool(st == 0 and np.array_equal(counts, oc) and np.array_equal(allele, oa)

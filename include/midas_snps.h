@@ -148,6 +148,11 @@ int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream);
 /* Device facts for logs: name (<=255 chars), compute units, HBM bytes. */
 int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes);
 
+/* What a plain device-to-device copy reaches on this device right now, in GB/s (bytes read + bytes written per second):
+ * `reps` passes of the library's own 16-bytes-per-lane copy kernel over `bytes` (>= 1 MiB), timed with HIP events.  The
+ * practical HBM ceiling the roofline fractions of bench.py are also held against (measurement aid; no reference counterpart). */
+int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, double* out_gbps);
+
 /* Page-locked host memory (hipHostMalloc).  Optional: every entry point takes ordinary memory; result buffers that come
  * from here are filled by one DMA instead of through the context's staging ring, and a caller that keeps them for the
  * lifetime of its context pays the pinning once.  NULL when no device / out of memory.                            */

@@ -223,6 +223,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_pack': (i32, [vp]),
         'midas_snps_batch_select_path': (i32, [vp, i32]),
         'midas_snps_set_default_path': (i32, [vp, i32]),
+        'midas_snps_copy_rate': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
         'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
         'midas_snps_batch_pack_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
         'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
@@ -279,7 +280,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
-    'midas_snps_batch_select_path', 'midas_snps_set_default_path',
+    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
@@ -695,6 +696,12 @@ class Context:
     def set_default_path(self, path: int):
         """The path of every batch created on this context from now on (PATH_AUTO: each batch's own choice)."""
         self._check(self._lib.midas_snps_set_default_path(self._h, int(path)))
+
+    def copy_rate(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
+        """GB/s (read + written) of a device-to-device copy with the library's 16-bytes-per-lane copy kernel."""
+        out = C.c_double(0.0)
+        self._check(self._lib.midas_snps_copy_rate(self._h, int(nbytes), int(reps), C.byref(out)))
+        return out.value
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
     for (int d = 32; d >= 1; d >>= 1) {
       alg += __shfl_down(alg, d);
       ent += __shfl_down(ent, d);
-      ngen += __shfl_down(ngen, d);
+      ngen += __shfl_down(ngen, d);   // (every slot holds the general reads of the workgroups that use it)
       const unsigned long long o = __shfl_down(mx, d);
       mx = o > mx ? o : mx;
       uns |= __shfl_down(uns, d);
@@ -445,12 +445,12 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
       p.totals->status = f->status;
       p.totals->alg_bytes = alg;
       p.totals->n_entries = ent;
-      p.totals->n_general = f->n_general;
+      p.totals->n_general = (uint32_t)ngen;
       p.totals->max_l = (uint32_t)mx;
       p.totals->unsorted = (uint32_t)uns;
       f->status = kNoError;
-      f->n_general = 0u;
     }
+    f->n_general = 0u;
     f->alg_bytes = 0ull;
     f->n_entries = 0ull;
     f->max_l = 0u;

@@ -196,8 +196,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
   const uint32_t one = 1u;
-  const uint8_t* const q_lane = p.qual + q0;            // (one 64-bit addition per pointer and read)
-  const uint8_t* const s_lane = p.seq4 + (q0 >> 1);
 
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
@@ -318,8 +316,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       so = (unsigned long long)f.a.w | ((unsigned long long)(f.a.z >> 24) << 32);
     }
     const bool has = q0 < l && !(kDebug & 128);
-    const uint8_t* qp = has ? q_lane + qo : p.qual;
-    const uint8_t* sp = has ? s_lane + so : p.seq4;
+    const uint8_t* qp = p.qual + (has ? qo + (unsigned long long)q0 : 0ull);
+    const uint8_t* sp = p.seq4 + (has ? so + (unsigned long long)(q0 >> 1) : 0ull);
     const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
     const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
     const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
@@ -340,7 +338,8 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   }
   __syncthreads();   // LDS zeroed, tables in place
 
-  unsigned long long acc_cov = 0ull, acc_depth = 0ull;
+  uint32_t acc_cov = 0u;                 // (a thread's sites between two flushes: far below 2^32)
+  unsigned long long acc_depth = 0ull;
   int t = w;
   for (;;) {
     const int tile_len = tile.len;
@@ -348,15 +347,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
     constexpr int REF_IT = TILE / (4 * kPileupBlock);
-    uint32_t refw[REF_IT];
-    if (p.out_allele) {
-      const uint8_t* ref = p.ref + tile.site_base;
-#pragma unroll
-      for (int it = 0; it < REF_IT; ++it) {
-        const int i = 4 * (tid + it * kPileupBlock);
-        if (i + 4 <= tile_len) refw[it] = *reinterpret_cast<const u32_a1*>(ref + i);
-      }
-    }
 
     // the record / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
     // the records of its first two iterations of the NEXT tile
@@ -506,6 +496,17 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       dat_cur = dat_n;
     }
 
+    // the tile's reference letters: requested here, behind the stream loop (two registers less in it), they arrive while
+    // the workgroup waits for its last wave and writes the counts out
+    uint32_t refw[REF_IT];
+    if (p.out_allele) {
+      const uint8_t* ref = p.ref + tile.site_base;
+#pragma unroll
+      for (int it = 0; it < REF_IT; ++it) {
+        const int i = 4 * (tid + it * kPileupBlock);
+        if (i + 4 <= tile_len) refw[it] = *reinterpret_cast<const u32_a1*>(ref + i);
+      }
+    }
     if (lane == 0) {
       if (w_aligned) atomicAdd(&s_stats[MIDAS_STAT_ALIGNED], (unsigned long long)w_aligned);
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
           u32x4_a8 nv; nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
           __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_a8*>(out + i));
           const uint32_t d = v.x + v.y + v.z + v.w;
-          acc_cov += d > 0u ? 1ull : 0ull;
+          acc_cov += d > 0u ? 1u : 0u;
           acc_depth += d;
         }
       }
@@ -577,10 +578,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         acc_depth += __shfl_down(acc_depth, d);
       }
       if (lane == 0) {
-        if (acc_cov) atomicAdd(&s_stats[MIDAS_STAT_COVERED], acc_cov);
+        if (acc_cov) atomicAdd(&s_stats[MIDAS_STAT_COVERED], (unsigned long long)acc_cov);
         if (acc_depth) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], acc_depth);
       }
-      acc_cov = 0ull;
+      acc_cov = 0u;
       acc_depth = 0ull;
       lds_barrier();
       if (tid < MIDAS_STATS) {

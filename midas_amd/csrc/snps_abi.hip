@@ -388,6 +388,37 @@ int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream) {
   return MIDAS_SNPS_OK;
 }
 
+// Device-to-device copy rate of THIS device, with the library's own copy kernel (16 bytes per lane, streaming stores): the
+// practical HBM ceiling a roofline fraction can be held against (the guide's 6.29 TB/s figure comes from such a kernel).
+int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, double* out_gbps) {
+  if (!ctx || !out_gbps || bytes < (1 << 20) || reps < 1) return MIDAS_SNPS_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n16 = (size_t)bytes / 16;
+  copy_u32x4 *src = nullptr, *dst = nullptr;
+  HIP_TRY(ctx, hipMalloc(&src, n16 * 16));
+  if (hipMalloc(&dst, n16 * 16) != hipSuccess) { (void)hipFree(src); return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "copy_rate: out of device memory"); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t s = ctx->stream;
+  int32_t st = MIDAS_SNPS_OK;
+  float ms = 0.f;
+  const int grid = ctx->prop.multiProcessorCount * 16;
+  if (hipMemsetAsync(src, 0x5A, n16 * 16, s) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) st = MIDAS_SNPS_ERR_HIP;
+  if (st == MIDAS_SNPS_OK) {
+    for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, s, dst, src, n16);
+    (void)hipEventRecord(e0, s);
+    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, s, dst, src, n16);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) st = MIDAS_SNPS_ERR_HIP;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  if (st != MIDAS_SNPS_OK) { (void)hipGetLastError(); return fail(ctx, st, "copy_rate: HIP runtime error"); }
+  *out_gbps = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+  return MIDAS_SNPS_OK;
+}
+
 int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path) {
   if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
   ctx->default_path = path;

@@ -208,6 +208,95 @@ CONFIGS = {
 }
 
 
+# ---- BASELINE.json configs[3]: 100 species x 16 contigs x 250 kb = 400 Mb, 80 M aligned 150 bp reads (30x on average), dealt
+# to the ranks CONTIG BY CONTIG with the product's own partitioner (dist.shard_items, the weights of run/snps.py).
+C4 = dict(n_species=100, contigs_per_species=16, contig_len=250000, total_reads=80_000_000, read_len=150, seed=BASE_SEED + 5)
+
+
+def c4_items(n_species=None, contigs_per_species=None, contig_len=None, total_reads=None, read_len=None, seed=None, sigma=0.5):
+    """The contigs of the configs[3] sample: [(species, contig_in_species, n_reads)], abundances log-normal over the species
+    (a metagenome is not flat), reads spread evenly over a species' contigs.  Deterministic in `seed`."""
+    a = dict(C4)
+    for k, v in dict(n_species=n_species, contigs_per_species=contigs_per_species, contig_len=contig_len, total_reads=total_reads,
+                     read_len=read_len, seed=seed).items():
+        if v is not None:
+            a[k] = v
+    rng = np.random.default_rng(a['seed'])
+    ab = rng.lognormal(0.0, sigma, a['n_species'])
+    per_contig = np.maximum(1, np.floor(ab / ab.sum() * a['total_reads'] / a['contigs_per_species'])).astype(np.int64)
+    items = [(s, k, int(per_contig[s])) for s in range(a['n_species']) for k in range(a['contigs_per_species'])]
+    return items, a
+
+
+def c4_weights(items, a):
+    """The LPT weights midas_amd/run/snps.py uses: 1.6 B per aligned base + 17 B per site (SURVEY 8d's figures)."""
+    return {(s, k): 1.6 * a['read_len'] * n + 17.0 * a['contig_len'] for s, k, n in items}
+
+
+def _take_reads(reads: ReadsSoA, sel: np.ndarray) -> dict:
+    """Rows `sel` (increasing) of a ReadsSoA as a dict of arrays with rebased offsets."""
+    def gather(data, off):
+        lens = (off[1:] - off[:-1])[sel]
+        new_off = np.zeros(sel.size + 1, dtype=np.int64)
+        np.cumsum(lens, out=new_off[1:])
+        ix = np.repeat(off[:-1][sel] - new_off[:-1], lens) + np.arange(int(new_off[-1]), dtype=np.int64)
+        return data[ix], new_off
+    d = {k: getattr(reads, k)[sel] for k in ('pos', 'mapq', 'flag', 'nm', 'l_seq')}
+    d['seq4'], d['seq_off'] = gather(reads.seq4, reads.seq_off)
+    d['qual'], d['qual_off'] = gather(reads.qual, reads.qual_off)
+    d['cigar'], d['cigar_off'] = gather(reads.cigar, reads.cigar_off)
+    return d
+
+
+def c4_share(rank: int, world: int, **kw):
+    """-> (ContigTable, ReadsSoA, facts) of the contigs rank `rank` of `world` owns.  Every contig table carries all the
+    species (n_species rows of counters on every rank, as the summary all-gather wants them).  A species' contigs share one
+    reference sequence and draw their reads -- each its own random subset, in position order -- from one pool of reads
+    generated against it: sixteen times cheaper to generate than sixteen contigs, and the partitioner, the pileup, the
+    per-species counters and the concatenation of the parts do not care."""
+    from . import dist
+    items, a = c4_items(**kw)
+    w = c4_weights(items, a)
+    owner = dist.shard_items(w, world)
+    mine = [(s, k, n) for s, k, n in items if owner[(s, k)] == rank]
+    loads = [sum(w[(s, k)] for s, k, n in items if owner[(s, k)] == r) for r in range(world)]
+    lengths, species, ids, refs, parts, rb = [], [], [], [], [], [0]
+    pool_of = {}
+    for s, k, n in mine:
+        if s not in pool_of:
+            pc, pr = make_dataset(n_species=1, contigs_per_species=1, contig_len=a['contig_len'], n_reads=int(n * 1.25) + 16,
+                                  read_len=a['read_len'], seed=a['seed'] + 7919 * (s + 1))
+            pool_of = {s: (pc, pr)}          # (one species at a time: items come species by species)
+        pc, pr = pool_of[s]
+        sel = np.sort(np.random.default_rng(a['seed'] + 104729 * (s + 1) + k).choice(pr.n_reads, size=n, replace=False))
+        parts.append(_take_reads(pr, sel))
+        lengths.append(a['contig_len']); species.append(s); ids.append("Species_%05d_c%d" % (s + 1, k + 1)); refs.append(pc.ref)
+        rb.append(rb[-1] + n)
+    def cat(key, off_key=None):
+        if not parts:
+            return np.zeros(0, dtype=_DT[key])
+        return np.concatenate([p[key] for p in parts])
+    def cat_off(key):
+        out = [np.zeros(1, dtype=np.int64)]
+        base = 0
+        for p in parts:
+            out.append(p[key][1:] + base)
+            base += int(p[key][-1])
+        return np.concatenate(out)
+    reads = ReadsSoA(pos=cat('pos'), mapq=cat('mapq'), flag=cat('flag'), nm=cat('nm'), l_seq=cat('l_seq'),
+                     seq_off=cat_off('seq_off'), qual_off=cat_off('qual_off'), cigar_off=cat_off('cigar_off'),
+                     seq4=cat('seq4'), qual=cat('qual'), cigar=cat('cigar'))
+    contigs = ContigTable(length=np.array(lengths, dtype=np.int64), species=np.array(species, dtype=np.int32),
+                          read_begin=np.array(rb, dtype=np.int64), ref=np.concatenate(refs) if refs else np.zeros(0, np.uint8),
+                          n_species=a['n_species'], ids=ids, species_ids=["Species_%05d" % (s + 1) for s in range(a['n_species'])])
+    facts = dict(n_items=len(items), my_items=len(mine), loads=loads, imbalance=max(loads) / (sum(loads) / world),
+                 total_sites=a['n_species'] * a['contigs_per_species'] * a['contig_len'], total_reads=sum(n for _, _, n in items))
+    return contigs, reads, facts
+
+
+_DT = dict(pos=np.int32, mapq=np.uint8, flag=np.uint16, nm=np.int32, l_seq=np.int32, seq4=np.uint8, qual=np.uint8, cigar=np.uint32)
+
+
 def write_sample(outdir, db_dir, contigs, reads, line_width=60, gz_fasta=False):
     """Lay a synthetic dataset out on disk the way `run_midas.py snps --build_db --align` would leave it:
     a minimal MIDAS DB (rep_genomes/<sp>/genome.fna + the files utility.check_database wants) and
