@@ -155,6 +155,39 @@ __device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t*
   if (pred) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// What the pileup kernel needs of a general read besides its columns: the clip lengths by pysam's rules and the one case in
+// which count_coverage raises IndexError for a kept read (a match op maps a query position >= l_seq onto a site inside the contig).
+__device__ void general_facts(const Fields& f, const CigarView& cg, uint32_t nc, long long clen, GenDesc* d) {
+  // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
+  long long qs = 0, qe = 0;
+  query_bounds(cg, nc, f.l, &qs, &qe);
+  long long al = qe - qs;
+  al = al < 0 ? 0 : al;
+  d->align_len = (uint32_t)(al > 2047 ? 2047 : al);      // (l_seq <= 1024)
+  d->lead = (uint32_t)(qs > 2047 ? 2047 : qs);
+  uint32_t flags = f.nm < 0 ? kGenNoNm : 0u;
+  long long qpos = 0, rpos = f.pos;
+  for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
+    const uint32_t op = v & 15u;
+    const long long len = (long long)(v >> 4);
+    if (op_is_match(op)) {
+      if (qpos + len > (long long)f.l) {
+        const long long qs2 = qpos > (long long)f.l ? qpos : (long long)f.l;
+        const long long rs = rpos + (qs2 - qpos), re = rpos + len;
+        if (rs < clen && re > 0) flags |= kGenOverrun;
+      }
+      qpos += len;
+      rpos += len;
+    } else if (op == OP_I || op == OP_S) {
+      qpos += len;
+    } else if (op == OP_D || op == OP_N) {
+      rpos += len;
+    }
+    return true;
+  });
+  d->flags = flags;
+}
+
 // ---- 1. classify -------------------------------------------------------------------------------------------------------
 // Two phases, like the packer's per-read kernels: phase A settles in a few dozen instructions the reads whose CIGAR is one
 // match op of the read's length (most of what an end-to-end aligner writes); everything else goes onto the workgroup's
@@ -304,6 +337,8 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
     const uint32_t k = k0 + threadIdx.x;
     bool general = false;
     uint32_t gi = 0;
+    GenDesc gd{};
+    int g_first = 0, g_span = 0, g_contig = 0;
     if (k < n_later) {
       const int i = (int)s_later[k];
       gi = (uint32_t)i;
@@ -340,15 +375,25 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
             }
           }
         } else {
-          idxrec_store_idle(p.rec, (size_t)i, (uint32_t)at.c);      // (the fill kernel takes the contig from here)
+          idxrec_store_idle(p.rec, (size_t)i, (uint32_t)at.c);
           general = true;
+          // the read's descriptor, complete but for the tiles it goes to: the fill kernel only places it
+          gd.idx = (uint32_t)i; gd.pos = f.pos; gd.l = (uint32_t)l; gd.nc = (uint32_t)nc;
+          gd.nm16 = f.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)f.nm;
+          gd.mapq = p.mapq[i];
+          gd.so = (unsigned long long)f.so; gd.qo = (unsigned long long)f.qo; gd.co = (unsigned long long)f.co;
+          general_facts(f, cg, (uint32_t)nc, at.clen, &gd);
+          g_contig = at.c;
           unsigned long long n = 0;
+          bool consecutive = true;
           // entries per tile: counted in LDS for the tiles near the workgroup's reads, one global atomic per tile afterwards
           general_tiles(f.pos, (uint32_t)nc, cg, at.clen, p.tile_shift, at.tile_base, [&](int t) {
             const unsigned w = (unsigned)(t - tile0);
             if (w < (unsigned)kGenWin) atomicAdd(&s_hist[w], 1u); else atomicAdd(&p.gcount[t], 1u);
+            if (n == 0) g_first = t; else if (t != g_first + (int)n) consecutive = false;
             ++n;
           });
+          g_span = (consecutive && n <= 255) ? (int)n : 0;      // 0: the fill kernel walks the CIGAR itself
           entries += n;
         }
       }
@@ -365,7 +410,14 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
         // waves that have already read theirs -- write after the round's reads)
         const uint32_t slot = b0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         __syncthreads();
-        if (general) s_later[slot] = gi;
+        if (general) {
+          s_later[slot] = gi;
+          if (p.gen_body) {      // (not on the batch's first pass, which sizes the array)
+            uint32_t* body = p.gen_body + ((size_t)p.gen_base[blockIdx.x] + slot) * kGenBodyWords;
+            gdesc_store(body, gd);
+            reinterpret_cast<uint4*>(body)[2] = make_uint4((uint32_t)g_first, (uint32_t)g_span, (uint32_t)g_contig, gi);
+          }
+        }
       } else {
         __syncthreads();
       }
@@ -408,9 +460,19 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   const int n = p.n_tiles + 1;
   const int per = (n + kScanBlock - 1) / kScanBlock;
   const int a = tid * per, b = a + per < n ? a + per : n;
+  // (up to 32 elements per thread are held in registers: one trip to memory for the loads, one for the stores)
+  constexpr int kKeep = 32;
+  uint32_t v[kKeep];
   unsigned long long sum = 0;
+  if (per <= kKeep) {
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) v[j] = (j < per && a + j < n) ? p.gcount[a + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) sum += v[j];
+  } else {
 #pragma unroll 8
-  for (int i = a; i < b; ++i) sum += p.gcount[i];
+    for (int i = a; i < b; ++i) sum += p.gcount[i];
+  }
   unsigned long long incl = sum;                      // inclusive scan over the wave
   for (int d = 1; d < 64; d <<= 1) {
     const unsigned long long o = __shfl_up(incl, d);
@@ -424,10 +486,18 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
   }
   __syncthreads();
   unsigned long long run = s_base[wave] + incl - sum;
+  if (per <= kKeep) {
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) {
+      if (j < per && a + j < n) p.goff[a + j] = (uint32_t)run;
+      run += v[j];
+    }
+  } else {
 #pragma unroll 8
-  for (int i = a; i < b; ++i) {
-    p.goff[i] = (uint32_t)run;
-    run += p.gcount[i];
+    for (int i = a; i < b; ++i) {
+      p.goff[i] = (uint32_t)run;
+      run += p.gcount[i];
+    }
   }
   // the pass's totals: the slots added up, then cleared for the next pass
   if (tid < kDirectFactSlots) {
@@ -459,95 +529,67 @@ __global__ __launch_bounds__(kScanBlock) void direct_scan_kernel(DirectIndexPara
 }
 
 // ---- 3. fill: the descriptors of the general reads, tile by tile -------------------------------------------------------
-// A workgroup takes 256 consecutive entries of the general-read list (reads of one neighbourhood: the classify kernel
-// appends a workgroup's reads together), ranks their tile entries in LDS, reserves the slots of a tile with ONE returning
-// atomic per tile and workgroup, and writes the descriptors.  (One returning atomic per entry, 0.55 M of them, took 0.12 ms.)
+// Workgroup b places the general reads of classify workgroup b (reads of one neighbourhood): their descriptors come ready
+// from the classify kernel (gen_body: descriptor, first tile, number of consecutive tiles), so a read costs one coalesced
+// fetch here; its tile entries are ranked in LDS, the slots of a tile reserved with ONE returning atomic per tile and
+// workgroup.  (One thread per read fetching its columns again -- nine scattered loads -- and one returning atomic per entry
+// took 0.12-0.16 ms on configs[2]: dependent trips to memory, not bytes.)
 constexpr int kFillKeep = 4;         // tile entries of a read ranked through LDS (a read has one or two; more go the direct way)
 __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParams p) {
   __shared__ uint32_t s_cnt[kGenWin], s_base[kGenWin];
   __shared__ int s_tile0;
-  const uint32_t n_gen = p.gen_count[blockIdx.x];            // the general reads of classify workgroup blockIdx.x ...
-  const uint32_t list0 = blockIdx.x * (uint32_t)kClsRun;     // ... lie at the start of its stretch of the list
+  const uint32_t n_gen = p.gen_count[blockIdx.x];
+  const size_t body0 = p.gen_base[blockIdx.x];
   for (uint32_t chunk = 0; chunk < n_gen; chunk += kClsBlock) {
     const uint32_t k = chunk + threadIdx.x;
     const bool act = k < n_gen;
     if (threadIdx.x < kGenWin) s_cnt[threadIdx.x] = 0u;
-    GenDesc d{};
-    CigarView cg{};
-    uint32_t nc = 0;
-    long long clen = 1;
-    int tile_base = 0;
+    uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = b0, b2 = b0;
     if (act) {
-      const int i = (int)p.gen_reads[list0 + k];
-      const Fields f = load_fields(p, i);
-      nc = (uint32_t)(f.co1 - f.co);
-      cg.load(p.cigar + f.co);
-      const int c = (int)(*reinterpret_cast<const uint32_t*>(p.rec + (size_t)i * kIdxRecBytes) & ~kInfoGeneral);   // its contig, left there by the classify kernel
-      clen = p.contig_len[c];
-      tile_base = p.contig_tile_base[c];
-      d.idx = (uint32_t)i;
-      d.pos = f.pos;
-      d.l = (uint32_t)f.l;
-      d.nc = nc;
-      d.nm16 = f.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)f.nm;
-      d.mapq = p.mapq[i];
-      d.so = (unsigned long long)f.so; d.qo = (unsigned long long)f.qo; d.co = (unsigned long long)f.co;
-      // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
-      long long qs = 0, qe = 0;
-      query_bounds(cg, nc, f.l, &qs, &qe);
-      long long al = qe - qs;
-      al = al < 0 ? 0 : al;
-      d.align_len = (uint32_t)(al > 2047 ? 2047 : al);      // (l_seq <= 1024)
-      d.lead = (uint32_t)(qs > 2047 ? 2047 : qs);
-      // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position
-      // >= l_seq onto a site inside the contig
-      uint32_t flags = f.nm < 0 ? kGenNoNm : 0u;
-      long long qpos = 0, rpos = f.pos;
-      for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
-        const uint32_t op = v & 15u;
-        const long long len = (long long)(v >> 4);
-        if (op_is_match(op)) {
-          if (qpos + len > (long long)f.l) {
-            const long long qs2 = qpos > (long long)f.l ? qpos : (long long)f.l;
-            const long long rs = rpos + (qs2 - qpos), re = rpos + len;
-            if (rs < clen && re > 0) flags |= kGenOverrun;
-          }
-          qpos += len;
-          rpos += len;
-        } else if (op == OP_I || op == OP_S) {
-          qpos += len;
-        } else if (op == OP_D || op == OP_N) {
-          rpos += len;
-        }
-        return true;
-      });
-      d.flags = flags;
-      if (threadIdx.x == 0) {
-        long long pc = f.pos < 0 ? 0 : f.pos;
-        pc = pc > clen - 1 ? clen - 1 : pc;
-        s_tile0 = tile_base + (int)(pc >> p.tile_shift);
-      }
+      const uint4* body = reinterpret_cast<const uint4*>(p.gen_body + (body0 + k) * kGenBodyWords);
+      b0 = body[0]; b1 = body[1]; b2 = body[2];
     }
+    const int t_first = (int)b2.x, t_span = (int)b2.y;
+    if (threadIdx.x == 0) s_tile0 = t_first;
     __syncthreads();
     const int tile0 = s_tile0;
+    auto place = [&](long long slot) {
+      if (slot >= 0 && slot < p.gdesc_capacity) {
+        uint4* q = reinterpret_cast<uint4*>(p.gdesc + (size_t)slot * kGenDescWords);
+        q[0] = b0; q[1] = b1;
+        p.gidx[slot] = b2.w;
+      }
+    };
+    auto direct = [&](int t) {
+      const uint32_t left = atomicSub(&p.gcount[t], 1u);
+      place((long long)p.goff[t] + (long long)left - 1);
+    };
     // the first entries of the read: rank inside the workgroup (LDS); anything else takes its slot directly
     int kept_tile[kFillKeep];
     uint32_t kept_rank[kFillKeep];
-    int n_kept = 0, ord = 0;
+    int n_kept = 0;
     if (act) {
-      general_tiles(d.pos, nc, cg, clen, p.tile_shift, tile_base, [&](int t) {
+      auto entry = [&](int t, int ord) {
         const unsigned w = (unsigned)(t - tile0);
         if (ord < kFillKeep && w < (unsigned)kGenWin) {
           kept_tile[n_kept] = t;
           kept_rank[n_kept] = atomicAdd(&s_cnt[w], 1u);
           ++n_kept;
         } else {
-          const uint32_t left = atomicSub(&p.gcount[t], 1u);
-          const long long slot = (long long)p.goff[t] + (long long)left - 1;
-          if (slot >= 0 && slot < p.gdesc_capacity) { gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d); p.gidx[slot] = d.idx; }
+          direct(t);
         }
-        ++ord;
-      });
+      };
+      if (t_span > 0) {
+        for (int j = 0; j < t_span; ++j) entry(t_first + j, j);
+      } else {      // tiles that are not consecutive (a long skip): walk the CIGAR again
+        const uint32_t nc = b1.w >> 16;
+        const unsigned long long co = (unsigned long long)b1.z | ((unsigned long long)((b0.x >> 22) & 0xFFu) << 32);
+        CigarView cg;
+        cg.load(p.cigar + co);
+        const int c = (int)b2.z;
+        int ord = 0;
+        general_tiles((long long)(int32_t)b0.y, nc, cg, p.contig_len[c], p.tile_shift, p.contig_tile_base[c], [&](int t) { entry(t, ord); ++ord; });
+      }
     }
     __syncthreads();
     if (threadIdx.x < kGenWin && s_cnt[threadIdx.x]) {       // counts a tile's entries back towards zero: ready for the next pass
@@ -557,8 +599,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_fill_kernel(DirectIndexParam
     __syncthreads();
     for (int e = 0; e < n_kept; ++e) {
       const int t = kept_tile[e];
-      const long long slot = (long long)p.goff[t] + (long long)s_base[t - tile0] + (long long)kept_rank[e];
-      if (slot >= 0 && slot < p.gdesc_capacity) { gdesc_store(p.gdesc + (size_t)slot * kGenDescWords, d); p.gidx[slot] = d.idx; }
+      place((long long)p.goff[t] + (long long)s_base[t - tile0] + (long long)kept_rank[e]);
     }
     __syncthreads();      // s_cnt / s_tile0 are rewritten by the next chunk
   }
@@ -574,7 +615,12 @@ hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s) {
   if (p.sorted) hipLaunchKernelGGL(direct_classify_kernel<true>, dim3(grid), dim3(kClsBlock), 0, s, p);
   else hipLaunchKernelGGL(direct_classify_kernel<false>, dim3(grid), dim3(kClsBlock), 0, s, p);
   hipLaunchKernelGGL(direct_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, p);
-  hipLaunchKernelGGL(direct_fill_kernel, dim3(grid), dim3(kClsBlock), 0, s, p);       // one workgroup per classify workgroup
+  if (p.gen_body) {
+    hipLaunchKernelGGL(direct_fill_kernel, dim3(grid), dim3(kClsBlock), 0, s, p);       // one workgroup per classify workgroup
+  } else {      // the batch's first pass only sizes things: nothing to place, the entry counts go back to zero
+    hipError_t e = hipMemsetAsync(p.gcount, 0, ((size_t)p.n_tiles + 1) * 4, s);
+    if (e != hipSuccess) return e;
+  }
   return hipGetLastError();
 }
 

@@ -160,6 +160,7 @@ hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);             
 constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0 (then bits 0-30: its contig); else lead | alen << 10 | trail << 21
 constexpr int kInfoAlenShift = 10, kInfoTrailShift = 21;
 constexpr int kGenDescWords = 8;                  // 32 bytes per (general read, tile) entry
+constexpr int kGenBodyWords = 12;                 // 48 bytes per general read: its descriptor + first tile, consecutive tiles, contig, read index
 
 // gdesc flag bits
 constexpr uint32_t kGenOverrun = 1;               // a match op maps a query position >= l_seq into the contig (IndexError if kept)
@@ -195,6 +196,8 @@ struct DirectIndexParams {
   uint32_t* goff;                                 // [n_tiles + 1] exclusive scan of gcount
   uint32_t* gen_reads;                            // [n_reads] the general reads: every classify workgroup fills the start of its own stretch
   uint32_t* gen_count;                            // [direct_index_blocks(n_reads)] how many it put there
+  const uint32_t* gen_base;                       // [direct_index_blocks(n_reads)] exclusive scan of gen_count (constant for a batch: set after its first pass)
+  uint32_t* gen_body;                             // [n_general][kGenBodyWords] the general reads' descriptors, classify -> fill (nullptr on the first pass)
   uint32_t* gdesc;                                // [n_entries][kGenDescWords]
   uint32_t* gidx;                                 // [n_entries] read index of an entry (error reports)
   int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)

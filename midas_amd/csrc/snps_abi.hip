@@ -105,6 +105,8 @@ struct midas_snps_batch {
   uint32_t* d_goff = nullptr;   // [n_tiles + 1]
   uint32_t* d_gen_reads = nullptr;   // [n_reads]
   uint32_t* d_gen_count = nullptr;   // [classify workgroups]
+  uint32_t* d_gen_base = nullptr;    // [classify workgroups] exclusive scan of d_gen_count
+  uint32_t* d_gen_body = nullptr;    // [general reads][kGenBodyWords]
   uint32_t* d_gdesc = nullptr;  // [gdesc_capacity][kGenDescWords]
   int64_t gdesc_capacity = 0;
   DirectFacts* d_dfacts = nullptr;
@@ -463,7 +465,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_gidx, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gen_count, b->d_gdesc,
+                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_gidx, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gen_count, b->d_gen_base, b->d_gen_body, b->d_gdesc,
                  b->d_dfacts, b->d_dtotals,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
@@ -629,7 +631,7 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->rec = b->d_info;
   ip->tbegin = trange_begin(b, par); ip->tend = trange_end(b, par);
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
-  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads; ip->gen_count = b->d_gen_count;
+  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads; ip->gen_count = b->d_gen_count; ip->gen_base = b->d_gen_base; ip->gen_body = b->d_gen_body;
   ip->gdesc = b->d_gdesc; ip->gidx = b->d_gidx; ip->gdesc_capacity = b->gdesc_capacity;
   ip->n_general_hint = b->direct_run_count > 0 ? (int64_t)b->h_dtotals.n_general : b->n_reads;
   ip->sorted = b->direct_sorted ? 1 : 0;
@@ -676,6 +678,16 @@ int32_t direct_prepare(midas_snps_batch* b) {
   b->direct_run_count += 1;
   const DirectTotals& t = b->h_dtotals;
   if (t.status != kNoError) return pack_status_to_error(ctx, t.status);
+  {     // where every classify workgroup's general reads go in gen_body: the batch never changes, so neither does this
+    const size_t nb = (size_t)direct_index_blocks(b->n_reads);
+    std::vector<uint32_t> cnt(nb), base(nb);
+    HIP_TRY(ctx, hipMemcpy(cnt.data(), b->d_gen_count, nb * 4, hipMemcpyDeviceToHost));
+    uint64_t acc = 0;
+    for (size_t k = 0; k < nb; ++k) { base[k] = (uint32_t)acc; acc += cnt[k]; }
+    HIP_TRY(ctx, hipMalloc(&b->d_gen_base, nb * 4));
+    HIP_TRY(ctx, hipMemcpy(b->d_gen_base, base.data(), nb * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&b->d_gen_body, (size_t)(acc > 0 ? acc : 1) * kGenBodyWords * 4));
+  }
   b->max_l_seq = (int32_t)t.max_l;
   b->direct_sorted = t.unsorted == 0;
   b->alg_bytes = (int64_t)t.alg_bytes + 17 * b->n_sites;
