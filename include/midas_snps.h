@@ -130,6 +130,10 @@ typedef struct midas_snps_batch midas_snps_batch;
 
 /* ---- library ------------------------------------------------------------ */
 int32_t midas_snps_abi_version(void);
+/* Host threads the library's parallel regions use (BAM inflate / decode, row formatting + gzip, table parsing): the CPUs the
+ * process may run on -- hardware threads, its affinity mask, a cgroup CPU quota, whichever is least -- divided by
+ * LOCAL_WORLD_SIZE under torchrun.  Replaces the `threads` argument of utility.parallel's mp.Pool (midas/utility.py:81-107). */
+int32_t midas_snps_cpu_budget(void);
 /* Static string for a status code (never NULL). */
 const char* midas_snps_status_string(int32_t status);
 
@@ -195,6 +199,20 @@ int32_t midas_snps_batch_select_path(midas_snps_batch* batch, int32_t path);
 /* The path of every batch created on the context from now on (the one-shot midas_snps_pileup included); AUTO = each
  * batch's own choice.                                                                                              */
 int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path);
+/* What the CIGAR op P (padding) does to the QUERY position in the walk behind count_coverage ([EXT] pysam
+ * get_aligned_pairs(matches_only=True), reached from midas/run/snps.py:194-199):
+ *   MIDAS_SNPS_PAD_SPEC   (default) nothing -- the SAM specification: P consumes neither query nor reference; the worked
+ *                         example of SAMv1 section 1.1 (read r002, 3S6M1P1I4M) only comes out as printed under this rule;
+ *   MIDAS_SNPS_PAD_PYSAM  the query advances, as get_aligned_pairs of the pysam releases of MIDAS's time does (BAM_CPAD sits
+ *                         in the branch of BAM_CINS / BAM_CSOFT_CLIP there): bases behind a pad are read one position late and
+ *                         a read whose last match op then runs past SEQ inside the contig raises IndexError when kept
+ *                         (MIDAS_SNPS_ERR_READ_CIGAR_OVERRUN here).
+ * bowtie2 -- the only aligner run_midas.py snps drives -- never writes P, so the two rules give the same tables on every BAM
+ * the reference itself produces; the switch exists because bit-identity is promised against the dependency, whose behaviour on
+ * this op cannot be pinned in an image without pysam.  Clip lengths (query_alignment_start / _end) never look at P.  Applies
+ * to batches created on the context afterwards (the one-shot midas_snps_pileup included).                              */
+enum { MIDAS_SNPS_PAD_SPEC = 0, MIDAS_SNPS_PAD_PYSAM = 1 };
+int32_t midas_snps_set_pad_rule(midas_snps_ctx* ctx, int32_t rule);
 /* Re-run the device packer over the batch's resident BAM-native arrays (the arrays batch_create uploaded, unchanged):
  * per read the CIGAR walk into gap-free match segments (pysam get_aligned_pairs(matches_only=True), reached from
  * midas/run/snps.py:194-199), the clip structure (query_alignment_sequence, :145), floor(mean(query_qualities))
@@ -265,6 +283,8 @@ int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_devi
 int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs,
                               void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
                               int64_t* out_n_records, int32_t* out_max_l_seq, char* err256);
+/* The pad rule (midas_snps_set_pad_rule) of the two host mirrors: process-wide, MIDAS_SNPS_PAD_SPEC unless set. */
+void midas_snps_pack_set_pad_rule(int32_t rule);
 
 /* The same mirror in the tile order of a batch (4096-site tiles; `contigs` required): what batch_create's device packer
  * must produce bit for bit -- records and payload in device order, orig_index[d] = input index of device record d,

@@ -89,6 +89,7 @@ class BatchInfo(C.Structure):
                 ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64)]
 
 
+PAD_SPEC, PAD_PYSAM = 0, 1       # what the CIGAR op P does to the query position (midas_snps_set_pad_rule)
 PATH_AUTO, PATH_DIRECT, PATH_PACKED = 0, 1, 2
 PATH_NAMES = {PATH_AUTO: "auto", PATH_DIRECT: "direct", PATH_PACKED: "packed"}
 
@@ -200,6 +201,7 @@ def load_library(build_if_missing: bool = True):
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     sig = {
         'midas_snps_abi_version': (i32, []),
+        'midas_snps_cpu_budget': (i32, []),
         'midas_snps_status_string': (C.c_char_p, [i32]),
         'midas_snps_create': (i32, [i32, C.POINTER(vp)]),
         'midas_snps_destroy': (None, [vp]),
@@ -223,6 +225,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_pack': (i32, [vp]),
         'midas_snps_batch_select_path': (i32, [vp, i32]),
         'midas_snps_set_default_path': (i32, [vp, i32]),
+        'midas_snps_set_pad_rule': (i32, [vp, i32]),
+        'midas_snps_pack_set_pad_rule': (None, [i32]),
         'midas_snps_copy_rate': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
         'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
         'midas_snps_batch_pack_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
@@ -273,14 +277,15 @@ def load_library(build_if_missing: bool = True):
 
 
 EXPORTED_SYMBOLS = [
-    'midas_snps_abi_version', 'midas_snps_status_string', 'midas_snps_create', 'midas_snps_destroy',
+    'midas_snps_abi_version', 'midas_snps_cpu_budget', 'midas_snps_status_string', 'midas_snps_create', 'midas_snps_destroy',
     'midas_snps_last_error', 'midas_snps_last_error_read', 'midas_snps_set_stream', 'midas_snps_device_info',
     'midas_snps_host_alloc', 'midas_snps_host_free',
     'midas_snps_pileup', 'midas_snps_batch_create', 'midas_snps_batch_destroy', 'midas_snps_batch_run',
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
-    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate',
+    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_set_pad_rule',
+    'midas_snps_pack_set_pad_rule',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
@@ -696,6 +701,11 @@ class Context:
     def set_default_path(self, path: int):
         """The path of every batch created on this context from now on (PATH_AUTO: each batch's own choice)."""
         self._check(self._lib.midas_snps_set_default_path(self._h, int(path)))
+
+    def set_pad_rule(self, rule: int):
+        """PAD_SPEC (default): the CIGAR op P consumes nothing; PAD_PYSAM: it advances the query position, as
+        get_aligned_pairs of the pysam releases of MIDAS's time does.  For batches created afterwards."""
+        self._check(self._lib.midas_snps_set_pad_rule(self._h, int(rule)))
 
     def copy_rate(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
         """GB/s (read + written) of a device-to-device copy with the library's 16-bytes-per-lane copy kernel."""

@@ -1116,16 +1116,30 @@ bool read_file(const char* path, std::vector<uint8_t>& file, char* err256) {
 int32_t midas_snps_table_count_rows(const char* path, int64_t* out_rows, char* err256) {
   if (!path || !out_rows) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out_rows = -1;
-  std::vector<uint8_t> file;
-  if (!read_file(path, file, err256)) return MIDAS_SNPS_ERR_INVALID_ARG;
-  const std::vector<TableMember> members = table_members(file);
-  if (members.empty()) return MIDAS_SNPS_OK;      // not one of ours: unknown without reading it
+  // only the gzip member headers are read (28 bytes each, found by the sizes the members announce): every rank of a merge
+  // asks this of every sample's table before any work starts, and reading whole files for it was N full reads of all inputs
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); set_err(err256, "cannot stat %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  const uint64_t fsz = (uint64_t)sb.st_size;
+  uint64_t p = 0;
   int64_t rows = 0;
-  for (const TableMember& m : members) {
-    if (m.rows < 0) return MIDAS_SNPS_OK;          // a round-1 file
-    rows += m.rows;
+  bool ours = fsz > 0;
+  while (ours && p < fsz) {
+    uint8_t h[kGzHeader];
+    const size_t want = (size_t)std::min<uint64_t>(kGzHeader, fsz - p);
+    if (want < (size_t)kGzHeaderOld || pread(fd, h, want, (off_t)p) != (ssize_t)want) { ours = false; break; }
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[12] != 'M' || h[13] != 'S' || rd16(h + 14) != 4) { ours = false; break; }
+    const size_t xlen = rd16(h + 10);
+    if (!(xlen == 16 && want >= (size_t)kGzHeader && h[20] == 'M' && h[21] == 'R' && rd16(h + 22) == 4)) { ours = false; break; }   // (xlen 8: a round-1 file)
+    const uint64_t total = rd32(h + 16);
+    if (total < 12 + xlen + 8 || p + total > fsz) { ours = false; break; }
+    rows += rd32(h + 24);
+    p += total;
   }
-  *out_rows = rows;
+  close(fd);
+  if (ours) *out_rows = rows;      // else: not one of ours (or a file that does not say): unknown without reading it
   return MIDAS_SNPS_OK;
 }
 

@@ -157,7 +157,7 @@ __device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t*
 
 // What the pileup kernel needs of a general read besides its columns: the clip lengths by pysam's rules and the one case in
 // which count_coverage raises IndexError for a kept read (a match op maps a query position >= l_seq onto a site inside the contig).
-__device__ void general_facts(const Fields& f, const CigarView& cg, uint32_t nc, long long clen, GenDesc* d) {
+__device__ void general_facts(const Fields& f, const CigarView& cg, uint32_t nc, long long clen, bool pad_advances, GenDesc* d) {
   // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
   long long qs = 0, qe = 0;
   query_bounds(cg, nc, f.l, &qs, &qe);
@@ -178,7 +178,7 @@ __device__ void general_facts(const Fields& f, const CigarView& cg, uint32_t nc,
       }
       qpos += len;
       rpos += len;
-    } else if (op == OP_I || op == OP_S) {
+    } else if (op == OP_I || op == OP_S || (op == OP_P && pad_advances)) {
       qpos += len;
     } else if (op == OP_D || op == OP_N) {
       rpos += len;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kClsBlock) void direct_classify_kernel(DirectIndexP
           gd.nm16 = f.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)f.nm;
           gd.mapq = p.mapq[i];
           gd.so = (unsigned long long)f.so; gd.qo = (unsigned long long)f.qo; gd.co = (unsigned long long)f.co;
-          general_facts(f, cg, (uint32_t)nc, at.clen, &gd);
+          general_facts(f, cg, (uint32_t)nc, at.clen, p.pad_advances != 0, &gd);
           g_contig = at.c;
           unsigned long long n = 0;
           bool consecutive = true;

@@ -90,6 +90,7 @@ struct PileupParams {
   int32_t reads_per_wave;            // 64 / lanes_per_read
   int32_t table_len;                 // entries of the filter tables in use (max_l_seq + 1)
   int32_t baseq, mapq, readq;
+  int32_t pad_advances;              // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
 };
 
 // ---- device packer (pack_reads.hip): BAM-native SoA resident in HBM -> rec / blob / orig / key of layout.h -----------
@@ -135,6 +136,7 @@ struct PackParams {
   uint32_t* tile_extra; uint32_t* tile_reads;   // [n_tiles] records reaching in / all records a tile will see
   PackFacts* facts;                      // [kPackFactSlots]
   int32_t n_records;
+  int32_t pad_advances;                  // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
   // outputs
   ReadRec* rec; uint8_t* blob; uint32_t* orig; uint32_t* key_out;
 };
@@ -201,6 +203,7 @@ struct DirectIndexParams {
   uint32_t* gdesc;                                // [n_entries][kGenDescWords]
   uint32_t* gidx;                                 // [n_entries] read index of an entry (error reports)
   int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)
+  int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
   int32_t sorted;                                 // the batch's first pass found every contig's reads in position order
   int32_t reach;                                  // the longest read of the batch: no class-0 read spans more sites
   int64_t n_general_hint;                         // general reads found by the batch's first pass (sizes the fill kernel's grid)
@@ -224,6 +227,7 @@ struct DirectParams {
   int32_t n_tiles, n_reads, grid_blocks;
   int32_t lanes_per_read, reads_per_wave, table_len;
   int32_t baseq, mapq_min, readq;
+  int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
 };
 
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill

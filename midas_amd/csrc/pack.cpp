@@ -13,6 +13,8 @@
 
 namespace midas {
 
+int g_pad_advances = 0;   // midas_snps_pack_set_pad_rule: the CIGAR op P advances the query position (host mirror)
+
 namespace {
 
 int hw_threads() {
@@ -83,7 +85,7 @@ uint8_t cigar_flags(const uint32_t* cg, uint32_t nc, uint32_t l, int64_t pos, in
       }
       qpos += len;
       rpos += len;
-    } else if (op == 1u || op == 4u) {
+    } else if (op == 1u || op == 4u || (op == 6u && g_pad_advances)) {
       qpos += len;
     } else if (op == 2u || op == 3u) {
       rpos += len;

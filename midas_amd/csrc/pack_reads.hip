@@ -202,7 +202,7 @@ struct PieceIter {
 
 // Facts about a record that keeps its CIGAR (layout.h kRec* bits): clip structure, the one condition under which the
 // reference would raise IndexError for a kept read, and its reference length.  pack.cpp cigar_flags.
-__device__ uint32_t general_flags(const ReadView& r, long long* reflen) {
+__device__ uint32_t general_flags(const ReadView& r, long long* reflen, bool pad_advances) {
   uint32_t f = 0;
   if (r.nc > 0u) {
     uint32_t lead = 0;
@@ -225,7 +225,7 @@ __device__ uint32_t general_flags(const ReadView& r, long long* reflen) {
       }
       qpos += len;
       rpos += len;
-    } else if (op == OP_I || op == OP_S) {
+    } else if (op == OP_I || op == OP_S || (op == OP_P && pad_advances)) {
       qpos += len;
     } else if (op == OP_D || op == OP_N) {
       rpos += len;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kPlanBlock) void pack_keys_kernel(PackParams p) {
     const int ns = (int)f.nseg;
     if (ns == 0) {
       long long reflen = 0;
-      const uint32_t flags = general_flags(r, &reflen);
+      const uint32_t flags = general_flags(r, &reflen, p.pad_advances != 0);
       out.emit(i, f.mapq, f.qo, f.so, j0, record_keys(r.pos, reflen, false, r.clen, p.tile_shift, tb),
                blob_bytes(r.l, r.nc, (uint32_t)p.lane_bases), r.pos, (int)r.l, 0, flags, r.nc,
                r.nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)r.nm);

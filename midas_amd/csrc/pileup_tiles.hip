@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
             found = lo < hi;
             if (found) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + (q0 - qpos); }
           }
-          if (m || op == OP_I || op == OP_S) { qpos += len; qpos = qpos > (1 << 29) ? (1 << 29) : qpos; }
+          if (m || op == OP_I || op == OP_S || (op == OP_P && p.pad_advances)) { qpos += len; qpos = qpos > (1 << 29) ? (1 << 29) : qpos; }
           if (m || op == OP_D || op == OP_N) { rrel += len; rrel = rrel > (1 << 29) ? (1 << 29) : rrel; }
           if (found) return true;   // H, P and anything else: no effect
         }

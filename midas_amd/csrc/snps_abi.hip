@@ -116,6 +116,7 @@ struct midas_snps_batch {
   int64_t direct_stream_reads = 0;   // sum over tiles of the positions their streams hold (>= n_reads: straddlers twice)
   int64_t direct_max_tile_reads = 0;
   int64_t direct_run_count = 0;
+  bool pad_advances = false;    // the context's pad rule when the batch was created (MIDAS_SNPS_PAD_PYSAM)
   bool direct_sorted = false;   // every contig's reads in position order (found by the first index pass): tile ranges need no atomics
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot: before the index kernel, before and after the pileup kernel
@@ -313,6 +314,8 @@ extern "C" {
 
 int32_t midas_snps_abi_version(void) { return MIDAS_SNPS_ABI_VERSION; }
 
+int32_t midas_snps_cpu_budget(void) { return (int32_t)midas::cpu_budget(); }
+
 const char* midas_snps_status_string(int32_t st) {
   switch (st) {
     case MIDAS_SNPS_OK: return "ok";
@@ -420,6 +423,14 @@ int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, d
   *out_gbps = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
   return MIDAS_SNPS_OK;
 }
+
+int32_t midas_snps_set_pad_rule(midas_snps_ctx* ctx, int32_t rule) {
+  if (!ctx || (rule != MIDAS_SNPS_PAD_SPEC && rule != MIDAS_SNPS_PAD_PYSAM)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  ctx->pad_rule = rule;
+  return MIDAS_SNPS_OK;
+}
+
+void midas_snps_pack_set_pad_rule(int32_t rule) { midas::g_pad_advances = rule == MIDAS_SNPS_PAD_PYSAM ? 1 : 0; }
 
 int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path) {
   if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
@@ -635,6 +646,7 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->gdesc = b->d_gdesc; ip->gidx = b->d_gidx; ip->gdesc_capacity = b->gdesc_capacity;
   ip->n_general_hint = b->direct_run_count > 0 ? (int64_t)b->h_dtotals.n_general : b->n_reads;
   ip->sorted = b->direct_sorted ? 1 : 0;
+  ip->pad_advances = b->pad_advances ? 1 : 0;
   ip->reach = b->max_l_seq;
   ip->facts = b->d_dfacts; ip->totals = b->d_dtotals;
   ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
@@ -765,6 +777,7 @@ int32_t ensure_packed(midas_snps_batch* b) {
     k.n_reads = (int32_t)n;
     k.contig_read_begin = b->d_contig_read_begin; k.contig_tile_base = b->d_contig_tile_base; k.contig_len = b->d_contig_len;
     k.n_contigs = b->n_contigs; k.n_tiles = (int32_t)b->n_tiles; k.tile_len = b->tile_len; k.tile_shift = kTileShift;
+    k.pad_advances = b->pad_advances ? 1 : 0;
   }
   b->key_bits = pack_key_bits((int32_t)b->n_tiles);
   // the first scan needs scratch before the record count is known: size it for the reads, regrow below for the records
@@ -906,6 +919,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   midas_snps_batch* b = new (std::nothrow) midas_snps_batch();
   if (!b) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "host allocation failed");
   b->ctx = ctx;
+  b->pad_advances = ctx->pad_rule == MIDAS_SNPS_PAD_PYSAM;
   b->n_reads = n;
   b->n_sites = n_sites;
   b->n_contigs = contigs->n_contigs;
@@ -1153,6 +1167,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.reads_per_wave = 64 / b->direct_lanes_per_read;
     dp.table_len = b->max_l_seq + 1;
     dp.baseq = thr->baseq; dp.mapq_min = thr->mapq; dp.readq = thr->readq;
+    dp.pad_advances = b->pad_advances ? 1 : 0;
     HIP_TRY(ctx, launch_pileup_direct(dp, b->direct_lane_bases, s));
     if (ev) {
       HIP_TRY(ctx, hipEventRecord(ev[2], s));
@@ -1215,6 +1230,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.baseq = thr->baseq;
   pp.mapq = thr->mapq;
   pp.readq = thr->readq;
+  pp.pad_advances = b->pad_advances ? 1 : 0;
   pp.filt = b->d_filt;
   pp.orig = b->d_orig;
   pp.table_len = b->max_l_seq + 1;

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <exception>
 #include <functional>
+#include <sched.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -23,6 +25,14 @@ inline int cpu_budget() {
   static const int budget = [] {
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
+    {     // the CPUs the process may run on (taskset, numactl, a Slurm cpuset without a quota): never more threads than those
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int n = CPU_COUNT(&set);
+        if (n >= 1 && (unsigned)n < hw) hw = (unsigned)n;
+      }
+    }
     double quota = -1, period = -1;
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
       char q[64] = {0};
@@ -42,8 +52,9 @@ inline int cpu_budget() {
     }
     // one process per GPU under torchrun: the node's CPUs are shared by LOCAL_WORLD_SIZE ranks
     if (const char* lws = getenv("LOCAL_WORLD_SIZE")) {
-      const long ranks = atol(lws);
-      if (ranks > 1) hw = hw / (unsigned)ranks > 0 ? hw / (unsigned)ranks : 1u;
+      char* end = nullptr;
+      const long ranks = strtol(lws, &end, 10);
+      if (end != lws && *end == '\0' && ranks > 1 && ranks <= 4096) hw = hw / (unsigned)ranks > 0 ? hw / (unsigned)ranks : 1u;
     }
     return (int)hw;
   }();
@@ -83,29 +94,55 @@ class Workers {
   // is left": the region ends when the caller's own work() has returned and every pool thread that started on it has
   // returned too.  A pool thread the host was slow to wake (a busy machine can take tens of milliseconds) finds the
   // region closed and goes back to sleep -- nobody waits for a thread that has nothing left to do.
+  // An exception thrown by work() on a pool thread or on a helper thread is caught there and rethrown by run() on the
+  // caller once the region is closed (the first one wins): no std::terminate, no job pointer left dangling, the pool
+  // never stays marked as taken.
   static void run(int nt, const std::function<void()>& work) {
     if (nt <= 1) { work(); return; }
+    std::exception_ptr failed;
+    std::mutex failed_m;
+    const std::function<void()> guarded = [&] {
+      try {
+        work();
+      } catch (...) {
+        std::lock_guard<std::mutex> g(failed_m);
+        if (!failed) failed = std::current_exception();
+      }
+    };
     Workers* w = instance();
     if (w->taken_.exchange(true, std::memory_order_acquire)) {     // another region is running (or this is a nested one)
       std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(work);
-      work();
+      try {
+        for (int t = 1; t < nt; ++t) th.emplace_back(guarded);
+      } catch (...) {                                              // (thread creation failed: go on with the ones we have)
+      }
+      guarded();
       for (auto& x : th) x.join();
-      return;
+    } else {
+      struct Region {                                              // closes the region and frees the pool on every way out
+        Workers* w;
+        ~Region() { w->close(); w->taken_.store(false, std::memory_order_release); }
+      } region{w};
+      w->open(nt - 1, &guarded);
+      guarded();
     }
-    w->open(nt - 1, &work);
-    work();
-    w->close();
-    w->taken_.store(false, std::memory_order_release);
+    if (failed) std::rethrow_exception(failed);
   }
 
  private:
   static Workers* instance() {
-    static std::mutex make;
-    std::lock_guard<std::mutex> g(make);
-    static Workers* self = nullptr;
-    if (!self || self->pid_ != getpid()) self = new Workers();   // (a forked child leaks the parent's object)
-    return self;
+    // (no lock: a mutex here could be held by another thread at fork() and would stay locked in the child for ever.  Two
+    // threads racing to make the first pool leak one empty object; the pool of a forked child is made anew, the parent's
+    // -- whose threads do not exist in the child -- is leaked.)
+    static std::atomic<Workers*> self{nullptr};
+    Workers* w = self.load(std::memory_order_acquire);
+    if (!w || w->pid_ != getpid()) {
+      Workers* made = new Workers();
+      if (self.compare_exchange_strong(w, made, std::memory_order_acq_rel)) w = made;
+      else if (w && w->pid_ == getpid()) delete made;
+      else { self.store(made, std::memory_order_release); w = made; }
+    }
+    return w;
   }
   Workers() : pid_(getpid()) {}
   void open(int n, const std::function<void()>* job) {

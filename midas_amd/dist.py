@@ -48,6 +48,17 @@ def init_from_env(device_backend=None):
     return world()
 
 
+def exit_message(e):
+    """What a caught SystemExit means for agree_or_exit: sys.exit(), sys.exit(None) and sys.exit(0) are NOT failures (None);
+    a string is the message the reference's sys.exit("\nError: ...") carries; any other status becomes a message naming it."""
+    code = e.code if isinstance(e, SystemExit) else e
+    if code is None or code == 0:
+        return None
+    if isinstance(code, str):
+        return code if code else "\nError: a stage stopped without a message\n"
+    return "\nError: a stage stopped with exit status %r\n" % (code,)
+
+
 def agree_or_exit(error_message=None):
     """Every rank calls this in front of a collective with its own error (None = fine).  If any rank failed, ALL ranks
     leave together -- the failing ones with their message, as the reference's sys.exit("\nError: ...") would, the others

@@ -175,7 +175,9 @@ def run_pipeline(args, make_context=_device_context):
     except abi.MidasSnpsError as e:
         error = "\nError: %s\n" % e.message
     except SystemExit as e:
-        error = str(e.code)
+        error = dist.exit_message(e)
+    except Exception as e:      # (an OSError from the decoder, a MemoryError ...: the other ranks must not wait for this one)
+        error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)       # (also: every part is on disk)
     for k, species in enumerate(species_list):
         if species.id in sharded and k % ws == rank:

@@ -289,7 +289,9 @@ def pangenome_coverage(args, species, genes, make_context=None):
     except abi.MidasSnpsError as e:
         error = "\nError: %s\n" % e.message
     except SystemExit as e:
-        error = str(e.code)
+        error = dist.exit_message(e)
+    except Exception as e:      # (an OSError from the decoder, a MemoryError ...: the other ranks must not wait for this one)
+        error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)       # every rank leaves with the failing one, in front of the summary all-gather
     normalize(args, species, genes)
     write_results(args, species, genes, mine)

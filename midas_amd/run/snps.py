@@ -462,7 +462,9 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     except abi.MidasSnpsError as e:
         error = _error_text(e)
     except SystemExit as e:
-        error = str(e.code)
+        error = dist.exit_message(e)
+    except Exception as e:      # (an OSError from the decoder, a MemoryError ...: the other ranks must not wait for this one)
+        error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)
 
     # one all-gather of the per-species partial counters; per-site output stays on its rank
@@ -525,23 +527,32 @@ def run_pipeline(args):
     print("  %s minutes" % round((time() - start) / 60, 2))
     print("  %s Gb maximum memory" % utility.max_mem_usage())
 
-    if args['build_db'] and rank == 0:
-        print("\nBuilding database of representative genomes")
-        args['log'].write("\nBuilding database of representative genomes\n")
-        start = time()
-        build_genome_db(args, species)
-        print("  %s minutes" % round((time() - start) / 60, 2))
-        print("  %s Gb maximum memory" % utility.max_mem_usage())
-
-    if args['align'] and rank == 0:
-        args['file_type'] = utility.auto_detect_file_type(args['m1'])
-        print("\nMapping reads to representative genomes")
-        args['log'].write("\nMapping reads to representative genomes\n")
-        start = time()
-        genome_align(args)
-        print("  %s minutes" % round((time() - start) / 60, 2))
-        print("  %s Gb maximum memory" % utility.max_mem_usage())
-    dist.barrier()
+    # rank 0 builds the database and maps the reads (bowtie2 / samtools on PATH, as in the reference); a failure there -- a
+    # sys.exit of those stages, a missing binary, a full disk -- is agreed on by every rank instead of leaving the others at
+    # the barrier until the collective's timeout
+    error = None
+    if rank == 0:
+        try:
+            if args['build_db']:
+                print("\nBuilding database of representative genomes")
+                args['log'].write("\nBuilding database of representative genomes\n")
+                start = time()
+                build_genome_db(args, species)
+                print("  %s minutes" % round((time() - start) / 60, 2))
+                print("  %s Gb maximum memory" % utility.max_mem_usage())
+            if args['align']:
+                args['file_type'] = utility.auto_detect_file_type(args['m1'])
+                print("\nMapping reads to representative genomes")
+                args['log'].write("\nMapping reads to representative genomes\n")
+                start = time()
+                genome_align(args)
+                print("  %s minutes" % round((time() - start) / 60, 2))
+                print("  %s Gb maximum memory" % utility.max_mem_usage())
+        except SystemExit as e:
+            error = dist.exit_message(e)
+        except Exception as e:
+            error = "\nError: %s: %s\n" % (type(e).__name__, e)
+    dist.agree_or_exit(error)
 
     if args['call']:
         if rank == 0:

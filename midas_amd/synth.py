@@ -242,16 +242,23 @@ def _take_reads(reads: ReadsSoA, sel: np.ndarray) -> dict:
         ix = np.repeat(off[:-1][sel] - new_off[:-1], lens) + np.arange(int(new_off[-1]), dtype=np.int64)
         return data[ix], new_off
     d = {k: getattr(reads, k)[sel] for k in ('pos', 'mapq', 'flag', 'nm', 'l_seq')}
-    d['seq4'], d['seq_off'] = gather(reads.seq4, reads.seq_off)
-    d['qual'], d['qual_off'] = gather(reads.qual, reads.qual_off)
+    n, l0 = reads.n_reads, int(reads.l_seq[0]) if reads.n_reads else 0
+    if n and reads.qual.size == n * l0 and reads.seq4.size == n * ((l0 + 1) // 2):      # reads of one length: whole rows
+        d['seq4'] = reads.seq4.reshape(n, (l0 + 1) // 2)[sel].reshape(-1)
+        d['qual'] = reads.qual.reshape(n, l0)[sel].reshape(-1)
+        d['seq_off'] = np.arange(sel.size + 1, dtype=np.int64) * ((l0 + 1) // 2)
+        d['qual_off'] = np.arange(sel.size + 1, dtype=np.int64) * l0
+    else:
+        d['seq4'], d['seq_off'] = gather(reads.seq4, reads.seq_off)
+        d['qual'], d['qual_off'] = gather(reads.qual, reads.qual_off)
     d['cigar'], d['cigar_off'] = gather(reads.cigar, reads.cigar_off)
     return d
 
 
 def c4_share(rank: int, world: int, **kw):
     """-> (ContigTable, ReadsSoA, facts) of the contigs rank `rank` of `world` owns.  Every contig table carries all the
-    species (n_species rows of counters on every rank, as the summary all-gather wants them).  A species' contigs share one
-    reference sequence and draw their reads -- each its own random subset, in position order -- from one pool of reads
+    species (n_species rows of counters on every rank, as the summary all-gather wants them).  A contig draws its reads -- its
+    own random subset, in position order -- from a pool of reads
     generated against it: sixteen times cheaper to generate than sixteen contigs, and the partitioner, the pileup, the
     per-species counters and the concatenation of the parts do not care."""
     from . import dist
@@ -261,13 +268,14 @@ def c4_share(rank: int, world: int, **kw):
     mine = [(s, k, n) for s, k, n in items if owner[(s, k)] == rank]
     loads = [sum(w[(s, k)] for s, k, n in items if owner[(s, k)] == r) for r in range(world)]
     lengths, species, ids, refs, parts, rb = [], [], [], [], [], [0]
-    pool_of = {}
+    n_pools = 8
+    pool_reads = int(max(n for _, _, n in items) * 1.25) + 16
     for s, k, n in mine:
-        if s not in pool_of:
-            pc, pr = make_dataset(n_species=1, contigs_per_species=1, contig_len=a['contig_len'], n_reads=int(n * 1.25) + 16,
-                                  read_len=a['read_len'], seed=a['seed'] + 7919 * (s + 1))
-            pool_of = {s: (pc, pr)}          # (one species at a time: items come species by species)
-        pc, pr = pool_of[s]
+        key = (a['seed'], a['contig_len'], a['read_len'], pool_reads, s % n_pools)
+        if key not in _C4_POOLS:      # (the partitioner deals a species' contigs to all the ranks: every rank needs every pool;
+            _C4_POOLS[key] = make_dataset(n_species=1, contigs_per_species=1, contig_len=a['contig_len'], n_reads=pool_reads,   # kept for
+                                          read_len=a['read_len'], seed=a['seed'] + 7919 * (s % n_pools + 1))              # the process)
+        pc, pr = _C4_POOLS[key]
         sel = np.sort(np.random.default_rng(a['seed'] + 104729 * (s + 1) + k).choice(pr.n_reads, size=n, replace=False))
         parts.append(_take_reads(pr, sel))
         lengths.append(a['contig_len']); species.append(s); ids.append("Species_%05d_c%d" % (s + 1, k + 1)); refs.append(pc.ref)
@@ -294,6 +302,7 @@ def c4_share(rank: int, world: int, **kw):
     return contigs, reads, facts
 
 
+_C4_POOLS = {}
 _DT = dict(pos=np.int32, mapq=np.uint8, flag=np.uint16, nm=np.int32, l_seq=np.int32, seq4=np.uint8, qual=np.uint8, cigar=np.uint32)
 
 

@@ -35,6 +35,15 @@ def _load():
     return _lib
 
 
+def set_pad_rule(pysam_rule: bool):
+    """What the CIGAR op P does to the query position in the walk: False = nothing (SAM specification, the default), True =
+    it advances (pysam's get_aligned_pairs of MIDAS's time).  include/midas_snps.h, midas_snps_set_pad_rule."""
+    lib = _load()
+    lib.midas_oracle_set_pad_rule.restype = None
+    lib.midas_oracle_set_pad_rule.argtypes = [C.c_int]
+    lib.midas_oracle_set_pad_rule(1 if pysam_rule else 0)
+
+
 def pileup(thr, contigs, reads, want_allele=True):
     """-> (status, err_read, counts[n_sites,4] u32, allele u8 | None, stats[n_species,4] i64)"""
     lib = _load()

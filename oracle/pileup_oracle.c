@@ -31,6 +31,12 @@ typedef struct {
   int64_t aligned_reads, mapped_reads;
 } read_stats;
 
+/* What the op P does to the query position in get_aligned_pairs: 0 = nothing (SAM specification, the default), 1 = it
+ * advances (the pysam releases of MIDAS's time put BAM_CPAD in the branch of BAM_CINS / BAM_CSOFT_CLIP).  See
+ * midas_snps_set_pad_rule in include/midas_snps.h. */
+static int g_pad_advances = 0;
+void midas_oracle_set_pad_rule(int rule) { g_pad_advances = rule == 1; }
+
 /* [EXT] pysam getQueryStart */
 static int64_t query_alignment_start(const uint32_t* cig, int64_t n) {
   int64_t start = 0;
@@ -138,11 +144,11 @@ int32_t midas_oracle_pileup(const midas_snps_thresholds* thr, const midas_snps_c
           }
           qpos += len;
           rpos += len;
-        } else if (op == OP_I || op == OP_S) {
+        } else if (op == OP_I || op == OP_S || (op == OP_P && g_pad_advances)) {
           qpos += len;
         } else if (op == OP_D || op == OP_N) {
           rpos += len;
-        } /* H, P, B: no effect */
+        } /* H, B, and P under the specification's rule: no effect */
       }
     }
     /* snps.py:201-213 */

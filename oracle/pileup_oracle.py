@@ -156,6 +156,14 @@ def keep_read(aln: Aln, args: dict, aln_stats: dict) -> bool:
         return True
 
 
+PAD_ADVANCES_QUERY = False      # set_pad_rule: what BAM_CPAD does to the query position (include/midas_snps.h, midas_snps_set_pad_rule)
+
+
+def set_pad_rule(pysam_rule: bool):
+    global PAD_ADVANCES_QUERY
+    PAD_ADVANCES_QUERY = bool(pysam_rule)
+
+
 def get_aligned_pairs_matches_only(aln: Aln) -> List[Tuple[int, int]]:
     """[EXT] pysam AlignedSegment.get_aligned_pairs(matches_only=True).
 
@@ -172,7 +180,7 @@ def get_aligned_pairs_matches_only(aln: Aln) -> List[Tuple[int, int]]:
                 pairs.append((qpos + i, rpos + i))
             qpos += ln
             rpos += ln
-        elif op in (BAM_CINS, BAM_CSOFT_CLIP):
+        elif op in (BAM_CINS, BAM_CSOFT_CLIP) or (op == BAM_CPAD and PAD_ADVANCES_QUERY):
             qpos += ln
         elif op in (BAM_CDEL, BAM_CREF_SKIP):
             rpos += ln

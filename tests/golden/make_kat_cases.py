@@ -72,10 +72,25 @@ cases.append(dict(name="k03c_refskip", contig_len=20, args={"mapid": 75.0},
                   counts=add(run("ACGT", 0), run("ACGT", 6)), aligned_reads=1, mapped_reads=1,
                   covered_bases=8, total_depth=8))
 
-# (4) H and P are no-ops
+# (4) H is a no-op; so is P under the SAM specification (the default pad rule, MIDAS_SNPS_PAD_SPEC) ...
 cases.append(dict(name="k04_hardclip_pad_noops", contig_len=20, args={},
                   reads=[read(3, "2H4M1P4M2H", "ACGTACGT")],
                   counts=run("ACGTACGT", 3), aligned_reads=1, mapped_reads=1, covered_bases=8, total_depth=8))
+# ... while under MIDAS_SNPS_PAD_PYSAM ("pad_rule": "pysam": get_aligned_pairs of the pysam releases of MIDAS's time advances
+# the QUERY on BAM_CPAD, in the branch of BAM_CINS / BAM_CSOFT_CLIP) the four bases behind the pad are read one position late:
+# sites 7..10 get seq[5], seq[6], seq[7] and -- seq[8] does not exist: the last pair indexes past SEQ inside the contig, which
+# is the IndexError of count_coverage for a kept read (status 5)
+cases.append(dict(name="k04b_pad_advances_query_pysam_rule_overruns", contig_len=20, args={}, pad_rule="pysam",
+                  reads=[read(3, "2H4M1P4M2H", "ACGTACGT")], error=5, error_read=0))
+# with one spare base stored behind the aligned ones (9 bases, 4M1P4M covers 8 under the specification) the pysam rule has
+# a base for every pair: sites 3..6 = seq[0..3] = ACGT, the pad skips seq[4] = 'T', sites 7..10 = seq[5..8] = CGTA.  The
+# filter sees align_len 9 (no clips), NM 0.  Under the specification's rule the same record gives sites 7..10 = seq[4..7] = TCGT
+cases.append(dict(name="k04c_pad_pysam_rule_reads_one_late", contig_len=20, args={}, pad_rule="pysam",
+                  reads=[read(3, "4M1P4M", "ACGTTCGTA")],
+                  counts=add(run("ACGT", 3), run("CGTA", 7)), aligned_reads=1, mapped_reads=1, covered_bases=8, total_depth=8))
+cases.append(dict(name="k04d_same_record_spec_rule", contig_len=20, args={},
+                  reads=[read(3, "4M1P4M", "ACGTTCGTA")],
+                  counts=add(run("ACGT", 3), run("TCGT", 7)), aligned_reads=1, mapped_reads=1, covered_bases=8, total_depth=8))
 
 # (5) N and IUPAC codes count nowhere (depth unchanged at those sites).  NM 2 of 6 -> pid 66.7; mapid 50
 cases.append(dict(name="k05_N_and_iupac_not_counted", contig_len=10, args={"mapid": 50.0},
@@ -206,6 +221,14 @@ cases.append(dict(name="s01_sam_spec_example_all_reads_kept", contig_len=45, ref
 # length 14 - 3 clipped), 5/6 = 83.3 % (r003), 8/9 = 88.9 % (r001/2) are below mapid 94; the supplementary r003
 # (5/5 = 100 %) has MAPQ 17 < 20; r004 is 11/11 = 100 %, MAPQ 30, aligned fraction 11/11
 sam_r004 = run(SAM_COLUMNS["r004"][1].replace(".", "-"), SAM_COLUMNS["r004"][0] - 1)
+# the same example under MIDAS_SNPS_PAD_PYSAM: r002 (3S6M1P1I4M, 14 stored bases) walks 3 + 6 + 1 (pad) + 1 = 11 query
+# positions before its last 4M, whose fourth pair would index seq[14]: IndexError if the read is kept -- it is, when
+# every read is kept (read index 1) --, and nothing happens at the CLI defaults, where keep_read drops r002 first
+cases.append(dict(name="s01b_sam_spec_example_all_reads_kept_pysam_pad_rule", contig_len=45, ref=SAM_REF, pad_rule="pysam",
+                  args={"mapid": 0.0, "aln_cov": 0.0, "mapq": 0, "readq": 0}, reads=SAM_READS, error=5, error_read=1))
+cases.append(dict(name="s02b_sam_spec_example_default_thresholds_pysam_pad_rule", contig_len=45, ref=SAM_REF, args={},
+                  pad_rule="pysam", reads=SAM_READS, counts=sam_r004, aligned_reads=6, mapped_reads=1, covered_bases=11,
+                  total_depth=11))
 cases.append(dict(name="s02_sam_spec_example_default_thresholds", contig_len=45, ref=SAM_REF, args={},
                   reads=SAM_READS, counts=sam_r004, aligned_reads=6, mapped_reads=1, covered_bases=11, total_depth=11))
 

@@ -68,6 +68,11 @@ def kat_inputs(case):
     return contigs, reads, abi.Thresholds.from_args(args), args
 
 
+def kat_pysam_pad_rule(case):
+    """True when the case states what the path does under MIDAS_SNPS_PAD_PYSAM (the CIGAR op P advances the query)."""
+    return case.get("pad_rule", "spec") == "pysam"
+
+
 def kat_expected_counts(case):
     exp = np.zeros((case["contig_len"], 4), dtype=np.uint32)
     for k, v in case.get("counts", {}).items():

@@ -49,13 +49,17 @@ def _same(ctx, thr, contigs, reads):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_hand_derived_cases_on_both_paths(path_ctx, case):
     contigs, reads, thr, _ = H.kat_inputs(case)
-    if "error" in case:
-        with pytest.raises(abi.MidasSnpsError) as ei:
-            path_ctx.pileup(thr, contigs, reads)
-        assert ei.value.status == case["error"]
-        assert ei.value.read_index == case.get("error_read", 0)
-        return
-    counts, allele, stats = path_ctx.pileup(thr, contigs, reads)
+    path_ctx.set_pad_rule(abi.PAD_PYSAM if H.kat_pysam_pad_rule(case) else abi.PAD_SPEC)
+    try:
+        if "error" in case:
+            with pytest.raises(abi.MidasSnpsError) as ei:
+                path_ctx.pileup(thr, contigs, reads)
+            assert ei.value.status == case["error"]
+            assert ei.value.read_index == case.get("error_read", 0)
+            return
+        counts, allele, stats = path_ctx.pileup(thr, contigs, reads)
+    finally:
+        path_ctx.set_pad_rule(abi.PAD_SPEC)
     np.testing.assert_array_equal(counts, H.kat_expected_counts(case))
     np.testing.assert_array_equal(stats, H.kat_expected_stats(case))
 
@@ -211,3 +215,54 @@ def test_auto_picks_direct_for_sorted_input_and_packed_otherwise(hip_ctx, thr_de
     b = hip_ctx.batch(hc, hr)
     assert b.info().path == abi.PATH_PACKED
     b.close()
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_pad_rule_pysam_on_random_cigars(path_ctx, seed):
+    """MIDAS_SNPS_PAD_PYSAM: the CIGAR op P advances the query position (get_aligned_pairs of the pysam releases of MIDAS's
+    time).  Reads with pads then take their bases one position late -- or run past SEQ, which is the IndexError status with
+    the lowest such read -- exactly as the oracle does under the same rule, on both device paths."""
+    rng = random.Random(seed)
+    L = 12000
+    reads = []
+    for _ in range(1500):
+        l = rng.choice([150, 100, 60, rng.randint(20, 300)])
+        n_pad = rng.choice([0, 0, 1, 1, 2])
+        spare = rng.choice([0, 0, 1, 2, 3]) if seed != 5 else 3          # seed 5: every read has room behind its pads
+        body = l - spare
+        if body < 8:
+            continue
+        cuts = sorted(rng.sample(range(2, body - 1), min(n_pad, body - 4)))
+        ops, prev = [], 0
+        for c in cuts + [body]:
+            ops.append((0, c - prev))
+            prev = c
+            if c != body:
+                ops.append((6, 1))                                          # 1P between two match runs
+        seq = "".join(rng.choice("ACGT") for _ in range(l))
+        reads.append(dict(pos=rng.randint(0, L - 320), cigar=ops, seq=seq, qual=[rng.choice([40, 35, 31, 29, 12]) for _ in range(l)],
+                          nm=rng.choice([0, 1, 2]), mapq=42))
+    reads.sort(key=lambda r: r['pos'])
+    soa = H.reads_from_dicts(reads)
+    contig = H.single_contig(L, len(reads), "".join(rng.choice("ACGT") for _ in range(L)))
+    thr = abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, aln_cov=0.0, mapid=50.0))
+    st0, _, oc0, _, _ = c_oracle.pileup(thr, contig, soa)                  # the specification's rule: never an overrun here
+    assert st0 == 0
+    c_oracle.set_pad_rule(True)
+    path_ctx.set_pad_rule(abi.PAD_PYSAM)
+    try:
+        st, er, oc, oa, os_ = c_oracle.pileup(thr, contig, soa)
+        if st != 0:
+            assert st == abi.ERR_READ_CIGAR_OVERRUN
+            with pytest.raises(abi.MidasSnpsError) as ei:
+                path_ctx.pileup(thr, contig, soa)
+            assert (ei.value.status, ei.value.read_index) == (st, er)
+        else:
+            counts, allele, stats = path_ctx.pileup(thr, contig, soa)
+            assert np.array_equal(counts, oc) and np.array_equal(stats, os_)
+            assert not np.array_equal(oc, oc0)                               # the rule does change the table
+    finally:
+        c_oracle.set_pad_rule(False)
+        path_ctx.set_pad_rule(abi.PAD_SPEC)
+    counts, _, _ = path_ctx.pileup(thr, contig, soa)                        # and back: the specification's table again
+    assert np.array_equal(counts, oc0)

@@ -32,13 +32,17 @@ def _assert_same(ctx, thr, contigs, reads):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_hand_derived_cases_through_c_abi(hip_ctx, case):
     contigs, reads, thr, _ = H.kat_inputs(case)
-    if "error" in case:
-        with pytest.raises(abi.MidasSnpsError) as ei:
-            hip_ctx.pileup(thr, contigs, reads)
-        assert ei.value.status == case["error"]
-        assert ei.value.read_index == case.get("error_read", 0)
-        return
-    counts, allele, stats = hip_ctx.pileup(thr, contigs, reads)
+    hip_ctx.set_pad_rule(abi.PAD_PYSAM if H.kat_pysam_pad_rule(case) else abi.PAD_SPEC)
+    try:
+        if "error" in case:
+            with pytest.raises(abi.MidasSnpsError) as ei:
+                hip_ctx.pileup(thr, contigs, reads)
+            assert ei.value.status == case["error"]
+            assert ei.value.read_index == case.get("error_read", 0)
+            return
+        counts, allele, stats = hip_ctx.pileup(thr, contigs, reads)
+    finally:
+        hip_ctx.set_pad_rule(abi.PAD_SPEC)
     np.testing.assert_array_equal(counts, H.kat_expected_counts(case))
     np.testing.assert_array_equal(stats, H.kat_expected_stats(case))
 

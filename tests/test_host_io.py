@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from midas_amd import abi, bam, fasta, synth
+from midas_amd import abi, bam, fasta, synth, utility
 from midas_amd.run import snps as msnps
 from oracle import pileup_oracle as po
 from tests import helpers as H
@@ -332,3 +332,61 @@ def test_cpu_budget_is_the_quota_or_the_hardware(monkeypatch, tmp_path):
     assert utility.cpu_budget() == 8
     monkeypatch.setattr(builtins, 'open', fake("400000 100000\n"))
     assert utility.cpu_budget() == 1
+
+
+def test_native_cpu_budget_follows_the_same_rule_as_the_python_one():
+    """midas::cpu_budget (workers.h) and utility.cpu_budget: hardware threads, affinity mask, cgroup quota, LOCAL_WORLD_SIZE --
+    the same number in this process (the native one is computed once per process)."""
+    import os
+    lib = abi.load_library()
+    assert lib.midas_snps_cpu_budget() == utility.cpu_budget()
+    assert 1 <= lib.midas_snps_cpu_budget() <= (os.cpu_count() or 1)
+
+
+def test_a_throwing_region_leaves_the_worker_pool_usable(tmp_path):
+    """A parallel region that fails (here: a table that cannot be read) must not leave the pool marked as taken: the next
+    region runs on the pool again and gives the right answer."""
+    rng = np.random.default_rng(3)
+    n = 40000
+    counts = rng.integers(0, 50, size=(n, 4)).astype(np.uint32)
+    allele = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    good = str(tmp_path / "t.snps.gz")
+    abi.write_rows(good, False, "c1", allele, counts, gz_level=4, threads=4)
+    with pytest.raises(abi.MidasSnpsError):
+        abi.read_snps_table(str(tmp_path / "missing.snps.gz"))
+    for _ in range(3):
+        c2, keys, _ = abi.read_snps_table(good)
+        assert np.array_equal(c2, counts)
+    assert abi.count_snps_rows(good) == n
+
+
+def test_decoder_reads_a_bam_assembled_from_the_spec_tables():
+    """tests/golden/spec_fixture.bam was put together byte by byte from the SAM/BAM specification by
+    tests/golden/make_bam_fixture.py (struct + zlib only, nothing of midas_amd): records straddling BGZF blocks, NM in every
+    integer width behind B / Z / H / A / f tags, a record without NM, one without SEQ, QUAL absent, an unmapped record, the
+    EOF block.  The decoder must hand back exactly the literals the generator wrote down."""
+    import json
+    with open(os.path.join(H.GOLDEN, "spec_fixture.json")) as f:
+        exp = json.load(f)
+    names, lens, refid, reads = abi.read_bam(os.path.join(H.GOLDEN, "spec_fixture.bam"))
+    assert [[n, l] for n, l in zip(names, lens)] == exp["refs"]
+    recs = exp["records"]
+    assert reads.n_reads == len(recs) == 9                      # the unmapped record (refID -1) is not part of any contig's fetch
+    for i, r in enumerate(recs):
+        assert int(refid[i]) == r["refid"] and int(reads.pos[i]) == r["pos"] and int(reads.mapq[i]) == r["mapq"]
+        assert int(reads.flag[i]) == r["flag"] and int(reads.l_seq[i]) == len(r["seq"])
+        nm = 2147483647 if r["nm"] == "overflow" else r["nm"]   # an NM above int32 (aux type I) is carried as INT32_MAX
+        assert int(reads.nm[i]) == nm
+        cg = reads.cigar[reads.cigar_off[i]:reads.cigar_off[i + 1]].tolist()
+        assert cg == r["cigar"]
+        q = reads.qual[reads.qual_off[i]:reads.qual_off[i + 1]].tolist()
+        assert q == r["qual"]
+        s4 = reads.seq4[reads.seq_off[i]:reads.seq_off[i + 1]]
+        seq = "".join(H.NT16[(int(s4[j >> 1]) >> (0 if j & 1 else 4)) & 15] for j in range(len(r["seq"])))
+        assert seq == r["seq"]
+    # ... and the rank-local slice walk sees the same records (one slice: the whole file)
+    sl = abi.BamSlice(os.path.join(H.GOLDEN, "spec_fixture.bam"), 0, 1)
+    try:
+        assert int(sl.ref_reads.sum()) == 9
+    finally:
+        sl.close()

@@ -16,7 +16,11 @@ CASES = H.load_kat_cases()
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_c_oracle_matches_hand_derived(case):
     contigs, reads, thr, _ = H.kat_inputs(case)
-    st, err_read, counts, allele, stats = c_oracle.pileup(thr, contigs, reads)
+    c_oracle.set_pad_rule(H.kat_pysam_pad_rule(case))
+    try:
+        st, err_read, counts, allele, stats = c_oracle.pileup(thr, contigs, reads)
+    finally:
+        c_oracle.set_pad_rule(False)
     if "error" in case:
         assert st == case["error"]
         assert err_read == case.get("error_read", 0)
@@ -33,9 +37,11 @@ def test_python_oracle_matches_hand_derived(case):
     stats = {'aligned_reads': 0, 'mapped_reads': 0}
     kind_of = {"TypeError": None, "KeyError": po.ERR_NO_NM, "ZeroDivisionError": po.ERR_ZERO_ALIGN,
                "IndexError": po.ERR_CIGAR_OVERRUN}
+    po.set_pad_rule(H.kat_pysam_pad_rule(case))
     try:
         cc = po.count_coverage(alns, case["contig_len"], args['baseq'], lambda r: po.keep_read(r, args, stats))
     except po.PileupError as e:
+        po.set_pad_rule(False)
         assert "error" in case, "unexpected %s" % e
         exp = case["error"]
         if e.kind == "TypeError":
@@ -44,6 +50,7 @@ def test_python_oracle_matches_hand_derived(case):
             assert kind_of[e.kind] == exp
         assert e.read_index == case.get("error_read", 0)
         return
+    po.set_pad_rule(False)
     assert "error" not in case
     got = np.array(cc, dtype=np.uint32).T
     np.testing.assert_array_equal(got, H.kat_expected_counts(case))
