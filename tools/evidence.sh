@@ -4,27 +4,28 @@
 # bench command for configs[2] and configs[1].  Text summaries only land in gpurun_out/evidence/ (the rocpd databases are
 # tens of MiB each and are deleted here).   usage: tools/evidence.sh [tag]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV
 cd $REPO
 timeout 2400 python -m pytest tests -m gpu -x -q > $EV/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $EV/pytest_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $EV/smoke.log 2>&1
-timeout 1200 python bench.py > $EV/bench_n1_c3.json 2> $EV/bench_n1_c3.err
+timeout 1200 python bench.py --steps 20 --warmup 5 > $EV/bench_n1_c3.json 2> $EV/bench_n1_c3.err
 timeout 900 python bench.py --config c2 > $EV/bench_n1_c2.json 2> $EV/bench_n1_c2.err
 timeout 900 python bench.py --config c4_rank --no-cpu > $EV/bench_n1_c4rank.json 2> $EV/bench_n1_c4rank.err
-timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu > $EV/bench_torchrun_n1.json 2> $EV/bench_torchrun_n1.err
+timeout 1500 python bench.py --config c4 --no-cpu --no-pmc --steps 20 > $EV/bench_n1_c4_whole.json 2> $EV/bench_n1_c4_whole.err
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu --no-pmc > $EV/bench_torchrun_n1.json 2> $EV/bench_torchrun_n1.err
 prof() {   # prof <name> <bench args...>
   local name=$1; shift
   local out=$REPO/gpurun_out/prof_${TAG}_$name
   mkdir -p $out
   ( cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python $REPO/bench.py --no-cpu "$@" > $out/trace.log 2>&1
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_1 -o pmc -- python $REPO/bench.py --no-cpu --steps 10 --warmup 2 --pack-steps 3 "$@" > $out/pmc_1.log 2>&1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_2 -o pmc -- python $REPO/bench.py --no-cpu --steps 10 --warmup 2 --pack-steps 3 "$@" > $out/pmc_2.log 2>&1 )
-  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu $*   (then --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command with --steps 10 --pack-steps 3)"
-    grep '^{' $out/trace.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('# bench line of the profiled run: value %.4g %s, ms_per_step %.4f, kernel_ms_avg %.4f, frac %.3f' % (d['value'], d['unit'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac']))" 2>/dev/null
+    rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python $REPO/bench.py --no-cpu --no-pmc "$@" > $out/trace.log 2>&1
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_1 -o pmc -- python $REPO/bench.py --no-cpu --no-pmc --steps 10 --warmup 2 --sustain-seconds 0 "$@" > $out/pmc_1.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_2 -o pmc -- python $REPO/bench.py --no-cpu --no-pmc --steps 10 --warmup 2 --sustain-seconds 0 "$@" > $out/pmc_2.log 2>&1 )
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-pmc $*   (then --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command with --steps 10 --warmup 2 --sustain-seconds 0)"
+    grep '^{' $out/trace.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('# bench line of the profiled run: value %.4g %s, ms_per_step %.4f, step kernels %.4f ms (index pass %.4f + pileup %.4f), frac %.3f' % (d['value'], d['unit'], d['ms_per_step'], r['kernels_ms_avg'], r['index_pass_ms_avg'], r['pileup_kernel_ms_avg'], r['frac']))" 2>/dev/null
     python tools/summarize_prof.py $out | grep -v "^JSON"; } > $EV/${TAG}_${name}_rocprofv3_stats_pmc.txt 2>&1
   rm -rf $out
 }

@@ -31,10 +31,11 @@ def main():
         q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
              "where kernel_name like '%midas%' or kernel_name like '%merge_sites%' group by kernel_name, counter_name")
         for k, c, v, n in cur.execute(q):
-            m = re.search(r"(\w+_kernel)", k)
+            m = re.search(r"(\w+_kernel(?:<\w+>)?)", k)
             short = m.group(1) if m else k[:40]
             print("%-22s %-28s %18.1f  (n=%d)" % (short, c, v, n))
             out["pmc"].setdefault(short, {})[c] = v
+    step = [k for k in out["pmc"] if k.startswith(("direct_classify_kernel<true>", "direct_scan_kernel", "direct_fill_kernel", "pileup_direct_kernel"))]
     for k, d in out["pmc"].items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
@@ -46,6 +47,10 @@ def main():
             d["hbm_bytes_per_launch"] = rd + wr
             print("%-22s HBM traffic/launch: read %.1f MB (FETCH_SIZE KiB x1024 x2 gfx950 correction) + write %.1f MB = %.1f MB"
                   % (k, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+    if step and all("hbm_bytes_per_launch" in out["pmc"][k] for k in step):
+        tot = sum(out["pmc"][k]["hbm_bytes_per_launch"] for k in step)
+        out["direct_step_hbm_bytes"] = tot
+        print("%-22s HBM traffic/step (index pass: classify<true> + scan + fill, then pileup_direct_kernel): %.1f MB" % ("direct step", tot / 1e6))
     print()
     print("JSON:", json.dumps(out))
 
