@@ -185,6 +185,31 @@ __device__ void general_facts(const Fields& f, const CigarView& cg, uint32_t nc,
     }
     return true;
   });
+  // `H* S? (M|=|X)+ (I|D|N) (M|=|X)+ S? H*` with the query adding up -- one indel, most of what is not class 0 in an aligner's
+  // output: the two match runs are described in the descriptor itself (kGenInline), the pileup kernel never fetches the CIGAR.
+  // (A gap below the tile length cannot jump a whole tile: such a read's tiles are consecutive, the fill kernel never walks it.)
+  {
+    uint32_t stage = 0, lead = 0, trail = 0, m1 = 0, m2 = 0, ins = 0, del = 0;
+    bool ok = f.l >= 1 && f.l <= kMaxLSeq && nc >= 3u;
+    for_each_op(cg, nc, [&](uint32_t, uint32_t v) {
+      const uint32_t op = v & 15u, len = v >> 4;
+      if (len == 0u) ok = false;
+      else if (op == OP_H) { if (stage == 4u || stage == 5u) stage = 6u; else if (stage != 0u && stage != 6u) ok = false; }
+      else if (op == OP_S) { if (stage == 0u) { lead = len; stage = 1u; } else if (stage == 4u) { trail = len; stage = 5u; } else ok = false; }
+      else if (op_is_match(op)) {
+        if (stage <= 2u) { m1 += len; stage = 2u; } else if (stage == 3u || stage == 4u) { m2 += len; stage = 4u; } else ok = false;
+      } else if (op == OP_I || op == OP_D || op == OP_N) {
+        if (stage == 2u) { if (op == OP_I) ins = len; else del = len; stage = 3u; } else ok = false;
+      } else ok = false;
+      if (m1 > 1023u || m2 > 1023u) ok = false;
+      return ok;
+    });
+    if (ok && stage >= 4u && ins <= 1023u && del <= 4000u && lead + m1 + ins + m2 + trail == (uint32_t)f.l &&
+        d->align_len == m1 + ins + m2 && d->lead == lead) {
+      flags |= kGenInline;
+      d->co = (unsigned long long)(m1 | (ins << 10) | (del << 20));      // (in place of the CIGAR offset)
+    }
+  }
   d->flags = flags;
 }
 

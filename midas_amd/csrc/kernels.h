@@ -167,6 +167,8 @@ constexpr int kGenBodyWords = 12;                 // 48 bytes per general read: 
 // gdesc flag bits
 constexpr uint32_t kGenOverrun = 1;               // a match op maps a query position >= l_seq into the contig (IndexError if kept)
 constexpr uint32_t kGenNoNm = 2;                  // record has no NM tag
+constexpr uint32_t kGenInline = 4;                // two match runs around ONE I / D / N: the descriptor's CIGAR word holds the geometry
+                                                  // (first run | inserted << 10 | deleted or skipped << 20) -- no CIGAR is fetched
 constexpr uint32_t kGenIdle = 0x80;               // the sentinel descriptor [gdesc_capacity]: what a lane without an entry fetches
 
 constexpr int kDirectFactSlots = 64;

@@ -418,10 +418,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         const int nc = (int)(rd_cur.l_nc >> 16);
         const int align_len = (int)(rd_cur.a & 2047u);
         const uint32_t* cig = p.cigar + ((size_t)rd_cur.co_lo | ((size_t)((rd_cur.a >> 22) & 0xFFu) << 32));
-        // the CIGAR is not prefetched (it would cost eight registers of the double-buffered bases): only the few iterations at
-        // the end of a tile's stream come here
+        // A read with ONE indel between two match runs (kGenInline) carries its geometry in the descriptor: no CIGAR is fetched
+        // for it.  For anything else the first four ops come with one 16-byte load, issued here and first needed behind the
+        // filter (not prefetched: it would cost eight registers of the double-buffered bases).
+        const bool inl = (gflags & kGenInline) != 0u;
         uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u;
-        if (act && nc > 0) {
+        if (act && nc > 0 && !inl) {
           const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // (may overhang into the array's slack)
           cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
         }
@@ -454,7 +456,21 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         // position only below 4096, and both only ever grow.
         int k = 0, qpos = 0, jlo = 0, jhi = 0, loc0 = 0;
         const int q1 = q0 + nb;
+        const int lead_g = (int)((rd_cur.a >> 11) & 2047u);
+        const int in_m1 = (int)(rd_cur.co_lo & 1023u), in_ins = (int)((rd_cur.co_lo >> 10) & 1023u), in_del = (int)(rd_cur.co_lo >> 20);
         auto next_segment = [&]() -> bool {
+          if (inl) {       // the two runs: query [lead, lead + m1) at pos ..., query [lead + m1 + ins, lead + alen) at pos + m1 + del ...
+            while (k < 2) {
+              const int qa = k == 0 ? lead_g : lead_g + in_m1 + in_ins;
+              const int qb = k == 0 ? lead_g + in_m1 : lead_g + align_len;
+              const int roff = k == 0 ? 0 : in_m1 + in_del;
+              ++k;
+              const int lo = qa > q0 ? qa : q0;
+              const int hi = qb < q1 ? qb : q1;
+              if (lo < hi) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + roff + (q0 - qa); return true; }
+            }
+            return false;
+          }
           while (k < nc) {
             const uint32_t v = k < 4 ? (k == 0 ? cg0 : (k == 1 ? cg1 : (k == 2 ? cg2 : cg3))) : cig[k];
             ++k;
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
           const int lo = jlo > -loc0 ? jlo : -loc0;
           const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
           tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s);
-          walking = (walking && k < nc) ? next_segment() : false;
+          walking = (walking && k < (inl ? 2 : nc)) ? next_segment() : false;
         }
       }
       // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
