@@ -113,6 +113,15 @@ typedef struct midas_snps_contigs {
   const int32_t* species;     /* [n_contigs]   species index in [0, n_species)      */
   const int64_t* read_begin;  /* [n_contigs+1] non-decreasing, last == n_reads      */
   const uint8_t* ref;         /* [sum(length)]                                      */
+  /* NULL, or [n_contigs]: entry c is a PIECE of a longer contig, starting at its 0-based position origin[c] (0: the contig's
+   * start).  A long contig can then be piled up piece by piece -- on different GPUs -- and the pieces' tables concatenated
+   * (midas_snps_write_part takes the position its rows start at).  `length`, `ref` and the read positions are the piece's:
+   * pos is relative to origin[c] and NEGATIVE for a read that starts in front of the piece and reaches into it -- such a
+   * read is tallied where it covers the piece, but with origin[c] > 0 it is the PREVIOUS piece's read: it is not counted in
+   * aligned_reads / mapped_reads here and what keep_read would raise for it is not reported here (its own piece does both;
+   * a CIGAR that overruns SEQ at a site of THIS piece is reported here, where the walk meets it).
+   * count_coverage is called per contig at midas/run/snps.py:194-199; the split is this library's.                       */
+  const int64_t* origin;
 } midas_snps_contigs;
 
 /* Per-species counters, in this order (midas/run/snps.py:172-176, 211-213, 143, 161).
@@ -366,6 +375,15 @@ int32_t midas_snps_write_table(const char* path, int32_t n_contigs, const char* 
 int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
                               const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
                               int32_t gz_level, int32_t threads, char* err256);
+/* The same for entries that are PIECES of contigs (midas_snps_contigs.origin): entry k's first row is position
+ * first_pos[k] + 1 of ref_ids[k] (first_pos NULL: all 0).  A piece's members are cut every MIDAS_SNPS_ROWS_PER_MEMBER rows
+ * from its first row, so when every piece but a contig's last holds a multiple of that many rows the concatenated pieces
+ * are byte for byte the rows of the whole contig.  (midas_snps_batch_write_part does this by itself from the origins the
+ * batch was created with.)                                                                                          */
+#define MIDAS_SNPS_ROWS_PER_MEMBER 16384
+int32_t midas_snps_write_pieces(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
+                                const int64_t* n_sites, const int64_t* first_pos, const uint8_t* const* allele,
+                                const uint32_t* const* counts, int32_t gz_level, int32_t threads, char* err256);
 
 /* The count columns of SEVERAL samples' tables in one go: what the lock-step zip over the samples' files does in
  * build_temp_count_matrix (midas/merge/snps.py:236-271, one r[-4:] per sample and row).  _open reads all files (in

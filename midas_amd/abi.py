@@ -77,7 +77,7 @@ class _Reads(C.Structure):
 
 class _Contigs(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("n_species", C.c_int32), ("length", C.c_void_p),
-                ("species", C.c_void_p), ("read_begin", C.c_void_p), ("ref", C.c_void_p)]
+                ("species", C.c_void_p), ("read_begin", C.c_void_p), ("ref", C.c_void_p), ("origin", C.c_void_p)]
 
 
 class BatchInfo(C.Structure):
@@ -154,8 +154,11 @@ class ContigTable:
     n_species: int
     ids: list = field(default_factory=list)           # contig ids, table order
     species_ids: list = field(default_factory=list)   # species ids, index order
+    origin: Optional[np.ndarray] = None               # [n_contigs] int64 or None: the entries are pieces of longer contigs
 
     def __post_init__(self):
+        if self.origin is not None:
+            self.origin = np.ascontiguousarray(self.origin, dtype=np.int64)
         self.length = np.ascontiguousarray(self.length, dtype=np.int64)
         self.species = np.ascontiguousarray(self.species, dtype=np.int32)
         self.read_begin = np.ascontiguousarray(self.read_begin, dtype=np.int64)
@@ -177,7 +180,7 @@ class ContigTable:
     def _c(self) -> _Contigs:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         return _Contigs(self.n_contigs, int(self.n_species), p(self.length), p(self.species),
-                        self.read_begin.ctypes.data_as(C.c_void_p), p(self.ref))
+                        self.read_begin.ctypes.data_as(C.c_void_p), p(self.ref), p(self.origin) if self.origin is not None else None)
 
 
 _lib = None
@@ -252,6 +255,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_table_count_rows': (i32, [C.c_char_p, C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_table': (i32, [C.c_char_p, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_write_part': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, i32, i32, C.c_char_p]),
+        'midas_snps_write_pieces': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_deflate_rows': (i32, [vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]),
         'midas_snps_batch_write_part': (i32, [vp, C.c_char_p, i32, i32, vp, vp, i32, i32]),
         'midas_snps_tableset_open': (i32, [i32, vp, C.POINTER(vp), vp, C.c_char_p]),
@@ -290,7 +294,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
-    'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_deflate_rows',
+    'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
@@ -327,10 +331,14 @@ def write_rows(path: str, append: bool, ref_id: str, allele: np.ndarray, counts:
         raise MidasSnpsError(st, err.value.decode())
 
 
-def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 4, threads: int = 0, header=None):
+ROWS_PER_MEMBER = 16384     # MIDAS_SNPS_ROWS_PER_MEMBER: pieces of a contig start at multiples of this
+
+
+def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 4, threads: int = 0, header=None, first_pos=None):
     """Header + the rows of every contig of one species in one call (midas_snps_write_table): ref_ids[k],
     alleles[k] (u8[n_k]) and counts[k] (u32[n_k,4]) describe contig k in output order.  header = True / False writes a
-    PART of a species' table instead (midas_snps_write_part): with or without the header member in front."""
+    PART of a species' table instead (midas_snps_write_part): with or without the header member in front.  first_pos:
+    the entries are pieces of contigs, entry k's first row is position first_pos[k] + 1 (midas_snps_write_pieces)."""
     lib = load_library()
     n = len(ref_ids)
     al = [np.ascontiguousarray(a, dtype=np.uint8) for a in alleles]
@@ -341,7 +349,11 @@ def write_table(path: str, ref_ids, alleles, counts, gz_level: int = 4, threads:
     pa = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in al])
     pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in cn])
     err = C.create_string_buffer(256)
-    if header is None:
+    if first_pos is not None:
+        fp = (C.c_int64 * max(n, 1))(*[int(x) for x in first_pos])
+        st = lib.midas_snps_write_pieces(path.encode(), 1 if (header is None or header) else 0, n, ids, ns, fp, pa, pc,
+                                         int(gz_level), int(threads), err)
+    elif header is None:
         st = lib.midas_snps_write_table(path.encode(), n, ids, ns, pa, pc, int(gz_level), int(threads), err)
     else:
         st = lib.midas_snps_write_part(path.encode(), 1 if header else 0, n, ids, ns, pa, pc, int(gz_level), int(threads), err)

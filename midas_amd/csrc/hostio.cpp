@@ -1461,7 +1461,11 @@ namespace {
 // Rows of any number of contigs -> gzip members of kRows rows, formatted and deflated by a pool, written in order.
 int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const char* const* ref_ids,
                       const int64_t* n_sites, const uint8_t* const* allele, const uint32_t* const* counts,
-                      int32_t gz_level, int32_t threads, char* err256, bool header = true, const midas::RowFeed* feed = nullptr) {
+                      int32_t gz_level, int32_t threads, char* err256, bool header = true, const midas::RowFeed* feed = nullptr,
+                      const int64_t* first_pos = nullptr) {
+  // first_pos[k] (NULL: 0): entry k is a piece of its contig and its first row is position first_pos[k] + 1.  Members are cut
+  // every kRowsPerMember rows from the entry's first row, so pieces that start at multiples of kRowsPerMember produce the
+  // bytes the whole contig would.
   Lap lap("write rows");
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
@@ -1538,11 +1542,12 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
       row_at.resize((size_t)(ch.hi - ch.lo));
       tail_at.resize((size_t)(ch.hi - ch.lo));
       char* p = text.data();
+      const int64_t row0 = first_pos ? first_pos[ch.contig] : 0;
       for (int64_t i = ch.lo; i < ch.hi; ++i) {
         // row = [contig.id, i+1, seq[i], depth, A, C, G, T] joined by tabs (midas/run/snps.py:202-210)
         row_at[(size_t)(i - ch.lo)] = (uint32_t)(p - text.data());
         memcpy(p, id, il); p += il;
-        *p++ = '\t'; p = put_u64(p, (uint64_t)(i + 1));
+        *p++ = '\t'; p = put_u64(p, (uint64_t)(row0 + i + 1));
         tail_at[(size_t)(i - ch.lo)] = (uint32_t)(p - text.data());
         *p++ = '\t'; *p++ = (char)al[i];
         const uint32_t* c = cn + 4 * i;
@@ -1628,8 +1633,8 @@ int32_t write_contigs(const char* path, bool append, int32_t n_contigs, const ch
 }  // extern "C"
 namespace midas {
 int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
-                       int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256) {
-  return write_contigs(path, false, n_contigs, ref_ids, n_sites, nullptr, nullptr, gz_level, threads, err256, with_header, &feed);
+                       int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256, const int64_t* first_pos) {
+  return write_contigs(path, false, n_contigs, ref_ids, n_sites, nullptr, nullptr, gz_level, threads, err256, with_header, &feed, first_pos);
 }
 }  // namespace midas
 extern "C" {
@@ -1678,6 +1683,17 @@ int32_t midas_snps_write_part(const char* path, int32_t with_header, int32_t n_c
   for (int32_t k = 0; k < n_contigs; ++k)
     if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k]))) return MIDAS_SNPS_ERR_INVALID_ARG;
   return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256, with_header != 0);
+}
+
+int32_t midas_snps_write_pieces(const char* path, int32_t with_header, int32_t n_contigs, const char* const* ref_ids,
+                                const int64_t* n_sites, const int64_t* first_pos, const uint8_t* const* allele,
+                                const uint32_t* const* counts, int32_t gz_level, int32_t threads, char* err256) {
+  if (!path || n_contigs < 0 || (n_contigs > 0 && (!ref_ids || !n_sites || !allele || !counts)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  for (int32_t k = 0; k < n_contigs; ++k)
+    if (!ref_ids[k] || n_sites[k] < 0 || (n_sites[k] > 0 && (!allele[k] || !counts[k])) || (first_pos && first_pos[k] < 0))
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+  return write_contigs(path, false, n_contigs, ref_ids, n_sites, allele, counts, gz_level, threads, err256, with_header != 0, nullptr, first_pos);
 }
 
 int32_t midas_merge_write_matrix(const char* path, const char* header_line, int64_t n_keep, const int64_t* keep,

@@ -18,6 +18,6 @@ struct RowFeed {
 };
 
 int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
-                       int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256);
+                       int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256, const int64_t* first_pos = nullptr);
 
 }  // namespace midas

@@ -100,7 +100,7 @@ struct Tile {               // 32 bytes
   int32_t species;
   int64_t site_base;        // index of `start` in the concatenated site space
   int32_t contig_len;
-  int32_t pad;
+  int32_t halo;             // 1: the contig entry is a piece with origin > 0 -- a read with pos < 0 belongs to the piece before it
 };
 static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 

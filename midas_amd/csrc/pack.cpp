@@ -502,6 +502,10 @@ int32_t validate_contigs(const midas_snps_contigs* c, int64_t n_reads, int64_t* 
       set_err(err256, "read_begin not monotone at contig %lld", i);
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
+    if (c->origin && (c->origin[i] < 0 || c->origin[i] + c->length[i] > 0x7FFFFFFFLL)) {
+      set_err(err256, "contig %lld: piece origin %lld out of range", i, c->origin[i]);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
     sites += c->length[i];
   }
   if (c->n_contigs > 0 && (c->read_begin[0] != 0 || c->read_begin[c->n_contigs] != n_reads)) {

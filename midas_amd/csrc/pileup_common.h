@@ -111,7 +111,7 @@ __device__ __forceinline__ Tile load_tile(ConstWords tiles, int t) {
   Tile x;
   x.contig = (int32_t)w[0]; x.start = (int32_t)w[1]; x.len = (int32_t)w[2]; x.species = (int32_t)w[3];
   x.site_base = (int64_t)((unsigned long long)w[4] | ((unsigned long long)w[5] << 32));
-  x.contig_len = (int32_t)w[6]; x.pad = 0;
+  x.contig_len = (int32_t)w[6]; x.halo = (int32_t)w[7];
   return x;
 }
 

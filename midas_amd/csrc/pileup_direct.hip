@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
         // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
         int cpos = pos < 0 ? 0 : pos;
         cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-        owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+        owner = act && cpos >= tile_start && cpos < tile_start + tile_len && !(tile.halo && pos < 0);
         const int rel = pos - tile_start;                                     // may wrap for absurd positions:
         int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // those are parked far right
         // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time ------------------------
@@ -503,7 +503,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       const bool head = owner && c == 0;
       w_aligned += (uint32_t)__popcll(__ballot(head));
       w_mapped += (uint32_t)__popcll(__ballot(head && keep));
-      if (head && err) {     // (the read's index: its place in the range, or the entry's word of gidx)
+      // (a read of the piece in front, midas_snps_contigs.origin: its own piece reports what keep_read raises, this one the
+      // overrun its walk runs into here)
+      const bool walk_err = gen_cur && tile.halo && pos < 0 && c == 0 && err == (uint32_t)E_CIGAR_OVERRUN;
+      if ((head && err) || walk_err) {     // (the read's index: its place in the range, or the entry's word of gidx)
         const uint32_t idx = gen_cur ? p.gidx[(size_t)(st.gb + (it - st.na) * rpw + g)] : (uint32_t)(st.rb + it * rpw + g);
         atomicMin(p.err, ((unsigned long long)idx << 8) | err);
       }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
       int cpos = pos < 0 ? 0 : pos;
       cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-      const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len;
+      const bool owner = act && cpos >= tile_start && cpos < tile_start + tile_len && !(tile.halo && pos < 0);
       // position of the read relative to the tile; a read that can never reach the tile is parked far right
       // (reference positions only grow along a CIGAR, so "far right" stays far right)
       const int rel = pos - tile_start;   // pos >= -1, tile_start >= 0: fits an int
@@ -413,7 +413,10 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
       const unsigned long long m_mp = __ballot(head && keep);
       w_aligned += (uint32_t)__popcll(m_al);
       w_mapped += (uint32_t)__popcll(m_mp);
-      if (head && err)   // input-order index of the record
+      // (a read of the piece in front, midas_snps_contigs.origin: its own piece reports what keep_read raises, this one the
+      // overrun its walk runs into here)
+      const bool walk_err = act && tile.halo && pos < 0 && c == 0 && err == (uint32_t)E_CIGAR_OVERRUN;
+      if ((head && err) || walk_err)   // input-order index of the record
         atomicMin(p.err, ((unsigned long long)p.orig[read_at(rg, vpos)] << 8) | err);
       }   // general path
 

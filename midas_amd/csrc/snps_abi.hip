@@ -58,6 +58,7 @@ struct midas_snps_batch {
   PackParams pk;                      // every pointer of a pack, filled once the buffers exist
   uint32_t* h_tile_reads = nullptr;   // pinned: reads every tile will see, fetched once per pack for the hot-spot plan
   std::vector<int64_t> h_contig_site; // [n_contigs + 1] first site of every contig in d_counts / d_allele
+  std::vector<int64_t> h_origin;      // [n_contigs] midas_snps_contigs.origin, empty when it was NULL
   std::vector<uint32_t> h_items;      // the work items last uploaded
   int64_t pack_count = 0;
   // device: the packed layout (layout.h)
@@ -967,7 +968,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
         t.species = contigs->species[c];
         t.site_base = site + x;
         t.contig_len = (int32_t)len;
-        t.pad = 0;
+        t.halo = (contigs->origin && contigs->origin[c] > 0) ? 1 : 0;
         tiles.push_back(t);
       }
       site += len;
@@ -976,6 +977,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     rbeg[contigs->n_contigs] = (int32_t)n;
     b->h_contig_site.assign((size_t)contigs->n_contigs + 1, 0);
     for (int32_t c = 0; c < contigs->n_contigs; ++c) b->h_contig_site[(size_t)c + 1] = b->h_contig_site[(size_t)c] + contigs->length[c];
+    if (contigs->origin) b->h_origin.assign(contigs->origin, contigs->origin + contigs->n_contigs);
   }
   b->n_tiles = (int64_t)tiles.size();
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
@@ -1341,12 +1343,13 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
   int32_t st = midas_snps_batch_sync(b);
   if (st != MIDAS_SNPS_OK) return st;
   if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part before batch_run");
-  std::vector<int64_t> n_sites((size_t)n_contigs), src((size_t)n_contigs);
+  std::vector<int64_t> n_sites((size_t)n_contigs), src((size_t)n_contigs), first((size_t)n_contigs, 0);
   for (int32_t k = 0; k < n_contigs; ++k) {
     const int32_t c = contig_index[k];
     if (c < 0 || c >= b->n_contigs || !ref_ids[k]) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part: contig index out of range");
     src[(size_t)k] = b->h_contig_site[(size_t)c];
     n_sites[(size_t)k] = b->h_contig_site[(size_t)c + 1] - b->h_contig_site[(size_t)c];
+    if (!b->h_origin.empty()) first[(size_t)k] = b->h_origin[(size_t)c];     // a piece's rows carry the contig's positions
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
@@ -1354,7 +1357,7 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
   BatchFeed user{b, (int64_t)(kFeedSlotBytes / 17 / (size_t)kRowsPerMember) * kRowsPerMember};
   RowFeed feed{src.data(), user.slab_sites, midas_snps_ctx::kStageSlots * kFeedSlotsPerStage, &user, batch_feed_fetch};
   char err[256] = {0};
-  st = write_rows_fed(path, with_header != 0, n_contigs, ref_ids, n_sites.data(), gz_level, threads, feed, err);
+  st = write_rows_fed(path, with_header != 0, n_contigs, ref_ids, n_sites.data(), gz_level, threads, feed, err, first.data());
   if (user.err != hipSuccess) return hip_fail(ctx, user.err, "batch_write_part: results to host");
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
   return MIDAS_SNPS_OK;

@@ -112,8 +112,13 @@ int32_t midas_oracle_pileup(const midas_snps_thresholds* thr, const midas_snps_c
       const int64_t n_cigar = reads->cigar_off[r + 1] - reads->cigar_off[r];
       const uint8_t* qual = reads->qual + reads->qual_off[r];
       const uint8_t* seq4 = reads->seq4 + reads->seq_off[r];
-      int k = keep_read(thr, l_seq, cig, n_cigar, reads->nm[r], qual, reads->mapq[r], &rs);
+      /* a piece of a longer contig (midas_snps_contigs.origin): a read that starts in front of it is the previous piece's --
+       * tallied here where it reaches in, counted there; what keep_read raises is reported there, a walk that overruns here, here */
+      const int halo = contigs->origin && contigs->origin[c] > 0 && reads->pos[r] < 0;
+      read_stats scratch = {0, 0};
+      int k = keep_read(thr, l_seq, cig, n_cigar, reads->nm[r], qual, reads->mapq[r], halo ? &scratch : &rs);
       if (k < 0) {
+        if (halo) continue;
         if (err_read) *err_read = r;
         return -k;
       }
@@ -127,7 +132,7 @@ int32_t midas_oracle_pileup(const midas_snps_thresholds* thr, const midas_snps_c
           for (int64_t i = 0; i < len; ++i) {
             const int64_t q = qpos + i, refpos = rpos + i;
             if (refpos >= 0 && refpos < length) {
-              if (q >= l_seq) {
+              if (q >= l_seq) {        /* (reported for a halo read too: this is where its walk fails) */
                 if (err_read) *err_read = r;
                 return MIDAS_SNPS_ERR_READ_CIGAR_OVERRUN;
               }
