@@ -346,6 +346,19 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
 int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256);
 int32_t midas_bam_slice_facts(const midas_bam* bam, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases,
                               int64_t* ref_first);
+/* What the walk of midas_bam_open_slice noted for cutting LONG references into pieces (midas_snps_contigs.origin), so that a
+ * rank that owns a piece of a 20 Mb contig inflates that piece's records and not the contig's:
+ *   out4     = {positions non-decreasing inside every reference so far (0/1), position of the slice's first and of its last
+ *               mapped record (-1: none), number of marks};
+ *   ref_span   [n_ref] the longest stretch of reference a record of that reference covers (M, D, N, =, X lengths summed): a
+ *               piece that starts at `lo` needs the records from position lo - max-over-slices(ref_span) on;
+ *   marks      [3 * n] {refID, bin, offset}: offset (uncompressed stream) of the first record of refID whose position is in
+ *               [bin, bin + 1) * MIDAS_BAM_MARK_SPAN or, when that bin has none, in a later bin -- listed whenever the bin
+ *               goes up, bin > 0 only (bin 0 is ref_first).  With positions sorted, every record of refID at a position >=
+ *               bin * MIDAS_BAM_MARK_SPAN lies at or behind the smallest such offset over the slices.
+ * marks may be NULL (ask for the count first); marks_capacity is in marks.                                               */
+#define MIDAS_BAM_MARK_SPAN 65536
+int32_t midas_bam_slice_marks(const midas_bam* bam, int64_t* out4, int64_t* ref_span, int64_t* marks, int64_t marks_capacity);
 int32_t midas_bam_load_ranges(midas_bam* bam, int32_t n_ranges, const int64_t* range_begin, const int64_t* range_end,
                               int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256);
 

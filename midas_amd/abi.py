@@ -247,6 +247,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_columns': (i32, [vp, vp]),
         'midas_bam_open_slice': (i32, [C.c_char_p, i32, i32, C.POINTER(vp), C.c_char_p]),
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
+        'midas_bam_slice_marks': (i32, [vp, vp, vp, vp, C.c_int64]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
         'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, C.c_char_p]),
@@ -293,7 +294,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
-    'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_load_ranges',
+    'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
@@ -565,6 +566,18 @@ class BamSlice:
         p = lambda x: x.ctypes.data_as(C.c_void_p)
         self._lib.midas_bam_slice_facts(h, p(out7), p(self.ref_reads), p(self.ref_bases), p(self.ref_first))
         (self.first, self.end, self.sorted, self.first_ref, self.last_ref, self.rec_begin, self.total) = (int(x) for x in out7)
+
+    def marks(self):
+        """(pos_sorted, first_pos, last_pos, ref_span int64 [n_ref], marks int64 [n, 3] = refID, bin, offset): what a
+        contig needs to be cut into pieces (midas_bam_slice_marks)."""
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        out4 = np.zeros(4, np.int64)
+        span = np.zeros(len(self.ref_names), np.int64)
+        self._lib.midas_bam_slice_marks(self._h, p(out4), p(span), None, 0)
+        marks = np.zeros((int(out4[3]), 3), np.int64)
+        if marks.size:
+            self._lib.midas_bam_slice_marks(self._h, p(out4), None, p(marks), marks.shape[0])
+        return int(out4[0]), int(out4[1]), int(out4[2]), span, marks
 
     def load_ranges(self, ranges):
         """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order."""

@@ -85,6 +85,12 @@ struct midas_bam {
   int64_t slice_first = -1, slice_end = -1;   // uncompressed offsets: first record starting in the slice / first one behind it
   int32_t slice_sorted = 1, slice_first_ref = -1, slice_last_ref = -1;
   std::vector<int64_t> ref_reads, ref_bases, ref_first;
+  // for cutting long references into pieces (midas_bam_slice_marks): positions sorted inside every reference so far, the
+  // first / last record's position, every reference's longest read span on it, and {refID, pos / MIDAS_BAM_MARK_SPAN,
+  // offset} of the first record of every (reference, position bin > 0) met
+  int32_t slice_pos_sorted = 1;
+  int64_t slice_first_pos = -1, slice_last_pos = -1;
+  std::vector<int64_t> ref_span, marks;
   std::string path;
   std::vector<std::string> ref_names;
   std::vector<int64_t> ref_lens;
@@ -943,6 +949,7 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
   b->ref_reads.assign(n_ref, 0);
   b->ref_bases.assign(n_ref, 0);
   b->ref_first.assign(n_ref, -1);
+  b->ref_span.assign(n_ref, 0);
   // this slice's blocks: those whose file offset falls into its share of the file's bytes
   auto first_block_at = [&](size_t fpos) {
     size_t lo = 0, hi = nb;
@@ -966,6 +973,7 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
   uint64_t u = u_lo == rec_begin ? rec_begin : (uint64_t)guess_record_start(w, u_lo, b->ref_lens, 32);
   b->slice_first = (int64_t)u;
   int32_t prev_ref = -1;
+  int64_t prev_pos = -1, mark_bin = 0;
   bool seen_unmapped = false;
   while (u < u_hi && u < m.total) {
     uint32_t bs = 0;
@@ -977,9 +985,31 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
     const int32_t refid = (int32_t)rd32(r + 4);
     if (refid >= 0) {
       if (seen_unmapped || refid < prev_ref) b->slice_sorted = 0;
-      if (b->slice_first_ref < 0) b->slice_first_ref = refid;
+      const int64_t pos = (int32_t)rd32(r + 8);
+      if (refid == prev_ref && pos < prev_pos) b->slice_pos_sorted = 0;
+      if (b->slice_first_ref < 0) { b->slice_first_ref = refid; b->slice_first_pos = pos; }
       b->slice_last_ref = refid;
+      b->slice_last_pos = pos;
+      if (refid != prev_ref) mark_bin = 0;
       prev_ref = refid;
+      prev_pos = pos;
+      {   // reference span: the lengths of the ops that consume reference (M, D, N, =, X)
+        const uint32_t l_name = r[12], n_cig = rd16(r + 16);
+        int64_t span = 0;
+        if (36ull + l_name + 4ull * n_cig <= 4ull + bs) {
+          const uint8_t* cg = r + 36 + l_name;
+          for (uint32_t k = 0; k < n_cig; ++k) {
+            const uint32_t v = rd32(cg + 4 * k), op = v & 15u;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
+          }
+        }
+        if (span > b->ref_span[refid]) b->ref_span[refid] = span;
+      }
+      const int64_t bin = pos > 0 ? pos / MIDAS_BAM_MARK_SPAN : 0;
+      if (bin > mark_bin) {
+        b->marks.push_back(refid); b->marks.push_back(bin); b->marks.push_back((int64_t)u);
+        mark_bin = bin;
+      }
       b->ref_reads[refid] += 1;
       b->ref_bases[refid] += (int64_t)rd32(r + 20);
       if (b->ref_first[refid] < 0) b->ref_first[refid] = (int64_t)u;
@@ -1001,6 +1031,18 @@ int32_t midas_bam_slice_facts(const midas_bam* b, int64_t* out7, int64_t* ref_re
   if (ref_reads) memcpy(ref_reads, b->ref_reads.data(), n * 8);
   if (ref_bases) memcpy(ref_bases, b->ref_bases.data(), n * 8);
   if (ref_first) memcpy(ref_first, b->ref_first.data(), n * 8);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_slice_marks(const midas_bam* b, int64_t* out4, int64_t* ref_span, int64_t* marks, int64_t marks_capacity) {
+  if (!b || !b->map || !out4) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const int64_t n = (int64_t)(b->marks.size() / 3);
+  out4[0] = b->slice_pos_sorted; out4[1] = b->slice_first_pos; out4[2] = b->slice_last_pos; out4[3] = n;
+  if (ref_span) memcpy(ref_span, b->ref_span.data(), b->ref_span.size() * 8);
+  if (marks) {
+    if (marks_capacity < n) return MIDAS_SNPS_ERR_INVALID_ARG;
+    memcpy(marks, b->marks.data(), (size_t)n * 24);
+  }
   return MIDAS_SNPS_OK;
 }
 

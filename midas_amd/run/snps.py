@@ -24,7 +24,7 @@ from time import time
 
 import numpy as np
 
-from midas_amd import abi, bam, dist, fasta, utility
+from midas_amd import abi, bam, dist, fasta, pieces, utility
 
 
 # zlib level of <species>.snps.gz.  The reference writes level 9 (gzip.open's default, midas/utility.py:194-206); the
@@ -32,6 +32,7 @@ from midas_amd import abi, bam, dist, fasta, utility
 # writer thread: level 9 0.2, 6 0.5, 4 1.7, 1 2.5 M rows/s for 28.5 / 29.0 / 30.4 / 34.5 MB -- 4 costs 5 % of file size and
 # takes the formatter from the largest to the second smallest item of the stage.
 GZ_LEVEL = 4
+SPLIT_LENGTH = 8 << 20      # contigs longer than this are dealt to the ranks in pieces (args['split_length']; 0: never)
 
 
 class Species:
@@ -194,10 +195,14 @@ def _exit_on(e):
     raise e
 
 
-def _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads):
-    """(ContigTable, ReadsSoA) for the given Contig objects: contigs in BAM header order, reads regrouped to match."""
+def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid, reads, halo=None):
+    """(ContigTable, ReadsSoA, keys) for the given work items -- (contig id, piece number), span[item] = (lo, hi, last):
+    contigs in BAM header order (pieces of one contig in position order), reads regrouped to match; keys[k] = the item of
+    table entry k.  Whole contigs only: the table of the reference's loop (midas/run/snps.py:187-199); with pieces the
+    entries carry their origin and the reads in front of a piece that reach into it (midas_amd/pieces.py)."""
     sp_index = {s: i for i, s in enumerate(species_ids)}
     order = {n: i for i, n in enumerate(ref_names)}
+    mine = [contigs[cid] for cid in sorted({cid for cid, _ in items})]
     missing = [c.id for c in mine if c.id not in order]
     # a contig that is not in the BAM header: pysam would raise on count_coverage(contig.id, ...)
     if missing:
@@ -209,11 +214,21 @@ def _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads):
                      % (c.id, ref_lens[order[c.id]], c.length))
     ids = [c.id for c in mine]
     sub, read_begin = bam.group_by_contig(ref_names, refid, reads, ids)
-    ref = np.frombuffer(''.join(c.seq for c in mine).encode('latin-1'), dtype=np.uint8)
-    table = abi.ContigTable(length=[c.length for c in mine], species=[sp_index[c.species_id] for c in mine],
-                            read_begin=read_begin, ref=ref, n_species=len(species_ids), ids=ids,
-                            species_ids=list(species_ids))
-    return table, sub
+    if all(span[it][0] == 0 and span[it][2] for it in items):
+        ref = np.frombuffer(''.join(c.seq for c in mine).encode('latin-1'), dtype=np.uint8)
+        table = abi.ContigTable(length=[c.length for c in mine], species=[sp_index[c.species_id] for c in mine],
+                                read_begin=read_begin, ref=ref, n_species=len(species_ids), ids=ids,
+                                species_ids=list(species_ids))
+        return table, sub, [(c.id, 0) for c in mine]
+    at = {c.id: k for k, c in enumerate(mine)}
+    keys = sorted(items, key=lambda it: (at[it[0]], it[1]))
+    plan = [(at[cid], span[(cid, j)][0], span[(cid, j)][1], span[(cid, j)][2], int(halo[cid]) if halo else 0) for cid, j in keys]
+    sub, read_begin = pieces.gather(sub, read_begin, plan)
+    ref = np.frombuffer(''.join(mine[k].seq[lo:hi] for k, lo, hi, _, _ in plan).encode('latin-1'), dtype=np.uint8)
+    table = abi.ContigTable(length=[hi - lo for _, lo, hi, _, _ in plan], species=[sp_index[mine[k].species_id] for k, *_ in plan],
+                            read_begin=read_begin, ref=ref, n_species=len(species_ids), ids=[cid for cid, _ in keys],
+                            species_ids=list(species_ids), origin=[lo for _, lo, _, _, _ in plan])
+    return table, sub, keys
 
 
 def _species_contig_order(species_ids, contigs):
@@ -231,32 +246,41 @@ def _part_path(args, species_id, k):
     return '%s/snps/output/%s.snps.gz.part%06d' % (args['outdir'], species_id, k)
 
 
-def _write_rows(args, path, table, pos, cids, counts, allele, off, header, batch=None):
-    ks = [pos[cid] for cid in cids]
+def _write_rows(args, path, table, pos, items, counts, allele, off, header, batch=None):
+    """The rows of the work items `items` (table entries pos[item]), in that order."""
+    ks = [pos[it] for it in items]
+    cids = [it[0] for it in items]
     level, threads = int(args.get('gz_level', GZ_LEVEL)), int(args.get('threads', 1) or 1)
-    if batch is not None:
+    if batch is not None:       # (the batch numbers a piece's rows from its origin by itself)
         batch.write_part(path, ks, cids, header=header is None or bool(header), gz_level=level, threads=threads)
         return
+    first = [int(table.origin[k]) for k in ks] if table.origin is not None else None
     abi.write_table(path, cids, [allele[off[k]:off[k + 1]] for k in ks], [counts[off[k]:off[k + 1]] for k in ks],
-                    gz_level=level, threads=threads, header=header)
+                    gz_level=level, threads=threads, header=header, first_pos=first)
 
 
 def _write_species(args, species_id, table, counts, allele):
     """<outdir>/snps/output/<species>.snps.gz of ONE species whose contigs are all in `table` -- header + rows in
     sorted(contig id) order (midas/run/snps.py:179-182, 187-192, 201-210), formatted and gzipped by the native writer."""
     sp = table.species_ids.index(species_id)
-    pos = {cid: k for k, cid in enumerate(table.ids)}
-    cids = sorted(cid for cid, k in pos.items() if table.species[k] == sp)   # (a species without contigs: header only)
+    pos = {(cid, 0): k for k, cid in enumerate(table.ids)}
+    cids = sorted(it for it, k in pos.items() if table.species[k] == sp)   # (a species without contigs: header only)
     _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], species_id), table, pos, cids, counts, allele,
                 table.site_offsets(), None)
 
 
-def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
-    """count_coverage + keep_read + emit for the contigs `mine` on one GPU.  Returns {species_id: partial aln_stats}
-    (sums over this rank's contigs).  Writes <species>.snps.gz directly when this rank owns every contig of the
-    species, else one part file per run of consecutive (sorted order) contigs it owns."""
+def _whole(order, contigs):
+    """Every contig one work item: ({species: [(contig id, 0)]}, {item: (0, length, True)})."""
+    items = {sp: [(cid, 0) for cid in cids] for sp, cids in order.items()}
+    return items, {(cid, 0): (0, contigs[cid].length, True) for cids in order.values() for cid in cids}
+
+
+def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, contigs, halo=None):
+    """count_coverage + keep_read + emit for the work items `mine` (contigs, or pieces of long ones) on one GPU.  Returns
+    {species_id: partial aln_stats} (sums over this rank's items).  Writes <species>.snps.gz directly when this rank owns
+    every item of the species, else one part file per run of consecutive (emit order) items it owns."""
     ref_names, ref_lens, refid, reads = decoded
-    table, sub = _contig_table(species_ids, mine, ref_names, ref_lens, refid, reads)
+    table, sub, keys = _contig_table(species_ids, mine, span, contigs, ref_names, ref_lens, refid, reads, halo)
     thr = abi.Thresholds.from_args(args)
     batch = None
     if mine and hasattr(ctx, 'batch'):
@@ -276,17 +300,17 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx):
         counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
         stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)
     try:
-        return _emit_contigs(args, species_ids, table, order, owner, counts, allele, stats, batch)
+        return _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, stats, batch)
     finally:
         if batch is not None:
             batch.close()
 
 
-def _emit_contigs(args, species_ids, table, order, owner, counts, allele, stats, batch):
+def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, stats, batch):
     """The rows and the partial counters of _pileup_contigs, from host arrays or (batch) from the device results."""
     rank, _ = dist.world()
     genome_length = np.bincount(table.species, weights=table.length, minlength=len(species_ids)).astype(np.int64)
-    pos = {cid: k for k, cid in enumerate(table.ids)}
+    pos = {it: k for k, it in enumerate(keys)}
     off = table.site_offsets()
     out = {}
     for i, sp in enumerate(species_ids):
@@ -316,8 +340,8 @@ def _emit_contigs(args, species_ids, table, order, owner, counts, allele, stats,
 
 
 def _join_parts(args, species_ids, order, owner, rank):
-    """Species whose contigs were spread over ranks: concatenate the parts in sorted-contig order into
-    <species>.snps.gz.  Done by the rank that owns the species' first contig (it wrote the header)."""
+    """Species whose work items were spread over ranks: concatenate the parts in emit order (sorted contigs, a contig's
+    pieces by position) into <species>.snps.gz.  Done by the rank that owns the species' first item (it wrote the header)."""
     for sp in species_ids:
         cids = order[sp]
         if not cids or len({owner.get(c, 0) for c in cids}) <= 1 or owner.get(cids[0], 0) != rank:
@@ -336,12 +360,11 @@ def _join_parts(args, species_ids, order, owner, rank):
 def species_pileup(args, species_id, contigs):
     """midas/run/snps.py:164-216 for ONE species on GPU 0: writes <species>.snps.gz, returns (species_id, aln_stats)."""
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
-    order = _species_contig_order([species_id], contigs)
-    mine = [contigs[c] for c in order[species_id]]
+    order, span = _whole(_species_contig_order([species_id], contigs), contigs)
     try:
         decoded = abi.read_bam(bampath)
         with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
-            stats = _pileup_contigs(args, [species_id], mine, order, {}, decoded, ctx)
+            stats = _pileup_contigs(args, [species_id], order[species_id], order, {}, decoded, ctx, span, contigs)
     except abi.MidasSnpsError as e:
         _exit_on(e)
     return (species_id, stats[species_id])
@@ -361,44 +384,87 @@ def _rank_local_plan(bampath, rank, ws):
         error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
     dist.agree_or_exit(error)
     n_ref = len(sl.ref_names)
-    mine = np.concatenate([np.array([sl.first, sl.end, sl.sorted, sl.first_ref, sl.last_ref, sl.rec_begin, sl.total, n_ref], np.int64),
-                           sl.ref_reads, sl.ref_bases, sl.ref_first])
+    pos_sorted, first_pos, last_pos, span, marks = sl.marks()
+    H = 12
+    mine = np.concatenate([np.array([sl.first, sl.end, sl.sorted, sl.first_ref, sl.last_ref, sl.rec_begin, sl.total, n_ref,
+                                     pos_sorted, first_pos, last_pos, marks.shape[0]], np.int64),
+                           sl.ref_reads, sl.ref_bases, sl.ref_first, span])
     allv = dist.all_gather_i64(mine)
-    head = allv[:, :8]
+    head = allv[:, :H]
     ok = bool((head[:, 7] == n_ref).all() and (head[:, 2] == 1).all() and head[0, 0] == head[0, 5] and head[-1, 1] == head[0, 6])
-    last_ref = -1
+    last_ref, last_at = -1, -1
+    in_order = bool((head[:, 8] == 1).all())      # positions inside every reference: needed only to cut long contigs
     for r in range(ws):
         if r + 1 < ws and head[r, 1] != head[r + 1, 0]:
             ok = False
         if head[r, 3] >= 0:
             if head[r, 3] < last_ref:
                 ok = False
-            last_ref = head[r, 4]
+            if head[r, 3] == last_ref and head[r, 9] < last_at:
+                in_order = False
+            last_ref, last_at = head[r, 4], head[r, 10]
     if not ok:
         sl.close()
         return None
-    reads_per = allv[:, 8:8 + n_ref].sum(axis=0)
-    bases_per = allv[:, 8 + n_ref:8 + 2 * n_ref].sum(axis=0)
-    firsts = allv[:, 8 + 2 * n_ref:8 + 3 * n_ref]
+    reads_per = allv[:, H:H + n_ref].sum(axis=0)
+    bases_per = allv[:, H + n_ref:H + 2 * n_ref].sum(axis=0)
+    firsts = allv[:, H + 2 * n_ref:H + 3 * n_ref]
     ref_first = np.where(firsts >= 0, firsts, np.iinfo(np.int64).max).min(axis=0)
     ref_first[reads_per == 0] = -1
-    return dict(slice=sl, ref_names=sl.ref_names, ref_lens=sl.ref_lens, ref_reads=reads_per, ref_bases=bases_per.astype(np.float64),
-                ref_first=ref_first, total=int(head[0, 6]))
-
-
-def _record_ranges(plan, ref_ids):
-    """Uncompressed [begin, end) record ranges of the given references: from a reference's first record to the first
-    record of the next reference that has any (the file is coordinate-sorted: _rank_local_plan checked), merged."""
-    first = plan['ref_first']
-    have = np.nonzero(first >= 0)[0]
-    nxt = {}
+    ref_span = allv[:, H + 3 * n_ref:H + 4 * n_ref].max(axis=0)
+    # the marks of every slice (a second, padded all-gather): per (reference, bin) the smallest offset
+    n_marks = int(head[:, 11].max())
+    pad = np.full((n_marks, 3), -1, np.int64)
+    pad[:marks.shape[0]] = marks
+    allm = dist.all_gather_i64(pad.reshape(-1)).reshape(-1, 3) if n_marks else pad
+    allm = allm[allm[:, 0] >= 0]
+    key = (allm[:, 0] << 32) | allm[:, 1]
+    o = np.lexsort((allm[:, 2], key))
+    key, off = key[o], allm[o, 2]
+    firstk = np.ones(key.size, bool)
+    firstk[1:] = key[1:] != key[:-1]
+    # where every reference's records end: at the first record of the next reference that has any
+    have = np.nonzero(ref_first >= 0)[0]
+    ref_end = np.full(n_ref, -1, np.int64)
     for k, r in enumerate(have):
-        nxt[int(r)] = int(first[have[k + 1]]) if k + 1 < len(have) else plan['total']
-    ranges = sorted((int(first[r]), nxt[int(r)]) for r in ref_ids if first[r] >= 0)
+        ref_end[r] = int(ref_first[have[k + 1]]) if k + 1 < len(have) else int(head[0, 6])
+    return dict(slice=sl, ref_names=sl.ref_names, ref_lens=sl.ref_lens, ref_reads=reads_per, ref_bases=bases_per.astype(np.float64),
+                ref_first=ref_first, ref_end=ref_end, total=int(head[0, 6]), pos_sorted=in_order, ref_span=ref_span,
+                mark_key=key[firstk], mark_off=off[firstk])
+
+
+def _offset_at(plan, ref, x):
+    """An offset at or in front of reference `ref`'s first record at a position >= x, and behind every record at a position
+    below x rounded down to the marks' grid (midas_bam_slice_marks; positions sorted inside the reference)."""
+    b = int(x) // pieces.MARK_SPAN
+    if b <= 0:
+        return int(plan['ref_first'][ref])
+    key = plan['mark_key']
+    i = int(np.searchsorted(key, (int(ref) << 32) | b, side='left'))
+    if i < key.size and int(key[i]) >> 32 == ref:
+        return int(plan['mark_off'][i])
+    return int(plan['ref_end'][ref])
+
+
+def _piece_range(plan, ref, lo, hi, last):
+    """Uncompressed [begin, end) holding the records piece [lo, hi) of reference `ref` needs: those that start in it and the
+    ones in front that can reach into it (at most the reference's longest read span away)."""
+    if plan['ref_first'][ref] < 0:
+        return None
+    b = _offset_at(plan, ref, max(0, lo - int(plan['ref_span'][ref]))) if lo > 0 else int(plan['ref_first'][ref])
+    e = int(plan['ref_end'][ref]) if last else _offset_at(plan, ref, hi)
+    return (b, max(b, e))
+
+
+def _record_ranges(plan, wanted):
+    """Uncompressed [begin, end) record ranges of the given (reference, lo, hi, last) pieces -- a whole reference: from its
+    first record to the first record of the next reference that has any (the file is coordinate-sorted: _rank_local_plan
+    checked) -- merged where they touch or overlap (a piece's halo lies in the piece before it)."""
+    ranges = sorted(r for r in (_piece_range(plan, *w) for w in wanted) if r is not None)
     merged = []
     for b, e in ranges:
-        if merged and merged[-1][1] == b:
-            merged[-1] = (merged[-1][0], e)
+        if merged and merged[-1][1] >= b:
+            merged[-1] = (merged[-1][0], max(e, merged[-1][1]))
         else:
             merged.append((b, e))
     return merged
@@ -439,26 +505,52 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         if rank == 0:
             args['log'].write("rank-local BAM decode: %d slices chained, %d records\n" % (ws, int(plan['ref_reads'].sum())))
 
-    # contig -> rank by bytes of aligned reads + sites (every rank computes the same assignment from the same numbers)
+    # work item -> rank by bytes of aligned reads + sites (every rank computes the same assignment from the same numbers).
+    # An item is a contig -- the unit count_coverage is called on -- or, for a contig longer than the split length in a BAM
+    # whose positions are sorted, a piece of it (midas_amd/pieces.py): one 20 Mb chromosome must not pin the job to one GPU.
     all_ids = sorted(species)
-    order = _species_contig_order(all_ids, contigs)
+    by_species = _species_contig_order(all_ids, contigs)
     ref_index = {n: i for i, n in enumerate(ref_names)}
-    weight = {cid: 1.6 * float(read_bytes[ref_index[cid]] if cid in ref_index else 0.0) + 17.0 * contigs[cid].length
-              for sp in all_ids for cid in order[sp]}      # ~1.63 B per aligned base, 17 B per site
+    piece_len = pieces.piece_length(int(args.get('split_length', SPLIT_LENGTH))) if plan is not None and plan['pos_sorted'] else 0
+    order, span, weight, halo = {sp: [] for sp in all_ids}, {}, {}, {}
+    n_cut = 0
+    for sp in all_ids:
+        for cid in by_species[sp]:
+            r = ref_index.get(cid, -1)
+            length = contigs[cid].length
+            cuts = pieces.cut(length, piece_len) if r >= 0 and piece_len and plan['ref_first'][r] >= 0 else [(0, length)]
+            n_cut += len(cuts) > 1
+            for j, (lo, hi) in enumerate(cuts):
+                it = (cid, j)
+                order[sp].append(it)
+                span[it] = (lo, hi, j + 1 == len(cuts))
+                share = 1.0
+                if len(cuts) > 1:        # the piece's share of the contig's reads: its share of the record bytes
+                    b, e = _piece_range(plan, r, lo, hi, span[it][2])
+                    share = (e - b) / float(max(1, plan['ref_end'][r] - plan['ref_first'][r]))
+                    halo[cid] = int(plan['ref_span'][r])
+                # ~1.63 B per aligned base, 17 B per site
+                weight[it] = 1.6 * share * float(read_bytes[r] if r >= 0 else 0.0) + 17.0 * (hi - lo)
     owner = dist.shard_items(weight, ws)
-    mine = [contigs[cid] for sp in all_ids for cid in order[sp] if owner[cid] == rank]
+    mine = [it for sp in all_ids for it in order[sp] if owner[it] == rank]
     if plan is not None:
         try:
-            refid, reads = plan['slice'].load_ranges(_record_ranges(plan, [ref_index[c.id] for c in mine if c.id in ref_index]))
+            refid, reads = plan['slice'].load_ranges(_record_ranges(plan, [(ref_index[cid],) + span[(cid, j)] for cid, j in mine
+                                                                           if cid in ref_index]))
             decoded = (ref_names, ref_lens, refid, reads)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)
+        if n_cut:
+            per_rank = dist.all_gather_i64([reads.n_reads])[:, 0]
+            if rank == 0:
+                args['log'].write("long contigs: %d cut into pieces of %d positions; records decoded per rank: %s of %d\n"
+                                  % (n_cut, piece_len, ' '.join(str(int(x)) for x in per_rank), int(plan['ref_reads'].sum())))
 
     local = {}
     try:
         with make_context() as ctx:
-            local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx)
+            local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx, span, contigs, halo)
     except abi.MidasSnpsError as e:
         error = _error_text(e)
     except SystemExit as e:

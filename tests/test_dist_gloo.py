@@ -175,6 +175,8 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
 rank, ws = dist.world()
 args = dict(outdir=out, db=db, build_db=False, align=False, call=True, species_id=None, threads=2, log=io.StringIO(),
             mapid=94.0, readq=20, mapq=20, baseq=30, aln_cov=0.75, remove_temp=False)
+if os.environ.get("SNPS_SPLIT_LENGTH"):
+    args['split_length'] = int(os.environ["SNPS_SPLIT_LENGTH"])
 species = msnps.initialize_species(args)
 contigs = msnps.initialize_contigs(species)
 msnps.pysam_pileup(args, species, contigs, make_context=OracleContext)
@@ -237,6 +239,46 @@ def test_two_ranks_snps_outputs_equal_single(tmp_path):
                 a = open(os.path.join(one, "snps", "output", f), "rb").read()
                 b = open(os.path.join(many, "snps", "output", f), "rb").read()
                 assert a == b, "%s differs between 1 and %d ranks" % (f, n)
+
+
+def test_one_long_contig_is_cut_into_pieces_across_ranks(tmp_path):
+    """One 20 Mb contig (a finished chromosome) and nothing else: whole contigs as work items would leave every rank but one
+    idle.  With 2 and 3 ranks the contig is dealt out in pieces; the table and the summary are byte for byte the single
+    process's, and the log shows that no rank decoded the contig's records whole (each inflates its pieces' ranges only)."""
+    import re
+    import shutil
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=20000000, n_reads=150000, seed=77, var_len=True)
+    db, one = str(tmp_path / "db"), str(tmp_path / "n1")
+    synth.write_sample(one, db, contigs, reads)
+    (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+    assert rc == 0, e
+    os.environ["SNPS_SPLIT_LENGTH"] = str(3 << 20)
+    try:
+        for n in (2, 3):
+            many = str(tmp_path / ("n%d" % n))
+            shutil.copytree(one, many, ignore=shutil.ignore_patterns("output"))
+            os.makedirs(os.path.join(many, "snps", "output"))
+            res = _run_snps_workers(tmp_path, script, many, db, n)
+            for rc, o, e in res:
+                assert rc == 0, e
+            log = "".join(o for _, o, _ in res)
+            m = re.search(r"long contigs: 1 cut into pieces of (\d+) positions; records decoded per rank: ([\d ]+) of (\d+)", log)
+            assert m, log
+            assert int(m.group(1)) == 3 << 20
+            per_rank, total = [int(x) for x in m.group(2).split()], int(m.group(3))
+            assert len(per_rank) == n and total == reads.n_reads
+            assert max(per_rank) < 0.75 * total and sum(per_rank) >= total          # (the sum holds every halo twice)
+            assert sum(per_rank) < 1.1 * total
+            assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
+            files = sorted(os.listdir(os.path.join(one, "snps", "output")))
+            assert sorted(os.listdir(os.path.join(many, "snps", "output"))) == files
+            for f in files:
+                assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(many, "snps", "output", f), "rb").read()
+    finally:
+        del os.environ["SNPS_SPLIT_LENGTH"]
 
 
 def test_two_ranks_on_a_bam_that_is_not_coordinate_sorted_fall_back_to_the_whole_decode(tmp_path):
