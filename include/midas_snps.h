@@ -222,6 +222,16 @@ int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path);
  * to batches created on the context afterwards (the one-shot midas_snps_pileup included).                              */
 enum { MIDAS_SNPS_PAD_SPEC = 0, MIDAS_SNPS_PAD_PYSAM = 1 };
 int32_t midas_snps_set_pad_rule(midas_snps_ctx* ctx, int32_t rule);
+/* Who formats and deflates the rows midas_snps_batch_write_part writes at gz levels 1-5 (the row coder's levels):
+ *   MIDAS_SNPS_ROWS_DEVICE (default)  a kernel, one workgroup per gzip member: what crosses the link is the DEFLATE stream
+ *                                     (~4 bytes a row) and the host only frames and writes the members;
+ *   MIDAS_SNPS_ROWS_HOST              the host's formatter threads, from counts and alleles streamed through the pinned ring
+ *                                     (the file is then byte for byte what midas_snps_write_part writes).
+ * Both give gzip files that inflate to the same text -- the rows of midas/run/snps.py:201-210 -- but not the same bytes: the
+ * two coders choose their matches differently.  Every rank of a job uses the same coder, so parts still concatenate into the
+ * file one rank writes.  The environment variable MIDAS_SNPS_ROW_CODER=host sets the default of new contexts.          */
+enum { MIDAS_SNPS_ROWS_DEVICE = 0, MIDAS_SNPS_ROWS_HOST = 1 };
+int32_t midas_snps_set_row_coder(midas_snps_ctx* ctx, int32_t coder);
 /* Re-run the device packer over the batch's resident BAM-native arrays (the arrays batch_create uploaded, unchanged):
  * per read the CIGAR walk into gap-free match segments (pysam get_aligned_pairs(matches_only=True), reached from
  * midas/run/snps.py:194-199), the clip structure (query_alignment_sequence, :145), floor(mean(query_qualities))

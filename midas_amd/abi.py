@@ -89,6 +89,7 @@ class BatchInfo(C.Structure):
                 ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64)]
 
 
+ROWS_DEVICE, ROWS_HOST = 0, 1    # who formats and deflates a batch's rows (midas_snps_set_row_coder)
 PAD_SPEC, PAD_PYSAM = 0, 1       # what the CIGAR op P does to the query position (midas_snps_set_pad_rule)
 PATH_AUTO, PATH_DIRECT, PATH_PACKED = 0, 1, 2
 PATH_NAMES = {PATH_AUTO: "auto", PATH_DIRECT: "direct", PATH_PACKED: "packed"}
@@ -229,6 +230,7 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_select_path': (i32, [vp, i32]),
         'midas_snps_set_default_path': (i32, [vp, i32]),
         'midas_snps_set_pad_rule': (i32, [vp, i32]),
+        'midas_snps_set_row_coder': (i32, [vp, i32]),
         'midas_snps_pack_set_pad_rule': (None, [i32]),
         'midas_snps_copy_rate': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
         'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
@@ -289,7 +291,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
-    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_set_pad_rule',
+    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_set_pad_rule', 'midas_snps_set_row_coder',
     'midas_snps_pack_set_pad_rule',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
@@ -731,6 +733,11 @@ class Context:
         """PAD_SPEC (default): the CIGAR op P consumes nothing; PAD_PYSAM: it advances the query position, as
         get_aligned_pairs of the pysam releases of MIDAS's time does.  For batches created afterwards."""
         self._check(self._lib.midas_snps_set_pad_rule(self._h, int(rule)))
+
+    def set_row_coder(self, coder: int):
+        """ROWS_DEVICE (default): Batch.write_part formats and deflates the rows in a kernel; ROWS_HOST: the host's
+        formatter threads do (the file then equals write_table's byte for byte).  Same text either way."""
+        self._check(self._lib.midas_snps_set_row_coder(self._h, int(coder)))
 
     def copy_rate(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
         """GB/s (read + written) of a device-to-device copy with the library's 16-bytes-per-lane copy kernel."""

@@ -60,6 +60,17 @@ def group_by_contig(ref_names, refid, reads, contig_ids):
     from .abi import ReadsSoA
     index_of = {n: i for i, n in enumerate(ref_names)}
     want = np.array([index_of.get(c, -1) for c in contig_ids], dtype=np.int64)
+    # the usual case costs two binary searches per contig: records already in refID order, the wanted contigs in header
+    # order, and no record of any other contig among them
+    n = int(refid.shape[0])
+    if want.size and (want >= 0).all() and (want.size == 1 or (want[1:] > want[:-1]).all()) and \
+            (n < 2 or bool((refid[1:] >= refid[:-1]).all())):
+        lo = np.searchsorted(refid, want, side='left')
+        hi = np.searchsorted(refid, want, side='right')
+        if int((hi - lo).sum()) == n:
+            read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
+            np.cumsum(hi - lo, out=read_begin[1:])
+            return reads, read_begin
     rank = np.full(len(ref_names) + 1, -1, dtype=np.int64)
     for k, r in enumerate(want):
         if r >= 0:

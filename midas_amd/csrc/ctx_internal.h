@@ -11,6 +11,7 @@ struct midas_snps_ctx {
   std::string err;
   int64_t err_read = -1;
   int pad_rule = 0;       // MIDAS_SNPS_PAD_SPEC: what P does to the query position (midas_snps_set_pad_rule)
+  int row_coder = 0;      // MIDAS_SNPS_ROWS_DEVICE: who formats and deflates a batch's rows (midas_snps_set_row_coder)
   int default_path = 0;   // MIDAS_SNPS_PATH_AUTO: what batches created on this context take (midas_snps_set_default_path)
   hipDeviceProp_t prop;
   // pinned staging ring for device -> pageable host copies, allocated on first use and kept for the context's lifetime

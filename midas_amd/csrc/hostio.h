@@ -20,4 +20,10 @@ struct RowFeed {
 int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
                        int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256, const int64_t* first_pos = nullptr);
 
+// Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
+// member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.
+struct CodedMember { const uint8_t* data; uint32_t n_bytes, crc, text_len, rows; };
+int32_t write_coded_members(const char* path, bool with_header, int32_t gz_level, int64_t n_members, const CodedMember* members,
+                            int32_t threads, char* err256);
+
 }  // namespace midas

@@ -232,6 +232,27 @@ struct DirectParams {
   int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
 };
 
+// rows_deflate.hip: the table's rows formatted and deflated on the device, one gzip member (<= 16 384 rows of one contig) at a time
+struct RowsMember {
+  long long site0;                 // the member's first site in the batch's counts / alleles
+  long long pos0;                  // ref_pos of its first row (1-based; a piece's origin included)
+  int32_t n_rows, id_off, id_len, pad;
+};
+struct RowsResult {
+  unsigned long long off;          // the member's DEFLATE stream in the arena
+  uint32_t n_bytes, crc, text_len;
+  uint32_t status;                 // 0 done; 1 not taken (contig id too long); 2 the arena was full
+};
+struct RowsParams {
+  const uint32_t* counts; const uint8_t* allele;
+  const uint8_t* ids;              // the contig ids, back to back
+  const RowsMember* members; int32_t n_members;
+  uint8_t* arena; unsigned long long arena_bytes;      // zeroed
+  unsigned long long* cursor;      // zeroed: bytes of the arena handed out
+  RowsResult* results;
+};
+hipError_t launch_rows_deflate(const RowsParams& p, int grid_blocks, hipStream_t s);
+
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);

@@ -356,6 +356,8 @@ int32_t midas_snps_create(int32_t device_ordinal, midas_snps_ctx** out_ctx) {
     return MIDAS_SNPS_ERR_NO_DEVICE;
   }
   ctx->stream = ctx->own_stream;
+  const char* coder = getenv("MIDAS_SNPS_ROW_CODER");
+  ctx->row_coder = (coder && strcmp(coder, "host") == 0) ? MIDAS_SNPS_ROWS_HOST : MIDAS_SNPS_ROWS_DEVICE;
   *out_ctx = ctx;
   return MIDAS_SNPS_OK;
 }
@@ -422,6 +424,12 @@ int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, d
   (void)hipFree(dst);
   if (st != MIDAS_SNPS_OK) { (void)hipGetLastError(); return fail(ctx, st, "copy_rate: HIP runtime error"); }
   *out_gbps = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_set_row_coder(midas_snps_ctx* ctx, int32_t coder) {
+  if (!ctx || (coder != MIDAS_SNPS_ROWS_DEVICE && coder != MIDAS_SNPS_ROWS_HOST)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  ctx->row_coder = coder;
   return MIDAS_SNPS_OK;
 }
 
@@ -1336,6 +1344,94 @@ bool batch_feed_fetch(void* user, int slot, int64_t src_lo, int64_t n, const uin
 }
 }  // namespace
 
+namespace {
+struct DeviceBuf {      // freed on every way out
+  void* p = nullptr;
+  ~DeviceBuf() { if (p) (void)hipFree(p); }
+};
+
+// The rows of the given contigs formatted and deflated on the device (rows_deflate.hip), framed and written by the host.
+// Returns MIDAS_SNPS_OK with *done = false when the device coder declines a member (a contig id beyond its limit, an arena
+// that turned out too small): the caller then takes the host's formatter for the whole part.
+int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_header, int32_t n_contigs, const int64_t* src,
+                             const int64_t* n_sites, const int64_t* first, const char* const* ref_ids, int32_t gz_level,
+                             int32_t threads, bool* done) {
+  midas_snps_ctx* ctx = b->ctx;
+  *done = false;
+  std::vector<RowsMember> members;
+  std::vector<uint8_t> ids;
+  for (int32_t k = 0; k < n_contigs; ++k) {
+    const size_t id_off = ids.size(), id_len = strlen(ref_ids[k]);
+    if (id_len > 192) return MIDAS_SNPS_OK;
+    ids.insert(ids.end(), ref_ids[k], ref_ids[k] + id_len);
+    for (int64_t lo = 0; lo < n_sites[k]; lo += kRowsPerMember) {
+      RowsMember m;
+      m.site0 = src[k] + lo;
+      m.pos0 = first[k] + lo + 1;
+      m.n_rows = (int32_t)std::min<int64_t>(kRowsPerMember, n_sites[k] - lo);
+      m.id_off = (int32_t)id_off; m.id_len = (int32_t)id_len; m.pad = 0;
+      members.push_back(m);
+    }
+  }
+  const int64_t n_members = (int64_t)members.size();
+  char err[256] = {0};
+  if (n_members == 0) {
+    const int32_t st = write_coded_members(path, with_header, gz_level, 0, nullptr, threads, err);
+    if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
+    *done = true;
+    return MIDAS_SNPS_OK;
+  }
+  if (n_members > 0x7FFFFFFFll || ids.size() > 0x7FFFFFFFull) return MIDAS_SNPS_OK;
+  int64_t rows = 0;
+  for (const RowsMember& m : members) rows += m.n_rows;
+  // the tables of a 20x genome take ~4 bytes a row; ten a row and a header's worth per member is room for any coverage seen
+  // so far, and a member that does not fit sends the part to the host's formatter
+  const unsigned long long arena_bytes = (unsigned long long)rows * 10ull + (unsigned long long)n_members * 1024ull + 4096ull;
+  DeviceBuf d_members, d_ids, d_results, d_arena, d_cursor;
+  HIP_TRY(ctx, hipMalloc(&d_members.p, (size_t)n_members * sizeof(RowsMember)));
+  HIP_TRY(ctx, hipMalloc(&d_ids.p, ids.size() + 16));
+  HIP_TRY(ctx, hipMalloc(&d_results.p, (size_t)n_members * sizeof(RowsResult)));
+  HIP_TRY(ctx, hipMalloc(&d_arena.p, (size_t)arena_bytes));
+  HIP_TRY(ctx, hipMalloc(&d_cursor.p, 8));
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(d_members.p, members.data(), (size_t)n_members * sizeof(RowsMember), hipMemcpyHostToDevice, s));
+  if (!ids.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ids.p, ids.data(), ids.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0, (size_t)arena_bytes, s));
+  HIP_TRY(ctx, hipMemsetAsync(d_cursor.p, 0, 8, s));
+  RowsParams rp;
+  rp.counts = b->d_counts; rp.allele = b->d_allele;
+  rp.ids = static_cast<const uint8_t*>(d_ids.p);
+  rp.members = static_cast<const RowsMember*>(d_members.p);
+  rp.n_members = (int32_t)n_members;
+  rp.arena = static_cast<uint8_t*>(d_arena.p); rp.arena_bytes = arena_bytes;
+  rp.cursor = static_cast<unsigned long long*>(d_cursor.p);
+  rp.results = static_cast<RowsResult*>(d_results.p);
+  HIP_TRY(ctx, launch_rows_deflate(rp, ctx->prop.multiProcessorCount, s));
+  std::vector<RowsResult> results((size_t)n_members);
+  unsigned long long used = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(results.data(), d_results.p, (size_t)n_members * sizeof(RowsResult), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(&used, d_cursor.p, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  for (const RowsResult& r : results)
+    if (r.status != 0u) return MIDAS_SNPS_OK;
+  if (used > arena_bytes) return MIDAS_SNPS_OK;
+  struct HostBuf { uint8_t* p = nullptr; ~HostBuf() { free(p); } } host;     // (malloc: no zero fill)
+  host.p = static_cast<uint8_t*>(malloc((size_t)used + 16));
+  if (!host.p) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "batch_write_part: out of host memory");
+  const int32_t cst = copy_to_host(ctx, host.p, d_arena.p, (size_t)used);
+  if (cst != MIDAS_SNPS_OK) return cst;
+  std::vector<CodedMember> coded((size_t)n_members);
+  for (int64_t k = 0; k < n_members; ++k) {
+    const RowsResult& r = results[(size_t)k];
+    coded[(size_t)k] = CodedMember{host.p + r.off, r.n_bytes, r.crc, r.text_len, (uint32_t)members[(size_t)k].n_rows};
+  }
+  const int32_t st = write_coded_members(path, with_header, gz_level, n_members, coded.data(), threads, err);
+  if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
+  *done = true;
+  return MIDAS_SNPS_OK;
+}
+}  // namespace
+
 int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32_t with_header, int32_t n_contigs,
                                     const int32_t* contig_index, const char* const* ref_ids, int32_t gz_level, int32_t threads) {
   if (!b || !path || n_contigs < 0 || (n_contigs > 0 && (!contig_index || !ref_ids))) return MIDAS_SNPS_ERR_INVALID_ARG;
@@ -1350,6 +1446,13 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
     src[(size_t)k] = b->h_contig_site[(size_t)c];
     n_sites[(size_t)k] = b->h_contig_site[(size_t)c + 1] - b->h_contig_site[(size_t)c];
     if (!b->h_origin.empty()) first[(size_t)k] = b->h_origin[(size_t)c];     // a piece's rows carry the contig's positions
+  }
+  // gz levels 1-5 are the row coder's: it runs on the device unless the context was told otherwise
+  if (gz_level >= 1 && gz_level <= 5 && ctx->row_coder == MIDAS_SNPS_ROWS_DEVICE) {
+    bool done = false;
+    st = write_part_on_device(b, path, with_header != 0, n_contigs, src.data(), n_sites.data(), first.data(), ref_ids, gz_level,
+                              threads, &done);
+    if (st != MIDAS_SNPS_OK || done) return st;
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)

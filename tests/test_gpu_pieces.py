@@ -29,6 +29,7 @@ def test_pieces_equal_the_whole_contig(path_ctx, piece_len, tmp_path):
     st, _, oc, oa, os_ = c_oracle.pileup(THR, table, reads)
     assert st == 0
     pt, pr, entries = pieces.split_table(table, reads, piece_len)
+    path_ctx.set_row_coder(abi.ROWS_HOST)
     b = path_ctx.batch(pt, pr)
     b.run(THR)
     counts, allele, stats = b.fetch()
@@ -39,7 +40,17 @@ def test_pieces_equal_the_whole_contig(path_ctx, piece_len, tmp_path):
     ids = [pt.ids[k] for k in range(pt.n_contigs)]
     part = str(tmp_path / "pieces.gz")
     b.write_part(part, list(range(pt.n_contigs)), ids, header=True, gz_level=4, threads=4)
+    # ... and so are the members of the device's row coder: the pieces' file equals the whole contigs' file from the same coder
+    path_ctx.set_row_coder(abi.ROWS_DEVICE)
+    dev_part = str(tmp_path / "pieces_dev.gz")
+    b.write_part(dev_part, list(range(pt.n_contigs)), ids, header=True, gz_level=4, threads=4)
     b.close()
+    bw = path_ctx.batch(table, reads)
+    bw.run(THR)
+    dev_whole = str(tmp_path / "whole_dev.gz")
+    bw.write_part(dev_whole, list(range(table.n_contigs)), table.ids, header=True, gz_level=4, threads=4)
+    bw.close()
+    assert open(dev_part, "rb").read() == open(dev_whole, "rb").read()
     whole = str(tmp_path / "whole.gz")
     off = table.site_offsets()
     abi.write_table(whole, table.ids, [oa[off[k]:off[k + 1]] for k in range(table.n_contigs)],
