@@ -65,8 +65,9 @@ def group_by_contig(ref_names, refid, reads, contig_ids):
     n = int(refid.shape[0])
     if want.size and (want >= 0).all() and (want.size == 1 or (want[1:] > want[:-1]).all()) and \
             (n < 2 or bool((refid[1:] >= refid[:-1]).all())):
-        lo = np.searchsorted(refid, want, side='left')
-        hi = np.searchsorted(refid, want, side='right')
+        w = want.astype(refid.dtype)      # (a wider needle type would make searchsorted convert all of refid)
+        lo = np.searchsorted(refid, w, side='left')
+        hi = np.searchsorted(refid, w, side='right')
         if int((hi - lo).sum()) == n:
             read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
             np.cumsum(hi - lo, out=read_begin[1:])

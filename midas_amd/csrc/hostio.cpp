@@ -1700,12 +1700,10 @@ int32_t write_coded_members(const char* path, bool with_header, int32_t gz_level
   const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
   if (fd < 0) { set_err(err256, "cannot open %s for writing", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
   std::atomic<int> bad{0};
-  auto write_all = [&](const struct iovec* iov, int n_iov, uint64_t off) {
-    struct iovec v[3];
-    for (int i = 0; i < n_iov; ++i) v[i] = iov[i];
+  auto write_all = [&](struct iovec* v, int n_iov, uint64_t off) {     // (consumes v)
     int first = 0;
     while (first < n_iov) {
-      const ssize_t got = pwritev(fd, v + first, n_iov - first, (off_t)off);
+      const ssize_t got = pwritev(fd, v + first, std::min(n_iov - first, 1024), (off_t)off);
       if (got <= 0) { bad = 1; return; }
       off += (uint64_t)got;
       size_t left = (size_t)got;
@@ -1714,30 +1712,30 @@ int32_t write_coded_members(const char* path, bool with_header, int32_t gz_level
     }
   };
   if (!head.empty()) { struct iovec v{head.data(), head.size()}; write_all(&v, 1, 0); }
-  // the page cache takes a few GB/s from one core: the members go out through several, each at its place
-  const int64_t kRun = 16;
-  const int64_t n_runs = (n_members + kRun - 1) / kRun;
-  std::atomic<int64_t> next{0};
-  int nt = writer_threads(threads);
-  if ((int64_t)nt > n_runs) nt = (int)std::max<int64_t>(1, n_runs);
-  Workers::run(nt, [&] {
-    for (;;) {
-      const int64_t run = next.fetch_add(1);
-      if (run >= n_runs || bad) return;
-      for (int64_t k = run * kRun; k < std::min(n_members, (run + 1) * kRun); ++k) {
-        const CodedMember& m = members[k];
-        const uint64_t total = kGzHeader + (uint64_t)m.n_bytes + 8u;
-        uint8_t frame[kGzHeader] = {0x1f, 0x8b, 8, 4 /* FEXTRA */, 0, 0, 0, 0, 0, 255, 16, 0, 'M', 'S', 4, 0,
-                                    (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16), (uint8_t)(total >> 24),
-                                    'M', 'R', 4, 0, (uint8_t)m.rows, (uint8_t)(m.rows >> 8), (uint8_t)(m.rows >> 16), (uint8_t)(m.rows >> 24)};
-        uint8_t tail[8];
-        memcpy(tail, &m.crc, 4);
-        memcpy(tail + 4, &m.text_len, 4);
-        struct iovec v[3] = {{frame, kGzHeader}, {const_cast<uint8_t*>(m.data), m.n_bytes}, {tail, 8}};
-        write_all(v, 3, at[(size_t)k]);
-      }
+  // One file takes buffered writes from one thread at a time (the inode's lock), at 2-3 GB/s: the members go out from the
+  // calling thread, hundreds per pwritev.  Callers with several tables to write (one per species) write them side by side.
+  (void)threads;
+  constexpr int64_t kBatch = 256;          // 3 iovecs a member, IOV_MAX is 1024
+  std::vector<uint8_t> frames((size_t)kBatch * (kGzHeader + 8));
+  std::vector<struct iovec> iov((size_t)kBatch * 3);
+  for (int64_t k0 = 0; k0 < n_members && !bad; k0 += kBatch) {
+    const int64_t k1 = std::min(n_members, k0 + kBatch);
+    for (int64_t k = k0; k < k1; ++k) {
+      const CodedMember& m = members[k];
+      const uint64_t total = kGzHeader + (uint64_t)m.n_bytes + 8u;
+      uint8_t* frame = frames.data() + (size_t)(k - k0) * (kGzHeader + 8);
+      const uint8_t fixed[kGzHeader] = {0x1f, 0x8b, 8, 4 /* FEXTRA */, 0, 0, 0, 0, 0, 255, 16, 0, 'M', 'S', 4, 0,
+                                        (uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16), (uint8_t)(total >> 24),
+                                        'M', 'R', 4, 0, (uint8_t)m.rows, (uint8_t)(m.rows >> 8), (uint8_t)(m.rows >> 16), (uint8_t)(m.rows >> 24)};
+      memcpy(frame, fixed, kGzHeader);
+      memcpy(frame + kGzHeader, &m.crc, 4);
+      memcpy(frame + kGzHeader + 4, &m.text_len, 4);
+      iov[(size_t)(k - k0) * 3] = {frame, kGzHeader};
+      iov[(size_t)(k - k0) * 3 + 1] = {const_cast<uint8_t*>(m.data), m.n_bytes};
+      iov[(size_t)(k - k0) * 3 + 2] = {frame + kGzHeader, 8};
     }
-  });
+    write_all(iov.data(), (int)(k1 - k0) * 3, at[(size_t)k0]);
+  }
   lap("frame + write");
   if (close(fd) != 0) bad = 1;
   if (bad) { set_err(err256, "write failed on %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }

@@ -1358,6 +1358,16 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
                              int32_t threads, bool* done) {
   midas_snps_ctx* ctx = b->ctx;
   *done = false;
+  // MIDAS_SNPS_TRACE=1: where the call spends its time, on stderr
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_last = now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = now();
+    fprintf(stderr, "[rows on device] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   std::vector<RowsMember> members;
   std::vector<uint8_t> ids;
   for (int32_t k = 0; k < n_contigs; ++k) {
@@ -1387,6 +1397,11 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   // the tables of a 20x genome take ~4 bytes a row; ten a row and a header's worth per member is room for any coverage seen
   // so far, and a member that does not fit sends the part to the host's formatter
   const unsigned long long arena_bytes = (unsigned long long)rows * 10ull + (unsigned long long)n_members * 1024ull + 4096ull;
+  std::vector<RowsResult> results((size_t)n_members);
+  struct HostBuf { uint8_t* p = nullptr; ~HostBuf() { free(p); } } host;     // (malloc: no zero fill)
+  {
+  std::lock_guard<std::mutex> device_part(ctx->device_mutex);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));       // (the calling thread may never have talked to the device)
   DeviceBuf d_members, d_ids, d_results, d_arena, d_cursor;
   HIP_TRY(ctx, hipMalloc(&d_members.p, (size_t)n_members * sizeof(RowsMember)));
   HIP_TRY(ctx, hipMalloc(&d_ids.p, ids.size() + 16));
@@ -1394,6 +1409,7 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   HIP_TRY(ctx, hipMalloc(&d_arena.p, (size_t)arena_bytes));
   HIP_TRY(ctx, hipMalloc(&d_cursor.p, 8));
   hipStream_t s = ctx->stream;
+  lap("members + hipMalloc");
   HIP_TRY(ctx, hipMemcpyAsync(d_members.p, members.data(), (size_t)n_members * sizeof(RowsMember), hipMemcpyHostToDevice, s));
   if (!ids.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ids.p, ids.data(), ids.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0, (size_t)arena_bytes, s));
@@ -1407,26 +1423,31 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   rp.cursor = static_cast<unsigned long long*>(d_cursor.p);
   rp.results = static_cast<RowsResult*>(d_results.p);
   HIP_TRY(ctx, launch_rows_deflate(rp, ctx->prop.multiProcessorCount, s));
-  std::vector<RowsResult> results((size_t)n_members);
   unsigned long long used = 0;
   HIP_TRY(ctx, hipMemcpyAsync(results.data(), d_results.p, (size_t)n_members * sizeof(RowsResult), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(&used, d_cursor.p, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  lap("memset + kernel");
   for (const RowsResult& r : results)
     if (r.status != 0u) return MIDAS_SNPS_OK;
   if (used > arena_bytes) return MIDAS_SNPS_OK;
-  struct HostBuf { uint8_t* p = nullptr; ~HostBuf() { free(p); } } host;     // (malloc: no zero fill)
   host.p = static_cast<uint8_t*>(malloc((size_t)used + 16));
   if (!host.p) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "batch_write_part: out of host memory");
   const int32_t cst = copy_to_host(ctx, host.p, d_arena.p, (size_t)used);
   if (cst != MIDAS_SNPS_OK) return cst;
+  lap("streams to host");
+  }
   std::vector<CodedMember> coded((size_t)n_members);
   for (int64_t k = 0; k < n_members; ++k) {
     const RowsResult& r = results[(size_t)k];
     coded[(size_t)k] = CodedMember{host.p + r.off, r.n_bytes, r.crc, r.text_len, (uint32_t)members[(size_t)k].n_rows};
   }
   const int32_t st = write_coded_members(path, with_header, gz_level, n_members, coded.data(), threads, err);
-  if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
+  if (st != MIDAS_SNPS_OK) {
+    std::lock_guard<std::mutex> g(ctx->device_mutex);
+    return fail(ctx, st, err);
+  }
+  lap("frame + write");
   *done = true;
   return MIDAS_SNPS_OK;
 }
@@ -1436,9 +1457,13 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
                                     const int32_t* contig_index, const char* const* ref_ids, int32_t gz_level, int32_t threads) {
   if (!b || !path || n_contigs < 0 || (n_contigs > 0 && (!contig_index || !ref_ids))) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
-  int32_t st = midas_snps_batch_sync(b);
-  if (st != MIDAS_SNPS_OK) return st;
-  if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part before batch_run");
+  int32_t st;
+  {   // (several host threads may be writing one table each: see ctx_internal.h, device_mutex)
+    std::lock_guard<std::mutex> g(ctx->device_mutex);
+    st = midas_snps_batch_sync(b);
+    if (st != MIDAS_SNPS_OK) return st;
+    if (!b->ran) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "batch_write_part before batch_run");
+  }
   std::vector<int64_t> n_sites((size_t)n_contigs), src((size_t)n_contigs), first((size_t)n_contigs, 0);
   for (int32_t k = 0; k < n_contigs; ++k) {
     const int32_t c = contig_index[k];
@@ -1454,6 +1479,8 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
                               threads, &done);
     if (st != MIDAS_SNPS_OK || done) return st;
   }
+  std::lock_guard<std::mutex> host_path(ctx->device_mutex);      // (the host's formatter owns the staging ring for the whole call)
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));

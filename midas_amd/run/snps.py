@@ -20,6 +20,9 @@ import os
 import shutil
 import subprocess
 import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from collections.abc import Mapping
 from time import time
 
 import numpy as np
@@ -32,6 +35,7 @@ from midas_amd import abi, bam, dist, fasta, pieces, utility
 # writer thread: level 9 0.2, 6 0.5, 4 1.7, 1 2.5 M rows/s for 28.5 / 29.0 / 30.4 / 34.5 MB -- 4 costs 5 % of file size and
 # takes the formatter from the largest to the second smallest item of the stage.
 GZ_LEVEL = 4
+WRITERS = 6                  # tables written side by side from a batch (_write_jobs)
 SPLIT_LENGTH = 8 << 20      # contigs longer than this are dealt to the ranks in pieces (args['split_length']; 0: never)
 
 
@@ -57,14 +61,40 @@ class Species:
 
 
 class Contig:
-    """One FASTA record of a representative genome: id, upper-cased sequence, length, owning species."""
-    __slots__ = ('id', 'seq', 'length', 'species_id')
+    """One FASTA record of a representative genome: id, upper-cased sequence, length, owning species.  The sequence is kept
+    as the bytes the device takes (`seq_bytes`); `seq` -- the str the reference's Contig carries -- is made when asked for."""
+    __slots__ = ('id', 'seq_bytes', '_seq', 'length', 'species_id', 'pool', 'pool_at')
 
-    def __init__(self, id, seq='', species_id=None):
+    def __init__(self, id, seq='', species_id=None, pool=None, pool_at=0):
         self.id = id
-        self.seq = seq
+        self._seq = seq if isinstance(seq, str) else None
+        self.seq_bytes = seq.encode('latin-1') if isinstance(seq, str) else seq      # (bytes-like: bytes or a uint8 array)
         self.length = len(seq)
         self.species_id = species_id
+        self.pool, self.pool_at = pool, pool_at     # initialize_contigs: all sequences back to back in one array
+
+    @property
+    def seq(self):
+        if self._seq is None:
+            self._seq = bytes(self.seq_bytes).decode('latin-1')
+        return self._seq
+
+
+def _reference_bytes(parts):
+    """The sequences parts = [(Contig, lo, hi)] back to back as one uint8 array: a view of the pool initialize_contigs read
+    them into when they lie there in this order (every contig of every genome, in the order of the BAM header -- the usual
+    case), else a copy."""
+    pool = parts[0][0].pool if parts else None
+    if pool is not None:
+        at = parts[0][0].pool_at + parts[0][1]
+        begin = at
+        for c, lo, hi in parts:
+            if c.pool is not pool or c.pool_at + lo != at:
+                break
+            at = c.pool_at + hi
+        else:
+            return pool[begin:at]
+    return np.frombuffer(b''.join(c.seq_bytes[lo:hi] for c, lo, hi in parts), dtype=np.uint8)
 
 
 def select_species(args, per_species='rep_genomes'):
@@ -102,14 +132,55 @@ def initialize_species(args):
 def _records(sp):
     if 'fna' not in sp.paths:
         sys.exit("\nError: Could not locate the representative genome of species: %s\n" % sp.id)
-    with utility.iopen(sp.paths['fna']) as handle:
-        for rec_id, rec_seq in fasta.parse(handle):
+    with utility.iopen(sp.paths['fna'], 'rb') as handle:
+        for rec_id, rec_seq in fasta.parse_bytes(handle.read()):
             yield rec_id, rec_seq.upper()
 
 
 def initialize_contigs(species):
     """{contig_id: Contig} over every species' representative genome, sequences upper-cased (midas/run/snps.py:55-67)."""
-    return {rid: Contig(rid, seq, sp.id) for sp in species.values() for rid, seq in _records(sp)}
+    pool, recs = bytearray(), []
+    for sp in species.values():
+        for rid, seq in _records(sp):
+            recs.append((rid, sp.id, len(pool), len(seq)))
+            pool += seq
+    arr = np.frombuffer(pool, dtype=np.uint8)
+    return {rid: Contig(rid, arr[at:at + n], sid, arr, at) for rid, sid, at, n in recs}
+
+
+class ContigsInBackground(Mapping):
+    """initialize_contigs on a thread of its own: the mapping is there at once and waits for the reader the first time it is
+    looked into.  The pileup's first act is the BAM decode -- native code that does not hold the interpreter -- so the
+    genomes are read while the alignments are inflated instead of in front of them.  What the reader raises (a missing
+    genome ends the run, midas/run/snps.py:57) is raised where the mapping is first used."""
+
+    def __init__(self, species):
+        self._out, self._err = None, None
+
+        def work():
+            try:
+                self._out = initialize_contigs(species)
+            except BaseException as e:       # (SystemExit included: it must end the main thread's run, not this thread)
+                self._err = e
+        self._thread = threading.Thread(target=work, name="read-genomes", daemon=True)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+    def __getitem__(self, key):
+        return self.wait()[key]
+
+    def __iter__(self):
+        return iter(self.wait())
+
+    def __len__(self):
+        return len(self.wait())
 
 
 def _shell(args, stages):
@@ -124,10 +195,10 @@ def build_genome_db(args, species):
     """snps/temp/genomes.fa = every selected genome, then `bowtie2-build` on it (midas/run/snps.py:69-95)."""
     temp = os.path.join(args['outdir'], 'snps', 'temp')
     n_seqs = n_bases = 0
-    with open(os.path.join(temp, 'genomes.fa'), 'w') as out:
+    with open(os.path.join(temp, 'genomes.fa'), 'wb') as out:
         for sp in species.values():
             for rid, seq in _records(sp):
-                out.write('>%s\n%s\n' % (rid, seq))
+                out.write(b'>' + rid.encode('latin-1') + b'\n' + seq + b'\n')
                 n_seqs += 1
                 n_bases += len(seq)
     print("  total genomes: %s\n  total contigs: %s\n  total base-pairs: %s" % (len(species), n_seqs, n_bases))
@@ -215,7 +286,7 @@ def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid,
     ids = [c.id for c in mine]
     sub, read_begin = bam.group_by_contig(ref_names, refid, reads, ids)
     if all(span[it][0] == 0 and span[it][2] for it in items):
-        ref = np.frombuffer(''.join(c.seq for c in mine).encode('latin-1'), dtype=np.uint8)
+        ref = _reference_bytes([(c, 0, c.length) for c in mine])
         table = abi.ContigTable(length=[c.length for c in mine], species=[sp_index[c.species_id] for c in mine],
                                 read_begin=read_begin, ref=ref, n_species=len(species_ids), ids=ids,
                                 species_ids=list(species_ids))
@@ -224,7 +295,7 @@ def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid,
     keys = sorted(items, key=lambda it: (at[it[0]], it[1]))
     plan = [(at[cid], span[(cid, j)][0], span[(cid, j)][1], span[(cid, j)][2], int(halo[cid]) if halo else 0) for cid, j in keys]
     sub, read_begin = pieces.gather(sub, read_begin, plan)
-    ref = np.frombuffer(''.join(mine[k].seq[lo:hi] for k, lo, hi, _, _ in plan).encode('latin-1'), dtype=np.uint8)
+    ref = _reference_bytes([(mine[k], lo, hi) for k, lo, hi, _, _ in plan])
     table = abi.ContigTable(length=[hi - lo for _, lo, hi, _, _ in plan], species=[sp_index[mine[k].species_id] for k, *_ in plan],
                             read_begin=read_begin, ref=ref, n_species=len(species_ids), ids=[cid for cid, _ in keys],
                             species_ids=list(species_ids), origin=[lo for _, lo, _, _, _ in plan])
@@ -313,6 +384,10 @@ def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, 
     pos = {it: k for k, it in enumerate(keys)}
     off = table.site_offsets()
     out = {}
+    jobs = []       # (path, items, header): one table or part each
+
+    def _write_rows(args_, path, table_, pos_, items, counts_, allele_, off_, header, batch_):
+        jobs.append((path, items, header))
     for i, sp in enumerate(species_ids):
         cids = order[sp]
         owned = [owner.get(cid, 0) == rank for cid in cids]
@@ -336,7 +411,23 @@ def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, 
                        'covered_bases': int(stats[i, abi.STAT_COVERED_BASES]),
                        'aligned_reads': int(stats[i, abi.STAT_ALIGNED_READS]),
                        'mapped_reads': int(stats[i, abi.STAT_MAPPED_READS])}
+    _write_jobs(args, jobs, table, pos, counts, allele, off, batch)
     return out
+
+
+def _write_jobs(args, jobs, table, pos, counts, allele, off, batch):
+    """The tables and parts of _emit_contigs.  From a batch the files are written side by side: one file takes buffered
+    writes at 2-3 GB/s however many threads feed it, the device part of each call is short and taken in turn
+    (midas_snps_batch_write_part), so a few writers at a time keep the device's row coder and the page cache both busy."""
+    writers = min(len(jobs), WRITERS) if batch is not None else 1
+    if writers <= 1:
+        for path, items, header in jobs:
+            _write_rows(args, path, table, pos, items, counts, allele, off, header, batch)
+        return
+    with ThreadPoolExecutor(max_workers=writers) as pool:
+        for f in [pool.submit(_write_rows, args, path, table, pos, items, counts, allele, off, header, batch)
+                  for path, items, header in jobs]:
+            f.result()
 
 
 def _join_parts(args, species_ids, order, owner, rank):
@@ -615,7 +706,8 @@ def run_pipeline(args):
     print("\nReading reference data")
     start = time()
     species = initialize_species(args)
-    contigs = initialize_contigs(species)
+    # (the genomes are read on a thread of their own and waited for where the pileup first needs them)
+    contigs = ContigsInBackground(species) if args['call'] else initialize_contigs(species)
     print("  %s minutes" % round((time() - start) / 60, 2))
     print("  %s Gb maximum memory" % utility.max_mem_usage())
 

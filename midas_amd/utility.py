@@ -17,6 +17,8 @@ _OPENERS = {'gz': gzip.open, 'bz2': bz2.BZ2File}
 def iopen(inpath, mode='r'):
     """Text handle on a plain, gzip (.gz) or bzip2 (.bz2) file, chosen by extension."""
     opener = _OPENERS.get(inpath.rsplit('.', 1)[-1])
+    if 'b' in mode:         # (bytes: the FASTA of a representative genome goes to the device as bytes)
+        return opener(inpath, mode) if opener else open(inpath, mode)
     return io.TextIOWrapper(opener(inpath, mode)) if opener else open(inpath, mode)
 
 

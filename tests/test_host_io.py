@@ -148,6 +148,8 @@ def test_fasta_parser_matches_biopython_conventions():
     # mode has turned them into LF by the time the parser sees them) and blanks inside sequence lines; an empty header
     text = "stray line\n>a\nAC>GT \tN\n\n>\nTT\n> \nGG\n>b x y\n"
     assert list(fasta.parse(io.StringIO(text))) == [("a", "AC>GTN"), ("", "TT"), ("", "GG"), ("b", "")]
+    for t in (text, text.replace("\n", "\r\n"), ">c1 description here\nacgt\nNNAC\n\n>c2\nGG\n>c3\tx\n", "", "no header at all\n"):
+        assert [(i, s.decode()) for i, s in fasta.parse_bytes(t.encode())] == list(fasta.parse(io.StringIO(t.replace("\r\n", "\n"))))
     assert list(fasta.parse(io.StringIO(""))) == [] and list(fasta.parse(io.StringIO("no header at all\n"))) == []
     import random
     rng = random.Random(4)

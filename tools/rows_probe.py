@@ -2,7 +2,7 @@ import sys, os, time, gzip
 sys.path.insert(0, '.')
 import numpy as np
 from midas_amd import abi, synth
-table, reads = synth.make_dataset(**synth.CONFIGS['c2'])
+table, reads = synth.make_dataset(**synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"])
 thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
 with abi.Context(0) as ctx:
     b = ctx.batch(table, reads); b.run(thr); b.sync()
