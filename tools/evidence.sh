@@ -31,4 +31,14 @@ prof() {   # prof <name> <bench args...>
 }
 prof c3
 prof c2 --config c2
+# the stage end to end at configs[1] (configs[2] takes three minutes of set-up: tools/e2e_stage.py c3, run by hand) and the
+# row coder's kernel under rocprofv3
+E2E_REPS=3 timeout 900 python tools/e2e_stage.py c2 /tmp/e2e_c2 > $EV/e2e_stage_c2.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_rows -o rows -- python $REPO/tools/rows_probe.py c2 > $EV/rows_probe_c2.log 2>&1 )
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/rows_probe.py c2   (three device-coded and three host-coded writes of the 15 M rows of configs[1])"
+  cat $EV/rows_probe_c2.log
+  f=$(find $REPO/gpurun_out/prof_rows -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && { echo "# kernel_stats.csv"; head -12 "$f"; }; } > $EV/${TAG}_rows_deflate_rocprofv3_stats.txt 2>&1
+rm -rf $REPO/gpurun_out/prof_rows
 ls -la $EV
