@@ -293,7 +293,7 @@ def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid,
         return table, sub, [(c.id, 0) for c in mine]
     at = {c.id: k for k, c in enumerate(mine)}
     keys = sorted(items, key=lambda it: (at[it[0]], it[1]))
-    plan = [(at[cid], span[(cid, j)][0], span[(cid, j)][1], span[(cid, j)][2], int(halo[cid]) if halo else 0) for cid, j in keys]
+    plan = [(at[cid], span[(cid, j)][0], span[(cid, j)][1], span[(cid, j)][2], int(halo.get(cid, 0)) if halo else 0) for cid, j in keys]
     sub, read_begin = pieces.gather(sub, read_begin, plan)
     ref = _reference_bytes([(mine[k], lo, hi) for k, lo, hi, _, _ in plan])
     table = abi.ContigTable(length=[hi - lo for _, lo, hi, _, _ in plan], species=[sp_index[mine[k].species_id] for k, *_ in plan],

@@ -179,7 +179,11 @@ if os.environ.get("SNPS_SPLIT_LENGTH"):
     args['split_length'] = int(os.environ["SNPS_SPLIT_LENGTH"])
 species = msnps.initialize_species(args)
 contigs = msnps.initialize_contigs(species)
-msnps.pysam_pileup(args, species, contigs, make_context=OracleContext)
+if os.environ.get("SNPS_REAL_DEVICE"):       # (tests/test_gpu_dist.py: the ranks share GPU 0)
+    os.environ["LOCAL_RANK"] = "0"
+    msnps.pysam_pileup(args, species, contigs)
+else:
+    msnps.pysam_pileup(args, species, contigs, make_context=OracleContext)
 if rank == 0:
     msnps.snps_summary(args, species)
     print("LOG:" + args['log'].getvalue().replace("\n", "|"))
@@ -279,6 +283,42 @@ def test_one_long_contig_is_cut_into_pieces_across_ranks(tmp_path):
                 assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(many, "snps", "output", f), "rb").read()
     finally:
         del os.environ["SNPS_SPLIT_LENGTH"]
+
+
+def mixed_sample():
+    """One species of a single 6 Mb contig and two of five 40 kb contigs each: pieces and whole contigs in one rank's table."""
+    from midas_amd import abi, synth
+    big, big_reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=6000000, n_reads=120000, seed=91, var_len=True)
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=5, contig_len=40000, n_reads=30000, seed=92)
+    table = abi.ContigTable(length=np.concatenate([big.length, contigs.length]), species=[0] + [1 + int(s) for s in contigs.species],
+                            read_begin=np.concatenate([big.read_begin, contigs.read_begin[1:] + big.read_begin[-1]]),
+                            ref=np.concatenate([big.ref, contigs.ref]), n_species=3,
+                            ids=["Big_00001_chromosome"] + list(contigs.ids), species_ids=["Big_00001"] + list(contigs.species_ids))
+    return table, synth.concat_reads([big_reads, reads])
+
+
+def test_pieces_and_whole_contigs_in_one_ranks_table(tmp_path):
+    import shutil
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    table, rd = mixed_sample()
+    db, one, two = str(tmp_path / "db"), str(tmp_path / "n1"), str(tmp_path / "n2")
+    synth.write_sample(one, db, table, rd)
+    (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+    assert rc == 0, e
+    shutil.copytree(one, two, ignore=shutil.ignore_patterns("output"))
+    os.makedirs(os.path.join(two, "snps", "output"))
+    os.environ["SNPS_SPLIT_LENGTH"] = str(1 << 20)
+    try:
+        res = _run_snps_workers(tmp_path, script, two, db, 2)
+    finally:
+        del os.environ["SNPS_SPLIT_LENGTH"]
+    assert all(rc == 0 for rc, _, _ in res), "\n".join(e[-1500:] for _, _, e in res)
+    assert any("long contigs: 1 cut into pieces of 1048576 positions" in o for _, o, _ in res)
+    for f in sorted(os.listdir(os.path.join(one, "snps", "output"))):
+        assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(two, "snps", "output", f), "rb").read()
+    assert open(os.path.join(one, "snps", "summary.txt")).read() == open(os.path.join(two, "snps", "summary.txt")).read()
 
 
 def test_two_ranks_on_a_bam_that_is_not_coordinate_sorted_fall_back_to_the_whole_decode(tmp_path):
