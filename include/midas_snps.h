@@ -354,6 +354,24 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
  * Replaces the same `pysam.AlignmentFile` + `fetch(contig, ...)` of midas/run/snps.py:186, 194-199 (which goes through
  * the .bai the reference builds at :130-137; no index file is needed here).                                           */
 int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256);
+/* The same decoders with the BGZF blocks inflated ON THE DEVICE of `ctx` (bgzf_inflate.hip: one thread per block, its Huffman
+ * tables in LDS) instead of by the host's threads: the compressed bytes go up, the inflated stream comes back, records are
+ * walked and decoded into columns by the host as before.  On a 16-CPU host inflating is two thirds of the pileup stage once
+ * the pileup and the row coder are on the device; with eight ranks sharing a node's CPUs it is more.  Same results, same
+ * statuses (a corrupt block: MIDAS_SNPS_ERR_BAD_LAYOUT); a device failure is an error, not a fall-back.
+ *   midas_bam_open_device          = midas_bam_open (whole file; then midas_bam_load as usual)
+ *   midas_bam_load_ranges_device   = midas_bam_load_ranges on a handle of midas_bam_open_slice
+ *   midas_snps_inflate_blocks      the inflater on its own: n raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k],
+ *                                  +ulen[k]) (host pointers; every stream must inflate to exactly ulen[k] bytes).  On a
+ *                                  corrupt stream *bad_block (may be NULL) is its index.
+ * Replaces the inflate inside pysam.AlignmentFile / htslib's bgzf.c behind midas/run/snps.py:186.                        */
+int32_t midas_bam_open_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, char* err256);
+int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
+                                     const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                                     int64_t* n_cigar, char* err256);
+int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, int64_t n_blocks,
+                                  const int64_t* cpos, const int32_t* clen, const int64_t* upos, const int32_t* ulen,
+                                  uint8_t* out, int64_t out_bytes, int64_t* bad_block);
 int32_t midas_bam_slice_facts(const midas_bam* bam, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases,
                               int64_t* ref_first);
 /* What the walk of midas_bam_open_slice noted for cutting LONG references into pieces (midas_snps_contigs.origin), so that a

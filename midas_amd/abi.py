@@ -250,6 +250,9 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_open_slice': (i32, [C.c_char_p, i32, i32, C.POINTER(vp), C.c_char_p]),
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
         'midas_bam_slice_marks': (i32, [vp, vp, vp, vp, C.c_int64]),
+        'midas_bam_open_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.c_char_p]),
+        'midas_bam_load_ranges_device': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_snps_inflate_blocks': (i32, [vp, vp, i64, i64, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
         'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, C.c_char_p]),
@@ -297,6 +300,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
+    'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
@@ -483,13 +487,17 @@ def read_snps_counts(paths, row_begin: int = 0, max_rows: int = -1):
         lib.midas_snps_tableset_close(h)
 
 
-def read_bam(path: str):
+def read_bam(path: str, ctx=None):
     """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA).  The arrays are views of
-    the decoder's own buffers (no copy); the native handle lives as long as any of them does."""
+    the decoder's own buffers (no copy); the native handle lives as long as any of them does.  ctx (a Context): the BGZF
+    blocks are inflated on its device instead of by the host's threads (midas_bam_open_device)."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
-    st = lib.midas_bam_open(path.encode(), C.byref(h), err)
+    if ctx is not None and getattr(ctx, 'inflates', False):
+        st = lib.midas_bam_open_device(path.encode(), ctx._h, C.byref(h), err)
+    else:
+        st = lib.midas_bam_open(path.encode(), C.byref(h), err)
     if st != 0:
         raise MidasSnpsError(st, err.value.decode())
     owner = _BamOwner(lib, h)
@@ -581,15 +589,20 @@ class BamSlice:
             self._lib.midas_bam_slice_marks(self._h, p(out4), None, p(marks), marks.shape[0])
         return int(out4[0]), int(out4[1]), int(out4[2]), span, marks
 
-    def load_ranges(self, ranges):
-        """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order."""
+    def load_ranges(self, ranges, ctx=None):
+        """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order.
+        ctx (a Context): the blocks are inflated on its device (midas_bam_load_ranges_device)."""
         rb = np.array([r[0] for r in ranges], np.int64)
         re_ = np.array([r[1] for r in ranges], np.int64)
         n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         err = C.create_string_buffer(256)
         p = lambda x: x.ctypes.data_as(C.c_void_p)
-        st = self._lib.midas_bam_load_ranges(self._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(sb), C.byref(qb),
-                                             C.byref(nc), err)
+        if ctx is not None and getattr(ctx, 'inflates', False):
+            st = self._lib.midas_bam_load_ranges_device(self._h, ctx._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(sb),
+                                                        C.byref(qb), C.byref(nc), err)
+        else:
+            st = self._lib.midas_bam_load_ranges(self._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(sb), C.byref(qb),
+                                                 C.byref(nc), err)
         if st != 0:
             raise MidasSnpsError(st, err.value.decode())
         keeper = _BamOwner(self._lib, None)
@@ -733,6 +746,24 @@ class Context:
         """PAD_SPEC (default): the CIGAR op P consumes nothing; PAD_PYSAM: it advances the query position, as
         get_aligned_pairs of the pysam releases of MIDAS's time does.  For batches created afterwards."""
         self._check(self._lib.midas_snps_set_pad_rule(self._h, int(rule)))
+
+    inflates = True      # read_bam / BamSlice.load_ranges may hand this context the BGZF blocks
+
+    def inflate_blocks(self, comp, cpos, clen, upos, ulen, out_bytes: int):
+        """Raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k], +ulen[k]) on the device (midas_snps_inflate_blocks).
+        Raises MidasSnpsError (ERR_BAD_LAYOUT, read_index = the stream) when a stream is corrupt."""
+        comp = np.ascontiguousarray(np.frombuffer(comp, np.uint8) if not isinstance(comp, np.ndarray) else comp, dtype=np.uint8)
+        cpos, upos = np.ascontiguousarray(cpos, np.int64), np.ascontiguousarray(upos, np.int64)
+        clen, ulen = np.ascontiguousarray(clen, np.int32), np.ascontiguousarray(ulen, np.int32)
+        out = np.zeros(max(int(out_bytes), 1), np.uint8)
+        bad = C.c_int64(-1)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_snps_inflate_blocks(self._h, p(comp), comp.size, cpos.size, p(cpos), p(clen), p(upos), p(ulen),
+                                                 p(out), int(out_bytes), C.byref(bad))
+        if st != 0:
+            msg = self._lib.midas_snps_last_error(self._h).decode() or self._lib.midas_snps_status_string(st).decode()
+            raise MidasSnpsError(st, msg, int(bad.value))
+        return out[:int(out_bytes)]
 
     def set_row_coder(self, coder: int):
         """ROWS_DEVICE (default): Batch.write_part formats and deflates the rows in a kernel; ROWS_HOST: the host's

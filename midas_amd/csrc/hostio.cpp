@@ -236,7 +236,7 @@ bool raw_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) {
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
-int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256) {
+int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
   fseek(f, 0, SEEK_END);
@@ -294,6 +294,17 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
   }
   if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   lap("block table");
+  if (inflater) {
+    std::vector<midas::InflateJob> jobs;
+    jobs.reserve(blocks.size());
+    for (const Blk& b : blocks) jobs.push_back({(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)b.clen, (uint32_t)b.ulen});
+    const midas::InflateSegment seg{comp.data(), comp.size()};
+    int64_t bad_job = -1;
+    const int32_t st = inflater->run(inflater->user, &seg, 1, jobs.data(), jobs.size(), out.data(), out.size(), &bad_job, err256);
+    if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) set_err(err256, "%s: corrupt deflate data", path.c_str());
+    lap("inflate blocks (inflater)");
+    return st;
+  }
   std::atomic<size_t> next{0};
   std::atomic<int> bad{0};
   auto work = [&] {
@@ -847,13 +858,16 @@ size_t parse_bam_header(const uint8_t* d, size_t n, midas_bam* b, bool* bad_magi
 
 extern "C" {
 
-int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) {
+int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) { return midas::bam_open_with(path, nullptr, out, err256); }
+}  // extern "C"
+
+int32_t midas::bam_open_with(const char* path, const midas::BlockInflater* inflater, midas_bam** out, char* err256) {
   if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
   midas_bam* b = new (std::nothrow) midas_bam();
   if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   b->path = path;
-  int32_t st = bgzf_inflate_file(b->path, b->data, err256);
+  int32_t st = bgzf_inflate_file(b->path, b->data, err256, inflater);
   if (st != MIDAS_SNPS_OK) { delete b; return st; }
   const RawBuf<uint8_t>& d = b->data;
   if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) {
@@ -881,6 +895,8 @@ int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) {
   *out = b;
   return MIDAS_SNPS_OK;
 }
+
+extern "C" {
 
 void midas_bam_close(midas_bam* b) { delete b; }
 
@@ -1083,6 +1099,13 @@ int32_t midas_bam_slice_marks(const midas_bam* b, int64_t* out4, int64_t* ref_sp
 
 int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* range_begin, const int64_t* range_end,
                               int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  return midas::bam_load_ranges_with(b, nullptr, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
+}
+}  // extern "C"
+
+int32_t midas::bam_load_ranges_with(midas_bam* b, const midas::BlockInflater* inflater, int32_t n_ranges, const int64_t* range_begin,
+                                    const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                                    int64_t* n_cigar, char* err256) {
   if (!b || !b->map || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();
@@ -1108,11 +1131,35 @@ int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* ran
   RawBuf<uint8_t> buf;
   if (!buf.resize(bytes)) { set_err(err256, "out of memory inflating %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   std::atomic<int> bad{0};
+  if (inflater) {
+    // runs of consecutive blocks are consecutive in the file: one segment each
+    std::vector<midas::InflateSegment> segs;
+    std::vector<midas::InflateJob> jobs;
+    jobs.reserve(list.size());
+    uint64_t cat = 0;
+    for (size_t k = 0; k < list.size(); ++k) {
+      const BgzfMap::Blk& blk = m.blocks[list[k]];
+      const bool joins = k > 0 && list[k] == list[k - 1] + 1;
+      if (!joins) {
+        if (!segs.empty()) cat += segs.back().n;
+        segs.push_back({m.base + blk.fpos, 0});
+      }
+      // (a block's stream lies between its header and its 8-byte footer; the segment runs on to the end of the block)
+      const uint64_t seg_base = cat;
+      jobs.push_back({seg_base + (uint64_t)(blk.cpos - (size_t)(segs.back().p - m.base)), (uint64_t)at[list[k]], (uint32_t)blk.clen, blk.ulen});
+      segs.back().n = (size_t)(blk.cpos + blk.clen + 8 - (size_t)(segs.back().p - m.base));
+    }
+    int64_t bad_job = -1;
+    const int32_t ist = inflater->run(inflater->user, segs.data(), segs.size(), jobs.data(), jobs.size(), buf.data(), bytes, &bad_job, err256);
+    if (ist == MIDAS_SNPS_ERR_BAD_LAYOUT) bad = 1;
+    else if (ist != MIDAS_SNPS_OK) return ist;
+  } else {
   run_pool(hw_threads(0), list.size(), [&](size_t k) {
     const BgzfMap::Blk& blk = m.blocks[list[k]];
     if (blk.ulen == 0) return;
     if (!raw_inflate(m.base + blk.cpos, (size_t)blk.clen, buf.data() + at[list[k]], (size_t)blk.ulen)) bad = 1;
   });
+  }
   if (bad) { set_err(err256, "%s: corrupt deflate data", b->path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   // walk every range from its first record to exactly its end (a range's blocks are consecutive in the buffer)
   std::vector<size_t> offs;
@@ -1140,6 +1187,8 @@ int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* ran
   if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
   return MIDAS_SNPS_OK;
 }
+
+extern "C" {
 
 namespace {
 // The gzip members of a table written by this library, found without inflating anything: {data offset, compressed bytes,

@@ -1,5 +1,6 @@
 #pragma once
 #include "../../include/midas_snps.h"
+#include <cstddef>
 
 namespace midas {
 
@@ -19,6 +20,25 @@ struct RowFeed {
 
 int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, const char* const* ref_ids, const int64_t* n_sites,
                        int32_t gz_level, int32_t threads, const RowFeed& feed, char* err256, const int64_t* first_pos = nullptr);
+
+// Many raw DEFLATE streams inflated at once by somebody else than the host's threads (the device: snps_abi.hip).  The
+// compressed bytes are given as segments that the streams' cpos count through back to back; upos are offsets into out.
+struct InflateJob { uint64_t cpos, upos; uint32_t clen, ulen; };
+struct InflateSegment { const uint8_t* p; size_t n; };
+struct BlockInflater {
+  void* user;
+  // MIDAS_SNPS_OK, MIDAS_SNPS_ERR_BAD_LAYOUT (a stream is corrupt: *bad_job says which) or what went wrong on the way
+  int32_t (*run)(void* user, const InflateSegment* segs, size_t n_segs, const InflateJob* jobs, size_t n_jobs, uint8_t* out,
+                 size_t out_bytes, int64_t* bad_job, char* err256);
+};
+}  // namespace midas
+struct midas_bam;
+namespace midas {
+// midas_bam_open / midas_bam_load_ranges with the BGZF blocks inflated by `inflater` (nullptr: the host's threads)
+int32_t bam_open_with(const char* path, const BlockInflater* inflater, midas_bam** out, char* err256);
+int32_t bam_load_ranges_with(midas_bam* bam, const BlockInflater* inflater, int32_t n_ranges, const int64_t* range_begin,
+                             const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                             int64_t* n_cigar, char* err256);
 
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.

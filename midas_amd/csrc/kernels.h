@@ -253,6 +253,16 @@ struct RowsParams {
 };
 hipError_t launch_rows_deflate(const RowsParams& p, int grid_blocks, hipStream_t s);
 
+// bgzf_inflate.hip: raw DEFLATE streams (BGZF blocks) inflated on the device, one thread per stream
+struct InflateBlock { unsigned long long cpos, upos; uint32_t clen, ulen; };
+struct InflateParams {
+  const uint8_t* comp;             // the streams (8 bytes of slack behind the last one)
+  const InflateBlock* blocks; long long n_blocks;
+  uint8_t* out;
+  uint32_t* status;                // per stream: 0 = inflated to exactly ulen bytes
+};
+hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s);
+
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);

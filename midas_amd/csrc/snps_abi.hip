@@ -427,6 +427,100 @@ int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, d
   return MIDAS_SNPS_OK;
 }
 
+namespace {
+// midas::BlockInflater over a context: the streams go to the device, one thread inflates each (bgzf_inflate.hip), the
+// inflated bytes come back through the staging ring.
+int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, const InflateJob* jobs, size_t n_jobs, uint8_t* out,
+                       size_t out_bytes, int64_t* bad_job, char* err256) {
+  midas_snps_ctx* ctx = static_cast<midas_snps_ctx*>(user);
+  if (bad_job) *bad_job = -1;
+  if (n_jobs == 0) return MIDAS_SNPS_OK;
+  size_t comp_bytes = 0;
+  for (size_t k = 0; k < n_segs; ++k) comp_bytes += segs[k].n;
+  for (size_t k = 0; k < n_jobs; ++k) {
+    if (jobs[k].cpos + jobs[k].clen > comp_bytes || jobs[k].upos + jobs[k].ulen > out_bytes) {
+      if (err256) snprintf(err256, 256, "device inflate: stream %lld lies outside the buffers", (long long)k);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+  }
+  auto hip_err = [&](hipError_t e, const char* what) {
+    if (err256) snprintf(err256, 256, "device inflate: %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP;
+  };
+#define INF_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
+  std::lock_guard<std::mutex> g(ctx->device_mutex);
+  INF_TRY(hipSetDevice(ctx->device));
+  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status;
+  INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 64));
+  INF_TRY(hipMalloc(&d_out.p, out_bytes + 64));
+  INF_TRY(hipMalloc(&d_blocks.p, n_jobs * sizeof(InflateBlock)));
+  INF_TRY(hipMalloc(&d_status.p, n_jobs * 4));
+  hipStream_t s = ctx->stream;
+  size_t at = 0;
+  for (size_t k = 0; k < n_segs; ++k) {
+    if (segs[k].n) INF_TRY(hipMemcpyAsync(static_cast<uint8_t*>(d_comp.p) + at, segs[k].p, segs[k].n, hipMemcpyHostToDevice, s));
+    at += segs[k].n;
+  }
+  INF_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_comp.p) + comp_bytes, 0, 64, s));
+  std::vector<InflateBlock> blocks(n_jobs);
+  for (size_t k = 0; k < n_jobs; ++k) blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, jobs[k].clen, jobs[k].ulen};
+  INF_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+  InflateParams ip;
+  ip.comp = static_cast<const uint8_t*>(d_comp.p);
+  ip.blocks = static_cast<const InflateBlock*>(d_blocks.p);
+  ip.n_blocks = (long long)n_jobs;
+  ip.out = static_cast<uint8_t*>(d_out.p);
+  ip.status = static_cast<uint32_t*>(d_status.p);
+  INF_TRY(launch_bgzf_inflate(ip, s));
+  std::vector<uint32_t> status(n_jobs);
+  INF_TRY(hipMemcpyAsync(status.data(), d_status.p, n_jobs * 4, hipMemcpyDeviceToHost, s));
+  INF_TRY(hipStreamSynchronize(s));
+#undef INF_TRY
+  for (size_t k = 0; k < n_jobs; ++k) {
+    if (status[k] != 0u) {
+      if (bad_job) *bad_job = (int64_t)k;
+      if (err256) snprintf(err256, 256, "corrupt deflate data (stream %lld: code %u)", (long long)k, status[k]);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+  }
+  const int32_t st = copy_to_host(ctx, out, d_out.p, out_bytes);
+  if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->err.c_str());
+  return st;
+}
+}  // namespace
+
+int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, int64_t n_blocks,
+                                  const int64_t* cpos, const int32_t* clen, const int64_t* upos, const int32_t* ulen,
+                                  uint8_t* out, int64_t out_bytes, int64_t* bad_block) {
+  if (!ctx || comp_bytes < 0 || n_blocks < 0 || out_bytes < 0 || (n_blocks > 0 && (!comp || !cpos || !clen || !upos || !ulen || !out)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  std::vector<InflateJob> jobs((size_t)n_blocks);
+  for (int64_t k = 0; k < n_blocks; ++k) {
+    if (cpos[k] < 0 || clen[k] < 0 || upos[k] < 0 || ulen[k] < 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "inflate_blocks: negative offset or size");
+    jobs[(size_t)k] = InflateJob{(uint64_t)cpos[k], (uint64_t)upos[k], (uint32_t)clen[k], (uint32_t)ulen[k]};
+  }
+  const InflateSegment seg{comp, (size_t)comp_bytes};
+  char err[256] = {0};
+  const int32_t st = device_inflate(ctx, &seg, 1, jobs.data(), jobs.size(), out, (size_t)out_bytes, bad_block, err);
+  if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_open_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, char* err256) {
+  if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const BlockInflater inf{ctx, device_inflate};
+  return bam_open_with(path, &inf, out, err256);
+}
+
+int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
+                                     const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                                     int64_t* n_cigar, char* err256) {
+  if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const BlockInflater inf{ctx, device_inflate};
+  return bam_load_ranges_with(bam, &inf, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
+}
+
 int32_t midas_snps_set_row_coder(midas_snps_ctx* ctx, int32_t coder) {
   if (!ctx || (coder != MIDAS_SNPS_ROWS_DEVICE && coder != MIDAS_SNPS_ROWS_HOST)) return MIDAS_SNPS_ERR_INVALID_ARG;
   ctx->row_coder = coder;

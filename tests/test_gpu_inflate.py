@@ -1,0 +1,137 @@
+"""BGZF blocks inflated on the device (bgzf_inflate.hip: one thread per DEFLATE stream, Huffman tables in LDS), held to zlib:
+stored, fixed and dynamic blocks, streams of several blocks, empty streams, the longest codes and distances, matches that
+overlap their own output, every compression level, and corrupt streams (a status, never a fault).  Then the BAM decoder with
+the device as its inflater against the same decoder on the host's threads."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, bam, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with abi.Context(0) as c:
+        yield c
+
+
+def _raw(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _payloads():
+    rng = np.random.default_rng(7)
+    text = b"".join(b"read_%07d\t%d\tACGTTGCA%s\n" % (i, int(rng.integers(0, 1 << 20)), bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 40)))
+                    for i in range(1200))
+    out = {
+        "empty": b"",
+        "one_byte": b"x",
+        "zeros_64k": bytes(65280),
+        "run_of_one_symbol": b"a" * 5000,
+        "period_3": b"abc" * 9000,
+        "random_64k": bytes(rng.integers(0, 256, 65280, dtype=np.uint8)),
+        "text": text[:65000],
+        "two_symbols": bytes(rng.choice(np.frombuffer(b"ab", np.uint8), 30000)),
+        "skewed": bytes(np.minimum(rng.geometric(0.08, 60000), 255).astype(np.uint8)),       # long codes for the rare bytes
+        "far_matches": bytes(rng.integers(0, 256, 32768, dtype=np.uint8)) * 2,                 # distance 32768 (one shy of 64 KiB)
+        "bam_like": bytes(rng.integers(0, 16, 30000, dtype=np.uint8)) + bytes(rng.integers(20, 42, 30000, dtype=np.uint8)),
+    }
+    out["far_matches"] = out["far_matches"][:65280]
+    return out
+
+
+def _inflate_all(ctx, streams, sizes):
+    cpos, at = [], 0
+    blob = bytearray()
+    for s in streams:
+        cpos.append(len(blob))
+        blob += s
+    upos = np.concatenate([[0], np.cumsum(sizes)])[:-1] if sizes else np.zeros(0, np.int64)
+    return ctx.inflate_blocks(bytes(blob), cpos, [len(s) for s in streams], upos, sizes, int(sum(sizes))), upos
+
+
+def test_streams_of_every_kind_against_zlib(ctx):
+    cases, streams, plain = [], [], []
+    for name, data in _payloads().items():
+        for level in (0, 1, 6, 9):
+            for strat, sname in ((zlib.Z_DEFAULT_STRATEGY, "default"), (zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huffman"), (zlib.Z_RLE, "rle")):
+                if level == 0 and sname != "default":
+                    continue
+                cases.append("%s/level%d/%s" % (name, level, sname))
+                streams.append(_raw(data, level, strat))
+                plain.append(data)
+    # streams of several DEFLATE blocks: full flushes in the middle, a stored block between two dynamic ones
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [bytes(np.random.default_rng(k).integers(60, 70, 9000, dtype=np.uint8)) for k in range(4)]
+    s = b"".join(c.compress(p) + c.flush(zlib.Z_FULL_FLUSH) for p in parts[:3]) + c.compress(parts[3]) + c.flush()
+    cases.append("several_blocks"); streams.append(s); plain.append(b"".join(parts))
+    out, upos = _inflate_all(ctx, streams, [len(p) for p in plain])
+    for name, p, u in zip(cases, plain, upos):
+        got = bytes(out[int(u):int(u) + len(p)])
+        assert got == p, "%s: first difference at %d" % (name, next((i for i in range(len(p)) if got[i] != p[i]), -1))
+    assert len(cases) > 120
+
+
+def test_corrupt_streams_are_a_status(ctx):
+    data = _payloads()["text"]
+    good = _raw(data)
+    rng = np.random.default_rng(3)
+    bad = []
+    for k in range(40):                       # flipped bits, truncations, garbage
+        b = bytearray(good)
+        if k % 3 == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k % 3 == 1:
+            b = b[:int(rng.integers(1, len(b) - 1))]
+        else:
+            b = bytearray(rng.integers(0, 256, int(rng.integers(10, 3000)), dtype=np.uint8).tobytes())
+        bad.append(bytes(b))
+    for b in bad:
+        try:                                   # what zlib makes of it: a complete stream of the expected size, or not
+            d = zlib.decompressobj(-15)
+            ref = d.decompress(b)
+            valid = d.eof and len(ref) == len(data)
+        except zlib.error:
+            valid = False
+        try:
+            out = ctx.inflate_blocks(b, [0], [len(b)], [0], [len(data)], len(data))
+            assert valid and bytes(out) == ref     # (a flipped bit inside a literal's code is still a valid stream: no CRC at this level)
+        except abi.MidasSnpsError as e:
+            assert not valid and e.status == abi.ERR_BAD_LAYOUT and e.read_index == 0
+    # the wrong size is an error too
+    with pytest.raises(abi.MidasSnpsError):
+        ctx.inflate_blocks(good, [0], [len(good)], [0], [len(data) - 1], len(data) - 1)
+    with pytest.raises(abi.MidasSnpsError):
+        ctx.inflate_blocks(good, [0], [len(good)], [0], [len(data) + 1], len(data) + 1)
+
+
+def test_bam_decoded_with_the_device_inflater_equals_the_host_decode(ctx, tmp_path):
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=60000, n_reads=150000, seed=synth.BASE_SEED + 61, var_len=True)
+    out, db = str(tmp_path / "s"), str(tmp_path / "db")
+    synth.write_sample(out, db, contigs, reads)
+    path = os.path.join(out, "snps", "temp", "genomes.bam")
+    names_h, lens_h, refid_h, host = abi.read_bam(path)
+    names_d, lens_d, refid_d, dev = abi.read_bam(path, ctx)
+    assert names_h == names_d and lens_h == lens_d
+    np.testing.assert_array_equal(refid_h, refid_d)
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(host, k), getattr(dev, k), err_msg=k)
+    # a rank's slice ranges
+    sl = abi.BamSlice(path, 1, 3)
+    ranges = [(sl.first, sl.end)]
+    a = sl.load_ranges(ranges)
+    b = abi.BamSlice(path, 1, 3).load_ranges(ranges, ctx)
+    np.testing.assert_array_equal(a[0], b[0])
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(a[1], k), getattr(b[1], k), err_msg=k)
+    # a truncated file
+    data = open(path, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(data[:len(data) // 2])
+    with pytest.raises(abi.MidasSnpsError):
+        abi.read_bam(cut, ctx)

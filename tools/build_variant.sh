@@ -10,5 +10,5 @@ C=midas_amd/csrc
 EXTRA=""
 case " $* " in *MIDAS_SNPS_STREAM_KERNEL*) EXTRA="tools/variants/pileup_stream.hip -I$C";; esac   # the barrier-free kernel lives outside the product tree
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-atomic-optimizer-strategy=None -x hip "$@" $C/pack.cpp $C/hostio.cpp $C/row_deflate.cpp $C/pack_reads.hip $C/index_reads.hip \
-  $C/pileup_tiles.hip $C/index_direct.hip $C/pileup_direct.hip $C/rows_deflate.hip $EXTRA $C/merge_sites.hip $C/genes_count.hip $C/snps_abi.hip -o midas_amd/lib/libmidas_snps_hip_$SUF.so -lz -lpthread -ldl
+  $C/pileup_tiles.hip $C/index_direct.hip $C/pileup_direct.hip $C/rows_deflate.hip $C/bgzf_inflate.hip $EXTRA $C/merge_sites.hip $C/genes_count.hip $C/snps_abi.hip -o midas_amd/lib/libmidas_snps_hip_$SUF.so -lz -lpthread -ldl
 echo built midas_amd/lib/libmidas_snps_hip_$SUF.so
