@@ -33,19 +33,24 @@ constexpr int kLens = 320;                      // u8: code lengths while a tabl
 enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadSymbol = 4, kBadDistance = 5,
                   kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8 };
 
+// (pointers that SAY they point into LDS: through a generic pointer every table look-up would be a FLAT access, which waits
+// for the thread's outstanding global stores -- one store acknowledgement per symbol)
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 struct Lds {
-  uint16_t* s16;
-  uint8_t* s8;
+  lds_u16* s16;
+  lds_u8* s8;
   int lane;
-  __device__ __forceinline__ uint16_t& h(int i) const { return s16[i * kLanes + lane]; }
-  __device__ __forceinline__ uint8_t& b(int i) const { return s8[i * kLanes + lane]; }
+  __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kLanes + lane]; }
+  __device__ __forceinline__ lds_u8& b(int i) const { return s8[i * kLanes + lane]; }
 };
 
 // The compressed stream, least significant bit first (RFC 1951 3.1.1), read in aligned 32-bit words.
 struct BitIn {
-  const uint32_t* w;       // next aligned word
+  const uint32_t* w;       // next aligned word to load
   const uint8_t* end;      // first byte behind the stream
   unsigned long long buf;
+  uint32_t ahead;          // the word after the ones in buf, loaded one refill early: nobody waits for a load just issued
   int n;                   // valid bits in buf
   long long budget;        // bits of the stream not yet moved into buf (negative: the stream has been overrun)
   __device__ __forceinline__ void open(const uint8_t* p, size_t len) {
@@ -58,13 +63,16 @@ struct BitIn {
     }
     budget -= n;
     w = reinterpret_cast<const uint32_t*>(p);
+    ahead = *w++;
   }
   // at least 32 valid bits behind this (the buffers have 8 bytes of slack behind the last stream)
   __device__ __forceinline__ void refill() {
     if (n <= 32) {
-      buf |= (unsigned long long)(*w++) << n;
+      buf |= (unsigned long long)ahead << n;
       n += 32;
       budget -= 32;
+      ahead = budget > -64 ? *w : 0u;      // (never more than a few words behind the stream's end)
+      ++w;
     }
   }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
@@ -197,10 +205,33 @@ __device__ uint32_t fixed_tables(const Lds& L) {
   return kOk;
 }
 
-__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst, uint32_t ulen) {
+// The inflated bytes: literals are gathered four at a time into aligned words (a byte store per literal is four times the
+// stores and four times the acknowledgements the next load of input waits behind); a match first puts the gathered bytes out.
+struct ByteOut {
+  uint8_t* dst;
+  uint32_t o;          // bytes produced, the gathered ones included
+  uint32_t acc;
+  int na;              // gathered bytes (they belong at o - na ..)
+  uint32_t head;       // bytes in front of the first aligned word
+  __device__ __forceinline__ void open(uint8_t* d) { dst = d; o = 0; acc = 0; na = 0; head = (uint32_t)((0u - reinterpret_cast<uintptr_t>(d)) & 3u); }
+  __device__ __forceinline__ void literal(uint32_t b) {
+    if (o < head) { dst[o++] = (uint8_t)b; return; }
+    acc |= b << (8 * na);
+    ++o;
+    if (++na == 4) { *reinterpret_cast<uint32_t*>(dst + o - 4) = acc; acc = 0; na = 0; }
+  }
+  __device__ __forceinline__ void flush() {
+    for (int k = 0; k < na; ++k) dst[o - na + k] = (uint8_t)(acc >> (8 * k));
+    acc = 0; na = 0;
+  }
+};
+
+__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen) {
   BitIn in;
   in.open(src, clen);
-  uint32_t o = 0;
+  ByteOut out;
+  out.open(dst_);
+  uint8_t* const dst = dst_;
   for (;;) {
     in.refill();
     const uint32_t last = in.take(1), type = in.take(2);
@@ -211,12 +242,12 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
       in.refill();
       const uint32_t nlen = in.take(16);
       if ((len ^ 0xFFFFu) != nlen) return kBadStored;
-      if (o + len > ulen) return kOutputOverrun;
+      if (out.o + len > ulen) return kOutputOverrun;
       for (uint32_t k = 0; k < len; ++k) {
         in.refill();
-        dst[o++] = (uint8_t)in.take(8);
+        out.literal(in.take(8));
+        if (in.overrun()) return kInputOverrun;
       }
-      if (in.overrun()) return kInputOverrun;
     } else if (type == 3u) {
       return kBadBlockType;
     } else {
@@ -227,8 +258,9 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits);
         if (s < 0) return kBadSymbol;
         if (s < 256) {
-          if (o >= ulen) return kOutputOverrun;
-          dst[o++] = (uint8_t)s;
+          if (out.o >= ulen) return kOutputOverrun;
+          out.literal((uint32_t)s);
+          if (in.overrun()) return kInputOverrun;
           continue;
         }
         if (s == 256) break;
@@ -240,8 +272,10 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         if (d < 0 || d >= 30) return kBadDistance;
         in.refill();
         const uint32_t dist = c_dist_base[d] + in.take(c_dist_extra[d]);
-        if (dist > o) return kBadDistance;
-        if (o + len > ulen) return kOutputOverrun;
+        if (dist > out.o) return kBadDistance;
+        if (out.o + len > ulen) return kOutputOverrun;
+        out.flush();
+        uint32_t o = out.o;
         // the copy, in runs no longer than the distance (a run never reads what it writes) and no longer than 16:
         // all of a run's loads are issued before its stores
         uint32_t left = len;
@@ -256,13 +290,15 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
           o += run;
           left -= run;
         }
+        out.o = o;
         if (in.overrun()) return kInputOverrun;
       }
       if (in.overrun()) return kInputOverrun;
     }
     if (last) break;
   }
-  return o == ulen ? kOk : kShortOutput;
+  out.flush();
+  return out.o == ulen ? kOk : kShortOutput;
 }
 
 __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
   __shared__ uint8_t s8[kLens * kLanes];
   const long long k = (long long)blockIdx.x * kLanes + threadIdx.x;
   if (k >= p.n_blocks) return;
-  Lds L{s16, s8, (int)threadIdx.x};
+  Lds L{(lds_u16*)s16, (lds_u8*)s8, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
   uint32_t st = kOk;
   if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen);

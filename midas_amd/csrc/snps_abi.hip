@@ -450,6 +450,14 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   };
 #define INF_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
   std::lock_guard<std::mutex> g(ctx->device_mutex);
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;       // where the call spends its time, on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[device inflate] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   INF_TRY(hipSetDevice(ctx->device));
   struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status;
   INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 64));
@@ -472,10 +480,12 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   ip.n_blocks = (long long)n_jobs;
   ip.out = static_cast<uint8_t*>(d_out.p);
   ip.status = static_cast<uint32_t*>(d_status.p);
+  if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("hipMalloc + streams up"); }
   INF_TRY(launch_bgzf_inflate(ip, s));
   std::vector<uint32_t> status(n_jobs);
   INF_TRY(hipMemcpyAsync(status.data(), d_status.p, n_jobs * 4, hipMemcpyDeviceToHost, s));
   INF_TRY(hipStreamSynchronize(s));
+  lap("kernel");
 #undef INF_TRY
   for (size_t k = 0; k < n_jobs; ++k) {
     if (status[k] != 0u) {
@@ -486,6 +496,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   }
   const int32_t st = copy_to_host(ctx, out, d_out.p, out_bytes);
   if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->err.c_str());
+  lap("inflated bytes down");
   return st;
 }
 }  // namespace

@@ -22,6 +22,7 @@ import subprocess
 import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
+from contextlib import ExitStack
 from collections.abc import Mapping
 from time import time
 
@@ -453,8 +454,8 @@ def species_pileup(args, species_id, contigs):
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
     order, span = _whole(_species_contig_order([species_id], contigs), contigs)
     try:
-        decoded = abi.read_bam(bampath)
         with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
+            decoded = abi.read_bam(bampath, ctx if args.get('device_inflate') else None)
             stats = _pileup_contigs(args, [species_id], order[species_id], order, {}, decoded, ctx, span, contigs)
     except abi.MidasSnpsError as e:
         _exit_on(e)
@@ -569,7 +570,24 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     """midas/run/snps.py:219-244.  Name kept for drop-in; there is no pysam underneath.
     N ranks: contigs are the work items (the unit count_coverage is called on, :187-199), dealt to the ranks by
     longest-processing-time over bytes of aligned reads + sites; a rank piles up its contigs, writes their rows, and one
-    all-gather of [n_species, 5] partial counters follows.  make_context: tests substitute a CPU double of the device."""
+    all-gather of [n_species, 5] partial counters follows.  make_context: tests substitute a CPU double of the device.
+    The context is opened first: with args['device_inflate'] the device also inflates the BAM's blocks
+    (midas_bam_open_device; off by default -- DESIGN.md 5 has the measurements that say why)."""
+    error, ctx = None, None
+    stack = ExitStack()
+    try:
+        ctx = stack.enter_context(make_context())
+    except abi.MidasSnpsError as e:
+        error = _error_text(e)
+    except Exception as e:
+        error = "\nError: %s: %s\n" % (type(e).__name__, e)
+    dist.agree_or_exit(error)
+    with stack:
+        return _count_alleles(args, species, contigs, ctx)
+
+
+def _count_alleles(args, species, contigs, ctx):
+    inflater = ctx if args.get('device_inflate') else None
     start = time()
     rank, ws = dist.world()
     if rank == 0:
@@ -585,7 +603,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     decoded = None
     if plan is None:
         try:
-            decoded = abi.read_bam(bampath)
+            decoded = abi.read_bam(bampath, inflater)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)
@@ -627,7 +645,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     if plan is not None:
         try:
             refid, reads = plan['slice'].load_ranges(_record_ranges(plan, [(ref_index[cid],) + span[(cid, j)] for cid, j in mine
-                                                                           if cid in ref_index]))
+                                                                           if cid in ref_index]), inflater)
             decoded = (ref_names, ref_lens, refid, reads)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
@@ -640,8 +658,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
 
     local = {}
     try:
-        with make_context() as ctx:
-            local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx, span, contigs, halo)
+        local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx, span, contigs, halo)
     except abi.MidasSnpsError as e:
         error = _error_text(e)
     except SystemExit as e:
