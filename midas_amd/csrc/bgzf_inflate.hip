@@ -1,4 +1,4 @@
-// BGZF blocks inflated on the device: one THREAD per block.
+// BGZF blocks inflated on the device: one THREAD per block decodes, one WAVEFRONT per block copies the matches.
 //
 // A BAM is a chain of independent <= 64 KiB DEFLATE streams (BGZF, SAM spec 4.1); htslib inflates them one after the other,
 // this library's host decoder on all cores -- and with the pileup at a millisecond and the rows coded on the device, that
@@ -7,8 +7,12 @@
 // (RFC 1951: stored, fixed and dynamic blocks).  What makes that workable on a GPU is where the tables live: every lane's
 // 9-bit literal/length and 7-bit distance look-up tables sit in LDS, interleaved [entry][lane], so the one dependent memory
 // access per symbol is an LDS read, not a trip to HBM.  Codes longer than the look-up width (rare symbols) fall back to the
-// canonical bit-by-bit walk over the per-length counts (the classic `puff` decoder), also from LDS.  Matches are copied in
-// runs of up to 16 bytes -- loads first, then stores -- so a match costs one memory round trip, not one per byte.
+// canonical bit-by-bit walk over the per-length counts (the classic `puff` decoder), also from LDS.
+// Two kernels.  The decoder writes the literals where they belong and only NOTES the matches (position, length, distance):
+// Huffman decoding never looks at the output, and a lane that stopped to copy a match -- a round trip to memory for bytes it
+// wrote a moment ago -- would hold up the other 63 lanes of its wavefront on almost every symbol (measured: 2.3 us per symbol
+// that way).  The resolver then takes one wavefront per block through the block's matches in order, 64 bytes of a match per
+// step, with a fence only in front of a match whose source was written since the last one.
 // Replaces the inflate inside `pysam.AlignmentFile(...)` of midas/run/snps.py:186 (htslib's bgzf.c); bounds-checked against
 // both buffers at every step: corrupt input yields a status, never a fault.
 #include <hip/hip_runtime.h>
@@ -226,7 +230,14 @@ struct ByteOut {
   }
 };
 
-__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen) {
+// a noted match: position in the block's output | length << 32 | distance << 41
+__device__ __forceinline__ unsigned long long match_pack(uint32_t o, uint32_t len, uint32_t dist) {
+  return (unsigned long long)o | ((unsigned long long)len << 32) | ((unsigned long long)dist << 41);
+}
+
+__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen,
+                                unsigned long long* mlist, uint32_t* n_matches) {
+  uint32_t m = 0;
   BitIn in;
   in.open(src, clen);
   ByteOut out;
@@ -274,23 +285,10 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         const uint32_t dist = c_dist_base[d] + in.take(c_dist_extra[d]);
         if (dist > out.o) return kBadDistance;
         if (out.o + len > ulen) return kOutputOverrun;
+        // noted, not copied (at most ulen / 3 of them: the list's room)
         out.flush();
-        uint32_t o = out.o;
-        // the copy, in runs no longer than the distance (a run never reads what it writes) and no longer than 16:
-        // all of a run's loads are issued before its stores
-        uint32_t left = len;
-        while (left) {
-          uint32_t run = left < dist ? left : dist;
-          run = run < 16u ? run : 16u;
-          uint8_t t[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) t[k] = (uint32_t)k < run ? dst[o - dist + k] : (uint8_t)0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) if ((uint32_t)k < run) dst[o + k] = t[k];
-          o += run;
-          left -= run;
-        }
-        out.o = o;
+        mlist[m++] = match_pack(out.o, len, dist);
+        out.o += len;
         if (in.overrun()) return kInputOverrun;
       }
       if (in.overrun()) return kInputOverrun;
@@ -298,6 +296,7 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
     if (last) break;
   }
   out.flush();
+  *n_matches = m;
   return out.o == ulen ? kOk : kShortOutput;
 }
 
@@ -308,9 +307,43 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
   if (k >= p.n_blocks) return;
   Lds L{(lds_u16*)s16, (lds_u8*)s8, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
-  uint32_t st = kOk;
-  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen);
+  uint32_t st = kOk, nm = 0;
+  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen, p.matches + b.mbase, &nm);
   p.status[k] = st;
+  p.n_matches[k] = st == kOk ? nm : 0u;
+}
+
+// The matches of one block, in order, by one wavefront: byte i of a match is the byte `distance` in front of it -- for a match
+// longer than its distance the first `distance` bytes repeat, so every byte's source lies in front of the match and the 64
+// lanes copy without looking at each other.  A match whose source reaches into what this wavefront has written since its last
+// fence waits for those stores (and drops its cache lines) first.
+constexpr int kResolveWaves = 4;
+__global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_resolve_kernel(InflateParams p) {
+  const long long k = (long long)blockIdx.x * kResolveWaves + (threadIdx.x >> 6);
+  if (k >= p.n_blocks) return;
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t n = p.n_matches[k];
+  if (n == 0u) return;
+  const InflateBlock b = p.blocks[k];
+  uint8_t* out = p.out + b.upos;
+  const unsigned long long* list = p.matches + b.mbase;
+  uint32_t dirty = 0xFFFFFFFFu;           // the lowest position written since the last fence
+  unsigned long long rec = list[0];
+  for (uint32_t m = 0; m < n; ++m) {
+    const unsigned long long next = m + 1 < n ? list[m + 1] : 0ull;
+    const uint32_t o = (uint32_t)rec, len = (uint32_t)(rec >> 32) & 511u, dist = (uint32_t)(rec >> 41);
+    const uint32_t span = len < dist ? len : dist;
+    if (o - dist + span > dirty) {          // (wave-uniform)
+      __threadfence();
+      dirty = 0xFFFFFFFFu;
+    }
+    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
+      const uint32_t from = o - dist + (i < dist ? i : i % dist);
+      out[o + i] = out[from];
+    }
+    dirty = dirty < o ? dirty : o;
+    rec = next;
+  }
 }
 
 }  // namespace
@@ -319,6 +352,10 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s) {
   if (p.n_blocks <= 0) return hipSuccess;
   const long long g = (p.n_blocks + kLanes - 1) / kLanes;
   hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kLanes), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const long long g2 = (p.n_blocks + kResolveWaves - 1) / kResolveWaves;
+  hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)g2), dim3(kLanes * kResolveWaves), 0, s, p);
   return hipGetLastError();
 }
 

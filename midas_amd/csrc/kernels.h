@@ -254,12 +254,14 @@ struct RowsParams {
 hipError_t launch_rows_deflate(const RowsParams& p, int grid_blocks, hipStream_t s);
 
 // bgzf_inflate.hip: raw DEFLATE streams (BGZF blocks) inflated on the device, one thread per stream
-struct InflateBlock { unsigned long long cpos, upos; uint32_t clen, ulen; };
+struct InflateBlock { unsigned long long cpos, upos, mbase; uint32_t clen, ulen; };   // mbase: the stream's room in `matches` (ulen / 3 + 1)
 struct InflateParams {
   const uint8_t* comp;             // the streams (8 bytes of slack behind the last one)
   const InflateBlock* blocks; long long n_blocks;
   uint8_t* out;
   uint32_t* status;                // per stream: 0 = inflated to exactly ulen bytes
+  unsigned long long* matches;     // the matches the decoder noted for the resolver
+  uint32_t* n_matches;             // per stream
 };
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s);
 

@@ -459,11 +459,10 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     t_last = t;
   };
   INF_TRY(hipSetDevice(ctx->device));
-  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status;
+  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status, d_matches;
   INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 64));
   INF_TRY(hipMalloc(&d_out.p, out_bytes + 64));
   INF_TRY(hipMalloc(&d_blocks.p, n_jobs * sizeof(InflateBlock)));
-  INF_TRY(hipMalloc(&d_status.p, n_jobs * 4));
   hipStream_t s = ctx->stream;
   size_t at = 0;
   for (size_t k = 0; k < n_segs; ++k) {
@@ -472,7 +471,13 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   }
   INF_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_comp.p) + comp_bytes, 0, 64, s));
   std::vector<InflateBlock> blocks(n_jobs);
-  for (size_t k = 0; k < n_jobs; ++k) blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, jobs[k].clen, jobs[k].ulen};
+  unsigned long long n_match_room = 0;
+  for (size_t k = 0; k < n_jobs; ++k) {
+    blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen};
+    n_match_room += jobs[k].ulen / 3u + 1u;       // (a match is three bytes at the least)
+  }
+  INF_TRY(hipMalloc(&d_matches.p, (size_t)n_match_room * 8));
+  INF_TRY(hipMalloc(&d_status.p, n_jobs * 8));
   INF_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
   InflateParams ip;
   ip.comp = static_cast<const uint8_t*>(d_comp.p);
@@ -480,6 +485,8 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   ip.n_blocks = (long long)n_jobs;
   ip.out = static_cast<uint8_t*>(d_out.p);
   ip.status = static_cast<uint32_t*>(d_status.p);
+  ip.n_matches = static_cast<uint32_t*>(d_status.p) + n_jobs;
+  ip.matches = static_cast<unsigned long long*>(d_matches.p);
   if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("hipMalloc + streams up"); }
   INF_TRY(launch_bgzf_inflate(ip, s));
   std::vector<uint32_t> status(n_jobs);

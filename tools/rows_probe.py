@@ -1,5 +1,5 @@
 import sys, os, time, gzip
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 from midas_amd import abi, synth
 table, reads = synth.make_dataset(**synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"])
