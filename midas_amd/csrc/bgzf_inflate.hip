@@ -31,7 +31,14 @@ constexpr int kSymLl = kLutD + (1 << kDBits);   // 288: symbols sorted by (lengt
 constexpr int kSymD = kSymLl + 288;             // 32
 constexpr int kCntLl = kSymD + 32;              // 16: codes per length
 constexpr int kCntD = kCntLl + 16;              // 16
-constexpr int kU16 = kCntD + 16;                // 992
+// per length, while a table is built: where the next symbol of that length goes in the sorted list, and the next code of that
+// length; afterwards, therefore: the END of the length's symbols and the END of its codes -- what the long-code path needs
+constexpr int kOffsLl = kCntD + 16;             // 16
+constexpr int kNextLl = kOffsLl + 16;           // 16
+constexpr int kOffsD = kNextLl + 16;            // 16
+constexpr int kNextD = kOffsD + 16;             // 16
+constexpr int kU16 = kNextD + 16;               // 1056
+constexpr int kRing = 16;                       // u32, per lane: the next 64 bytes of the lane's stream
 constexpr int kLens = 320;                      // u8: code lengths while a table is built
 
 enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadSymbol = 4, kBadDistance = 5,
@@ -41,24 +48,43 @@ enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 
 // for the thread's outstanding global stores -- one store acknowledgement per symbol)
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct Lds {
   lds_u16* s16;
   lds_u8* s8;
+  lds_u32* s32;
   int lane;
+  __device__ __forceinline__ lds_u32& r(uint32_t i) const { return s32[(i & (kRing - 1)) * kLanes + lane]; }
   __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kLanes + lane]; }
   __device__ __forceinline__ lds_u8& b(int i) const { return s8[i * kLanes + lane]; }
 };
 
-// The compressed stream, least significant bit first (RFC 1951 3.1.1), read in aligned 32-bit words.
+// The compressed stream, least significant bit first (RFC 1951 3.1.1).  Between memory and the bit buffer sits a ring of 32
+// words per lane in LDS, topped up 32 bytes at a time by loads that are issued EIGHT steps of the symbol loop before their
+// words are needed.  (A lane that loaded its next word only when it ran dry would not stall just itself: a wavefront waits
+// for its outstanding loads as one, some lane of 64 runs dry on nearly every step, and every step would cost a trip to
+// memory -- 2.3 us per symbol, measured.)
 struct BitIn {
-  const uint32_t* w;       // next aligned word to load
-  const uint8_t* end;      // first byte behind the stream
+  const uint32_t* w;       // next aligned words to fetch
   unsigned long long buf;
-  uint32_t ahead;          // the word after the ones in buf, loaded one refill early: nobody waits for a load just issued
   int n;                   // valid bits in buf
   long long budget;        // bits of the stream not yet moved into buf (negative: the stream has been overrun)
-  __device__ __forceinline__ void open(const uint8_t* p, size_t len) {
-    end = p + len;
+  uint32_t rd, wr;         // ring positions (words, counted up for ever)
+  uint32_t pre[8];         // the words on their way
+  bool on_the_way;
+  __device__ __forceinline__ void fetch() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[k] = w[k];
+    w += 8;
+    on_the_way = true;
+  }
+  __device__ __forceinline__ void land(const Lds& L) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.r(wr + (uint32_t)k) = pre[k];
+    wr += 8u;
+    on_the_way = false;
+  }
+  __device__ __forceinline__ void open(const Lds& L, const uint8_t* p, size_t len) {
     buf = 0; n = 0;
     budget = (long long)len * 8;
     while ((reinterpret_cast<uintptr_t>(p) & 3u) && n < 32) {      // bytes up to the first aligned word
@@ -67,16 +93,26 @@ struct BitIn {
     }
     budget -= n;
     w = reinterpret_cast<const uint32_t*>(p);
-    ahead = *w++;
+    rd = wr = 0u;
+    fetch();
   }
-  // at least 32 valid bits behind this (the buffers have 8 bytes of slack behind the last stream)
-  __device__ __forceinline__ void refill() {
+  // every eighth step of the symbol loop, all lanes of the step together: what was fetched last time goes into the ring,
+  // the next 32 bytes are asked for (if the ring has room for them behind those)
+  __device__ __forceinline__ void top_up(const Lds& L) {
+    if (on_the_way && wr - rd <= (uint32_t)kRing - 8u) land(L);
+    if (!on_the_way && wr - rd <= (uint32_t)kRing - 8u && budget - 32ll * (long long)(wr - rd) > -1024) fetch();
+  }
+  // at least 32 valid bits behind this (the stream buffer has 256 bytes of slack behind the last stream)
+  __device__ __forceinline__ void refill(const Lds& L) {
     if (n <= 32) {
-      buf |= (unsigned long long)ahead << n;
+      if (rd == wr) {                 // the ring ran dry (a table header, a stretch of long matches): wait for the words
+        if (!on_the_way) fetch();
+        land(L);
+      }
+      buf |= (unsigned long long)L.r(rd) << n;
+      ++rd;
       n += 32;
       budget -= 32;
-      ahead = budget > -64 ? *w : 0u;      // (never more than a few words behind the stream's end)
-      ++w;
     }
   }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
@@ -89,8 +125,8 @@ struct BitIn {
 // Canonical Huffman tables of one alphabet from the code lengths in L.b(0..n): counts per length, symbols sorted by
 // (length, symbol), and the look-up table over the first `bits` bits.  False: over-subscribed or incomplete (an incomplete
 // code is allowed only as the single-code case, as zlib allows it).
-__device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lut_at, int bits) {
-  for (int l = 0; l < 16; ++l) L.h(cnt_at + l) = 0;
+__device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lut_at, int bits, int kOffs, int kNext) {
+  for (int l = 0; l < 16; ++l) { L.h(cnt_at + l) = 0; L.h(kOffs + l) = 0; L.h(kNext + l) = 0; }
   for (int s = 0; s < n; ++s) L.h(cnt_at + L.b(s)) += 1;
   for (int i = 0; i < (1 << bits); ++i) L.h(lut_at + i) = 0;
   if (L.h(cnt_at) == n) return true;              // no codes at all: legal for the distance alphabet of a literal-only block
@@ -101,23 +137,25 @@ __device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lu
     if (left < 0) return false;                   // over-subscribed
   }
   if (left > 0 && !(n - (int)L.h(cnt_at) == 1 && L.h(cnt_at + 1) == 1)) return false;     // incomplete
-  // offsets of every length in the sorted symbol list (kept in registers: 15 small numbers would not pay for LDS round trips)
-  uint32_t offs[16];
-  offs[1] = 0;
-#pragma unroll
-  for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + L.h(cnt_at + l);
-  // first code of every length (RFC 1951 3.2.2)
-  uint32_t next[16];
-  uint32_t code = 0;
-  next[0] = 0;
-#pragma unroll
-  for (int l = 1; l < 16; ++l) { code = (code + (l > 1 ? (uint32_t)L.h(cnt_at + l - 1) : 0u)) << 1; next[l] = code; }
+  // per length: where its next symbol goes in the sorted list, and its next code (RFC 1951 3.2.2) -- in LDS, indexed by the
+  // symbol's length (a lane's own index: registers cannot be indexed per lane)
+  {
+    uint32_t off = 0, code = 0;
+    L.h(kOffs) = 0; L.h(kNext) = 0;
+    for (int l = 1; l < 16; ++l) {
+      const uint32_t c = L.h(cnt_at + l);
+      code = (code + (l > 1 ? (uint32_t)L.h(cnt_at + l - 1) : 0u)) << 1;
+      L.h(kOffs + l) = (uint16_t)off;
+      L.h(kNext + l) = (uint16_t)code;
+      off += c;
+    }
+  }
   for (int s = 0; s < n; ++s) {
     const int l = L.b(s);
     if (!l) continue;
-    uint32_t o = 0, c = 0;
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { if (k == l) { o = offs[k]; offs[k] = o + 1; c = next[k]; next[k] = c + 1; } }
+    const uint32_t o = L.h(kOffs + l), c = L.h(kNext + l);
+    L.h(kOffs + l) = (uint16_t)(o + 1u);
+    L.h(kNext + l) = (uint16_t)(c + 1u);
     L.h(sym_at + (int)o) = (uint16_t)s;
     if (l <= bits) {
       const uint32_t r = __brev(c) >> (32 - l);
@@ -127,49 +165,61 @@ __device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lu
   return true;
 }
 
-// One symbol: the look-up table, else the canonical walk length by length.  Returns -1 on a code no symbol has.
-__device__ __forceinline__ int decode(const Lds& L, BitIn& in, int cnt_at, int sym_at, int lut_at, int bits) {
+// One symbol: the look-up table; a code longer than the table's width (a rare symbol -- but with 64 streams in a wavefront
+// some lane meets one on most steps, so this path has to be short too) is found by its length: canonical codes of length l
+// are the numbers below end[l] that no shorter code is a prefix of, and their symbols end at sorted position offs_end[l].
+// Returns -1 on a code no symbol has.
+__device__ __forceinline__ int decode(const Lds& L, BitIn& in, int cnt_at, int sym_at, int lut_at, int bits, int offs_at, int next_at) {
   const uint32_t e = L.h(lut_at + (int)in.peek(bits));
   if (e) { in.skip((int)(e & 15u)); return (int)(e >> 4); }
-  int code = 0, first = 0, index = 0;
-  unsigned long long b = in.buf;
-  for (int l = 1; l < 16; ++l) {
-    code |= (int)(b & 1ull);
-    b >>= 1;
-    const int count = (int)L.h(cnt_at + l);
-    if (code - count < first) { in.skip(l); return (int)L.h(sym_at + index + (code - first)); }
-    index += count;
-    first += count;
-    first <<= 1;
-    code <<= 1;
+  const uint32_t v15 = __brev((uint32_t)in.buf) >> 17;          // the next 15 bits as a code reads them, first bit on top
+  for (int l = bits + 1; l < 16; ++l) {
+    const uint32_t code = v15 >> (15 - l);
+    const uint32_t end = L.h(next_at + l);
+    if (code < end) {
+      const uint32_t count = L.h(cnt_at + l);
+      if (code + count < end) return -1;                         // (below the length's first code: an incomplete code's gap)
+      in.skip(l);
+      return (int)L.h(sym_at + (int)(L.h(offs_at + l) - (end - code)));
+    }
   }
   return -1;
 }
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// RFC 1951 3.2.5 in closed form (a table in constant memory would be a trip to memory, waited for, on every match -- and
+// with 64 streams in a wavefront some lane has a match on almost every step):
+//   length code 257 + s -> (first length, extra bits);  distance code d -> (first distance, extra bits)
+__device__ __forceinline__ void length_of(int s, uint32_t* base, int* extra) {
+  if (s < 8) { *base = 3u + (uint32_t)s; *extra = 0; return; }
+  if (s == 28) { *base = 258u; *extra = 0; return; }
+  *extra = (s >> 2) - 1;
+  *base = 3u + ((4u + (uint32_t)(s & 3)) << *extra);
+}
+__device__ __forceinline__ void distance_of(int d, uint32_t* base, int* extra) {
+  if (d < 4) { *base = 1u + (uint32_t)d; *extra = 0; return; }
+  *extra = (d >> 1) - 1;
+  *base = 1u + ((2u + (uint32_t)(d & 1)) << *extra);
+}
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // The literal / length and distance tables of a dynamic block (RFC 1951 3.2.7) into LDS.
 __device__ uint32_t read_dynamic_header(const Lds& L, BitIn& in) {
-  in.refill();
+  in.refill(L);
   const int hlit = (int)in.take(5) + 257, hdist = (int)in.take(5) + 1, hclen = (int)in.take(4) + 4;
   if (hlit > 286 || hdist > 30) return kBadCodeLengths;
   for (int i = 0; i < 19; ++i) L.b(i) = 0;
   for (int i = 0; i < hclen; ++i) {
-    in.refill();
+    in.refill(L);
     L.b(c_cl_order[i]) = (uint8_t)in.take(3);
   }
   // the code-length code borrows the distance alphabet's arrays (they are built last)
-  if (!build_tables(L, 19, kCntD, kSymD, kLutD, kDBits)) return kBadCodeLengths;
+  if (!build_tables(L, 19, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD)) return kBadCodeLengths;
   // (the lengths are decoded into the top of the byte array first: the code-length code's own lengths sit at 0..18 until here)
   int i = 0, prev = 0;
   const int total = hlit + hdist;
   while (i < total) {
-    in.refill();
-    const int s = decode(L, in, kCntD, kSymD, kLutD, kDBits);
+    in.refill(L);
+    const int s = decode(L, in, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD);
     if (s < 0) return kBadCodeLengths;
     int rep = 1, val = s;
     if (s == 16) { if (i == 0) return kBadCodeLengths; val = prev; rep = 3 + (int)in.take(2); }
@@ -187,19 +237,20 @@ __device__ uint32_t read_dynamic_header(const Lds& L, BitIn& in) {
   // distance lengths first (they sit behind the literal / length ones and are copied down to a scratch stretch of the
   // symbol array while the literal / length tables are built from 0..hlit)
   for (int k = 0; k < hdist; ++k) L.h(kSymD + k) = L.b(hlit + k);
-  if (!build_tables(L, hlit, kCntLl, kSymLl, kLutLl, kLlBits)) return kBadCodeLengths;
+  if (!build_tables(L, hlit, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl)) return kBadCodeLengths;
   for (int k = 0; k < hdist; ++k) L.b(k) = (uint8_t)L.h(kSymD + k);
-  if (!build_tables(L, hdist, kCntD, kSymD, kLutD, kDBits)) return kBadCodeLengths;
+  if (!build_tables(L, hdist, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD)) return kBadCodeLengths;
   return kOk;
 }
 
 __device__ uint32_t fixed_tables(const Lds& L) {
   for (int s = 0; s < 288; ++s) L.b(s) = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-  if (!build_tables(L, 288, kCntLl, kSymLl, kLutLl, kLlBits)) return kBadCodeLengths;
+  if (!build_tables(L, 288, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl)) return kBadCodeLengths;
   for (int s = 0; s < 30; ++s) L.b(s) = 5;
   // (30 codes of 5 bits leave the code incomplete, as the format defines it: build by hand what build_tables would refuse)
   for (int l = 0; l < 16; ++l) L.h(kCntD + l) = 0;
   L.h(kCntD + 5) = 30;
+  for (int l = 0; l < 16; ++l) { L.h(kOffsD + l) = (uint16_t)(l >= 5 ? 30 : 0); L.h(kNextD + l) = 0; }     // (every code is in the table)
   for (int i = 0; i < (1 << kDBits); ++i) L.h(kLutD + i) = 0;
   for (int s = 0; s < 30; ++s) {
     L.h(kSymD + s) = (uint16_t)s;
@@ -237,25 +288,25 @@ __device__ __forceinline__ unsigned long long match_pack(uint32_t o, uint32_t le
 
 __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen,
                                 unsigned long long* mlist, uint32_t* n_matches) {
-  uint32_t m = 0;
+  uint32_t m = 0, tick = 0;
   BitIn in;
-  in.open(src, clen);
+  in.open(L, src, clen);
   ByteOut out;
   out.open(dst_);
   uint8_t* const dst = dst_;
   for (;;) {
-    in.refill();
+    in.refill(L);
     const uint32_t last = in.take(1), type = in.take(2);
     if (type == 0u) {                                        // stored: to the next byte, LEN, ~LEN, the bytes
       in.skip(in.n & 7);
-      in.refill();
+      in.refill(L);
       const uint32_t len = in.take(16);
-      in.refill();
+      in.refill(L);
       const uint32_t nlen = in.take(16);
       if ((len ^ 0xFFFFu) != nlen) return kBadStored;
       if (out.o + len > ulen) return kOutputOverrun;
       for (uint32_t k = 0; k < len; ++k) {
-        in.refill();
+        in.refill(L);
         out.literal(in.take(8));
         if (in.overrun()) return kInputOverrun;
       }
@@ -265,8 +316,11 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
       const uint32_t st = type == 1u ? fixed_tables(L) : read_dynamic_header(L, in);
       if (st != kOk) return st;
       for (;;) {
-        in.refill();
-        int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits);
+        // (one count for all the lanes that take this step together: they top their rings up at the same steps)
+        tick = (uint32_t)__builtin_amdgcn_readfirstlane((int)tick) + 1u;
+        if ((tick & 7u) == 0u) in.top_up(L);
+        in.refill(L);
+        int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl);
         if (s < 0) return kBadSymbol;
         if (s < 256) {
           if (out.o >= ulen) return kOutputOverrun;
@@ -277,12 +331,17 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         if (s == 256) break;
         s -= 257;
         if (s >= 29) return kBadSymbol;
-        const uint32_t len = c_len_base[s] + in.take(c_len_extra[s]);      // (<= 5 extra bits: still >= 12 valid bits left)
-        in.refill();
-        const int d = decode(L, in, kCntD, kSymD, kLutD, kDBits);
+        uint32_t len;
+        int extra;
+        length_of(s, &len, &extra);
+        len += in.take(extra);                                               // (<= 5 extra bits: still >= 12 valid bits left)
+        in.refill(L);
+        const int d = decode(L, in, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD);
         if (d < 0 || d >= 30) return kBadDistance;
-        in.refill();
-        const uint32_t dist = c_dist_base[d] + in.take(c_dist_extra[d]);
+        in.refill(L);
+        uint32_t dist;
+        distance_of(d, &dist, &extra);
+        dist += in.take(extra);
         if (dist > out.o) return kBadDistance;
         if (out.o + len > ulen) return kOutputOverrun;
         // noted, not copied (at most ulen / 3 of them: the list's room)
@@ -303,9 +362,10 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
 __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
   __shared__ uint16_t s16[kU16 * kLanes];
   __shared__ uint8_t s8[kLens * kLanes];
+  __shared__ uint32_t s32[kRing * kLanes];
   const long long k = (long long)blockIdx.x * kLanes + threadIdx.x;
   if (k >= p.n_blocks) return;
-  Lds L{(lds_u16*)s16, (lds_u8*)s8, (int)threadIdx.x};
+  Lds L{(lds_u16*)s16, (lds_u8*)s8, (lds_u32*)s32, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
   uint32_t st = kOk, nm = 0;
   if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen, p.matches + b.mbase, &nm);
@@ -313,10 +373,12 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
   p.n_matches[k] = st == kOk ? nm : 0u;
 }
 
-// The matches of one block, in order, by one wavefront: byte i of a match is the byte `distance` in front of it -- for a match
-// longer than its distance the first `distance` bytes repeat, so every byte's source lies in front of the match and the 64
-// lanes copy without looking at each other.  A match whose source reaches into what this wavefront has written since its last
-// fence waits for those stores (and drops its cache lines) first.
+// The matches of one block, in order, by one wavefront -- 64 at a time where they allow it.  A match only reads what lies in
+// front of it, so a run of consecutive matches whose sources all lie in front of the run's FIRST destination can be copied at
+// the same moment, one lane per match (most matches of a BAM are a few bytes long); the run ends in front of the first match
+// that reads what the run writes.  One fence per run makes the run's bytes visible to the next one's loads.  Inside a lane the
+// copy goes in pieces no longer than the distance and no longer than 16 bytes, loads first, then stores (a match longer than
+// its distance repeats its first `distance` bytes: the pieces read what the lane itself stored a step earlier).
 constexpr int kResolveWaves = 4;
 __global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_resolve_kernel(InflateParams p) {
   const long long k = (long long)blockIdx.x * kResolveWaves + (threadIdx.x >> 6);
@@ -327,33 +389,48 @@ __global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_resolve_kernel(In
   const InflateBlock b = p.blocks[k];
   uint8_t* out = p.out + b.upos;
   const unsigned long long* list = p.matches + b.mbase;
-  uint32_t dirty = 0xFFFFFFFFu;           // the lowest position written since the last fence
-  unsigned long long rec = list[0];
-  for (uint32_t m = 0; m < n; ++m) {
-    const unsigned long long next = m + 1 < n ? list[m + 1] : 0ull;
+  uint32_t m = 0;
+  while (m < n) {
+    const bool have = m + (uint32_t)lane < n;
+    const unsigned long long rec = have ? list[m + (uint32_t)lane] : 0ull;
     const uint32_t o = (uint32_t)rec, len = (uint32_t)(rec >> 32) & 511u, dist = (uint32_t)(rec >> 41);
+    const uint32_t first = (uint32_t)__shfl((int)o, 0);                  // the run's first destination
     const uint32_t span = len < dist ? len : dist;
-    if (o - dist + span > dirty) {          // (wave-uniform)
-      __threadfence();
-      dirty = 0xFFFFFFFFu;
+    const bool free_of_run = have && (lane == 0 || o - dist + span <= first);
+    const unsigned long long ok = __ballot(free_of_run);
+    const int run = ok == ~0ull ? 64 : (int)__ffsll((long long)~ok) - 1;  // leading lanes that are free
+    if (lane < run) {
+      uint32_t at = o, left = len;
+      while (left) {
+        uint32_t piece = left < dist ? left : dist;
+        piece = piece < 16u ? piece : 16u;
+        uint8_t t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = (uint32_t)q < piece ? out[at - dist + q] : (uint8_t)0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if ((uint32_t)q < piece) out[at + q] = t[q];
+        at += piece;
+        left -= piece;
+      }
     }
-    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
-      const uint32_t from = o - dist + (i < dist ? i : i % dist);
-      out[o + i] = out[from];
-    }
-    dirty = dirty < o ? dirty : o;
-    rec = next;
+    // (the run's stores in front of the next run's loads.  The same wavefront, the same CU's cache: a workgroup-scope fence.
+    // An agent-scope __threadfence() writes the XCD's whole L2 back -- 150 us a time here.)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    m += (uint32_t)run;
   }
 }
 
 }  // namespace
 
-hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s) {
+hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {
   if (p.n_blocks <= 0) return hipSuccess;
-  const long long g = (p.n_blocks + kLanes - 1) / kLanes;
-  hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kLanes), 0, s, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (phases & 1) {
+    const long long g = (p.n_blocks + kLanes - 1) / kLanes;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kLanes), 0, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (!(phases & 2)) return hipSuccess;
   const long long g2 = (p.n_blocks + kResolveWaves - 1) / kResolveWaves;
   hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)g2), dim3(kLanes * kResolveWaves), 0, s, p);
   return hipGetLastError();

@@ -263,7 +263,7 @@ struct InflateParams {
   unsigned long long* matches;     // the matches the decoder noted for the resolver
   uint32_t* n_matches;             // per stream
 };
-hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s);
+hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases = 3);    // 1: decode, 2: resolve the matches
 
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);

@@ -460,7 +460,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   };
   INF_TRY(hipSetDevice(ctx->device));
   struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status, d_matches;
-  INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 64));
+  INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 512));
   INF_TRY(hipMalloc(&d_out.p, out_bytes + 64));
   INF_TRY(hipMalloc(&d_blocks.p, n_jobs * sizeof(InflateBlock)));
   hipStream_t s = ctx->stream;
@@ -469,7 +469,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     if (segs[k].n) INF_TRY(hipMemcpyAsync(static_cast<uint8_t*>(d_comp.p) + at, segs[k].p, segs[k].n, hipMemcpyHostToDevice, s));
     at += segs[k].n;
   }
-  INF_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_comp.p) + comp_bytes, 0, 64, s));
+  INF_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_comp.p) + comp_bytes, 0, 512, s));
   std::vector<InflateBlock> blocks(n_jobs);
   unsigned long long n_match_room = 0;
   for (size_t k = 0; k < n_jobs; ++k) {
@@ -488,7 +488,16 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   ip.n_matches = static_cast<uint32_t*>(d_status.p) + n_jobs;
   ip.matches = static_cast<unsigned long long*>(d_matches.p);
   if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("hipMalloc + streams up"); }
-  INF_TRY(launch_bgzf_inflate(ip, s));
+  if (trace) {
+    INF_TRY(launch_bgzf_inflate(ip, s, 1));
+    INF_TRY(hipStreamSynchronize(s));
+    lap("decode kernel");
+    INF_TRY(launch_bgzf_inflate(ip, s, 2));
+    INF_TRY(hipStreamSynchronize(s));
+    lap("resolve kernel");
+  } else {
+    INF_TRY(launch_bgzf_inflate(ip, s));
+  }
   std::vector<uint32_t> status(n_jobs);
   INF_TRY(hipMemcpyAsync(status.data(), d_status.p, n_jobs * 4, hipMemcpyDeviceToHost, s));
   INF_TRY(hipStreamSynchronize(s));
