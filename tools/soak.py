@@ -1,13 +1,19 @@
 """Developer soak (GPU box): random dataset shapes against the C oracle, every batch run three times (the self-resetting
-device counters -- split tickets, dynamic work items -- must leave no state behind).  usage: python tools/soak.py [seconds] [seed] [big]"""
+device counters -- split tickets, dynamic work items -- must leave no state behind), on the path the batch chooses and on the
+other one; the same work cut into pieces (midas_snps_contigs.origin); the rows from the device's coder against the host
+formatter's text; the columns' bytes through zlib and back through the device inflater.
+usage: python tools/soak.py [seconds] [seed] [big]"""
+import gzip
 import os
 import sys
+import tempfile
 import time
+import zlib
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from midas_amd import abi, synth  # noqa: E402
+from midas_amd import abi, pieces, synth  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 
 
@@ -32,6 +38,7 @@ def main():
     ctx = abi.Context(0)
     t_end = time.time() + budget
     n = bad = 0
+    tally = {'rows': 0, 'pieces': 0, 'inflate': 0}
     while time.time() < t_end:
         read_len = int(rng.choice([36, 75, 100, 125, 150, 151, 250]))
         big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # > 1024 tiles: the dynamic work-item path
@@ -61,15 +68,62 @@ def main():
             counts, allele, stats = b.fetch()
             ok = ok and np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)
         info = b.info()
+        extra = []
+        if st == 0 and ok:
+            # the other path
+            other = abi.PATH_PACKED if info.path == abi.PATH_DIRECT else abi.PATH_DIRECT
+            try:
+                b.select_path(other)
+                b.run(thr)
+                c2, a2, s2 = b.fetch()
+                if not (np.array_equal(c2, oc) and np.array_equal(a2, oa) and np.array_equal(s2, os_)):
+                    ok = False; extra.append("other path")
+            except abi.MidasSnpsError:
+                pass                                   # (the direct path declines unsorted input; there is none here)
+            # rows: device coder vs host formatter, as text
+            if contigs.n_sites <= 3000000 and rng.random() < 0.5:
+                with tempfile.TemporaryDirectory() as td:
+                    pick = list(range(contigs.n_contigs))
+                    ctx.set_row_coder(abi.ROWS_DEVICE)
+                    b.write_part(td + "/d.gz", pick, contigs.ids, header=True, gz_level=4, threads=4)
+                    off = contigs.site_offsets()
+                    abi.write_table(td + "/h.gz", contigs.ids, [oa[off[k]:off[k + 1]] for k in pick],
+                                    [oc[off[k]:off[k + 1]] for k in pick], gz_level=4, threads=4)
+                    if gzip.open(td + "/d.gz", "rb").read() != gzip.open(td + "/h.gz", "rb").read():
+                        ok = False; extra.append("rows")
+                    tally['rows'] += 1
         b.close()
+        if st == 0 and ok and reads.n_reads > 0 and not tag and rng.random() < 0.5:
+            # the same work in pieces
+            pt, pr, _ = pieces.split_table(contigs, reads, int(rng.choice([65536, 131072, 262144])))
+            if pt.n_contigs > contigs.n_contigs:
+                c3, a3, s3 = ctx.pileup(thr, pt, pr)
+                if not (np.array_equal(c3, oc) and np.array_equal(a3, oa) and np.array_equal(s3, os_)):
+                    ok = False; extra.append("pieces")
+                tally['pieces'] += 1
+        if reads.n_reads > 0 and rng.random() < 0.3:
+            # BAM-like bytes through zlib and back through the device inflater, in BGZF-sized streams
+            blob = np.concatenate([reads.seq4[:400000], reads.qual[:400000], reads.cigar[:50000].view(np.uint8)]).tobytes()
+            chunks = [blob[i:i + 65280] for i in range(0, len(blob), 65280)]
+            lvl = int(rng.choice([1, 6, 9]))
+            streams = []
+            for ch in chunks:
+                co = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+                streams.append(co.compress(ch) + co.flush())
+            cpos = np.concatenate([[0], np.cumsum([len(s) for s in streams])])[:-1]
+            upos = np.concatenate([[0], np.cumsum([len(c) for c in chunks])])[:-1]
+            got = ctx.inflate_blocks(b"".join(streams), cpos, [len(s) for s in streams], upos, [len(c) for c in chunks], len(blob))
+            if bytes(got) != blob:
+                ok = False; extra.append("inflate")
+            tally['inflate'] += 1
         n += 1
         if not ok:
             bad += 1
-            print("MISMATCH", kw, tag, args, flush=True)
+            print("MISMATCH", kw, tag, args, extra, flush=True)
         elif n % 10 == 0:
             print("%d cases ok (last: %d sites, %d reads, %d tiles, %d items%s)" % (n, info.n_sites, info.n_reads, info.n_tiles,
                                                                                    info.n_work_items, tag), flush=True)
-    print("soak: %d cases, %d mismatches" % (n, bad))
+    print("soak: %d cases (of them %s), %d mismatches" % (n, ", ".join("%d with %s" % (v, k) for k, v in tally.items()), bad))
     sys.exit(1 if bad else 0)
 
 
