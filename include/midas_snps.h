@@ -364,8 +364,19 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
  *   midas_snps_inflate_blocks      the inflater on its own: n raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k],
  *                                  +ulen[k]) (host pointers; every stream must inflate to exactly ulen[k] bytes).  On a
  *                                  corrupt stream *bad_block (may be NULL) is its index.
- * Replaces the inflate inside pysam.AlignmentFile / htslib's bgzf.c behind midas/run/snps.py:186.                        */
+ * Replaces the inflate inside pysam.AlignmentFile / htslib's bgzf.c behind midas/run/snps.py:186.
+ *   midas_bam_load_device          open + load in one call, and SEQ / QUAL / CIGAR never come down: the host walks the
+ *                                  records and decodes the small columns from the inflated stream as before, the three payload
+ *                                  columns are cut out of the stream where it lies on the device.  midas_bam_columns then hands
+ *                                  out DEVICE addresses for entries 9-11 (midas_bam_payload_on_device says so; midas_bam_copy
+ *                                  refuses them), which midas_snps_batch_create / midas_snps_pileup accept in
+ *                                  midas_snps_reads.seq4 / qual / cigar (they copy device to device).  They belong to `bam`.
+ *   midas_snps_copy_from_device    bytes of such a column into host memory (tests; host code that must slice a payload).   */
 int32_t midas_bam_open_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, char* err256);
+int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
+                              int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+int32_t midas_bam_payload_on_device(const midas_bam* bam);
+int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* src, int64_t bytes);
 int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
                                      const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                      int64_t* n_cigar, char* err256);

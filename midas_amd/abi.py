@@ -116,6 +116,9 @@ class ReadsSoA:
     seq4: np.ndarray
     qual: np.ndarray
     cigar: np.ndarray
+    # (seq4, qual, cigar) as DEVICE addresses + whatever keeps them alive (read_bam(..., payload_on_device=True)): the three
+    # arrays above are empty then, and only a Context's batch / pileup -- which copy device to device -- can take the reads
+    device: Optional[tuple] = None
 
     def __post_init__(self):
         for k, dt in _SOA_DTYPES.items():
@@ -140,9 +143,11 @@ class ReadsSoA:
 
     def _c(self) -> _Reads:
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # zero-size arrays still have a valid address
+        payload = (p(self.seq4), p(self.qual), p(self.cigar)) if self.device is None else \
+            tuple(C.c_void_p(int(x)) for x in self.device[:3])
         return _Reads(self.n_reads, p(self.pos), p(self.mapq), p(self.flag), p(self.nm), p(self.l_seq),
                       self.seq_off.ctypes.data_as(C.c_void_p), self.qual_off.ctypes.data_as(C.c_void_p),
-                      self.cigar_off.ctypes.data_as(C.c_void_p), p(self.seq4), p(self.qual), p(self.cigar))
+                      self.cigar_off.ctypes.data_as(C.c_void_p), *payload)
 
 
 @dataclass
@@ -251,6 +256,9 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
         'midas_bam_slice_marks': (i32, [vp, vp, vp, vp, C.c_int64]),
         'midas_bam_open_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.c_char_p]),
+        'midas_bam_load_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_bam_payload_on_device': (i32, [vp]),
+        'midas_snps_copy_from_device': (i32, [vp, vp, vp, i64]),
         'midas_bam_load_ranges_device': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_inflate_blocks': (i32, [vp, vp, i64, i64, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
@@ -300,7 +308,8 @@ EXPORTED_SYMBOLS = [
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
-    'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks',
+    'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
+    'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
@@ -487,13 +496,26 @@ def read_snps_counts(paths, row_begin: int = 0, max_rows: int = -1):
         lib.midas_snps_tableset_close(h)
 
 
-def read_bam(path: str, ctx=None):
+def read_bam(path: str, ctx=None, payload_on_device: bool = False):
     """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA).  The arrays are views of
     the decoder's own buffers (no copy); the native handle lives as long as any of them does.  ctx (a Context): the BGZF
-    blocks are inflated on its device instead of by the host's threads (midas_bam_open_device)."""
+    blocks are inflated on its device instead of by the host's threads (midas_bam_open_device); with payload_on_device SEQ,
+    QUAL and CIGAR are also cut out of the inflated stream there and never come down (midas_bam_load_device): the ReadsSoA
+    carries their device addresses (`device`) and only that context's batches can take it."""
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
+    if payload_on_device:
+        if ctx is None or not getattr(ctx, 'inflates', False):
+            raise MidasSnpsError(ERR_INVALID_ARG, "payload_on_device needs a device context")
+        n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        st = lib.midas_bam_load_device(path.encode(), ctx._h, C.byref(h), C.byref(n), C.byref(sb), C.byref(qb), C.byref(nc), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        owner = _BamOwner(lib, h)
+        names, lens = _bam_refs(lib, h)
+        refid, reads = _bam_columns(lib, h, int(n.value), int(sb.value), int(qb.value), int(nc.value), owner, on_device=True)
+        return names, lens, refid, reads
     if ctx is not None and getattr(ctx, 'inflates', False):
         st = lib.midas_bam_open_device(path.encode(), ctx._h, C.byref(h), err)
     else:
@@ -541,8 +563,9 @@ class _Column:
             if n else np.empty(0, dt).__array_interface__
 
 
-def _bam_columns(lib, h, n, sb, qb, nc, owner=None):
-    """(refid, ReadsSoA) over the decoder's own buffers.  `owner` (a _BamOwner) is kept alive by every array."""
+def _bam_columns(lib, h, n, sb, qb, nc, owner=None, on_device=False):
+    """(refid, ReadsSoA) over the decoder's own buffers.  `owner` (a _BamOwner) is kept alive by every array.  on_device:
+    the last three columns are device addresses (midas_bam_load_device) and go into ReadsSoA.device."""
     ptrs = (C.c_void_p * 12)()
     st = lib.midas_bam_columns(h, ptrs)
     if st != 0:
@@ -552,8 +575,11 @@ def _bam_columns(lib, h, n, sb, qb, nc, owner=None):
     spec = [('refid', np.int32, n), ('pos', np.int32, n), ('mapq', np.uint8, n), ('flag', np.uint16, n), ('nm', np.int32, n),
             ('l_seq', np.int32, n), ('seq_off', np.int64, n + 1), ('qual_off', np.int64, n + 1), ('cigar_off', np.int64, n + 1),
             ('seq4', np.uint8, sb), ('qual', np.uint8, qb), ('cigar', np.uint32, nc)]
-    a = {name: np.asarray(_Column(owner, ptrs[k] or 0, cnt, dt)) for k, (name, dt, cnt) in enumerate(spec)}
+    a = {name: np.asarray(_Column(owner, ptrs[k] or 0, cnt, dt)) for k, (name, dt, cnt) in enumerate(spec[:9 if on_device else 12])}
     refid = a.pop('refid')
+    if on_device:
+        a.update(seq4=np.zeros(0, np.uint8), qual=np.zeros(0, np.uint8), cigar=np.zeros(0, np.uint32),
+                 device=(ptrs[9] or 0, ptrs[10] or 0, ptrs[11] or 0, owner))
     return refid, ReadsSoA(**a)
 
 
@@ -764,6 +790,20 @@ class Context:
             msg = self._lib.midas_snps_last_error(self._h).decode() or self._lib.midas_snps_status_string(st).decode()
             raise MidasSnpsError(st, msg, int(bad.value))
         return out[:int(out_bytes)]
+
+    def fetch_payload(self, reads: "ReadsSoA") -> "ReadsSoA":
+        """A ReadsSoA whose SEQ / QUAL / CIGAR live on the device (read_bam(..., payload_on_device=True)) with those three
+        columns copied down: for tests, and for host code that has to slice them."""
+        if reads.device is None:
+            return reads
+        n = reads.n_reads
+        sizes = (int(reads.seq_off[n]), int(reads.qual_off[n]), int(reads.cigar_off[n]) * 4)
+        out = [np.zeros(max(s, 1), np.uint8) for s in sizes]
+        for buf, src, s in zip(out, reads.device[:3], sizes):
+            self._check(self._lib.midas_snps_copy_from_device(self._h, buf.ctypes.data_as(C.c_void_p), C.c_void_p(int(src)), s))
+        d = reads.as_dict()
+        d.update(seq4=out[0][:sizes[0]], qual=out[1][:sizes[1]], cigar=out[2][:sizes[2]].view(np.uint32))
+        return ReadsSoA(**d)
 
     def set_row_coder(self, coder: int):
         """ROWS_DEVICE (default): Batch.write_part formats and deflates the rows in a kernel; ROWS_HOST: the host's

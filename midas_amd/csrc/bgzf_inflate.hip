@@ -420,7 +420,43 @@ __global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_resolve_kernel(In
   }
 }
 
+// The payload columns cut out of the inflated stream where it lies, in HBM: one wavefront per record copies the record's
+// CIGAR ops, 4-bit SEQ and QUAL (BAM record layout: SAM spec 4.2) to the offsets the host's size pass computed.  What the host
+// decoder does with three memcpy per record -- and then sends up the link again.
+__global__ __launch_bounds__(256) void bam_payload_kernel(PayloadParams p) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  for (long long i = wave; i < p.n_records; i += n_waves) {
+    const uint8_t* r = p.stream + p.rec_off[i];
+    const uint32_t l_name = r[12];
+    const uint32_t n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+    const uint32_t l = (uint32_t)r[20] | ((uint32_t)r[21] << 8) | ((uint32_t)r[22] << 16) | ((uint32_t)r[23] << 24);
+    const uint8_t* q = r + 36 + l_name;
+    uint32_t* cg = p.cigar + p.cigar_off[i];
+    for (uint32_t k = (uint32_t)lane; k < n_cig; k += 64u) {
+      const uint8_t* s = q + 4u * k;
+      cg[k] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    }
+    q += 4ull * n_cig;
+    uint8_t* sq = p.seq4 + p.seq_off[i];
+    const uint32_t ns = (l + 1u) / 2u;
+    for (uint32_t k = (uint32_t)lane; k < ns; k += 64u) sq[k] = q[k];
+    q += ns;
+    uint8_t* ql = p.qual + p.qual_off[i];
+    for (uint32_t k = (uint32_t)lane; k < l; k += 64u) ql[k] = q[k];
+  }
+}
+
 }  // namespace
+
+hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s) {
+  if (p.n_records <= 0) return hipSuccess;
+  long long g = (p.n_records + 3) / 4;
+  const long long cap = (long long)grid_blocks * 16;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(bam_payload_kernel, dim3((unsigned)g), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
 
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {
   if (p.n_blocks <= 0) return hipSuccess;

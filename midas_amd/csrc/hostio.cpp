@@ -107,6 +107,16 @@ struct midas_bam {
   RawBuf<uint32_t> cigar;
   size_t n_records = 0;
   bool loaded = false;
+  // midas_bam_load_device: SEQ / QUAL / CIGAR are cut out of the inflated stream ON THE DEVICE and stay there (the columns
+  // call hands out device pointers for them); the host decodes everything else
+  bool payload_on_device = false;
+  std::vector<uint64_t> rec_off;        // where every decoded record starts in the inflated stream (kept for the device's cut)
+  void* dev_payload[3] = {nullptr, nullptr, nullptr};
+  void (*dev_free)(void*) = nullptr;
+  ~midas_bam() {
+    if (dev_free)
+      for (void* q : dev_payload) if (q) dev_free(q);
+  }
 };
 
 // One sample's <species>.snps.gz, parsed: what build_temp_count_matrix (midas/merge/snps.py:246-271) extracts.
@@ -644,7 +654,9 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
     }
   }
   lap("record sizes + offsets");
-  if (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n])) {
+  const bool on_device = b->payload_on_device;
+  if (on_device) b->rec_off.assign(offs.begin(), offs.end());
+  if (!on_device && (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n]))) {
     set_err(err256, "out of memory decoding %s", b->path.c_str());
     return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   }
@@ -666,12 +678,12 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
         const uint32_t l = rd32(r + 16);
         b->l_seq[i] = (int32_t)l;
         const uint8_t* q = r + 32 + l_read_name;
-        memcpy(b->cigar.data() + b->cigar_off[i], q, 4ull * n_cig);
-        q += 4ull * n_cig;
-        memcpy(b->seq4.data() + b->seq_off[i], q, (l + 1) / 2);
-        q += (l + 1) / 2;
-        memcpy(b->qual.data() + b->qual_off[i], q, l);
-        q += l;
+        if (!on_device) {
+          memcpy(b->cigar.data() + b->cigar_off[i], q, 4ull * n_cig);
+          memcpy(b->seq4.data() + b->seq_off[i], q + 4ull * n_cig, (l + 1) / 2);
+          memcpy(b->qual.data() + b->qual_off[i], q + 4ull * n_cig + (l + 1) / 2, l);
+        }
+        q += 4ull * n_cig + (l + 1) / 2 + l;
         b->nm[i] = find_nm(q, r + bs);
       }
     }
@@ -815,6 +827,17 @@ extern "C" {
 int32_t midas_bam_open(const char* path, midas_bam** out, char* err256) { return midas::bam_open_with(path, nullptr, out, err256); }
 }  // extern "C"
 
+void midas::bam_keep_payload_on_device(midas_bam* b) { b->payload_on_device = true; }
+const uint64_t* midas::bam_record_offsets(const midas_bam* b, size_t* n) { *n = b->rec_off.size(); return b->rec_off.data(); }
+void midas::bam_offsets(const midas_bam* b, const int64_t** seq_off, const int64_t** qual_off, const int64_t** cigar_off) {
+  *seq_off = b->seq_off.data(); *qual_off = b->qual_off.data(); *cigar_off = b->cigar_off.data();
+}
+void midas::bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void (*free_fn)(void*)) {
+  b->dev_payload[0] = seq4; b->dev_payload[1] = qual; b->dev_payload[2] = cigar;
+  b->dev_free = free_fn;
+  std::vector<uint64_t>().swap(b->rec_off);
+}
+
 int32_t midas::bam_open_with(const char* path, const midas::BlockInflater* inflater, midas_bam** out, char* err256) {
   if (!path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
@@ -882,17 +905,21 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
     lap("release");
   }
   if (n_reads) *n_reads = (int64_t)b->n_records;
-  if (seq_bytes) *seq_bytes = (int64_t)b->seq4.size();
-  if (qual_bytes) *qual_bytes = (int64_t)b->qual.size();
-  if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
+  const size_t nr = b->n_records;
+  if (seq_bytes) *seq_bytes = b->payload_on_device ? b->seq_off[nr] : (int64_t)b->seq4.size();
+  if (qual_bytes) *qual_bytes = b->payload_on_device ? b->qual_off[nr] : (int64_t)b->qual.size();
+  if (n_cigar) *n_cigar = b->payload_on_device ? b->cigar_off[nr] : (int64_t)b->cigar.size();
   return MIDAS_SNPS_OK;
 }
+
+int32_t midas_bam_payload_on_device(const midas_bam* b) { return b && b->payload_on_device ? 1 : 0; }
 
 int32_t midas_bam_columns(const midas_bam* b, const void** out12) {
   if (!b || !b->loaded || !out12) return MIDAS_SNPS_ERR_INVALID_ARG;
   const void* v[12] = {b->refid.data(), b->pos.data(), b->mapq.data(), b->flag.data(), b->nm.data(), b->l_seq.data(),
                        b->seq_off.data(), b->qual_off.data(), b->cigar_off.data(), b->seq4.data(), b->qual.data(),
                        b->cigar.data()};
+  if (b->payload_on_device) { v[9] = b->dev_payload[0]; v[10] = b->dev_payload[1]; v[11] = b->dev_payload[2]; }
   memcpy(out12, v, sizeof v);
   return MIDAS_SNPS_OK;
 }
@@ -901,6 +928,7 @@ int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t
                        int32_t* l_seq, int64_t* seq_off, int64_t* qual_off, int64_t* cigar_off, uint8_t* seq4,
                        uint8_t* qual, uint32_t* cigar) {
   if (!b || !b->loaded) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (b->payload_on_device && (seq4 || qual || cigar)) return MIDAS_SNPS_ERR_INVALID_ARG;     // (they are not in host memory)
   const size_t n = b->n_records;
   // the three big columns are copied by all cores (a single memcpy of ~250 MB is 60 ms of the stage)
   auto cp = [](void* dst, const void* src, size_t bytes) {

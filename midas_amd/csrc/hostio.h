@@ -40,6 +40,12 @@ int32_t bam_load_ranges_with(midas_bam* bam, const BlockInflater* inflater, int3
                              const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                              int64_t* n_cigar, char* err256);
 
+// midas_bam_load_device (snps_abi.hip): the payload columns are cut on the device
+void bam_keep_payload_on_device(midas_bam* b);        // before midas_bam_load: decode everything but SEQ / QUAL / CIGAR
+const uint64_t* bam_record_offsets(const midas_bam* b, size_t* n);
+void bam_offsets(const midas_bam* b, const int64_t** seq_off, const int64_t** qual_off, const int64_t** cigar_off);
+void bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void (*free_fn)(void*));
+
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.
 struct CodedMember { const uint8_t* data; uint32_t n_bytes, crc, text_len, rows; };

@@ -263,7 +263,15 @@ struct InflateParams {
   unsigned long long* matches;     // the matches the decoder noted for the resolver
   uint32_t* n_matches;             // per stream
 };
-hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases = 3);    // 1: decode, 2: resolve the matches
+hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases = 3);
+struct PayloadParams {
+  const uint8_t* stream;                   // the inflated BAM
+  const unsigned long long* rec_off;       // where every record starts in it
+  long long n_records;
+  const long long* seq_off; const long long* qual_off; const long long* cigar_off;     // [n_records + 1], elements
+  uint8_t* seq4; uint8_t* qual; uint32_t* cigar;
+};
+hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s);    // 1: decode, 2: resolve the matches
 
 hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);

@@ -430,9 +430,16 @@ int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, d
 namespace {
 // midas::BlockInflater over a context: the streams go to the device, one thread inflates each (bgzf_inflate.hip), the
 // inflated bytes come back through the staging ring.
+struct InflateUser {
+  midas_snps_ctx* ctx;
+  bool keep = false;            // leave the inflated stream on the device: `kept` (the caller frees it)
+  void* kept = nullptr;
+  size_t kept_bytes = 0;
+};
 int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, const InflateJob* jobs, size_t n_jobs, uint8_t* out,
                        size_t out_bytes, int64_t* bad_job, char* err256) {
-  midas_snps_ctx* ctx = static_cast<midas_snps_ctx*>(user);
+  InflateUser* iu = static_cast<InflateUser*>(user);
+  midas_snps_ctx* ctx = iu->ctx;
   if (bad_job) *bad_job = -1;
   if (n_jobs == 0) return MIDAS_SNPS_OK;
   size_t comp_bytes = 0;
@@ -513,6 +520,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   const int32_t st = copy_to_host(ctx, out, d_out.p, out_bytes);
   if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->err.c_str());
   lap("inflated bytes down");
+  if (st == MIDAS_SNPS_OK && iu->keep) { iu->kept = d_out.p; iu->kept_bytes = out_bytes; d_out.p = nullptr; }
   return st;
 }
 }  // namespace
@@ -529,22 +537,105 @@ int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int6
   }
   const InflateSegment seg{comp, (size_t)comp_bytes};
   char err[256] = {0};
-  const int32_t st = device_inflate(ctx, &seg, 1, jobs.data(), jobs.size(), out, (size_t)out_bytes, bad_block, err);
+  InflateUser iu{ctx};
+  const int32_t st = device_inflate(&iu, &seg, 1, jobs.data(), jobs.size(), out, (size_t)out_bytes, bad_block, err);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, err);
   return MIDAS_SNPS_OK;
 }
 
 int32_t midas_bam_open_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, char* err256) {
   if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
-  const BlockInflater inf{ctx, device_inflate};
+  InflateUser iu{ctx};
+  const BlockInflater inf{&iu, device_inflate};
   return bam_open_with(path, &inf, out, err256);
+}
+
+namespace {
+void device_free(void* p) { (void)hipFree(p); }
+}
+
+int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
+                              int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  if (!ctx || !path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  InflateUser iu{ctx};
+  iu.keep = true;
+  struct Kept { InflateUser* u; ~Kept() { if (u->kept) (void)hipFree(u->kept); } } kept{&iu};       // (freed on every way out)
+  const BlockInflater inf{&iu, device_inflate};
+  midas_bam* b = nullptr;
+  int32_t st = bam_open_with(path, &inf, &b, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  struct Handle { midas_bam* b; ~Handle() { if (b) midas_bam_close(b); } } handle{b};
+  bam_keep_payload_on_device(b);
+  int64_t n = 0, sb = 0, qb = 0, nc = 0;
+  st = midas_bam_load(b, &n, &sb, &qb, &nc, err256);        // the host walks the records and decodes the small columns
+  if (st != MIDAS_SNPS_OK) return st;
+  size_t n_off = 0;
+  const uint64_t* rec_off = bam_record_offsets(b, &n_off);
+  const int64_t *seq_off, *qual_off, *cigar_off;
+  bam_offsets(b, &seq_off, &qual_off, &cigar_off);
+  auto hip_err = [&](hipError_t e, const char* what) {
+    if (err256) snprintf(err256, 256, "device decode: %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP;
+  };
+#define DEC_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
+  {
+    std::lock_guard<std::mutex> g(ctx->device_mutex);
+    DEC_TRY(hipSetDevice(ctx->device));
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_rec, d_so, d_qo, d_co, d_seq, d_qual, d_cig;
+    const size_t n1 = (size_t)n + 1;
+    DEC_TRY(hipMalloc(&d_rec.p, n1 * 8));
+    DEC_TRY(hipMalloc(&d_so.p, n1 * 8));
+    DEC_TRY(hipMalloc(&d_qo.p, n1 * 8));
+    DEC_TRY(hipMalloc(&d_co.p, n1 * 8));
+    DEC_TRY(hipMalloc(&d_seq.p, (size_t)sb + 64));
+    DEC_TRY(hipMalloc(&d_qual.p, (size_t)qb + 64));
+    DEC_TRY(hipMalloc(&d_cig.p, (size_t)nc * 4 + 64));       // (the kernels read CIGARs 16 bytes at a time: slack behind the last)
+    hipStream_t s = ctx->stream;
+    if (n > 0) DEC_TRY(hipMemcpyAsync(d_rec.p, rec_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_so.p, seq_off, n1 * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_qo.p, qual_off, n1 * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_co.p, cigar_off, n1 * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_cig.p) + (size_t)nc * 4, 0, 64, s));
+    PayloadParams pp;
+    pp.stream = static_cast<const uint8_t*>(iu.kept);
+    pp.rec_off = static_cast<const unsigned long long*>(d_rec.p);
+    pp.n_records = n;
+    pp.seq_off = static_cast<const long long*>(d_so.p);
+    pp.qual_off = static_cast<const long long*>(d_qo.p);
+    pp.cigar_off = static_cast<const long long*>(d_co.p);
+    pp.seq4 = static_cast<uint8_t*>(d_seq.p);
+    pp.qual = static_cast<uint8_t*>(d_qual.p);
+    pp.cigar = static_cast<uint32_t*>(d_cig.p);
+    DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
+    DEC_TRY(hipStreamSynchronize(s));
+    bam_set_device_payload(b, d_seq.p, d_qual.p, d_cig.p, device_free);
+    d_seq.p = d_qual.p = d_cig.p = nullptr;
+  }
+#undef DEC_TRY
+  if (n_reads) *n_reads = n;
+  if (seq_bytes) *seq_bytes = sb;
+  if (qual_bytes) *qual_bytes = qb;
+  if (n_cigar) *n_cigar = nc;
+  *out = b;
+  handle.b = nullptr;
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || bytes < 0 || (bytes > 0 && (!dst || !src))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> g(ctx->device_mutex);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return copy_to_host(ctx, dst, src, (size_t)bytes);
 }
 
 int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
                                      const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                      int64_t* n_cigar, char* err256) {
   if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
-  const BlockInflater inf{ctx, device_inflate};
+  InflateUser iu{ctx};
+  const BlockInflater inf{&iu, device_inflate};
   return bam_load_ranges_with(bam, &inf, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
 }
 
@@ -1143,9 +1234,10 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     B_TRY(hipMemcpyAsync(b->d_seq_off, reads->seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
     B_TRY(hipMemcpyAsync(b->d_qual_off, reads->qual_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
     B_TRY(hipMemcpyAsync(b->d_cigar_off, reads->cigar_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    if (seq_bytes > 0) B_TRY(hipMemcpyAsync(b->d_seq4, reads->seq4, (size_t)seq_bytes, hipMemcpyHostToDevice, s));
-    if (qual_bytes > 0) B_TRY(hipMemcpyAsync(b->d_qual, reads->qual, (size_t)qual_bytes, hipMemcpyHostToDevice, s));
-    if (n_cigar > 0) B_TRY(hipMemcpyAsync(b->d_cigar, reads->cigar, (size_t)n_cigar * 4, hipMemcpyHostToDevice, s));
+    // (seq4 / qual / cigar may be DEVICE pointers -- midas_bam_load_device leaves these columns there: the kind is inferred)
+    if (seq_bytes > 0) B_TRY(hipMemcpyAsync(b->d_seq4, reads->seq4, (size_t)seq_bytes, hipMemcpyDefault, s));
+    if (qual_bytes > 0) B_TRY(hipMemcpyAsync(b->d_qual, reads->qual, (size_t)qual_bytes, hipMemcpyDefault, s));
+    if (n_cigar > 0) B_TRY(hipMemcpyAsync(b->d_cigar, reads->cigar, (size_t)n_cigar * 4, hipMemcpyDefault, s));
   }
   B_TRY(hipMemsetAsync(b->d_seq4 + seq_bytes, 0, 64, s));
   B_TRY(hipMemsetAsync(b->d_qual + qual_bytes, 0, 64, s));

@@ -129,6 +129,20 @@ def test_bam_decoded_with_the_device_inflater_equals_the_host_decode(ctx, tmp_pa
     np.testing.assert_array_equal(a[0], b[0])
     for k in abi._SOA_DTYPES:
         np.testing.assert_array_equal(getattr(a[1], k), getattr(b[1], k), err_msg=k)
+    # the payload columns cut on the device and left there: the same bytes, and a batch takes them where they are
+    names_p, lens_p, refid_p, on_dev = abi.read_bam(path, ctx, payload_on_device=True)
+    assert on_dev.device is not None and on_dev.seq4.size == 0 and names_p == names_h
+    np.testing.assert_array_equal(refid_h, refid_p)
+    down = ctx.fetch_payload(on_dev)
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(host, k), getattr(down, k), err_msg=k)
+    table = abi.ContigTable(length=contigs.length, species=contigs.species, read_begin=contigs.read_begin, ref=contigs.ref,
+                            n_species=contigs.n_species)
+    thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
+    want = ctx.pileup(thr, table, host)
+    got = ctx.pileup(thr, table, on_dev)
+    for a_, b_ in zip(want, got):
+        np.testing.assert_array_equal(a_, b_)
     # a truncated file
     data = open(path, "rb").read()
     cut = str(tmp_path / "cut.bam")
