@@ -97,9 +97,9 @@ typedef struct midas_snps_reads {
   const int64_t* seq_off;
   const int64_t* qual_off;
   const int64_t* cigar_off;
-  const uint8_t* seq4;
-  const uint8_t* qual;
-  const uint32_t* cigar;
+  const uint8_t* seq4;        /* these three: host memory, or memory of the context's device (midas_bam_load_device leaves  */
+  const uint8_t* qual;        /* them there) -- all three alike; midas_snps_batch_create / midas_snps_pileup copy either way;     */
+  const uint32_t* cigar;      /* the host-only entry points (midas_snps_pack_reads*) take host memory only                        */
 } midas_snps_reads;
 
 /* Contig table: what initialize_contigs() builds (midas/run/snps.py:55-67), flattened.

@@ -72,6 +72,8 @@ def group_by_contig(ref_names, refid, reads, contig_ids):
             read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
             np.cumsum(hi - lo, out=read_begin[1:])
             return reads, read_begin
+    if getattr(reads, 'device', None) is not None:
+        raise ValueError("the reads' SEQ / QUAL / CIGAR are on the device: fetch them (Context.fetch_payload) before regrouping")
     rank = np.full(len(ref_names) + 1, -1, dtype=np.int64)
     for k, r in enumerate(want):
         if r >= 0:

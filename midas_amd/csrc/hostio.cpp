@@ -246,23 +246,69 @@ bool raw_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) {
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
-int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256);
-
 int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  fseek(f, 0, SEEK_END);
+  const long fsz = ftell(f);
+  fseek(f, 0, SEEK_SET);
   Lap lap("bam inflate");
-  // the file is mapped, not read: the inflaters take the blocks straight out of the page cache (a copy of a 1.3 GB BAM into a
-  // buffer of its own was 20-70 ms of the stage and 1.3 GB of memory)
-  BgzfMap m;
-  const int32_t mst = bgzf_map_file(path, m, err256);
-  if (mst != MIDAS_SNPS_OK) return mst;
-  lap("map + block table");
-  if (!out.resize((size_t)m.total)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  const std::vector<BgzfMap::Blk>& blocks = m.blocks;
+  RawBuf<uint8_t> comp;
+  if (!comp.resize((size_t)fsz)) { fclose(f); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  {   // the file comes in through several threads: one core copies ~4 GB/s out of the page cache, a BAM is 100s of MB
+    const int fd = fileno(f);
+    const size_t piece = (size_t)8 << 20, n_pieces = ((size_t)fsz + piece - 1) / piece;
+    std::atomic<size_t> nextp{0};
+    std::atomic<int> short_read{0};
+    Workers::run((int)std::min<size_t>(n_pieces, 16), [&] {
+      for (;;) {
+        const size_t k = nextp.fetch_add(1);
+        if (k >= n_pieces) return;
+        size_t off = k * piece;
+        const size_t end = std::min((size_t)fsz, off + piece);
+        while (off < end) {
+          const ssize_t got = pread(fd, comp.data() + off, end - off, (off_t)off);
+          if (got <= 0) { short_read = 1; return; }
+          off += (size_t)got;
+        }
+      }
+    });
+    fclose(f);
+    if (short_read) { set_err(err256, "short read on %s", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  }
+  lap("read file");
+  struct Blk { size_t cpos, clen, upos, ulen; };
+  std::vector<Blk> blocks;
+  size_t p = 0, upos = 0;
+  while (p < comp.size()) {
+    if (p + 18 > comp.size() || comp[p] != 0x1f || comp[p + 1] != 0x8b || comp[p + 2] != 8 || !(comp[p + 3] & 4)) {
+      set_err(err256, "%s: not a BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const size_t xlen = rd16(&comp[p + 10]);
+    size_t q = p + 12, xend = p + 12 + xlen;
+    size_t bsize = 0;
+    while (q + 4 <= xend) {
+      const uint16_t slen = rd16(&comp[q + 2]);
+      if (comp[q] == 'B' && comp[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&comp[q + 4]) + 1;
+      q += 4 + slen;
+    }
+    if (bsize == 0 || p + bsize > comp.size() || bsize < xlen + 20) {
+      set_err(err256, "%s: truncated BGZF block at offset %lld", path.c_str(), (long long)p);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+    const size_t isize = rd32(&comp[p + bsize - 4]);
+    blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize});
+    upos += isize;
+    p += bsize;
+  }
+  if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  lap("block table");
   if (inflater) {
     std::vector<midas::InflateJob> jobs;
     jobs.reserve(blocks.size());
-    for (const BgzfMap::Blk& b : blocks) jobs.push_back({(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)b.clen, (uint32_t)b.ulen});
-    const midas::InflateSegment seg{m.base, m.size};
+    for (const Blk& b : blocks) jobs.push_back({(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)b.clen, (uint32_t)b.ulen});
+    const midas::InflateSegment seg{comp.data(), comp.size()};
     int64_t bad_job = -1;
     const int32_t st = inflater->run(inflater->user, &seg, 1, jobs.data(), jobs.size(), out.data(), out.size(), &bad_job, err256);
     if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) set_err(err256, "%s: corrupt deflate data", path.c_str());
@@ -275,9 +321,9 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= blocks.size()) return;
-      const BgzfMap::Blk& b = blocks[i];
+      const Blk& b = blocks[i];
       if (b.ulen == 0) continue;
-      if (!raw_inflate(m.base + b.cpos, (size_t)b.clen, out.data() + b.upos, (size_t)b.ulen)) { bad = 1; return; }
+      if (!raw_inflate(comp.data() + b.cpos, (size_t)b.clen, out.data() + b.upos, (size_t)b.ulen)) { bad = 1; return; }
     }
   };
   const int nt = hw_threads(0);

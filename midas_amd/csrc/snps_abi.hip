@@ -485,6 +485,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   }
   INF_TRY(hipMalloc(&d_matches.p, (size_t)n_match_room * 8));
   INF_TRY(hipMalloc(&d_status.p, n_jobs * 8));
+  if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("streams up + hipMalloc"); }
   INF_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
   InflateParams ip;
   ip.comp = static_cast<const uint8_t*>(d_comp.p);
@@ -560,16 +561,26 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
   *out = nullptr;
   InflateUser iu{ctx};
   iu.keep = true;
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[device decode] %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   struct Kept { InflateUser* u; ~Kept() { if (u->kept) (void)hipFree(u->kept); } } kept{&iu};       // (freed on every way out)
   const BlockInflater inf{&iu, device_inflate};
   midas_bam* b = nullptr;
   int32_t st = bam_open_with(path, &inf, &b, err256);
   if (st != MIDAS_SNPS_OK) return st;
   struct Handle { midas_bam* b; ~Handle() { if (b) midas_bam_close(b); } } handle{b};
+  lap("open (map, inflate, header)");
   bam_keep_payload_on_device(b);
   int64_t n = 0, sb = 0, qb = 0, nc = 0;
   st = midas_bam_load(b, &n, &sb, &qb, &nc, err256);        // the host walks the records and decodes the small columns
   if (st != MIDAS_SNPS_OK) return st;
+  lap("host walk + small columns");
   size_t n_off = 0;
   const uint64_t* rec_off = bam_record_offsets(b, &n_off);
   const int64_t *seq_off, *qual_off, *cigar_off;
@@ -593,11 +604,13 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
     DEC_TRY(hipMalloc(&d_qual.p, (size_t)qb + 64));
     DEC_TRY(hipMalloc(&d_cig.p, (size_t)nc * 4 + 64));       // (the kernels read CIGARs 16 bytes at a time: slack behind the last)
     hipStream_t s = ctx->stream;
+    lap("hipMalloc of the columns");
     if (n > 0) DEC_TRY(hipMemcpyAsync(d_rec.p, rec_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
     DEC_TRY(hipMemcpyAsync(d_so.p, seq_off, n1 * 8, hipMemcpyHostToDevice, s));
     DEC_TRY(hipMemcpyAsync(d_qo.p, qual_off, n1 * 8, hipMemcpyHostToDevice, s));
     DEC_TRY(hipMemcpyAsync(d_co.p, cigar_off, n1 * 8, hipMemcpyHostToDevice, s));
     DEC_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_cig.p) + (size_t)nc * 4, 0, 64, s));
+    if (trace) { DEC_TRY(hipStreamSynchronize(s)); lap("offsets up"); }
     PayloadParams pp;
     pp.stream = static_cast<const uint8_t*>(iu.kept);
     pp.rec_off = static_cast<const unsigned long long*>(d_rec.p);
@@ -610,9 +623,11 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
     pp.cigar = static_cast<uint32_t*>(d_cig.p);
     DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
     DEC_TRY(hipStreamSynchronize(s));
+    lap("payload kernel");
     bam_set_device_payload(b, d_seq.p, d_qual.p, d_cig.p, device_free);
     d_seq.p = d_qual.p = d_cig.p = nullptr;
   }
+  lap("free scratch");
 #undef DEC_TRY
   if (n_reads) *n_reads = n;
   if (seq_bytes) *seq_bytes = sb;

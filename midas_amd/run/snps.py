@@ -603,7 +603,11 @@ def _count_alleles(args, species, contigs, ctx):
     decoded = None
     if plan is None:
         try:
-            decoded = abi.read_bam(bampath, inflater)
+            # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
+            decoded = abi.read_bam(bampath, inflater, payload_on_device=inflater is not None and ws == 1)
+            if decoded[3].device is not None and decoded[2].size > 1 and not bool((decoded[2][1:] >= decoded[2][:-1]).all()):
+                # records not grouped by reference: the regroup slices the payload, which it can only do in host memory
+                decoded = decoded[:3] + (ctx.fetch_payload(decoded[3]),)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)

@@ -17,6 +17,6 @@ if not os.path.exists(bam):
 ctx = abi.Context(0) if os.environ.get("DECODE_ON_DEVICE") else None     # DECODE_ON_DEVICE=1: the device inflates the blocks
 for k in range(3):
     t = time.perf_counter()
-    d = abi.read_bam(bam, ctx)
+    d = abi.read_bam(bam, ctx, payload_on_device=os.environ.get("DECODE_ON_DEVICE") == "2")
     print("run %d: %.3f s, %d records" % (k + 1, time.perf_counter() - t, d[3].n_reads), flush=True)
     del d

@@ -23,17 +23,19 @@ synth.write_sample(out, db, contigs, reads)
 print("setup (generate + write FASTA/BAM, not part of the stage): %.1f s; BAM %.0f MB" % (
     time.time() - t0, os.path.getsize(os.path.join(out, 'snps/temp/genomes.bam')) / 1e6), flush=True)
 
-def stage(rep_check=True):
+def stage(rep_check=True, device_decode=False):
+    """device_decode: --device_inflate -- the BGZF blocks are inflated on the device and SEQ / QUAL / CIGAR stay there."""
     args = dict(abi.DEFAULT_ARGS, outdir=out, db=db, build_db=False, threads=utility.cpu_budget(),
                 log=open(os.devnull, 'w'))
     T = {}
     # what run_pipeline does: the genomes are read on a thread of their own while the BAM is decoded
     t = time.perf_counter(); species = msnps.initialize_species(args); cs = msnps.ContigsInBackground(species)
     ctx = abi.Context(0)
-    decoded = abi.read_bam(os.path.join(out, 'snps/temp/genomes.bam')); T_bam = time.perf_counter() - t
-    cs = cs.wait(); T['read FASTA (background thread) || BAM decode (native, parallel inflate; alone: %.3f s)' % T_bam] = time.perf_counter() - t
-    # (the opt-in alternative, not part of the stage's total: the same decode with the BGZF blocks inflated on the device)
-    t = time.perf_counter(); d2 = abi.read_bam(os.path.join(out, 'snps/temp/genomes.bam'), ctx); T_dev_decode = time.perf_counter() - t; del d2
+    bam_path = os.path.join(out, 'snps/temp/genomes.bam')
+    decoded = abi.read_bam(bam_path, ctx, payload_on_device=True) if device_decode else abi.read_bam(bam_path)
+    T_bam = time.perf_counter() - t
+    how = "blocks inflated and payload columns cut on the device" if device_decode else "native, parallel inflate"
+    cs = cs.wait(); T['read FASTA (background thread) || BAM decode (%s; alone: %.3f s)' % (how, T_bam)] = time.perf_counter() - t
     ids = sorted(species)
     order, span = msnps._whole(msnps._species_contig_order(ids, cs), cs)
     items = [it for sp in ids for it in order[sp]]
@@ -63,15 +65,17 @@ def stage(rep_check=True):
             sz_dev += os.path.getsize(a); sz_host += os.path.getsize(h)
             os.remove(h)
         b.close()
-        t = time.perf_counter(); ctx.pileup(thr, table, sub, pinned_slot=0); T2 = time.perf_counter() - t
-        t = time.perf_counter(); ctx.pileup(thr, table, sub, pinned_slot=0); T3 = time.perf_counter() - t
+        T2 = T3 = 0.0
+        if not device_decode:
+            t = time.perf_counter(); ctx.pileup(thr, table, sub, pinned_slot=0); T2 = time.perf_counter() - t
+            t = time.perf_counter(); ctx.pileup(thr, table, sub, pinned_slot=0); T3 = time.perf_counter() - t
     tot = sum(T.values())
     for k, v in T.items():
         print("  %-52s %8.3f s  %5.1f %%" % (k, v, 100 * v / tot))
     print("  %-52s %8.3f s  -> %.3e sites/s end to end (%d sites, %d reads)" % ("TOTAL pileup stage", tot, contigs.n_sites / tot, contigs.n_sites, reads.n_reads))
     print("  (the same rows by the host's formatter, %d threads: %.3f s; %d vs %d bytes, the same text%s)" % (args['threads'], T_host, sz_dev, sz_host, "" if rep_check else " (checked on run 1)"))
-    print("  (the same BAM decoded with the blocks inflated on the device, args['device_inflate']: %.3f s)" % T_dev_decode)
-    print("  one-shot midas_snps_pileup into pinned results: first call %.1f ms (pins the buffers), second %.1f ms" % (T2 * 1e3, T3 * 1e3))
+    if not device_decode:
+        print("  one-shot midas_snps_pileup into pinned results: first call %.1f ms (pins the buffers), second %.1f ms" % (T2 * 1e3, T3 * 1e3))
     sz = sum(os.path.getsize(os.path.join(out, 'snps/output', f)) for f in os.listdir(os.path.join(out, 'snps/output')))
     print("  output: %.0f MB gz" % (sz / 1e6))
 
@@ -79,3 +83,6 @@ def stage(rep_check=True):
 for rep in range(int(os.environ.get('E2E_REPS', '1'))):
     print('---- run %d ----' % (rep + 1), flush=True)
     stage(rep == 0)
+    if os.environ.get('E2E_DEVICE_DECODE'):
+        print('---- run %d, --device_inflate ----' % (rep + 1), flush=True)
+        stage(False, True)
