@@ -42,7 +42,7 @@ constexpr int kRing = 16;                       // u32, per lane: the next 64 by
 constexpr int kLens = 320;                      // u8: code lengths while a table is built
 
 enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadSymbol = 4, kBadDistance = 5,
-                  kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8 };
+                  kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8, kMatchRoom = kInflateMatchRoom };
 
 // (pointers that SAY they point into LDS: through a generic pointer every table look-up would be a FLAT access, which waits
 // for the thread's outstanding global stores -- one store acknowledgement per symbol)
@@ -287,7 +287,7 @@ __device__ __forceinline__ unsigned long long match_pack(uint32_t o, uint32_t le
 }
 
 __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen,
-                                unsigned long long* mlist, uint32_t* n_matches) {
+                                unsigned long long* mlist, uint32_t mcap, uint32_t* n_matches) {
   uint32_t m = 0, tick = 0;
   BitIn in;
   in.open(L, src, clen);
@@ -344,8 +344,9 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         dist += in.take(extra);
         if (dist > out.o) return kBadDistance;
         if (out.o + len > ulen) return kOutputOverrun;
-        // noted, not copied (at most ulen / 3 of them: the list's room)
+        // noted, not copied
         out.flush();
+        if (m == mcap) return kMatchRoom;
         mlist[m++] = match_pack(out.o, len, dist);
         out.o += len;
         if (in.overrun()) return kInputOverrun;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
   Lds L{(lds_u16*)s16, (lds_u8*)s8, (lds_u32*)s32, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
   uint32_t st = kOk, nm = 0;
-  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen, p.matches + b.mbase, &nm);
+  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen, p.matches + b.mbase, b.mcap, &nm);
   p.status[k] = st;
   p.n_matches[k] = st == kOk ? nm : 0u;
 }

@@ -112,10 +112,10 @@ struct midas_bam {
   bool payload_on_device = false;
   std::vector<uint64_t> rec_off;        // where every decoded record starts in the inflated stream (kept for the device's cut)
   void* dev_payload[3] = {nullptr, nullptr, nullptr};
+  void* dev_owner = nullptr;            // the device allocation the three live in
   void (*dev_free)(void*) = nullptr;
   ~midas_bam() {
-    if (dev_free)
-      for (void* q : dev_payload) if (q) dev_free(q);
+    if (dev_free && dev_owner) dev_free(dev_owner);
   }
 };
 
@@ -878,8 +878,9 @@ const uint64_t* midas::bam_record_offsets(const midas_bam* b, size_t* n) { *n = 
 void midas::bam_offsets(const midas_bam* b, const int64_t** seq_off, const int64_t** qual_off, const int64_t** cigar_off) {
   *seq_off = b->seq_off.data(); *qual_off = b->qual_off.data(); *cigar_off = b->cigar_off.data();
 }
-void midas::bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void (*free_fn)(void*)) {
+void midas::bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void* owner, void (*free_fn)(void*)) {
   b->dev_payload[0] = seq4; b->dev_payload[1] = qual; b->dev_payload[2] = cigar;
+  b->dev_owner = owner;
   b->dev_free = free_fn;
   std::vector<uint64_t>().swap(b->rec_off);
 }

@@ -44,7 +44,7 @@ int32_t bam_load_ranges_with(midas_bam* bam, const BlockInflater* inflater, int3
 void bam_keep_payload_on_device(midas_bam* b);        // before midas_bam_load: decode everything but SEQ / QUAL / CIGAR
 const uint64_t* bam_record_offsets(const midas_bam* b, size_t* n);
 void bam_offsets(const midas_bam* b, const int64_t** seq_off, const int64_t** qual_off, const int64_t** cigar_off);
-void bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void (*free_fn)(void*));
+void bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void* owner, void (*free_fn)(void*));   // owner: freed once, at close
 
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.

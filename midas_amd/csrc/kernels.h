@@ -254,7 +254,8 @@ struct RowsParams {
 hipError_t launch_rows_deflate(const RowsParams& p, int grid_blocks, hipStream_t s);
 
 // bgzf_inflate.hip: raw DEFLATE streams (BGZF blocks) inflated on the device, one thread per stream
-struct InflateBlock { unsigned long long cpos, upos, mbase; uint32_t clen, ulen; };   // mbase: the stream's room in `matches` (ulen / 3 + 1)
+struct InflateBlock { unsigned long long cpos, upos, mbase; uint32_t clen, ulen, mcap, pad; };   // mbase, mcap: the stream's room in `matches`
+constexpr uint32_t kInflateMatchRoom = 9;      // status: the stream has more matches than its room (decode it again with more)
 struct InflateParams {
   const uint8_t* comp;             // the streams (8 bytes of slack behind the last one)
   const InflateBlock* blocks; long long n_blocks;

@@ -433,8 +433,10 @@ namespace {
 struct InflateUser {
   midas_snps_ctx* ctx;
   bool keep = false;            // leave the inflated stream on the device: `kept` (the caller frees it)
-  void* kept = nullptr;
+  void* kept = nullptr;         // the arena; the inflated stream is at its start
   size_t kept_bytes = 0;
+  uint8_t* scratch = nullptr;   // what lies behind the stream in the arena: dead once the call returns, the caller's to reuse
+  size_t scratch_bytes = 0;
 };
 int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, const InflateJob* jobs, size_t n_jobs, uint8_t* out,
                        size_t out_bytes, int64_t* bad_job, char* err256) {
@@ -466,10 +468,27 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     t_last = t;
   };
   INF_TRY(hipSetDevice(ctx->device));
-  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_comp, d_out, d_blocks, d_status, d_matches;
-  INF_TRY(hipMalloc(&d_comp.p, comp_bytes + 512));
-  INF_TRY(hipMalloc(&d_out.p, out_bytes + 64));
-  INF_TRY(hipMalloc(&d_blocks.p, n_jobs * sizeof(InflateBlock)));
+  // ONE allocation for everything the call needs (a hipMalloc / hipFree pair costs tens of milliseconds per gigabyte here, and
+  // the match lists' worst-case room alone is 2.7 bytes per output byte): | inflated | compressed | blocks | status | matches |
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // Room for the matches of a stream: a sixth of its bytes (a BAM's blocks hold one match per eight bytes or so; the bound
+  // is one per three) -- device memory costs ~17 ms a gigabyte to allocate here and the lists are the largest buffer.  A
+  // stream with more is decoded again, with the bound's room, in a second small launch.
+  std::vector<InflateBlock> blocks(n_jobs);
+  unsigned long long n_match_room = 0;
+  for (size_t k = 0; k < n_jobs; ++k) {
+    const uint32_t cap = jobs[k].ulen / 6u + 16u;
+    blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen, cap, 0u};
+    n_match_room += cap;
+  }
+  const size_t at_out = 0, at_comp = up(out_bytes + 64), at_blocks = at_comp + up(comp_bytes + 512),
+               at_status = at_blocks + up(n_jobs * sizeof(InflateBlock)), at_matches = at_status + up(n_jobs * 8),
+               arena_bytes = at_matches + up((size_t)n_match_room * 8);
+  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } arena;
+  INF_TRY(hipMalloc(&arena.p, arena_bytes));
+  uint8_t* const base = static_cast<uint8_t*>(arena.p);
+  struct View { void* p; } d_out{base + at_out}, d_comp{base + at_comp}, d_blocks{base + at_blocks}, d_status{base + at_status},
+      d_matches{base + at_matches};
   hipStream_t s = ctx->stream;
   size_t at = 0;
   for (size_t k = 0; k < n_segs; ++k) {
@@ -477,15 +496,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     at += segs[k].n;
   }
   INF_TRY(hipMemsetAsync(static_cast<uint8_t*>(d_comp.p) + comp_bytes, 0, 512, s));
-  std::vector<InflateBlock> blocks(n_jobs);
-  unsigned long long n_match_room = 0;
-  for (size_t k = 0; k < n_jobs; ++k) {
-    blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen};
-    n_match_room += jobs[k].ulen / 3u + 1u;       // (a match is three bytes at the least)
-  }
-  INF_TRY(hipMalloc(&d_matches.p, (size_t)n_match_room * 8));
-  INF_TRY(hipMalloc(&d_status.p, n_jobs * 8));
-  if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("streams up + hipMalloc"); }
+  if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("hipMalloc + streams up"); }
   INF_TRY(hipMemcpyAsync(d_blocks.p, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
   InflateParams ip;
   ip.comp = static_cast<const uint8_t*>(d_comp.p);
@@ -495,7 +506,6 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   ip.status = static_cast<uint32_t*>(d_status.p);
   ip.n_matches = static_cast<uint32_t*>(d_status.p) + n_jobs;
   ip.matches = static_cast<unsigned long long*>(d_matches.p);
-  if (trace) { INF_TRY(hipStreamSynchronize(s)); lap("hipMalloc + streams up"); }
   if (trace) {
     INF_TRY(launch_bgzf_inflate(ip, s, 1));
     INF_TRY(hipStreamSynchronize(s));
@@ -510,6 +520,38 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   INF_TRY(hipMemcpyAsync(status.data(), d_status.p, n_jobs * 4, hipMemcpyDeviceToHost, s));
   INF_TRY(hipStreamSynchronize(s));
   lap("kernel");
+  {   // the streams whose matches did not fit: again, with the bound's room
+    std::vector<size_t> again;
+    for (size_t k = 0; k < n_jobs; ++k)
+      if (status[k] == kInflateMatchRoom) again.push_back(k);
+    if (!again.empty()) {
+      std::vector<InflateBlock> b2(again.size());
+      unsigned long long room2 = 0;
+      for (size_t j = 0; j < again.size(); ++j) {
+        const InflateJob& q = jobs[again[j]];
+        const uint32_t cap = q.ulen / 3u + 1u;
+        b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
+        room2 += cap;
+      }
+      Buf d_b2, d_s2, d_m2;
+      INF_TRY(hipMalloc(&d_b2.p, b2.size() * sizeof(InflateBlock)));
+      INF_TRY(hipMalloc(&d_s2.p, b2.size() * 8));
+      INF_TRY(hipMalloc(&d_m2.p, (size_t)room2 * 8));
+      INF_TRY(hipMemcpyAsync(d_b2.p, b2.data(), b2.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+      InflateParams ip2 = ip;
+      ip2.blocks = static_cast<const InflateBlock*>(d_b2.p);
+      ip2.n_blocks = (long long)b2.size();
+      ip2.status = static_cast<uint32_t*>(d_s2.p);
+      ip2.n_matches = static_cast<uint32_t*>(d_s2.p) + b2.size();
+      ip2.matches = static_cast<unsigned long long*>(d_m2.p);
+      INF_TRY(launch_bgzf_inflate(ip2, s));
+      std::vector<uint32_t> st2(b2.size());
+      INF_TRY(hipMemcpyAsync(st2.data(), d_s2.p, b2.size() * 4, hipMemcpyDeviceToHost, s));
+      INF_TRY(hipStreamSynchronize(s));
+      for (size_t j = 0; j < again.size(); ++j) status[again[j]] = st2[j];
+      lap("streams decoded again");
+    }
+  }
 #undef INF_TRY
   for (size_t k = 0; k < n_jobs; ++k) {
     if (status[k] != 0u) {
@@ -521,7 +563,10 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   const int32_t st = copy_to_host(ctx, out, d_out.p, out_bytes);
   if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->err.c_str());
   lap("inflated bytes down");
-  if (st == MIDAS_SNPS_OK && iu->keep) { iu->kept = d_out.p; iu->kept_bytes = out_bytes; d_out.p = nullptr; }
+  if (st == MIDAS_SNPS_OK && iu->keep) {     // the caller takes the arena: the inflated stream, and everything behind it as scratch
+    iu->kept = arena.p; iu->kept_bytes = out_bytes; iu->scratch = base + at_comp; iu->scratch_bytes = arena_bytes - at_comp;
+    arena.p = nullptr;
+  }
   return st;
 }
 }  // namespace
@@ -594,15 +639,21 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
   {
     std::lock_guard<std::mutex> g(ctx->device_mutex);
     DEC_TRY(hipSetDevice(ctx->device));
-    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_rec, d_so, d_qo, d_co, d_seq, d_qual, d_cig;
+    // the columns and the offsets the cut needs go where the compressed bytes and the match lists were (the arena's scratch is
+    // 2.7 x the stream, the columns 0.9 x): no second allocation
+    struct View { void* p = nullptr; } d_rec, d_so, d_qo, d_co, d_seq, d_qual, d_cig;
     const size_t n1 = (size_t)n + 1;
-    DEC_TRY(hipMalloc(&d_rec.p, n1 * 8));
-    DEC_TRY(hipMalloc(&d_so.p, n1 * 8));
-    DEC_TRY(hipMalloc(&d_qo.p, n1 * 8));
-    DEC_TRY(hipMalloc(&d_co.p, n1 * 8));
-    DEC_TRY(hipMalloc(&d_seq.p, (size_t)sb + 64));
-    DEC_TRY(hipMalloc(&d_qual.p, (size_t)qb + 64));
-    DEC_TRY(hipMalloc(&d_cig.p, (size_t)nc * 4 + 64));       // (the kernels read CIGARs 16 bytes at a time: slack behind the last)
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t at = 0;
+    auto take = [&](View& v, size_t bytes) { v.p = iu.scratch + at; at += up(bytes); };
+    take(d_seq, (size_t)sb + 64); take(d_qual, (size_t)qb + 64); take(d_cig, (size_t)nc * 4 + 64);
+    take(d_rec, n1 * 8); take(d_so, n1 * 8); take(d_qo, n1 * 8); take(d_co, n1 * 8);
+    struct Own { void* p = nullptr; ~Own() { if (p) (void)hipFree(p); } } own;
+    if (at > iu.scratch_bytes) {      // (very short reads: more offsets than the scratch has room for -- a buffer of their own)
+      DEC_TRY(hipMalloc(&own.p, at));
+      const ptrdiff_t shift = static_cast<uint8_t*>(own.p) - iu.scratch;
+      for (View* v : {&d_seq, &d_qual, &d_cig, &d_rec, &d_so, &d_qo, &d_co}) v->p = static_cast<uint8_t*>(v->p) + shift;
+    }
     hipStream_t s = ctx->stream;
     lap("hipMalloc of the columns");
     if (n > 0) DEC_TRY(hipMemcpyAsync(d_rec.p, rec_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
@@ -624,8 +675,13 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
     DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
     DEC_TRY(hipStreamSynchronize(s));
     lap("payload kernel");
-    bam_set_device_payload(b, d_seq.p, d_qual.p, d_cig.p, device_free);
-    d_seq.p = d_qual.p = d_cig.p = nullptr;
+    if (own.p) {                      // (the columns have their own buffer: the arena goes now)
+      bam_set_device_payload(b, d_seq.p, d_qual.p, d_cig.p, own.p, device_free);
+      own.p = nullptr;
+    } else {
+      bam_set_device_payload(b, d_seq.p, d_qual.p, d_cig.p, iu.kept, device_free);     // (the arena lives as long as the columns)
+      iu.kept = nullptr;
+    }
   }
   lap("free scratch");
 #undef DEC_TRY

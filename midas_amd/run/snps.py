@@ -455,7 +455,7 @@ def species_pileup(args, species_id, contigs):
     order, span = _whole(_species_contig_order([species_id], contigs), contigs)
     try:
         with abi.Context(int(os.environ.get("LOCAL_RANK", "0"))) as ctx:
-            decoded = abi.read_bam(bampath, ctx if args.get('device_inflate') else None)
+            decoded = abi.read_bam(bampath, ctx if _inflate_on_device(args, ctx, bampath, 1) else None)
             stats = _pileup_contigs(args, [species_id], order[species_id], order, {}, decoded, ctx, span, contigs)
     except abi.MidasSnpsError as e:
         _exit_on(e)
@@ -571,8 +571,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     N ranks: contigs are the work items (the unit count_coverage is called on, :187-199), dealt to the ranks by
     longest-processing-time over bytes of aligned reads + sites; a rank piles up its contigs, writes their rows, and one
     all-gather of [n_species, 5] partial counters follows.  make_context: tests substitute a CPU double of the device.
-    The context is opened first: with args['device_inflate'] the device also inflates the BAM's blocks
-    (midas_bam_open_device; off by default -- DESIGN.md 5 has the measurements that say why)."""
+    The context is opened first: the device may also inflate the BAM's blocks (_inflate_on_device)."""
     error, ctx = None, None
     stack = ExitStack()
     try:
@@ -586,8 +585,23 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         return _count_alleles(args, species, contigs, ctx)
 
 
+def _inflate_on_device(args, ctx, bampath, ws):
+    """args['device_inflate']: 'on' / True, 'off' / False, or 'auto' (the default): on for one rank and a BAM of 0.5-8 GB --
+    where the measurements of DESIGN.md 3.4 have the device ahead (configs[2]: stage 0.68 s against 0.71-0.95 s) and its
+    one-call buffers (ten times the file) fit beside everything else; the host's threads are as fast on smaller files."""
+    want = args.get('device_inflate', 'auto')
+    if not getattr(ctx, 'inflates', False) or want in (False, 'off'):
+        return False
+    if want in (True, 'on'):
+        return True
+    try:
+        size = os.path.getsize(bampath)
+    except OSError:
+        return False
+    return ws == 1 and (512 << 20) <= size <= (8 << 30)
+
+
 def _count_alleles(args, species, contigs, ctx):
-    inflater = ctx if args.get('device_inflate') else None
     start = time()
     rank, ws = dist.world()
     if rank == 0:
@@ -595,6 +609,7 @@ def _count_alleles(args, species, contigs, ctx):
         args['log'].write("\nCounting alleles\n")
 
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
+    inflater = ctx if _inflate_on_device(args, ctx, bampath, ws) else None
     # N ranks: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and each
     # decodes only the records of the contigs it ends up owning.  One rank (or a BAM the slices cannot vouch for:
     # not coordinate-sorted, or a guessed record boundary that the neighbouring slice does not confirm): decode it whole.

@@ -145,8 +145,9 @@ def build_parser():
     parser.add_argument('--remove_temp', action='store_true', help="delete <outdir>/snps/temp when done")
     parser.add_argument('--split_length', type=int, default=8 << 20, metavar='INT',
                         help="under torchrun, contigs longer than this are dealt to the GPUs in pieces (0: never; default 8 Mb)")
-    parser.add_argument('--device_inflate', action='store_true',
-                        help="inflate the BAM's blocks on the GPU instead of with the host's threads (pays where a rank has few CPUs)")
+    parser.add_argument('--device_inflate', choices=('auto', 'on', 'off'), default='auto',
+                        help="inflate the BAM's blocks on the GPU instead of with the host's threads; auto (default): for one "
+                             "rank and a BAM of 0.5-8 GB")
     for title, options in OPTION_GROUPS:
         group = parser.add_argument_group(title)
         for flags, kw in options:

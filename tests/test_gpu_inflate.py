@@ -41,6 +41,10 @@ def _payloads():
         "far_matches": bytes(rng.integers(0, 256, 32768, dtype=np.uint8)) * 2,                 # distance 32768 (one shy of 64 KiB)
         "bam_like": bytes(rng.integers(0, 16, 30000, dtype=np.uint8)) + bytes(rng.integers(20, 42, 30000, dtype=np.uint8)),
     }
+    # as many matches as a stream can hold (one per 3-4 bytes: tokens of three bytes from a small dictionary, in random order):
+    # more than the decoder's first-pass room for them, so these streams go through its second pass
+    tokens = rng.integers(0, 256, (400, 3), dtype=np.uint8)
+    out["dense_matches"] = tokens.tobytes() + tokens[rng.integers(0, 400, 20000)].tobytes()
     out["far_matches"] = out["far_matches"][:65280]
     return out
 
