@@ -39,6 +39,6 @@ E2E_REPS=3 timeout 900 python tools/e2e_stage.py c2 /tmp/e2e_c2 > $EV/e2e_stage_
 { echo "# rocprofv3 --kernel-trace --stats -- python tools/rows_probe.py c2   (three device-coded and three host-coded writes of the 15 M rows of configs[1])"
   cat $EV/rows_probe_c2.log
   f=$(find $REPO/gpurun_out/prof_rows -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && { echo "# kernel_stats.csv"; head -12 "$f"; }; } > $EV/${TAG}_rows_deflate_rocprofv3_stats.txt 2>&1
+  [ -n "$f" ] && { echo "# kernel_stats.csv"; head -12 "$f"; }; } > $EV/${TAG}_rows_probe_c2.txt 2>&1
 rm -rf $REPO/gpurun_out/prof_rows
 ls -la $EV
