@@ -315,12 +315,15 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
     } else {
       const uint32_t st = type == 1u ? fixed_tables(L) : read_dynamic_header(L, in);
       if (st != kOk) return st;
+      in.refill(L);
       for (;;) {
         // (one count for all the lanes that take this step together: they top their rings up at the same steps)
         tick = (uint32_t)__builtin_amdgcn_readfirstlane((int)tick) + 1u;
         if ((tick & 7u) == 0u) in.top_up(L);
-        in.refill(L);
+        // at least 15 valid bits here (32 after a literal, 19 after a match): the symbol is decoded first and the buffer filled
+        // up behind it -- one round trip to the ring fewer on the way to the next table look-up
         int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl);
+        in.refill(L);
         if (s < 0) return kBadSymbol;
         if (s < 256) {
           if (out.o >= ulen) return kOutputOverrun;
@@ -334,8 +337,7 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         uint32_t len;
         int extra;
         length_of(s, &len, &extra);
-        len += in.take(extra);                                               // (<= 5 extra bits: still >= 12 valid bits left)
-        in.refill(L);
+        len += in.take(extra);                                               // (<= 5 extra bits of >= 32: 27 left for the distance code)
         const int d = decode(L, in, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD);
         if (d < 0 || d >= 30) return kBadDistance;
         in.refill(L);
