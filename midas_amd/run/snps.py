@@ -586,9 +586,12 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
 
 
 def _inflate_on_device(args, ctx, bampath, ws):
-    """args['device_inflate']: 'on' / True, 'off' / False, or 'auto' (the default): on for one rank and a BAM of 0.5-8 GB --
-    where the measurements of DESIGN.md 3.4 have the device ahead (configs[2]: stage 0.68 s against 0.71-0.95 s) and its
-    one-call buffers (ten times the file) fit beside everything else; the host's threads are as fast on smaller files."""
+    """args['device_inflate']: 'on' / True, 'off' / False, or 'auto' (the default) -- on where the measurements of DESIGN.md
+    3.4 have the device ahead and its one-call buffers (six times the compressed bytes) fit beside everything else:
+      * one rank and a BAM of 0.5-8 GB (configs[2]: stage 0.64-0.74 s against 0.78-0.89 s; smaller files: the host's threads
+        are as fast);
+      * a rank with few CPUs -- eight ranks share a node's cores under torchrun -- and a share of the BAM of 32 MB-8 GB (a
+        1.26 GB BAM with the 2 CPUs of an 8-rank node's rank: decode 0.87 s against 3.0 s)."""
     want = args.get('device_inflate', 'auto')
     if not getattr(ctx, 'inflates', False) or want in (False, 'off'):
         return False
@@ -598,7 +601,9 @@ def _inflate_on_device(args, ctx, bampath, ws):
         size = os.path.getsize(bampath)
     except OSError:
         return False
-    return ws == 1 and (512 << 20) <= size <= (8 << 30)
+    if ws == 1 and (512 << 20) <= size <= (8 << 30):
+        return True
+    return utility.cpu_budget() <= 4 and (32 << 20) <= size // max(1, ws) <= (8 << 30)
 
 
 def _count_alleles(args, species, contigs, ctx):
