@@ -177,6 +177,8 @@ args = dict(outdir=out, db=db, build_db=False, align=False, call=True, species_i
             mapid=94.0, readq=20, mapq=20, baseq=30, aln_cov=0.75, remove_temp=False)
 if os.environ.get("SNPS_SPLIT_LENGTH"):
     args['split_length'] = int(os.environ["SNPS_SPLIT_LENGTH"])
+if os.environ.get("SNPS_DEVICE_INFLATE"):
+    args['device_inflate'] = os.environ["SNPS_DEVICE_INFLATE"]
 species = msnps.initialize_species(args)
 contigs = msnps.initialize_contigs(species)
 if os.environ.get("SNPS_REAL_DEVICE"):       # (tests/test_gpu_dist.py: the ranks share GPU 0)

@@ -27,21 +27,25 @@ def test_ranks_sharing_one_gpu_write_the_single_process_files(tmp_path):
     os.environ.update(env)
     try:
         outs = {}
-        for n in (1, 2, 3):
-            d = str(tmp_path / ("gpu_n%d" % n))
+        # (11, 12: one and two ranks again with the BGZF blocks inflated on the device -- one rank also leaves SEQ / QUAL / CIGAR
+        # there, two ranks inflate their slices' blocks)
+        for n in (1, 2, 3, 11, 12):
+            os.environ["SNPS_DEVICE_INFLATE"] = "on" if n > 10 else "off"
+            tag, n = n, (n - 10 if n > 10 else n)
+            d = str(tmp_path / ("gpu_n%d" % tag))
             shutil.copytree(cpu, d, ignore=shutil.ignore_patterns("output"))
             os.makedirs(os.path.join(d, "snps", "output"))
             res = _run_snps_workers(tmp_path, script, d, db, n)
             assert all(rc == 0 for rc, _, _ in res), "\n".join("rank %d: rc %d\n%s" % (k, rc, e[-1500:]) for k, (rc, _, e) in enumerate(res))
             if n > 1:
                 assert any("long contigs: 1 cut into pieces" in o for _, o, _ in res)
-            outs[n] = d
+            outs[tag] = d
     finally:
-        for k in env:
-            del os.environ[k]
+        for k in list(env) + ["SNPS_DEVICE_INFLATE"]:
+            os.environ.pop(k, None)
     files = sorted(os.listdir(os.path.join(cpu, "snps", "output")))
     assert len(files) == table.n_species
-    for n in (1, 2, 3):
+    for n in (1, 2, 3, 11, 12):
         assert sorted(os.listdir(os.path.join(outs[n], "snps", "output"))) == files
         assert open(os.path.join(outs[n], "snps", "summary.txt")).read() == open(os.path.join(cpu, "snps", "summary.txt")).read()
         for f in files:
