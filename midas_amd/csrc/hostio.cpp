@@ -660,7 +660,8 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
   Lap lap("bam decode");
   // sizes first, by all threads (every record header is a cache miss), then three running sums over contiguous arrays
   b->seq_off[0] = b->qual_off[0] = b->cigar_off[0] = 0;
-  {
+  const bool on_device = b->payload_on_device;     // SEQ / QUAL / CIGAR are cut on the device: the small columns are all the
+  {                                                // host decodes, and it does so here, on its one visit to the record
     std::atomic<size_t> nexts{0};
     std::atomic<long long> overrun{-1};
     Workers::run(hw_threads(0), [&] {
@@ -681,6 +682,15 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
           b->cigar_off[i + 1] = n_cig;
           b->seq_off[i + 1] = (l + 1) / 2;
           b->qual_off[i + 1] = l;
+          if (on_device) {
+            b->refid[i] = (int32_t)rd32(r);
+            b->pos[i] = (int32_t)rd32(r + 4);
+            b->mapq[i] = r[9];
+            b->flag[i] = rd16(r + 14);
+            b->l_seq[i] = (int32_t)l;
+            const uint64_t body = (uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l;
+            b->nm[i] = body <= bs ? find_nm(r + body, r + bs) : -1;
+          }
         }
       }
     });
@@ -700,8 +710,11 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
     }
   }
   lap("record sizes + offsets");
-  const bool on_device = b->payload_on_device;
-  if (on_device) b->rec_off.assign(offs.begin(), offs.end());
+  if (on_device) {
+    b->rec_off.assign(offs.begin(), offs.end());
+    b->loaded = true;
+    return MIDAS_SNPS_OK;
+  }
   if (!on_device && (!b->cigar.resize((size_t)b->cigar_off[n]) || !b->seq4.resize((size_t)b->seq_off[n]) || !b->qual.resize((size_t)b->qual_off[n]))) {
     set_err(err256, "out of memory decoding %s", b->path.c_str());
     return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
