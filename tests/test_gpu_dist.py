@@ -53,3 +53,33 @@ def test_ranks_sharing_one_gpu_write_the_single_process_files(tmp_path):
             assert got == open(os.path.join(outs[1], "snps", "output", f), "rb").read(), "%s: %d ranks vs 1" % (f, n)
     for f in files:          # device coder vs host coder: the same text
         assert gzip.open(os.path.join(outs[1], "snps", "output", f), "rb").read() == gzip.open(os.path.join(cpu, "snps", "output", f), "rb").read()
+
+
+def test_device_payload_with_records_not_grouped_by_reference(tmp_path):
+    """--device_inflate on for a BAM whose contigs are written in reverse order: the payload columns left on the device have to
+    come down again for the regroup -- same files as with the host inflating."""
+    import numpy as np
+    from midas_amd import bam, synth
+    from tests.test_gpu_parity import _subset
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=2, contig_len=15000, n_reads=6000, seed=21)
+    db, a, b = str(tmp_path / "db"), str(tmp_path / "host"), str(tmp_path / "dev")
+    synth.write_sample(a, db, contigs, reads)
+    rb = contigs.read_begin
+    order = np.concatenate([np.arange(rb[c], rb[c + 1]) for c in reversed(range(contigs.n_contigs))])
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(rb))[order]
+    bam.write_bam(os.path.join(a, "snps", "temp", "genomes.bam"), contigs.ids, [int(x) for x in contigs.length], refid, _subset(reads, order))
+    shutil.copytree(a, b)
+    os.environ["SNPS_REAL_DEVICE"] = "1"
+    try:
+        for d, how in ((a, "off"), (b, "on")):
+            os.environ["SNPS_DEVICE_INFLATE"] = how
+            (rc, o, e), = _run_snps_workers(tmp_path, script, d, db, 1)
+            assert rc == 0, e[-1500:]
+    finally:
+        for k in ("SNPS_REAL_DEVICE", "SNPS_DEVICE_INFLATE"):
+            os.environ.pop(k, None)
+    for f in sorted(os.listdir(os.path.join(a, "snps", "output"))):
+        assert open(os.path.join(a, "snps", "output", f), "rb").read() == open(os.path.join(b, "snps", "output", f), "rb").read()
+    assert open(os.path.join(a, "snps", "summary.txt")).read() == open(os.path.join(b, "snps", "summary.txt")).read()
