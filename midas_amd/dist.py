@@ -18,7 +18,14 @@ import numpy as np
 _STAT_COLS = 5   # genome_length, covered_bases, total_depth, aligned_reads, mapped_reads
 
 
+def _alone():
+    """One process and no process group can exist: torch is not even imported (a second and a half of the single-GPU command)."""
+    return int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1 and 'torch.distributed' not in sys.modules
+
+
 def world():
+    if _alone():
+        return 0, 1
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -32,6 +39,8 @@ COLLECTIVE_TIMEOUT = datetime.timedelta(hours=48)
 
 def init_from_env(device_backend=None):
     """Join the process group torchrun described (RANK / WORLD_SIZE / MASTER_*); no-op for a single process."""
+    if _alone():
+        return 0, 1
     import torch
     import torch.distributed as dist
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,13 +73,13 @@ def agree_or_exit(error_message=None):
     leave together -- the failing ones with their message, as the reference's sys.exit("\nError: ...") would, the others
     naming the failed ranks -- instead of one rank exiting and its peers blocking in the collective until the
     watchdog kills them."""
-    import torch
-    import torch.distributed as dist
     rank, ws = world()
     if ws == 1:
         if error_message is not None:
             sys.exit(error_message)
         return
+    import torch
+    import torch.distributed as dist
     flag = torch.tensor([1 if error_message is not None else 0], dtype=torch.int64)
     if dist.get_backend() == "nccl":
         flag = flag.cuda()
@@ -106,12 +115,12 @@ shard_items = shard_species
 def all_gather_summary(rows):
     """rows: int64 [n_species_total, 5], zero outside the species this rank owns.
     One all-gather of the rows (<= 100 species x 40 B per rank), then a local sum over ranks."""
-    import torch
-    import torch.distributed as dist
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     rank, ws = world()
     if ws == 1:
         return rows.copy()
+    import torch
+    import torch.distributed as dist
     on_gpu = dist.get_backend() == "nccl"
     t = torch.from_numpy(rows)
     if on_gpu:
@@ -123,12 +132,12 @@ def all_gather_summary(rows):
 
 def all_gather_i64(values):
     """values: int64 array of the same length on every rank -> [world, len] (rank-major)."""
-    import torch
-    import torch.distributed as dist
     v = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
     rank, ws = world()
     if ws == 1:
         return v.reshape(1, -1).copy()
+    import torch
+    import torch.distributed as dist
     t = torch.from_numpy(v)
     if dist.get_backend() == "nccl":
         t = t.cuda()
@@ -140,12 +149,12 @@ def all_gather_i64(values):
 def all_gather_rows_f64(rows):
     """Like all_gather_summary for float64 rows (the genes summary has means and medians): rows are zero outside the
     species this rank owns, so the sum over ranks is the owner's row (nan stays nan)."""
-    import torch
-    import torch.distributed as dist
     rows = np.ascontiguousarray(rows, dtype=np.float64)
     rank, ws = world()
     if ws == 1:
         return rows.copy()
+    import torch
+    import torch.distributed as dist
     t = torch.from_numpy(rows)
     if dist.get_backend() == "nccl":
         t = t.cuda()
@@ -155,6 +164,8 @@ def all_gather_rows_f64(rows):
 
 
 def barrier():
+    if _alone():
+        return
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
