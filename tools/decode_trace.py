@@ -1,6 +1,7 @@
 """Developer script: where midas_bam_load spends its time on a configs[k] BAM (library built with -DMIDAS_HOSTIO_TRACE:
 tools/build_variant.sh trace -DMIDAS_HOSTIO_TRACE; MIDAS_SNPS_LIBRARY=midas_amd/lib/libmidas_snps_hip_trace.so).
-usage: python tools/decode_trace.py [config] [workdir]"""
+DECODE_ON_DEVICE=1: the BGZF blocks are inflated on the device; =2: and SEQ / QUAL / CIGAR left there (midas_bam_load_device);
+LOCAL_WORLD_SIZE=8 gives the host code the CPU budget of one rank of eight.   usage: python tools/decode_trace.py [config] [workdir]"""
 import os
 import sys
 import time

@@ -1,3 +1,6 @@
+"""Developer script (GPU box): the rows of one configs[k] batch written three times by the device's row coder and three times by the
+host's formatter (Batch.write_part, one file), sizes and times, and the two files' inflated text compared.  MIDAS_SNPS_TRACE=1
+prints the device call's phases.   usage: python tools/rows_probe.py [config]"""
 import sys, os, time, gzip
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
