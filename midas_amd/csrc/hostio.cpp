@@ -648,7 +648,8 @@ int64_t guess_record_start(BamWindow& w, uint64_t from, const std::vector<int64_
 }
 
 // records [offs] of the inflated bytes d -> the SoA columns of b (what fetch(contig, ...) can return: refID >= 0)
-int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>& offs, char* err256) {
+constexpr size_t kHeadWords = 6;     // (walk_records below fills them)
+int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>& offs, char* err256, const uint32_t* heads = nullptr) {
   const size_t n = offs.size();
   b->n_records = n;
   const size_t n1 = n ? n : 1;
@@ -671,10 +672,13 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
         const size_t hi = std::min(n, lo + 8192);
         for (size_t i = lo; i < hi; ++i) {
           const uint8_t* r = &d[offs[i] + 4];
-          const uint32_t bs = rd32(&d[offs[i]]);
-          const uint32_t l_read_name = r[8];
-          const uint32_t n_cig = rd16(r + 12);
-          const uint32_t l = rd32(r + 16);
+          // (the record's fixed part: out of the walk's copy when there is one -- no cache miss per record here)
+          uint32_t hw[kHeadWords];
+          if (heads) memcpy(hw, heads + i * kHeadWords, sizeof hw); else memcpy(hw, &d[offs[i]], sizeof hw);
+          const uint32_t bs = hw[0];
+          const uint32_t l_read_name = hw[3] & 0xFFu;
+          const uint32_t n_cig = hw[4] & 0xFFFFu;
+          const uint32_t l = hw[5];
           if ((uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l > bs) {
             long long none = -1;
             overrun.compare_exchange_strong(none, (long long)i);
@@ -683,10 +687,10 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
           b->seq_off[i + 1] = (l + 1) / 2;
           b->qual_off[i + 1] = l;
           if (on_device) {
-            b->refid[i] = (int32_t)rd32(r);
-            b->pos[i] = (int32_t)rd32(r + 4);
-            b->mapq[i] = r[9];
-            b->flag[i] = rd16(r + 14);
+            b->refid[i] = (int32_t)hw[1];
+            b->pos[i] = (int32_t)hw[2];
+            b->mapq[i] = (uint8_t)(hw[3] >> 8);
+            b->flag[i] = (uint16_t)(hw[4] >> 16);
             b->l_seq[i] = (int32_t)l;
             const uint64_t body = (uint64_t)32 + l_read_name + 4ull * n_cig + (l + 1) / 2 + l;
             b->nm[i] = body <= bs ? find_nm(r + body, r + bs) : -1;
@@ -761,14 +765,25 @@ int32_t decode_records(midas_bam* b, const uint8_t* d, const std::vector<size_t>
 // the chain that started at the true first record ended on exactly its guess -- then the guess was a true boundary and
 // the walk is the one a single core would have made.  A piece whose guess the chain does not hit is walked again from
 // where the chain stands (nothing is ever taken on plausibility alone).
+// heads (optional): the six leading words of every kept record -- block_size, refID, pos, l_read_name | mapq << 8 | bin << 16,
+// n_cigar_op | flag << 16, l_seq -- taken while the walk has the record's first cache line in hand anyway, so that the decoder's
+// size pass (and, with the payload on the device, its whole small-column pass) never has to come back for them.
 int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std::vector<int64_t>& ref_lens,
-                     std::vector<size_t>& offs, const char* path, char* err256) {
-  struct Piece { size_t start = 0, end = 0, bad_at = 0; bool bad = false; std::vector<size_t> offs; };
+                     std::vector<size_t>& offs, const char* path, char* err256, std::vector<uint32_t>* heads = nullptr) {
+  struct Piece { size_t start = 0, end = 0, bad_at = 0; bool bad = false; std::vector<size_t> offs; std::vector<uint32_t> heads; };
+  const bool want_heads = heads != nullptr;
   auto walk = [&](size_t p, size_t stop, Piece& pc) {     // records starting in [p, stop); pc.end = first start >= stop
     while (p + 4 <= total && p < stop) {
       const size_t bs = rd32(&d[p]);
       if (bs < 32 || p + 4 + bs > total) { pc.bad = true; pc.bad_at = p; break; }
-      if ((int32_t)rd32(&d[p + 4]) >= 0) pc.offs.push_back(p);
+      if ((int32_t)rd32(&d[p + 4]) >= 0) {
+        pc.offs.push_back(p);
+        if (want_heads) {
+          uint32_t w[kHeadWords];
+          memcpy(w, &d[p], sizeof w);       // (bs >= 32: the 24 bytes are the record's)
+          pc.heads.insert(pc.heads.end(), w, w + kHeadWords);
+        }
+      }
       p += 4 + bs;
     }
     pc.end = p;
@@ -781,6 +796,7 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
     walk(rec_begin, total, all);
     if (all.bad) { set_err(err256, "%s: truncated alignment record at byte %lld", path, (long long)all.bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
     offs.swap(all.offs);
+    if (want_heads) heads->swap(all.heads);
     return MIDAS_SNPS_OK;
   }
   const size_t per = span / n_pieces;
@@ -818,6 +834,7 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
       const size_t k = next.fetch_add(1);
       if (k >= pieces.size()) return;
       pieces[k].offs.reserve(per / 200);
+      if (want_heads) pieces[k].heads.reserve(per / 200 * kHeadWords);
       walk(pieces[k].start, k + 1 < pieces.size() ? pieces[k + 1].start : total, pieces[k]);
     }
   });
@@ -840,6 +857,7 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
     cur = pc->end;
   }
   offs.resize(n_total);
+  if (want_heads) heads->resize(n_total * kHeadWords);
   std::vector<size_t> at(pieces.size() + 1, 0);
   for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + use[k]->offs.size();
   next = 0;
@@ -848,6 +866,8 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
       const size_t k = next.fetch_add(1);
       if (k >= pieces.size()) return;
       if (!use[k]->offs.empty()) memcpy(offs.data() + at[k], use[k]->offs.data(), use[k]->offs.size() * sizeof(size_t));
+      if (want_heads && !use[k]->heads.empty())
+        memcpy(heads->data() + at[k] * kHeadWords, use[k]->heads.data(), use[k]->heads.size() * sizeof(uint32_t));
     }
   });
   return MIDAS_SNPS_OK;
@@ -954,10 +974,11 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
     // pass 1: record offsets (what fetch(contig, ...) can ever return: refID >= 0)
     Lap lap("bam load");
     std::vector<size_t> offs;
-    const int32_t wst = walk_records(d.data(), d.size(), b->rec_begin, b->ref_lens, offs, b->path.c_str(), err256);
+    std::vector<uint32_t> heads;
+    const int32_t wst = walk_records(d.data(), d.size(), b->rec_begin, b->ref_lens, offs, b->path.c_str(), err256, &heads);
     if (wst != MIDAS_SNPS_OK) return wst;
     lap("record walk");
-    const int32_t st = decode_records(b, d.data(), offs, err256);
+    const int32_t st = decode_records(b, d.data(), offs, err256, heads.data());
     if (st != MIDAS_SNPS_OK) return st;
     lap("decode_records");
     // the inflated stream is no longer needed; unmapping hundreds of MB takes ~10 ms, which nobody has to wait for
