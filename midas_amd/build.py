@@ -1,5 +1,10 @@
-"""Build the in-tree native library with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build the in-tree native library with hipcc for gfx950 (cross-compiles without a GPU).
 
+Every source is compiled to its own object (in parallel, kept under midas_amd/lib/obj/ and reused while neither the source
+nor any header changed), then the objects are linked into midas_amd/lib/libmidas_snps_hip.so.
+"""
+
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -8,11 +13,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_NAME = "libmidas_snps_hip.so"
 LIB_PATH = os.path.join(LIB_DIR, LIB_NAME)
 
-SOURCES = ["pack.cpp", "hostio.cpp", "row_deflate.cpp", "pack_reads.hip", "index_reads.hip", "pileup_tiles.hip", "index_direct.hip", "pileup_direct.hip", "rows_deflate.hip", "bgzf_inflate.hip", "merge_sites.hip", "genes_count.hip", "snps_abi.hip"]
-HEADERS = ["layout.h", "pack.h", "kernels.h", "device_common.h", "pileup_common.h", "direct_common.h", "ctx_internal.h", "hostio.h", "row_deflate.h", "workers.h", os.path.join("..", "..", "include", "midas_snps.h")]
+SOURCES = ["pack.cpp", "hostio.cpp", "row_deflate.cpp", "pack_reads.hip", "index_reads.hip", "pileup_tiles.hip", "index_direct.hip", "pileup_direct.hip", "rows_deflate.hip", "bgzf_inflate.hip", "bam_walk.hip", "merge_sites.hip", "genes_count.hip", "snps_abi.hip"]
+HEADERS = ["layout.h", "pack.h", "kernels.h", "device_common.h", "pileup_common.h", "direct_common.h", "ctx_internal.h", "hostio.h", "row_deflate.h", "workers.h", "crc32.h", os.path.join("..", "..", "include", "midas_snps.h")]
+
+# The atomic optimizer turns a one-lane atomicAdd into mbcnt/readfirstlane and waits for the result at once; the
+# pileup kernel fetches its next work item that way and must not stall on it (pileup_tiles.hip, dynamic items).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _hipcc():
@@ -22,39 +32,86 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build %s" % LIB_NAME)
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _newest_header():
+    t = 0.0
+    for h in HEADERS:
+        p = os.path.join(CSRC, h)
+        if os.path.exists(p):
+            t = max(t, os.path.getmtime(p))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    if _newest_header() > t:
+        return True
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
 
 
-def build_native(force=False, verbose=False):
-    """Compile midas_amd/csrc/* into midas_amd/lib/libmidas_snps_hip.so (gfx950 only)."""
-    if not force and not _stale():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    # The atomic optimizer turns a one-lane atomicAdd into mbcnt/readfirstlane and waits for the result at once; the
-    # pileup kernel fetches its next work item that way and must not stall on it (pileup_tiles.hip, dynamic items).
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-           "-amdgpu-atomic-optimizer-strategy=None", "-x", "hip"] + srcs + \
-          ["-o", tmp, "-lz", "-lpthread", "-ldl"]
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.unlink(tmp)
-        raise RuntimeError("hipcc failed (%d):\n%s" % (res.returncode, res.stdout))
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError("hipcc failed (%d): %s\n%s" % (res.returncode, " ".join(cmd), res.stdout))
+
+
+def build_native(force=False, verbose=False, extra_flags=(), lib_path=None):
+    """Compile midas_amd/csrc/* into midas_amd/lib/libmidas_snps_hip.so (gfx950 only).
+
+    `extra_flags` / `lib_path`: developer variants (tools/build_variant.sh): other -D switches, another output name; their
+    objects are not cached.
+    """
+    variant = bool(extra_flags) or lib_path is not None
+    out = lib_path or LIB_PATH
+    if not force and not variant and not _stale():
+        return out
+    hipcc = _hipcc()
+    obj_dir = OBJ_DIR if not variant else OBJ_DIR + ".variant.%d" % os.getpid()
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_t = _newest_header()
+    jobs = []
+    objs = []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(obj_dir, s.replace(".", "_") + ".o")
+        objs.append(obj)
+        if force or variant or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-x", "hip", "-c", src, "-o", obj])
+    try:
+        workers = max(1, min(len(jobs), (os.cpu_count() or 4)))
+        if jobs:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+                for f in [pool.submit(_run, j, verbose) for j in jobs]:
+                    f.result()
+        tmp = out + ".tmp.%d" % os.getpid()
+        try:
+            _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp, "-lz", "-lpthread", "-ldl"], verbose)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+    finally:
+        if variant:
+            shutil.rmtree(obj_dir, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:]]
+    force = "--force" in args
+    out = None
+    extra = []
+    it = iter(a for a in args if a != "--force")
+    for a in it:
+        if a == "-o":
+            out = next(it)
+        else:
+            extra.append(a)
+    print(build_native(force=force, verbose=True, extra_flags=extra, lib_path=out))
