@@ -389,7 +389,7 @@ def main():
             "sustain": {"steps": sustain_steps, "seconds": a.sustain_seconds,
                         "note": "untimed back-to-back steps in front of the timed region (same work)"},
             "path": {"taken": path, "general_reads": int(info.direct_general_reads),
-                     "general_entries": int(info.direct_general_entries), "stream_reads": int(info.direct_stream_reads),
+                     "reach": int(info.direct_reach), "stream_reads": int(info.direct_stream_reads),
                      "lanes_per_read": int(info.lanes_per_read), "lane_bases": int(info.lane_bases)},
         }
         if share is not None:

@@ -197,12 +197,13 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
                                 const midas_snps_reads* reads, midas_snps_batch** out_batch);
 void midas_snps_batch_destroy(midas_snps_batch* batch);
 /* The two device paths of a batch.  DIRECT: the pileup kernel reads the batch's BAM-native arrays where they are -- 4-bit
- * SEQ, QUAL, CIGAR and the per-read columns; an index pass (one thread per read) finds, per 4096-site tile, the run of
- * reads touching it and describes the reads that are not one gap-free match segment; nothing is sorted or copied.  It wants
- * position-sorted reads (what samtools sort writes; any order is CORRECT, only slower).  PACKED: the reads are first laid
- * out in tile order as records + one byte per base (midas_snps_batch_pack), which handles any order and cuts coverage hot
- * spots into parts.  batch_create picks DIRECT unless the reads are badly ordered or a tile holds a hot spot; AUTO
- * restores that choice.  Both paths give bit-identical results (tests/test_gpu_direct.py).                          */
+ * SEQ, QUAL, CIGAR and the per-read columns -- and visits every read once: a pass over the positions alone (4 bytes per
+ * read) finds, per 4096-site tile, the run of reads that can touch it; the kernel decides in registers what a read's CIGAR
+ * is and tallies it; nothing is sorted, copied or described beforehand.  It wants position-sorted reads (what samtools sort
+ * writes; any order is CORRECT, only slower).  PACKED: the reads are first laid out in tile order as records + one byte per
+ * base (midas_snps_batch_pack), which handles any order and cuts coverage hot spots into parts.  batch_create picks DIRECT
+ * unless the reads are badly ordered, one read spans many tiles or a tile holds a hot spot; AUTO restores that choice.
+ * Both paths give bit-identical results (tests/test_gpu_direct.py).                                                */
 enum { MIDAS_SNPS_PATH_AUTO = 0, MIDAS_SNPS_PATH_DIRECT = 1, MIDAS_SNPS_PATH_PACKED = 2 };
 int32_t midas_snps_batch_select_path(midas_snps_batch* batch, int32_t path);
 /* The path of every batch created on the context from now on (the one-shot midas_snps_pileup included); AUTO = each
@@ -270,8 +271,8 @@ typedef struct midas_snps_batch_info {
   int32_t path_auto;        /* what the batch's own numbers recommend (see midas_snps_batch_select_path)       */
   int32_t lane_bases;       /* bases per lane of the active path's kernel                                      */
   int32_t reserved0;
-  int64_t direct_general_reads;   /* reads that are not one gap-free match segment (walked op by op)          */
-  int64_t direct_general_entries; /* (general read, tile) descriptors                                          */
+  int64_t direct_general_reads;   /* reads that are not one or two gap-free match runs (walked op by op)      */
+  int64_t direct_reach;           /* longest reference span of a read: how far back a tile's read range reaches */
   int64_t direct_stream_reads;    /* sum over tiles of the reads their streams hold: n_reads + straddlers when sorted */
   int64_t direct_max_tile_reads;
 } midas_snps_batch_info;

@@ -106,12 +106,13 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:]]
     force = "--force" in args
+    verbose = "-v" in args
     out = None
     extra = []
-    it = iter(a for a in args if a != "--force")
+    it = iter(a for a in args if a not in ("--force", "-v"))
     for a in it:
         if a == "-o":
             out = next(it)
         else:
             extra.append(a)
-    print(build_native(force=force, verbose=True, extra_flags=extra, lib_path=out))
+    print(build_native(force=force, verbose=verbose, extra_flags=extra, lib_path=out))

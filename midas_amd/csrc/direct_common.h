@@ -1,5 +1,5 @@
 // Helpers shared by the kernels of the direct path (index_direct.hip, pileup_direct.hip): views of a read's CIGAR in the
-// BAM-native array, the clip rules of pysam's query_alignment_start / _end, and the layout of a general read's descriptor.
+// BAM-native array, the clip rules of pysam's query_alignment_start / _end, and the CIGAR shapes the pileup kernel settles in registers.
 #pragma once
 #include "device_common.h"
 
@@ -58,47 +58,37 @@ __device__ __forceinline__ void query_bounds(const CigarView& cg, uint32_t nc, l
   *end = l_seq - trail;
 }
 
-// Index record of a class-0 read, kIdxRecBytes = 20 bytes (five words), written by the classify kernel for the pileup kernel:
-//   w0 leading clip | aligned length << 10 | trailing clip << 21 (bit 31 clear)        w1 pos        w2 QUAL offset, low word
-//   w3 NM (11 bits) | mapq << 11 | bits 32-39 of the QUAL offset << 19 | bits 32-36 of the SEQ offset << 27        w4 SEQ offset, low word
-// The record of any other read (and the sentinel behind the last read): w0 = bit 31 | the read's contig -- skipped where it lies.
-// Descriptor of one (general read, tile) entry, kGenDescWords = 8 words:
-//   w0 aligned length (pysam: query_alignment_end - _start, >= 0) | leading soft clip << 11 | bits 32-39 of the CIGAR offset << 22
-//   w1 pos        w2 NM (16 bits, 0xFFFF = absent) | mapq << 16 | bits 32-39 of the SEQ offset << 24        w3 SEQ offset, low word
-//   w4 QUAL offset, low word        w5 bits 32-39 of the QUAL offset | kGen* flags << 8
-//   w6 CIGAR offset (elements), low word        w7 l_seq | n_cigar << 16
-// (the read's index of an entry, needed only for an error report, is kept apart: gidx[entry]).  The pileup kernel fetches
-// either kind with the same two unconditional 16-byte loads (the second one of a record overhangs into the next record).
-constexpr int kIdxRecBytes = 20;
-constexpr uint32_t kIdxMaxNm = 2047;
-struct GenDesc {
-  uint32_t idx; int32_t pos; uint32_t l, nc, nm16, mapq, flags, align_len, lead;
-  unsigned long long so, qo, co;
-};
-__device__ __forceinline__ void gdesc_store(uint32_t* g, const GenDesc& d) {
-  uint4* q = reinterpret_cast<uint4*>(g);
-  q[0] = make_uint4(d.align_len | (d.lead << 11) | ((uint32_t)((d.co >> 32) & 0xFF) << 22), (uint32_t)d.pos,
-                    d.nm16 | (d.mapq << 16) | ((uint32_t)((d.so >> 32) & 0xFF) << 24), (uint32_t)d.so);
-  q[1] = make_uint4((uint32_t)d.qo, (uint32_t)((d.qo >> 32) & 0xFF) | (d.flags << 8), (uint32_t)d.co, d.l | (d.nc << 16));
-}
-__device__ __forceinline__ void gdesc_store_idle(uint32_t* g) {
-  uint4* q = reinterpret_cast<uint4*>(g);
-  q[0] = make_uint4(0u, 0u, 0u, 0u);
-  q[1] = make_uint4(0u, (uint32_t)kGenIdle << 8, 0u, 0u);
-}
-__device__ __forceinline__ bool idxrec_fits(int32_t nm, unsigned long long so) { return (uint32_t)nm <= kIdxMaxNm && (so >> 37) == 0ull; }
-__device__ __forceinline__ void idxrec_store(uint8_t* rec, size_t i, uint32_t info, int32_t pos, uint32_t nm, uint32_t mapq,
-                                             unsigned long long so, unsigned long long qo) {
-  uint32_t* r = reinterpret_cast<uint32_t*>(rec + i * kIdxRecBytes);
-  u32x4_a4 v;
-  v.x = info; v.y = (uint32_t)pos; v.z = (uint32_t)qo;
-  v.w = nm | (mapq << 11) | ((uint32_t)((qo >> 32) & 0xFF) << 19) | ((uint32_t)((so >> 32) & 0x1F) << 27);
-  *reinterpret_cast<u32x4_a4*>(r) = v;
-  r[4] = (uint32_t)so;
-}
-// the record of a read that is not class 0 (and the sentinel behind the last read): nothing to do where it lies
-__device__ __forceinline__ void idxrec_store_idle(uint8_t* rec, size_t i, uint32_t contig) {
-  *reinterpret_cast<uint32_t*>(rec + i * kIdxRecBytes) = kInfoGeneral | contig;
+// The shape of a read's CIGAR as the pileup kernel settles it in registers: ONE or TWO gap-free match runs,
+//   `H* S? (M|=|X)+ ((I|D|N) (M|=|X)+)? S? H*`, every length >= 1, the lengths of S / M / I adding up to l_seq
+// -- everything an end-to-end or local aligner writes for a read with at most one indel.  The query positions
+// [lead, lead + m1) lie on the sites pos ..., [lead + m1 + ins, lead + alen) on pos + m1 + del ...; alen = m1 + ins + m2 is
+// len(aln.query_alignment_sequence) (midas/run/snps.py:145: pysam takes soft clips off both ends, inserted bases stay).
+// Any other read is walked op by op (pileup_direct.hip, the slow path).
+struct ReadShape { uint32_t lead, m1, ins, del, alen; };
+constexpr uint32_t kMaxFastGap = 65535;     // a longer deletion / skip goes the slow way (its arithmetic saturates)
+
+// One forward pass over the first four ops (registers); nc <= 4.  Stages: 0 leading hard clips, 1 behind the leading soft
+// clip, 2 in the first run, 3 behind the indel, 4 in the second run, 5 behind the trailing soft clip, 6 trailing hard clips.
+__device__ __forceinline__ bool decode_shape(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t nc, uint32_t l, ReadShape* out) {
+  uint32_t stage = 0, lead = 0, trail = 0, m1 = 0, m2 = 0, ins = 0, del = 0;
+  bool ok = nc >= 1u && nc <= 4u && l >= 1u;
+  auto step = [&](uint32_t v) {
+    const uint32_t op = v & 15u, len = v >> 4;
+    if (len == 0u) ok = false;
+    else if (op_is_match(op)) { if (stage <= 2u) { m1 += len; stage = 2u; } else if (stage <= 4u) { m2 += len; stage = 4u; } else ok = false; }
+    else if (op == OP_S) { if (stage == 0u) { lead = len; stage = 1u; } else if (stage == 2u || stage == 4u) { trail = len; stage = 5u; } else ok = false; }
+    else if (op == OP_I || op == OP_D || op == OP_N) { if (stage == 2u) { if (op == OP_I) ins = len; else del = len; stage = 3u; } else ok = false; }
+    else if (op == OP_H) { if (stage == 2u || stage == 4u || stage == 5u) stage = 6u; else if (stage != 0u && stage != 6u) ok = false; }
+    else ok = false;
+  };
+  if (nc > 0u) step(c0);
+  if (nc > 1u) step(c1);
+  if (nc > 2u) step(c2);
+  if (nc > 3u) step(c3);
+  // (sums of at most four 28-bit lengths: no wrap)
+  ok = ok && stage != 3u && stage >= 2u && lead + m1 + ins + m2 + trail == l && del <= kMaxFastGap;
+  out->lead = lead; out->m1 = m1; out->ins = ins; out->del = del; out->alen = m1 + ins + m2;
+  return ok;
 }
 
 }  // namespace direct

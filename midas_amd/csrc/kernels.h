@@ -150,82 +150,54 @@ hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);             
 
 
 // ---- direct path (index_direct.hip + pileup_direct.hip): the pileup kernel reads the BAM-native arrays themselves ------
-// Coordinate-sorted input needs no packed payload: a classify pass (one thread per read) sorts the reads into
-//   class 0  `H* S? (M|=|X)+ S? H*`, lengths adding up, inside its contig, NM present: ONE gap-free match segment.  The
-//            pileup kernel finds these by position -- per tile the lowest and highest read index touching it
-//            (atomicMin / atomicMax; reads are position-sorted, so that is a contiguous range) -- and takes everything
-//            else it needs (clip lengths, aligned length) from one word per read, `info`;
-//   general  everything else (indels, skips, pads, odd clips, reads without NM / SEQ, positions outside the contig ...):
-//            gathered per tile into 48-byte descriptors (count -> scan -> fill), walked op by op on the device.
+// One visit per read.  A ranges pass over the positions alone (4 bytes per read) leaves, per tile, the run of read indices
+// that can touch it; the pileup kernel fetches those reads' columns (pos, l_seq, NM, mapq, the CSR offsets), then their
+// bases and the first four CIGAR ops, decides in registers whether the CIGAR is one or two gap-free match runs
+// (direct_common.h: ReadShape -- everything with at most one indel) and tallies it; any other read (several indels, pads,
+// odd clips, no NM / SEQ, a start off the contig ...) is walked op by op where it lies.
 // Unsorted input only widens the ranges (slower, never wrong); the host falls back to the packed path when the ranges of a
 // batch add up to much more than its reads.
-constexpr uint32_t kInfoGeneral = 0x80000000u;   // info word: bit 31 = not class 0 (then bits 0-30: its contig); else lead | alen << 10 | trail << 21
-constexpr int kInfoAlenShift = 10, kInfoTrailShift = 21;
-constexpr int kGenDescWords = 8;                  // 32 bytes per (general read, tile) entry
-constexpr int kGenBodyWords = 12;                 // 48 bytes per general read: its descriptor + first tile, consecutive tiles, contig, read index
-
-// gdesc flag bits
-constexpr uint32_t kGenOverrun = 1;               // a match op maps a query position >= l_seq into the contig (IndexError if kept)
-constexpr uint32_t kGenNoNm = 2;                  // record has no NM tag
-constexpr uint32_t kGenInline = 4;                // two match runs around ONE I / D / N: the descriptor's CIGAR word holds the geometry
-                                                  // (first run | inserted << 10 | deleted or skipped << 20) -- no CIGAR is fetched
-constexpr uint32_t kGenIdle = 0x80;               // the sentinel descriptor [gdesc_capacity]: what a lane without an entry fetches
+constexpr uint32_t kGenIdle = 0x80;               // flag byte of a lane without a read
 
 constexpr int kDirectFactSlots = 64;
-struct alignas(128) DirectFacts {                 // per-slot partial sums of one classify pass (slot 0 also holds the status)
+struct alignas(128) DirectFacts {                 // per-slot partial results of the facts pass (batch_create), added up by the host
   unsigned long long status;                      // min((read << 8) | kPack*), kNoError when every read is well-formed
   unsigned long long alg_bytes;                   // sum(ceil(l/2) + l + 4*n_cigar + 16)
-  unsigned long long n_entries;                   // (general read, tile) entries
-  uint32_t n_general;                             // general reads
+  uint32_t n_general;                             // reads the pileup kernel walks op by op
   uint32_t max_l;                                 // longest read
+  uint32_t max_span;                              // longest reference span (sum of M/=/X/D/N lengths) of a read
   uint32_t unsorted;                              // some contig's reads are not in position order
-};
-struct DirectTotals {                             // the slots added up by the scan kernel (one per run, host reads it at create)
-  unsigned long long status, alg_bytes, n_entries;
-  uint32_t n_general, max_l, unsorted;
 };
 
 struct DirectIndexParams {
-  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int32_t* pos; const int32_t* nm; const int32_t* l_seq;
   const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
   const uint32_t* cigar;
   int64_t seq_bytes, qual_bytes, n_cigar;
   int32_t n_reads;
   const int32_t* contig_read_begin; const int32_t* contig_tile_base; const int32_t* contig_len;
   int32_t n_contigs, n_tiles, tile_shift;
-  uint8_t* rec;                                   // [n_reads + 1] 20-byte index records (direct_common.h), the last one a sentinel
-  uint32_t* tbegin; uint32_t* tend;               // [n_tiles] this run's parity: min index / max index + 1 of the class-0 reads touching a tile
+  uint32_t* tbegin; uint32_t* tend;               // [n_tiles] this run's parity: [first, last + 1) of the reads that can touch a tile
   uint32_t* tbegin_next; uint32_t* tend_next;     // the other parity, reset here for the next run
-  uint32_t* gcount;                               // [n_tiles + 1] general entries per tile (zero on entry; the fill kernel counts it back to zero)
-  uint32_t* goff;                                 // [n_tiles + 1] exclusive scan of gcount
-  uint32_t* gen_reads;                            // [n_reads] the general reads: every classify workgroup fills the start of its own stretch
-  uint32_t* gen_count;                            // [direct_index_blocks(n_reads)] how many it put there
-  const uint32_t* gen_base;                       // [direct_index_blocks(n_reads)] exclusive scan of gen_count (constant for a batch: set after its first pass)
-  uint32_t* gen_body;                             // [n_general][kGenBodyWords] the general reads' descriptors, classify -> fill (nullptr on the first pass)
-  uint32_t* gdesc;                                // [n_entries][kGenDescWords]
-  uint32_t* gidx;                                 // [n_entries] read index of an entry (error reports)
-  int64_t gdesc_capacity;                         // entries gdesc can hold (0 on the sizing run at batch creation)
-  int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
-  int32_t sorted;                                 // the batch's first pass found every contig's reads in position order
-  int32_t reach;                                  // the longest read of the batch: no class-0 read spans more sites
-  int64_t n_general_hint;                         // general reads found by the batch's first pass (sizes the fill kernel's grid)
-  DirectFacts* facts;                             // [kDirectFactSlots]
-  DirectTotals* totals;
+  int32_t sorted;                                 // the facts pass found every contig's reads in position order
+  int32_t reach;                                  // the longest reference span of the batch's reads: no read touches a site further from its start
+  DirectFacts* facts;                             // [kDirectFactSlots] (facts pass only)
   unsigned long long* stats; unsigned long long* err;
   int32_t n_stat_words;
 };
 
 struct DirectParams {
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
   const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
-  const uint8_t* rec;                             // index records, written by the classify kernel
-  const uint32_t* tbegin; const uint32_t* tend; const uint32_t* goff; const uint32_t* gdesc; const uint32_t* gidx;
-  int64_t gdesc_capacity;                         // entries; the sentinel descriptor sits behind them
+  const uint32_t* tbegin; const uint32_t* tend;
   const uint8_t* ref;
   const Tile* tiles;
   const FilterTables* filt;
   uint32_t* out_counts; uint8_t* out_allele;
   unsigned long long* stats; unsigned long long* err;
   uint32_t* sched;                                // kSchedWords: {8 item counters, workgroups done}
+  unsigned long long* probe;                      // developer builds (MIDAS_SNPS_DEBUG_BITS & 256): per-wave cycle counts
   int32_t n_tiles, n_reads, grid_blocks;
   int32_t lanes_per_read, reads_per_wave, table_len;
   int32_t baseq, mapq_min, readq;
@@ -274,7 +246,8 @@ struct PayloadParams {
 };
 hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s);    // 1: decode, 2: resolve the matches
 
-hipError_t launch_direct_index(const DirectIndexParams& p, hipStream_t s);       // classify + scan + fill
+hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s);       // once per batch: validation, totals
+hipError_t launch_direct_ranges(const DirectIndexParams& p, hipStream_t s);      // every pass: the tile ranges, from the positions
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);
 int direct_index_blocks(int64_t n_reads);

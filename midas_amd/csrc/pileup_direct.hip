@@ -1,5 +1,6 @@
 // gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM-native arrays themselves: 4-bit SEQ, QUAL, CIGAR and
-// the per-read columns where the decoder put them -- no packed payload, no sort, one pass per read.  Integer counting: no MFMA.
+// the per-read columns where the decoder put them -- no packed payload, no sort, no per-read record, ONE visit per read.
+// Integer counting: no MFMA.
 //
 // Reference semantics implemented here (citations into /root/reference):
 //   keep_read                       midas/run/snps.py:141-162  (query_alignment_sequence :145, np.mean(query_qualities) :151)
@@ -7,20 +8,24 @@
 //                                   only 'A','C','G','T' counted)
 //   depth / covered / total_depth   midas/run/snps.py:204-213
 //   str(rec.seq).upper()            midas/run/snps.py:62
+// The reference filters and counts a read in one pass (keep_read inside count_coverage's iterator); so does this kernel.
 //
 // Work decomposition: as in pileup_tiles.hip -- tiles of <= 4096 sites, a persistent 512-thread workgroup per item, tallies
-// in LDS as [site][A,C,G,T] u32, one coalesced write-out per tile, items handed out by per-XCD counters.  What differs is
-// where a tile's reads come from and what a lane does with them:
+// in LDS as [site][A,C,G,T] u32, one coalesced write-out per tile, items handed out by per-XCD counters.
 //
-// Stream.  The index pass (index_direct.hip) left, per tile, the range [tbegin, tend) of read indices holding every class-0
-// read (one gap-free match segment) that touches the tile -- the input is position-sorted, so that is a contiguous run of
-// the read arrays -- and a list of 48-byte descriptors of the general reads touching it.  Both are dealt to the waves as
-// ONE virtual stream, range first: the leading wave-iterations are pure class 0 and branch over the CIGAR walk.
+// Stream.  The ranges pass (index_direct.hip, 4 bytes per read) left, per tile, the run [tbegin, tend) of read indices that
+// can touch the tile -- the input is position-sorted, so that is a contiguous run of the read arrays.  It is dealt to the
+// workgroup's waves as wave-iterations of floor(64 / lanes per read) reads.
 //
 // Lane mapping.  A lane owns LB (30 or 32) consecutive bases of a read's STORED query: two 16-byte loads of QUAL, one of
 // 4-bit SEQ (LB is even, so a lane's bases start on a byte).  A read of l_seq bases takes ceil(l_seq / LB) adjacent lanes
-// (5 for 150 bp) and a wave works on floor(64 / lanes) reads at a time.  Loads are issued two iterations (per-read columns)
-// and one iteration (bases) ahead of their use.
+// (5 for 150 bp).  Loads are issued two iterations (the read's columns: pos, l_seq, NM, mapq, SEQ / QUAL / CIGAR offsets)
+// and one iteration (bases + the first four CIGAR ops) ahead of their use; none of them sits in a branch.
+//
+// Per read.  The lanes of a read decide in registers what its CIGAR is: ONE or TWO gap-free match runs (direct_common.h
+// ReadShape: clips, at most one insertion / deletion / skip -- what an aligner writes for nearly every read) are tallied
+// straight from the shape, the lane that holds the indel in a second masked pass; anything else (several indels, pads, odd
+// clips, no NM / SEQ, a start off the contig) is walked op by op where it lies, the slow path.
 //
 // Per base, from the raw bytes:  the 4-bit codes of eight bases (one dword) are split into their even and odd nibbles
 // (two masks), mapped to v_perm_b32 selectors by `(n + 7) ^ 8` -- A, C, G, T (1, 2, 4, 8) land on table slots 0, 1, 3, 7,
@@ -132,15 +137,33 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
   }
 }
 
-// The per-tile stream: the index records rb .. rb + n0 (class 0; a general read in the range is skipped there), then the
-// tile's general descriptors gb .. gb + ng -- as wave-iterations: na of the first kind, then ng_it of the second.
-struct Stream { int rb, n0, gb, ng, na, total; };
+// The per-tile stream: the reads rb .. rb + n0 of the read arrays, as `total` wave-iterations.
+struct Stream { int rb, n0, total; };
+
+// Workgroup shape and prefetch depth (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384 -DMIDAS_DIRECT_DEPTH=2).
+//   DEPTH = iterations a wave's base loads run ahead of their use (the read's columns one more).  While a wave tallies --
+//   LDS atomics, which the sixteen waves of a CU queue up for -- only what it requested beforehand keeps the memory pipe busy.
+#ifndef MIDAS_DIRECT_BLOCK
+#define MIDAS_DIRECT_BLOCK 512
+#endif
+#ifndef MIDAS_DIRECT_DEPTH
+#define MIDAS_DIRECT_DEPTH 1
+#endif
+constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
+constexpr int kDirectDepth = MIDAS_DIRECT_DEPTH;
+static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
+static_assert(kDirectDepth == 1 || kDirectDepth == 2, "one or two iterations ahead");
+constexpr int kDirectWavesPerSimd = (2 * kDirectBlock / 64 + 3) / 4;      // two workgroups per CU
+
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
 template <int LB, bool BQ0>
-__global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectParams p) {
+__global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
   constexpr int TILE = kTileSites;
-  constexpr int NWAVES = kPileupBlock / 64;
-  constexpr int OUT_IT = TILE / kPileupBlock;
+  constexpr int NWAVES = kDirectBlock / 64;
+  constexpr int DEPTH = kDirectDepth;
+  constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_mhi[33 * 8];   // [h][w]: 0xFF in the bytes of the bases j >= h
   __shared__ __attribute__((aligned(16))) uint32_t s_mlo[33 * 8];   // [l][w]: 0xFF in the bytes of the bases j <  l
@@ -159,15 +182,22 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   int w = (int)blockIdx.x;
   if (w >= w_end) return;
   int w_next = w + (int)gridDim.x;
+#if MIDAS_SNPS_DEBUG_BITS & 256
+  unsigned long long pr_cols = 0, pr_bases = 0, pr_work = 0, pr_sync = 0, pr_out = 0, pr_iters = 0;
+  const unsigned long long pr_t0 = __builtin_readcyclecounter();
+#define PROBE_NOW() __builtin_readcyclecounter()
+#else
+#define PROBE_NOW() 0ull
+#endif
 
   {
     uint4* z = reinterpret_cast<uint4*>(lds);
-    for (int i = tid; i < TILE; i += kPileupBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < p.table_len; i += kPileupBlock) {
+    for (int i = tid; i < TILE; i += kDirectBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < p.table_len; i += kDirectBlock) {
       s_tables[i] = p.filt->min_match[i];
       s_tables[p.table_len + i] = p.filt->min_align[i];
     }
-    for (int i = tid; i < 33 * 8; i += kPileupBlock) {
+    for (int i = tid; i < 33 * 8; i += kDirectBlock) {
       const int h = i >> 3, wd = i & 7;
       uint32_t mh = 0, ml = 0;
       for (int b = 0; b < 4; ++b) {
@@ -186,7 +216,6 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const int rpw = p.reads_per_wave;
   const int g = lane / lpr;
   const int c = lane - g * lpr;
-  const bool lane_used = g < rpw;
   const int q0 = c * LB;                           // first base of the lane in the read's stored query
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
   const uint32_t qsum_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_qsum + wave * 64 + g);
@@ -200,17 +229,18 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
   const ConstWords c_te = (ConstWords)(size_t)p.tend;
-  const ConstWords c_go = (ConstWords)(size_t)p.goff;
   auto load_stream = [&](int tt) -> Stream {
     Stream s;
-    const uint32_t b = c_tb[tt], e = c_te[tt], g0 = c_go[tt], g1 = c_go[tt + 1];
+    const uint32_t b = c_tb[tt], e = c_te[tt];
     s.rb = e > b ? (int)b : 0;
     s.n0 = e > b ? (int)(e - b) : 0;
-    s.gb = (int)g0;
-    s.ng = (int)(g1 - g0);
-    s.na = (s.n0 + rpw - 1) / rpw;
-    s.total = s.na + (s.ng + rpw - 1) / rpw;
+    s.total = (s.n0 + rpw - 1) / rpw;
     return s;
+  };
+  // reads of a stream's wave-iteration `it` (wave-uniform): the lanes with g below it hold one
+  auto reads_in = [&](const Stream& st, int it) -> int {
+    const long long left = (long long)st.n0 - (long long)it * rpw;
+    return left <= 0 ? 0 : (left < rpw ? (int)left : rpw);
   };
 
   // Sum of a read's quality bytes over its lanes (np.mean(aln.query_qualities), midas/run/snps.py:151): every lane adds its
@@ -240,14 +270,23 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
   // other code a slot or a selector constant that reads 0xFF.
   // The lanes `go` tally bases [lo, hi) of their 30 / 32, the first of the lane at tile-relative site loc0.  Group by group
   // (decode eight bases, tally them), so that only one group's looked-up bytes are alive at a time.
-  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4]) {
+  // (sparse: a pass with few lanes, e.g. the one lane of a read that holds its indel -- a group of eight bases none of the
+  // wave's lanes has a base in is skipped)
+  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4], auto sparse_tag) {
+    constexpr bool SPARSE = decltype(sparse_tag)::value;
     const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
-    const bool masked = __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
+    const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
+    unsigned long long gmask[4];
+    if (SPARSE) {
+#pragma unroll
+      for (int S = 0; S < 4; ++S) gmask[S] = __ballot(go && lo < 8 * S + 8 && hi > 8 * S);
+    }
     if (!go) return;                                                    // outside [lo, hi) (a row of each table, LDS)
     const uint32_t* mh = s_mhi + 8 * (hi > 32 ? 32 : hi);
     const uint32_t* ml = s_mlo + 8 * (lo < 0 ? 0 : lo);
     auto group = [&](auto sidx, auto off, auto nbases) {
       constexpr int S = decltype(sidx)::value;
+      if (SPARSE && gmask[S] == 0ull) return;
       const uint32_t x = sq[S];
       const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
       const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
@@ -267,75 +306,78 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
   };
 
-  // ---- stage F: the record / descriptor of this lane's read in wave-iteration `it` of a tile's stream.  Raw loads: nothing is
-  // computed from them here, and NO load sits in a branch -- a lane without a read fetches the sentinel record, a lane
-  // without bases the first bytes of the arrays -- so that the compiler can count the loads in flight (a load in a branch
-  // makes it wait for every outstanding load, vmcnt(0), before the first use of any of them: the prefetch of the next
-  // iteration's bases would be waited for at once).
-  struct Raw { uint4 a, b; };
-  const uint8_t* const gd_base = reinterpret_cast<const uint8_t*>(p.gdesc);
-  const uint8_t* const idle_rec = p.rec + (size_t)p.n_reads * kIdxRecBytes;       // the two sentinels
-  const uint8_t* const idle_gd = gd_base + (size_t)p.gdesc_capacity * (kGenDescWords * 4);
+  // ---- stage F: the columns of this lane's read in wave-iteration `it` of a tile's stream.  Raw loads: nothing is computed
+  // from them here, and NO load sits in a branch -- a lane without a read fetches read 0's columns, a lane without bases the
+  // first bytes of the arrays -- so that the compiler can count the loads in flight (a load in a branch makes it wait for
+  // every outstanding load, vmcnt(0), before the first use of any of them: the prefetch of the next iteration's bases would
+  // be waited for at once).
+  struct Raw { uint32_t pos, l, nm, mapq, so_lo, so_hi, qo_lo, qo_hi, co_lo, co_hi, co1_lo; };
   auto fetch = [&](const Stream& st, int it) -> Raw {
-    const bool gen = it >= st.na;                                   // (wave-uniform)
-    const int v = (gen ? it - st.na : it) * rpw + g;
-    const bool act = lane_used && it < st.total && v < (gen ? st.ng : st.n0);
-    const uint8_t* src = gen ? gd_base + (size_t)(uint32_t)(st.gb + v) * (kGenDescWords * 4) : p.rec + (size_t)(uint32_t)(st.rb + v) * kIdxRecBytes;
-    src = act ? src : (gen ? idle_gd : idle_rec);
+    const long long v = (long long)it * rpw + g;
+    const size_t r = v < (long long)st.n0 ? (size_t)((long long)st.rb + v) : (size_t)0;
     Raw f;
-    const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src);
-    const u32x4_a4 b = *reinterpret_cast<const u32x4_a4*>(src + 16);      // (of a 20-byte record: its last word and the next record's head)
-    f.a = make_uint4(a.x, a.y, a.z, a.w);
-    f.b = make_uint4(b.x, b.y, b.z, b.w);
+    f.pos = (uint32_t)p.pos[r];
+    f.l = (uint32_t)p.l_seq[r];
+    f.nm = (uint32_t)p.nm[r];
+    f.mapq = p.mapq[r];
+    const u32x2_a8 so = *reinterpret_cast<const u32x2_a8*>(p.seq_off + r);
+    const u32x2_a8 qo = *reinterpret_cast<const u32x2_a8*>(p.qual_off + r);
+    const u32x3_a4 co = *reinterpret_cast<const u32x3_a4*>(p.cigar_off + r);      // cigar_off[r] and the low word of cigar_off[r + 1]
+    f.so_lo = so.x; f.so_hi = so.y; f.qo_lo = qo.x; f.qo_hi = qo.y; f.co_lo = co.x; f.co_hi = co.y; f.co1_lo = co.z;
     return f;
   };
-  // ---- stage D: what the read's processing needs of its record, and the lane's bases (two 16-byte loads of QUAL, one of SEQ)
-  //   a: class 0 the info word; general: aligned length | leading clip << 11 | CIGAR offset bits 32-39 << 22
-  //   nmq: NM | mapq << 16 | kGen* flags << 24 (kGenIdle: nothing to do)        l_nc: l_seq | n_cigar << 16
-  struct Rd { uint32_t a, pos, nmq, l_nc, co_lo; };
-  struct Dat { uint32_t q[8]; uint32_t s[4]; };
-  auto settle = [&](const Raw& f, bool gen, Rd& r, Dat& d) {
-    unsigned long long so, qo;
-    int l;
-    r.a = f.a.x; r.pos = f.a.y;
-    if (!gen) {       // (wave-uniform; no load in here)
-      const bool act = !(f.a.x >> 31);
-      l = (int)((f.a.x & 1023u) + ((f.a.x >> kInfoAlenShift) & 2047u) + ((f.a.x >> kInfoTrailShift) & 1023u));
-      l = act ? l : 0;
-      r.nmq = (f.a.w & 2047u) | (((f.a.w >> 11) & 0xFFu) << 16) | (act ? 0u : (uint32_t)kGenIdle << 24);
-      r.l_nc = (uint32_t)l;
-      r.co_lo = 0u;
-      qo = (unsigned long long)f.a.z | ((unsigned long long)((f.a.w >> 19) & 0xFFu) << 32);
-      so = (unsigned long long)f.b.x | ((unsigned long long)(f.a.w >> 27) << 32);
-    } else {
-      l = (int)(f.b.w & 0xFFFFu);                                    // (0 in the sentinel)
-      r.nmq = (f.a.z & 0x00FFFFFFu) | (((f.b.y >> 8) & 0xFFu) << 24);
-      r.l_nc = f.b.w;
-      r.co_lo = f.b.z;
-      qo = (unsigned long long)f.b.x | ((unsigned long long)(f.b.y & 0xFFu) << 32);
-      so = (unsigned long long)f.a.w | ((unsigned long long)(f.a.z >> 24) << 32);
-    }
-    const bool has = q0 < l && !(kDebug & 128);
+  // ---- stage D: what the read's processing needs of its columns, and the lane's bases (two 16-byte loads of QUAL, one of
+  // SEQ) + the read's first four CIGAR ops (one 16-byte load; the array has slack behind its last op)
+  //   nmq: NM (16 bits, 0xFFFF = no NM tag) | mapq << 16 | kGenIdle << 24 (a lane without a read)      l_nc: l_seq | n_cigar << 16
+  struct Rd { uint32_t pos, nmq, l_nc; };
+  struct Dat { uint32_t q[8]; uint32_t s[4]; uint32_t cg[4]; };
+  auto settle = [&](const Raw& f, int n_reads_it, Rd& r, Dat& d) {
+    const bool act = g < n_reads_it;
+    const uint32_t l = act ? f.l : 0u;
+    const uint32_t nc = act ? f.co1_lo - f.co_lo : 0u;          // (<= 65534, checked when the batch was made)
+    r.pos = f.pos;
+    r.l_nc = l | (nc << 16);
+    r.nmq = ((int32_t)f.nm < 0 ? 0xFFFFu : f.nm) | ((f.mapq & 0xFFu) << 16) | (act ? 0u : (uint32_t)kGenIdle << 24);
+    const unsigned long long so = (unsigned long long)f.so_lo | ((unsigned long long)f.so_hi << 32);
+    const unsigned long long qo = (unsigned long long)f.qo_lo | ((unsigned long long)f.qo_hi << 32);
+    const unsigned long long co = (unsigned long long)f.co_lo | ((unsigned long long)f.co_hi << 32);
+    const bool has = q0 < (int)l && !(kDebug & 128);
     const uint8_t* qp = p.qual + (has ? qo + (unsigned long long)q0 : 0ull);
     const uint8_t* sp = p.seq4 + (has ? so + (unsigned long long)(q0 >> 1) : 0ull);
+    const uint32_t* cp = p.cigar + (act && !(kDebug & 128) ? co : 0ull);
     const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
     const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
     const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
+    const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cp);
     d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
     d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
     d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
+    d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
   };
 
   Tile tile = load_tile(c_tiles, w);
   Stream st = load_stream(w);
-  Raw raw_n = fetch(st, wave + NWAVES);
-  bool gen_n = wave + NWAVES >= st.na;       // kind of the iteration raw_n belongs to (wave-uniform)
-  Rd rd_cur;
-  Dat dat_cur;
-  {
-    const Raw raw_c = fetch(st, wave);
-    settle(raw_c, wave >= st.na, rd_cur, dat_cur);
-  }
+  // the pipeline of a wave: cur (being tallied), with DEPTH == 2 ahead1 (bases requested one iteration ago), raw_n: the
+  // columns of the iteration DEPTH + 1 ahead of cur's -- its bases are requested at the top of the next loop body
+  Raw raw_n;
+  int nr_n;                                     // reads of the iteration raw_n belongs to (wave-uniform)
+  Rd rd_cur, rd_a1;
+  Dat dat_cur, dat_a1;
+  auto prime = [&](const Stream& s0) {
+    const Raw r0 = fetch(s0, wave);
+    const Raw r1 = fetch(s0, wave + NWAVES);
+    if (DEPTH == 2) {
+      raw_n = fetch(s0, wave + 2 * NWAVES);
+      nr_n = reads_in(s0, wave + 2 * NWAVES);
+      settle(r0, reads_in(s0, wave), rd_cur, dat_cur);
+      settle(r1, reads_in(s0, wave + NWAVES), rd_a1, dat_a1);
+    } else {
+      settle(r0, reads_in(s0, wave), rd_cur, dat_cur);
+      raw_n = r1;
+      nr_n = reads_in(s0, wave + NWAVES);
+    }
+  };
+  prime(st);
   __syncthreads();   // LDS zeroed, tables in place
 
   uint32_t acc_cov = 0u;                 // (a thread's sites between two flushes: far below 2^32)
@@ -346,133 +388,179 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     const int tile_start = tile.start;
     const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
-    constexpr int REF_IT = TILE / (4 * kPileupBlock);
+    constexpr int REF_IT = (TILE + 4 * kDirectBlock - 1) / (4 * kDirectBlock);
 
-    // the record / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
-    // the records of its first two iterations of the NEXT tile
+    // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last DEPTH + 1 iterations
+    // fetch the columns of its first DEPTH + 1 iterations of the NEXT tile
     const int n_w = it_hi > wave ? (it_hi - wave + NWAVES - 1) / NWAVES : 0;
-    const bool xt = w_next < w_end && n_w >= 2;
+    const bool xt = w_next < w_end && n_w >= DEPTH + 1;
     Stream xs = st;
     if (xt) xs = load_stream(w_next);
-    for (int it = wave; it < it_hi; it += NWAVES) {
+    int k_it = 0;                               // the wave's k-th iteration of this tile
+    for (int it = wave; it < it_hi; it += NWAVES, ++k_it) {
+      const unsigned long long pt0 = PROBE_NOW();
       Rd rd_n;
       Dat dat_n;
-      settle(raw_n, gen_n, rd_n, dat_n);       // (the record of the next iteration has arrived: its bases are requested ...)
-      {                                        // ... then the record of the one after it
-        const bool over = xt && it + 2 * NWAVES >= it_hi;
+      settle(raw_n, nr_n, rd_n, dat_n);        // (the columns of the iteration DEPTH ahead have arrived: its bases are requested ...)
+      {                                        // ... then the columns of the one after it
+        const int kf = k_it + DEPTH + 1;       // the wave's iteration (of this tile, or counted on into the next) to fetch for
+        const bool over = xt && kf >= n_w;
         Stream fs;
-        fs.rb = over ? xs.rb : st.rb; fs.n0 = over ? xs.n0 : st.n0; fs.gb = over ? xs.gb : st.gb; fs.ng = over ? xs.ng : st.ng;
-        fs.na = over ? xs.na : st.na; fs.total = over ? xs.total : st.total;
-        const int fi = over ? ((it + NWAVES < it_hi) ? wave : wave + NWAVES) : it + 2 * NWAVES;
+        fs.rb = over ? xs.rb : st.rb; fs.n0 = over ? xs.n0 : st.n0; fs.total = over ? xs.total : st.total;
+        const int fi = wave + (over ? kf - n_w : kf) * NWAVES;
         raw_n = fetch(fs, fi);
-        gen_n = fi >= fs.na;
+        nr_n = reads_in(fs, fi);
       }
-      const bool gen_cur = it >= st.na;        // (wave-uniform) a general-descriptor iteration
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      asm volatile("" :: "v"(rd_n.pos), "v"(rd_n.l_nc));
+      const unsigned long long pt1 = PROBE_NOW();
+      asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[3]));
+      const unsigned long long pt2 = PROBE_NOW();
+      pr_cols += pt1 - pt0; pr_bases += pt2 - pt1; pr_iters += 1;
+#endif
 
       if (kDebug & 4) {          // (developer timing variant: the stream of loads only)
-        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(rd_cur.a));
-        rd_cur = rd_n; dat_cur = dat_n;
+        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[0]), "v"(rd_cur.pos));
+        if (DEPTH == 2) { rd_cur = rd_a1; dat_cur = dat_a1; rd_a1 = rd_n; dat_a1 = dat_n; } else { rd_cur = rd_n; dat_cur = dat_n; }
         continue;
       }
       const int pos = (int)rd_cur.pos;
       const int l = (int)(rd_cur.l_nc & 0xFFFFu);
+      const uint32_t nc = rd_cur.l_nc >> 16;
       const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
       const bool has = nb > 0;
-      uint32_t qsum = read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
+      uint32_t qsum = (kDebug & 64) ? 0x00FFFFFFu : read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
       const bool t_noqual = (qsum >> 31) != 0u;
       qsum &= 0x7FFFFFFFu;
-      const int nm = (int)(rd_cur.nmq & 0xFFFFu), mapq = (int)((rd_cur.nmq >> 16) & 0xFFu);
+      const uint32_t nm16 = rd_cur.nmq & 0xFFFFu;
+      const int nm = (int)nm16, mapq = (int)((rd_cur.nmq >> 16) & 0xFFu);
+      const bool act = !((rd_cur.nmq >> 24) & kGenIdle);
       uint32_t qv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
+
+      // ---- the read's shape, in registers: one match op of the read's length settles most reads; anything else takes the
+      // four-op grammar (wave-uniform branch) ------------------------------------------------------------------------------
+      ReadShape sh;
+      sh.lead = 0u; sh.m1 = (uint32_t)l; sh.ins = 0u; sh.del = 0u; sh.alen = (uint32_t)l;
+      bool shaped = nc == 1u && op_is_match(dat_cur.cg[0] & 15u) && (dat_cur.cg[0] >> 4) == (uint32_t)l && l >= 1;
+      if (__ballot(act && !shaped) != 0ull) {
+        ReadShape s2;
+        const bool ok = decode_shape(dat_cur.cg[0], dat_cur.cg[1], dat_cur.cg[2], dat_cur.cg[3], nc, (uint32_t)l, &s2);
+        if (!shaped) { sh = s2; shaped = ok; }
+      }
+      // one or two match runs, NM present, the start inside the contig: the fast path.  Everything else is walked.
+      const bool fast = act && shaped && nm16 != 0xFFFFu && pos >= 0 && pos < tile.contig_len;
+      const bool slow = act && !fast;
+
+      // ======================= fast: one or two gap-free match runs ==========================================================
+      const int lead = (int)sh.lead, align_len = (int)sh.alen;
       bool keep, owner;
       uint32_t err;
-      if (!gen_cur) {
-        // ======================= class 0: one gap-free match segment ============================================================
-        const bool act = !((rd_cur.nmq >> 24) & kGenIdle);
-        const int lead = (int)(rd_cur.a & 1023u);
-        const int align_len = (int)((rd_cur.a >> kInfoAlenShift) & 2047u);
-        // ---- keep_read (midas/run/snps.py:141-162): a class-0 read has SEQ, NM and a non-empty aligned part -----------------
+      {
+        // ---- keep_read (midas/run/snps.py:141-162): such a read has SEQ, NM and a non-empty aligned part -----------------------
         const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
         const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
         const bool t_pid = align_len - nm < min_match;                                                       // pid < mapid
         const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);             // readq, mapq, aln_cov
-        err = (act && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
-        keep = act && !(t_pid | t_noqual | t_drop);
+        err = (fast && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
+        keep = fast && !(t_pid | t_noqual | t_drop);
         const int rel = pos - tile_start;            // 0 <= pos < contig length: no wrap
-        owner = act && rel >= 0 && rel < tile_len;
-        // the segment: query [lead, lead + align_len) at sites pos ...; this lane's part of it, clipped to the tile
-        const int loc0 = rel + (q0 - lead);
-        int lo = lead - q0;
-        lo = lo > -loc0 ? lo : -loc0;
-        lo = lo > 0 ? lo : 0;
-        int hi = lead + align_len - q0;
-        hi = hi < tile_len - loc0 ? hi : tile_len - loc0;
-        hi = hi < nb ? hi : nb;
-        const bool go = keep && lo < hi;
-        if (!(kDebug & 1) && __ballot(go) != 0ull) tally_range(go, lo, hi, loc0, qv, dat_cur.s);
-      } else {
-        // ======================= general reads: descriptors, walked op by op =================================================
-        const uint32_t gflags = rd_cur.nmq >> 24;
-        const bool act = !(gflags & kGenIdle);
-        const int nc = (int)(rd_cur.l_nc >> 16);
-        const int align_len = (int)(rd_cur.a & 2047u);
-        const uint32_t* cig = p.cigar + ((size_t)rd_cur.co_lo | ((size_t)((rd_cur.a >> 22) & 0xFFu) << 32));
-        // A read with ONE indel between two match runs (kGenInline) carries its geometry in the descriptor: no CIGAR is fetched
-        // for it.  For anything else the first four ops come with one 16-byte load, issued here and first needed behind the
-        // filter (not prefetched: it would cost eight registers of the double-buffered bases).
-        const bool inl = (gflags & kGenInline) != 0u;
-        uint32_t cg0 = 0u, cg1 = 0u, cg2 = 0u, cg3 = 0u;
-        if (act && nc > 0 && !inl) {
-          const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cig);   // (may overhang into the array's slack)
-          cg0 = cv.x; cg1 = cv.y; cg2 = cv.z; cg3 = cv.w;
+        owner = fast && rel >= 0 && rel < tile_len;
+        // run A: query [lead, lead + m1) at sites pos ...; run B: query [lead + m1 + ins, lead + alen) at pos + m1 + del ...
+        // -- this lane's part of each, clipped to the tile
+        const int qa1 = lead + (int)sh.m1, qb0 = qa1 + (int)sh.ins, qb1 = lead + align_len;
+        const int loc_a = rel + (q0 - lead);
+        const int loc_b = loc_a + (int)sh.del - (int)sh.ins;
+        int lo_a = lead - q0, hi_a = qa1 - q0, lo_b = qb0 - q0, hi_b = qb1 - q0;
+        lo_a = lo_a > -loc_a ? lo_a : -loc_a;
+        lo_a = lo_a > 0 ? lo_a : 0;
+        hi_a = hi_a < tile_len - loc_a ? hi_a : tile_len - loc_a;
+        hi_a = hi_a < nb ? hi_a : nb;
+        lo_b = lo_b > -loc_b ? lo_b : -loc_b;
+        lo_b = lo_b > 0 ? lo_b : 0;
+        hi_b = hi_b < tile_len - loc_b ? hi_b : tile_len - loc_b;
+        hi_b = hi_b < nb ? hi_b : nb;
+        const bool go_a = keep && lo_a < hi_a, go_b = keep && lo_b < hi_b;
+        // first pass: every lane its run (the lane that holds the indel: the part in front of it); second pass, only when a
+        // lane of the wave has bases on both sides of an indel: the part behind it
+        const bool go1 = go_a | go_b;
+        if (!(kDebug & 1) && __ballot(go1) != 0ull)
+          tally_range(go1, go_a ? lo_a : lo_b, go_a ? hi_a : hi_b, go_a ? loc_a : loc_b, qv, dat_cur.s, std::false_type{});
+        const bool go2 = go_a & go_b;
+        if (!(kDebug & (1 | 16)) && __ballot(go2) != 0ull) tally_range(go2, lo_b, hi_b, loc_b, qv, dat_cur.s, std::true_type{});
+      }
+      // ======================= slow: walked op by op ============================================================================
+      if (__ballot(slow) != 0ull) {
+        const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
+        CigarView cg;
+        cg.c0 = dat_cur.cg[0]; cg.c1 = dat_cur.cg[1]; cg.c2 = dat_cur.cg[2]; cg.c3 = dat_cur.cg[3];
+        cg.p = p.cigar;
+        if (slow && nc > 4u) cg.p = p.cigar + p.cigar_off[idx];      // (only a CIGAR of more than four ops is read again)
+        const uint32_t ncs = slow ? nc : 0u;
+        // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
+        long long qs = 0, qe = 0;
+        query_bounds(cg, ncs, l, &qs, &qe);
+        long long al = qe - qs;
+        al = al < 0 ? 0 : (al > 2047 ? 2047 : al);      // (l_seq <= 1024)
+        const int align_g = (int)al;
+        // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position >= l_seq
+        // onto a site inside the contig
+        bool t_over = false;
+        {
+          long long qpos = 0, rpos = pos;
+          const long long clen = tile.contig_len;
+          for_each_op(cg, ncs, [&](uint32_t, uint32_t v) {
+            const uint32_t op = v & 15u;
+            const long long len = (long long)(v >> 4);
+            if (op_is_match(op)) {
+              if (qpos + len > (long long)l) {
+                const long long qs2 = qpos > (long long)l ? qpos : (long long)l;
+                const long long rs = rpos + (qs2 - qpos), re = rpos + len;
+                if (rs < clen && re > 0) t_over = true;
+              }
+              qpos += len;
+              rpos += len;
+            } else if (op == OP_I || op == OP_S || (op == OP_P && p.pad_advances)) {
+              qpos += len;
+            } else if (op == OP_D || op == OP_N) {
+              rpos += len;
+            }
+            return true;
+          });
         }
         // ---- keep_read, every test evaluated, the reference's order decides which outcome wins ---------------------------
-        const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+        const int min_match = s_tables[align_g < p.table_len ? align_g : 0];
         const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
         const bool t_noseq = l == 0;
-        const bool t_nonm = (gflags & kGenNoNm) != 0u;
-        const bool t_zero = align_len == 0;
-        const bool t_pid = align_len - nm < min_match;
-        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);
-        const bool t_over = (gflags & kGenOverrun) != 0u;
-        err = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
-        err = t_drop ? 0u : err;
-        err = t_noqual ? (uint32_t)E_NO_QUAL : err;
-        err = t_pid ? 0u : err;
-        err = t_zero ? (uint32_t)E_ZERO_ALIGN : err;
-        err = t_nonm ? (uint32_t)E_NO_NM : err;
-        err = t_noseq ? (uint32_t)E_NO_SEQ : err;
-        err = act ? err : 0u;
-        keep = act && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
+        const bool t_nonm = nm16 == 0xFFFFu;
+        const bool t_zero = align_g == 0;
+        const bool t_pid = align_g - nm < min_match;
+        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_g < min_align);
+        uint32_t e = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
+        e = t_drop ? 0u : e;
+        e = t_noqual ? (uint32_t)E_NO_QUAL : e;
+        e = t_pid ? 0u : e;
+        e = t_zero ? (uint32_t)E_ZERO_ALIGN : e;
+        e = t_nonm ? (uint32_t)E_NO_NM : e;
+        e = t_noseq ? (uint32_t)E_NO_SEQ : e;
+        const bool keep_s = slow && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
         // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
         int cpos = pos < 0 ? 0 : pos;
         cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
-        owner = act && cpos >= tile_start && cpos < tile_start + tile_len && !(tile.halo && pos < 0);
+        const bool owner_s = slow && cpos >= tile_start && cpos < tile_start + tile_len && !(tile.halo && pos < 0);
+        if (slow) { err = e; keep = keep_s; owner = owner_s; }
         const int rel = pos - tile_start;                                     // may wrap for absurd positions:
         int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // those are parked far right
         // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time ------------------------
         // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative reference
         // position only below 4096, and both only ever grow.
-        int k = 0, qpos = 0, jlo = 0, jhi = 0, loc0 = 0;
+        uint32_t k = 0;
+        int qpos = 0, jlo = 0, jhi = 0, loc0 = 0;
         const int q1 = q0 + nb;
-        const int lead_g = (int)((rd_cur.a >> 11) & 2047u);
-        const int in_m1 = (int)(rd_cur.co_lo & 1023u), in_ins = (int)((rd_cur.co_lo >> 10) & 1023u), in_del = (int)(rd_cur.co_lo >> 20);
         auto next_segment = [&]() -> bool {
-          if (inl) {       // the two runs: query [lead, lead + m1) at pos ..., query [lead + m1 + ins, lead + alen) at pos + m1 + del ...
-            while (k < 2) {
-              const int qa = k == 0 ? lead_g : lead_g + in_m1 + in_ins;
-              const int qb = k == 0 ? lead_g + in_m1 : lead_g + align_len;
-              const int roff = k == 0 ? 0 : in_m1 + in_del;
-              ++k;
-              const int lo = qa > q0 ? qa : q0;
-              const int hi = qb < q1 ? qb : q1;
-              if (lo < hi) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + roff + (q0 - qa); return true; }
-            }
-            return false;
-          }
           while (k < nc) {
-            const uint32_t v = k < 4 ? (k == 0 ? cg0 : (k == 1 ? cg1 : (k == 2 ? cg2 : cg3))) : cig[k];
+            const uint32_t v = cg[k];
             ++k;
             const uint32_t op = v & 15u;
             const int len = (int)(v >> 4);
@@ -490,13 +578,13 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
           }
           return false;
         };
-        bool walking = keep && has;
+        bool walking = keep_s && has;
         if (walking) walking = next_segment();
         while (__ballot(walking) != 0ull) {
           const int lo = jlo > -loc0 ? jlo : -loc0;
           const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
-          tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s);
-          walking = (walking && k < (inl ? 2 : nc)) ? next_segment() : false;
+          if (!(kDebug & 1)) tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s, std::true_type{});
+          walking = (walking && k < nc) ? next_segment() : false;
         }
       }
       // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
@@ -505,14 +593,16 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       w_mapped += (uint32_t)__popcll(__ballot(head && keep));
       // (a read of the piece in front, midas_snps_contigs.origin: its own piece reports what keep_read raises, this one the
       // overrun its walk runs into here)
-      const bool walk_err = gen_cur && tile.halo && pos < 0 && c == 0 && err == (uint32_t)E_CIGAR_OVERRUN;
-      if ((head && err) || walk_err) {     // (the read's index: its place in the range, or the entry's word of gidx)
-        const uint32_t idx = gen_cur ? p.gidx[(size_t)(st.gb + (it - st.na) * rpw + g)] : (uint32_t)(st.rb + it * rpw + g);
+      const bool walk_err = slow && tile.halo && pos < 0 && c == 0 && err == (uint32_t)E_CIGAR_OVERRUN;
+      if ((head && err) || walk_err) {
+        const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
         atomicMin(p.err, ((unsigned long long)idx << 8) | err);
       }
 
-      rd_cur = rd_n;
-      dat_cur = dat_n;
+      if (DEPTH == 2) { rd_cur = rd_a1; dat_cur = dat_a1; rd_a1 = rd_n; dat_a1 = dat_n; } else { rd_cur = rd_n; dat_cur = dat_n; }
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      pr_work += PROBE_NOW() - pt2;
+#endif
     }
 
     // the tile's reference letters: requested here, behind the stream loop (two registers less in it), they arrive while
@@ -522,7 +612,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       const uint8_t* ref = p.ref + tile.site_base;
 #pragma unroll
       for (int it = 0; it < REF_IT; ++it) {
-        const int i = 4 * (tid + it * kPileupBlock);
+        const int i = 4 * (tid + it * kDirectBlock);
         if (i + 4 <= tile_len) refw[it] = *reinterpret_cast<const u32_a1*>(ref + i);
       }
     }
@@ -536,14 +626,27 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     const int tn = more ? wn : t;
     const Tile ntile = load_tile(c_tiles, tn);
     const Stream nst = load_stream(tn);
-    Raw raw_c;
-    if (more && !xt) {   // (with xt the pipeline already holds the next tile's first two iterations)
-      raw_c = fetch(nst, wave);
-      raw_n = fetch(nst, wave + NWAVES);
-      gen_n = wave + NWAVES >= nst.na;
+    const unsigned long long ps0 = PROBE_NOW();
+    if (more && !xt) {   // (with xt the pipeline already holds the next tile's first iterations)
+      // (the columns are requested in front of the barrier, the bases behind it)
+      const Raw r0 = fetch(nst, wave);
+      const Raw r1 = fetch(nst, wave + NWAVES);
+      Raw r2 = r1;
+      if (DEPTH == 2) r2 = fetch(nst, wave + 2 * NWAVES);
+      lds_barrier();       // every tally of this tile is in LDS
+      settle(r0, reads_in(nst, wave), rd_cur, dat_cur);
+      if (DEPTH == 2) {
+        settle(r1, reads_in(nst, wave + NWAVES), rd_a1, dat_a1);
+        raw_n = r2;
+        nr_n = reads_in(nst, wave + 2 * NWAVES);
+      } else {
+        raw_n = r1;
+        nr_n = reads_in(nst, wave + NWAVES);
+      }
+    } else {
+      lds_barrier();       // every tally of this tile is in LDS
     }
-    lds_barrier();       // every tally of this tile is in LDS
-    if (more && !xt) settle(raw_c, wave >= nst.na, rd_cur, dat_cur);
+    const unsigned long long ps1 = PROBE_NOW();
     uint32_t ticket = 0;
     if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
@@ -554,7 +657,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       const int lim = (kDebug & 2) ? 0 : tile_len;
 #pragma unroll
       for (int it = 0; it < OUT_IT; ++it) {
-        const int i = tid + it * kPileupBlock;
+        const int i = tid + it * kDirectBlock;
         if (i < lim) {
           const uint4 v = lds4[i];
           lds4[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -571,7 +674,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
       uint8_t* al = p.out_allele + tile.site_base;
 #pragma unroll
       for (int it = 0; it < REF_IT; ++it) {
-        const int i = 4 * (tid + it * kPileupBlock);
+        const int i = 4 * (tid + it * kDirectBlock);
         if (i + 4 <= tile_len) {
           __builtin_nontemporal_store(upper4(refw[it]), reinterpret_cast<u32_a1*>(al + i));
         } else {
@@ -585,6 +688,12 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     }
     if (dynamic && more && tid == 0) s_next_ticket = ticket;
     lds_barrier();       // tallies re-zeroed, this tile's s_stats additions done
+#if MIDAS_SNPS_DEBUG_BITS & 256
+    pr_sync += ps1 - ps0;
+    pr_out += PROBE_NOW() - ps1;
+#else
+    (void)ps0; (void)ps1;
+#endif
     if (more) {
       const long long nn = dynamic ? 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
                                    : (long long)wn + (long long)gridDim.x;
@@ -623,6 +732,14 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_direct_kernel(DirectPa
     tile = ntile;
     st = nst;
   }
+#if MIDAS_SNPS_DEBUG_BITS & 256
+  if (lane == 0 && p.probe) {      // per wave: cycles waiting for columns / bases, working, at the barrier, writing out; iterations; all
+    unsigned long long* o = p.probe + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+    o[0] = pr_cols; o[1] = pr_bases; o[2] = pr_work; o[3] = pr_sync; o[4] = pr_out; o[5] = pr_iters;
+    o[6] = __builtin_readcyclecounter() - pr_t0; o[7] = 0ull;
+  }
+#endif
+#undef PROBE_NOW
 }
 
 }  // namespace
@@ -640,11 +757,11 @@ hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream
   const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
   const bool bq0 = p.baseq <= 0;
   if (lane_bases == 32) {
-    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
-    else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
   } else {
-    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<30, true>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
-    else hipLaunchKernelGGL((pileup_direct_kernel<30, false>), dim3(grid), dim3(kPileupBlock), dyn_lds, stream, p);
+    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<30, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    else hipLaunchKernelGGL((pileup_direct_kernel<30, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
   }
   return hipGetLastError();
 }

@@ -99,20 +99,11 @@ struct midas_snps_batch {
   int path = MIDAS_SNPS_PATH_DIRECT;   // the path batch_run takes
   int path_auto = MIDAS_SNPS_PATH_DIRECT;   // what the batch's own numbers recommend
   bool packed_built = false;    // rec / blob / orig / key exist (the packed path's layout is built on first use)
-  uint8_t* d_info = nullptr;    // [n_reads + 1] 20-byte index records of the direct path (+ slack)
-  uint32_t* d_gidx = nullptr;   // [gdesc_capacity] read index of a general entry
   uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
-  uint32_t* d_gcount = nullptr; // [n_tiles + 1]
-  uint32_t* d_goff = nullptr;   // [n_tiles + 1]
-  uint32_t* d_gen_reads = nullptr;   // [n_reads]
-  uint32_t* d_gen_count = nullptr;   // [classify workgroups]
-  uint32_t* d_gen_base = nullptr;    // [classify workgroups] exclusive scan of d_gen_count
-  uint32_t* d_gen_body = nullptr;    // [general reads][kGenBodyWords]
-  uint32_t* d_gdesc = nullptr;  // [gdesc_capacity][kGenDescWords]
-  int64_t gdesc_capacity = 0;
   DirectFacts* d_dfacts = nullptr;
-  DirectTotals* d_dtotals = nullptr;
-  DirectTotals h_dtotals{};
+  unsigned long long* d_probe = nullptr;   // developer builds only (MIDAS_SNPS_DEBUG_BITS & 256)
+  int64_t direct_general = 0;   // reads the pileup kernel walks op by op (facts pass)
+  int32_t direct_reach = 1;     // longest reference span of a read: what a tile's range must reach back over
   int32_t direct_lane_bases = 30, direct_lanes_per_read = 1;
   int64_t direct_stream_reads = 0;   // sum over tiles of the positions their streams hold (>= n_reads: straddlers twice)
   int64_t direct_max_tile_reads = 0;
@@ -768,8 +759,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split, b->d_info, b->d_gidx, b->d_trange, b->d_gcount, b->d_goff, b->d_gen_reads, b->d_gen_count, b->d_gen_base, b->d_gen_body, b->d_gdesc,
-                 b->d_dfacts, b->d_dtotals,
+                 b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_probe,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -924,105 +914,89 @@ uint32_t* trange_end(midas_snps_batch* b, int par) { return trange_begin(b, par)
 
 void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   const int par = (int)(b->direct_run_count & 1);
-  ip->pos = b->d_pos; ip->mapq = b->d_mapq; ip->nm = b->d_nm; ip->l_seq = b->d_lseq;
+  ip->pos = b->d_pos; ip->nm = b->d_nm; ip->l_seq = b->d_lseq;
   ip->seq_off = b->d_seq_off; ip->qual_off = b->d_qual_off; ip->cigar_off = b->d_cigar_off;
   ip->cigar = b->d_cigar;
   ip->seq_bytes = b->seq_bytes; ip->qual_bytes = b->qual_bytes; ip->n_cigar = b->n_cigar;
   ip->n_reads = (int32_t)b->n_reads;
   ip->contig_read_begin = b->d_contig_read_begin; ip->contig_tile_base = b->d_contig_tile_base; ip->contig_len = b->d_contig_len;
   ip->n_contigs = b->n_contigs; ip->n_tiles = (int32_t)b->n_tiles; ip->tile_shift = kTileShift;
-  ip->rec = b->d_info;
   ip->tbegin = trange_begin(b, par); ip->tend = trange_end(b, par);
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
-  ip->gcount = b->d_gcount; ip->goff = b->d_goff; ip->gen_reads = b->d_gen_reads; ip->gen_count = b->d_gen_count; ip->gen_base = b->d_gen_base; ip->gen_body = b->d_gen_body;
-  ip->gdesc = b->d_gdesc; ip->gidx = b->d_gidx; ip->gdesc_capacity = b->gdesc_capacity;
-  ip->n_general_hint = b->direct_run_count > 0 ? (int64_t)b->h_dtotals.n_general : b->n_reads;
   ip->sorted = b->direct_sorted ? 1 : 0;
-  ip->pad_advances = b->pad_advances ? 1 : 0;
-  ip->reach = b->max_l_seq;
-  ip->facts = b->d_dfacts; ip->totals = b->d_dtotals;
+  ip->reach = b->direct_reach;
+  ip->facts = b->d_dfacts;
   ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
   ip->n_stat_words = b->d_work ? b->n_species * MIDAS_STATS : 0;
 }
 
-// Buffers of the direct path, and its index pass run once: every read validated on the device (the statuses of the packer),
-// the batch's totals, the descriptors of the general reads sized -- and the numbers the choice of path rests on.
+// Buffers of the direct path, its facts pass (once: every read validated on the device -- the statuses of the packer --, the
+// batch's totals, the longest reference span of a read) and one ranges pass: the numbers the choice of path rests on.
 int32_t direct_prepare(midas_snps_batch* b) {
   midas_snps_ctx* ctx = b->ctx;
   hipStream_t s = ctx->stream;
-  const size_t n1 = (size_t)(b->n_reads > 0 ? b->n_reads : 1);
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
-  HIP_TRY(ctx, hipMalloc(&b->d_info, (n1 + 1) * 20 + 64));
-  HIP_TRY(ctx, hipMalloc(&b->d_gen_reads, n1 * 4));
-  HIP_TRY(ctx, hipMalloc(&b->d_gen_count, (size_t)direct_index_blocks(b->n_reads) * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_trange, nt * 4 * 4));
-  HIP_TRY(ctx, hipMalloc(&b->d_gcount, (nt + 1) * 4));
-  HIP_TRY(ctx, hipMalloc(&b->d_goff, (nt + 1) * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots));
-  HIP_TRY(ctx, hipMalloc(&b->d_dtotals, sizeof(DirectTotals)));
-  HIP_TRY(ctx, hipMalloc(&b->d_gdesc, 64));      // (room for the sentinel descriptor)
-  HIP_TRY(ctx, hipMalloc(&b->d_gidx, 64));
   // tile bounds start clean (every pass resets the other parity's); counters at zero; status words at "no error"
   HIP_TRY(ctx, hipMemsetAsync(b->d_trange, 0, nt * 16, s));
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 0), 0xFF, nt * 4, s));
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 1), 0xFF, nt * 4, s));
-  HIP_TRY(ctx, hipMemsetAsync(b->d_gcount, 0, (nt + 1) * 4, s));
-  HIP_TRY(ctx, hipMemsetAsync(b->d_goff, 0, (nt + 1) * 4, s));
   HIP_TRY(ctx, hipMemsetAsync(b->d_dfacts, 0, sizeof(DirectFacts) * kDirectFactSlots, s));
-  HIP_TRY(ctx, hipMemsetAsync(&b->d_dfacts->status, 0xFF, 8, s));
+  for (int k = 0; k < kDirectFactSlots; ++k) HIP_TRY(ctx, hipMemsetAsync(&b->d_dfacts[k].status, 0xFF, 8, s));
   DirectIndexParams ip;
   fill_direct_index(b, &ip);
-  HIP_TRY(ctx, launch_direct_index(ip, s));
-  HIP_TRY(ctx, hipMemcpyAsync(&b->h_dtotals, b->d_dtotals, sizeof(DirectTotals), hipMemcpyDeviceToHost, s));
-  std::vector<uint32_t> tb(nt), te(nt), go(nt + 1);
-  HIP_TRY(ctx, hipMemcpyAsync(tb.data(), ip.tbegin, nt * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(te.data(), ip.tend, nt * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(go.data(), b->d_goff, (nt + 1) * 4, hipMemcpyDeviceToHost, s));
+  std::vector<DirectFacts> facts(kDirectFactSlots);
+  if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_facts(ip, s));
+  HIP_TRY(ctx, hipMemcpyAsync(facts.data(), b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  b->direct_run_count += 1;
-  const DirectTotals& t = b->h_dtotals;
-  if (t.status != kNoError) return pack_status_to_error(ctx, t.status);
-  {     // where every classify workgroup's general reads go in gen_body: the batch never changes, so neither does this
-    const size_t nb = (size_t)direct_index_blocks(b->n_reads);
-    std::vector<uint32_t> cnt(nb), base(nb);
-    HIP_TRY(ctx, hipMemcpy(cnt.data(), b->d_gen_count, nb * 4, hipMemcpyDeviceToHost));
-    uint64_t acc = 0;
-    for (size_t k = 0; k < nb; ++k) { base[k] = (uint32_t)acc; acc += cnt[k]; }
-    HIP_TRY(ctx, hipMalloc(&b->d_gen_base, nb * 4));
-    HIP_TRY(ctx, hipMemcpy(b->d_gen_base, base.data(), nb * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc(&b->d_gen_body, (size_t)(acc > 0 ? acc : 1) * kGenBodyWords * 4));
+  unsigned long long status = kNoError, alg = 0, n_general = 0;
+  uint32_t max_l = 0, max_span = 0, unsorted = 0;
+  for (const DirectFacts& f : facts) {
+    status = std::min(status, f.status);
+    alg += f.alg_bytes;
+    n_general += f.n_general;
+    max_l = std::max(max_l, f.max_l);
+    max_span = std::max(max_span, f.max_span);
+    unsorted |= f.unsorted;
   }
-  b->max_l_seq = (int32_t)t.max_l;
-  b->direct_sorted = t.unsorted == 0;
-  b->alg_bytes = (int64_t)t.alg_bytes + 17 * b->n_sites;
+  if (status != kNoError) return pack_status_to_error(ctx, status);
+  b->max_l_seq = (int32_t)max_l;
+  b->direct_sorted = unsorted == 0;
+  b->direct_general = (int64_t)n_general;
+  b->direct_reach = (int32_t)std::max<uint32_t>(1u, std::max(max_l, max_span));
+  b->alg_bytes = (int64_t)alg + 17 * b->n_sites;
   b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
   b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;
-  if (t.n_entries > 0) {
-    (void)hipFree(b->d_gdesc);
-    b->d_gdesc = nullptr;
-    HIP_TRY(ctx, hipMalloc(&b->d_gdesc, ((size_t)t.n_entries + 1) * kGenDescWords * 4));
-    (void)hipFree(b->d_gidx);
-    b->d_gidx = nullptr;
-    HIP_TRY(ctx, hipMalloc(&b->d_gidx, (size_t)t.n_entries * 4));
-    b->gdesc_capacity = (int64_t)t.n_entries;
-  }
-  // how well the reads are ordered: a tile's stream holds every read between the first and the last class-0 read touching it
+  // the tile ranges once, to see how well the reads are ordered: a tile's stream holds every read between the first and the
+  // last that can touch it
+  fill_direct_index(b, &ip);
+  HIP_TRY(ctx, launch_direct_ranges(ip, s));
+  std::vector<uint32_t> tb(nt), te(nt);
+  HIP_TRY(ctx, hipMemcpyAsync(tb.data(), ip.tbegin, nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(te.data(), ip.tend, nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  b->direct_run_count += 1;
   int64_t stream = 0, worst = 0;
   for (size_t k = 0; k < (size_t)b->n_tiles; ++k) {
-    const int64_t n0 = te[k] > tb[k] ? (int64_t)te[k] - (int64_t)tb[k] : 0, m = (int64_t)go[k + 1] - (int64_t)go[k];
-    stream += n0 + m;
-    worst = std::max(worst, n0 + m);
+    const int64_t n0 = te[k] > tb[k] ? (int64_t)te[k] - (int64_t)tb[k] : 0;
+    stream += n0;
+    worst = std::max(worst, n0);
   }
   b->direct_stream_reads = stream;
   b->direct_max_tile_reads = worst;
   // Coordinate-sorted input makes the streams add up to the reads plus the few that straddle a tile border.  Much more than
-  // that (unsorted input), or one tile holding far more than a workgroup's fair share (a coverage hot spot: the packed path
-  // cuts such a tile into parts), and the packed path is the faster one.
+  // that (unsorted input, or one read with a reference span of many tiles), or one tile holding far more than a workgroup's
+  // fair share (a coverage hot spot: the packed path cuts such a tile into parts), and the packed path is the faster one.
   const int64_t fair = stream / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
   const bool ordered = stream <= b->n_reads + b->n_reads / 2 + 4096;
   const bool hot = worst > std::max<int64_t>(2048, 2 * fair);
   b->path_auto = (ordered && !hot) ? MIDAS_SNPS_PATH_DIRECT : MIDAS_SNPS_PATH_PACKED;
   b->path = ctx->default_path == MIDAS_SNPS_PATH_AUTO ? b->path_auto : ctx->default_path;
+#if MIDAS_SNPS_DEBUG_BITS & 256
+  HIP_TRY(ctx, hipMalloc(&b->d_probe, (size_t)ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8 * 8));
+  HIP_TRY(ctx, hipMemset(b->d_probe, 0, (size_t)ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8 * 8));
+#endif
   return MIDAS_SNPS_OK;
 }
 
@@ -1437,15 +1411,17 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   }
 
   if (b->path == MIDAS_SNPS_PATH_DIRECT) {
-    // ---- direct path: classify + scan + fill, then the pileup kernel over the raw arrays -------------------------------
+    // ---- direct path: the tile ranges from the positions, then the pileup kernel over the raw arrays (one visit per read) ----
     DirectIndexParams dip;
     fill_direct_index(b, &dip);
-    HIP_TRY(ctx, launch_direct_index(dip, s));
+    HIP_TRY(ctx, launch_direct_ranges(dip, s));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     DirectParams dp;
+    dp.pos = b->d_pos; dp.mapq = b->d_mapq; dp.nm = b->d_nm; dp.l_seq = b->d_lseq;
+    dp.seq_off = b->d_seq_off; dp.qual_off = b->d_qual_off; dp.cigar_off = b->d_cigar_off;
     dp.seq4 = b->d_seq4; dp.qual = b->d_qual; dp.cigar = b->d_cigar;
-    dp.rec = b->d_info;
-    dp.tbegin = dip.tbegin; dp.tend = dip.tend; dp.goff = b->d_goff; dp.gdesc = b->d_gdesc; dp.gidx = b->d_gidx; dp.gdesc_capacity = b->gdesc_capacity;
+    dp.tbegin = dip.tbegin; dp.tend = dip.tend;
+    dp.probe = b->d_probe;
     dp.ref = b->d_ref;
     dp.tiles = b->d_tiles;
     dp.filt = b->d_filt;
@@ -1777,6 +1753,17 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
   return MIDAS_SNPS_OK;
 }
 
+#if MIDAS_SNPS_DEBUG_BITS & 256
+// developer builds only: the direct pileup kernel's per-wave cycle counts of the last run (8 words per wave)
+int32_t midas_snps_debug_probe(midas_snps_batch* b, unsigned long long* out, int64_t n_words) {
+  if (!b || !out || !b->d_probe) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const int64_t have = (int64_t)b->ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8;
+  HIP_TRY(b->ctx, hipDeviceSynchronize());
+  HIP_TRY(b->ctx, hipMemcpy(out, b->d_probe, (size_t)std::min(have, n_words) * 8, hipMemcpyDeviceToHost));
+  return MIDAS_SNPS_OK;
+}
+#endif
+
 int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_info* out) {
   if (!b || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   out->n_reads = b->n_reads;
@@ -1791,8 +1778,8 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->path_auto = b->path_auto;
   out->lane_bases = b->path == MIDAS_SNPS_PATH_DIRECT ? b->direct_lane_bases : b->lane_bases;
   out->reserved0 = 0;
-  out->direct_general_reads = (int64_t)b->h_dtotals.n_general;
-  out->direct_general_entries = (int64_t)b->h_dtotals.n_entries;
+  out->direct_general_reads = b->direct_general;
+  out->direct_reach = b->direct_reach;
   out->direct_stream_reads = b->direct_stream_reads;
   out->direct_max_tile_reads = b->direct_max_tile_reads;
   return MIDAS_SNPS_OK;

@@ -194,7 +194,8 @@ def test_auto_picks_direct_for_sorted_input_and_packed_otherwise(hip_ctx, thr_de
     assert info.path == abi.PATH_DIRECT and info.path_auto == abi.PATH_DIRECT
     assert info.packed_bytes == 0                                         # nothing was packed
     assert reads.n_reads <= info.direct_stream_reads <= reads.n_reads * 1.1   # every read once, straddlers twice
-    assert 0 < info.direct_general_reads < reads.n_reads * 0.2
+    assert info.direct_general_reads == 0          # clips and single indels are settled in registers: nothing is walked op by op
+    assert 150 <= info.direct_reach <= 153         # the longest reference span: 150 bp + a deletion of up to three
     b.close()
     # the same reads, contig by contig in random order: the streams no longer add up -> packed
     d = reads.as_dict()

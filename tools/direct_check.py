@@ -36,9 +36,9 @@ def main():
     b = ctx.batch(contigs, reads)
     print("batch_create: %.3f s" % (time.time() - t0), flush=True)
     info = b.info()
-    print("reads %d sites %d tiles %d | auto path %s | general reads %d entries %d | stream reads %d (%.3f x) max/tile %d | lanes %d x %d bases"
+    print("reads %d sites %d tiles %d | auto path %s | general reads %d reach %d | stream reads %d (%.3f x) max/tile %d | lanes %d x %d bases"
           % (info.n_reads, info.n_sites, info.n_tiles, abi.PATH_NAMES[info.path_auto], info.direct_general_reads,
-             info.direct_general_entries, info.direct_stream_reads, info.direct_stream_reads / max(1, info.n_reads),
+             info.direct_reach, info.direct_stream_reads, info.direct_stream_reads / max(1, info.n_reads),
              info.direct_max_tile_reads, info.lanes_per_read, info.lane_bases), flush=True)
     res = {}
     only = os.environ.get('DIRECT_CHECK_PATHS')
