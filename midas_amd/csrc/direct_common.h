@@ -67,28 +67,37 @@ __device__ __forceinline__ void query_bounds(const CigarView& cg, uint32_t nc, l
 struct ReadShape { uint32_t lead, m1, ins, del, alen; };
 constexpr uint32_t kMaxFastGap = 65535;     // a longer deletion / skip goes the slow way (its arithmetic saturates)
 
-// One forward pass over the first four ops (registers); nc <= 4.  Stages: 0 leading hard clips, 1 behind the leading soft
-// clip, 2 in the first run, 3 behind the indel, 4 in the second run, 5 behind the trailing soft clip, 6 trailing hard clips.
+// Branch-free, on the first four ops (registers).  An op's class -- 0 match (M, =, X), 1 soft clip, 2 gap (I, D, N), 3 anything
+// else -- comes out of a 32-bit table; the classes of the read's ops, two bits each, form a key that is compared with the one
+// key its op count and leading clip allow:
+//   M | S M | M S | S M S | M G M | S M G M | M G M S          (S M G M S has five ops: it is walked)
+// Reads with hard clips or a match run written as several ops (4=2X ...) are walked op by op as well -- correct, only slower.
+// Zero-length ops are harmless here (the formulas hold for them); an empty aligned part is not (keep_read divides by it).
+constexpr uint32_t kOpClass = 0xFFFC3DA8u;      // two bits per op code 0..15
+constexpr uint32_t kShapeKeys = 0x48080400u;    // key of the ops behind the leading clip, by their number 1..4: M, M S, M G M, M G M S
 __device__ __forceinline__ bool decode_shape(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t nc, uint32_t l, ReadShape* out) {
-  uint32_t stage = 0, lead = 0, trail = 0, m1 = 0, m2 = 0, ins = 0, del = 0;
-  bool ok = nc >= 1u && nc <= 4u && l >= 1u;
-  auto step = [&](uint32_t v) {
-    const uint32_t op = v & 15u, len = v >> 4;
-    if (len == 0u) ok = false;
-    else if (op_is_match(op)) { if (stage <= 2u) { m1 += len; stage = 2u; } else if (stage <= 4u) { m2 += len; stage = 4u; } else ok = false; }
-    else if (op == OP_S) { if (stage == 0u) { lead = len; stage = 1u; } else if (stage == 2u || stage == 4u) { trail = len; stage = 5u; } else ok = false; }
-    else if (op == OP_I || op == OP_D || op == OP_N) { if (stage == 2u) { if (op == OP_I) ins = len; else del = len; stage = 3u; } else ok = false; }
-    else if (op == OP_H) { if (stage == 2u || stage == 4u || stage == 5u) stage = 6u; else if (stage != 0u && stage != 6u) ok = false; }
-    else ok = false;
-  };
-  if (nc > 0u) step(c0);
-  if (nc > 1u) step(c1);
-  if (nc > 2u) step(c2);
-  if (nc > 3u) step(c3);
+  const uint32_t op0 = c0 & 15u, op1 = c1 & 15u, op2 = c2 & 15u, op3 = c3 & 15u;
+  const uint32_t len0 = c0 >> 4, len1 = c1 >> 4, len2 = c2 >> 4, len3 = c3 >> 4;
+  const uint32_t k0 = __builtin_amdgcn_ubfe(kOpClass, op0 << 1, 2u), k1 = __builtin_amdgcn_ubfe(kOpClass, op1 << 1, 2u);
+  const uint32_t k2 = __builtin_amdgcn_ubfe(kOpClass, op2 << 1, 2u), k3 = __builtin_amdgcn_ubfe(kOpClass, op3 << 1, 2u);
+  const uint32_t ncc = nc > 5u ? 5u : nc;
+  const uint32_t key = (k0 | (k1 << 2) | (k2 << 4) | (k3 << 6)) & ((1u << (2u * ncc)) - 1u);        // (the ops behind the read's are not its own)
+  const bool lead_p = k0 == 1u;
+  const uint32_t nr = ncc - (lead_p ? 1u : 0u);                                                       // ops behind the leading clip
+  const uint32_t want_r = (kShapeKeys >> (8u * ((nr - 1u) & 3u))) & 0xFFu;
+  const uint32_t want = lead_p ? (1u | (want_r << 2)) : want_r;
+  const uint32_t r0 = lead_p ? len1 : len0, r1 = lead_p ? len2 : len1, r2 = lead_p ? len3 : len2;
+  const uint32_t gop = lead_p ? op2 : op1;
+  const bool has_gap = nr >= 3u;
+  const uint32_t lead = lead_p ? len0 : 0u;
+  const uint32_t gap = has_gap ? r1 : 0u;
+  const uint32_t ins = gop == OP_I ? gap : 0u;
+  const uint32_t m2 = has_gap ? r2 : 0u;
+  const uint32_t trail = nr == 2u ? r1 : (nr == 4u ? len3 : 0u);
+  const uint32_t alen = r0 + ins + m2;
+  out->lead = lead; out->m1 = r0; out->ins = ins; out->del = gap - ins; out->alen = alen;
   // (sums of at most four 28-bit lengths: no wrap)
-  ok = ok && stage != 3u && stage >= 2u && lead + m1 + ins + m2 + trail == l && del <= kMaxFastGap;
-  out->lead = lead; out->m1 = m1; out->ins = ins; out->del = del; out->alen = m1 + ins + m2;
-  return ok;
+  return nc >= 1u && nc <= 4u && nr >= 1u && key == want && lead + alen + trail == l && alen >= 1u && gap - ins <= kMaxFastGap;
 }
 
 }  // namespace direct

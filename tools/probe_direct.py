@@ -41,11 +41,32 @@ def main():
     a = np.frombuffer(out, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
     a = a[a[:, 6] > 0]
     tot = a[:, 6].sum()
-    names = ["wait columns + issue", "wait bases", "work", "barrier 1", "write-out + barrier 2", "iterations", "all"]
-    for k in range(5):
-        print("%-24s %6.1f %% of wave cycles   (%.0f cycles / iteration)" % (names[k], 100 * a[:, k].sum() / tot, a[:, k].sum() / a[:, 5].sum()))
+    names = ["wait columns + issue", "wait bases", "work", "barrier 1 (DB: wait for a clean buffer)", "write-out + barrier 2 (DB: drain, all of it)", "iterations", "all", "DB: of the drain, waiting for the tile's last wave"]
+    for k in (0, 2, 3, 4, 7):
+        print("%-52s %6.1f %% of wave cycles   (%.0f cycles / iteration)" % (names[k], 100 * a[:, k].sum() / tot, a[:, k].sum() / a[:, 5].sum()))
     print("iterations per wave: mean %.1f  min %d  max %d ; cycles per wave: mean %.0f  min %.0f  max %.0f" % (
         a[:, 5].mean(), a[:, 5].min(), a[:, 5].max(), a[:, 6].mean(), a[:, 6].min(), a[:, 6].max()))
+    # where the workgroups ran: HW_ID (cu_id bits 8-11, sh_id 12, se_id 13-15) and XCC_ID (bits 0-3) of every wave
+    raw = np.frombuffer(out, dtype=np.uint64).reshape(-1, 8)
+    raw = raw[raw[:, 6] > 0]
+    hw = (raw[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    xcc = ((raw[:, 1] >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
+    cu = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 15)
+    cyc = raw[:, 6].astype(np.float64)
+    n_w = 8
+    wg_cyc = cyc.reshape(-1, n_w).max(axis=1)
+    wg_cu = cu.reshape(-1, n_w)[:, 0]
+    wg_xcc = xcc.reshape(-1, n_w)[:, 0]
+    print("workgroups %d on %d distinct CUs; workgroups per CU: %s" % (wg_cyc.size, np.unique(wg_cu).size, np.bincount(np.unique(wg_cu, return_counts=True)[1]).tolist()))
+    for x in range(8):
+        m = wg_xcc == x
+        if m.any():
+            print("XCC %d: %3d workgroups, cycles mean %.0f min %.0f max %.0f" % (x, m.sum(), wg_cyc[m].mean(), wg_cyc[m].min(), wg_cyc[m].max()))
+    within = (cyc.reshape(-1, n_w).max(axis=1) - cyc.reshape(-1, n_w).min(axis=1))
+    print("spread inside a workgroup (max - min wave cycles): mean %.0f max %.0f" % (within.mean(), within.max()))
+    order = np.argsort(wg_cyc)
+    print("slowest workgroups (block, cu, cycles):", [(int(i), int(wg_cu[i]), int(wg_cyc[i])) for i in order[-6:]])
+    print("fastest workgroups (block, cu, cycles):", [(int(i), int(wg_cu[i]), int(wg_cyc[i])) for i in order[:6]])
     b.close()
     ctx.close()
 

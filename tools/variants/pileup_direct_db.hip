@@ -53,6 +53,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // Eight bases of one lane: q0 / q1 two words of four quality bytes (bases in order), the / tho threshold bytes and cde / cdo
 // counter offsets of the even / odd bases (byte i of an `e` word: base 2i, of an `o` word: base 2i + 1).
+#if MIDAS_SNPS_DEBUG_BITS & 512
+#define MIDAS_DS_ADD(T, O) "s_nop 0\n\t"      /* developer timing variant: everything but the LDS atomics */
+#else
+#define MIDAS_DS_ADD(T, O) "ds_add_u32 " T ", %[one] offset:" O "\n\t"
+#endif
 template <int OFF, int NB>
 __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t the, uint32_t tho, uint32_t cde, uint32_t cdo,
                                             uint32_t abase, uint32_t one) {
@@ -79,21 +84,21 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
         "v_cmp_gt_u32_sdwa %[m7], %[q1], %[to] src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[m0]\n\t"
-        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        MIDAS_DS_ADD("%[t0]", "%[off]")
         "s_mov_b64 exec, %[m1]\n\t"
-        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        MIDAS_DS_ADD("%[t1]", "%[off]+16")
         "s_mov_b64 exec, %[m2]\n\t"
-        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        MIDAS_DS_ADD("%[t2]", "%[off]+32")
         "s_mov_b64 exec, %[m3]\n\t"
-        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        MIDAS_DS_ADD("%[t3]", "%[off]+48")
         "s_mov_b64 exec, %[m4]\n\t"
-        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        MIDAS_DS_ADD("%[t4]", "%[off]+64")
         "s_mov_b64 exec, %[m5]\n\t"
-        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
+        MIDAS_DS_ADD("%[t5]", "%[off]+80")
         "s_mov_b64 exec, %[m6]\n\t"
-        "ds_add_u32 %[t6], %[one] offset:%[off]+96\n\t"
+        MIDAS_DS_ADD("%[t6]", "%[off]+96")
         "s_mov_b64 exec, %[m7]\n\t"
-        "ds_add_u32 %[t7], %[one] offset:%[off]+112\n\t"
+        MIDAS_DS_ADD("%[t7]", "%[off]+112")
         "s_mov_b64 exec, %[sv]"
         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
           [t7] "=&v"(t7), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5),
@@ -117,17 +122,17 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
         "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[m0]\n\t"
-        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        MIDAS_DS_ADD("%[t0]", "%[off]")
         "s_mov_b64 exec, %[m1]\n\t"
-        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        MIDAS_DS_ADD("%[t1]", "%[off]+16")
         "s_mov_b64 exec, %[m2]\n\t"
-        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        MIDAS_DS_ADD("%[t2]", "%[off]+32")
         "s_mov_b64 exec, %[m3]\n\t"
-        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        MIDAS_DS_ADD("%[t3]", "%[off]+48")
         "s_mov_b64 exec, %[m4]\n\t"
-        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        MIDAS_DS_ADD("%[t4]", "%[off]+64")
         "s_mov_b64 exec, %[m5]\n\t"
-        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
+        MIDAS_DS_ADD("%[t5]", "%[off]+80")
         "s_mov_b64 exec, %[sv]"
         : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [m0] "=&s"(m0),
           [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [sv] "=&s"(save)
@@ -137,24 +142,148 @@ __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t t
   }
 }
 
+#undef MIDAS_DS_ADD
+// The same eight (six) bases onto 16-bit tallies, [site][A | C << 16, G | T << 16] = 8 bytes per site (the double-buffered tile
+// of the DB kernel): cde / cdo give the dword of the base's counter (0 or 4), she / sho the shift of its half (0 or 16); the
+// value 1 << shift is formed under the base's mask right in front of its ds_add (four rotating registers).
+template <int OFF, int NB>
+__device__ __forceinline__ void tally_group16(uint32_t q0, uint32_t q1, uint32_t the, uint32_t tho, uint32_t cde, uint32_t cdo,
+                                              uint32_t she, uint32_t sho, uint32_t abase, uint32_t one) {
+  static_assert(NB == 8 || NB == 6, "a group holds 8 bases, or 6 at the end of a 30-base lane");
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7, va, vb, vc, vd;
+  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, save;
+  if (NB == 8) {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t6], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_or_b32_sdwa %[t7], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m6], %[q1], %[te] src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m7], %[q1], %[to] src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_lshlrev_b32_sdwa %[va], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vb], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vc], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vd], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "ds_add_u32 %[t0], %[va] offset:%[off]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "ds_add_u32 %[t1], %[vb] offset:%[off]+8\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "ds_add_u32 %[t2], %[vc] offset:%[off]+16\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "ds_add_u32 %[t3], %[vd] offset:%[off]+24\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_lshlrev_b32_sdwa %[va], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vb], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vc], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vd], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "s_mov_b64 exec, %[m4]\n\t"
+        "ds_add_u32 %[t4], %[va] offset:%[off]+32\n\t"
+        "s_mov_b64 exec, %[m5]\n\t"
+        "ds_add_u32 %[t5], %[vb] offset:%[off]+40\n\t"
+        "s_mov_b64 exec, %[m6]\n\t"
+        "ds_add_u32 %[t6], %[vc] offset:%[off]+48\n\t"
+        "s_mov_b64 exec, %[m7]\n\t"
+        "ds_add_u32 %[t7], %[vd] offset:%[off]+56\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+          [t7] "=&v"(t7), [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [vd] "=&v"(vd), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+          [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [m6] "=&s"(m6), [m7] "=&s"(m7), [sv] "=&s"(save)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [se] "v"(she), [so] "v"(sho),
+          [ab] "v"(abase), [one] "v"(one), [off] "n"(OFF)
+        : "memory");
+  } else {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %[va], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vb], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vc], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vd], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "ds_add_u32 %[t0], %[va] offset:%[off]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "ds_add_u32 %[t1], %[vb] offset:%[off]+8\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "ds_add_u32 %[t2], %[vc] offset:%[off]+16\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "ds_add_u32 %[t3], %[vd] offset:%[off]+24\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_lshlrev_b32_sdwa %[va], %[se], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[vb], %[so], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+        "s_mov_b64 exec, %[m4]\n\t"
+        "ds_add_u32 %[t4], %[va] offset:%[off]+32\n\t"
+        "s_mov_b64 exec, %[m5]\n\t"
+        "ds_add_u32 %[t5], %[vb] offset:%[off]+40\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+          [va] "=&v"(va), [vb] "=&v"(vb), [vc] "=&v"(vc), [vd] "=&v"(vd), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+          [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [sv] "=&s"(save)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [se] "v"(she), [so] "v"(sho),
+          [ab] "v"(abase), [one] "v"(one), [off] "n"(OFF)
+        : "memory");
+  }
+}
+
 // The per-tile stream: the reads rb .. rb + n0 of the read arrays, as `total` wave-iterations.
 struct Stream { int rb, n0, total; };
 
-// Workgroup shape (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384).
+// Workgroup shape and prefetch depth (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384 -DMIDAS_DIRECT_DEPTH=2).
+//   DEPTH = iterations a wave's base loads run ahead of their use (the read's columns one more).  While a wave tallies --
+//   LDS atomics, which the sixteen waves of a CU queue up for -- only what it requested beforehand keeps the memory pipe busy.
 #ifndef MIDAS_DIRECT_BLOCK
 #define MIDAS_DIRECT_BLOCK 512
 #endif
+#ifndef MIDAS_DIRECT_DEPTH
+#define MIDAS_DIRECT_DEPTH 1
+#endif
 constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
+constexpr int kDirectDepth = MIDAS_DIRECT_DEPTH;
 static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
+static_assert(kDirectDepth == 1 || kDirectDepth == 2, "one or two iterations ahead");
 constexpr int kDirectWavesPerSimd = (2 * kDirectBlock / 64 + 3) / 4;      // two workgroups per CU
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
-template <int LB, bool BQ0>
+// DB: the tile's tallies are 16-bit (8 bytes per site) and DOUBLE-BUFFERED, and the workgroup's waves are no longer held
+// together by barriers: a wave that has finished its share of tile k goes straight on to tile k + 1 (the other buffer) and
+// the finished tile is written out, slice by slice, by whichever waves get there first -- the write-out of one tile runs
+// under the tallies of the next, nobody waits for the slowest wave, and the waves drift apart instead of queueing for the
+// LDS together.  Synchronisation: three counters per buffer in LDS (waves done, slices handed out, slices clean).  Exact
+// while a tile's stream holds at most 65 535 reads (every read adds at most one to a counter); the host picks the 32-bit
+// kernel (!DB: one buffer, two barriers per tile) otherwise.
+template <int LB, bool BQ0, bool DB>
 __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
   constexpr int TILE = kTileSites;
+  constexpr int BUF_WORDS = DB ? 2 * TILE : 4 * TILE;       // one tile of tallies
+  constexpr int SLICE = 256;                                 // sites a wave writes out at a time (DB)
+  constexpr int NSLICES = TILE / SLICE;
+  static_assert(TILE % SLICE == 0, "whole slices");
   constexpr int NWAVES = kDirectBlock / 64;
+  constexpr int DEPTH = kDirectDepth;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_mhi[33 * 8];   // [h][w]: 0xFF in the bytes of the bases j >= h
@@ -162,6 +291,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
+  __shared__ uint32_t s_sync[8];     // DB: [0,1] waves done with the tile in buffer 0 / 1 (cumulative), [2,3] slices handed out, [4,5] slices clean
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   const int tid = threadIdx.x;
@@ -179,7 +309,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   if (w >= w_end) return;
   int w_next = w + (int)gridDim.x;
 #if MIDAS_SNPS_DEBUG_BITS & 256
-  unsigned long long pr_cols = 0, pr_bases = 0, pr_work = 0, pr_sync = 0, pr_out = 0, pr_iters = 0;
+  unsigned long long pr_cols = 0, pr_bases = 0, pr_work = 0, pr_sync = 0, pr_out = 0, pr_iters = 0, pr_wdone = 0;
   const unsigned long long pr_t0 = __builtin_readcyclecounter();
 #define PROBE_NOW() __builtin_readcyclecounter()
 #else
@@ -206,6 +336,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     }
     s_qsum[tid] = 0u;
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
+    if (tid < 8) s_sync[tid] = 0u;
   }
 
   const int lpr = p.lanes_per_read;
@@ -218,7 +349,10 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   // v_perm_b32 tables (slots 0, 1, 3, 7 = A, C, G, T): threshold bytes and counter offsets
   const uint32_t thr = BQ0 ? 0u : (uint32_t)(p.baseq > 256 ? 255 : p.baseq - 1);
   const uint32_t th_lo = thr | (thr << 8) | 0x00FF0000u | (thr << 24), th_hi = 0x00FFFFFFu | (thr << 24);
-  const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
+  // counter of a base: u32 tallies byte offset 0 / 4 / 8 / 12; u16 tallies dword 0 (A | C << 16) or 4 (G | T << 16) and the half's shift
+  const uint32_t cd_lo = DB ? 0x04000000u : 0x08000400u, cd_hi = DB ? 0x04000000u : 0x0C000000u;
+  const uint32_t sh_lo = 0x00001000u, sh_hi = 0x10000000u;
+  uint32_t buf_base = lds_base;                     // LDS byte address of the tally buffer in use
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
   const uint32_t one = 1u;
 
@@ -270,7 +404,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   // wave's lanes has a base in is skipped)
   auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4], auto sparse_tag) {
     constexpr bool SPARSE = decltype(sparse_tag)::value;
-    const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
+    const uint32_t abase = ((uint32_t)loc0 << (DB ? 3 : 4)) + buf_base;
     const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
     unsigned long long gmask[4];
     if (SPARSE) {
@@ -293,7 +427,12 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         te |= h.x | l.x;
         to |= h.y | l.y;
       }
-      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
+      if constexpr (DB) {
+        const uint32_t she = __builtin_amdgcn_perm(sh_hi, sh_lo, se), sho = __builtin_amdgcn_perm(sh_hi, sh_lo, so);
+        tally_group16<decltype(off)::value / 2, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, she, sho, abase, one);
+      } else {
+        tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
+      }
     };
     using std::integral_constant;
     group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 8>{});
@@ -353,20 +492,25 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 
   Tile tile = load_tile(c_tiles, w);
   Stream st = load_stream(w);
-  // The pipeline of a wave, in two register sets that swap roles every iteration (the loop below is unrolled by two: a copy
-  // at its back edge would have to WAIT for the loads it copies -- the next iteration's bases, requested a moment ago):
-  //   set A / B   one holds the iteration being tallied, the other the next one's bases (in flight)
-  //   raw X       the columns of the iteration after that (in flight); its bases are requested at the top of the next body
-  // Between tiles the current iteration sits in set A.
-  Raw rawX;
-  int nrX = 0;                                  // reads of the iteration the columns belong to (wave-uniform)
-  Rd rdA, rdB;
-  Dat datA, datB;
+  // the pipeline of a wave: cur (being tallied), with DEPTH == 2 ahead1 (bases requested one iteration ago), raw_n: the
+  // columns of the iteration DEPTH + 1 ahead of cur's -- its bases are requested at the top of the next loop body
+  Raw raw_n;
+  int nr_n;                                     // reads of the iteration raw_n belongs to (wave-uniform)
+  Rd rd_cur, rd_a1;
+  Dat dat_cur, dat_a1;
   auto prime = [&](const Stream& s0) {
     const Raw r0 = fetch(s0, wave);
-    rawX = fetch(s0, wave + NWAVES);
-    nrX = reads_in(s0, wave + NWAVES);
-    settle(r0, reads_in(s0, wave), rdA, datA);
+    const Raw r1 = fetch(s0, wave + NWAVES);
+    if (DEPTH == 2) {
+      raw_n = fetch(s0, wave + 2 * NWAVES);
+      nr_n = reads_in(s0, wave + 2 * NWAVES);
+      settle(r0, reads_in(s0, wave), rd_cur, dat_cur);
+      settle(r1, reads_in(s0, wave + NWAVES), rd_a1, dat_a1);
+    } else {
+      settle(r0, reads_in(s0, wave), rd_cur, dat_cur);
+      raw_n = r1;
+      nr_n = reads_in(s0, wave + NWAVES);
+    }
   };
   prime(st);
   __syncthreads();   // LDS zeroed, tables in place
@@ -374,32 +518,125 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   uint32_t acc_cov = 0u;                 // (a thread's sites between two flushes: far below 2^32)
   unsigned long long acc_depth = 0ull;
   int t = w;
+  // ---- DB: the counters that replace the barriers, and the cooperative write-out --------------------------------------------
+  const uint32_t sync_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)s_sync;
+  int k_tile = 0;                        // ordinal of the tile among this workgroup's
+  Tile ptile = tile;                     // the tile before (its tallies sit in the other buffer until they are written out)
+  int acc_sp = tile.species;             // species acc_cov / acc_depth belong to
+  uint32_t rd_al = 0u, rd_mp = 0u;       // reads counted / kept by this wave since its last flush (species of the current tile)
+  auto wait_ge = [&](uint32_t addr, uint32_t target) {      // spin (politely) until the LDS counter has reached target
+    for (;;) {
+      uint32_t v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+      if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  auto flush_acc = [&]() {               // this wave's covered sites / depth of species acc_sp
+    for (int d = 32; d >= 1; d >>= 1) {
+      acc_cov += __shfl_down(acc_cov, d);
+      acc_depth += __shfl_down(acc_depth, d);
+    }
+    if (lane == 0) {
+      if (acc_cov) atomicAdd(&p.stats[(size_t)acc_sp * MIDAS_STATS + MIDAS_STAT_COVERED], (unsigned long long)acc_cov);
+      if (acc_depth) atomicAdd(&p.stats[(size_t)acc_sp * MIDAS_STATS + MIDAS_STAT_DEPTH], acc_depth);
+    }
+    acc_cov = 0u;
+    acc_depth = 0ull;
+  };
+  // Write out (and re-zero) the tile T whose tallies sit in buffer bb, generation gen of that buffer, together with the other
+  // waves: slices of 256 sites are handed out by a ticket, a wave takes slices until none is left.  Every wave calls this
+  // exactly once per tile, so the ticket counter advances by NSLICES + NWAVES per generation.
+  auto drain = [&](const Tile& T, int bb, int gen) {
+    const unsigned long long pd0 = PROBE_NOW();
+    wait_ge(sync_base + 4u * (uint32_t)bb, (uint32_t)NWAVES * (uint32_t)(gen + 1));      // every wave has finished the tile
+#if MIDAS_SNPS_DEBUG_BITS & 256
+    pr_wdone += PROBE_NOW() - pd0;
+#else
+    (void)pd0;
+#endif
+    uint2* buf = reinterpret_cast<uint2*>(lds) + (size_t)bb * TILE;
+    for (;;) {
+      uint32_t tk = 0u;
+      if (lane == 0)
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(sync_base + 8u + 4u * (uint32_t)bb), "v"(1u) : "memory");
+      const int sl = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)tk) - (uint32_t)(NSLICES + NWAVES) * (uint32_t)gen);
+      if (sl >= NSLICES) break;
+      const int s0 = sl * SLICE;
+      if (s0 < T.len && !(kDebug & 2)) {
+        if (T.species != acc_sp) { flush_acc(); acc_sp = T.species; }
+        uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((kDebug & 8) ? 0 : T.site_base);
+        uint32_t refw = 0u;
+        const int ia = s0 + 4 * lane;
+        if (p.out_allele && ia + 4 <= T.len) refw = *reinterpret_cast<const u32_a1*>(p.ref + T.site_base + ia);
+#pragma unroll
+        for (int r = 0; r < SLICE / 64; ++r) {
+          const int i = s0 + lane + 64 * r;
+          if (i < T.len) {
+            const uint2 v = buf[i];
+            buf[i] = make_uint2(0u, 0u);
+            u32x4_a8 nv; nv.x = v.x & 0xFFFFu; nv.y = v.x >> 16; nv.z = v.y & 0xFFFFu; nv.w = v.y >> 16;
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_a8*>(out + i));
+            const uint32_t d = nv.x + nv.y + nv.z + nv.w;
+            acc_cov += d > 0u ? 1u : 0u;
+            acc_depth += d;
+          }
+        }
+        if (p.out_allele && ia < T.len) {
+          uint8_t* al = p.out_allele + T.site_base;
+          if (ia + 4 <= T.len) {
+            __builtin_nontemporal_store(upper4(refw), reinterpret_cast<u32_a1*>(al + ia));
+          } else {
+            const uint8_t* ref = p.ref + T.site_base;
+            for (int j = ia; j < T.len; ++j) {
+              uint32_t ch = ref[j];
+              if (ch >= 'a' && ch <= 'z') ch -= 32u;
+              al[j] = (uint8_t)ch;
+            }
+          }
+        }
+      }
+      if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(sync_base + 16u + 4u * (uint32_t)bb), "v"(1u) : "memory");   // (behind the zeroing stores)
+    }
+  };
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
     const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
+    if constexpr (DB) {      // the buffer this tile tallies into: clean once the tile two before has been written out
+      const int bb = k_tile & 1;
+      const unsigned long long pc0 = PROBE_NOW();
+      if (k_tile >= 2) wait_ge(sync_base + 16u + 4u * (uint32_t)bb, (uint32_t)NSLICES * (uint32_t)(k_tile >> 1));
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      pr_sync += PROBE_NOW() - pc0;
+#else
+      (void)pc0;
+#endif
+      buf_base = lds_base + (uint32_t)bb * (uint32_t)(BUF_WORDS * 4);
+    }
     constexpr int REF_IT = (TILE + 4 * kDirectBlock - 1) / (4 * kDirectBlock);
 
-    // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
-    // the columns of its first two iterations of the NEXT tile
+    // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last DEPTH + 1 iterations
+    // fetch the columns of its first DEPTH + 1 iterations of the NEXT tile
     const int n_w = it_hi > wave ? (it_hi - wave + NWAVES - 1) / NWAVES : 0;
-    const bool xt = w_next < w_end && n_w >= 2;
+    const bool xt = w_next < w_end && n_w >= DEPTH + 1;
     Stream xs = st;
     if (xt) xs = load_stream(w_next);
-    // one wave-iteration: `it` of the tile's stream, the wave's k_it-th; tallies (rd_cur, dat_cur), requests the bases of the
-    // next iteration into (rd_n, dat_n) from the columns rawX and then the columns of the one after it into rawX
-    auto iteration = [&](int it, int k_it, Rd& rd_cur, Dat& dat_cur, Rd& rd_n, Dat& dat_n) {
+    int k_it = 0;                               // the wave's k-th iteration of this tile
+    for (int it = wave; it < it_hi; it += NWAVES, ++k_it) {
       const unsigned long long pt0 = PROBE_NOW();
-      settle(rawX, nrX, rd_n, dat_n);          // (the columns of the next iteration have arrived: its bases are requested ...)
+      Rd rd_n;
+      Dat dat_n;
+      settle(raw_n, nr_n, rd_n, dat_n);        // (the columns of the iteration DEPTH ahead have arrived: its bases are requested ...)
       {                                        // ... then the columns of the one after it
-        const int kf = k_it + 2;               // the wave's iteration (of this tile, or counted on into the next) to fetch for
+        const int kf = k_it + DEPTH + 1;       // the wave's iteration (of this tile, or counted on into the next) to fetch for
         const bool over = xt && kf >= n_w;
         Stream fs;
         fs.rb = over ? xs.rb : st.rb; fs.n0 = over ? xs.n0 : st.n0; fs.total = over ? xs.total : st.total;
         const int fi = wave + (over ? kf - n_w : kf) * NWAVES;
-        rawX = fetch(fs, fi);
-        nrX = reads_in(fs, fi);
+        raw_n = fetch(fs, fi);
+        nr_n = reads_in(fs, fi);
       }
 #if MIDAS_SNPS_DEBUG_BITS & 256
       asm volatile("" :: "v"(rd_n.pos), "v"(rd_n.l_nc));
@@ -411,7 +648,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 
       if (kDebug & 4) {          // (developer timing variant: the stream of loads only)
         asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[0]), "v"(rd_cur.pos));
-        return;
+        if (DEPTH == 2) { rd_cur = rd_a1; dat_cur = dat_a1; rd_a1 = rd_n; dat_a1 = dat_n; } else { rd_cur = rd_n; dat_cur = dat_n; }
+        continue;
       }
       const int pos = (int)rd_cur.pos;
       const int l = (int)(rd_cur.l_nc & 0xFFFFu);
@@ -588,25 +826,54 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         atomicMin(p.err, ((unsigned long long)idx << 8) | err);
       }
 
+      if (DEPTH == 2) { rd_cur = rd_a1; dat_cur = dat_a1; rd_a1 = rd_n; dat_a1 = dat_n; } else { rd_cur = rd_n; dat_cur = dat_n; }
 #if MIDAS_SNPS_DEBUG_BITS & 256
       pr_work += PROBE_NOW() - pt2;
 #endif
-    };
-    {
-      int it = wave, k_it = 0;
-      bool odd = false;
-      while (it < it_hi) {
-        iteration(it, k_it, rdA, datA, rdB, datB);
-        it += NWAVES;
-        ++k_it;
-        if (it >= it_hi) { odd = true; break; }
-        iteration(it, k_it, rdB, datB, rdA, datA);
-        it += NWAVES;
-        ++k_it;
-      }
-      if (odd) { rdA = rdB; datA = datB; }      // (once per tile, not per iteration)
     }
 
+    if constexpr (DB) {
+      // ---- this wave has finished tile k: counted behind its tallies (a wave's LDS operations are carried out in order) --------
+      const int bb = k_tile & 1;
+      if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(sync_base + 4u * (uint32_t)bb), "v"(1u) : "memory");
+      rd_al += w_aligned;
+      rd_mp += w_mapped;
+      const int wn = w_next;
+      const bool more = wn < w_end;
+      const int tn = more ? wn : t;
+      const Tile ntile = load_tile(c_tiles, tn);
+      const Stream nst = load_stream(tn);
+      if (more && !xt) prime(nst);       // (with xt the pipeline already holds the next tile's first iterations)
+      if ((!more || ntile.species != tile.species) && lane == 0) {
+        if (rd_al) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + MIDAS_STAT_ALIGNED], (unsigned long long)rd_al);
+        if (rd_mp) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + MIDAS_STAT_MAPPED], (unsigned long long)rd_mp);
+      }
+      if (!more || ntile.species != tile.species) { rd_al = 0u; rd_mp = 0u; }
+      // ---- write out what is finished: the tile before this one (every wave left it long ago), at the end this one too --------
+      const unsigned long long po0 = PROBE_NOW();
+      if (k_tile >= 1) drain(ptile, bb ^ 1, (k_tile - 1) >> 1);
+      if (!more) {
+        drain(tile, bb, k_tile >> 1);
+        flush_acc();
+#if MIDAS_SNPS_DEBUG_BITS & 256
+        pr_out += PROBE_NOW() - po0;
+#endif
+        break;
+      }
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      pr_out += PROBE_NOW() - po0;
+#else
+      (void)po0;
+#endif
+      ptile = tile;
+      tile = ntile;
+      st = nst;
+      w = wn;
+      t = tn;
+      w_next = wn + (int)gridDim.x;
+      ++k_tile;
+      continue;
+    }
     // the tile's reference letters: requested here, behind the stream loop (two registers less in it), they arrive while
     // the workgroup waits for its last wave and writes the counts out
     uint32_t refw[REF_IT];
@@ -632,10 +899,19 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     if (more && !xt) {   // (with xt the pipeline already holds the next tile's first iterations)
       // (the columns are requested in front of the barrier, the bases behind it)
       const Raw r0 = fetch(nst, wave);
-      rawX = fetch(nst, wave + NWAVES);
-      nrX = reads_in(nst, wave + NWAVES);
+      const Raw r1 = fetch(nst, wave + NWAVES);
+      Raw r2 = r1;
+      if (DEPTH == 2) r2 = fetch(nst, wave + 2 * NWAVES);
       lds_barrier();       // every tally of this tile is in LDS
-      settle(r0, reads_in(nst, wave), rdA, datA);
+      settle(r0, reads_in(nst, wave), rd_cur, dat_cur);
+      if (DEPTH == 2) {
+        settle(r1, reads_in(nst, wave + NWAVES), rd_a1, dat_a1);
+        raw_n = r2;
+        nr_n = reads_in(nst, wave + 2 * NWAVES);
+      } else {
+        raw_n = r1;
+        nr_n = reads_in(nst, wave + NWAVES);
+      }
     } else {
       lds_barrier();       // every tally of this tile is in LDS
     }
@@ -731,7 +1007,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     uint32_t hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
     o[0] = pr_cols; o[1] = (unsigned long long)hw_id | ((unsigned long long)xcc_id << 32); o[2] = pr_work; o[3] = pr_sync; o[4] = pr_out; o[5] = pr_iters;
-    o[6] = __builtin_readcyclecounter() - pr_t0; o[7] = 0ull;
+    o[6] = __builtin_readcyclecounter() - pr_t0; o[7] = pr_wdone;
   }
 #endif
 #undef PROBE_NOW
@@ -751,13 +1027,16 @@ hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream
   const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
   const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
   const bool bq0 = p.baseq <= 0;
+  const bool db = p.tally16 != 0;
+#define MIDAS_LAUNCH_DIRECT(LB, BQ, DBL) hipLaunchKernelGGL((pileup_direct_kernel<LB, BQ, DBL>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p)
   if (lane_bases == 32) {
-    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
-    else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    if (bq0) { if (db) MIDAS_LAUNCH_DIRECT(32, true, true); else MIDAS_LAUNCH_DIRECT(32, true, false); }
+    else { if (db) MIDAS_LAUNCH_DIRECT(32, false, true); else MIDAS_LAUNCH_DIRECT(32, false, false); }
   } else {
-    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<30, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
-    else hipLaunchKernelGGL((pileup_direct_kernel<30, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    if (bq0) { if (db) MIDAS_LAUNCH_DIRECT(30, true, true); else MIDAS_LAUNCH_DIRECT(30, true, false); }
+    else { if (db) MIDAS_LAUNCH_DIRECT(30, false, true); else MIDAS_LAUNCH_DIRECT(30, false, false); }
   }
+#undef MIDAS_LAUNCH_DIRECT
   return hipGetLastError();
 }
 
