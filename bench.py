@@ -6,19 +6,22 @@
       --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one full pass of the hot path FROM THE BAM-NATIVE ARRAYS resident in HBM (pos, mapq, NM, l_seq, CSR offsets,
-4-bit SEQ, QUAL, CIGAR -- what the BAM decoder hands over) to the per-site counts: the device's index pass (one thread per
-read: validation, CIGAR class, per-tile read ranges -- the index_bam analogue), then the pileup kernel, which reads SEQ /
-QUAL / CIGAR where they are: read filter (keep_read), CIGAR walk, mean-quality reduction, A/C/G/T tallies per site, counts
-+ ref allele emission and the per-species counters.  Nothing is sorted, packed or cached between steps.  With N > 1 a rank's
-K steps are its share of the job and the job's one exchange -- the all-gather of every rank's per-species summary rows over
-RCCL -- follows them, inside the timed region.
+4-bit SEQ, QUAL, CIGAR -- what the BAM decoder hands over) to the per-site counts: the ranges pass (positions only, 4 bytes
+per read: per tile the run of reads that can touch it -- the index_bam analogue), then the pileup kernel, which visits every
+read ONCE: it fetches the read's columns, SEQ, QUAL and CIGAR where they are, decides the CIGAR's shape in registers, filters
+(keep_read), reduces the mean quality, tallies A/C/G/T per site and emits counts, ref alleles and the per-species counters.
+Nothing is sorted, packed, described or cached between steps.  With N > 1 a rank's K steps are its share of the job and the
+job's one exchange -- the all-gather of every rank's per-species summary rows over RCCL -- follows them, inside the timed
+region.
 
 Workload (default): BASELINE.json configs[2], the largest single-GPU configuration -- 20 species, 80 Mb, 10 666 667 aligned
 synthetic 150 bp reads (20x) per GPU (`--config c2` = configs[1]; `--config c4_rank` = one rank's share of configs[3]).
-Multi-GPU default is weak scaling: every rank owns its own configs[2]-sized set of species.  `--config c4` is
-BASELINE.json configs[3] itself -- 100 species, 400 Mb, 80 M aligned reads -- dealt to the N ranks contig by contig with the
-product's partitioner (midas_amd.dist.shard_items, the weights of midas_amd/run/snps.py): strong scaling, no data-path
-collective, one all-gather of the summary rows.
+Multi-GPU: the line's own figures are weak scaling -- every rank owns its own configs[2]-sized set of species, so N = 1
+agrees with the single-GPU line -- and, with no extra flag, the same line carries `configs3_strong`: BASELINE.json
+configs[3] itself -- ONE sample of 100 species, 400 Mb, 80 M aligned reads -- dealt to the N ranks contig by contig with
+the product's partitioner (midas_amd.dist.shard_items, the weights of midas_amd/run/snps.py): strong scaling, no data-path
+collective, one RCCL all-gather of the summary rows, 400 M sites / the slowest rank (`--configs3` adds the block at N = 1,
+`--config c4` makes configs[3] the line's own workload).
 
 Secondary figures in the same JSON line: the step over a resident PACKED batch (`value_resident_packed`: the tile-ordered
 records + one byte per base of pack_reads.hip, built once, outside the region), the device copy rate of this box, the CPU
@@ -47,7 +50,12 @@ WORKLOADS = {
     "c4": "configs[3]: 100 species (1600 contigs x 250 kb = 400 Mb), 80M aligned synthetic 150 bp reads (30x on average, "
           "log-normal abundances), contig-sharded over the ranks by midas_amd.dist.shard_items",
 }
-STEP_KERNELS = ["direct_classify_kernel", "direct_scan_kernel", "direct_fill_kernel", "pileup_direct_kernel"]
+STEP_KERNELS = ["direct_ranges_kernel", "pileup_direct_kernel"]
+CALIB_BYTES = 1 << 30
+# how a step kernel's read bytes split over load widths (bytes per lane): weights of the calibrated FETCH_SIZE factors.
+# ranges: pos[i], pos[i-1] dwords.  pileup, per 150 bp read: 241 B by 16-byte loads (QUAL 150, SEQ 75, first CIGAR ops 16),
+# 13 B by dword / byte loads (pos, l_seq, NM, mapq), 16 B by 8-byte loads (SEQ / QUAL offsets), 12 B by a 12-byte load.
+LOAD_MIX = {"direct_ranges_kernel": {4: 1.0}, "pileup_direct_kernel": {16: 241.0 / 282.0, 8: 28.0 / 282.0, 4: 13.0 / 282.0}}
 
 
 def load_pmc_traffic(key, workload):
@@ -152,6 +160,7 @@ def pmc_child(path, steps):
         b.run(thr)
     b.sync()
     b.close()
+    ctx.calibration_pass(CALIB_BYTES)      # known byte counts at 4 / 8 / 16 bytes per lane: the counters' factors
     ctx.close()
 
 
@@ -179,31 +188,112 @@ def measure_traffic(contigs, reads, steps=6):
             cur = sqlite3.connect(dbs[0]).cursor()
             q = "select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name"
             rows_ = list(cur.execute(q, (counter,)))
-            sorted_variant = any("direct_classify_kernel<true>" in r[0] for r in rows_)
             for name, v, n in rows_:
-                if sorted_variant and "direct_classify_kernel<false>" in name:
-                    continue        # (the batch's creation runs the classify kernel's atomic variant once: not part of a step)
-                for k in STEP_KERNELS:
+                for k in STEP_KERNELS + ["midas_calib_read4_kernel", "midas_calib_read8_kernel", "midas_calib_read16_kernel",
+                                         "midas_calib_write16_kernel"]:
                     if k in name:
                         e = per.setdefault(k, {})
                         e[counter] = float(v)
                         e[counter + "_launches"] = int(n)
+        # the counters' factors for this box and these access widths: known bytes / (counter KiB * 1024)
+        calib = {}
+        for w in (4, 8, 16):
+            v = per.pop("midas_calib_read%d_kernel" % w, {}).get("FETCH_SIZE")
+            calib["fetch_factor_%dB_per_lane" % w] = CALIB_BYTES / (v * 1024.0) if v else None
+        v = per.pop("midas_calib_write16_kernel", {}).get("WRITE_SIZE")
+        calib["write_factor_16B_per_lane"] = CALIB_BYTES / (v * 1024.0) if v else None
         total_r = total_w = 0.0
         for k, e in per.items():
-            rd = e.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
-            wr = e.get("WRITE_SIZE", 0.0) * 1024.0
+            mix = LOAD_MIX.get(k, {16: 1.0})
+            fr = sum(wt * (calib.get("fetch_factor_%dB_per_lane" % w) or 2.0) for w, wt in mix.items())
+            fw = calib.get("write_factor_16B_per_lane") or 1.0
+            rd = e.get("FETCH_SIZE", 0.0) * 1024.0 * fr
+            wr = e.get("WRITE_SIZE", 0.0) * 1024.0 * fw
+            e["fetch_factor"] = fr
+            e["write_factor"] = fw
             e["hbm_read_bytes_corrected"] = rd
             e["hbm_write_bytes"] = wr
             total_r += rd
             total_w += wr
         return {"per_kernel": per, "hbm_bytes_per_step": total_r + total_w, "hbm_read_bytes": total_r, "hbm_write_bytes": total_w,
-                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this box; bytes = KiB*1024, "
-                          "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads; narrow column loads are "
-                          "over-corrected by that), WRITE_SIZE uncorrected"}
+                "calibration": calib,
+                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this box; bytes = KiB * 1024 * "
+                          "factor, the factor CALIBRATED in the same passes by kernels that move a known 1 GiB with 4-, 8- and "
+                          "16-byte-per-lane loads / 16-byte stores (midas_snps_calibration_pass) and applied per kernel by the "
+                          "byte mix of its load widths (bench.py LOAD_MIX); averages include the one ranges launch of batch_create"}
     except Exception as e:  # a courtesy measurement: never fail the bench on it
         return {"error": str(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def configs3_strong(ctx, thr, rank, world, collective, steps):
+    """BASELINE.json configs[3] as the product deals it: ONE 100-species sample (400 Mb, 80 M aligned reads), its contigs dealt
+    to the ranks by midas_amd.dist.shard_items, every rank piling up its share, one all-gather of the summary rows per job.
+    Strong scaling: value = 400 M sites / the slowest rank.  Returns the block rank 0 prints (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    from midas_amd import abi, synth
+    contigs, reads, share = synth.c4_share(rank, world)
+    batch = ctx.batch(contigs, reads)
+    info = batch.info()
+    n_sp = contigs.n_species
+    rows = torch.zeros((n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
+    gathered = torch.zeros((world, n_sp, abi.NUM_STATS), dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        batch.run(thr)
+    batch.sync()
+    if collective:
+        dist.all_gather_into_tensor(gathered, rows)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    batch.enable_timing(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run(thr)
+    batch.stats_to_device(rows.data_ptr())
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                      # this rank's share of the job, steps times
+    if collective:
+        dist.all_gather_into_tensor(gathered, rows)     # the job's one exchange: every rank's per-species rows
+        torch.cuda.synchronize()
+    else:
+        gathered[0].copy_(rows)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    batch.sync()
+    tm = [batch.timing(i) for i in range(steps)]
+    kern = float(np.mean([t["index_ms"] + t["pileup_ms"] for t in tm]))
+    vals = torch.tensor([own, elapsed, kern, float(info.n_sites), float(info.n_reads), float(info.algorithmic_bytes)], dtype=torch.float64, device="cuda")
+    allv = torch.zeros((world, vals.numel()), dtype=torch.float64, device="cuda")
+    if collective:
+        dist.all_gather_into_tensor(allv, vals)
+    else:
+        allv[0].copy_(vals)
+    allv = allv.cpu().numpy()
+    total = gathered.sum(dim=0).cpu().numpy()           # the fold snps_summary does: per-species counters over the ranks
+    batch.close()
+    if rank != 0:
+        return None
+    own_ms = (allv[:, 0] / steps * 1e3).tolist()
+    kern_ms = allv[:, 2].tolist()
+    job = float(allv[:, 1].max())
+    sites = float(allv[:, 3].sum())
+    return {
+        "workload": WORKLOADS["c4"], "scaling": "strong", "steps": steps,
+        "value": sites * steps / job, "unit": "sites/s", "ms_per_step": job / steps * 1e3,
+        "total_sites": int(sites), "total_reads": int(allv[:, 4].sum()),
+        "ranks": int(world), "collective": "RCCL all_gather_into_tensor of int64[n_species=%d][%d] per rank (torch.distributed "
+                                           "backend nccl, world size %d)" % (n_sp, abi.NUM_STATS, dist.get_world_size() if collective else 1)
+                                           if collective else "none (one rank, no --force-collective)",
+        "per_rank_ms_per_step": own_ms, "per_rank_kernels_ms": kern_ms,
+        "rank_time_max_over_mean": max(own_ms) / (sum(own_ms) / len(own_ms)),
+        "partition": {"items": share["n_items"], "weight_max_over_mean": share["imbalance"]},
+        "roofline_frac_slowest_rank": float((allv[:, 5] / (allv[:, 2] * 1e-3) / 1e9 / HBM_PEAK_GBPS).min()),
+        "reads_counted_once": bool(int(total[:, abi.STAT_ALIGNED_READS].sum()) == int(allv[:, 4].sum())),
+    }
 
 
 def main():
@@ -218,6 +308,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 traffic measurement")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="untimed back-to-back steps in front of the timed region (the driver's GPU-busy sampler sees them)")
+    ap.add_argument("--configs3", action="store_true",
+                    help="add the configs3_strong block (BASELINE configs[3] dealt to the ranks) at N = 1 too; always on for N > 1")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the summary all-gather even with one rank (exercises the N>1 step on a 1-GPU box)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
@@ -353,6 +445,10 @@ def main():
         finally:
             batch.select_path(abi.PATH_AUTO)
 
+    strong = None
+    if (world > 1 or a.configs3) and a.config != "c4":
+        strong = configs3_strong(ctx, thr, rank, world, collective, max(1, min(a.steps, 50)))
+
     out = None
     if rank == 0:
         achieved = info.algorithmic_bytes / (step_kernels_ms * 1e-3) / 1e9
@@ -369,15 +465,15 @@ def main():
             "data": "synthetic (seeded generator midas_amd/synth.py; SURVEY 8d distributions)",
             "config": {"workload": WORKLOADS.get(a.config, a.config),
                        "step": "BAM-native arrays resident in HBM -> per-site counts, alleles and per-species counters "
-                               "(device index pass + pileup kernel; path: %s)" % path,
+                               "(ranges pass + pileup kernel, one visit per read; path: %s)" % path,
                        "sites_per_gpu": int(info.n_sites), "reads_per_gpu": int(info.n_reads),
                        "thresholds": args,
                        "parallelism": ("contig-sharded x%d (dist.shard_items), " % world if a.config == "c4" else
                                        "species-sharded x%d, " % world) + "one RCCL all-gather of the summary rows per job"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm",
-                         "kernel": "the step's kernels: direct_classify_kernel + direct_scan_kernel + direct_fill_kernel (index "
-                                   "pass) + pileup_direct_kernel" if path == "direct" else "index_reads_kernel + pileup_tiles_kernel",
+                         "kernel": "the step's kernels: direct_ranges_kernel (positions -> per-tile read ranges) + "
+                                   "pileup_direct_kernel (one visit per read)" if path == "direct" else "index_reads_kernel + pileup_tiles_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(info.algorithmic_bytes),
@@ -399,17 +495,22 @@ def main():
             per = [float(x) / a.steps * 1e3 for x in el_all.cpu().tolist()]
             out["per_rank_ms_per_step"] = per
             out["rank_time_max_over_mean"] = max(per) / (sum(per) / len(per))
+        if strong is not None:
+            out["configs3_strong"] = strong
         if packed is not None:
             out["value_resident_packed"] = packed["value"]
             out["resident_packed"] = packed
         if world == 1:
-            try:      # the practical ceiling of this box: the library's own 16-bytes-per-lane copy kernel, the same minute
-                ceil = ctx.copy_rate(1 << 30, 10)
-                out["roofline"]["copy_ceiling_GBps_this_box"] = ceil
-                out["roofline"]["copy_ceiling_method"] = "midas_snps_copy_rate: 10 passes of a 16-bytes-per-lane copy kernel over 1 GiB"
-                out["roofline"]["frac_of_copy_ceiling_this_box"] = achieved / ceil
+            try:      # what this box streams right now: kernels built to saturate (4 workgroups per CU, 16 B per lane, 4 GiB buffers)
+                rates = ctx.stream_rates(1 << 32, 3)
+                ceil = max(rates.values())
+                out["roofline"]["stream_rates_GBps_this_box"] = rates
+                out["roofline"]["ceiling_GBps_this_box"] = ceil
+                out["roofline"]["ceiling_method"] = ("midas_snps_stream_rates: read stream, write stream and copy over 4 GiB buffers, "
+                                                     "3 passes each; the ceiling is the largest of the three")
+                out["roofline"]["frac_of_ceiling_this_box"] = achieved / ceil
             except Exception as e:
-                out["roofline"]["copy_ceiling_error"] = str(e)
+                out["roofline"]["ceiling_error"] = str(e)
             if not a.no_pmc:
                 live = measure_traffic(contigs, reads)
                 if live is not None:
@@ -418,9 +519,10 @@ def main():
                         out["roofline"]["traffic"] = live["hbm_bytes_per_step"]
                         out["roofline"]["traffic_source"] = "rocprofv3 --pmc on this box (roofline.traffic_this_box)"
                         out["roofline"]["traffic_over_algorithmic"] = live["hbm_bytes_per_step"] / info.algorithmic_bytes
-                        if "copy_ceiling_GBps_this_box" in out["roofline"]:
-                            out["roofline"]["hbm_traffic_frac_of_copy_ceiling_this_box"] = \
-                                live["hbm_bytes_per_step"] / (step_kernels_ms * 1e-3) / 1e9 / out["roofline"]["copy_ceiling_GBps_this_box"]
+                        if "ceiling_GBps_this_box" in out["roofline"]:
+                            out["roofline"]["hbm_traffic_GBps"] = live["hbm_bytes_per_step"] / (step_kernels_ms * 1e-3) / 1e9
+                            out["roofline"]["hbm_traffic_frac_of_ceiling_this_box"] = \
+                                out["roofline"]["hbm_traffic_GBps"] / out["roofline"]["ceiling_GBps_this_box"]
         if world == 1 and not a.no_cpu:
             cb, cb_all, cb_species, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
             out["cpu_baseline"] = cb

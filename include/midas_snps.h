@@ -165,6 +165,17 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
  * `reps` passes of the library's own 16-bytes-per-lane copy kernel over `bytes` (>= 1 MiB), timed with HIP events.  The
  * practical HBM ceiling the roofline fractions of bench.py are also held against (measurement aid; no reference counterpart). */
 int32_t midas_snps_copy_rate(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, double* out_gbps);
+/* The same question asked properly: a read stream, a write stream and a copy over `bytes` per buffer (use >= 4 GiB: far
+ * beyond the 256 MiB Infinity Cache), `reps` passes each, by kernels built to saturate the memory pipe (a persistent grid
+ * of 4 workgroups per CU, 16 bytes per lane, four independent accesses in flight).  out_gbps[0] bytes read per second by the
+ * read stream, [1] bytes written per second by the write stream, [2] bytes read + written per second by the copy.  bench.py
+ * quotes the largest of them as this box's ceiling (measurement aid; no reference counterpart).                       */
+int32_t midas_snps_stream_rates(midas_snps_ctx* ctx, int64_t bytes, int32_t reps, double out_gbps[3]);
+/* Counter calibration for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: reads `bytes` once with 4-, 8- and 16-byte-per-lane
+ * loads and writes them once with 16-byte stores, one kernel each (midas_calib_read4_kernel, _read8_, _read16_,
+ * midas_calib_write16_kernel): the counter value of each against the bytes it is known to move is the factor bench.py
+ * applies to a product kernel with that access width (measurement aid; no reference counterpart).                     */
+int32_t midas_snps_calibration_pass(midas_snps_ctx* ctx, int64_t bytes);
 
 /* Page-locked host memory (hipHostMalloc).  Optional: every entry point takes ordinary memory; result buffers that come
  * from here are filled by one DMA instead of through the context's staging ring, and a caller that keeps them for the

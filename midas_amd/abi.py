@@ -235,6 +235,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_batch_select_path': (i32, [vp, i32]),
         'midas_snps_set_default_path': (i32, [vp, i32]),
         'midas_snps_set_pad_rule': (i32, [vp, i32]),
+        'midas_snps_stream_rates': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
+        'midas_snps_calibration_pass': (i32, [vp, i64]),
         'midas_snps_set_row_coder': (i32, [vp, i32]),
         'midas_snps_pack_set_pad_rule': (None, [i32]),
         'midas_snps_copy_rate': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
@@ -302,7 +304,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_sync', 'midas_snps_batch_fetch', 'midas_snps_batch_get_info',
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
-    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_set_pad_rule', 'midas_snps_set_row_coder',
+    'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_stream_rates', 'midas_snps_calibration_pass', 'midas_snps_set_pad_rule', 'midas_snps_set_row_coder',
     'midas_snps_pack_set_pad_rule',
     'midas_snps_batch_pack_timing',
     'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
@@ -815,6 +817,16 @@ class Context:
         out = C.c_double(0.0)
         self._check(self._lib.midas_snps_copy_rate(self._h, int(nbytes), int(reps), C.byref(out)))
         return out.value
+
+    def stream_rates(self, nbytes: int = 1 << 32, reps: int = 5):
+        """GB/s of a saturating read stream, write stream and copy (read + written) over nbytes per buffer."""
+        out = (C.c_double * 3)()
+        self._check(self._lib.midas_snps_stream_rates(self._h, int(nbytes), int(reps), out))
+        return {"read_GBps": out[0], "write_GBps": out[1], "copy_GBps": out[2]}
+
+    def calibration_pass(self, nbytes: int = 1 << 30):
+        """The known-byte-count kernels that calibrate FETCH_SIZE / WRITE_SIZE (run it under rocprofv3 --pmc)."""
+        self._check(self._lib.midas_snps_calibration_pass(self._h, int(nbytes)))
 
     def device_info(self):
         name = C.create_string_buffer(256)
