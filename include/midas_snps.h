@@ -99,7 +99,7 @@ typedef struct midas_snps_reads {
   const int64_t* cigar_off;
   const uint8_t* seq4;        /* these three: host memory, or memory of the context's device (midas_bam_load_device leaves  */
   const uint8_t* qual;        /* them there) -- all three alike; midas_snps_batch_create / midas_snps_pileup copy either way;     */
-  const uint32_t* cigar;      /* the host-only entry points (midas_snps_pack_reads*) take host memory only                        */
+  const uint32_t* cigar;      /* the host-only entry points (midas_snps_write_*, midas_genes_*) take host memory only                 */
 } midas_snps_reads;
 
 /* Contig table: what initialize_contigs() builds (midas/run/snps.py:55-67), flattened.
@@ -252,7 +252,7 @@ int32_t midas_snps_set_row_coder(midas_snps_ctx* ctx, int32_t coder);
  * "raw reads resident in HBM -> counts" (pack + run).  Returns after the pack has finished (the hot-spot plan needs
  * the per-tile read counts on the host).                                                                          */
 int32_t midas_snps_batch_pack(midas_snps_batch* batch);
-/* Copy the packed device layout back (tests: it must equal midas_snps_pack_reads' host mirror bit for bit).
+/* Copy the packed device layout back (tests: it must equal the host mirror tests/mirror/pack_mirror.cpp bit for bit).
  * rec16 [(n_records+1)*16], blob [blob_bytes], orig_index / key [n_records]; any pointer may be NULL; the two sizes
  * are always returned.                                                                                            */
 int32_t midas_snps_batch_fetch_packed(midas_snps_batch* batch, void* rec16, void* blob, uint32_t* orig_index,
@@ -302,29 +302,6 @@ int32_t midas_snps_batch_timing(midas_snps_batch* batch, int32_t slot, float out
  * RCCL; the counters never round-trip through the host.  Replaces the pickled (species_id, aln_stats)
  * tuples returned through the Pool pipe (midas/run/snps.py:216, 228).                             */
 int32_t midas_snps_batch_stats_to_device(midas_snps_batch* batch, void* dst_device_i64);
-
-/* ---- host-only helpers (no GPU needed) -------------------------------------
- * The host mirror of the device packer (batch_create packs on the GPU; this is the same layout computed on the CPU),
- * exposed so that CPU-only tests can pin the device layout and GPU tests can hold the device packer to it.  A read whose
- * CIGAR is clips at the ends around M/=/X/I/D/N ops becomes one device record per gap-free match segment; any other
- * read becomes one record that keeps its CIGAR.  *out_blob_bytes and *out_n_records always receive the payload size
- * and the record count; if rec16/blob are non-NULL they receive (n_records+1)*16 bytes of records (the last one a
- * sentinel holding the end of the payload) and the payload itself.  `contigs` may be NULL (then the "CIGAR reaches
- * past SEQ inside the contig" record flag is computed against unbounded contigs).                                   */
-int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs,
-                              void* rec16, void* blob, int64_t blob_capacity, int64_t* out_blob_bytes,
-                              int64_t* out_n_records, int32_t* out_max_l_seq, char* err256);
-/* The pad rule (midas_snps_set_pad_rule) of the two host mirrors: process-wide, MIDAS_SNPS_PAD_SPEC unless set. */
-void midas_snps_pack_set_pad_rule(int32_t rule);
-
-/* The same mirror in the tile order of a batch (4096-site tiles; `contigs` required): what batch_create's device packer
- * must produce bit for bit -- records and payload in device order, orig_index[d] = input index of device record d,
- * key[d] = its index key (tile << 7 | reach << 2 | class).  orig_index / key may be NULL; rec16 == blob == NULL is a
- * size query.                                                                                                       */
-int32_t midas_snps_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16,
-                                    void* blob, int64_t blob_capacity, uint32_t* orig_index, uint32_t* key,
-                                    int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq,
-                                    char* err256);
 
 /* ---- host I/O (no GPU needed) ------------------------------------------------
  * BAM decode.  Replaces `pysam.AlignmentFile(bampath, 'rb')` and htslib's record decode

@@ -238,14 +238,10 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_stream_rates': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
         'midas_snps_calibration_pass': (i32, [vp, i64]),
         'midas_snps_set_row_coder': (i32, [vp, i32]),
-        'midas_snps_pack_set_pad_rule': (None, [i32]),
         'midas_snps_copy_rate': (i32, [vp, i64, i32, C.POINTER(C.c_double)]),
         'midas_snps_batch_fetch_packed': (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
         'midas_snps_batch_pack_timing': (i32, [vp, i32, C.POINTER(C.c_float)]),
-        'midas_snps_pack_reads': (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p]),
     }
-    sig['midas_snps_pack_reads_tiled'] = (i32, [C.POINTER(_Reads), C.POINTER(_Contigs), vp, vp, i64, vp, vp, C.POINTER(i64),
-                                                 C.POINTER(i64), C.POINTER(i32), C.c_char_p])
     sig.update({
         'midas_bam_open': (i32, [C.c_char_p, C.POINTER(vp), C.c_char_p]),
         'midas_bam_close': (None, [vp]),
@@ -305,9 +301,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_enable_timing', 'midas_snps_batch_timing', 'midas_snps_batch_time_pileup_only',
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
     'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_stream_rates', 'midas_snps_calibration_pass', 'midas_snps_set_pad_rule', 'midas_snps_set_row_coder',
-    'midas_snps_pack_set_pad_rule',
     'midas_snps_batch_pack_timing',
-    'midas_snps_pack_reads', 'midas_snps_pack_reads_tiled',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
     'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
@@ -643,53 +637,6 @@ class BamSlice:
             self._h = None
 
     __del__ = close
-
-
-def pack_reads(reads: ReadsSoA, contigs: Optional["ContigTable"] = None):
-    """Host-only: run the packer and return (rec[n_records,16] uint8, blob uint8, max_l_seq).  n_records >= n_reads:
-    a read with indels or clips is served as one record per match segment (layout.h)."""
-    lib = load_library()
-    r = reads._c()
-    cc = contigs._c() if contigs is not None else None
-    cp = C.byref(cc) if cc is not None else None
-    nbytes = C.c_int64(0)
-    nrec = C.c_int64(0)
-    maxl = C.c_int32(0)
-    err = C.create_string_buffer(256)
-    st = lib.midas_snps_pack_reads(C.byref(r), cp, None, None, 0, C.byref(nbytes), C.byref(nrec), C.byref(maxl), err)
-    if st != 0:
-        raise MidasSnpsError(st, err.value.decode())
-    n = int(nrec.value)
-    rec = np.zeros((n + 1, 16), dtype=np.uint8)   # + sentinel record
-    blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
-    st = lib.midas_snps_pack_reads(C.byref(r), cp, rec.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p),
-                                   blob.size, C.byref(nbytes), C.byref(nrec), C.byref(maxl), err)
-    if st != 0:
-        raise MidasSnpsError(st, err.value.decode())
-    return rec[:n], blob[:int(nbytes.value)], int(maxl.value)
-
-
-def pack_reads_tiled(reads: ReadsSoA, contigs: "ContigTable"):
-    """Host mirror of the device packer in a batch's tile order -> (rec[n+1,16] u8 incl. sentinel, blob, orig u32, key u32)."""
-    lib = load_library()
-    r, cc = reads._c(), contigs._c()
-    nbytes, nrec, maxl = C.c_int64(0), C.c_int64(0), C.c_int32(0)
-    err = C.create_string_buffer(256)
-    st = lib.midas_snps_pack_reads_tiled(C.byref(r), C.byref(cc), None, None, 0, None, None, C.byref(nbytes), C.byref(nrec),
-                                         C.byref(maxl), err)
-    if st != 0:
-        raise MidasSnpsError(st, err.value.decode())
-    n = int(nrec.value)
-    rec = np.zeros((n + 1, 16), dtype=np.uint8)
-    blob = np.zeros(max(int(nbytes.value), 1), dtype=np.uint8)
-    orig = np.zeros(max(n, 1), np.uint32)
-    key = np.zeros(max(n, 1), np.uint32)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    st = lib.midas_snps_pack_reads_tiled(C.byref(r), C.byref(cc), p(rec), p(blob), blob.size, p(orig), p(key), C.byref(nbytes),
-                                         C.byref(nrec), C.byref(maxl), err)
-    if st != 0:
-        raise MidasSnpsError(st, err.value.decode())
-    return rec, blob[:int(nbytes.value)], orig[:n], key[:n]
 
 
 class PinnedPool:

@@ -54,9 +54,12 @@ def write_bam(path, ref_names, ref_lengths, refid, reads, read_names=None, heade
         f.write(_EOF_BLOCK)
 
 
-def group_by_contig(ref_names, refid, reads, contig_ids):
+def group_by_contig(ref_names, refid, reads, contig_ids, fetch=None):
     """Records of a decoded BAM -> (ReadsSoA in contig-table order, read_begin) for the given contig ids.
-    A coordinate-sorted BAM is already grouped by refID; anything else is stably regrouped."""
+    A coordinate-sorted BAM is already grouped by refID; anything else -- records of contigs that are not wanted among
+    them (species.txt edited after the alignment, a BAM from elsewhere), records out of refID order -- is stably regrouped.
+    `fetch`: brings SEQ / QUAL / CIGAR down when they were left on the device (Context.fetch_payload): the regroup slices
+    them, which it can only do in host memory."""
     from .abi import ReadsSoA
     index_of = {n: i for i, n in enumerate(ref_names)}
     want = np.array([index_of.get(c, -1) for c in contig_ids], dtype=np.int64)
@@ -73,7 +76,9 @@ def group_by_contig(ref_names, refid, reads, contig_ids):
             np.cumsum(hi - lo, out=read_begin[1:])
             return reads, read_begin
     if getattr(reads, 'device', None) is not None:
-        raise ValueError("the reads' SEQ / QUAL / CIGAR are on the device: fetch them (Context.fetch_payload) before regrouping")
+        if fetch is None:
+            raise ValueError("the reads' SEQ / QUAL / CIGAR are on the device: fetch them (Context.fetch_payload) before regrouping")
+        reads = fetch(reads)
     rank = np.full(len(ref_names) + 1, -1, dtype=np.int64)
     for k, r in enumerate(want):
         if r >= 0:

@@ -19,7 +19,7 @@
 #include "kernels.h"
 #include "layout.h"
 #include "hostio.h"
-#include "pack.h"
+#include "contigs.h"
 #include "workers.h"
 
 #include <algorithm>
@@ -713,8 +713,6 @@ int32_t midas_snps_set_pad_rule(midas_snps_ctx* ctx, int32_t rule) {
   return MIDAS_SNPS_OK;
 }
 
-void midas_snps_pack_set_pad_rule(int32_t rule) { midas::g_pad_advances = rule == MIDAS_SNPS_PAD_PYSAM ? 1 : 0; }
-
 int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path) {
   if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
   ctx->default_path = path;
@@ -727,30 +725,6 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
   if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
   return MIDAS_SNPS_OK;
-}
-
-int32_t midas_snps_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob, int64_t blob_capacity,
-                              int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
-  PackSummary s;
-  int32_t st = pack_reads(reads, contigs, 0, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr, nullptr,
-                          blob_capacity, &s, err256);
-  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
-  if (out_n_records) *out_n_records = s.n_records;
-  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
-  return st;
-}
-
-int32_t midas_snps_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, void* rec16, void* blob,
-                                    int64_t blob_capacity, uint32_t* orig_index, uint32_t* key, int64_t* out_blob_bytes,
-                                    int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
-  PackSummary s;
-  if (!contigs) return MIDAS_SNPS_ERR_INVALID_ARG;
-  int32_t st = pack_reads(reads, contigs, kTileSites, reinterpret_cast<ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
-                          orig_index, key, blob_capacity, &s, err256);
-  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
-  if (out_n_records) *out_n_records = s.n_records;
-  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
-  return st;
 }
 
 void midas_snps_batch_destroy(midas_snps_batch* b) {

@@ -267,7 +267,7 @@ def _exit_on(e):
     raise e
 
 
-def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid, reads, halo=None):
+def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid, reads, halo=None, fetch=None):
     """(ContigTable, ReadsSoA, keys) for the given work items -- (contig id, piece number), span[item] = (lo, hi, last):
     contigs in BAM header order (pieces of one contig in position order), reads regrouped to match; keys[k] = the item of
     table entry k.  Whole contigs only: the table of the reference's loop (midas/run/snps.py:187-199); with pieces the
@@ -285,7 +285,7 @@ def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid,
             sys.exit("\nError: contig '%s' has length %d in the BAM header but %d in the FASTA\n"
                      % (c.id, ref_lens[order[c.id]], c.length))
     ids = [c.id for c in mine]
-    sub, read_begin = bam.group_by_contig(ref_names, refid, reads, ids)
+    sub, read_begin = bam.group_by_contig(ref_names, refid, reads, ids, fetch=fetch)
     if all(span[it][0] == 0 and span[it][2] for it in items):
         ref = _reference_bytes([(c, 0, c.length) for c in mine])
         table = abi.ContigTable(length=[c.length for c in mine], species=[sp_index[c.species_id] for c in mine],
@@ -352,7 +352,8 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, c
     {species_id: partial aln_stats} (sums over this rank's items).  Writes <species>.snps.gz directly when this rank owns
     every item of the species, else one part file per run of consecutive (emit order) items it owns."""
     ref_names, ref_lens, refid, reads = decoded
-    table, sub, keys = _contig_table(species_ids, mine, span, contigs, ref_names, ref_lens, refid, reads, halo)
+    table, sub, keys = _contig_table(species_ids, mine, span, contigs, ref_names, ref_lens, refid, reads, halo,
+                                     fetch=getattr(ctx, 'fetch_payload', None))
     thr = abi.Thresholds.from_args(args)
     batch = None
     if mine and hasattr(ctx, 'batch'):
@@ -582,6 +583,10 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)
     with stack:
+        # the drop-in runs the dependency's rule for the CIGAR op P (pysam's get_aligned_pairs treats BAM_CPAD like an
+        # insertion: the query position advances); --pad_rule spec selects the SAM specification's (P consumes nothing)
+        if hasattr(ctx, 'set_pad_rule'):
+            ctx.set_pad_rule(abi.PAD_SPEC if args.get('pad_rule', 'pysam') == 'spec' else abi.PAD_PYSAM)
         return _count_alleles(args, species, contigs, ctx)
 
 
@@ -625,9 +630,6 @@ def _count_alleles(args, species, contigs, ctx):
         try:
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
             decoded = abi.read_bam(bampath, inflater, payload_on_device=inflater is not None and ws == 1)
-            if decoded[3].device is not None and decoded[2].size > 1 and not bool((decoded[2][1:] >= decoded[2][:-1]).all()):
-                # records not grouped by reference: the regroup slices the payload, which it can only do in host memory
-                decoded = decoded[:3] + (ctx.fetch_payload(decoded[3]),)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)

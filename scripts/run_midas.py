@@ -148,6 +148,10 @@ def build_parser():
     parser.add_argument('--device_inflate', choices=('auto', 'on', 'off'), default='auto',
                         help="inflate the BAM's blocks on the GPU instead of with the host's threads; auto (default): for one "
                              "rank and a BAM of 0.5-8 GB")
+    parser.add_argument('--pad_rule', choices=('pysam', 'spec'), default='pysam',
+                        help="what the CIGAR op P does to the query position in the pileup: pysam (default) = it advances, as in\n"
+                             "get_aligned_pairs of the pysam releases MIDAS runs on; spec = nothing, the SAM specification's rule.\n"
+                             "bowtie2 never writes P: the choice only matters for BAMs from elsewhere")
     for title, options in OPTION_GROUPS:
         group = parser.add_argument_group(title)
         for flags, kw in options:

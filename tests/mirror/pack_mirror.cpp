@@ -1,6 +1,8 @@
-// Host packer: BAM-native SoA records -> the device layout of layout.h.
-// Validates everything the kernels assume, so that malformed input is an error status, never UB.
-#include "pack.h"
+// TEST INFRASTRUCTURE (not part of the product library): the host mirror of the device packer (midas_amd/csrc/pack_reads.hip).
+// BAM-native SoA records -> the device layout of layout.h, computed the plain way on the CPU: the CPU tests pin the layout on
+// it, the GPU tests hold the device packer to it bit for bit (tests/test_gpu_pack.py).  Built by tests/mirror/__init__.py
+// into tests/mirror/libmidas_snps_mirror.so.
+#include "pack_mirror.h"
 
 #include <algorithm>
 #include <atomic>
@@ -9,11 +11,11 @@
 #include <thread>
 #include <vector>
 
-#include "workers.h"
+#include "../../midas_amd/csrc/workers.h"
 
 namespace midas {
 
-int g_pad_advances = 0;   // midas_snps_pack_set_pad_rule: the CIGAR op P advances the query position (host mirror)
+thread_local int g_pad_advances = 0;   // the pad rule of the call in progress (every entry point takes it as an argument)
 
 namespace {
 
@@ -474,50 +476,38 @@ int32_t pack_reads(const midas_snps_reads* r, const midas_snps_contigs* contigs,
   return MIDAS_SNPS_OK;
 }
 
-int32_t validate_contigs(const midas_snps_contigs* c, int64_t n_reads, int64_t* out_sites, char* err256) {
-  if (!c || c->n_contigs < 0 || c->n_species < 0) {
-    set_err(err256, "bad contig table header");
-    return MIDAS_SNPS_ERR_INVALID_ARG;
-  }
-  if (c->n_contigs > 0 && (!c->length || !c->species || !c->read_begin || !c->ref)) {
-    set_err(err256, "NULL array in midas_snps_contigs");
-    return MIDAS_SNPS_ERR_INVALID_ARG;
-  }
-  int64_t sites = 0;
-  for (int32_t i = 0; i < c->n_contigs; ++i) {
-    if (c->length[i] <= 0) {
-      // reference: pysam raises ValueError("interval of size 0") for an empty contig
-      set_err(err256, "contig %lld has length %lld (count_coverage: interval of size 0)", i, c->length[i]);
-      return MIDAS_SNPS_ERR_UNSUPPORTED;
-    }
-    if (c->length[i] > 0x7FFFFFFFLL) {
-      set_err(err256, "contig %lld longer than 2^31-1 (BAM limit)", i);
-      return MIDAS_SNPS_ERR_UNSUPPORTED;
-    }
-    if (c->species[i] < 0 || c->species[i] >= c->n_species) {
-      set_err(err256, "contig %lld: species index %lld out of range", i, c->species[i]);
-      return MIDAS_SNPS_ERR_INVALID_ARG;
-    }
-    if (c->read_begin[i] < 0 || c->read_begin[i + 1] < c->read_begin[i]) {
-      set_err(err256, "read_begin not monotone at contig %lld", i);
-      return MIDAS_SNPS_ERR_BAD_LAYOUT;
-    }
-    if (c->origin && (c->origin[i] < 0 || c->origin[i] + c->length[i] > 0x7FFFFFFFLL)) {
-      set_err(err256, "contig %lld: piece origin %lld out of range", i, c->origin[i]);
-      return MIDAS_SNPS_ERR_INVALID_ARG;
-    }
-    sites += c->length[i];
-  }
-  if (c->n_contigs > 0 && (c->read_begin[0] != 0 || c->read_begin[c->n_contigs] != n_reads)) {
-    set_err(err256, "read_begin must start at 0 and end at n_reads (%lld)", (long long)n_reads);
-    return MIDAS_SNPS_ERR_BAD_LAYOUT;
-  }
-  if (c->n_contigs == 0 && n_reads != 0) {
-    set_err(err256, "reads without contigs");
-    return MIDAS_SNPS_ERR_BAD_LAYOUT;
-  }
-  *out_sites = sites;
-  return MIDAS_SNPS_OK;
-}
+
 
 }  // namespace midas
+
+extern "C" {
+
+// pad_rule: MIDAS_SNPS_PAD_SPEC / MIDAS_SNPS_PAD_PYSAM (include/midas_snps.h, midas_snps_set_pad_rule)
+int32_t midas_mirror_pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t pad_rule, void* rec16, void* blob,
+                                int64_t blob_capacity, int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
+  midas::g_pad_advances = pad_rule == MIDAS_SNPS_PAD_PYSAM ? 1 : 0;
+  midas::PackSummary s;
+  int32_t st = midas::pack_reads(reads, contigs, 0, reinterpret_cast<midas::ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob), nullptr, nullptr,
+                                 blob_capacity, &s, err256);
+  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
+  if (out_n_records) *out_n_records = s.n_records;
+  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
+  return st;
+}
+
+// the same in the tile order of a batch (tile_sites = the library's tile: 4096): what batch_create's device packer must produce
+int32_t midas_mirror_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t pad_rule, int32_t tile_sites,
+                                      void* rec16, void* blob, int64_t blob_capacity, uint32_t* orig_index, uint32_t* key,
+                                      int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
+  if (!contigs) return MIDAS_SNPS_ERR_INVALID_ARG;
+  midas::g_pad_advances = pad_rule == MIDAS_SNPS_PAD_PYSAM ? 1 : 0;
+  midas::PackSummary s;
+  int32_t st = midas::pack_reads(reads, contigs, tile_sites, reinterpret_cast<midas::ReadRec*>(rec16), reinterpret_cast<uint8_t*>(blob),
+                                 orig_index, key, blob_capacity, &s, err256);
+  if (out_blob_bytes) *out_blob_bytes = s.blob_bytes;
+  if (out_n_records) *out_n_records = s.n_records;
+  if (out_max_l_seq) *out_max_l_seq = s.max_l_seq;
+  return st;
+}
+
+}  // extern "C"

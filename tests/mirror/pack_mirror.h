@@ -1,6 +1,6 @@
 #pragma once
 #include "../../include/midas_snps.h"
-#include "layout.h"
+#include "../../midas_amd/csrc/layout.h"
 
 namespace midas {
 
@@ -20,12 +20,10 @@ struct PackSummary {
 // tile_len > 0 (needs `contigs`): device order = per tile window [simple reads][other reads]; orig_index[j]
 // (nullable, n_reads entries) receives the input index of device record j, key_out[j] (nullable) its index key
 // tile << 7 | min(reach, 31) << 2 | class (see index_reads.hip).
-extern int g_pad_advances;   // the CIGAR op P advances the query position (host mirror; midas_snps_pack_set_pad_rule)
+extern thread_local int g_pad_advances;   // the CIGAR op P advances the query position (set by the entry points from their pad_rule argument)
 int32_t pack_reads(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t tile_len, ReadRec* rec,
                    uint8_t* blob, uint32_t* orig_index, uint32_t* key_out, int64_t blob_capacity, PackSummary* out,
                    char* err256);
 
-int32_t validate_contigs(const midas_snps_contigs* contigs, int64_t n_reads, int64_t* out_sites,
-                         char* err256);
 
 }  // namespace midas

@@ -9,6 +9,7 @@ import pytest
 
 from midas_amd import abi, build, synth
 from tests import helpers as H
+from tests import mirror
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -108,7 +109,7 @@ def test_pack_layout_matches_design():
         dict(pos=9, cigar="5M", seq="ACGTN", nm=None, mapq=0),
         dict(pos=11, cigar="4M", seq="ACGT", qual="absent"),
     ])
-    rec, blob, maxl = abi.pack_reads(reads)
+    rec, blob, maxl = mirror.pack_reads(reads)
     assert maxl == 10 and rec.shape == (3, 16)
     r = rec.view(REC_DTYPE).reshape(3)
     # read 0 is served as its one match segment: the 7 aligned bases at pos 7 (the soft clip is in no record);
@@ -144,7 +145,7 @@ def test_pack_serves_reads_as_match_segments():
         dict(pos=500, cigar="10=1X20=119S", seq=seq, nm=1),      # -> one segment of 31
         dict(pos=700, cigar="2H10S30M5N40M3D60M10S4H", seq=seq, nm=3),   # three segments
     ])
-    rec, blob, _ = abi.pack_reads(reads)
+    rec, blob, _ = mirror.pack_reads(reads)
     r = rec.view(REC_DTYPE).reshape(-1)
     assert r["pos"].tolist() == [100, 175, 300, 372, 500, 700, 735, 778]
     assert (r["l"] & 0x7FF).tolist() == [75, 73, 70, 75, 31, 30, 40, 60]
@@ -163,7 +164,7 @@ def test_pack_uses_all_32_slots_where_that_saves_a_lane():
     seq = "".join("ACGT"[(5 * i) % 4] for i in range(125))
     quals = [30 + (i % 10) for i in range(125)]
     reads = H.reads_from_dicts([dict(pos=10, cigar="125M", seq=seq, nm=0, qual=quals)])
-    rec, blob, maxl = abi.pack_reads(reads)
+    rec, blob, maxl = mirror.pack_reads(reads)
     assert maxl == 125 and blob.size == 128
     assert blob.tolist() == base_bytes(seq, quals, lane_bases=32)
     assert not blob[125:128].any()
@@ -173,7 +174,7 @@ def test_pack_keeps_qualities_in_six_bits():
     """Qualities above 62 are stored as 62 (exact for every baseq <= 62, layout.h); 0xFF bytes (QUAL absent) too."""
     reads = H.reads_from_dicts([dict(pos=0, cigar="6M", seq="ACGTAC", qual=[0, 1, 61, 62, 63, 93]),
                                 dict(pos=0, cigar="4M", seq="ACGT", qual="absent")])
-    rec, blob, _ = abi.pack_reads(reads)
+    rec, blob, _ = mirror.pack_reads(reads)
     assert blob[:6].tolist() == [1 << 2 | 0, 2 << 2 | 1, 62 << 2 | 2, 63 << 2 | 3, 63 << 2 | 0, 63 << 2 | 1]
     assert blob[32:36].tolist() == [63 << 2 | 0, 63 << 2 | 1, 63 << 2 | 2, 63 << 2 | 3]
 
@@ -186,26 +187,26 @@ def test_pack_keeps_the_cigar_of_reads_it_cannot_segment():
     reads = H.reads_from_dicts([dict(pos=0, cigar=cg, seq=seq[:l]) for cg, l, _ in cases] +
                                [dict(pos=0, cigar="60M", seq=seq, nm=None), dict(pos=0, cigar="60M", seq=seq, nm=1024),
                                 dict(pos=-1, cigar="60M", seq=seq)])
-    rec, _, _ = abi.pack_reads(reads)
+    rec, _, _ = mirror.pack_reads(reads)
     r = rec.view(REC_DTYPE).reshape(-1)
     assert rec.shape[0] == len(cases) + 3
     assert ((r["flags"] & 2) == 0).all()                        # none of them is "simple"
     assert r["n"].tolist() == [1, 3, 3, 3, 1, 1, 1, 1, 1, 1]    # the op counts, i.e. the CIGARs are stored
     # seven match ops separated by insertions: more segments than a read may be served as
     many = H.reads_from_dicts([dict(pos=0, cigar="5M1I" * 6 + "5M", seq="A" * 41, nm=6)])
-    rec, _, _ = abi.pack_reads(many)
+    rec, _, _ = mirror.pack_reads(many)
     assert rec.shape[0] == 1 and not (rec[0, 15] & 2)
     six = H.reads_from_dicts([dict(pos=0, cigar="5M1I" * 5 + "5M", seq="A" * 35, nm=5)])
-    rec, _, _ = abi.pack_reads(six)
+    rec, _, _ = mirror.pack_reads(six)
     assert rec.shape[0] == 6 and all(rec[:, 15] & 2)
 
 
 def test_pack_overrun_flag_needs_the_contig_length():
     reads = H.reads_from_dicts([dict(pos=0, cigar="12M", seq="ACGTACGTAC"),      # query 10..11 -> sites 10..11
                                 dict(pos=15, cigar="12M", seq="ACGTACGTAC")])    # query 10..11 -> sites 25..26
-    rec, _, _ = abi.pack_reads(reads, H.single_contig(20, 2))
+    rec, _, _ = mirror.pack_reads(reads, H.single_contig(20, 2))
     assert (rec[:, 15] & 8).tolist() == [8, 0]      # the second read overruns only beyond the contig end
-    rec, _, _ = abi.pack_reads(reads, None)
+    rec, _, _ = mirror.pack_reads(reads, None)
     assert (rec[:, 15] & 8).tolist() == [8, 8]
 
 
@@ -217,7 +218,7 @@ def test_pack_cigar_fast_path_flags():
              ("5S5S140M", 150, 4, 1), ("140M5S5S", 150, 4, 1), ("2H148M", 148, 2, 1), ("10S", 10, 0, 1), ("5S5S", 10, 4, 1),
              ("75M2I73M", 150, 2, 2), ("75M2D75M", 150, 2, 2), ("150I", 150, 0, 1)]
     for cg, l, f, k in cases:
-        rec, _, _ = abi.pack_reads(H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l)]))
+        rec, _, _ = mirror.pack_reads(H.reads_from_dicts([dict(pos=0, cigar=cg, seq="A" * l)]))
         assert rec.shape[0] == k and (rec[0, 15] & 0x0F) == f, (cg, rec.shape[0], rec[0, 15] & 0x0F)
 
 
@@ -225,18 +226,18 @@ def test_pack_rejects_malformed_input_with_status():
     ok = H.reads_from_dicts([dict(pos=0, cigar="4M", seq="ACGT")])
     bad = abi.ReadsSoA(**{**ok.as_dict(), 'qual_off': np.array([0, 2], dtype=np.int64)})
     with pytest.raises(abi.MidasSnpsError) as ei:
-        abi.pack_reads(bad)
+        mirror.pack_reads(bad)
     assert ei.value.status == abi.ERR_BAD_LAYOUT
     long_read = H.reads_from_dicts([dict(pos=0, cigar="1025M", seq="A" * 1025)])
     with pytest.raises(abi.MidasSnpsError) as ei:
-        abi.pack_reads(long_read)
+        mirror.pack_reads(long_read)
     assert ei.value.status == abi.ERR_UNSUPPORTED
 
 
 def test_pack_round_trips_synthetic_reads():
     contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=9000, n_reads=3000,
                                         seed=5, var_len=True)
-    rec, blob, maxl = abi.pack_reads(reads, contigs)
+    rec, blob, maxl = mirror.pack_reads(reads, contigs)
     r = rec.view(REC_DTYPE).reshape(-1)
     nt16 = "=ACMGRSVTWYHKDBN"
     # walk the records in input order (no tile order without a tile length): read i owns k_i consecutive records

@@ -54,6 +54,49 @@ def test_run_midas_snps_pileup_matches_reference_text(tmp_path, extra):
     assert os.path.isfile(os.path.join(out, "snps", "readme.txt")) and os.path.isfile(os.path.join(out, "snps", "log.txt"))
 
 
+@pytest.mark.parametrize("inflate", ["on", "off"])
+def test_bam_with_records_of_a_species_that_is_not_selected(tmp_path, inflate):
+    """species.txt edited after the alignment (or a BAM from elsewhere): the BAM holds records of contigs nobody asked for.
+    pysam's count_coverage is called per wanted contig (midas/run/snps.py:187-199) and never sees them; neither may the
+    decode that leaves SEQ / QUAL / CIGAR on the device (--device_inflate on, one rank) nor the host's."""
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=2, contig_len=5000, n_reads=6000, seed=23)
+    out, db = str(tmp_path / "sample"), str(tmp_path / "db")
+    synth.write_sample(out, db, contigs, reads)
+    listing = os.path.join(out, "snps", "species.txt")
+    kept = [l for l in open(listing).read().split() if l != contigs.species_ids[1]]
+    open(listing, "w").write("".join(l + "\n" for l in kept))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_midas.py"), "snps", out, "--pileup", "-d", db,
+                        "--device_inflate", inflate], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = _oracle_outputs(contigs, reads, dict(abi.DEFAULT_ARGS))
+    for sp in kept:
+        assert gzip.open(os.path.join(out, "snps", "output", sp + ".snps.gz"), "rt").read() == exp[sp][0], sp
+    assert not os.path.exists(os.path.join(out, "snps", "output", contigs.species_ids[1] + ".snps.gz"))
+
+
+def test_the_cli_runs_the_dependencys_pad_rule_by_default(tmp_path):
+    """A BAM with the CIGAR op P: the drop-in counts what pysam's get_aligned_pairs would (the query position advances over a
+    pad: hand-derived case k04c), `--pad_rule spec` what the SAM specification says (P consumes nothing: the table of the
+    same read without the pad)."""
+    import numpy as np
+    from tests import helpers as H
+    cases = {c["name"]: c for c in H.load_kat_cases()}
+    case = cases["k04c_pad_pysam_rule_reads_one_late"]
+    contigs, reads, _, _ = H.kat_inputs(case)
+    tables = {}
+    for rule in (None, "spec"):
+        out, db = str(tmp_path / ("sample_%s" % rule)), str(tmp_path / ("db_%s" % rule))
+        synth.write_sample(out, db, contigs, reads)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_midas.py"), "snps", out, "--pileup", "-d", db] +
+                           (["--pad_rule", rule] if rule else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = gzip.open(os.path.join(out, "snps", "output", "sp.snps.gz"), "rt").read().splitlines()[1:]
+        tables[rule] = np.array([[int(x) for x in row.split("\t")[4:8]] for row in rows], dtype=np.uint32)
+    assert np.array_equal(tables[None], H.kat_expected_counts(case))
+    st, _, spec_counts, _, _ = __import__("oracle.c_oracle", fromlist=["pileup"]).pileup(abi.Thresholds.from_args(abi.DEFAULT_ARGS), contigs, reads)
+    assert st == 0 and np.array_equal(tables["spec"], spec_counts) and not np.array_equal(tables["spec"], tables[None])
+
+
 def test_reference_exceptions_become_error_exits(tmp_path):
     contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=1, contig_len=3000, n_reads=200, seed=5)
     reads.nm[17] = -1     # bowtie2 writes NM on every aligned record; its absence is a KeyError in the reference

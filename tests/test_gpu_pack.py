@@ -13,13 +13,14 @@ import pytest
 
 from midas_amd import abi, synth
 from tests import helpers as H
+from tests import mirror
 from tests.test_gpu_parity import _random_cigar
 
 pytestmark = pytest.mark.gpu
 
 
 def _same_layout(ctx, contigs, reads, repack=0):
-    want = abi.pack_reads_tiled(reads, contigs)
+    want = mirror.pack_reads_tiled(reads, contigs)
     b = ctx.batch(contigs, reads)
     try:
         for rnd in range(repack + 1):
@@ -105,7 +106,7 @@ def test_empty_batches(hip_ctx):
 
 def test_c2_full_size_and_results_survive_a_repack(hip_ctx, thr_default):
     contigs, reads = synth.make_dataset(**synth.CONFIGS['c2'])
-    want = abi.pack_reads_tiled(reads, contigs)
+    want = mirror.pack_reads_tiled(reads, contigs)
     b = hip_ctx.batch(contigs, reads)
     try:
         b.run(thr_default)
