@@ -351,8 +351,11 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
  *   midas_bam_open_device          = midas_bam_open (whole file; then midas_bam_load as usual)
  *   midas_bam_load_ranges_device   = midas_bam_load_ranges on a handle of midas_bam_open_slice
  *   midas_snps_inflate_blocks      the inflater on its own: n raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k],
- *                                  +ulen[k]) (host pointers; every stream must inflate to exactly ulen[k] bytes).  On a
- *                                  corrupt stream *bad_block (may be NULL) is its index.
+ *                                  +ulen[k]) (host pointers; every stream must inflate to exactly ulen[k] bytes and, when
+ *                                  `crc` is not NULL, to bytes whose CRC-32 is crc[k]).  On a corrupt stream *bad_block (may
+ *                                  be NULL) is its index.
+ * Every BGZF block is held to the CRC-32 in its footer on both decoders, as htslib's bgzf_read_block does: a block that
+ * inflates to the right size from damaged bytes is MIDAS_SNPS_ERR_BAD_LAYOUT naming the block's file offset.
  * Replaces the inflate inside pysam.AlignmentFile / htslib's bgzf.c behind midas/run/snps.py:186.
  *   midas_bam_load_device          open + load in one call, and SEQ / QUAL / CIGAR never come down: the host walks the
  *                                  records and decodes the small columns from the inflated stream as before, the three payload
@@ -371,7 +374,7 @@ int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_
                                      int64_t* n_cigar, char* err256);
 int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, int64_t n_blocks,
                                   const int64_t* cpos, const int32_t* clen, const int64_t* upos, const int32_t* ulen,
-                                  uint8_t* out, int64_t out_bytes, int64_t* bad_block);
+                                  const uint32_t* crc, uint8_t* out, int64_t out_bytes, int64_t* bad_block);
 int32_t midas_bam_slice_facts(const midas_bam* bam, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases,
                               int64_t* ref_first);
 /* What the walk of midas_bam_open_slice noted for cutting LONG references into pieces (midas_snps_contigs.origin), so that a

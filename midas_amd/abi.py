@@ -258,7 +258,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_payload_on_device': (i32, [vp]),
         'midas_snps_copy_from_device': (i32, [vp, vp, vp, i64]),
         'midas_bam_load_ranges_device': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
-        'midas_snps_inflate_blocks': (i32, [vp, vp, i64, i64, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]),
+        'midas_snps_inflate_blocks': (i32, [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]),
         'midas_bam_load_ranges': (i32, [vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_write_rows': (i32, [C.c_char_p, i32, C.c_char_p, i64, vp, vp, i32, i32, C.c_char_p]),
         'midas_merge_write_info': (i32, [C.c_char_p, C.c_char_p, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, C.c_char_p]),
@@ -724,8 +724,9 @@ class Context:
 
     inflates = True      # read_bam / BamSlice.load_ranges may hand this context the BGZF blocks
 
-    def inflate_blocks(self, comp, cpos, clen, upos, ulen, out_bytes: int):
+    def inflate_blocks(self, comp, cpos, clen, upos, ulen, out_bytes: int, crc=None):
         """Raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k], +ulen[k]) on the device (midas_snps_inflate_blocks).
+        crc: the CRC-32 every stream's inflated bytes must have (None: not checked).
         Raises MidasSnpsError (ERR_BAD_LAYOUT, read_index = the stream) when a stream is corrupt."""
         comp = np.ascontiguousarray(np.frombuffer(comp, np.uint8) if not isinstance(comp, np.ndarray) else comp, dtype=np.uint8)
         cpos, upos = np.ascontiguousarray(cpos, np.int64), np.ascontiguousarray(upos, np.int64)
@@ -733,8 +734,9 @@ class Context:
         out = np.zeros(max(int(out_bytes), 1), np.uint8)
         bad = C.c_int64(-1)
         p = lambda x: x.ctypes.data_as(C.c_void_p)
+        crc = None if crc is None else np.ascontiguousarray(crc, np.uint32)
         st = self._lib.midas_snps_inflate_blocks(self._h, p(comp), comp.size, cpos.size, p(cpos), p(clen), p(upos), p(ulen),
-                                                 p(out), int(out_bytes), C.byref(bad))
+                                                 None if crc is None else p(crc), p(out), int(out_bytes), C.byref(bad))
         if st != 0:
             msg = self._lib.midas_snps_last_error(self._h).decode() or self._lib.midas_snps_status_string(st).decode()
             raise MidasSnpsError(st, msg, int(bad.value))

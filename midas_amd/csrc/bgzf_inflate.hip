@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "crc32.h"
 
 namespace midas {
 namespace {
@@ -452,6 +453,33 @@ __global__ __launch_bounds__(256) void bam_payload_kernel(PayloadParams p) {
 
 }  // namespace
 
+// The CRC-32 of every inflated block against the one its BGZF footer holds (htslib checks it behind pysam.AlignmentFile,
+// midas/run/snps.py:186; a flipped literal bit inflates to the right SIZE).  One wavefront per block, behind the resolver: a
+// lane runs the table-driven CRC over its 1/64 of the block from a zero register, the registers are moved to the end of the
+// block (crc32.h) and folded.  A block that inflated cleanly but sums wrongly gets the status kInflateCrc.
+constexpr int kCrcWaves = 4;
+__global__ __launch_bounds__(kLanes * kCrcWaves) void bgzf_crc_kernel(InflateParams p) {
+  __shared__ crc::Tables T;
+  crc::build_tables(T);
+  const int lane = (int)(threadIdx.x & 63u);
+  const long long n_waves = (long long)gridDim.x * kCrcWaves;
+  for (long long k = (long long)blockIdx.x * kCrcWaves + (threadIdx.x >> 6); k < p.n_blocks; k += n_waves) {
+    if (p.status[k] != 0u) continue;
+    const InflateBlock b = p.blocks[k];
+    const uint32_t chunk = ((b.ulen + 63u) / 64u + 3u) & ~3u;
+    const uint32_t lo = (uint32_t)lane * chunk;
+    uint32_t part = 0u;
+    if (lo < b.ulen) {
+      const uint32_t n = b.ulen - lo < chunk ? b.ulen - lo : chunk;
+      const uint32_t c = crc::update(T, 0u, p.out + b.upos + lo, n);
+      part = crc::gf_mul(c, crc::gf_xpow8((unsigned long long)(b.ulen - lo - n), T.x2n));
+    }
+    if (lane == 0) part ^= crc::gf_mul(0xFFFFFFFFu, crc::gf_xpow8((unsigned long long)b.ulen, T.x2n));      // the initial register
+    for (int d = 32; d >= 1; d >>= 1) part ^= (uint32_t)__shfl_xor((int)part, d);
+    if (lane == 0 && (part ^ 0xFFFFFFFFu) != p.want_crc[k]) p.status[k] = kInflateCrc;
+  }
+}
+
 hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s) {
   if (p.n_records <= 0) return hipSuccess;
   long long g = (p.n_records + 3) / 4;
@@ -472,6 +500,11 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
   if (!(phases & 2)) return hipSuccess;
   const long long g2 = (p.n_blocks + kResolveWaves - 1) / kResolveWaves;
   hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)g2), dim3(kLanes * kResolveWaves), 0, s, p);
+  if (p.want_crc) {
+    long long g3 = (p.n_blocks + kCrcWaves - 1) / kCrcWaves;
+    g3 = g3 > 2048 ? 2048 : g3;
+    hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)g3), dim3(kLanes * kCrcWaves), 0, s, p);
+  }
   return hipGetLastError();
 }
 

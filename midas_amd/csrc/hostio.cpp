@@ -200,6 +200,7 @@ struct Libdeflate {
   void* (*alloc)() = nullptr;
   int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
   void (*release)(void*) = nullptr;
+  uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
   Libdeflate() {
     const char* pick = getenv("MIDAS_SNPS_INFLATE");
     if (pick && strcmp(pick, "zlib") == 0) return;
@@ -208,7 +209,9 @@ struct Libdeflate {
     void* a = dlsym(h, "libdeflate_alloc_decompressor");
     void* r = dlsym(h, "libdeflate_deflate_decompress");
     void* f = dlsym(h, "libdeflate_free_decompressor");
+    void* c = dlsym(h, "libdeflate_crc32");
     if (!a || !r || !f) return;
+    if (c) crc = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(c);
     alloc = reinterpret_cast<void* (*)()>(a);
     run = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(r);
     release = reinterpret_cast<void (*)(void*)>(f);
@@ -244,6 +247,19 @@ bool raw_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) {
   return rc == Z_STREAM_END && zs.avail_out == 0;
 }
 
+// CRC-32 (gzip's) of a buffer: libdeflate's (carry-less multiplication, tens of GB/s a core) when it is there, else zlib's.
+uint32_t crc32_of(const uint8_t* p, size_t n) {
+  const Libdeflate& l = libdeflate();
+  if (l.crc) return l.crc(0u, p, n);
+  return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
+// A BGZF block: its stream inflated to exactly n_out bytes AND those bytes' CRC-32 equal to the one stored behind the stream
+// (what htslib's bgzf_read_block checks behind pysam.AlignmentFile, midas/run/snps.py:186).  false: corrupt, one way or the other.
+bool bgzf_block_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) {
+  if (!raw_inflate(in, n_in, out, n_out)) return false;
+  return crc32_of(out, n_out) == rd32(in + n_in);
+}
+
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
 int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
@@ -277,7 +293,7 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     if (short_read) { set_err(err256, "short read on %s", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   }
   lap("read file");
-  struct Blk { size_t cpos, clen, upos, ulen; };
+  struct Blk { size_t cpos, clen, upos, ulen, fpos; };
   std::vector<Blk> blocks;
   size_t p = 0, upos = 0;
   while (p < comp.size()) {
@@ -298,7 +314,7 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
     const size_t isize = rd32(&comp[p + bsize - 4]);
-    blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize});
+    blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize, p});
     upos += isize;
     p += bsize;
   }
@@ -307,29 +323,30 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
   if (inflater) {
     std::vector<midas::InflateJob> jobs;
     jobs.reserve(blocks.size());
-    for (const Blk& b : blocks) jobs.push_back({(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)b.clen, (uint32_t)b.ulen});
+    for (const Blk& b : blocks) jobs.push_back({(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)b.clen, (uint32_t)b.ulen, rd32(&comp[b.cpos + b.clen]), 1u});
     const midas::InflateSegment seg{comp.data(), comp.size()};
     int64_t bad_job = -1;
     const int32_t st = inflater->run(inflater->user, &seg, 1, jobs.data(), jobs.size(), out.data(), out.size(), &bad_job, err256);
-    if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) set_err(err256, "%s: corrupt deflate data", path.c_str());
+    if (st == MIDAS_SNPS_ERR_BAD_LAYOUT)
+      set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path.c_str(),
+              (long long)(bad_job >= 0 && (size_t)bad_job < blocks.size() ? blocks[(size_t)bad_job].fpos : -1));
     lap("inflate blocks (inflater)");
     return st;
   }
   std::atomic<size_t> next{0};
-  std::atomic<int> bad{0};
+  std::atomic<long long> bad{-1};
   auto work = [&] {
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= blocks.size()) return;
       const Blk& b = blocks[i];
-      if (b.ulen == 0) continue;
-      if (!raw_inflate(comp.data() + b.cpos, (size_t)b.clen, out.data() + b.upos, (size_t)b.ulen)) { bad = 1; return; }
+      if (!bgzf_block_inflate(comp.data() + b.cpos, (size_t)b.clen, out.data() + b.upos, (size_t)b.ulen)) { bad = (long long)b.fpos; return; }
     }
   };
   const int nt = hw_threads(0);
   Workers::run(nt, work);
   lap("inflate blocks");
-  if (bad) { set_err(err256, "%s: corrupt deflate data", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  if (bad >= 0) { set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path.c_str(), (long long)bad.load()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   return MIDAS_SNPS_OK;
 }
 
@@ -571,8 +588,7 @@ struct BamWindow {
     const size_t first = b_hi;
     run_pool(hw_threads(0), new_hi - b_hi, [&](size_t k) {
       const BgzfMap::Blk& b = m->blocks[first + k];
-      if (b.ulen == 0) return;
-      if (!raw_inflate(m->base + b.cpos, (size_t)b.clen, buf.data() + at[k], (size_t)b.ulen)) bad = 1;
+      if (!bgzf_block_inflate(m->base + b.cpos, (size_t)b.clen, buf.data() + at[k], (size_t)b.ulen)) bad = 1;
     });
     b_hi = new_hi;
     return bad == 0;
@@ -1193,7 +1209,7 @@ int32_t midas::bam_load_ranges_with(midas_bam* b, const midas::BlockInflater* in
     if (needed[i]) { at[i] = bytes; bytes += m.blocks[i].ulen; list.push_back(i); }
   RawBuf<uint8_t> buf;
   if (!buf.resize(bytes)) { set_err(err256, "out of memory inflating %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  std::atomic<int> bad{0};
+  std::atomic<long long> bad{-1};
   if (inflater) {
     // runs of consecutive blocks are consecutive in the file: one segment each
     std::vector<midas::InflateSegment> segs;
@@ -1209,21 +1225,21 @@ int32_t midas::bam_load_ranges_with(midas_bam* b, const midas::BlockInflater* in
       }
       // (a block's stream lies between its header and its 8-byte footer; the segment runs on to the end of the block)
       const uint64_t seg_base = cat;
-      jobs.push_back({seg_base + (uint64_t)(blk.cpos - (size_t)(segs.back().p - m.base)), (uint64_t)at[list[k]], (uint32_t)blk.clen, blk.ulen});
+      jobs.push_back({seg_base + (uint64_t)(blk.cpos - (size_t)(segs.back().p - m.base)), (uint64_t)at[list[k]], (uint32_t)blk.clen, blk.ulen,
+                      rd32(m.base + blk.cpos + blk.clen), 1u});
       segs.back().n = (size_t)(blk.cpos + blk.clen + 8 - (size_t)(segs.back().p - m.base));
     }
     int64_t bad_job = -1;
     const int32_t ist = inflater->run(inflater->user, segs.data(), segs.size(), jobs.data(), jobs.size(), buf.data(), bytes, &bad_job, err256);
-    if (ist == MIDAS_SNPS_ERR_BAD_LAYOUT) bad = 1;
+    if (ist == MIDAS_SNPS_ERR_BAD_LAYOUT) bad = bad_job >= 0 && (size_t)bad_job < list.size() ? (long long)m.blocks[list[(size_t)bad_job]].fpos : 0;
     else if (ist != MIDAS_SNPS_OK) return ist;
   } else {
   run_pool(hw_threads(0), list.size(), [&](size_t k) {
     const BgzfMap::Blk& blk = m.blocks[list[k]];
-    if (blk.ulen == 0) return;
-    if (!raw_inflate(m.base + blk.cpos, (size_t)blk.clen, buf.data() + at[list[k]], (size_t)blk.ulen)) bad = 1;
+    if (!bgzf_block_inflate(m.base + blk.cpos, (size_t)blk.clen, buf.data() + at[list[k]], (size_t)blk.ulen)) bad = (long long)blk.fpos;
   });
   }
-  if (bad) { set_err(err256, "%s: corrupt deflate data", b->path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  if (bad >= 0) { set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", b->path.c_str(), (long long)bad.load()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   // walk every range from its first record to exactly its end (a range's blocks are consecutive in the buffer)
   std::vector<size_t> offs;
   for (int32_t k = 0; k < n_ranges; ++k) {

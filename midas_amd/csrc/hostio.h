@@ -23,7 +23,7 @@ int32_t write_rows_fed(const char* path, bool with_header, int32_t n_contigs, co
 
 // Many raw DEFLATE streams inflated at once by somebody else than the host's threads (the device: snps_abi.hip).  The
 // compressed bytes are given as segments that the streams' cpos count through back to back; upos are offsets into out.
-struct InflateJob { uint64_t cpos, upos; uint32_t clen, ulen; };
+struct InflateJob { uint64_t cpos, upos; uint32_t clen, ulen; uint32_t crc, check_crc; };   // check_crc != 0: the inflated bytes' CRC-32 must be `crc`
 struct InflateSegment { const uint8_t* p; size_t n; };
 struct BlockInflater {
   void* user;

@@ -228,6 +228,7 @@ hipError_t launch_rows_deflate(const RowsParams& p, int grid_blocks, hipStream_t
 // bgzf_inflate.hip: raw DEFLATE streams (BGZF blocks) inflated on the device, one thread per stream
 struct InflateBlock { unsigned long long cpos, upos, mbase; uint32_t clen, ulen, mcap, pad; };   // mbase, mcap: the stream's room in `matches`
 constexpr uint32_t kInflateMatchRoom = 9;      // status: the stream has more matches than its room (decode it again with more)
+constexpr uint32_t kInflateCrc = 10;           // status: inflated to the right size, but the bytes' CRC-32 is not the footer's
 struct InflateParams {
   const uint8_t* comp;             // the streams (8 bytes of slack behind the last one)
   const InflateBlock* blocks; long long n_blocks;
@@ -235,6 +236,7 @@ struct InflateParams {
   uint32_t* status;                // per stream: 0 = inflated to exactly ulen bytes
   unsigned long long* matches;     // the matches the decoder noted for the resolver
   uint32_t* n_matches;             // per stream
+  const uint32_t* want_crc;        // per stream: the CRC-32 its inflated bytes must have (BGZF footer); nullptr: not checked
 };
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases = 3);
 struct PayloadParams {

@@ -472,14 +472,16 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen, cap, 0u};
     n_match_room += cap;
   }
+  bool check = n_jobs > 0;       // the streams' CRC-32 is verified when every one of them brings it (BGZF blocks do)
+  for (size_t k = 0; k < n_jobs; ++k) check = check && jobs[k].check_crc != 0u;
   const size_t at_out = 0, at_comp = up(out_bytes + 64), at_blocks = at_comp + up(comp_bytes + 512),
-               at_status = at_blocks + up(n_jobs * sizeof(InflateBlock)), at_matches = at_status + up(n_jobs * 8),
-               arena_bytes = at_matches + up((size_t)n_match_room * 8);
+               at_status = at_blocks + up(n_jobs * sizeof(InflateBlock)), at_crc = at_status + up(n_jobs * 8),
+               at_matches = at_crc + up(n_jobs * 4), arena_bytes = at_matches + up((size_t)n_match_room * 8);
   struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } arena;
   INF_TRY(hipMalloc(&arena.p, arena_bytes));
   uint8_t* const base = static_cast<uint8_t*>(arena.p);
   struct View { void* p; } d_out{base + at_out}, d_comp{base + at_comp}, d_blocks{base + at_blocks}, d_status{base + at_status},
-      d_matches{base + at_matches};
+      d_crc{base + at_crc}, d_matches{base + at_matches};
   hipStream_t s = ctx->stream;
   size_t at = 0;
   for (size_t k = 0; k < n_segs; ++k) {
@@ -497,6 +499,14 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   ip.status = static_cast<uint32_t*>(d_status.p);
   ip.n_matches = static_cast<uint32_t*>(d_status.p) + n_jobs;
   ip.matches = static_cast<unsigned long long*>(d_matches.p);
+  ip.want_crc = nullptr;
+  std::vector<uint32_t> want;
+  if (check) {
+    want.resize(n_jobs);
+    for (size_t k = 0; k < n_jobs; ++k) want[k] = jobs[k].crc;
+    INF_TRY(hipMemcpyAsync(d_crc.p, want.data(), n_jobs * 4, hipMemcpyHostToDevice, s));
+    ip.want_crc = static_cast<const uint32_t*>(d_crc.p);
+  }
   if (trace) {
     INF_TRY(launch_bgzf_inflate(ip, s, 1));
     INF_TRY(hipStreamSynchronize(s));
@@ -524,7 +534,13 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
         b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
         room2 += cap;
       }
-      Buf d_b2, d_s2, d_m2;
+      Buf d_b2, d_s2, d_m2, d_c2;
+      std::vector<uint32_t> want2(again.size());
+      for (size_t j = 0; j < again.size(); ++j) want2[j] = jobs[again[j]].crc;
+      if (check) {
+        INF_TRY(hipMalloc(&d_c2.p, again.size() * 4));
+        INF_TRY(hipMemcpyAsync(d_c2.p, want2.data(), again.size() * 4, hipMemcpyHostToDevice, s));
+      }
       INF_TRY(hipMalloc(&d_b2.p, b2.size() * sizeof(InflateBlock)));
       INF_TRY(hipMalloc(&d_s2.p, b2.size() * 8));
       INF_TRY(hipMalloc(&d_m2.p, (size_t)room2 * 8));
@@ -535,6 +551,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
       ip2.status = static_cast<uint32_t*>(d_s2.p);
       ip2.n_matches = static_cast<uint32_t*>(d_s2.p) + b2.size();
       ip2.matches = static_cast<unsigned long long*>(d_m2.p);
+      ip2.want_crc = check ? static_cast<const uint32_t*>(d_c2.p) : nullptr;
       INF_TRY(launch_bgzf_inflate(ip2, s));
       std::vector<uint32_t> st2(b2.size());
       INF_TRY(hipMemcpyAsync(st2.data(), d_s2.p, b2.size() * 4, hipMemcpyDeviceToHost, s));
@@ -547,7 +564,8 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   for (size_t k = 0; k < n_jobs; ++k) {
     if (status[k] != 0u) {
       if (bad_job) *bad_job = (int64_t)k;
-      if (err256) snprintf(err256, 256, "corrupt deflate data (stream %lld: code %u)", (long long)k, status[k]);
+      if (err256) snprintf(err256, 256, status[k] == kInflateCrc ? "CRC-32 mismatch (stream %lld: the inflated bytes are not the ones that were compressed)"
+                                                                 : "corrupt deflate data (stream %lld: code %u)", (long long)k, status[k]);
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
   }
@@ -564,13 +582,13 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
 
 int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, int64_t n_blocks,
                                   const int64_t* cpos, const int32_t* clen, const int64_t* upos, const int32_t* ulen,
-                                  uint8_t* out, int64_t out_bytes, int64_t* bad_block) {
+                                  const uint32_t* crc, uint8_t* out, int64_t out_bytes, int64_t* bad_block) {
   if (!ctx || comp_bytes < 0 || n_blocks < 0 || out_bytes < 0 || (n_blocks > 0 && (!comp || !cpos || !clen || !upos || !ulen || !out)))
     return MIDAS_SNPS_ERR_INVALID_ARG;
   std::vector<InflateJob> jobs((size_t)n_blocks);
   for (int64_t k = 0; k < n_blocks; ++k) {
     if (cpos[k] < 0 || clen[k] < 0 || upos[k] < 0 || ulen[k] < 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "inflate_blocks: negative offset or size");
-    jobs[(size_t)k] = InflateJob{(uint64_t)cpos[k], (uint64_t)upos[k], (uint32_t)clen[k], (uint32_t)ulen[k]};
+    jobs[(size_t)k] = InflateJob{(uint64_t)cpos[k], (uint64_t)upos[k], (uint32_t)clen[k], (uint32_t)ulen[k], crc ? crc[k] : 0u, crc ? 1u : 0u};
   }
   const InflateSegment seg{comp, (size_t)comp_bytes};
   char err[256] = {0};

@@ -49,14 +49,14 @@ def _payloads():
     return out
 
 
-def _inflate_all(ctx, streams, sizes):
+def _inflate_all(ctx, streams, sizes, crc=None):
     cpos, at = [], 0
     blob = bytearray()
     for s in streams:
         cpos.append(len(blob))
         blob += s
     upos = np.concatenate([[0], np.cumsum(sizes)])[:-1] if sizes else np.zeros(0, np.int64)
-    return ctx.inflate_blocks(bytes(blob), cpos, [len(s) for s in streams], upos, sizes, int(sum(sizes))), upos
+    return ctx.inflate_blocks(bytes(blob), cpos, [len(s) for s in streams], upos, sizes, int(sum(sizes)), crc=crc), upos
 
 
 def test_streams_of_every_kind_against_zlib(ctx):
@@ -74,7 +74,7 @@ def test_streams_of_every_kind_against_zlib(ctx):
     parts = [bytes(np.random.default_rng(k).integers(60, 70, 9000, dtype=np.uint8)) for k in range(4)]
     s = b"".join(c.compress(p) + c.flush(zlib.Z_FULL_FLUSH) for p in parts[:3]) + c.compress(parts[3]) + c.flush()
     cases.append("several_blocks"); streams.append(s); plain.append(b"".join(parts))
-    out, upos = _inflate_all(ctx, streams, [len(p) for p in plain])
+    out, upos = _inflate_all(ctx, streams, [len(p) for p in plain], crc=[zlib.crc32(p) for p in plain])     # (sizes AND sums)
     for name, p, u in zip(cases, plain, upos):
         got = bytes(out[int(u):int(u) + len(p)])
         assert got == p, "%s: first difference at %d" % (name, next((i for i in range(len(p)) if got[i] != p[i]), -1))
@@ -104,9 +104,14 @@ def test_corrupt_streams_are_a_status(ctx):
             valid = False
         try:
             out = ctx.inflate_blocks(b, [0], [len(b)], [0], [len(data)], len(data))
-            assert valid and bytes(out) == ref     # (a flipped bit inside a literal's code is still a valid stream: no CRC at this level)
+            assert valid and bytes(out) == ref     # (a flipped bit inside a literal's code is still a valid stream ...)
         except abi.MidasSnpsError as e:
             assert not valid and e.status == abi.ERR_BAD_LAYOUT and e.read_index == 0
+        if valid and ref != data:                  # (... which the CRC-32 of the original bytes refuses)
+            with pytest.raises(abi.MidasSnpsError) as ei:
+                ctx.inflate_blocks(b, [0], [len(b)], [0], [len(data)], len(data), crc=[zlib.crc32(data)])
+            assert ei.value.status == abi.ERR_BAD_LAYOUT and ei.value.read_index == 0 and "CRC" in ei.value.message
+    assert bytes(ctx.inflate_blocks(good, [0], [len(good)], [0], [len(data)], len(data), crc=[zlib.crc32(data)])) == data
     # the wrong size is an error too
     with pytest.raises(abi.MidasSnpsError):
         ctx.inflate_blocks(good, [0], [len(good)], [0], [len(data) - 1], len(data) - 1)
@@ -153,3 +158,33 @@ def test_bam_decoded_with_the_device_inflater_equals_the_host_decode(ctx, tmp_pa
     open(cut, "wb").write(data[:len(data) // 2])
     with pytest.raises(abi.MidasSnpsError):
         abi.read_bam(cut, ctx)
+
+
+def _flip_a_stored_byte(path):
+    """A BAM written with stored (level 0) DEFLATE blocks, one payload byte of its third block flipped: every block still
+    inflates to the size its footer states -- only the CRC-32 knows.  Returns the block's file offset."""
+    raw = bytearray(open(path, "rb").read())
+    p, blocks = 0, []
+    while p < len(raw):
+        blocks.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    at = blocks[2]
+    raw[at + 18 + 5 + 1000] ^= 0x10          # (18 bytes of BGZF header, 5 of the stored block's)
+    open(path, "wb").write(bytes(raw))
+    return at
+
+
+def test_a_damaged_bgzf_block_is_refused_by_both_decoders(ctx, tmp_path):
+    """htslib (behind pysam.AlignmentFile, midas/run/snps.py:186) checks every block's CRC-32; so do the host's threads and
+    the device's kernels -- the whole-file decode, the decode that leaves the payload on the device, and the slices'."""
+    from midas_amd import bam
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=40000, n_reads=4000, seed=9)
+    path = str(tmp_path / "stored.bam")
+    refid = np.repeat(np.arange(2, dtype=np.int32), np.diff(contigs.read_begin))
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=0)
+    abi.read_bam(path)                                                    # (undamaged: fine)
+    at = _flip_a_stored_byte(path)
+    for kw in (dict(), dict(ctx=ctx), dict(ctx=ctx, payload_on_device=True)):
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            abi.read_bam(path, **kw)
+        assert ei.value.status == abi.ERR_BAD_LAYOUT and "offset %d" % at in ei.value.message, (kw, ei.value.message)

@@ -131,6 +131,32 @@ def test_bam_decoder_rejects_garbage(tmp_path):
         abi.read_bam(str(tmp_path / "missing.bam"))
 
 
+def test_a_damaged_bgzf_block_is_refused(tmp_path):
+    """htslib (behind pysam.AlignmentFile, midas/run/snps.py:186) checks every block's CRC-32.  A BAM of stored (level 0)
+    DEFLATE blocks with one payload byte flipped inflates to the right sizes -- only the sums know: the whole-file decode and
+    the slices' both name the block."""
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=40000, n_reads=4000, seed=9)
+    path = str(tmp_path / "stored.bam")
+    refid = np.repeat(np.arange(2, dtype=np.int32), np.diff(contigs.read_begin))
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=0)
+    abi.read_bam(path)
+    raw = bytearray(open(path, "rb").read())
+    p, blocks = 0, []
+    while p < len(raw):
+        blocks.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    at = blocks[2]
+    raw[at + 18 + 5 + 1000] ^= 0x10          # (18 bytes of BGZF header, 5 of the stored block's)
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        abi.read_bam(path)
+    assert ei.value.status == abi.ERR_BAD_LAYOUT and "offset %d" % at in ei.value.message and "CRC" in ei.value.message
+    with pytest.raises(abi.MidasSnpsError) as ei:
+        s = abi.BamSlice(path, 0, 1)
+        s.load_ranges([(s.rec_begin, s.total)])
+    assert ei.value.status == abi.ERR_BAD_LAYOUT
+
+
 def test_group_by_contig_regroups_and_drops_foreign_contigs():
     reads = H.reads_from_dicts([dict(pos=5, cigar="4M", seq="ACGT"), dict(pos=1, cigar="4M", seq="CCCC"),
                                 dict(pos=2, cigar="4M", seq="GGGG"), dict(pos=9, cigar="4M", seq="TTTT")])
