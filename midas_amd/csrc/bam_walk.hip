@@ -1,0 +1,281 @@
+// gfx950 record walk of a BAM whose inflated stream lies in HBM (bgzf_inflate.hip put it there): what iterating
+// pysam.AlignmentFile does behind midas/run/snps.py:186 -- find every alignment record, decode its fixed fields and its NM tag
+// -- without the stream ever coming down to the host.
+//
+// The records form a chain: a record's block_size leads to the next one (SAM spec 4.2).  One thread following it from the
+// first record would make ten million dependent trips to memory.  Here the stream is cut into chunks of 32 KiB and
+//   bam_walk_kernel     one thread per chunk: GUESSES a record boundary inside its chunk (the first offset from which four
+//                       plausible records follow one another -- every fixed field in range, a printable NUL-terminated
+//                       name, CIGAR op codes <= 8, the variable parts inside block_size) and walks the chain from there to
+//                       the end of the chunk: where it started, where it ended, how many records with refID >= 0 it met.
+//                       The host then stitches the chunks IN ORDER: a chunk's walk counts only if the chain that started at
+//                       the true first record ended exactly on its guess -- then the guess was a true boundary and the walk
+//                       is the one a single thread would have made.  A chunk whose guess the chain does not hit is walked
+//                       again from where the chain stands (the same kernel, a list of chunks with forced starts): nothing is
+//                       ever taken on plausibility alone.
+//   bam_offsets_kernel  one thread per chunk, from the chunk's confirmed start: the offset of every kept record.
+//   bam_columns_kernel  one thread per record: refID, pos, mapq, flag, l_seq, the lengths of its CIGAR / SEQ / QUAL (for the
+//                       CSR offsets), NM from the aux fields (any integer width, as pysam's tags do), and the one malformation
+//                       a record can have on its own: variable parts that overrun block_size (the lowest such record wins).
+//   bam_scan_*          inclusive scans of the three length arrays, in place: the CSR offsets.
+// The payload columns are then cut by bam_payload_kernel (bgzf_inflate.hip) as before.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace midas {
+
+namespace {
+
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+typedef uint16_t u16_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t rd32(const uint8_t* p) { return *reinterpret_cast<const u32_a1*>(p); }
+__device__ __forceinline__ uint32_t rd16(const uint8_t* p) { return *reinterpret_cast<const u16_a1*>(p); }
+
+constexpr unsigned long long kNone = ~0ull;
+constexpr int kChain = 4;
+
+// Could an alignment record start at d + u?  (The host's plausible_bytes, hostio.cpp.)  *bs = its block_size.
+__device__ bool plausible(const BamWalkParams& p, unsigned long long u, uint32_t* bs_out) {
+  if (u + 36 > p.total) return false;
+  const uint8_t* r = p.d + u;
+  const uint32_t bs = rd32(r);
+  if (bs < 32u || bs > (1u << 26)) return false;
+  const int32_t refid = (int32_t)rd32(r + 4), pos = (int32_t)rd32(r + 8);
+  const uint32_t lrn = r[12], n_cig = rd16(r + 16), l = rd32(r + 20);
+  const int32_t nref = (int32_t)rd32(r + 24), npos = (int32_t)rd32(r + 28);
+  if (refid < -1 || refid >= p.n_ref || nref < -1 || nref >= p.n_ref || pos < -1 || npos < -1) return false;
+  if (refid >= 0 && (long long)pos > p.ref_lens[refid]) return false;
+  if (lrn < 1u || l > (1u << 26)) return false;
+  if (32ull + lrn + 4ull * n_cig + (l + 1u) / 2u + l > bs) return false;
+  if (u + 4ull + 32ull + lrn + 4ull * n_cig > p.total) return false;
+  const uint8_t* name = r + 36;
+  if (name[lrn - 1u] != 0) return false;
+  for (uint32_t k = 0; k + 1u < lrn; ++k)
+    if (name[k] < 33 || name[k] > 126) return false;
+  const uint8_t* cg = name + lrn;
+  for (uint32_t k = 0; k < n_cig && k < 64u; ++k)
+    if ((rd32(cg + 4u * k) & 15u) > 8u) return false;
+  *bs_out = bs;
+  return true;
+}
+
+__global__ __launch_bounds__(64) void bam_walk_kernel(BamWalkParams p, const long long* list, long long n_list) {
+  const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  long long c;
+  unsigned long long start;
+  if (list) {
+    if (i >= n_list) return;
+    c = list[i];
+    start = p.start[c];                                 // forced: where the chain stands
+  } else {
+    if (i >= p.n_chunks) return;
+    c = i;
+    const unsigned long long lo = (unsigned long long)c * p.chunk, hi = lo + p.chunk < p.total ? lo + p.chunk : p.total;
+    start = kNone;
+    if (p.rec_begin >= lo && p.rec_begin < hi) {
+      start = p.rec_begin;                              // the true first record
+    } else if (lo > p.rec_begin) {
+      for (unsigned long long u = lo; u < hi && u + 36 <= p.total && start == kNone; ++u) {
+        unsigned long long v = u;
+        int ok = 0;
+        while (ok < kChain) {
+          if (v == p.total) break;                      // the stream ends on a record boundary: as good as a full chain
+          uint32_t bs = 0;
+          if (!plausible(p, v, &bs)) { ok = -1; break; }
+          v += 4ull + bs;
+          if (v > p.total) { ok = -1; break; }
+          ++ok;
+        }
+        if (ok >= 0) start = u;
+      }
+    }
+    p.start[c] = start;
+  }
+  const unsigned long long stop = ((unsigned long long)c + 1ull) * p.chunk;
+  uint32_t kept = 0, bad = 0;
+  unsigned long long q = start;
+  if (start != kNone) {
+    while (q + 4 <= p.total && q < stop) {
+      const uint32_t bs = rd32(p.d + q);
+      if (bs < 32u || q + 4ull + bs > p.total) { bad = 1u; break; }
+      kept += (int32_t)rd32(p.d + q + 4) >= 0 ? 1u : 0u;
+      q += 4ull + bs;
+    }
+  }
+  p.end[c] = q;
+  p.kept[c] = kept;
+  p.bad[c] = bad;
+}
+
+__global__ __launch_bounds__(64) void bam_offsets_kernel(BamWalkParams p, const unsigned long long* base, unsigned long long* rec_off) {
+  const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.n_chunks || p.kept[c] == 0u) return;
+  const unsigned long long stop = ((unsigned long long)c + 1ull) * p.chunk;
+  unsigned long long q = p.start[c], j = base[c];
+  while (q + 4 <= p.total && q < stop) {
+    const uint32_t bs = rd32(p.d + q);
+    if (bs < 32u || q + 4ull + bs > p.total) break;
+    if ((int32_t)rd32(p.d + q + 4) >= 0) rec_off[j++] = q;
+    q += 4ull + bs;
+  }
+}
+
+// NM:i (any integer width) from the aux block, or -1 (hostio.cpp find_nm)
+__device__ int32_t find_nm(const uint8_t* a, const uint8_t* end) {
+  while (a + 3 <= end) {
+    const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+    a += 3;
+    unsigned long long sz = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'Z': case 'H': {
+        const uint8_t* z = a;
+        while (z < end && *z) ++z;
+        if (z >= end) return -1;
+        sz = (unsigned long long)(z - a) + 1ull;
+        break;
+      }
+      case 'B': {
+        if (a + 5 > end) return -1;
+        const char st = (char)a[0];
+        const unsigned long long cnt = rd32(a + 1);
+        const unsigned long long es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        sz = 5ull + cnt * es;
+        break;
+      }
+      default: return -1;
+    }
+    if (sz > (unsigned long long)(end - a)) return -1;
+    if (t0 == 'N' && t1 == 'M') {
+      switch (ty) {
+        case 'c': return (int8_t)a[0];
+        case 'C': return a[0];
+        case 's': return (int16_t)rd16(a);
+        case 'S': return (int32_t)rd16(a);
+        case 'i': return (int32_t)rd32(a);
+        case 'I': { const uint32_t v = rd32(a); return v > 0x7FFFFFFFu ? 0x7FFFFFFF : (int32_t)v; }
+        default: return -1;
+      }
+    }
+    a += sz;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { p.seq_off[0] = 0; p.qual_off[0] = 0; p.cigar_off[0] = 0; }
+  if (i >= p.n) return;
+  const uint8_t* r = p.d + p.rec_off[i];
+  const uint32_t bs = rd32(r);
+  const uint32_t w3 = rd32(r + 12), w4 = rd32(r + 16), l = rd32(r + 20);
+  const uint32_t lrn = w3 & 0xFFu, n_cig = w4 & 0xFFFFu;
+  const unsigned long long body = 32ull + lrn + 4ull * n_cig + (l + 1u) / 2u + l;
+  p.refid[i] = (int32_t)rd32(r + 4);
+  p.pos[i] = (int32_t)rd32(r + 8);
+  p.mapq[i] = (uint8_t)(w3 >> 8);
+  p.flag[i] = (uint16_t)(w4 >> 16);
+  p.l_seq[i] = (int32_t)l;
+  p.cigar_off[i + 1] = n_cig;
+  p.seq_off[i + 1] = (l + 1u) / 2u;
+  p.qual_off[i + 1] = l;
+  int32_t nm = -1;
+  if (body > bs) atomicMin(p.bad_record, (unsigned long long)i);
+  else nm = find_nm(r + 4 + body, r + 4 + bs);
+  p.nm[i] = nm;
+}
+
+// ---- inclusive scan of an int64 array, in place: tiles of 4096, three launches ---------------------------------------------
+constexpr int kScanBlock = 256, kScanItems = 16, kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ long long block_inclusive(long long v, long long* lds, long long* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long x = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long o = __shfl_up(x, d);
+    if (lane >= d) x += o;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  long long base = 0;
+  for (int w = 0; w < wave; ++w) base += lds[w];
+  *total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return x + base;
+}
+
+__global__ __launch_bounds__(kScanBlock) void bam_scan_sums_kernel(const long long* a0, const long long* a1, const long long* a2, long long n,
+                                                                   long long* sums) {
+  __shared__ long long lds[4];
+  const long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : a2);
+  const long long lo = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  long long s = 0;
+  for (int k = 0; k < kScanItems; ++k) s += lo + k < n ? a[lo + k] : 0;
+  long long total;
+  (void)block_inclusive(s, lds, &total);
+  if (threadIdx.x == 0) sums[(long long)blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanBlock) void bam_scan_tiles_kernel(long long* sums, long long n_tiles) {     // one block per array: exclusive scan of its tile sums
+  __shared__ long long lds[4];
+  long long* s = sums + (long long)blockIdx.x * n_tiles;
+  long long carry = 0;
+  for (long long lo = 0; lo < n_tiles; lo += kScanBlock) {
+    const long long i = lo + threadIdx.x;
+    const long long v = i < n_tiles ? s[i] : 0;
+    long long total;
+    const long long inc = block_inclusive(v, lds, &total);
+    if (i < n_tiles) s[i] = carry + inc - v;
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(kScanBlock) void bam_scan_apply_kernel(long long* a0, long long* a1, long long* a2, long long n, const long long* sums) {
+  __shared__ long long lds[4];
+  long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : a2);
+  const long long lo = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  long long v[kScanItems];
+  long long s = 0;
+  for (int k = 0; k < kScanItems; ++k) { v[k] = lo + k < n ? a[lo + k] : 0; s += v[k]; }
+  long long total;
+  const long long inc = block_inclusive(s, lds, &total);
+  long long run = sums[(long long)blockIdx.y * gridDim.x + blockIdx.x] + inc - s;
+  for (int k = 0; k < kScanItems; ++k) {
+    run += v[k];
+    if (lo + k < n) a[lo + k] = run;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s) {
+  const long long n = list ? n_list : p.n_chunks;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bam_walk_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, p, list, n_list);
+  return hipGetLastError();
+}
+
+hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* base, unsigned long long* rec_off, hipStream_t s) {
+  if (p.n_chunks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bam_offsets_kernel, dim3((unsigned)((p.n_chunks + 63) / 64)), dim3(64), 0, s, p, base, rec_off);
+  return hipGetLastError();
+}
+
+size_t bam_scan_scratch_bytes(long long n_records) {
+  const long long tiles = (n_records + 1 + kScanTile - 1) / kScanTile;
+  return (size_t)(3 * (tiles > 0 ? tiles : 1)) * sizeof(long long);
+}
+
+// the columns of n records and, by three scans, their CSR offsets (n + 1 entries each)
+hipError_t launch_bam_columns(const BamColumnsParams& p, long long* scan_scratch, hipStream_t s) {
+  hipLaunchKernelGGL(bam_columns_kernel, dim3((unsigned)((p.n + 256) / 256)), dim3(256), 0, s, p);
+  const long long n1 = p.n + 1;
+  const long long tiles = (n1 + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(bam_scan_sums_kernel, dim3((unsigned)tiles, 3), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, n1, scan_scratch);
+  hipLaunchKernelGGL(bam_scan_tiles_kernel, dim3(3), dim3(kScanBlock), 0, s, scan_scratch, tiles);
+  hipLaunchKernelGGL(bam_scan_apply_kernel, dim3((unsigned)tiles, 3), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, n1, scan_scratch);
+  return hipGetLastError();
+}
+
+}  // namespace midas

@@ -2,8 +2,55 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
+
+// The context's device arena: ONE allocation that the BAM decodes of a context take turns in (a hipMalloc / hipFree pair
+// costs ~17 ms a gigabyte here, and a decode wants a few times the BAM's inflated size).  A decode borrows it (take), a BAM
+// handle whose payload columns were cut into it keeps it until it is closed (give) -- whoever asks meanwhile gets an
+// allocation of its own.  Shared with its borrowers: the context may be destroyed before the last handle is closed.
+struct midas_arena_pool {
+  std::mutex m;
+  int device = -1;
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool lent = false, closing = false;
+  void* take(size_t need, bool* pooled) {       // nullptr: out of device memory
+    std::lock_guard<std::mutex> g(m);
+    if (!lent && !closing) {
+      if (bytes < need) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        // (a little more than asked: the next BAM of about this size fits too)
+        const size_t want = need + need / 16;
+        if (hipMalloc(&p, want) == hipSuccess) bytes = want;
+        else { (void)hipGetLastError(); p = nullptr; if (hipMalloc(&p, need) == hipSuccess) bytes = need; else { (void)hipGetLastError(); p = nullptr; } }
+      }
+      if (p) { lent = true; *pooled = true; return p; }
+      return nullptr;
+    }
+    void* q = nullptr;
+    *pooled = false;
+    if (hipMalloc(&q, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return q;
+  }
+  void give(void* q) {
+    std::lock_guard<std::mutex> g(m);
+    if (q && q == p) {
+      lent = false;
+      if (closing) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    } else if (q) {
+      (void)hipFree(q);
+    }
+  }
+  void close() {                                  // the context goes: free now, or when the borrower gives it back
+    std::lock_guard<std::mutex> g(m);
+    closing = true;
+    if (!lent && p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+  }
+};
 
 struct midas_snps_ctx {
   int device = -1;
@@ -18,6 +65,7 @@ struct midas_snps_ctx {
   // call -- kernel, copies through the staging ring below -- is taken one at a time, the file writes run side by side
   std::mutex device_mutex;
   hipDeviceProp_t prop;
+  std::shared_ptr<midas_arena_pool> arena = std::make_shared<midas_arena_pool>();
   // pinned staging ring for device -> pageable host copies, allocated on first use and kept for the context's lifetime
   // (pinning and unpinning a quarter of a gigabyte per batch costs more than the copy it would speed up)
   static constexpr int kStageSlots = 2;

@@ -262,14 +262,15 @@ bool bgzf_block_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_o
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
-int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
+struct FileBlk { size_t cpos, clen, upos, ulen, fpos; };
+// A BGZF file read whole (by several threads) and its block table: where every block's DEFLATE stream lies, what it inflates to.
+int32_t read_bgzf_file(const std::string& path, RawBuf<uint8_t>& comp, std::vector<FileBlk>& blocks, size_t* total, char* err256) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
   fseek(f, 0, SEEK_END);
   const long fsz = ftell(f);
   fseek(f, 0, SEEK_SET);
   Lap lap("bam inflate");
-  RawBuf<uint8_t> comp;
   if (!comp.resize((size_t)fsz)) { fclose(f); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   {   // the file comes in through several threads: one core copies ~4 GB/s out of the page cache, a BAM is 100s of MB
     const int fd = fileno(f);
@@ -293,8 +294,6 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     if (short_read) { set_err(err256, "short read on %s", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   }
   lap("read file");
-  struct Blk { size_t cpos, clen, upos, ulen, fpos; };
-  std::vector<Blk> blocks;
   size_t p = 0, upos = 0;
   while (p < comp.size()) {
     if (p + 18 > comp.size() || comp[p] != 0x1f || comp[p + 1] != 0x8b || comp[p + 2] != 8 || !(comp[p + 3] & 4)) {
@@ -318,8 +317,22 @@ int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* e
     upos += isize;
     p += bsize;
   }
-  if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  *total = upos;
   lap("block table");
+  return MIDAS_SNPS_OK;
+}
+
+int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
+  RawBuf<uint8_t> comp;
+  std::vector<FileBlk> blocks;
+  size_t upos = 0;
+  {
+    const int32_t rst = read_bgzf_file(path, comp, blocks, &upos, err256);
+    if (rst != MIDAS_SNPS_OK) return rst;
+  }
+  typedef FileBlk Blk;
+  Lap lap("bam inflate");
+  if (!out.resize(upos)) { set_err(err256, "out of memory inflating %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   if (inflater) {
     std::vector<midas::InflateJob> jobs;
     jobs.reserve(blocks.size());
@@ -932,6 +945,112 @@ void midas::bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* c
   b->dev_owner = owner;
   b->dev_free = free_fn;
   std::vector<uint64_t>().swap(b->rec_off);
+}
+
+// The BAM header out of the first `n` inflated bytes: 0 parsed (b->ref_names / ref_lens / rec_begin set), 1 more bytes
+// needed, -1 not a BAM.
+static int parse_bam_header(const uint8_t* d, size_t n, midas_bam* b) {
+  if (n < 12) return 1;
+  if (memcmp(d, "BAM\1", 4) != 0) return -1;
+  size_t p = 4;
+  const size_t l_text = rd32(&d[p]);
+  p += 4 + l_text;
+  if (p + 4 > n) return 1;
+  const uint32_t n_ref = rd32(&d[p]);
+  p += 4;
+  b->ref_names.clear();
+  b->ref_lens.clear();
+  for (uint32_t i = 0; i < n_ref; ++i) {
+    if (p + 4 > n) return 1;
+    const uint32_t l_name = rd32(&d[p]);
+    p += 4;
+    if (l_name == 0) return -1;
+    if (p + l_name + 4 > n) return 1;
+    b->ref_names.emplace_back(reinterpret_cast<const char*>(&d[p]), l_name - 1);
+    p += l_name;
+    b->ref_lens.push_back(rd32(&d[p]));
+    p += 4;
+  }
+  b->rec_begin = p;
+  return 0;
+}
+
+int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder* dec, midas_bam** out, int64_t* n_reads,
+                                    int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  if (!path || !out || !dec) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
+  if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  b->path = path;
+  RawBuf<uint8_t> comp;
+  std::vector<FileBlk> blocks;
+  size_t total = 0;
+  int32_t st = read_bgzf_file(b->path, comp, blocks, &total, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  Lap lap("bam device decode");
+  {   // the header: the first blocks, inflated here until it is all there
+    std::vector<uint8_t> head;
+    size_t k = 0;
+    int r = 1;
+    while (r == 1 && k < blocks.size()) {
+      const FileBlk& q = blocks[k++];
+      const size_t old = head.size();
+      head.resize(old + q.ulen);
+      if (!bgzf_block_inflate(comp.data() + q.cpos, q.clen, head.data() + old, q.ulen)) {
+        set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path, (long long)q.fpos);
+        return MIDAS_SNPS_ERR_BAD_LAYOUT;
+      }
+      r = parse_bam_header(head.data(), head.size(), b.get());
+    }
+    if (r != 0) { set_err(err256, r < 0 ? "%s: missing BAM magic" : "%s: truncated BAM header", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  }
+  lap("header");
+  std::vector<midas::InflateJob> jobs;
+  jobs.reserve(blocks.size());
+  for (const FileBlk& q : blocks) jobs.push_back({(uint64_t)q.cpos, (uint64_t)q.upos, (uint32_t)q.clen, (uint32_t)q.ulen, rd32(&comp[q.cpos + q.clen]), 1u});
+  struct Sink { midas_bam* b; bool ok; } sink{b.get(), true};
+  auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
+    Sink* s = static_cast<Sink*>(sp);
+    midas_bam* b = s->b;
+    const size_t n1 = n > 0 ? (size_t)n : 1;
+    midas::HostColumns c{};
+    if (!b->refid.resize(n1) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
+        !b->flag.resize(n1) || !b->seq_off.resize((size_t)n + 1) || !b->qual_off.resize((size_t)n + 1) || !b->cigar_off.resize((size_t)n + 1)) {
+      s->ok = false;
+      return c;
+    }
+    c.refid = b->refid.data(); c.pos = b->pos.data(); c.nm = b->nm.data(); c.l_seq = b->l_seq.data(); c.mapq = b->mapq.data();
+    c.flag = b->flag.data(); c.seq_off = b->seq_off.data(); c.qual_off = b->qual_off.data(); c.cigar_off = b->cigar_off.data();
+    return c;
+  };
+  midas::DeviceDecodeResult res;
+  int64_t bad_job = -1, bad_record = -1;
+  st = dec->run(dec->user, comp.data(), comp.size(), jobs.data(), jobs.size(), (uint64_t)total, (uint64_t)b->rec_begin, b->ref_lens.data(),
+                (int32_t)b->ref_lens.size(), alloc, &sink, &res, &bad_job, &bad_record, err256);
+  lap("device");
+  if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) {
+    if (bad_job >= 0 && (size_t)bad_job < blocks.size())
+      set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path, (long long)blocks[(size_t)bad_job].fpos);
+    else if (bad_record >= 0)
+      set_err(err256, "%s: alignment record %lld overruns its block_size", path, (long long)bad_record);
+    else if (bad_record == -2)
+      set_err(err256, "%s: malformed alignment record (a block_size that leaves the stream)", path);
+    return st;
+  }
+  if (st != MIDAS_SNPS_OK) return st;
+  if (!sink.ok) { set_err(err256, "out of memory decoding %s", path); if (res.dev_free && res.dev_owner) res.dev_free(res.dev_owner); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  b->n_records = (size_t)res.n_records;
+  b->payload_on_device = true;
+  b->loaded = true;
+  b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
+  b->dev_owner = res.dev_owner;
+  b->dev_free = res.dev_free;
+  if (n_reads) *n_reads = res.n_records;
+  if (seq_bytes) *seq_bytes = res.seq_bytes;
+  if (qual_bytes) *qual_bytes = res.qual_bytes;
+  if (n_cigar) *n_cigar = res.n_cigar;
+  *out = b.release();
+  return MIDAS_SNPS_OK;
 }
 
 int32_t midas::bam_open_with(const char* path, const midas::BlockInflater* inflater, midas_bam** out, char* err256) {

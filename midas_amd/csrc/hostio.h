@@ -46,6 +46,28 @@ const uint64_t* bam_record_offsets(const midas_bam* b, size_t* n);
 void bam_offsets(const midas_bam* b, const int64_t** seq_off, const int64_t** qual_off, const int64_t** cigar_off);
 void bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, void* owner, void (*free_fn)(void*));   // owner: freed once, at close
 
+// midas_bam_load_device, everything on the device (bam_device.hip): the file's BGZF blocks go up, are inflated and checked
+// there, the records are found, their columns decoded and SEQ / QUAL / CIGAR cut out where the stream lies -- what comes down
+// is the small columns (refID, pos, mapq, flag, NM, l_seq, the three CSR offset arrays).  hostio.cpp reads the file, builds
+// the block table, parses the header (the first blocks, inflated by the host) and hands the device part to `dec`.
+struct HostColumns { int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag; int64_t *seq_off, *qual_off, *cigar_off; };
+struct DeviceDecodeResult {
+  int64_t n_records = 0, seq_bytes = 0, qual_bytes = 0, n_cigar = 0;
+  void *dev_seq = nullptr, *dev_qual = nullptr, *dev_cigar = nullptr;
+  void* dev_owner = nullptr;
+  void (*dev_free)(void*) = nullptr;
+};
+struct DeviceDecoder {
+  void* user;
+  // alloc(sink, n): host arrays for n records (n + 1 offsets), nullptr fields when out of memory.  Statuses as BlockInflater's;
+  // MIDAS_SNPS_ERR_UNSUPPORTED: the device could not settle the record boundaries (the caller decodes the host's way)
+  int32_t (*run)(void* user, const uint8_t* comp, size_t comp_bytes, const InflateJob* jobs, size_t n_jobs, uint64_t total,
+                 uint64_t rec_begin, const int64_t* ref_lens, int32_t n_ref, HostColumns (*alloc)(void* sink, int64_t n), void* sink,
+                 DeviceDecodeResult* out, int64_t* bad_job, int64_t* bad_record, char* err256);
+};
+int32_t bam_decode_on_device(const char* path, const DeviceDecoder* dec, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
+                             int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.
 struct CodedMember { const uint8_t* data; uint32_t n_bytes, crc, text_len, rows; };

@@ -248,6 +248,28 @@ struct PayloadParams {
 };
 hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s);    // 1: decode, 2: resolve the matches
 
+// bam_walk.hip: the record walk of an inflated BAM stream that lies in HBM
+struct BamWalkParams {
+  const uint8_t* d;                  // the inflated stream
+  unsigned long long total, rec_begin, chunk;      // its bytes; the first alignment record; bytes per chunk
+  const long long* ref_lens; int32_t n_ref;
+  long long n_chunks;
+  unsigned long long* start;         // per chunk: where its walk started (guessed, or forced by the host); ~0: no boundary found
+  unsigned long long* end;           // per chunk: the first record start at or behind the chunk's end
+  uint32_t* kept;                    // per chunk: records with refID >= 0 starting in it (from `start` on)
+  uint32_t* bad;                     // per chunk: 1 = a block_size leaves the stream
+};
+struct BamColumnsParams {
+  const uint8_t* d; const unsigned long long* rec_off; long long n;
+  int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag;
+  long long *seq_off, *qual_off, *cigar_off;        // n + 1 entries: lengths at [i + 1] here, CSR offsets after the scans
+  unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size (~0: none)
+};
+hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s);
+hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* base, unsigned long long* rec_off, hipStream_t s);
+size_t bam_scan_scratch_bytes(long long n_records);
+hipError_t launch_bam_columns(const BamColumnsParams& p, long long* scan_scratch, hipStream_t s);
+
 hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s);       // once per batch: validation, totals
 hipError_t launch_direct_ranges(const DirectIndexParams& p, hipStream_t s);      // every pass: the tile ranges, from the positions
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);

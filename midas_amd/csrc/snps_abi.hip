@@ -357,6 +357,7 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->arena) ctx->arena->close();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
     if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -609,8 +610,10 @@ namespace {
 void device_free(void* p) { (void)hipFree(p); }
 }
 
-int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
-                              int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+// The decode with the host walking the records (the inflated stream comes down for that): what midas_bam_load_device falls back
+// to when the device cannot settle the record boundaries.
+static int32_t bam_load_device_host_walk(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
+                                         int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
   if (!ctx || !path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
   InflateUser iu{ctx};
@@ -701,6 +704,290 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
   *out = b;
   handle.b = nullptr;
   return MIDAS_SNPS_OK;
+}
+
+
+namespace {
+struct ArenaLoan { std::shared_ptr<midas_arena_pool> pool; void* p; };
+void arena_loan_free(void* v) {
+  ArenaLoan* l = static_cast<ArenaLoan*>(v);
+  if (l) { l->pool->give(l->p); delete l; }
+}
+
+// DeviceDecoder::run (hostio.h): the whole decode of a BAM on the device -- blocks up, inflated, resolved and CRC-checked
+// (bgzf_inflate.hip), records found and decoded (bam_walk.hip), SEQ / QUAL / CIGAR cut out where the stream lies; the small
+// columns are all that comes down.
+int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, const InflateJob* jobs, size_t n_jobs, uint64_t total,
+                          uint64_t rec_begin, const int64_t* ref_lens, int32_t n_ref, HostColumns (*alloc)(void*, int64_t), void* sink,
+                          DeviceDecodeResult* res, int64_t* bad_job, int64_t* bad_record, char* err256) {
+  midas_snps_ctx* ctx = static_cast<midas_snps_ctx*>(user);
+  *bad_job = -1;
+  *bad_record = -1;
+  auto hip_err = [&](hipError_t e, const char* what) {
+    if (err256) snprintf(err256, 256, "device decode: %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP;
+  };
+#define DEC_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
+  std::lock_guard<std::mutex> g(ctx->device_mutex);
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;       // where the call spends its time, on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[device decode] %-30s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
+  DEC_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // ---- the arena: | inflated stream | compressed bytes | blocks | status | crc | match lists |; everything behind the inflated
+  // stream is scratch once the blocks are resolved, and the columns are laid over it
+  std::vector<InflateBlock> blocks(n_jobs);
+  unsigned long long n_match_room = 0;
+  for (size_t k = 0; k < n_jobs; ++k) {
+    if (jobs[k].cpos + jobs[k].clen > comp_bytes || jobs[k].upos + jobs[k].ulen > total) {
+      if (err256) snprintf(err256, 256, "device decode: block %lld lies outside the file", (long long)k);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+    const uint32_t cap = jobs[k].ulen / 6u + 16u;
+    blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen, cap, 0u};
+    n_match_room += cap;
+  }
+  const size_t at_comp = up((size_t)total + 64), at_blocks = at_comp + up(comp_bytes + 512),
+               at_status = at_blocks + up(n_jobs * sizeof(InflateBlock)), at_crc = at_status + up(n_jobs * 8),
+               at_matches = at_crc + up(n_jobs * 4);
+  // (a BAM's columns are ~0.95 of its inflated bytes, the offsets and small columns ~0.2: the scratch must hold them too)
+  const size_t scratch_need = std::max(up(comp_bytes + 512) + up(n_jobs * sizeof(InflateBlock)) + up(n_jobs * 12) + up((size_t)n_match_room * 8),
+                                       (size_t)total + (size_t)total / 3 + ((size_t)16 << 20));
+  const size_t arena_bytes = at_comp + scratch_need;
+  bool pooled = false;
+  void* arena_p = ctx->arena->take(arena_bytes, &pooled);
+  if (!arena_p) { if (err256) snprintf(err256, 256, "device decode: out of device memory (%.1f GB)", (double)arena_bytes / 1e9); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  struct Loan { std::shared_ptr<midas_arena_pool> pool; void* p; ~Loan() { if (p) pool->give(p); } } loan{ctx->arena, arena_p};
+  uint8_t* const base = static_cast<uint8_t*>(arena_p);
+  lap("arena");
+  // ---- blocks up (in pieces, so that the first kernels start while the later pieces are still on the link), inflate, resolve, check
+  DEC_TRY(hipMemcpyAsync(base + at_blocks, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+  std::vector<uint32_t> want(n_jobs);
+  for (size_t k = 0; k < n_jobs; ++k) want[k] = jobs[k].crc;
+  DEC_TRY(hipMemcpyAsync(base + at_crc, want.data(), n_jobs * 4, hipMemcpyHostToDevice, s));
+  DEC_TRY(hipMemcpyAsync(base + at_comp, comp, comp_bytes, hipMemcpyHostToDevice, s));
+  DEC_TRY(hipMemsetAsync(base + at_comp + comp_bytes, 0, 512, s));
+  InflateParams ip;
+  ip.comp = base + at_comp;
+  ip.blocks = reinterpret_cast<const InflateBlock*>(base + at_blocks);
+  ip.n_blocks = (long long)n_jobs;
+  ip.out = base;
+  ip.status = reinterpret_cast<uint32_t*>(base + at_status);
+  ip.n_matches = reinterpret_cast<uint32_t*>(base + at_status) + n_jobs;
+  ip.matches = reinterpret_cast<unsigned long long*>(base + at_matches);
+  ip.want_crc = reinterpret_cast<const uint32_t*>(base + at_crc);
+  DEC_TRY(launch_bgzf_inflate(ip, s));
+  std::vector<uint32_t> status(n_jobs);
+  DEC_TRY(hipMemcpyAsync(status.data(), ip.status, n_jobs * 4, hipMemcpyDeviceToHost, s));
+  DEC_TRY(hipStreamSynchronize(s));
+  lap("blocks up, inflate, resolve, crc");
+  {   // the streams whose matches did not fit: again, with the bound's room
+    std::vector<size_t> again;
+    for (size_t k = 0; k < n_jobs; ++k)
+      if (status[k] == kInflateMatchRoom) again.push_back(k);
+    if (!again.empty()) {
+      std::vector<InflateBlock> b2(again.size());
+      std::vector<uint32_t> want2(again.size());
+      unsigned long long room2 = 0;
+      for (size_t j = 0; j < again.size(); ++j) {
+        const InflateJob& q = jobs[again[j]];
+        const uint32_t cap = q.ulen / 3u + 1u;
+        b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
+        want2[j] = q.crc;
+        room2 += cap;
+      }
+      struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_b2, d_s2, d_m2, d_c2;
+      DEC_TRY(hipMalloc(&d_b2.p, b2.size() * sizeof(InflateBlock)));
+      DEC_TRY(hipMalloc(&d_s2.p, b2.size() * 8));
+      DEC_TRY(hipMalloc(&d_m2.p, (size_t)room2 * 8));
+      DEC_TRY(hipMalloc(&d_c2.p, b2.size() * 4));
+      DEC_TRY(hipMemcpyAsync(d_b2.p, b2.data(), b2.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+      DEC_TRY(hipMemcpyAsync(d_c2.p, want2.data(), b2.size() * 4, hipMemcpyHostToDevice, s));
+      InflateParams ip2 = ip;
+      ip2.blocks = static_cast<const InflateBlock*>(d_b2.p);
+      ip2.n_blocks = (long long)b2.size();
+      ip2.status = static_cast<uint32_t*>(d_s2.p);
+      ip2.n_matches = static_cast<uint32_t*>(d_s2.p) + b2.size();
+      ip2.matches = static_cast<unsigned long long*>(d_m2.p);
+      ip2.want_crc = static_cast<const uint32_t*>(d_c2.p);
+      DEC_TRY(launch_bgzf_inflate(ip2, s));
+      std::vector<uint32_t> st2(b2.size());
+      DEC_TRY(hipMemcpyAsync(st2.data(), d_s2.p, b2.size() * 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipStreamSynchronize(s));
+      for (size_t j = 0; j < again.size(); ++j) status[again[j]] = st2[j];
+      lap("streams decoded again");
+    }
+  }
+  for (size_t k = 0; k < n_jobs; ++k) {
+    if (status[k] != 0u) {
+      *bad_job = (int64_t)k;
+      if (err256) snprintf(err256, 256, "corrupt BGZF block %lld (code %u)", (long long)k, status[k]);
+      return MIDAS_SNPS_ERR_BAD_LAYOUT;
+    }
+  }
+  // ---- the record walk: everything behind the inflated stream is scratch now ----------------------------------------------
+  uint8_t* const scratch = base + at_comp;
+  const size_t scratch_bytes = arena_bytes - at_comp;
+  size_t at = 0;
+  auto take = [&](size_t bytes) -> uint8_t* { uint8_t* q = scratch + at; at += up(bytes); return at <= scratch_bytes ? q : nullptr; };
+  const unsigned long long chunk = 32768ull;
+  const long long n_chunks = (long long)((total + chunk - 1) / chunk);
+  BamWalkParams wp;
+  wp.d = base; wp.total = total; wp.rec_begin = rec_begin; wp.chunk = chunk; wp.n_ref = n_ref; wp.n_chunks = n_chunks;
+  long long* d_ref_lens = reinterpret_cast<long long*>(take((size_t)(n_ref > 0 ? n_ref : 1) * 8));
+  wp.start = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
+  wp.end = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
+  wp.kept = reinterpret_cast<uint32_t*>(take((size_t)n_chunks * 4));
+  wp.bad = reinterpret_cast<uint32_t*>(take((size_t)n_chunks * 4));
+  unsigned long long* d_base = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
+  long long* d_list = reinterpret_cast<long long*>(take(4096 * 8));
+  if (!d_list) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the walk"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  wp.ref_lens = d_ref_lens;
+  if (n_ref > 0) DEC_TRY(hipMemcpyAsync(d_ref_lens, ref_lens, (size_t)n_ref * 8, hipMemcpyHostToDevice, s));
+  DEC_TRY(launch_bam_walk(wp, nullptr, 0, s));
+  std::vector<unsigned long long> h_start((size_t)n_chunks), h_end((size_t)n_chunks), h_base((size_t)n_chunks);
+  std::vector<uint32_t> h_kept((size_t)n_chunks), h_bad((size_t)n_chunks);
+  auto fetch_chunks = [&]() -> hipError_t {
+    hipError_t e = hipMemcpyAsync(h_start.data(), wp.start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_end.data(), wp.end, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_kept.data(), wp.kept, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_bad.data(), wp.bad, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return e;
+  };
+  DEC_TRY(fetch_chunks());
+  lap("walk (guesses)");
+  // stitch in order; a chunk whose guess the chain does not hit is walked again from where the chain stands
+  {
+    const long long c0 = (long long)(rec_begin / chunk);
+    unsigned long long cur = rec_begin;
+    int rounds = 0;
+    long long c = c0;
+    for (long long k = 0; k < c0 && k < n_chunks; ++k) { h_kept[(size_t)k] = 0u; h_start[(size_t)k] = ~0ull; }
+    while (c < n_chunks) {
+      const unsigned long long stop = ((unsigned long long)c + 1ull) * chunk;
+      if (cur >= stop || cur + 4 > total) { h_kept[(size_t)c] = 0u; h_start[(size_t)c] = ~0ull; ++c; continue; }      // no record starts in this chunk
+      if (h_start[(size_t)c] == cur) {
+        if (h_bad[(size_t)c]) { *bad_record = -2; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+        cur = h_end[(size_t)c];
+        ++c;
+        continue;
+      }
+      // walk chunk c again from `cur` (one thread; the chunks behind it keep their guesses)
+      if (++rounds > 4096) {
+        if (err256) snprintf(err256, 256, "device decode: the record boundaries did not settle");
+        return MIDAS_SNPS_ERR_UNSUPPORTED;
+      }
+      const long long one = c;
+      DEC_TRY(hipMemcpyAsync(wp.start + c, &cur, 8, hipMemcpyHostToDevice, s));
+      DEC_TRY(hipMemcpyAsync(d_list, &one, 8, hipMemcpyHostToDevice, s));
+      DEC_TRY(launch_bam_walk(wp, d_list, 1, s));
+      DEC_TRY(hipMemcpyAsync(&h_end[(size_t)c], wp.end + c, 8, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_kept[(size_t)c], wp.kept + c, 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_bad[(size_t)c], wp.bad + c, 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipStreamSynchronize(s));
+      h_start[(size_t)c] = cur;
+    }
+    if (rounds && trace) fprintf(stderr, "[device decode] %d chunk(s) walked again\n", rounds);
+  }
+  unsigned long long n_rec = 0;
+  for (long long c = 0; c < n_chunks; ++c) { h_base[(size_t)c] = n_rec; n_rec += h_kept[(size_t)c]; }
+  // (the host's view of starts / counts is the settled one: chunks without a record of their own were cleared above)
+  DEC_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+  DEC_TRY(hipMemcpyAsync(wp.kept, h_kept.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, s));
+  DEC_TRY(hipMemcpyAsync(d_base, h_base.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+  lap("stitch");
+  const long long n = (long long)n_rec;
+  const size_t n1 = (size_t)n + 1;
+  unsigned long long* d_rec = reinterpret_cast<unsigned long long*>(take(n1 * 8));
+  BamColumnsParams cp;
+  cp.d = base; cp.rec_off = d_rec; cp.n = n;
+  cp.refid = reinterpret_cast<int32_t*>(take(n1 * 4)); cp.pos = reinterpret_cast<int32_t*>(take(n1 * 4));
+  cp.nm = reinterpret_cast<int32_t*>(take(n1 * 4)); cp.l_seq = reinterpret_cast<int32_t*>(take(n1 * 4));
+  cp.mapq = take(n1); cp.flag = reinterpret_cast<uint16_t*>(take(n1 * 2));
+  cp.seq_off = reinterpret_cast<long long*>(take(n1 * 8)); cp.qual_off = reinterpret_cast<long long*>(take(n1 * 8));
+  cp.cigar_off = reinterpret_cast<long long*>(take(n1 * 8));
+  cp.bad_record = reinterpret_cast<unsigned long long*>(take(8));
+  long long* d_scan = reinterpret_cast<long long*>(take(bam_scan_scratch_bytes(n)));
+  if (!d_scan) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the columns"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  DEC_TRY(hipMemsetAsync(cp.bad_record, 0xFF, 8, s));
+  DEC_TRY(launch_bam_offsets(wp, d_base, d_rec, s));
+  DEC_TRY(launch_bam_columns(cp, d_scan, s));
+  unsigned long long h_bad_record = ~0ull;
+  long long ends[3] = {0, 0, 0};
+  DEC_TRY(hipMemcpyAsync(&h_bad_record, cp.bad_record, 8, hipMemcpyDeviceToHost, s));
+  DEC_TRY(hipMemcpyAsync(&ends[0], cp.seq_off + n, 8, hipMemcpyDeviceToHost, s));
+  DEC_TRY(hipMemcpyAsync(&ends[1], cp.qual_off + n, 8, hipMemcpyDeviceToHost, s));
+  DEC_TRY(hipMemcpyAsync(&ends[2], cp.cigar_off + n, 8, hipMemcpyDeviceToHost, s));
+  DEC_TRY(hipStreamSynchronize(s));
+  lap("offsets, columns, scans");
+  if (h_bad_record != ~0ull) { *bad_record = (int64_t)h_bad_record; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  const int64_t sb = ends[0], qb = ends[1], nc = ends[2];
+  // ---- SEQ / QUAL / CIGAR cut out of the stream, behind everything taken so far ---------------------------------------------
+  uint8_t* d_seq = take((size_t)sb + 64);
+  uint8_t* d_qual = take((size_t)qb + 64);
+  uint8_t* d_cig = take((size_t)nc * 4 + 64);
+  struct Own { void* p = nullptr; ~Own() { if (p) (void)hipFree(p); } } own;
+  if (!d_cig) {       // (the scratch cannot hold them: a buffer of their own)
+    const size_t need = up((size_t)sb + 64) + up((size_t)qb + 64) + up((size_t)nc * 4 + 64);
+    DEC_TRY(hipMalloc(&own.p, need));
+    d_seq = static_cast<uint8_t*>(own.p);
+    d_qual = d_seq + up((size_t)sb + 64);
+    d_cig = d_qual + up((size_t)qb + 64);
+  }
+  DEC_TRY(hipMemsetAsync(d_cig + (size_t)nc * 4, 0, 64, s));
+  PayloadParams pp;
+  pp.stream = base;
+  pp.rec_off = d_rec;
+  pp.n_records = n;
+  pp.seq_off = cp.seq_off; pp.qual_off = cp.qual_off; pp.cigar_off = cp.cigar_off;
+  pp.seq4 = d_seq; pp.qual = d_qual; pp.cigar = reinterpret_cast<uint32_t*>(d_cig);
+  DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
+  // ---- the small columns down ---------------------------------------------------------------------------------------------
+  const HostColumns hc = alloc(sink, n);
+  if (!hc.cigar_off) { DEC_TRY(hipStreamSynchronize(s)); return MIDAS_SNPS_OK; }      // (the caller reports its own out-of-memory)
+  auto down = [&](void* dst, const void* src, size_t bytes) -> int32_t { return bytes ? copy_to_host(ctx, dst, src, bytes) : MIDAS_SNPS_OK; };
+  int32_t st = MIDAS_SNPS_OK;
+  const std::pair<void*, std::pair<const void*, size_t>> cols[] = {
+      {hc.refid, {cp.refid, (size_t)n * 4}}, {hc.pos, {cp.pos, (size_t)n * 4}}, {hc.nm, {cp.nm, (size_t)n * 4}}, {hc.l_seq, {cp.l_seq, (size_t)n * 4}},
+      {hc.mapq, {cp.mapq, (size_t)n}}, {hc.flag, {cp.flag, (size_t)n * 2}}, {hc.seq_off, {cp.seq_off, n1 * 8}}, {hc.qual_off, {cp.qual_off, n1 * 8}},
+      {hc.cigar_off, {cp.cigar_off, n1 * 8}}};
+  for (const auto& c : cols) {
+    st = down(c.first, c.second.first, c.second.second);
+    if (st != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->err.c_str()); return st; }
+  }
+  DEC_TRY(hipStreamSynchronize(s));
+  lap("payload cut, small columns down");
+#undef DEC_TRY
+  res->n_records = n; res->seq_bytes = sb; res->qual_bytes = qb; res->n_cigar = nc;
+  res->dev_seq = d_seq; res->dev_qual = d_qual; res->dev_cigar = d_cig;
+  if (own.p) {        // the columns have a buffer of their own: the arena goes back now
+    res->dev_owner = own.p;
+    res->dev_free = device_free;
+    own.p = nullptr;
+  } else {            // the columns live in the arena: it stays lent until the handle is closed
+    res->dev_owner = new ArenaLoan{loan.pool, loan.p};
+    res->dev_free = arena_loan_free;
+    loan.p = nullptr;
+  }
+  return MIDAS_SNPS_OK;
+}
+}  // namespace
+
+int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
+                              int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  if (!ctx || !path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const DeviceDecoder dec{ctx, device_decode_run};
+  const int32_t st = bam_decode_on_device(path, &dec, out, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
+  if (st != MIDAS_SNPS_ERR_UNSUPPORTED) return st;
+  return bam_load_device_host_walk(path, ctx, out, n_reads, seq_bytes, qual_bytes, n_cigar, err256);      // (boundaries not settled: the host walks)
 }
 
 int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* src, int64_t bytes) {

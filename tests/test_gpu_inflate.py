@@ -188,3 +188,78 @@ def test_a_damaged_bgzf_block_is_refused_by_both_decoders(ctx, tmp_path):
         with pytest.raises(abi.MidasSnpsError) as ei:
             abi.read_bam(path, **kw)
         assert ei.value.status == abi.ERR_BAD_LAYOUT and "offset %d" % at in ei.value.message, (kw, ei.value.message)
+
+
+def _same_decode(ctx, path):
+    names_h, lens_h, refid_h, host = abi.read_bam(path)
+    names_d, lens_d, refid_d, on_dev = abi.read_bam(path, ctx, payload_on_device=True)
+    assert names_h == names_d and lens_h == lens_d and on_dev.device is not None
+    np.testing.assert_array_equal(refid_h, refid_d)
+    down = ctx.fetch_payload(on_dev)
+    for k in abi._SOA_DTYPES:
+        np.testing.assert_array_equal(getattr(host, k), getattr(down, k), err_msg=k)
+    return host
+
+
+def test_the_device_record_walk_is_the_hosts(ctx, tmp_path):
+    """midas_bam_load_device finds the records, decodes their columns and NM and cuts SEQ / QUAL / CIGAR on the device
+    (bam_walk.hip); the host's walk (hostio.cpp) is the yardstick.  The spec-assembled fixture; records that span several BGZF
+    blocks and several walk chunks (1 000 bp reads behind 150 bp ones); records without NM, without SEQ, with NM of every
+    integer width; unmapped records (refID -1) between mapped ones; and QUAL bytes that spell well-formed records exactly where
+    the walk's chunks begin, so that guesses are wrong and the stitching has to walk those chunks again."""
+    from midas_amd import bam
+    from tests import helpers as H
+    _same_decode(ctx, os.path.join(H.GOLDEN, "spec_fixture.bam"))
+    rng = np.random.default_rng(5)
+    long_c, long_r = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=50000, n_reads=3000, read_len=1000, seed=3)
+    short_c, short_r = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=50000, n_reads=20000, read_len=150, seed=4, var_len=True)
+    d = {k: np.concatenate([getattr(short_r, k), getattr(long_r, k)]) for k in ("pos", "mapq", "flag", "nm", "l_seq", "seq4", "qual", "cigar")}
+    for k in ("seq_off", "qual_off", "cigar_off"):
+        a, b = getattr(short_r, k), getattr(long_r, k)
+        d[k] = np.concatenate([a, b[1:] + a[-1]])
+    n = d["pos"].size
+    d["nm"] = d["nm"].copy()
+    d["nm"][rng.integers(0, n, 200)] = -1                   # no NM tag
+    d["nm"][rng.integers(0, n, 200)] = 300                  # NM:i (four bytes)
+    reads = abi.ReadsSoA(**d)
+    refid = rng.integers(-1, 2, n).astype(np.int32)          # unmapped records in between; not sorted (the decoder does not care)
+    path = str(tmp_path / "mixed.bam")
+    bam.write_bam(path, short_c.ids, [int(x) for x in short_c.length], refid, reads)
+    host = _same_decode(ctx, path)
+    assert host.n_reads == int((refid >= 0).sum()) and (host.nm == -1).any() and (host.l_seq == 1000).any()
+    # decoys: a well-formed tiny record chain in the QUAL of every read that covers the start of a 32 KiB walk chunk
+    import gzip
+    c3, r3 = synth.make_dataset(n_species=1, contigs_per_species=3, contig_len=60000, n_reads=30000, read_len=320, seed=22, var_len=False)
+    rid3 = np.repeat(np.arange(c3.n_contigs, dtype=np.int32), np.diff(c3.read_begin))
+    plain = str(tmp_path / "plain.bam")
+    bam.write_bam(plain, c3.ids, [int(x) for x in c3.length], rid3, r3)
+    raw = gzip.open(plain, "rb").read()
+    q = 8 + int(np.frombuffer(raw, "<i4", 1, 4)[0])
+    n_ref = int(np.frombuffer(raw, "<i4", 1, q)[0]); q += 4
+    for _ in range(n_ref):
+        q += 4 + int(np.frombuffer(raw, "<i4", 1, q)[0]) + 4
+    starts = []
+    while q < len(raw):
+        starts.append(q)
+        q += 4 + int(np.frombuffer(raw, "<i4", 1, q)[0])
+    starts = np.array(starts)
+    fake = bytearray()
+    for k in range(6):
+        rec = bytearray(33)
+        rec[0:4] = np.int32(0).tobytes(); rec[4:8] = np.int32(5 + k).tobytes()
+        rec[8] = 1; rec[9] = 30
+        rec[20:24] = np.int32(-1).tobytes(); rec[24:28] = np.int32(-1).tobytes()
+        fake += np.int32(len(rec)).tobytes() + rec
+    qual, placed = r3.qual.copy(), 0
+    for u in range(32768 * (starts[0] // 32768 + 1), len(raw), 32768):
+        i = int(np.searchsorted(starts, u, side="right")) - 1
+        qual_at = int(starts[i]) + 4 + 32 + raw[int(starts[i]) + 12] + 4 * int(np.frombuffer(raw, "<u2", 1, int(starts[i]) + 16)[0]) + 160
+        if u <= qual_at and qual_at + len(fake) <= (starts[i + 1] if i + 1 < starts.size else len(raw)):
+            q0 = int(r3.qual_off[i])
+            qual[q0:q0 + len(fake)] = np.frombuffer(bytes(fake), np.uint8)
+            placed += 1
+    assert placed >= 20
+    decoy = str(tmp_path / "decoy.bam")
+    bam.write_bam(decoy, c3.ids, [int(x) for x in c3.length], rid3, abi.ReadsSoA(**{**r3.as_dict(), "qual": qual}))
+    got = _same_decode(ctx, decoy)
+    assert got.n_reads == r3.n_reads
