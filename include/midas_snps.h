@@ -343,6 +343,13 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
  * Replaces the same `pysam.AlignmentFile` + `fetch(contig, ...)` of midas/run/snps.py:186, 194-199 (which goes through
  * the .bai the reference builds at :130-137; no index file is needed here).                                           */
 int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256);
+/* The decoder's inverse (host only; what puts the synthetic samples of bench.py and the tests on disk -- samtools is not in
+ * the image): records in the given order, refid[i] = reference of record i (-1: unmapped), names "r<i>", aux = NM + YT:Z:UU,
+ * BGZF blocks of 0xff00 bytes deflated at `level` (0-9) by `threads` threads (0: the CPU budget), CRC-32 and the EOF block
+ * as the specification wants them.  No reference counterpart (bowtie2 | samtools view | samtools sort write genomes.bam,
+ * midas/run/snps.py:97-128).                                                                                         */
+int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int64_t* ref_lens,
+                        const midas_snps_reads* reads, const int32_t* refid, int32_t level, int32_t threads, char* err256);
 /* The same decoders with the BGZF blocks inflated ON THE DEVICE of `ctx` (bgzf_inflate.hip: one thread per block, its Huffman
  * tables in LDS) instead of by the host's threads: the compressed bytes go up, the inflated stream comes back, records are
  * walked and decoded into columns by the host as before.  On a 16-CPU host inflating is two thirds of the pileup stage once

@@ -245,6 +245,7 @@ def load_library(build_if_missing: bool = True):
     sig.update({
         'midas_bam_open': (i32, [C.c_char_p, C.POINTER(vp), C.c_char_p]),
         'midas_bam_close': (None, [vp]),
+        'midas_bam_write': (i32, [C.c_char_p, i32, C.POINTER(C.c_char_p), vp, C.POINTER(_Reads), vp, i32, i32, C.c_char_p]),
         'midas_bam_n_refs': (i32, [vp]),
         'midas_bam_ref': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64)]),
         'midas_bam_load': (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
@@ -302,7 +303,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_stats_to_device', 'midas_snps_batch_pack', 'midas_snps_batch_fetch_packed',
     'midas_snps_batch_select_path', 'midas_snps_set_default_path', 'midas_snps_copy_rate', 'midas_snps_stream_rates', 'midas_snps_calibration_pass', 'midas_snps_set_pad_rule', 'midas_snps_set_row_coder',
     'midas_snps_batch_pack_timing',
-    'midas_bam_open', 'midas_bam_close', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
+    'midas_bam_open', 'midas_bam_close', 'midas_bam_write', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
     'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
     'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
@@ -557,6 +558,21 @@ class _Column:
         dt = np.dtype(dtype)
         self.__array_interface__ = {'shape': (int(n),), 'typestr': dt.str, 'data': (int(ptr) if n else 0, True), 'version': 3} \
             if n else np.empty(0, dt).__array_interface__
+
+
+def write_bam(path, ref_names, ref_lengths, refid, reads, level=6, threads=0):
+    """The native BAM writer (midas_bam_write): records in the given order, names "r<i>", aux NM + YT:Z:UU -- the bytes of
+    midas_amd/bam.py's pure-Python writer, made by all cores."""
+    lib = load_library()
+    names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    lens = np.ascontiguousarray(ref_lengths, np.int64)
+    rid = np.ascontiguousarray(refid, np.int32)
+    r = reads._c()
+    err = C.create_string_buffer(256)
+    st = lib.midas_bam_write(path.encode(), len(ref_names), names, lens.ctypes.data_as(C.c_void_p), C.byref(r),
+                             rid.ctypes.data_as(C.c_void_p), int(level), int(threads), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode())
 
 
 def _bam_columns(lib, h, n, sb, qb, nc, owner=None, on_device=False):

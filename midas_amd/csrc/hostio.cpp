@@ -1088,6 +1088,149 @@ int32_t midas::bam_open_with(const char* path, const midas::BlockInflater* infla
   return MIDAS_SNPS_OK;
 }
 
+// ---- the decoder's inverse: BAM-native SoA records -> a BGZF-compressed BAM file (the synthetic samples of bench / tests) ----
+namespace {
+// bytes of record i as this writer lays it out: name "r<i>", bin 4680, no mate, aux = NM (C below 256, i above; none when
+// negative) + "YTZUU\0" -- what midas_amd/bam.py's pure-Python writer produces, byte for byte
+inline size_t name_len_of(uint64_t i) { size_t n = 3; while (i >= 10) { i /= 10; ++n; } return n; }     // 'r', digits, NUL
+inline size_t record_bytes(const midas_snps_reads* r, int64_t i) {
+  const size_t l = (size_t)r->l_seq[i], nc = (size_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+  const int32_t nm = r->nm[i];
+  return 4 + 32 + name_len_of((uint64_t)i) + 4 * nc + (l + 1) / 2 + l + (nm < 0 ? 0 : (nm < 256 ? 4 : 7)) + 6;
+}
+void put_record(const midas_snps_reads* r, const int32_t* refid, int64_t i, uint8_t* o, size_t total) {
+  const uint32_t l = (uint32_t)r->l_seq[i], nc = (uint32_t)(r->cigar_off[i + 1] - r->cigar_off[i]);
+  const size_t nl = name_len_of((uint64_t)i);
+  auto w32 = [&](size_t at, uint32_t v) { memcpy(o + at, &v, 4); };
+  w32(0, (uint32_t)(total - 4));
+  w32(4, (uint32_t)refid[i]);
+  w32(8, (uint32_t)r->pos[i]);
+  w32(12, (uint32_t)nl | ((uint32_t)r->mapq[i] << 8) | (4680u << 16));
+  w32(16, nc | ((uint32_t)(r->flag ? r->flag[i] : 0) << 16));
+  w32(20, l);
+  w32(24, 0xFFFFFFFFu);
+  w32(28, 0xFFFFFFFFu);
+  w32(32, 0u);
+  uint8_t* q = o + 36;
+  q[0] = 'r';
+  { uint64_t v = (uint64_t)i; for (size_t k = nl - 2; k >= 1; --k) { q[k] = (uint8_t)('0' + v % 10); v /= 10; } }
+  q[nl - 1] = 0;
+  q += nl;
+  memcpy(q, r->cigar + r->cigar_off[i], 4ull * nc); q += 4ull * nc;
+  memcpy(q, r->seq4 + r->seq_off[i], (l + 1) / 2); q += (l + 1) / 2;
+  memcpy(q, r->qual + r->qual_off[i], l); q += l;
+  const int32_t nm = r->nm[i];
+  if (nm >= 0 && nm < 256) { q[0] = 'N'; q[1] = 'M'; q[2] = 'C'; q[3] = (uint8_t)nm; q += 4; }
+  else if (nm >= 256) { q[0] = 'N'; q[1] = 'M'; q[2] = 'i'; memcpy(q + 3, &nm, 4); q += 7; }
+  memcpy(q, "YTZUU\0", 6);
+}
+}  // namespace
+
+extern "C" int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int64_t* ref_lens,
+                                   const midas_snps_reads* reads, const int32_t* refid, int32_t level, int32_t threads, char* err256) {
+  if (!path || n_ref < 0 || (n_ref > 0 && (!ref_names || !ref_lens)) || !reads || (reads->n_reads > 0 && !refid) || level < 0 || level > 9)
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  const int64_t n = reads->n_reads;
+  // the header
+  std::string head = "BAM\1";
+  std::string text = "@HD\tVN:1.0\tSO:coordinate\n";
+  for (int32_t k = 0; k < n_ref; ++k) text += "@SQ\tSN:" + std::string(ref_names[k]) + "\tLN:" + std::to_string((long long)ref_lens[k]) + "\n";
+  auto app32 = [&](std::string& d, uint32_t v) { d.append(reinterpret_cast<const char*>(&v), 4); };
+  app32(head, (uint32_t)text.size());
+  head += text;
+  app32(head, (uint32_t)n_ref);
+  for (int32_t k = 0; k < n_ref; ++k) {
+    const std::string nm = ref_names[k];
+    app32(head, (uint32_t)nm.size() + 1);
+    head.append(nm.c_str(), nm.size() + 1);
+    app32(head, (uint32_t)ref_lens[k]);
+  }
+  // where every record starts in the stream
+  std::vector<uint64_t> off((size_t)n + 1);
+  off[0] = head.size();
+  {
+    const size_t piece = 1 << 16, n_pieces = ((size_t)n + piece - 1) / piece;
+    std::vector<uint64_t> sums(n_pieces + 1, 0);
+    run_pool(hw_threads(threads), n_pieces, [&](size_t k) {
+      uint64_t s = 0;
+      for (size_t i = k * piece, e = std::min((size_t)n, i + piece); i < e; ++i) { const size_t b = record_bytes(reads, (int64_t)i); off[i + 1] = b; s += b; }
+      sums[k + 1] = s;
+    });
+    for (size_t k = 0; k < n_pieces; ++k) sums[k + 1] += sums[k];
+    run_pool(hw_threads(threads), n_pieces, [&](size_t k) {
+      uint64_t at = off[0] + sums[k];
+      for (size_t i = k * piece, e = std::min((size_t)n, i + piece); i < e; ++i) { const uint64_t b = off[i + 1]; off[i + 1] = at + b; at += b; }
+    });
+  }
+  const uint64_t total = off[(size_t)n];
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_err(err256, "cannot create %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  const uint64_t kBlock = 0xff00;
+  const uint64_t n_blocks = (total + kBlock - 1) / kBlock;
+  const uint64_t batch = 4096;          // blocks assembled and compressed at a time (256 MB of stream)
+  std::vector<uint8_t> stream, packed;
+  std::vector<uint32_t> packed_len;
+  bool ok = true;
+  for (uint64_t b0 = 0; b0 < n_blocks && ok; b0 += batch) {
+    const uint64_t b1 = std::min(n_blocks, b0 + batch), u0 = b0 * kBlock, u1 = std::min(total, b1 * kBlock);
+    stream.resize((size_t)(u1 - u0));
+    // the stream bytes [u0, u1): header part, then the records that overlap
+    if (u0 < head.size()) memcpy(stream.data(), head.data() + u0, (size_t)(std::min<uint64_t>(head.size(), u1) - u0));
+    const size_t r0 = (size_t)(std::upper_bound(off.begin(), off.end(), u0) - off.begin()) - (u0 >= off[0] ? 1 : 0);
+    const size_t r_first = u0 >= off[0] ? r0 : 0;
+    const size_t r_end = (size_t)(std::lower_bound(off.begin(), off.end(), u1) - off.begin());     // records starting below u1
+    const size_t n_r = r_end > r_first ? r_end - r_first : 0;
+    const size_t piece = 4096, n_pieces = (n_r + piece - 1) / piece;
+    run_pool(hw_threads(threads), n_pieces, [&](size_t k) {
+      std::vector<uint8_t> tmp;
+      for (size_t i = r_first + k * piece, e = std::min(r_end, i + piece); i < e && i < (size_t)n; ++i) {
+        const uint64_t a = off[i], z = off[i + 1];
+        if (z <= u0 || a >= u1) continue;
+        if (a >= u0 && z <= u1) { put_record(reads, refid, (int64_t)i, stream.data() + (a - u0), (size_t)(z - a)); continue; }
+        tmp.resize((size_t)(z - a));
+        put_record(reads, refid, (int64_t)i, tmp.data(), tmp.size());
+        const uint64_t lo = std::max(a, u0), hi = std::min(z, u1);
+        memcpy(stream.data() + (lo - u0), tmp.data() + (lo - a), (size_t)(hi - lo));
+      }
+    });
+    const size_t nb = (size_t)(b1 - b0), cap = 0x10000 + 64;
+    packed.resize(nb * cap);
+    packed_len.assign(nb, 0);
+    std::atomic<int> bad{0};
+    run_pool(hw_threads(threads), nb, [&](size_t k) {
+      const uint8_t* in = stream.data() + k * kBlock;
+      const size_t n_in = (size_t)std::min<uint64_t>(kBlock, (u1 - u0) - k * kBlock);
+      uint8_t* o = packed.data() + k * cap;
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+      zs.next_in = const_cast<Bytef*>(in);
+      zs.avail_in = (uInt)n_in;
+      zs.next_out = o + 18;
+      zs.avail_out = (uInt)(cap - 26);
+      const int rc = deflate(&zs, Z_FINISH);
+      const size_t clen = zs.total_out;
+      deflateEnd(&zs);
+      if (rc != Z_STREAM_END || clen + 26 > 0x10000) { bad = 1; return; }
+      const uint8_t hd[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+      memcpy(o, hd, 16);
+      const uint16_t bsize = (uint16_t)(clen + 25);
+      memcpy(o + 16, &bsize, 2);
+      const uint32_t crc = crc32_of(in, n_in), isize = (uint32_t)n_in;
+      memcpy(o + 18 + clen, &crc, 4);
+      memcpy(o + 22 + clen, &isize, 4);
+      packed_len[k] = (uint32_t)(clen + 26);
+    });
+    if (bad) { ok = false; break; }
+    for (size_t k = 0; k < nb && ok; ++k) ok = fwrite(packed.data() + k * cap, 1, packed_len[k], f) == packed_len[k];
+  }
+  static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) ok = fwrite(eof_block, 1, 28, f) == 28;
+  if (fclose(f) != 0) ok = false;
+  if (!ok) { set_err(err256, "could not write %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  return MIDAS_SNPS_OK;
+}
+
 extern "C" {
 
 void midas_bam_close(midas_bam* b) { delete b; }

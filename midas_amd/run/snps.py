@@ -592,9 +592,9 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
 
 def _inflate_on_device(args, ctx, bampath, ws):
     """args['device_inflate']: 'on' / True, 'off' / False, or 'auto' (the default) -- on where the measurements of DESIGN.md
-    3.4 have the device ahead and its one-call buffers (six times the compressed bytes) fit beside everything else:
-      * one rank and a BAM of 0.5-8 GB (configs[2]: stage 0.64-0.74 s against 0.78-0.89 s; smaller files: the host's threads
-        are as fast);
+    3.4 have the device ahead and its one-call arena (about eight times the compressed bytes) fits beside everything else:
+      * one rank and a BAM of at least 0.5 GB whose decode + batch fit the device's memory (configs[2]: stage 0.34-0.42 s
+        against 0.9-1.06 s with the host's threads inflating; smaller files: the host's threads are as fast);
       * a rank with few CPUs -- eight ranks share a node's cores under torchrun -- and a share of the BAM of 32 MB-8 GB (a
         1.26 GB BAM with the 2 CPUs of an 8-rank node's rank: decode 0.87 s against 3.0 s)."""
     want = args.get('device_inflate', 'auto')
@@ -606,8 +606,12 @@ def _inflate_on_device(args, ctx, bampath, ws):
         size = os.path.getsize(bampath)
     except OSError:
         return False
-    if ws == 1 and (512 << 20) <= size <= (8 << 30):
-        return True
+    if ws == 1 and size >= (512 << 20):
+        try:
+            hbm = int(ctx.device_info()['hbm_bytes'])
+        except Exception:
+            hbm = 0
+        return size * 12 <= hbm          # arena ~8 x, the batch's columns and counts ~3 x
     return utility.cpu_budget() <= 4 and (32 << 20) <= size // max(1, ws) <= (8 << 30)
 
 
@@ -629,7 +633,15 @@ def _count_alleles(args, species, contigs, ctx):
     if plan is None:
         try:
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
-            decoded = abi.read_bam(bampath, inflater, payload_on_device=inflater is not None and ws == 1)
+            try:
+                decoded = abi.read_bam(bampath, inflater, payload_on_device=inflater is not None and ws == 1)
+            except abi.MidasSnpsError as e:
+                # 'auto' chose the device and the device could not (its memory, a HIP error): the host's threads can
+                if inflater is None or args.get('device_inflate', 'auto') != 'auto' or e.status not in (abi.ERR_OUT_OF_MEMORY, abi.ERR_HIP):
+                    raise
+                args['log'].write("device decode failed (%s): decoding with the host's threads\n" % e.message)
+                inflater = None
+                decoded = abi.read_bam(bampath)
         except abi.MidasSnpsError as e:
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)

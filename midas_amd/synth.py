@@ -339,8 +339,9 @@ def write_sample(outdir, db_dir, contigs, reads, line_width=60, gz_fasta=False):
         for k, cid in enumerate(contigs.ids):
             h.write(">%s\n%s\n" % (cid, bytes(contigs.ref[off[k]:off[k + 1]]).decode().upper()))
     refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
-    bam.write_bam(os.path.join(outdir, "snps", "temp", "genomes.bam"), contigs.ids,
-                  [int(x) for x in contigs.length], refid, reads)
+    from . import abi as _abi       # (the native writer: the bytes of bam.write_bam, by all cores -- a configs[3] BAM is 9 GB)
+    _abi.write_bam(os.path.join(outdir, "snps", "temp", "genomes.bam"), contigs.ids,
+                   [int(x) for x in contigs.length], refid, reads)
 
 
 def write_db_tables(db_dir, species_ids):
