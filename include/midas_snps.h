@@ -356,7 +356,11 @@ int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_
  * the pileup and the row coder are on the device; with eight ranks sharing a node's CPUs it is more.  Same results, same
  * statuses (a corrupt block: MIDAS_SNPS_ERR_BAD_LAYOUT); a device failure is an error, not a fall-back.
  *   midas_bam_open_device          = midas_bam_open (whole file; then midas_bam_load as usual)
- *   midas_bam_load_ranges_device   = midas_bam_load_ranges on a handle of midas_bam_open_slice
+ *   midas_bam_open_slice_device    = midas_bam_open_slice with the slice's blocks inflated AND walked on the device (bam_walk.hip):
+ *                                  what comes down is refID / pos / l_seq / reference span / offset of the slice's records, which
+ *                                  the host folds into the same facts (a rank of an 8-rank node has two CPUs for a gigabyte of BAM)
+ *   midas_bam_load_ranges_device   = midas_bam_load_ranges on a handle of midas_bam_open_slice, decoded like midas_bam_load_device:
+ *                                  SEQ / QUAL / CIGAR of the ranges' records stay on the device (midas_bam_payload_on_device == 1)
  *   midas_snps_inflate_blocks      the inflater on its own: n raw DEFLATE streams comp[cpos[k], +clen[k]) -> out[upos[k],
  *                                  +ulen[k]) (host pointers; every stream must inflate to exactly ulen[k] bytes and, when
  *                                  `crc` is not NULL, to bytes whose CRC-32 is crc[k]).  On a corrupt stream *bad_block (may
@@ -372,6 +376,7 @@ int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_
  *                                  midas_snps_reads.seq4 / qual / cigar (they copy device to device).  They belong to `bam`.
  *   midas_snps_copy_from_device    bytes of such a column into host memory (tests; host code that must slice a payload).   */
 int32_t midas_bam_open_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, char* err256);
+int32_t midas_bam_open_slice_device(const char* path, int32_t slice, int32_t n_slices, midas_snps_ctx* ctx, midas_bam** out, char* err256);
 int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
                               int64_t* qual_bytes, int64_t* n_cigar, char* err256);
 int32_t midas_bam_payload_on_device(const midas_bam* bam);

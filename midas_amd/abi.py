@@ -255,6 +255,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_slice_facts': (i32, [vp, vp, vp, vp, vp]),
         'midas_bam_slice_marks': (i32, [vp, vp, vp, vp, C.c_int64]),
         'midas_bam_open_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.c_char_p]),
+        'midas_bam_open_slice_device': (i32, [C.c_char_p, i32, i32, vp, C.POINTER(vp), C.c_char_p]),
         'midas_bam_load_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_payload_on_device': (i32, [vp]),
         'midas_snps_copy_from_device': (i32, [vp, vp, vp, i64]),
@@ -305,7 +306,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_batch_pack_timing',
     'midas_bam_open', 'midas_bam_close', 'midas_bam_write', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
-    'midas_bam_open_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
+    'midas_bam_open_device', 'midas_bam_open_slice_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
     'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
@@ -599,11 +600,15 @@ class BamSlice:
     """Rank-local view of a BAM (midas_bam_open_slice): this rank's share of the file walked, facts to exchange with the
     other ranks, then only the record ranges this rank owns decoded (midas_bam_load_ranges)."""
 
-    def __init__(self, path: str, slice_index: int, n_slices: int):
+    def __init__(self, path: str, slice_index: int, n_slices: int, ctx=None):
+        """ctx (a Context): the slice's blocks are inflated and walked on its device (midas_bam_open_slice_device)."""
         self._lib = load_library()
         h = C.c_void_p()
         err = C.create_string_buffer(256)
-        st = self._lib.midas_bam_open_slice(path.encode(), int(slice_index), int(n_slices), C.byref(h), err)
+        if ctx is not None and getattr(ctx, 'inflates', False):
+            st = self._lib.midas_bam_open_slice_device(path.encode(), int(slice_index), int(n_slices), ctx._h, C.byref(h), err)
+        else:
+            st = self._lib.midas_bam_open_slice(path.encode(), int(slice_index), int(n_slices), C.byref(h), err)
         if st != 0:
             raise MidasSnpsError(st, err.value.decode())
         self._h = h
@@ -629,7 +634,8 @@ class BamSlice:
 
     def load_ranges(self, ranges, ctx=None):
         """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order.
-        ctx (a Context): the blocks are inflated on its device (midas_bam_load_ranges_device)."""
+        ctx (a Context): the ranges are decoded on its device and SEQ / QUAL / CIGAR stay there (midas_bam_load_ranges_device):
+        the ReadsSoA carries their device addresses (`device`), as read_bam(..., payload_on_device=True)'s does."""
         rb = np.array([r[0] for r in ranges], np.int64)
         re_ = np.array([r[1] for r in ranges], np.int64)
         n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
@@ -645,7 +651,8 @@ class BamSlice:
             raise MidasSnpsError(st, err.value.decode())
         keeper = _BamOwner(self._lib, None)
         keeper._slice = self                # the arrays keep this object (and with it the native handle) alive
-        return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value), keeper)
+        return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value), keeper,
+                            on_device=bool(self._lib.midas_bam_payload_on_device(self._h)))
 
     def close(self):
         if getattr(self, '_h', None):

@@ -3,7 +3,8 @@
 // -- without the stream ever coming down to the host.
 //
 // The records form a chain: a record's block_size leads to the next one (SAM spec 4.2).  One thread following it from the
-// first record would make ten million dependent trips to memory.  Here the stream is cut into chunks of 32 KiB and
+// first record would make ten million dependent trips to memory.  Here the stream -- the whole file's, a rank's slice of it, or
+// the runs of blocks that hold a rank's contigs (segments) -- is cut into chunks of at most 32 KiB and
 //   bam_walk_kernel     one thread per chunk: GUESSES a record boundary inside its chunk (the first offset from which four
 //                       plausible records follow one another -- every fixed field in range, a printable NUL-terminated
 //                       name, CIGAR op codes <= 8, the variable parts inside block_size) and walks the chain from there to
@@ -36,8 +37,8 @@ constexpr unsigned long long kNone = ~0ull;
 constexpr int kChain = 4;
 
 // Could an alignment record start at d + u?  (The host's plausible_bytes, hostio.cpp.)  *bs = its block_size.
-__device__ bool plausible(const BamWalkParams& p, unsigned long long u, uint32_t* bs_out) {
-  if (u + 36 > p.total) return false;
+__device__ bool plausible(const BamWalkParams& p, unsigned long long u, unsigned long long total, uint32_t* bs_out) {
+  if (u + 36 > total) return false;
   const uint8_t* r = p.d + u;
   const uint32_t bs = rd32(r);
   if (bs < 32u || bs > (1u << 26)) return false;
@@ -48,7 +49,7 @@ __device__ bool plausible(const BamWalkParams& p, unsigned long long u, uint32_t
   if (refid >= 0 && (long long)pos > p.ref_lens[refid]) return false;
   if (lrn < 1u || l > (1u << 26)) return false;
   if (32ull + lrn + 4ull * n_cig + (l + 1u) / 2u + l > bs) return false;
-  if (u + 4ull + 32ull + lrn + 4ull * n_cig > p.total) return false;
+  if (u + 4ull + 32ull + lrn + 4ull * n_cig > total) return false;
   const uint8_t* name = r + 36;
   if (name[lrn - 1u] != 0) return false;
   for (uint32_t k = 0; k + 1u < lrn; ++k)
@@ -63,59 +64,64 @@ __device__ bool plausible(const BamWalkParams& p, unsigned long long u, uint32_t
 __global__ __launch_bounds__(64) void bam_walk_kernel(BamWalkParams p, const long long* list, long long n_list) {
   const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
   long long c;
-  unsigned long long start;
   if (list) {
     if (i >= n_list) return;
     c = list[i];
-    start = p.start[c];                                 // forced: where the chain stands
   } else {
     if (i >= p.n_chunks) return;
     c = i;
-    const unsigned long long lo = (unsigned long long)c * p.chunk, hi = lo + p.chunk < p.total ? lo + p.chunk : p.total;
-    start = kNone;
-    if (p.rec_begin >= lo && p.rec_begin < hi) {
-      start = p.rec_begin;                              // the true first record
-    } else if (lo > p.rec_begin) {
-      for (unsigned long long u = lo; u < hi && u + 36 <= p.total && start == kNone; ++u) {
-        unsigned long long v = u;
-        int ok = 0;
-        while (ok < kChain) {
-          if (v == p.total) break;                      // the stream ends on a record boundary: as good as a full chain
-          uint32_t bs = 0;
-          if (!plausible(p, v, &bs)) { ok = -1; break; }
-          v += 4ull + bs;
-          if (v > p.total) { ok = -1; break; }
-          ++ok;
-        }
-        if (ok >= 0) start = u;
+  }
+  const unsigned long long lo = p.lo[c], hi = p.hi[c], total = p.limit[c], stop = p.stop[c] < hi ? p.stop[c] : hi;
+  unsigned long long start = kNone;
+  if (list || p.forced[c]) {
+    start = p.start[c];                                 // given: a known record start, or where the chain stands
+  } else {
+    for (unsigned long long u = lo; u < hi && u + 36 <= total && start == kNone; ++u) {
+      unsigned long long v = u;
+      int ok = 0;
+      while (ok < kChain) {
+        if (v == total) break;                          // the segment ends on a record boundary: as good as a full chain
+        uint32_t bs = 0;
+        if (!plausible(p, v, total, &bs)) { ok = -1; break; }
+        v += 4ull + bs;
+        if (v > total) { ok = -1; break; }
+        ++ok;
       }
+      if (ok >= 0) start = u;
     }
     p.start[c] = start;
   }
-  const unsigned long long stop = ((unsigned long long)c + 1ull) * p.chunk;
-  uint32_t kept = 0, bad = 0;
+  uint32_t kept = 0, unmapped = 0, bad = 0;
+  unsigned long long first_unmapped = kNone;
   unsigned long long q = start;
   if (start != kNone) {
-    while (q + 4 <= p.total && q < stop) {
+    while (q + 4 <= total && q < stop) {
       const uint32_t bs = rd32(p.d + q);
-      if (bs < 32u || q + 4ull + bs > p.total) { bad = 1u; break; }
-      kept += (int32_t)rd32(p.d + q + 4) >= 0 ? 1u : 0u;
+      if (bs < 32u || q + 4ull + bs > total) { bad = 1u; break; }
+      if ((int32_t)rd32(p.d + q + 4) >= 0) {
+        ++kept;
+      } else {
+        if (!unmapped) first_unmapped = q;
+        ++unmapped;
+      }
       q += 4ull + bs;
     }
   }
   p.end[c] = q;
   p.kept[c] = kept;
+  p.unmapped[c] = unmapped;
+  p.first_unmapped[c] = first_unmapped;
   p.bad[c] = bad;
 }
 
 __global__ __launch_bounds__(64) void bam_offsets_kernel(BamWalkParams p, const unsigned long long* base, unsigned long long* rec_off) {
   const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
   if (c >= p.n_chunks || p.kept[c] == 0u) return;
-  const unsigned long long stop = ((unsigned long long)c + 1ull) * p.chunk;
+  const unsigned long long hi = p.hi[c], total = p.limit[c], stop = p.stop[c] < hi ? p.stop[c] : hi;
   unsigned long long q = p.start[c], j = base[c];
-  while (q + 4 <= p.total && q < stop) {
+  while (q + 4 <= total && q < stop) {
     const uint32_t bs = rd32(p.d + q);
-    if (bs < 32u || q + 4ull + bs > p.total) break;
+    if (bs < 32u || q + 4ull + bs > total) break;
     if ((int32_t)rd32(p.d + q + 4) >= 0) rec_off[j++] = q;
     q += 4ull + bs;
   }
@@ -186,6 +192,17 @@ __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   if (body > bs) atomicMin(p.bad_record, (unsigned long long)i);
   else nm = find_nm(r + 4 + body, r + 4 + bs);
   p.nm[i] = nm;
+  if (p.span) {       // reference span: the lengths of the ops that consume reference (M, D, N, =, X)
+    long long span = 0;
+    if (body <= bs) {
+      const uint8_t* cg = r + 36 + lrn;
+      for (uint32_t k = 0; k < n_cig; ++k) {
+        const uint32_t v = rd32(cg + 4u * k), op = v & 15u;
+        if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) span += v >> 4;
+      }
+    }
+    p.span[i] = (int32_t)(span > 0x7FFFFFFFll ? 0x7FFFFFFFll : span);
+  }
 }
 
 // ---- inclusive scan of an int64 array, in place: tiles of 4096, three launches ---------------------------------------------

@@ -975,6 +975,17 @@ static int parse_bam_header(const uint8_t* d, size_t n, midas_bam* b) {
   return 0;
 }
 
+static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) {
+  const size_t n1 = n > 0 ? (size_t)n : 1;
+  if (!b->refid.resize(n1) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
+      !b->flag.resize(n1) || !b->seq_off.resize((size_t)n + 1) || !b->qual_off.resize((size_t)n + 1) || !b->cigar_off.resize((size_t)n + 1))
+    return false;
+  c->refid = b->refid.data(); c->pos = b->pos.data(); c->nm = b->nm.data(); c->l_seq = b->l_seq.data(); c->mapq = b->mapq.data();
+  c->flag = b->flag.data(); c->seq_off = b->seq_off.data(); c->qual_off = b->qual_off.data(); c->cigar_off = b->cigar_off.data();
+  c->span = nullptr; c->rec_off = nullptr;
+  return true;
+}
+
 int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder* dec, midas_bam** out, int64_t* n_reads,
                                     int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
   if (!path || !out || !dec) return MIDAS_SNPS_ERR_INVALID_ARG;
@@ -1011,22 +1022,16 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
   struct Sink { midas_bam* b; bool ok; } sink{b.get(), true};
   auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
     Sink* s = static_cast<Sink*>(sp);
-    midas_bam* b = s->b;
-    const size_t n1 = n > 0 ? (size_t)n : 1;
     midas::HostColumns c{};
-    if (!b->refid.resize(n1) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
-        !b->flag.resize(n1) || !b->seq_off.resize((size_t)n + 1) || !b->qual_off.resize((size_t)n + 1) || !b->cigar_off.resize((size_t)n + 1)) {
-      s->ok = false;
-      return c;
-    }
-    c.refid = b->refid.data(); c.pos = b->pos.data(); c.nm = b->nm.data(); c.l_seq = b->l_seq.data(); c.mapq = b->mapq.data();
-    c.flag = b->flag.data(); c.seq_off = b->seq_off.data(); c.qual_off = b->qual_off.data(); c.cigar_off = b->cigar_off.data();
+    if (!alloc_host_columns(s->b, n, &c)) s->ok = false;
     return c;
   };
   midas::DeviceDecodeResult res;
   int64_t bad_job = -1, bad_record = -1;
-  st = dec->run(dec->user, comp.data(), comp.size(), jobs.data(), jobs.size(), (uint64_t)total, (uint64_t)b->rec_begin, b->ref_lens.data(),
-                (int32_t)b->ref_lens.size(), alloc, &sink, &res, &bad_job, &bad_record, err256);
+  midas::DecodeSegment seg;
+  seg.job_lo = 0; seg.job_hi = jobs.size(); seg.from = (uint64_t)b->rec_begin; seg.exact = 1; seg.stop = (uint64_t)total;
+  st = dec->run(dec->user, comp.data(), jobs.data(), jobs.size(), (uint64_t)total, &seg, 1, b->ref_lens.data(), (int32_t)b->ref_lens.size(),
+                1, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
   lap("device");
   if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) {
     if (bad_job >= 0 && (size_t)bad_job < blocks.size())
@@ -1310,6 +1315,39 @@ int32_t midas_bam_copy(const midas_bam* b, int32_t* refid, int32_t* pos, uint8_t
 }
 
 int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256) {
+  return midas::bam_open_slice_with(path, slice, n_slices, nullptr, out, err256);
+}
+}  // extern "C"
+
+// One record's contribution to a slice's facts (the same bookkeeping for the host's walk and the device's columns)
+namespace {
+struct SliceFold {
+  midas_bam* b;
+  int32_t prev_ref = -1;
+  int64_t prev_pos = -1, mark_bin = 0;
+  void mapped(int32_t refid, int64_t pos, int64_t span, int64_t l_seq, uint64_t u, bool after_unmapped) {
+    if (after_unmapped || refid < prev_ref) b->slice_sorted = 0;
+    if (refid == prev_ref && pos < prev_pos) b->slice_pos_sorted = 0;
+    if (b->slice_first_ref < 0) { b->slice_first_ref = refid; b->slice_first_pos = pos; }
+    b->slice_last_ref = refid;
+    b->slice_last_pos = pos;
+    if (refid != prev_ref) mark_bin = 0;
+    prev_ref = refid;
+    prev_pos = pos;
+    if (span > b->ref_span[refid]) b->ref_span[refid] = span;
+    const int64_t bin = pos > 0 ? pos / MIDAS_BAM_MARK_SPAN : 0;
+    if (bin > mark_bin) {
+      b->marks.push_back(refid); b->marks.push_back(bin); b->marks.push_back((int64_t)u);
+      mark_bin = bin;
+    }
+    b->ref_reads[refid] += 1;
+    b->ref_bases[refid] += l_seq;
+    if (b->ref_first[refid] < 0) b->ref_first[refid] = (int64_t)u;
+  }
+};
+}  // namespace
+
+int32_t midas::bam_open_slice_with(const char* path, int32_t slice, int32_t n_slices, const midas::DeviceDecoder* dec, midas_bam** out, char* err256) {
   if (!path || !out || n_slices < 1 || slice < 0 || slice >= n_slices) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
   std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
@@ -1359,13 +1397,65 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u_lo) lo = mid + 1; else hi = mid; }
     w.b_lo = w.b_hi = lo;
   }
+  if (dec && u_lo < u_hi && w.b_lo < nb) {
+    // ---- the device: the slice's blocks (and a margin behind them, for the record that straddles the slice's end) inflated
+    // and walked there; what comes down is refID / pos / l_seq / reference span / offset of every record that starts in the
+    // slice, folded into the facts below exactly as the host's walk folds them
+    const size_t j_lo = w.b_lo, j_hi = std::min(nb, std::max(b_hi, j_lo + 1) + 256);
+    const uint64_t ubase = m.blocks[j_lo].upos;
+    std::vector<midas::InflateJob> jobs;
+    jobs.reserve(j_hi - j_lo);
+    for (size_t j = j_lo; j < j_hi; ++j) {
+      const BgzfMap::Blk& q = m.blocks[j];
+      jobs.push_back({(uint64_t)q.cpos, q.upos - ubase, (uint32_t)q.clen, q.ulen, rd32(m.base + q.cpos + q.clen), 1u});
+    }
+    const uint64_t total = (j_hi < nb ? m.blocks[j_hi].upos : m.total) - ubase;
+    midas::DecodeSegment seg;
+    seg.job_lo = 0; seg.job_hi = jobs.size(); seg.from = u_lo - ubase; seg.exact = u_lo == rec_begin ? 1 : 0; seg.stop = u_hi - ubase;
+    struct Cols { std::vector<int32_t> refid, pos, l_seq, span, nm; std::vector<uint8_t> mapq; std::vector<uint16_t> flag;
+                  std::vector<int64_t> so, qo, co; std::vector<uint64_t> rec; bool ok = true; } cols;
+    auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
+      Cols* c = static_cast<Cols*>(sp);
+      midas::HostColumns h{};
+      try {
+        const size_t n1 = n > 0 ? (size_t)n : 1;
+        c->refid.resize(n1); c->pos.resize(n1); c->l_seq.resize(n1); c->span.resize(n1); c->nm.resize(n1); c->mapq.resize(n1);
+        c->flag.resize(n1); c->so.resize((size_t)n + 1); c->qo.resize((size_t)n + 1); c->co.resize((size_t)n + 1); c->rec.resize(n1);
+      } catch (...) { c->ok = false; return h; }
+      h.refid = c->refid.data(); h.pos = c->pos.data(); h.nm = c->nm.data(); h.l_seq = c->l_seq.data(); h.mapq = c->mapq.data();
+      h.flag = c->flag.data(); h.seq_off = c->so.data(); h.qual_off = c->qo.data(); h.cigar_off = c->co.data();
+      h.span = c->span.data(); h.rec_off = c->rec.data();
+      return h;
+    };
+    midas::DeviceDecodeResult res;
+    int64_t bad_job = -1, bad_record = -1;
+    const int32_t dst = dec->run(dec->user, m.base, jobs.data(), jobs.size(), total, &seg, 1, b->ref_lens.data(), (int32_t)n_ref, 0, 1, alloc, &cols,
+                                 &res, &bad_job, &bad_record, err256);
+    if (dst == MIDAS_SNPS_ERR_BAD_LAYOUT && bad_job >= 0) {
+      set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path, (long long)m.blocks[j_lo + (size_t)bad_job].fpos);
+      return dst;
+    }
+    if (dst != MIDAS_SNPS_OK && dst != MIDAS_SNPS_ERR_UNSUPPORTED && dst != MIDAS_SNPS_ERR_BAD_LAYOUT) return dst;
+    if (dst == MIDAS_SNPS_OK && cols.ok && seg.first != ~0ull) {
+      b->slice_first = (int64_t)(seg.first + ubase);
+      b->slice_end = (int64_t)(seg.end + ubase);
+      SliceFold fold{b.get()};
+      for (int64_t i = 0; i < res.n_records; ++i) {
+        const uint64_t u = cols.rec[(size_t)i] + ubase;
+        fold.mapped(cols.refid[(size_t)i], cols.pos[(size_t)i], cols.span[(size_t)i], cols.l_seq[(size_t)i], u,
+                    seg.first_unmapped != ~0ull && cols.rec[(size_t)i] > seg.first_unmapped);
+      }
+      *out = b.release();
+      return MIDAS_SNPS_OK;
+    }
+    // (no boundary inside the slice, boundaries that did not settle, a record longer than the margin: the host's walk decides)
+  }
   if (!w.extend(std::max(b_hi, w.b_lo + 1))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   // The first record that starts in the slice: known exactly when the slice begins at the header's end, else guessed
   // (32 plausible records in a row) -- and verified by the caller against the end of the slice before.
   uint64_t u = u_lo == rec_begin ? rec_begin : (uint64_t)guess_record_start(w, u_lo, b->ref_lens, 32);
   b->slice_first = (int64_t)u;
-  int32_t prev_ref = -1;
-  int64_t prev_pos = -1, mark_bin = 0;
+  SliceFold fold{b.get()};
   bool seen_unmapped = false;
   while (u < u_hi && u < m.total) {
     uint32_t bs = 0;
@@ -1376,35 +1466,17 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
     const uint8_t* r = w.at(u);
     const int32_t refid = (int32_t)rd32(r + 4);
     if (refid >= 0) {
-      if (seen_unmapped || refid < prev_ref) b->slice_sorted = 0;
-      const int64_t pos = (int32_t)rd32(r + 8);
-      if (refid == prev_ref && pos < prev_pos) b->slice_pos_sorted = 0;
-      if (b->slice_first_ref < 0) { b->slice_first_ref = refid; b->slice_first_pos = pos; }
-      b->slice_last_ref = refid;
-      b->slice_last_pos = pos;
-      if (refid != prev_ref) mark_bin = 0;
-      prev_ref = refid;
-      prev_pos = pos;
-      {   // reference span: the lengths of the ops that consume reference (M, D, N, =, X)
-        const uint32_t l_name = r[12], n_cig = rd16(r + 16);
-        int64_t span = 0;
-        if (36ull + l_name + 4ull * n_cig <= 4ull + bs) {
-          const uint8_t* cg = r + 36 + l_name;
-          for (uint32_t k = 0; k < n_cig; ++k) {
-            const uint32_t v = rd32(cg + 4 * k), op = v & 15u;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
-          }
+      // reference span: the lengths of the ops that consume reference (M, D, N, =, X)
+      const uint32_t l_name = r[12], n_cig = rd16(r + 16);
+      int64_t span = 0;
+      if (36ull + l_name + 4ull * n_cig <= 4ull + bs) {
+        const uint8_t* cg = r + 36 + l_name;
+        for (uint32_t k = 0; k < n_cig; ++k) {
+          const uint32_t v = rd32(cg + 4 * k), op = v & 15u;
+          if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4;
         }
-        if (span > b->ref_span[refid]) b->ref_span[refid] = span;
       }
-      const int64_t bin = pos > 0 ? pos / MIDAS_BAM_MARK_SPAN : 0;
-      if (bin > mark_bin) {
-        b->marks.push_back(refid); b->marks.push_back(bin); b->marks.push_back((int64_t)u);
-        mark_bin = bin;
-      }
-      b->ref_reads[refid] += 1;
-      b->ref_bases[refid] += (int64_t)rd32(r + 20);
-      if (b->ref_first[refid] < 0) b->ref_first[refid] = (int64_t)u;
+      fold.mapped(refid, (int32_t)rd32(r + 8), span, (int64_t)rd32(r + 20), u, seen_unmapped);
     } else {
       seen_unmapped = true;
     }
@@ -1414,6 +1486,8 @@ int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, 
   *out = b.release();
   return MIDAS_SNPS_OK;
 }
+
+extern "C" {
 
 int32_t midas_bam_slice_facts(const midas_bam* b, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases, int64_t* ref_first) {
   if (!b || !b->map || !out7) return MIDAS_SNPS_ERR_INVALID_ARG;
@@ -1443,6 +1517,94 @@ int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* ran
   return midas::bam_load_ranges_with(b, nullptr, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
 }
 }  // extern "C"
+
+// A rank's record ranges decoded on the device: every range is a segment of its own (the blocks from the one holding its first
+// byte to the one holding its last), its first record known exactly; SEQ / QUAL / CIGAR stay on the device.
+int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecoder* dec, int32_t n_ranges, const int64_t* range_begin,
+                                         const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                                         int64_t* n_cigar, char* err256) {
+  if (!b || !b->map || !dec || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const BgzfMap& m = *b->map;
+  const size_t nb = m.blocks.size();
+  auto block_of = [&](uint64_t u) {   // the block holding uncompressed offset u (u < total)
+    size_t lo = 0, hi = nb;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  std::vector<midas::InflateJob> jobs;
+  std::vector<midas::DecodeSegment> segs;
+  std::vector<size_t> job_block;
+  uint64_t at = 0;
+  for (int32_t k = 0; k < n_ranges; ++k) {
+    if (range_begin[k] < (int64_t)b->rec_begin || range_end[k] < range_begin[k] || (uint64_t)range_end[k] > m.total) {
+      set_err(err256, "%s: record range %lld outside the file", b->path.c_str(), (long long)k);
+      return MIDAS_SNPS_ERR_INVALID_ARG;
+    }
+    if (range_end[k] == range_begin[k]) continue;
+    const size_t b0 = block_of((uint64_t)range_begin[k]), b1 = block_of((uint64_t)range_end[k] - 1);
+    midas::DecodeSegment sg;
+    sg.job_lo = jobs.size();
+    const uint64_t seg_base = at, ubase = m.blocks[b0].upos;
+    for (size_t j = b0; j <= b1; ++j) {
+      const BgzfMap::Blk& q = m.blocks[j];
+      jobs.push_back({(uint64_t)q.cpos, at, (uint32_t)q.clen, q.ulen, rd32(m.base + q.cpos + q.clen), 1u});
+      job_block.push_back(j);
+      at += q.ulen;
+    }
+    sg.job_hi = jobs.size();
+    sg.from = seg_base + ((uint64_t)range_begin[k] - ubase);
+    sg.exact = 1;
+    sg.stop = seg_base + ((uint64_t)range_end[k] - ubase);
+    segs.push_back(sg);
+  }
+  struct Sink { midas_bam* b; bool ok; } sink{b, true};
+  auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
+    Sink* s = static_cast<Sink*>(sp);
+    midas::HostColumns c{};
+    if (!alloc_host_columns(s->b, n, &c)) s->ok = false;
+    return c;
+  };
+  midas::DeviceDecodeResult res;
+  int64_t bad_job = -1, bad_record = -1;
+  if (b->dev_free && b->dev_owner) { b->dev_free(b->dev_owner); b->dev_owner = nullptr; }      // (a handle is loaded once; be safe)
+  if (segs.empty()) {
+    midas::HostColumns c{};
+    if (!alloc_host_columns(b, 0, &c)) { set_err(err256, "out of memory decoding %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+    b->seq_off[0] = b->qual_off[0] = b->cigar_off[0] = 0;
+  } else {
+    const int32_t st = dec->run(dec->user, m.base, jobs.data(), jobs.size(), at, segs.data(), segs.size(), b->ref_lens.data(), (int32_t)b->ref_lens.size(),
+                                1, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
+    if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) {
+      if (bad_job >= 0 && (size_t)bad_job < job_block.size())
+        set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", b->path.c_str(), (long long)m.blocks[job_block[(size_t)bad_job]].fpos);
+      else if (bad_record >= 0)
+        set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)bad_record);
+      else
+        set_err(err256, "%s: record range ends inside a record", b->path.c_str());
+      return st;
+    }
+    if (st != MIDAS_SNPS_OK) return st;
+    if (!sink.ok) { if (res.dev_free && res.dev_owner) res.dev_free(res.dev_owner); set_err(err256, "out of memory decoding %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+    for (const midas::DecodeSegment& sg : segs) {
+      if (sg.end != sg.stop) {         // the chain from the range's first record must land exactly on its end
+        if (res.dev_free && res.dev_owner) res.dev_free(res.dev_owner);
+        set_err(err256, "%s: record range ends inside a record", b->path.c_str());
+        return MIDAS_SNPS_ERR_BAD_LAYOUT;
+      }
+    }
+  }
+  b->n_records = (size_t)res.n_records;
+  b->payload_on_device = true;
+  b->loaded = true;
+  b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
+  b->dev_owner = res.dev_owner;
+  b->dev_free = res.dev_free;
+  if (n_reads) *n_reads = res.n_records;
+  if (seq_bytes) *seq_bytes = res.seq_bytes;
+  if (qual_bytes) *qual_bytes = res.qual_bytes;
+  if (n_cigar) *n_cigar = res.n_cigar;
+  return MIDAS_SNPS_OK;
+}
 
 int32_t midas::bam_load_ranges_with(midas_bam* b, const midas::BlockInflater* inflater, int32_t n_ranges, const int64_t* range_begin,
                                     const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,

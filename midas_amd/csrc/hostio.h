@@ -50,23 +50,48 @@ void bam_set_device_payload(midas_bam* b, void* seq4, void* qual, void* cigar, v
 // there, the records are found, their columns decoded and SEQ / QUAL / CIGAR cut out where the stream lies -- what comes down
 // is the small columns (refID, pos, mapq, flag, NM, l_seq, the three CSR offset arrays).  hostio.cpp reads the file, builds
 // the block table, parses the header (the first blocks, inflated by the host) and hands the device part to `dec`.
-struct HostColumns { int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag; int64_t *seq_off, *qual_off, *cigar_off; };
+struct HostColumns {
+  int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag; int64_t *seq_off, *qual_off, *cigar_off;
+  int32_t* span; uint64_t* rec_off;        // (only asked for by the slice walk: reference span and buffer offset of every record)
+};
 struct DeviceDecodeResult {
   int64_t n_records = 0, seq_bytes = 0, qual_bytes = 0, n_cigar = 0;
   void *dev_seq = nullptr, *dev_qual = nullptr, *dev_cigar = nullptr;
   void* dev_owner = nullptr;
   void (*dev_free)(void*) = nullptr;
 };
+// A run of consecutive BGZF blocks of the file, inflated back to back into the decode buffer, and the records wanted from it.
+struct DecodeSegment {
+  size_t job_lo, job_hi;        // its blocks: jobs [job_lo, job_hi)
+  uint64_t from;                // buffer offset of its first record (exact != 0), or of where to start guessing one
+  int32_t exact;
+  uint64_t stop;                // records that start at or behind this buffer offset are not wanted (the blocks reach a little further)
+  // out
+  uint64_t first = ~0ull;       // the first record found (~0: none)
+  uint64_t end = 0;             // the first record start at or behind `stop` that the chain reached (the segment's end when it ran out)
+  int64_t n_records = 0, n_unmapped = 0;
+  uint64_t first_unmapped = ~0ull;
+};
 struct DeviceDecoder {
   void* user;
-  // alloc(sink, n): host arrays for n records (n + 1 offsets), nullptr fields when out of memory.  Statuses as BlockInflater's;
-  // MIDAS_SNPS_ERR_UNSUPPORTED: the device could not settle the record boundaries (the caller decodes the host's way)
-  int32_t (*run)(void* user, const uint8_t* comp, size_t comp_bytes, const InflateJob* jobs, size_t n_jobs, uint64_t total,
-                 uint64_t rec_begin, const int64_t* ref_lens, int32_t n_ref, HostColumns (*alloc)(void* sink, int64_t n), void* sink,
-                 DeviceDecodeResult* out, int64_t* bad_job, int64_t* bad_record, char* err256);
+  // jobs[k]: cpos = offset of block k's DEFLATE stream from comp_base (the mapped / read file), upos = where it inflates to in
+  // the decode buffer of buffer_bytes.  payload: cut SEQ / QUAL / CIGAR and leave them on the device (res->dev_*); extra: also
+  // hand out span and rec_off.  alloc(sink, n): host arrays for n records (n + 1 offsets), nullptr fields when out of memory.
+  // Statuses as BlockInflater's; MIDAS_SNPS_ERR_UNSUPPORTED: the device could not settle the record boundaries (the caller
+  // decodes the host's way).  *bad_record: index of a record that overruns its block_size, -2: a block_size leaves its segment.
+  int32_t (*run)(void* user, const uint8_t* comp_base, const InflateJob* jobs, size_t n_jobs, uint64_t buffer_bytes, DecodeSegment* segs,
+                 size_t n_segs, const int64_t* ref_lens, int32_t n_ref, int payload, int extra, HostColumns (*alloc)(void* sink, int64_t n),
+                 void* sink, DeviceDecodeResult* out, int64_t* bad_job, int64_t* bad_record, char* err256);
 };
 int32_t bam_decode_on_device(const char* path, const DeviceDecoder* dec, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
                              int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+// midas_bam_open_slice / midas_bam_load_ranges with the device doing the work (dec == nullptr: the host's threads, as before):
+// the slice's blocks are inflated and walked on the device, the host folds the records' columns into the slice's facts; a
+// rank's record ranges are decoded like a whole file, SEQ / QUAL / CIGAR staying on the device
+int32_t bam_open_slice_with(const char* path, int32_t slice, int32_t n_slices, const DeviceDecoder* dec, midas_bam** out, char* err256);
+int32_t bam_load_ranges_on_device(midas_bam* bam, const DeviceDecoder* dec, int32_t n_ranges, const int64_t* range_begin,
+                                  const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
+                                  int64_t* n_cigar, char* err256);
 
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.

@@ -250,19 +250,27 @@ hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream
 
 // bam_walk.hip: the record walk of an inflated BAM stream that lies in HBM
 struct BamWalkParams {
-  const uint8_t* d;                  // the inflated stream
-  unsigned long long total, rec_begin, chunk;      // its bytes; the first alignment record; bytes per chunk
+  const uint8_t* d;                  // the inflated bytes: one or several SEGMENTS (runs of consecutive BGZF blocks) back to back
   const long long* ref_lens; int32_t n_ref;
   long long n_chunks;
-  unsigned long long* start;         // per chunk: where its walk started (guessed, or forced by the host); ~0: no boundary found
-  unsigned long long* end;           // per chunk: the first record start at or behind the chunk's end
-  uint32_t* kept;                    // per chunk: records with refID >= 0 starting in it (from `start` on)
-  uint32_t* bad;                     // per chunk: 1 = a block_size leaves the stream
+  // per chunk (a chunk is <= 32 KiB of ONE segment; the host lays them out)
+  const unsigned long long* lo;      // first byte of the chunk
+  const unsigned long long* hi;      // one past its last byte (records STARTING in [lo, hi) are the chunk's)
+  const unsigned long long* stop;    // the segment's stop: records starting at or behind it are not wanted
+  const unsigned long long* limit;   // the segment's end: no record may reach past it
+  const uint8_t* forced;             // 1: start[c] is given (a known record start, or where the chain stands); 0: guess one, scanning from lo
+  unsigned long long* start;         // where the chunk's walk started; ~0: no boundary found
+  unsigned long long* end;           // the first record start at or behind min(hi, stop) the walk reached
+  uint32_t* kept;                    // records with refID >= 0 that start in the chunk (from `start` on, below stop)
+  uint32_t* unmapped;                // records with refID < 0 among them ...
+  unsigned long long* first_unmapped;   // ... and where the first one starts (~0: none)
+  uint32_t* bad;                     // 1 = a block_size leaves the segment
 };
 struct BamColumnsParams {
   const uint8_t* d; const unsigned long long* rec_off; long long n;
   int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag;
   long long *seq_off, *qual_off, *cigar_off;        // n + 1 entries: lengths at [i + 1] here, CSR offsets after the scans
+  int32_t* span;                                    // (nullable) reference span: the lengths of the record's M / D / N / = / X ops
   unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size (~0: none)
 };
 hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s);

@@ -714,12 +714,12 @@ void arena_loan_free(void* v) {
   if (l) { l->pool->give(l->p); delete l; }
 }
 
-// DeviceDecoder::run (hostio.h): the whole decode of a BAM on the device -- blocks up, inflated, resolved and CRC-checked
-// (bgzf_inflate.hip), records found and decoded (bam_walk.hip), SEQ / QUAL / CIGAR cut out where the stream lies; the small
-// columns are all that comes down.
-int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, const InflateJob* jobs, size_t n_jobs, uint64_t total,
-                          uint64_t rec_begin, const int64_t* ref_lens, int32_t n_ref, HostColumns (*alloc)(void*, int64_t), void* sink,
-                          DeviceDecodeResult* res, int64_t* bad_job, int64_t* bad_record, char* err256) {
+// DeviceDecoder::run (hostio.h): BGZF blocks of a BAM -- the whole file's, a rank's slice, or the runs that hold a rank's contigs --
+// decoded on the device: up, inflated, resolved and CRC-checked (bgzf_inflate.hip), records found and decoded (bam_walk.hip), SEQ /
+// QUAL / CIGAR cut out where the stream lies; the small columns are all that comes down.
+int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob* jobs, size_t n_jobs, uint64_t total, DecodeSegment* segs,
+                          size_t n_segs, const int64_t* ref_lens, int32_t n_ref, int payload, int extra, HostColumns (*alloc)(void*, int64_t),
+                          void* sink, DeviceDecodeResult* res, int64_t* bad_job, int64_t* bad_record, char* err256) {
   midas_snps_ctx* ctx = static_cast<midas_snps_ctx*>(user);
   *bad_job = -1;
   *bad_record = -1;
@@ -741,18 +741,32 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
   DEC_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  // ---- the arena: | inflated stream | compressed bytes | blocks | status | crc | match lists |; everything behind the inflated
-  // stream is scratch once the blocks are resolved, and the columns are laid over it
+  // ---- the compressed bytes: every segment's blocks are consecutive in the file, the segments go up back to back ----------
+  std::vector<size_t> seg_at(n_segs + 1, 0);      // where segment k's bytes start in the device's copy
+  for (size_t k = 0; k < n_segs; ++k) {
+    const DecodeSegment& sg = segs[k];
+    if (sg.job_lo >= sg.job_hi || sg.job_hi > n_jobs) { if (err256) snprintf(err256, 256, "device decode: empty segment"); return MIDAS_SNPS_ERR_INVALID_ARG; }
+    const size_t bytes = (size_t)(jobs[sg.job_hi - 1].cpos + jobs[sg.job_hi - 1].clen + 8 - jobs[sg.job_lo].cpos);
+    seg_at[k + 1] = seg_at[k] + bytes;
+  }
+  const size_t comp_bytes = seg_at[n_segs];
+  // ---- the arena: | inflated bytes | compressed bytes | blocks | status | crc | match lists |; everything behind the inflated
+  // bytes is scratch once the blocks are resolved, and the columns are laid over it
   std::vector<InflateBlock> blocks(n_jobs);
+  std::vector<uint32_t> want(n_jobs);
   unsigned long long n_match_room = 0;
-  for (size_t k = 0; k < n_jobs; ++k) {
-    if (jobs[k].cpos + jobs[k].clen > comp_bytes || jobs[k].upos + jobs[k].ulen > total) {
-      if (err256) snprintf(err256, 256, "device decode: block %lld lies outside the file", (long long)k);
-      return MIDAS_SNPS_ERR_INVALID_ARG;
+  for (size_t k = 0; k < n_segs; ++k) {
+    const uint64_t c0 = jobs[segs[k].job_lo].cpos;
+    for (size_t j = segs[k].job_lo; j < segs[k].job_hi; ++j) {
+      if (jobs[j].upos + jobs[j].ulen > total || jobs[j].cpos < c0) {
+        if (err256) snprintf(err256, 256, "device decode: block %lld lies outside the buffers", (long long)j);
+        return MIDAS_SNPS_ERR_INVALID_ARG;
+      }
+      const uint32_t cap = jobs[j].ulen / 6u + 16u;
+      blocks[j] = InflateBlock{(unsigned long long)(seg_at[k] + (jobs[j].cpos - c0)), jobs[j].upos, n_match_room, jobs[j].clen, jobs[j].ulen, cap, 0u};
+      want[j] = jobs[j].crc;
+      n_match_room += cap;
     }
-    const uint32_t cap = jobs[k].ulen / 6u + 16u;
-    blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen, cap, 0u};
-    n_match_room += cap;
   }
   const size_t at_comp = up((size_t)total + 64), at_blocks = at_comp + up(comp_bytes + 512),
                at_status = at_blocks + up(n_jobs * sizeof(InflateBlock)), at_crc = at_status + up(n_jobs * 8),
@@ -767,12 +781,11 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
   struct Loan { std::shared_ptr<midas_arena_pool> pool; void* p; ~Loan() { if (p) pool->give(p); } } loan{ctx->arena, arena_p};
   uint8_t* const base = static_cast<uint8_t*>(arena_p);
   lap("arena");
-  // ---- blocks up (in pieces, so that the first kernels start while the later pieces are still on the link), inflate, resolve, check
+  // ---- blocks up, inflate, resolve, check ------------------------------------------------------------------------------------
   DEC_TRY(hipMemcpyAsync(base + at_blocks, blocks.data(), n_jobs * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
-  std::vector<uint32_t> want(n_jobs);
-  for (size_t k = 0; k < n_jobs; ++k) want[k] = jobs[k].crc;
   DEC_TRY(hipMemcpyAsync(base + at_crc, want.data(), n_jobs * 4, hipMemcpyHostToDevice, s));
-  DEC_TRY(hipMemcpyAsync(base + at_comp, comp, comp_bytes, hipMemcpyHostToDevice, s));
+  for (size_t k = 0; k < n_segs; ++k)
+    DEC_TRY(hipMemcpyAsync(base + at_comp + seg_at[k], comp_base + jobs[segs[k].job_lo].cpos, seg_at[k + 1] - seg_at[k], hipMemcpyHostToDevice, s));
   DEC_TRY(hipMemsetAsync(base + at_comp + comp_bytes, 0, 512, s));
   InflateParams ip;
   ip.comp = base + at_comp;
@@ -797,10 +810,10 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
       std::vector<uint32_t> want2(again.size());
       unsigned long long room2 = 0;
       for (size_t j = 0; j < again.size(); ++j) {
-        const InflateJob& q = jobs[again[j]];
+        const InflateBlock& q = blocks[again[j]];
         const uint32_t cap = q.ulen / 3u + 1u;
         b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
-        want2[j] = q.crc;
+        want2[j] = want[again[j]];
         room2 += cap;
       }
       struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_b2, d_s2, d_m2, d_c2;
@@ -832,77 +845,117 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
       return MIDAS_SNPS_ERR_BAD_LAYOUT;
     }
   }
-  // ---- the record walk: everything behind the inflated stream is scratch now ----------------------------------------------
+  // ---- the record walk: chunks of at most 32 KiB, laid out segment by segment over [from, stop) ---------------------------
+  const unsigned long long kChunk = 32768ull;
+  std::vector<unsigned long long> h_lo, h_hi, h_stop, h_limit, h_start;
+  std::vector<uint8_t> h_forced;
+  std::vector<size_t> seg_chunk(n_segs + 1, 0);
+  for (size_t k = 0; k < n_segs; ++k) {
+    const DecodeSegment& sg = segs[k];
+    const unsigned long long limit = jobs[sg.job_hi - 1].upos + jobs[sg.job_hi - 1].ulen;
+    const unsigned long long stop = sg.stop < limit ? sg.stop : limit;
+    for (unsigned long long lo = sg.from; lo < stop; lo += kChunk) {
+      h_lo.push_back(lo); h_hi.push_back(lo + kChunk < stop ? lo + kChunk : stop); h_stop.push_back(stop); h_limit.push_back(limit);
+      const bool first = lo == sg.from;
+      h_forced.push_back(first && sg.exact ? 1 : 0);
+      h_start.push_back(first && sg.exact ? sg.from : ~0ull);
+    }
+    seg_chunk[k + 1] = h_lo.size();
+  }
+  const long long n_chunks = (long long)h_lo.size();
   uint8_t* const scratch = base + at_comp;
   const size_t scratch_bytes = arena_bytes - at_comp;
   size_t at = 0;
   auto take = [&](size_t bytes) -> uint8_t* { uint8_t* q = scratch + at; at += up(bytes); return at <= scratch_bytes ? q : nullptr; };
-  const unsigned long long chunk = 32768ull;
-  const long long n_chunks = (long long)((total + chunk - 1) / chunk);
+  const size_t nc1 = (size_t)(n_chunks > 0 ? n_chunks : 1);
   BamWalkParams wp;
-  wp.d = base; wp.total = total; wp.rec_begin = rec_begin; wp.chunk = chunk; wp.n_ref = n_ref; wp.n_chunks = n_chunks;
+  wp.d = base; wp.n_ref = n_ref; wp.n_chunks = n_chunks;
   long long* d_ref_lens = reinterpret_cast<long long*>(take((size_t)(n_ref > 0 ? n_ref : 1) * 8));
-  wp.start = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
-  wp.end = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
-  wp.kept = reinterpret_cast<uint32_t*>(take((size_t)n_chunks * 4));
-  wp.bad = reinterpret_cast<uint32_t*>(take((size_t)n_chunks * 4));
-  unsigned long long* d_base = reinterpret_cast<unsigned long long*>(take((size_t)n_chunks * 8));
+  unsigned long long* d_lo = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  unsigned long long* d_hi = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  unsigned long long* d_stop = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  unsigned long long* d_limit = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  uint8_t* d_forced = take(nc1);
+  wp.start = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  wp.end = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  wp.kept = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+  wp.unmapped = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+  wp.first_unmapped = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+  wp.bad = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+  unsigned long long* d_base = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
   long long* d_list = reinterpret_cast<long long*>(take(4096 * 8));
   if (!d_list) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the walk"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  wp.ref_lens = d_ref_lens;
+  wp.lo = d_lo; wp.hi = d_hi; wp.stop = d_stop; wp.limit = d_limit; wp.forced = d_forced; wp.ref_lens = d_ref_lens;
   if (n_ref > 0) DEC_TRY(hipMemcpyAsync(d_ref_lens, ref_lens, (size_t)n_ref * 8, hipMemcpyHostToDevice, s));
-  DEC_TRY(launch_bam_walk(wp, nullptr, 0, s));
-  std::vector<unsigned long long> h_start((size_t)n_chunks), h_end((size_t)n_chunks), h_base((size_t)n_chunks);
-  std::vector<uint32_t> h_kept((size_t)n_chunks), h_bad((size_t)n_chunks);
-  auto fetch_chunks = [&]() -> hipError_t {
-    hipError_t e = hipMemcpyAsync(h_start.data(), wp.start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_end.data(), wp.end, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_kept.data(), wp.kept, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_bad.data(), wp.bad, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    return e;
-  };
-  DEC_TRY(fetch_chunks());
+  std::vector<unsigned long long> h_end(nc1), h_base(nc1), h_fu(nc1);
+  std::vector<uint32_t> h_kept(nc1), h_bad(nc1), h_unm(nc1);
+  if (n_chunks > 0) {
+    DEC_TRY(hipMemcpyAsync(d_lo, h_lo.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_hi, h_hi.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_stop, h_stop.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_limit, h_limit.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_forced, h_forced.data(), (size_t)n_chunks, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(launch_bam_walk(wp, nullptr, 0, s));
+    DEC_TRY(hipMemcpyAsync(h_start.data(), wp.start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipMemcpyAsync(h_end.data(), wp.end, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipMemcpyAsync(h_kept.data(), wp.kept, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipMemcpyAsync(h_unm.data(), wp.unmapped, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipMemcpyAsync(h_fu.data(), wp.first_unmapped, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipMemcpyAsync(h_bad.data(), wp.bad, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+    DEC_TRY(hipStreamSynchronize(s));
+  }
   lap("walk (guesses)");
-  // stitch in order; a chunk whose guess the chain does not hit is walked again from where the chain stands
-  {
-    const long long c0 = (long long)(rec_begin / chunk);
-    unsigned long long cur = rec_begin;
-    int rounds = 0;
-    long long c = c0;
-    for (long long k = 0; k < c0 && k < n_chunks; ++k) { h_kept[(size_t)k] = 0u; h_start[(size_t)k] = ~0ull; }
-    while (c < n_chunks) {
-      const unsigned long long stop = ((unsigned long long)c + 1ull) * chunk;
-      if (cur >= stop || cur + 4 > total) { h_kept[(size_t)c] = 0u; h_start[(size_t)c] = ~0ull; ++c; continue; }      // no record starts in this chunk
-      if (h_start[(size_t)c] == cur) {
-        if (h_bad[(size_t)c]) { *bad_record = -2; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
-        cur = h_end[(size_t)c];
+  // stitch every segment in order; a chunk whose guess the chain does not hit is walked again from where the chain stands
+  int rounds = 0;
+  for (size_t k = 0; k < n_segs; ++k) {
+    DecodeSegment& sg = segs[k];
+    sg.first = ~0ull; sg.n_records = 0; sg.n_unmapped = 0; sg.first_unmapped = ~0ull;
+    unsigned long long cur = sg.exact ? sg.from : ~0ull;
+    const unsigned long long limit = jobs[sg.job_hi - 1].upos + jobs[sg.job_hi - 1].ulen;
+    sg.end = sg.stop < limit ? sg.stop : limit;
+    for (size_t c = seg_chunk[k]; c < seg_chunk[k + 1];) {
+      if (cur == ~0ull) {            // (a guessed first record: the first chunk that found a boundary gives it)
+        if (h_start[c] == ~0ull) { h_kept[c] = 0u; h_unm[c] = 0u; ++c; continue; }
+        cur = h_start[c];
+      }
+      if (cur >= h_hi[c] || cur + 4 > h_limit[c]) { h_kept[c] = 0u; h_unm[c] = 0u; h_start[c] = ~0ull; ++c; continue; }   // no record starts in this chunk
+      if (h_start[c] == cur) {
+        if (h_bad[c]) { *bad_record = -2; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+        if (sg.first == ~0ull) sg.first = cur;
+        sg.n_records += h_kept[c];
+        if (h_unm[c] && sg.first_unmapped == ~0ull) sg.first_unmapped = h_fu[c];
+        sg.n_unmapped += h_unm[c];
+        cur = h_end[c];
         ++c;
         continue;
       }
-      // walk chunk c again from `cur` (one thread; the chunks behind it keep their guesses)
       if (++rounds > 4096) {
         if (err256) snprintf(err256, 256, "device decode: the record boundaries did not settle");
         return MIDAS_SNPS_ERR_UNSUPPORTED;
       }
-      const long long one = c;
+      const long long one = (long long)c;
       DEC_TRY(hipMemcpyAsync(wp.start + c, &cur, 8, hipMemcpyHostToDevice, s));
       DEC_TRY(hipMemcpyAsync(d_list, &one, 8, hipMemcpyHostToDevice, s));
       DEC_TRY(launch_bam_walk(wp, d_list, 1, s));
-      DEC_TRY(hipMemcpyAsync(&h_end[(size_t)c], wp.end + c, 8, hipMemcpyDeviceToHost, s));
-      DEC_TRY(hipMemcpyAsync(&h_kept[(size_t)c], wp.kept + c, 4, hipMemcpyDeviceToHost, s));
-      DEC_TRY(hipMemcpyAsync(&h_bad[(size_t)c], wp.bad + c, 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_end[c], wp.end + c, 8, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_kept[c], wp.kept + c, 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_unm[c], wp.unmapped + c, 4, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_fu[c], wp.first_unmapped + c, 8, hipMemcpyDeviceToHost, s));
+      DEC_TRY(hipMemcpyAsync(&h_bad[c], wp.bad + c, 4, hipMemcpyDeviceToHost, s));
       DEC_TRY(hipStreamSynchronize(s));
-      h_start[(size_t)c] = cur;
+      h_start[c] = cur;
     }
-    if (rounds && trace) fprintf(stderr, "[device decode] %d chunk(s) walked again\n", rounds);
+    if (cur != ~0ull) sg.end = cur;
   }
+  if (rounds && trace) fprintf(stderr, "[device decode] %d chunk(s) walked again\n", rounds);
   unsigned long long n_rec = 0;
   for (long long c = 0; c < n_chunks; ++c) { h_base[(size_t)c] = n_rec; n_rec += h_kept[(size_t)c]; }
-  // (the host's view of starts / counts is the settled one: chunks without a record of their own were cleared above)
-  DEC_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
-  DEC_TRY(hipMemcpyAsync(wp.kept, h_kept.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, s));
-  DEC_TRY(hipMemcpyAsync(d_base, h_base.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+  if (n_chunks > 0) {
+    DEC_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(wp.kept, h_kept.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, s));
+    DEC_TRY(hipMemcpyAsync(d_base, h_base.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+  }
   lap("stitch");
   const long long n = (long long)n_rec;
   const size_t n1 = (size_t)n + 1;
@@ -914,6 +967,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
   cp.mapq = take(n1); cp.flag = reinterpret_cast<uint16_t*>(take(n1 * 2));
   cp.seq_off = reinterpret_cast<long long*>(take(n1 * 8)); cp.qual_off = reinterpret_cast<long long*>(take(n1 * 8));
   cp.cigar_off = reinterpret_cast<long long*>(take(n1 * 8));
+  cp.span = extra ? reinterpret_cast<int32_t*>(take(n1 * 4)) : nullptr;
   cp.bad_record = reinterpret_cast<unsigned long long*>(take(8));
   long long* d_scan = reinterpret_cast<long long*>(take(bam_scan_scratch_bytes(n)));
   if (!d_scan) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the columns"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
@@ -931,34 +985,37 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
   if (h_bad_record != ~0ull) { *bad_record = (int64_t)h_bad_record; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   const int64_t sb = ends[0], qb = ends[1], nc = ends[2];
   // ---- SEQ / QUAL / CIGAR cut out of the stream, behind everything taken so far ---------------------------------------------
-  uint8_t* d_seq = take((size_t)sb + 64);
-  uint8_t* d_qual = take((size_t)qb + 64);
-  uint8_t* d_cig = take((size_t)nc * 4 + 64);
+  uint8_t *d_seq = nullptr, *d_qual = nullptr, *d_cig = nullptr;
   struct Own { void* p = nullptr; ~Own() { if (p) (void)hipFree(p); } } own;
-  if (!d_cig) {       // (the scratch cannot hold them: a buffer of their own)
-    const size_t need = up((size_t)sb + 64) + up((size_t)qb + 64) + up((size_t)nc * 4 + 64);
-    DEC_TRY(hipMalloc(&own.p, need));
-    d_seq = static_cast<uint8_t*>(own.p);
-    d_qual = d_seq + up((size_t)sb + 64);
-    d_cig = d_qual + up((size_t)qb + 64);
+  if (payload) {
+    d_seq = take((size_t)sb + 64);
+    d_qual = take((size_t)qb + 64);
+    d_cig = take((size_t)nc * 4 + 64);
+    if (!d_cig) {       // (the scratch cannot hold them: a buffer of their own)
+      const size_t need = up((size_t)sb + 64) + up((size_t)qb + 64) + up((size_t)nc * 4 + 64);
+      DEC_TRY(hipMalloc(&own.p, need));
+      d_seq = static_cast<uint8_t*>(own.p);
+      d_qual = d_seq + up((size_t)sb + 64);
+      d_cig = d_qual + up((size_t)qb + 64);
+    }
+    DEC_TRY(hipMemsetAsync(d_cig + (size_t)nc * 4, 0, 64, s));
+    PayloadParams pp;
+    pp.stream = base;
+    pp.rec_off = d_rec;
+    pp.n_records = n;
+    pp.seq_off = cp.seq_off; pp.qual_off = cp.qual_off; pp.cigar_off = cp.cigar_off;
+    pp.seq4 = d_seq; pp.qual = d_qual; pp.cigar = reinterpret_cast<uint32_t*>(d_cig);
+    DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
   }
-  DEC_TRY(hipMemsetAsync(d_cig + (size_t)nc * 4, 0, 64, s));
-  PayloadParams pp;
-  pp.stream = base;
-  pp.rec_off = d_rec;
-  pp.n_records = n;
-  pp.seq_off = cp.seq_off; pp.qual_off = cp.qual_off; pp.cigar_off = cp.cigar_off;
-  pp.seq4 = d_seq; pp.qual = d_qual; pp.cigar = reinterpret_cast<uint32_t*>(d_cig);
-  DEC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
   // ---- the small columns down ---------------------------------------------------------------------------------------------
   const HostColumns hc = alloc(sink, n);
   if (!hc.cigar_off) { DEC_TRY(hipStreamSynchronize(s)); return MIDAS_SNPS_OK; }      // (the caller reports its own out-of-memory)
-  auto down = [&](void* dst, const void* src, size_t bytes) -> int32_t { return bytes ? copy_to_host(ctx, dst, src, bytes) : MIDAS_SNPS_OK; };
+  auto down = [&](void* dst, const void* src, size_t bytes) -> int32_t { return bytes && dst ? copy_to_host(ctx, dst, src, bytes) : MIDAS_SNPS_OK; };
   int32_t st = MIDAS_SNPS_OK;
   const std::pair<void*, std::pair<const void*, size_t>> cols[] = {
       {hc.refid, {cp.refid, (size_t)n * 4}}, {hc.pos, {cp.pos, (size_t)n * 4}}, {hc.nm, {cp.nm, (size_t)n * 4}}, {hc.l_seq, {cp.l_seq, (size_t)n * 4}},
       {hc.mapq, {cp.mapq, (size_t)n}}, {hc.flag, {cp.flag, (size_t)n * 2}}, {hc.seq_off, {cp.seq_off, n1 * 8}}, {hc.qual_off, {cp.qual_off, n1 * 8}},
-      {hc.cigar_off, {cp.cigar_off, n1 * 8}}};
+      {hc.cigar_off, {cp.cigar_off, n1 * 8}}, {extra ? hc.span : nullptr, {cp.span, (size_t)n * 4}}, {extra ? hc.rec_off : nullptr, {d_rec, (size_t)n * 8}}};
   for (const auto& c : cols) {
     st = down(c.first, c.second.first, c.second.second);
     if (st != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->err.c_str()); return st; }
@@ -968,6 +1025,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp, size_t comp_bytes, co
 #undef DEC_TRY
   res->n_records = n; res->seq_bytes = sb; res->qual_bytes = qb; res->n_cigar = nc;
   res->dev_seq = d_seq; res->dev_qual = d_qual; res->dev_cigar = d_cig;
+  if (!payload) return MIDAS_SNPS_OK;       // (the arena goes back with `loan`)
   if (own.p) {        // the columns have a buffer of their own: the arena goes back now
     res->dev_owner = own.p;
     res->dev_free = device_free;
@@ -1001,9 +1059,18 @@ int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_
                                      const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                      int64_t* n_cigar, char* err256) {
   if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
-  InflateUser iu{ctx};
+  const DeviceDecoder dec{ctx, device_decode_run};
+  const int32_t st = bam_load_ranges_on_device(bam, &dec, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
+  if (st != MIDAS_SNPS_ERR_UNSUPPORTED) return st;
+  InflateUser iu{ctx};       // (boundaries not settled on the device: its inflater, the host's walk)
   const BlockInflater inf{&iu, device_inflate};
   return bam_load_ranges_with(bam, &inf, n_ranges, range_begin, range_end, n_reads, seq_bytes, qual_bytes, n_cigar, err256);
+}
+
+int32_t midas_bam_open_slice_device(const char* path, int32_t slice, int32_t n_slices, midas_snps_ctx* ctx, midas_bam** out, char* err256) {
+  if (!ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const DeviceDecoder dec{ctx, device_decode_run};
+  return bam_open_slice_with(path, slice, n_slices, &dec, out, err256);
 }
 
 int32_t midas_snps_set_row_coder(midas_snps_ctx* ctx, int32_t coder) {

@@ -295,6 +295,8 @@ def _contig_table(species_ids, items, span, contigs, ref_names, ref_lens, refid,
     at = {c.id: k for k, c in enumerate(mine)}
     keys = sorted(items, key=lambda it: (at[it[0]], it[1]))
     plan = [(at[cid], span[(cid, j)][0], span[(cid, j)][1], span[(cid, j)][2], int(halo.get(cid, 0)) if halo else 0) for cid, j in keys]
+    if getattr(sub, 'device', None) is not None and fetch is not None:
+        sub = fetch(sub)          # (cutting pieces slices SEQ / QUAL / CIGAR: in host memory)
     sub, read_begin = pieces.gather(sub, read_begin, plan)
     ref = _reference_bytes([(mine[k], lo, hi) for k, lo, hi, _, _ in plan])
     table = abi.ContigTable(length=[hi - lo for _, lo, hi, _, _ in plan], species=[sp_index[mine[k].species_id] for k, *_ in plan],
@@ -463,7 +465,7 @@ def species_pileup(args, species_id, contigs):
     return (species_id, stats[species_id])
 
 
-def _rank_local_plan(bampath, rank, ws):
+def _rank_local_plan(bampath, rank, ws, inflater=None):
     """Phase 1 of the rank-local decode (include/midas_snps.h, midas_bam_open_slice): walk this rank's share of the BAM,
     all-gather {first record, end, sorted, first/last refID} and the per-reference {reads, bases, first record offset} of
     every slice, and accept the slices only if they chain: slice 0 starts at the header's end, every slice ends where the
@@ -472,7 +474,7 @@ def _rank_local_plan(bampath, rank, ws):
     the whole file, as a single rank does), else what the assignment and the range loads need."""
     error, sl = None, None
     try:
-        sl = abi.BamSlice(bampath, rank, ws)
+        sl = abi.BamSlice(bampath, rank, ws, ctx=inflater)       # (a Context: the slice is inflated and walked on its device)
     except abi.MidasSnpsError as e:
         error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
     dist.agree_or_exit(error)
@@ -627,7 +629,7 @@ def _count_alleles(args, species, contigs, ctx):
     # N ranks: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and each
     # decodes only the records of the contigs it ends up owning.  One rank (or a BAM the slices cannot vouch for:
     # not coordinate-sorted, or a guessed record boundary that the neighbouring slice does not confirm): decode it whole.
-    plan = _rank_local_plan(bampath, rank, ws) if ws > 1 else None
+    plan = _rank_local_plan(bampath, rank, ws, inflater) if ws > 1 else None
     error = None
     decoded = None
     if plan is None:

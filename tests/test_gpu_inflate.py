@@ -130,14 +130,29 @@ def test_bam_decoded_with_the_device_inflater_equals_the_host_decode(ctx, tmp_pa
     np.testing.assert_array_equal(refid_h, refid_d)
     for k in abi._SOA_DTYPES:
         np.testing.assert_array_equal(getattr(host, k), getattr(dev, k), err_msg=k)
-    # a rank's slice ranges
+    # a rank's slice: walked on the device, the same facts; its ranges decoded there, the same records (payload left there)
+    for k_slice, n_slices in ((0, 1), (0, 3), (1, 3), (2, 3), (5, 7)):
+        sl = abi.BamSlice(path, k_slice, n_slices)
+        sd = abi.BamSlice(path, k_slice, n_slices, ctx=ctx)
+        for f in ("first", "end", "sorted", "first_ref", "last_ref", "rec_begin", "total"):
+            assert getattr(sl, f) == getattr(sd, f), (k_slice, n_slices, f)
+        for f in ("ref_reads", "ref_bases", "ref_first"):
+            np.testing.assert_array_equal(getattr(sl, f), getattr(sd, f), err_msg=f)
+        for x, y in zip(sl.marks(), sd.marks()):
+            np.testing.assert_array_equal(x, y)
     sl = abi.BamSlice(path, 1, 3)
-    ranges = [(sl.first, sl.end)]
-    a = sl.load_ranges(ranges)
-    b = abi.BamSlice(path, 1, 3).load_ranges(ranges, ctx)
-    np.testing.assert_array_equal(a[0], b[0])
-    for k in abi._SOA_DTYPES:
-        np.testing.assert_array_equal(getattr(a[1], k), getattr(b[1], k), err_msg=k)
+    mid = int(sl.ref_first[sl.ref_first >= 0][-1])          # (a reference's first record: an exact boundary inside the slice)
+    for ranges in ([(sl.first, sl.end)], [(sl.first, mid), (mid, sl.end)], [(mid, sl.end)], []):
+        a = sl.load_ranges(ranges)
+        b = abi.BamSlice(path, 1, 3).load_ranges(ranges, ctx)
+        assert b[1].device is not None or not ranges
+        np.testing.assert_array_equal(a[0], b[0])
+        down = ctx.fetch_payload(b[1])
+        for k in abi._SOA_DTYPES:
+            np.testing.assert_array_equal(getattr(a[1], k), getattr(down, k), err_msg=k)
+    with pytest.raises(abi.MidasSnpsError) as ei:                  # a range that ends inside a record
+        abi.BamSlice(path, 1, 3).load_ranges([(sl.first, sl.end - 7)], ctx)
+    assert ei.value.status == abi.ERR_BAD_LAYOUT
     # the payload columns cut on the device and left there: the same bytes, and a batch takes them where they are
     names_p, lens_p, refid_p, on_dev = abi.read_bam(path, ctx, payload_on_device=True)
     assert on_dev.device is not None and on_dev.seq4.size == 0 and names_p == names_h
