@@ -4,7 +4,7 @@
 # bench command for configs[2] and configs[1].  Text summaries only land in gpurun_out/evidence/ (the rocpd databases are
 # tens of MiB each and are deleted here).   usage: tools/evidence.sh [tag]
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV
@@ -25,7 +25,7 @@ prof() {   # prof <name> <bench args...>
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_1 -o pmc -- python $REPO/bench.py --no-cpu --no-pmc --steps 10 --warmup 2 --sustain-seconds 0 "$@" > $out/pmc_1.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_2 -o pmc -- python $REPO/bench.py --no-cpu --no-pmc --steps 10 --warmup 2 --sustain-seconds 0 "$@" > $out/pmc_2.log 2>&1 )
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-pmc $*   (then --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command with --steps 10 --warmup 2 --sustain-seconds 0)"
-    grep '^{' $out/trace.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('# bench line of the profiled run: value %.4g %s, ms_per_step %.4f, step kernels %.4f ms (index pass %.4f + pileup %.4f), frac %.3f' % (d['value'], d['unit'], d['ms_per_step'], r['kernels_ms_avg'], r['index_pass_ms_avg'], r['pileup_kernel_ms_avg'], r['frac']))" 2>/dev/null
+    grep '^{' $out/trace.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('# bench line of the profiled run: value %.4g %s, ms_per_step %.4f, step kernels %.4f ms (ranges pass %.4f + pileup %.4f), frac %.3f' % (d['value'], d['unit'], d['ms_per_step'], r['kernels_ms_avg'], r['index_pass_ms_avg'], r['pileup_kernel_ms_avg'], r['frac']))" 2>/dev/null
     python tools/summarize_prof.py $out | grep -v "^JSON"; } > $EV/${TAG}_${name}_rocprofv3_stats_pmc.txt 2>&1
   rm -rf $out
 }

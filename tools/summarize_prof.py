@@ -35,7 +35,7 @@ def main():
             short = m.group(1) if m else k[:40]
             print("%-22s %-28s %18.1f  (n=%d)" % (short, c, v, n))
             out["pmc"].setdefault(short, {})[c] = v
-    step = [k for k in out["pmc"] if k.startswith(("direct_classify_kernel<true>", "direct_scan_kernel", "direct_fill_kernel", "pileup_direct_kernel"))]
+    step = [k for k in out["pmc"] if k.startswith(("direct_ranges_kernel", "pileup_direct_kernel"))]
     for k, d in out["pmc"].items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
@@ -50,7 +50,7 @@ def main():
     if step and all("hbm_bytes_per_launch" in out["pmc"][k] for k in step):
         tot = sum(out["pmc"][k]["hbm_bytes_per_launch"] for k in step)
         out["direct_step_hbm_bytes"] = tot
-        print("%-22s HBM traffic/step (index pass: classify<true> + scan + fill, then pileup_direct_kernel): %.1f MB" % ("direct step", tot / 1e6))
+        print("%-22s HBM traffic/step (direct_ranges_kernel + pileup_direct_kernel; FETCH_SIZE x2: the factor bench.py calibrates on the box for 4-, 8- and 16-byte loads): %.1f MB" % ("direct step", tot / 1e6))
     print()
     print("JSON:", json.dumps(out))
 
