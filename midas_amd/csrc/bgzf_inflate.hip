@@ -261,17 +261,24 @@ __device__ uint32_t fixed_tables(const Lds& L) {
   return kOk;
 }
 
-// The inflated bytes: literals are gathered four at a time into aligned words (a byte store per literal is four times the
-// stores and four times the acknowledgements the next load of input waits behind); a match first puts the gathered bytes out.
+// The inflated bytes: literals are gathered four at a time into ALIGNED words (a byte store per literal is four times the
+// stores and four times the acknowledgements the next load of input waits behind). A match first puts the gathered bytes
+// out; the literals behind it go out byte by byte until the output position is a multiple of four again (`lead`), so that
+// every word store is aligned wherever the matches fall.
 struct ByteOut {
   uint8_t* dst;
   uint32_t o;          // bytes produced, the gathered ones included
   uint32_t acc;
   int na;              // gathered bytes (they belong at o - na ..)
-  uint32_t head;       // bytes in front of the first aligned word
-  __device__ __forceinline__ void open(uint8_t* d) { dst = d; o = 0; acc = 0; na = 0; head = (uint32_t)((0u - reinterpret_cast<uintptr_t>(d)) & 3u); }
+  uint32_t lead;       // literals to store singly before the next aligned word starts
+  uint32_t skew;       // (0 - dst) & 3: dst + o is a multiple of four exactly where o - skew is
+  __device__ __forceinline__ void open(uint8_t* d) {
+    dst = d; o = 0; acc = 0; na = 0;
+    skew = (uint32_t)((0u - reinterpret_cast<uintptr_t>(d)) & 3u);
+    lead = skew;
+  }
   __device__ __forceinline__ void literal(uint32_t b) {
-    if (o < head) { dst[o++] = (uint8_t)b; return; }
+    if (lead) { dst[o++] = (uint8_t)b; --lead; return; }
     acc |= b << (8 * na);
     ++o;
     if (++na == 4) { *reinterpret_cast<uint32_t*>(dst + o - 4) = acc; acc = 0; na = 0; }
@@ -280,6 +287,8 @@ struct ByteOut {
     for (int k = 0; k < na; ++k) dst[o - na + k] = (uint8_t)(acc >> (8 * k));
     acc = 0; na = 0;
   }
+  // `len` bytes are left for someone else to fill (a noted match); the gathered literals must be out already
+  __device__ __forceinline__ void leave(uint32_t len) { o += len; lead = (skew - o) & 3u; }
 };
 
 // a noted match: position in the block's output | length << 32 | distance << 41
@@ -351,7 +360,7 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         out.flush();
         if (m == mcap) return kMatchRoom;
         mlist[m++] = match_pack(out.o, len, dist);
-        out.o += len;
+        out.leave(len);
         if (in.overrun()) return kInputOverrun;
       }
       if (in.overrun()) return kInputOverrun;
@@ -492,6 +501,17 @@ hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {
   if (p.n_blocks <= 0) return hipSuccess;
   if (phases & 1) {
+    // the block inflater keeps 64 lanes' tables and input rings in LDS: most of gfx950's 160 KiB. A device with less
+    // cannot run it; say so instead of leaving it to the launch (the callers fall back to the host's inflater).
+    static const bool fits = [] {
+      hipFuncAttributes fa{};
+      int dev = 0, lds = 0;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(bgzf_inflate_kernel)) != hipSuccess) return true;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return true;
+      return fa.sharedSizeBytes <= (size_t)lds;
+    }();
+    if (!fits) return hipErrorLaunchOutOfResources;
     const long long g = (p.n_blocks + kLanes - 1) / kLanes;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kLanes), 0, s, p);
     const hipError_t e = hipGetLastError();

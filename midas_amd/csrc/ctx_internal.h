@@ -56,7 +56,12 @@ struct midas_snps_ctx {
   int device = -1;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  std::string err;
+  std::string err;             // last error text: written and read under err_mutex only (set_error / error_text):
+                               // the table writers run on several host threads of one context
+  std::mutex err_mutex;
+  void set_error(const std::string& msg) { std::lock_guard<std::mutex> g(err_mutex); err = msg; }
+  void clear_error() { std::lock_guard<std::mutex> g(err_mutex); err.clear(); }
+  std::string error_text() { std::lock_guard<std::mutex> g(err_mutex); return err; }
   int64_t err_read = -1;
   int pad_rule = 0;       // MIDAS_SNPS_PAD_SPEC: what P does to the query position (midas_snps_set_pad_rule)
   int row_coder = 0;      // MIDAS_SNPS_ROWS_DEVICE: who formats and deflates a batch's rows (midas_snps_set_row_coder)

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void genes_sum_heavy_kernel(SumKParams p) {
 }
 
 int32_t gfail(midas_snps_ctx* ctx, int32_t st, const char* msg) {
-  ctx->err = msg;
+  ctx->set_error(msg);
   return st;
 }
 
@@ -203,7 +203,7 @@ extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thres
       (reads->n_reads > 0 && (!ref_id || !reads->mapq || !reads->nm || !reads->l_seq || !reads->qual_off || !reads->cigar_off ||
                               !reads->qual || !reads->cigar)))
     return MIDAS_SNPS_ERR_INVALID_ARG;
-  ctx->err.clear();
+  ctx->clear_error();
   ctx->err_read = -1;
   if (out_kernel_ms) *out_kernel_ms = 0.f;
   const int64_t n = reads->n_reads;
@@ -354,7 +354,7 @@ extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thres
     snprintf(buf, sizeof buf, "read %lld: keep_read would raise (%s)", (long long)ctx->err_read,
              kind == 1 ? "no SEQ: TypeError" : kind == 2 ? "no NM tag: KeyError" : kind == 3 ? "aligned length 0: ZeroDivisionError"
                                                                                                 : "no QUAL: TypeError");
-    ctx->err = buf;
+    ctx->set_error(buf);
     return kind;
   }
   return MIDAS_SNPS_OK;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void midas_calib_write16_kernel(v4u* dst, s
 }
 
 int32_t fail(midas_snps_ctx* ctx, int32_t st, const char* msg) {
-  if (ctx) ctx->err = msg;
+  if (ctx) ctx->set_error(msg);
   return st;
 }
 

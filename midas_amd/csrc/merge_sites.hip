@@ -353,7 +353,7 @@ int32_t mfail(midas_snps_ctx* ctx, int32_t st, const char* what, hipError_t e) {
   char buf[384];
   snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
   (void)hipGetLastError();
-  ctx->err = buf;
+  ctx->set_error(buf);
   return st;
 }
 
@@ -375,7 +375,7 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
   if (!ctx || !prm || n_samples <= 0 || n_sites < 0 || !sample_counts || !mean_depth || !out_calls ||
       !out_count_samples || !out_pooled || !out_depth || !out_minor_count)
     return MIDAS_SNPS_ERR_INVALID_ARG;
-  ctx->err.clear();
+  ctx->clear_error();
   ctx->err_read = -1;
   if (out_kernel_ms) *out_kernel_ms = 0.f;
   std::vector<void*> dev;
@@ -464,7 +464,7 @@ extern "C" int32_t midas_merge_sites(midas_snps_ctx* ctx, const midas_merge_para
       ctx->err_read = (int64_t)(lo + (long long)err);
       snprintf(buf, sizeof buf, "site %lld: a sample with mean_coverage 0 reached site_depth/mean_depth "
                "(reference: ZeroDivisionError in compute_prevalence)", (long long)ctx->err_read + 1);
-      ctx->err = buf;
+      ctx->set_error(buf);
       status = MIDAS_MERGE_ERR_ZERO_MEAN_DEPTH;
     }
   }

@@ -170,7 +170,7 @@ namespace {
 
 int32_t fail(midas_snps_ctx* ctx, int32_t st, const std::string& msg) {
   if (ctx) {
-    ctx->err = msg;
+    ctx->set_error(msg);
   }
   return st;
 }
@@ -378,7 +378,14 @@ void midas_snps_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-const char* midas_snps_last_error(const midas_snps_ctx* ctx) { return ctx ? ctx->err.c_str() : "NULL context"; }
+// The text is copied out under the context's error lock into a buffer of the calling thread (valid until that thread asks again):
+// the table writers of one context run on several host threads.
+const char* midas_snps_last_error(const midas_snps_ctx* ctx) {
+  if (!ctx) return "NULL context";
+  static thread_local std::string text;
+  text = const_cast<midas_snps_ctx*>(ctx)->error_text();
+  return text.c_str();
+}
 
 int64_t midas_snps_last_error_read(const midas_snps_ctx* ctx) { return ctx ? ctx->err_read : -1; }
 
@@ -571,7 +578,7 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
     }
   }
   const int32_t st = copy_to_host(ctx, out, d_out.p, out_bytes);
-  if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->err.c_str());
+  if (st != MIDAS_SNPS_OK && err256) snprintf(err256, 256, "device inflate: results to host: %s", ctx->error_text().c_str());
   lap("inflated bytes down");
   if (st == MIDAS_SNPS_OK && iu->keep) {     // the caller takes the arena: the inflated stream, and everything behind it as scratch
     iu->kept = arena.p; iu->kept_bytes = out_bytes; iu->scratch = base + at_comp; iu->scratch_bytes = arena_bytes - at_comp;
@@ -1018,7 +1025,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
       {hc.cigar_off, {cp.cigar_off, n1 * 8}}, {extra ? hc.span : nullptr, {cp.span, (size_t)n * 4}}, {extra ? hc.rec_off : nullptr, {d_rec, (size_t)n * 8}}};
   for (const auto& c : cols) {
     st = down(c.first, c.second.first, c.second.second);
-    if (st != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->err.c_str()); return st; }
+    if (st != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->error_text().c_str()); return st; }
   }
   DEC_TRY(hipStreamSynchronize(s));
   lap("payload cut, small columns down");
@@ -1493,7 +1500,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
                                 const midas_snps_reads* reads, midas_snps_batch** out_batch) {
   if (!ctx || !contigs || !reads || !out_batch) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out_batch = nullptr;
-  ctx->err.clear();
+  ctx->clear_error();
   ctx->err_read = -1;
   char ebuf[256] = {0};
   int64_t n_sites = 0;

@@ -155,18 +155,27 @@ class ContigsInBackground(Mapping):
     genomes are read while the alignments are inflated instead of in front of them.  What the reader raises (a missing
     genome ends the run, midas/run/snps.py:57) is raised where the mapping is first used."""
 
-    def __init__(self, species):
-        self._out, self._err = None, None
+    def __init__(self, species, start=True):
+        self._out, self._err, self._thread, self._species = None, None, None, species
+        if start:
+            self.start()
+
+    def start(self):
+        """Begin reading (once).  run_pipeline starts it behind the build / align stages when those run: they read the same
+        FASTA files on rank 0 and hold the machine for the length of an alignment."""
+        if self._thread is not None or self._out is not None or self._err is not None:
+            return
 
         def work():
             try:
-                self._out = initialize_contigs(species)
+                self._out = initialize_contigs(self._species)
             except BaseException as e:       # (SystemExit included: it must end the main thread's run, not this thread)
                 self._err = e
         self._thread = threading.Thread(target=work, name="read-genomes", daemon=True)
         self._thread.start()
 
     def wait(self):
+        self.start()
         if self._thread is not None:
             self._thread.join()
             self._thread = None
@@ -658,6 +667,15 @@ def _count_alleles(args, species, contigs, ctx):
     # An item is a contig -- the unit count_coverage is called on -- or, for a contig longer than the split length in a BAM
     # whose positions are sorted, a piece of it (midas_amd/pieces.py): one 20 Mb chromosome must not pin the job to one GPU.
     all_ids = sorted(species)
+    # first use of the genomes: what their reader raised (a missing genome's sys.exit, an OSError) ends every rank together
+    try:
+        if isinstance(contigs, ContigsInBackground):
+            contigs = contigs.wait()
+    except SystemExit as e:
+        error = dist.exit_message(e)
+    except Exception as e:
+        error = "\nError: %s: %s\n" % (type(e).__name__, e)
+    dist.agree_or_exit(error)
     by_species = _species_contig_order(all_ids, contigs)
     ref_index = {n: i for i, n in enumerate(ref_names)}
     piece_len = pieces.piece_length(int(args.get('split_length', SPLIT_LENGTH))) if plan is not None and plan['pos_sorted'] else 0
@@ -764,7 +782,9 @@ def run_pipeline(args):
     start = time()
     species = initialize_species(args)
     # (the genomes are read on a thread of their own and waited for where the pileup first needs them)
-    contigs = ContigsInBackground(species) if args['call'] else initialize_contigs(species)
+    # (with --build_db / --align in front of the pileup the reader starts behind them: rank 0 reads the same files there)
+    contigs = (ContigsInBackground(species, start=not (args['build_db'] or args['align'])) if args['call']
+               else initialize_contigs(species))
     print("  %s minutes" % round((time() - start) / 60, 2))
     print("  %s Gb maximum memory" % utility.max_mem_usage())
 
@@ -796,6 +816,8 @@ def run_pipeline(args):
     dist.agree_or_exit(error)
 
     if args['call']:
+        if isinstance(contigs, ContigsInBackground):
+            contigs.start()
         if rank == 0:
             index_bam(args)
         pysam_pileup(args, species, contigs)
