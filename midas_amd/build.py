@@ -62,13 +62,13 @@ def _run(cmd, verbose):
         raise RuntimeError("hipcc failed (%d): %s\n%s" % (res.returncode, " ".join(cmd), res.stdout))
 
 
-def build_native(force=False, verbose=False, extra_flags=(), lib_path=None):
+def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, replace=None):
     """Compile midas_amd/csrc/* into midas_amd/lib/libmidas_snps_hip.so (gfx950 only).
 
-    `extra_flags` / `lib_path`: developer variants (tools/build_variant.sh): other -D switches, another output name; their
-    objects are not cached.
+    `extra_flags` / `lib_path` / `replace`: developer variants (tools/build_variant.sh): other -D switches, another output
+    name, another file in place of a source ({"pileup_direct.hip": "tools/variants/x.hip"}); their objects are not cached.
     """
-    variant = bool(extra_flags) or lib_path is not None
+    variant = bool(extra_flags) or lib_path is not None or bool(replace)
     out = lib_path or LIB_PATH
     if not force and not variant and not _stale():
         return out
@@ -79,11 +79,11 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None):
     jobs = []
     objs = []
     for s in _sources():
-        src = os.path.join(CSRC, s)
+        src = os.path.abspath(replace[s]) if replace and s in replace else os.path.join(CSRC, s)
         obj = os.path.join(obj_dir, s.replace(".", "_") + ".o")
         objs.append(obj)
         if force or variant or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
-            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-x", "hip", "-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-I", CSRC, "-x", "hip", "-c", src, "-o", obj])
     try:
         workers = max(1, min(len(jobs), (os.cpu_count() or 4)))
         if jobs:
@@ -109,10 +109,14 @@ if __name__ == "__main__":
     verbose = "-v" in args
     out = None
     extra = []
+    repl = {}
     it = iter(a for a in args if a not in ("--force", "-v"))
     for a in it:
         if a == "-o":
             out = next(it)
+        elif a == "--replace":
+            k, v = next(it).split("=", 1)
+            repl[k] = v
         else:
             extra.append(a)
-    print(build_native(force=force, verbose=verbose, extra_flags=extra, lib_path=out))
+    print(build_native(force=force, verbose=verbose, extra_flags=extra, lib_path=out, replace=repl))

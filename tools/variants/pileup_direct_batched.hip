@@ -1,0 +1,872 @@
+// DEVELOPER VARIANT, NOT IN THE PRODUCT (round 4; build: python -m midas_amd.build -o midas_amd/lib/libmidas_snps_hip_batched.so
+// --replace pileup_direct.hip=tools/variants/pileup_direct_batched.hip).  The pileup kernel with a read's own work -- columns,
+// CIGAR shape, the quality-free tests of keep_read -- done by ONE lane per read for a batch of up to five of a wave's iterations
+// and handed to the lanes that hold its bases by ds_bpermute_b32.  Bit-exact (tests/test_gpu_direct.py, 107 cases) and 15 % fewer
+// vector instructions (381 M against 447 M per launch on configs[2]) -- and 5 % SLOWER on the same box (1.077 against 1.026 ms):
+// the per-batch loads sit in branches, so the compiler's load counting forces the iteration's own bases to be waited for before
+// the next ones are requested, the requests leave a few hundred cycles later, and this kernel is bound by the bytes it keeps in
+// flight (one iteration of bases per wave, 48 KB per CU), not by instruction issue.  Requesting from offsets fetched an
+// iteration earlier needs five more registers per lane: 84 spills at the 128 this occupancy allows, 2.26 ms.  DESIGN.md 3.A.
+// (A tile's SEQ / QUAL are addressed by 32-bit offsets from those of its first read here: a product version would have the
+// facts pass check that a stream's entries lie within 4 GiB.)
+// gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM-native arrays themselves: 4-bit SEQ, QUAL, CIGAR and
+// the per-read columns where the decoder put them -- no packed payload, no sort, no per-read record, ONE visit per read.
+// Integer counting: no MFMA.
+//
+// Reference semantics implemented here (citations into /root/reference):
+//   keep_read                       midas/run/snps.py:141-162  (query_alignment_sequence :145, np.mean(query_qualities) :151)
+//   count_coverage call site        midas/run/snps.py:194-199  ([EXT] pysam: get_aligned_pairs(matches_only), qual >= quality_threshold,
+//                                   only 'A','C','G','T' counted)
+//   depth / covered / total_depth   midas/run/snps.py:204-213
+//   str(rec.seq).upper()            midas/run/snps.py:62
+// The reference filters and counts a read in one pass (keep_read inside count_coverage's iterator); so does this kernel.
+//
+// Work decomposition: as in pileup_tiles.hip -- tiles of <= 4096 sites, a persistent 512-thread workgroup per item, tallies
+// in LDS as [site][A,C,G,T] u32, one coalesced write-out per tile, items handed out by per-XCD counters.
+//
+// Stream.  The ranges pass (index_direct.hip, 4 bytes per read) left, per tile, the run [tbegin, tend) of read indices that
+// can touch the tile -- the input is position-sorted, so that is a contiguous run of the read arrays.  It is dealt to the
+// workgroup's waves as wave-iterations of floor(64 / lanes per read) reads.
+//
+// Lane mapping.  A lane owns LB (30 or 32) consecutive bases of a read's STORED query: two 16-byte loads of QUAL, one of
+// 4-bit SEQ (LB is even, so a lane's bases start on a byte).  A read of l_seq bases takes ceil(l_seq / LB) adjacent lanes
+// (5 for 150 bp).  Loads are issued two iterations (the read's columns: pos, l_seq, NM, mapq, SEQ / QUAL / CIGAR offsets)
+// and one iteration (bases + the first four CIGAR ops) ahead of their use; none of them sits in a branch.
+//
+// Per read.  The lanes of a read decide in registers what its CIGAR is: ONE or TWO gap-free match runs (direct_common.h
+// ReadShape: clips, at most one insertion / deletion / skip -- what an aligner writes for nearly every read) are tallied
+// straight from the shape, the lane that holds the indel in a second masked pass; anything else (several indels, pads, odd
+// clips, no NM / SEQ, a start off the contig) is walked op by op where it lies, the slow path.
+//
+// Per base, from the raw bytes:  the 4-bit codes of eight bases (one dword) are split into their even and odd nibbles
+// (two masks), mapped to v_perm_b32 selectors by `(n + 7) ^ 8` -- A, C, G, T (1, 2, 4, 8) land on table slots 0, 1, 3, 7,
+// every other code on a slot or a selector constant that yields 0xFF -- and looked up twice: a THRESHOLD byte (baseq - 1
+// for A/C/G/T, 0xFF for anything else) and the byte offset of the base's counter.  Then per base one SDWA compare
+// `qual.byte > threshold.byte` into a lane mask (the byte selects of the two operands are independent, so the even / odd
+// order of the looked-up bytes costs nothing), one SDWA OR forming the LDS address, one returnless ds_add under the mask.
+// Clipping (soft clips, segment borders, tile edges, the read's tail) ORs 0xFF into threshold bytes: two table rows from LDS.
+// The read's mean quality is v_sad_u8 over the lane's bytes and a sum over the read's lanes; sum(q) < readq * l_seq is the
+// reference's np.mean(q) < readq exactly.
+#include "direct_common.h"
+#include "pileup_common.h"
+
+#include <type_traits>
+
+namespace midas {
+
+using namespace dev;
+using namespace pile;
+using namespace direct;
+
+namespace {
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Eight bases of one lane: q0 / q1 two words of four quality bytes (bases in order), the / tho threshold bytes and cde / cdo
+// counter offsets of the even / odd bases (byte i of an `e` word: base 2i, of an `o` word: base 2i + 1).
+template <int OFF, int NB>
+__device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t the, uint32_t tho, uint32_t cde, uint32_t cdo,
+                                            uint32_t abase, uint32_t one) {
+  static_assert(NB == 8 || NB == 6, "a group holds 8 bases, or 6 at the end of a 30-base lane");
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, save;
+  if (NB == 8) {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t6], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_or_b32_sdwa %[t7], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m6], %[q1], %[te] src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m7], %[q1], %[to] src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        "s_mov_b64 exec, %[m4]\n\t"
+        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        "s_mov_b64 exec, %[m5]\n\t"
+        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
+        "s_mov_b64 exec, %[m6]\n\t"
+        "ds_add_u32 %[t6], %[one] offset:%[off]+96\n\t"
+        "s_mov_b64 exec, %[m7]\n\t"
+        "ds_add_u32 %[t7], %[one] offset:%[off]+112\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+          [t7] "=&v"(t7), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5),
+          [m6] "=&s"(m6), [m7] "=&s"(m7), [sv] "=&s"(save)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
+          [off] "n"(OFF)
+        : "memory");
+  } else {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        "s_mov_b64 exec, %[m4]\n\t"
+        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        "s_mov_b64 exec, %[m5]\n\t"
+        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [m0] "=&s"(m0),
+          [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [sv] "=&s"(save)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
+          [off] "n"(OFF)
+        : "memory");
+  }
+}
+
+// The per-tile stream: the reads rb .. rb + n0 of the read arrays, as `total` wave-iterations.
+struct Stream { int rb, n0, total; };
+
+// Workgroup shape (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384).
+#ifndef MIDAS_DIRECT_BLOCK
+#define MIDAS_DIRECT_BLOCK 512
+#endif
+constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
+static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
+constexpr int kDirectWavesPerSimd = (2 * kDirectBlock / 64 + 3) / 4;      // two workgroups per CU
+
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int LB, bool BQ0>
+__global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
+  constexpr int TILE = kTileSites;
+  constexpr int NWAVES = kDirectBlock / 64;
+  constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_mhi[33 * 8];   // [h][w]: 0xFF in the bytes of the bases j >= h
+  __shared__ __attribute__((aligned(16))) uint32_t s_mlo[33 * 8];   // [l][w]: 0xFF in the bytes of the bases j <  l
+  __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
+  __shared__ unsigned long long s_stats[MIDAS_STATS];
+  __shared__ uint32_t s_next_ticket;
+  extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w_end = p.n_tiles;
+#ifdef MIDAS_DIRECT_STATIC
+  const bool dynamic = false;       // (developer variant: tiles dealt round robin)
+#else
+  const bool dynamic = (gridDim.x % kSchedGroups) == 0;
+#endif
+  const int sched_group = (int)(blockIdx.x % kSchedGroups);
+  uint32_t* const sched = p.sched;
+  int w = (int)blockIdx.x;
+  if (w >= w_end) return;
+  int w_next = w + (int)gridDim.x;
+#if MIDAS_SNPS_DEBUG_BITS & 256
+  unsigned long long pr_cols = 0, pr_bases = 0, pr_work = 0, pr_sync = 0, pr_out = 0, pr_iters = 0;
+  const unsigned long long pr_t0 = __builtin_readcyclecounter();
+#define PROBE_NOW() __builtin_readcyclecounter()
+#else
+#define PROBE_NOW() 0ull
+#endif
+
+  {
+    uint4* z = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < TILE; i += kDirectBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < p.table_len; i += kDirectBlock) {
+      s_tables[i] = p.filt->min_match[i];
+      s_tables[p.table_len + i] = p.filt->min_align[i];
+    }
+    for (int i = tid; i < 33 * 8; i += kDirectBlock) {
+      const int h = i >> 3, wd = i & 7;
+      uint32_t mh = 0, ml = 0;
+      for (int b = 0; b < 4; ++b) {
+        const int j = 8 * (wd >> 1) + 2 * b + (wd & 1);       // base held by byte b of word wd (even / odd split)
+        if (j >= h) mh |= 0xFFu << (8 * b);
+        if (j < h) ml |= 0xFFu << (8 * b);
+      }
+      s_mhi[i] = mh;
+      s_mlo[i] = ml;
+    }
+    s_qsum[tid] = 0u;
+    if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
+  }
+
+  const int lpr = p.lanes_per_read;
+  const int rpw = p.reads_per_wave;
+  const int g = lane / lpr;
+  const int c = lane - g * lpr;
+  const int q0 = c * LB;                           // first base of the lane in the read's stored query
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t qsum_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_qsum + wave * 64 + g);
+  // v_perm_b32 tables (slots 0, 1, 3, 7 = A, C, G, T): threshold bytes and counter offsets
+  const uint32_t thr = BQ0 ? 0u : (uint32_t)(p.baseq > 256 ? 255 : p.baseq - 1);
+  const uint32_t th_lo = thr | (thr << 8) | 0x00FF0000u | (thr << 24), th_hi = 0x00FFFFFFu | (thr << 24);
+  const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
+  const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
+  const uint32_t one = 1u;
+
+  const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
+  const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
+  const ConstWords c_te = (ConstWords)(size_t)p.tend;
+  auto load_stream = [&](int tt) -> Stream {
+    Stream s;
+    const uint32_t b = c_tb[tt], e = c_te[tt];
+    s.rb = e > b ? (int)b : 0;
+    s.n0 = e > b ? (int)(e - b) : 0;
+    s.total = __builtin_amdgcn_readfirstlane((s.n0 + rpw - 1) / rpw);
+    return s;
+  };
+  // reads of a stream's wave-iteration `it` (wave-uniform): the lanes with g below it hold one
+  auto reads_in = [&](const Stream& st, int it) -> int {
+    const long long left = (long long)st.n0 - (long long)it * rpw;
+    return left <= 0 ? 0 : (left < rpw ? (int)left : rpw);
+  };
+
+  // Sum of a read's quality bytes over its lanes (np.mean(aln.query_qualities), midas/run/snps.py:151): every lane adds its
+  // part to the read's LDS slot, reads the slot back and clears it -- three LDS operations of one wave, executed in
+  // order, instead of a shuffle per lane of the read.  Bit 31: QUAL absent.
+  auto read_sum = [&](uint32_t part) -> uint32_t {
+    uint32_t tot;
+    asm volatile("ds_add_u32 %1, %2\n\tds_read_b32 %0, %1\n\tds_write_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(tot) : "v"(qsum_addr), "v"(part), "v"(0u) : "memory");
+    return tot;
+  };
+  auto lane_qsum = [&](const uint32_t (&q)[8], int nb) -> uint32_t {
+    uint32_t part = 0;
+    if (nb == LB) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) part = __builtin_amdgcn_sad_u8(q[k], 0u, part);
+      part = __builtin_amdgcn_sad_u8(LB == 32 ? q[7] : (q[7] & 0x0000FFFFu), 0u, part);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
+    }
+    if (c == 0) part |= ((q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
+    return part;
+  };
+  // Threshold bytes and counter offsets of eight bases from their 4-bit codes (one dword of SEQ): the even and the odd
+  // nibbles become v_perm_b32 selectors by (n + 7) ^ 8 -- A, C, G, T (1, 2, 4, 8) select table slots 0, 1, 3, 7, every
+  // other code a slot or a selector constant that reads 0xFF.
+  // The lanes `go` tally bases [lo, hi) of their 30 / 32, the first of the lane at tile-relative site loc0.  Group by group
+  // (decode eight bases, tally them), so that only one group's looked-up bytes are alive at a time.
+  // (sparse: a pass with few lanes, e.g. the one lane of a read that holds its indel -- a group of eight bases none of the
+  // wave's lanes has a base in is skipped)
+  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4], auto sparse_tag) {
+    constexpr bool SPARSE = decltype(sparse_tag)::value;
+    const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
+    const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
+    unsigned long long gmask[4];
+    if (SPARSE) {
+#pragma unroll
+      for (int S = 0; S < 4; ++S) gmask[S] = __ballot(go && lo < 8 * S + 8 && hi > 8 * S);
+    }
+    if (!go) return;                                                    // outside [lo, hi) (a row of each table, LDS)
+    const uint32_t* mh = s_mhi + 8 * (hi > 32 ? 32 : hi);
+    const uint32_t* ml = s_mlo + 8 * (lo < 0 ? 0 : lo);
+    auto group = [&](auto sidx, auto off, auto nbases) {
+      constexpr int S = decltype(sidx)::value;
+      if (SPARSE && gmask[S] == 0ull) return;
+      const uint32_t x = sq[S];
+      const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
+      const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
+      uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
+      const uint32_t ce = __builtin_amdgcn_perm(cd_hi, cd_lo, se), co = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
+      if (masked) {
+        const uint2 h = *reinterpret_cast<const uint2*>(mh + 2 * S), l = *reinterpret_cast<const uint2*>(ml + 2 * S);
+        te |= h.x | l.x;
+        to |= h.y | l.y;
+      }
+      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
+    };
+    using std::integral_constant;
+    group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 1>{}, integral_constant<int, 128>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 2>{}, integral_constant<int, 256>{}, integral_constant<int, 8>{});
+    group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
+  };
+
+  // ---- batches: a read's own work, ONE lane per read -------------------------------------------------------------------------
+  // A read's columns, the shape of its CIGAR and the tests of keep_read that need no quality are the same for every lane that
+  // holds bases of it: settled per wave-iteration (12 reads of 150 bp) they would be computed by five lanes each.  So a wave
+  // settles them for a BATCH of up to S = floor(64 / reads per iteration) of its own iterations of a tile at once, one lane
+  // per read and ahead of their use -- P-step 0: the columns (coalesced: adjacent lanes, adjacent reads); 1: the first four
+  // CIGAR ops; 2: shape + tests, packed into five words -- one step per iteration, in front of the iteration's own loads.
+  // An iteration then pulls the five words of its lanes' read from the lane that owns it (ds_bpermute_b32):
+  //   w0 pos      w1 / w2 QUAL / SEQ offsets, relative to those of the tile's first read (32 bits: checked at batch_create)
+  //   w3 l_seq | lead << 11 | flags << 22      w4 m1 | alen << 11 | gap << 22 (the inserted or deleted length: <= 1023)
+  // flags: 1 the slot holds a read; 2 one or two match runs and NM present; 4 passes the mapid, mapq and aln_cov tests;
+  //        8 passes the mapid test (what decides between "dropped" and "no QUAL" for a read without qualities); 16 the gap is
+  //        a deletion / skip
+  constexpr uint32_t F_READ = 1u, F_SHAPED = 2u, F_PASS = 4u, F_PID = 8u, F_DEL = 16u;
+  const int S = __builtin_amdgcn_readfirstlane(64 / rpw);      // (a VALU division: back into a scalar register)
+  const int pj = lane / rpw, pg = lane - pj * rpw;     // the iteration of a batch, and the read of it, this lane owns
+  const bool gvalid = g < rpw;
+  const ConstWords c_qoff = (ConstWords)(size_t)p.qual_off, c_soff = (ConstWords)(size_t)p.seq_off;
+  // the batch in the making: its stream, its first iteration (the wave's k0-th of the tile) and their number, the tile (this
+  // one or the next), the QUAL / SEQ offsets of the tile's first read
+  struct Target { int rb, n0, k0, len; bool next; unsigned long long qb, sb; };
+  // the batch in use: where its tile's payload begins is all an iteration needs of it
+  struct InUse { int k0, len; bool next; const uint8_t* qbase; const uint8_t* sbase; };
+  auto make_target = [&](const Stream& s, int k0, int len, bool next) -> Target {
+    Target b;
+    b.rb = __builtin_amdgcn_readfirstlane(s.rb); b.n0 = __builtin_amdgcn_readfirstlane(s.n0);
+    b.k0 = __builtin_amdgcn_readfirstlane(k0); b.len = __builtin_amdgcn_readfirstlane(len); b.next = next;
+    const size_t i = 2 * (size_t)b.rb;
+    b.qb = (unsigned long long)c_qoff[i] | ((unsigned long long)c_qoff[i + 1] << 32);
+    b.sb = (unsigned long long)c_soff[i] | ((unsigned long long)c_soff[i + 1] << 32);
+    return b;
+  };
+  // a batch never ends with a tail too short to hide the three P-steps of the one behind it
+  auto batch_len = [&](int rem) -> int { return rem <= S ? rem : (S >= 4 && rem < S + 3 ? rem - 3 : S); };
+  auto waves_iters = [&](const Stream& s) -> int { return s.total > wave ? (s.total - wave + NWAVES - 1) / NWAVES : 0; };
+
+  uint32_t P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, P6 = 0, P7 = 0, P8 = 0, C0 = 0, C1 = 0, C2 = 0, C3 = 0;   // the batch in the making
+  uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;                                                                     // the batch in use
+  auto p_valid = [&](const Target& b, uint32_t* v) -> bool {
+    *v = (uint32_t)(wave + (b.k0 + pj) * NWAVES) * (uint32_t)rpw + (uint32_t)pg;
+    return pj < b.len && *v < (uint32_t)b.n0;
+  };
+  auto pstep = [&](int stage, const Target& b) {
+    uint32_t v;
+    const bool valid = p_valid(b, &v) && !(kDebug & 128);
+    if (stage == 0) {
+      const size_t r = valid ? (size_t)b.rb + v : (size_t)0;
+      P0 = (uint32_t)p.pos[r];
+      P3 = (uint32_t)p.l_seq[r];
+      P4 = (uint32_t)p.nm[r];
+      P5 = p.mapq[r];
+      P2 = *reinterpret_cast<const uint32_t*>(p.seq_off + r);
+      P1 = *reinterpret_cast<const uint32_t*>(p.qual_off + r);
+      const u32x3_a4 co = *reinterpret_cast<const u32x3_a4*>(p.cigar_off + r);      // cigar_off[r] and the low word of cigar_off[r + 1]
+      P6 = co.x; P7 = co.y; P8 = co.z;
+    } else if (stage == 1) {
+      const unsigned long long co = (unsigned long long)P6 | ((unsigned long long)P7 << 32);
+      const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(p.cigar + (valid ? co : 0ull));
+      C0 = cv.x; C1 = cv.y; C2 = cv.z; C3 = cv.w;
+    } else {
+      const uint32_t l = valid ? P3 : 0u;
+      const uint32_t nc = valid ? P8 - P6 : 0u;               // (<= 65534, checked when the batch was made)
+      const uint32_t nm16 = (int32_t)P4 < 0 ? 0xFFFFu : P4;
+      ReadShape sh;
+      sh.lead = 0u; sh.m1 = l; sh.ins = 0u; sh.del = 0u; sh.alen = l;
+      bool shaped = nc == 1u && op_is_match(C0 & 15u) && (C0 >> 4) == l && l >= 1u;
+      if (__ballot(valid && !shaped) != 0ull) {
+        ReadShape s2;
+        const bool ok = decode_shape(C0, C1, C2, C3, nc, l, &s2);
+        if (!shaped) { sh = s2; shaped = ok; }
+      }
+      // keep_read (midas/run/snps.py:141-162) for such a read: it has SEQ, NM and a non-empty aligned part
+      const int align_len = (int)sh.alen;
+      const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
+      const int min_align = s_tables[p.table_len + ((int)l < p.table_len ? (int)l : 0)];
+      const bool t_pid = align_len - (int)nm16 < min_match;                                          // pid < mapid
+      const bool t_drop = ((int)(P5 & 0xFFu) < p.mapq_min) | (align_len < min_align);                // mapq, aln_cov
+      const uint32_t gap = sh.ins + sh.del;                                                          // (one of them is 0)
+      shaped = shaped && gap <= 1023u;                                                               // (ten bits in w4)
+      const uint32_t fl = (valid ? F_READ : 0u) | (valid && shaped && nm16 != 0xFFFFu ? F_SHAPED : 0u) |
+                          (!(t_pid | t_drop) ? F_PASS : 0u) | (!t_pid ? F_PID : 0u) | (sh.del ? F_DEL : 0u);
+      P1 -= (uint32_t)b.qb;
+      P2 -= (uint32_t)b.sb;
+      P3 = l | (sh.lead << 11) | (fl << 22);
+      P4 = sh.m1 | (sh.alen << 11) | (gap << 22);
+    }
+  };
+
+  // ---- an iteration's loads: the five words of its lanes' read out of the batch in use, and the lane's bases (two 16-byte
+  // loads of QUAL, one of SEQ).  NO load sits in a divergent branch: a lane without bases fetches the first bytes of the
+  // tile's payload.
+  struct Rd { uint32_t w0, w3, w4; };
+  struct Dat { uint32_t q[8]; uint32_t s[4]; };
+  auto settle = [&](const InUse& b, int slot, Rd& r, Dat& d) {
+    const bool any = slot < b.len;                                       // (wave-uniform)
+    const int src = (((any ? slot : 0) * rpw + (gvalid ? g : 0)) << 2);
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D1);
+    const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D2);
+    const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D3);
+    r.w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D0);
+    r.w4 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D4);
+    r.w3 = any && gvalid ? w3 : 0u;
+    const int l = (int)(r.w3 & 0x7FFu);
+    const bool has = q0 < l && ((r.w3 >> 22) & F_READ) != 0u;
+    const uint32_t qo = has ? w1 + (uint32_t)q0 : 0u;
+    const uint32_t so = has ? w2 + (uint32_t)(q0 >> 1) : 0u;
+    const uint8_t* qp = b.qbase + qo;
+    const uint8_t* sp = b.sbase + so;
+    const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
+    const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
+    const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
+    d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
+    d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
+    d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
+  };
+
+  Tile tile = load_tile(c_tiles, w);
+  Stream st = load_stream(w);
+  // The pipeline of a wave: two register sets that swap roles every iteration (the loop below is unrolled by two: a copy at
+  // its back edge would have to WAIT for the loads it copies) -- one holds the iteration being tallied, the other the next
+  // one's bases (in flight); behind them the batch in use (D0..D4), the batch in the making (P.., C..) and its P-step.
+  // Between tiles the current iteration sits in set A.
+  Rd rdA, rdB;
+  Dat datA, datB;
+  rdA.w0 = rdA.w3 = rdA.w4 = 0u;
+  InUse cb;                                   // the batch in use; jn: the slot in it of the NEXT iteration to request
+  cb.k0 = 0; cb.len = 0; cb.next = false; cb.qbase = p.qual; cb.sbase = p.seq4;
+  Target tb = make_target(st, 0, 0, false);   // the batch in the making (t_valid), `stage` = its next P-step
+  int jn = 0, stage = 3;
+  bool t_valid = false, have_cur = false;
+  __syncthreads();   // LDS zeroed, tables in place
+
+  uint32_t acc_cov = 0u;                 // (a thread's sites between two flushes: far below 2^32)
+  unsigned long long acc_depth = 0ull;
+  int t = w;
+  for (;;) {
+    const int tile_len = tile.len;
+    const int tile_start = tile.start;
+    const int it_hi = st.total;
+    uint32_t w_aligned = 0, w_mapped = 0;
+    constexpr int REF_IT = (TILE + 4 * kDirectBlock - 1) / (4 * kDirectBlock);
+
+    // this wave's iterations of the tile, and of the next one (the batches run on across the tile boundary, as the
+    // prefetch of pileup_tiles.hip does)
+    const int n_w = waves_iters(st);
+    const bool xt = w_next < w_end;
+    Stream xs = st;
+    if (xt) xs = load_stream(w_next);
+    const int x_nw = xt ? waves_iters(xs) : 0;
+    // the batch behind the one in use: the tile's next, or the first of the next tile (one tile ahead is all that is known)
+    auto plan = [&]() {
+      const int k1 = cb.k0 + cb.len;
+      t_valid = false;
+      if (!cb.next) {
+        if (k1 < n_w) { tb = make_target(st, k1, batch_len(n_w - k1), false); t_valid = true; }
+        else if (x_nw > 0) { tb = make_target(xs, 0, batch_len(x_nw), true); t_valid = true; }
+      } else if (k1 < x_nw) {
+        tb = make_target(xs, k1, batch_len(x_nw - k1), true);
+        t_valid = true;
+      }
+      stage = t_valid ? 0 : 3;
+    };
+    // Where the P-steps sit in an iteration matters: their loads are in branches, and behind a branch the compiler can only
+    // count on the FEWEST loads any path issued -- a wait for older loads then takes a branch's fresh loads with it (measured:
+    // 1.5 k cycles per iteration).  So a step runs at the top of an iteration, behind a wait for everything in flight (the
+    // iteration's own bases, needed now anyway) and in front of the next iteration's loads.
+    //   roll_if_due: the next iteration is the first of the batch in the making -- that batch becomes the one in use (its
+    //   steps are normally done by then: batches of three iterations or more; whatever is left runs here and waits)
+    auto roll_if_due = [&]() {
+      if (jn >= cb.len && t_valid) {
+        for (; stage < 3; ++stage) pstep(stage, tb);
+        D0 = P0; D1 = P1; D2 = P2; D3 = P3; D4 = P4;
+        cb.k0 = tb.k0; cb.len = tb.len; cb.next = tb.next; cb.qbase = p.qual + tb.qb; cb.sbase = p.seq4 + tb.sb;
+        jn = 0;
+        plan();
+      }
+    };
+    auto one_step = [&]() {
+      if (stage < 3) { pstep(stage, tb); ++stage; }
+    };
+    if (!have_cur) {
+      cb.k0 = 0; cb.len = 0; cb.next = false; jn = 0;
+      if (n_w > 0 && !t_valid) {     // nothing was prepared for this tile (the kernel's first, or one whose predecessor could not know it)
+        tb = make_target(st, 0, batch_len(n_w), false);
+        t_valid = true;
+        stage = 0;
+      }
+    }
+    if (!t_valid) plan();
+    if (!t_valid) plan();
+
+    // one wave-iteration: `it` of the tile's stream; tallies (rd_cur, dat_cur), requests the next iteration's words and bases
+    // into (rd_n, dat_n)
+    auto iteration = [&](int it, Rd& rd_cur, Dat& dat_cur, Rd& rd_n, Dat& dat_n) {
+      const unsigned long long pt0 = PROBE_NOW();
+      // (the iteration's own bases, requested an iteration ago, are waited for HERE: with nothing in flight the step's
+      // waits cost nothing, and the loads behind it -- the step's, then the next iteration's bases -- are counted exactly)
+      asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[1]), "v"(dat_cur.q[2]), "v"(dat_cur.q[3]), "v"(dat_cur.q[4]), "v"(dat_cur.q[5]),
+                         "v"(dat_cur.q[6]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[1]), "v"(dat_cur.s[2]), "v"(dat_cur.s[3]));
+      roll_if_due();
+      one_step();
+      settle(cb, jn, rd_n, dat_n);
+      ++jn;
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      asm volatile("" :: "v"(rd_n.w0), "v"(rd_n.w3));
+      const unsigned long long pt1 = PROBE_NOW();
+      asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[3]));
+      const unsigned long long pt2 = PROBE_NOW();
+      pr_cols += pt1 - pt0; pr_bases += pt2 - pt1; pr_iters += 1;
+#endif
+
+      if (kDebug & 4) {          // (developer timing variant: the stream of loads only)
+        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(rd_cur.w0));
+        return;
+      }
+      const int pos = (int)rd_cur.w0;
+      const int l = (int)(rd_cur.w3 & 0x7FFu);
+      const uint32_t fl = rd_cur.w3 >> 22;
+      const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
+      const bool has = nb > 0;
+      uint32_t qsum = (kDebug & 64) ? 0x00FFFFFFu : read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
+      const bool t_noqual = (qsum >> 31) != 0u;
+      qsum &= 0x7FFFFFFFu;
+      const bool act = (fl & F_READ) != 0u;
+      uint32_t qv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
+      // one or two match runs, NM present, the start inside the contig: the fast path.  Everything else is walked.
+      const bool fast = (fl & F_SHAPED) != 0u && (uint32_t)pos < (uint32_t)tile.contig_len;
+      const bool slow = act && !fast;
+
+      // ======================= fast: one or two gap-free match runs ==========================================================
+      const int lead = (int)((rd_cur.w3 >> 11) & 0x7FFu), m1 = (int)(rd_cur.w4 & 0x7FFu), align_len = (int)((rd_cur.w4 >> 11) & 0x7FFu);
+      const int gap = (int)(rd_cur.w4 >> 22);
+      const int ins = (fl & F_DEL) ? 0 : gap, del = (fl & F_DEL) ? gap : 0;
+      bool keep, owner;
+      uint32_t err;
+      {
+        // ---- keep_read (midas/run/snps.py:141-162): what the batch left open is the mean quality and QUAL's presence -----------
+        const bool t_q = (int)qsum < rq * l;                                                                 // readq
+        err = (fast && (fl & F_PID) && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;
+        keep = fast && (fl & F_PASS) && !(t_noqual | t_q);
+        const int rel = pos - tile_start;            // 0 <= pos < contig length: no wrap
+        owner = fast && rel >= 0 && rel < tile_len;
+        // run A: query [lead, lead + m1) at sites pos ...; run B: query [lead + m1 + ins, lead + alen) at pos + m1 + del ...
+        // -- this lane's part of each, clipped to the tile
+        const int qa1 = lead + m1, qb0 = qa1 + ins, qb1 = lead + align_len;
+        const int loc_a = rel + (q0 - lead);
+        const int loc_b = loc_a + del - ins;
+        int lo_a = lead - q0, hi_a = qa1 - q0, lo_b = qb0 - q0, hi_b = qb1 - q0;
+        lo_a = lo_a > -loc_a ? lo_a : -loc_a;
+        lo_a = lo_a > 0 ? lo_a : 0;
+        hi_a = hi_a < tile_len - loc_a ? hi_a : tile_len - loc_a;
+        hi_a = hi_a < nb ? hi_a : nb;
+        const bool go_a = keep && lo_a < hi_a;
+        bool go_b = false;
+        int lo_b2 = 0, hi_b2 = 0;
+        if (__ballot(keep && align_len != m1) != 0ull) {     // (wave-uniform: a read of the iteration has a second run)
+          lo_b = lo_b > -loc_b ? lo_b : -loc_b;
+          lo_b = lo_b > 0 ? lo_b : 0;
+          hi_b = hi_b < tile_len - loc_b ? hi_b : tile_len - loc_b;
+          hi_b = hi_b < nb ? hi_b : nb;
+          go_b = keep && lo_b < hi_b;
+          lo_b2 = lo_b; hi_b2 = hi_b;
+        }
+        // first pass: every lane its run (the lane that holds the indel: the part in front of it); second pass, only when a
+        // lane of the wave has bases on both sides of an indel: the part behind it
+        const bool go1 = go_a | go_b;
+        if (!(kDebug & 1) && __ballot(go1) != 0ull)
+          tally_range(go1, go_a ? lo_a : lo_b2, go_a ? hi_a : hi_b2, go_a ? loc_a : loc_b, qv, dat_cur.s, std::false_type{});
+        const bool go2 = go_a & go_b;
+        if (!(kDebug & (1 | 16)) && __ballot(go2) != 0ull) tally_range(go2, lo_b2, hi_b2, loc_b, qv, dat_cur.s, std::true_type{});
+      }
+      // ======================= slow: walked op by op (its columns and its CIGAR are read here, where it lies) ===================
+      if (__ballot(slow) != 0ull) {
+        const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
+        const size_t ri = slow ? (size_t)idx : (size_t)0;
+        const uint32_t nm_raw = (uint32_t)p.nm[ri];
+        const uint32_t nm16 = (int32_t)nm_raw < 0 ? 0xFFFFu : nm_raw;
+        const int nm = (int)nm16, mapq = (int)p.mapq[ri];
+        const long long co0 = p.cigar_off[ri], co1 = p.cigar_off[ri + 1];
+        const uint32_t nc = slow ? (uint32_t)(co1 - co0) : 0u;
+        CigarView cg;
+        cg.load(p.cigar + (slow ? co0 : 0ll));
+        const uint32_t ncs = nc;
+        // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
+        long long qs = 0, qe = 0;
+        query_bounds(cg, ncs, l, &qs, &qe);
+        long long al = qe - qs;
+        al = al < 0 ? 0 : (al > 2047 ? 2047 : al);      // (l_seq <= 1024)
+        const int align_g = (int)al;
+        // the one case in which count_coverage raises IndexError for a kept read: a match op maps a query position >= l_seq
+        // onto a site inside the contig
+        bool t_over = false;
+        {
+          long long qpos = 0, rpos = pos;
+          const long long clen = tile.contig_len;
+          for_each_op(cg, ncs, [&](uint32_t, uint32_t v) {
+            const uint32_t op = v & 15u;
+            const long long len = (long long)(v >> 4);
+            if (op_is_match(op)) {
+              if (qpos + len > (long long)l) {
+                const long long qs2 = qpos > (long long)l ? qpos : (long long)l;
+                const long long rs = rpos + (qs2 - qpos), re = rpos + len;
+                if (rs < clen && re > 0) t_over = true;
+              }
+              qpos += len;
+              rpos += len;
+            } else if (op == OP_I || op == OP_S || (op == OP_P && p.pad_advances)) {
+              qpos += len;
+            } else if (op == OP_D || op == OP_N) {
+              rpos += len;
+            }
+            return true;
+          });
+        }
+        // ---- keep_read, every test evaluated, the reference's order decides which outcome wins ---------------------------
+        const int min_match = s_tables[align_g < p.table_len ? align_g : 0];
+        const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+        const bool t_noseq = l == 0;
+        const bool t_nonm = nm16 == 0xFFFFu;
+        const bool t_zero = align_g == 0;
+        const bool t_pid = align_g - nm < min_match;
+        const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_g < min_align);
+        uint32_t e = t_over ? (uint32_t)E_CIGAR_OVERRUN : 0u;
+        e = t_drop ? 0u : e;
+        e = t_noqual ? (uint32_t)E_NO_QUAL : e;
+        e = t_pid ? 0u : e;
+        e = t_zero ? (uint32_t)E_ZERO_ALIGN : e;
+        e = t_nonm ? (uint32_t)E_NO_NM : e;
+        e = t_noseq ? (uint32_t)E_NO_SEQ : e;
+        const bool keep_s = slow && !(t_noseq | t_nonm | t_zero | t_pid | t_noqual | t_drop | t_over);
+        // owner tile of a read = the tile holding its (clamped) start: it alone counts the read in the stats
+        int cpos = pos < 0 ? 0 : pos;
+        cpos = cpos > tile.contig_len - 1 ? tile.contig_len - 1 : cpos;
+        const bool owner_s = slow && cpos >= tile_start && cpos < tile_start + tile_len && !(tile.halo && pos < 0);
+        if (slow) { err = e; keep = keep_s; owner = owner_s; }
+        const int rel = pos - tile_start;                                     // may wrap for absurd positions:
+        int rrel = (rel > (1 << 25) || rel < -(1 << 30)) ? (1 << 25) : rel;   // those are parked far right
+        // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time ------------------------
+        // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative reference
+        // position only below 4096, and both only ever grow.
+        uint32_t k = 0;
+        int qpos = 0, jlo = 0, jhi = 0, loc0 = 0;
+        const int q1 = q0 + nb;
+        auto next_segment = [&]() -> bool {
+          while (k < nc) {
+            const uint32_t v = cg[k];
+            ++k;
+            const uint32_t op = v & 15u;
+            const int len = (int)(v >> 4);
+            const bool m = consumes_both(op);
+            bool found = false;
+            if (m) {
+              const int lo = qpos > q0 ? qpos : q0;
+              const int hi = (qpos + len) < q1 ? (qpos + len) : q1;
+              found = lo < hi;
+              if (found) { jlo = lo - q0; jhi = hi - q0; loc0 = rrel + (q0 - qpos); }
+            }
+            if (m || op == OP_I || op == OP_S || (op == OP_P && p.pad_advances)) { qpos += len; qpos = qpos > (1 << 29) ? (1 << 29) : qpos; }
+            if (m || op == OP_D || op == OP_N) { rrel += len; rrel = rrel > (1 << 29) ? (1 << 29) : rrel; }
+            if (found) return true;   // H, P and anything else: no effect
+          }
+          return false;
+        };
+        bool walking = keep_s && has;
+        if (walking) walking = next_segment();
+        while (__ballot(walking) != 0ull) {
+          const int lo = jlo > -loc0 ? jlo : -loc0;
+          const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
+          if (!(kDebug & 1)) tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s, std::true_type{});
+          walking = (walking && k < nc) ? next_segment() : false;
+        }
+      }
+      // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
+      const bool head = owner && c == 0;
+      w_aligned += (uint32_t)__popcll(__ballot(head));
+      w_mapped += (uint32_t)__popcll(__ballot(head && keep));
+      // (a read of the piece in front, midas_snps_contigs.origin: its own piece reports what keep_read raises, this one the
+      // overrun its walk runs into here)
+      const bool walk_err = slow && tile.halo && pos < 0 && c == 0 && err == (uint32_t)E_CIGAR_OVERRUN;
+      if ((head && err) || walk_err) {
+        const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
+        atomicMin(p.err, ((unsigned long long)idx << 8) | err);
+      }
+
+#if MIDAS_SNPS_DEBUG_BITS & 256
+      pr_work += PROBE_NOW() - pt2;
+#endif
+    };
+    {
+      int it = wave;
+      bool odd = false;
+      if (!have_cur && it < it_hi) {     // (nothing was requested for the tile's first iteration: made, requested and waited for here)
+        roll_if_due();
+        settle(cb, jn, rdA, datA);
+        ++jn;
+      }
+      while (it < it_hi) {
+        iteration(it, rdA, datA, rdB, datB);
+        it += NWAVES;
+        if (it >= it_hi) { odd = true; break; }
+        iteration(it, rdB, datB, rdA, datA);
+        it += NWAVES;
+      }
+      if (odd) { rdA = rdB; datA = datB; }      // (once per tile, not per iteration)
+    }
+    // (the batch in use now is the next tile's first one, if the last iteration found it made)
+    have_cur = cb.next;
+    cb.next = false;
+    tb.next = false;
+
+    // the tile's reference letters: requested here, behind the stream loop (two registers less in it), they arrive while
+    // the workgroup waits for its last wave and writes the counts out
+    uint32_t refw[REF_IT];
+    if (p.out_allele) {
+      const uint8_t* ref = p.ref + tile.site_base;
+#pragma unroll
+      for (int it = 0; it < REF_IT; ++it) {
+        const int i = 4 * (tid + it * kDirectBlock);
+        if (i + 4 <= tile_len) refw[it] = *reinterpret_cast<const u32_a1*>(ref + i);
+      }
+    }
+    if (lane == 0) {
+      if (w_aligned) atomicAdd(&s_stats[MIDAS_STAT_ALIGNED], (unsigned long long)w_aligned);
+      if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
+    }
+    // ---- next tile ---------------------------------------------------------------------------------------------------------
+    const int wn = w_next;
+    const bool more = wn < w_end;
+    const int tn = more ? wn : t;
+    const Tile ntile = load_tile(c_tiles, tn);
+    const Stream nst = load_stream(tn);
+    const unsigned long long ps0 = PROBE_NOW();
+    lds_barrier();       // every tally of this tile is in LDS
+    const unsigned long long ps1 = PROBE_NOW();
+    uint32_t ticket = 0;
+    if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
+
+    // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered / total-depth partials ---------------------------
+    {
+      uint4* out = reinterpret_cast<uint4*>(p.out_counts) + ((kDebug & 8) ? 0 : tile.site_base);
+      uint4* lds4 = reinterpret_cast<uint4*>(lds);
+      const int lim = (kDebug & 2) ? 0 : tile_len;
+#pragma unroll
+      for (int it = 0; it < OUT_IT; ++it) {
+        const int i = tid + it * kDirectBlock;
+        if (i < lim) {
+          const uint4 v = lds4[i];
+          lds4[i] = make_uint4(0u, 0u, 0u, 0u);
+          u32x4_a8 nv; nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
+          __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_a8*>(out + i));
+          const uint32_t d = v.x + v.y + v.z + v.w;
+          acc_cov += d > 0u ? 1u : 0u;
+          acc_depth += d;
+        }
+      }
+    }
+    if (p.out_allele && !(kDebug & 2)) {
+      const uint8_t* ref = p.ref + tile.site_base;
+      uint8_t* al = p.out_allele + tile.site_base;
+#pragma unroll
+      for (int it = 0; it < REF_IT; ++it) {
+        const int i = 4 * (tid + it * kDirectBlock);
+        if (i + 4 <= tile_len) {
+          __builtin_nontemporal_store(upper4(refw[it]), reinterpret_cast<u32_a1*>(al + i));
+        } else {
+          for (int j = i; j < tile_len; ++j) {
+            uint32_t ch = ref[j];
+            if (ch >= 'a' && ch <= 'z') ch -= 32u;
+            al[j] = (uint8_t)ch;
+          }
+        }
+      }
+    }
+    if (dynamic && more && tid == 0) s_next_ticket = ticket;
+    lds_barrier();       // tallies re-zeroed, this tile's s_stats additions done
+#if MIDAS_SNPS_DEBUG_BITS & 256
+    pr_sync += ps1 - ps0;
+    pr_out += PROBE_NOW() - ps1;
+#else
+    (void)ps0; (void)ps1;
+#endif
+    if (more) {
+      const long long nn = dynamic ? 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
+                                   : (long long)wn + (long long)gridDim.x;
+      w_next = __builtin_amdgcn_readfirstlane((int)(nn < (long long)w_end ? nn : (long long)w_end));
+    }
+    const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
+    if (flush) {
+      for (int d = 32; d >= 1; d >>= 1) {
+        acc_cov += __shfl_down(acc_cov, d);
+        acc_depth += __shfl_down(acc_depth, d);
+      }
+      if (lane == 0) {
+        if (acc_cov) atomicAdd(&s_stats[MIDAS_STAT_COVERED], (unsigned long long)acc_cov);
+        if (acc_depth) atomicAdd(&s_stats[MIDAS_STAT_DEPTH], acc_depth);
+      }
+      acc_cov = 0u;
+      acc_depth = 0ull;
+      lds_barrier();
+      if (tid < MIDAS_STATS) {
+        const unsigned long long v = s_stats[tid];
+        if (v) atomicAdd(&p.stats[(size_t)tile.species * MIDAS_STATS + tid], v);
+        s_stats[tid] = 0ull;
+      }
+      if (!more) {
+        if (dynamic && tid == 0) {   // the last workgroup to leave rewinds the counters for the next launch
+          if (atomicAdd(&sched[32 * kSchedGroups], 1u) == gridDim.x - 1u) {
+            for (int k = 0; k <= kSchedGroups; ++k) sched[32 * k] = 0u;
+          }
+        }
+        break;
+      }
+      lds_barrier();     // s_stats reset before the next tile adds to it
+    }
+    w = wn;
+    t = tn;
+    tile = ntile;
+    st = nst;
+  }
+#if MIDAS_SNPS_DEBUG_BITS & 256
+  if (lane == 0 && p.probe) {      // per wave: cycles waiting for columns / bases, working, at the barrier, writing out; iterations; all
+    unsigned long long* o = p.probe + ((size_t)blockIdx.x * NWAVES + wave) * 8;
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+    o[0] = pr_cols; o[1] = (unsigned long long)hw_id | ((unsigned long long)xcc_id << 32); o[2] = pr_work; o[3] = pr_sync; o[4] = pr_out; o[5] = pr_iters;
+    o[6] = __builtin_readcyclecounter() - pr_t0; o[7] = 0ull;
+  }
+#endif
+#undef PROBE_NOW
+}
+
+}  // namespace
+
+int direct_lane_bases(int32_t max_l_seq) {
+  // 30 bases per lane: the lanes of a read start 120 tally dwords apart and spread over the LDS banks; 32 only where it
+  // saves a whole lane per read (151 bp: 5 lanes instead of 6)
+  const int l = max_l_seq > 0 ? max_l_seq : 1;
+  return (l + 31) / 32 < (l + 29) / 30 ? 32 : 30;
+}
+
+hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t stream) {
+  if (p.n_tiles <= 0) return hipSuccess;
+  const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
+  const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
+  const bool bq0 = p.baseq <= 0;
+  if (lane_bases == 32) {
+    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+  } else {
+    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<30, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    else hipLaunchKernelGGL((pileup_direct_kernel<30, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace midas
