@@ -561,6 +561,21 @@ int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thresholds* thr,
                           const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length, int64_t* out_aligned,
                           int64_t* out_mapped, double* out_depth, float* out_kernel_ms);
 
+/* The two halves of midas_genes_count, for N ranks below the species (midas_amd/run/genes.py): a gene's running fp64 sum has
+ * to be formed in BAM order on ONE rank, so every rank turns ITS slice of the unsorted BAM into terms, the (gene, term) pairs
+ * travel to the gene's owner (one all-to-all; the slices are in file order, so are the pairs a rank receives), and the owner sums.
+ *   midas_genes_terms: out_term[i] = len(query_alignment_sequence) / float(gene_length[ref_id[i]]) for a read keep_read
+ *     passes, +0.0 for one it drops (adding it leaves a running sum unchanged bit for bit: the pair still counts as an
+ *     alignment of its gene).  Statuses and midas_snps_last_error_read as midas_genes_count (the read index is the slice's).
+ *   midas_genes_sum: the pairs (gene[i] in [0, n_genes), term[i]), in the order their reads have in the BAM -> per gene
+ *     the number of pairs (aligned_reads), of pairs with a term above zero (mapped_reads) and their sum in that order.
+ * midas_genes_count(reads) == midas_genes_sum(ref_id, midas_genes_terms(reads)) bit for bit (tests/test_gpu_genes.py).     */
+int32_t midas_genes_terms(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads,
+                          const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length, double* out_term,
+                          float* out_kernel_ms);
+int32_t midas_genes_sum(midas_snps_ctx* ctx, int64_t n_pairs, const int32_t* gene, const double* term, int64_t n_genes,
+                        int64_t* out_aligned, int64_t* out_mapped, double* out_depth, float* out_kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,6 +281,8 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_table_key_bytes': (i64, [vp]),
         'midas_snps_table_copy': (i32, [vp, vp, vp, vp]),
         'midas_genes_count': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Reads), vp, i64, vp, vp, vp, vp, C.POINTER(C.c_float)]),
+        'midas_genes_terms': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Reads), vp, i64, vp, vp, C.POINTER(C.c_float)]),
+        'midas_genes_sum': (i32, [vp, i64, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_float)]),
         'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 5 + [C.POINTER(C.c_float)]),
     })
     for name, (res, args) in sig.items():
@@ -311,7 +313,8 @@ EXPORTED_SYMBOLS = [
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
-    'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_merge_write_info', 'midas_merge_write_matrix',
+    'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_genes_terms', 'midas_genes_sum', 'midas_merge_write_info',
+    'midas_merge_write_matrix',
 ]
 
 
@@ -840,6 +843,30 @@ class Context:
                                          C.byref(ms))
         self._check(st)
         return aligned, mapped, depth, float(ms.value)
+
+    def genes_terms(self, thr: Thresholds, reads: "ReadsSoA", ref_id, gene_length):
+        """midas_genes_terms(): per read of a slice its term (f64; +0.0 for a read keep_read drops)."""
+        rid = np.ascontiguousarray(ref_id, dtype=np.int32)
+        gl = np.ascontiguousarray(gene_length, dtype=np.int64)
+        term = np.zeros(int(reads.n_reads), np.float64)
+        ms = C.c_float(0)
+        r = reads._c()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_genes_terms(self._h, C.byref(thr), C.byref(r), p(rid), gl.shape[0], p(gl), p(term), C.byref(ms))
+        self._check(st)
+        return term
+
+    def genes_sum(self, gene, term, n_genes):
+        """midas_genes_sum(): (gene, term) pairs in BAM order -> per gene (aligned_reads i64, mapped_reads i64, depth f64)."""
+        g = np.ascontiguousarray(gene, dtype=np.int32)
+        t = np.ascontiguousarray(term, dtype=np.float64)
+        n = int(n_genes)
+        aligned, mapped, depth = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float64)
+        ms = C.c_float(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = self._lib.midas_genes_sum(self._h, g.shape[0], p(g), p(t), n, p(aligned), p(mapped), p(depth), C.byref(ms))
+        self._check(st)
+        return aligned, mapped, depth
 
     def merge_sites(self, prm: "MergeParams", sample_counts, mean_depth):
         """midas_merge_sites(): sample_counts = list of [n_sites,4] uint32 arrays (one per sample).

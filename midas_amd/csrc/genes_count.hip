@@ -9,13 +9,17 @@
 //   filter  one thread per read, BAM order: keep_read with the exceptions the reference would raise (lowest read
 //           index wins), and the read's term  align_len / float(gene.length)  (+0.0 for a read that is dropped:
 //           adding it leaves the running sum unchanged bit for bit);
-//   sort    stable LSD radix sort of (gene, term) pairs by gene (hipCUB): BAM order survives inside a gene;
+//   sort    stable LSD radix sort of (gene, term) pairs by gene, eight bits of the gene index a pass (the kernels below: a
+//           gene index has as many bits as the pangenome has genes, nothing else is sorted here): BAM order survives inside a gene;
 //   bounds  first sorted position of every gene;
 //   sum     one thread per gene adds its terms one after the other (a gene with many reads: one wave stages 512
 //           terms at a time in LDS and adds them in the same order).
 // Genes are independent, so the device parallelism of the last step is over genes (10^5 - 10^6 per sample).
+//
+// N ranks (run/genes.py): the two halves are entry points of their own -- midas_genes_terms (host + filter: a rank's slice of
+// the BAM -> one term per read) and midas_genes_sum (sort + bounds + sum over the pairs a gene's owner received, which arrive
+// in BAM order) -- so that a gene's running sum is formed on ONE rank in the order the reference forms it.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -81,6 +85,132 @@ __global__ __launch_bounds__(256) void genes_bounds_kernel(const uint32_t* key, 
   const long long prev = i == 0 ? -1 : (long long)key[i - 1];
   const long long cur = i == n ? n_genes : (long long)key[i];
   for (long long g = prev + 1; g <= cur; ++g) begin[g] = i;
+}
+
+// ---- stable LSD radix sort of (gene, term) pairs, eight bits of the key a pass -------------------------------------------------
+// A workgroup owns kSortBlock consecutive pairs, each of its four waves a quarter of them, taken 64 at a time: the order of
+// equal digits is (workgroup, wave, round, lane) = the input order.
+//   hist     per workgroup the number of keys of every digit            -> hist[digit][workgroup]
+//   scan     exclusive scan over hist in that (digit-major) order       -> where a workgroup's keys of a digit go
+//   scatter  a wave finds, per round, the lanes that share a lane's digit (eight ballots), ranks the lane among them and
+//            moves its pair to the digit's cursor of the wave (LDS), which the lowest of those lanes then advances
+constexpr int kSortThreads = 256, kSortWaves = kSortThreads / 64, kSortRounds = 16;
+constexpr int kSortBlock = kSortThreads * kSortRounds;      // 4096 pairs
+
+__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t* key, long long n, int shift, uint32_t* hist, uint32_t n_blocks) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kSortBlock;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long i = base + (long long)r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup: exclusive scan of m counters, 4096 at a time with a running carry
+__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* v, long long m) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long t0 = 0; t0 < m; t0 += 4096) {
+    const long long i = t0 + 4ll * threadIdx.x;
+    uint32_t a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = i + k < m ? v[i + k] : 0u;
+    const uint32_t mine = a[0] + a[1] + a[2] + a[3];
+    uint32_t inc = mine;                                   // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    uint32_t run = before + inc - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < m) v[i + k] = run;
+      run += a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = run;                // (the last thread's running total is the tile's)
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t* key, const double* term, long long n, int shift,
+                                                                     const uint32_t* hist, uint32_t n_blocks, uint32_t* key_out, double* term_out) {
+  __shared__ uint32_t cursor[kSortWaves][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < kSortWaves * 256; d += kSortThreads) (&cursor[0][0])[d] = 0u;
+  __syncthreads();
+  // the wave's own counts per digit ...
+  const long long wbase = (long long)blockIdx.x * kSortBlock + (long long)wave * (kSortBlock / kSortWaves);
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long i = wbase + (long long)r * 64 + lane;
+    if (i < n) atomicAdd(&cursor[wave][(key[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  // ... become where its keys of a digit start: the workgroup's place for the digit + the waves in front
+  {
+    const int d = threadIdx.x;       // 256 threads, 256 digits
+    uint32_t at = hist[(size_t)d * n_blocks + blockIdx.x];
+    for (int w = 0; w < kSortWaves; ++w) {
+      const uint32_t c = cursor[w][d];
+      cursor[w][d] = at;
+      at += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long i = wbase + (long long)r * 64 + lane;
+    const bool live = i < n;
+    const uint32_t k = live ? key[i] : 0u;
+    const uint32_t d = (k >> shift) & 255u;
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long has = __ballot(live && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? has : ~has;
+    }
+    if (live) {
+      const uint32_t at = cursor[wave][d] + (uint32_t)__popcll(peers & below);
+      key_out[at] = k;
+      term_out[at] = term[i];
+    }
+    // (LDS operations of one wave are carried out in order: every lane has read the cursor before its lowest peer moves it,
+    // and the next round reads what this one wrote)
+    if (live && (peers & below) == 0ull) cursor[wave][d] += (uint32_t)__popcll(peers);
+  }
+}
+
+// `bits` low bits of the keys decide (they are below 2^bits).  The sorted pairs end up in (*key_sorted, *term_sorted): one of
+// the two buffer pairs.  hist: 256 * ceil(n / kSortBlock) counters.
+hipError_t sort_pairs(uint32_t* key_a, double* term_a, uint32_t* key_b, double* term_b, long long n, int bits, uint32_t* hist,
+                      hipStream_t s, uint32_t** key_sorted, double** term_sorted) {
+  uint32_t* kin = key_a; double* tin = term_a; uint32_t* kout = key_b; double* tout = term_b;
+  const uint32_t n_blocks = (uint32_t)((n + kSortBlock - 1) / kSortBlock);
+  for (int shift = 0; shift < bits && n > 0; shift += 8) {
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(kSortThreads), 0, s, kin, n, shift, hist, n_blocks);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 256ll * n_blocks);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_blocks), dim3(kSortThreads), 0, s, kin, tin, n, shift, hist, n_blocks, kout, tout);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    std::swap(kin, kout);
+    std::swap(tin, tout);
+  }
+  *key_sorted = kin;
+  *term_sorted = tin;
+  return hipSuccess;
 }
 
 struct SumKParams {
@@ -184,11 +314,25 @@ void host_ranges(int64_t n, F&& fn) {
 
 using namespace midas;
 
+namespace {
+
+// The device buffers of one call; freed when it goes out of scope.
+struct DevBufs {
+  std::vector<void*> ptrs;
+  ~DevBufs() { for (void* q : ptrs) (void)hipFree(q); }
+  template <class T> hipError_t get(T** out, size_t bytes) {
+    void* q = nullptr;
+    const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e == hipSuccess) ptrs.push_back(q);
+    *out = static_cast<T*>(q);
+    return e;
+  }
+};
+
 #define G_TRY(call)                                                                                              \
   do {                                                                                                           \
     hipError_t e__ = (call);                                                                                     \
     if (e__ != hipSuccess) {                                                                                     \
-      for (void* q__ : dev_ptrs) (void)hipFree(q__);                                                             \
       char buf__[384];                                                                                           \
       snprintf(buf__, sizeof buf__, "%s: %s", #call, hipGetErrorString(e__));                                    \
       (void)hipGetLastError();                                                                                   \
@@ -196,20 +340,11 @@ using namespace midas;
     }                                                                                                            \
   } while (0)
 
-extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads,
-                                     const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length,
-                                     int64_t* out_aligned, int64_t* out_mapped, double* out_depth, float* out_kernel_ms) {
-  if (!ctx || !thr || !reads || n_genes < 0 || reads->n_reads < 0 || (n_genes > 0 && (!gene_length || !out_aligned || !out_mapped || !out_depth)) ||
-      (reads->n_reads > 0 && (!ref_id || !reads->mapq || !reads->nm || !reads->l_seq || !reads->qual_off || !reads->cigar_off ||
-                              !reads->qual || !reads->cigar)))
-    return MIDAS_SNPS_ERR_INVALID_ARG;
-  ctx->clear_error();
-  ctx->err_read = -1;
-  if (out_kernel_ms) *out_kernel_ms = 0.f;
+// host: per read, the numbers keep_read looks at (all cores).  0, or the status of the first malformed read in BAM order.
+int32_t pack_records(midas_snps_ctx* ctx, const midas_snps_reads* reads, const int32_t* ref_id, int64_t n_genes, std::vector<uint2>* recs,
+                     int32_t* max_l_out) {
   const int64_t n = reads->n_reads;
-  if (n > 0x7FFFFFFFll || n_genes > 0x7FFFFFFFll) return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "more than 2^31-1 reads or genes");
-  // ---- host: per read, the numbers keep_read looks at (all cores) ------------------------------------------------
-  std::vector<uint2> recs((size_t)n);
+  recs->resize((size_t)n);
   std::atomic<int64_t> bad_ref{INT64_MAX}, bad_layout{INT64_MAX}, bad_size{INT64_MAX};
   std::atomic<int32_t> max_l_all{0};
   auto lower = [](std::atomic<int64_t>& a, int64_t v) {
@@ -248,78 +383,122 @@ extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thres
       const uint32_t flags = (l == 0 ? kNoSeq : 0u) | (reads->nm[i] < 0 ? kNoNm : 0u) | ((l > 0 && q[0] == 0xFF) ? kNoQual : 0u);
       const uint32_t nm = (uint32_t)(reads->nm[i] < 0 ? 0 : reads->nm[i]);
       const uint32_t qmean = l > 0 ? qsum / (uint32_t)l : 0u;
-      recs[(size_t)i] = make_uint2((uint32_t)al | ((uint32_t)l << 11) | (flags << 22), nm | (qmean << 16) | ((uint32_t)reads->mapq[i] << 24));
+      (*recs)[(size_t)i] = make_uint2((uint32_t)al | ((uint32_t)l << 11) | (flags << 22), nm | (qmean << 16) | ((uint32_t)reads->mapq[i] << 24));
       max_l = std::max<int32_t>(max_l, (int32_t)l);
     }
     int32_t cur = max_l_all.load();
     while (max_l > cur && !max_l_all.compare_exchange_weak(cur, max_l)) {}
   });
-  {
-    // the first malformed read in BAM order decides, as a single forward pass would
-    const int64_t first = std::min(bad_ref.load(), std::min(bad_layout.load(), bad_size.load()));
-    if (first != INT64_MAX) {
-      ctx->err_read = first;
-      char buf[200];
-      if (first == bad_ref.load()) {
-        snprintf(buf, sizeof buf, "read %lld: reference id %lld is not a gene of the pangenome (the reference fails in getrname / genes[...])",
-                 (long long)first, (long long)ref_id[first]);
-        return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, buf);
-      }
-      if (first == bad_layout.load()) return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative size or CSR offsets shorter than l_seq");
-      return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "l_seq > 1024 or NM > 65534 is not supported");
-    }
+  *max_l_out = max_l_all.load();
+  // the first malformed read in BAM order decides, as a single forward pass would
+  const int64_t first = std::min(bad_ref.load(), std::min(bad_layout.load(), bad_size.load()));
+  if (first == INT64_MAX) return MIDAS_SNPS_OK;
+  ctx->err_read = first;
+  char buf[200];
+  if (first == bad_ref.load()) {
+    snprintf(buf, sizeof buf, "read %lld: reference id %lld is not a gene of the pangenome (the reference fails in getrname / genes[...])",
+             (long long)first, (long long)ref_id[first]);
+    return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, buf);
   }
+  if (first == bad_layout.load()) return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative size or CSR offsets shorter than l_seq");
+  return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "l_seq > 1024 or NM > 65534 is not supported");
+}
+
+int32_t raise_status(midas_snps_ctx* ctx, unsigned long long err) {
+  const int32_t kind = (int32_t)(err & 0xFF);
+  ctx->err_read = (int64_t)(err >> 8);
+  char buf[200];
+  snprintf(buf, sizeof buf, "read %lld: keep_read would raise (%s)", (long long)ctx->err_read,
+           kind == 1 ? "no SEQ: TypeError" : kind == 2 ? "no NM tag: KeyError" : kind == 3 ? "aligned length 0: ZeroDivisionError"
+                                                                                              : "no QUAL: TypeError");
+  ctx->set_error(buf);
+  return kind;
+}
+
+// One call, either half or both.  reads != nullptr: the terms are made here (host records + filter kernel) from the reads and
+// their genes `gene` (= ref_id); else `term_in` holds them.  out_term != nullptr: they are handed back (and, with no sums asked
+// for, that is all).  out_aligned != nullptr: sort + bounds + sums.
+int32_t genes_run(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads, int64_t n, const int32_t* gene,
+                  const double* term_in, int64_t n_genes, const int64_t* gene_length, double* out_term, int64_t* out_aligned,
+                  int64_t* out_mapped, double* out_depth, float* out_kernel_ms) {
+  ctx->clear_error();
+  ctx->err_read = -1;
+  if (out_kernel_ms) *out_kernel_ms = 0.f;
+  if (n > 0x7FFFFFFFll || n_genes > 0x7FFFFFFFll) return gfail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "more than 2^31-1 reads or genes");
+  const bool filter = reads != nullptr, sums = out_aligned != nullptr;
+  std::vector<uint2> recs;
   FilterTables ft;
   memset(&ft, 0, sizeof ft);
-  build_filter_tables(thr->mapid, thr->aln_cov, max_l_all.load(), &ft);
+  if (filter) {
+    int32_t max_l = 0;
+    const int32_t st = pack_records(ctx, reads, gene, n_genes, &recs, &max_l);
+    if (st != MIDAS_SNPS_OK) return st;
+    build_filter_tables(thr->mapid, thr->aln_cov, max_l, &ft);
+  } else {
+    for (int64_t i = 0; i < n; ++i)
+      if (gene[i] < 0 || gene[i] >= n_genes) {
+        ctx->err_read = i;
+        return gfail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "a pair's gene index is outside the gene table");
+      }
+  }
   // ---- device ------------------------------------------------------------------------------------------------------
-  std::vector<void*> dev_ptrs;
+  DevBufs dev;
   G_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const size_t ng = (size_t)(n_genes > 0 ? n_genes : 1), nr = (size_t)(n > 0 ? n : 1);
-  uint2* d_recs = nullptr; uint32_t* d_key = nullptr; uint32_t* d_key_sorted = nullptr; double* d_term = nullptr; double* d_term_sorted = nullptr;
+  const size_t n_sort_blocks = (nr + kSortBlock - 1) / kSortBlock;
+  uint2* d_recs = nullptr; uint32_t* d_key = nullptr; uint32_t* d_key_b = nullptr; double* d_term = nullptr; double* d_term_b = nullptr;
   int64_t* d_len = nullptr; FilterTables* d_ft = nullptr; long long* d_begin = nullptr; long long* d_al = nullptr; long long* d_mp = nullptr;
-  double* d_dp = nullptr; unsigned long long* d_err = nullptr; unsigned int* d_heavy = nullptr; void* d_tmp = nullptr;
-  G_TRY(hipMalloc(&d_recs, nr * sizeof(uint2))); dev_ptrs.push_back(d_recs);
-  G_TRY(hipMalloc(&d_key, nr * 4)); dev_ptrs.push_back(d_key);
-  G_TRY(hipMalloc(&d_key_sorted, nr * 4)); dev_ptrs.push_back(d_key_sorted);
-  G_TRY(hipMalloc(&d_term, nr * 8)); dev_ptrs.push_back(d_term);
-  G_TRY(hipMalloc(&d_term_sorted, nr * 8)); dev_ptrs.push_back(d_term_sorted);
-  G_TRY(hipMalloc(&d_len, ng * 8)); dev_ptrs.push_back(d_len);
-  G_TRY(hipMalloc(&d_ft, sizeof(FilterTables))); dev_ptrs.push_back(d_ft);
-  G_TRY(hipMalloc(&d_begin, (ng + 1) * 8)); dev_ptrs.push_back(d_begin);
-  G_TRY(hipMalloc(&d_al, ng * 8)); dev_ptrs.push_back(d_al);
-  G_TRY(hipMalloc(&d_mp, ng * 8)); dev_ptrs.push_back(d_mp);
-  G_TRY(hipMalloc(&d_dp, ng * 8)); dev_ptrs.push_back(d_dp);
-  G_TRY(hipMalloc(&d_err, 16)); dev_ptrs.push_back(d_err);
-  G_TRY(hipMalloc(&d_heavy, (ng + 1) * 4)); dev_ptrs.push_back(d_heavy);
+  double* d_dp = nullptr; unsigned long long* d_err = nullptr; unsigned int* d_heavy = nullptr; uint32_t* d_hist = nullptr;
+  G_TRY(dev.get(&d_key, nr * 4));
+  G_TRY(dev.get(&d_term, nr * 8));
+  G_TRY(dev.get(&d_err, 16));
+  if (filter) {
+    G_TRY(dev.get(&d_recs, nr * sizeof(uint2)));
+    G_TRY(dev.get(&d_len, ng * 8));
+    G_TRY(dev.get(&d_ft, sizeof(FilterTables)));
+  }
+  if (sums) {
+    G_TRY(dev.get(&d_key_b, nr * 4));
+    G_TRY(dev.get(&d_term_b, nr * 8));
+    G_TRY(dev.get(&d_hist, n_sort_blocks * 256 * 4));
+    G_TRY(dev.get(&d_begin, (ng + 1) * 8));
+    G_TRY(dev.get(&d_al, ng * 8));
+    G_TRY(dev.get(&d_mp, ng * 8));
+    G_TRY(dev.get(&d_dp, ng * 8));
+    G_TRY(dev.get(&d_heavy, (ng + 1) * 4));
+  }
   int key_bits = 1;
   while (key_bits < 32 && ((int64_t)1 << key_bits) < n_genes) ++key_bits;
-  size_t tmp_bytes = 0;
-  G_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key_sorted, d_term, d_term_sorted, (int)n, 0, key_bits, s));
-  G_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16)); dev_ptrs.push_back(d_tmp);
   if (n > 0) {
-    G_TRY(hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, s));
-    G_TRY(hipMemcpyAsync(d_key, ref_id, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_key, gene, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (filter) G_TRY(hipMemcpyAsync(d_recs, recs.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, s));
+    else G_TRY(hipMemcpyAsync(d_term, term_in, (size_t)n * 8, hipMemcpyHostToDevice, s));
   }
-  if (n_genes > 0) G_TRY(hipMemcpyAsync(d_len, gene_length, (size_t)n_genes * 8, hipMemcpyHostToDevice, s));
-  G_TRY(hipMemcpyAsync(d_ft, &ft, sizeof ft, hipMemcpyHostToDevice, s));
+  if (filter) {
+    if (n_genes > 0) G_TRY(hipMemcpyAsync(d_len, gene_length, (size_t)n_genes * 8, hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_ft, &ft, sizeof ft, hipMemcpyHostToDevice, s));
+  }
   G_TRY(hipMemsetAsync(d_err, 0xFF, 8, s));
-  G_TRY(hipMemsetAsync(d_heavy, 0, 4, s));
+  if (sums) G_TRY(hipMemsetAsync(d_heavy, 0, 4, s));
   hipEvent_t e0, e1;
   G_TRY(hipEventCreate(&e0));
   G_TRY(hipEventCreate(&e1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
   unsigned long long err = ~0ull;
-  if (n_genes > 0) {
-    G_TRY(hipEventRecord(e0, s));
-    if (n > 0) {
-      FilterKParams f;
-      f.rec = d_recs; f.gene = d_key; f.gene_len = d_len; f.filt = d_ft; f.term = d_term; f.err = d_err; f.n = n;
-      f.mapq = thr->mapq; f.readq = thr->readq;
-      hipLaunchKernelGGL(genes_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f);
-      G_TRY(hipGetLastError());
-      G_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key_sorted, d_term, d_term_sorted, (int)n, 0, key_bits, s));
-    }
+  G_TRY(hipEventRecord(e0, s));
+  if (filter && n > 0) {
+    FilterKParams f;
+    f.rec = d_recs; f.gene = d_key; f.gene_len = d_len; f.filt = d_ft; f.term = d_term; f.err = d_err; f.n = n;
+    f.mapq = thr->mapq; f.readq = thr->readq;
+    hipLaunchKernelGGL(genes_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f);
+    G_TRY(hipGetLastError());
+  }
+  if (out_term && n > 0) G_TRY(hipMemcpyAsync(out_term, d_term, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (sums && n_genes > 0) {
+    uint32_t* d_key_sorted = d_key;
+    double* d_term_sorted = d_term;
+    G_TRY(sort_pairs(d_key, d_term, d_key_b, d_term_b, n, key_bits, d_hist, s, &d_key_sorted, &d_term_sorted));
     hipLaunchKernelGGL(genes_bounds_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_key_sorted, (long long)n,
                        (long long)n_genes, d_begin);
     G_TRY(hipGetLastError());
@@ -338,24 +517,50 @@ extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thres
     G_TRY(hipMemcpyAsync(out_aligned, d_al, (size_t)n_genes * 8, hipMemcpyDeviceToHost, s));
     G_TRY(hipMemcpyAsync(out_mapped, d_mp, (size_t)n_genes * 8, hipMemcpyDeviceToHost, s));
     G_TRY(hipMemcpyAsync(out_depth, d_dp, (size_t)n_genes * 8, hipMemcpyDeviceToHost, s));
-    G_TRY(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, s));
-    G_TRY(hipStreamSynchronize(s));
-    float ms = 0.f;
-    G_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (out_kernel_ms) *out_kernel_ms = ms;
+  } else {
+    G_TRY(hipEventRecord(e1, s));
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  for (void* q : dev_ptrs) (void)hipFree(q);
-  if (err != ~0ull) {
-    const int32_t kind = (int32_t)(err & 0xFF);
-    ctx->err_read = (int64_t)(err >> 8);
-    char buf[200];
-    snprintf(buf, sizeof buf, "read %lld: keep_read would raise (%s)", (long long)ctx->err_read,
-             kind == 1 ? "no SEQ: TypeError" : kind == 2 ? "no NM tag: KeyError" : kind == 3 ? "aligned length 0: ZeroDivisionError"
-                                                                                                : "no QUAL: TypeError");
-    ctx->set_error(buf);
-    return kind;
-  }
+  G_TRY(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, s));
+  G_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  G_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (out_kernel_ms) *out_kernel_ms = ms;
+  if (err != ~0ull) return raise_status(ctx, err);
   return MIDAS_SNPS_OK;
+}
+
+bool reads_ok(const midas_snps_reads* reads, const int32_t* ref_id) {
+  return reads && reads->n_reads >= 0 &&
+         (reads->n_reads == 0 || (ref_id && reads->mapq && reads->nm && reads->l_seq && reads->qual_off && reads->cigar_off && reads->qual && reads->cigar));
+}
+
+}  // namespace
+
+extern "C" int32_t midas_genes_count(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads,
+                                     const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length,
+                                     int64_t* out_aligned, int64_t* out_mapped, double* out_depth, float* out_kernel_ms) {
+  if (!ctx || !thr || n_genes < 0 || !reads_ok(reads, ref_id) || (n_genes > 0 && (!gene_length || !out_aligned || !out_mapped || !out_depth)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  int64_t dummy_a = 0, dummy_m = 0;
+  double dummy_d = 0.0;
+  return genes_run(ctx, thr, reads, reads->n_reads, ref_id, nullptr, n_genes, gene_length, nullptr, n_genes > 0 ? out_aligned : &dummy_a,
+                   n_genes > 0 ? out_mapped : &dummy_m, n_genes > 0 ? out_depth : &dummy_d, out_kernel_ms);
+}
+
+extern "C" int32_t midas_genes_terms(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const midas_snps_reads* reads,
+                                     const int32_t* ref_id, int64_t n_genes, const int64_t* gene_length, double* out_term,
+                                     float* out_kernel_ms) {
+  if (!ctx || !thr || n_genes < 0 || !reads_ok(reads, ref_id) || (n_genes > 0 && !gene_length) || (reads->n_reads > 0 && !out_term))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  return genes_run(ctx, thr, reads, reads->n_reads, ref_id, nullptr, n_genes, gene_length, out_term, nullptr, nullptr, nullptr, out_kernel_ms);
+}
+
+extern "C" int32_t midas_genes_sum(midas_snps_ctx* ctx, int64_t n_pairs, const int32_t* gene, const double* term, int64_t n_genes,
+                                   int64_t* out_aligned, int64_t* out_mapped, double* out_depth, float* out_kernel_ms) {
+  if (!ctx || n_pairs < 0 || n_genes < 0 || (n_pairs > 0 && (!gene || !term)) || (n_genes > 0 && (!out_aligned || !out_mapped || !out_depth)))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
+  int64_t dummy_a = 0, dummy_m = 0;
+  double dummy_d = 0.0;
+  return genes_run(ctx, nullptr, nullptr, n_pairs, gene, term, n_genes, nullptr, nullptr, n_genes > 0 ? out_aligned : &dummy_a,
+                   n_genes > 0 ? out_mapped : &dummy_m, n_genes > 0 ? out_depth : &dummy_d, out_kernel_ms);
 }

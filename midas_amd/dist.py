@@ -163,6 +163,36 @@ def all_gather_rows_f64(rows):
     return out.reshape((ws,) + tuple(t.shape)).sum(dim=0).cpu().numpy()
 
 
+def all_to_all_v(parts):
+    """parts: one 1-D array per rank (same dtype everywhere), parts[r] goes to rank r -> the arrays received, by source rank.
+    One exchange of the counts (all-gather), then one all_to_all_single with uneven splits (RCCL on GPUs, gloo on CPUs)."""
+    rank, ws = world()
+    parts = [np.ascontiguousarray(p) for p in parts]
+    assert len(parts) == ws
+    if ws == 1:
+        return [parts[0].copy()]
+    import torch
+    import torch.distributed as dist
+    dtype = parts[0].dtype
+    counts = all_gather_i64(np.array([p.size for p in parts], np.int64))        # counts[src, dst]
+    send_n = [int(x) for x in counts[rank]]
+    recv_n = [int(x) for x in counts[:, rank]]
+    # (as bytes: every dtype travels the same way)
+    send = torch.from_numpy(np.concatenate(parts).view(np.uint8) if sum(send_n) else np.zeros(0, np.uint8))
+    isz = dtype.itemsize
+    on_gpu = dist.get_backend() == "nccl"
+    if on_gpu:
+        send = send.cuda()
+    recv = torch.empty(sum(recv_n) * isz, dtype=torch.uint8, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[n * isz for n in recv_n], input_split_sizes=[n * isz for n in send_n])
+    got = recv.cpu().numpy().view(dtype)
+    out, at = [], 0
+    for n in recv_n:
+        out.append(got[at:at + n].copy())
+        at += n
+    return out
+
+
 def barrier():
     if _alone():
         return

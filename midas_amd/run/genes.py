@@ -169,20 +169,114 @@ def fold_counts(species, genes, gene_ids, aligned, mapped, depth):
         sp.fraction_covered = sp.covered_genes / float(sp.pangenome_size)
 
 
-def count_mapped_bp(args, species, genes, ctx, mine=None):
-    """genes.py:165-199 with the BAM pass on the device: native BAM decode, one midas_genes_count call.  `mine` (N > 1):
-    the species this rank owns -- only reads on their genes are counted here."""
+def _missing_gene_check(ref_names, refid, genes):
+    """The reference: KeyError in genes[bamfile.getrname(...)] at the first read of a gene the database does not have."""
+    if all(n in genes for n in ref_names):
+        return
+    used = set(np.unique(refid).tolist())
+    bad = [n for i, n in enumerate(ref_names) if n not in genes and i in used]
+    if bad:
+        sys.exit("\nError: gene '%s' of the BAM header is not in the pangenome database\n" % bad[0])
+
+
+def _thresholds(args):
+    return abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **{k: args[k] for k in ('mapid', 'readq', 'mapq', 'aln_cov')}))
+
+
+def _slices_chain(bam_path, rank, ws):
+    """Every rank walks its share of the (unsorted) BAM's bytes; the slices are accepted if they chain: slice 0 starts at the
+    header's end, every slice ends where the next one starts (a guessed record boundary is confirmed by a walk that began at
+    an exact one), the last ends with the file.  -> this rank's slice, or None (every rank then decodes the whole file)."""
+    error, sl = None, None
+    try:
+        sl = abi.BamSlice(bam_path, rank, ws)
+    except abi.MidasSnpsError as e:
+        error = "\nError: could not read %s\n%s\n" % (bam_path, e.message)
+    dist.agree_or_exit(error)
+    head = dist.all_gather_i64(np.array([sl.first, sl.end, sl.rec_begin, sl.total, len(sl.ref_names)], np.int64))
+    ok = bool((head[:, 4] == head[0, 4]).all() and head[0, 0] == head[0, 2] and head[-1, 1] == head[0, 3])
+    for r in range(ws - 1):
+        ok = ok and head[r, 1] == head[r + 1, 0]
+    if not ok:
+        sl.close()
+        return None
+    return sl
+
+
+def _count_below_the_species(args, species, genes, ctx, mine, owner, sl):
+    """N ranks, genes.py:165-199 below the species: a rank decodes ITS slice of the unsorted BAM and turns every read into a
+    term (midas_genes_terms); the (gene, term) pairs go to the rank that owns the gene's species -- one all-to-all, and since the
+    slices are in file order the pairs a rank receives, taken by source rank, are too -- and the owner adds a gene's terms up
+    in that order (midas_genes_sum): the reference's running fp64 sum, bit for bit, with no rank decoding the whole file."""
+    rank, ws = dist.world()
     bam_path = os.path.join(args['outdir'], 'genes', 'temp', 'pangenomes.bam')
+    error, refid, reads, term = None, None, None, None
+    ref_names = sl.ref_names
+    try:
+        refid, reads = sl.load_ranges([(sl.first, sl.end)])
+        _missing_gene_check(ref_names, refid, genes)
+    except abi.MidasSnpsError as e:
+        error = "\nError: could not read %s\n%s\n" % (bam_path, e.message)
+    except SystemExit as e:
+        error = dist.exit_message(e)
+    dist.agree_or_exit(error)
+    n_local = int(reads.n_reads)
+    per_rank = dist.all_gather_i64([n_local])[:, 0]
+    base = int(per_rank[:rank].sum())                 # this slice's first read in the BAM
+    if rank == 0:
+        line = "rank-local BAM decode (genes): %d slices chained, %d records; records decoded per rank: %s" % (
+            ws, int(per_rank.sum()), ' '.join(str(int(x)) for x in per_rank))
+        print("  " + line)
+        if args.get('log') is not None:
+            args['log'].write(line + "\n")
+    lengths = np.array([genes[n].length if n in genes else sl.ref_lens[i] for i, n in enumerate(ref_names)], dtype=np.int64)
+    try:
+        term = ctx.genes_terms(_thresholds(args), reads, refid, lengths)
+    except abi.MidasSnpsError as e:
+        where = " [read %d of the BAM]" % (e.read_index + base) if e.read_index >= 0 else ""
+        error = "\nError: %s%s\n" % (e.message, where)
+    dist.agree_or_exit(error)
+    # gene (header index) -> the rank that owns its species; -1: not in the database (no read is on such a gene, checked above)
+    ref_owner = np.array([owner[genes[n].species_id] if n in genes else -1 for n in ref_names], dtype=np.int64)
+    dest = ref_owner[refid] if n_local else np.zeros(0, np.int64)
+    order = np.argsort(dest, kind='stable')           # (stable: file order survives inside a destination)
+    cuts = np.searchsorted(dest[order], np.arange(ws + 1))
+    g_parts = [refid[order[cuts[r]:cuts[r + 1]]].astype(np.int32) for r in range(ws)]
+    t_parts = [term[order[cuts[r]:cuts[r + 1]]] for r in range(ws)]
+    got_g = np.concatenate(dist.all_to_all_v(g_parts))
+    got_t = np.concatenate(dist.all_to_all_v(t_parts))
+    # this rank's genes, renumbered
+    gene_ids = [n for n in ref_names if n in genes and genes[n].species_id in mine]
+    local = np.full(len(ref_names), -1, dtype=np.int64)
+    local[[i for i, n in enumerate(ref_names) if n in genes and genes[n].species_id in mine]] = np.arange(len(gene_ids))
+    try:
+        aligned, mapped, depth = ctx.genes_sum(local[got_g], got_t, len(gene_ids))
+    except abi.MidasSnpsError as e:
+        error = "\nError: %s\n" % e.message
+    dist.agree_or_exit(error)
+    fold_counts(species, genes, gene_ids, aligned, mapped, depth)
+    print("  total aligned reads: %s" % sum(sp.aligned_reads for sp in species.values()))
+    print("  total mapped reads: %s" % sum(sp.mapped_reads for sp in species.values()))
+    return 0.0
+
+
+def count_mapped_bp(args, species, genes, ctx, mine=None, owner=None):
+    """genes.py:165-199 with the BAM pass on the device: native BAM decode, one midas_genes_count call.  `mine` (N > 1):
+    the species this rank owns -- only reads on their genes are counted here; with `owner` (species -> rank) and a BAM whose
+    slices chain, every rank decodes only its slice (_count_below_the_species)."""
+    bam_path = os.path.join(args['outdir'], 'genes', 'temp', 'pangenomes.bam')
+    if mine is not None and owner is not None and hasattr(ctx, 'genes_terms'):
+        sl = _slices_chain(bam_path, *dist.world())
+        if sl is not None:
+            try:
+                return _count_below_the_species(args, species, genes, ctx, mine, owner, sl)
+            finally:
+                sl.close()
     try:
         ref_names, ref_lens, refid, reads = abi.read_bam(bam_path)
     except abi.MidasSnpsError as e:
         sys.exit("\nError: could not read %s\n%s\n" % (bam_path, e.message))
-    missing = [n for n in ref_names if n not in genes]
-    if missing:    # the reference: KeyError in genes[bamfile.getrname(...)] at the first read of such a gene
-        used = set(np.unique(refid).tolist())
-        bad = [n for i, n in enumerate(ref_names) if n not in genes and i in used]
-        if bad:
-            sys.exit("\nError: gene '%s' of the BAM header is not in the pangenome database\n" % bad[0])
+    _missing_gene_check(ref_names, refid, genes)
     gene_ids = list(ref_names)
     if mine is not None:     # this rank's genes, and the reads on them (BAM order inside a gene is kept)
         gene_ids = [n for n in ref_names if n in genes and genes[n].species_id in mine]
@@ -191,8 +285,7 @@ def count_mapped_bp(args, species, genes, ctx, mine=None):
         ref_lens = [genes[n].length for n in gene_ids]
     lengths = np.array([genes[n].length if n in genes else ref_lens[i] for i, n in enumerate(gene_ids)], dtype=np.int64)
     try:
-        aligned, mapped, depth, ms = ctx.genes_count(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **{
-            k: args[k] for k in ('mapid', 'readq', 'mapq', 'aln_cov')})), reads, refid, lengths)
+        aligned, mapped, depth, ms = ctx.genes_count(_thresholds(args), reads, refid, lengths)
     except abi.MidasSnpsError as e:
         where = " [read %d of the BAM]" % e.read_index if e.read_index >= 0 else ""
         sys.exit("\nError: %s%s\n" % (e.message, where))
@@ -277,7 +370,7 @@ def pangenome_coverage(args, species, genes, make_context=None):
     """N > 1 (torchrun): species are dealt to the ranks by pangenome size; a rank counts the reads on its species' genes,
     writes their tables, and one all-gather of the summary rows lets rank 0 write summary.txt."""
     rank, ws = dist.world()
-    mine = None
+    mine, owner = None, None
     if ws > 1:
         owner = dist.shard_species({sp.id: float(sp.pangenome_size) for sp in species.values()}, ws)
         mine = {sp for sp, r in owner.items() if r == rank}
@@ -285,7 +378,7 @@ def pangenome_coverage(args, species, genes, make_context=None):
     error, ms = None, 0.0
     try:
         with make_context() as ctx:
-            ms = count_mapped_bp(args, species, genes, ctx, mine)
+            ms = count_mapped_bp(args, species, genes, ctx, mine, owner)
     except abi.MidasSnpsError as e:
         error = "\nError: %s\n" % e.message
     except SystemExit as e:

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from midas_amd import dist
 
@@ -103,6 +104,21 @@ class OracleContext:
         n = len(gene_length)
         al, mp, dp, _ = go.count_mapped_bp(args, recs, list(range(n)), ["x"] * n, [int(x) for x in gene_length])
         return np.array(al, np.int64), np.array(mp, np.int64), np.array(dp, np.float64), 0.0
+    # the two halves (midas_genes_terms / midas_genes_sum): what N ranks use below the species
+    def genes_terms(self, thr, reads, ref_id, gene_length):
+        out = np.zeros(int(reads.n_reads), np.float64)
+        for i, (aln, rid) in enumerate(zip(po.alns_from_soa(reads.as_dict()), ref_id)):
+            a = max(0, po.query_alignment_end(aln) - po.query_alignment_start(aln))
+            if go.keep_read(a, len(aln.seq), aln.nm, aln.qual, aln.mapq, thr.mapid, thr.readq, thr.mapq, thr.aln_cov):
+                out[i] = a / float(int(gene_length[int(rid)]))
+        return out
+    def genes_sum(self, gene, term, n_genes):
+        al, mp, dp = [0] * n_genes, [0] * n_genes, [0.0] * n_genes
+        for g, t in zip(np.asarray(gene).tolist(), np.asarray(term).tolist()):
+            al[g] += 1
+            mp[g] += t > 0
+            dp[g] += t
+        return np.array(al, np.int64), np.array(mp, np.int64), np.array(dp, np.float64)
 
 
 out, db = sys.argv[1], sys.argv[2]
@@ -112,18 +128,45 @@ args = dict(outdir=out, db=db, build_db=False, align=False, cov=True, species_id
             mapid=94.0, readq=20, mapq=0, aln_cov=0.75)
 species = mgenes.initialize_species(args)
 genes = mgenes.initialize_genes(args, species)
-mgenes.pangenome_coverage(args, species, genes, make_context=OracleContext)
+real = os.environ.get("GENES_REAL_DEVICE") == "1"      # (tests/test_gpu_dist.py: the ranks share device 0)
+mgenes.pangenome_coverage(args, species, genes, make_context=(lambda: abi.Context(0)) if real else OracleContext)
 dist.barrier()
+if dist.world()[0] == 0:
+    sys.stderr.write("LOG " + args['log'].getvalue().replace("\n", " | ") + "\n")
 '''
 
 
-def test_two_ranks_gloo_genes_outputs_equal_the_single_process_ones(tmp_path):
-    """run_midas.py genes with N = 2: species dealt to the ranks, each writes its own tables, summary rows gathered --
-    the files are the single-process files (the device call is played by the oracle here; the GPU tests cover it)."""
+def _run_genes_workers(script, sample, db, n_ranks, extra_env=None):
+    """The genes worker as n_ranks processes over gloo -> their stderr texts (rank 0's carries the run's log)."""
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env1.update(extra_env or {})
+    port = _free_port()
+    procs = []
+    for k in range(n_ranks):
+        env = dict(env1)
+        if n_ranks > 1:
+            env.update(RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), sample, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    errs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e
+        errs.append(e)
+    return errs
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_gloo_genes_outputs_equal_the_single_process_ones(tmp_path, n_ranks):
+    """run_midas.py genes with N = 2, 3: species dealt to the ranks; every rank decodes ITS slice of the unsorted BAM, the
+    (gene, term) pairs travel to the gene's owner (one all-to-all) and are summed there in file order -- the files are the
+    single-process files byte for byte, and the log shows that no rank decoded the whole BAM (the device calls are played
+    by the oracle here; the GPU tests cover them)."""
     import gzip
+    import re
     import shutil
     from midas_amd import synth
-    ds = synth.make_pangenome_dataset(n_species=3, genes_per_species=20, n_reads=1500, seed=5)
+    ds = synth.make_pangenome_dataset(n_species=3, genes_per_species=20, n_reads=40000, seed=5)
     one, two, db = str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "db")
     synth.write_pangenome_sample(one, db, ds)
     shutil.copytree(one, two)
@@ -133,15 +176,12 @@ def test_two_ranks_gloo_genes_outputs_equal_the_single_process_ones(tmp_path):
     r = subprocess.run([sys.executable, str(script), one, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        env=env1, timeout=300)
     assert r.returncode == 0, r.stderr
-    port = _free_port()
-    procs = []
-    for k in range(2):
-        env = dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), two, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                      text=True, env=env))
-    for p in procs:
-        o, e = p.communicate(timeout=300)
-        assert p.returncode == 0, e
+    errs = _run_genes_workers(script, two, db, n_ranks)
+    m = re.search(r"rank-local BAM decode \(genes\): (\d+) slices chained, (\d+) records; records decoded per rank: ([\d ]+)", errs[0])
+    assert m, errs[0]
+    per = [int(x) for x in m.group(3).split()]
+    total = int(m.group(2))
+    assert int(m.group(1)) == n_ranks and total == sum(per) > 30000 and max(per) < total * 0.7      # no rank decoded the whole file
     assert open(os.path.join(two, "genes", "summary.txt")).read() == open(os.path.join(one, "genes", "summary.txt")).read()
     for sp in ds['species_ids']:
         a = gzip.open(os.path.join(one, "genes", "output", sp + ".genes.gz"), "rt").read()

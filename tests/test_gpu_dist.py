@@ -8,7 +8,7 @@ import shutil
 
 import pytest
 
-from tests.test_dist_gloo import ROOT, SNPS_WORKER, _run_snps_workers
+from tests.test_dist_gloo import GENES_WORKER, ROOT, SNPS_WORKER, _run_genes_workers, _run_snps_workers
 
 pytestmark = pytest.mark.gpu
 
@@ -83,3 +83,35 @@ def test_device_payload_with_records_not_grouped_by_reference(tmp_path):
     for f in sorted(os.listdir(os.path.join(a, "snps", "output"))):
         assert open(os.path.join(a, "snps", "output", f), "rb").read() == open(os.path.join(b, "snps", "output", f), "rb").read()
     assert open(os.path.join(a, "snps", "summary.txt")).read() == open(os.path.join(b, "snps", "summary.txt")).read()
+
+
+def test_genes_ranks_sharing_one_gpu_write_the_single_process_files(tmp_path):
+    """`run_midas.py genes` below the species as 2 and 3 processes on one real GPU: every rank decodes its slice of the
+    unsorted BAM, makes its reads' terms on the device (midas_genes_terms), the pairs travel to the genes' owners (gloo
+    all-to-all) and are sorted and summed there (midas_genes_sum) -- the tables and the summary are those of one process on
+    the device and of the CPU double (the oracle), byte for byte."""
+    import re
+    from midas_amd import synth
+    ds = synth.make_pangenome_dataset(n_species=5, genes_per_species=60, n_reads=90000, seed=17)
+    cpu, db = str(tmp_path / "cpu"), str(tmp_path / "db")
+    synth.write_pangenome_sample(cpu, db, ds)
+    script = tmp_path / "genes_worker.py"
+    script.write_text(GENES_WORKER % {"root": ROOT})
+    _run_genes_workers(script, cpu, db, 1)                                    # the CPU double, one process
+    outs = {}
+    for n in (1, 2, 3):
+        d = str(tmp_path / ("gpu_n%d" % n))
+        shutil.copytree(cpu, d, ignore=shutil.ignore_patterns("output", "summary.txt"))
+        os.makedirs(os.path.join(d, "genes", "output"), exist_ok=True)
+        errs = _run_genes_workers(script, d, db, n, {"GENES_REAL_DEVICE": "1"})
+        if n > 1:
+            m = re.search(r"rank-local BAM decode \(genes\): (\d+) slices chained, (\d+) records; records decoded per rank: ([\d ]+)", errs[0])
+            assert m, errs[0][-2000:]
+            per = [int(x) for x in m.group(3).split()]
+            assert len(per) == n and max(per) < 0.7 * sum(per)
+        outs[n] = d
+    for n in (1, 2, 3):
+        assert open(os.path.join(outs[n], "genes", "summary.txt")).read() == open(os.path.join(cpu, "genes", "summary.txt")).read()
+        for sp in ds['species_ids']:
+            a = gzip.open(os.path.join(cpu, "genes", "output", sp + ".genes.gz"), "rb").read()
+            assert gzip.open(os.path.join(outs[n], "genes", "output", sp + ".genes.gz"), "rb").read() == a, "%s: %d ranks" % (sp, n)

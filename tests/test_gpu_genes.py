@@ -157,3 +157,60 @@ def test_run_midas_genes_error_exit(tmp_path):
     r = _run_cli(out, db, fq)
     assert r.returncode == 1
     assert "NM" in r.stderr and "read 41" in r.stderr
+
+
+def test_the_two_halves_are_the_whole():
+    """midas_genes_sum(ref_id, midas_genes_terms(reads)) == midas_genes_count(reads) bit for bit -- and so is the sum over pairs
+    that were made slice by slice and put back together in file order (what N ranks do below the species)."""
+    ds = synth.make_pangenome_dataset(n_species=4, genes_per_species=300, n_reads=60000, seed=23)
+    lengths = [len(s) for s in ds['gene_seq']]
+    thr = abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, **GENES_ARGS))
+    with abi.Context(0) as ctx:
+        aligned, mapped, depth, _ = ctx.genes_count(thr, ds['reads'], ds['refid'], lengths)
+        term = ctx.genes_terms(thr, ds['reads'], ds['refid'], lengths)
+        n = int(ds['reads'].n_reads)
+        assert n > 40000 and term.shape == (n,) and (term >= 0).all() and (term > 0).sum() == mapped.sum()
+        a2, m2, d2 = ctx.genes_sum(ds['refid'], term, len(lengths))
+        assert np.array_equal(a2, aligned) and np.array_equal(m2, mapped) and d2.tobytes() == depth.tobytes()
+        # slices of the reads (three unequal ones), terms per slice, concatenated
+        cuts = [0, 17000, 17001, n]
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            sub = synth.take_reads(ds['reads'], np.arange(lo, hi))
+            parts.append(ctx.genes_terms(thr, sub, ds['refid'][lo:hi], lengths))
+        a3, m3, d3 = ctx.genes_sum(ds['refid'], np.concatenate(parts), len(lengths))
+        assert np.array_equal(a3, aligned) and np.array_equal(m3, mapped) and d3.tobytes() == depth.tobytes()
+        # an owner that holds only some genes: the pairs of those genes, renumbered
+        own = np.arange(len(lengths)) % 3 == 1
+        new_id = np.cumsum(own) - 1
+        sel = own[ds['refid']]
+        a4, m4, d4 = ctx.genes_sum(new_id[ds['refid'][sel]], term[sel], int(own.sum()))
+        assert np.array_equal(a4, aligned[own]) and np.array_equal(m4, mapped[own]) and d4.tobytes() == depth[own].tobytes()
+
+
+@pytest.mark.parametrize("n_genes,n_pairs", [(1, 5000), (255, 70000), (257, 70000), (70000, 300000), (1 << 17, 1 << 20)])
+def test_the_pair_sort_keeps_file_order_inside_a_gene(n_genes, n_pairs):
+    """The radix sort of genes_count.hip against numpy's stable sort: per gene the sequential fp64 sum of its terms in input
+    order (terms of wildly different magnitudes, so any reordering shows), gene counts straddling the 8-bit digit borders."""
+    rng = np.random.default_rng(n_genes + n_pairs)
+    gene = rng.integers(0, n_genes, n_pairs).astype(np.int32)
+    if n_genes > 300:
+        gene[: n_pairs // 4] = 7                        # one heavy gene (summed by a whole wave)
+    term = np.exp(rng.uniform(-30, 30, n_pairs))
+    term[rng.random(n_pairs) < 0.2] = 0.0
+    with abi.Context(0) as ctx:
+        aligned, mapped, depth = ctx.genes_sum(gene, term, n_genes)
+    order = np.argsort(gene, kind='stable')
+    gs, ts = gene[order], term[order]
+    begin = np.searchsorted(gs, np.arange(n_genes + 1))
+    assert np.array_equal(aligned, np.diff(begin))
+    exp = np.zeros(n_genes)
+    expm = np.zeros(n_genes, np.int64)
+    for g in np.unique(gs):
+        acc = 0.0
+        for t in ts[begin[g]:begin[g + 1]].tolist():
+            acc += t
+        exp[g] = acc
+        expm[g] = int((ts[begin[g]:begin[g + 1]] > 0).sum())
+    assert np.array_equal(mapped, expm)
+    assert depth.tobytes() == exp.tobytes()
