@@ -9,8 +9,8 @@
 //   filter  one thread per read, BAM order: keep_read with the exceptions the reference would raise (lowest read
 //           index wins), and the read's term  align_len / float(gene.length)  (+0.0 for a read that is dropped:
 //           adding it leaves the running sum unchanged bit for bit);
-//   sort    stable LSD radix sort of (gene, term) pairs by gene, eight bits of the gene index a pass (the kernels below: a
-//           gene index has as many bits as the pangenome has genes, nothing else is sorted here): BAM order survives inside a gene;
+//   sort    stable LSD radix sort of (gene, term) pairs by gene, eight bits of the gene index a pass (device_sort.hip, the
+//           library's own: a gene index has as many bits as the pangenome has genes): BAM order survives inside a gene;
 //   bounds  first sorted position of every gene;
 //   sum     one thread per gene adds its terms one after the other (a gene with many reads: one wave stages 512
 //           terms at a time in LDS and adds them in the same order).
@@ -85,132 +85,6 @@ __global__ __launch_bounds__(256) void genes_bounds_kernel(const uint32_t* key, 
   const long long prev = i == 0 ? -1 : (long long)key[i - 1];
   const long long cur = i == n ? n_genes : (long long)key[i];
   for (long long g = prev + 1; g <= cur; ++g) begin[g] = i;
-}
-
-// ---- stable LSD radix sort of (gene, term) pairs, eight bits of the key a pass -------------------------------------------------
-// A workgroup owns kSortBlock consecutive pairs, each of its four waves a quarter of them, taken 64 at a time: the order of
-// equal digits is (workgroup, wave, round, lane) = the input order.
-//   hist     per workgroup the number of keys of every digit            -> hist[digit][workgroup]
-//   scan     exclusive scan over hist in that (digit-major) order       -> where a workgroup's keys of a digit go
-//   scatter  a wave finds, per round, the lanes that share a lane's digit (eight ballots), ranks the lane among them and
-//            moves its pair to the digit's cursor of the wave (LDS), which the lowest of those lanes then advances
-constexpr int kSortThreads = 256, kSortWaves = kSortThreads / 64, kSortRounds = 16;
-constexpr int kSortBlock = kSortThreads * kSortRounds;      // 4096 pairs
-
-__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t* key, long long n, int shift, uint32_t* hist, uint32_t n_blocks) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0u;
-  __syncthreads();
-  const long long base = (long long)blockIdx.x * kSortBlock;
-#pragma unroll 4
-  for (int r = 0; r < kSortRounds; ++r) {
-    const long long i = base + (long long)r * kSortThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
-}
-
-// one workgroup: exclusive scan of m counters, 4096 at a time with a running carry
-__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* v, long long m) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0u;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long long t0 = 0; t0 < m; t0 += 4096) {
-    const long long i = t0 + 4ll * threadIdx.x;
-    uint32_t a[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = i + k < m ? v[i + k] : 0u;
-    const uint32_t mine = a[0] + a[1] + a[2] + a[3];
-    uint32_t inc = mine;                                   // inclusive scan over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t before = carry_s;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
-    uint32_t run = before + inc - mine;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (i + k < m) v[i + k] = run;
-      run += a[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = run;                // (the last thread's running total is the tile's)
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t* key, const double* term, long long n, int shift,
-                                                                     const uint32_t* hist, uint32_t n_blocks, uint32_t* key_out, double* term_out) {
-  __shared__ uint32_t cursor[kSortWaves][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int d = threadIdx.x; d < kSortWaves * 256; d += kSortThreads) (&cursor[0][0])[d] = 0u;
-  __syncthreads();
-  // the wave's own counts per digit ...
-  const long long wbase = (long long)blockIdx.x * kSortBlock + (long long)wave * (kSortBlock / kSortWaves);
-  for (int r = 0; r < kSortRounds; ++r) {
-    const long long i = wbase + (long long)r * 64 + lane;
-    if (i < n) atomicAdd(&cursor[wave][(key[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  // ... become where its keys of a digit start: the workgroup's place for the digit + the waves in front
-  {
-    const int d = threadIdx.x;       // 256 threads, 256 digits
-    uint32_t at = hist[(size_t)d * n_blocks + blockIdx.x];
-    for (int w = 0; w < kSortWaves; ++w) {
-      const uint32_t c = cursor[w][d];
-      cursor[w][d] = at;
-      at += c;
-    }
-  }
-  __syncthreads();
-  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int r = 0; r < kSortRounds; ++r) {
-    const long long i = wbase + (long long)r * 64 + lane;
-    const bool live = i < n;
-    const uint32_t k = live ? key[i] : 0u;
-    const uint32_t d = (k >> shift) & 255u;
-    unsigned long long peers = __ballot(live);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long has = __ballot(live && ((d >> b) & 1u));
-      peers &= ((d >> b) & 1u) ? has : ~has;
-    }
-    if (live) {
-      const uint32_t at = cursor[wave][d] + (uint32_t)__popcll(peers & below);
-      key_out[at] = k;
-      term_out[at] = term[i];
-    }
-    // (LDS operations of one wave are carried out in order: every lane has read the cursor before its lowest peer moves it,
-    // and the next round reads what this one wrote)
-    if (live && (peers & below) == 0ull) cursor[wave][d] += (uint32_t)__popcll(peers);
-  }
-}
-
-// `bits` low bits of the keys decide (they are below 2^bits).  The sorted pairs end up in (*key_sorted, *term_sorted): one of
-// the two buffer pairs.  hist: 256 * ceil(n / kSortBlock) counters.
-hipError_t sort_pairs(uint32_t* key_a, double* term_a, uint32_t* key_b, double* term_b, long long n, int bits, uint32_t* hist,
-                      hipStream_t s, uint32_t** key_sorted, double** term_sorted) {
-  uint32_t* kin = key_a; double* tin = term_a; uint32_t* kout = key_b; double* tout = term_b;
-  const uint32_t n_blocks = (uint32_t)((n + kSortBlock - 1) / kSortBlock);
-  for (int shift = 0; shift < bits && n > 0; shift += 8) {
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(kSortThreads), 0, s, kin, n, shift, hist, n_blocks);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 256ll * n_blocks);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_blocks), dim3(kSortThreads), 0, s, kin, tin, n, shift, hist, n_blocks, kout, tout);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    std::swap(kin, kout);
-    std::swap(tin, tout);
-  }
-  *key_sorted = kin;
-  *term_sorted = tin;
-  return hipSuccess;
 }
 
 struct SumKParams {
@@ -446,7 +320,6 @@ int32_t genes_run(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const m
   G_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const size_t ng = (size_t)(n_genes > 0 ? n_genes : 1), nr = (size_t)(n > 0 ? n : 1);
-  const size_t n_sort_blocks = (nr + kSortBlock - 1) / kSortBlock;
   uint2* d_recs = nullptr; uint32_t* d_key = nullptr; uint32_t* d_key_b = nullptr; double* d_term = nullptr; double* d_term_b = nullptr;
   int64_t* d_len = nullptr; FilterTables* d_ft = nullptr; long long* d_begin = nullptr; long long* d_al = nullptr; long long* d_mp = nullptr;
   double* d_dp = nullptr; unsigned long long* d_err = nullptr; unsigned int* d_heavy = nullptr; uint32_t* d_hist = nullptr;
@@ -461,7 +334,7 @@ int32_t genes_run(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const m
   if (sums) {
     G_TRY(dev.get(&d_key_b, nr * 4));
     G_TRY(dev.get(&d_term_b, nr * 8));
-    G_TRY(dev.get(&d_hist, n_sort_blocks * 256 * 4));
+    G_TRY(dev.get(&d_hist, sort_scratch_words((long long)nr) * 4));
     G_TRY(dev.get(&d_begin, (ng + 1) * 8));
     G_TRY(dev.get(&d_al, ng * 8));
     G_TRY(dev.get(&d_mp, ng * 8));
@@ -498,7 +371,7 @@ int32_t genes_run(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const m
   if (sums && n_genes > 0) {
     uint32_t* d_key_sorted = d_key;
     double* d_term_sorted = d_term;
-    G_TRY(sort_pairs(d_key, d_term, d_key_b, d_term_b, n, key_bits, d_hist, s, &d_key_sorted, &d_term_sorted));
+    G_TRY(launch_sort_pairs_f64(d_key, d_term, d_key_b, d_term_b, n, key_bits, d_hist, s, &d_key_sorted, &d_term_sorted));
     hipLaunchKernelGGL(genes_bounds_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, d_key_sorted, (long long)n,
                        (long long)n_genes, d_begin);
     G_TRY(hipGetLastError());

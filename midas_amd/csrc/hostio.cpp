@@ -177,20 +177,17 @@ int writer_threads(int want) {
 }
 
 // Developer variants (-DMIDAS_HOSTIO_TRACE): where the host stages spend their time, on stderr.
-struct Lap {
-#ifdef MIDAS_HOSTIO_TRACE
+struct Lap {       // where a call spends its time, on stderr, when MIDAS_SNPS_TRACE is set
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   const char* who;
-  explicit Lap(const char* w) : who(w) {}
+  bool on;
+  explicit Lap(const char* w) : who(w), on(getenv("MIDAS_SNPS_TRACE") != nullptr) {}
   void operator()(const char* what) {
+    if (!on) return;
     const auto n = std::chrono::steady_clock::now();
     fprintf(stderr, "[%s] %-34s %8.2f ms\n", who, what, std::chrono::duration<double, std::milli>(n - t).count());
     t = n;
   }
-#else
-  explicit Lap(const char*) {}
-  void operator()(const char*) {}
-#endif
 };
 
 // One raw DEFLATE stream of known inflated size (a BGZF block, a member of one of this library's tables) -> out.  Through

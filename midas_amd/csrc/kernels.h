@@ -204,6 +204,16 @@ struct DirectParams {
   int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
 };
 
+// device_sort.hip: the library's own exclusive scan of 32-bit counters and stable 8-bit-digit radix sort of (key, value) pairs
+size_t scan_scratch_words(long long n);                 // 32-bit words of `sums` a scan of n counters needs
+hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* sums, hipStream_t s);     // in == out allowed
+size_t sort_scratch_words(long long n);                 // 32-bit words of `scratch` a sort of n pairs needs
+// keys below 2^bits; the sorted pairs end up in (*key_sorted, *val_sorted) = one of the two buffer pairs
+hipError_t launch_sort_pairs_u32(uint32_t* key_a, uint32_t* val_a, uint32_t* key_b, uint32_t* val_b, long long n, int bits, uint32_t* scratch,
+                                 hipStream_t s, uint32_t** key_sorted, uint32_t** val_sorted);
+hipError_t launch_sort_pairs_f64(uint32_t* key_a, double* val_a, uint32_t* key_b, double* val_b, long long n, int bits, uint32_t* scratch,
+                                 hipStream_t s, uint32_t** key_sorted, double** val_sorted);
+
 // rows_deflate.hip: the table's rows formatted and deflated on the device, one gzip member (<= 16 384 rows of one contig) at a time
 struct RowsMember {
   long long site0;                 // the member's first site in the batch's counts / alleles

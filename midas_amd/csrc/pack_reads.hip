@@ -13,10 +13,10 @@
 // Pipeline (all on one stream, no host round trip in between once the buffers exist):
 //   pack_plan_kernel     1 thread / read   validate, CIGAR -> number of device records (match segments cut at tile
 //                                          boundaries, or one record that keeps its CIGAR); algorithmic bytes, longest read
-//   [scan]                                 first device record of every read (hipCUB exclusive sum)
+//   [scan]                                 first device record of every read (exclusive sum, device_sort.hip)
 //   pack_keys_kernel     1 thread / read   per record: sort key (tile, class, bank phase), payload size, index key and a
 //                                          16-byte descriptor (position, read, query offset, length, the filter's numbers)
-//   [radix sort]                           stable sort of (key, record) -- input order survives inside a key (hipCUB)
+//   [radix sort]                           stable sort of (key, record) -- input order survives inside a key (device_sort.hip)
 //   pack_bounds_kernel   1 thread / record first sorted position of every key
 //   pack_dest_kernel     1 thread / record device position of every record: a tile's segment records are dealt round-robin
 //                                          over their eight bank phases (layout.h), everything else keeps the sorted order;
@@ -29,7 +29,6 @@
 //
 // HBM roofline of the scatter kernel (the dominant one): it reads the raw read (ceil(l/2) + l + 4 n_cigar + 16 B of
 // fixed fields) and writes 32 B per 31 bases + 16 B of record.
-#include <hipcub/hipcub.hpp>
 
 #include "device_common.h"
 
@@ -807,12 +806,9 @@ __global__ __launch_bounds__(kScatterBlock) void pack_scatter_kernel(PackParams 
 }  // namespace
 
 size_t pack_sort_temp_bytes(int64_t max_records, int key_bits) {
-  size_t a = 0, b = 0, c = 0;
-  uint32_t* nil = nullptr;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, nil, nil, nil, nil, (int)max_records, 0, key_bits, nullptr);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, nil, nil, (int)max_records + 1, nullptr);
-  c = a > b ? a : b;
-  return c + 256;
+  (void)key_bits;
+  const size_t a = sort_scratch_words((long long)max_records), b = scan_scratch_words((long long)max_records + 1);
+  return 4 * (a > b ? a : b) + 256;
 }
 
 int pack_key_bits(int32_t n_tiles) {
@@ -834,7 +830,8 @@ hipError_t launch_pack_plan(const PackParams& p, void* tmp, size_t tmp_bytes, hi
   if (e != hipSuccess) return e;
   if (p.n_reads > 0) {
     hipLaunchKernelGGL(pack_plan_kernel, dim3(plan_grid(p.n_reads)), dim3(kPlanBlock), 0, s, p);
-    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, p.cnt, p.first, p.n_reads + 1, s);
+    (void)tmp_bytes;
+    e = launch_scan_u32(p.cnt, p.first, (long long)p.n_reads + 1, static_cast<uint32_t*>(tmp), s);
     if (e != hipSuccess) return e;
   } else {
     e = hipMemsetAsync(p.first, 0, 4, s);
@@ -855,8 +852,17 @@ hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, i
   const int m = p.n_records;
   hipError_t e = hipSuccess;
   if (m > 0) {
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, p.sort_key, p.key_sorted, p.sort_val, p.val_sorted, m, 0, key_bits, s);
+    // (the library's own stable radix sort, device_sort.hip: the pairs end up in one of the two buffer pairs)
+    uint32_t* ks = nullptr;
+    uint32_t* vs = nullptr;
+    e = launch_sort_pairs_u32(p.sort_key, p.sort_val, p.key_sorted, p.val_sorted, m, key_bits, static_cast<uint32_t*>(tmp), s, &ks, &vs);
     if (e != hipSuccess) return e;
+    if (ks != p.key_sorted) {
+      e = hipMemcpyAsync(p.key_sorted, ks, (size_t)m * 4, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return e;
+      e = hipMemcpyAsync(p.val_sorted, vs, (size_t)m * 4, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return e;
+    }
   }
   const int nbins = p.n_tiles * kPackBinsPerTile;
   const int gb = m > 0 ? (m + kPlanBlock - 1) / kPlanBlock : (nbins + kPlanBlock) / kPlanBlock;
@@ -867,7 +873,8 @@ hipError_t launch_pack_order(const PackParams& p, void* tmp, size_t tmp_bytes, i
     e = hipMemsetAsync(p.off8, 0, 4, s);
     if (e != hipSuccess) return e;
   } else {
-    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, p.bytes8_dev, p.off8, m + 1, s);
+    (void)tmp_bytes;
+    e = launch_scan_u32(p.bytes8_dev, p.off8, (long long)m + 1, static_cast<uint32_t*>(tmp), s);
     if (e != hipSuccess) return e;
   }
   return hipGetLastError();

@@ -794,6 +794,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   for (size_t k = 0; k < n_segs; ++k)
     DEC_TRY(hipMemcpyAsync(base + at_comp + seg_at[k], comp_base + jobs[segs[k].job_lo].cpos, seg_at[k + 1] - seg_at[k], hipMemcpyHostToDevice, s));
   DEC_TRY(hipMemsetAsync(base + at_comp + comp_bytes, 0, 512, s));
+  if (trace) { DEC_TRY(hipStreamSynchronize(s)); lap("blocks up"); }
   InflateParams ip;
   ip.comp = base + at_comp;
   ip.blocks = reinterpret_cast<const InflateBlock*>(base + at_blocks);
