@@ -261,36 +261,78 @@ bool bgzf_block_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_o
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
 struct FileBlk { size_t cpos, clen, upos, ulen, fpos; };
 // A BGZF file read whole (by several threads) and its block table: where every block's DEFLATE stream lies, what it inflates to.
-int32_t read_bgzf_file(const std::string& path, RawBuf<uint8_t>& comp, std::vector<FileBlk>& blocks, size_t* total, char* err256) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
-  fseek(f, 0, SEEK_END);
-  const long fsz = ftell(f);
-  fseek(f, 0, SEEK_SET);
+// A whole file's bytes for reading: the file MAPPED where that works (a BAM of a gigabyte is in the page cache when the pileup
+// stage starts -- bowtie2 | samtools just wrote it; copying it into a fresh buffer costs a first-touch fault and a copy per
+// page, 90 ms a gigabyte on the GPU box, mapping it 10) -- else read into a buffer by several threads.
+struct FileImage {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  void* map = nullptr;
+  RawBuf<uint8_t> buf;
+  FileImage() = default;
+  FileImage(const FileImage&) = delete;
+  FileImage& operator=(const FileImage&) = delete;
+  ~FileImage() { if (map) munmap(map, n); }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+  const uint8_t& operator[](size_t i) const { return p[i]; }
+};
+
+int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<FileBlk>& blocks, size_t* total, char* err256) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); set_err(err256, "cannot stat %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  const size_t fsz = (size_t)sb.st_size;
   Lap lap("bam inflate");
-  if (!comp.resize((size_t)fsz)) { fclose(f); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  {   // the file comes in through several threads: one core copies ~4 GB/s out of the page cache, a BAM is 100s of MB
-    const int fd = fileno(f);
-    const size_t piece = (size_t)8 << 20, n_pieces = ((size_t)fsz + piece - 1) / piece;
+  const size_t piece = (size_t)8 << 20, n_pieces = (fsz + piece - 1) / piece;
+  const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
+  void* m = fsz > 0 && !getenv("MIDAS_SNPS_NO_MMAP") ? mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+  if (m != MAP_FAILED) {
+    (void)madvise(m, fsz, MADV_WILLNEED);
+    comp.map = m;
+    comp.p = static_cast<const uint8_t*>(m);
+    comp.n = fsz;
+    // the pages are mapped in by several threads (one read per page; the kernel maps a run of cached pages per fault)
+    std::atomic<size_t> nextp{0};
+    std::atomic<unsigned> sink{0};
+    Workers::run(n_workers, [&] {
+      unsigned acc = 0;
+      for (;;) {
+        const size_t k = nextp.fetch_add(1);
+        if (k >= n_pieces) break;
+        const size_t end = std::min(fsz, (k + 1) * piece);
+        for (size_t off = k * piece; off < end; off += 4096) acc += comp.p[off];
+      }
+      sink += acc;
+    });
+    close(fd);
+    lap("map file");
+  } else {
+    if (!comp.buf.resize(fsz)) { close(fd); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+    // the file comes in through several threads: one core copies ~4 GB/s out of the page cache, a BAM is 100s of MB
     std::atomic<size_t> nextp{0};
     std::atomic<int> short_read{0};
-    Workers::run((int)std::min<size_t>(n_pieces, 16), [&] {
+    uint8_t* const dst = comp.buf.data();
+    Workers::run(n_workers, [&] {
       for (;;) {
         const size_t k = nextp.fetch_add(1);
         if (k >= n_pieces) return;
         size_t off = k * piece;
-        const size_t end = std::min((size_t)fsz, off + piece);
+        const size_t end = std::min(fsz, off + piece);
         while (off < end) {
-          const ssize_t got = pread(fd, comp.data() + off, end - off, (off_t)off);
+          const ssize_t got = pread(fd, dst + off, end - off, (off_t)off);
           if (got <= 0) { short_read = 1; return; }
           off += (size_t)got;
         }
       }
     });
-    fclose(f);
+    close(fd);
     if (short_read) { set_err(err256, "short read on %s", path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    comp.p = comp.buf.data();
+    comp.n = fsz;
+    lap("read file");
   }
-  lap("read file");
   size_t p = 0, upos = 0;
   while (p < comp.size()) {
     if (p + 18 > comp.size() || comp[p] != 0x1f || comp[p + 1] != 0x8b || comp[p + 2] != 8 || !(comp[p + 3] & 4)) {
@@ -320,7 +362,7 @@ int32_t read_bgzf_file(const std::string& path, RawBuf<uint8_t>& comp, std::vect
 }
 
 int32_t bgzf_inflate_file(const std::string& path, RawBuf<uint8_t>& out, char* err256, const midas::BlockInflater* inflater = nullptr) {
-  RawBuf<uint8_t> comp;
+  FileImage comp;
   std::vector<FileBlk> blocks;
   size_t upos = 0;
   {
@@ -990,7 +1032,7 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
   std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
   if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   b->path = path;
-  RawBuf<uint8_t> comp;
+  FileImage comp;
   std::vector<FileBlk> blocks;
   size_t total = 0;
   int32_t st = read_bgzf_file(b->path, comp, blocks, &total, err256);
