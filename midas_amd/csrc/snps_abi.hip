@@ -833,7 +833,13 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   ip.n_matches = reinterpret_cast<uint32_t*>(base + at_status) + n_jobs;
   ip.matches = reinterpret_cast<unsigned long long*>(base + at_matches);
   ip.want_crc = reinterpret_cast<const uint32_t*>(base + at_crc);
-  DEC_TRY(launch_bgzf_inflate(ip, s));
+  if (trace) {      // (phase by phase, each waited for)
+    DEC_TRY(launch_bgzf_inflate(ip, s, 1)); DEC_TRY(hipStreamSynchronize(s)); lap("  inflate kernel");
+    DEC_TRY(launch_bgzf_inflate(ip, s, 2 | 8)); DEC_TRY(hipStreamSynchronize(s)); lap("  resolve kernel");
+    DEC_TRY(launch_bgzf_inflate(ip, s, 4)); DEC_TRY(hipStreamSynchronize(s)); lap("  crc kernel");
+  } else {
+    DEC_TRY(launch_bgzf_inflate(ip, s));
+  }
   std::vector<uint32_t> status(n_jobs);
   DEC_TRY(hipMemcpyAsync(status.data(), ip.status, n_jobs * 4, hipMemcpyDeviceToHost, s));
   DEC_TRY(hipStreamSynchronize(s));
