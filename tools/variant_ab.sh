@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box: the batched pileup kernel against the one before it (tools/variants/pileup_direct_r04a.hip), same box: time, probes
+# GPU box: a pileup-kernel variant against the shipped kernel on ONE box: time, tallies off, loads only, probes.  Build first:
+#   python -m midas_amd.build -o midas_amd/lib/libmidas_snps_hip_old.so --replace pileup_direct.hip=<the kernel to compare with>
+#   (+ _probe / _oldprobe with -DMIDAS_SNPS_DEBUG_BITS=256, _dbg1 / _dbg4 with =1 / =4)
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 O=gpurun_out/r04_fourth.txt
