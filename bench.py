@@ -227,6 +227,33 @@ def measure_traffic(contigs, reads, steps=6):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _on_one_gpu():
+    """MIDAS_BENCH_ONE_GPU=1 (tests/test_gpu_bench.py): the N > 1 code of this script run as N processes that SHARE device 0 and
+    talk over gloo -- RCCL refuses two ranks on one device.  Everything but the transport is the path the driver launches."""
+    return os.environ.get("MIDAS_BENCH_ONE_GPU") == "1"
+
+
+def _all_gather(out, inp):
+    import torch.distributed as dist
+    if _on_one_gpu():          # gloo: through host copies
+        i = inp.cpu().contiguous()
+        o = out.cpu().reshape((out.numel() // i.numel() * i.shape[0],) + tuple(i.shape[1:]))     # (gloo wants the concatenated form)
+        dist.all_gather_into_tensor(o, i)
+        out.copy_(o.reshape(out.shape))
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _all_reduce(t, op):
+    import torch.distributed as dist
+    if _on_one_gpu():
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def configs3_strong(ctx, thr, rank, world, collective, steps):
     """BASELINE.json configs[3] as the product deals it: ONE 100-species sample (400 Mb, 80 M aligned reads), its contigs dealt
     to the ranks by midas_amd.dist.shard_items, every rank piling up its share, one all-gather of the summary rows per job.
@@ -244,7 +271,7 @@ def configs3_strong(ctx, thr, rank, world, collective, steps):
         batch.run(thr)
     batch.sync()
     if collective:
-        dist.all_gather_into_tensor(gathered, rows)
+        _all_gather(gathered, rows)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -256,7 +283,7 @@ def configs3_strong(ctx, thr, rank, world, collective, steps):
     torch.cuda.synchronize()
     own = time.perf_counter() - t0                      # this rank's share of the job, steps times
     if collective:
-        dist.all_gather_into_tensor(gathered, rows)     # the job's one exchange: every rank's per-species rows
+        _all_gather(gathered, rows)     # the job's one exchange: every rank's per-species rows
         torch.cuda.synchronize()
     else:
         gathered[0].copy_(rows)
@@ -269,7 +296,7 @@ def configs3_strong(ctx, thr, rank, world, collective, steps):
     vals = torch.tensor([own, elapsed, kern, float(info.n_sites), float(info.n_reads), float(info.algorithmic_bytes)], dtype=torch.float64, device="cuda")
     allv = torch.zeros((world, vals.numel()), dtype=torch.float64, device="cuda")
     if collective:
-        dist.all_gather_into_tensor(allv, vals)
+        _all_gather(allv, vals)
     else:
         allv[0].copy_(vals)
     allv = allv.cpu().numpy()
@@ -331,6 +358,8 @@ def main():
         sys.exit("--gpus (%d) != WORLD_SIZE (%d)" % (a.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    if _on_one_gpu():
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     collective = world > 1 or a.force_collective
     if collective:
@@ -340,7 +369,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if _on_one_gpu():
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     share = None
     if a.config == "c4":        # configs[3]: this rank's contigs of the one 400 Mb sample (strong scaling)
@@ -353,8 +385,14 @@ def main():
     thr = abi.Thresholds.from_args(args)
 
     ctx = abi.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)           # launch on torch's stream: torch events / RCCL see the kernels
+    # The step runs on a stream torch knows as its current one: torch's copies and the RCCL collectives order themselves
+    # behind the kernels and the stats copy.  (Torch's DEFAULT stream has the null handle, which midas_snps_set_stream takes
+    # for "the context's own stream" -- a stream torch does not wait for: the all-gather could read rows that were still
+    # being written.  Found by tests/test_gpu_bench.py; hence a stream of our own, made current.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    assert stream.cuda_stream != 0
     batch = ctx.batch(contigs, reads)            # uploads the BAM-native arrays as they are; picks the path
     info = batch.info()
     n_sp = contigs.n_species
@@ -370,7 +408,7 @@ def main():
             if collective:
                 batch.stats_to_device(rows[i].data_ptr())
         if collective and n > 0:
-            dist.all_gather_into_tensor(gathered, rows)
+            _all_gather(gathered, rows)
 
     job(a.warmup)
     batch.sync()
@@ -386,7 +424,7 @@ def main():
     torch.cuda.synchronize()
     batch.enable_timing(a.steps)                 # HIP events on the step's stream: before the index pass, between it and the
     if collective:      # RCCL builds its communicator and channels on first use: never inside the timed region
-        dist.all_gather_into_tensor(gathered, rows)
+        _all_gather(gathered, rows)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -405,9 +443,9 @@ def main():
     el_all = None
     if collective:
         el_all = torch.zeros(world, dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(el_all, el)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sites, op=dist.ReduceOp.SUM)
+        _all_gather(el_all, el)
+        _all_reduce(el, dist.ReduceOp.MAX)
+        _all_reduce(sites, dist.ReduceOp.SUM)
     elapsed = float(el.item())
     total_sites = float(sites.item())
 

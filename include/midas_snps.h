@@ -156,7 +156,11 @@ const char* midas_snps_last_error(const midas_snps_ctx* ctx);
 /* Lowest index of a read that made the last pileup fail with a MIDAS_SNPS_ERR_READ_* status, else -1. */
 int64_t midas_snps_last_error_read(const midas_snps_ctx* ctx);
 /* Launch on an existing HIP stream (hipStream_t as void*; e.g. torch's current stream) instead of
- * the context's own.  NULL restores the context's stream.                                       */
+ * the context's own.  NULL restores the context's stream -- so HIP's null (legacy default) stream
+ * cannot be named here: a caller whose framework runs on the default stream (torch.cuda.current_stream()
+ * has the handle 0 until a stream is made current) makes a stream of its own current and passes that
+ * one, as bench.py does; otherwise the framework's copies and collectives do not wait for this
+ * library's kernels.                                                                             */
 int32_t midas_snps_set_stream(midas_snps_ctx* ctx, void* hip_stream);
 /* Device facts for logs: name (<=255 chars), compute units, HBM bytes. */
 int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t* n_cu, int64_t* hbm_bytes);
