@@ -7,15 +7,23 @@
 
 namespace midas {
 
+// The shape of the pileup kernels (both paths): tiles of 2048 sites = 32 KiB of LDS tallies, workgroups of 256 threads, FOUR
+// resident per CU (16 waves, 128 VGPRs each).  Until late in round 4: 4096 sites, 512 threads, two per CU -- the same waves and
+// the same iterations per wave and tile, but four workgroups' load / barrier / write-out phases interleave more evenly than
+// two's: 2 % faster on every workload, both paths (profiles/r04_kernel_experiments.txt, section 10).
 #ifndef MIDAS_TILE_SHIFT
-#define MIDAS_TILE_SHIFT 12
+#define MIDAS_TILE_SHIFT 11
 #endif
 #ifndef MIDAS_PILEUP_BLOCK
-#define MIDAS_PILEUP_BLOCK 512
+#define MIDAS_PILEUP_BLOCK 256
 #endif
-constexpr int kTileShift = MIDAS_TILE_SHIFT;             // 4096 sites per tile: 64 KiB of LDS tallies, 2 workgroups per CU
+#ifndef MIDAS_WORKGROUPS_PER_CU
+#define MIDAS_WORKGROUPS_PER_CU 4
+#endif
+constexpr int kTileShift = MIDAS_TILE_SHIFT;
 constexpr int kTileSites = 1 << kTileShift;
-constexpr int kPileupBlock = MIDAS_PILEUP_BLOCK;          // 8 waves
+constexpr int kPileupBlock = MIDAS_PILEUP_BLOCK;          // 4 waves
+constexpr int kWorkgroupsPerCU = MIDAS_WORKGROUPS_PER_CU;
 constexpr int kIndexBlock = 256;
 
 // Per-species counters, same order as MIDAS_SNPS_STAT_* in include/midas_snps.h.

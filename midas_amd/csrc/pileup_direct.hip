@@ -10,7 +10,7 @@
 //   str(rec.seq).upper()            midas/run/snps.py:62
 // The reference filters and counts a read in one pass (keep_read inside count_coverage's iterator); so does this kernel.
 //
-// Work decomposition: as in pileup_tiles.hip -- tiles of <= 4096 sites, a persistent 512-thread workgroup per item, tallies
+// Work decomposition: as in pileup_tiles.hip -- tiles of <= 2048 sites, a persistent 256-thread workgroup per item (four per CU), tallies
 // in LDS as [site][A,C,G,T] u32, one coalesced write-out per tile, items handed out by per-XCD counters.
 //
 // Stream.  The ranges pass (index_direct.hip, 4 bytes per read) left, per tile, the run [tbegin, tend) of read indices that
@@ -142,11 +142,11 @@ struct Stream { int rb, n0, total; };
 
 // Workgroup shape (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384).
 #ifndef MIDAS_DIRECT_BLOCK
-#define MIDAS_DIRECT_BLOCK 512
+#define MIDAS_DIRECT_BLOCK 256
 #endif
 constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
 static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
-constexpr int kDirectWavesPerSimd = (2 * kDirectBlock / 64 + 3) / 4;      // two workgroups per CU
+constexpr int kDirectWavesPerSimd = (kWorkgroupsPerCU * kDirectBlock / 64 + 3) / 4;      // four workgroups per CU
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));

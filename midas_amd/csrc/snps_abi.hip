@@ -1186,7 +1186,7 @@ int32_t plan_work_items(midas_snps_batch* b, const uint32_t* tile_reads) {
   const size_t nt = (size_t)b->n_tiles;
   int64_t total_reads = 0;
   for (size_t t = 0; t < nt; ++t) total_reads += tile_reads[t];
-  const int64_t fair = total_reads / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
+  const int64_t fair = total_reads / (kWorkgroupsPerCU * (int64_t)ctx->prop.multiProcessorCount) + 1;
   int64_t split_reads = std::max<int64_t>(2048, 2 * fair), part_reads = std::max<int64_t>(1024, fair);
 #ifdef MIDAS_SNPS_SPLIT_READS   // developer variants only (tools/build_variant.sh)
   split_reads = MIDAS_SNPS_SPLIT_READS;
@@ -1389,14 +1389,14 @@ int32_t direct_prepare(midas_snps_batch* b) {
   // Coordinate-sorted input makes the streams add up to the reads plus the few that straddle a tile border.  Much more than
   // that (unsorted input, or one read with a reference span of many tiles), or one tile holding far more than a workgroup's
   // fair share (a coverage hot spot: the packed path cuts such a tile into parts), and the packed path is the faster one.
-  const int64_t fair = stream / (2 * (int64_t)ctx->prop.multiProcessorCount) + 1;
+  const int64_t fair = stream / (kWorkgroupsPerCU * (int64_t)ctx->prop.multiProcessorCount) + 1;
   const bool ordered = stream <= b->n_reads + b->n_reads / 2 + 4096;
   const bool hot = worst > std::max<int64_t>(2048, 2 * fair);
   b->path_auto = (ordered && !hot) ? MIDAS_SNPS_PATH_DIRECT : MIDAS_SNPS_PATH_PACKED;
   b->path = ctx->default_path == MIDAS_SNPS_PATH_AUTO ? b->path_auto : ctx->default_path;
 #if MIDAS_SNPS_DEBUG_BITS & 256
-  HIP_TRY(ctx, hipMalloc(&b->d_probe, (size_t)ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8 * 8));
-  HIP_TRY(ctx, hipMemset(b->d_probe, 0, (size_t)ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8 * 8));
+  HIP_TRY(ctx, hipMalloc(&b->d_probe, (size_t)ctx->prop.multiProcessorCount * kWorkgroupsPerCU * (kPileupBlock / 64) * 8 * 8));
+  HIP_TRY(ctx, hipMemset(b->d_probe, 0, (size_t)ctx->prop.multiProcessorCount * kWorkgroupsPerCU * (kPileupBlock / 64) * 8 * 8));
 #endif
   return MIDAS_SNPS_OK;
 }
@@ -1830,7 +1830,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.stats = work_stats(b); dp.err = work_err(b);
     dp.sched = b->d_ticket + b->n_tiles;
     dp.n_tiles = (int32_t)b->n_tiles; dp.n_reads = (int32_t)b->n_reads;
-    dp.grid_blocks = ctx->prop.multiProcessorCount * 2;
+    dp.grid_blocks = ctx->prop.multiProcessorCount * kWorkgroupsPerCU;
 #ifdef MIDAS_SNPS_GRID_BLOCKS
     dp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
 #endif
@@ -1891,7 +1891,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   pp.n_items = (int32_t)b->n_items;
   pp.n_whole_items = (int32_t)b->n_whole_items;
   pp.n_reads = (int32_t)b->n_records;
-  pp.grid_blocks = ctx->prop.multiProcessorCount * 2;
+  pp.grid_blocks = ctx->prop.multiProcessorCount * kWorkgroupsPerCU;
 #ifdef MIDAS_SNPS_GRID_BLOCKS   // developer variants only (tools/build_variant.sh)
   pp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
 #endif
@@ -2158,7 +2158,7 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
 // developer builds only: the direct pileup kernel's per-wave cycle counts of the last run (8 words per wave)
 int32_t midas_snps_debug_probe(midas_snps_batch* b, unsigned long long* out, int64_t n_words) {
   if (!b || !out || !b->d_probe) return MIDAS_SNPS_ERR_INVALID_ARG;
-  const int64_t have = (int64_t)b->ctx->prop.multiProcessorCount * 2 * (kPileupBlock / 64) * 8;
+  const int64_t have = (int64_t)b->ctx->prop.multiProcessorCount * kWorkgroupsPerCU * (kPileupBlock / 64) * 8;
   HIP_TRY(b->ctx, hipDeviceSynchronize());
   HIP_TRY(b->ctx, hipMemcpy(out, b->d_probe, (size_t)std::min(have, n_words) * 8, hipMemcpyDeviceToHost));
   return MIDAS_SNPS_OK;

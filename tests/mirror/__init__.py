@@ -13,7 +13,7 @@ from midas_amd import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libmidas_snps_mirror.so")
-TILE_SITES = 4096          # the library's tile (midas_amd/csrc/kernels.h kTileSites)
+TILE_SITES = 2048          # the library's tile (midas_amd/csrc/kernels.h kTileSites)
 
 
 def build(force=False):

@@ -495,7 +495,7 @@ int32_t midas_mirror_pack_reads(const midas_snps_reads* reads, const midas_snps_
   return st;
 }
 
-// the same in the tile order of a batch (tile_sites = the library's tile: 4096): what batch_create's device packer must produce
+// the same in the tile order of a batch (tile_sites = the library's tile: 2048): what batch_create's device packer must produce
 int32_t midas_mirror_pack_reads_tiled(const midas_snps_reads* reads, const midas_snps_contigs* contigs, int32_t pad_rule, int32_t tile_sites,
                                       void* rec16, void* blob, int64_t blob_capacity, uint32_t* orig_index, uint32_t* key,
                                       int64_t* out_blob_bytes, int64_t* out_n_records, int32_t* out_max_l_seq, char* err256) {
