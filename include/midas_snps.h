@@ -213,7 +213,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
 void midas_snps_batch_destroy(midas_snps_batch* batch);
 /* The two device paths of a batch.  DIRECT: the pileup kernel reads the batch's BAM-native arrays where they are -- 4-bit
  * SEQ, QUAL, CIGAR and the per-read columns -- and visits every read once: a pass over the positions alone (4 bytes per
- * read) finds, per 4096-site tile, the run of reads that can touch it; the kernel decides in registers what a read's CIGAR
+ * read) finds, per 2048-site tile, the run of reads that can touch it; the kernel decides in registers what a read's CIGAR
  * is and tallies it; nothing is sorted, copied or described beforehand.  It wants position-sorted reads (what samtools sort
  * writes; any order is CORRECT, only slower).  PACKED: the reads are first laid out in tile order as records + one byte per
  * base (midas_snps_batch_pack), which handles any order and cuts coverage hot spots into parts.  batch_create picks DIRECT

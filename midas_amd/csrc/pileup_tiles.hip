@@ -7,8 +7,8 @@
 //   depth / covered / total_depth   midas/run/snps.py:204-213
 //   str(rec.seq).upper()            midas/run/snps.py:62
 //
-// Work decomposition.  The site space is cut into tiles of <= 4096 sites that never span contigs.  A
-// persistent 512-thread workgroup takes tiles blockIdx, blockIdx + grid, then whatever a per-XCD counter hands it
+// Work decomposition.  The site space is cut into tiles of <= 2048 sites that never span contigs.  A
+// persistent 256-thread workgroup (four per CU) takes tiles blockIdx, blockIdx + grid, then whatever a per-XCD counter hands it
 // (a hot-spot tile comes as several parts, accumulated with global atomics by a second instantiation); a tile's tallies live in
 // LDS as [site][A,C,G,T] u32, reads are streamed straight from the packed HBM arrays through a
 // two-deep register prefetch pipeline, tallies are LDS atomics, and the tile is written out once,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kPileupBlock, 4) void pileup_tiles_kernel(PileupPar
 
       // ---- CIGAR walk ([EXT] get_aligned_pairs(matches_only=True)): one match segment at a time -----
       // 32-bit saturating positions: a query position only matters below q1 <= 1024 and a tile-relative
-      // reference position only below 4096, and both only ever grow.
+      // reference position only below the tile length, and both only ever grow.
       int k = k0;
       int qpos = lead_s;
       const int q1 = q0 + nvalid;
