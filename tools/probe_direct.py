@@ -33,7 +33,7 @@ def main():
     tm = [b.timing(i) for i in range(8)]
     print("probe build: index %.4f ms pileup %.4f ms" % (np.mean([t['index_ms'] for t in tm]), np.mean([t['pileup_ms'] for t in tm])))
     lib = abi.load_library()
-    n = 256 * 2 * 8 * 8
+    n = 256 * 4 * 4 * 8          # CUs x workgroups per CU x waves per workgroup x words
     out = (C.c_ulonglong * n)()
     lib.midas_snps_debug_probe.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int64]
     st = lib.midas_snps_debug_probe(b._h, out, n)
@@ -53,7 +53,7 @@ def main():
     xcc = ((raw[:, 1] >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
     cu = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 15)
     cyc = raw[:, 6].astype(np.float64)
-    n_w = 8
+    n_w = 4
     wg_cyc = cyc.reshape(-1, n_w).max(axis=1)
     wg_cu = cu.reshape(-1, n_w)[:, 0]
     wg_xcc = xcc.reshape(-1, n_w)[:, 0]
