@@ -561,6 +561,13 @@ def main():
                             out["roofline"]["hbm_traffic_GBps"] = live["hbm_bytes_per_step"] / (step_kernels_ms * 1e-3) / 1e9
                             out["roofline"]["hbm_traffic_frac_of_ceiling_this_box"] = \
                                 out["roofline"]["hbm_traffic_GBps"] / out["roofline"]["ceiling_GBps_this_box"]
+                            # the step's traffic is a MIX of reads and writes: what this box gives each, one after the other
+                            # (an optimistic bound: its own copy kernel, half and half, stays below the sum of its parts)
+                            rd, wr = live.get("hbm_read_bytes"), live.get("hbm_write_bytes")
+                            if rd and wr and rates.get("read_GBps") and rates.get("write_GBps"):
+                                t_mix = rd / (rates["read_GBps"] * 1e9) + wr / (rates["write_GBps"] * 1e9)
+                                out["roofline"]["mixed_traffic_floor_ms_this_box"] = t_mix * 1e3
+                                out["roofline"]["frac_of_mixed_traffic_floor_this_box"] = t_mix * 1e3 / step_kernels_ms
         if world == 1 and not a.no_cpu:
             cb, cb_all, cb_species, ref = cpu_baseline(thr, contigs, reads, a.cpu_seconds)
             out["cpu_baseline"] = cb
