@@ -153,11 +153,11 @@ struct Stream { int rb, n0, total; };
 
 // Workgroup shape (developer sweeps: tools/build_variant.sh x -DMIDAS_DIRECT_BLOCK=384).
 #ifndef MIDAS_DIRECT_BLOCK
-#define MIDAS_DIRECT_BLOCK 512
+#define MIDAS_DIRECT_BLOCK 256
 #endif
 constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
 static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
-constexpr int kDirectWavesPerSimd = (2 * kDirectBlock / 64 + 3) / 4;      // two workgroups per CU
+constexpr int kDirectWavesPerSimd = (kWorkgroupsPerCU * kDirectBlock / 64 + 3) / 4;
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
