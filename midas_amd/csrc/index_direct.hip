@@ -92,11 +92,11 @@ __global__ __launch_bounds__(kIdxBlock) void direct_ranges_kernel(DirectIndexPar
   const long long lo = (long long)blockIdx.x * kIdxRun;
   const long long hi = lo + kIdxRun < (long long)p.n_reads ? lo + kIdxRun : (long long)p.n_reads;
   if (lo >= hi) return;
-  // the contig of the workgroup's first read: one binary search per workgroup, the threads walk on from there
-  if (threadIdx.x == 0) s_c0 = contig_of_read(p, (int)lo);
-  __syncthreads();
+  // the contig of the workgroup's first read, as the facts pass left it (the batch does not change: a binary search of nine
+  // dependent loads per workgroup and pass was most of this kernel's 28 us); the threads walk on from there
+  (void)s_c0;
   ContigCursor cur;
-  cur.c = s_c0;
+  cur.c = p.block_contig[blockIdx.x];
   cur.fetch(p);
   const int lane = threadIdx.x & 63;
   constexpr int U = kIdxRun / kIdxBlock;
@@ -181,7 +181,10 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   __shared__ int s_c0;
   const long long lo = (long long)blockIdx.x * kIdxRun;
   const long long hi = lo + kIdxRun < (long long)p.n_reads ? lo + kIdxRun : (long long)p.n_reads;
-  if (threadIdx.x == 0 && lo < hi) s_c0 = contig_of_read(p, (int)lo);
+  if (threadIdx.x == 0 && lo < hi) {
+    s_c0 = contig_of_read(p, (int)lo);
+    p.block_contig[blockIdx.x] = s_c0;
+  }
   __syncthreads();
   unsigned long long alg = 0, status = kNoError;
   uint32_t maxl = 0, maxspan = 0, unsorted = 0, general = 0;

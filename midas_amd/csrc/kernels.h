@@ -190,6 +190,8 @@ struct DirectIndexParams {
   int32_t sorted;                                 // the facts pass found every contig's reads in position order
   int32_t reach;                                  // the longest reference span of the batch's reads: no read touches a site further from its start
   DirectFacts* facts;                             // [kDirectFactSlots] (facts pass only)
+  int32_t* block_contig;                          // [direct_index_blocks(n_reads)] the contig of a workgroup's first read: found by the facts
+                                                  // pass (one binary search per workgroup), read by every ranges pass
   unsigned long long* stats; unsigned long long* err;
   int32_t n_stat_words;
 };

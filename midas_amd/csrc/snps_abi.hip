@@ -101,6 +101,7 @@ struct midas_snps_batch {
   bool packed_built = false;    // rec / blob / orig / key exist (the packed path's layout is built on first use)
   uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
   DirectFacts* d_dfacts = nullptr;
+  int32_t* d_block_contig = nullptr;   // per workgroup of the direct path's index kernels: the contig of its first read
   unsigned long long* d_probe = nullptr;   // developer builds only (MIDAS_SNPS_DEBUG_BITS & 256)
   int64_t direct_general = 0;   // reads the pileup kernel walks op by op (facts pass)
   int32_t direct_reach = 1;     // longest reference span of a read: what a tile's range must reach back over
@@ -1160,7 +1161,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_probe,
+                 b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_block_contig, b->d_probe,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -1327,6 +1328,7 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->sorted = b->direct_sorted ? 1 : 0;
   ip->reach = b->direct_reach;
   ip->facts = b->d_dfacts;
+  ip->block_contig = b->d_block_contig;
   ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
   ip->n_stat_words = b->d_work ? b->n_species * MIDAS_STATS : 0;
 }
@@ -1339,6 +1341,8 @@ int32_t direct_prepare(midas_snps_batch* b) {
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
   HIP_TRY(ctx, hipMalloc(&b->d_trange, nt * 4 * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots));
+  HIP_TRY(ctx, hipMalloc(&b->d_block_contig, (size_t)direct_index_blocks(b->n_reads) * 4));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_block_contig, 0, (size_t)direct_index_blocks(b->n_reads) * 4, s));
   // tile bounds start clean (every pass resets the other parity's); counters at zero; status words at "no error"
   HIP_TRY(ctx, hipMemsetAsync(b->d_trange, 0, nt * 16, s));
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 0), 0xFF, nt * 4, s));
