@@ -1,6 +1,6 @@
-// gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM's own bytes: per read ONE 16-byte record (pos, l_seq,
-// n_cigar, NM, mapq, payload offset -- layout.h DirectRec) and its CIGAR / 4-bit SEQ / QUAL bytes as BAM lays them out, one
-// run per read -- nothing decoded, sorted or decided beforehand, ONE visit per read.  Integer counting: no MFMA.
+// gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM-native arrays themselves: 4-bit SEQ, QUAL, CIGAR and
+// the per-read columns where the decoder put them -- no packed payload, no sort, no per-read record, ONE visit per read.
+// Integer counting: no MFMA.
 //
 // Reference semantics implemented here (citations into /root/reference):
 //   keep_read                       midas/run/snps.py:141-162  (query_alignment_sequence :145, np.mean(query_qualities) :151)
@@ -19,9 +19,8 @@
 //
 // Lane mapping.  A lane owns LB (30 or 32) consecutive bases of a read's STORED query: two 16-byte loads of QUAL, one of
 // 4-bit SEQ (LB is even, so a lane's bases start on a byte).  A read of l_seq bases takes ceil(l_seq / LB) adjacent lanes
-// (5 for 150 bp).  Loads are issued two iterations (the read's record: one dwordx4) and one iteration (bases + the first four
-// CIGAR ops: four dwordx4 off ONE scalar base per wave-iteration -- the payload of the iteration's first read -- plus a 32-bit
-// lane offset) ahead of their use; none of them sits in a branch.
+// (5 for 150 bp).  Loads are issued two iterations (the read's columns: pos, l_seq, NM, mapq, SEQ / QUAL / CIGAR offsets)
+// and one iteration (bases + the first four CIGAR ops) ahead of their use; none of them sits in a branch.
 //
 // Per read.  The lanes of a read decide in registers what its CIGAR is: ONE or TWO gap-free match runs (direct_common.h
 // ReadShape: clips, at most one insertion / deletion / skip -- what an aligner writes for nearly every read) are tallied
@@ -34,8 +33,7 @@
 // for A/C/G/T, 0xFF for anything else) and the byte offset of the base's counter.  Then per base one SDWA compare
 // `qual.byte > threshold.byte` into a lane mask (the byte selects of the two operands are independent, so the even / odd
 // order of the looked-up bytes costs nothing), one SDWA OR forming the LDS address, one returnless ds_add under the mask.
-// Clipping (soft clips, segment borders, tile edges, the read's tail) zeroes the 4-bit codes of the bases outside (code 0 is
-// no base: its threshold byte is 0xFF): two rows of a nibble-mask table from LDS per partial pass.
+// Clipping (soft clips, segment borders, tile edges, the read's tail) ORs 0xFF into threshold bytes: two table rows from LDS.
 // The read's mean quality is v_sad_u8 over the lane's bytes and a sum over the read's lanes; sum(q) < readq * l_seq is the
 // reference's np.mean(q) < readq exactly.
 #include "direct_common.h"
@@ -150,6 +148,8 @@ constexpr int kDirectBlock = MIDAS_DIRECT_BLOCK;
 static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1024, "whole wavefronts");
 constexpr int kDirectWavesPerSimd = (kWorkgroupsPerCU * kDirectBlock / 64 + 3) / 4;      // four workgroups per CU
 
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
 template <int LB, bool BQ0>
 __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   constexpr int NWAVES = kDirectBlock / 64;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_khi[33 * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's four SEQ words
-  __shared__ __attribute__((aligned(16))) uint32_t s_klo[33 * 4];   // [l][w]: 0xF in the nibbles of the bases j >= l
+  __shared__ __attribute__((aligned(16))) uint32_t s_mhi[33 * 8];   // [h][w]: 0xFF in the bytes of the bases j >= h
+  __shared__ __attribute__((aligned(16))) uint32_t s_mlo[33 * 8];   // [l][w]: 0xFF in the bytes of the bases j <  l
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
@@ -193,17 +193,16 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       s_tables[i] = p.filt->min_match[i];
       s_tables[p.table_len + i] = p.filt->min_align[i];
     }
-    for (int i = tid; i < 33 * 4; i += kDirectBlock) {
-      const int h = i >> 2, wd = i & 3;
-      uint32_t kh = 0, kl = 0;
-      for (int k = 0; k < 8; ++k) {
-        const int j = 8 * wd + k;                              // base k of word wd: byte k / 2, the HIGH nibble when k is even
-        const uint32_t nib = 0xFu << (8 * (k >> 1) + ((k & 1) ? 0 : 4));
-        if (j < h) kh |= nib;
-        if (j >= h) kl |= nib;
+    for (int i = tid; i < 33 * 8; i += kDirectBlock) {
+      const int h = i >> 3, wd = i & 7;
+      uint32_t mh = 0, ml = 0;
+      for (int b = 0; b < 4; ++b) {
+        const int j = 8 * (wd >> 1) + 2 * b + (wd & 1);       // base held by byte b of word wd (even / odd split)
+        if (j >= h) mh |= 0xFFu << (8 * b);
+        if (j < h) ml |= 0xFFu << (8 * b);
       }
-      s_khi[i] = kh;
-      s_klo[i] = kl;
+      s_mhi[i] = mh;
+      s_mlo[i] = ml;
     }
     s_qsum[tid] = 0u;
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
@@ -272,27 +271,28 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4], auto sparse_tag) {
     constexpr bool SPARSE = decltype(sparse_tag)::value;
     const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
-    const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: the codes outside become 0
+    const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: 0xFF into the threshold bytes
     unsigned long long gmask[4];
     if (SPARSE) {
 #pragma unroll
       for (int S = 0; S < 4; ++S) gmask[S] = __ballot(go && lo < 8 * S + 8 && hi > 8 * S);
     }
     if (!go) return;                                                    // outside [lo, hi) (a row of each table, LDS)
-    uint4 keep = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (masked) {
-      const uint4 kh = *reinterpret_cast<const uint4*>(s_khi + 4 * (hi > 32 ? 32 : hi));
-      const uint4 kl = *reinterpret_cast<const uint4*>(s_klo + 4 * (lo < 0 ? 0 : lo));
-      keep.x = kh.x & kl.x; keep.y = kh.y & kl.y; keep.z = kh.z & kl.z; keep.w = kh.w & kl.w;
-    }
+    const uint32_t* mh = s_mhi + 8 * (hi > 32 ? 32 : hi);
+    const uint32_t* ml = s_mlo + 8 * (lo < 0 ? 0 : lo);
     auto group = [&](auto sidx, auto off, auto nbases) {
       constexpr int S = decltype(sidx)::value;
       if (SPARSE && gmask[S] == 0ull) return;
-      const uint32_t x = masked ? (sq[S] & (S == 0 ? keep.x : (S == 1 ? keep.y : (S == 2 ? keep.z : keep.w)))) : sq[S];
+      const uint32_t x = sq[S];
       const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
       const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
-      const uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
+      uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
       const uint32_t ce = __builtin_amdgcn_perm(cd_hi, cd_lo, se), co = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
+      if (masked) {
+        const uint2 h = *reinterpret_cast<const uint2*>(mh + 2 * S), l = *reinterpret_cast<const uint2*>(ml + 2 * S);
+        te |= h.x | l.x;
+        to |= h.y | l.y;
+      }
       tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
     };
     using std::integral_constant;
@@ -302,46 +302,49 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
   };
 
-  // ---- stage F: the record of this lane's read in wave-iteration `it` of a tile's stream: ONE dwordx4.  Raw loads: nothing is
-  // computed from them here, and NO load sits in a branch -- a lane without a read fetches read 0's record, a lane without
-  // bases the first bytes of the iteration's payload -- so that the compiler can count the loads in flight (a load in a branch
-  // makes it wait for every outstanding load, vmcnt(0), before the first use of any of them: the prefetch of the next
-  // iteration's bases would be waited for at once).
-  struct Raw { uint32_t pos, l_nc, nmq, off; };
-  const uint4* const recs = reinterpret_cast<const uint4*>(p.rec);
+  // ---- stage F: the columns of this lane's read in wave-iteration `it` of a tile's stream.  Raw loads: nothing is computed
+  // from them here, and NO load sits in a branch -- a lane without a read fetches read 0's columns, a lane without bases the
+  // first bytes of the arrays -- so that the compiler can count the loads in flight (a load in a branch makes it wait for
+  // every outstanding load, vmcnt(0), before the first use of any of them: the prefetch of the next iteration's bases would
+  // be waited for at once).
+  struct Raw { uint32_t pos, l, nm, mapq, so_lo, so_hi, qo_lo, qo_hi, co_lo, co_hi, co1_lo; };
   auto fetch = [&](const Stream& st, int it) -> Raw {
-    const uint32_t v = (uint32_t)(it * rpw) + (uint32_t)g;       // (a stream holds fewer than 2^31 reads, it * rpw <= n0 + 63)
-    const uint32_t r = v < (uint32_t)st.n0 ? (uint32_t)st.rb + v : 0u;
-    const uint4 x = recs[r];
+    const long long v = (long long)it * rpw + g;
+    const size_t r = v < (long long)st.n0 ? (size_t)((long long)st.rb + v) : (size_t)0;
     Raw f;
-    f.pos = x.x; f.l_nc = x.y; f.nmq = x.z; f.off = x.w;
+    f.pos = (uint32_t)p.pos[r];
+    f.l = (uint32_t)p.l_seq[r];
+    f.nm = (uint32_t)p.nm[r];
+    f.mapq = p.mapq[r];
+    const u32x2_a8 so = *reinterpret_cast<const u32x2_a8*>(p.seq_off + r);
+    const u32x2_a8 qo = *reinterpret_cast<const u32x2_a8*>(p.qual_off + r);
+    const u32x3_a4 co = *reinterpret_cast<const u32x3_a4*>(p.cigar_off + r);      // cigar_off[r] and the low word of cigar_off[r + 1]
+    f.so_lo = so.x; f.so_hi = so.y; f.qo_lo = qo.x; f.qo_hi = qo.y; f.co_lo = co.x; f.co_hi = co.y; f.co1_lo = co.z;
     return f;
   };
-  // ---- stage D: what the read's processing needs of its record, and the lane's bases (two 16-byte loads of QUAL, one of
-  // SEQ) + the read's first four CIGAR ops (one 16-byte load; the payload has slack behind its last read).  The four loads go
-  // off ONE scalar base -- the payload of the iteration's first read (lane 0's) -- plus a 32-bit lane offset: the reads of an
-  // iteration are neighbours in the payload.
+  // ---- stage D: what the read's processing needs of its columns, and the lane's bases (two 16-byte loads of QUAL, one of
+  // SEQ) + the read's first four CIGAR ops (one 16-byte load; the array has slack behind its last op)
   //   nmq: NM (16 bits, 0xFFFF = no NM tag) | mapq << 16 | kGenIdle << 24 (a lane without a read)      l_nc: l_seq | n_cigar << 16
   struct Rd { uint32_t pos, nmq, l_nc; };
   struct Dat { uint32_t q[8]; uint32_t s[4]; uint32_t cg[4]; };
   auto settle = [&](const Raw& f, int n_reads_it, Rd& r, Dat& d) {
     const bool act = g < n_reads_it;
-    const uint32_t l_nc = act ? f.l_nc : 0u;
+    const uint32_t l = act ? f.l : 0u;
+    const uint32_t nc = act ? f.co1_lo - f.co_lo : 0u;          // (<= 65534, checked when the batch was made)
     r.pos = f.pos;
-    r.l_nc = l_nc;
-    r.nmq = act ? f.nmq : ((uint32_t)kGenIdle << 24);
-    const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.off);        // (lane 0: the iteration's first read, or read 0)
-    const uint8_t* const base = p.payload + ((unsigned long long)off0 << 3);
-    const uint32_t l = l_nc & 0xFFFFu, nc4 = (l_nc >> 16) << 2;
-    const uint32_t rel = (f.off - off0) << 3;                          // (an iteration's reads lie within a few hundred KB)
-    const bool has = (uint32_t)q0 < l && !(kDebug & 128);
-    const uint32_t vc = act && !(kDebug & 128) ? rel : 0u;
-    const uint32_t vs = has ? rel + nc4 + (uint32_t)(q0 >> 1) : 0u;
-    const uint32_t vq = has ? rel + nc4 + ((l + 1u) >> 1) + (uint32_t)q0 : 0u;
-    const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(base + (size_t)vq);
-    const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(base + (size_t)vq + 16);
-    const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(base + (size_t)vs);
-    const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(base + (size_t)vc);
+    r.l_nc = l | (nc << 16);
+    r.nmq = ((int32_t)f.nm < 0 ? 0xFFFFu : f.nm) | ((f.mapq & 0xFFu) << 16) | (act ? 0u : (uint32_t)kGenIdle << 24);
+    const unsigned long long so = (unsigned long long)f.so_lo | ((unsigned long long)f.so_hi << 32);
+    const unsigned long long qo = (unsigned long long)f.qo_lo | ((unsigned long long)f.qo_hi << 32);
+    const unsigned long long co = (unsigned long long)f.co_lo | ((unsigned long long)f.co_hi << 32);
+    const bool has = q0 < (int)l && !(kDebug & 128);
+    const uint8_t* qp = p.qual + (has ? qo + (unsigned long long)q0 : 0ull);
+    const uint8_t* sp = p.seq4 + (has ? so + (unsigned long long)(q0 >> 1) : 0ull);
+    const uint32_t* cp = p.cigar + (act && !(kDebug & 128) ? co : 0ull);
+    const u32x4_a1 qa = *reinterpret_cast<const u32x4_a1*>(qp);
+    const u32x4_a1 qb = *reinterpret_cast<const u32x4_a1*>(qp + 16);
+    const u32x4_a1 sv = *reinterpret_cast<const u32x4_a1*>(sp);
+    const u32x4_a4 cv = *reinterpret_cast<const u32x4_a4*>(cp);
     d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
     d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
     d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
         CigarView cg;
         cg.c0 = dat_cur.cg[0]; cg.c1 = dat_cur.cg[1]; cg.c2 = dat_cur.cg[2]; cg.c3 = dat_cur.cg[3];
-        cg.p = reinterpret_cast<const uint32_t*>(p.payload);
-        if (slow && nc > 4u) cg.p = reinterpret_cast<const uint32_t*>(p.payload + ((unsigned long long)p.rec[idx].off8 << 3));   // (only a CIGAR of more than four ops is read again)
+        cg.p = p.cigar;
+        if (slow && nc > 4u) cg.p = p.cigar + p.cigar_off[idx];      // (only a CIGAR of more than four ops is read again)
         const uint32_t ncs = slow ? nc : 0u;
         // [EXT] pysam query_alignment_start / _end -> len(aln.query_alignment_sequence) (midas/run/snps.py:145)
         long long qs = 0, qe = 0;

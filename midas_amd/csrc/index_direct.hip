@@ -250,12 +250,142 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   }
 }
 
+// ---- once per batch: the direct layout (layout.h DirectRec + payload) ------------------------------------------------------
+// A read's 41 bytes of columns in seven arrays become ONE 16-byte record and its CIGAR / SEQ / QUAL bytes ONE run of the
+// payload (BAM's own order), so that the pileup kernel finds everything a lane needs behind one dwordx4 load.  Every read was
+// validated by the facts pass before this runs.  Three launches: payload units per workgroup's reads, their scan (one
+// workgroup), records + gather.
+__device__ __forceinline__ uint32_t read_units(const DirectLayoutParams& p, long long i) {
+  return direct_payload_units((uint32_t)p.l_seq[i], (uint32_t)(p.cigar_off[i + 1] - p.cigar_off[i]));
+}
+
+__global__ __launch_bounds__(kIdxBlock) void direct_layout_units_kernel(DirectLayoutParams p) {
+  __shared__ unsigned long long red[4];
+  const long long lo = (long long)blockIdx.x * kIdxRun;
+  const long long hi = lo + kIdxRun < p.n_reads ? lo + kIdxRun : p.n_reads;
+  unsigned long long u = 0;
+  for (long long i = lo + threadIdx.x; i < hi; i += kIdxBlock) u += read_units(p, i);
+  u = block_sum(u, red);
+  if (threadIdx.x == 0) p.block_units[blockIdx.x] = u;
+}
+
+// exclusive scan of the workgroups' units, in place; [n_blocks] = all of them (one workgroup: a few thousand entries)
+__global__ __launch_bounds__(kIdxBlock) void direct_layout_scan_kernel(unsigned long long* v, int n_blocks) {
+  __shared__ unsigned long long part[kIdxBlock];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0ull;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += kIdxBlock) {
+    const int i = base + (int)threadIdx.x;
+    const unsigned long long x = i < n_blocks ? v[i] : 0ull;
+    part[threadIdx.x] = x;
+    __syncthreads();
+    for (int d = 1; d < kIdxBlock; d <<= 1) {       // (Hillis-Steele: 8 rounds of 256)
+      const unsigned long long y = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+      __syncthreads();
+      part[threadIdx.x] += y;
+      __syncthreads();
+    }
+    const unsigned long long c = carry;
+    if (i < n_blocks) v[i] = c + part[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == kIdxBlock - 1) carry = c + part[kIdxBlock - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) v[n_blocks] = carry;
+}
+
+typedef uint32_t lay_u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+// `len` bytes src -> dst by the 16 lanes of a group: whole 16-byte chunks by one (unaligned) load and store, the tail bytewise
+__device__ __forceinline__ void group_copy(uint8_t* dst, const uint8_t* src, uint32_t len, int gl) {
+  for (uint32_t k = (uint32_t)gl * 16u; k < len; k += 256u) {
+    if (k + 16u <= len) {
+      *reinterpret_cast<lay_u32x4_a1*>(dst + k) = *reinterpret_cast<const lay_u32x4_a1*>(src + k);
+    } else {
+      for (uint32_t j = k; j < len; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kIdxBlock) void direct_layout_fill_kernel(DirectLayoutParams p) {
+  constexpr int U = kIdxRun / kIdxBlock;
+  __shared__ uint32_t s_off[kIdxRun];            // a read's first unit, relative to the workgroup's
+  __shared__ uint32_t s_part[kIdxBlock];
+  const long long lo = (long long)blockIdx.x * kIdxRun;
+  const long long hi = lo + kIdxRun < p.n_reads ? lo + kIdxRun : p.n_reads;
+  const unsigned long long base = p.block_units[blockIdx.x];
+  // thread t owns the reads lo + t * U ... (read order = payload order)
+  uint32_t units[U], sum = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long i = lo + (long long)threadIdx.x * U + u;
+    units[u] = i < hi ? read_units(p, i) : 0u;
+    sum += units[u];
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < kIdxBlock; d <<= 1) {
+    const uint32_t y = (int)threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += y;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - sum;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long i = lo + (long long)threadIdx.x * U + u;
+    s_off[threadIdx.x * U + u] = run;
+    if (i < hi) {
+      const int32_t nm = p.nm[i];
+      DirectRec r;
+      r.pos = p.pos[i];
+      r.l_nc = (uint32_t)p.l_seq[i] | ((uint32_t)(p.cigar_off[i + 1] - p.cigar_off[i]) << 16);
+      r.nmq = (nm < 0 ? (uint32_t)kNmAbsent : (uint32_t)nm) | ((uint32_t)p.mapq[i] << 16);
+      r.off8 = (uint32_t)(base + run);
+      p.rec[i] = r;
+    }
+    run += units[u];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {      // the sentinel: where the payload ends
+    DirectRec r;
+    r.pos = 0; r.l_nc = 0u; r.nmq = 0u; r.off8 = (uint32_t)(base + s_part[kIdxBlock - 1]);
+    p.rec[p.n_reads] = r;
+  }
+  __syncthreads();
+  // the bytes: a group of 16 lanes per read
+  const int grp = (int)(threadIdx.x >> 4), gl = (int)(threadIdx.x & 15);
+  for (long long i = lo + grp; i < hi; i += kIdxBlock / 16) {
+    const uint32_t l = (uint32_t)p.l_seq[i];
+    const long long co = p.cigar_off[i];
+    const uint32_t nc4 = 4u * (uint32_t)(p.cigar_off[i + 1] - co), sl = (l + 1u) >> 1;
+    uint8_t* dst = p.payload + 8ull * (base + s_off[(int)(i - lo)]);
+    group_copy(dst, reinterpret_cast<const uint8_t*>(p.cigar + co), nc4, gl);
+    group_copy(dst + nc4, p.seq4 + p.seq_off[i], sl, gl);
+    group_copy(dst + nc4 + sl, p.qual + p.qual_off[i], l, gl);
+    const uint32_t used = nc4 + sl + l, room = (used + 7u) & ~7u;
+    if (gl == 0)
+      for (uint32_t j = used; j < room; ++j) dst[j] = 0;
+  }
+}
+
 }  // namespace
 
 int direct_index_blocks(int64_t n_reads) { return n_reads > 0 ? (int)((n_reads + kIdxRun - 1) / kIdxRun) : 1; }
 
 hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s) {
   hipLaunchKernelGGL(direct_facts_kernel, dim3(direct_index_blocks(p.n_reads)), dim3(kIdxBlock), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_direct_layout_sizes(const DirectLayoutParams& p, hipStream_t s) {
+  const int nb = direct_index_blocks(p.n_reads);
+  hipLaunchKernelGGL(direct_layout_units_kernel, dim3(nb), dim3(kIdxBlock), 0, s, p);
+  hipLaunchKernelGGL(direct_layout_scan_kernel, dim3(1), dim3(kIdxBlock), 0, s, p.block_units, nb);
+  return hipGetLastError();
+}
+
+hipError_t launch_direct_layout_fill(const DirectLayoutParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(direct_layout_fill_kernel, dim3(direct_index_blocks(p.n_reads)), dim3(kIdxBlock), 0, s, p);
   return hipGetLastError();
 }
 

@@ -196,7 +196,21 @@ struct DirectIndexParams {
   int32_t n_stat_words;
 };
 
+// the direct layout (layout.h DirectRec + payload), built once per batch from the caller's arrays
+struct DirectLayoutParams {
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
+  const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
+  int64_t n_reads;
+  unsigned long long* block_units;                // [direct_index_blocks(n_reads) + 1] payload units per workgroup's reads, then their exclusive scan
+  DirectRec* rec;                                 // [n_reads + 1] (the last one a sentinel: off8 = all units)
+  uint8_t* payload;
+};
+
 struct DirectParams {
+  const DirectRec* rec;                           // [n_reads + 1]
+  const uint8_t* payload;                         // per read [cigar][seq][qual], 8-byte aligned (64 bytes of slack behind the last)
+  // (the caller's arrays: read by developer variants of the kernel only)
   const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
   const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
   const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
@@ -299,6 +313,8 @@ size_t bam_scan_scratch_bytes(long long n_records);
 hipError_t launch_bam_columns(const BamColumnsParams& p, long long* scan_scratch, hipStream_t s);
 
 hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s);       // once per batch: validation, totals
+hipError_t launch_direct_layout_sizes(const DirectLayoutParams& p, hipStream_t s);   // once per batch: payload units per workgroup + their scan
+hipError_t launch_direct_layout_fill(const DirectLayoutParams& p, hipStream_t s);    // once per batch: records + payload
 hipError_t launch_direct_ranges(const DirectIndexParams& p, hipStream_t s);      // every pass: the tile ranges, from the positions
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);

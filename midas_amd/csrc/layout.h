@@ -110,6 +110,23 @@ __host__ __device__ inline uint32_t blob_bytes(uint32_t l_seq, uint32_t n_cigar_
   return (blob_cigar_off(l_seq, bases) + 4u * n_cigar_stored + 7u) & ~7u;
 }
 
+// ---- direct path (index_direct.hip + pileup_direct.hip) ------------------------------------------------------------------
+// One 16-byte record per read -- the 16 fixed bytes SURVEY 8(d) counts per read -- and the read's variable part in BAM order,
+// `[cigar 4 * n_cigar][seq ceil(l / 2)][qual l]`, padded to 8 bytes, reads back to back in input order: ONE dwordx4 load
+// gives a lane everything it needs to find its bases.  Built once per batch from the caller's arrays (direct_layout_kernel);
+// a re-encoding of columns and a gather of bytes, nothing is decided in it (no CIGAR shape, no filter outcome).
+struct DirectRec {          // 16 bytes, 16-byte aligned
+  int32_t pos;              // BAM pos (0-based leftmost)
+  uint32_t l_nc;            // l_seq (bits 0-15) | n_cigar << 16
+  uint32_t nmq;             // NM (bits 0-15, kNmAbsent = no tag) | mapq << 16 ; bits 24-31 zero (the kernel's own lane flags)
+  uint32_t off8;            // the read's payload, in 8-byte units
+};
+static_assert(sizeof(DirectRec) == 16, "DirectRec must be 16 bytes");
+__host__ __device__ inline uint32_t direct_payload_units(uint32_t l_seq, uint32_t n_cigar) {     // 8-byte units of one read
+  return (4u * n_cigar + ((l_seq + 1u) >> 1) + l_seq + 7u) >> 3;
+}
+constexpr unsigned long long kMaxDirectPayloadUnits = 0xFFFFFFFFull;    // 32 GiB per batch
+
 // Error word written by the kernels: (read_index << 8) | kind, reduced with atomicMin.
 constexpr unsigned long long kNoError = ~0ull;
 

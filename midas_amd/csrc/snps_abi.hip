@@ -102,6 +102,10 @@ struct midas_snps_batch {
   uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
   DirectFacts* d_dfacts = nullptr;
   int32_t* d_block_contig = nullptr;   // per workgroup of the direct path's index kernels: the contig of its first read
+  DirectRec* d_drec = nullptr;         // [n_reads + 1] the direct layout: one 16-byte record per read ...
+  uint8_t* d_dpay = nullptr;           // ... and its CIGAR / SEQ / QUAL bytes as one run (layout.h)
+  unsigned long long* d_dunits = nullptr;   // (scratch of the layout's scan)
+  int64_t direct_payload_bytes = 0;
   unsigned long long* d_probe = nullptr;   // developer builds only (MIDAS_SNPS_DEBUG_BITS & 256)
   int64_t direct_general = 0;   // reads the pileup kernel walks op by op (facts pass)
   int32_t direct_reach = 1;     // longest reference span of a read: what a tile's range must reach back over
@@ -1161,7 +1165,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
-                 b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_block_contig, b->d_probe,
+                 b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_block_contig, b->d_probe, b->d_drec, b->d_dpay, b->d_dunits,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -1373,6 +1377,39 @@ int32_t direct_prepare(midas_snps_batch* b) {
   b->alg_bytes = (int64_t)alg + 17 * b->n_sites;
   b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
   b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;
+  // the direct layout: one 16-byte record per read and its CIGAR / SEQ / QUAL bytes as one run of the payload (every read
+  // was validated above)
+  {
+    const size_t n1 = (size_t)(b->n_reads > 0 ? b->n_reads : 1);
+    const int nb = direct_index_blocks(b->n_reads);
+    HIP_TRY(ctx, hipMalloc(&b->d_drec, (n1 + 1) * sizeof(DirectRec)));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_drec, 0, (n1 + 1) * sizeof(DirectRec), s));
+    HIP_TRY(ctx, hipMalloc(&b->d_dunits, ((size_t)nb + 1) * 8));
+    DirectLayoutParams lp;
+    lp.pos = b->d_pos; lp.mapq = b->d_mapq; lp.nm = b->d_nm; lp.l_seq = b->d_lseq;
+    lp.seq_off = b->d_seq_off; lp.qual_off = b->d_qual_off; lp.cigar_off = b->d_cigar_off;
+    lp.seq4 = b->d_seq4; lp.qual = b->d_qual; lp.cigar = b->d_cigar;
+    lp.n_reads = b->n_reads;
+    lp.block_units = b->d_dunits;
+    lp.rec = b->d_drec;
+    lp.payload = nullptr;
+    unsigned long long units = 0;
+    if (b->n_reads > 0) {
+      HIP_TRY(ctx, launch_direct_layout_sizes(lp, s));
+      HIP_TRY(ctx, hipMemcpyAsync(&units, b->d_dunits + nb, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    if (units > kMaxDirectPayloadUnits) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "read payload of %llu bytes exceeds the 32 GiB a batch can address", units * 8ull);
+      return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, buf);
+    }
+    b->direct_payload_bytes = (int64_t)(units * 8ull);
+    HIP_TRY(ctx, hipMalloc(&b->d_dpay, (size_t)b->direct_payload_bytes + 64));      // slack: a lane's 16-byte loads may overhang
+    HIP_TRY(ctx, hipMemsetAsync(b->d_dpay + b->direct_payload_bytes, 0, 64, s));
+    lp.payload = b->d_dpay;
+    if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_layout_fill(lp, s));
+  }
   // the tile ranges once, to see how well the reads are ordered: a tile's stream holds every read between the first and the
   // last that can touch it
   fill_direct_index(b, &ip);
@@ -1822,6 +1859,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     HIP_TRY(ctx, launch_direct_ranges(dip, s));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     DirectParams dp;
+    dp.rec = b->d_drec; dp.payload = b->d_dpay;
     dp.pos = b->d_pos; dp.mapq = b->d_mapq; dp.nm = b->d_nm; dp.l_seq = b->d_lseq;
     dp.seq_off = b->d_seq_off; dp.qual_off = b->d_qual_off; dp.cigar_off = b->d_cigar_off;
     dp.seq4 = b->d_seq4; dp.qual = b->d_qual; dp.cigar = b->d_cigar;
