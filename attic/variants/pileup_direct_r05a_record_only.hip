@@ -51,13 +51,6 @@ using namespace direct;
 
 namespace {
 
-// (developer listings: hipcc -S -DMIDAS_ISA_MARKS puts `; MARK name` lines into the assembly, tools/isa/segments.py counts between them)
-#ifdef MIDAS_ISA_MARKS
-#define MIDAS_MARK(name) asm volatile("; MARK " name)
-#else
-#define MIDAS_MARK(name) do { } while (0)
-#endif
-
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Eight bases of one lane: q0 / q1 two words of four quality bytes (bases in order), the / tho threshold bytes and cde / cdo
@@ -163,9 +156,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   constexpr int TILE = kTileSites;
   constexpr int NWAVES = kDirectBlock / 64;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
-  constexpr int OV = kDirectOverhang;       // sites behind the tile's last that the tallies also hold (see "chunks" below)
-  static_assert(OV <= kDirectBlock, "the overhang is moved by the write-out's first round");
-  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * (TILE + OV)];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_khi[33 * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's four SEQ words
   __shared__ __attribute__((aligned(16))) uint32_t s_klo[33 * 4];   // [l][w]: 0xF in the nibbles of the bases j >= l
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
@@ -176,18 +167,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Work items.  The tiles [0, n_chunked_tiles) are dealt in CHUNKS of chunk_tiles consecutive tiles, the rest one by one (the
-  // chip's last tens of microseconds need the fine grain).  Inside a chunk a read is visited ONCE, by the tile it starts in:
-  // what it adds behind that tile's last site lands in the OV sites the tallies hold beyond the tile and moves to the front
-  // when the workgroup goes on to the next tile (same contig).  Only a chunk's first tile streams the reads that reach in
-  // from the tile before it, as every tile did before (7.5 % of the reads seen twice at 2048 sites and 150 bp; a quarter of
-  // that with chunks of four).  The host asks for chunks when the reads are position-sorted and none spans more than OV sites.
-  const int K = p.chunk_tiles > 1 ? p.chunk_tiles : 1;
-  const int T4 = K > 1 ? p.n_chunked_tiles : 0;
-  const int n4 = T4 / K;
-  const int w_end = n4 + (p.n_tiles - T4);              // items
-  auto item_first = [&](int i) -> int { return i < n4 ? i * K : T4 + (i - n4); };
-  auto item_end = [&](int i) -> int { return i < n4 ? i * K + K : T4 + (i - n4) + 1; };
+  const int w_end = p.n_tiles;
 #ifdef MIDAS_DIRECT_STATIC
   const bool dynamic = false;       // (developer variant: tiles dealt round robin)
 #else
@@ -195,10 +175,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 #endif
   const int sched_group = (int)(blockIdx.x % kSchedGroups);
   uint32_t* const sched = p.sched;
-  if ((int)blockIdx.x >= w_end) return;
-  int c_first = item_first((int)blockIdx.x), c_end = item_end((int)blockIdx.x);      // the chunk in work: tiles [c_first, c_end)
-  int i_next = (int)blockIdx.x + (int)gridDim.x;                                      // the item after it (>= w_end: none)
-  i_next = i_next < w_end ? i_next : w_end;
+  int w = (int)blockIdx.x;
+  if (w >= w_end) return;
+  int w_next = w + (int)gridDim.x;
 #if MIDAS_SNPS_DEBUG_BITS & 256
   unsigned long long pr_cols = 0, pr_bases = 0, pr_work = 0, pr_sync = 0, pr_out = 0, pr_iters = 0;
   const unsigned long long pr_t0 = __builtin_readcyclecounter();
@@ -209,7 +188,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 
   {
     uint4* z = reinterpret_cast<uint4*>(lds);
-    for (int i = tid; i < TILE + OV; i += kDirectBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < TILE; i += kDirectBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < p.table_len; i += kDirectBlock) {
       s_tables[i] = p.filt->min_match[i];
       s_tables[p.table_len + i] = p.filt->min_align[i];
@@ -247,10 +226,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
   const ConstWords c_te = (ConstWords)(size_t)p.tend;
-  // (cin: the tile continues a chunk in its contig -- the reads that reach in from the tile before were tallied by that tile)
-  auto load_stream = [&](int tt, bool cin) -> Stream {
+  auto load_stream = [&](int tt) -> Stream {
     Stream s;
-    const uint32_t b = cin ? c_te[tt - 1] : c_tb[tt], e = c_te[tt];
+    const uint32_t b = c_tb[tt], e = c_te[tt];
     s.rb = e > b ? (int)b : 0;
     s.n0 = e > b ? (int)(e - b) : 0;
     s.total = (s.n0 + rpw - 1) / rpw;
@@ -370,8 +348,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
   };
 
-  Tile tile = load_tile(c_tiles, c_first);
-  Stream st = load_stream(c_first, false);
+  Tile tile = load_tile(c_tiles, w);
+  Stream st = load_stream(w);
   // The pipeline of a wave, in two register sets that swap roles every iteration (the loop below is unrolled by two: a copy
   // at its back edge would have to WAIT for the loads it copies -- the next iteration's bases, requested a moment ago):
   //   set A / B   one holds the iteration being tallied, the other the next one's bases (in flight)
@@ -392,16 +370,10 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 
   uint32_t acc_cov = 0u;                 // (a thread's sites between two flushes: far below 2^32)
   unsigned long long acc_depth = 0ull;
-  int t = c_first;
+  int t = w;
   for (;;) {
     const int tile_len = tile.len;
     const int tile_start = tile.start;
-    // the tile after this one: the chunk's next, or the next item's first
-    const bool in_chunk = t + 1 < c_end;
-    const bool more = in_chunk || i_next < w_end;
-    const int wn = in_chunk ? t + 1 : (more ? item_first(i_next) : t);
-    const bool cout = in_chunk && (int32_t)c_tiles[8 * (size_t)wn] == tile.contig;      // its first OV sites are tallied here
-    const int ext_len = tile_len + (cout ? OV : 0);
     const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
     constexpr int REF_IT = (TILE + 4 * kDirectBlock - 1) / (4 * kDirectBlock);
@@ -409,14 +381,13 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     // the column / base prefetch runs across the tile boundary (as in pileup_tiles.hip): a wave's last two iterations fetch
     // the columns of its first two iterations of the NEXT tile
     const int n_w = it_hi > wave ? (it_hi - wave + NWAVES - 1) / NWAVES : 0;
-    const bool xt = more && n_w >= 2;
+    const bool xt = w_next < w_end && n_w >= 2;
     Stream xs = st;
-    if (xt) xs = load_stream(wn, cout);
+    if (xt) xs = load_stream(w_next);
     // one wave-iteration: `it` of the tile's stream, the wave's k_it-th; tallies (rd_cur, dat_cur), requests the bases of the
     // next iteration into (rd_n, dat_n) from the columns rawX and then the columns of the one after it into rawX
     auto iteration = [&](int it, int k_it, Rd& rd_cur, Dat& dat_cur, Rd& rd_n, Dat& dat_n) {
       const unsigned long long pt0 = PROBE_NOW();
-      MIDAS_MARK("settle");
       settle(rawX, nrX, rd_n, dat_n);          // (the columns of the next iteration have arrived: its bases are requested ...)
       {                                        // ... then the columns of the one after it
         const int kf = k_it + 2;               // the wave's iteration (of this tile, or counted on into the next) to fetch for
@@ -439,7 +410,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[0]), "v"(rd_cur.pos));
         return;
       }
-      MIDAS_MARK("qsum");
       const int pos = (int)rd_cur.pos;
       const int l = (int)(rd_cur.l_nc & 0xFFFFu);
       const uint32_t nc = rd_cur.l_nc >> 16;
@@ -457,7 +427,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 
       // ---- the read's shape, in registers: one match op of the read's length settles most reads; anything else takes the
       // four-op grammar (wave-uniform branch) ------------------------------------------------------------------------------
-      MIDAS_MARK("shape");
       ReadShape sh;
       sh.lead = 0u; sh.m1 = (uint32_t)l; sh.ins = 0u; sh.del = 0u; sh.alen = (uint32_t)l;
       bool shaped = nc == 1u && op_is_match(dat_cur.cg[0] & 15u) && (dat_cur.cg[0] >> 4) == (uint32_t)l && l >= 1;
@@ -471,7 +440,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       const bool slow = act && !fast;
 
       // ======================= fast: one or two gap-free match runs ==========================================================
-      MIDAS_MARK("filter");
       const int lead = (int)sh.lead, align_len = (int)sh.alen;
       bool keep, owner;
       uint32_t err;
@@ -493,25 +461,22 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         int lo_a = lead - q0, hi_a = qa1 - q0, lo_b = qb0 - q0, hi_b = qb1 - q0;
         lo_a = lo_a > -loc_a ? lo_a : -loc_a;
         lo_a = lo_a > 0 ? lo_a : 0;
-        hi_a = hi_a < ext_len - loc_a ? hi_a : ext_len - loc_a;
+        hi_a = hi_a < tile_len - loc_a ? hi_a : tile_len - loc_a;
         hi_a = hi_a < nb ? hi_a : nb;
         lo_b = lo_b > -loc_b ? lo_b : -loc_b;
         lo_b = lo_b > 0 ? lo_b : 0;
-        hi_b = hi_b < ext_len - loc_b ? hi_b : ext_len - loc_b;
+        hi_b = hi_b < tile_len - loc_b ? hi_b : tile_len - loc_b;
         hi_b = hi_b < nb ? hi_b : nb;
         const bool go_a = keep && lo_a < hi_a, go_b = keep && lo_b < hi_b;
         // first pass: every lane its run (the lane that holds the indel: the part in front of it); second pass, only when a
         // lane of the wave has bases on both sides of an indel: the part behind it
         const bool go1 = go_a | go_b;
-        MIDAS_MARK("pass1");
         if (!(kDebug & 1) && __ballot(go1) != 0ull)
           tally_range(go1, go_a ? lo_a : lo_b, go_a ? hi_a : hi_b, go_a ? loc_a : loc_b, qv, dat_cur.s, std::false_type{});
         const bool go2 = go_a & go_b;
-        MIDAS_MARK("pass2");
         if (!(kDebug & (1 | 16)) && __ballot(go2) != 0ull) tally_range(go2, lo_b, hi_b, loc_b, qv, dat_cur.s, std::true_type{});
       }
       // ======================= slow: walked op by op ============================================================================
-      MIDAS_MARK("slowgate");
       if (__ballot(slow) != 0ull) {
         const uint32_t idx = (uint32_t)(st.rb + it * rpw + g);
         CigarView cg;
@@ -603,13 +568,12 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         if (walking) walking = next_segment();
         while (__ballot(walking) != 0ull) {
           const int lo = jlo > -loc0 ? jlo : -loc0;
-          const int hi = jhi < ext_len - loc0 ? jhi : ext_len - loc0;
+          const int hi = jhi < tile_len - loc0 ? jhi : tile_len - loc0;
           if (!(kDebug & 1)) tally_range(walking && lo < hi, lo, hi, loc0, qv, dat_cur.s, std::true_type{});
           walking = (walking && k < nc) ? next_segment() : false;
         }
       }
       // ---- per-species read counters: one ballot per wave ---------------------------------------------------------------
-      MIDAS_MARK("counters");
       const bool head = owner && c == 0;
       w_aligned += (uint32_t)__popcll(__ballot(head));
       w_mapped += (uint32_t)__popcll(__ballot(head && keep));
@@ -621,7 +585,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         atomicMin(p.err, ((unsigned long long)idx << 8) | err);
       }
 
-      MIDAS_MARK("iterend");
 #if MIDAS_SNPS_DEBUG_BITS & 256
       pr_work += PROBE_NOW() - pt2;
 #endif
@@ -657,10 +620,11 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       if (w_mapped) atomicAdd(&s_stats[MIDAS_STAT_MAPPED], (unsigned long long)w_mapped);
     }
     // ---- next tile ---------------------------------------------------------------------------------------------------------
-    const int tn = wn;
+    const int wn = w_next;
+    const bool more = wn < w_end;
+    const int tn = more ? wn : t;
     const Tile ntile = load_tile(c_tiles, tn);
-    const Stream nst = load_stream(tn, cout);
-    const bool take = more && !in_chunk;          // the next tile opens the next item: draw the one after it
+    const Stream nst = load_stream(tn);
     const unsigned long long ps0 = PROBE_NOW();
     if (more && !xt) {   // (with xt the pipeline already holds the next tile's first iterations)
       // (the columns are requested in front of the barrier, the bases behind it)
@@ -674,7 +638,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     }
     const unsigned long long ps1 = PROBE_NOW();
     uint32_t ticket = 0;
-    if (dynamic && take && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
+    if (dynamic && more && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
     // ---- emit the tile: counts[site][A,C,G,T] (and re-zero LDS), covered / total-depth partials ---------------------------
     {
@@ -686,12 +650,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         const int i = tid + it * kDirectBlock;
         if (i < lim) {
           const uint4 v = lds4[i];
-          if (it == 0 && cout && i < OV) {      // what this tile's reads added behind it opens the next tile
-            lds4[i] = lds4[TILE + i];
-            lds4[TILE + i] = make_uint4(0u, 0u, 0u, 0u);
-          } else {
-            lds4[i] = make_uint4(0u, 0u, 0u, 0u);
-          }
+          lds4[i] = make_uint4(0u, 0u, 0u, 0u);
           u32x4_a8 nv; nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
           __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_a8*>(out + i));
           const uint32_t d = v.x + v.y + v.z + v.w;
@@ -717,7 +676,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         }
       }
     }
-    if (dynamic && take && tid == 0) s_next_ticket = ticket;
+    if (dynamic && more && tid == 0) s_next_ticket = ticket;
     lds_barrier();       // tallies re-zeroed, this tile's s_stats additions done
 #if MIDAS_SNPS_DEBUG_BITS & 256
     pr_sync += ps1 - ps0;
@@ -725,12 +684,10 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 #else
     (void)ps0; (void)ps1;
 #endif
-    if (take) {
+    if (more) {
       const long long nn = dynamic ? 2ll * (long long)gridDim.x + (long long)kSchedGroups * s_next_ticket + sched_group
-                                   : (long long)i_next + (long long)gridDim.x;
-      c_first = item_first(i_next);
-      c_end = item_end(i_next);
-      i_next = __builtin_amdgcn_readfirstlane((int)(nn < (long long)w_end ? nn : (long long)w_end));
+                                   : (long long)wn + (long long)gridDim.x;
+      w_next = __builtin_amdgcn_readfirstlane((int)(nn < (long long)w_end ? nn : (long long)w_end));
     }
     const bool flush = !more || ntile.species != tile.species;   // workgroup-uniform
     if (flush) {
@@ -760,6 +717,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       }
       lds_barrier();     // s_stats reset before the next tile adds to it
     }
+    w = wn;
     t = tn;
     tile = ntile;
     st = nst;
@@ -788,9 +746,7 @@ int direct_lane_bases(int32_t max_l_seq) {
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
   const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
-  const int k = p.chunk_tiles > 1 ? p.chunk_tiles : 1;
-  const int n_items = k > 1 ? p.n_chunked_tiles / k + (p.n_tiles - p.n_chunked_tiles) : p.n_tiles;      // (every workgroup of the grid has work)
-  const int grid = n_items < p.grid_blocks ? n_items : p.grid_blocks;
+  const int grid = p.n_tiles < p.grid_blocks ? p.n_tiles : p.grid_blocks;
   const bool bq0 = p.baseq <= 0;
   if (lane_bases == 32) {
     if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);

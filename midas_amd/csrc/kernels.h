@@ -166,6 +166,13 @@ hipError_t launch_pack_scatter(const PackParams& p, hipStream_t s);             
 // Unsorted input only widens the ranges (slower, never wrong); the host falls back to the packed path when the ranges of a
 // batch add up to much more than its reads.
 constexpr uint32_t kGenIdle = 0x80;               // flag byte of a lane without a read
+// Chunks of the direct pileup kernel (pileup_direct.hip "Work items"): a workgroup takes kDirectChunkTiles consecutive tiles at
+// a time and carries what a tile's reads add behind its last site -- at most kDirectOverhang sites -- over to the next tile.
+#ifndef MIDAS_DIRECT_CHUNK
+#define MIDAS_DIRECT_CHUNK 4
+#endif
+constexpr int kDirectChunkTiles = MIDAS_DIRECT_CHUNK;
+constexpr int kDirectOverhang = 160;
 
 constexpr int kDirectFactSlots = 64;
 struct alignas(128) DirectFacts {                 // per-slot partial results of the facts pass (batch_create), added up by the host
@@ -226,6 +233,7 @@ struct DirectParams {
   int32_t lanes_per_read, reads_per_wave, table_len;
   int32_t baseq, mapq_min, readq;
   int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
+  int32_t chunk_tiles, n_chunked_tiles;           // tiles [0, n_chunked_tiles) are dealt in chunks of chunk_tiles (1: every tile by itself)
 };
 
 // device_sort.hip: the library's own exclusive scan of 32-bit counters and stable 8-bit-digit radix sort of (key, value) pairs

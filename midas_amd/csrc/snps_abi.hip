@@ -1405,8 +1405,9 @@ int32_t direct_prepare(midas_snps_batch* b) {
       return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, buf);
     }
     b->direct_payload_bytes = (int64_t)(units * 8ull);
-    HIP_TRY(ctx, hipMalloc(&b->d_dpay, (size_t)b->direct_payload_bytes + 64));      // slack: a lane's 16-byte loads may overhang
-    HIP_TRY(ctx, hipMemsetAsync(b->d_dpay + b->direct_payload_bytes, 0, 64, s));
+    constexpr size_t kPaySlack = 64;            // a lane's 16-byte loads may overhang the last read
+    HIP_TRY(ctx, hipMalloc(&b->d_dpay, (size_t)b->direct_payload_bytes + kPaySlack));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_dpay + b->direct_payload_bytes, 0, kPaySlack, s));
     lp.payload = b->d_dpay;
     if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_layout_fill(lp, s));
   }
@@ -1881,6 +1882,13 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.table_len = b->max_l_seq + 1;
     dp.baseq = thr->baseq; dp.mapq_min = thr->mapq; dp.readq = thr->readq;
     dp.pad_advances = b->pad_advances ? 1 : 0;
+    // chunks of consecutive tiles with a carried overhang (a read visited once): position-sorted reads none of which spans more
+    // than the overhang; the last eighth of the tiles one by one, so that the workgroups finish together
+    dp.chunk_tiles = 1; dp.n_chunked_tiles = 0;
+    if (kDirectChunkTiles > 1 && b->direct_sorted && b->direct_reach <= kDirectOverhang) {
+      dp.chunk_tiles = kDirectChunkTiles;
+      dp.n_chunked_tiles = (int32_t)((b->n_tiles - b->n_tiles / 8) / kDirectChunkTiles * kDirectChunkTiles);
+    }
     HIP_TRY(ctx, launch_pileup_direct(dp, b->direct_lane_bases, s));
     if (ev) {
       HIP_TRY(ctx, hipEventRecord(ev[2], s));
