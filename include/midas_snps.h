@@ -358,7 +358,9 @@ int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_
  * tables in LDS) instead of by the host's threads: the compressed bytes go up, the inflated stream comes back, records are
  * walked and decoded into columns by the host as before.  On a 16-CPU host inflating is two thirds of the pileup stage once
  * the pileup and the row coder are on the device; with eight ranks sharing a node's CPUs it is more.  Same results, same
- * statuses (a corrupt block: MIDAS_SNPS_ERR_BAD_LAYOUT); a device failure is an error, not a fall-back.
+ * statuses (a corrupt block: MIDAS_SNPS_ERR_BAD_LAYOUT).  At this boundary a device failure is a status (ERR_OUT_OF_MEMORY,
+ * ERR_HIP), never a silent fall-back; the Python host (midas_amd/run/snps.py, --device_inflate auto) answers those two with the
+ * host decode and passes every other status on.
  *   midas_bam_open_device          = midas_bam_open (whole file; then midas_bam_load as usual)
  *   midas_bam_open_slice_device    = midas_bam_open_slice with the slice's blocks inflated AND walked on the device (bam_walk.hip):
  *                                  what comes down is refID / pos / l_seq / reference span / offset of the slice's records, which

@@ -54,6 +54,18 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
 
 
+def _compile(obj, cmd, verbose):
+    """One object, written under a per-process name and renamed into place: ranks of one launch that all find the library
+    missing may compile the same source at once and none of them ever links a half-written object."""
+    tmp = obj + ".tmp.%d" % os.getpid()
+    try:
+        _run(cmd + [tmp], verbose)
+        os.replace(tmp, obj)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -83,12 +95,12 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, repl
         obj = os.path.join(obj_dir, s.replace(".", "_") + ".o")
         objs.append(obj)
         if force or variant or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
-            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-I", CSRC, "-x", "hip", "-c", src, "-o", obj])
+            jobs.append((obj, [hipcc] + FLAGS + list(extra_flags) + ["-I", CSRC, "-x", "hip", "-c", src, "-o"]))
     try:
         workers = max(1, min(len(jobs), (os.cpu_count() or 4)))
         if jobs:
             with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-                for f in [pool.submit(_run, j, verbose) for j in jobs]:
+                for f in [pool.submit(_compile, o, j, verbose) for (o, j) in jobs]:
                     f.result()
         tmp = out + ".tmp.%d" % os.getpid()
         try:

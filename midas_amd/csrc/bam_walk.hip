@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   const uint32_t w3 = rd32(r + 12), w4 = rd32(r + 16), l = rd32(r + 20);
   const uint32_t lrn = w3 & 0xFFu, n_cig = w4 & 0xFFFFu;
   const unsigned long long body = 32ull + lrn + 4ull * n_cig + (l + 1u) / 2u + l;
-  p.refid[i] = (int32_t)rd32(r + 4);
+  const int32_t refid = (int32_t)rd32(r + 4);
+  p.refid[i] = refid;
   p.pos[i] = (int32_t)rd32(r + 8);
   p.mapq[i] = (uint8_t)(w3 >> 8);
   p.flag[i] = (uint16_t)(w4 >> 16);
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   p.seq_off[i + 1] = (l + 1u) / 2u;
   p.qual_off[i + 1] = l;
   int32_t nm = -1;
-  if (body > bs) atomicMin(p.bad_record, (unsigned long long)i);
+  // (a chained walk checks block_size only: a record whose refID names no reference is caught here, as the host walk's
+  // plausible_record() catches it -- the host folds per-reference tables by it)
+  if (body > bs || refid < 0 || refid >= p.n_ref) atomicMin(p.bad_record, (unsigned long long)i);
   else nm = find_nm(r + 4 + body, r + 4 + bs);
   p.nm[i] = nm;
   if (p.span) {       // reference span: the lengths of the ops that consume reference (M, D, N, =, X)

@@ -354,10 +354,13 @@ int32_t genes_run(midas_snps_ctx* ctx, const midas_snps_thresholds* thr, const m
   }
   G_TRY(hipMemsetAsync(d_err, 0xFF, 8, s));
   if (sums) G_TRY(hipMemsetAsync(d_heavy, 0, 4, s));
-  hipEvent_t e0, e1;
-  G_TRY(hipEventCreate(&e0));
-  G_TRY(hipEventCreate(&e1));
-  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+  struct EvGuard {      // (constructed before either event exists: a failing second create must not leak the first)
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } evg;
+  G_TRY(hipEventCreate(&evg.a));
+  G_TRY(hipEventCreate(&evg.b));
+  const hipEvent_t e0 = evg.a, e1 = evg.b;
   unsigned long long err = ~0ull;
   G_TRY(hipEventRecord(e0, s));
   if (filter && n > 0) {

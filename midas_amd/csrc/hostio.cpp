@@ -1076,7 +1076,7 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
     if (bad_job >= 0 && (size_t)bad_job < blocks.size())
       set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", path, (long long)blocks[(size_t)bad_job].fpos);
     else if (bad_record >= 0)
-      set_err(err256, "%s: alignment record %lld overruns its block_size", path, (long long)bad_record);
+      set_err(err256, "%s: alignment record %lld overruns its block_size or names no reference of the header", path, (long long)bad_record);
     else if (bad_record == -2)
       set_err(err256, "%s: malformed alignment record (a block_size that leaves the stream)", path);
     return st;
@@ -1617,7 +1617,7 @@ int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecode
       if (bad_job >= 0 && (size_t)bad_job < job_block.size())
         set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", b->path.c_str(), (long long)m.blocks[job_block[(size_t)bad_job]].fpos);
       else if (bad_record >= 0)
-        set_err(err256, "%s: alignment record %lld overruns its block_size", b->path.c_str(), (long long)bad_record);
+        set_err(err256, "%s: alignment record %lld overruns its block_size or names no reference of the header", b->path.c_str(), (long long)bad_record);
       else
         set_err(err256, "%s: record range ends inside a record", b->path.c_str());
       return st;

@@ -310,10 +310,12 @@ struct BamWalkParams {
 };
 struct BamColumnsParams {
   const uint8_t* d; const unsigned long long* rec_off; long long n;
+  int32_t n_ref;                                    // references of the header: a kept record's refID must lie below it
   int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag;
   long long *seq_off, *qual_off, *cigar_off;        // n + 1 entries: lengths at [i + 1] here, CSR offsets after the scans
   int32_t* span;                                    // (nullable) reference span: the lengths of the record's M / D / N / = / X ops
-  unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size (~0: none)
+  unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size or whose
+                                                    // refID names no reference of the header (~0: none)
 };
 hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s);
 hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* base, unsigned long long* rec_off, hipStream_t s);

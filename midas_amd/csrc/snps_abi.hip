@@ -1021,7 +1021,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   const size_t n1 = (size_t)n + 1;
   unsigned long long* d_rec = reinterpret_cast<unsigned long long*>(take(n1 * 8));
   BamColumnsParams cp;
-  cp.d = base; cp.rec_off = d_rec; cp.n = n;
+  cp.d = base; cp.rec_off = d_rec; cp.n = n; cp.n_ref = n_ref;
   cp.refid = reinterpret_cast<int32_t*>(take(n1 * 4)); cp.pos = reinterpret_cast<int32_t*>(take(n1 * 4));
   cp.nm = reinterpret_cast<int32_t*>(take(n1 * 4)); cp.l_seq = reinterpret_cast<int32_t*>(take(n1 * 4));
   cp.mapq = take(n1); cp.flag = reinterpret_cast<uint16_t*>(take(n1 * 2));

@@ -238,6 +238,9 @@ def _count_below_the_species(args, species, genes, ctx, mine, owner, sl):
     dist.agree_or_exit(error)
     # gene (header index) -> the rank that owns its species; -1: not in the database (no read is on such a gene, checked above)
     ref_owner = np.array([owner[genes[n].species_id] if n in genes else -1 for n in ref_names], dtype=np.int64)
+    # (every record of a slice is on a gene of the header and of the database: _missing_gene_check and midas_genes_terms said so
+    # above -- a negative index here would silently wrap)
+    assert n_local == 0 or (int(refid.min()) >= 0 and int(ref_owner[refid].min()) >= 0), "record on no gene of the database"
     dest = ref_owner[refid] if n_local else np.zeros(0, np.int64)
     order = np.argsort(dest, kind='stable')           # (stable: file order survives inside a destination)
     cuts = np.searchsorted(dest[order], np.arange(ws + 1))
@@ -255,8 +258,12 @@ def _count_below_the_species(args, species, genes, ctx, mine, owner, sl):
         error = "\nError: %s\n" % e.message
     dist.agree_or_exit(error)
     fold_counts(species, genes, gene_ids, aligned, mapped, depth)
-    print("  total aligned reads: %s" % sum(sp.aligned_reads for sp in species.values()))
-    print("  total mapped reads: %s" % sum(sp.mapped_reads for sp in species.values()))
+    # the sample's totals (midas/run/genes.py:196-197 prints them once): every rank holds its own species' share
+    totals = dist.all_gather_i64([sum(sp.aligned_reads for sp in species.values() if sp.id in mine),
+                                  sum(sp.mapped_reads for sp in species.values() if sp.id in mine)]).sum(axis=0)
+    if rank == 0:
+        print("  total aligned reads: %s" % int(totals[0]))
+        print("  total mapped reads: %s" % int(totals[1]))
     return 0.0
 
 

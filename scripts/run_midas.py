@@ -146,8 +146,10 @@ def build_parser():
     parser.add_argument('--split_length', type=int, default=8 << 20, metavar='INT',
                         help="under torchrun, contigs longer than this are dealt to the GPUs in pieces (0: never; default 8 Mb)")
     parser.add_argument('--device_inflate', choices=('auto', 'on', 'off'), default='auto',
-                        help="inflate the BAM's blocks on the GPU instead of with the host's threads; auto (default): for one "
-                             "rank and a BAM of 0.5-8 GB")
+                        help="inflate the BAM's blocks on the GPU instead of with the host's threads; auto (default): for one rank "
+                             "and a BAM of at least 0.5 GB whose decode fits the device's memory (twelve times the file), and for a "
+                             "rank that has few CPUs; in auto a device that cannot (out of memory, HIP error) hands over to the host's "
+                             "threads, with 'on' that is an error")
     parser.add_argument('--pad_rule', choices=('pysam', 'spec'), default='pysam',
                         help="what the CIGAR op P does to the query position in the pileup: pysam (default) = it advances, as in\n"
                              "get_aligned_pairs of the pysam releases MIDAS runs on; spec = nothing, the SAM specification's rule.\n"
