@@ -844,7 +844,9 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
     while (p + 4 <= total && p < stop) {
       const size_t bs = rd32(&d[p]);
       if (bs < 32 || p + 4 + bs > total) { pc.bad = true; pc.bad_at = p; break; }
-      if ((int32_t)rd32(&d[p + 4]) >= 0) {
+      const int32_t rid = (int32_t)rd32(&d[p + 4]);
+      if (rid >= (int32_t)ref_lens.size()) { pc.bad = true; pc.bad_at = p; break; }      // (names no reference of the header)
+      if (rid >= 0) {
         pc.offs.push_back(p);
         if (want_heads) {
           uint32_t w[kHeadWords];
@@ -862,7 +864,7 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
   if (n_pieces < 2) {
     Piece all;
     walk(rec_begin, total, all);
-    if (all.bad) { set_err(err256, "%s: truncated alignment record at byte %lld", path, (long long)all.bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    if (all.bad) { set_err(err256, "%s: truncated or malformed alignment record at byte %lld", path, (long long)all.bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
     offs.swap(all.offs);
     if (want_heads) heads->swap(all.heads);
     return MIDAS_SNPS_OK;
@@ -919,7 +921,7 @@ int32_t walk_records(const uint8_t* d, size_t total, size_t rec_begin, const std
       fprintf(stderr, "[bam load] piece %zu of %zu walked again: guess %zu, chain at %zu\n", k, pieces.size(), pieces[k].start, cur);
 #endif
     }
-    if (pc->bad) { set_err(err256, "%s: truncated alignment record at byte %lld", path, (long long)pc->bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+    if (pc->bad) { set_err(err256, "%s: truncated or malformed alignment record at byte %lld", path, (long long)pc->bad_at); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
     use[k] = pc;
     n_total += pc->offs.size();
     cur = pc->end;

@@ -278,3 +278,51 @@ def test_the_device_record_walk_is_the_hosts(ctx, tmp_path):
     bam.write_bam(decoy, c3.ids, [int(x) for x in c3.length], rid3, abi.ReadsSoA(**{**r3.as_dict(), "qual": qual}))
     got = _same_decode(ctx, decoy)
     assert got.n_reads == r3.n_reads
+
+
+def _point_a_record_at_no_reference(path, n_ref):
+    """A BAM of stored (level 0) blocks: the refID of the first record of its third block is set to n_ref + 3 and the block's
+    CRC-32 recomputed -- every block is intact, one record names a reference the header does not have."""
+    raw = bytearray(open(path, "rb").read())
+    p, blocks = 0, []
+    while p < len(raw):
+        blocks.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    # the inflated stream, to find a record start inside the third block
+    sizes = [int.from_bytes(raw[b + 18 + 1:b + 18 + 3], "little") for b in blocks]      # LEN of the stored block
+    stream = b"".join(bytes(raw[b + 23:b + 23 + n]) for b, n in zip(blocks, sizes))
+    q = 8 + int.from_bytes(stream[4:8], "little")
+    nr = int.from_bytes(stream[q:q + 4], "little"); q += 4
+    for _ in range(nr):
+        q += 4 + int.from_bytes(stream[q:q + 4], "little") + 4
+    lo = sum(sizes[:2])
+    while q < lo:
+        q += 4 + int.from_bytes(stream[q:q + 4], "little")
+    assert q + 8 <= lo + sizes[2]
+    at = blocks[2] + 23 + (q - lo) + 4                        # the record's refID in the file
+    raw[at:at + 4] = int(n_ref + 3).to_bytes(4, "little")
+    data = bytes(raw[blocks[2] + 23:blocks[2] + 23 + sizes[2]])
+    foot = (blocks[3] if len(blocks) > 3 else len(raw)) - 8      # (the block ends with CRC-32 and ISIZE)
+    raw[foot:foot + 4] = (zlib.crc32(data) & 0xFFFFFFFF).to_bytes(4, "little")
+    open(path, "wb").write(bytes(raw))
+
+
+def test_a_record_of_no_reference_is_refused_by_every_decoder(ctx, tmp_path):
+    """pysam / htslib refuse a record whose refID is not in the header (midas/run/snps.py:186 would raise on fetch); the host's
+    walk does (plausible_record), and so do the device's whole-file decode, its payload-on-device form and a slice walked on
+    the device -- none of them indexes a per-reference table with it."""
+    from midas_amd import bam
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=40000, n_reads=4000, seed=11)
+    path = str(tmp_path / "noref.bam")
+    refid = np.repeat(np.arange(2, dtype=np.int32), np.diff(contigs.read_begin))
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=0)
+    abi.read_bam(path, ctx)                                               # (as written: fine)
+    _point_a_record_at_no_reference(path, 2)
+    for kw in (dict(), dict(ctx=ctx), dict(ctx=ctx, payload_on_device=True)):
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            abi.read_bam(path, **kw)
+        assert ei.value.status == abi.ERR_BAD_LAYOUT, (kw, ei.value.message)
+    for kw in (dict(), dict(ctx=ctx)):
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            abi.BamSlice(path, 0, 1, **kw)
+        assert ei.value.status == abi.ERR_BAD_LAYOUT, (kw, ei.value.message)

@@ -61,7 +61,7 @@ def test_large_bam_goes_through_the_parallel_record_walk(tmp_path):
     _rewrite_bgzf(path, cut, lambda raw: raw[:len(raw) - 11])
     with pytest.raises(abi.MidasSnpsError) as e:
         abi.read_bam(cut)
-    assert "truncated alignment record" in e.value.message
+    assert "truncated or malformed alignment record" in e.value.message
 
 
 def test_record_walk_is_not_fooled_by_bytes_that_look_like_records(tmp_path):
@@ -418,3 +418,21 @@ def test_decoder_reads_a_bam_assembled_from_the_spec_tables():
         assert int(sl.ref_reads.sum()) == 9
     finally:
         sl.close()
+
+
+def test_a_record_of_no_reference_is_refused_by_the_host_decoders(tmp_path):
+    """pysam / htslib refuse a record whose refID is not in the header (midas/run/snps.py:186); so do the host's whole-file walk
+    and its slice walk -- neither hands an index past the header's references on (the device twins: tests/test_gpu_inflate.py)."""
+    import numpy as np
+    from midas_amd import abi, bam, synth
+    from tests.test_gpu_inflate import _point_a_record_at_no_reference
+    contigs, reads = synth.make_dataset(n_species=1, contigs_per_species=2, contig_len=40000, n_reads=4000, seed=11)
+    path = str(tmp_path / "noref.bam")
+    refid = np.repeat(np.arange(2, dtype=np.int32), np.diff(contigs.read_begin))
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=0)
+    abi.read_bam(path)
+    _point_a_record_at_no_reference(path, 2)
+    for f in (lambda: abi.read_bam(path), lambda: abi.BamSlice(path, 0, 1)):
+        with pytest.raises(abi.MidasSnpsError) as ei:
+            f()
+        assert ei.value.status == abi.ERR_BAD_LAYOUT
