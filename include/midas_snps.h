@@ -218,8 +218,12 @@ void midas_snps_batch_destroy(midas_snps_batch* batch);
  * writes; any order is CORRECT, only slower).  PACKED: the reads are first laid out in tile order as records + one byte per
  * base (midas_snps_batch_pack), which handles any order and cuts coverage hot spots into parts.  batch_create picks DIRECT
  * unless the reads are badly ordered, one read spans many tiles or a tile holds a hot spot; AUTO restores that choice.
- * Both paths give bit-identical results (tests/test_gpu_direct.py).                                                */
-enum { MIDAS_SNPS_PATH_AUTO = 0, MIDAS_SNPS_PATH_DIRECT = 1, MIDAS_SNPS_PATH_PACKED = 2 };
+ * Both paths give bit-identical results (tests/test_gpu_direct.py).  LONG: a batch that holds a read beyond the two fast
+ * paths' limits -- l_seq above 1024, more than 65 534 CIGAR ops, NM above 65 534; pysam knows no such limits
+ * (midas/run/snps.py:187-199) -- is not refused: batch_create gives it the long path (pileup_long.hip: one thread per read,
+ * op by op and base by base from the caller's arrays, global atomics, the ratio tests in fp64), exact and slow, the only
+ * path such a batch has (selecting DIRECT or PACKED on it is MIDAS_SNPS_ERR_UNSUPPORTED; any batch may select LONG).      */
+enum { MIDAS_SNPS_PATH_AUTO = 0, MIDAS_SNPS_PATH_DIRECT = 1, MIDAS_SNPS_PATH_PACKED = 2, MIDAS_SNPS_PATH_LONG = 3 };
 int32_t midas_snps_batch_select_path(midas_snps_batch* batch, int32_t path);
 /* The path of every batch created on the context from now on (the one-shot midas_snps_pileup included); AUTO = each
  * batch's own choice.                                                                                              */
@@ -282,7 +286,7 @@ typedef struct midas_snps_batch_info {
   int32_t tile_sites;
   int32_t lanes_per_read;
   int64_t n_work_items;     /* >= n_tiles: a tile holding a coverage hot spot is processed as several parts */
-  int32_t path;             /* MIDAS_SNPS_PATH_DIRECT / _PACKED: what batch_run takes                         */
+  int32_t path;             /* MIDAS_SNPS_PATH_DIRECT / _PACKED / _LONG: what batch_run takes                 */
   int32_t path_auto;        /* what the batch's own numbers recommend (see midas_snps_batch_select_path)       */
   int32_t lane_bases;       /* bases per lane of the active path's kernel                                      */
   int32_t reserved0;

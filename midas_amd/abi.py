@@ -91,8 +91,8 @@ class BatchInfo(C.Structure):
 
 ROWS_DEVICE, ROWS_HOST = 0, 1    # who formats and deflates a batch's rows (midas_snps_set_row_coder)
 PAD_SPEC, PAD_PYSAM = 0, 1       # what the CIGAR op P does to the query position (midas_snps_set_pad_rule)
-PATH_AUTO, PATH_DIRECT, PATH_PACKED = 0, 1, 2
-PATH_NAMES = {PATH_AUTO: "auto", PATH_DIRECT: "direct", PATH_PACKED: "packed"}
+PATH_AUTO, PATH_DIRECT, PATH_PACKED, PATH_LONG = 0, 1, 2, 3
+PATH_NAMES = {PATH_AUTO: "auto", PATH_DIRECT: "direct", PATH_PACKED: "packed", PATH_LONG: "long"}
 
 
 _SOA_DTYPES = {

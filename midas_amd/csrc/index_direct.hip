@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   }
   __syncthreads();
   unsigned long long alg = 0, status = kNoError;
-  uint32_t maxl = 0, maxspan = 0, unsorted = 0, general = 0;
+  uint32_t maxl = 0, maxspan = 0, unsorted = 0, general = 0, n_long = 0;
   ContigCursor cur;
   if (lo < hi) {
     cur.c = s_c0;
@@ -210,13 +210,12 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
       status = s < status ? s : status;
       continue;
     }
-    if (l > kMaxLSeq || nc > kMaxField16 || f.nm > kMaxField16) {
-      const unsigned long long s = ((unsigned long long)i << 8) | kPackUnsupported;
-      status = s < status ? s : status;
-      continue;
-    }
     alg += (unsigned long long)((l + 1) / 2 + l + 4 * nc + 16);
     maxl = (uint32_t)l > maxl ? (uint32_t)l : maxl;
+    if (l > kMaxLSeq || nc > kMaxField16 || f.nm > kMaxField16) {      // beyond the fast paths: the batch takes the long path (pileup_long.hip)
+      n_long += 1u;
+      continue;
+    }
     CigarView cg;
     cg.load(p.cigar + f.co);
     // reference span: what the ranges kernel must reach over (sites from the read's start to its last aligned base)
@@ -235,6 +234,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   }
   alg = block_sum(alg, red);
   const unsigned long long ngen = block_sum((unsigned long long)general, red);
+  const unsigned long long nlong = block_sum((unsigned long long)n_long, red);
   const unsigned long long bmax = block_max((unsigned long long)maxl, red);
   const unsigned long long bspan = block_max((unsigned long long)maxspan, red);
   const unsigned long long any_unsorted = block_max((unsigned long long)unsorted, red);
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
     DirectFacts* f = p.facts + (blockIdx.x % kDirectFactSlots);
     if (alg) atomicAdd(&f->alg_bytes, alg);
     if (ngen) atomicAdd(&f->n_general, (uint32_t)ngen);
+    if (nlong) atomicAdd(&f->n_long, (uint32_t)nlong);
     if (bmax) atomicMax(&f->max_l, (uint32_t)bmax);
     if (bspan) atomicMax(&f->max_span, (uint32_t)bspan);
     if (any_unsorted) atomicOr(&f->unsorted, 1u);

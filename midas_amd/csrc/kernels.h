@@ -182,6 +182,7 @@ struct alignas(128) DirectFacts {                 // per-slot partial results of
   uint32_t max_l;                                 // longest read
   uint32_t max_span;                              // longest reference span (sum of M/=/X/D/N lengths) of a read
   uint32_t unsorted;                              // some contig's reads are not in position order
+  uint32_t n_long;                                // reads beyond the fast paths' limits (l_seq > kMaxLSeq, n_cigar / NM > kMaxField16): the batch takes the long path
 };
 
 struct DirectIndexParams {
@@ -321,6 +322,24 @@ hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long l
 hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* base, unsigned long long* rec_off, hipStream_t s);
 size_t bam_scan_scratch_bytes(long long n_records);
 hipError_t launch_bam_columns(const BamColumnsParams& p, long long* scan_scratch, hipStream_t s);
+
+// ---- long path (pileup_long.hip): batches holding a read beyond the fast paths' limits; one thread per read, global atomics ----
+struct LongParams {
+  const int32_t* pos; const uint8_t* mapq; const int32_t* nm; const int32_t* l_seq;
+  const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
+  const uint8_t* seq4; const uint8_t* qual; const uint32_t* cigar;
+  long long n_reads, n_sites;
+  const int32_t* contig_read_begin; const int32_t* contig_tile_base;
+  int32_t n_contigs, n_tiles;
+  const Tile* tiles;
+  const uint8_t* ref;
+  uint32_t* out_counts; uint8_t* out_allele;
+  unsigned long long* stats; unsigned long long* err;
+  int32_t n_stat_words;
+  int32_t baseq, mapq_min, readq, pad_advances;
+  double mapid, aln_cov;
+};
+hipError_t launch_pileup_long(const LongParams& p, hipStream_t s);
 
 hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s);       // once per batch: validation, totals
 hipError_t launch_direct_layout_sizes(const DirectLayoutParams& p, hipStream_t s);   // once per batch: payload units per workgroup + their scan

@@ -114,6 +114,7 @@ struct midas_snps_batch {
   int64_t direct_max_tile_reads = 0;
   int64_t direct_run_count = 0;
   bool pad_advances = false;    // the context's pad rule when the batch was created (MIDAS_SNPS_PAD_PYSAM)
+  int64_t n_long = 0;           // reads beyond the fast paths' limits: > 0 and the batch runs on the long path only (pileup_long.hip)
   bool direct_sorted = false;   // every contig's reads in position order (found by the first index pass): tile ranges need no atomics
   // timing
   std::vector<hipEvent_t> ev;  // 3 per slot: before the index kernel, before and after the pileup kernel
@@ -1146,7 +1147,8 @@ int32_t midas_snps_set_pad_rule(midas_snps_ctx* ctx, int32_t rule) {
 }
 
 int32_t midas_snps_set_default_path(midas_snps_ctx* ctx, int32_t path) {
-  if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (!ctx || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED && path != MIDAS_SNPS_PATH_LONG))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
   ctx->default_path = path;
   return MIDAS_SNPS_OK;
 }
@@ -1359,12 +1361,13 @@ int32_t direct_prepare(midas_snps_batch* b) {
   if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_facts(ip, s));
   HIP_TRY(ctx, hipMemcpyAsync(facts.data(), b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  unsigned long long status = kNoError, alg = 0, n_general = 0;
+  unsigned long long status = kNoError, alg = 0, n_general = 0, n_long = 0;
   uint32_t max_l = 0, max_span = 0, unsorted = 0;
   for (const DirectFacts& f : facts) {
     status = std::min(status, f.status);
     alg += f.alg_bytes;
     n_general += f.n_general;
+    n_long += f.n_long;
     max_l = std::max(max_l, f.max_l);
     max_span = std::max(max_span, f.max_span);
     unsorted |= f.unsorted;
@@ -1375,6 +1378,11 @@ int32_t direct_prepare(midas_snps_batch* b) {
   b->direct_general = (int64_t)n_general;
   b->direct_reach = (int32_t)std::max<uint32_t>(1u, std::max(max_l, max_span));
   b->alg_bytes = (int64_t)alg + 17 * b->n_sites;
+  b->n_long = (int64_t)n_long;
+  if (n_long > 0) {      // a read beyond the fast paths' limits: the whole batch takes the long path, nothing else is built
+    b->path_auto = b->path = MIDAS_SNPS_PATH_LONG;
+    return MIDAS_SNPS_OK;
+  }
   b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
   b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;
   // the direct layout: one 16-byte record per read and its CIGAR / SEQ / QUAL bytes as one run of the payload (every read
@@ -1447,6 +1455,7 @@ int32_t direct_prepare(midas_snps_batch* b) {
 int32_t ensure_packed(midas_snps_batch* b) {
   if (b->packed_built) return MIDAS_SNPS_OK;
   midas_snps_ctx* ctx = b->ctx;
+  if (b->n_long > 0) return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "the batch holds reads beyond the packed layout's limits: it has the long path only");
   hipStream_t s = ctx->stream;
   char ebuf[256] = {0};
   const int64_t n = b->n_reads, n_sites = b->n_sites;
@@ -1763,9 +1772,15 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
 }
 
 int32_t midas_snps_batch_select_path(midas_snps_batch* b, int32_t path) {
-  if (!b || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (!b || (path != MIDAS_SNPS_PATH_AUTO && path != MIDAS_SNPS_PATH_DIRECT && path != MIDAS_SNPS_PATH_PACKED && path != MIDAS_SNPS_PATH_LONG))
+    return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (b->n_long > 0 && (path == MIDAS_SNPS_PATH_DIRECT || path == MIDAS_SNPS_PATH_PACKED)) {
+    char buf[200];
+    snprintf(buf, sizeof buf, "%lld read(s) with l_seq > %d or n_cigar / NM > %d: the batch has the long path only", (long long)b->n_long, kMaxLSeq, kMaxField16);
+    return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, buf);
+  }
   b->path = path == MIDAS_SNPS_PATH_AUTO ? b->path_auto : path;
   if (b->path == MIDAS_SNPS_PATH_PACKED) return ensure_packed(b);
   return MIDAS_SNPS_OK;
@@ -1832,10 +1847,16 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
   if (!b || !thr) return MIDAS_SNPS_ERR_INVALID_ARG;
   midas_snps_ctx* ctx = b->ctx;
   if (thr->reserved != 0) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "thresholds.reserved must be 0");
-  if (b->path != MIDAS_SNPS_PATH_DIRECT && thr->baseq > kMaxPackedQual && (b->packed_built ? b->has_high_qual : true) &&
-      ensure_packed(b) == MIDAS_SNPS_OK && b->has_high_qual)   // (Illumina tops out in the forties; BAM allows 93)
-    return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "baseq above 62 on reads that hold base qualities above 62 is not supported "
-                                                  "(qualities are kept in six bits)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // The packed payload keeps a quality in six bits (exact for every threshold <= 62).  A baseq above that on reads that hold
+  // qualities above it (BAM allows 93; Illumina tops out in the forties) is served by the direct kernel, which compares the
+  // BAM's own bytes and is exact on any read order -- this one run only, the batch's path stays what it is.
+  int run_path = b->path;
+  if (run_path == MIDAS_SNPS_PATH_PACKED && thr->baseq > kMaxPackedQual) {
+    const int32_t pst = ensure_packed(b);
+    if (pst != MIDAS_SNPS_OK) return pst;
+    if (b->has_high_qual) run_path = MIDAS_SNPS_PATH_DIRECT;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   hipEvent_t* ev = b->timing_slots > 0 ? &b->ev[(size_t)(b->timed_runs % b->timing_slots) * 3] : nullptr;
@@ -1853,7 +1874,32 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     b->filt_valid = true;
   }
 
-  if (b->path == MIDAS_SNPS_PATH_DIRECT) {
+  if (run_path == MIDAS_SNPS_PATH_LONG) {
+    // ---- long path: one thread per read over the caller's arrays (reads beyond the fast paths' limits; any batch may ask for it) ----
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
+    LongParams lp;
+    lp.pos = b->d_pos; lp.mapq = b->d_mapq; lp.nm = b->d_nm; lp.l_seq = b->d_lseq;
+    lp.seq_off = b->d_seq_off; lp.qual_off = b->d_qual_off; lp.cigar_off = b->d_cigar_off;
+    lp.seq4 = b->d_seq4; lp.qual = b->d_qual; lp.cigar = b->d_cigar;
+    lp.n_reads = b->n_reads; lp.n_sites = b->n_sites;
+    lp.contig_read_begin = b->d_contig_read_begin; lp.contig_tile_base = b->d_contig_tile_base;
+    lp.n_contigs = b->n_contigs; lp.n_tiles = (int32_t)b->n_tiles;
+    lp.tiles = b->d_tiles; lp.ref = b->d_ref;
+    lp.out_counts = b->d_counts; lp.out_allele = b->d_allele;
+    lp.stats = work_stats(b); lp.err = work_err(b);
+    lp.n_stat_words = b->n_species * MIDAS_STATS;
+    lp.baseq = thr->baseq; lp.mapq_min = thr->mapq; lp.readq = thr->readq; lp.pad_advances = b->pad_advances ? 1 : 0;
+    lp.mapid = thr->mapid; lp.aln_cov = thr->aln_cov;
+    HIP_TRY(ctx, launch_pileup_long(lp, s));
+    if (ev) {
+      HIP_TRY(ctx, hipEventRecord(ev[2], s));
+      b->timed_runs += 1;
+    }
+    b->ran = true;
+    b->run_count += 1;
+    return MIDAS_SNPS_OK;
+  }
+  if (run_path == MIDAS_SNPS_PATH_DIRECT) {
     // ---- direct path: the tile ranges from the positions, then the pileup kernel over the raw arrays (one visit per read) ----
     DirectIndexParams dip;
     fill_direct_index(b, &dip);

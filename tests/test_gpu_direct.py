@@ -1,8 +1,10 @@
-"""The two device paths of a batch, held to the oracle and to each other.
+"""The device paths of a batch, held to the oracle and to each other.
 
-DIRECT: the pileup kernel reads the BAM-native arrays where they are (index_direct.hip + pileup_direct.hip).
+DIRECT: the pileup kernel reads the BAM's own bytes (index_direct.hip + pileup_direct.hip).
 PACKED: tile-ordered records + one byte per base (pack_reads.hip + index_reads.hip + pileup_tiles.hip).
-Both must give bit-identical counts, alleles, counters and statuses on every input, in any read order; `auto` picks DIRECT
+LONG:   one thread per read over the caller's arrays (pileup_long.hip) -- the path of batches that hold a read beyond the fast
+        paths' limits, and a structurally different third implementation of the same rules for every other batch.
+All must give bit-identical counts, alleles, counters and statuses on every input, in any read order; `auto` picks DIRECT
 for position-sorted input without coverage hot spots.
 """
 import random
@@ -17,7 +19,7 @@ from tests.test_gpu_parity import _random_cigar
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [abi.PATH_DIRECT, abi.PATH_PACKED]
+PATHS = [abi.PATH_DIRECT, abi.PATH_PACKED, abi.PATH_LONG]
 CASES = H.load_kat_cases()
 
 
@@ -94,7 +96,7 @@ def test_random_cigar_grammar(path_ctx, seed):
     ref = "".join(rng.choice("ACGTacgtN") for _ in range(L))
     contig = H.single_contig(L, len(reads), ref)
     sets = [dict(abi.DEFAULT_ARGS), dict(abi.DEFAULT_ARGS, baseq=0, mapid=80.0, aln_cov=0.3, readq=10, mapq=0)]
-    if path_ctx.forced_path == abi.PATH_DIRECT:      # (the packed path refuses a baseq above 62 on qualities above 62)
+    if True:      # (a baseq above 62 on qualities above 62: the packed path hands such a run to the direct kernel)
         sets += [dict(abi.DEFAULT_ARGS, baseq=93, mapid=1.0, readq=0), dict(abi.DEFAULT_ARGS, baseq=201, mapid=1.0, readq=0),
                  dict(abi.DEFAULT_ARGS, baseq=-3, readq=-1), dict(abi.DEFAULT_ARGS, baseq=255, readq=0, mapid=0.0),
                  dict(abi.DEFAULT_ARGS, baseq=256, readq=0, mapid=0.0), dict(abi.DEFAULT_ARGS, baseq=1, readq=300)]
