@@ -37,6 +37,8 @@ from midas_amd import abi, bam, dist, fasta, pieces, utility
 # takes the formatter from the largest to the second smallest item of the stage.
 GZ_LEVEL = 4
 WRITERS = 6                  # tables written side by side from a batch (_write_jobs)
+MAX_BATCH_READS = 1 << 30   # a rank's work items go to the device in batches of at most this many reads (args['max_batch_reads']) ...
+MAX_BATCH_PAYLOAD = 24 << 30   # ... and about this many bytes of SEQ / QUAL / CIGAR (the library's own limits: 2 * 10^9 reads, 32 GiB)
 SPLIT_LENGTH = 8 << 20      # contigs longer than this are dealt to the ranks in pieces (args['split_length']; 0: never)
 
 
@@ -358,10 +360,72 @@ def _whole(order, contigs):
     return items, {(cid, 0): (0, contigs[cid].length, True) for cids in order.values() for cid in cids}
 
 
+def _batch_groups(args, mine, order, ref_names, refid, reads, ctx):
+    """The rank's work items as the batches the device takes one after the other: consecutive items of the emit order (species
+    by species, a species' contigs sorted) until a batch would hold more reads or payload than a batch can (the library's
+    limits are 2 * 10^9 reads and 32 GiB of payload per batch) or than the device's memory has room for beside its results.
+    The reference streams contig by contig (midas/run/snps.py:187-199) and has no such limit; nearly every job is ONE batch."""
+    wanted = set(mine)
+    emit = [it for sp in sorted(order) for it in order[sp] if it in wanted]
+    if len(emit) <= 1 or not hasattr(ctx, 'batch'):
+        return [emit]
+    max_reads = int(args.get('max_batch_reads') or MAX_BATCH_READS)
+    max_payload = MAX_BATCH_PAYLOAD
+    try:        # raw arrays + the direct layout ~ 3.6 bytes per base, 17 bytes of results per site: keep to half the device
+        max_payload = min(max_payload, int(ctx.device_info()['hbm_bytes']) // 8)
+    except Exception:
+        pass
+    index_of = {n: i for i, n in enumerate(ref_names)}
+    n_ref = len(ref_names)
+    per_reads = np.bincount(refid, minlength=n_ref) if refid.size else np.zeros(n_ref, np.int64)
+    per_bases = np.bincount(refid, weights=reads.l_seq, minlength=n_ref) if refid.size else np.zeros(n_ref)
+    n_pieces = {}
+    for cid, _ in emit:
+        n_pieces[cid] = n_pieces.get(cid, 0) + 1
+    groups, cur, cur_reads, cur_bytes = [], [], 0, 0.0
+    for it in emit:
+        r = index_of.get(it[0], -1)
+        k = float(n_pieces[it[0]])
+        nr = int(per_reads[r] / k) if r >= 0 else 0
+        nb = (1.6 * float(per_bases[r]) + 8.0 * float(per_reads[r])) / k if r >= 0 else 0.0
+        if cur and (cur_reads + nr > max_reads or cur_bytes + nb > max_payload):
+            groups.append(cur)
+            cur, cur_reads, cur_bytes = [], 0, 0.0
+        cur.append(it)
+        cur_reads += nr
+        cur_bytes += nb
+    groups.append(cur)
+    return groups
+
+
 def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, contigs, halo=None):
     """count_coverage + keep_read + emit for the work items `mine` (contigs, or pieces of long ones) on one GPU.  Returns
-    {species_id: partial aln_stats} (sums over this rank's items).  Writes <species>.snps.gz directly when this rank owns
-    every item of the species, else one part file per run of consecutive (emit order) items it owns."""
+    {species_id: partial aln_stats} (sums over this rank's items).  Writes <species>.snps.gz directly when ONE batch of this
+    rank holds every item of the species, else one part file per run of consecutive (emit order) items of a batch."""
+    ref_names, ref_lens, refid, reads = decoded
+    rank, _ = dist.world()
+    groups = _batch_groups(args, mine, order, ref_names, refid, reads, ctx) if mine else [[]]
+    if len(groups) > 1 and args.get('log') is not None:
+        args['log'].write("the rank's %d work items go to the device in %d batches (reads per batch <= %d)\n"
+                          % (len(mine), len(groups), int(args.get('max_batch_reads') or MAX_BATCH_READS)))
+    if len(groups) > 1 and getattr(reads, 'device', None) is not None and hasattr(ctx, 'fetch_payload'):
+        decoded = (ref_names, ref_lens, refid, ctx.fetch_payload(reads))      # (each batch regroups its own reads: in host memory, once)
+    total = {}
+    for group in groups:
+        here = set(group)
+        part = _pileup_batch(args, species_ids, group, order, lambda it: owner.get(it, 0) == rank and it in here,
+                             decoded, ctx, span, contigs, halo, first=group is groups[0])
+        for sp, st in part.items():
+            if sp in total:
+                for k in st:
+                    total[sp][k] += st[k]
+            else:
+                total[sp] = dict(st)
+    return total
+
+
+def _pileup_batch(args, species_ids, mine, order, owned, decoded, ctx, span, contigs, halo, first):
+    """One batch of _pileup_contigs: the work items `mine`, of which owned(item) says "in this batch"."""
     ref_names, ref_lens, refid, reads = decoded
     table, sub, keys = _contig_table(species_ids, mine, span, contigs, ref_names, ref_lens, refid, reads, halo,
                                      fetch=getattr(ctx, 'fetch_payload', None))
@@ -384,14 +448,15 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, c
         counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
         stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)
     try:
-        return _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, stats, batch)
+        return _emit_contigs(args, species_ids, table, keys, order, owned, counts, allele, stats, batch, first)
     finally:
         if batch is not None:
             batch.close()
 
 
-def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, stats, batch):
-    """The rows and the partial counters of _pileup_contigs, from host arrays or (batch) from the device results."""
+def _emit_contigs(args, species_ids, table, keys, order, owned_item, counts, allele, stats, batch, first=True):
+    """The rows and the partial counters of one batch, from host arrays or (batch) from the device results.  owned_item(item):
+    the item is in this batch; `first`: the rank's first batch (the one that writes the header-only files of empty species)."""
     rank, _ = dist.world()
     genome_length = np.bincount(table.species, weights=table.length, minlength=len(species_ids)).astype(np.int64)
     pos = {it: k for k, it in enumerate(keys)}
@@ -403,9 +468,9 @@ def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, 
         jobs.append((path, items, header))
     for i, sp in enumerate(species_ids):
         cids = order[sp]
-        owned = [owner.get(cid, 0) == rank for cid in cids]
+        owned = [bool(owned_item(cid)) for cid in cids]
         if all(owned):       # (a species without contigs still gets its header-only file, from rank 0)
-            if cids or rank == 0:
+            if cids or (rank == 0 and first):
                 _write_rows(args, '%s/snps/output/%s.snps.gz' % (args['outdir'], sp), table, pos, cids, counts, allele, off, None, batch)
         else:
             k = 0
@@ -418,7 +483,7 @@ def _emit_contigs(args, species_ids, table, keys, order, owner, counts, allele, 
                     e += 1
                 _write_rows(args, _part_path(args, sp, k), table, pos, cids[k:e], counts, allele, off, k == 0, batch)
                 k = e
-        if any(owned) or (not cids and rank == 0):
+        if any(owned) or (not cids and rank == 0 and first):
             out[sp] = {'genome_length': int(genome_length[i]),
                        'total_depth': int(stats[i, abi.STAT_TOTAL_DEPTH]),
                        'covered_bases': int(stats[i, abi.STAT_COVERED_BASES]),
@@ -444,21 +509,32 @@ def _write_jobs(args, jobs, table, pos, counts, allele, off, batch):
 
 
 def _join_parts(args, species_ids, order, owner, rank):
-    """Species whose work items were spread over ranks: concatenate the parts in emit order (sorted contigs, a contig's
-    pieces by position) into <species>.snps.gz.  Done by the rank that owns the species' first item (it wrote the header)."""
+    """Species whose work items were spread over ranks -- or over several batches of one rank: concatenate the parts in emit
+    order (sorted contigs, a contig's pieces by position; a part is named by the index of its first item) into
+    <species>.snps.gz.  Done by the rank that owns the species' first item (its first part carries the header)."""
+    import glob
     for sp in species_ids:
         cids = order[sp]
-        if not cids or len({owner.get(c, 0) for c in cids}) <= 1 or owner.get(cids[0], 0) != rank:
+        if not cids or owner.get(cids[0], 0) != rank:
             continue
-        starts = [k for k in range(len(cids)) if k == 0 or owner.get(cids[k], 0) != owner.get(cids[k - 1], 0)]
         final = '%s/snps/output/%s.snps.gz' % (args['outdir'], sp)
+        parts = sorted(glob.glob(glob.escape(final) + '.part[0-9][0-9][0-9][0-9][0-9][0-9]'))
+        if not parts:
+            continue
         with open(final + '.tmp', 'wb') as dst:
-            for k in starts:
-                with open(_part_path(args, sp, k), 'rb') as src:
+            for path in parts:
+                with open(path, 'rb') as src:
                     shutil.copyfileobj(src, dst, 1 << 24)
         os.replace(final + '.tmp', final)
-        for k in starts:
-            os.remove(_part_path(args, sp, k))
+        for path in parts:
+            os.remove(path)
+
+
+def _remove_stale_parts(args):
+    """Part files of an earlier, interrupted run must not end up in this run's tables."""
+    import glob
+    for path in glob.glob(glob.escape('%s/snps/output' % args['outdir']) + '/*.snps.gz.part[0-9][0-9][0-9][0-9][0-9][0-9]'):
+        os.remove(path)
 
 
 def species_pileup(args, species_id, contigs):
@@ -634,6 +710,8 @@ def _count_alleles(args, species, contigs, ctx):
         args['log'].write("\nCounting alleles\n")
 
     bampath = '%s/snps/temp/genomes.bam' % args['outdir']
+    if rank == 0:
+        _remove_stale_parts(args)       # (before the first point every rank waits at)
     inflater = ctx if _inflate_on_device(args, ctx, bampath, ws) else None
     # N ranks: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and each
     # decodes only the records of the contigs it ends up owning.  One rank (or a BAM the slices cannot vouch for:
@@ -732,8 +810,7 @@ def _count_alleles(args, species, contigs, ctx):
             st = local[sp]
             rows[i] = [st['genome_length'], st['covered_bases'], st['total_depth'], st['aligned_reads'], st['mapped_reads']]
     rows = dist.all_gather_summary(rows)
-    if ws > 1:       # the all-gather is also the "every part is on disk" point
-        _join_parts(args, all_ids, order, owner, rank)
+    _join_parts(args, all_ids, order, owner, rank)       # (the all-gather is also the "every part is on disk" point)
 
     # update alignment stats for species objects -- midas/run/snps.py:230-241
     for i, species_id in enumerate(all_ids):

@@ -145,6 +145,9 @@ def build_parser():
     parser.add_argument('--remove_temp', action='store_true', help="delete <outdir>/snps/temp when done")
     parser.add_argument('--split_length', type=int, default=8 << 20, metavar='INT',
                         help="under torchrun, contigs longer than this are dealt to the GPUs in pieces (0: never; default 8 Mb)")
+    parser.add_argument('--max_batch_reads', type=int, default=0, metavar='INT',
+                        help="a GPU's contigs go to the device in batches of at most this many reads (0: the built-in limit, 2^30; "
+                             "nearly every job is one batch -- the tables do not depend on it)")
     parser.add_argument('--device_inflate', choices=('auto', 'on', 'off'), default='auto',
                         help="inflate the BAM's blocks on the GPU instead of with the host's threads; auto (default): for one rank "
                              "and a BAM of at least 0.5 GB whose decode fits the device's memory (twelve times the file), and for a "

@@ -149,3 +149,31 @@ def test_rows_streamed_from_the_device_are_the_bytes_of_the_host_writer(tmp_path
                     b.write_part(str(tmp_path / "bad.gz"), [nc], ["x"])
             finally:
                 b.close()
+
+
+@pytest.mark.parametrize("inflate", ["on", "off"])
+def test_a_share_dealt_to_the_device_in_several_batches_writes_the_same_files(tmp_path, inflate):
+    """The reference streams contig by contig and has no size limit (midas/run/snps.py:187-199); a batch of the device has
+    (2 * 10^9 reads, 32 GiB of payload, the device's memory), so a GPU's contigs go up in as many batches as it takes.
+    Forced here with --max_batch_reads: the tables and the summary are byte for byte those of the one-batch run, species whose
+    contigs fall into different batches included."""
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=4, contig_len=6000, n_reads=9000, seed=17,
+                                        var_len=True, lowercase_frac=0.05)
+    outs = []
+    for name, extra in (("one", []), ("many", ["--max_batch_reads", "1700"])):
+        out, db = str(tmp_path / name), str(tmp_path / ("db_" + name))
+        synth.write_sample(out, db, contigs, reads)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_midas.py"), "snps", out, "--pileup", "-d", db,
+                            "--device_inflate", inflate] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+    log = open(os.path.join(outs[1], "snps", "log.txt")).read()
+    assert "work items go to the device in" in log and "work items go to the device in" not in open(os.path.join(outs[0], "snps", "log.txt")).read()
+    n_batches = int(log.split("work items go to the device in ")[1].split()[0])
+    assert n_batches >= 4
+    for sp in contigs.species_ids:
+        a = open(os.path.join(outs[0], "snps", "output", sp + ".snps.gz"), "rb").read()
+        b = open(os.path.join(outs[1], "snps", "output", sp + ".snps.gz"), "rb").read()
+        assert a == b, sp
+    assert open(os.path.join(outs[0], "snps", "summary.txt")).read() == open(os.path.join(outs[1], "snps", "summary.txt")).read()
+    assert not [f for f in os.listdir(os.path.join(outs[1], "snps", "output")) if ".part" in f]
