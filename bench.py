@@ -323,6 +323,108 @@ def configs3_strong(ctx, thr, rank, world, collective, steps):
     }
 
 
+def native_rccl(ctx, rank, world, n_species=100, timeout_s=90.0):
+    """The PRODUCT's exchange (midas_amd/dist.py -> midas_comm_*, comm.cpp: librccl's ncclCommInitRank / ncclAllGather bound by the
+    library itself, no process group) exercised beside the harness's torch.distributed: the per-species summary rows of every
+    rank, all-gathered over xGMI, held to what torch's all-gather returns.  Time-bounded (a thread): a hang here must not cost
+    the bench line.  Returns a dict on every rank."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    from midas_amd import abi
+    res = {}
+
+    def work():
+        try:
+            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                ident.copy_(torch.tensor(list(abi.Comm.unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(ident, 0)
+            t0 = time.perf_counter()
+            comm = abi.Comm(ctx, bytes(ident.cpu().tolist()), rank, world)
+            init_ms = (time.perf_counter() - t0) * 1e3
+            rows = (np.arange(n_species * 5, dtype=np.int64).reshape(n_species, 5) + 1) * (rank + 1)
+            comm.all_gather(rows.tobytes())      # (channels are built on first use)
+            t0 = time.perf_counter()
+            got = comm.all_gather(rows.tobytes())
+            ms = (time.perf_counter() - t0) * 1e3
+            ok = all(np.array_equal(np.frombuffer(got[r], np.int64).reshape(n_species, 5), rows // (rank + 1) * (r + 1)) for r in range(world))
+            back = comm.all_to_all_v([bytes([rank, r]) * 1000 for r in range(world)], [2000] * world)
+            ok = ok and all(back[r] == bytes([r, rank]) * 1000 for r in range(world))
+            comm.close()
+            res.update(ok=bool(ok), comm_init_ms=init_ms, all_gather_ms=ms, ranks=world,
+                       what="midas_comm_create (ncclCommInitRank) + midas_comm_all_gather of int64[%d][5] per rank + midas_comm_all_to_all_v, "
+                            "host buffers in and out" % n_species)
+        except Exception as e:      # noqa: BLE001
+            res.update(ok=False, error="%s: %s" % (type(e).__name__, e))
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        res.update(ok=False, error="timed out after %d s" % timeout_s, hung=True)
+    return res
+
+
+def merge50(ctx, n_sites=2_000_000, n_samples=50, reps=3, cpu_sites=3000):
+    """BASELINE configs[4]: `merge_midas.py snps` across 50 samples -- the per-site cross-sample arithmetic of
+    midas/merge/snps.py:13-114, 324-364 (pooled counts, major / minor allele, per-sample depth and minor-allele count, prevalence,
+    the site filter) for one species' sites through midas_merge_sites (merge_sites.hip).  Not the graded metric: a block of its
+    own with its own roofline and CPU leg (oracle/merge_oracle.py, the reference's loops restated, on a slice)."""
+    from midas_amd import abi
+    from oracle import merge_oracle as mo
+    rng = np.random.default_rng(20260927 + 5)
+    ref = rng.integers(0, 4, n_sites)
+    alt = (ref + rng.integers(1, 4, n_sites)) % 4
+    snp = rng.random(n_sites) < 0.03
+    rows = np.arange(n_sites)
+    counts = []
+    for _ in range(n_samples):
+        depth = rng.poisson(10.0, n_sites).astype(np.uint32)
+        na = np.where(snp, rng.binomial(depth, 0.3), 0).astype(np.uint32)
+        c = np.zeros((n_sites, 4), np.uint32)
+        c[rows, ref] = depth - na
+        c[rows, alt] += na
+        counts.append(c)
+    mean = [10.0] * n_samples
+    margs = dict(abi.DEFAULT_MERGE_ARGS)
+    prm = abi.MergeParams.from_args(margs)
+    alg = n_sites * (24 * n_samples + 40)      # per (site, sample) 16 B of counts in, 8 B out (depth, minor count); 40 B of per-site outputs
+    ms, res = [], None
+    for _ in range(reps):
+        res = ctx.merge_sites(prm, counts, mean)
+        ms.append(res['kernel_ms'])
+    k_ms = float(np.mean(ms[1:])) if len(ms) > 1 else float(ms[0])
+    # CPU leg + parity on a slice: the reference's own per-site loops, restated
+    sel = rng.choice(n_sites, size=cpu_sites, replace=False)
+    t0, bad = time.perf_counter(), 0
+    for i in sel:
+        c = [[int(x) for x in counts[s][i]] for s in range(n_samples)]
+        pooled = mo.pooled_counts(c)
+        major, minor, st = mo.call_alleles(pooled, margs['allele_freq'])
+        mafs, depths = mo.per_sample(c, major, minor)
+        cs, prev = mo.prevalence(mean, depths, margs['site_depth'], margs['site_ratio'])
+        why = mo.flag_reason(prev, st, margs['site_prev'], margs['snp_type'])
+        ok = (res['major'][i] == (255 if major is None else major) and res['minor'][i] == (255 if minor is None else minor)
+              and res['snp_type'][i] == [None, 'mono', 'bi', 'tri', 'quad'].index(st) and res['count_samples'][i] == cs
+              and res['flag'][i] == {None: 0, 'min_prev': 1, 'snp_type': 2}[why] and list(res['depth'][:, i]) == depths
+              and list(res['pooled'][i]) == pooled)
+        bad += not ok
+    cpu_s = time.perf_counter() - t0
+    ach = alg / (k_ms * 1e-3) / 1e9
+    return {"metric": "sites/sec, cross-sample SNP merge (midas_merge_sites)", "value": n_sites / (k_ms * 1e-3), "unit": "sites/s",
+            "workload": "BASELINE configs[4]: %d samples x %d sites of one species (synthetic: Poisson depth 10, 3 %% of the sites "
+                        "bi-allelic), merge_midas.py snps defaults" % (n_samples, n_sites),
+            "kernel_ms": k_ms, "kernel_ms_runs": ms, "timing": "HIP events around merge_sites_kernel, inputs resident in HBM",
+            "roofline": {"bound": "hbm", "kernel": "merge_sites_kernel", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": int(alg),
+                         "algorithmic_bytes": "per site 16 B of counts in and 8 B out per sample + 40 B of per-site results",
+                         "traffic": None},
+            "cpu_baseline": {"value": cpu_sites / cpu_s, "unit": "sites/s", "cores": 1, "kind": "port",
+                             "sample": "%d of the sites through oracle/merge_oracle.py (the reference's per-site loops, Python), %.1f s" % (cpu_sites, cpu_s)},
+            "parity_vs_oracle": bad == 0, "sites_kept": int((res['flag'] == 0).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +441,7 @@ def main():
                     help="add the configs3_strong block (BASELINE configs[3] dealt to the ranks) at N = 1 too; always on for N > 1")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the summary all-gather even with one rank (exercises the N>1 step on a 1-GPU box)")
+    ap.add_argument("--no-merge50", action="store_true", help="skip the merge50 block (BASELINE configs[4], rank 0 at N = 1)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.pmc_child:
@@ -580,10 +683,25 @@ def main():
                                            and np.array_equal(stats, os_))
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / cb_all["value"]
+            if not a.no_merge50:
+                try:
+                    out["merge50"] = merge50(ctx)
+                except Exception as e:      # (a block beside the graded line: never fail the bench on it)
+                    out["merge50"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
                 out["cpu_python_shaped_estimate"] = python_shaped_estimate(contigs, reads, args)
             except Exception as e:  # the estimate is a courtesy number; never fail the bench on it
                 out["cpu_python_shaped_estimate"] = {"error": str(e)}
+    native = None
+    if collective and not _on_one_gpu():       # (every rank: the product's own RCCL binding beside the harness's process group)
+        native = native_rccl(ctx, rank, world)
+        if rank == 0:
+            out["native_rccl"] = native
+    if native is not None and native.get("hung"):       # (a thread sits in RCCL: say what was measured and leave at once)
+        if rank == 0:
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        os._exit(0)
     batch.close()
     ctx.close()
     if collective:

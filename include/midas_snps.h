@@ -586,6 +586,27 @@ int32_t midas_genes_terms(midas_snps_ctx* ctx, const midas_snps_thresholds* thr,
 int32_t midas_genes_sum(midas_snps_ctx* ctx, int64_t n_pairs, const int32_t* gene, const double* term, int64_t n_genes,
                         int64_t* out_aligned, int64_t* out_mapped, double* out_depth, float* out_kernel_ms);
 
+/* ---- the exchange between ranks (comm.cpp): RCCL itself, no process group ------------------------------------------------
+ * One process per GPU; the only thing ranks exchange on this path is the per-species summary rows -- the reference's pool
+ * workers return (species_id, aln_stats) through a pipe, midas/run/snps.py:225-241, midas/utility.py:81-107 -- plus, on the
+ * genes path, the (gene, term) pairs (midas/run/genes.py:165-199 computes them in one process).  librccl.so is loaded at run
+ * time by the first of these calls (MIDAS_SNPS_ERR_UNSUPPORTED with the reason in err256 when it cannot be); a single-GPU run
+ * never touches it.  Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others however the caller likes
+ * (midas_amd/dist.py: a file in <outdir>/snps/temp); every rank then joins with its context's device (ncclCommInitRank:
+ * collective, returns when all have).  Buffers are the caller's host memory; the collective runs on the context's stream.
+ *   all_gather     every rank's bytes_per_rank bytes, rank-major, to every rank (ncclAllGather over xGMI)
+ *   all_to_all_v   send_bytes[r] bytes to rank r (taken from `send` back to back in rank order), recv_bytes[r] from rank r
+ *                  (left in `recv` in rank order): grouped ncclSend / ncclRecv                                             */
+typedef struct midas_comm midas_comm;
+/* the PCI bus id of the context's device (two ranks on ONE device cannot form an RCCL communicator: the caller checks first) */
+int32_t midas_comm_device_key(midas_snps_ctx* ctx, char* out64);
+int32_t midas_comm_unique_id(uint8_t* out_id128, char* err256);
+int32_t midas_comm_create(midas_snps_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world, midas_comm** out, char* err256);
+void midas_comm_destroy(midas_comm* comm);
+int32_t midas_comm_all_gather(midas_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, char* err256);
+int32_t midas_comm_all_to_all_v(midas_comm* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes,
+                                char* err256);
+
 #ifdef __cplusplus
 }
 #endif

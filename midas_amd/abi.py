@@ -284,6 +284,12 @@ def load_library(build_if_missing: bool = True):
         'midas_genes_terms': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Reads), vp, i64, vp, vp, C.POINTER(C.c_float)]),
         'midas_genes_sum': (i32, [vp, i64, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_float)]),
         'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 5 + [C.POINTER(C.c_float)]),
+        'midas_comm_device_key': (i32, [vp, C.c_char_p]),
+        'midas_comm_unique_id': (i32, [vp, C.c_char_p]),
+        'midas_comm_create': (i32, [vp, vp, i32, i32, C.POINTER(vp), C.c_char_p]),
+        'midas_comm_destroy': (None, [vp]),
+        'midas_comm_all_gather': (i32, [vp, vp, vp, i64, C.c_char_p]),
+        'midas_comm_all_to_all_v': (i32, [vp, vp, vp, vp, vp, C.c_char_p]),
     })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
@@ -315,6 +321,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_genes_terms', 'midas_genes_sum', 'midas_merge_write_info',
     'midas_merge_write_matrix',
+    'midas_comm_device_key', 'midas_comm_unique_id', 'midas_comm_create', 'midas_comm_destroy', 'midas_comm_all_gather', 'midas_comm_all_to_all_v',
 ]
 
 
@@ -892,6 +899,73 @@ class Context:
 
     def batch(self, contigs: ContigTable, reads: ReadsSoA) -> "Batch":
         return Batch(self, contigs, reads)
+
+
+class Comm:
+    """An RCCL communicator of the ranks' contexts (comm.cpp): the all-gather of the summary rows over xGMI and the genes
+    path's all-to-all, with no process group behind them.  midas_amd/dist.py makes one per job (the id travels through a file)."""
+
+    def __init__(self, ctx: "Context", id128: bytes, rank: int, world: int):
+        self._lib = ctx._lib
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        buf = C.create_string_buffer(bytes(id128), 128)
+        st = self._lib.midas_comm_create(ctx._h, C.cast(buf, C.c_void_p), self.rank, self.world, C.byref(h), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode() or "midas_comm_create failed")
+        self._h = h
+        self._ctx = ctx          # (the communicator runs on the context's stream: keep it alive)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load_library()
+        out, err = C.create_string_buffer(128), C.create_string_buffer(256)
+        st = lib.midas_comm_unique_id(C.cast(out, C.c_void_p), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode() or "midas_comm_unique_id failed")
+        return out.raw
+
+    @staticmethod
+    def device_key(ctx: "Context") -> str:
+        out = C.create_string_buffer(64)
+        ctx._check(ctx._lib.midas_comm_device_key(ctx._h, out))
+        return out.value.decode()
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.midas_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def all_gather(self, data: bytes):
+        """every rank's `data` (the same length everywhere), by rank"""
+        n = len(data)
+        out, err = C.create_string_buffer(max(1, n * self.world)), C.create_string_buffer(256)
+        src = C.create_string_buffer(bytes(data), max(1, n))
+        st = self._lib.midas_comm_all_gather(self._h, C.cast(src, C.c_void_p), C.cast(out, C.c_void_p), n, err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode() or "midas_comm_all_gather failed")
+        raw = out.raw
+        return [raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def all_to_all_v(self, parts, recv_bytes):
+        """parts[r]: the bytes for rank r; recv_bytes[r]: how many come from rank r -> the bytes received, by source rank"""
+        send = b"".join(bytes(p) for p in parts)
+        sb = np.array([len(p) for p in parts], np.int64)
+        rb = np.array([int(x) for x in recv_bytes], np.int64)
+        out, err = C.create_string_buffer(max(1, int(rb.sum()))), C.create_string_buffer(256)
+        src = C.create_string_buffer(send, max(1, len(send)))
+        st = self._lib.midas_comm_all_to_all_v(self._h, C.cast(src, C.c_void_p), sb.ctypes.data_as(C.c_void_p), C.cast(out, C.c_void_p),
+                                               rb.ctypes.data_as(C.c_void_p), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode() or "midas_comm_all_to_all_v failed")
+        raw, got, at = out.raw, [], 0
+        for n in rb:
+            got.append(raw[at:at + int(n)])
+            at += int(n)
+        return got
 
 
 class Batch:

@@ -17,7 +17,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_NAME = "libmidas_snps_hip.so"
 LIB_PATH = os.path.join(LIB_DIR, LIB_NAME)
 
-SOURCES = ["contigs.cpp", "hostio.cpp", "row_deflate.cpp", "pack_reads.hip", "index_reads.hip", "pileup_tiles.hip", "index_direct.hip", "pileup_direct.hip", "pileup_long.hip", "rows_deflate.hip", "bgzf_inflate.hip", "bam_walk.hip", "measure.hip", "merge_sites.hip", "genes_count.hip", "device_sort.hip", "snps_abi.hip"]
+SOURCES = ["contigs.cpp", "hostio.cpp", "row_deflate.cpp", "comm.cpp", "pack_reads.hip", "index_reads.hip", "pileup_tiles.hip", "index_direct.hip", "pileup_direct.hip", "pileup_long.hip", "rows_deflate.hip", "bgzf_inflate.hip", "bam_walk.hip", "measure.hip", "merge_sites.hip", "genes_count.hip", "device_sort.hip", "snps_abi.hip"]
 HEADERS = ["layout.h", "contigs.h", "kernels.h", "device_common.h", "pileup_common.h", "direct_common.h", "ctx_internal.h", "hostio.h", "row_deflate.h", "workers.h", "crc32.h", os.path.join("..", "..", "include", "midas_snps.h")]
 
 # The atomic optimizer turns a one-lane atomicAdd into mbcnt/readfirstlane and waits for the result at once; the

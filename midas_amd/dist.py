@@ -1,5 +1,5 @@
 """Multi-GPU plumbing for the pileup stage: one process per GPU, contigs sharded over ranks, and a single
-all-gather of the per-species summary rows (RCCL over xGMI when the backend is "nccl", gloo in CPU tests).
+all-gather of the per-species summary rows -- RCCL over xGMI.
 
 The reference's only parallelism is `mp.Pool(threads)` with one task per species whose return value,
 (species_id, aln_stats), is pickled back through a pipe (midas/run/snps.py:225-228, midas/utility.py:81-107).
@@ -7,15 +7,144 @@ Here the unit of work is the contig -- the unit `count_coverage` is called on (m
 species keeps every GPU busy; per-site output never leaves its rank (the owner writes its contigs' part of
 <species>.snps.gz, parts are concatenated in sorted-contig order), and only [n_species, 5] int64 counters (partial sums
 per rank) are exchanged.
+
+Two transports behind the same functions:
+
+* NATIVE (the product's, `init_from_env(rendezvous_dir=...)` under torchrun's RANK / WORLD_SIZE / LOCAL_RANK): no torch, no
+  process group -- a rank starts as fast as a single process.  The ranks of a node meet in a directory of the sample
+  (<outdir>/snps/temp): small control messages (does every rank still stand, the numbers of the rank-local decode plan) go
+  through files there; once a rank has its device context (`attach_context`) the ranks form an RCCL communicator through the
+  library's own binding (midas_comm_*, comm.cpp: ncclCommInitRank with the id rank 0 wrote) and the summary rows -- and the
+  genes path's all-to-all -- travel over xGMI.  Ranks that share ONE device (tests on a one-GPU box; RCCL refuses that) stay on
+  the files for those too.
+* TORCH (`init_from_env("gloo")`, or a process group the caller already initialised -- bench.py, the CPU tests): the same
+  collectives through torch.distributed.
 """
 
 import datetime
 import os
 import sys
+import time
 
 import numpy as np
 
 _STAT_COLS = 5   # genome_length, covered_bases, total_depth, aligned_reads, mapped_reads
+_native = None   # the native transport once init_from_env started it
+
+
+class _Native:
+    """The ranks of one node, met in a directory.  all_gather_bytes: every rank writes `<seq>.<rank>` (under a temporary
+    name, then renamed) and reads the others'; a rank removes its file of two exchanges ago when it starts a new one -- by
+    then every rank has read it (a rank that starts exchange k has finished k - 1, for which all had written k - 1, i.e. all
+    had finished reading k - 2)."""
+
+    def __init__(self, rank, ws, root):
+        self.rank, self.ws = rank, ws
+        nonce = "%s.%d.%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+        self.dir = os.path.join(root, "ranks." + nonce)
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+        self.comm = None
+        self.comm_state = "no device context yet"
+        self.deadline = COLLECTIVE_TIMEOUT.total_seconds()
+
+    def _path(self, seq, r):
+        return os.path.join(self.dir, "%d.%d" % (seq, r))
+
+    def all_gather_bytes(self, data):
+        seq = self.seq
+        self.seq += 1
+        if seq >= 2:
+            try:
+                os.remove(self._path(seq - 2, self.rank))
+            except OSError:
+                pass
+        mine = self._path(seq, self.rank)
+        with open(mine + ".tmp", "wb") as f:
+            f.write(data)
+        os.replace(mine + ".tmp", mine)
+        out, t0, nap = [], time.monotonic(), 0.0002
+        for r in range(self.ws):
+            if r == self.rank:
+                out.append(bytes(data))
+                continue
+            path = self._path(seq, r)
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    if time.monotonic() - t0 > self.deadline:
+                        sys.exit("\nError: rank %d waited %d s for rank %d at exchange %d (%s)\n" % (self.rank, self.deadline, r, seq, self.dir))
+                    time.sleep(nap)
+                    nap = min(nap * 1.5, 0.005)
+        return out
+
+    def attach(self, ctx):
+        """Form the RCCL communicator of the ranks' devices (once): rank 0 makes the id, a file carries it."""
+        if self.comm is not None or not hasattr(ctx, '_h'):
+            return
+        from . import abi
+        key = abi.Comm.device_key(ctx)
+        keys = [k.decode() for k in self.all_gather_bytes(key.encode())]
+        if len(set(keys)) < self.ws:
+            self.comm_state = "ranks share a device (%s): RCCL refuses that, the exchange stays on files" % ", ".join(sorted(set(keys)))
+            return
+        ident, error = b"\0" * 128, b""
+        if self.rank == 0:
+            try:
+                ident = abi.Comm.unique_id()
+            except abi.MidasSnpsError as e:
+                error = e.message.encode()
+        got = self.all_gather_bytes(ident + error)
+        if got[0][128:]:
+            self.comm_state = "RCCL is not available (%s): the exchange stays on files" % got[0][128:].decode()
+            return
+        try:
+            self.comm = abi.Comm(ctx, got[0][:128], self.rank, self.ws)
+            state = b"ok"
+        except abi.MidasSnpsError as e:
+            state = e.message.encode()
+        states = self.all_gather_bytes(state)
+        if any(x != b"ok" for x in states):
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            self.comm_state = "ncclCommInitRank failed (%s): the exchange stays on files" % b"; ".join(x for x in states if x != b"ok").decode()
+            return
+        self.comm_state = "RCCL communicator of %d ranks (librccl, ncclCommInitRank)" % self.ws
+
+    def data_all_gather(self, data):
+        """equal-sized payloads: over RCCL when the communicator stands"""
+        if self.comm is not None:
+            return self.comm.all_gather(data)
+        return self.all_gather_bytes(data)
+
+    def detach(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+            self.comm_state = "no device context any more"
+
+    def close(self):
+        """Leave: every other rank says so when it has read its last file; rank 0 waits for all of them -- it may remove the
+        sample's temp directory right afterwards."""
+        self.detach()
+        bye = lambda r: os.path.join(self.dir, "bye.%d" % r)
+        if self.rank != 0:
+            open(bye(self.rank), "wb").close()
+        else:
+            t0 = time.monotonic()
+            for r in range(1, self.ws):
+                while not os.path.exists(bye(r)):
+                    if time.monotonic() - t0 > 600:
+                        break
+                    time.sleep(0.001)
+        # (a rank's last files stay until rank 0 clears the place: somebody may still be reading them)
+        if self.rank == 0:          # (every other rank has left: the meeting place goes)
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
 
 
 def _alone():
@@ -23,11 +152,21 @@ def _alone():
     return int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1 and 'torch.distributed' not in sys.modules
 
 
+def _torch_group():
+    """torch.distributed when the caller initialised a group (bench.py, the gloo tests), else None -- without importing torch."""
+    if 'torch.distributed' not in sys.modules:
+        return None
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
 def world():
+    if _native is not None:
+        return _native.rank, _native.ws
     if _alone():
         return 0, 1
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    dist = _torch_group()
+    if dist is not None:
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
@@ -37,16 +176,29 @@ def world():
 COLLECTIVE_TIMEOUT = datetime.timedelta(hours=48)
 
 
-def init_from_env(device_backend=None):
-    """Join the process group torchrun described (RANK / WORLD_SIZE / MASTER_*); no-op for a single process."""
+def init_from_env(device_backend=None, rendezvous_dir=None):
+    """Join the ranks torchrun described (RANK / WORLD_SIZE / MASTER_*); no-op for a single process.
+    rendezvous_dir (and no backend named, no group initialised by the caller): the native transport, no torch.
+    device_backend "gloo" / "nccl": a torch.distributed process group, as the tests and bench.py use."""
+    global _native
+    if _native is not None:
+        return world()
     if _alone():
         return 0, 1
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if _torch_group() is not None:
+        return world()
+    if ws <= 1:
+        return 0, 1
+    if device_backend is None and rendezvous_dir is not None and os.environ.get("MIDAS_DIST_BACKEND", "native") == "native":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        _native = _Native(int(os.environ.get("RANK", "0")), ws, rendezvous_dir)
+        return world()
     import torch
     import torch.distributed as dist
-    ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or dist.is_initialized():
-        return world()
-    backend = device_backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    backend = device_backend or os.environ.get("MIDAS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "native":
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,6 +207,28 @@ def init_from_env(device_backend=None):
     else:
         dist.init_process_group(backend, timeout=COLLECTIVE_TIMEOUT)
     return world()
+
+
+def attach_context(ctx):
+    """The rank has its device context: the native transport forms its RCCL communicator on it (collective: every rank calls
+    this at the same point).  Returns a line for the log, or None when there is nothing to say."""
+    if _native is None:
+        return None
+    _native.attach(ctx)
+    return "ranks: %s" % _native.comm_state
+
+
+def detach_context():
+    """The device context is about to go: the communicator goes first (the files carry what little follows)."""
+    if _native is not None:
+        _native.detach()
+
+
+def finalize():
+    global _native
+    if _native is not None:
+        _native.close()
+        _native = None
 
 
 def exit_message(e):
@@ -78,6 +252,14 @@ def agree_or_exit(error_message=None):
         if error_message is not None:
             sys.exit(error_message)
         return
+    if _native is not None:
+        flags = _native.all_gather_bytes(b"1" if error_message is not None else b"0")
+        failed = [r for r, f in enumerate(flags) if f != b"0"]
+        if not failed:
+            return
+        if error_message is not None:
+            sys.exit(error_message)
+        sys.exit("\nError: rank(s) %s failed, see their message; rank %d stops with them\n" % (failed, rank))
     import torch
     import torch.distributed as dist
     flag = torch.tensor([1 if error_message is not None else 0], dtype=torch.int64)
@@ -119,6 +301,9 @@ def all_gather_summary(rows):
     rank, ws = world()
     if ws == 1:
         return rows.copy()
+    if _native is not None:       # ncclAllGather over xGMI (midas_comm_all_gather) once the communicator stands
+        got = _native.data_all_gather(rows.tobytes())
+        return np.sum([np.frombuffer(g, np.int64).reshape(rows.shape) for g in got], axis=0)
     import torch
     import torch.distributed as dist
     on_gpu = dist.get_backend() == "nccl"
@@ -136,6 +321,8 @@ def all_gather_i64(values):
     rank, ws = world()
     if ws == 1:
         return v.reshape(1, -1).copy()
+    if _native is not None:
+        return np.stack([np.frombuffer(g, np.int64) for g in _native.all_gather_bytes(v.tobytes())])
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(v)
@@ -153,6 +340,9 @@ def all_gather_rows_f64(rows):
     rank, ws = world()
     if ws == 1:
         return rows.copy()
+    if _native is not None:
+        got = _native.data_all_gather(rows.tobytes())
+        return np.sum([np.frombuffer(g, np.float64).reshape(rows.shape) for g in got], axis=0)
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(rows)
@@ -171,6 +361,20 @@ def all_to_all_v(parts):
     assert len(parts) == ws
     if ws == 1:
         return [parts[0].copy()]
+    if _native is not None:
+        dtype = parts[0].dtype
+        counts = all_gather_i64(np.array([p.size for p in parts], np.int64))        # counts[src, dst]
+        if _native.comm is not None:       # grouped ncclSend / ncclRecv (midas_comm_all_to_all_v)
+            got = _native.comm.all_to_all_v([p.tobytes() for p in parts], [int(n) * dtype.itemsize for n in counts[:, rank]])
+        else:                               # (ranks that share a device: every rank's parts through the files, each takes its own)
+            sizes = np.array([p.nbytes for p in parts], np.int64)
+            blobs = _native.all_gather_bytes(sizes.tobytes() + b"".join(p.tobytes() for p in parts))
+            got = []
+            for src in range(ws):
+                sz = np.frombuffer(blobs[src][:8 * ws], np.int64)
+                at = 8 * ws + int(sz[:rank].sum())
+                got.append(blobs[src][at:at + int(sz[rank])])
+        return [np.frombuffer(g, dtype).copy() for g in got]
     import torch
     import torch.distributed as dist
     dtype = parts[0].dtype
@@ -194,8 +398,11 @@ def all_to_all_v(parts):
 
 
 def barrier():
+    if _native is not None:
+        _native.all_gather_bytes(b"")
+        return
     if _alone():
         return
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    dist = _torch_group()
+    if dist is not None:
         dist.barrier()

@@ -139,7 +139,9 @@ def run_pipeline(args, make_context=_device_context):
     it, so one species with fifty samples keeps every GPU busy, as the reference's line-range shards keep every core
     (:366-386); the parts are concatenated afterwards.  Any other species goes whole to rank (index mod N).
     make_context: tests substitute a CPU double of the device."""
-    rank, ws = dist.init_from_env()
+    # (N ranks meet in the output directory: no process group, no torch -- midas_amd/dist.py; they exchange nothing but
+    # "still standing" flags: a species is sharded by site range and every rank writes its own part)
+    rank, ws = dist.init_from_env(rendezvous_dir=args['outdir'])
     if rank == 0:
         print("Identifying species and samples")
     species_list = merge.select_species(args, dtype='snps')
@@ -185,3 +187,4 @@ def run_pipeline(args, make_context=_device_context):
             write_snps_readme(args, species)
             species.write_sample_info(dtype='snps', outdir=args['outdir'])
     dist.barrier()
+    dist.finalize()

@@ -385,7 +385,13 @@ def pangenome_coverage(args, species, genes, make_context=None):
     error, ms = None, 0.0
     try:
         with make_context() as ctx:
-            ms = count_mapped_bp(args, species, genes, ctx, mine, owner)
+            line = dist.attach_context(ctx)      # (N ranks: the RCCL communicator of their devices, for the all-to-all of the pairs)
+            if line and rank == 0 and args.get('log') is not None:
+                args['log'].write(line + "\n")
+            try:
+                ms = count_mapped_bp(args, species, genes, ctx, mine, owner)
+            finally:
+                dist.detach_context()
     except abi.MidasSnpsError as e:
         error = "\nError: %s\n" % e.message
     except SystemExit as e:
@@ -413,7 +419,8 @@ def run_pipeline(args):
         print("  %s Gb maximum memory" % utility.max_mem_usage())
         return out
 
-    rank, ws = dist.init_from_env()
+    # (N ranks meet in the sample's temp directory: no process group, no torch -- midas_amd/dist.py)
+    rank, ws = dist.init_from_env(rendezvous_dir=os.path.join(args['outdir'], 'genes', 'temp'))
     species = timed("Reading reference data", None, initialize_species, args)
     genes = initialize_genes(args, species)
     if args['build_db'] and rank == 0:
@@ -425,5 +432,6 @@ def run_pipeline(args):
     if args['cov']:
         timed("Computing coverage of pangenomes", "Computing coverage of pangenomes", pangenome_coverage, args, species, genes)
     dist.barrier()
+    dist.finalize()
     if args['remove_temp'] and rank == 0:
         remove_tmp(args)

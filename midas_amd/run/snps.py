@@ -674,7 +674,13 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         # insertion: the query position advances); --pad_rule spec selects the SAM specification's (P consumes nothing)
         if hasattr(ctx, 'set_pad_rule'):
             ctx.set_pad_rule(abi.PAD_SPEC if args.get('pad_rule', 'pysam') == 'spec' else abi.PAD_PYSAM)
-        return _count_alleles(args, species, contigs, ctx)
+        line = dist.attach_context(ctx)      # (N ranks: the RCCL communicator of their devices, for the summary rows)
+        if line and dist.world()[0] == 0 and args.get('log') is not None:
+            args['log'].write(line + "\n")
+        try:
+            return _count_alleles(args, species, contigs, ctx)
+        finally:
+            dist.detach_context()
 
 
 def _inflate_on_device(args, ctx, bampath, ws):
@@ -853,7 +859,8 @@ def remove_tmp(args):
 
 def run_pipeline(args):
     """Run entire pipeline -- midas/run/snps.py:268-305"""
-    rank, ws = dist.init_from_env()
+    # (N ranks meet in the sample's temp directory: no process group, no torch -- midas_amd/dist.py)
+    rank, ws = dist.init_from_env(rendezvous_dir=os.path.join(args['outdir'], 'snps', 'temp'))
 
     print("\nReading reference data")
     start = time()
@@ -901,6 +908,7 @@ def run_pipeline(args):
         if rank == 0:
             snps_summary(args, species)
     dist.barrier()
+    dist.finalize()      # (rank 0 returns when every rank has left the rendezvous directory: it may go with temp/)
 
     if args['remove_temp'] and rank == 0:
         remove_tmp(args)

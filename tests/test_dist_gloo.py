@@ -211,7 +211,11 @@ class OracleContext:
 
 out, db = sys.argv[1], sys.argv[2]
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    dist.init_from_env("gloo")
+    if os.environ.get("SNPS_TRANSPORT") == "native":      # the product's own: the ranks meet in the sample's temp directory, no torch
+        dist.init_from_env(rendezvous_dir=os.path.join(out, "snps", "temp"))
+        assert "torch" not in sys.modules
+    else:
+        dist.init_from_env("gloo")
 rank, ws = dist.world()
 args = dict(outdir=out, db=db, build_db=False, align=False, call=True, species_id=None, threads=2, log=io.StringIO(),
             mapid=94.0, readq=20, mapq=20, baseq=30, aln_cov=0.75, remove_temp=False)
@@ -230,11 +234,16 @@ if rank == 0:
     msnps.snps_summary(args, species)
     print("LOG:" + args['log'].getvalue().replace("\n", "|"))
 dist.barrier()
+dist.finalize()
+if os.environ.get("SNPS_TRANSPORT") == "native":
+    assert "torch" not in sys.modules
 '''
 
 
-def _run_snps_workers(tmp_path, script, outdir, db, n_ranks):
+def _run_snps_workers(tmp_path, script, outdir, db, n_ranks, transport=None):
     env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if transport:
+        env1["SNPS_TRANSPORT"] = transport
     if n_ranks == 1:
         r = subprocess.run([sys.executable, str(script), outdir, db], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            env=env1, timeout=300)
@@ -285,6 +294,58 @@ def test_two_ranks_snps_outputs_equal_single(tmp_path):
                 a = open(os.path.join(one, "snps", "output", f), "rb").read()
                 b = open(os.path.join(many, "snps", "output", f), "rb").read()
                 assert a == b, "%s differs between 1 and %d ranks" % (f, n)
+
+
+def test_native_transport_ranks_meet_in_the_samples_directory(tmp_path):
+    """The product's own transport (midas_amd/dist.py): under RANK / WORLD_SIZE the ranks meet in <outdir>/snps/temp and never
+    import torch -- the flags of agree_or_exit, the numbers of the rank-local decode plan and (with no device to form an RCCL
+    communicator on: the device is played by the oracle here) the summary rows all travel through files there.  2 and 3 ranks:
+    every table and summary.txt byte for byte the single process's, nothing left behind in the meeting place."""
+    import shutil
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=3, contig_len=17000, n_reads=9000, seed=12)
+    db, one = str(tmp_path / "db"), str(tmp_path / "n1")
+    synth.write_sample(one, db, contigs, reads)
+    (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+    assert rc == 0, e
+    for n in (2, 3):
+        many = str(tmp_path / ("n%d" % n))
+        shutil.copytree(one, many, ignore=shutil.ignore_patterns("output"))
+        os.makedirs(os.path.join(many, "snps", "output"))
+        res = _run_snps_workers(tmp_path, script, many, db, n, transport="native")
+        for rc, o, e in res:
+            assert rc == 0, e
+        assert any("rank-local BAM decode: %d slices chained" % n in o for _, o, _ in res)
+        assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
+        for f in sorted(os.listdir(os.path.join(one, "snps", "output"))):
+            assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(many, "snps", "output", f), "rb").read(), f
+        assert not [d for d in os.listdir(os.path.join(many, "snps", "temp")) if d.startswith("ranks.")]
+
+
+def test_native_transport_a_failing_rank_takes_the_others_down(tmp_path):
+    """agree_or_exit over the files: a rank whose stage fails leaves with its message, the others name it and leave too."""
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+from midas_amd import dist
+rank, ws = dist.init_from_env(rendezvous_dir=sys.argv[1])
+dist.agree_or_exit(None)
+dist.agree_or_exit("\\nError: rank 1 could not read its slice\\n" if rank == 1 else None)
+print("not reached")
+''' % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = [subprocess.Popen([sys.executable, str(script), str(meet)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"))
+             for k in range(3)]
+    res = [(p.communicate(timeout=120), p.returncode) for p in procs]
+    for k, ((o, e), rc) in enumerate(res):
+        assert rc != 0 and "not reached" not in o
+        assert ("could not read its slice" in e) if k == 1 else ("rank(s) [1] failed" in e), (k, e)
 
 
 def test_one_long_contig_is_cut_into_pieces_across_ranks(tmp_path):

@@ -115,3 +115,63 @@ def test_genes_ranks_sharing_one_gpu_write_the_single_process_files(tmp_path):
         for sp in ds['species_ids']:
             a = gzip.open(os.path.join(cpu, "genes", "output", sp + ".genes.gz"), "rb").read()
             assert gzip.open(os.path.join(outs[n], "genes", "output", sp + ".genes.gz"), "rb").read() == a, "%s: %d ranks" % (sp, n)
+
+
+def test_the_librarys_rccl_binding_on_a_one_rank_communicator():
+    """midas_comm_* (comm.cpp): ncclGetUniqueId / ncclCommInitRank / ncclAllGather / grouped ncclSend + ncclRecv of librccl.so,
+    loaded at run time, on the one GPU this box has (RCCL refuses two ranks on one device: the N-rank form is the driver's
+    8-GPU run).  No torch anywhere in the process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from midas_amd import abi
+ctx = abi.Context(0)
+ident = abi.Comm.unique_id()
+assert len(ident) == 128 and any(ident)
+comm = abi.Comm(ctx, ident, 0, 1)
+rows = np.arange(100 * 5, dtype=np.int64).reshape(100, 5) * 3 - 7
+got = comm.all_gather(rows.tobytes())
+assert len(got) == 1 and np.array_equal(np.frombuffer(got[0], np.int64).reshape(100, 5), rows)
+blob = np.random.default_rng(1).integers(0, 255, 1 << 20, dtype=np.uint8).tobytes()
+back = comm.all_to_all_v([blob], [len(blob)])
+assert back == [blob]
+assert comm.all_to_all_v([b""], [0]) == [b""]
+comm.close()
+ctx.close()
+assert "torch" not in sys.modules
+print("rccl ok", abi.Comm.device_key(abi.Context(0)))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_native_transport_with_ranks_sharing_one_gpu(tmp_path):
+    """The product's own transport on a real device: 2 and 3 ranks meet in the sample's temp directory, find that they share
+    one GPU (the log says so: RCCL refuses that) and keep to the files for the summary rows too -- the tables and summary.txt
+    are byte for byte the single process's, and torch is never imported (the worker asserts it)."""
+    from midas_amd import synth
+    script = tmp_path / "snps_worker.py"
+    script.write_text(SNPS_WORKER % {"root": ROOT})
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=3, contig_len=17000, n_reads=9000, seed=12)
+    db, one = str(tmp_path / "db"), str(tmp_path / "n1")
+    synth.write_sample(one, db, contigs, reads)
+    os.environ["SNPS_REAL_DEVICE"] = "1"
+    try:
+        (rc, o, e), = _run_snps_workers(tmp_path, script, one, db, 1)
+        assert rc == 0, e[-1500:]
+        for n in (2, 3):
+            many = str(tmp_path / ("n%d" % n))
+            shutil.copytree(one, many, ignore=shutil.ignore_patterns("output"))
+            os.makedirs(os.path.join(many, "snps", "output"))
+            res = _run_snps_workers(tmp_path, script, many, db, n, transport="native")
+            assert all(rc == 0 for rc, _, _ in res), "\n".join("rank %d: rc %d\n%s" % (k, rc, e[-1500:]) for k, (rc, _, e) in enumerate(res))
+            assert any("ranks share a device" in o for _, o, _ in res)
+            assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
+            for f in sorted(os.listdir(os.path.join(one, "snps", "output"))):
+                assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(many, "snps", "output", f), "rb").read(), f
+    finally:
+        os.environ.pop("SNPS_REAL_DEVICE", None)
