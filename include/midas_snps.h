@@ -351,6 +351,18 @@ int32_t midas_bam_copy(const midas_bam* bam, int32_t* refid, int32_t* pos, uint8
  * Replaces the same `pysam.AlignmentFile` + `fetch(contig, ...)` of midas/run/snps.py:186, 194-199 (which goes through
  * the .bai the reference builds at :130-137; no index file is needed here).                                           */
 int32_t midas_bam_open_slice(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, char* err256);
+/* The ONE-PASS form of the rank-local decode, for a coordinate-sorted BAM whose references are short beside a rank's share
+ * (the usual metagenome: thousands of contigs): the file is dealt to the ranks as CONTIGUOUS runs of whole references.  Rank
+ * `slice` of `n_slices` looks where its equal share of the file's bytes begins, guesses a record start there and walks the
+ * records -- on the host, a few blocks -- to the first record of the next reference, at most max_walk uncompressed bytes on.
+ * out3 = {first, total, rec_begin}: `first` = the uncompressed offset its share begins at (rec_begin for slice 0; `total` for an
+ * empty share; -1: no reference border within max_walk -- a long chromosome: plan with midas_bam_open_slice instead).  The ranks
+ * exchange their `first` (one all-gather of one number each) and every rank decodes [first of its own, first of the next) ONCE
+ * with midas_bam_load_ranges / _device on this handle -- which also proves the next rank's guess: a range must end exactly on a
+ * record border, and rank 0 starts at the header's end.  The reference reads the file once per worker through the index
+ * (midas/run/snps.py:186-199); so does this, without an index.                                                          */
+int32_t midas_bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3,
+                             char* err256);
 /* The decoder's inverse (host only; what puts the synthetic samples of bench.py and the tests on disk -- samtools is not in
  * the image): records in the given order, refid[i] = reference of record i (-1: unmapped), names "r<i>", aux = NM + YT:Z:UU,
  * BGZF blocks of 0xff00 bytes deflated at `level` (0-9) by `threads` threads (0: the CPU budget), CRC-32 and the EOF block

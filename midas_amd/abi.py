@@ -284,6 +284,7 @@ def load_library(build_if_missing: bool = True):
         'midas_genes_terms': (i32, [vp, C.POINTER(Thresholds), C.POINTER(_Reads), vp, i64, vp, vp, C.POINTER(C.c_float)]),
         'midas_genes_sum': (i32, [vp, i64, vp, vp, i64, vp, vp, vp, C.POINTER(C.c_float)]),
         'midas_merge_sites': (i32, [vp, C.POINTER(MergeParams), i32, i64, C.POINTER(vp), vp] + [vp] * 5 + [C.POINTER(C.c_float)]),
+        'midas_bam_open_share': (i32, [C.c_char_p, i32, i32, i64, C.POINTER(vp), vp, C.c_char_p]),
         'midas_comm_device_key': (i32, [vp, C.c_char_p]),
         'midas_comm_unique_id': (i32, [vp, C.c_char_p]),
         'midas_comm_create': (i32, [vp, vp, i32, i32, C.POINTER(vp), C.c_char_p]),
@@ -321,6 +322,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_genes_terms', 'midas_genes_sum', 'midas_merge_write_info',
     'midas_merge_write_matrix',
+    'midas_bam_open_share',
     'midas_comm_device_key', 'midas_comm_unique_id', 'midas_comm_create', 'midas_comm_destroy', 'midas_comm_all_gather', 'midas_comm_all_to_all_v',
 ]
 
@@ -670,6 +672,25 @@ class BamSlice:
             self._h = None
 
     __del__ = close
+
+
+class BamShare(BamSlice):
+    """A rank's CONTIGUOUS share of a coordinate-sorted BAM (midas_bam_open_share): where this rank's equal share of the file's
+    bytes begins, moved forward to the next reference's first record.  `first` (-1: no reference border nearby), `total`,
+    `rec_begin`; load_ranges as a slice's -- the one-pass rank-local decode of midas_amd/run/snps.py."""
+
+    def __init__(self, path: str, slice_index: int, n_slices: int, max_walk: int = 256 << 20):
+        self._lib = load_library()
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        out3 = np.zeros(3, np.int64)
+        st = self._lib.midas_bam_open_share(path.encode(), int(slice_index), int(n_slices), int(max_walk), C.byref(h),
+                                            out3.ctypes.data_as(C.c_void_p), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        self._h = h
+        self.ref_names, self.ref_lens = _bam_refs(self._lib, h)
+        self.first, self.total, self.rec_begin = (int(x) for x in out3)
 
 
 class PinnedPool:

@@ -1528,6 +1528,96 @@ int32_t midas::bam_open_slice_with(const char* path, int32_t slice, int32_t n_sl
   return MIDAS_SNPS_OK;
 }
 
+// A rank's CONTIGUOUS share of a coordinate-sorted BAM, for the one-pass rank-local decode: the file is cut where slice
+// `slice` of `n_slices` equal byte shares begins, moved FORWARD to the first record of the next reference (contig) -- found by
+// inflating a few blocks on the host: a record start is guessed (32 plausible records in a row) and the records walked until the
+// refID changes, at most max_walk uncompressed bytes.  out3 = {first, total, rec_begin}: first = uncompressed offset of the
+// share's first record (the header's end for slice 0; -1: no contig border within max_walk, or no boundary could be guessed --
+// the caller then plans the old way, midas_bam_open_slice; total when the share is empty).  The boundary is a GUESS until the
+// rank before has decoded its own share up to exactly this offset (midas_bam_load_ranges checks that a range ends on a record
+// border).  The handle takes midas_bam_load_ranges / _device like a slice's.
+int32_t midas::bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3, char* err256) {
+  if (!path || !out || !out3 || n_slices < 1 || slice < 0 || slice >= n_slices || max_walk < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
+  if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  b->path = path;
+  b->map.reset(new BgzfMap());
+  int32_t st = bgzf_map_file(b->path, *b->map, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  const BgzfMap& m = *b->map;
+  const size_t nb = m.blocks.size();
+  size_t rec_begin = 0;
+  {
+    BamWindow w;
+    w.m = &m;
+    size_t k = 1;
+    for (;;) {
+      if (!w.extend(std::min(nb, k))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      bool bad_magic = false;
+      rec_begin = parse_bam_header(w.buf.data(), w.buf.size(), b.get(), &bad_magic);
+      if (bad_magic) { set_err(err256, "%s: missing BAM magic", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      if (rec_begin) break;
+      if (k >= nb) { set_err(err256, "%s: truncated BAM header", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      k *= 2;
+    }
+  }
+  b->rec_begin = rec_begin;
+  const size_t n_ref = b->ref_lens.size();
+  b->ref_reads.assign(n_ref, 0);
+  b->ref_bases.assign(n_ref, 0);
+  b->ref_first.assign(n_ref, -1);
+  b->ref_span.assign(n_ref, 0);
+  out3[1] = (int64_t)m.total;
+  out3[2] = (int64_t)rec_begin;
+  int64_t first = -1;
+  if (slice == 0) {
+    first = (int64_t)rec_begin;
+  } else {
+    size_t lo = 0, hi = nb;
+    const size_t fpos = (size_t)((unsigned __int128)m.size * slice / n_slices);
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].fpos < fpos) lo = mid + 1; else hi = mid; }
+    const uint64_t u_lo = std::max<uint64_t>(lo < nb ? m.blocks[lo].upos : m.total, rec_begin);
+    if (u_lo >= m.total) {
+      first = (int64_t)m.total;
+    } else {
+      BamWindow w;
+      w.m = &m;
+      {
+        size_t a = 0, z = nb;
+        while (a < z) { const size_t mid = (a + z) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u_lo) a = mid + 1; else z = mid; }
+        w.b_lo = w.b_hi = a;
+      }
+      if (!w.extend(std::min(nb, w.b_lo + 2))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      const int64_t g = u_lo == rec_begin ? (int64_t)rec_begin : guess_record_start(w, u_lo, b->ref_lens, 32);
+      if (g >= 0) {
+        uint64_t u = (uint64_t)g;
+        int32_t prev = 0x7fffffff;
+        while (u < m.total && u - (uint64_t)g <= (uint64_t)max_walk) {
+          uint32_t bs = 0;
+          if (!plausible_record(w, u, b->ref_lens, &bs) || !w.need(u, 4ull + bs)) break;      // (a wrong guess runs into this: no boundary)
+          const int32_t refid = (int32_t)rd32(w.at(u) + 4);
+          if (prev != 0x7fffffff && refid != prev) { first = (int64_t)u; break; }
+          prev = refid;
+          u += 4ull + bs;
+        }
+        if (first < 0 && u >= m.total) first = (int64_t)m.total;        // the file's last reference runs to the end: an empty share
+      }
+    }
+  }
+  out3[0] = first;
+  b->slice_first = first;
+  b->slice_end = first;
+  *out = b.release();
+  return MIDAS_SNPS_OK;
+}
+
+extern "C" {
+int32_t midas_bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3, char* err256) {
+  return midas::bam_open_share(path, slice, n_slices, max_walk, out, out3, err256);
+}
+}
+
 extern "C" {
 
 int32_t midas_bam_slice_facts(const midas_bam* b, int64_t* out7, int64_t* ref_reads, int64_t* ref_bases, int64_t* ref_first) {

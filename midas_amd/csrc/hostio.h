@@ -89,6 +89,7 @@ int32_t bam_decode_on_device(const char* path, const DeviceDecoder* dec, midas_b
 // the slice's blocks are inflated and walked on the device, the host folds the records' columns into the slice's facts; a
 // rank's record ranges are decoded like a whole file, SEQ / QUAL / CIGAR staying on the device
 int32_t bam_open_slice_with(const char* path, int32_t slice, int32_t n_slices, const DeviceDecoder* dec, midas_bam** out, char* err256);
+int32_t bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3, char* err256);
 int32_t bam_load_ranges_on_device(midas_bam* bam, const DeviceDecoder* dec, int32_t n_ranges, const int64_t* range_begin,
                                   const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                   int64_t* n_cigar, char* err256);

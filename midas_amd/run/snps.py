@@ -613,6 +613,40 @@ def _rank_local_plan(bampath, rank, ws, inflater=None):
                 mark_key=key[firstk], mark_off=off[firstk])
 
 
+def _header_lengths(bampath):
+    """The reference lengths of the BAM's header (None when it cannot be read: the decode that follows says why)."""
+    try:
+        sh = abi.BamShare(bampath, 0, 1)
+    except abi.MidasSnpsError:
+        return None
+    try:
+        return [int(x) for x in sh.ref_lens]
+    finally:
+        sh.close()
+
+
+def _one_pass_shares(bampath, rank, ws):
+    """The one-pass form of the rank-local decode (include/midas_snps.h, midas_bam_open_share): the file is dealt to the ranks as
+    contiguous runs of whole contigs -- every rank looks where its equal share of the bytes begins and walks a few blocks on to
+    the next contig's first record; one all-gather of those offsets; rank r then decodes [first_r, first_r+1) ONCE, and that
+    decode proves the next rank's guess (a range must end on a record border; rank 0 starts at the header's end).  Returns
+    (handle, begin, end) or None when a rank found no contig border nearby (the caller plans with the slices, as before)."""
+    error, sh = None, None
+    try:
+        sh = abi.BamShare(bampath, rank, ws)
+    except abi.MidasSnpsError as e:
+        error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+    dist.agree_or_exit(error)
+    allv = dist.all_gather_i64([sh.first, sh.total, sh.rec_begin, len(sh.ref_names)])
+    firsts = [int(x) for x in allv[:, 0]] + [int(allv[0, 1])]
+    ok = bool((allv[:, 0] >= 0).all() and (allv[:, 1] == allv[0, 1]).all() and (allv[:, 3] == allv[0, 3]).all()
+              and firsts[0] == int(allv[0, 2]) and all(a <= b for a, b in zip(firsts[:-1], firsts[1:])))
+    if not ok:
+        sh.close()
+        return None
+    return sh, firsts[rank], firsts[rank + 1]
+
+
 def _offset_at(plan, ref, x):
     """An offset at or in front of reference `ref`'s first record at a position >= x, and behind every record at a position
     below x rounded down to the marks' grid (midas_bam_slice_marks; positions sorted inside the reference)."""
@@ -719,13 +753,61 @@ def _count_alleles(args, species, contigs, ctx):
     if rank == 0:
         _remove_stale_parts(args)       # (before the first point every rank waits at)
     inflater = ctx if _inflate_on_device(args, ctx, bampath, ws) else None
-    # N ranks: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and each
-    # decodes only the records of the contigs it ends up owning.  One rank (or a BAM the slices cannot vouch for:
-    # not coordinate-sorted, or a guessed record boundary that the neighbouring slice does not confirm): decode it whole.
-    plan = _rank_local_plan(bampath, rank, ws, inflater) if ws > 1 else None
+    # N ranks, ONE pass where the contigs are short beside a rank's share (the usual metagenome): contiguous shares of whole
+    # contigs, every block inflated once, by the rank that piles its records up (_one_pass_shares).  A contig longer than the
+    # split length wants to be cut into pieces, which needs the slices' walk: the two-pass plan below.
     error = None
     decoded = None
-    if plan is None:
+    plan, share = None, None
+    split_length = int(args.get('split_length', SPLIT_LENGTH))
+    if ws > 1:
+        lengths = _header_lengths(bampath)
+        if lengths is not None and (split_length <= 0 or max(lengths, default=0) <= pieces.piece_length(split_length)):
+            share = _one_pass_shares(bampath, rank, ws)
+        if share is not None:
+            retry = 0
+            try:
+                refid, reads = share[0].load_ranges([(share[1], share[2])], inflater)
+                decoded = (share[0].ref_names, share[0].ref_lens, refid, reads)
+            except abi.MidasSnpsError as e:
+                if e.status == abi.ERR_BAD_LAYOUT and "ends inside a record" in e.message:
+                    retry = 1          # (the next rank's guessed border is not a record border: plan with the slices instead)
+                elif inflater is not None and args.get('device_inflate', 'auto') == 'auto' and e.status in (abi.ERR_OUT_OF_MEMORY, abi.ERR_HIP):
+                    retry = 1
+                else:
+                    error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
+            dist.agree_or_exit(error)
+            if int(dist.all_gather_i64([retry])[:, 0].max()):
+                share[0].close()
+                share, decoded = None, None
+        # ... else two passes: every rank walks its share of the BAM's bytes, the ranks exchange a few numbers per reference, and
+        # each decodes only the records of the contigs (or pieces) it ends up owning.  A BAM the slices cannot vouch for (not
+        # coordinate-sorted, a guessed record boundary the neighbouring slice does not confirm): decoded whole, as one rank does.
+        if share is None:
+            plan = _rank_local_plan(bampath, rank, ws, inflater)
+    if share is not None:
+        # whole contigs per rank only if the file is grouped by reference: every share's refIDs ascending, and the next share's
+        # first beyond this one's last
+        ref_names, ref_lens, refid, reads = decoded
+        grouped = int(refid.size < 2 or bool((refid[1:] >= refid[:-1]).all()))
+        have = dist.all_gather_i64([int(refid[0]) if refid.size else -1, int(refid[-1]) if refid.size else -1, int(reads.n_reads), grouped])
+        seen = -1
+        for k in range(ws):
+            if have[k, 0] >= 0:
+                grouped = grouped and have[k, 0] > seen
+                seen = int(have[k, 1])
+        if not (grouped and bool((have[:, 3] == 1).all())):
+            share[0].close()
+            share, decoded = None, None
+            plan = _rank_local_plan(bampath, rank, ws, inflater)
+    if share is not None:
+        read_bytes = np.zeros(len(ref_names))
+        if rank == 0:
+            line = "rank-local BAM decode: %d slices chained in ONE pass (contiguous shares of whole contigs), %d records; records decoded per rank: %s" % (
+                ws, int(have[:, 2].sum()), ' '.join(str(int(x)) for x in have[:, 2]))
+            print("  " + line)
+            args['log'].write(line + "\n")
+    elif plan is None:
         try:
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
             try:
@@ -775,14 +857,27 @@ def _count_alleles(args, species, contigs, ctx):
                 it = (cid, j)
                 order[sp].append(it)
                 span[it] = (lo, hi, j + 1 == len(cuts))
-                share = 1.0
+                frac = 1.0
                 if len(cuts) > 1:        # the piece's share of the contig's reads: its share of the record bytes
                     b, e = _piece_range(plan, r, lo, hi, span[it][2])
-                    share = (e - b) / float(max(1, plan['ref_end'][r] - plan['ref_first'][r]))
+                    frac = (e - b) / float(max(1, plan['ref_end'][r] - plan['ref_first'][r]))
                     halo[cid] = int(plan['ref_span'][r])
                 # ~1.63 B per aligned base, 17 B per site
-                weight[it] = 1.6 * share * float(read_bytes[r] if r >= 0 else 0.0) + 17.0 * (hi - lo)
-    owner = dist.shard_items(weight, ws)
+                weight[it] = 1.6 * frac * float(read_bytes[r] if r >= 0 else 0.0) + 17.0 * (hi - lo)
+    if share is not None:
+        # a contig is piled up by the rank that decoded its records; one without any goes to the last rank whose records lie in
+        # front of it (every rank computes the same assignment from the same few numbers)
+        owner = {}
+        for sp in all_ids:
+            for it in order[sp]:
+                r = ref_index.get(it[0], -1)
+                at = 0
+                for k in range(ws):
+                    if have[k, 0] >= 0 and have[k, 0] <= r:
+                        at = k
+                owner[it] = at
+    else:
+        owner = dist.shard_items(weight, ws)
     mine = [it for sp in all_ids for it in order[sp] if owner[it] == rank]
     if plan is not None:
         try:

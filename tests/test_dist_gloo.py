@@ -285,7 +285,7 @@ def test_two_ranks_snps_outputs_equal_single(tmp_path):
             res = _run_snps_workers(tmp_path, script, many, db, n)
             for rc, o, e in res:
                 assert rc == 0, e
-            assert any("rank-local BAM decode: %d slices chained" % n in o for _, o, _ in res)   # nobody decoded the whole file
+            assert any("rank-local BAM decode: %d slices chained in ONE pass" % n in o for _, o, _ in res)   # every block inflated once, by its owner
             assert open(os.path.join(many, "snps", "summary.txt")).read() == open(os.path.join(one, "snps", "summary.txt")).read()
             files = sorted(os.listdir(os.path.join(one, "snps", "output")))
             assert sorted(os.listdir(os.path.join(many, "snps", "output"))) == files       # no part file left behind
