@@ -24,6 +24,17 @@ namespace midas {
 namespace {
 
 constexpr int kLanes = 64;
+// Streams per workgroup of the decoder.  A stream's tables take 2.5 KiB of LDS, so a CU holds 64 streams whatever the shape;
+// what the shape decides is how many WAVEFRONTS those 64 streams are.  The decoder is a chain of dependent LDS reads (table
+// look-up, input ring) and the lanes of a wavefront diverge at every step (literal / match / long code / refill: a step costs
+// the sum of the paths any lane takes).  Measured on the 46 500 blocks of configs[2]'s BAM (profiles/r05_inflate_shapes.txt):
+// 64 streams per wavefront 78.7 ms, 16: 76.3, 8: 68.3, 4: 83.4 (the CU no longer holds 64 streams), 2: 122.  With the literal
+// stores compiled out: 73 of 76 ms -- the stores are not what it waits for.
+#ifndef MIDAS_INFLATE_LANES
+#define MIDAS_INFLATE_LANES 8
+#endif
+constexpr int kDecLanes = MIDAS_INFLATE_LANES;
+static_assert(kDecLanes >= 2 && kDecLanes <= 64 && (kDecLanes & (kDecLanes - 1)) == 0, "a power of two up to a wavefront");
 constexpr int kLlBits = 9, kDBits = 7;
 // u16 arrays, per lane, interleaved [index][lane]
 constexpr int kLutLl = 0;                       // 512: (symbol << 4) | length, 0 = not in the table
@@ -55,9 +66,9 @@ struct Lds {
   lds_u8* s8;
   lds_u32* s32;
   int lane;
-  __device__ __forceinline__ lds_u32& r(uint32_t i) const { return s32[(i & (kRing - 1)) * kLanes + lane]; }
-  __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kLanes + lane]; }
-  __device__ __forceinline__ lds_u8& b(int i) const { return s8[i * kLanes + lane]; }
+  __device__ __forceinline__ lds_u32& r(uint32_t i) const { return s32[(i & (kRing - 1)) * kDecLanes + lane]; }
+  __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kDecLanes + lane]; }
+  __device__ __forceinline__ lds_u8& b(int i) const { return s8[i * kDecLanes + lane]; }
 };
 
 // The compressed stream, least significant bit first (RFC 1951 3.1.1).  Between memory and the bit buffer sits a ring of 32
@@ -281,7 +292,11 @@ struct ByteOut {
     if (lead) { dst[o++] = (uint8_t)b; --lead; return; }
     acc |= b << (8 * na);
     ++o;
+#ifdef MIDAS_INFLATE_NO_STORE      // (developer timing variant: the literals are not stored -- WRONG output)
+    if (++na == 4) { acc = 0; na = 0; }
+#else
     if (++na == 4) { *reinterpret_cast<uint32_t*>(dst + o - 4) = acc; acc = 0; na = 0; }
+#endif
   }
   __device__ __forceinline__ void flush() {
     for (int k = 0; k < na; ++k) dst[o - na + k] = (uint8_t)(acc >> (8 * k));
@@ -372,11 +387,11 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
   return out.o == ulen ? kOk : kShortOutput;
 }
 
-__global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateParams p) {
-  __shared__ uint16_t s16[kU16 * kLanes];
-  __shared__ uint8_t s8[kLens * kLanes];
-  __shared__ uint32_t s32[kRing * kLanes];
-  const long long k = (long long)blockIdx.x * kLanes + threadIdx.x;
+__global__ __launch_bounds__(kDecLanes) void bgzf_inflate_kernel(InflateParams p) {
+  __shared__ uint16_t s16[kU16 * kDecLanes];
+  __shared__ uint8_t s8[kLens * kDecLanes];
+  __shared__ uint32_t s32[kRing * kDecLanes];
+  const long long k = (long long)blockIdx.x * kDecLanes + threadIdx.x;
   if (k >= p.n_blocks) return;
   Lds L{(lds_u16*)s16, (lds_u8*)s8, (lds_u32*)s32, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
@@ -512,8 +527,8 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
       return fa.sharedSizeBytes <= (size_t)lds;
     }();
     if (!fits) return hipErrorLaunchOutOfResources;
-    const long long g = (p.n_blocks + kLanes - 1) / kLanes;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kLanes), 0, s, p);
+    const long long g = (p.n_blocks + kDecLanes - 1) / kDecLanes;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kDecLanes), 0, s, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -28,7 +28,10 @@ using namespace direct;
 namespace {
 
 constexpr int kIdxBlock = 256;
-constexpr int kIdxRun = 2048;        // reads per workgroup
+#ifndef MIDAS_IDX_RUN
+#define MIDAS_IDX_RUN 2048
+#endif
+constexpr int kIdxRun = MIDAS_IDX_RUN;        // reads per workgroup
 
 // contig of read i: the last contig whose first read is <= i (empty contigs share their begin with the next one)
 __device__ __forceinline__ int contig_of_read(const DirectIndexParams& p, int i) {

@@ -172,6 +172,10 @@ constexpr uint32_t kGenIdle = 0x80;               // flag byte of a lane without
 #define MIDAS_DIRECT_CHUNK 4
 #endif
 constexpr int kDirectChunkTiles = MIDAS_DIRECT_CHUNK;
+#ifndef MIDAS_DIRECT_TAIL_DIV
+#define MIDAS_DIRECT_TAIL_DIV 8
+#endif
+constexpr int kDirectTailDiv = MIDAS_DIRECT_TAIL_DIV;      // the last 1 / kDirectTailDiv of the tiles are dealt one by one
 constexpr int kDirectOverhang = 160;
 
 constexpr int kDirectFactSlots = 64;

@@ -1933,7 +1933,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.chunk_tiles = 1; dp.n_chunked_tiles = 0;
     if (kDirectChunkTiles > 1 && b->direct_sorted && b->direct_reach <= kDirectOverhang) {
       dp.chunk_tiles = kDirectChunkTiles;
-      dp.n_chunked_tiles = (int32_t)((b->n_tiles - b->n_tiles / 8) / kDirectChunkTiles * kDirectChunkTiles);
+      dp.n_chunked_tiles = (int32_t)((b->n_tiles - b->n_tiles / kDirectTailDiv) / kDirectChunkTiles * kDirectChunkTiles);
     }
     HIP_TRY(ctx, launch_pileup_direct(dp, b->direct_lane_bases, s));
     if (ev) {
