@@ -4,7 +4,7 @@
 # bench command for configs[2] and configs[1].  Text summaries only land in gpurun_out/evidence/ (the rocpd databases are
 # tens of MiB each and are deleted here).   usage: tools/evidence.sh [tag]
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV
@@ -41,4 +41,7 @@ E2E_REPS=3 timeout 900 python tools/e2e_stage.py c2 /tmp/e2e_c2 > $EV/e2e_stage_
   f=$(find $REPO/gpurun_out/prof_rows -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && { echo "# kernel_stats.csv"; head -12 "$f"; }; } > $EV/${TAG}_rows_probe_c2.txt 2>&1
 rm -rf $REPO/gpurun_out/prof_rows
+# the merge kernel at configs[4]'s shape (50 samples), a soak of random shapes against the oracle on every path
+bash tools/profile_merge.sh ${TAG}_merge 2000000 50 > /dev/null 2>&1; cp $REPO/gpurun_out/prof_${TAG}_merge/summary.txt $EV/${TAG}_merge_sites.txt
+timeout 600 python tools/soak.py 300 5 > $EV/${TAG}_soak.txt 2>&1
 ls -la $EV

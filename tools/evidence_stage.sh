@@ -3,7 +3,7 @@
 # device, alternating), configs[3] through the files with the command line, and the multi-rank product path as 1, 2 and 3
 # processes on one GPU.  Text only, into gpurun_out/evidence/.   usage: tools/evidence_stage.sh [tag]
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV

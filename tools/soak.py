@@ -80,6 +80,14 @@ def main():
                     ok = False; extra.append("other path")
             except abi.MidasSnpsError:
                 pass                                   # (the direct path declines unsorted input; there is none here)
+            # the long path (pileup_long.hip): a third implementation of the same rules (small cases: it is built for exactness)
+            if info.path != abi.PATH_LONG and reads.n_reads <= 400000:
+                b.select_path(abi.PATH_LONG)
+                b.run(thr)
+                c4, a4, s4 = b.fetch()
+                if not (np.array_equal(c4, oc) and np.array_equal(a4, oa) and np.array_equal(s4, os_)):
+                    ok = False; extra.append("long path")
+                b.select_path(abi.PATH_AUTO)
             # rows: device coder vs host formatter, as text
             if contigs.n_sites <= 3000000 and rng.random() < 0.5:
                 with tempfile.TemporaryDirectory() as td:
