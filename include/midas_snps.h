@@ -203,18 +203,21 @@ int32_t midas_snps_pileup(midas_snps_ctx* ctx, const midas_snps_thresholds* thr,
 
 /* ---- resident batches: upload once, run many ------------------------------
  * A batch is the device-resident form of (contig table, reads): the caller's BAM-native arrays
- * are uploaded as they are and packed ON THE DEVICE (midas_snps_batch_pack below) into read
- * records + payload in tile order, next to the reference letters and the tile table.
+ * are uploaded as they are, every read is validated on the device, and the DIRECT layout is built from
+ * them once -- one 16-byte record per read (pos, l_seq, n_cigar, NM, mapq, payload offset) and the read's
+ * CIGAR / SEQ / QUAL bytes as one run of a payload in BAM's own order: columns re-encoded and bytes
+ * gathered, nothing decided -- next to the reference letters and the tile table.  (The PACKED layout,
+ * tile-ordered records + one byte per base, is built on first use: unsorted input, coverage hot spots.)
  * Creating it replaces what `pysam.AlignmentFile(bampath)` + htslib's record decode do per worker
  * (midas/run/snps.py:186); running it replaces index_bam (:130-137, the device
  * builds its own per-tile read index each run) and the calls named above.      */
 int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
                                 const midas_snps_reads* reads, midas_snps_batch** out_batch);
 void midas_snps_batch_destroy(midas_snps_batch* batch);
-/* The two device paths of a batch.  DIRECT: the pileup kernel reads the batch's BAM-native arrays where they are -- 4-bit
- * SEQ, QUAL, CIGAR and the per-read columns -- and visits every read once: a pass over the positions alone (4 bytes per
+/* The device paths of a batch.  DIRECT: the pileup kernel reads a read's 16-byte record and its BAM-order payload -- 4-bit
+ * SEQ, QUAL, CIGAR as the BAM holds them -- and visits every read once: a pass over the positions alone (4 bytes per
  * read) finds, per 2048-site tile, the run of reads that can touch it; the kernel decides in registers what a read's CIGAR
- * is and tallies it; nothing is sorted, copied or described beforehand.  It wants position-sorted reads (what samtools sort
+ * is and tallies it; nothing is sorted or decided beforehand.  It wants position-sorted reads (what samtools sort
  * writes; any order is CORRECT, only slower).  PACKED: the reads are first laid out in tile order as records + one byte per
  * base (midas_snps_batch_pack), which handles any order and cuts coverage hot spots into parts.  batch_create picks DIRECT
  * unless the reads are badly ordered, one read spans many tiles or a tile holds a hot spot; AUTO restores that choice.

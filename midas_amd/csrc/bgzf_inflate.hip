@@ -516,8 +516,8 @@ hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {
   if (p.n_blocks <= 0) return hipSuccess;
   if (phases & 1) {
-    // the block inflater keeps 64 lanes' tables and input rings in LDS: most of gfx950's 160 KiB. A device with less
-    // cannot run it; say so instead of leaving it to the launch (the callers fall back to the host's inflater).
+    // the block inflater keeps its streams' tables and input rings in LDS (2.5 KiB a stream). A device that cannot give a
+    // workgroup that much cannot run it; say so instead of leaving it to the launch (the callers fall back to the host's inflater).
     static const bool fits = [] {
       hipFuncAttributes fa{};
       int dev = 0, lds = 0;
