@@ -336,9 +336,10 @@ def native_rccl(ctx, rank, world, n_species=100, timeout_s=90.0):
 
     def work():
         try:
-            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            torch.cuda.set_device(ctx.device)        # (the current device is per thread)
+            ident = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % ctx.device)
             if rank == 0:
-                ident.copy_(torch.tensor(list(abi.Comm.unique_id()), dtype=torch.uint8))
+                ident.copy_(torch.tensor(list(abi.Comm.unique_id()), dtype=torch.uint8).to(ident.device))
             if world > 1:
                 dist.broadcast(ident, 0)
             t0 = time.perf_counter()

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   constexpr int NWAVES = kDirectBlock / 64;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
   constexpr int OV = kDirectOverhang;       // sites behind the tile's last that the tallies also hold (see "chunks" below)
-  static_assert(OV <= kDirectBlock, "the overhang is moved by the write-out's first round");
+  static_assert(OV <= TILE, "the overhang is moved by the write-out's first rounds");
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * (TILE + OV)];
   __shared__ __attribute__((aligned(16))) uint32_t s_khi[33 * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's four SEQ words
   __shared__ __attribute__((aligned(16))) uint32_t s_klo[33 * 4];   // [l][w]: 0xF in the nibbles of the bases j >= l
@@ -401,7 +401,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     const bool more = in_chunk || i_next < w_end;
     const int wn = in_chunk ? t + 1 : (more ? item_first(i_next) : t);
     const bool cout = in_chunk && (int32_t)c_tiles[8 * (size_t)wn] == tile.contig;      // its first OV sites are tallied here
-    const int ext_len = tile_len + (cout ? OV : 0);
+    // (the contig's last tile may be shorter than the overhang: nothing is tallied behind the contig's end)
+    const int next_len = (int32_t)c_tiles[8 * (size_t)wn + 2];
+    const int ext_len = tile_len + (cout ? (next_len < OV ? next_len : OV) : 0);
     const int it_hi = st.total;
     uint32_t w_aligned = 0, w_mapped = 0;
     constexpr int REF_IT = (TILE + 4 * kDirectBlock - 1) / (4 * kDirectBlock);
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         const int i = tid + it * kDirectBlock;
         if (i < lim) {
           const uint4 v = lds4[i];
-          if (it == 0 && cout && i < OV) {      // what this tile's reads added behind it opens the next tile
+          if (cout && i < OV) {                 // what this tile's reads added behind it opens the next tile
             lds4[i] = lds4[TILE + i];
             lds4[TILE + i] = make_uint4(0u, 0u, 0u, 0u);
           } else {

@@ -1,0 +1,104 @@
+"""The direct kernel's chunks (pileup_direct.hip "Work items"): a workgroup takes four consecutive tiles and carries what a
+tile's reads add behind its last site (at most 160 sites) over to the next tile, so that a read is visited once.  The cases
+here keep every read's reference span within the overhang -- the condition under which the host asks for chunks -- and put the
+reads where the hand-over can go wrong: on and around every tile border, at contig ends, in contigs whose lengths are exact
+multiples of the tile and of the chunk, in many short contigs (chunks that span contigs), with deletions that stretch a read to
+exactly the overhang, with soft clips and insertions, and as pieces with halo reads.  Held to the C oracle, bit for bit."""
+import random
+
+import numpy as np
+import pytest
+
+from midas_amd import abi, pieces
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TILE = 2048
+
+
+def _reads_for(rng, length, n, dense_borders=True):
+    out = []
+    borders = [b for b in range(TILE, length, TILE)]
+    for _ in range(n):
+        l = rng.choice([150, 150, 100, 36, 151])
+        kind = rng.random()
+        if kind < 0.55:
+            cigar, span = [(0, l)], l
+        elif kind < 0.70:
+            a = rng.randint(1, l - 2)
+            d = rng.randint(1, 160 - l) if l < 159 else 1
+            cigar, span = [(0, a), (2, d), (0, l - a)], l + d            # a deletion: up to exactly 160 sites of span
+        elif kind < 0.80:
+            a, i = rng.randint(1, l - 10), rng.randint(1, 5)
+            cigar, span = [(0, a), (1, i), (0, l - a - i)], l - i
+        elif kind < 0.92:
+            s, t = rng.randint(0, min(20, (l - 6) // 2)), rng.randint(0, min(20, (l - 6) // 2))
+            m = l - s - t
+            cigar = ([(4, s)] if s else []) + [(0, m)] + ([(4, t)] if t else [])
+            span = m
+        else:
+            a = rng.randint(5, l - 30)
+            cigar, span = [(0, a), (3, 7), (7, 10), (8, 2), (0, l - a - 12)], l + 7      # five ops: walked op by op
+        if dense_borders and borders and rng.random() < 0.5:
+            b = rng.choice(borders)
+            pos = b - rng.randint(0, span + 3) + rng.choice([0, 0, 1, -1, 2])
+        else:
+            pos = rng.randint(-3, length - 1)
+        pos = max(-2, min(length - 1, pos))
+        out.append(dict(pos=pos, cigar=cigar, seq="".join(rng.choice("ACGTACGTACGTN") for _ in range(l)),
+                        qual=[rng.choice([40, 38, 31, 30, 29, 12]) for _ in range(l)], nm=rng.choice([0, 1, 2, 3]),
+                        mapq=rng.choice([42, 42, 30, 19])))
+    out.sort(key=lambda r: r["pos"])
+    return out
+
+
+def _table(rng, lengths):
+    reads, begin, ref = [], [0], []
+    for n in lengths:
+        rs = _reads_for(rng, n, max(40, n // 12))
+        reads += rs
+        begin.append(len(reads))
+        ref.append("".join(rng.choice("ACGTacgtN") for _ in range(n)))
+    soa = H.reads_from_dicts(reads)
+    table = abi.ContigTable(length=lengths, species=[k % 3 for k in range(len(lengths))], read_begin=begin,
+                            ref=np.frombuffer("".join(ref).encode(), np.uint8), n_species=3,
+                            ids=["c%d" % k for k in range(len(lengths))], species_ids=["s0", "s1", "s2"])
+    return table, soa
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_chunked_tiles_hand_their_overhang_over_exactly(hip_ctx, seed):
+    rng = random.Random(seed)
+    lengths = [TILE * 4, TILE * 8 + 1, TILE * 3 - 1, TILE, 5, TILE + 160, TILE * 2, 700, TILE * 12, TILE * 5 + 161, 1, TILE * 4 + 2047]
+    rng.shuffle(lengths)
+    table, soa = _table(rng, lengths + [TILE * 40])
+    for args in (dict(abi.DEFAULT_ARGS), dict(abi.DEFAULT_ARGS, baseq=0, mapid=50.0, aln_cov=0.2, readq=0, mapq=0)):
+        thr = abi.Thresholds.from_args(args)
+        st, er, oc, oa, os_ = c_oracle.pileup(thr, table, soa)
+        assert st == 0, (st, er)
+        b = hip_ctx.batch(table, soa)
+        info = b.info()
+        assert info.path == abi.PATH_DIRECT and info.direct_reach <= 160 and info.n_tiles >= 80      # (the chunks are on)
+        for _ in range(2):
+            b.run(thr)
+            counts, allele, stats = b.fetch()
+            bad = np.nonzero((counts != oc).any(axis=1))[0]
+            assert bad.size == 0, "counts differ at %d sites, first %s" % (bad.size, bad[:8])
+            assert np.array_equal(allele, oa) and np.array_equal(stats, os_)
+        b.select_path(abi.PATH_PACKED)
+        b.run(thr)
+        c2, _, s2 = b.fetch()
+        assert np.array_equal(c2, oc) and np.array_equal(s2, os_)
+        b.close()
+
+
+def test_chunks_and_pieces_with_halo_reads(hip_ctx, thr_default):
+    rng = random.Random(9)
+    table, soa = _table(rng, [TILE * 70, TILE * 9 + 5])
+    st, _, oc, oa, os_ = c_oracle.pileup(thr_default, table, soa)
+    assert st == 0
+    pt, pr, _ = pieces.split_table(table, soa, 65536)
+    assert pt.n_contigs > table.n_contigs
+    counts, allele, stats = hip_ctx.pileup(thr_default, pt, pr)
+    assert np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)

@@ -134,7 +134,17 @@ def test_malformed_reads_are_statuses_from_the_device(hip_ctx, thr_default):
     with pytest.raises(abi.MidasSnpsError) as ei:
         hip_ctx.pileup(thr_default, contig, bad)
     assert ei.value.status == abi.ERR_BAD_LAYOUT
+    # a read beyond the packed layout's limits is not malformed: the batch runs (on the long path, round 5) and only the packed
+    # and the direct path decline it
     long_read = H.reads_from_dicts([dict(pos=0, cigar="4M", seq="ACGT"), dict(pos=0, cigar="1025M", seq="A" * 1025)])
+    table = H.single_contig(5000, 2)
+    from oracle import c_oracle
+    st, _, oc, oa, os_ = c_oracle.pileup(thr_default, table, long_read)
+    counts, allele, stats = hip_ctx.pileup(thr_default, table, long_read)
+    assert st == 0 and np.array_equal(counts, oc) and np.array_equal(stats, os_)
+    b = hip_ctx.batch(table, long_read)
+    assert b.info().path == abi.PATH_LONG
     with pytest.raises(abi.MidasSnpsError) as ei:
-        hip_ctx.pileup(thr_default, H.single_contig(5000, 2), long_read)
-    assert ei.value.status == abi.ERR_UNSUPPORTED and ei.value.read_index == 1
+        b.select_path(abi.PATH_PACKED)
+    assert ei.value.status == abi.ERR_UNSUPPORTED
+    b.close()

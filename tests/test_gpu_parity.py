@@ -264,17 +264,16 @@ def test_unsupported_and_malformed_inputs_are_statuses_not_crashes(hip_ctx, thr_
     with pytest.raises(abi.MidasSnpsError) as ei:
         hip_ctx.pileup(thr_default, zero, abi.ReadsSoA.empty())
     assert ei.value.status == abi.ERR_UNSUPPORTED
+    # (a 2 000-base read is beyond the fast paths, not beyond the library: the batch runs on the long path, tests/test_gpu_long.py)
     long_read = H.reads_from_dicts([dict(pos=0, cigar="2000M", seq="A" * 2000)])
-    with pytest.raises(abi.MidasSnpsError) as ei:
-        hip_ctx.pileup(thr_default, H.single_contig(5000, 1), long_read)
-    assert ei.value.status == abi.ERR_UNSUPPORTED
+    _assert_same(hip_ctx, thr_default, H.single_contig(5000, 1), long_read)
 
 
-def test_qualities_above_62_are_exact_up_to_baseq_62_and_refused_beyond(hip_ctx):
+def test_qualities_above_62_are_exact_at_every_baseq_on_the_packed_path_too(hip_ctx):
     """The PACKED path keeps a base's quality in six bits (layout.h): Phred 63..93 are stored as 62, which changes no comparison
-    with a baseq <= 62; a baseq above 62 on such a batch is a status, not a wrong table.  Batches without such qualities take
-    any baseq (nothing passes above their maximum, as in the reference).  The DIRECT path compares the quality bytes
-    themselves and takes every baseq (tests/test_gpu_direct.py)."""
+    with a baseq <= 62; a baseq above 62 on a batch that holds such qualities is run by the direct kernel, which compares the
+    quality bytes themselves (round 5; until then it was a status).  Batches without such qualities take any baseq on the
+    packed kernel (nothing passes above their maximum, as in the reference)."""
     hip_ctx.set_default_path(abi.PATH_PACKED)
     try:
         _packed_quality_limits(hip_ctx)
@@ -295,10 +294,8 @@ def _packed_quality_limits(hip_ctx):
     contig = H.single_contig(L, len(reads), "".join("ACGT"[i] for i in rng.integers(0, 4, L)))
     for bq in (0, 1, 41, 61, 62):
         _assert_same(hip_ctx, abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, soa)
-    for bq in (63, 64, 94):
-        with pytest.raises(abi.MidasSnpsError) as ei:
-            hip_ctx.pileup(abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, soa)
-        assert ei.value.status == abi.ERR_UNSUPPORTED
+    for bq in (63, 64, 70, 93, 94):
+        _assert_same(hip_ctx, abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, soa)
     low = H.reads_from_dicts([dict(r, qual=[min(q, 62) for q in r['qual']]) for r in reads])
     for bq in (62, 63, 200):
         counts, _ = _assert_same(hip_ctx, abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, baseq=bq, readq=0)), contig, low)
