@@ -367,7 +367,7 @@ def native_rccl(ctx, rank, world, n_species=100, timeout_s=90.0):
     return res
 
 
-def merge50(ctx, n_sites=2_000_000, n_samples=50, reps=3, cpu_sites=3000):
+def merge50(ctx, n_sites=2_000_000, n_samples=50, reps=3, cpu_sites=150_000):
     """BASELINE configs[4]: `merge_midas.py snps` across 50 samples -- the per-site cross-sample arithmetic of
     midas/merge/snps.py:13-114, 324-364 (pooled counts, major / minor allele, per-sample depth and minor-allele count, prevalence,
     the site filter) for one species' sites through midas_merge_sites (merge_sites.hip).  Not the graded metric: a block of its
