@@ -360,6 +360,13 @@ def _whole(order, contigs):
     return items, {(cid, 0): (0, contigs[cid].length, True) for cids in order.values() for cid in cids}
 
 
+def _lap(name, t0):
+    """(MIDAS_SNPS_TRACE=1: the stage's phases on stderr, beside the library's own laps)"""
+    if os.environ.get("MIDAS_SNPS_TRACE"):
+        sys.stderr.write("[stage] %-44s %9.3f ms\n" % (name, (time() - t0) * 1e3))
+    return time()
+
+
 def _batch_groups(args, mine, order, ref_names, refid, reads, ctx):
     """The rank's work items as the batches the device takes one after the other: consecutive items of the emit order (species
     by species, a species' contigs sorted) until a batch would hold more reads or payload than a batch can (the library's
@@ -375,6 +382,9 @@ def _batch_groups(args, mine, order, ref_names, refid, reads, ctx):
         max_payload = min(max_payload, int(ctx.device_info()['hbm_bytes']) // 8)
     except Exception:
         pass
+    # (nearly every job: everything fits one batch -- two sums, no per-contig tables)
+    if int(refid.size) <= max_reads and 1.6 * float(reads.l_seq.sum(dtype=np.int64)) + 8.0 * float(refid.size) <= max_payload:
+        return [emit]
     index_of = {n: i for i, n in enumerate(ref_names)}
     n_ref = len(ref_names)
     per_reads = np.bincount(refid, minlength=n_ref) if refid.size else np.zeros(n_ref, np.int64)
@@ -427,20 +437,24 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, c
 def _pileup_batch(args, species_ids, mine, order, owned, decoded, ctx, span, contigs, halo, first):
     """One batch of _pileup_contigs: the work items `mine`, of which owned(item) says "in this batch"."""
     ref_names, ref_lens, refid, reads = decoded
+    t_lap = time()
     table, sub, keys = _contig_table(species_ids, mine, span, contigs, ref_names, ref_lens, refid, reads, halo,
                                      fetch=getattr(ctx, 'fetch_payload', None))
+    t_lap = _lap("  contig table + regroup", t_lap)
     thr = abi.Thresholds.from_args(args)
     batch = None
     if mine and hasattr(ctx, 'batch'):
         # the results stay on the device: the row writer takes them slab by slab through the context's page-locked ring
         # (midas_snps_batch_write_part), formatting one slab while the next crosses the link
         batch = ctx.batch(table, sub)
+        t_lap = _lap("  batch_create", t_lap)
         try:
             batch.run(thr)
             _, _, stats = batch.fetch(counts=False, allele=False)
         except BaseException:
             batch.close()
             raise
+        t_lap = _lap("  device pass + counters down", t_lap)
         counts = allele = None
     elif mine:      # (a test double of the device: one-shot call, host arrays)
         counts, allele, stats = ctx.pileup(thr, table, sub)
@@ -448,10 +462,13 @@ def _pileup_batch(args, species_ids, mine, order, owned, decoded, ctx, span, con
         counts, allele = np.zeros((0, 4), np.uint32), np.zeros(0, np.uint8)
         stats = np.zeros((len(species_ids), abi.NUM_STATS), np.int64)
     try:
-        return _emit_contigs(args, species_ids, table, keys, order, owned, counts, allele, stats, batch, first)
+        out = _emit_contigs(args, species_ids, table, keys, order, owned, counts, allele, stats, batch, first)
+        t_lap = _lap("  rows", t_lap)
+        return out
     finally:
         if batch is not None:
             batch.close()
+            _lap("  batch closed", t_lap)
 
 
 def _emit_contigs(args, species_ids, table, keys, order, owned_item, counts, allele, stats, batch, first=True):
@@ -893,9 +910,11 @@ def _count_alleles(args, species, contigs, ctx):
                 args['log'].write("long contigs: %d cut into pieces of %d positions; records decoded per rank: %s of %d\n"
                                   % (n_cut, piece_len, ' '.join(str(int(x)) for x in per_rank), int(plan['ref_reads'].sum())))
 
+    t_lap = _lap("decode, plan, genomes, work items", start)
     local = {}
     try:
         local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx, span, contigs, halo)
+        t_lap = _lap("pileup of the rank's contigs (all batches)", t_lap)
     except abi.MidasSnpsError as e:
         error = _error_text(e)
     except SystemExit as e:

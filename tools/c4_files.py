@@ -59,7 +59,7 @@ def main():
         print("run_midas.py snps --pileup --device_inflate %-4s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
             how, dt, contigs.n_sites / dt, len(os.listdir(os.path.join(out, 'snps/output'))), sz / 1e9), flush=True)
         for line in r.stderr.splitlines():
-            if line.startswith('[device decode]'):
+            if line.startswith(('[device decode]', '[batch_create]', '[stage]')):
                 print("    " + line)
         runs.append(dt)
         if how == 'auto':
