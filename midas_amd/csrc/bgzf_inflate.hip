@@ -1,4 +1,5 @@
-// BGZF blocks inflated on the device: one THREAD per block decodes, one WAVEFRONT per block copies the matches.
+// BGZF blocks inflated on the device: one THREAD per block decodes its Huffman codes into a token stream, one WAVEFRONT per
+// block then lays the block's bytes out from the tokens.
 //
 // A BAM is a chain of independent <= 64 KiB DEFLATE streams (BGZF, SAM spec 4.1); htslib inflates them one after the other,
 // this library's host decoder on all cores -- and with the pileup at a millisecond and the rows coded on the device, that
@@ -7,12 +8,24 @@
 // (RFC 1951: stored, fixed and dynamic blocks).  What makes that workable on a GPU is where the tables live: every lane's
 // 9-bit literal/length and 7-bit distance look-up tables sit in LDS, interleaved [entry][lane], so the one dependent memory
 // access per symbol is an LDS read, not a trip to HBM.  Codes longer than the look-up width (rare symbols) fall back to the
-// canonical bit-by-bit walk over the per-length counts (the classic `puff` decoder), also from LDS.
-// Two kernels.  The decoder writes the literals where they belong and only NOTES the matches (position, length, distance):
-// Huffman decoding never looks at the output, and a lane that stopped to copy a match -- a round trip to memory for bytes it
-// wrote a moment ago -- would hold up the other 63 lanes of its wavefront on almost every symbol (measured: 2.3 us per symbol
-// that way).  The resolver then takes one wavefront per block through the block's matches in order, 64 bytes of a match per
-// step, with a fence only in front of a match whose source was written since the last one.
+// canonical walk over the per-length counts (the classic `puff` decoder), also from LDS.
+//
+// Two kernels, and what passes between them (round 5; a block of a BAM is ~13 000 literals and ~8 000 matches of 6.5 bytes):
+//   decode   Huffman decoding never looks at the output, so the decoder writes NO output byte.  A lane turns its stream into
+//            (a) TOKENS, one dword per match: literals in front of it (9 bits) | length - 3 (8) | distance - 1 (15) -- a run of
+//            511 literals or more, and the literals behind the last match, as an escape token that only carries a count --
+//            and (b) the stream's LITERALS, back to back.  Both are gathered in small per-lane rings in LDS and leave for HBM
+//            in 16-byte stores at the one point of the symbol loop that all lanes of a wavefront pass together every eighth
+//            step, where the input ring is topped up as well: no memory instruction sits in a divergent branch of the loop.
+//            (Round 4's decoder stored every literal where it belongs -- with a match every 2.6 symbols that is a byte store
+//            per literal in a branch, and every top-up of the input ring waited for all of them: 2 700 cycles per symbol.)
+//            The tokens grow from the front of the block's room in `matches`, the literals (bytes in reverse order) from its
+//            end: one room, no second buffer.
+//   place    one wavefront per block, 64 tokens at a time: two prefix sums give every token its place in the output and in
+//            the literal stream; the literals of the NEXT 64 tokens are copied while this window's matches are resolved --
+//            a match only reads what lies in front of it, so every unfinished match whose source ends in front of the first
+//            unfinished token's bytes is copied at the same moment, one lane per match, 8 bytes per load (most matches of a
+//            BAM are a few bytes long); one workgroup-scope fence per such step.  Tokens are fetched a window ahead.
 // Replaces the inflate inside `pysam.AlignmentFile(...)` of midas/run/snps.py:186 (htslib's bgzf.c); bounds-checked against
 // both buffers at every step: corrupt input yields a status, never a fault.
 #include <hip/hip_runtime.h>
@@ -24,12 +37,10 @@ namespace midas {
 namespace {
 
 constexpr int kLanes = 64;
-// Streams per workgroup of the decoder.  A stream's tables take 2.5 KiB of LDS, so a CU holds 64 streams whatever the shape;
-// what the shape decides is how many WAVEFRONTS those 64 streams are.  The decoder is a chain of dependent LDS reads (table
-// look-up, input ring) and the lanes of a wavefront diverge at every step (literal / match / long code / refill: a step costs
-// the sum of the paths any lane takes).  Measured on the 46 500 blocks of configs[2]'s BAM (profiles/r05_inflate_shapes.txt):
-// 64 streams per wavefront 78.7 ms, 16: 76.3, 8: 68.3, 4: 83.4 (the CU no longer holds 64 streams), 2: 122.  With the literal
-// stores compiled out: 73 of 76 ms -- the stores are not what it waits for.
+// Streams per workgroup of the decoder.  A stream's tables and rings take 2.3 KiB of LDS, so a CU holds 64 streams whatever
+// the shape; what the shape decides is how many WAVEFRONTS those 64 streams are.  The lanes of a wavefront diverge at every
+// step (literal / match / long code: a step costs the sum of the paths any lane takes), and a wavefront instruction costs the
+// SIMD four cycles however few lanes are in it.
 #ifndef MIDAS_INFLATE_LANES
 #define MIDAS_INFLATE_LANES 8
 #endif
@@ -43,18 +54,27 @@ constexpr int kSymLl = kLutD + (1 << kDBits);   // 288: symbols sorted by (lengt
 constexpr int kSymD = kSymLl + 288;             // 32
 constexpr int kCntLl = kSymD + 32;              // 16: codes per length
 constexpr int kCntD = kCntLl + 16;              // 16
-// per length, while a table is built: where the next symbol of that length goes in the sorted list, and the next code of that
-// length; afterwards, therefore: the END of the length's symbols and the END of its codes -- what the long-code path needs
+// per length: the END of the length's symbols in the sorted list and the END of its codes -- what the long-code path needs
 constexpr int kOffsLl = kCntD + 16;             // 16
 constexpr int kNextLl = kOffsLl + 16;           // 16
 constexpr int kOffsD = kNextLl + 16;            // 16
 constexpr int kNextD = kOffsD + 16;             // 16
 constexpr int kU16 = kNextD + 16;               // 1056
-constexpr int kRing = 16;                       // u32, per lane: the next 64 bytes of the lane's stream
-constexpr int kLens = 320;                      // u8: code lengths while a table is built
+// u32 arrays, per lane, interleaved
+constexpr int kRing = 16;                       // the next 64 bytes of the lane's stream
+constexpr int kLitRing = 8;                     // gathered literals (four to a dword) on their way out
+constexpr int kTokRing = 32;                    // tokens on their way out
+constexpr int kU32 = kRing + kLitRing + kTokRing;
+// While a table header is read the code lengths (u8, up to 320 of them) lie where the literal/length look-up table is built
+// afterwards: a table is built in two steps -- counts and the sorted symbols from the lengths, then the look-up table from
+// the sorted symbols -- and the second step no longer reads a length.  The distance alphabet's lengths wait in the distance
+// look-up table's place meanwhile.
+constexpr int kLensAtD = 2 * kLutD;             // byte index of the distance lengths' parking place (the u16 array kLutD)
 
 enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadSymbol = 4, kBadDistance = 5,
                   kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8, kMatchRoom = kInflateMatchRoom };
+
+constexpr uint32_t kEscape = 0xFF800000u;       // token: 511 in the literal field, the low 23 bits a count of literals, no match
 
 // (pointers that SAY they point into LDS: through a generic pointer every table look-up would be a FLAT access, which waits
 // for the thread's outstanding global stores -- one store acknowledgement per symbol)
@@ -62,16 +82,26 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct Lds {
+  static constexpr uint32_t kLitW = kLitRing, kTokW = kTokRing;
   lds_u16* s16;
-  lds_u8* s8;
+  lds_u8* s8;          // the same memory as s16, as bytes (the code lengths' place)
   lds_u32* s32;
   int lane;
   __device__ __forceinline__ lds_u32& r(uint32_t i) const { return s32[(i & (kRing - 1)) * kDecLanes + lane]; }
+  __device__ __forceinline__ lds_u32& lit(uint32_t i) const { return s32[(kRing + (i & (kLitRing - 1))) * kDecLanes + lane]; }
+  __device__ __forceinline__ lds_u32& tok(uint32_t i) const { return s32[(kRing + kLitRing + (i & (kTokRing - 1))) * kDecLanes + lane]; }
   __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kDecLanes + lane]; }
-  __device__ __forceinline__ lds_u8& b(int i) const { return s8[i * kDecLanes + lane]; }
+  // byte i of the lane's own u16 slots (slot i / 2): a lane's bytes never touch another lane's entries -- the lanes of a wavefront
+  // read their table headers at different times
+  __device__ __forceinline__ lds_u8& b(int i) const { return s8[(((i >> 1) * kDecLanes + lane) << 1) + (i & 1)]; }
 };
 
-// The compressed stream, least significant bit first (RFC 1951 3.1.1).  Between memory and the bit buffer sits a ring of 32
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+typedef uint16_t u16_a1 __attribute__((aligned(1)));
+typedef unsigned long long u64_a1 __attribute__((aligned(1)));
+
+// The compressed stream, least significant bit first (RFC 1951 3.1.1).  Between memory and the bit buffer sits a ring of 16
 // words per lane in LDS, topped up 32 bytes at a time by loads that are issued EIGHT steps of the symbol loop before their
 // words are needed.  (A lane that loaded its next word only when it ran dry would not stall just itself: a wavefront waits
 // for its outstanding loads as one, some lane of 64 runs dry on nearly every step, and every step would cost a trip to
@@ -134,14 +164,15 @@ struct BitIn {
   __device__ __forceinline__ bool overrun() const { return budget + n < 0; }
 };
 
-// Canonical Huffman tables of one alphabet from the code lengths in L.b(0..n): counts per length, symbols sorted by
-// (length, symbol), and the look-up table over the first `bits` bits.  False: over-subscribed or incomplete (an incomplete
-// code is allowed only as the single-code case, as zlib allows it).
-__device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lut_at, int bits, int kOffs, int kNext) {
+// Canonical Huffman tables of one alphabet, step one: from the code lengths in L.b(at .. at + n) the counts per length and
+// the symbols sorted by (length, symbol); afterwards offs[l] / next[l] are the END of length l's symbols in the sorted list
+// and the END of its codes.  False: over-subscribed or incomplete (an incomplete code is allowed only as the single-code
+// case, as zlib allows it).  `*none`: the alphabet has no code at all (legal for the distances of a literal-only block).
+__device__ bool sort_symbols(const Lds& L, int at, int n, int cnt_at, int sym_at, int kOffs, int kNext, bool* none) {
   for (int l = 0; l < 16; ++l) { L.h(cnt_at + l) = 0; L.h(kOffs + l) = 0; L.h(kNext + l) = 0; }
-  for (int s = 0; s < n; ++s) L.h(cnt_at + L.b(s)) += 1;
-  for (int i = 0; i < (1 << bits); ++i) L.h(lut_at + i) = 0;
-  if (L.h(cnt_at) == n) return true;              // no codes at all: legal for the distance alphabet of a literal-only block
+  for (int s = 0; s < n; ++s) L.h(cnt_at + L.b(at + s)) += 1;
+  *none = L.h(cnt_at) == n;
+  if (*none) return true;
   int left = 1;
   for (int l = 1; l < 16; ++l) {
     left <<= 1;
@@ -149,38 +180,50 @@ __device__ bool build_tables(const Lds& L, int n, int cnt_at, int sym_at, int lu
     if (left < 0) return false;                   // over-subscribed
   }
   if (left > 0 && !(n - (int)L.h(cnt_at) == 1 && L.h(cnt_at + 1) == 1)) return false;     // incomplete
-  // per length: where its next symbol goes in the sorted list, and its next code (RFC 1951 3.2.2) -- in LDS, indexed by the
+  // per length: where its next symbol goes in the sorted list, and its first code (RFC 1951 3.2.2) -- in LDS, indexed by the
   // symbol's length (a lane's own index: registers cannot be indexed per lane)
   {
     uint32_t off = 0, code = 0;
-    L.h(kOffs) = 0; L.h(kNext) = 0;
     for (int l = 1; l < 16; ++l) {
       const uint32_t c = L.h(cnt_at + l);
       code = (code + (l > 1 ? (uint32_t)L.h(cnt_at + l - 1) : 0u)) << 1;
       L.h(kOffs + l) = (uint16_t)off;
-      L.h(kNext + l) = (uint16_t)code;
+      L.h(kNext + l) = (uint16_t)(code + c);      // the END of the length's codes
       off += c;
     }
   }
   for (int s = 0; s < n; ++s) {
-    const int l = L.b(s);
+    const int l = L.b(at + s);
     if (!l) continue;
-    const uint32_t o = L.h(kOffs + l), c = L.h(kNext + l);
+    const uint32_t o = L.h(kOffs + l);
     L.h(kOffs + l) = (uint16_t)(o + 1u);
-    L.h(kNext + l) = (uint16_t)(c + 1u);
     L.h(sym_at + (int)o) = (uint16_t)s;
-    if (l <= bits) {
-      const uint32_t r = __brev(c) >> (32 - l);
-      for (uint32_t k = r; k < (1u << bits); k += 1u << l) L.h(lut_at + (int)k) = (uint16_t)((s << 4) | l);
-    }
   }
   return true;
 }
+// ... step two: the look-up table over the first `bits` bits, from the sorted symbols and the counts alone
+__device__ void fill_lut(const Lds& L, int cnt_at, int sym_at, int lut_at, int bits, bool none) {
+  for (int i = 0; i < (1 << bits); ++i) L.h(lut_at + i) = 0;
+  if (none) return;
+  uint32_t code = 0;
+  int idx = 0;
+  for (int l = 1; l <= bits; ++l) {
+    const int c = (int)L.h(cnt_at + l);
+    for (int k = 0; k < c; ++k) {
+      const uint32_t s = L.h(sym_at + idx);
+      ++idx;
+      const uint32_t r = __brev(code) >> (32 - l);
+      for (uint32_t j = r; j < (1u << bits); j += 1u << l) L.h(lut_at + (int)j) = (uint16_t)((s << 4) | (uint32_t)l);
+      ++code;
+    }
+    code <<= 1;
+  }
+}
 
-// One symbol: the look-up table; a code longer than the table's width (a rare symbol -- but with 64 streams in a wavefront
-// some lane meets one on most steps, so this path has to be short too) is found by its length: canonical codes of length l
-// are the numbers below end[l] that no shorter code is a prefix of, and their symbols end at sorted position offs_end[l].
-// Returns -1 on a code no symbol has.
+// One symbol: the look-up table; a code longer than the table's width (a rare symbol -- but with several streams in a
+// wavefront some lane meets one on many steps, so this path has to be short too) is found by its length: canonical codes of
+// length l are the numbers below end[l] that no shorter code is a prefix of, and their symbols end at sorted position
+// offs_end[l].  Returns -1 on a code no symbol has.
 __device__ __forceinline__ int decode(const Lds& L, BitIn& in, int cnt_at, int sym_at, int lut_at, int bits, int offs_at, int next_at) {
   const uint32_t e = L.h(lut_at + (int)in.peek(bits));
   if (e) { in.skip((int)(e & 15u)); return (int)(e >> 4); }
@@ -199,18 +242,18 @@ __device__ __forceinline__ int decode(const Lds& L, BitIn& in, int cnt_at, int s
 }
 
 // RFC 1951 3.2.5 in closed form (a table in constant memory would be a trip to memory, waited for, on every match -- and
-// with 64 streams in a wavefront some lane has a match on almost every step):
+// with several streams in a wavefront some lane has a match on almost every step):
 //   length code 257 + s -> (first length, extra bits);  distance code d -> (first distance, extra bits)
 __device__ __forceinline__ void length_of(int s, uint32_t* base, int* extra) {
-  if (s < 8) { *base = 3u + (uint32_t)s; *extra = 0; return; }
-  if (s == 28) { *base = 258u; *extra = 0; return; }
-  *extra = (s >> 2) - 1;
-  *base = 3u + ((4u + (uint32_t)(s & 3)) << *extra);
+  const int e = s < 8 ? 0 : (s >> 2) - 1;
+  uint32_t b = s < 8 ? 3u + (uint32_t)s : 3u + ((4u + (uint32_t)(s & 3)) << e);
+  *extra = s == 28 ? 0 : e;
+  *base = s == 28 ? 258u : b;
 }
 __device__ __forceinline__ void distance_of(int d, uint32_t* base, int* extra) {
-  if (d < 4) { *base = 1u + (uint32_t)d; *extra = 0; return; }
-  *extra = (d >> 1) - 1;
-  *base = 1u + ((2u + (uint32_t)(d & 1)) << *extra);
+  const int e = d < 4 ? 0 : (d >> 1) - 1;
+  *extra = e;
+  *base = d < 4 ? 1u + (uint32_t)d : 1u + ((2u + (uint32_t)(d & 1)) << e);
 }
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -225,8 +268,10 @@ __device__ uint32_t read_dynamic_header(const Lds& L, BitIn& in) {
     L.b(c_cl_order[i]) = (uint8_t)in.take(3);
   }
   // the code-length code borrows the distance alphabet's arrays (they are built last)
-  if (!build_tables(L, 19, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD)) return kBadCodeLengths;
-  // (the lengths are decoded into the top of the byte array first: the code-length code's own lengths sit at 0..18 until here)
+  bool none;
+  if (!sort_symbols(L, 0, 19, kCntD, kSymD, kOffsD, kNextD, &none)) return kBadCodeLengths;
+  fill_lut(L, kCntD, kSymD, kLutD, kDBits, none);
+  // (the code-length code's own lengths at 0..18 are dead from here: decode() reads counts and symbols, not lengths)
   int i = 0, prev = 0;
   const int total = hlit + hdist;
   while (i < total) {
@@ -238,28 +283,28 @@ __device__ uint32_t read_dynamic_header(const Lds& L, BitIn& in) {
     else if (s == 17) { val = 0; rep = 3 + (int)in.take(3); }
     else if (s == 18) { val = 0; rep = 11 + (int)in.take(7); }
     if (i + rep > total) return kBadCodeLengths;
-    // both alphabets' lengths land in one run; they are moved apart below.  The array is read by build_tables from index 0,
-    // and the code-length code's own lengths (0..18) are dead by now -- decode() reads counts and symbols, not lengths.
-    for (int k = 0; k < rep; ++k) L.b(i + k) = (uint8_t)val;
+    for (int k = 0; k < rep; ++k) L.b(i + k) = (uint8_t)val;       // both alphabets' lengths land in one run
     i += rep;
     prev = val;
     if (in.overrun()) return kInputOverrun;
   }
   if (L.b(256) == 0) return kBadCodeLengths;                  // no end-of-block code
-  // distance lengths first (they sit behind the literal / length ones and are copied down to a scratch stretch of the
-  // symbol array while the literal / length tables are built from 0..hlit)
-  for (int k = 0; k < hdist; ++k) L.h(kSymD + k) = L.b(hlit + k);
-  if (!build_tables(L, hlit, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl)) return kBadCodeLengths;
-  for (int k = 0; k < hdist; ++k) L.b(k) = (uint8_t)L.h(kSymD + k);
-  if (!build_tables(L, hdist, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD)) return kBadCodeLengths;
+  // The distance lengths are parked where the distance look-up table will be (the code-length code's table is dead), the
+  // literal / length alphabet is sorted, THEN its look-up table overwrites the lengths' place.
+  for (int k = 0; k < hdist; ++k) L.b(kLensAtD + k) = L.b(hlit + k);
+  if (!sort_symbols(L, 0, hlit, kCntLl, kSymLl, kOffsLl, kNextLl, &none)) return kBadCodeLengths;
+  fill_lut(L, kCntLl, kSymLl, kLutLl, kLlBits, none);
+  if (!sort_symbols(L, kLensAtD, hdist, kCntD, kSymD, kOffsD, kNextD, &none)) return kBadCodeLengths;
+  fill_lut(L, kCntD, kSymD, kLutD, kDBits, none);
   return kOk;
 }
 
 __device__ uint32_t fixed_tables(const Lds& L) {
+  bool none;
   for (int s = 0; s < 288; ++s) L.b(s) = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-  if (!build_tables(L, 288, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl)) return kBadCodeLengths;
-  for (int s = 0; s < 30; ++s) L.b(s) = 5;
-  // (30 codes of 5 bits leave the code incomplete, as the format defines it: build by hand what build_tables would refuse)
+  if (!sort_symbols(L, 0, 288, kCntLl, kSymLl, kOffsLl, kNextLl, &none)) return kBadCodeLengths;
+  fill_lut(L, kCntLl, kSymLl, kLutLl, kLlBits, none);
+  // (30 codes of 5 bits leave the code incomplete, as the format defines it: build by hand what sort_symbols would refuse)
   for (int l = 0; l < 16; ++l) L.h(kCntD + l) = 0;
   L.h(kCntD + 5) = 30;
   for (int l = 0; l < 16; ++l) { L.h(kOffsD + l) = (uint16_t)(l >= 5 ? 30 : 0); L.h(kNextD + l) = 0; }     // (every code is in the table)
@@ -272,53 +317,87 @@ __device__ uint32_t fixed_tables(const Lds& L) {
   return kOk;
 }
 
-// The inflated bytes: literals are gathered four at a time into ALIGNED words (a byte store per literal is four times the
-// stores and four times the acknowledgements the next load of input waits behind). A match first puts the gathered bytes
-// out; the literals behind it go out byte by byte until the output position is a multiple of four again (`lead`), so that
-// every word store is aligned wherever the matches fall.
-struct ByteOut {
-  uint8_t* dst;
-  uint32_t o;          // bytes produced, the gathered ones included
-  uint32_t acc;
-  int na;              // gathered bytes (they belong at o - na ..)
-  uint32_t lead;       // literals to store singly before the next aligned word starts
-  uint32_t skew;       // (0 - dst) & 3: dst + o is a multiple of four exactly where o - skew is
-  __device__ __forceinline__ void open(uint8_t* d) {
-    dst = d; o = 0; acc = 0; na = 0;
-    skew = (uint32_t)((0u - reinterpret_cast<uintptr_t>(d)) & 3u);
-    lead = skew;
+// What a stream's decoder leaves behind: tokens and literals, in the stream's ROOM of `room` dwords (kernels.h InflateBlock:
+// mbase, mcap).  Dwords 0 and 1 stay free (the placer's 8-byte loads of literals may reach that far down), token i is dword
+// 2 + i, literal j the byte 4 * room - 1 - j: the literals run DOWN from the room's end, four to a dword.
+template <class LV>
+struct TokenOut {
+  static constexpr uint32_t kLitW = LV::kLitW, kTokW = LV::kTokW;
+  uint32_t* area;
+  uint32_t room;
+  uint32_t o;          // bytes of output accounted for
+  uint32_t run;        // literals since the last token
+  uint32_t acc;        // literals gathered for the next dword (first literal in the top byte)
+  int na;
+  uint32_t lw, lr;     // literal dwords gathered / stored
+  uint32_t tw, tr;     // tokens gathered / stored
+  bool full;           // the room is too small (the stream is decoded again with more)
+  __device__ __forceinline__ void open(uint32_t* a, uint32_t room_dwords) {
+    area = a; room = room_dwords; o = 0; run = 0; acc = 0; na = 0; lw = lr = tw = tr = 0; full = false;
   }
-  __device__ __forceinline__ void literal(uint32_t b) {
-    if (lead) { dst[o++] = (uint8_t)b; --lead; return; }
-    acc |= b << (8 * na);
-    ++o;
-#ifdef MIDAS_INFLATE_NO_STORE      // (developer timing variant: the literals are not stored -- WRONG output)
-    if (++na == 4) { acc = 0; na = 0; }
-#else
-    if (++na == 4) { *reinterpret_cast<uint32_t*>(dst + o - 4) = acc; acc = 0; na = 0; }
-#endif
+  // (one dword kept free for the literals' last, partly filled dword)
+  __device__ __forceinline__ bool fits() const { return 2u + tw + lw + 2u <= room; }
+  __device__ __forceinline__ void store_lits(const LV& L) {           // four dwords, the earliest literals at the highest address
+    u32x4_a4 v;
+    v.w = L.lit(lr); v.z = L.lit(lr + 1u); v.y = L.lit(lr + 2u); v.x = L.lit(lr + 3u);
+    *reinterpret_cast<u32x4_a4*>(area + (room - 4u - lr)) = v;
+    lr += 4u;
   }
-  __device__ __forceinline__ void flush() {
-    for (int k = 0; k < na; ++k) dst[o - na + k] = (uint8_t)(acc >> (8 * k));
-    acc = 0; na = 0;
+  __device__ __forceinline__ void store_toks(const LV& L) {
+    u32x4_a4 v;
+    v.x = L.tok(tr); v.y = L.tok(tr + 1u); v.z = L.tok(tr + 2u); v.w = L.tok(tr + 3u);
+    *reinterpret_cast<u32x4_a4*>(area + (2u + tr)) = v;
+    tr += 4u;
   }
-  // `len` bytes are left for someone else to fill (a noted match); the gathered literals must be out already
-  __device__ __forceinline__ void leave(uint32_t len) { o += len; lead = (skew - o) & 3u; }
+  __device__ __forceinline__ void literal(const LV& L, uint32_t b) {
+    acc |= b << (24 - 8 * na);
+    ++o; ++run;
+    if (++na == 4) {
+      if (!fits()) { full = true; acc = 0; na = 0; return; }
+      if (lw - lr == kLitW) store_lits(L);               // (only when the lanes' common step was long in coming)
+      L.lit(lw) = acc;
+      ++lw;
+      acc = 0; na = 0;
+    }
+  }
+  __device__ __forceinline__ void push(const LV& L, uint32_t t) {
+    if (!fits()) { full = true; return; }
+    if (tw - tr == kTokW) store_toks(L);
+    L.tok(tw) = t;
+    ++tw;
+  }
+  __device__ __forceinline__ void match(const LV& L, uint32_t len, uint32_t dist) {
+    if (run >= 511u) { push(L, kEscape | run); run = 0; }
+    push(L, (run << 23) | ((len - 3u) << 15) | (dist - 1u));
+    run = 0;
+    o += len;
+  }
+  // the lanes' common step: whole 16-byte stores of what has gathered
+  __device__ __forceinline__ void service(const LV& L) {
+    if (lw - lr >= 4u) store_lits(L);
+    while (tw - tr >= 4u) store_toks(L);
+  }
+  __device__ __forceinline__ void finish(const LV& L) {
+    if (run) { push(L, kEscape | run); run = 0; }
+    if (na) {
+      if (!fits()) full = true;
+      else { if (lw - lr == kLitW) store_lits(L); L.lit(lw) = acc; ++lw; }
+      acc = 0; na = 0;
+    }
+    if (full) return;
+    for (; tr < tw; ++tr) area[2u + tr] = L.tok(tr);
+    for (; lr < lw; ++lr) area[room - 1u - lr] = L.lit(lr);
+  }
 };
 
-// a noted match: position in the block's output | length << 32 | distance << 41
-__device__ __forceinline__ unsigned long long match_pack(uint32_t o, uint32_t len, uint32_t dist) {
-  return (unsigned long long)o | ((unsigned long long)len << 32) | ((unsigned long long)dist << 41);
-}
-
-__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint8_t* dst_, uint32_t ulen,
-                                unsigned long long* mlist, uint32_t mcap, uint32_t* n_matches) {
-  uint32_t m = 0, tick = 0;
+__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint32_t ulen, uint32_t* area, uint32_t room,
+                                uint32_t* n_tokens) {
+  uint32_t tick = 0;
   BitIn in;
   in.open(L, src, clen);
-  ByteOut out;
-  out.open(dst_);
-  uint8_t* const dst = dst_;
+  TokenOut<Lds> out;
+  out.open(area, room);
+  if (room < 8u) return kMatchRoom;
   for (;;) {
     in.refill(L);
     const uint32_t last = in.take(1), type = in.take(2);
@@ -332,8 +411,10 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
       if (out.o + len > ulen) return kOutputOverrun;
       for (uint32_t k = 0; k < len; ++k) {
         in.refill(L);
-        out.literal(in.take(8));
+        out.literal(L, in.take(8));
+        if ((k & 15u) == 15u) { out.service(L); in.top_up(L); }
         if (in.overrun()) return kInputOverrun;
+        if (out.full) return kMatchRoom;
       }
     } else if (type == 3u) {
       return kBadBlockType;
@@ -342,9 +423,10 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
       if (st != kOk) return st;
       in.refill(L);
       for (;;) {
-        // (one count for all the lanes that take this step together: they top their rings up at the same steps)
+        // (one count for all the lanes that take this step together: they top their rings up and send what they gathered
+        // at the same steps)
         tick = (uint32_t)__builtin_amdgcn_readfirstlane((int)tick) + 1u;
-        if ((tick & 7u) == 0u) in.top_up(L);
+        if ((tick & 7u) == 0u) { out.service(L); in.top_up(L); }
         // at least 15 valid bits here (32 after a literal, 19 after a match): the symbol is decoded first and the buffer filled
         // up behind it -- one round trip to the ring fewer on the way to the next table look-up
         int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl);
@@ -352,8 +434,9 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         if (s < 0) return kBadSymbol;
         if (s < 256) {
           if (out.o >= ulen) return kOutputOverrun;
-          out.literal((uint32_t)s);
+          out.literal(L, (uint32_t)s);
           if (in.overrun()) return kInputOverrun;
+          if (out.full) return kMatchRoom;
           continue;
         }
         if (s == 256) break;
@@ -371,80 +454,588 @@ __device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, u
         dist += in.take(extra);
         if (dist > out.o) return kBadDistance;
         if (out.o + len > ulen) return kOutputOverrun;
-        // noted, not copied
-        out.flush();
-        if (m == mcap) return kMatchRoom;
-        mlist[m++] = match_pack(out.o, len, dist);
-        out.leave(len);
+        out.match(L, len, dist);
         if (in.overrun()) return kInputOverrun;
+        if (out.full) return kMatchRoom;
       }
       if (in.overrun()) return kInputOverrun;
     }
     if (last) break;
   }
-  out.flush();
-  *n_matches = m;
+  out.finish(L);
+  if (out.full) return kMatchRoom;
+  *n_tokens = out.tw;
   return out.o == ulen ? kOk : kShortOutput;
 }
 
 __global__ __launch_bounds__(kDecLanes) void bgzf_inflate_kernel(InflateParams p) {
   __shared__ uint16_t s16[kU16 * kDecLanes];
-  __shared__ uint8_t s8[kLens * kDecLanes];
-  __shared__ uint32_t s32[kRing * kDecLanes];
+  __shared__ uint32_t s32[kU32 * kDecLanes];
   const long long k = (long long)blockIdx.x * kDecLanes + threadIdx.x;
   if (k >= p.n_blocks) return;
-  Lds L{(lds_u16*)s16, (lds_u8*)s8, (lds_u32*)s32, (int)threadIdx.x};
+  Lds L{(lds_u16*)s16, (lds_u8*)s16, (lds_u32*)s32, (int)threadIdx.x};
   const InflateBlock b = p.blocks[k];
-  uint32_t st = kOk, nm = 0;
-  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, p.out + b.upos, b.ulen, p.matches + b.mbase, b.mcap, &nm);
+  uint32_t st = kOk, nt = 0;
+  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, b.ulen, reinterpret_cast<uint32_t*>(p.matches + b.mbase), b.mcap * 2u, &nt);
   p.status[k] = st;
-  p.n_matches[k] = st == kOk ? nm : 0u;
+  p.n_matches[k] = st == kOk ? nt : 0u;
 }
 
-// The matches of one block, in order, by one wavefront -- 64 at a time where they allow it.  A match only reads what lies in
-// front of it, so a run of consecutive matches whose sources all lie in front of the run's FIRST destination can be copied at
-// the same moment, one lane per match (most matches of a BAM are a few bytes long); the run ends in front of the first match
-// that reads what the run writes.  One fence per run makes the run's bytes visible to the next one's loads.  Inside a lane the
-// copy goes in pieces no longer than the distance and no longer than 16 bytes, loads first, then stores (a match longer than
-// its distance repeats its first `distance` bytes: the pieces read what the lane itself stored a step earlier).
+// ---- the decoder, wavefront-wide (the shipped one) --------------------------------------------------------------------------
+// The look-up-table decoder above keeps 2.3 KiB of tables per stream in LDS: 64 streams a CU, eight lanes to a wavefront, and a
+// step of its symbol loop -- three hundred instructions of one wavefront, most of them depending on the one before -- takes
+// ~3 000 cycles (measured: 75 ms for configs[2]'s 46 500 blocks, whatever the stores do).  What a CU lacks there is streams in
+// flight.  This decoder needs 816 bytes a stream, so a CU holds three full wavefronts of 64 streams:
+//   * no look-up table.  A canonical Huffman code is decoded by COMPARISON: with the next 15 bits read as a code reads them
+//     (first bit on top), the codes of length l are exactly the values in [limit[l-1], limit[l]) -- limit[l] = (first code of
+//     length l + their number) << (15 - l), increasing in l -- so the length is one more than the number of limits the value
+//     has reached: fifteen compares against REGISTERS (a lane's two alphabets are 30 VGPRs; the loop is unrolled, no register is
+//     indexed), no branch, no rare long-code path for the lanes of a wavefront to diverge into.  The symbol then is
+//     sorted_symbols[(value >> (15 - l)) + base[l]]: two dependent LDS reads (16 + 288 entries).
+//   * the lanes' LDS is interleaved by dword ([word][lane]): any access pattern is conflict-free.
+//   * a table header is read in TWO PASSES over its bits instead of through a buffer of code lengths (320 bytes a lane that
+//     LDS does not have): pass one counts the codes per length, the limits and bases follow from the counts, pass two reads
+//     the same bits again and puts every symbol at its place in the sorted list.  The code-length code itself (19 symbols of at
+//     most 7 bits) lives entirely in registers (symbols 5 bits each in two words, bases a byte each in one).
+//   * one loop for all lanes with a state per lane (header wanted / symbols / stored bytes / done): headers are read at the
+//     lanes' common eighth step, by all lanes that want one together -- zlib ends a block after 16 383 symbols, so the streams
+//     of a BAM reach their second header at the same step and no lane waits for another's header.
+// Output as above: tokens and literals through small LDS rings, 16-byte stores at the common step.
+namespace w64 {
+
+constexpr int kW = 64;
+// byte offsets in a lane's own LDS space
+constexpr int aSymLl = 0;       // u16 x 288: literal/length symbols sorted by (length, symbol)
+constexpr int aSymD = 576;      // u8 x 32: distance symbols
+constexpr int aBaseLl = 608;    // u16 x 16: per length, sorted position of its first symbol - its first code
+constexpr int aBaseD = 640;     // u16 x 16
+constexpr int aRing = 672;      // u32 x 16: the next 64 bytes of the stream
+constexpr int aLit = 736;       // u32 x 4
+constexpr int aTok = 752;       // u32 x 16
+constexpr int kLaneBytes = 816;
+constexpr int aCntLl = aTok;    // u16 x 16 each, while a table header is read (the token ring is empty then)
+constexpr int aCntD = aTok + 32;
+constexpr uint32_t kRingW = 16;
+
+struct Lane {
+  static constexpr uint32_t kLitW = 4, kTokW = 16;
+  lds_u8* base;      // the lane's byte 0
+  __device__ __forceinline__ lds_u8* at(int a) const { return base + ((a >> 2) << 8) + (a & 3); }     // [word][lane]: 256 bytes a word row
+  __device__ __forceinline__ lds_u8& b(int a) const { return *at(a); }
+  __device__ __forceinline__ lds_u16& h(int a) const { return *reinterpret_cast<lds_u16*>(at(a)); }     // a even
+  __device__ __forceinline__ lds_u32& w(int a) const { return *reinterpret_cast<lds_u32*>(at(a)); }     // a a multiple of four
+  __device__ __forceinline__ lds_u32& r(uint32_t i) const { return w(aRing + 4 * (int)(i & (kRingW - 1u))); }
+  __device__ __forceinline__ lds_u32& lit(uint32_t i) const { return w(aLit + 4 * (int)(i & (kLitW - 1u))); }
+  __device__ __forceinline__ lds_u32& tok(uint32_t i) const { return w(aTok + 4 * (int)(i & (kTokW - 1u))); }
+};
+
+// (BitIn of the decoder above, over this layout, that can also go back to a bit it has passed)
+struct Bits {
+  const uint8_t* src;
+  size_t clen;
+  const uint32_t* wp;
+  unsigned long long buf;
+  int n;
+  long long budget;
+  uint32_t rd, wr, lead;
+  uint32_t pre[8];
+  bool on_the_way;
+  __device__ __forceinline__ void fetch() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[k] = wp[k];
+    wp += 8;
+    on_the_way = true;
+  }
+  __device__ __forceinline__ void land(const Lane& L) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.r(wr + (uint32_t)k) = pre[k];
+    wr += 8u;
+    on_the_way = false;
+  }
+  __device__ __forceinline__ void open_at(const Lane& L, size_t byte) {
+    const uint8_t* p = src + byte;
+    const size_t len = clen > byte ? clen - byte : 0;
+    buf = 0; n = 0;
+    budget = (long long)len * 8;
+    while ((reinterpret_cast<uintptr_t>(p) & 3u) && n < 32) {
+      buf |= (unsigned long long)(*p++) << n;
+      n += 8;
+    }
+    budget -= n;
+    lead = (uint32_t)n + 8u * (uint32_t)byte;       // bits in front of the first aligned word, from the stream's first bit
+    wp = reinterpret_cast<const uint32_t*>(p);
+    rd = wr = 0u;
+    fetch();
+  }
+  __device__ __forceinline__ void open(const Lane& L, const uint8_t* s, size_t len) { src = s; clen = len; open_at(L, 0); }
+  // bits of the stream consumed so far, and the way back to such a position
+  __device__ __forceinline__ unsigned long long consumed() const { return (unsigned long long)lead + 32ull * rd - (unsigned long long)n; }
+  __device__ __forceinline__ void seek(const Lane& L, unsigned long long bit) {
+    open_at(L, (size_t)(bit >> 3));
+    refill(L);
+    skip((int)(bit & 7ull));
+  }
+  __device__ __forceinline__ void top_up(const Lane& L) {
+    if (on_the_way && wr - rd <= kRingW - 8u) land(L);
+    if (!on_the_way && wr - rd <= kRingW - 8u && budget - 32ll * (long long)(wr - rd) > -1024) fetch();
+  }
+  __device__ __forceinline__ void refill(const Lane& L) {
+    if (n <= 32) {
+      if (rd == wr) {
+        if (!on_the_way) fetch();
+        land(L);
+      }
+      buf |= (unsigned long long)L.r(rd) << n;
+      ++rd;
+      n += 32;
+      budget -= 32;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
+  __device__ __forceinline__ void skip(int k) { buf >>= k; n -= k; }
+  __device__ __forceinline__ uint32_t take(int k) { const uint32_t v = peek(k); skip(k); return v; }
+  __device__ __forceinline__ bool overrun() const { return budget + n < 0; }
+};
+
+// From the counts per length (u16 x 16 at cnt_at): the limits (registers), the bases (LDS), and in the counts' place the
+// sorted position of every length's first symbol.  False: over-subscribed, or incomplete (allowed as the one-code case zlib
+// allows, as an alphabet without any code -- the distances of a literal-only block -- and where the format itself is: fixed).
+__device__ __forceinline__ bool limits_from_counts(const Lane& L, int cnt_at, int base_at, uint32_t (&lim)[16], bool fixed) {
+  int left = 1;
+  uint32_t code = 0, off = 0;
+  bool ok = true;
+  lim[0] = 0;
+#pragma unroll
+  for (int l = 1; l < 16; ++l) {
+    const uint32_t c = L.h(cnt_at + 2 * l);
+    left = (left << 1) - (int)c;
+    ok = ok && left >= 0;
+    lim[l] = (code + c) << (15 - l);
+    L.h(base_at + 2 * l) = (uint16_t)(off - code);
+    L.h(cnt_at + 2 * l) = (uint16_t)off;
+    off += c;
+    code = (code + c) << 1;
+  }
+  const bool one = off == 1u && lim[1] == (1u << 14);        // a single code of one bit
+  return ok && (left == 0 || one || off == 0u || fixed);
+}
+// One symbol of an alphabet: its code's length, 0 when the next bits are no code.  (sym8: the distance alphabet's bytes)
+template <bool SYM8>
+__device__ __forceinline__ int decode(const Lane& L, const Bits& in, const uint32_t (&lim)[16], int base_at, int sym_at, uint32_t* sym) {
+  const uint32_t v = __brev((uint32_t)in.buf) >> 17;
+  uint32_t l = 1;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) l += v >= lim[k] ? 1u : 0u;
+  const bool bad = l > 15u;
+  l = bad ? 15u : l;
+  const uint32_t idx = ((v >> (15u - l)) + (uint32_t)L.h(base_at + 2 * (int)l)) & 0xFFFFu;
+  // (a position beyond the table can only come from a value that is no code)
+  *sym = SYM8 ? (uint32_t)L.b(sym_at + (int)(idx & 31u)) : (uint32_t)L.h(sym_at + 2 * (int)(idx < 288u ? idx : 0u));
+  return bad ? 0 : (int)l;
+}
+
+// The code-length code of a dynamic header, in registers.
+struct ClCode {
+  uint32_t lim[8];                  // limits over the next SEVEN bits
+  unsigned long long base;          // per length, a byte: sorted position of its first symbol - its first code
+  unsigned long long sym_a, sym_b;  // sorted symbols, five bits each: positions 0..11, 12..18
+  __device__ __forceinline__ bool build(unsigned long long lens3) {      // lens3: 3 bits per symbol 0..18
+    uint32_t cnt[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) cnt[l] = 0;
+    for (int s = 0; s < 19; ++s) {
+      const uint32_t l = (uint32_t)(lens3 >> (3 * s)) & 7u;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) cnt[q] += l == (uint32_t)q ? 1u : 0u;
+    }
+    int left = 1;
+    uint32_t code = 0, off = 0;
+    unsigned long long offs = 0;      // per length, a byte: where its next symbol goes
+    bool ok = true;
+    base = 0;
+    lim[0] = 0;
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+      const uint32_t c = cnt[l];
+      left = (left << 1) - (int)c;
+      ok = ok && left >= 0;
+      lim[l] = (code + c) << (7 - l);
+      base |= (unsigned long long)((off - code) & 255u) << (8 * l);
+      offs |= (unsigned long long)off << (8 * l);
+      off += c;
+      code = (code + c) << 1;
+    }
+    const bool one = off == 1u && cnt[1] == 1u;
+    if (!(ok && (left == 0 || one))) return false;
+    sym_a = 0; sym_b = 0;
+    for (int s = 0; s < 19; ++s) {
+      const uint32_t l = (uint32_t)(lens3 >> (3 * s)) & 7u;
+      if (!l) continue;
+      const uint32_t pos = (uint32_t)(offs >> (8 * l)) & 255u;
+      offs += 1ull << (8 * l);
+      if (pos < 12u) sym_a |= (unsigned long long)s << (5 * pos); else sym_b |= (unsigned long long)s << (5 * (pos - 12u));
+    }
+    return true;
+  }
+  // a code-length symbol (0..18), -1: no code; the bits are taken
+  __device__ __forceinline__ int decode(Bits& in) const {
+    const uint32_t v = __brev((uint32_t)in.buf) >> 25;
+    uint32_t l = 1;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) l += v >= lim[k] ? 1u : 0u;
+    if (l > 7u) return -1;
+    const uint32_t pos = ((v >> (7u - l)) + ((uint32_t)(base >> (8 * l)) & 255u)) & 255u;
+    if (pos >= 19u) return -1;
+    in.skip((int)l);
+    return (int)((pos < 12u ? (sym_a >> (5 * pos)) : (sym_b >> (5 * (pos - 12u)))) & 31ull);
+  }
+};
+
+struct Tables {
+  uint32_t ll[16], d[16];       // the limits of the block in work
+};
+
+// One pass over the code lengths of a dynamic header (hlit + hdist of them, run-length coded): COUNT them per alphabet and
+// length, or PLACE every symbol in its alphabet's sorted list.
+template <bool PLACE>
+__device__ __forceinline__ uint32_t lengths_pass(const Lane& L, Bits& in, const ClCode& cl, int hlit, int hdist, bool* has_eob) {
+  int i = 0, prev = 0;
+  const int total = hlit + hdist;
+  while (i < total) {
+    in.refill(L);
+    const int s = cl.decode(in);
+    if (s < 0) return kBadCodeLengths;
+    int rep = 1, val = s;
+    if (s == 16) { if (i == 0) return kBadCodeLengths; val = prev; rep = 3 + (int)in.take(2); }
+    else if (s == 17) { val = 0; rep = 3 + (int)in.take(3); }
+    else if (s == 18) { val = 0; rep = 11 + (int)in.take(7); }
+    if (i + rep > total) return kBadCodeLengths;
+    if (val) {
+      for (int k = 0; k < rep; ++k) {
+        const int sy = i + k;
+        const bool isd = sy >= hlit;
+        const int cnt_at = (isd ? aCntD : aCntLl) + 2 * val;
+        const uint32_t c = L.h(cnt_at);
+        L.h(cnt_at) = (uint16_t)(c + 1u);
+        if (PLACE) {
+          if (isd) L.b(aSymD + (int)(c & 31u)) = (uint8_t)(sy - hlit);
+          else L.h(aSymLl + 2 * (int)(c < 288u ? c : 0u)) = (uint16_t)sy;
+        } else if (sy == 256) {
+          *has_eob = true;
+        }
+      }
+    }
+    i += rep;
+    prev = val;
+    if (in.overrun()) return kInputOverrun;
+  }
+  return kOk;
+}
+
+__device__ __forceinline__ uint32_t dynamic_tables(const Lane& L, Bits& in, Tables& T) {
+  in.refill(L);
+  const int hlit = (int)in.take(5) + 257, hdist = (int)in.take(5) + 1, hclen = (int)in.take(4) + 4;
+  if (hlit > 286 || hdist > 30) return kBadCodeLengths;
+  unsigned long long lens3 = 0;
+  for (int i = 0; i < hclen; ++i) {
+    in.refill(L);
+    lens3 |= (unsigned long long)in.take(3) << (3 * c_cl_order[i]);
+  }
+  ClCode cl;
+  if (!cl.build(lens3)) return kBadCodeLengths;
+  const unsigned long long mark = in.consumed();
+  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.h(aCntD + 2 * l) = 0; }
+  bool has_eob = false;
+  uint32_t st = lengths_pass<false>(L, in, cl, hlit, hdist, &has_eob);
+  if (st != kOk) return st;
+  if (!has_eob) return kBadCodeLengths;                  // no end-of-block code
+  if (!limits_from_counts(L, aCntLl, aBaseLl, T.ll, false)) return kBadCodeLengths;
+  if (!limits_from_counts(L, aCntD, aBaseD, T.d, false)) return kBadCodeLengths;
+  const unsigned long long end = in.consumed();
+  in.seek(L, mark);                                      // the same bits again: every symbol to its place
+  st = lengths_pass<true>(L, in, cl, hlit, hdist, &has_eob);
+  if (st != kOk) return st;
+  return in.consumed() == end ? kOk : kBadCodeLengths;
+}
+
+__device__ __forceinline__ uint32_t fixed_tables(const Lane& L, Tables& T) {
+  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.h(aCntD + 2 * l) = 0; }
+  L.h(aCntLl + 2 * 7) = 24; L.h(aCntLl + 2 * 8) = 152; L.h(aCntLl + 2 * 9) = 112;
+  L.h(aCntD + 2 * 5) = 30;                               // (30 codes of 5 bits: incomplete, as the format defines it)
+  if (!limits_from_counts(L, aCntLl, aBaseLl, T.ll, true)) return kBadCodeLengths;
+  if (!limits_from_counts(L, aCntD, aBaseD, T.d, true)) return kBadCodeLengths;
+  for (int s = 0; s < 288; ++s) {
+    const int l = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+    const uint32_t c = L.h(aCntLl + 2 * l);
+    L.h(aCntLl + 2 * l) = (uint16_t)(c + 1u);
+    L.h(aSymLl + 2 * (int)c) = (uint16_t)s;
+  }
+  for (int s = 0; s < 30; ++s) L.b(aSymD + s) = (uint8_t)s;
+  return kOk;
+}
+
+enum : uint32_t { kWantHeader = 0, kSymbols = 1, kStored = 2, kDone = 3 };
+
+__global__ __launch_bounds__(kW) void bgzf_decode_kernel(InflateParams p) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kLaneBytes / 4 * kW];
+  const long long k = (long long)blockIdx.x * kW + threadIdx.x;
+  const bool have = k < p.n_blocks;
+  Lane L{reinterpret_cast<lds_u8*>((lds_u32*)lds) + 4 * (int)threadIdx.x};
+  InflateBlock b{};
+  if (have) b = p.blocks[k];
+  Bits in;
+  TokenOut<Lane> out;
+  Tables T;
+#pragma unroll
+  for (int l = 0; l < 16; ++l) { T.ll[l] = 0; T.d[l] = 0; }
+  uint32_t state = kDone, status = kOk, last = 0, stored_left = 0;
+  const uint32_t ulen = b.ulen;
+  out.open(have ? reinterpret_cast<uint32_t*>(p.matches + b.mbase) : nullptr, b.mcap * 2u);
+  if (have && ulen) {
+    if (out.room < 8u) { status = kMatchRoom; }
+    else { in.open(L, p.comp + b.cpos, (size_t)b.clen); state = kWantHeader; }
+  } else {
+    in.src = nullptr; in.clen = 0; in.wp = nullptr; in.buf = 0; in.n = 0; in.budget = 0; in.rd = in.wr = in.lead = 0; in.on_the_way = false;
+  }
+  auto fail = [&](uint32_t code) { status = code; state = kDone; };
+  uint32_t iter = 0;
+  while (__ballot(state != kDone) != 0ull) {
+    if ((iter & 7u) == 0u) {
+      if (state != kDone) { out.service(L); in.top_up(L); }
+      if (state == kWantHeader) {                          // all lanes that want one, together
+        // (the tokens' ring lends its place to the counts: what it holds goes out first)
+        while (out.tr < out.tw) { out.area[2u + out.tr] = L.tok(out.tr); ++out.tr; }
+        in.refill(L);
+        last = in.take(1);
+        const uint32_t type = in.take(2);
+        if (type == 3u) {
+          fail(kBadBlockType);
+        } else if (type == 0u) {                           // stored: to the next byte, LEN, ~LEN, the bytes
+          in.skip(in.n & 7);
+          in.refill(L);
+          const uint32_t len = in.take(16);
+          in.refill(L);
+          const uint32_t nlen = in.take(16);
+          if ((len ^ 0xFFFFu) != nlen) fail(kBadStored);
+          else if (out.o + len > ulen) fail(kOutputOverrun);
+          else { stored_left = len; state = len ? kStored : (last ? kDone : kWantHeader); }
+        } else {
+          const uint32_t st = type == 1u ? fixed_tables(L, T) : dynamic_tables(L, in, T);
+          if (st != kOk) fail(st); else { in.refill(L); state = kSymbols; }
+        }
+        if (state != kDone && in.overrun()) fail(kInputOverrun);
+      }
+    }
+    ++iter;
+    if (state == kSymbols) {
+      uint32_t s;
+      const int l = decode<false>(L, in, T.ll, aBaseLl, aSymLl, &s);
+      in.skip(l);
+      in.refill(L);
+      if (l == 0) {
+        fail(kBadSymbol);
+      } else if (s < 256u) {
+        if (out.o >= ulen) fail(kOutputOverrun); else out.literal(L, s);
+      } else if (s == 256u) {
+        state = last ? kDone : kWantHeader;
+      } else {
+        const int sl = (int)s - 257;
+        if (sl >= 29) {
+          fail(kBadSymbol);
+        } else {
+          uint32_t len, dist, d;
+          int extra;
+          length_of(sl, &len, &extra);
+          len += in.take(extra);                           // (<= 5 extra bits of >= 32: 27 left for the distance code)
+          const int dl = decode<true>(L, in, T.d, aBaseD, aSymD, &d);
+          in.skip(dl);
+          in.refill(L);
+          if (dl == 0 || d >= 30u) {
+            fail(kBadDistance);
+          } else {
+            distance_of((int)d, &dist, &extra);
+            dist += in.take(extra);
+            if (dist > out.o) fail(kBadDistance);
+            else if (out.o + len > ulen) fail(kOutputOverrun);
+            else out.match(L, len, dist);
+          }
+        }
+      }
+      if (status == kOk) {
+        if (in.overrun()) fail(kInputOverrun);
+        else if (out.full) fail(kMatchRoom);
+      }
+    } else if (state == kStored) {
+      for (int q = 0; q < 4 && stored_left; ++q) {
+        in.refill(L);
+        out.literal(L, in.take(8));
+        --stored_left;
+      }
+      if (in.overrun()) fail(kInputOverrun);
+      else if (out.full) fail(kMatchRoom);
+      else if (!stored_left) state = last ? kDone : kWantHeader;
+    }
+  }
+  if (!have) return;
+  uint32_t nt = 0;
+  if (status == kOk && ulen) {
+    out.finish(L);
+    if (out.full) status = kMatchRoom;
+    else if (out.o != ulen) status = kShortOutput;
+    nt = out.tw;
+  }
+  p.status[k] = status;
+  p.n_matches[k] = status == kOk ? nt : 0u;
+}
+
+}  // namespace w64
+
+// ---- the placer ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// n (1..8) bytes of v to an address of any alignment: two overlapping dwords from four bytes on
+__device__ __forceinline__ void store_upto8(uint8_t* dst, unsigned long long v, uint32_t n) {
+  if (n >= 8u) {
+    *reinterpret_cast<u64_a1*>(dst) = v;
+  } else if (n >= 4u) {
+    *reinterpret_cast<u32_a1*>(dst) = (uint32_t)v;
+    *reinterpret_cast<u32_a1*>(dst + (n - 4u)) = (uint32_t)(v >> (8u * (n - 4u)));
+  } else {
+    if (n >= 2u) *reinterpret_cast<u16_a1*>(dst) = (uint16_t)v;
+    if (n & 1u) dst[n - 1u] = (uint8_t)(v >> (8u * (n - 1u)));
+  }
+}
+__device__ __forceinline__ unsigned long long bswap64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  return ((unsigned long long)__builtin_bswap32(lo) << 32) | (unsigned long long)__builtin_bswap32(hi);
+}
+
+// eight bytes of the sequence with period `dist` (1..7 bytes, in the low bytes of pat), from its byte `phase` on
+__device__ __forceinline__ unsigned long long periodic8(unsigned long long pat, uint32_t dist, uint32_t phase) {
+  const uint32_t bits = 8u * dist;
+  unsigned long long w = phase ? ((pat >> (8u * phase)) | (pat << (bits - 8u * phase))) & ((1ull << bits) - 1ull) : pat;
+  w |= w << bits;                          // 2 * dist bytes (dist <= 7: bits <= 56)
+  if (2u * bits < 64u) w |= w << (2u * bits);
+  if (4u * bits < 64u) w |= w << (4u * bits);
+  return w;
+}
+
+// 64 tokens of a block, one a lane: where each one's bytes go
+struct Window {
+  uint32_t lits, len, dist;   // len 0: no match (an escape token, or a lane behind the block's last token)
+  uint32_t start;             // the token's first byte in the block's output (its literals), the match follows at start + lits
+  uint32_t lsrc;              // its first literal's index in the block's literal stream
+  uint32_t end_o, end_l;      // (all lanes) what the window's tokens add up to, the tokens in front of it included
+};
+__device__ __forceinline__ Window make_window(uint32_t t, uint32_t carry_o, uint32_t carry_l, int lane) {
+  Window w;
+  const bool esc = (t >> 23) == 511u;
+  w.lits = esc ? (t & 0x7FFFFFu) : (t >> 23);
+  w.len = esc ? 0u : ((t >> 15) & 255u) + 3u;
+  w.dist = (t & 0x7FFFu) + 1u;
+  const uint32_t io = wave_scan_incl(w.lits + w.len, lane), il = wave_scan_incl(w.lits, lane);
+  w.start = carry_o + io - (w.lits + w.len);
+  w.lsrc = carry_l + il - w.lits;
+  w.end_o = carry_o + (uint32_t)__shfl((int)io, 63);
+  w.end_l = carry_l + (uint32_t)__shfl((int)il, 63);
+  return w;
+}
+// the window's literals from the block's literal stream (bytes in reverse order below lit_end) to their places
+__device__ __forceinline__ void place_literals(const Window& w, uint8_t* out, const uint8_t* lit_end, int lane) {
+  const uint32_t n = w.lits;
+  uint8_t* dst = out + w.start;
+  if (n > 0u && n <= 64u) {
+    uint32_t k = 0;
+    for (; k + 8u <= n; k += 8u)
+      *reinterpret_cast<u64_a1*>(dst + k) = bswap64(*reinterpret_cast<const u64_a1*>(lit_end - (w.lsrc + k) - 8u));
+    if (k < n) {
+      if (n >= 8u) {          // the last eight once more (the same bytes)
+        *reinterpret_cast<u64_a1*>(dst + (n - 8u)) = bswap64(*reinterpret_cast<const u64_a1*>(lit_end - (w.lsrc + n)));
+      } else {
+        store_upto8(dst, bswap64(*reinterpret_cast<const u64_a1*>(lit_end - w.lsrc - 8u)), n);
+      }
+    }
+  }
+  // a long run of literals (a stored block, incompressible bytes): the whole wavefront copies it, a byte a lane
+  unsigned long long big = __ballot(n > 64u);
+  while (big) {
+    const int src = (int)__ffsll((long long)big) - 1;
+    big &= big - 1ull;
+    const uint32_t bn = (uint32_t)__shfl((int)n, src), bs = (uint32_t)__shfl((int)w.start, src), bl = (uint32_t)__shfl((int)w.lsrc, src);
+    for (uint32_t t = (uint32_t)lane; t < bn; t += 64u) out[bs + t] = *(lit_end - 1 - (bl + t));
+  }
+}
+
 constexpr int kResolveWaves = 4;
-__global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_resolve_kernel(InflateParams p) {
+__global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_place_kernel(InflateParams p) {
   const long long k = (long long)blockIdx.x * kResolveWaves + (threadIdx.x >> 6);
   if (k >= p.n_blocks) return;
+  if (p.status[k] != kOk) return;
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t n = p.n_matches[k];
   if (n == 0u) return;
   const InflateBlock b = p.blocks[k];
   uint8_t* out = p.out + b.upos;
-  const unsigned long long* list = p.matches + b.mbase;
-  uint32_t m = 0;
-  while (m < n) {
-    const bool have = m + (uint32_t)lane < n;
-    const unsigned long long rec = have ? list[m + (uint32_t)lane] : 0ull;
-    const uint32_t o = (uint32_t)rec, len = (uint32_t)(rec >> 32) & 511u, dist = (uint32_t)(rec >> 41);
-    const uint32_t first = (uint32_t)__shfl((int)o, 0);                  // the run's first destination
-    const uint32_t span = len < dist ? len : dist;
-    const bool free_of_run = have && (lane == 0 || o - dist + span <= first);
-    const unsigned long long ok = __ballot(free_of_run);
-    const int run = ok == ~0ull ? 64 : (int)__ffsll((long long)~ok) - 1;  // leading lanes that are free
-    if (lane < run) {
-      uint32_t at = o, left = len;
-      while (left) {
-        uint32_t piece = left < dist ? left : dist;
-        piece = piece < 16u ? piece : 16u;
-        uint8_t t[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t[q] = (uint32_t)q < piece ? out[at - dist + q] : (uint8_t)0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) if ((uint32_t)q < piece) out[at + q] = t[q];
-        at += piece;
-        left -= piece;
+  const uint32_t* area = reinterpret_cast<const uint32_t*>(p.matches + b.mbase);
+  const uint32_t* toks = area + 2;
+  const uint8_t* lit_end = reinterpret_cast<const uint8_t*>(area + 2u * (size_t)b.mcap);
+  auto fetch = [&](uint32_t base) -> uint32_t { const uint32_t i = base + (uint32_t)lane; return i < n ? toks[i] : kEscape; };
+  uint32_t t_next = fetch(64u);
+  Window cur = make_window(fetch(0u), 0u, 0u, lane);
+  place_literals(cur, out, lit_end, lane);
+  for (uint32_t base = 0; base < n; base += 64u) {
+    // the next window: its tokens arrived while the last one was resolved; its literals go out now, in front of this window's
+    // matches (every step below starts with a fence: they are in place, and visible, before this wavefront reads them)
+    const Window nxt = make_window(t_next, cur.end_o, cur.end_l, lane);
+    t_next = fetch(base + 128u);
+    if (base + 64u < n) place_literals(nxt, out, lit_end, lane);
+    unsigned long long todo = __ballot(cur.len > 0u);
+    const uint32_t o = cur.start + cur.lits;
+    const uint32_t span = cur.len < cur.dist ? cur.len : cur.dist;
+    while (todo) {
+      // (this wavefront's stores in front of its loads.  The same wavefront, the same CU's cache: a workgroup-scope fence.  An
+      // agent-scope __threadfence() writes the XCD's whole L2 back -- 150 us a time here.)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const int f = (int)__ffsll((long long)todo) - 1;
+      const uint32_t front = (uint32_t)__shfl((int)cur.start, f);              // everything below is final
+      const bool mine = ((todo >> lane) & 1ull) != 0ull && (lane == f || o - cur.dist + span <= front);
+      if (mine) {
+        uint8_t* dst = out + o;
+        const uint8_t* s = dst - cur.dist;
+        const uint32_t len = cur.len;
+        if (cur.dist >= 8u || cur.dist >= len) {
+          // eight bytes a time.  Source and destination apart (nearly every match), or at least eight bytes apart: a load
+          // then reads what this lane itself stored an iteration earlier at the latest (a lane's accesses keep their order)
+          if (len <= 8u) {
+            store_upto8(dst, *reinterpret_cast<const u64_a1*>(s), len);
+          } else {
+            uint32_t q = 0;
+            for (; q + 8u <= len; q += 8u) *reinterpret_cast<u64_a1*>(dst + q) = *reinterpret_cast<const u64_a1*>(s + q);
+            if (q < len) *reinterpret_cast<u64_a1*>(dst + (len - 8u)) = *reinterpret_cast<const u64_a1*>(s + (len - 8u));
+          }
+        } else {
+          // a match longer than its distance of fewer than eight bytes repeats its first `distance` bytes (a run of one
+          // quality, of zeros): the period is built in registers, nothing is read back
+          const uint32_t dist = cur.dist;
+          const unsigned long long pat = *reinterpret_cast<const u64_a1*>(s) & ((1ull << (8u * dist)) - 1ull);
+          uint32_t q = 0, phase = 0;
+          for (; q < len; q += 8u) {
+            const unsigned long long w = periodic8(pat, dist, phase);
+            const uint32_t left = len - q;
+            if (left >= 8u) *reinterpret_cast<u64_a1*>(dst + q) = w; else store_upto8(dst + q, w, left);
+            phase = (phase + 8u) % dist;
+          }
+        }
       }
+      todo &= ~__ballot(mine);
     }
-    // (the run's stores in front of the next run's loads.  The same wavefront, the same CU's cache: a workgroup-scope fence.
-    // An agent-scope __threadfence() writes the XCD's whole L2 back -- 150 us a time here.)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    m += (uint32_t)run;
+    cur = nxt;
   }
 }
 
@@ -516,19 +1107,28 @@ hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {
   if (p.n_blocks <= 0) return hipSuccess;
   if (phases & 1) {
-    // the block inflater keeps its streams' tables and input rings in LDS (2.5 KiB a stream). A device that cannot give a
+    // the block inflater keeps its streams' tables and rings in LDS (2.3 KiB a stream). A device that cannot give a
     // workgroup that much cannot run it; say so instead of leaving it to the launch (the callers fall back to the host's inflater).
     static const bool fits = [] {
       hipFuncAttributes fa{};
       int dev = 0, lds = 0;
+#ifdef MIDAS_INFLATE_LUT
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(bgzf_inflate_kernel)) != hipSuccess) return true;
+#else
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(w64::bgzf_decode_kernel)) != hipSuccess) return true;
+#endif
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return true;
       return fa.sharedSizeBytes <= (size_t)lds;
     }();
     if (!fits) return hipErrorLaunchOutOfResources;
+#ifdef MIDAS_INFLATE_LUT      // (developer variant: the look-up-table decoder, eight streams a wavefront)
     const long long g = (p.n_blocks + kDecLanes - 1) / kDecLanes;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kDecLanes), 0, s, p);
+#else
+    const long long g = (p.n_blocks + w64::kW - 1) / w64::kW;
+    hipLaunchKernelGGL(w64::bgzf_decode_kernel, dim3((unsigned)g), dim3(w64::kW), 0, s, p);
+#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -541,7 +1141,7 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
   }
   if (!(phases & 2)) return hipSuccess;
   const long long g2 = (p.n_blocks + kResolveWaves - 1) / kResolveWaves;
-  hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)g2), dim3(kLanes * kResolveWaves), 0, s, p);
+  hipLaunchKernelGGL(bgzf_place_kernel, dim3((unsigned)g2), dim3(kLanes * kResolveWaves), 0, s, p);
   if (p.want_crc && !(phases & 8)) {       // (8: a caller that times the phases launches the check by itself, phases = 4)
     long long g3 = (p.n_blocks + kCrcWaves - 1) / kCrcWaves;
     g3 = g3 > 2048 ? 2048 : g3;

@@ -99,8 +99,11 @@ __global__ __launch_bounds__(kIdxBlock) void direct_ranges_kernel(DirectIndexPar
   // dependent loads per workgroup and pass was most of this kernel's 28 us); the threads walk on from there
   (void)s_c0;
   ContigCursor cur;
-  cur.c = p.block_contig[blockIdx.x];
-  cur.fetch(p);
+  {   // (the contig's row of the tables with it: one load, in flight together with the positions below)
+    const DirectBlockCursor bc = p.block_contig[blockIdx.x];
+    cur.c = bc.c; cur.begin = bc.begin; cur.next_begin = bc.next_begin; cur.tile_base = bc.tile_base; cur.tile_end = bc.tile_end;
+    cur.clen = bc.clen;
+  }
   const int lane = threadIdx.x & 63;
   constexpr int U = kIdxRun / kIdxBlock;
   int32_t pos[U], before[U];
@@ -186,7 +189,13 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   const long long hi = lo + kIdxRun < (long long)p.n_reads ? lo + kIdxRun : (long long)p.n_reads;
   if (threadIdx.x == 0 && lo < hi) {
     s_c0 = contig_of_read(p, (int)lo);
-    p.block_contig[blockIdx.x] = s_c0;
+    ContigCursor c0;
+    c0.c = s_c0;
+    c0.fetch(p);
+    DirectBlockCursor bc;
+    bc.c = c0.c; bc.begin = c0.begin; bc.next_begin = c0.next_begin; bc.tile_base = c0.tile_base; bc.tile_end = c0.tile_end; bc.pad = 0;
+    bc.clen = c0.clen;
+    p.block_contig[blockIdx.x] = bc;
   }
   __syncthreads();
   unsigned long long alg = 0, status = kNoError;

@@ -189,6 +189,8 @@ struct alignas(128) DirectFacts {                 // per-slot partial results of
   uint32_t n_long;                                // reads beyond the fast paths' limits (l_seq > kMaxLSeq, n_cigar / NM > kMaxField16): the batch takes the long path
 };
 
+// the contig a workgroup of the direct path's index kernels starts in (index_direct.hip ContigCursor, as the facts pass left it)
+struct DirectBlockCursor { int32_t c, begin, next_begin, tile_base, tile_end, pad; long long clen; };
 struct DirectIndexParams {
   const int32_t* pos; const int32_t* nm; const int32_t* l_seq;
   const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
@@ -202,8 +204,9 @@ struct DirectIndexParams {
   int32_t sorted;                                 // the facts pass found every contig's reads in position order
   int32_t reach;                                  // the longest reference span of the batch's reads: no read touches a site further from its start
   DirectFacts* facts;                             // [kDirectFactSlots] (facts pass only)
-  int32_t* block_contig;                          // [direct_index_blocks(n_reads)] the contig of a workgroup's first read: found by the facts
-                                                  // pass (one binary search per workgroup), read by every ranges pass
+  DirectBlockCursor* block_contig;                // [direct_index_blocks(n_reads)] the contig of a workgroup's first read and that contig's
+                                                  // row of the contig tables: found by the facts pass (one binary search per workgroup), ONE
+                                                  // 32-byte load of every ranges pass
   unsigned long long* stats; unsigned long long* err;
   int32_t n_stat_words;
 };

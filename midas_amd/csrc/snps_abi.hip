@@ -101,7 +101,7 @@ struct midas_snps_batch {
   bool packed_built = false;    // rec / blob / orig / key exist (the packed path's layout is built on first use)
   uint32_t* d_trange = nullptr; // [2 parities][tbegin n_tiles][tend n_tiles]
   DirectFacts* d_dfacts = nullptr;
-  int32_t* d_block_contig = nullptr;   // per workgroup of the direct path's index kernels: the contig of its first read
+  DirectBlockCursor* d_block_contig = nullptr;   // per workgroup of the direct path's index kernels: the contig of its first read
   DirectRec* d_drec = nullptr;         // [n_reads + 1] the direct layout: one 16-byte record per read ...
   uint8_t* d_dpay = nullptr;           // ... and its CIGAR / SEQ / QUAL bytes as one run (layout.h)
   unsigned long long* d_dunits = nullptr;   // (scratch of the layout's scan)
@@ -1347,8 +1347,8 @@ int32_t direct_prepare(midas_snps_batch* b) {
   const size_t nt = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
   HIP_TRY(ctx, hipMalloc(&b->d_trange, nt * 4 * 4));
   HIP_TRY(ctx, hipMalloc(&b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots));
-  HIP_TRY(ctx, hipMalloc(&b->d_block_contig, (size_t)direct_index_blocks(b->n_reads) * 4));
-  HIP_TRY(ctx, hipMemsetAsync(b->d_block_contig, 0, (size_t)direct_index_blocks(b->n_reads) * 4, s));
+  HIP_TRY(ctx, hipMalloc(&b->d_block_contig, (size_t)direct_index_blocks(b->n_reads) * sizeof(DirectBlockCursor)));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_block_contig, 0, (size_t)direct_index_blocks(b->n_reads) * sizeof(DirectBlockCursor), s));
   // tile bounds start clean (every pass resets the other parity's); counters at zero; status words at "no error"
   HIP_TRY(ctx, hipMemsetAsync(b->d_trange, 0, nt * 16, s));
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 0), 0xFF, nt * 4, s));
