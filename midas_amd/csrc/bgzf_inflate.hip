@@ -30,6 +30,9 @@
 // both buffers at every step: corrupt input yields a status, never a fault.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 #include "crc32.h"
 
@@ -485,13 +488,13 @@ __global__ __launch_bounds__(kDecLanes) void bgzf_inflate_kernel(InflateParams p
 // The look-up-table decoder above keeps 2.3 KiB of tables per stream in LDS: 64 streams a CU, eight lanes to a wavefront, and a
 // step of its symbol loop -- three hundred instructions of one wavefront, most of them depending on the one before -- takes
 // ~3 000 cycles (measured: 75 ms for configs[2]'s 46 500 blocks, whatever the stores do).  What a CU lacks there is streams in
-// flight.  This decoder needs 816 bytes a stream, so a CU holds three full wavefronts of 64 streams:
+// flight.  This decoder needs 512 bytes a stream, so a CU holds five full wavefronts of 64 streams:
 //   * no look-up table.  A canonical Huffman code is decoded by COMPARISON: with the next 15 bits read as a code reads them
 //     (first bit on top), the codes of length l are exactly the values in [limit[l-1], limit[l]) -- limit[l] = (first code of
 //     length l + their number) << (15 - l), increasing in l -- so the length is one more than the number of limits the value
 //     has reached: fifteen compares against REGISTERS (a lane's two alphabets are 30 VGPRs; the loop is unrolled, no register is
 //     indexed), no branch, no rare long-code path for the lanes of a wavefront to diverge into.  The symbol then is
-//     sorted_symbols[(value >> (15 - l)) + base[l]]: two dependent LDS reads (16 + 288 entries).
+//     sorted_symbols[(value >> (15 - l)) + base[l]]: two dependent LDS reads (16 + 288 entries; the symbols' ninth bit in a bitmap).
 //   * the lanes' LDS is interleaved by dword ([word][lane]): any access pattern is conflict-free.
 //   * a table header is read in TWO PASSES over its bits instead of through a buffer of code lengths (320 bytes a lane that
 //     LDS does not have): pass one counts the codes per length, the limits and bases follow from the counts, pass two reads
@@ -504,21 +507,23 @@ __global__ __launch_bounds__(kDecLanes) void bgzf_inflate_kernel(InflateParams p
 namespace w64 {
 
 constexpr int kW = 64;
-// byte offsets in a lane's own LDS space
-constexpr int aSymLl = 0;       // u16 x 288: literal/length symbols sorted by (length, symbol)
-constexpr int aSymD = 576;      // u8 x 32: distance symbols
-constexpr int aBaseLl = 608;    // u16 x 16: per length, sorted position of its first symbol - its first code
-constexpr int aBaseD = 640;     // u16 x 16
-constexpr int aRing = 672;      // u32 x 16: the next 64 bytes of the stream
-constexpr int aLit = 736;       // u32 x 4
-constexpr int aTok = 752;       // u32 x 16
-constexpr int kLaneBytes = 816;
-constexpr int aCntLl = aTok;    // u16 x 16 each, while a table header is read (the token ring is empty then)
-constexpr int aCntD = aTok + 32;
-constexpr uint32_t kRingW = 16;
+// byte offsets in a lane's own LDS space: 512 bytes a stream, 32 KiB a workgroup -- five workgroups fill a CU's 160 KiB
+constexpr int aSymLl = 0;       // u8 x 288: literal/length symbols sorted by (length, symbol), their low eight bits ...
+constexpr int aSymHi = 288;     // ... and bit 8 (a length code or the end of the block), one bit a symbol: 9 dwords
+constexpr int aSymD = 324;      // u8 x 32: distance symbols
+constexpr int aBaseLl = 356;    // u16 x 16: per length, sorted position of its first symbol - its first code
+constexpr int aBaseD = 388;     // u16 x 16
+constexpr int aRing = 420;      // u32 x 8: the next 32 bytes of the stream
+constexpr int aLit = 452;       // u32 x 4
+constexpr int aTok = 468;       // u32 x 8
+constexpr int kLaneBytes = 512;
+constexpr int aCntLl = aTok;    // u16 x 16, while a table header is read (the token ring is empty then)
+constexpr int aCntD = aLit;     // u8 x 16 (at most 30 distance codes; the literal ring is empty then)
+constexpr uint32_t kRingW = 8, kFetchW = 4;
+constexpr uint32_t kCommonStep = 4;      // the lanes send what they gathered and top their rings up every fourth step
 
 struct Lane {
-  static constexpr uint32_t kLitW = 4, kTokW = 16;
+  static constexpr uint32_t kLitW = 4, kTokW = 8;
   lds_u8* base;      // the lane's byte 0
   __device__ __forceinline__ lds_u8* at(int a) const { return base + ((a >> 2) << 8) + (a & 3); }     // [word][lane]: 256 bytes a word row
   __device__ __forceinline__ lds_u8& b(int a) const { return *at(a); }
@@ -527,6 +532,18 @@ struct Lane {
   __device__ __forceinline__ lds_u32& r(uint32_t i) const { return w(aRing + 4 * (int)(i & (kRingW - 1u))); }
   __device__ __forceinline__ lds_u32& lit(uint32_t i) const { return w(aLit + 4 * (int)(i & (kLitW - 1u))); }
   __device__ __forceinline__ lds_u32& tok(uint32_t i) const { return w(aTok + 4 * (int)(i & (kTokW - 1u))); }
+  // the literal/length symbol at sorted position pos (< 288)
+  __device__ __forceinline__ uint32_t sym_ll(uint32_t pos) const {
+    const uint32_t lo = b(aSymLl + (int)pos), hi = w(aSymHi + 4 * (int)(pos >> 5));
+    return lo | (((hi >> (pos & 31u)) & 1u) << 8);
+  }
+  __device__ __forceinline__ void put_sym_ll(uint32_t pos, uint32_t sym) const {
+    b(aSymLl + (int)pos) = (uint8_t)sym;
+    if (sym & 256u) w(aSymHi + 4 * (int)(pos >> 5)) |= 1u << (pos & 31u);
+  }
+  __device__ __forceinline__ void clear_sym_hi() const {
+    for (int k = 0; k < 9; ++k) w(aSymHi + 4 * k) = 0u;
+  }
 };
 
 // (BitIn of the decoder above, over this layout, that can also go back to a bit it has passed)
@@ -534,34 +551,32 @@ struct Bits {
   const uint8_t* src;
   size_t clen;
   const uint32_t* wp;
+  const uint8_t* fetch_end;   // no word is fetched from here on (the streams' buffer has 256 bytes of slack behind its last stream)
   unsigned long long buf;
   int n;
-  long long budget;
   uint32_t rd, wr, lead;
-  uint32_t pre[8];
+  uint32_t pre[kFetchW];
   bool on_the_way;
   __device__ __forceinline__ void fetch() {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pre[k] = wp[k];
-    wp += 8;
+    for (int k = 0; k < (int)kFetchW; ++k) pre[k] = wp[k];
+    wp += kFetchW;
     on_the_way = true;
   }
   __device__ __forceinline__ void land(const Lane& L) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) L.r(wr + (uint32_t)k) = pre[k];
-    wr += 8u;
+    for (int k = 0; k < (int)kFetchW; ++k) L.r(wr + (uint32_t)k) = pre[k];
+    wr += kFetchW;
     on_the_way = false;
   }
   __device__ __forceinline__ void open_at(const Lane& L, size_t byte) {
     const uint8_t* p = src + byte;
-    const size_t len = clen > byte ? clen - byte : 0;
     buf = 0; n = 0;
-    budget = (long long)len * 8;
+    fetch_end = src + clen + 128;
     while ((reinterpret_cast<uintptr_t>(p) & 3u) && n < 32) {
       buf |= (unsigned long long)(*p++) << n;
       n += 8;
     }
-    budget -= n;
     lead = (uint32_t)n + 8u * (uint32_t)byte;       // bits in front of the first aligned word, from the stream's first bit
     wp = reinterpret_cast<const uint32_t*>(p);
     rd = wr = 0u;
@@ -576,9 +591,10 @@ struct Bits {
     skip((int)(bit & 7ull));
   }
   __device__ __forceinline__ void top_up(const Lane& L) {
-    if (on_the_way && wr - rd <= kRingW - 8u) land(L);
-    if (!on_the_way && wr - rd <= kRingW - 8u && budget - 32ll * (long long)(wr - rd) > -1024) fetch();
+    if (on_the_way && wr - rd <= kRingW - kFetchW) land(L);
+    if (!on_the_way && wr - rd <= kRingW - kFetchW && reinterpret_cast<const uint8_t*>(wp) < fetch_end) fetch();
   }
+  // at least 32 valid bits behind this; wherever the lanes are NOT at their common step (table headers, stored bytes)
   __device__ __forceinline__ void refill(const Lane& L) {
     if (n <= 32) {
       if (rd == wr) {
@@ -588,18 +604,53 @@ struct Bits {
       buf |= (unsigned long long)L.r(rd) << n;
       ++rd;
       n += 32;
-      budget -= 32;
     }
+  }
+  // ... and in the symbol loop: no branch.  The ring holds the word (the loop looks after that once a step: short())
+  __device__ __forceinline__ void refill_fast(const Lane& L) {
+    const bool need = n <= 32;
+    const unsigned long long w = (unsigned long long)L.r(rd) << (need ? n : 0);
+    buf |= need ? w : 0ull;
+    rd += need ? 1u : 0u;
+    n += need ? 32 : 0;
+  }
+  __device__ __forceinline__ bool short_of_words() const { return wr - rd < 2u; }      // (a step refills twice at most)
+  __device__ __forceinline__ void emergency(const Lane& L) {
+    if (!on_the_way && reinterpret_cast<const uint8_t*>(wp) < fetch_end) fetch();
+    if (on_the_way && wr - rd <= kRingW - kFetchW) land(L);
   }
   __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
   __device__ __forceinline__ void skip(int k) { buf >>= k; n -= k; }
   __device__ __forceinline__ uint32_t take(int k) { const uint32_t v = peek(k); skip(k); return v; }
-  __device__ __forceinline__ bool overrun() const { return budget + n < 0; }
+  __device__ __forceinline__ bool overrun() const { return consumed() > 8ull * (unsigned long long)clen; }
 };
 
+// The limits of an alphabet as the symbol loop compares them: limit - 1 as 16-bit halves, two to a register (lengths 1|2, 3|4
+// ... 15|none), so that one packed subtraction answers two compares and no condition code is involved.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+struct Limits {
+  pk16 p[8];
+  __device__ __forceinline__ void pack(const uint32_t (&lim)[16]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t lo = (lim[2 * j + 1] - 1u) & 0xFFFFu;
+      const uint32_t hi = 2 * j + 2 < 16 ? (lim[2 * j + 2] - 1u) & 0xFFFFu : 0x7FFFu;      // (a limit no value reaches)
+      p[j].x = (short)lo; p[j].y = (short)hi;
+    }
+  }
+  // the length of the code the 15 bits v begin with: 1 + the number of limits v has reached (16: no code)
+  __device__ __forceinline__ uint32_t length(uint32_t v) const {
+    pk16 vv; vv.x = (short)v; vv.y = (short)v;
+    pk16 acc = (p[0] - vv) >> 15;            // -1 where limit - 1 - v < 0, i.e. v >= limit
+#pragma unroll
+    for (int j = 1; j < 8; ++j) acc += (p[j] - vv) >> 15;
+    return (uint32_t)(1 - (int)acc.x - (int)acc.y);
+  }
+};
 // From the counts per length (u16 x 16 at cnt_at): the limits (registers), the bases (LDS), and in the counts' place the
 // sorted position of every length's first symbol.  False: over-subscribed, or incomplete (allowed as the one-code case zlib
 // allows, as an alphabet without any code -- the distances of a literal-only block -- and where the format itself is: fixed).
+template <bool CNT8>
 __device__ __forceinline__ bool limits_from_counts(const Lane& L, int cnt_at, int base_at, uint32_t (&lim)[16], bool fixed) {
   int left = 1;
   uint32_t code = 0, off = 0;
@@ -607,12 +658,12 @@ __device__ __forceinline__ bool limits_from_counts(const Lane& L, int cnt_at, in
   lim[0] = 0;
 #pragma unroll
   for (int l = 1; l < 16; ++l) {
-    const uint32_t c = L.h(cnt_at + 2 * l);
+    const uint32_t c = CNT8 ? (uint32_t)L.b(cnt_at + l) : (uint32_t)L.h(cnt_at + 2 * l);
     left = (left << 1) - (int)c;
     ok = ok && left >= 0;
     lim[l] = (code + c) << (15 - l);
     L.h(base_at + 2 * l) = (uint16_t)(off - code);
-    L.h(cnt_at + 2 * l) = (uint16_t)off;
+    if (CNT8) L.b(cnt_at + l) = (uint8_t)off; else L.h(cnt_at + 2 * l) = (uint16_t)off;
     off += c;
     code = (code + c) << 1;
   }
@@ -621,16 +672,14 @@ __device__ __forceinline__ bool limits_from_counts(const Lane& L, int cnt_at, in
 }
 // One symbol of an alphabet: its code's length, 0 when the next bits are no code.  (sym8: the distance alphabet's bytes)
 template <bool SYM8>
-__device__ __forceinline__ int decode(const Lane& L, const Bits& in, const uint32_t (&lim)[16], int base_at, int sym_at, uint32_t* sym) {
+__device__ __forceinline__ int decode(const Lane& L, const Bits& in, const Limits& lim, int base_at, int sym_at, uint32_t* sym) {
   const uint32_t v = __brev((uint32_t)in.buf) >> 17;
-  uint32_t l = 1;
-#pragma unroll
-  for (int k = 1; k < 16; ++k) l += v >= lim[k] ? 1u : 0u;
+  uint32_t l = lim.length(v);
   const bool bad = l > 15u;
   l = bad ? 15u : l;
   const uint32_t idx = ((v >> (15u - l)) + (uint32_t)L.h(base_at + 2 * (int)l)) & 0xFFFFu;
   // (a position beyond the table can only come from a value that is no code)
-  *sym = SYM8 ? (uint32_t)L.b(sym_at + (int)(idx & 31u)) : (uint32_t)L.h(sym_at + 2 * (int)(idx < 288u ? idx : 0u));
+  *sym = SYM8 ? (uint32_t)L.b(sym_at + (int)(idx & 31u)) : L.sym_ll(idx < 288u ? idx : 0u);
   return bad ? 0 : (int)l;
 }
 
@@ -692,7 +741,7 @@ struct ClCode {
 };
 
 struct Tables {
-  uint32_t ll[16], d[16];       // the limits of the block in work
+  Limits ll, d;                 // of the block in work
 };
 
 // One pass over the code lengths of a dynamic header (hlit + hdist of them, run-length coded): COUNT them per alphabet and
@@ -714,12 +763,12 @@ __device__ __forceinline__ uint32_t lengths_pass(const Lane& L, Bits& in, const 
       for (int k = 0; k < rep; ++k) {
         const int sy = i + k;
         const bool isd = sy >= hlit;
-        const int cnt_at = (isd ? aCntD : aCntLl) + 2 * val;
-        const uint32_t c = L.h(cnt_at);
-        L.h(cnt_at) = (uint16_t)(c + 1u);
+        uint32_t c;
+        if (isd) { c = L.b(aCntD + val); L.b(aCntD + val) = (uint8_t)(c + 1u); }
+        else { c = L.h(aCntLl + 2 * val); L.h(aCntLl + 2 * val) = (uint16_t)(c + 1u); }
         if (PLACE) {
           if (isd) L.b(aSymD + (int)(c & 31u)) = (uint8_t)(sy - hlit);
-          else L.h(aSymLl + 2 * (int)(c < 288u ? c : 0u)) = (uint16_t)sy;
+          else L.put_sym_ll(c < 288u ? c : 0u, (uint32_t)sy);
         } else if (sy == 256) {
           *has_eob = true;
         }
@@ -744,13 +793,17 @@ __device__ __forceinline__ uint32_t dynamic_tables(const Lane& L, Bits& in, Tabl
   ClCode cl;
   if (!cl.build(lens3)) return kBadCodeLengths;
   const unsigned long long mark = in.consumed();
-  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.h(aCntD + 2 * l) = 0; }
+  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.b(aCntD + l) = 0; }
+  L.clear_sym_hi();
   bool has_eob = false;
   uint32_t st = lengths_pass<false>(L, in, cl, hlit, hdist, &has_eob);
   if (st != kOk) return st;
   if (!has_eob) return kBadCodeLengths;                  // no end-of-block code
-  if (!limits_from_counts(L, aCntLl, aBaseLl, T.ll, false)) return kBadCodeLengths;
-  if (!limits_from_counts(L, aCntD, aBaseD, T.d, false)) return kBadCodeLengths;
+  uint32_t lim[16];
+  if (!limits_from_counts<false>(L, aCntLl, aBaseLl, lim, false)) return kBadCodeLengths;
+  T.ll.pack(lim);
+  if (!limits_from_counts<true>(L, aCntD, aBaseD, lim, false)) return kBadCodeLengths;
+  T.d.pack(lim);
   const unsigned long long end = in.consumed();
   in.seek(L, mark);                                      // the same bits again: every symbol to its place
   st = lengths_pass<true>(L, in, cl, hlit, hdist, &has_eob);
@@ -759,16 +812,20 @@ __device__ __forceinline__ uint32_t dynamic_tables(const Lane& L, Bits& in, Tabl
 }
 
 __device__ __forceinline__ uint32_t fixed_tables(const Lane& L, Tables& T) {
-  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.h(aCntD + 2 * l) = 0; }
+  for (int l = 0; l < 16; ++l) { L.h(aCntLl + 2 * l) = 0; L.b(aCntD + l) = 0; }
+  L.clear_sym_hi();
   L.h(aCntLl + 2 * 7) = 24; L.h(aCntLl + 2 * 8) = 152; L.h(aCntLl + 2 * 9) = 112;
-  L.h(aCntD + 2 * 5) = 30;                               // (30 codes of 5 bits: incomplete, as the format defines it)
-  if (!limits_from_counts(L, aCntLl, aBaseLl, T.ll, true)) return kBadCodeLengths;
-  if (!limits_from_counts(L, aCntD, aBaseD, T.d, true)) return kBadCodeLengths;
+  L.b(aCntD + 5) = 30;                               // (30 codes of 5 bits: incomplete, as the format defines it)
+  uint32_t lim[16];
+  if (!limits_from_counts<false>(L, aCntLl, aBaseLl, lim, true)) return kBadCodeLengths;
+  T.ll.pack(lim);
+  if (!limits_from_counts<true>(L, aCntD, aBaseD, lim, true)) return kBadCodeLengths;
+  T.d.pack(lim);
   for (int s = 0; s < 288; ++s) {
     const int l = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
     const uint32_t c = L.h(aCntLl + 2 * l);
     L.h(aCntLl + 2 * l) = (uint16_t)(c + 1u);
-    L.h(aSymLl + 2 * (int)c) = (uint16_t)s;
+    L.put_sym_ll(c, (uint32_t)s);
   }
   for (int s = 0; s < 30; ++s) L.b(aSymD + s) = (uint8_t)s;
   return kOk;
@@ -786,8 +843,12 @@ __global__ __launch_bounds__(kW) void bgzf_decode_kernel(InflateParams p) {
   Bits in;
   TokenOut<Lane> out;
   Tables T;
+  {
+    uint32_t none[16];
 #pragma unroll
-  for (int l = 0; l < 16; ++l) { T.ll[l] = 0; T.d[l] = 0; }
+    for (int l = 0; l < 16; ++l) none[l] = 0;
+    T.ll.pack(none); T.d.pack(none);
+  }
   uint32_t state = kDone, status = kOk, last = 0, stored_left = 0;
   const uint32_t ulen = b.ulen;
   out.open(have ? reinterpret_cast<uint32_t*>(p.matches + b.mbase) : nullptr, b.mcap * 2u);
@@ -795,16 +856,19 @@ __global__ __launch_bounds__(kW) void bgzf_decode_kernel(InflateParams p) {
     if (out.room < 8u) { status = kMatchRoom; }
     else { in.open(L, p.comp + b.cpos, (size_t)b.clen); state = kWantHeader; }
   } else {
-    in.src = nullptr; in.clen = 0; in.wp = nullptr; in.buf = 0; in.n = 0; in.budget = 0; in.rd = in.wr = in.lead = 0; in.on_the_way = false;
+    in.src = nullptr; in.clen = 0; in.wp = nullptr; in.fetch_end = nullptr; in.buf = 0; in.n = 0; in.rd = in.wr = in.lead = 0; in.on_the_way = false;
   }
   auto fail = [&](uint32_t code) { status = code; state = kDone; };
   uint32_t iter = 0;
   while (__ballot(state != kDone) != 0ull) {
-    if ((iter & 7u) == 0u) {
-      if (state != kDone) { out.service(L); in.top_up(L); }
+    if ((iter & (kCommonStep - 1u)) == 0u) {
+      // (the words fetched eight steps ago go into the ring BEFORE this step's stores are issued: the wait in front of them
+      // would otherwise wait for those stores as well)
+      if (state != kDone) { in.top_up(L); out.service(L); }
       if (state == kWantHeader) {                          // all lanes that want one, together
-        // (the tokens' ring lends its place to the counts: what it holds goes out first)
+        // (the tokens' and the literals' rings lend their places to the counts: what they hold goes out first)
         while (out.tr < out.tw) { out.area[2u + out.tr] = L.tok(out.tr); ++out.tr; }
+        while (out.lr < out.lw) { out.area[out.room - 1u - out.lr] = L.lit(out.lr); ++out.lr; }
         in.refill(L);
         last = in.take(1);
         const uint32_t type = in.take(2);
@@ -827,44 +891,42 @@ __global__ __launch_bounds__(kW) void bgzf_decode_kernel(InflateParams p) {
       }
     }
     ++iter;
+    // (a lane whose ring is about to run dry -- a stretch of long matches with many extra bits -- gets its words here, in a
+    // branch the wavefront rarely takes; the refills below then never wait)
+    if (__ballot(state == kSymbols && in.short_of_words()) != 0ull) {
+      if (state == kSymbols && in.short_of_words()) in.emergency(L);
+    }
     if (state == kSymbols) {
-      uint32_t s;
+      uint32_t s, err = 0;
       const int l = decode<false>(L, in, T.ll, aBaseLl, aSymLl, &s);
       in.skip(l);
-      in.refill(L);
+      in.refill_fast(L);
       if (l == 0) {
-        fail(kBadSymbol);
+        err = kBadSymbol;
       } else if (s < 256u) {
-        if (out.o >= ulen) fail(kOutputOverrun); else out.literal(L, s);
+        if (out.o >= ulen) err = kOutputOverrun; else out.literal(L, s);
       } else if (s == 256u) {
         state = last ? kDone : kWantHeader;
       } else {
         const int sl = (int)s - 257;
-        if (sl >= 29) {
-          fail(kBadSymbol);
-        } else {
-          uint32_t len, dist, d;
-          int extra;
-          length_of(sl, &len, &extra);
-          len += in.take(extra);                           // (<= 5 extra bits of >= 32: 27 left for the distance code)
-          const int dl = decode<true>(L, in, T.d, aBaseD, aSymD, &d);
-          in.skip(dl);
-          in.refill(L);
-          if (dl == 0 || d >= 30u) {
-            fail(kBadDistance);
-          } else {
-            distance_of((int)d, &dist, &extra);
-            dist += in.take(extra);
-            if (dist > out.o) fail(kBadDistance);
-            else if (out.o + len > ulen) fail(kOutputOverrun);
-            else out.match(L, len, dist);
-          }
-        }
+        uint32_t len, dist, d;
+        int extra;
+        length_of(sl < 29 ? sl : 0, &len, &extra);
+        len += in.take(extra);                             // (<= 5 extra bits of >= 32: 27 left for the distance code)
+        const int dl = decode<true>(L, in, T.d, aBaseD, aSymD, &d);
+        in.skip(dl);
+        in.refill_fast(L);
+        int dextra;
+        distance_of(d < 30u ? (int)d : 0, &dist, &dextra);
+        dist += in.take(dextra);
+        if (sl >= 29) err = kBadSymbol;
+        else if (dl == 0 || d >= 30u || dist > out.o) err = kBadDistance;
+        else if (out.o + len > ulen) err = kOutputOverrun;
+        else out.match(L, len, dist);
       }
-      if (status == kOk) {
-        if (in.overrun()) fail(kInputOverrun);
-        else if (out.full) fail(kMatchRoom);
-      }
+      if (!err && in.overrun()) err = kInputOverrun;
+      if (!err && out.full) err = kMatchRoom;
+      if (err) fail(err);
     } else if (state == kStored) {
       for (int q = 0; q < 4 && stored_left; ++q) {
         in.refill(L);
@@ -1127,6 +1189,11 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kDecLanes), 0, s, p);
 #else
     const long long g = (p.n_blocks + w64::kW - 1) / w64::kW;
+    if (getenv("MIDAS_SNPS_TRACE")) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, w64::bgzf_decode_kernel, w64::kW, 0) == hipSuccess)
+        fprintf(stderr, "[device decode] decoder: %lld workgroups of %d streams, %d resident a CU\n", g, w64::kW, occ);
+    }
     hipLaunchKernelGGL(w64::bgzf_decode_kernel, dim3((unsigned)g), dim3(w64::kW), 0, s, p);
 #endif
     const hipError_t e = hipGetLastError();
