@@ -1,31 +1,30 @@
-// BGZF blocks inflated on the device: one THREAD per block decodes its Huffman codes into a token stream, one WAVEFRONT per
+// BGZF blocks inflated on the device: one LANE per block decodes its Huffman codes into a token stream, one WAVEFRONT per
 // block then lays the block's bytes out from the tokens.
 //
 // A BAM is a chain of independent <= 64 KiB DEFLATE streams (BGZF, SAM spec 4.1); htslib inflates them one after the other,
 // this library's host decoder on all cores -- and with the pileup at a millisecond and the rows coded on the device, that
 // host inflate is two thirds of the stage.  DEFLATE decoding is a serial dependency chain inside a stream, but
-// a 1.3 GB BAM holds 45 000 streams: each lane of a wavefront takes one and runs an ordinary table-driven inflater on it
-// (RFC 1951: stored, fixed and dynamic blocks).  What makes that workable on a GPU is where the tables live: every lane's
-// 9-bit literal/length and 7-bit distance look-up tables sit in LDS, interleaved [entry][lane], so the one dependent memory
-// access per symbol is an LDS read, not a trip to HBM.  Codes longer than the look-up width (rare symbols) fall back to the
-// canonical walk over the per-length counts (the classic `puff` decoder), also from LDS.
+// a 1.3 GB BAM holds 45 000 streams: each lane of a wavefront takes one (RFC 1951: stored, fixed and dynamic blocks).
 //
-// Two kernels, and what passes between them (round 5; a block of a BAM is ~13 000 literals and ~8 000 matches of 6.5 bytes):
-//   decode   Huffman decoding never looks at the output, so the decoder writes NO output byte.  A lane turns its stream into
-//            (a) TOKENS, one dword per match: literals in front of it (9 bits) | length - 3 (8) | distance - 1 (15) -- a run of
-//            511 literals or more, and the literals behind the last match, as an escape token that only carries a count --
-//            and (b) the stream's LITERALS, back to back.  Both are gathered in small per-lane rings in LDS and leave for HBM
-//            in 16-byte stores at the one point of the symbol loop that all lanes of a wavefront pass together every eighth
-//            step, where the input ring is topped up as well: no memory instruction sits in a divergent branch of the loop.
-//            (Round 4's decoder stored every literal where it belongs -- with a match every 2.6 symbols that is a byte store
-//            per literal in a branch, and every top-up of the input ring waited for all of them: 2 700 cycles per symbol.)
-//            The tokens grow from the front of the block's room in `matches`, the literals (bytes in reverse order) from its
-//            end: one room, no second buffer.
+// Two kernels, and what passes between them (a block of a BAM is ~13 000 literals and ~8 000 matches of 6.5 bytes):
+//   decode   (namespace w64 below) Huffman decoding never looks at the output, so the decoder writes NO output byte.  A lane
+//            turns its stream into (a) TOKENS, one dword per match: literals in front of it (9 bits) | length - 3 (8) |
+//            distance - 1 (15) -- a run of 511 literals or more, and the literals behind the last match, as an escape token
+//            that only carries a count -- and (b) the stream's LITERALS, back to back.  Both are gathered in small per-lane
+//            rings in LDS and leave for HBM in 16-byte stores at the one point of the symbol loop that all lanes of a
+//            wavefront pass together every fourth step, where the input ring is topped up as well: no memory instruction sits
+//            in a divergent branch of the loop.  The tokens grow from the front of the block's room in `matches`, the
+//            literals (bytes in reverse order) from its end: one room, no second buffer.
 //   place    one wavefront per block, 64 tokens at a time: two prefix sums give every token its place in the output and in
 //            the literal stream; the literals of the NEXT 64 tokens are copied while this window's matches are resolved --
 //            a match only reads what lies in front of it, so every unfinished match whose source ends in front of the first
 //            unfinished token's bytes is copied at the same moment, one lane per match, 8 bytes per load (most matches of a
 //            BAM are a few bytes long); one workgroup-scope fence per such step.  Tokens are fetched a window ahead.
+// History of the decoder (git log): round 3 -- one lane per stream with 9-bit / 7-bit look-up tables in LDS
+// (2.5 KiB a stream: 64 streams a CU), literals stored where they belong, matches noted for a resolver that copied them with
+// byte loads and a fence per run: 68-77 ms + 20 ms on configs[2]'s 46 500 blocks.  Round 5 -- tokens instead of output bytes
+// (no faster by itself: a step of the look-up decoder is three hundred dependent instructions of one wavefront, 3 000
+// cycles, whatever the stores do), then the decoder below: 26 ms + 10 ms.
 // Replaces the inflate inside `pysam.AlignmentFile(...)` of midas/run/snps.py:186 (htslib's bgzf.c); bounds-checked against
 // both buffers at every step: corrupt input yields a status, never a fault.
 #include <hip/hip_runtime.h>
@@ -40,39 +39,6 @@ namespace midas {
 namespace {
 
 constexpr int kLanes = 64;
-// Streams per workgroup of the decoder.  A stream's tables and rings take 2.3 KiB of LDS, so a CU holds 64 streams whatever
-// the shape; what the shape decides is how many WAVEFRONTS those 64 streams are.  The lanes of a wavefront diverge at every
-// step (literal / match / long code: a step costs the sum of the paths any lane takes), and a wavefront instruction costs the
-// SIMD four cycles however few lanes are in it.
-#ifndef MIDAS_INFLATE_LANES
-#define MIDAS_INFLATE_LANES 8
-#endif
-constexpr int kDecLanes = MIDAS_INFLATE_LANES;
-static_assert(kDecLanes >= 2 && kDecLanes <= 64 && (kDecLanes & (kDecLanes - 1)) == 0, "a power of two up to a wavefront");
-constexpr int kLlBits = 9, kDBits = 7;
-// u16 arrays, per lane, interleaved [index][lane]
-constexpr int kLutLl = 0;                       // 512: (symbol << 4) | length, 0 = not in the table
-constexpr int kLutD = kLutLl + (1 << kLlBits);  // 128 (also the code-length code's table while a dynamic header is read)
-constexpr int kSymLl = kLutD + (1 << kDBits);   // 288: symbols sorted by (length, symbol)
-constexpr int kSymD = kSymLl + 288;             // 32
-constexpr int kCntLl = kSymD + 32;              // 16: codes per length
-constexpr int kCntD = kCntLl + 16;              // 16
-// per length: the END of the length's symbols in the sorted list and the END of its codes -- what the long-code path needs
-constexpr int kOffsLl = kCntD + 16;             // 16
-constexpr int kNextLl = kOffsLl + 16;           // 16
-constexpr int kOffsD = kNextLl + 16;            // 16
-constexpr int kNextD = kOffsD + 16;             // 16
-constexpr int kU16 = kNextD + 16;               // 1056
-// u32 arrays, per lane, interleaved
-constexpr int kRing = 16;                       // the next 64 bytes of the lane's stream
-constexpr int kLitRing = 8;                     // gathered literals (four to a dword) on their way out
-constexpr int kTokRing = 32;                    // tokens on their way out
-constexpr int kU32 = kRing + kLitRing + kTokRing;
-// While a table header is read the code lengths (u8, up to 320 of them) lie where the literal/length look-up table is built
-// afterwards: a table is built in two steps -- counts and the sorted symbols from the lengths, then the look-up table from
-// the sorted symbols -- and the second step no longer reads a length.  The distance alphabet's lengths wait in the distance
-// look-up table's place meanwhile.
-constexpr int kLensAtD = 2 * kLutD;             // byte index of the distance lengths' parking place (the u16 array kLutD)
 
 enum : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadCodeLengths = 3, kBadSymbol = 4, kBadDistance = 5,
                   kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8, kMatchRoom = kInflateMatchRoom };
@@ -84,165 +50,10 @@ constexpr uint32_t kEscape = 0xFF800000u;       // token: 511 in the literal fie
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct Lds {
-  static constexpr uint32_t kLitW = kLitRing, kTokW = kTokRing;
-  lds_u16* s16;
-  lds_u8* s8;          // the same memory as s16, as bytes (the code lengths' place)
-  lds_u32* s32;
-  int lane;
-  __device__ __forceinline__ lds_u32& r(uint32_t i) const { return s32[(i & (kRing - 1)) * kDecLanes + lane]; }
-  __device__ __forceinline__ lds_u32& lit(uint32_t i) const { return s32[(kRing + (i & (kLitRing - 1))) * kDecLanes + lane]; }
-  __device__ __forceinline__ lds_u32& tok(uint32_t i) const { return s32[(kRing + kLitRing + (i & (kTokRing - 1))) * kDecLanes + lane]; }
-  __device__ __forceinline__ lds_u16& h(int i) const { return s16[i * kDecLanes + lane]; }
-  // byte i of the lane's own u16 slots (slot i / 2): a lane's bytes never touch another lane's entries -- the lanes of a wavefront
-  // read their table headers at different times
-  __device__ __forceinline__ lds_u8& b(int i) const { return s8[(((i >> 1) * kDecLanes + lane) << 1) + (i & 1)]; }
-};
-
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 typedef uint16_t u16_a1 __attribute__((aligned(1)));
 typedef unsigned long long u64_a1 __attribute__((aligned(1)));
-
-// The compressed stream, least significant bit first (RFC 1951 3.1.1).  Between memory and the bit buffer sits a ring of 16
-// words per lane in LDS, topped up 32 bytes at a time by loads that are issued EIGHT steps of the symbol loop before their
-// words are needed.  (A lane that loaded its next word only when it ran dry would not stall just itself: a wavefront waits
-// for its outstanding loads as one, some lane of 64 runs dry on nearly every step, and every step would cost a trip to
-// memory -- 2.3 us per symbol, measured.)
-struct BitIn {
-  const uint32_t* w;       // next aligned words to fetch
-  unsigned long long buf;
-  int n;                   // valid bits in buf
-  long long budget;        // bits of the stream not yet moved into buf (negative: the stream has been overrun)
-  uint32_t rd, wr;         // ring positions (words, counted up for ever)
-  uint32_t pre[8];         // the words on their way
-  bool on_the_way;
-  __device__ __forceinline__ void fetch() {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pre[k] = w[k];
-    w += 8;
-    on_the_way = true;
-  }
-  __device__ __forceinline__ void land(const Lds& L) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) L.r(wr + (uint32_t)k) = pre[k];
-    wr += 8u;
-    on_the_way = false;
-  }
-  __device__ __forceinline__ void open(const Lds& L, const uint8_t* p, size_t len) {
-    buf = 0; n = 0;
-    budget = (long long)len * 8;
-    while ((reinterpret_cast<uintptr_t>(p) & 3u) && n < 32) {      // bytes up to the first aligned word
-      buf |= (unsigned long long)(*p++) << n;
-      n += 8;
-    }
-    budget -= n;
-    w = reinterpret_cast<const uint32_t*>(p);
-    rd = wr = 0u;
-    fetch();
-  }
-  // every eighth step of the symbol loop, all lanes of the step together: what was fetched last time goes into the ring,
-  // the next 32 bytes are asked for (if the ring has room for them behind those)
-  __device__ __forceinline__ void top_up(const Lds& L) {
-    if (on_the_way && wr - rd <= (uint32_t)kRing - 8u) land(L);
-    if (!on_the_way && wr - rd <= (uint32_t)kRing - 8u && budget - 32ll * (long long)(wr - rd) > -1024) fetch();
-  }
-  // at least 32 valid bits behind this (the stream buffer has 256 bytes of slack behind the last stream)
-  __device__ __forceinline__ void refill(const Lds& L) {
-    if (n <= 32) {
-      if (rd == wr) {                 // the ring ran dry (a table header, a stretch of long matches): wait for the words
-        if (!on_the_way) fetch();
-        land(L);
-      }
-      buf |= (unsigned long long)L.r(rd) << n;
-      ++rd;
-      n += 32;
-      budget -= 32;
-    }
-  }
-  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
-  __device__ __forceinline__ void skip(int k) { buf >>= k; n -= k; }
-  __device__ __forceinline__ uint32_t take(int k) { const uint32_t v = peek(k); skip(k); return v; }
-  // bits consumed beyond the stream's end?
-  __device__ __forceinline__ bool overrun() const { return budget + n < 0; }
-};
-
-// Canonical Huffman tables of one alphabet, step one: from the code lengths in L.b(at .. at + n) the counts per length and
-// the symbols sorted by (length, symbol); afterwards offs[l] / next[l] are the END of length l's symbols in the sorted list
-// and the END of its codes.  False: over-subscribed or incomplete (an incomplete code is allowed only as the single-code
-// case, as zlib allows it).  `*none`: the alphabet has no code at all (legal for the distances of a literal-only block).
-__device__ bool sort_symbols(const Lds& L, int at, int n, int cnt_at, int sym_at, int kOffs, int kNext, bool* none) {
-  for (int l = 0; l < 16; ++l) { L.h(cnt_at + l) = 0; L.h(kOffs + l) = 0; L.h(kNext + l) = 0; }
-  for (int s = 0; s < n; ++s) L.h(cnt_at + L.b(at + s)) += 1;
-  *none = L.h(cnt_at) == n;
-  if (*none) return true;
-  int left = 1;
-  for (int l = 1; l < 16; ++l) {
-    left <<= 1;
-    left -= (int)L.h(cnt_at + l);
-    if (left < 0) return false;                   // over-subscribed
-  }
-  if (left > 0 && !(n - (int)L.h(cnt_at) == 1 && L.h(cnt_at + 1) == 1)) return false;     // incomplete
-  // per length: where its next symbol goes in the sorted list, and its first code (RFC 1951 3.2.2) -- in LDS, indexed by the
-  // symbol's length (a lane's own index: registers cannot be indexed per lane)
-  {
-    uint32_t off = 0, code = 0;
-    for (int l = 1; l < 16; ++l) {
-      const uint32_t c = L.h(cnt_at + l);
-      code = (code + (l > 1 ? (uint32_t)L.h(cnt_at + l - 1) : 0u)) << 1;
-      L.h(kOffs + l) = (uint16_t)off;
-      L.h(kNext + l) = (uint16_t)(code + c);      // the END of the length's codes
-      off += c;
-    }
-  }
-  for (int s = 0; s < n; ++s) {
-    const int l = L.b(at + s);
-    if (!l) continue;
-    const uint32_t o = L.h(kOffs + l);
-    L.h(kOffs + l) = (uint16_t)(o + 1u);
-    L.h(sym_at + (int)o) = (uint16_t)s;
-  }
-  return true;
-}
-// ... step two: the look-up table over the first `bits` bits, from the sorted symbols and the counts alone
-__device__ void fill_lut(const Lds& L, int cnt_at, int sym_at, int lut_at, int bits, bool none) {
-  for (int i = 0; i < (1 << bits); ++i) L.h(lut_at + i) = 0;
-  if (none) return;
-  uint32_t code = 0;
-  int idx = 0;
-  for (int l = 1; l <= bits; ++l) {
-    const int c = (int)L.h(cnt_at + l);
-    for (int k = 0; k < c; ++k) {
-      const uint32_t s = L.h(sym_at + idx);
-      ++idx;
-      const uint32_t r = __brev(code) >> (32 - l);
-      for (uint32_t j = r; j < (1u << bits); j += 1u << l) L.h(lut_at + (int)j) = (uint16_t)((s << 4) | (uint32_t)l);
-      ++code;
-    }
-    code <<= 1;
-  }
-}
-
-// One symbol: the look-up table; a code longer than the table's width (a rare symbol -- but with several streams in a
-// wavefront some lane meets one on many steps, so this path has to be short too) is found by its length: canonical codes of
-// length l are the numbers below end[l] that no shorter code is a prefix of, and their symbols end at sorted position
-// offs_end[l].  Returns -1 on a code no symbol has.
-__device__ __forceinline__ int decode(const Lds& L, BitIn& in, int cnt_at, int sym_at, int lut_at, int bits, int offs_at, int next_at) {
-  const uint32_t e = L.h(lut_at + (int)in.peek(bits));
-  if (e) { in.skip((int)(e & 15u)); return (int)(e >> 4); }
-  const uint32_t v15 = __brev((uint32_t)in.buf) >> 17;          // the next 15 bits as a code reads them, first bit on top
-  for (int l = bits + 1; l < 16; ++l) {
-    const uint32_t code = v15 >> (15 - l);
-    const uint32_t end = L.h(next_at + l);
-    if (code < end) {
-      const uint32_t count = L.h(cnt_at + l);
-      if (code + count < end) return -1;                         // (below the length's first code: an incomplete code's gap)
-      in.skip(l);
-      return (int)L.h(sym_at + (int)(L.h(offs_at + l) - (end - code)));
-    }
-  }
-  return -1;
-}
 
 // RFC 1951 3.2.5 in closed form (a table in constant memory would be a trip to memory, waited for, on every match -- and
 // with several streams in a wavefront some lane has a match on almost every step):
@@ -259,66 +70,6 @@ __device__ __forceinline__ void distance_of(int d, uint32_t* base, int* extra) {
   *base = d < 4 ? 1u + (uint32_t)d : 1u + ((2u + (uint32_t)(d & 1)) << e);
 }
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-// The literal / length and distance tables of a dynamic block (RFC 1951 3.2.7) into LDS.
-__device__ uint32_t read_dynamic_header(const Lds& L, BitIn& in) {
-  in.refill(L);
-  const int hlit = (int)in.take(5) + 257, hdist = (int)in.take(5) + 1, hclen = (int)in.take(4) + 4;
-  if (hlit > 286 || hdist > 30) return kBadCodeLengths;
-  for (int i = 0; i < 19; ++i) L.b(i) = 0;
-  for (int i = 0; i < hclen; ++i) {
-    in.refill(L);
-    L.b(c_cl_order[i]) = (uint8_t)in.take(3);
-  }
-  // the code-length code borrows the distance alphabet's arrays (they are built last)
-  bool none;
-  if (!sort_symbols(L, 0, 19, kCntD, kSymD, kOffsD, kNextD, &none)) return kBadCodeLengths;
-  fill_lut(L, kCntD, kSymD, kLutD, kDBits, none);
-  // (the code-length code's own lengths at 0..18 are dead from here: decode() reads counts and symbols, not lengths)
-  int i = 0, prev = 0;
-  const int total = hlit + hdist;
-  while (i < total) {
-    in.refill(L);
-    const int s = decode(L, in, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD);
-    if (s < 0) return kBadCodeLengths;
-    int rep = 1, val = s;
-    if (s == 16) { if (i == 0) return kBadCodeLengths; val = prev; rep = 3 + (int)in.take(2); }
-    else if (s == 17) { val = 0; rep = 3 + (int)in.take(3); }
-    else if (s == 18) { val = 0; rep = 11 + (int)in.take(7); }
-    if (i + rep > total) return kBadCodeLengths;
-    for (int k = 0; k < rep; ++k) L.b(i + k) = (uint8_t)val;       // both alphabets' lengths land in one run
-    i += rep;
-    prev = val;
-    if (in.overrun()) return kInputOverrun;
-  }
-  if (L.b(256) == 0) return kBadCodeLengths;                  // no end-of-block code
-  // The distance lengths are parked where the distance look-up table will be (the code-length code's table is dead), the
-  // literal / length alphabet is sorted, THEN its look-up table overwrites the lengths' place.
-  for (int k = 0; k < hdist; ++k) L.b(kLensAtD + k) = L.b(hlit + k);
-  if (!sort_symbols(L, 0, hlit, kCntLl, kSymLl, kOffsLl, kNextLl, &none)) return kBadCodeLengths;
-  fill_lut(L, kCntLl, kSymLl, kLutLl, kLlBits, none);
-  if (!sort_symbols(L, kLensAtD, hdist, kCntD, kSymD, kOffsD, kNextD, &none)) return kBadCodeLengths;
-  fill_lut(L, kCntD, kSymD, kLutD, kDBits, none);
-  return kOk;
-}
-
-__device__ uint32_t fixed_tables(const Lds& L) {
-  bool none;
-  for (int s = 0; s < 288; ++s) L.b(s) = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-  if (!sort_symbols(L, 0, 288, kCntLl, kSymLl, kOffsLl, kNextLl, &none)) return kBadCodeLengths;
-  fill_lut(L, kCntLl, kSymLl, kLutLl, kLlBits, none);
-  // (30 codes of 5 bits leave the code incomplete, as the format defines it: build by hand what sort_symbols would refuse)
-  for (int l = 0; l < 16; ++l) L.h(kCntD + l) = 0;
-  L.h(kCntD + 5) = 30;
-  for (int l = 0; l < 16; ++l) { L.h(kOffsD + l) = (uint16_t)(l >= 5 ? 30 : 0); L.h(kNextD + l) = 0; }     // (every code is in the table)
-  for (int i = 0; i < (1 << kDBits); ++i) L.h(kLutD + i) = 0;
-  for (int s = 0; s < 30; ++s) {
-    L.h(kSymD + s) = (uint16_t)s;
-    const uint32_t r = __brev((uint32_t)s) >> 27;
-    for (uint32_t k = r; k < (1u << kDBits); k += 32u) L.h(kLutD + (int)k) = (uint16_t)((s << 4) | 5);
-  }
-  return kOk;
-}
 
 // What a stream's decoder leaves behind: tokens and literals, in the stream's ROOM of `room` dwords (kernels.h InflateBlock:
 // mbase, mcap).  Dwords 0 and 1 stay free (the placer's 8-byte loads of literals may reach that far down), token i is dword
@@ -393,117 +144,28 @@ struct TokenOut {
   }
 };
 
-__device__ uint32_t inflate_one(const Lds& L, const uint8_t* src, size_t clen, uint32_t ulen, uint32_t* area, uint32_t room,
-                                uint32_t* n_tokens) {
-  uint32_t tick = 0;
-  BitIn in;
-  in.open(L, src, clen);
-  TokenOut<Lds> out;
-  out.open(area, room);
-  if (room < 8u) return kMatchRoom;
-  for (;;) {
-    in.refill(L);
-    const uint32_t last = in.take(1), type = in.take(2);
-    if (type == 0u) {                                        // stored: to the next byte, LEN, ~LEN, the bytes
-      in.skip(in.n & 7);
-      in.refill(L);
-      const uint32_t len = in.take(16);
-      in.refill(L);
-      const uint32_t nlen = in.take(16);
-      if ((len ^ 0xFFFFu) != nlen) return kBadStored;
-      if (out.o + len > ulen) return kOutputOverrun;
-      for (uint32_t k = 0; k < len; ++k) {
-        in.refill(L);
-        out.literal(L, in.take(8));
-        if ((k & 15u) == 15u) { out.service(L); in.top_up(L); }
-        if (in.overrun()) return kInputOverrun;
-        if (out.full) return kMatchRoom;
-      }
-    } else if (type == 3u) {
-      return kBadBlockType;
-    } else {
-      const uint32_t st = type == 1u ? fixed_tables(L) : read_dynamic_header(L, in);
-      if (st != kOk) return st;
-      in.refill(L);
-      for (;;) {
-        // (one count for all the lanes that take this step together: they top their rings up and send what they gathered
-        // at the same steps)
-        tick = (uint32_t)__builtin_amdgcn_readfirstlane((int)tick) + 1u;
-        if ((tick & 7u) == 0u) { out.service(L); in.top_up(L); }
-        // at least 15 valid bits here (32 after a literal, 19 after a match): the symbol is decoded first and the buffer filled
-        // up behind it -- one round trip to the ring fewer on the way to the next table look-up
-        int s = decode(L, in, kCntLl, kSymLl, kLutLl, kLlBits, kOffsLl, kNextLl);
-        in.refill(L);
-        if (s < 0) return kBadSymbol;
-        if (s < 256) {
-          if (out.o >= ulen) return kOutputOverrun;
-          out.literal(L, (uint32_t)s);
-          if (in.overrun()) return kInputOverrun;
-          if (out.full) return kMatchRoom;
-          continue;
-        }
-        if (s == 256) break;
-        s -= 257;
-        if (s >= 29) return kBadSymbol;
-        uint32_t len;
-        int extra;
-        length_of(s, &len, &extra);
-        len += in.take(extra);                                               // (<= 5 extra bits of >= 32: 27 left for the distance code)
-        const int d = decode(L, in, kCntD, kSymD, kLutD, kDBits, kOffsD, kNextD);
-        if (d < 0 || d >= 30) return kBadDistance;
-        in.refill(L);
-        uint32_t dist;
-        distance_of(d, &dist, &extra);
-        dist += in.take(extra);
-        if (dist > out.o) return kBadDistance;
-        if (out.o + len > ulen) return kOutputOverrun;
-        out.match(L, len, dist);
-        if (in.overrun()) return kInputOverrun;
-        if (out.full) return kMatchRoom;
-      }
-      if (in.overrun()) return kInputOverrun;
-    }
-    if (last) break;
-  }
-  out.finish(L);
-  if (out.full) return kMatchRoom;
-  *n_tokens = out.tw;
-  return out.o == ulen ? kOk : kShortOutput;
-}
-
-__global__ __launch_bounds__(kDecLanes) void bgzf_inflate_kernel(InflateParams p) {
-  __shared__ uint16_t s16[kU16 * kDecLanes];
-  __shared__ uint32_t s32[kU32 * kDecLanes];
-  const long long k = (long long)blockIdx.x * kDecLanes + threadIdx.x;
-  if (k >= p.n_blocks) return;
-  Lds L{(lds_u16*)s16, (lds_u8*)s16, (lds_u32*)s32, (int)threadIdx.x};
-  const InflateBlock b = p.blocks[k];
-  uint32_t st = kOk, nt = 0;
-  if (b.ulen) st = inflate_one(L, p.comp + b.cpos, (size_t)b.clen, b.ulen, reinterpret_cast<uint32_t*>(p.matches + b.mbase), b.mcap * 2u, &nt);
-  p.status[k] = st;
-  p.n_matches[k] = st == kOk ? nt : 0u;
-}
-
-// ---- the decoder, wavefront-wide (the shipped one) --------------------------------------------------------------------------
-// The look-up-table decoder above keeps 2.3 KiB of tables per stream in LDS: 64 streams a CU, eight lanes to a wavefront, and a
-// step of its symbol loop -- three hundred instructions of one wavefront, most of them depending on the one before -- takes
-// ~3 000 cycles (measured: 75 ms for configs[2]'s 46 500 blocks, whatever the stores do).  What a CU lacks there is streams in
-// flight.  This decoder needs 512 bytes a stream, so a CU holds five full wavefronts of 64 streams:
+// ---- the decoder ----------------------------------------------------------------------------------------------------------
+// What a CU must hold is STREAMS: a step of the symbol loop is a few hundred instructions of one wavefront, most of them
+// depending on the one before, and only other wavefronts can fill the gaps.  This decoder needs 512 bytes of LDS a stream, so
+// a CU holds five full wavefronts of 64 streams (a look-up-table decoder: 2.3 KiB, 64 streams):
 //   * no look-up table.  A canonical Huffman code is decoded by COMPARISON: with the next 15 bits read as a code reads them
 //     (first bit on top), the codes of length l are exactly the values in [limit[l-1], limit[l]) -- limit[l] = (first code of
 //     length l + their number) << (15 - l), increasing in l -- so the length is one more than the number of limits the value
-//     has reached: fifteen compares against REGISTERS (a lane's two alphabets are 30 VGPRs; the loop is unrolled, no register is
-//     indexed), no branch, no rare long-code path for the lanes of a wavefront to diverge into.  The symbol then is
-//     sorted_symbols[(value >> (15 - l)) + base[l]]: two dependent LDS reads (16 + 288 entries; the symbols' ninth bit in a bitmap).
+//     has reached: fifteen compares against REGISTERS (limit - 1 as 16-bit halves, two to a register, one packed subtraction
+//     per pair and no condition code: a lane's two alphabets are 16 VGPRs), no branch, no rare long-code path for the lanes of
+//     a wavefront to diverge into.  The symbol then is sorted_symbols[(value >> (15 - l)) + base[l]]: two dependent LDS reads
+//     (16 + 288 entries; the symbols' ninth bit in a bitmap).
 //   * the lanes' LDS is interleaved by dword ([word][lane]): any access pattern is conflict-free.
 //   * a table header is read in TWO PASSES over its bits instead of through a buffer of code lengths (320 bytes a lane that
 //     LDS does not have): pass one counts the codes per length, the limits and bases follow from the counts, pass two reads
 //     the same bits again and puts every symbol at its place in the sorted list.  The code-length code itself (19 symbols of at
 //     most 7 bits) lives entirely in registers (symbols 5 bits each in two words, bases a byte each in one).
 //   * one loop for all lanes with a state per lane (header wanted / symbols / stored bytes / done): headers are read at the
-//     lanes' common eighth step, by all lanes that want one together -- zlib ends a block after 16 383 symbols, so the streams
-//     of a BAM reach their second header at the same step and no lane waits for another's header.
-// Output as above: tokens and literals through small LDS rings, 16-byte stores at the common step.
+//     lanes' common step, by all lanes that want one together -- zlib ends a block after 16 383 symbols, so the streams of a
+//     BAM reach their second header at the same step and no lane waits for another's header.
+// Measured (profiles/r05_inflate_w64.txt): configs[2]'s 46 500 blocks in 26 ms -- 727 wavefronts, all resident at once (2.8 a
+// CU), each taking ~3 000 cycles a step for its 270 vector + 120 scalar instructions: the kernel's time is one wavefront's
+// latency, and what the 512 bytes buy shows on BAMs of more blocks than a chip holds wavefronts.
 namespace w64 {
 
 constexpr int kW = 64;
@@ -1060,13 +722,33 @@ __global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_place_kernel(Infl
     unsigned long long todo = __ballot(cur.len > 0u);
     const uint32_t o = cur.start + cur.lits;
     const uint32_t span = cur.len < cur.dist ? cur.len : cur.dist;
+    // Which of this window's tokens a match waits for: those whose bytes its source [a, bnd) touches.  The tokens' bytes lie
+    // back to back in token order, so that is a run of lanes, found by two binary searches over the lanes' `start` (shuffles);
+    // a source that ends in front of the window waits for nothing.  A match is copied as soon as none of the tokens it waits
+    // for still has its own match to copy (their literals are in place already): the steps of a window are the longest chain
+    // of matches that feed one another, not the number of runs that happen to sit in file order.
+    unsigned long long dep = 0;
+    {
+      const uint32_t a = o - cur.dist, bnd = a + span;
+      const uint32_t wstart = (uint32_t)__shfl((int)cur.start, 0);
+      uint32_t jlo = 0, jhi = 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t c1 = jlo + (uint32_t)d, c2 = jhi + (uint32_t)d;
+        const uint32_t s1 = (uint32_t)__shfl((int)cur.start, (int)(c1 & 63u)), s2 = (uint32_t)__shfl((int)cur.start, (int)(c2 & 63u));
+        if (c1 < 64u && s1 <= a) jlo = c1;
+        if (c2 < 64u && s2 <= bnd - 1u) jhi = c2;
+      }
+      if (cur.len > 0u && bnd > wstart) {
+        const uint32_t lo = a >= wstart ? jlo : 0u;
+        dep = (jhi >= 63u ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << lo) - 1ull) & ~(1ull << lane);
+      }
+    }
     while (todo) {
       // (this wavefront's stores in front of its loads.  The same wavefront, the same CU's cache: a workgroup-scope fence.  An
       // agent-scope __threadfence() writes the XCD's whole L2 back -- 150 us a time here.)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int f = (int)__ffsll((long long)todo) - 1;
-      const uint32_t front = (uint32_t)__shfl((int)cur.start, f);              // everything below is final
-      const bool mine = ((todo >> lane) & 1ull) != 0ull && (lane == f || o - cur.dist + span <= front);
+      const bool mine = ((todo >> lane) & 1ull) != 0ull && (todo & dep) == 0ull;
       if (mine) {
         uint8_t* dst = out + o;
         const uint8_t* s = dst - cur.dist;
@@ -1174,20 +856,12 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
     static const bool fits = [] {
       hipFuncAttributes fa{};
       int dev = 0, lds = 0;
-#ifdef MIDAS_INFLATE_LUT
-      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(bgzf_inflate_kernel)) != hipSuccess) return true;
-#else
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(w64::bgzf_decode_kernel)) != hipSuccess) return true;
-#endif
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return true;
       return fa.sharedSizeBytes <= (size_t)lds;
     }();
     if (!fits) return hipErrorLaunchOutOfResources;
-#ifdef MIDAS_INFLATE_LUT      // (developer variant: the look-up-table decoder, eight streams a wavefront)
-    const long long g = (p.n_blocks + kDecLanes - 1) / kDecLanes;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)g), dim3(kDecLanes), 0, s, p);
-#else
     const long long g = (p.n_blocks + w64::kW - 1) / w64::kW;
     if (getenv("MIDAS_SNPS_TRACE")) {
       int occ = 0;
@@ -1195,7 +869,6 @@ hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases
         fprintf(stderr, "[device decode] decoder: %lld workgroups of %d streams, %d resident a CU\n", g, w64::kW, occ);
     }
     hipLaunchKernelGGL(w64::bgzf_decode_kernel, dim3((unsigned)g), dim3(w64::kW), 0, s, p);
-#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

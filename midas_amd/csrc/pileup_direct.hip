@@ -419,9 +419,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     auto iteration = [&](int it, int k_it, Rd& rd_cur, Dat& dat_cur, Rd& rd_n, Dat& dat_n) {
       const unsigned long long pt0 = PROBE_NOW();
       MIDAS_MARK("settle");
-#ifdef MIDAS_DIRECT_PRIO_LOADS
-      __builtin_amdgcn_s_setprio(3);    // (developer variant: the requests for the next iterations ahead of the other waves' tallies)
-#endif
       settle(rawX, nrX, rd_n, dat_n);          // (the columns of the next iteration have arrived: its bases are requested ...)
       {                                        // ... then the columns of the one after it
         const int kf = k_it + 2;               // the wave's iteration (of this tile, or counted on into the next) to fetch for
@@ -432,9 +429,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         rawX = fetch(fs, fi);
         nrX = reads_in(fs, fi);
       }
-#ifdef MIDAS_DIRECT_PRIO_LOADS
-      __builtin_amdgcn_s_setprio(0);
-#endif
 #if MIDAS_SNPS_DEBUG_BITS & 256
       asm volatile("" :: "v"(rd_n.pos), "v"(rd_n.l_nc));
       const unsigned long long pt1 = PROBE_NOW();
@@ -681,9 +675,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       lds_barrier();       // every tally of this tile is in LDS
     }
     const unsigned long long ps1 = PROBE_NOW();
-#ifdef MIDAS_DIRECT_PRIO_OUT
-    __builtin_amdgcn_s_setprio(3);      // (developer variant: the write-out ahead of the other workgroups' tallies)
-#endif
     uint32_t ticket = 0;
     if (dynamic && take && tid == 0) ticket = atomicAdd(&sched[32 * sched_group], 1u);
 
@@ -729,9 +720,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       }
     }
     if (dynamic && take && tid == 0) s_next_ticket = ticket;
-#ifdef MIDAS_DIRECT_PRIO_OUT
-    __builtin_amdgcn_s_setprio(0);
-#endif
     lds_barrier();       // tallies re-zeroed, this tile's s_stats additions done
 #if MIDAS_SNPS_DEBUG_BITS & 256
     pr_sync += ps1 - ps0;
