@@ -373,8 +373,8 @@ int32_t midas_bam_open_share(const char* path, int32_t slice, int32_t n_slices, 
  * midas/run/snps.py:97-128).                                                                                         */
 int32_t midas_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int64_t* ref_lens,
                         const midas_snps_reads* reads, const int32_t* refid, int32_t level, int32_t threads, char* err256);
-/* The same decoders with the BGZF blocks inflated ON THE DEVICE of `ctx` (bgzf_inflate.hip: one thread per block, its Huffman
- * tables in LDS) instead of by the host's threads: the compressed bytes go up, the inflated stream comes back, records are
+/* The same decoders with the BGZF blocks inflated ON THE DEVICE of `ctx` (bgzf_inflate.hip: one lane per block decodes its
+ * Huffman codes -- by comparison against per-length limits in registers -- into tokens, a wavefront per block lays the bytes out) instead of by the host's threads: the compressed bytes go up, the inflated stream comes back, records are
  * walked and decoded into columns by the host as before.  On a 16-CPU host inflating is two thirds of the pileup stage once
  * the pileup and the row coder are on the device; with eight ranks sharing a node's CPUs it is more.  Same results, same
  * statuses (a corrupt block: MIDAS_SNPS_ERR_BAD_LAYOUT).  At this boundary a device failure is a status (ERR_OUT_OF_MEMORY,

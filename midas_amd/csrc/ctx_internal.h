@@ -2,9 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <vector>
 
 // The context's device arena: ONE allocation that the BAM decodes of a context take turns in (a hipMalloc / hipFree pair
 // costs ~17 ms a gigabyte here, and a decode wants a few times the BAM's inflated size).  A decode borrows it (take), a BAM
@@ -44,6 +46,30 @@ struct midas_arena_pool {
     } else if (q) {
       (void)hipFree(q);
     }
+  }
+  // Columns a device decode has copied down and that still lie in a lent arena as well (midas_bam_load_device: the small
+  // columns of a BAM whose payload stays on the device): a batch made from those very host arrays -- read-only views of the
+  // decoder's buffers -- copies them device to device instead of sending them up the link again.
+  struct Twin { const uint8_t* host; const uint8_t* dev; size_t bytes; const void* owner; };
+  std::vector<Twin> twins;
+  void add_twin(const void* host, const void* dev, size_t bytes, const void* owner) {
+    if (!host || !dev || !bytes) return;
+    std::lock_guard<std::mutex> g(m);
+    twins.push_back(Twin{static_cast<const uint8_t*>(host), static_cast<const uint8_t*>(dev), bytes, owner});
+  }
+  void drop_twins(const void* owner) {
+    std::lock_guard<std::mutex> g(m);
+    size_t k = 0;
+    for (size_t i = 0; i < twins.size(); ++i)
+      if (twins[i].owner != owner) twins[k++] = twins[i];
+    twins.resize(k);
+  }
+  const void* find_twin(const void* host, size_t bytes) {        // the device's copy of host[0, bytes), or nullptr
+    const uint8_t* h = static_cast<const uint8_t*>(host);
+    std::lock_guard<std::mutex> g(m);
+    for (const Twin& t : twins)
+      if (h >= t.host && bytes <= t.bytes && (size_t)(h - t.host) <= t.bytes - bytes) return t.dev + (h - t.host);
+    return nullptr;
   }
   void close() {                                  // the context goes: free now, or when the borrower gives it back
     std::lock_guard<std::mutex> g(m);

@@ -503,13 +503,15 @@ int32_t device_inflate(void* user, const InflateSegment* segs, size_t n_segs, co
   // ONE allocation for everything the call needs (a hipMalloc / hipFree pair costs tens of milliseconds per gigabyte here, and
   // the match lists' worst-case room alone is 2.7 bytes per output byte): | inflated | compressed | blocks | status | matches |
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  // Room for the matches of a stream: a sixth of its bytes (a BAM's blocks hold one match per eight bytes or so; the bound
-  // is one per three) -- device memory costs ~17 ms a gigabyte to allocate here and the lists are the largest buffer.  A
-  // stream with more is decoded again, with the bound's room, in a second small launch.
+  // Room for a stream's tokens and literals (bgzf_inflate.hip: a dword per match from the front, the literals from the end): as
+  // many bytes as the stream inflates to -- a BAM's block needs ~0.7 of that (8 000 tokens + 13 000 literals for 64 KiB), the
+  // bound is 4/3 (a match per three bytes) -- because device memory costs ~17 ms a gigabyte to allocate here and this is the
+  // second largest buffer.  A stream that needs more says so (kInflateMatchRoom) and is decoded again, with the bound's room,
+  // in a second small launch.  (InflateBlock counts the room in 8-byte units.)
   std::vector<InflateBlock> blocks(n_jobs);
   unsigned long long n_match_room = 0;
   for (size_t k = 0; k < n_jobs; ++k) {
-    const uint32_t cap = jobs[k].ulen / 6u + 16u;
+    const uint32_t cap = jobs[k].ulen / 8u + 16u;
     blocks[k] = InflateBlock{jobs[k].cpos, jobs[k].upos, n_match_room, jobs[k].clen, jobs[k].ulen, cap, 0u};
     n_match_room += cap;
   }
@@ -751,7 +753,7 @@ namespace {
 struct ArenaLoan { std::shared_ptr<midas_arena_pool> pool; void* p; };
 void arena_loan_free(void* v) {
   ArenaLoan* l = static_cast<ArenaLoan*>(v);
-  if (l) { l->pool->give(l->p); delete l; }
+  if (l) { l->pool->drop_twins(l->p); l->pool->give(l->p); delete l; }
 }
 
 // DeviceDecoder::run (hostio.h): BGZF blocks of a BAM -- the whole file's, a rank's slice, or the runs that hold a rank's contigs --
@@ -802,7 +804,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
         if (err256) snprintf(err256, 256, "device decode: block %lld lies outside the buffers", (long long)j);
         return MIDAS_SNPS_ERR_INVALID_ARG;
       }
-      const uint32_t cap = jobs[j].ulen / 6u + 16u;
+      const uint32_t cap = jobs[j].ulen / 8u + 16u;
       blocks[j] = InflateBlock{(unsigned long long)(seg_at[k] + (jobs[j].cpos - c0)), jobs[j].upos, n_match_room, jobs[j].clen, jobs[j].ulen, cap, 0u};
       want[j] = jobs[j].crc;
       n_match_room += cap;
@@ -1094,6 +1096,10 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
     res->dev_free = device_free;
     own.p = nullptr;
   } else {            // the columns live in the arena: it stays lent until the handle is closed
+    // (and with them the small columns the host has just been given: a batch made from those host arrays need not send them up
+    // again -- midas_arena_pool::find_twin, midas_snps_batch_create)
+    for (const auto& c : cols)
+      if (c.first && c.second.first != static_cast<const void*>(d_rec)) loan.pool->add_twin(c.first, c.second.first, c.second.second, loan.p);
     res->dev_owner = new ArenaLoan{loan.pool, loan.p};
     res->dev_free = arena_loan_free;
     loan.p = nullptr;
@@ -1726,13 +1732,19 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMalloc(&b->d_qual, (size_t)qual_bytes + 64));
   B_TRY(hipMalloc(&b->d_cigar, ((size_t)n_cigar + 16) * 4));
   if (n > 0) {
-    B_TRY(hipMemcpyAsync(b->d_pos, reads->pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_mapq, reads->mapq, (size_t)n, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_nm, reads->nm, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_lseq, reads->l_seq, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_seq_off, reads->seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_qual_off, reads->qual_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    B_TRY(hipMemcpyAsync(b->d_cigar_off, reads->cigar_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    // (a column that a device decode of this context copied down a moment ago and still holds -- the caller passes the decoder's
+    // own read-only buffers, or a run of them -- is copied where it lies instead of going up the link again)
+    auto column_up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+      const void* twin = ctx->arena->find_twin(src, bytes);
+      return twin ? hipMemcpyAsync(dst, twin, bytes, hipMemcpyDeviceToDevice, s) : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    };
+    B_TRY(column_up(b->d_pos, reads->pos, (size_t)n * 4));
+    B_TRY(column_up(b->d_mapq, reads->mapq, (size_t)n));
+    B_TRY(column_up(b->d_nm, reads->nm, (size_t)n * 4));
+    B_TRY(column_up(b->d_lseq, reads->l_seq, (size_t)n * 4));
+    B_TRY(column_up(b->d_seq_off, reads->seq_off, (size_t)(n + 1) * 8));
+    B_TRY(column_up(b->d_qual_off, reads->qual_off, (size_t)(n + 1) * 8));
+    B_TRY(column_up(b->d_cigar_off, reads->cigar_off, (size_t)(n + 1) * 8));
     // (seq4 / qual / cigar may be DEVICE pointers -- midas_bam_load_device leaves these columns there: the kind is inferred)
     if (seq_bytes > 0) B_TRY(hipMemcpyAsync(b->d_seq4, reads->seq4, (size_t)seq_bytes, hipMemcpyDefault, s));
     if (qual_bytes > 0) B_TRY(hipMemcpyAsync(b->d_qual, reads->qual, (size_t)qual_bytes, hipMemcpyDefault, s));

@@ -1,4 +1,5 @@
-"""BGZF blocks inflated on the device (bgzf_inflate.hip: one thread per DEFLATE stream, Huffman tables in LDS), held to zlib:
+"""BGZF blocks inflated on the device (bgzf_inflate.hip: one lane per DEFLATE stream decodes it into tokens, one wavefront per
+stream lays the bytes out), held to zlib:
 stored, fixed and dynamic blocks, streams of several blocks, empty streams, the longest codes and distances, matches that
 overlap their own output, every compression level, and corrupt streams (a status, never a fault).  Then the BAM decoder with
 the device as its inflater against the same decoder on the host's threads."""
@@ -79,6 +80,45 @@ def test_streams_of_every_kind_against_zlib(ctx):
         got = bytes(out[int(u):int(u) + len(p)])
         assert got == p, "%s: first difference at %d" % (name, next((i for i in range(len(p)) if got[i] != p[i]), -1))
     assert len(cases) > 120
+
+
+def test_streams_whose_table_headers_fall_at_different_steps(ctx):
+    """The decoder reads table headers at the lanes' common step, by all lanes of a wavefront that want one together
+    (bgzf_inflate.hip, namespace w64).  zlib's own streams of a BAM reach their headers at the same symbol; these do not: every
+    stream is a different number of DEFLATE blocks of different lengths -- dynamic, fixed and stored ones, empty stored blocks
+    (a sync flush) and a block that ends on the stream's last byte -- and the streams of one wavefront are of every size from a few
+    bytes to a full BGZF block.  Also the counts that decide whether a rare kind of literal run reaches the tokens: runs of 511
+    literals and more (an escape token) between matches."""
+    rng = np.random.default_rng(11)
+    streams, plain = [], []
+    for k in range(200):
+        parts, c = [], zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15, 8,
+                                        [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED][k % 5])
+        s, budget = b"", int(rng.integers(40, 65280))
+        while budget > 0:
+            n = int(min(budget, rng.integers(1, 9000)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:   # incompressible: literals only (long literal runs), or stored by zlib's choice
+                piece = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            elif kind == 1:  # few symbols: short codes, many matches
+                piece = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+            elif kind == 2:  # a repeat of what came before (far matches) with fresh bytes in between
+                src = b"".join(parts) or b"seed"
+                piece = (src[-min(len(src), 3000):] + bytes(rng.integers(30, 45, 700, dtype=np.uint8)))[:n]
+            else:            # skewed bytes: long codes
+                piece = bytes(np.minimum(rng.geometric(0.05, n), 255).astype(np.uint8))
+            parts.append(piece)
+            budget -= len(piece)
+            s += c.compress(piece)
+            if budget > 0:
+                s += c.flush([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK][int(rng.integers(0, 3))])
+        s += c.flush()
+        streams.append(s)
+        plain.append(b"".join(parts))
+    out, upos = _inflate_all(ctx, streams, [len(p) for p in plain], crc=[zlib.crc32(p) for p in plain])
+    for k, (p, u) in enumerate(zip(plain, upos)):
+        got = bytes(out[int(u):int(u) + len(p)])
+        assert got == p, "stream %d: first difference at %d of %d" % (k, next((i for i in range(len(p)) if got[i] != p[i]), -1), len(p))
 
 
 def test_corrupt_streams_are_a_status(ctx):
