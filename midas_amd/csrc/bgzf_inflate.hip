@@ -120,6 +120,24 @@ struct TokenOut {
     L.tok(tw) = t;
     ++tw;
   }
+  // one step of the symbol loop: a literal, a match or neither (predicated: every lane runs it)
+  __device__ __forceinline__ void step(const LV& L, bool lit, uint32_t b, bool mat, uint32_t len, uint32_t dist) {
+    acc |= lit ? b << (24 - 8 * na) : 0u;
+    na += lit ? 1 : 0;
+    if (na == 4) {
+      if (!fits()) { full = true; }
+      else {
+        if (lw - lr == kLitW) store_lits(L);
+        L.lit(lw) = acc;
+        ++lw;
+      }
+      acc = 0; na = 0;
+    }
+    if (mat && run >= 511u) { push(L, kEscape | run); run = 0; }
+    if (mat) push(L, (run << 23) | ((len - 3u) << 15) | (dist - 1u));
+    run = mat ? 0u : run + (lit ? 1u : 0u);
+    o += lit ? 1u : (mat ? len : 0u);
+  }
   __device__ __forceinline__ void match(const LV& L, uint32_t len, uint32_t dist) {
     if (run >= 511u) { push(L, kEscape | run); run = 0; }
     push(L, (run << 23) | ((len - 3u) << 15) | (dist - 1u));
@@ -559,33 +577,33 @@ __global__ __launch_bounds__(kW) void bgzf_decode_kernel(InflateParams p) {
       if (state == kSymbols && in.short_of_words()) in.emergency(L);
     }
     if (state == kSymbols) {
-      uint32_t s, err = 0;
+      // One symbol, and where it is a length code the distance behind it -- written so that a wavefront whose lanes meet
+      // literals AND matches at every step (64 streams: always) runs ONE instruction sequence: both halves are computed by every
+      // lane, a lane's kind decides what is committed.  (As nested branches the same step spent a third of its time on the
+      // scalar unit moving execution masks.)
+      uint32_t s;
       const int l = decode<false>(L, in, T.ll, aBaseLl, aSymLl, &s);
       in.skip(l);
       in.refill_fast(L);
-      if (l == 0) {
-        err = kBadSymbol;
-      } else if (s < 256u) {
-        if (out.o >= ulen) err = kOutputOverrun; else out.literal(L, s);
-      } else if (s == 256u) {
-        state = last ? kDone : kWantHeader;
-      } else {
-        const int sl = (int)s - 257;
-        uint32_t len, dist, d;
-        int extra;
-        length_of(sl < 29 ? sl : 0, &len, &extra);
-        len += in.take(extra);                             // (<= 5 extra bits of >= 32: 27 left for the distance code)
-        const int dl = decode<true>(L, in, T.d, aBaseD, aSymD, &d);
-        in.skip(dl);
-        in.refill_fast(L);
-        int dextra;
-        distance_of(d < 30u ? (int)d : 0, &dist, &dextra);
-        dist += in.take(dextra);
-        if (sl >= 29) err = kBadSymbol;
-        else if (dl == 0 || d >= 30u || dist > out.o) err = kBadDistance;
-        else if (out.o + len > ulen) err = kOutputOverrun;
-        else out.match(L, len, dist);
-      }
+      const bool good = l != 0;
+      const bool is_lit = good && s < 256u, is_eob = good && s == 256u, is_len = good && s > 256u;
+      const int sl = (int)s - 257;
+      const bool sl_ok = sl < 29;
+      uint32_t len, dist, d;
+      int extra, dextra;
+      length_of(is_len && sl_ok ? sl : 0, &len, &extra);
+      len += in.take(is_len ? extra : 0);                  // (<= 5 extra bits of >= 32: 27 left for the distance code)
+      const int dl0 = decode<true>(L, in, T.d, aBaseD, aSymD, &d);
+      in.skip(is_len ? dl0 : 0);
+      in.refill_fast(L);
+      distance_of(d < 30u ? (int)d : 0, &dist, &dextra);
+      dist += in.take(is_len ? dextra : 0);
+      uint32_t err = good ? 0u : (uint32_t)kBadSymbol;
+      err = is_len && !sl_ok ? (uint32_t)kBadSymbol : err;
+      err = !err && is_len && (dl0 == 0 || d >= 30u || dist > out.o) ? (uint32_t)kBadDistance : err;
+      err = !err && ((is_lit && out.o >= ulen) || (is_len && out.o + len > ulen)) ? (uint32_t)kOutputOverrun : err;
+      out.step(L, is_lit && !err, s, is_len && !err, len, dist);
+      state = is_eob ? (last ? (uint32_t)kDone : (uint32_t)kWantHeader) : state;
       if (!err && in.overrun()) err = kInputOverrun;
       if (!err && out.full) err = kMatchRoom;
       if (err) fail(err);

@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // The context's device arena: ONE allocation that the BAM decodes of a context take turns in (a hipMalloc / hipFree pair
@@ -103,4 +104,9 @@ struct midas_snps_ctx {
   static constexpr size_t kStageBytes = (size_t)32 << 20;
   void* stage[kStageSlots] = {nullptr, nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr};
+  // Page-locking the ring costs ~0.2 ms a megabyte -- 14 ms that the first BAM decode of a process used to pay in front of its
+  // upload.  midas_snps_create starts it on a thread of its own (the caller goes on to read its species and contigs); whoever
+  // needs the ring first waits for that thread (stage_join), and allocates by itself what it did not get.
+  std::thread stage_thread;
+  void stage_join() { if (stage_thread.joinable()) stage_thread.join(); }
 };

@@ -248,6 +248,7 @@ int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t byt
     return MIDAS_SNPS_OK;
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
+  ctx->stage_join();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
     if (!ctx->stage_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
@@ -293,6 +294,7 @@ int32_t copy_to_device_staged(midas_snps_ctx* ctx, void* dst, const void* src, s
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
     return MIDAS_SNPS_OK;
   }
+  ctx->stage_join();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
     if (!ctx->stage_ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
@@ -382,12 +384,19 @@ int32_t midas_snps_create(int32_t device_ordinal, midas_snps_ctx** out_ctx) {
   ctx->stream = ctx->own_stream;
   const char* coder = getenv("MIDAS_SNPS_ROW_CODER");
   ctx->row_coder = (coder && strcmp(coder, "host") == 0) ? MIDAS_SNPS_ROWS_HOST : MIDAS_SNPS_ROWS_DEVICE;
+  // the pinned staging ring, page-locked beside whatever the caller does next (ctx_internal.h: stage_thread)
+  ctx->stage_thread = std::thread([ctx] {
+    if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
+      if (hipHostMalloc(&ctx->stage[k], midas_snps_ctx::kStageBytes, kHostAllocFlags) != hipSuccess) { (void)hipGetLastError(); ctx->stage[k] = nullptr; }
+  });
   *out_ctx = ctx;
   return MIDAS_SNPS_OK;
 }
 
 void midas_snps_destroy(midas_snps_ctx* ctx) {
   if (!ctx) return;
+  ctx->stage_join();
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->arena) ctx->arena->close();
@@ -2253,6 +2262,7 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
   std::lock_guard<std::mutex> host_path(ctx->device_mutex);      // (the host's formatter owns the staging ring for the whole call)
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
+  ctx->stage_join();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k)
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
   BatchFeed user{b, (int64_t)(kFeedSlotBytes / 17 / (size_t)kRowsPerMember) * kRowsPerMember};
