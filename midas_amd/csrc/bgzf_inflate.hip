@@ -801,30 +801,30 @@ __global__ __launch_bounds__(kLanes * kResolveWaves) void bgzf_place_kernel(Infl
   }
 }
 
-// The payload columns cut out of the inflated stream where it lies, in HBM: one wavefront per record copies the record's
-// CIGAR ops, 4-bit SEQ and QUAL (BAM record layout: SAM spec 4.2) to the offsets the host's size pass computed.  What the host
-// decoder does with three memcpy per record -- and then sends up the link again.
+// The payload columns cut out of the inflated stream where it lies, in HBM: HALF a wavefront per record copies the record's
+// CIGAR ops, 4-bit SEQ and QUAL (BAM record layout: SAM spec 4.2) to the offsets the size pass computed, eight bytes a lane
+// and load (any alignment), the last few bytes singly -- a 150 bp record is 30 lanes' worth, two records share a wavefront's
+// trip to memory.  What the host decoder does with three memcpy per record -- and then sends up the link again.
+__device__ __forceinline__ void copy_run32(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t sl) {
+  const uint32_t whole = n & ~7u;
+  for (uint32_t k = sl * 8u; k < whole; k += 256u) *reinterpret_cast<u64_a1*>(dst + k) = *reinterpret_cast<const u64_a1*>(src + k);
+  if (sl < (n & 7u)) dst[whole + sl] = src[whole + sl];
+}
 __global__ __launch_bounds__(256) void bam_payload_kernel(PayloadParams p) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
-  for (long long i = wave; i < p.n_records; i += n_waves) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, sl = lane & 31u;
+  const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub, n_slots = (long long)gridDim.x * 8;
+  for (long long i = slot; i < p.n_records; i += n_slots) {
     const uint8_t* r = p.stream + p.rec_off[i];
     const uint32_t l_name = r[12];
     const uint32_t n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
     const uint32_t l = (uint32_t)r[20] | ((uint32_t)r[21] << 8) | ((uint32_t)r[22] << 16) | ((uint32_t)r[23] << 24);
     const uint8_t* q = r + 36 + l_name;
-    uint32_t* cg = p.cigar + p.cigar_off[i];
-    for (uint32_t k = (uint32_t)lane; k < n_cig; k += 64u) {
-      const uint8_t* s = q + 4u * k;
-      cg[k] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    }
+    copy_run32(reinterpret_cast<uint8_t*>(p.cigar + p.cigar_off[i]), q, 4u * n_cig, sl);
     q += 4ull * n_cig;
-    uint8_t* sq = p.seq4 + p.seq_off[i];
     const uint32_t ns = (l + 1u) / 2u;
-    for (uint32_t k = (uint32_t)lane; k < ns; k += 64u) sq[k] = q[k];
+    copy_run32(p.seq4 + p.seq_off[i], q, ns, sl);
     q += ns;
-    uint8_t* ql = p.qual + p.qual_off[i];
-    for (uint32_t k = (uint32_t)lane; k < l; k += 64u) ql[k] = q[k];
+    copy_run32(p.qual + p.qual_off[i], q, l, sl);
   }
 }
 
