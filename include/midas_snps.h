@@ -622,6 +622,18 @@ int32_t midas_comm_all_gather(midas_comm* comm, const void* send, void* recv, in
 int32_t midas_comm_all_to_all_v(midas_comm* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes,
                                 char* err256);
 
+/* The selected species' representative genomes read by all cores: initialize_contigs (midas/run/snps.py:55-67 -- Bio.SeqIO
+ * over genome.fna[.gz], `str(rec.seq).upper()`).  Every file is read through zlib's gz layer (plain text passes through), cut
+ * into records at the '>' that start a line (id = the header's first whitespace-separated word; what precedes the first header
+ * is no record), whitespace removed, ASCII a-z upper-cased; the sequences of all files lie back to back in one pool, in file and
+ * record order.  columns: out[0..5] = pool (uint8), rec_off (int64), rec_len (int64), rec_file (int32: index into paths), ids
+ * (char, back to back), id_off (int64, n_records + 1); sizes[0..1] = bytes of the pool and of the ids.  They belong to the handle. */
+typedef struct midas_fasta midas_fasta;
+int32_t midas_fasta_load(int32_t n_files, const char* const* paths, int32_t threads, midas_fasta** out, char* err256);
+int64_t midas_fasta_n_records(const midas_fasta* f);
+int32_t midas_fasta_columns(const midas_fasta* f, const void** out, int64_t* sizes);
+void midas_fasta_close(midas_fasta* f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,6 +272,10 @@ def load_library(build_if_missing: bool = True):
         'midas_snps_write_pieces': (i32, [C.c_char_p, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_char_p]),
         'midas_snps_deflate_rows': (i32, [vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]),
         'midas_snps_batch_write_part': (i32, [vp, C.c_char_p, i32, i32, vp, vp, i32, i32]),
+        'midas_fasta_load': (i32, [i32, vp, i32, C.POINTER(vp), C.c_char_p]),
+        'midas_fasta_n_records': (i64, [vp]),
+        'midas_fasta_columns': (i32, [vp, vp, vp]),
+        'midas_fasta_close': (None, [vp]),
         'midas_snps_tableset_open': (i32, [i32, vp, C.POINTER(vp), vp, C.c_char_p]),
         'midas_snps_tableset_read_counts': (i32, [vp, i64, i64, vp, C.c_char_p]),
         'midas_snps_tableset_close': (None, [vp]),
@@ -319,6 +323,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
+    'midas_fasta_load', 'midas_fasta_n_records', 'midas_fasta_columns', 'midas_fasta_close',
     'midas_snps_table_open', 'midas_snps_table_open_range', 'midas_snps_table_count_rows', 'midas_snps_table_close', 'midas_snps_table_rows', 'midas_snps_table_key_bytes',
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_genes_terms', 'midas_genes_sum', 'midas_merge_write_info',
     'midas_merge_write_matrix',
@@ -571,6 +576,44 @@ class _Column:
         dt = np.dtype(dtype)
         self.__array_interface__ = {'shape': (int(n),), 'typestr': dt.str, 'data': (int(ptr) if n else 0, True), 'version': 3} \
             if n else np.empty(0, dt).__array_interface__
+
+
+class _FastaOwner:
+    def __init__(self, lib, h):
+        self._lib, self._h = lib, h
+
+    def __del__(self):
+        if self._h:
+            self._lib.midas_fasta_close(self._h)
+            self._h = None
+
+
+def read_fasta_files(paths, threads: int = 0):
+    """The FASTA files `paths` (plain or gzip) read by all cores (midas_fasta_load): (pool, records) -- every sequence back to
+    back in one read-only uint8 array (whitespace out, ASCII letters upper-cased), records = [(id, file index, offset, length)]
+    in file and record order: what midas_amd/fasta.py parse_bytes yields for each file, `seq.upper()` applied."""
+    lib = load_library()
+    n = len(paths)
+    c_paths = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    st = lib.midas_fasta_load(n, c_paths, int(threads), C.byref(h), err)
+    if st != 0:
+        raise MidasSnpsError(st, err.value.decode() or "midas_fasta_load failed")
+    owner = _FastaOwner(lib, h)
+    nrec = int(lib.midas_fasta_n_records(h))
+    ptrs, sizes = (C.c_void_p * 6)(), (C.c_int64 * 2)()
+    st = lib.midas_fasta_columns(h, ptrs, sizes)
+    if st != 0:
+        raise MidasSnpsError(st, "midas_fasta_columns failed")
+    pool = np.asarray(_Column(owner, ptrs[0] or 0, int(sizes[0]), np.uint8))
+    off = np.asarray(_Column(owner, ptrs[1] or 0, nrec, np.int64))
+    ln = np.asarray(_Column(owner, ptrs[2] or 0, nrec, np.int64))
+    fi = np.asarray(_Column(owner, ptrs[3] or 0, nrec, np.int32))
+    ids = bytes(np.asarray(_Column(owner, ptrs[4] or 0, int(sizes[1]), np.uint8)))
+    io = np.asarray(_Column(owner, ptrs[5] or 0, nrec + 1, np.int64))
+    recs = [(ids[int(io[k]):int(io[k + 1])].decode('latin-1'), int(fi[k]), int(off[k]), int(ln[k])) for k in range(nrec)]
+    return pool, recs
 
 
 def write_bam(path, ref_names, ref_lengths, refid, reads, level=6, threads=0):

@@ -2699,3 +2699,184 @@ int32_t midas_merge_write_info(const char* path, const char* header_line, int64_
 }
 
 }  // extern "C"
+
+// ---- representative genomes: FASTA files read by all cores ------------------------------------------------------------------
+// initialize_contigs (midas/run/snps.py:55-67) parses every selected species' genome.fna[.gz] with Biopython and upper-cases
+// the sequences; the Python host's own split / join reader takes 0.8 s for configs[3]'s 400 Mb -- on one core, beside a BAM
+// decode that no longer takes that long.  Here every file is a task: read through zlib's gz layer (plain files pass through
+// it untouched), cut into records at the '>' that start a line, whitespace taken out and ASCII letters upper-cased in the same
+// pass, the sequences of all files laid back to back in one pool.  The records are exactly midas_amd/fasta.py parse_bytes'
+// (the tests hold the two to each other): id = the header's first whitespace-separated word, whatever precedes the first header
+// is no record, a '>' inside a line is sequence.
+struct midas_fasta {
+  RawBuf<uint8_t> pool;                      // every record's sequence, back to back, in file and record order (not zero-filled)
+  std::vector<int64_t> rec_off, rec_len;     // [n_records]
+  std::vector<int32_t> rec_file;             // [n_records] index into the caller's list of files
+  std::vector<char> ids;                     // the records' ids, back to back
+  std::vector<int64_t> id_off;               // [n_records + 1]
+};
+
+namespace {
+inline bool fasta_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }     // bytes.split() / bytes.strip(): " \t\n\r\x0b\x0c"
+struct FastaFile {
+  uint8_t* seq = nullptr;        // malloc'd, never zero-filled
+  size_t seq_len = 0;
+  std::vector<int64_t> off, len, id_off;
+  std::string ids;
+  int32_t status = MIDAS_SNPS_OK;
+  std::string err;
+  FastaFile() = default;
+  FastaFile(const FastaFile&) = delete;
+  FastaFile& operator=(const FastaFile&) = delete;
+  ~FastaFile() { free(seq); }
+};
+void fasta_parse_file(const char* path, FastaFile* out) {
+  gzFile g = gzopen(path, "rb");
+  if (!g) { out->status = MIDAS_SNPS_ERR_INVALID_ARG; out->err = std::string("cannot open ") + path; return; }
+  (void)gzbuffer(g, 1 << 20);
+  auto big = [](size_t bytes) -> uint8_t* { return static_cast<uint8_t*>(malloc(bytes ? bytes : 1)); };
+  struct Bytes { uint8_t* p = nullptr; ~Bytes() { free(p); } } data;
+  size_t n = 0, cap = (size_t)8 << 20;
+  {   // (a plain file's size is its text's; a gzip file's is a first guess)
+    struct stat sb;
+    if (stat(path, &sb) == 0 && sb.st_size > 0) cap = std::max(cap, (size_t)sb.st_size + ((size_t)2 << 20));
+  }
+  data.p = big(cap);
+  for (;;) {
+    if (data.p && cap - n < ((size_t)1 << 20)) {
+      uint8_t* q = big(cap * 2);
+      if (q) memcpy(q, data.p, n);
+      free(data.p);
+      data.p = q;
+      cap *= 2;
+    }
+    if (!data.p) { gzclose(g); out->status = MIDAS_SNPS_ERR_OUT_OF_MEMORY; out->err = std::string("out of memory reading ") + path; return; }
+    const int got = gzread(g, data.p + n, (unsigned)std::min<size_t>(cap - n, (size_t)1 << 30));
+    if (got < 0) { gzclose(g); out->status = MIDAS_SNPS_ERR_BAD_LAYOUT; out->err = std::string("read error (corrupt gzip data?) on ") + path; return; }
+    if (got == 0) break;
+    n += (size_t)got;
+  }
+  if (gzclose(g) != Z_OK) {       // (Z_BUF_ERROR: the file ends inside a gzip member)
+    out->status = MIDAS_SNPS_ERR_BAD_LAYOUT; out->err = std::string("truncated or corrupt gzip data in ") + path; return;
+  }
+  out->seq = big(n ? n : 1);      // (a sequence is never longer than its text)
+  if (!out->seq) { out->status = MIDAS_SNPS_ERR_OUT_OF_MEMORY; out->err = std::string("out of memory reading ") + path; return; }
+  uint8_t* const dst = out->seq;
+  size_t w_at = 0;
+  out->id_off.push_back(0);
+  const uint8_t* const d = data.p;
+  size_t p = 0;
+  // to the first header: a '>' at the file's start or behind a newline
+  if (!(n > 0 && d[0] == '>')) {
+    for (;;) {
+      const void* nl = p < n ? memchr(d + p, '\n', n - p) : nullptr;
+      if (!nl) { p = n; break; }
+      p = (size_t)(static_cast<const uint8_t*>(nl) - d) + 1;
+      if (p < n && d[p] == '>') break;
+    }
+  }
+  while (p < n) {        // d[p] == '>': one record
+    size_t h0 = p + 1;
+    const void* nl = memchr(d + h0, '\n', n - h0);
+    const size_t h1 = nl ? (size_t)(static_cast<const uint8_t*>(nl) - d) : n;
+    size_t q = nl ? h1 + 1 : n;
+    while (h0 < h1 && fasta_space(d[h0])) ++h0;                 // header.strip().split()[0]
+    size_t w = h0;
+    while (w < h1 && !fasta_space(d[w])) ++w;
+    out->ids.append(reinterpret_cast<const char*>(d + h0), w - h0);
+    out->id_off.push_back((int64_t)out->ids.size());
+    const size_t at = w_at;
+    // the body, line by line up to a line that begins with '>': whitespace out, a-z up (no branch per byte: the byte is
+    // written and the position moves on only if it was no whitespace)
+    while (q < n && d[q] != '>') {
+      const void* e = memchr(d + q, '\n', n - q);
+      const size_t end = e ? (size_t)(static_cast<const uint8_t*>(e) - d) : n;
+      for (size_t k = q; k < end; ++k) {
+        const uint8_t c = d[k];
+        dst[w_at] = (uint8_t)(c - (((uint8_t)(c - 'a') < 26u) ? 32u : 0u));
+        w_at += fasta_space(c) ? 0u : 1u;
+      }
+      q = e ? end + 1 : n;
+    }
+    out->off.push_back((int64_t)at);
+    out->len.push_back((int64_t)(w_at - at));
+    p = q;
+  }
+  out->seq_len = w_at;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t midas_fasta_load(int32_t n_files, const char* const* paths, int32_t threads, midas_fasta** out, char* err256) {
+  if (!out || n_files < 0 || (n_files > 0 && !paths)) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  for (int32_t k = 0; k < n_files; ++k) if (!paths[k]) return MIDAS_SNPS_ERR_INVALID_ARG;
+  Lap lap("fasta");
+  std::unique_ptr<FastaFile[]> files(new FastaFile[(size_t)n_files > 0 ? (size_t)n_files : 1]);
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : (int64_t)midas::cpu_budget(), n_files));
+  std::atomic<int32_t> next{0};
+  Workers::run(nt, [&] {
+    for (;;) {
+      const int32_t k = next.fetch_add(1);
+      if (k >= n_files) return;
+      fasta_parse_file(paths[k], &files[(size_t)k]);
+    }
+  });
+  lap("files read and parsed");
+  for (int32_t k = 0; k < n_files; ++k)
+    if (files[(size_t)k].status != MIDAS_SNPS_OK) { set_err(err256, "%s", files[(size_t)k].err.c_str()); return files[(size_t)k].status; }
+  std::unique_ptr<midas_fasta> f(new (std::nothrow) midas_fasta());
+  if (!f) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  std::vector<int64_t> base((size_t)n_files + 1, 0);
+  size_t n_rec = 0, id_bytes = 0;
+  for (int32_t k = 0; k < n_files; ++k) {
+    base[(size_t)k + 1] = base[(size_t)k] + (int64_t)files[(size_t)k].seq_len;
+    n_rec += files[(size_t)k].off.size();
+    id_bytes += files[(size_t)k].ids.size();
+  }
+  if (!f->pool.resize((size_t)base[(size_t)n_files])) { set_err(err256, "out of memory reading the genomes"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  try {
+    f->rec_off.reserve(n_rec); f->rec_len.reserve(n_rec); f->rec_file.reserve(n_rec);
+    f->ids.reserve(id_bytes); f->id_off.reserve(n_rec + 1);
+  } catch (const std::bad_alloc&) { set_err(err256, "out of memory reading the genomes"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  f->id_off.push_back(0);
+  for (int32_t k = 0; k < n_files; ++k) {
+    const FastaFile& q = files[(size_t)k];
+    for (size_t r = 0; r < q.off.size(); ++r) {
+      f->rec_off.push_back(base[(size_t)k] + q.off[r]);
+      f->rec_len.push_back(q.len[r]);
+      f->rec_file.push_back(k);
+      f->ids.insert(f->ids.end(), q.ids.begin() + (ptrdiff_t)q.id_off[r], q.ids.begin() + (ptrdiff_t)q.id_off[r + 1]);
+      f->id_off.push_back((int64_t)f->ids.size());
+    }
+  }
+  next = 0;
+  Workers::run(nt, [&] {
+    for (;;) {
+      const int32_t k = next.fetch_add(1);
+      if (k >= n_files) return;
+      if (files[(size_t)k].seq_len) memcpy(f->pool.p + base[(size_t)k], files[(size_t)k].seq, files[(size_t)k].seq_len);
+      free(files[(size_t)k].seq);
+      files[(size_t)k].seq = nullptr;
+    }
+  });
+  lap("sequences to the pool");
+  *out = f.release();
+  return MIDAS_SNPS_OK;
+}
+
+int64_t midas_fasta_n_records(const midas_fasta* f) { return f ? (int64_t)f->rec_off.size() : 0; }
+
+/* out[0..5] = pool (u8), rec_off (i64), rec_len (i64), rec_file (i32), ids (char), id_off (i64, n + 1); sizes[0..1] = pool bytes, id bytes */
+int32_t midas_fasta_columns(const midas_fasta* f, const void** out, int64_t* sizes) {
+  if (!f || !out || !sizes) return MIDAS_SNPS_ERR_INVALID_ARG;
+  out[0] = f->pool.p; out[1] = f->rec_off.data(); out[2] = f->rec_len.data(); out[3] = f->rec_file.data();
+  out[4] = f->ids.data(); out[5] = f->id_off.data();
+  sizes[0] = (int64_t)f->pool.n; sizes[1] = (int64_t)f->ids.size();
+  return MIDAS_SNPS_OK;
+}
+
+void midas_fasta_close(midas_fasta* f) { delete f; }
+
+}  // extern "C"

@@ -140,15 +140,23 @@ def _records(sp):
             yield rec_id, rec_seq.upper()
 
 
-def initialize_contigs(species):
-    """{contig_id: Contig} over every species' representative genome, sequences upper-cased (midas/run/snps.py:55-67)."""
-    pool, recs = bytearray(), []
-    for sp in species.values():
-        for rid, seq in _records(sp):
-            recs.append((rid, sp.id, len(pool), len(seq)))
-            pool += seq
-    arr = np.frombuffer(pool, dtype=np.uint8)
-    return {rid: Contig(rid, arr[at:at + n], sid, arr, at) for rid, sid, at, n in recs}
+FASTA_THREADS = 2   # the genomes are read BESIDE the BAM decode, whose copy threads need the cores (all cores: configs[3] 2.8 s instead of 2.2 s)
+
+
+def initialize_contigs(species, threads=None):
+    """{contig_id: Contig} over every species' representative genome, sequences upper-cased (midas/run/snps.py:55-67).  The
+    files are read by the library's FASTA reader, one file a task on all cores (midas_fasta_load: the records of
+    midas_amd/fasta.py, which the tests hold it to -- 400 Mb of genomes take the interpreter's own reader 0.8 s on its one core,
+    beside a BAM decode that is done sooner)."""
+    sps = list(species.values())
+    for sp in sps:
+        if 'fna' not in sp.paths:
+            sys.exit("\nError: Could not locate the representative genome of species: %s\n" % sp.id)
+    try:
+        arr, recs = abi.read_fasta_files([sp.paths['fna'] for sp in sps], threads=FASTA_THREADS if threads is None else threads)
+    except abi.MidasSnpsError as e:
+        sys.exit("\nError: %s\n" % e.message)
+    return {rid: Contig(rid, arr[at:at + n], sps[fi].id, arr, at) for rid, fi, at, n in recs}
 
 
 class ContigsInBackground(Mapping):
@@ -840,7 +848,9 @@ def _count_alleles(args, species, contigs, ctx):
             error = "\nError: could not read %s\n%s\n" % (bampath, e.message)
         dist.agree_or_exit(error)
         ref_names, ref_lens, refid, reads = decoded
-        read_bytes = np.bincount(refid, weights=reads.l_seq, minlength=len(ref_names)) if refid.size else np.zeros(len(ref_names))
+        # (the weights only decide which rank takes which contig: with one rank there is nothing to decide, and a weighted
+        # bincount over 80 M reads is half a second of one core)
+        read_bytes = np.bincount(refid, weights=reads.l_seq, minlength=len(ref_names)) if refid.size and ws > 1 else np.zeros(len(ref_names))
     else:
         ref_names, ref_lens, read_bytes = plan['ref_names'], plan['ref_lens'], plan['ref_bases']
         if rank == 0:

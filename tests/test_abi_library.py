@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "midas_snps.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(midas_(?:snps|bam|merge|genes|comm)_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(midas_(?:snps|bam|merge|genes|comm|fasta)_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_library_builds_for_gfx950_and_loads():
