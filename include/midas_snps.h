@@ -58,8 +58,11 @@ enum {
   MIDAS_SNPS_ERR_NO_DEVICE = -2,         /* no HIP device / not gfx950 / HIP runtime failure at create */
   MIDAS_SNPS_ERR_HIP = -3,               /* a HIP runtime call failed (message has hipGetErrorString) */
   MIDAS_SNPS_ERR_OUT_OF_MEMORY = -4,
-  MIDAS_SNPS_ERR_UNSUPPORTED = -5,       /* l_seq > 1024, l_seq/n_cigar/NM > 65534, > 2^31-1 reads, zero-length contig,
-                                            baseq > 62 on a batch that holds base qualities above 62 */
+  MIDAS_SNPS_ERR_UNSUPPORTED = -5,       /* a batch beyond what one batch addresses: > 2*10^9 reads, > 32 GiB of read payload
+                                            (the caller splits it); baseq > 62 on a PACKED batch holding qualities above 62;
+                                            selecting the DIRECT / PACKED path on a batch that holds a read beyond their
+                                            limits (l_seq > 1024, n_cigar / NM > 65534: such a batch RUNS, on the long path);
+                                            a contig of length < 1 (pysam: "interval of size 0") or >= 2^31 (BAM's limit)     */
   MIDAS_SNPS_ERR_BAD_LAYOUT = -6         /* offsets out of range / not monotone, read_begin inconsistent */
 };
 
