@@ -1,3 +1,6 @@
+// ROUND 6 EXPERIMENT, NOT SHIPPED (profiles/r06_kernel_experiments.txt section 1): 38 bases per lane -- a 150 bp read on four lanes, 16 reads per
+// wave-iteration, -15 % vector instructions per read, bit-exact -- measured 2.7 % SLOWER than 30 bases per lane on configs[2].
+// Needs `typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));` in device_common.h.
 // gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM's own bytes: per read ONE 16-byte record (pos, l_seq,
 // n_cigar, NM, mapq, payload offset -- layout.h DirectRec) and its CIGAR / 4-bit SEQ / QUAL bytes as BAM lays them out, one
 // run per read -- nothing decoded, sorted or decided beforehand, ONE visit per read.  Integer counting: no MFMA.
@@ -64,92 +67,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // counter offsets of the even / odd bases (byte i of an `e` word: base 2i, of an `o` word: base 2i + 1).
 template <int OFF, int NB>
 __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t the, uint32_t tho, uint32_t cde, uint32_t cdo,
-                                            uint32_t abase, uint32_t one, uint32_t dummy) {
+                                            uint32_t abase, uint32_t one) {
   static_assert(NB == 8 || NB == 6, "a group holds 8 bases, or 6 at the end of a 30-base lane");
   uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
   unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, save;
-#ifdef MIDAS_TALLY_DUMMY
-  // (developer variant, profiles/r06_kernel_experiments.txt: EXEC stays as it is -- every lane adds, a lane whose base does not count
-  // adds to a slot of its own in a dummy region, chosen by one v_cndmask on the address)
-  if (NB == 8) {
-    asm volatile(
-        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
-        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
-        "v_or_b32_sdwa %[t6], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
-        "v_or_b32_sdwa %[t7], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
-        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
-        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_cmp_gt_u32_sdwa %[m6], %[q1], %[te] src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
-        "v_cmp_gt_u32_sdwa %[m7], %[q1], %[to] src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
-        "v_cndmask_b32_e64 %[t0], %[dm], %[t0], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[t1], %[dm], %[t1], %[m1]\n\t"
-        "v_cndmask_b32_e64 %[t2], %[dm], %[t2], %[m2]\n\t"
-        "v_cndmask_b32_e64 %[t3], %[dm], %[t3], %[m3]\n\t"
-        "v_cndmask_b32_e64 %[t4], %[dm], %[t4], %[m4]\n\t"
-        "v_cndmask_b32_e64 %[t5], %[dm], %[t5], %[m5]\n\t"
-        "v_cndmask_b32_e64 %[t6], %[dm], %[t6], %[m6]\n\t"
-        "v_cndmask_b32_e64 %[t7], %[dm], %[t7], %[m7]\n\t"
-        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
-        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
-        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
-        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
-        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
-        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
-        "ds_add_u32 %[t6], %[one] offset:%[off]+96\n\t"
-        "ds_add_u32 %[t7], %[one] offset:%[off]+112"
-        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
-          [t7] "=&v"(t7), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5),
-          [m6] "=&s"(m6), [m7] "=&s"(m7)
-        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
-          [dm] "v"(dummy), [off] "n"(OFF)
-        : "memory");
-    (void)save;
-    return;
-  } else {
-    asm volatile(
-        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
-        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
-        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
-        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
-        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
-        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
-        "v_cndmask_b32_e64 %[t0], %[dm], %[t0], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[t1], %[dm], %[t1], %[m1]\n\t"
-        "v_cndmask_b32_e64 %[t2], %[dm], %[t2], %[m2]\n\t"
-        "v_cndmask_b32_e64 %[t3], %[dm], %[t3], %[m3]\n\t"
-        "v_cndmask_b32_e64 %[t4], %[dm], %[t4], %[m4]\n\t"
-        "v_cndmask_b32_e64 %[t5], %[dm], %[t5], %[m5]\n\t"
-        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
-        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
-        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
-        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
-        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
-        "ds_add_u32 %[t5], %[one] offset:%[off]+80"
-        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [m0] "=&s"(m0),
-          [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5)
-        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
-          [dm] "v"(dummy), [off] "n"(OFF)
-        : "memory");
-    (void)save; (void)t6; (void)t7; (void)m6; (void)m7;
-    return;
-  }
-#else
-  (void)dummy;
-#endif
   if (NB == 8) {
     asm volatile(
         "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
@@ -242,20 +163,21 @@ constexpr int kDirectWavesPerSimd = (kWorkgroupsPerCU * kDirectBlock / 64 + 3) /
 
 template <int LB, bool BQ0>
 __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
+  static_assert(LB == 30 || LB == 32 || LB == 38, "a lane's bases: 8 or 10 dwords of QUAL, 4 or 5 of SEQ");
+  constexpr int QW = (LB + 3) / 4;          // dwords of QUAL a lane holds (the last one of LB = 30 / 38: two bytes)
+  constexpr int SW = (LB + 7) / 8;          // dwords of 4-bit SEQ = groups of eight bases (the last one of LB = 30 / 38: six bases)
   constexpr int TILE = kTileSites;
   constexpr int NWAVES = kDirectBlock / 64;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
   constexpr int OV = kDirectOverhang;       // sites behind the tile's last that the tallies also hold (see "chunks" below)
   static_assert(OV <= TILE, "the overhang is moved by the write-out's first rounds");
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * (TILE + OV)];
-  __shared__ __attribute__((aligned(16))) uint32_t s_khi[33 * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's four SEQ words
-  __shared__ __attribute__((aligned(16))) uint32_t s_klo[33 * 4];   // [l][w]: 0xF in the nibbles of the bases j >= l
+  __shared__ __attribute__((aligned(16))) uint32_t s_khi[(LB + 1) * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's first four SEQ words
+  __shared__ __attribute__((aligned(16))) uint32_t s_klo[(LB + 1) * 4];   // [l][w]: 0xF in the nibbles of the bases j >= l
+  __shared__ uint32_t s_k4[SW > 4 ? 2 * (LB + 1) : 2];                    // the same two rows for a fifth SEQ word: [h], [LB + 1 + l]
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
-#ifdef MIDAS_TALLY_DUMMY
-  __shared__ uint32_t s_dummy[64 + 128];      // a slot per lane + the reach of the tally's immediate offsets (<= 496 bytes)
-#endif
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   const int tid = threadIdx.x;
@@ -299,8 +221,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       s_tables[i] = p.filt->min_match[i];
       s_tables[p.table_len + i] = p.filt->min_align[i];
     }
-    for (int i = tid; i < 33 * 4; i += kDirectBlock) {
-      const int h = i >> 2, wd = i & 3;
+    for (int i = tid; i < (LB + 1) * (SW > 4 ? 5 : 4); i += kDirectBlock) {
+      const bool fifth = i >= (LB + 1) * 4;
+      const int h = fifth ? i - (LB + 1) * 4 : i >> 2, wd = fifth ? 4 : i & 3;
       uint32_t kh = 0, kl = 0;
       for (int k = 0; k < 8; ++k) {
         const int j = 8 * wd + k;                              // base k of word wd: byte k / 2, the HIGH nibble when k is even
@@ -308,8 +231,13 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
         if (j < h) kh |= nib;
         if (j >= h) kl |= nib;
       }
-      s_khi[i] = kh;
-      s_klo[i] = kl;
+      if (fifth) {
+        s_k4[h] = kh;
+        s_k4[LB + 1 + h] = kl;
+      } else {
+        s_khi[i] = kh;
+        s_klo[i] = kl;
+      }
     }
     s_qsum[tid] = 0u;
     if (tid < MIDAS_STATS) s_stats[tid] = 0ull;
@@ -328,11 +256,6 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
   const uint32_t one = 1u;
-#ifdef MIDAS_TALLY_DUMMY
-  const uint32_t dummy = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_dummy + lane);
-#else
-  const uint32_t dummy = 0u;
-#endif
 
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
@@ -361,15 +284,15 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
                  : "=&v"(tot) : "v"(qsum_addr), "v"(part), "v"(0u) : "memory");
     return tot;
   };
-  auto lane_qsum = [&](const uint32_t (&q)[8], int nb) -> uint32_t {
+  auto lane_qsum = [&](const uint32_t (&q)[QW], int nb) -> uint32_t {
     uint32_t part = 0;
     if (nb == LB) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k) part = __builtin_amdgcn_sad_u8(q[k], 0u, part);
-      part = __builtin_amdgcn_sad_u8(LB == 32 ? q[7] : (q[7] & 0x0000FFFFu), 0u, part);
+      for (int k = 0; k < QW - 1; ++k) part = __builtin_amdgcn_sad_u8(q[k], 0u, part);
+      part = __builtin_amdgcn_sad_u8(LB % 4 == 0 ? q[QW - 1] : (q[QW - 1] & 0x0000FFFFu), 0u, part);
     } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) part = __builtin_amdgcn_sad_u8(q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
+      for (int k = 0; k < QW; ++k) part = __builtin_amdgcn_sad_u8(q[k] & low_bytes_mask(nb - 4 * k), 0u, part);
     }
     if (c == 0) part |= ((q[0] & 0xFFu) == 0xFFu) ? 0x80000000u : 0u;   // QUAL absent (BAM: first byte 0xFF)
     return part;
@@ -381,37 +304,41 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   // (decode eight bases, tally them), so that only one group's looked-up bytes are alive at a time.
   // (sparse: a pass with few lanes, e.g. the one lane of a read that holds its indel -- a group of eight bases none of the
   // wave's lanes has a base in is skipped)
-  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[8], const uint32_t (&sq)[4], auto sparse_tag) {
+  auto tally_range = [&](bool go, int lo, int hi, int loc0, const uint32_t (&qv)[QW], const uint32_t (&sq)[SW], auto sparse_tag) {
     constexpr bool SPARSE = decltype(sparse_tag)::value;
     const uint32_t abase = ((uint32_t)loc0 << 4) + lds_base;
     const bool masked = !(kDebug & 32) && __ballot(go && (lo > 0 || hi < LB)) != 0ull;   // partial lanes: the codes outside become 0
-    unsigned long long gmask[4];
+    unsigned long long gmask[SW];
     if (SPARSE) {
 #pragma unroll
-      for (int S = 0; S < 4; ++S) gmask[S] = __ballot(go && lo < 8 * S + 8 && hi > 8 * S);
+      for (int S = 0; S < SW; ++S) gmask[S] = __ballot(go && lo < 8 * S + 8 && hi > 8 * S);
     }
     if (!go) return;                                                    // outside [lo, hi) (a row of each table, LDS)
     uint4 keep = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint32_t keep4 = 0xFFFFFFFFu;
     if (masked) {
-      const uint4 kh = *reinterpret_cast<const uint4*>(s_khi + 4 * (hi > 32 ? 32 : hi));
-      const uint4 kl = *reinterpret_cast<const uint4*>(s_klo + 4 * (lo < 0 ? 0 : lo));
+      const int hc = hi > LB ? LB : hi, lc = lo < 0 ? 0 : lo;
+      const uint4 kh = *reinterpret_cast<const uint4*>(s_khi + 4 * hc);
+      const uint4 kl = *reinterpret_cast<const uint4*>(s_klo + 4 * lc);
       keep.x = kh.x & kl.x; keep.y = kh.y & kl.y; keep.z = kh.z & kl.z; keep.w = kh.w & kl.w;
+      if (SW > 4) keep4 = s_k4[hc] & s_k4[LB + 1 + lc];
     }
     auto group = [&](auto sidx, auto off, auto nbases) {
       constexpr int S = decltype(sidx)::value;
       if (SPARSE && gmask[S] == 0ull) return;
-      const uint32_t x = masked ? (sq[S] & (S == 0 ? keep.x : (S == 1 ? keep.y : (S == 2 ? keep.z : keep.w)))) : sq[S];
+      const uint32_t x = masked ? (sq[S] & (S == 0 ? keep.x : (S == 1 ? keep.y : (S == 2 ? keep.z : (S == 3 ? keep.w : keep4))))) : sq[S];
       const uint32_t se = (((x >> 4) & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;   // even bases (high nibbles)
       const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
       const uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
       const uint32_t ce = __builtin_amdgcn_perm(cd_hi, cd_lo, se), co = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
-      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one, dummy);
+      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
     };
     using std::integral_constant;
     group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 8>{});
     group(integral_constant<int, 1>{}, integral_constant<int, 128>{}, integral_constant<int, 8>{});
     group(integral_constant<int, 2>{}, integral_constant<int, 256>{}, integral_constant<int, 8>{});
-    group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 32 ? 8 : 6)>{});
+    group(integral_constant<int, 3>{}, integral_constant<int, 384>{}, integral_constant<int, (LB == 30 ? 6 : 8)>{});
+    if constexpr (SW > 4) group(integral_constant<int, 4>{}, integral_constant<int, 512>{}, integral_constant<int, LB - 32>{});
   };
 
   // ---- stage F: the record of this lane's read in wave-iteration `it` of a tile's stream: ONE dwordx4.  Raw loads: nothing is
@@ -435,7 +362,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   // iteration are neighbours in the payload.
   //   nmq: NM (16 bits, 0xFFFF = no NM tag) | mapq << 16 | kGenIdle << 24 (a lane without a read)      l_nc: l_seq | n_cigar << 16
   struct Rd { uint32_t pos, nmq, l_nc; };
-  struct Dat { uint32_t q[8]; uint32_t s[4]; uint32_t cg[4]; };
+  struct Dat { uint32_t q[QW]; uint32_t s[SW]; uint32_t cg[4]; };
   auto settle = [&](const Raw& f, int n_reads_it, Rd& r, Dat& d) {
     const bool act = g < n_reads_it;
     const uint32_t l_nc = act ? f.l_nc : 0u;
@@ -457,6 +384,11 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     d.q[0] = qa.x; d.q[1] = qa.y; d.q[2] = qa.z; d.q[3] = qa.w;
     d.q[4] = qb.x; d.q[5] = qb.y; d.q[6] = qb.z; d.q[7] = qb.w;
     d.s[0] = sv.x; d.s[1] = sv.y; d.s[2] = sv.z; d.s[3] = sv.w;
+    if constexpr (QW > 8) {           // (38 bases: 8 more bytes of QUAL, 4 more of SEQ -- the payload's slack covers a lane's overhang)
+      const u32x2_a1 qc = *reinterpret_cast<const u32x2_a1*>(base + (size_t)vq + 32);
+      d.q[8] = qc.x; d.q[9] = qc.y;
+      d.s[4] = *reinterpret_cast<const u32_a1*>(base + (size_t)vs + 16);
+    }
     d.cg[0] = cv.x; d.cg[1] = cv.y; d.cg[2] = cv.z; d.cg[3] = cv.w;
   };
 
@@ -522,13 +454,13 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 #if MIDAS_SNPS_DEBUG_BITS & 256
       asm volatile("" :: "v"(rd_n.pos), "v"(rd_n.l_nc));
       const unsigned long long pt1 = PROBE_NOW();
-      asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[3]));
+      asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[QW - 1]), "v"(dat_cur.s[SW - 1]), "v"(dat_cur.cg[3]));
       const unsigned long long pt2 = PROBE_NOW();
       pr_cols += pt1 - pt0; pr_bases += pt2 - pt1; pr_iters += 1;
 #endif
 
       if (kDebug & 4) {          // (developer timing variant: the stream of loads only)
-        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[7]), "v"(dat_cur.s[0]), "v"(dat_cur.s[3]), "v"(dat_cur.cg[0]), "v"(rd_cur.pos));
+        asm volatile("" :: "v"(dat_cur.q[0]), "v"(dat_cur.q[QW - 1]), "v"(dat_cur.s[0]), "v"(dat_cur.s[SW - 1]), "v"(dat_cur.cg[0]), "v"(rd_cur.pos));
         return;
       }
       MIDAS_MARK("qsum");
@@ -543,9 +475,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       const uint32_t nm16 = rd_cur.nmq & 0xFFFFu;
       const int nm = (int)nm16, mapq = (int)((rd_cur.nmq >> 16) & 0xFFu);
       const bool act = !((rd_cur.nmq >> 24) & kGenIdle);
-      uint32_t qv[8];
+      uint32_t qv[QW];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
+      for (int k = 0; k < QW; ++k) qv[k] = BQ0 ? 0x01010101u : dat_cur.q[k];
 
       // ---- the read's shape, in registers: one match op of the read's length settles most reads; anything else takes the
       // four-op grammar (wave-uniform branch) ------------------------------------------------------------------------------
@@ -871,10 +803,21 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
 }  // namespace
 
 int direct_lane_bases(int32_t max_l_seq) {
-  // 30 bases per lane: the lanes of a read start 120 tally dwords apart and spread over the LDS banks; 32 only where it
-  // saves a whole lane per read (151 bp: 5 lanes instead of 6)
+  // The per-read work of a wave-iteration (fetch, quality sum, CIGAR shape, filter, run geometry) costs the same vector
+  // instructions whatever the number of reads the wave holds: the more reads per iteration, the less of it per base.
+  // 38 bases per lane put a 150 bp read on FOUR lanes -- 16 reads per wave-iteration and all 64 lanes at work, where 30
+  // bases per lane hold 12 reads on 60 lanes.  With 30 and 38 the lanes of a read start 120 / 152 tally dwords apart and
+  // spread over the LDS banks (32 or 40 would put them on ONE bank); 32 only where it holds more reads than both.
   const int l = max_l_seq > 0 ? max_l_seq : 1;
-  return (l + 31) / 32 < (l + 29) / 30 ? 32 : 30;
+  auto reads_per_wave = [&](int lb) { return 64 / ((l + lb - 1) / lb); };
+#ifdef MIDAS_DIRECT_NO_LB38
+  return reads_per_wave(32) > reads_per_wave(30) ? 32 : 30;
+#else
+  int best = 30;
+  if (reads_per_wave(38) > reads_per_wave(best)) best = 38;
+  if (reads_per_wave(32) > reads_per_wave(best)) best = 32;
+  return best;
+#endif
 }
 
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t stream) {
@@ -884,7 +827,10 @@ hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream
   const int n_items = k > 1 ? p.n_chunked_tiles / k + (p.n_tiles - p.n_chunked_tiles) : p.n_tiles;      // (every workgroup of the grid has work)
   const int grid = n_items < p.grid_blocks ? n_items : p.grid_blocks;
   const bool bq0 = p.baseq <= 0;
-  if (lane_bases == 32) {
+  if (lane_bases == 38) {
+    if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<38, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    else hipLaunchKernelGGL((pileup_direct_kernel<38, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+  } else if (lane_bases == 32) {
     if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
     else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
   } else {

@@ -173,7 +173,7 @@ __device__ int32_t find_nm(const uint8_t* a, const uint8_t* end) {
 
 __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) { p.seq_off[0] = 0; p.qual_off[0] = 0; p.cigar_off[0] = 0; }
+  if (i == 0) { p.seq_off[0] = 0; p.qual_off[0] = 0; p.cigar_off[0] = 0; if (p.unit_off) p.unit_off[0] = 0; }
   if (i >= p.n) return;
   const uint8_t* r = p.d + p.rec_off[i];
   const uint32_t bs = rd32(r);
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   p.cigar_off[i + 1] = n_cig;
   p.seq_off[i + 1] = (l + 1u) / 2u;
   p.qual_off[i + 1] = l;
+  if (p.unit_off) p.unit_off[i + 1] = (4ll * n_cig + (l + 1u) / 2u + (long long)l + 7ll) >> 3;     // (layout.h direct_payload_units, any l)
   int32_t nm = -1;
   // (a chained walk checks block_size only: a record whose refID names no reference is caught here, as the host walk's
   // plausible_record() catches it -- the host folds per-reference tables by it)
@@ -227,10 +228,10 @@ __device__ __forceinline__ long long block_inclusive(long long v, long long* lds
   return x + base;
 }
 
-__global__ __launch_bounds__(kScanBlock) void bam_scan_sums_kernel(const long long* a0, const long long* a1, const long long* a2, long long n,
-                                                                   long long* sums) {
+__global__ __launch_bounds__(kScanBlock) void bam_scan_sums_kernel(const long long* a0, const long long* a1, const long long* a2, const long long* a3,
+                                                                   long long n, long long* sums) {
   __shared__ long long lds[4];
-  const long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : a2);
+  const long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : (blockIdx.y == 2 ? a2 : a3));
   const long long lo = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
   long long s = 0;
   for (int k = 0; k < kScanItems; ++k) s += lo + k < n ? a[lo + k] : 0;
@@ -251,9 +252,9 @@ __global__ __launch_bounds__(kScanBlock) void bam_scan_tiles_kernel(long long* s
     carry += total;
   }
 }
-__global__ __launch_bounds__(kScanBlock) void bam_scan_apply_kernel(long long* a0, long long* a1, long long* a2, long long n, const long long* sums) {
+__global__ __launch_bounds__(kScanBlock) void bam_scan_apply_kernel(long long* a0, long long* a1, long long* a2, long long* a3, long long n, const long long* sums) {
   __shared__ long long lds[4];
-  long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : a2);
+  long long* a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : (blockIdx.y == 2 ? a2 : a3));
   const long long lo = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
   long long v[kScanItems];
   long long s = 0;
@@ -267,7 +268,55 @@ __global__ __launch_bounds__(kScanBlock) void bam_scan_apply_kernel(long long* a
   }
 }
 
+// ---- the records in the pileup kernel's own layout (layout.h DirectRec + payload), straight from the inflated stream ----------
+// A record's CIGAR ops, 4-bit SEQ and QUAL are ONE run of its bytes (SAM spec 4.2: ... read_name, cigar, seq, qual, aux) -- and
+// that run, in that order, is the direct layout's payload of a read.  HALF a wavefront per record copies it ONCE to the 8-byte
+// unit the scan gave it (eight bytes a lane and load, any alignment; the tail to the next unit zeroed) and writes the read's
+// 16-byte record.  What pysam.AlignmentFile + the iteration of midas/run/snps.py:186-199 hand to count_coverage, as the kernel
+// that replaces count_coverage reads it: nothing is cut into columns and gathered back.
+typedef unsigned long long u64_a1 __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void bam_direct_kernel(BamDirectParams p) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, sl = lane & 31u;
+  const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub, n_slots = (long long)gridDim.x * 8;
+  for (long long i = slot; i < p.n_records; i += n_slots) {
+    const uint8_t* r = p.stream + p.rec_off[i];
+    const uint32_t l_name = r[12];
+    const uint32_t n_cig = rd16(r + 16);
+    const uint32_t l = rd32(r + 20);
+    const uint8_t* src = r + 36 + l_name;
+    const unsigned long long used = 4ull * n_cig + (l + 1u) / 2u + (unsigned long long)l;
+    const unsigned long long u0 = (unsigned long long)p.unit_off[i], room = ((unsigned long long)p.unit_off[i + 1] - u0) << 3;
+    uint8_t* dst = p.payload + (u0 << 3);
+    const unsigned long long whole = used & ~7ull;
+    for (unsigned long long k = (unsigned long long)sl * 8ull; k < whole; k += 256ull) *reinterpret_cast<u64_a1*>(dst + k) = *reinterpret_cast<const u64_a1*>(src + k);
+    if (sl < 8u && whole + sl < room) dst[whole + sl] = whole + sl < used ? src[whole + sl] : (uint8_t)0;      // the last unit: bytes, then zeros
+    if (sl == 0u) {
+      const int32_t nm = p.nm[i];
+      DirectRec rec;
+      rec.pos = p.pos[i];
+      rec.l_nc = (l > 0xFFFFu ? 0xFFFFu : l) | ((n_cig > 0xFFFFu ? 0xFFFFu : n_cig) << 16);     // (beyond the fast paths' limits: the batch takes the long path)
+      rec.nmq = (nm < 0 ? (uint32_t)kNmAbsent : (nm > kMaxField16 ? (uint32_t)kMaxField16 : (uint32_t)nm)) | ((uint32_t)r[13] << 16);
+      rec.off8 = (uint32_t)u0;
+      p.rec[i] = rec;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {       // the sentinel: where the payload ends
+    DirectRec rec;
+    rec.pos = 0; rec.l_nc = 0u; rec.nmq = 0u; rec.off8 = (uint32_t)p.unit_off[p.n_records];
+    p.rec[p.n_records] = rec;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_bam_direct(const BamDirectParams& p, int grid_blocks, hipStream_t s) {
+  long long g = (p.n_records + 3) / 4;
+  const long long cap = (long long)grid_blocks * 16;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(bam_direct_kernel, dim3((unsigned)g), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
 
 hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s) {
   const long long n = list ? n_list : p.n_chunks;
@@ -284,7 +333,7 @@ hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* 
 
 size_t bam_scan_scratch_bytes(long long n_records) {
   const long long tiles = (n_records + 1 + kScanTile - 1) / kScanTile;
-  return (size_t)(3 * (tiles > 0 ? tiles : 1)) * sizeof(long long);
+  return (size_t)(4 * (tiles > 0 ? tiles : 1)) * sizeof(long long);
 }
 
 // the columns of n records and, by three scans, their CSR offsets (n + 1 entries each)
@@ -292,9 +341,10 @@ hipError_t launch_bam_columns(const BamColumnsParams& p, long long* scan_scratch
   hipLaunchKernelGGL(bam_columns_kernel, dim3((unsigned)((p.n + 256) / 256)), dim3(256), 0, s, p);
   const long long n1 = p.n + 1;
   const long long tiles = (n1 + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(bam_scan_sums_kernel, dim3((unsigned)tiles, 3), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, n1, scan_scratch);
-  hipLaunchKernelGGL(bam_scan_tiles_kernel, dim3(3), dim3(kScanBlock), 0, s, scan_scratch, tiles);
-  hipLaunchKernelGGL(bam_scan_apply_kernel, dim3((unsigned)tiles, 3), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, n1, scan_scratch);
+  const unsigned na = p.unit_off ? 4u : 3u;       // (the payload units of the direct layout are a fourth array)
+  hipLaunchKernelGGL(bam_scan_sums_kernel, dim3((unsigned)tiles, na), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, p.unit_off, n1, scan_scratch);
+  hipLaunchKernelGGL(bam_scan_tiles_kernel, dim3(na), dim3(kScanBlock), 0, s, scan_scratch, tiles);
+  hipLaunchKernelGGL(bam_scan_apply_kernel, dim3((unsigned)tiles, na), dim3(kScanBlock), 0, s, p.seq_off, p.qual_off, p.cigar_off, p.unit_off, n1, scan_scratch);
   return hipGetLastError();
 }
 

@@ -114,7 +114,15 @@ struct midas_bam {
   void* dev_payload[3] = {nullptr, nullptr, nullptr};
   void* dev_owner = nullptr;            // the device allocation the three live in
   void (*dev_free)(void*) = nullptr;
+  // midas_bam_load_resident: EVERY column stays on the device, the records also in the pileup kernel's own layout; only refID is
+  // in host memory.  midas_bam_resident_to_columns turns the handle into the payload_on_device form above (and keeps this).
+  bool resident = false;
+  midas::ResidentReads rr;
+  int64_t rr_seq_bytes = 0, rr_qual_bytes = 0, rr_n_cigar = 0;
+  void* dev_owner2 = nullptr;           // (the three payload columns cut later, in a buffer of their own)
+  void (*dev_free2)(void*) = nullptr;
   ~midas_bam() {
+    if (dev_free2 && dev_owner2) dev_free2(dev_owner2);
     if (dev_free && dev_owner) dev_free(dev_owner);
   }
 };
@@ -1016,6 +1024,45 @@ static int parse_bam_header(const uint8_t* d, size_t n, midas_bam* b) {
   return 0;
 }
 
+static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c);
+bool midas::bam_alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) { return alloc_host_columns(b, n, c); }
+const midas::ResidentReads* midas::bam_resident(const midas_bam* b, int64_t* n_records, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar) {
+  if (!b || !b->resident) return nullptr;
+  if (n_records) *n_records = (int64_t)b->n_records;
+  if (seq_bytes) *seq_bytes = b->rr_seq_bytes;
+  if (qual_bytes) *qual_bytes = b->rr_qual_bytes;
+  if (n_cigar) *n_cigar = b->rr_n_cigar;
+  return &b->rr;
+}
+void midas::bam_resident_became_columns(midas_bam* b, void* seq4, void* qual, void* cigar, void* owner, void (*free_fn)(void*)) {
+  b->dev_payload[0] = seq4; b->dev_payload[1] = qual; b->dev_payload[2] = cigar;
+  b->dev_owner2 = owner;
+  b->dev_free2 = free_fn;
+  b->payload_on_device = true;
+}
+// (resident decode: refID is the one column the host asks for)
+static bool alloc_host_refid(midas_bam* b, int64_t n, midas::HostColumns* c) {
+  if (!b->refid.resize(n > 0 ? (size_t)n : 1)) return false;
+  *c = midas::HostColumns{};
+  c->refid = b->refid.data();
+  return true;
+}
+// what a device decode left in `res`, taken into the handle
+static void adopt_device_result(midas_bam* b, const midas::DeviceDecodeResult& res, int payload) {
+  b->n_records = (size_t)res.n_records;
+  b->loaded = true;
+  b->dev_owner = res.dev_owner;
+  b->dev_free = res.dev_free;
+  if (payload == 2) {
+    b->resident = true;
+    b->payload_on_device = false;
+    b->rr = res.resident;
+    b->rr_seq_bytes = res.seq_bytes; b->rr_qual_bytes = res.qual_bytes; b->rr_n_cigar = res.n_cigar;
+  } else {
+    b->payload_on_device = true;
+    b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
+  }
+}
 static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) {
   const size_t n1 = n > 0 ? (size_t)n : 1;
   if (!b->refid.resize(n1) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
@@ -1028,7 +1075,7 @@ static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) {
 }
 
 int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder* dec, midas_bam** out, int64_t* n_reads,
-                                    int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+                                    int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256, int payload) {
   if (!path || !out || !dec) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out = nullptr;
   std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
@@ -1060,11 +1107,11 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
   std::vector<midas::InflateJob> jobs;
   jobs.reserve(blocks.size());
   for (const FileBlk& q : blocks) jobs.push_back({(uint64_t)q.cpos, (uint64_t)q.upos, (uint32_t)q.clen, (uint32_t)q.ulen, rd32(&comp[q.cpos + q.clen]), 1u});
-  struct Sink { midas_bam* b; bool ok; } sink{b.get(), true};
+  struct Sink { midas_bam* b; bool ok; int payload; } sink{b.get(), true, payload};
   auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
     Sink* s = static_cast<Sink*>(sp);
     midas::HostColumns c{};
-    if (!alloc_host_columns(s->b, n, &c)) s->ok = false;
+    if (!(s->payload == 2 ? alloc_host_refid(s->b, n, &c) : alloc_host_columns(s->b, n, &c))) s->ok = false;
     return c;
   };
   midas::DeviceDecodeResult res;
@@ -1072,7 +1119,7 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
   midas::DecodeSegment seg;
   seg.job_lo = 0; seg.job_hi = jobs.size(); seg.from = (uint64_t)b->rec_begin; seg.exact = 1; seg.stop = (uint64_t)total;
   st = dec->run(dec->user, comp.data(), jobs.data(), jobs.size(), (uint64_t)total, &seg, 1, b->ref_lens.data(), (int32_t)b->ref_lens.size(),
-                1, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
+                payload, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
   lap("device");
   if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) {
     if (bad_job >= 0 && (size_t)bad_job < blocks.size())
@@ -1085,12 +1132,7 @@ int32_t midas::bam_decode_on_device(const char* path, const midas::DeviceDecoder
   }
   if (st != MIDAS_SNPS_OK) return st;
   if (!sink.ok) { set_err(err256, "out of memory decoding %s", path); if (res.dev_free && res.dev_owner) res.dev_free(res.dev_owner); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
-  b->n_records = (size_t)res.n_records;
-  b->payload_on_device = true;
-  b->loaded = true;
-  b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
-  b->dev_owner = res.dev_owner;
-  b->dev_free = res.dev_free;
+  adopt_device_result(b.get(), res, payload);
   if (n_reads) *n_reads = res.n_records;
   if (seq_bytes) *seq_bytes = res.seq_bytes;
   if (qual_bytes) *qual_bytes = res.qual_bytes;
@@ -1325,6 +1367,8 @@ int32_t midas_bam_columns(const midas_bam* b, const void** out12) {
                        b->seq_off.data(), b->qual_off.data(), b->cigar_off.data(), b->seq4.data(), b->qual.data(),
                        b->cigar.data()};
   if (b->payload_on_device) { v[9] = b->dev_payload[0]; v[10] = b->dev_payload[1]; v[11] = b->dev_payload[2]; }
+  if (b->resident && !b->payload_on_device)       // (every column but refID is on the device: midas_bam_resident_to_columns brings them)
+    for (int k = 1; k < 12; ++k) v[k] = nullptr;
   memcpy(out12, v, sizeof v);
   return MIDAS_SNPS_OK;
 }
@@ -1653,7 +1697,7 @@ int32_t midas_bam_load_ranges(midas_bam* b, int32_t n_ranges, const int64_t* ran
 // byte to the one holding its last), its first record known exactly; SEQ / QUAL / CIGAR stay on the device.
 int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecoder* dec, int32_t n_ranges, const int64_t* range_begin,
                                          const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
-                                         int64_t* n_cigar, char* err256) {
+                                         int64_t* n_cigar, char* err256, int payload) {
   if (!b || !b->map || !dec || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();
@@ -1688,23 +1732,24 @@ int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecode
     sg.stop = seg_base + ((uint64_t)range_end[k] - ubase);
     segs.push_back(sg);
   }
-  struct Sink { midas_bam* b; bool ok; } sink{b, true};
+  struct Sink { midas_bam* b; bool ok; int payload; } sink{b, true, payload};
   auto alloc = [](void* sp, int64_t n) -> midas::HostColumns {
     Sink* s = static_cast<Sink*>(sp);
     midas::HostColumns c{};
-    if (!alloc_host_columns(s->b, n, &c)) s->ok = false;
+    if (!(s->payload == 2 ? alloc_host_refid(s->b, n, &c) : alloc_host_columns(s->b, n, &c))) s->ok = false;
     return c;
   };
   midas::DeviceDecodeResult res;
   int64_t bad_job = -1, bad_record = -1;
   if (b->dev_free && b->dev_owner) { b->dev_free(b->dev_owner); b->dev_owner = nullptr; }      // (a handle is loaded once; be safe)
   if (segs.empty()) {
+    payload = 1;        // (nothing to decode: an empty handle of the ordinary kind)
     midas::HostColumns c{};
     if (!alloc_host_columns(b, 0, &c)) { set_err(err256, "out of memory decoding %s", b->path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
     b->seq_off[0] = b->qual_off[0] = b->cigar_off[0] = 0;
   } else {
     const int32_t st = dec->run(dec->user, m.base, jobs.data(), jobs.size(), at, segs.data(), segs.size(), b->ref_lens.data(), (int32_t)b->ref_lens.size(),
-                                1, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
+                                payload, 0, alloc, &sink, &res, &bad_job, &bad_record, err256);
     if (st == MIDAS_SNPS_ERR_BAD_LAYOUT) {
       if (bad_job >= 0 && (size_t)bad_job < job_block.size())
         set_err(err256, "%s: corrupt BGZF block at file offset %lld (deflate data or CRC-32)", b->path.c_str(), (long long)m.blocks[job_block[(size_t)bad_job]].fpos);
@@ -1724,12 +1769,7 @@ int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecode
       }
     }
   }
-  b->n_records = (size_t)res.n_records;
-  b->payload_on_device = true;
-  b->loaded = true;
-  b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
-  b->dev_owner = res.dev_owner;
-  b->dev_free = res.dev_free;
+  adopt_device_result(b, res, payload);
   if (n_reads) *n_reads = res.n_records;
   if (seq_bytes) *seq_bytes = res.seq_bytes;
   if (qual_bytes) *qual_bytes = res.qual_bytes;

@@ -54,11 +54,23 @@ struct HostColumns {
   int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag; int64_t *seq_off, *qual_off, *cigar_off;
   int32_t* span; uint64_t* rec_off;        // (only asked for by the slice walk: reference span and buffer offset of every record)
 };
+// payload == 2 ("resident"): every column stays where the device decoded it, the records also in the pileup kernel's own
+// layout (layout.h DirectRec + payload, one copy of every record's [cigar][seq][qual] run): device addresses, all of them in
+// the allocation `dev_owner` stands for.  stream / rec_off: the inflated bytes and every record's start in them, kept so that
+// the three payload columns can still be cut (midas_bam_resident_to_columns) for the paths that read them.
+struct ResidentReads {
+  void* rec = nullptr; uint8_t* payload = nullptr;
+  int32_t *refid = nullptr, *pos = nullptr, *nm = nullptr, *l_seq = nullptr; uint8_t* mapq = nullptr; uint16_t* flag = nullptr;
+  int64_t *seq_off = nullptr, *qual_off = nullptr, *cigar_off = nullptr, *unit_off = nullptr;
+  const uint8_t* stream = nullptr; const uint64_t* rec_off = nullptr;
+  int64_t payload_units = 0;
+};
 struct DeviceDecodeResult {
   int64_t n_records = 0, seq_bytes = 0, qual_bytes = 0, n_cigar = 0;
   void *dev_seq = nullptr, *dev_qual = nullptr, *dev_cigar = nullptr;
   void* dev_owner = nullptr;
   void (*dev_free)(void*) = nullptr;
+  ResidentReads resident;       // (payload == 2)
 };
 // A run of consecutive BGZF blocks of the file, inflated back to back into the decode buffer, and the records wanted from it.
 struct DecodeSegment {
@@ -75,8 +87,9 @@ struct DecodeSegment {
 struct DeviceDecoder {
   void* user;
   // jobs[k]: cpos = offset of block k's DEFLATE stream from comp_base (the mapped / read file), upos = where it inflates to in
-  // the decode buffer of buffer_bytes.  payload: cut SEQ / QUAL / CIGAR and leave them on the device (res->dev_*); extra: also
-  // hand out span and rec_off.  alloc(sink, n): host arrays for n records (n + 1 offsets), nullptr fields when out of memory.
+  // the decode buffer of buffer_bytes.  payload: 1 = cut SEQ / QUAL / CIGAR and leave them on the device (res->dev_*), 2 = leave
+  // EVERYTHING on the device, in the direct layout (res->resident; only refID comes down: alloc may leave the other fields
+  // nullptr); extra: also hand out span and rec_off.  alloc(sink, n): host arrays for n records (n + 1 offsets), nullptr fields when out of memory.
   // Statuses as BlockInflater's; MIDAS_SNPS_ERR_UNSUPPORTED: the device could not settle the record boundaries (the caller
   // decodes the host's way).  *bad_record: index of a record that overruns its block_size, -2: a block_size leaves its segment.
   int32_t (*run)(void* user, const uint8_t* comp_base, const InflateJob* jobs, size_t n_jobs, uint64_t buffer_bytes, DecodeSegment* segs,
@@ -84,7 +97,14 @@ struct DeviceDecoder {
                  void* sink, DeviceDecodeResult* out, int64_t* bad_job, int64_t* bad_record, char* err256);
 };
 int32_t bam_decode_on_device(const char* path, const DeviceDecoder* dec, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
-                             int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+                             int64_t* qual_bytes, int64_t* n_cigar, char* err256, int payload = 1);
+// a handle decoded with payload == 2: its device columns (nullptr: it is not such a handle), record count and array totals
+const ResidentReads* bam_resident(const midas_bam* b, int64_t* n_records, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar);
+// midas_bam_resident_to_columns (snps_abi.hip): the handle's host columns for n records (false: out of memory); then the handle
+// is as after midas_bam_load_device -- small columns in host memory, the three payload columns at the given device addresses,
+// `owner` (freed with the handle, besides what it holds already) keeping them alive
+bool bam_alloc_host_columns(midas_bam* b, int64_t n, HostColumns* c);
+void bam_resident_became_columns(midas_bam* b, void* seq4, void* qual, void* cigar, void* owner, void (*free_fn)(void*));
 // midas_bam_open_slice / midas_bam_load_ranges with the device doing the work (dec == nullptr: the host's threads, as before):
 // the slice's blocks are inflated and walked on the device, the host folds the records' columns into the slice's facts; a
 // rank's record ranges are decoded like a whole file, SEQ / QUAL / CIGAR staying on the device
@@ -92,7 +112,7 @@ int32_t bam_open_slice_with(const char* path, int32_t slice, int32_t n_slices, c
 int32_t bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3, char* err256);
 int32_t bam_load_ranges_on_device(midas_bam* bam, const DeviceDecoder* dec, int32_t n_ranges, const int64_t* range_begin,
                                   const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
-                                  int64_t* n_cigar, char* err256);
+                                  int64_t* n_cigar, char* err256, int payload = 1);
 
 // Members whose DEFLATE streams exist already (the device's row coder): frame them (this library's gzip header with the
 // member's size and row count, CRC-32, ISIZE) and write them in order behind the header line's member.

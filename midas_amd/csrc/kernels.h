@@ -321,10 +321,19 @@ struct BamColumnsParams {
   int32_t n_ref;                                    // references of the header: a kept record's refID must lie below it
   int32_t *refid, *pos, *nm, *l_seq; uint8_t* mapq; uint16_t* flag;
   long long *seq_off, *qual_off, *cigar_off;        // n + 1 entries: lengths at [i + 1] here, CSR offsets after the scans
+  long long* unit_off;                              // (nullable) n + 1 entries: 8-byte units of the record's direct-layout payload, then their scan
   int32_t* span;                                    // (nullable) reference span: the lengths of the record's M / D / N / = / X ops
   unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size or whose
                                                     // refID names no reference of the header (~0: none)
 };
+// the records of an inflated stream as the direct layout (layout.h): DirectRec[n + 1] + payload, one copy of every record's
+// [cigar][seq][qual] run; pos / nm: the columns bam_columns_kernel decoded, unit_off: its scanned payload units
+struct BamDirectParams {
+  const uint8_t* stream; const unsigned long long* rec_off; long long n_records;
+  const int32_t* pos; const int32_t* nm; const long long* unit_off;
+  DirectRec* rec; uint8_t* payload;
+};
+hipError_t launch_bam_direct(const BamDirectParams& p, int grid_blocks, hipStream_t s);
 hipError_t launch_bam_walk(const BamWalkParams& p, const long long* list, long long n_list, hipStream_t s);
 hipError_t launch_bam_offsets(const BamWalkParams& p, const unsigned long long* base, unsigned long long* rec_off, hipStream_t s);
 size_t bam_scan_scratch_bytes(long long n_records);
