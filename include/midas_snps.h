@@ -412,6 +412,32 @@ int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* 
 int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
                                      const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                      int64_t* n_cigar, char* err256);
+/* ONE pass from the BAM's bytes to the pileup kernel's input (round 6).  The reference opens the BAM and counts in one go
+ * (midas/run/snps.py:186-199); so does this: the decode above with NOTHING cut into columns and gathered back -- a record's CIGAR
+ * ops, 4-bit SEQ and QUAL are one run of its bytes, in the order the direct path's payload has, and the device decoder copies that
+ * run ONCE into the payload and writes the read's 16-byte record beside it.  Every column stays where the device decoded it
+ * ("resident"); the host gets refID alone (midas_bam_columns: entry 0, the others NULL -- it groups the records by contig with it).
+ *   midas_bam_load_resident          = midas_bam_load_device; *sum_l_seq: the bases of all records (what a caller sizes batches by)
+ *   midas_bam_load_ranges_resident   = midas_bam_load_ranges_device
+ *   midas_snps_batch_create_resident = midas_snps_batch_create over the handle's records [first_read, first_read +
+ *                                      contigs->read_begin[n_contigs]) where they lie: nothing is uploaded, copied or built; the
+ *                                      batch's facts pass validates them as it validates a caller's arrays.  The batch borrows the
+ *                                      handle's device memory: midas_bam_close comes AFTER midas_snps_batch_destroy.  The packed and the
+ *                                      long path (unsorted positions, coverage hot spots, reads beyond the fast paths' limits) cut
+ *                                      their three payload columns out of the handle's inflated stream when first asked for.
+ *   midas_bam_resident_to_columns    the fall-back for a host that must regroup or slice the records (contigs it does not
+ *                                      want among them, pieces of long contigs): the small columns come down, SEQ / QUAL /
+ *                                      CIGAR are cut into device columns -- the handle then answers as after midas_bam_load_device
+ *                                      (and stays resident as well).
+ * MIDAS_SNPS_ERR_UNSUPPORTED: more than 32 GiB of read payload in one decode (the record's offset is 32 bits of 8-byte units):
+ * decode with midas_bam_load_device instead.                                                                                    */
+int32_t midas_bam_load_resident(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* sum_l_seq, char* err256);
+int32_t midas_bam_load_ranges_resident(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
+                                       const int64_t* range_end, int64_t* n_reads, int64_t* sum_l_seq, char* err256);
+int32_t midas_bam_is_resident(const midas_bam* bam);
+int32_t midas_bam_resident_to_columns(midas_bam* bam, midas_snps_ctx* ctx, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256);
+int32_t midas_snps_batch_create_resident(midas_snps_ctx* ctx, const midas_snps_contigs* contigs, const midas_bam* bam, int64_t first_read,
+                                         midas_snps_batch** out_batch);
 int32_t midas_snps_inflate_blocks(midas_snps_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, int64_t n_blocks,
                                   const int64_t* cpos, const int32_t* clen, const int64_t* upos, const int32_t* ulen,
                                   const uint32_t* crc, uint8_t* out, int64_t out_bytes, int64_t* bad_block);

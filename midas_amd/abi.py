@@ -150,6 +150,32 @@ class ReadsSoA:
                       self.cigar_off.ctypes.data_as(C.c_void_p), *payload)
 
 
+class ResidentReads:
+    """The records of a BAM decoded on a Context's device with EVERY column left there, in the pileup kernel's own layout
+    (read_bam(..., resident=True), midas_bam_load_resident): what the host holds is the count, the bases' total and the native
+    handle.  Only that context's Batch takes them -- records [first, first + n) of the handle, where they lie; a host that must
+    look into the columns asks Context.fetch_payload, which turns them into an ordinary ReadsSoA (midas_bam_resident_to_columns)."""
+    device = ('resident',)        # (read like ReadsSoA.device: "not in host memory")
+
+    def __init__(self, lib, handle, owner, n_reads: int, l_seq_total: int, first: int = 0):
+        self._lib, self._h, self.owner = lib, handle, owner
+        self._n, self.l_seq_total, self.first = int(n_reads), int(l_seq_total), int(first)
+
+    @property
+    def n_reads(self) -> int:
+        return self._n
+
+    def to_columns(self, ctx) -> "ReadsSoA":
+        """The same records as a ReadsSoA whose SEQ / QUAL / CIGAR are device columns (as read_bam(payload_on_device=True)'s)."""
+        sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        err = C.create_string_buffer(256)
+        st = self._lib.midas_bam_resident_to_columns(self._h, ctx._h, C.byref(sb), C.byref(qb), C.byref(nc), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        _, reads = _bam_columns(self._lib, self._h, self._n, int(sb.value), int(qb.value), int(nc.value), self.owner, on_device=True)
+        return reads
+
+
 @dataclass
 class ContigTable:
     """Flattened `contigs` dict of midas/run/snps.py:55-67 (see midas_snps_contigs)."""
@@ -258,6 +284,11 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_open_slice_device': (i32, [C.c_char_p, i32, i32, vp, C.POINTER(vp), C.c_char_p]),
         'midas_bam_load_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_payload_on_device': (i32, [vp]),
+        'midas_bam_load_resident': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_bam_load_ranges_resident': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_bam_is_resident': (i32, [vp]),
+        'midas_bam_resident_to_columns': (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
+        'midas_snps_batch_create_resident': (i32, [vp, C.POINTER(_Contigs), vp, i64, C.POINTER(vp)]),
         'midas_snps_copy_from_device': (i32, [vp, vp, vp, i64]),
         'midas_bam_load_ranges_device': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_inflate_blocks': (i32, [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, C.POINTER(i64)]),
@@ -321,6 +352,8 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
     'midas_bam_open_device', 'midas_bam_open_slice_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
     'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
+    'midas_bam_load_resident', 'midas_bam_load_ranges_resident', 'midas_bam_is_resident', 'midas_bam_resident_to_columns',
+    'midas_snps_batch_create_resident',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_fasta_load', 'midas_fasta_n_records', 'midas_fasta_columns', 'midas_fasta_close',
@@ -511,7 +544,7 @@ def read_snps_counts(paths, row_begin: int = 0, max_rows: int = -1):
         lib.midas_snps_tableset_close(h)
 
 
-def read_bam(path: str, ctx=None, payload_on_device: bool = False):
+def read_bam(path: str, ctx=None, payload_on_device: bool = False, resident: bool = False):
     """Decode a BAM with the native reader -> (ref_names, ref_lengths, refid[int32], ReadsSoA).  The arrays are views of
     the decoder's own buffers (no copy); the native handle lives as long as any of them does.  ctx (a Context): the BGZF
     blocks are inflated on its device instead of by the host's threads (midas_bam_open_device); with payload_on_device SEQ,
@@ -520,6 +553,23 @@ def read_bam(path: str, ctx=None, payload_on_device: bool = False):
     lib = load_library()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
+    if resident:
+        # ONE pass from the BAM's bytes to the kernel's input: every column stays on the device, in the direct layout; refID
+        # alone comes down (midas_bam_load_resident).  More payload than the layout addresses: the columns' way.
+        if ctx is None or not getattr(ctx, 'inflates', False):
+            raise MidasSnpsError(ERR_INVALID_ARG, "resident needs a device context")
+        n, total = C.c_int64(), C.c_int64()
+        st = lib.midas_bam_load_resident(path.encode(), ctx._h, C.byref(h), C.byref(n), C.byref(total), err)
+        if st == ERR_UNSUPPORTED:
+            return read_bam(path, ctx, payload_on_device=True)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        owner = _BamOwner(lib, h)
+        names, lens = _bam_refs(lib, h)
+        ptrs = (C.c_void_p * 12)()
+        lib.midas_bam_columns(h, ptrs)
+        refid = np.asarray(_Column(owner, ptrs[0] or 0, int(n.value), np.int32))
+        return names, lens, refid, ResidentReads(lib, h, owner, int(n.value), int(total.value))
     if payload_on_device:
         if ctx is None or not getattr(ctx, 'inflates', False):
             raise MidasSnpsError(ERR_INVALID_ARG, "payload_on_device needs a device context")
@@ -687,7 +737,7 @@ class BamSlice:
             self._lib.midas_bam_slice_marks(self._h, p(out4), None, p(marks), marks.shape[0])
         return int(out4[0]), int(out4[1]), int(out4[2]), span, marks
 
-    def load_ranges(self, ranges, ctx=None):
+    def load_ranges(self, ranges, ctx=None, resident: bool = False):
         """[(begin, end)] uncompressed record ranges -> (refid int32, ReadsSoA) of the records in them, in file order.
         ctx (a Context): the ranges are decoded on its device and SEQ / QUAL / CIGAR stay there (midas_bam_load_ranges_device):
         the ReadsSoA carries their device addresses (`device`), as read_bam(..., payload_on_device=True)'s does."""
@@ -696,6 +746,20 @@ class BamSlice:
         n, sb, qb, nc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         err = C.create_string_buffer(256)
         p = lambda x: x.ctypes.data_as(C.c_void_p)
+        if resident and ctx is not None and getattr(ctx, 'inflates', False) and len(ranges):
+            # (everything stays on the device, in the direct layout: read_bam(..., resident=True)'s form for a rank's ranges)
+            total = C.c_int64()
+            st = self._lib.midas_bam_load_ranges_resident(self._h, ctx._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(total), err)
+            if st == 0 and self._lib.midas_bam_is_resident(self._h):
+                keeper = _BamOwner(self._lib, None)
+                keeper._slice = self
+                ptrs = (C.c_void_p * 12)()
+                self._lib.midas_bam_columns(self._h, ptrs)
+                refid = np.asarray(_Column(keeper, ptrs[0] or 0, int(n.value), np.int32))
+                return refid, ResidentReads(self._lib, self._h, keeper, int(n.value), int(total.value))
+            if st != ERR_UNSUPPORTED:
+                if st != 0:
+                    raise MidasSnpsError(st, err.value.decode())
         if ctx is not None and getattr(ctx, 'inflates', False):
             st = self._lib.midas_bam_load_ranges_device(self._h, ctx._h, len(ranges), p(rb), p(re_), C.byref(n), C.byref(sb),
                                                         C.byref(qb), C.byref(nc), err)
@@ -844,6 +908,8 @@ class Context:
         columns copied down: for tests, and for host code that has to slice them."""
         if reads.device is None:
             return reads
+        if isinstance(reads, ResidentReads):
+            reads = reads.to_columns(self)
         n = reads.n_reads
         sizes = (int(reads.seq_off[n]), int(reads.qual_off[n]), int(reads.cigar_off[n]) * 4)
         out = [np.zeros(max(s, 1), np.uint8) for s in sizes]
@@ -1041,8 +1107,13 @@ class Batch:
         self.n_sites = contigs.n_sites
         self.n_species = int(contigs.n_species)
         h = C.c_void_p()
-        c, r = contigs._c(), reads._c()
-        ctx._check(self._lib.midas_snps_batch_create(ctx._h, C.byref(c), C.byref(r), C.byref(h)))
+        c = contigs._c()
+        if isinstance(reads, ResidentReads):       # the handle's records where they lie (and the handle alive as long as the batch)
+            self._keep = reads.owner
+            ctx._check(self._lib.midas_snps_batch_create_resident(ctx._h, C.byref(c), reads._h, reads.first, C.byref(h)))
+        else:
+            r = reads._c()
+            ctx._check(self._lib.midas_snps_batch_create(ctx._h, C.byref(c), C.byref(r), C.byref(h)))
         self._h = h
 
     def close(self):

@@ -75,6 +75,15 @@ def group_by_contig(ref_names, refid, reads, contig_ids, fetch=None):
             read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
             np.cumsum(hi - lo, out=read_begin[1:])
             return reads, read_begin
+        # records that stayed on the device in the kernel's own layout (abi.ResidentReads): ONE run of them -- the wanted
+        # contigs next to each other in the file, as the contigs of a batch are -- is taken where it lies
+        if hasattr(reads, 'l_seq_total') and int((hi - lo).sum()) == int(hi[-1] - lo[0]):
+            from .abi import ResidentReads
+            read_begin = np.zeros(len(contig_ids) + 1, dtype=np.int64)
+            np.cumsum(hi - lo, out=read_begin[1:])
+            run = int(hi[-1] - lo[0])
+            share = reads.l_seq_total * run // max(1, reads.n_reads)
+            return ResidentReads(reads._lib, reads._h, reads.owner, run, share, first=reads.first + int(lo[0])), read_begin
     if getattr(reads, 'device', None) is not None:
         if fetch is None:
             raise ValueError("the reads' SEQ / QUAL / CIGAR are on the device: fetch them (Context.fetch_payload) before regrouping")

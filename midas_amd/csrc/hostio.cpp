@@ -1024,8 +1024,9 @@ static int parse_bam_header(const uint8_t* d, size_t n, midas_bam* b) {
   return 0;
 }
 
-static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c);
-bool midas::bam_alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) { return alloc_host_columns(b, n, c); }
+static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c, bool keep_refid = false);
+// (a resident handle's refID column is in use -- the host holds views of it: it stays where it is)
+bool midas::bam_alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) { return alloc_host_columns(b, n, c, b->resident); }
 const midas::ResidentReads* midas::bam_resident(const midas_bam* b, int64_t* n_records, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar) {
   if (!b || !b->resident) return nullptr;
   if (n_records) *n_records = (int64_t)b->n_records;
@@ -1063,9 +1064,9 @@ static void adopt_device_result(midas_bam* b, const midas::DeviceDecodeResult& r
     b->dev_payload[0] = res.dev_seq; b->dev_payload[1] = res.dev_qual; b->dev_payload[2] = res.dev_cigar;
   }
 }
-static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c) {
+static bool alloc_host_columns(midas_bam* b, int64_t n, midas::HostColumns* c, bool keep_refid) {
   const size_t n1 = n > 0 ? (size_t)n : 1;
-  if (!b->refid.resize(n1) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
+  if ((!keep_refid && !b->refid.resize(n1)) || !b->pos.resize(n1) || !b->nm.resize(n1) || !b->l_seq.resize(n1) || !b->mapq.resize(n1) ||
       !b->flag.resize(n1) || !b->seq_off.resize((size_t)n + 1) || !b->qual_off.resize((size_t)n + 1) || !b->cigar_off.resize((size_t)n + 1))
     return false;
   c->refid = b->refid.data(); c->pos = b->pos.data(); c->nm = b->nm.data(); c->l_seq = b->l_seq.data(); c->mapq = b->mapq.data();

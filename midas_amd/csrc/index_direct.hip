@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
       continue;
     }
     CigarView cg;
-    cg.load(p.cigar + f.co);
+    cg.load(p.rec ? reinterpret_cast<const uint32_t*>(p.payload + ((unsigned long long)p.rec[i].off8 << 3)) : p.cigar + f.co);
     // reference span: what the ranges kernel must reach over (sites from the read's start to its last aligned base)
     unsigned long long span = 0;
     for_each_op(cg, (uint32_t)nc, [&](uint32_t, uint32_t v) {

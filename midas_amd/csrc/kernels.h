@@ -195,6 +195,7 @@ struct DirectIndexParams {
   const int32_t* pos; const int32_t* nm; const int32_t* l_seq;
   const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
   const uint32_t* cigar;
+  const DirectRec* rec; const uint8_t* payload;   // (facts pass of a resident batch, which has no CIGAR column: a read's ops open its payload run; else nullptr)
   int64_t seq_bytes, qual_bytes, n_cigar;
   int32_t n_reads;
   const int32_t* contig_read_begin; const int32_t* contig_tile_base; const int32_t* contig_len;

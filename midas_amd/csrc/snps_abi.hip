@@ -49,6 +49,14 @@ struct midas_snps_batch {
   uint8_t* d_qual = nullptr;
   uint32_t* d_cigar = nullptr;
   int64_t seq_bytes = 0, qual_bytes = 0, n_cigar = 0;
+  // midas_snps_batch_create_resident: the reads are a run of a device-decoded BAM's records.  The columns above and the direct
+  // layout below point INTO the BAM handle's device memory (not owned: the caller keeps the handle open); SEQ / QUAL / CIGAR
+  // as columns do not exist until a path that reads them asks (ensure_raw_payload: cut out of the handle's inflated stream
+  // into raw_owned, the three pointers biased so that the BAM's absolute CSR offsets index them)
+  bool resident = false;
+  midas::ResidentReads rr;
+  int64_t rr_first = 0;
+  void* raw_owned = nullptr;
   // device: scratch of the packer (one slab each: per read, per record)
   uint8_t* d_pack_reads = nullptr;    // nseg, cnt, first, facts, bin_start, tile_extra, tile_reads
   uint8_t* d_pack_recs = nullptr;     // sort keys / values (in + out), bytes8, dest, bytes8_dev, off8
@@ -1040,6 +1048,7 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   cp.seq_off = reinterpret_cast<long long*>(take(n1 * 8)); cp.qual_off = reinterpret_cast<long long*>(take(n1 * 8));
   cp.cigar_off = reinterpret_cast<long long*>(take(n1 * 8));
   cp.span = extra ? reinterpret_cast<int32_t*>(take(n1 * 4)) : nullptr;
+  cp.unit_off = payload == 2 ? reinterpret_cast<long long*>(take(n1 * 8)) : nullptr;
   cp.bad_record = reinterpret_cast<unsigned long long*>(take(8));
   long long* d_scan = reinterpret_cast<long long*>(take(bam_scan_scratch_bytes(n)));
   if (!d_scan) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the columns"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
@@ -1047,15 +1056,53 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   DEC_TRY(launch_bam_offsets(wp, d_base, d_rec, s));
   DEC_TRY(launch_bam_columns(cp, d_scan, s));
   unsigned long long h_bad_record = ~0ull;
-  long long ends[3] = {0, 0, 0};
+  long long ends[4] = {0, 0, 0, 0};
   DEC_TRY(hipMemcpyAsync(&h_bad_record, cp.bad_record, 8, hipMemcpyDeviceToHost, s));
   DEC_TRY(hipMemcpyAsync(&ends[0], cp.seq_off + n, 8, hipMemcpyDeviceToHost, s));
   DEC_TRY(hipMemcpyAsync(&ends[1], cp.qual_off + n, 8, hipMemcpyDeviceToHost, s));
   DEC_TRY(hipMemcpyAsync(&ends[2], cp.cigar_off + n, 8, hipMemcpyDeviceToHost, s));
+  if (cp.unit_off) DEC_TRY(hipMemcpyAsync(&ends[3], cp.unit_off + n, 8, hipMemcpyDeviceToHost, s));
   DEC_TRY(hipStreamSynchronize(s));
   lap("offsets, columns, scans");
   if (h_bad_record != ~0ull) { *bad_record = (int64_t)h_bad_record; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   const int64_t sb = ends[0], qb = ends[1], nc = ends[2];
+  if (payload == 2) {
+    // ---- resident: the records in the pileup kernel's own layout, ONE copy of every record's [cigar][seq][qual] run; every
+    // column stays where it was decoded and only refID comes down (the host groups the records by contig with it) -------------
+    const unsigned long long units = (unsigned long long)ends[3];
+    if (units > kMaxDirectPayloadUnits) {
+      if (err256) snprintf(err256, 256, "device decode: %llu bytes of read payload exceed the 32 GiB the direct layout addresses", units * 8ull);
+      return MIDAS_SNPS_ERR_UNSUPPORTED;
+    }
+    DirectRec* d_drec = reinterpret_cast<DirectRec*>(take((n1 + 1) * sizeof(DirectRec)));
+    uint8_t* d_pay = take((size_t)units * 8 + 64);
+    if (!d_pay) { if (err256) snprintf(err256, 256, "device decode: the arena is too small for the direct layout"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+    DEC_TRY(hipMemsetAsync(d_pay + (size_t)units * 8, 0, 64, s));       // (a lane's 16-byte loads may overhang the last read)
+    BamDirectParams dp;
+    dp.stream = base; dp.rec_off = d_rec; dp.n_records = n;
+    dp.pos = cp.pos; dp.nm = cp.nm; dp.unit_off = cp.unit_off;
+    dp.rec = d_drec; dp.payload = d_pay;
+    DEC_TRY(launch_bam_direct(dp, ctx->prop.multiProcessorCount, s));
+    const HostColumns hc = alloc(sink, n);
+    if (!hc.refid) { DEC_TRY(hipStreamSynchronize(s)); return MIDAS_SNPS_OK; }      // (the caller reports its own out-of-memory)
+    if (n > 0) {
+      const int32_t dst = copy_to_host(ctx, hc.refid, cp.refid, (size_t)n * 4);
+      if (dst != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->error_text().c_str()); return dst; }
+    }
+    DEC_TRY(hipStreamSynchronize(s));
+    lap("direct layout, refID down");
+    res->n_records = n; res->seq_bytes = sb; res->qual_bytes = qb; res->n_cigar = nc;
+    ResidentReads& rr = res->resident;
+    rr.rec = d_drec; rr.payload = d_pay; rr.refid = cp.refid; rr.pos = cp.pos; rr.nm = cp.nm; rr.l_seq = cp.l_seq; rr.mapq = cp.mapq; rr.flag = cp.flag;
+    rr.seq_off = reinterpret_cast<int64_t*>(cp.seq_off); rr.qual_off = reinterpret_cast<int64_t*>(cp.qual_off);
+    rr.cigar_off = reinterpret_cast<int64_t*>(cp.cigar_off); rr.unit_off = reinterpret_cast<int64_t*>(cp.unit_off);
+    rr.stream = base; rr.rec_off = reinterpret_cast<const uint64_t*>(d_rec);
+    rr.payload_units = (int64_t)units;
+    res->dev_owner = new ArenaLoan{loan.pool, loan.p};       // everything lives in the arena: it stays lent until the handle is closed
+    res->dev_free = arena_loan_free;
+    loan.p = nullptr;
+    return MIDAS_SNPS_OK;
+  }
   // ---- SEQ / QUAL / CIGAR cut out of the stream, behind everything taken so far ---------------------------------------------
   uint8_t *d_seq = nullptr, *d_qual = nullptr, *d_cig = nullptr;
   struct Own { void* p = nullptr; ~Own() { if (p) (void)hipFree(p); } } own;
@@ -1126,6 +1173,82 @@ int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam**
   return bam_load_device_host_walk(path, ctx, out, n_reads, seq_bytes, qual_bytes, n_cigar, err256);      // (boundaries not settled: the host walks)
 }
 
+int32_t midas_bam_load_resident(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* sum_l_seq, char* err256) {
+  if (!ctx || !path || !out) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const DeviceDecoder dec{ctx, device_decode_run};
+  int64_t qb = 0;
+  const int32_t st = bam_decode_on_device(path, &dec, out, n_reads, nullptr, &qb, nullptr, err256, 2);
+  if (sum_l_seq) *sum_l_seq = qb;       // (QUAL holds one byte per base)
+  return st;
+}
+
+int32_t midas_bam_load_ranges_resident(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
+                                       const int64_t* range_end, int64_t* n_reads, int64_t* sum_l_seq, char* err256) {
+  if (!bam || !ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  const DeviceDecoder dec{ctx, device_decode_run};
+  int64_t qb = 0;
+  const int32_t st = bam_load_ranges_on_device(bam, &dec, n_ranges, range_begin, range_end, n_reads, nullptr, &qb, nullptr, err256, 2);
+  if (sum_l_seq) *sum_l_seq = qb;
+  return st;
+}
+
+int32_t midas_bam_is_resident(const midas_bam* bam) { return bam_resident(bam, nullptr, nullptr, nullptr, nullptr) ? 1 : 0; }
+
+// The fall-back of a resident handle: the three payload columns cut out of the inflated stream it still holds (a buffer of
+// their own), the small columns brought down -- afterwards the handle answers midas_bam_columns as after midas_bam_load_device.
+int32_t midas_bam_resident_to_columns(midas_bam* bam, midas_snps_ctx* ctx, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256) {
+  if (!bam || !ctx) return MIDAS_SNPS_ERR_INVALID_ARG;
+  int64_t n = 0, sb = 0, qb = 0, nc = 0;
+  const midas::ResidentReads* rr = bam_resident(bam, &n, &sb, &qb, &nc);
+  if (!rr) { if (err256) snprintf(err256, 256, "the BAM handle holds no device-resident records"); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  if (seq_bytes) *seq_bytes = sb;
+  if (qual_bytes) *qual_bytes = qb;
+  if (n_cigar) *n_cigar = nc;
+  if (midas_bam_payload_on_device(bam)) return MIDAS_SNPS_OK;         // (done before)
+  auto hip_err = [&](hipError_t e, const char* what) {
+    if (err256) snprintf(err256, 256, "resident BAM to columns: %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP;
+  };
+#define RC_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
+  std::lock_guard<std::mutex> g(ctx->device_mutex);
+  RC_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t at_q = up((size_t)sb + 64), at_c = at_q + up((size_t)qb + 64), bytes = at_c + up((size_t)nc * 4 + 64);
+  struct Own { void* p = nullptr; ~Own() { if (p) (void)hipFree(p); } } own;
+  RC_TRY(hipMalloc(&own.p, bytes));
+  uint8_t* base = static_cast<uint8_t*>(own.p);
+  RC_TRY(hipMemsetAsync(base + sb, 0, 64, s));
+  RC_TRY(hipMemsetAsync(base + at_q + qb, 0, 64, s));
+  RC_TRY(hipMemsetAsync(base + at_c + (size_t)nc * 4, 0, 64, s));
+  PayloadParams pp;
+  pp.stream = rr->stream;
+  pp.rec_off = reinterpret_cast<const unsigned long long*>(rr->rec_off);
+  pp.n_records = n;
+  pp.seq_off = reinterpret_cast<const long long*>(rr->seq_off); pp.qual_off = reinterpret_cast<const long long*>(rr->qual_off);
+  pp.cigar_off = reinterpret_cast<const long long*>(rr->cigar_off);
+  pp.seq4 = base; pp.qual = base + at_q; pp.cigar = reinterpret_cast<uint32_t*>(base + at_c);
+  RC_TRY(launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
+  HostColumns hc{};
+  if (!bam_alloc_host_columns(bam, n, &hc)) { if (err256) snprintf(err256, 256, "resident BAM to columns: out of host memory"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  const size_t n1 = (size_t)n + 1;
+  const std::pair<void*, std::pair<const void*, size_t>> cols[] = {
+      {hc.pos, {rr->pos, (size_t)n * 4}}, {hc.nm, {rr->nm, (size_t)n * 4}}, {hc.l_seq, {rr->l_seq, (size_t)n * 4}}, {hc.mapq, {rr->mapq, (size_t)n}},
+      {hc.flag, {rr->flag, (size_t)n * 2}}, {hc.seq_off, {rr->seq_off, n1 * 8}}, {hc.qual_off, {rr->qual_off, n1 * 8}}, {hc.cigar_off, {rr->cigar_off, n1 * 8}}};
+  for (const auto& c : cols) {
+    if (!c.second.second) continue;
+    const int32_t st = copy_to_host(ctx, c.first, c.second.first, c.second.second);
+    if (st != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "resident BAM to columns: %s", ctx->error_text().c_str()); return st; }
+  }
+  // (refID is in the handle's host memory already, and stays there: the caller holds views of it)
+  RC_TRY(hipStreamSynchronize(s));
+#undef RC_TRY
+  bam_resident_became_columns(bam, base, base + at_q, base + at_c, own.p, device_free);
+  own.p = nullptr;
+  return MIDAS_SNPS_OK;
+}
+
 int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* src, int64_t bytes) {
   if (!ctx || bytes < 0 || (bytes > 0 && (!dst || !src))) return MIDAS_SNPS_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> g(ctx->device_mutex);
@@ -1181,6 +1304,11 @@ int32_t midas_snps_device_info(const midas_snps_ctx* ctx, char* name256, int32_t
 void midas_snps_batch_destroy(midas_snps_batch* b) {
   if (!b) return;
   if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  if (b->resident) {      // (borrowed from the BAM handle, or biased into raw_owned)
+    b->d_pos = nullptr; b->d_mapq = nullptr; b->d_nm = nullptr; b->d_lseq = nullptr; b->d_seq_off = nullptr; b->d_qual_off = nullptr;
+    b->d_cigar_off = nullptr; b->d_seq4 = nullptr; b->d_qual = nullptr; b->d_cigar = nullptr; b->d_drec = nullptr; b->d_dpay = nullptr;
+    (void)hipFree(b->raw_owned);
+  }
   void* dev[] = {b->d_pos, b->d_mapq, b->d_nm, b->d_lseq, b->d_seq_off, b->d_qual_off, b->d_cigar_off, b->d_seq4, b->d_qual,
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
@@ -1337,11 +1465,49 @@ int32_t run_pack(midas_snps_batch* b, hipEvent_t* ev) {
 uint32_t* trange_begin(midas_snps_batch* b, int par) { return b->d_trange + (size_t)par * 2 * (b->n_tiles > 0 ? b->n_tiles : 1); }
 uint32_t* trange_end(midas_snps_batch* b, int par) { return trange_begin(b, par) + (b->n_tiles > 0 ? b->n_tiles : 1); }
 
+// SEQ / QUAL / CIGAR of a resident batch as the three columns the packed and the long path read: cut out of the BAM handle's
+// inflated stream on first use (bam_payload_kernel over the batch's records), into one buffer of the batch's own; the
+// pointers are biased by the first read's offsets, so the BAM's absolute CSR offsets index them.
+int32_t ensure_raw_payload(midas_snps_batch* b) {
+  if (!b->resident || b->raw_owned || b->n_reads <= 0) return MIDAS_SNPS_OK;
+  midas_snps_ctx* ctx = b->ctx;
+  hipStream_t s = ctx->stream;
+  long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  const int64_t* offs[3] = {b->d_seq_off, b->d_qual_off, b->d_cigar_off};
+  for (int k = 0; k < 3; ++k) {
+    HIP_TRY(ctx, hipMemcpyAsync(&lo[k], offs[k], 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&hi[k], offs[k] + b->n_reads, 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t sb = (size_t)(hi[0] - lo[0]), qb = (size_t)(hi[1] - lo[1]), cb = (size_t)(hi[2] - lo[2]) * 4;
+  const size_t at_q = up(sb + 64), at_c = at_q + up(qb + 64), bytes = at_c + up(cb + 64);
+  HIP_TRY(ctx, hipMalloc(&b->raw_owned, bytes));
+  uint8_t* base = static_cast<uint8_t*>(b->raw_owned);
+  HIP_TRY(ctx, hipMemsetAsync(base + sb, 0, 64, s));
+  HIP_TRY(ctx, hipMemsetAsync(base + at_q + qb, 0, 64, s));
+  HIP_TRY(ctx, hipMemsetAsync(base + at_c + cb, 0, 64, s));
+  b->d_seq4 = base - lo[0];
+  b->d_qual = base + at_q - lo[1];
+  b->d_cigar = reinterpret_cast<uint32_t*>(base + at_c) - lo[2];
+  PayloadParams pp;
+  pp.stream = b->rr.stream;
+  pp.rec_off = reinterpret_cast<const unsigned long long*>(b->rr.rec_off) + b->rr_first;
+  pp.n_records = b->n_reads;
+  pp.seq_off = reinterpret_cast<const long long*>(b->d_seq_off); pp.qual_off = reinterpret_cast<const long long*>(b->d_qual_off);
+  pp.cigar_off = reinterpret_cast<const long long*>(b->d_cigar_off);
+  pp.seq4 = b->d_seq4; pp.qual = b->d_qual; pp.cigar = b->d_cigar;
+  HIP_TRY(ctx, launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
+  return MIDAS_SNPS_OK;
+}
+
 void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   const int par = (int)(b->direct_run_count & 1);
   ip->pos = b->d_pos; ip->nm = b->d_nm; ip->l_seq = b->d_lseq;
   ip->seq_off = b->d_seq_off; ip->qual_off = b->d_qual_off; ip->cigar_off = b->d_cigar_off;
   ip->cigar = b->d_cigar;
+  ip->rec = b->resident ? b->d_drec : nullptr;          // (a resident batch has no CIGAR column: the facts pass reads the ops in the payload)
+  ip->payload = b->resident ? b->d_dpay : nullptr;
   ip->seq_bytes = b->seq_bytes; ip->qual_bytes = b->qual_bytes; ip->n_cigar = b->n_cigar;
   ip->n_reads = (int32_t)b->n_reads;
   ip->contig_read_begin = b->d_contig_read_begin; ip->contig_tile_base = b->d_contig_tile_base; ip->contig_len = b->d_contig_len;
@@ -1403,8 +1569,8 @@ int32_t direct_prepare(midas_snps_batch* b) {
   b->direct_lane_bases = direct_lane_bases(b->max_l_seq);
   b->direct_lanes_per_read = b->max_l_seq <= b->direct_lane_bases ? 1 : (b->max_l_seq + b->direct_lane_bases - 1) / b->direct_lane_bases;
   // the direct layout: one 16-byte record per read and its CIGAR / SEQ / QUAL bytes as one run of the payload (every read
-  // was validated above)
-  {
+  // was validated above).  A resident batch has it already: the device decoder wrote it (bam_walk.hip, bam_direct_kernel).
+  if (!b->resident) {
     const size_t n1 = (size_t)(b->n_reads > 0 ? b->n_reads : 1);
     const int nb = direct_index_blocks(b->n_reads);
     HIP_TRY(ctx, hipMalloc(&b->d_drec, (n1 + 1) * sizeof(DirectRec)));
@@ -1436,6 +1602,7 @@ int32_t direct_prepare(midas_snps_batch* b) {
     lp.payload = b->d_dpay;
     if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_layout_fill(lp, s));
   }
+  if (b->resident) b->direct_payload_bytes = b->rr.payload_units * 8;
   // the tile ranges once, to see how well the reads are ordered: a tile's stream holds every read between the first and the
   // last that can touch it
   fill_direct_index(b, &ip);
@@ -1473,6 +1640,10 @@ int32_t ensure_packed(midas_snps_batch* b) {
   if (b->packed_built) return MIDAS_SNPS_OK;
   midas_snps_ctx* ctx = b->ctx;
   if (b->n_long > 0) return fail(ctx, MIDAS_SNPS_ERR_UNSUPPORTED, "the batch holds reads beyond the packed layout's limits: it has the long path only");
+  {
+    const int32_t rst = ensure_raw_payload(b);
+    if (rst != MIDAS_SNPS_OK) return rst;
+  }
   hipStream_t s = ctx->stream;
   char ebuf[256] = {0};
   const int64_t n = b->n_reads, n_sites = b->n_sites;
@@ -1612,9 +1783,14 @@ int32_t ensure_packed(midas_snps_batch* b) {
 
 extern "C" {
 
-int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
-                                const midas_snps_reads* reads, midas_snps_batch** out_batch) {
-  if (!ctx || !contigs || !reads || !out_batch) return MIDAS_SNPS_ERR_INVALID_ARG;
+}  // extern "C"
+
+namespace {
+// midas_snps_batch_create (reads: the caller's arrays, uploaded) and midas_snps_batch_create_resident (rbam: a device-decoded
+// BAM whose records [first, first + contigs->read_begin[n_contigs]) are the batch's reads, used where they lie)
+int32_t batch_create_impl(midas_snps_ctx* ctx, const midas_snps_contigs* contigs, const midas_snps_reads* reads, const midas_bam* rbam,
+                          int64_t first, midas_snps_batch** out_batch) {
+  if (!ctx || !contigs || (!reads && !rbam) || !out_batch) return MIDAS_SNPS_ERR_INVALID_ARG;
   *out_batch = nullptr;
   ctx->clear_error();
   ctx->err_read = -1;
@@ -1633,20 +1809,31 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
     fprintf(stderr, "[batch_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
-  int32_t st = validate_contigs(contigs, reads->n_reads, &n_sites, ebuf);
+  const midas::ResidentReads* rr = nullptr;
+  int64_t r_total = 0, r_sb = 0, r_qb = 0, r_nc = 0;
+  if (rbam) {
+    rr = bam_resident(rbam, &r_total, &r_sb, &r_qb, &r_nc);
+    if (!rr) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "the BAM handle holds no device-resident records (midas_bam_load_resident)");
+    if (contigs->n_contigs < 0 || (contigs->n_contigs > 0 && !contigs->read_begin)) return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "bad contig table header");
+  }
+  const int64_t n = rbam ? (contigs->n_contigs > 0 ? contigs->read_begin[contigs->n_contigs] : 0) : reads->n_reads;
+  int32_t st = validate_contigs(contigs, n, &n_sites, ebuf);
   if (st != MIDAS_SNPS_OK) return fail(ctx, st, ebuf);
-  const int64_t n = reads->n_reads;
   if (n < 0 || n > 2000000000LL) {
     snprintf(ebuf, sizeof ebuf, "n_reads %lld out of range", (long long)n);
     return fail(ctx, n < 0 ? MIDAS_SNPS_ERR_INVALID_ARG : MIDAS_SNPS_ERR_UNSUPPORTED, ebuf);
   }
-  if (n > 0 && (!reads->pos || !reads->mapq || !reads->nm || !reads->l_seq || !reads->seq_off || !reads->qual_off ||
-                !reads->cigar_off || !reads->seq4 || !reads->qual || !reads->cigar))
+  if (rbam && (first < 0 || first > r_total || n > r_total - first)) {
+    snprintf(ebuf, sizeof ebuf, "records [%lld, %lld) lie outside the BAM handle's %lld", (long long)first, (long long)(first + n), (long long)r_total);
+    return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, ebuf);
+  }
+  if (!rbam && n > 0 && (!reads->pos || !reads->mapq || !reads->nm || !reads->l_seq || !reads->seq_off || !reads->qual_off ||
+                         !reads->cigar_off || !reads->seq4 || !reads->qual || !reads->cigar))
     return fail(ctx, MIDAS_SNPS_ERR_INVALID_ARG, "NULL array in midas_snps_reads");
   // the CSR offsets' last entries are the array sizes (the device checks every read against them)
-  const int64_t seq_bytes = n > 0 ? reads->seq_off[n] : 0, qual_bytes = n > 0 ? reads->qual_off[n] : 0,
-                n_cigar = n > 0 ? reads->cigar_off[n] : 0;
-  if (seq_bytes < 0 || qual_bytes < 0 || n_cigar < 0 || (n > 0 && (reads->seq_off[0] < 0 || reads->qual_off[0] < 0 || reads->cigar_off[0] < 0)))
+  const int64_t seq_bytes = rbam ? r_sb : (n > 0 ? reads->seq_off[n] : 0), qual_bytes = rbam ? r_qb : (n > 0 ? reads->qual_off[n] : 0),
+                n_cigar = rbam ? r_nc : (n > 0 ? reads->cigar_off[n] : 0);
+  if (!rbam && (seq_bytes < 0 || qual_bytes < 0 || n_cigar < 0 || (n > 0 && (reads->seq_off[0] < 0 || reads->qual_off[0] < 0 || reads->cigar_off[0] < 0))))
     return fail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "negative CSR offset in midas_snps_reads");
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1730,6 +1917,16 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   // ---- upload the reads as they are: the packer runs on the device -----------------------------------------------
   // (64 bytes of slack behind the byte arrays: the packer's 16-byte loads may overhang the last read)
   const size_t n1 = (size_t)(n > 0 ? n : 1);
+  if (rbam) {
+    // ... or use them where the device decoder left them: the columns and the direct layout of the handle's records from `first` on
+    b->resident = true;
+    b->rr = *rr;
+    b->rr_first = first;
+    b->d_pos = rr->pos + first; b->d_mapq = rr->mapq + first; b->d_nm = rr->nm + first; b->d_lseq = rr->l_seq + first;
+    b->d_seq_off = rr->seq_off + first; b->d_qual_off = rr->qual_off + first; b->d_cigar_off = rr->cigar_off + first;
+    b->d_drec = static_cast<DirectRec*>(rr->rec) + first;
+    b->d_dpay = rr->payload;
+  } else {
   B_TRY(hipMalloc(&b->d_pos, n1 * 4));
   B_TRY(hipMalloc(&b->d_mapq, n1));
   B_TRY(hipMalloc(&b->d_nm, n1 * 4));
@@ -1762,6 +1959,7 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   B_TRY(hipMemsetAsync(b->d_seq4 + seq_bytes, 0, 64, s));
   B_TRY(hipMemsetAsync(b->d_qual + qual_bytes, 0, 64, s));
   B_TRY(hipMemsetAsync(b->d_cigar + n_cigar, 0, 64, s));
+  }
   lap("H2D raw reads");
 
   // ---- reference letters, workspace, outputs --------------------------------------------------------------------
@@ -1792,6 +1990,20 @@ int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* c
   lap("packed layout");
   *out_batch = b;
   return MIDAS_SNPS_OK;
+}
+}  // namespace
+
+extern "C" {
+int32_t midas_snps_batch_create(midas_snps_ctx* ctx, const midas_snps_contigs* contigs,
+                                const midas_snps_reads* reads, midas_snps_batch** out_batch) {
+  if (!reads) return MIDAS_SNPS_ERR_INVALID_ARG;
+  return batch_create_impl(ctx, contigs, reads, nullptr, 0, out_batch);
+}
+
+int32_t midas_snps_batch_create_resident(midas_snps_ctx* ctx, const midas_snps_contigs* contigs, const midas_bam* bam, int64_t first_read,
+                                         midas_snps_batch** out_batch) {
+  if (!bam) return MIDAS_SNPS_ERR_INVALID_ARG;
+  return batch_create_impl(ctx, contigs, nullptr, bam, first_read, out_batch);
 }
 
 int32_t midas_snps_batch_select_path(midas_snps_batch* b, int32_t path) {
@@ -1899,6 +2111,10 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
 
   if (run_path == MIDAS_SNPS_PATH_LONG) {
     // ---- long path: one thread per read over the caller's arrays (reads beyond the fast paths' limits; any batch may ask for it) ----
+    {
+      const int32_t rst = ensure_raw_payload(b);
+      if (rst != MIDAS_SNPS_OK) return rst;
+    }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     LongParams lp;
     lp.pos = b->d_pos; lp.mapq = b->d_mapq; lp.nm = b->d_nm; lp.l_seq = b->d_lseq;

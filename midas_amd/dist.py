@@ -32,21 +32,112 @@ _STAT_COLS = 5   # genome_length, covered_bases, total_depth, aligned_reads, map
 _native = None   # the native transport once init_from_env started it
 
 
+def _process_start(pid):
+    """The kernel's start time of process `pid` (clock ticks since boot, /proc/<pid>/stat field 22), None when it is gone:
+    with the pid it names ONE process of this node for good, however often pids are reused."""
+    try:
+        with open("/proc/%d/stat" % pid, "rb") as f:
+            return int(f.read().rsplit(b")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def _meeting_name():
+    """The directory the ranks of ONE launch meet in: what every rank of the launch is told alike and no other launch on the
+    node shares -- the rendezvous address torchrun hands out, and the run id when one was given (MIDAS_RUN_ID, or torchrun's
+    --rdzv-id).  Nothing a rank has by itself (its parent, its pid): ranks started through per-rank wrapper shells meet too."""
+    run = os.environ.get("MIDAS_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    key = "%s_%s" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"))
+    if run and run != "none":
+        key += "." + run
+    return "ranks." + "".join(c if c.isalnum() or c in "._-" else "_" for c in key)
+
+
 class _Native:
-    """The ranks of one node, met in a directory.  all_gather_bytes: every rank writes `<seq>.<rank>` (under a temporary
-    name, then renamed) and reads the others'; a rank removes its file of two exchanges ago when it starts a new one -- by
-    then every rank has read it (a rank that starts exchange k has finished k - 1, for which all had written k - 1, i.e. all
-    had finished reading k - 2)."""
+    """The ranks of one node, met in a directory.
+
+    Meeting (once, at most MEET_TIMEOUT): the directory's name is the same for every launch on this address and port, and a
+    run that crashed leaves its files in it -- so nothing found there is believed until it is tied to a LIVING process of this
+    launch.  Every rank writes `hello.<rank>.<pid>` = its process start time and a random token.  Rank 0 waits for a hello of
+    every rank whose process lives (pid + start time, /proc), clears what older generations left, makes a fresh subdirectory
+    `gen.<random>` and publishes `current` = that name and the (pid, token) of every rank it met.  A rank trusts `current` only
+    when it lists its own pid and token -- a stale one names dead processes -- and from then on every file of the exchange lives
+    in the generation's subdirectory, which no other launch has ever written to.
+
+    all_gather_bytes: every rank writes `<seq>.<rank>` (under a temporary name, then renamed) and reads the others'; a rank
+    removes its file of two exchanges ago when it starts a new one -- by then every rank has read it (a rank that starts
+    exchange k has finished k - 1, for which all had written k - 1, i.e. all had finished reading k - 2)."""
 
     def __init__(self, rank, ws, root):
         self.rank, self.ws = rank, ws
-        nonce = "%s.%d.%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
-        self.dir = os.path.join(root, "ranks." + nonce)
-        os.makedirs(self.dir, exist_ok=True)
+        self.root = os.path.join(root, _meeting_name())
+        os.makedirs(self.root, exist_ok=True)
         self.seq = 0
         self.comm = None
         self.comm_state = "no device context yet"
         self.deadline = COLLECTIVE_TIMEOUT.total_seconds()
+        self.dir = self._meet()
+
+    def _meet(self):
+        import glob
+        import secrets
+        pid, token, t0 = os.getpid(), secrets.token_hex(8), time.monotonic()
+        limit = float(os.environ.get("MIDAS_MEET_TIMEOUT", MEET_TIMEOUT))
+        for old in glob.glob(os.path.join(glob.escape(self.root), "hello.%d.*" % self.rank)):       # (this rank's place in older launches)
+            try:
+                os.remove(old)
+            except OSError:
+                pass
+        mine = os.path.join(self.root, "hello.%d.%d" % (self.rank, pid))
+        with open(mine + ".tmp", "w") as f:
+            f.write("%d %s" % (_process_start(pid) or 0, token))
+        os.replace(mine + ".tmp", mine)
+
+        def late(what):
+            sys.exit("\nError: rank %d of %d waited %.0f s %s in %s\n(the ranks of a launch meet there: they must run on ONE node, see the "
+                     "same directory, and be given the same MASTER_ADDR / MASTER_PORT -- and MIDAS_RUN_ID, if set; MIDAS_MEET_TIMEOUT "
+                     "changes the wait)\n" % (self.rank, self.ws, limit, what, self.root))
+        current = os.path.join(self.root, "current")
+        if self.rank == 0:
+            met, nap = {}, 0.0005
+            while len(met) < self.ws:
+                for path in glob.glob(os.path.join(glob.escape(self.root), "hello.*.*")):
+                    parts = os.path.basename(path).split(".")
+                    try:
+                        r, p = int(parts[1]), int(parts[2])
+                        with open(path) as f:
+                            started, tok = f.read().split()
+                    except (OSError, ValueError, IndexError):
+                        continue          # (half-written or just removed: looked at again)
+                    if 0 <= r < self.ws and _process_start(p) == int(started) and int(started) != 0:
+                        met[r] = (p, tok)
+                if len(met) < self.ws:
+                    if time.monotonic() - t0 > limit:
+                        late("for rank(s) %s" % sorted(set(range(self.ws)) - set(met)))
+                    time.sleep(nap)
+                    nap = min(nap * 1.5, 0.02)
+            import shutil
+            for old in glob.glob(os.path.join(glob.escape(self.root), "gen.*")):
+                shutil.rmtree(old, ignore_errors=True)
+            gen = "gen." + secrets.token_hex(8)
+            os.makedirs(os.path.join(self.root, gen))
+            with open(current + ".tmp", "w") as f:
+                f.write(gen + "\n" + "".join("%d %d %s\n" % (r, met[r][0], met[r][1]) for r in range(self.ws)))
+            os.replace(current + ".tmp", current)
+            return os.path.join(self.root, gen)
+        nap = 0.0005
+        while True:
+            try:
+                with open(current) as f:
+                    lines = f.read().split("\n")
+                if ("%d %d %s" % (self.rank, pid, token)) in lines[1:]:
+                    return os.path.join(self.root, lines[0])
+            except OSError:
+                pass
+            if time.monotonic() - t0 > limit:
+                late("for rank 0's list of the ranks it met")
+            time.sleep(nap)
+            nap = min(nap * 1.5, 0.02)
 
     def _path(self, seq, r):
         return os.path.join(self.dir, "%d.%d" % (seq, r))
@@ -142,9 +233,18 @@ class _Native:
                         break
                     time.sleep(0.001)
         # (a rank's last files stay until rank 0 clears the place: somebody may still be reading them)
-        if self.rank == 0:          # (every other rank has left: the meeting place goes)
+        try:
+            os.remove(os.path.join(self.root, "hello.%d.%d" % (self.rank, os.getpid())))
+        except OSError:
+            pass
+        if self.rank == 0:          # (every other rank has left: the generation's files go, and the meeting place when it is empty)
             import shutil
             shutil.rmtree(self.dir, ignore_errors=True)
+            try:
+                os.remove(os.path.join(self.root, "current"))
+                os.rmdir(self.root)
+            except OSError:
+                pass
 
 
 def _alone():
@@ -174,6 +274,9 @@ def world():
 # Rank 0 builds the bowtie2 database and aligns (tens of minutes to hours) while the other ranks wait at a barrier: the
 # default collective timeout (10 min with nccl) would let the watchdog kill the job before the pileup starts.
 COLLECTIVE_TIMEOUT = datetime.timedelta(hours=48)
+# ... but the ranks MEET within minutes of their start or not at all (a launcher that gave them different directories or
+# addresses, a rank that died at import): that wait is short and its message says where they were expected.
+MEET_TIMEOUT = 120.0
 
 
 def init_from_env(device_backend=None, rendezvous_dir=None):
@@ -190,7 +293,10 @@ def init_from_env(device_backend=None, rendezvous_dir=None):
         return world()
     if ws <= 1:
         return 0, 1
-    if device_backend is None and rendezvous_dir is not None and os.environ.get("MIDAS_DIST_BACKEND", "native") == "native":
+    # (the native transport's ranks meet in a directory and tell their devices apart by PCI bus id: ONE node.  A launch over
+    # several nodes -- LOCAL_WORLD_SIZE below WORLD_SIZE -- takes the torch process group below, as before round 5.)
+    one_node = int(os.environ.get("LOCAL_WORLD_SIZE", ws) or ws) == ws
+    if device_backend is None and rendezvous_dir is not None and one_node and os.environ.get("MIDAS_DIST_BACKEND", "native") == "native":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         _native = _Native(int(os.environ.get("RANK", "0")), ws, rendezvous_dir)
         return world()

@@ -391,12 +391,17 @@ def _batch_groups(args, mine, order, ref_names, refid, reads, ctx):
     except Exception:
         pass
     # (nearly every job: everything fits one batch -- two sums, no per-contig tables)
-    if int(refid.size) <= max_reads and 1.6 * float(reads.l_seq.sum(dtype=np.int64)) + 8.0 * float(refid.size) <= max_payload:
+    resident = isinstance(reads, abi.ResidentReads)       # (every column but refID is on the device: the bases' total came with the decode)
+    bases = float(reads.l_seq_total) if resident else float(reads.l_seq.sum(dtype=np.int64))
+    if int(refid.size) <= max_reads and 1.6 * bases + 8.0 * float(refid.size) <= max_payload:
         return [emit]
     index_of = {n: i for i, n in enumerate(ref_names)}
     n_ref = len(ref_names)
     per_reads = np.bincount(refid, minlength=n_ref) if refid.size else np.zeros(n_ref, np.int64)
-    per_bases = np.bincount(refid, weights=reads.l_seq, minlength=n_ref) if refid.size else np.zeros(n_ref)
+    if resident:
+        per_bases = per_reads * (bases / max(1, int(refid.size)))
+    else:
+        per_bases = np.bincount(refid, weights=reads.l_seq, minlength=n_ref) if refid.size else np.zeros(n_ref)
     n_pieces = {}
     for cid, _ in emit:
         n_pieces[cid] = n_pieces.get(cid, 0) + 1
@@ -426,8 +431,9 @@ def _pileup_contigs(args, species_ids, mine, order, owner, decoded, ctx, span, c
     if len(groups) > 1 and args.get('log') is not None:
         args['log'].write("the rank's %d work items go to the device in %d batches (reads per batch <= %d)\n"
                           % (len(mine), len(groups), int(args.get('max_batch_reads') or MAX_BATCH_READS)))
-    if len(groups) > 1 and getattr(reads, 'device', None) is not None and hasattr(ctx, 'fetch_payload'):
-        decoded = (ref_names, ref_lens, refid, ctx.fetch_payload(reads))      # (each batch regroups its own reads: in host memory, once)
+    if len(groups) > 1 and getattr(reads, 'device', None) is not None and hasattr(ctx, 'fetch_payload') and not isinstance(reads, abi.ResidentReads):
+        # (each batch regroups its own reads: in host memory, once.  Resident records are taken run by run where they lie.)
+        decoded = (ref_names, ref_lens, refid, ctx.fetch_payload(reads))
     total = {}
     for group in groups:
         here = set(group)
@@ -763,7 +769,7 @@ def _inflate_on_device(args, ctx, bampath, ws):
             hbm = int(ctx.device_info()['hbm_bytes'])
         except Exception:
             hbm = 0
-        return size * 12 <= hbm          # arena ~8 x, the batch's columns and counts ~3 x
+        return size * 9 <= hbm           # arena ~8 x (the batch reads the decoder's own layout: no copy of its own); results < 1 x
     return utility.cpu_budget() <= 4 and (32 << 20) <= size // max(1, ws) <= (8 << 30)
 
 
@@ -792,7 +798,7 @@ def _count_alleles(args, species, contigs, ctx):
         if share is not None:
             retry = 0
             try:
-                refid, reads = share[0].load_ranges([(share[1], share[2])], inflater)
+                refid, reads = share[0].load_ranges([(share[1], share[2])], inflater, resident=True)
                 decoded = (share[0].ref_names, share[0].ref_lens, refid, reads)
             except abi.MidasSnpsError as e:
                 if e.status == abi.ERR_BAD_LAYOUT and "ends inside a record" in e.message:
@@ -836,7 +842,8 @@ def _count_alleles(args, species, contigs, ctx):
         try:
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
             try:
-                decoded = abi.read_bam(bampath, inflater, payload_on_device=inflater is not None and ws == 1)
+                # ... in the pileup kernel's own layout, every column included (abi.ResidentReads): ONE pass from the file to the tallies
+                decoded = abi.read_bam(bampath, inflater, resident=inflater is not None and ws == 1)
             except abi.MidasSnpsError as e:
                 # 'auto' chose the device and the device could not (its memory, a HIP error): the host's threads can
                 if inflater is None or args.get('device_inflate', 'auto') != 'auto' or e.status not in (abi.ERR_OUT_OF_MEMORY, abi.ERR_HIP):

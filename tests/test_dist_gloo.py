@@ -3,6 +3,7 @@ Covers the species -> rank assignment and the single all-gather of per-species s
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -346,6 +347,101 @@ print("not reached")
     for k, ((o, e), rc) in enumerate(res):
         assert rc != 0 and "not reached" not in o
         assert ("could not read its slice" in e) if k == 1 else ("rank(s) [1] failed" in e), (k, e)
+
+
+MEET_WORKER = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from midas_amd import dist
+rank, ws = dist.init_from_env(rendezvous_dir=sys.argv[1])
+dist.agree_or_exit(None)
+got = dist.all_gather_i64([rank * 10 + 1, os.getpid()])
+assert [int(x) for x in got[:, 0]] == [r * 10 + 1 for r in range(ws)], got
+rows = np.zeros((3, 5), np.int64); rows[rank %% 3, :] = rank + 1
+tot = dist.all_gather_summary(rows)
+assert int(tot.sum()) == 5 * sum(r + 1 for r in range(ws)), tot
+dist.barrier()
+dist.finalize()
+print("met %%d of %%d" %% (rank, ws))
+'''
+
+
+def _meet_env(k, n, port, extra=None):
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "MIDAS_RUN_ID")}
+    env.update(RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.update(extra or {})
+    return env
+
+
+def test_native_transport_ignores_what_a_crashed_launch_left_behind(tmp_path):
+    """The meeting place has the same name for every launch on one address and port, and a run that was killed leaves its files
+    there: a stale list of ranks, a stale failure flag, a stale ncclUniqueId.  Nothing of it may reach the next launch -- a rank
+    believes only what names its own living process (midas_amd/dist.py, _Native._meet)."""
+    from midas_amd import dist
+    script = tmp_path / "w.py"
+    script.write_text(MEET_WORKER % ROOT)
+    meet = tmp_path / "meet"
+    env0 = _meet_env(0, 3, 29500)
+    name = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from midas_amd import dist; print(dist._meeting_name())" % ROOT],
+                          env=env0, stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    assert name == "ranks.127.0.0.1_29500"
+    place = meet / name
+    stale = place / "gen.00deadbeef"
+    stale.mkdir(parents=True)
+    (place / "current").write_text("gen.00deadbeef\n0 999999 aaaa\n1 999998 bbbb\n2 999997 cccc\n")
+    for r in range(3):
+        (place / ("hello.%d.%d" % (r, 999999 - r))).write_text("12345 stale")
+        (stale / ("0.%d" % r)).write_bytes(b"1")        # "this rank failed" in the first agree_or_exit of the dead run
+        (stale / ("1.%d" % r)).write_bytes(b"\x07" * 16)
+    procs = [subprocess.Popen([sys.executable, str(script), str(meet)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_meet_env(k, 3, 29500)) for k in range(3)]
+    for k, p in enumerate(procs):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0 and "met %d of 3" % k in o, (k, o, e)
+    assert not os.path.exists(str(place))           # the last launch cleared the place, the dead one's generation included
+
+
+def test_native_transport_ranks_of_different_parents_meet(tmp_path):
+    """A launcher that starts every rank through a shell of its own gives the ranks different parent processes: the meeting
+    place is named from what the launch tells all of them alike (MASTER_ADDR, MASTER_PORT, the run id), never from a rank's parent."""
+    script = tmp_path / "w.py"
+    script.write_text(MEET_WORKER % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    procs = [subprocess.Popen(["sh", "-c", "sleep 0.0%d; exec %s %s %s" % (k, sys.executable, script, meet)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=_meet_env(k, 2, 1234, {"MIDAS_RUN_ID": "job 7/a"})) for k in range(2)]
+    wrapped = [subprocess.Popen(["sh", "-c", "%s %s %s; true" % (sys.executable, script, meet)], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, env=_meet_env(k, 2, 1235)) for k in range(2)]      # (the rank is a CHILD of its shell)
+    for k, p in enumerate(procs + wrapped):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0 and "met %d of 2" % (k % 2) in o, (k, o, e)
+
+
+def test_native_transport_a_rank_that_meets_nobody_says_where_it_waited(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(MEET_WORKER % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    for k in (0, 1):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, str(script), str(meet)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=_meet_env(k, 2, 777, {"MIDAS_MEET_TIMEOUT": "1.5"}), timeout=60)
+        assert r.returncode != 0 and time.time() - t0 < 30
+        assert "waited" in r.stderr and str(meet) in r.stderr and "MASTER_ADDR" in r.stderr, r.stderr
+
+
+def test_a_launch_over_several_nodes_does_not_take_the_native_transport():
+    """LOCAL_WORLD_SIZE below WORLD_SIZE: the ranks cannot meet in a directory -- init_from_env goes on to the torch process group."""
+    code = ("import sys; sys.path.insert(0, %r)\nfrom midas_amd import dist\n"
+            "import torch.distributed as td\n"
+            "calls = []\ntd.init_process_group = lambda *a, **k: calls.append((a, k))\n"
+            "dist.world = lambda: (0, 4)\n"
+            "dist.init_from_env(rendezvous_dir='/nonexistent/never/made')\n"
+            "assert dist._native is None and calls, calls\nprint('torch group asked for')\n") % ROOT
+    env = _meet_env(0, 4, 5, {"LOCAL_WORLD_SIZE": "2"})
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "torch group asked for" in r.stdout, r.stderr
 
 
 def test_one_long_contig_is_cut_into_pieces_across_ranks(tmp_path):

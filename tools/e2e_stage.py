@@ -32,9 +32,9 @@ def stage(rep_check=True, device_decode=False):
     t = time.perf_counter(); species = msnps.initialize_species(args); cs = msnps.ContigsInBackground(species)
     ctx = abi.Context(0)
     bam_path = os.path.join(out, 'snps/temp/genomes.bam')
-    decoded = abi.read_bam(bam_path, ctx, payload_on_device=True) if device_decode else abi.read_bam(bam_path)
+    decoded = abi.read_bam(bam_path, ctx, resident=True) if device_decode else abi.read_bam(bam_path)
     T_bam = time.perf_counter() - t
-    how = "blocks inflated and payload columns cut on the device" if device_decode else "native, parallel inflate"
+    how = "decoded on the device into the kernel's own layout, everything resident" if device_decode else "native, parallel inflate"
     cs = cs.wait(); T['read FASTA (background thread) || BAM decode (%s; alone: %.3f s)' % (how, T_bam)] = time.perf_counter() - t
     ids = sorted(species)
     order, span = msnps._whole(msnps._species_contig_order(ids, cs), cs)
