@@ -643,6 +643,10 @@ int32_t midas_genes_sum(midas_snps_ctx* ctx, int64_t n_pairs, const int32_t* gen
  *                  (left in `recv` in rank order): grouped ncclSend / ncclRecv                                             */
 typedef struct midas_comm midas_comm;
 /* the PCI bus id of the context's device (two ranks on ONE device cannot form an RCCL communicator: the caller checks first) */
+/* Whether this process can use RCCL at all (librccl loads and answers); *out_version: ncclGetVersion.  The ranks ask BEFORE they
+ * call midas_comm_create together, and stay on their other transport if any of them cannot -- ncclCommInitRank waits for every
+ * rank of the communicator, one that never arrives would hold the others there.                                                 */
+int32_t midas_comm_probe(int32_t* out_version, char* err256);
 int32_t midas_comm_device_key(midas_snps_ctx* ctx, char* out64);
 int32_t midas_comm_unique_id(uint8_t* out_id128, char* err256);
 int32_t midas_comm_create(midas_snps_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world, midas_comm** out, char* err256);

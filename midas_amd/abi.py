@@ -322,6 +322,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_open_share': (i32, [C.c_char_p, i32, i32, i64, C.POINTER(vp), vp, C.c_char_p]),
         'midas_comm_device_key': (i32, [vp, C.c_char_p]),
         'midas_comm_unique_id': (i32, [vp, C.c_char_p]),
+        'midas_comm_probe': (i32, [C.POINTER(i32), C.c_char_p]),
         'midas_comm_create': (i32, [vp, vp, i32, i32, C.POINTER(vp), C.c_char_p]),
         'midas_comm_destroy': (None, [vp]),
         'midas_comm_all_gather': (i32, [vp, vp, vp, i64, C.c_char_p]),
@@ -361,7 +362,7 @@ EXPORTED_SYMBOLS = [
     'midas_snps_table_copy', 'midas_merge_sites', 'midas_genes_count', 'midas_genes_terms', 'midas_genes_sum', 'midas_merge_write_info',
     'midas_merge_write_matrix',
     'midas_bam_open_share',
-    'midas_comm_device_key', 'midas_comm_unique_id', 'midas_comm_create', 'midas_comm_destroy', 'midas_comm_all_gather', 'midas_comm_all_to_all_v',
+    'midas_comm_device_key', 'midas_comm_probe', 'midas_comm_unique_id', 'midas_comm_create', 'midas_comm_destroy', 'midas_comm_all_gather', 'midas_comm_all_to_all_v',
 ]
 
 
@@ -1055,6 +1056,16 @@ class Comm:
         if st != 0:
             raise MidasSnpsError(st, err.value.decode() or "midas_comm_unique_id failed")
         return out.raw
+
+    @staticmethod
+    def probe() -> int:
+        """RCCL's version when this process can use it at all (midas_comm_probe); raises MidasSnpsError when it cannot."""
+        lib = load_library()
+        v, err = C.c_int32(0), C.create_string_buffer(256)
+        st = lib.midas_comm_probe(C.byref(v), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode() or "midas_comm_probe failed")
+        return int(v.value)
 
     @staticmethod
     def device_key(ctx: "Context") -> str:

@@ -33,6 +33,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
 std::mutex g_lock;
@@ -66,6 +67,7 @@ bool load_rccl(char* err256) {
   SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
+  SYM(GetVersion, "ncclGetVersion")
 #undef SYM
   g_rccl = r;
   return true;
@@ -136,6 +138,17 @@ int32_t midas_comm_unique_id(uint8_t* out_id128, char* err256) {
   return MIDAS_SNPS_OK;
 }
 
+// Can this process use RCCL at all (the library loads, every entry point the binding needs is there, it answers)?  The ranks
+// ask this BEFORE they call midas_comm_create together: a rank that could not would leave the others inside ncclCommInitRank,
+// which waits for every rank of the communicator.
+int32_t midas_comm_probe(int32_t* out_version, char* err256) {
+  if (!load_rccl(err256)) return MIDAS_SNPS_ERR_UNSUPPORTED;
+  int v = 0;
+  C_NCCL(g_rccl.GetVersion(&v));
+  if (out_version) *out_version = v;
+  return MIDAS_SNPS_OK;
+}
+
 int32_t midas_comm_device_key(midas_snps_ctx* ctx, char* out64) {
   if (!ctx || !out64) return MIDAS_SNPS_ERR_INVALID_ARG;
   char bus[32] = {0};
@@ -202,14 +215,20 @@ int32_t midas_comm_all_to_all_v(midas_comm* c, const void* send, const int64_t* 
   if (st != MIDAS_SNPS_OK) return st;
   if (ns) C_HIP(hipMemcpyAsync(c->d_send, send, ns, hipMemcpyHostToDevice, s));
   C_NCCL(g_rccl.GroupStart());
+  // (an open group is closed on EVERY way out: a thread left inside ncclGroupStart makes the communicator useless for what
+  // follows -- the first failure is what is reported)
   size_t so = 0, ro = 0;
-  for (int r = 0; r < c->world; ++r) {
-    if (send_bytes[r]) C_NCCL(g_rccl.Send(c->d_send + so, (size_t)send_bytes[r], ncclUint8, r, c->comm, s));
-    if (recv_bytes[r]) C_NCCL(g_rccl.Recv(c->d_recv + ro, (size_t)recv_bytes[r], ncclUint8, r, c->comm, s));
+  ncclResult_t first = ncclSuccess;
+  const char* where = "";
+  for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
+    if (send_bytes[r]) { first = g_rccl.Send(c->d_send + so, (size_t)send_bytes[r], ncclUint8, r, c->comm, s); where = "ncclSend"; }
+    if (first == ncclSuccess && recv_bytes[r]) { first = g_rccl.Recv(c->d_recv + ro, (size_t)recv_bytes[r], ncclUint8, r, c->comm, s); where = "ncclRecv"; }
     so += (size_t)send_bytes[r];
     ro += (size_t)recv_bytes[r];
   }
-  C_NCCL(g_rccl.GroupEnd());
+  const ncclResult_t ended = g_rccl.GroupEnd();
+  if (first != ncclSuccess) return nccl_fail(first, where, err256);
+  if (ended != ncclSuccess) return nccl_fail(ended, "ncclGroupEnd", err256);
   if (nr) C_HIP(hipMemcpyAsync(recv, c->d_recv, nr, hipMemcpyDeviceToHost, s));
   C_HIP(hipStreamSynchronize(s));
   return MIDAS_SNPS_OK;

@@ -37,7 +37,10 @@ def _process_start(pid):
     with the pid it names ONE process of this node for good, however often pids are reused."""
     try:
         with open("/proc/%d/stat" % pid, "rb") as f:
-            return int(f.read().rsplit(b")", 1)[1].split()[19])
+            fields = f.read().rsplit(b")", 1)[1].split()
+        if fields[0] in (b"Z", b"X"):          # (dead, only not reaped by its parent yet)
+            return None
+        return int(fields[19])
     except (OSError, ValueError, IndexError):
         return None
 
@@ -76,6 +79,7 @@ class _Native:
         self.comm = None
         self.comm_state = "no device context yet"
         self.deadline = COLLECTIVE_TIMEOUT.total_seconds()
+        self.peers = {}          # rank -> (pid, process start time) of the launch's ranks, as met
         self.dir = self._meet()
 
     def _meet(self):
@@ -124,6 +128,7 @@ class _Native:
             with open(current + ".tmp", "w") as f:
                 f.write(gen + "\n" + "".join("%d %d %s\n" % (r, met[r][0], met[r][1]) for r in range(self.ws)))
             os.replace(current + ".tmp", current)
+            self.peers = {r: (met[r][0], _process_start(met[r][0])) for r in range(self.ws)}
             return os.path.join(self.root, gen)
         nap = 0.0005
         while True:
@@ -131,6 +136,10 @@ class _Native:
                 with open(current) as f:
                     lines = f.read().split("\n")
                 if ("%d %d %s" % (self.rank, pid, token)) in lines[1:]:
+                    for ln in lines[1:]:
+                        if ln:
+                            r, p = int(ln.split()[0]), int(ln.split()[1])
+                            self.peers[r] = (p, _process_start(p))
                     return os.path.join(self.root, lines[0])
             except OSError:
                 pass
@@ -160,14 +169,24 @@ class _Native:
                 out.append(bytes(data))
                 continue
             path = self._path(seq, r)
+            looked = time.monotonic()
             while True:
                 try:
                     with open(path, "rb") as f:
                         out.append(f.read())
                     break
                 except FileNotFoundError:
-                    if time.monotonic() - t0 > self.deadline:
+                    now = time.monotonic()
+                    if now - t0 > self.deadline:
                         sys.exit("\nError: rank %d waited %d s for rank %d at exchange %d (%s)\n" % (self.rank, self.deadline, r, seq, self.dir))
+                    # a rank may wait for hours (rank 0 aligns) -- but not for a process that is gone: a rank that died without
+                    # a word (killed, an uncaught exception) is noticed within a second, not at the collective's deadline
+                    if now - looked > 0.5 and r in self.peers:
+                        looked = now
+                        p, started = self.peers[r]
+                        if _process_start(p) != started and not os.path.exists(path):
+                            sys.exit("\nError: rank %d (process %d) is gone without a message; rank %d, waiting for it at exchange %d, stops too\n"
+                                     % (r, p, self.rank, seq))
                     time.sleep(nap)
                     nap = min(nap * 1.5, 0.005)
         return out
@@ -182,21 +201,29 @@ class _Native:
         if len(set(keys)) < self.ws:
             self.comm_state = "ranks share a device (%s): RCCL refuses that, the exchange stays on files" % ", ".join(sorted(set(keys)))
             return
+        # Every rank says whether it can use RCCL at all (the library loads and answers) BEFORE any of them enters
+        # ncclCommInitRank, which waits for all ranks of the communicator: one that could not would hold the others there.
         ident, error = b"\0" * 128, b""
-        if self.rank == 0:
-            try:
+        try:
+            abi.Comm.probe()
+            if self.rank == 0:
                 ident = abi.Comm.unique_id()
-            except abi.MidasSnpsError as e:
-                error = e.message.encode()
+        except abi.MidasSnpsError as e:
+            error = e.message.encode() or b"RCCL failed"
+        except Exception as e:
+            error = ("%s: %s" % (type(e).__name__, e)).encode()
         got = self.all_gather_bytes(ident + error)
-        if got[0][128:]:
-            self.comm_state = "RCCL is not available (%s): the exchange stays on files" % got[0][128:].decode()
+        bad = ["rank %d: %s" % (r, g[128:].decode(errors="replace")) for r, g in enumerate(got) if g[128:]]
+        if bad:
+            self.comm_state = "RCCL is not available (%s): the exchange stays on files" % "; ".join(bad)
             return
         try:
             self.comm = abi.Comm(ctx, got[0][:128], self.rank, self.ws)
             state = b"ok"
         except abi.MidasSnpsError as e:
-            state = e.message.encode()
+            state = e.message.encode() or b"midas_comm_create failed"
+        except Exception as e:        # (whatever it was: the other ranks are told, nobody is left waiting for this one's "ok")
+            state = ("%s: %s" % (type(e).__name__, e)).encode()
         states = self.all_gather_bytes(state)
         if any(x != b"ok" for x in states):
             if self.comm is not None:

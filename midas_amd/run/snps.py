@@ -549,7 +549,9 @@ def _join_parts(args, species_ids, order, owner, rank):
         if not cids or owner.get(cids[0], 0) != rank:
             continue
         final = '%s/snps/output/%s.snps.gz' % (args['outdir'], sp)
-        parts = sorted(glob.glob(glob.escape(final) + '.part[0-9][0-9][0-9][0-9][0-9][0-9]'))
+        # (a part is named by the index of its first item, %06d: seven digits from the millionth item on -- by number, not by name)
+        parts = sorted((p for p in glob.glob(glob.escape(final) + '.part*') if p[len(final) + 5:].isdigit()),
+                       key=lambda p: int(p[len(final) + 5:]))
         if not parts:
             continue
         with open(final + '.tmp', 'wb') as dst:
@@ -564,8 +566,9 @@ def _join_parts(args, species_ids, order, owner, rank):
 def _remove_stale_parts(args):
     """Part files of an earlier, interrupted run must not end up in this run's tables."""
     import glob
-    for path in glob.glob(glob.escape('%s/snps/output' % args['outdir']) + '/*.snps.gz.part[0-9][0-9][0-9][0-9][0-9][0-9]'):
-        os.remove(path)
+    for path in glob.glob(glob.escape('%s/snps/output' % args['outdir']) + '/*.snps.gz.part*'):
+        if path.rsplit('.part', 1)[1].isdigit():
+            os.remove(path)
 
 
 def species_pileup(args, species_id, contigs):
@@ -801,8 +804,11 @@ def _count_alleles(args, species, contigs, ctx):
                 refid, reads = share[0].load_ranges([(share[1], share[2])], inflater, resident=True)
                 decoded = (share[0].ref_names, share[0].ref_lens, refid, reads)
             except abi.MidasSnpsError as e:
-                if e.status == abi.ERR_BAD_LAYOUT and "ends inside a record" in e.message:
-                    retry = 1          # (the next rank's guessed border is not a record border: plan with the slices instead)
+                if e.status == abi.ERR_BAD_LAYOUT:
+                    # a guessed border that is no record border -- this rank's end, or its own start (then the decode meets
+                    # something that is no record): plan with the slices instead, whose walk vouches for every border; a file
+                    # that really is damaged is reported by that plan, with the block or record it stumbles over
+                    retry = 1
                 elif inflater is not None and args.get('device_inflate', 'auto') == 'auto' and e.status in (abi.ERR_OUT_OF_MEMORY, abi.ERR_HIP):
                     retry = 1
                 else:

@@ -431,6 +431,86 @@ def test_native_transport_a_rank_that_meets_nobody_says_where_it_waited(tmp_path
         assert "waited" in r.stderr and str(meet) in r.stderr and "MASTER_ADDR" in r.stderr, r.stderr
 
 
+ATTACH_WORKER = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from midas_amd import abi, dist
+rank, ws = dist.init_from_env(rendezvous_dir=sys.argv[1])
+mode = sys.argv[2]
+made = []
+class FakeComm:                      # stands in for the RCCL binding: what attach() does around it is what is under test
+    def __init__(self, ctx, ident, r, w):
+        assert ident == b"I" * 128 and (r, w) == (rank, ws)
+        if mode == "create" and r == 1:
+            raise abi.MidasSnpsError(abi.ERR_HIP, "ncclCommInitRank: unhandled system error")
+        made.append(self); self.open = True
+    def close(self): self.open = False
+    def all_gather(self, data): raise AssertionError("a communicator that did not come up everywhere must not be used")
+    @staticmethod
+    def device_key(ctx): return "0000:%%02x:00.0" %% rank
+    @staticmethod
+    def probe():
+        if mode == "probe" and rank == 2:
+            raise abi.MidasSnpsError(abi.ERR_UNSUPPORTED, "librccl.so not found: no such file")
+        return 22203
+    @staticmethod
+    def unique_id(): return b"I" * 128
+abi.Comm = FakeComm
+class Ctx: _h = 1
+line = dist.attach_context(Ctx())
+assert dist._native.comm is None and all(not c.open for c in made), line
+assert "stays on files" in line and ("rank 2: librccl.so not found" in line if mode == "probe" else "unhandled system error" in line), line
+assert (mode == "probe" or rank == 1) == (not made), (mode, made)          # probe failure: NO rank entered ncclCommInitRank
+rows = np.zeros((2, 5), np.int64); rows[rank %% 2] = rank + 1
+assert int(dist.all_gather_summary(rows).sum()) == 5 * sum(r + 1 for r in range(ws))
+dist.barrier(); dist.finalize()
+print("fell back together")
+'''
+
+
+@pytest.mark.parametrize("mode", ["probe", "create"])
+def test_native_transport_falls_back_to_files_together_when_rccl_fails_on_one_rank(tmp_path, mode):
+    """One rank cannot load RCCL (found before anybody enters ncclCommInitRank), or its ncclCommInitRank fails: EVERY rank drops
+    the communicator and the summary rows travel through the files -- nobody waits inside RCCL, nobody uses half a communicator."""
+    script = tmp_path / "w.py"
+    script.write_text(ATTACH_WORKER % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    procs = [subprocess.Popen([sys.executable, str(script), str(meet), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_meet_env(k, 3, 4242)) for k in range(3)]
+    for k, p in enumerate(procs):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0 and "fell back together" in o, (k, o, e)
+
+
+def test_native_transport_a_rank_that_dies_without_a_word_is_noticed_at_once(tmp_path):
+    """A rank killed between two exchanges (no sys.exit message, no flag): the ranks waiting for it know its process from the
+    meeting and stop within a second of its death -- not at the collective's 48 h deadline."""
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys, time
+sys.path.insert(0, %r)
+from midas_amd import dist
+rank, ws = dist.init_from_env(rendezvous_dir=sys.argv[1])
+dist.agree_or_exit(None)
+if rank == 1:
+    os._exit(9)
+dist.all_gather_i64([rank])
+print("not reached")
+''' % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script), str(meet)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=_meet_env(k, 3, 4343)) for k in range(3)]
+    for k, p in enumerate(procs):
+        o, e = p.communicate(timeout=60)
+        assert p.returncode != 0 and "not reached" not in o
+        assert k == 1 or "rank 1 (process %d) is gone" % procs[1].pid in e, (k, e)
+    assert time.time() - t0 < 30
+
+
 def test_a_launch_over_several_nodes_does_not_take_the_native_transport():
     """LOCAL_WORLD_SIZE below WORLD_SIZE: the ranks cannot meet in a directory -- init_from_env goes on to the torch process group."""
     code = ("import sys; sys.path.insert(0, %r)\nfrom midas_amd import dist\n"

@@ -175,3 +175,66 @@ def test_native_transport_with_ranks_sharing_one_gpu(tmp_path):
                 assert open(os.path.join(one, "snps", "output", f), "rb").read() == open(os.path.join(many, "snps", "output", f), "rb").read(), f
     finally:
         os.environ.pop("SNPS_REAL_DEVICE", None)
+
+
+def _device_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return int(n.value) if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="one GPU on this box: RCCL refuses two ranks on one device (the first multi-GPU lease runs this)")
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_the_products_transport_between_ranks_on_their_own_gpus(tmp_path, n_ranks):
+    """The product's own exchange between REAL ranks -- one process per GPU, met in a directory, an RCCL communicator formed
+    through the library's binding (midas_comm_*), the summary rows all-gathered and a ragged all-to-all over xGMI -- on the first
+    box that has the devices.  No torch in the ranks."""
+    import subprocess
+    import sys
+    if _device_count() < n_ranks:
+        pytest.skip("%d GPUs here" % _device_count())
+    script = tmp_path / "w.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from midas_amd import abi, dist
+rank, ws = dist.init_from_env(rendezvous_dir=sys.argv[1])
+ctx = abi.Context(int(os.environ["LOCAL_RANK"]))
+line = dist.attach_context(ctx)
+assert dist._native.comm is not None and "RCCL communicator of %%d ranks" %% ws in line, line
+rows = np.zeros((100, 5), np.int64)
+rows[rank::ws] = np.arange(5) + 1000 * (rank + 1)
+tot = dist.all_gather_summary(rows)
+want = np.zeros((100, 5), np.int64)
+for r in range(ws):
+    want[r::ws] = np.arange(5) + 1000 * (r + 1)
+assert np.array_equal(tot, want)
+rng = np.random.default_rng(rank)
+parts = [rng.integers(0, 1 << 40, 1000 * ((rank + d) %% 3) + d, dtype=np.int64) for d in range(ws)]
+got = dist.all_to_all_v(parts)
+for src in range(ws):
+    theirs = np.random.default_rng(src)
+    sent = [theirs.integers(0, 1 << 40, 1000 * ((src + d) %% 3) + d, dtype=np.int64) for d in range(ws)]
+    assert np.array_equal(got[src], sent[rank]), (rank, src)
+f = dist.all_gather_rows_f64(np.full((3, 2), rank + 0.5))
+assert float(f.sum()) == 6 * sum(r + 0.5 for r in range(ws))
+dist.detach_context()
+ctx.close()
+dist.barrier(); dist.finalize()
+assert "torch" not in sys.modules
+print("rccl between %%d ranks ok" %% ws)
+''' % ROOT)
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    procs = [subprocess.Popen([sys.executable, str(script), str(meet)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env1, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+                                       HSA_ENABLE_IPC_MODE_LEGACY="0")) for k in range(n_ranks)]
+    for k, p in enumerate(procs):
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0 and "rccl between %d ranks ok" % n_ranks in o, (k, o, e[-3000:])
