@@ -1,3 +1,5 @@
+// ROUND 6 EXPERIMENT, NOT SHIPPED (profiles/r06_kernel_experiments.txt section 2): build with -DMIDAS_TALLY_DUMMY -- the tally without EXEC moves
+// (every lane adds; a base that does not count adds to a dummy slot chosen by v_cndmask_b32 on the address).  Bit-exact, not faster.
 // gfx950 (CDNA4) pileup kernel of the MIDAS SNP path that reads the BAM's own bytes: per read ONE 16-byte record (pos, l_seq,
 // n_cigar, NM, mapq, payload offset -- layout.h DirectRec) and its CIGAR / 4-bit SEQ / QUAL bytes as BAM lays them out, one
 // run per read -- nothing decoded, sorted or decided beforehand, ONE visit per read.  Integer counting: no MFMA.
@@ -64,10 +66,92 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // counter offsets of the even / odd bases (byte i of an `e` word: base 2i, of an `o` word: base 2i + 1).
 template <int OFF, int NB>
 __device__ __forceinline__ void tally_group(uint32_t q0, uint32_t q1, uint32_t the, uint32_t tho, uint32_t cde, uint32_t cdo,
-                                            uint32_t abase, uint32_t one) {
+                                            uint32_t abase, uint32_t one, uint32_t dummy) {
   static_assert(NB == 8 || NB == 6, "a group holds 8 bases, or 6 at the end of a 30-base lane");
   uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
   unsigned long long m0, m1, m2, m3, m4, m5, m6, m7, save;
+#ifdef MIDAS_TALLY_DUMMY
+  // (developer variant, profiles/r06_kernel_experiments.txt: EXEC stays as it is -- every lane adds, a lane whose base does not count
+  // adds to a slot of its own in a dummy region, chosen by one v_cndmask on the address)
+  if (NB == 8) {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t6], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_or_b32_sdwa %[t7], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m6], %[q1], %[te] src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+        "v_cmp_gt_u32_sdwa %[m7], %[q1], %[to] src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_cndmask_b32_e64 %[t0], %[dm], %[t0], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[t1], %[dm], %[t1], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[t2], %[dm], %[t2], %[m2]\n\t"
+        "v_cndmask_b32_e64 %[t3], %[dm], %[t3], %[m3]\n\t"
+        "v_cndmask_b32_e64 %[t4], %[dm], %[t4], %[m4]\n\t"
+        "v_cndmask_b32_e64 %[t5], %[dm], %[t5], %[m5]\n\t"
+        "v_cndmask_b32_e64 %[t6], %[dm], %[t6], %[m6]\n\t"
+        "v_cndmask_b32_e64 %[t7], %[dm], %[t7], %[m7]\n\t"
+        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        "ds_add_u32 %[t5], %[one] offset:%[off]+80\n\t"
+        "ds_add_u32 %[t6], %[one] offset:%[off]+96\n\t"
+        "ds_add_u32 %[t7], %[one] offset:%[off]+112"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+          [t7] "=&v"(t7), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5),
+          [m6] "=&s"(m6), [m7] "=&s"(m7)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
+          [dm] "v"(dummy), [off] "n"(OFF)
+        : "memory");
+    (void)save;
+    return;
+  } else {
+    asm volatile(
+        "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t1], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_or_b32_sdwa %[t2], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t3], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_or_b32_sdwa %[t4], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_or_b32_sdwa %[t5], %[ab], %[co] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m0], %[q0], %[te] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m1], %[q0], %[to] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa %[m2], %[q0], %[te] src0_sel:BYTE_2 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m3], %[q0], %[to] src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %[m4], %[q1], %[te] src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+        "v_cmp_gt_u32_sdwa %[m5], %[q1], %[to] src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+        "v_cndmask_b32_e64 %[t0], %[dm], %[t0], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[t1], %[dm], %[t1], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[t2], %[dm], %[t2], %[m2]\n\t"
+        "v_cndmask_b32_e64 %[t3], %[dm], %[t3], %[m3]\n\t"
+        "v_cndmask_b32_e64 %[t4], %[dm], %[t4], %[m4]\n\t"
+        "v_cndmask_b32_e64 %[t5], %[dm], %[t5], %[m5]\n\t"
+        "ds_add_u32 %[t0], %[one] offset:%[off]\n\t"
+        "ds_add_u32 %[t1], %[one] offset:%[off]+16\n\t"
+        "ds_add_u32 %[t2], %[one] offset:%[off]+32\n\t"
+        "ds_add_u32 %[t3], %[one] offset:%[off]+48\n\t"
+        "ds_add_u32 %[t4], %[one] offset:%[off]+64\n\t"
+        "ds_add_u32 %[t5], %[one] offset:%[off]+80"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [m0] "=&s"(m0),
+          [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5)
+        : [q0] "v"(q0), [q1] "v"(q1), [te] "v"(the), [to] "v"(tho), [ce] "v"(cde), [co] "v"(cdo), [ab] "v"(abase), [one] "v"(one),
+          [dm] "v"(dummy), [off] "n"(OFF)
+        : "memory");
+    (void)save; (void)t6; (void)t7; (void)m6; (void)m7;
+    return;
+  }
+#else
+  (void)dummy;
+#endif
   if (NB == 8) {
     asm volatile(
         "v_or_b32_sdwa %[t0], %[ab], %[ce] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
@@ -171,6 +255,9 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
+#ifdef MIDAS_TALLY_DUMMY
+  __shared__ uint32_t s_dummy[64 + 128];      // a slot per lane + the reach of the tally's immediate offsets (<= 496 bytes)
+#endif
   extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
 
   const int tid = threadIdx.x;
@@ -181,8 +268,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   // what it adds behind that tile's last site lands in the OV sites the tallies hold beyond the tile and moves to the front
   // when the workgroup goes on to the next tile (same contig).  Only a chunk's first tile streams the reads that reach in
   // from the tile before it, as every tile did before (7.5 % of the reads seen twice at 2048 sites and 150 bp; a quarter of
-  // that with chunks of four).  The host asks for chunks when the reads are position-sorted; a read that spans more than OV sites
-  // (a long deletion, an N skip) makes the chunks it touches fall back to tile-by-tile (chunk_ok), not the batch.
+  // that with chunks of four).  The host asks for chunks when the reads are position-sorted and none spans more than OV sites.
   const int K = p.chunk_tiles > 1 ? p.chunk_tiles : 1;
   const int T4 = K > 1 ? p.n_chunked_tiles : 0;
   const int n4 = T4 / K;
@@ -244,6 +330,11 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   const uint32_t cd_lo = 0x08000400u, cd_hi = 0x0C000000u;
   const int rq = p.readq < 0 ? 0 : (p.readq > 256 ? 256 : p.readq);   // sum(q) < rq * l  <=>  np.mean(q) < readq (q <= 255)
   const uint32_t one = 1u;
+#ifdef MIDAS_TALLY_DUMMY
+  const uint32_t dummy = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(s_dummy + lane);
+#else
+  const uint32_t dummy = 0u;
+#endif
 
   const ConstWords c_tiles = (ConstWords)(size_t)p.tiles;
   const ConstWords c_tb = (ConstWords)(size_t)p.tbegin;
@@ -316,7 +407,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       const uint32_t so = ((x & 0x0F0F0F0Fu) + 0x07070707u) ^ 0x08080808u;          // odd bases
       const uint32_t te = __builtin_amdgcn_perm(th_hi, th_lo, se), to = __builtin_amdgcn_perm(th_hi, th_lo, so);
       const uint32_t ce = __builtin_amdgcn_perm(cd_hi, cd_lo, se), co = __builtin_amdgcn_perm(cd_hi, cd_lo, so);
-      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one);
+      tally_group<decltype(off)::value, decltype(nbases)::value>(qv[2 * S], qv[2 * S + 1], te, to, ce, co, abase, one, dummy);
     };
     using std::integral_constant;
     group(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 8>{});

@@ -295,7 +295,8 @@ typedef struct midas_snps_batch_info {
   int32_t path;             /* MIDAS_SNPS_PATH_DIRECT / _PACKED / _LONG: what batch_run takes                 */
   int32_t path_auto;        /* what the batch's own numbers recommend (see midas_snps_batch_select_path)       */
   int32_t lane_bases;       /* bases per lane of the active path's kernel                                      */
-  int32_t reserved0;
+  int32_t layout_build_us;  /* device time (HIP events, microseconds) batch_create spent building the direct layout -- the 16-byte records
+                               and the payload runs -- from the caller's arrays; 0 for a batch over resident records (the decoder wrote it) */
   int64_t direct_general_reads;   /* reads that are not one or two gap-free match runs (walked op by op)      */
   int64_t direct_reach;           /* longest reference span of a read: how far back a tile's read range reaches */
   int64_t direct_stream_reads;    /* sum over tiles of the reads their streams hold: n_reads + straddlers when sorted */

@@ -84,7 +84,7 @@ class BatchInfo(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_sites", C.c_int64), ("n_tiles", C.c_int64),
                 ("packed_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64),
                 ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32), ("n_work_items", C.c_int64),
-                ("path", C.c_int32), ("path_auto", C.c_int32), ("lane_bases", C.c_int32), ("reserved0", C.c_int32),
+                ("path", C.c_int32), ("path_auto", C.c_int32), ("lane_bases", C.c_int32), ("layout_build_us", C.c_int32),
                 ("direct_general_reads", C.c_int64), ("direct_reach", C.c_int64),
                 ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64)]
 

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   }
   __syncthreads();
   unsigned long long alg = 0, status = kNoError;
-  uint32_t maxl = 0, maxspan = 0, unsorted = 0, general = 0, n_long = 0;
+  uint32_t maxl = 0, maxspan = 0, unsorted = 0, general = 0, n_long = 0, n_out = 0, maxcommon = 0;
   ContigCursor cur;
   if (lo < hi) {
     cur.c = s_c0;
@@ -239,6 +239,29 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
     });
     span = span > 0x3FFFFFFFull ? 0x3FFFFFFFull : span;
     maxspan = (uint32_t)span > maxspan ? (uint32_t)span : maxspan;
+    if (span > (unsigned long long)kDirectOverhang) {
+      // an outlier (a long deletion, an N skip): listed with the tiles behind its own that it reaches, so that the ranges pass
+      // can keep to the common span; where it leaves its tile's overhang -- or reaches into tiles beyond the next -- the chunks
+      // of those tiles are dealt tile by tile (tile_flag)
+      n_out += 1u;
+      const long long last = cur.clen - 1;
+      long long pc = f.pos;
+      pc = pc < 0 ? 0 : (pc > last ? last : pc);
+      long long e = (long long)f.pos + (long long)span - 1;
+      e = e > last ? last : e;
+      if (e >= pc) {
+        const uint32_t ka = (uint32_t)cur.tile_base + (uint32_t)(pc >> p.tile_shift), kb = (uint32_t)cur.tile_base + (uint32_t)(e >> p.tile_shift);
+        if (kb > ka) {
+          const uint32_t slot = atomicAdd(p.n_outliers_listed, 1u);
+          if (slot < p.outlier_cap) p.outliers[slot] = DirectOutlier{(uint32_t)i, ka + 1u, kb, 0u};
+        }
+        const long long tile_start = (pc >> p.tile_shift) << p.tile_shift;
+        if (e - tile_start >= (long long)(1 << p.tile_shift) + kDirectOverhang)
+          for (uint32_t t = ka; t <= kb; ++t) p.tile_flag[t] = 1;
+      }
+    } else {
+      maxcommon = (uint32_t)span > maxcommon ? (uint32_t)span : maxcommon;
+    }
     ReadShape sh;
     const bool fast = (uint32_t)nc <= 4u && decode_shape(cg.c0, cg.c1, cg.c2, cg.c3, (uint32_t)nc, (uint32_t)l, &sh) && f.nm >= 0 &&
                       f.pos >= 0 && (long long)f.pos < cur.clen;
@@ -249,6 +272,8 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
   const unsigned long long nlong = block_sum((unsigned long long)n_long, red);
   const unsigned long long bmax = block_max((unsigned long long)maxl, red);
   const unsigned long long bspan = block_max((unsigned long long)maxspan, red);
+  const unsigned long long bcommon = block_max((unsigned long long)maxcommon, red);
+  const unsigned long long nout = block_sum((unsigned long long)n_out, red);
   const unsigned long long any_unsorted = block_max((unsigned long long)unsorted, red);
   const unsigned long long worst = ~block_max(~status, red);       // (the lowest status word)
   if (threadIdx.x == 0) {
@@ -258,6 +283,8 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
     if (nlong) atomicAdd(&f->n_long, (uint32_t)nlong);
     if (bmax) atomicMax(&f->max_l, (uint32_t)bmax);
     if (bspan) atomicMax(&f->max_span, (uint32_t)bspan);
+    if (bcommon) atomicMax(&f->max_span_common, (uint32_t)bcommon);
+    if (nout) atomicAdd(&f->n_outliers, (uint32_t)nout);
     if (any_unsorted) atomicOr(&f->unsorted, 1u);
     if (worst != kNoError) atomicMin(&f->status, worst);
   }
@@ -381,7 +408,22 @@ __global__ __launch_bounds__(kIdxBlock) void direct_layout_fill_kernel(DirectLay
   }
 }
 
+// every pass, behind the ranges kernel, when the batch has outliers: a tile an outlier reaches begins its stream no later than
+// at that read
+__global__ __launch_bounds__(256) void direct_outliers_kernel(const DirectOutlier* list, uint32_t n, uint32_t* tbegin) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const DirectOutlier o = list[j];
+  for (uint32_t t = o.t_first; t <= o.t_last; ++t) atomicMin(&tbegin[t], o.read);
+}
+
 }  // namespace
+
+hipError_t launch_direct_outliers(const DirectOutlier* list, uint32_t n, uint32_t* tbegin, hipStream_t s) {
+  if (n == 0u) return hipSuccess;
+  hipLaunchKernelGGL(direct_outliers_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, list, n, tbegin);
+  return hipGetLastError();
+}
 
 int direct_index_blocks(int64_t n_reads) { return n_reads > 0 ? (int)((n_reads + kIdxRun - 1) / kIdxRun) : 1; }
 

@@ -187,7 +187,12 @@ struct alignas(128) DirectFacts {                 // per-slot partial results of
   uint32_t max_span;                              // longest reference span (sum of M/=/X/D/N lengths) of a read
   uint32_t unsorted;                              // some contig's reads are not in position order
   uint32_t n_long;                                // reads beyond the fast paths' limits (l_seq > kMaxLSeq, n_cigar / NM > kMaxField16): the batch takes the long path
+  uint32_t n_outliers;                            // reads whose reference span exceeds kDirectOverhang (a long deletion, an N skip) ...
+  uint32_t max_span_common;                       // ... and the longest span of all the others
 };
+// A read that spans more than the overhang: the tiles behind the one it starts in, [t_first, t_last], must find it in their
+// streams although the ranges pass reaches back over the COMMON span only (direct_outliers_kernel, every pass).
+struct DirectOutlier { uint32_t read, t_first, t_last, pad; };
 
 // the contig a workgroup of the direct path's index kernels starts in (index_direct.hip ContigCursor, as the facts pass left it)
 struct DirectBlockCursor { int32_t c, begin, next_begin, tile_base, tile_end, pad; long long clen; };
@@ -196,6 +201,8 @@ struct DirectIndexParams {
   const int64_t* seq_off; const int64_t* qual_off; const int64_t* cigar_off;
   const uint32_t* cigar;
   const DirectRec* rec; const uint8_t* payload;   // (facts pass of a resident batch, which has no CIGAR column: a read's ops open its payload run; else nullptr)
+  DirectOutlier* outliers; uint32_t* n_outliers_listed; uint32_t outlier_cap;    // facts pass: the list (entries beyond the cap are counted, not listed)
+  uint8_t* tile_flag;                             // facts pass: [n_tiles] 1 = an outlier leaves its tile's overhang here or reaches in: the tile's chunk is dealt tile by tile
   int64_t seq_bytes, qual_bytes, n_cigar;
   int32_t n_reads;
   const int32_t* contig_read_begin; const int32_t* contig_tile_base; const int32_t* contig_len;
@@ -243,6 +250,7 @@ struct DirectParams {
   int32_t baseq, mapq_min, readq;
   int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
   int32_t chunk_tiles, n_chunked_tiles;           // tiles [0, n_chunked_tiles) are dealt in chunks of chunk_tiles (1: every tile by itself)
+  const uint8_t* chunk_ok;                        // nullptr, or per chunk: 0 = its tiles are piled up one by one (an outlier read), no overhang carried
 };
 
 // device_sort.hip: the library's own exclusive scan of 32-bit counters and stable 8-bit-digit radix sort of (key, value) pairs
@@ -362,6 +370,7 @@ hipError_t launch_direct_facts(const DirectIndexParams& p, hipStream_t s);      
 hipError_t launch_direct_layout_sizes(const DirectLayoutParams& p, hipStream_t s);   // once per batch: payload units per workgroup + their scan
 hipError_t launch_direct_layout_fill(const DirectLayoutParams& p, hipStream_t s);    // once per batch: records + payload
 hipError_t launch_direct_ranges(const DirectIndexParams& p, hipStream_t s);      // every pass: the tile ranges, from the positions
+hipError_t launch_direct_outliers(const DirectOutlier* list, uint32_t n, uint32_t* tbegin, hipStream_t s);   // every pass behind it, when the batch has outliers
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t s);
 int direct_lane_bases(int32_t max_l_seq);
 int direct_index_blocks(int64_t n_reads);

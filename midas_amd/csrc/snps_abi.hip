@@ -114,6 +114,17 @@ struct midas_snps_batch {
   uint8_t* d_dpay = nullptr;           // ... and its CIGAR / SEQ / QUAL bytes as one run (layout.h)
   unsigned long long* d_dunits = nullptr;   // (scratch of the layout's scan)
   int64_t direct_payload_bytes = 0;
+  int32_t layout_build_us = 0;         // device time of the layout's three launches (batch_get_info)
+  // reads that span more than the overhang (a long deletion, an N skip): listed once (facts pass), so that the ranges pass keeps
+  // to the common span and only the chunks they touch are dealt tile by tile
+  DirectOutlier* d_outliers = nullptr;
+  uint32_t* d_n_outliers = nullptr;
+  uint8_t* d_tile_flag = nullptr;
+  uint8_t* d_chunk_ok = nullptr;       // per chunk of kDirectChunkTiles tiles (nullptr: every chunk carries its overhang)
+  uint32_t outlier_cap = 0, n_outliers_listed = 0;
+  int64_t n_outliers = 0;
+  int32_t direct_reach_ranges = 1;     // what the ranges pass reaches back over: the common span when the outliers are listed, else direct_reach
+  bool direct_chunks = false;          // chunked tiles (position-sorted reads, outliers listed)
   unsigned long long* d_probe = nullptr;   // developer builds only (MIDAS_SNPS_DEBUG_BITS & 256)
   int64_t direct_general = 0;   // reads the pileup kernel walks op by op (facts pass)
   int32_t direct_reach = 1;     // longest reference span of a read: what a tile's range must reach back over
@@ -1313,6 +1324,7 @@ void midas_snps_batch_destroy(midas_snps_batch* b) {
                  b->d_cigar, b->d_pack_reads, b->d_pack_recs, b->d_sort_tmp, b->d_rec, b->d_blob, b->d_ref, b->d_tiles,
                  b->d_contig_read_begin, b->d_contig_tile_base, b->d_contig_len, b->d_work, b->d_items, b->d_ticket, b->d_filt,
                  b->d_wg_begin, b->d_tile_split, b->d_trange, b->d_dfacts, b->d_block_contig, b->d_probe, b->d_drec, b->d_dpay, b->d_dunits,
+                 b->d_outliers, b->d_n_outliers, b->d_tile_flag, b->d_chunk_ok,
                  b->d_orig, b->d_key, b->d_counts, b->d_allele};
   for (void* q : dev) (void)hipFree(q);
   if (b->h_tile_reads) (void)hipHostFree(b->h_tile_reads);
@@ -1515,7 +1527,9 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->tbegin = trange_begin(b, par); ip->tend = trange_end(b, par);
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
   ip->sorted = b->direct_sorted ? 1 : 0;
-  ip->reach = b->direct_reach;
+  ip->reach = b->direct_reach_ranges;
+  ip->outliers = b->d_outliers; ip->n_outliers_listed = b->d_n_outliers; ip->outlier_cap = b->outlier_cap;
+  ip->tile_flag = b->d_tile_flag;
   ip->facts = b->d_dfacts;
   ip->block_contig = b->d_block_contig;
   ip->stats = b->d_work ? work_stats(b) : nullptr; ip->err = b->d_work ? work_err(b) : nullptr;
@@ -1538,15 +1552,23 @@ int32_t direct_prepare(midas_snps_batch* b) {
   HIP_TRY(ctx, hipMemsetAsync(trange_begin(b, 1), 0xFF, nt * 4, s));
   HIP_TRY(ctx, hipMemsetAsync(b->d_dfacts, 0, sizeof(DirectFacts) * kDirectFactSlots, s));
   for (int k = 0; k < kDirectFactSlots; ++k) HIP_TRY(ctx, hipMemsetAsync(&b->d_dfacts[k].status, 0xFF, 8, s));
+  b->outlier_cap = (uint32_t)std::max<int64_t>(4096, b->n_reads / 64);
+  HIP_TRY(ctx, hipMalloc(&b->d_outliers, (size_t)b->outlier_cap * sizeof(DirectOutlier)));
+  HIP_TRY(ctx, hipMalloc(&b->d_n_outliers, 4));
+  HIP_TRY(ctx, hipMalloc(&b->d_tile_flag, nt));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_n_outliers, 0, 4, s));
+  HIP_TRY(ctx, hipMemsetAsync(b->d_tile_flag, 0, nt, s));
   DirectIndexParams ip;
   fill_direct_index(b, &ip);
   std::vector<DirectFacts> facts(kDirectFactSlots);
   if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_facts(ip, s));
   HIP_TRY(ctx, hipMemcpyAsync(facts.data(), b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  unsigned long long status = kNoError, alg = 0, n_general = 0, n_long = 0;
-  uint32_t max_l = 0, max_span = 0, unsorted = 0;
+  unsigned long long status = kNoError, alg = 0, n_general = 0, n_long = 0, n_outliers = 0;
+  uint32_t max_l = 0, max_span = 0, unsorted = 0, max_common = 0;
   for (const DirectFacts& f : facts) {
+    n_outliers += f.n_outliers;
+    max_common = std::max(max_common, f.max_span_common);
     status = std::min(status, f.status);
     alg += f.alg_bytes;
     n_general += f.n_general;
@@ -1560,6 +1582,32 @@ int32_t direct_prepare(midas_snps_batch* b) {
   b->direct_sorted = unsorted == 0;
   b->direct_general = (int64_t)n_general;
   b->direct_reach = (int32_t)std::max<uint32_t>(1u, std::max(max_l, max_span));
+  b->direct_reach_ranges = b->direct_reach;
+  b->n_outliers = (int64_t)n_outliers;
+  // Chunks (a workgroup takes kDirectChunkTiles consecutive tiles and carries a tile's overhang on): position-sorted reads.  A
+  // read that spans more than the overhang does not switch them off for the batch: the outliers are listed -- the ranges pass
+  // then reaches back over the COMMON span only and direct_outliers_kernel adds them to the tiles they reach -- and only the
+  // chunks they touch are dealt tile by tile.  Too many of them for the list (reads longer than the overhang, say): as before
+  // round 6 -- the full reach, no chunks.
+  b->direct_chunks = false;
+  if (kDirectChunkTiles > 1 && unsorted == 0 && max_l <= (uint32_t)kDirectOverhang) {
+    uint32_t listed = 0;
+    HIP_TRY(ctx, hipMemcpy(&listed, b->d_n_outliers, 4, hipMemcpyDeviceToHost));
+    if (listed <= b->outlier_cap) {
+      b->direct_chunks = true;
+      b->n_outliers_listed = listed;
+      if (n_outliers > 0) {
+        b->direct_reach_ranges = (int32_t)std::max<uint32_t>(1u, std::max(max_l, max_common));
+        const int64_t n_chunked = (b->n_tiles - b->n_tiles / kDirectTailDiv) / kDirectChunkTiles * kDirectChunkTiles;
+        std::vector<uint8_t> flag(nt), ok((size_t)std::max<int64_t>(1, n_chunked / kDirectChunkTiles), 1);
+        HIP_TRY(ctx, hipMemcpy(flag.data(), b->d_tile_flag, nt, hipMemcpyDeviceToHost));
+        for (int64_t t = 0; t < n_chunked; ++t)
+          if (flag[(size_t)t]) ok[(size_t)(t / kDirectChunkTiles)] = 0;
+        HIP_TRY(ctx, hipMalloc(&b->d_chunk_ok, ok.size()));
+        HIP_TRY(ctx, hipMemcpy(b->d_chunk_ok, ok.data(), ok.size(), hipMemcpyHostToDevice));
+      }
+    }
+  }
   b->alg_bytes = (int64_t)alg + 17 * b->n_sites;
   b->n_long = (int64_t)n_long;
   if (n_long > 0) {      // a read beyond the fast paths' limits: the whole batch takes the long path, nothing else is built
@@ -1585,6 +1633,11 @@ int32_t direct_prepare(midas_snps_batch* b) {
     lp.rec = b->d_drec;
     lp.payload = nullptr;
     unsigned long long units = 0;
+    hipEvent_t lev[2] = {nullptr, nullptr};       // (how long the layout takes on the device: reported beside the step it feeds)
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipEventDestroy(e[k]); } } ev_guard{lev};
+    HIP_TRY(ctx, hipEventCreate(&lev[0]));
+    HIP_TRY(ctx, hipEventCreate(&lev[1]));
+    HIP_TRY(ctx, hipEventRecord(lev[0], s));
     if (b->n_reads > 0) {
       HIP_TRY(ctx, launch_direct_layout_sizes(lp, s));
       HIP_TRY(ctx, hipMemcpyAsync(&units, b->d_dunits + nb, 8, hipMemcpyDeviceToHost, s));
@@ -1601,12 +1654,18 @@ int32_t direct_prepare(midas_snps_batch* b) {
     HIP_TRY(ctx, hipMemsetAsync(b->d_dpay + b->direct_payload_bytes, 0, kPaySlack, s));
     lp.payload = b->d_dpay;
     if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_layout_fill(lp, s));
+    HIP_TRY(ctx, hipEventRecord(lev[1], s));
+    HIP_TRY(ctx, hipEventSynchronize(lev[1]));
+    float lms = 0.f;
+    if (hipEventElapsedTime(&lms, lev[0], lev[1]) == hipSuccess) b->layout_build_us = (int32_t)(lms * 1000.f + 0.5f);
+    (void)hipGetLastError();
   }
   if (b->resident) b->direct_payload_bytes = b->rr.payload_units * 8;
   // the tile ranges once, to see how well the reads are ordered: a tile's stream holds every read between the first and the
   // last that can touch it
   fill_direct_index(b, &ip);
   HIP_TRY(ctx, launch_direct_ranges(ip, s));
+  if (b->direct_reach_ranges != b->direct_reach) HIP_TRY(ctx, launch_direct_outliers(b->d_outliers, b->n_outliers_listed, ip.tbegin, s));
   std::vector<uint32_t> tb(nt), te(nt);
   HIP_TRY(ctx, hipMemcpyAsync(tb.data(), ip.tbegin, nt * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(te.data(), ip.tend, nt * 4, hipMemcpyDeviceToHost, s));
@@ -2143,6 +2202,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     DirectIndexParams dip;
     fill_direct_index(b, &dip);
     HIP_TRY(ctx, launch_direct_ranges(dip, s));
+    if (b->direct_reach_ranges != b->direct_reach) HIP_TRY(ctx, launch_direct_outliers(b->d_outliers, b->n_outliers_listed, dip.tbegin, s));
     if (ev) HIP_TRY(ctx, hipEventRecord(ev[1], s));
     DirectParams dp;
     dp.rec = b->d_drec; dp.payload = b->d_dpay;
@@ -2170,7 +2230,8 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     // chunks of consecutive tiles with a carried overhang (a read visited once): position-sorted reads none of which spans more
     // than the overhang; the last eighth of the tiles one by one, so that the workgroups finish together
     dp.chunk_tiles = 1; dp.n_chunked_tiles = 0;
-    if (kDirectChunkTiles > 1 && b->direct_sorted && b->direct_reach <= kDirectOverhang) {
+    dp.chunk_ok = b->d_chunk_ok;
+    if (b->direct_chunks) {
       dp.chunk_tiles = kDirectChunkTiles;
       dp.n_chunked_tiles = (int32_t)((b->n_tiles - b->n_tiles / kDirectTailDiv) / kDirectChunkTiles * kDirectChunkTiles);
     }
@@ -2514,7 +2575,7 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->path = b->path;
   out->path_auto = b->path_auto;
   out->lane_bases = b->path == MIDAS_SNPS_PATH_DIRECT ? b->direct_lane_bases : b->lane_bases;
-  out->reserved0 = 0;
+  out->layout_build_us = b->layout_build_us;
   out->direct_general_reads = b->direct_general;
   out->direct_reach = b->direct_reach;
   out->direct_stream_reads = b->direct_stream_reads;

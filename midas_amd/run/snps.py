@@ -368,11 +368,29 @@ def _whole(order, contigs):
     return items, {(cid, 0): (0, contigs[cid].length, True) for cids in order.values() for cid in cids}
 
 
+PHASES = None       # a list: every lap of the stage is appended as (name, seconds) -- bench.py's stage_e2e block sets it
+
+
 def _lap(name, t0):
     """(MIDAS_SNPS_TRACE=1: the stage's phases on stderr, beside the library's own laps)"""
+    now = time()
+    if PHASES is not None:
+        PHASES.append((name, now - t0))
     if os.environ.get("MIDAS_SNPS_TRACE"):
-        sys.stderr.write("[stage] %-44s %9.3f ms\n" % (name, (time() - t0) * 1e3))
-    return time()
+        sys.stderr.write("[stage] %-44s %9.3f ms\n" % (name, (now - t0) * 1e3))
+    return now
+
+
+def _since_process_start():
+    """Seconds this process has existed (its start time in /proc, to the clock tick): what lies in front of the stage's first
+    line -- the interpreter, the imports -- belongs to the command's wall time too."""
+    try:
+        import time as _t
+        with open("/proc/self/stat", "rb") as f:
+            ticks = int(f.read().rsplit(b")", 1)[1].split()[19])
+        return _t.clock_gettime(_t.CLOCK_BOOTTIME) - ticks / float(os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError, AttributeError):
+        return 0.0
 
 
 def _batch_groups(args, mine, order, ref_names, refid, reads, ctx):
@@ -730,6 +748,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     The context is opened first: the device may also inflate the BAM's blocks (_inflate_on_device)."""
     error, ctx = None, None
     stack = ExitStack()
+    t_lap = time()
     try:
         ctx = stack.enter_context(make_context())
     except abi.MidasSnpsError as e:
@@ -737,6 +756,7 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
     except Exception as e:
         error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)
+    _lap("device context (library loaded, HIP runtime up)", t_lap)
     with stack:
         # the drop-in runs the dependency's rule for the CIGAR op P (pysam's get_aligned_pairs treats BAM_CPAD like an
         # insertion: the query position advances); --pad_rule spec selects the SAM specification's (P consumes nothing)
@@ -748,7 +768,10 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         try:
             return _count_alleles(args, species, contigs, ctx)
         finally:
+            t_lap = time()
             dist.detach_context()
+            stack.close()
+            _lap("device context closed", t_lap)
 
 
 def _inflate_on_device(args, ctx, bampath, ws):
@@ -954,6 +977,7 @@ def _count_alleles(args, species, contigs, ctx):
             rows[i] = [st['genome_length'], st['covered_bases'], st['total_depth'], st['aligned_reads'], st['mapped_reads']]
     rows = dist.all_gather_summary(rows)
     _join_parts(args, all_ids, order, owner, rank)       # (the all-gather is also the "every part is on disk" point)
+    _lap("summary rows exchanged, parts joined", t_lap)
 
     # update alignment stats for species objects -- midas/run/snps.py:230-241
     for i, species_id in enumerate(all_ids):
@@ -997,7 +1021,11 @@ def remove_tmp(args):
 def run_pipeline(args):
     """Run entire pipeline -- midas/run/snps.py:268-305"""
     # (N ranks meet in the sample's temp directory: no process group, no torch -- midas_amd/dist.py)
+    t_lap = time()
+    if PHASES is not None or os.environ.get("MIDAS_SNPS_TRACE"):
+        _lap("process start -> run_pipeline (interpreter, imports, arguments)", t_lap - _since_process_start())
     rank, ws = dist.init_from_env(rendezvous_dir=os.path.join(args['outdir'], 'snps', 'temp'))
+    t_lap = _lap("ranks met", t_lap)
 
     print("\nReading reference data")
     start = time()
@@ -1041,11 +1069,14 @@ def run_pipeline(args):
             contigs.start()
         if rank == 0:
             index_bam(args)
+        t_lap = _lap("species, genome reader started, index_bam", t_lap)
         pysam_pileup(args, species, contigs)
+        t_lap = time()
         if rank == 0:
             snps_summary(args, species)
     dist.barrier()
     dist.finalize()      # (rank 0 returns when every rank has left the rendezvous directory: it may go with temp/)
+    _lap("summary.txt, ranks leave", t_lap)
 
     if args['remove_temp'] and rank == 0:
         remove_tmp(args)

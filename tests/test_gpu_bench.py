@@ -37,10 +37,17 @@ def test_two_ranks_of_bench_py_on_one_gpu():
     lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]        # rank 0 prints the one line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "sites/s"
-    assert d["config"]["sites_per_gpu"] == 15000000
-    # the whole job: both ranks' sites over the slowest rank's time
-    assert abs(d["value"] - 2 * 15000000 * 5 / (d["ms_per_step"] * 5 / 1e3)) / d["value"] < 1e-6
+    # N > 1: the line's own value is configs[3] -- BASELINE's multi-GPU configuration, ONE sample dealt to the ranks (strong) --
+    # and the per-rank configs[2]-style replicas are a block of their own
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "sites/s"
+    assert d["config"]["workload"].startswith("configs[3]") and d["config"]["sites_per_gpu"] == 200000000
     c3 = d["configs3_strong"]
     assert c3["ranks"] == 2 and c3["scaling"] == "strong" and c3["total_sites"] == 400000000 and c3["reads_counted_once"] is True
     assert len(c3["per_rank_ms_per_step"]) == 2 and c3["partition"]["weight_max_over_mean"] < 1.1
+    assert d["value"] == c3["value"] and d["ms_per_step"] == c3["ms_per_step"] and c3["steps"] == 5
+    # the whole job: every site of the sample, K times, over the slowest rank's time
+    assert abs(d["value"] - 400000000 * 5 / (d["ms_per_step"] * 5 / 1e3)) / d["value"] < 1e-6
+    assert 0.0 < d["roofline"]["frac"] < 1.0 and len(d["per_rank_ms_per_step"]) == 2
+    w = d["weak_replicas"]
+    assert w["scaling"] == "weak" and w["sites_per_gpu"] == 15000000 and "roofline" in w
+    assert abs(w["value"] - 2 * 15000000 * 5 / (w["ms_per_step"] * 5 / 1e3)) / w["value"] < 1e-6

@@ -102,3 +102,57 @@ def test_chunks_and_pieces_with_halo_reads(hip_ctx, thr_default):
     assert pt.n_contigs > table.n_contigs
     counts, allele, stats = hip_ctx.pileup(thr_default, pt, pr)
     assert np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)
+
+
+def test_a_few_long_spans_do_not_switch_the_chunks_off(hip_ctx):
+    """Real alignments hold the odd read with a 20 bp deletion or an N skip: its span exceeds the overhang.  Such outliers are
+    listed once per batch -- the ranges pass keeps to the common span (the tiles' streams stay as short as without them), the
+    tiles they reach find them through the list, and only the chunks they touch are piled up tile by tile.  Outliers on tile
+    and chunk borders, reaching one tile or many, first and last in their contig; held to the C oracle on both paths."""
+    rng = random.Random(21)
+    lengths = [TILE * 16, TILE * 4 + 5, TILE * 40, 900, TILE * 9]
+    reads, begin, ref = [], [0], []
+    n_out = 0
+    for n in lengths:
+        rs = _reads_for(rng, n, max(40, n // 12))
+        borders = [b for b in range(TILE, n, TILE)]
+        for k in range(max(2, n // 6000)):
+            l = 150
+            a = rng.randint(10, l - 10)
+            gap = rng.choice([11, 20, 200, 500, 1900, TILE, 3 * TILE + 7])                      # D or N: spans of 161 ... 6 300 sites
+            op = rng.choice([2, 3])
+            pos = (rng.choice(borders) - rng.choice([0, 1, a, a + gap // 2, l + gap - 1, l + gap, 161])) if borders and rng.random() < 0.7 \
+                else rng.randint(0, max(0, n - 1))
+            pos = max(0, min(n - 1, pos))
+            rs.append(dict(pos=pos, cigar=[(0, a), (op, gap), (0, l - a)], seq="".join(rng.choice("ACGT") for _ in range(l)),
+                           qual=[40] * l, nm=gap if op == 2 else 0, mapq=42))
+            n_out += 1
+        rs.sort(key=lambda r: r["pos"])
+        reads += rs
+        begin.append(len(reads))
+        ref.append("".join(rng.choice("ACGTacgtN") for _ in range(n)))
+    soa = H.reads_from_dicts(reads)
+    table = abi.ContigTable(length=lengths, species=[k % 2 for k in range(len(lengths))], read_begin=begin,
+                            ref=np.frombuffer("".join(ref).encode(), np.uint8), n_species=2,
+                            ids=["c%d" % k for k in range(len(lengths))], species_ids=["s0", "s1"])
+    args = dict(abi.DEFAULT_ARGS, mapid=0.0)          # (a 500 bp deletion is NM 500: keep those reads)
+    thr = abi.Thresholds.from_args(args)
+    st, er, oc, oa, os_ = c_oracle.pileup(thr, table, soa)
+    assert st == 0, (st, er)
+    b = hip_ctx.batch(table, soa)
+    info = b.info()
+    assert info.path == abi.PATH_DIRECT and info.direct_reach > 3 * TILE
+    # the streams are those of the common span -- the reads plus the straddlers (half of these reads sit on tile borders) -- not
+    # every read within 6 000 sites of a tile, which would be four tiles' worth per tile
+    assert info.direct_stream_reads < 2.5 * info.n_reads, (info.direct_stream_reads, info.n_reads)
+    for _ in range(2):
+        b.run(thr)
+        counts, allele, stats = b.fetch()
+        bad = np.nonzero((counts != oc).any(axis=1))[0]
+        assert bad.size == 0, "counts differ at %d sites, first %s" % (bad.size, bad[:8])
+        assert np.array_equal(allele, oa) and np.array_equal(stats, os_)
+    b.select_path(abi.PATH_PACKED)
+    b.run(thr)
+    c2, _, s2 = b.fetch()
+    assert np.array_equal(c2, oc) and np.array_equal(s2, os_)
+    b.close()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box (round 6): parity of the product kernel, then product against named variants on ONE box, alternating.
-#   tools/r06_ab.sh "<pytest targets or ->" <variant> [<variant> ...]
+# GPU box : parity of the product kernel, then product against named variants on ONE box, alternating.
+#   tools/ab_variants.sh "<pytest targets or ->" <variant> [<variant> ...]
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
-O=gpurun_out/r06_ab_$(date +%H%M%S).txt
+O=gpurun_out/ab_variants_$(date +%H%M%S).txt
 L=$PWD/midas_amd/lib/libmidas_snps_hip
 T=$1; shift
 if [ "$T" != "-" ]; then ( timeout 900 python -m pytest $T -x -q 2>&1 | tail -3 ) > $O; fi

@@ -58,9 +58,13 @@ def main():
         sz = sum(os.path.getsize(os.path.join(out, 'snps/output', f)) for f in os.listdir(os.path.join(out, 'snps/output')))
         print("run_midas.py snps --pileup --device_inflate %-4s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
             how, dt, contigs.n_sites / dt, len(os.listdir(os.path.join(out, 'snps/output'))), sz / 1e9), flush=True)
+        top = 0.0
         for line in r.stderr.splitlines():
-            if line.startswith(('[device decode]', '[batch_create]', '[stage]')):
+            if line.startswith(('[device decode]', '[batch_create]', '[stage]', '[bam ', '[fasta]')):
                 print("    " + line)
+            if line.startswith('[stage] ') and not line.startswith('[stage]   '):        # (un-indented: the stage's own consecutive phases)
+                top += float(line.split()[-2])
+        print("    the stage's un-indented phases add up to %.3f s of the %.3f s wall (the rest: interpreter exit, the launcher)" % (top / 1e3, dt), flush=True)
         runs.append(dt)
         if how == 'auto':
             keep = {f: text_crc(os.path.join(out, 'snps/output', f)) for f in sorted(os.listdir(os.path.join(out, 'snps/output')))} if len(runs) == 1 else keep
