@@ -409,6 +409,10 @@ int32_t midas_bam_open_slice_device(const char* path, int32_t slice, int32_t n_s
 int32_t midas_bam_load_device(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* seq_bytes,
                               int64_t* qual_bytes, int64_t* n_cigar, char* err256);
 int32_t midas_bam_payload_on_device(const midas_bam* bam);
+/* A handle of midas_bam_open_slice / _open_share whose ranges are loaded needs its file no more: the mapping is handed to a
+ * thread that unmaps it (a page-table walk of 0.2 s for a 9 GB BAM) while the caller piles the records up; the columns / the
+ * resident records stay.  midas_bam_load_ranges* on the handle afterwards is MIDAS_SNPS_ERR_INVALID_ARG.                       */
+void midas_bam_release_file(midas_bam* bam);
 int32_t midas_snps_copy_from_device(midas_snps_ctx* ctx, void* dst, const void* src, int64_t bytes);
 int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
                                      const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,

@@ -284,6 +284,7 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_open_slice_device': (i32, [C.c_char_p, i32, i32, vp, C.POINTER(vp), C.c_char_p]),
         'midas_bam_load_device': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_payload_on_device': (i32, [vp]),
+        'midas_bam_release_file': (None, [vp]),
         'midas_bam_load_resident': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_load_ranges_resident': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_is_resident': (i32, [vp]),
@@ -352,7 +353,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open', 'midas_bam_close', 'midas_bam_write', 'midas_bam_n_refs', 'midas_bam_ref', 'midas_bam_load', 'midas_bam_copy', 'midas_bam_columns',
     'midas_bam_open_slice', 'midas_bam_slice_facts', 'midas_bam_slice_marks', 'midas_bam_load_ranges',
     'midas_bam_open_device', 'midas_bam_open_slice_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
-    'midas_bam_payload_on_device', 'midas_snps_copy_from_device',
+    'midas_bam_payload_on_device', 'midas_snps_copy_from_device', 'midas_bam_release_file',
     'midas_bam_load_resident', 'midas_bam_load_ranges_resident', 'midas_bam_is_resident', 'midas_bam_resident_to_columns',
     'midas_snps_batch_create_resident',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
@@ -773,6 +774,11 @@ class BamSlice:
         keeper._slice = self                # the arrays keep this object (and with it the native handle) alive
         return _bam_columns(self._lib, self._h, int(n.value), int(sb.value), int(qb.value), int(nc.value), keeper,
                             on_device=bool(self._lib.midas_bam_payload_on_device(self._h)))
+
+    def release_file(self):
+        """The ranges are loaded: the file's mapping is unmapped on a thread of its own (midas_bam_release_file)."""
+        if getattr(self, '_h', None):
+            self._lib.midas_bam_release_file(self._h)
 
     def close(self):
         if getattr(self, '_h', None):

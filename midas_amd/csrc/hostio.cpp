@@ -599,6 +599,26 @@ int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256) {
   void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
   if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   m.base = static_cast<const uint8_t*>(a);
+  {   // the pages are mapped in by several threads (one read per page: the kernel maps a run of cached pages per fault) -- the
+      // block table's walk below and the decoders' copies then find them there
+    (void)madvise(a, m.size, MADV_WILLNEED);
+    const size_t piece = (size_t)8 << 20, n_pieces = (m.size + piece - 1) / piece;
+    const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
+    std::atomic<size_t> nextp{0};
+    std::atomic<unsigned> sink{0};
+    const uint8_t* base = m.base;
+    const size_t fsz = m.size;
+    Workers::run(n_workers, [&] {
+      unsigned acc = 0;
+      for (;;) {
+        const size_t k = nextp.fetch_add(1);
+        if (k >= n_pieces) break;
+        const size_t end = std::min(fsz, (k + 1) * piece);
+        for (size_t off = k * piece; off < end; off += 4096) acc += base[off];
+      }
+      sink += acc;
+    });
+  }
   size_t p = 0;
   uint64_t upos = 0;
   while (p < m.size) {
@@ -1361,6 +1381,14 @@ int32_t midas_bam_load(midas_bam* b, int64_t* n_reads, int64_t* seq_bytes, int64
 }
 
 int32_t midas_bam_payload_on_device(const midas_bam* b) { return b && b->payload_on_device ? 1 : 0; }
+
+// The file's mapping is not needed any more (its records are decoded): it is taken from the handle and unmapped on a thread of
+// its own.  Unmapping a BAM of gigabytes is a page-table walk of a tenth of a second and more -- time the caller can spend on
+// the pileup instead of at the handle's close.  The handle keeps its columns / resident records; it cannot load ranges again.
+void midas_bam_release_file(midas_bam* b) {
+  if (!b || !b->map) return;
+  std::thread([](std::unique_ptr<BgzfMap> gone) { gone.reset(); }, std::move(b->map)).detach();
+}
 
 int32_t midas_bam_columns(const midas_bam* b, const void** out12) {
   if (!b || !b->loaded || !out12) return MIDAS_SNPS_ERR_INVALID_ARG;

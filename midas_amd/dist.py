@@ -466,6 +466,24 @@ def all_gather_i64(values):
     return out.reshape(ws, -1).cpu().numpy()
 
 
+def all_gather_blob(data):
+    """data: bytes of any length on every rank -> the ranks' blobs, by rank (the genomes' index: midas_amd/run/snps.py)."""
+    data = bytes(data)
+    rank, ws = world()
+    if ws == 1:
+        return [data]
+    if _native is not None:
+        return _native.all_gather_bytes(data)
+    sizes = all_gather_i64([len(data)])[:, 0]
+    width = (int(sizes.max()) + 7) // 8
+    if width == 0:
+        return [b""] * ws
+    padded = np.zeros(width * 8, np.uint8)
+    padded[:len(data)] = np.frombuffer(data, np.uint8)
+    got = all_gather_i64(padded.view(np.int64))
+    return [got[r].view(np.uint8)[:int(sizes[r])].tobytes() for r in range(ws)]
+
+
 def all_gather_rows_f64(rows):
     """Like all_gather_summary for float64 rows (the genes summary has means and medians): rows are zero outside the
     species this rank owns, so the sum over ranks is the owner's row (nan stays nan)."""

@@ -71,8 +71,8 @@ class Contig:
     def __init__(self, id, seq='', species_id=None, pool=None, pool_at=0):
         self.id = id
         self._seq = seq if isinstance(seq, str) else None
-        self.seq_bytes = seq.encode('latin-1') if isinstance(seq, str) else seq      # (bytes-like: bytes or a uint8 array)
-        self.length = len(seq)
+        self.seq_bytes = seq.encode('latin-1') if isinstance(seq, str) else seq      # (bytes-like: bytes or a uint8 array; None: known
+        self.length = len(seq) if seq is not None else 0                             #  by id, species and length only -- DealtContigs)
         self.species_id = species_id
         self.pool, self.pool_at = pool, pool_at     # initialize_contigs: all sequences back to back in one array
 
@@ -149,6 +149,8 @@ def initialize_contigs(species, threads=None):
     midas_amd/fasta.py, which the tests hold it to -- 400 Mb of genomes take the interpreter's own reader 0.8 s on its one core,
     beside a BAM decode that is done sooner)."""
     sps = list(species.values())
+    if not sps:
+        return {}
     for sp in sps:
         if 'fna' not in sp.paths:
             sys.exit("\nError: Could not locate the representative genome of species: %s\n" % sp.id)
@@ -159,14 +161,80 @@ def initialize_contigs(species, threads=None):
     return {rid: Contig(rid, arr[at:at + n], sps[fi].id, arr, at) for rid, fi, at, n in recs}
 
 
+class DealtContigs(Mapping):
+    """N ranks: every rank would read every species' genome -- the same 400 Mb parsed eight times over, on two CPUs each, and at
+    eight ranks the longest thing a rank does.  Instead the genome FILES are dealt to the ranks (contiguous runs of the species
+    list, by file size: the order the alignment's contigs -- and with them the ranks' shares of the BAM -- follow); a rank reads
+    its run beside its BAM decode; `exchange()` all-gathers what every rank learned -- (contig id, species, length), a few tens
+    of bytes a contig -- so that every rank knows EVERY contig (the emit order, the weights and the owners need no more); the
+    sequences of contigs this rank piles up but another rank read are parsed when `need()` asks (the runs and the shares rarely
+    differ by more than a species at each end).  Looks like initialize_contigs' dict; a contig whose sequence is not here has
+    `seq_bytes` None until needed."""
+
+    def __init__(self, species, loaded):
+        self._species, self._all = species, dict(loaded)
+        self._have = {c.species_id for c in loaded.values()}         # species whose files this rank has parsed
+        self._mine = list(loaded)
+
+    def exchange(self):
+        """Collective: every rank's (id, species, length) of the contigs it read -> the index of all contigs, on every rank."""
+        order = {sp: k for k, sp in enumerate(self._species)}
+        ids = list(self._species)
+        mine = "\n".join("%s\t%d\t%d" % (cid, order[self._all[cid].species_id], self._all[cid].length) for cid in self._mine)
+        for r, blob in enumerate(dist.all_gather_blob(mine.encode('latin-1'))):
+            for line in blob.decode('latin-1').split("\n") if blob else ():
+                cid, k, n = line.rsplit("\t", 2)
+                if cid not in self._all:
+                    c = Contig(cid, None, ids[int(k)])
+                    c.length = int(n)
+                    self._all[cid] = c
+        return self
+
+    def need(self, contig_ids):
+        """The sequences of these contigs are about to be piled up: the files of those another rank read are parsed now."""
+        missing = sorted({self._all[cid].species_id for cid in contig_ids if self._all[cid].seq_bytes is None} - self._have)
+        if missing:
+            self._all.update(initialize_contigs({sp: self._species[sp] for sp in missing}))
+            self._have.update(missing)
+        return len(missing)
+
+    def __getitem__(self, key):
+        return self._all[key]
+
+    def __iter__(self):
+        return iter(self._all)
+
+    def __len__(self):
+        return len(self._all)
+
+
+def deal_species(species, rank, ws):
+    """The species whose genome files rank `rank` of `ws` reads: a contiguous run of the species list, the runs even in bytes."""
+    ids = list(species)
+    size = []
+    for sp in ids:
+        try:
+            size.append(max(1, os.path.getsize(species[sp].paths.get('fna', ''))))
+        except OSError:
+            size.append(1)          # (a missing genome: whoever is dealt it says so, midas/run/snps.py:57)
+    total, acc, mine = float(sum(size)) or 1.0, 0.0, []
+    for sp, s in zip(ids, size):
+        if min(ws - 1, int(ws * (acc + s / 2.0) / total)) == rank:
+            mine.append(sp)
+        acc += s
+    return mine
+
+
 class ContigsInBackground(Mapping):
     """initialize_contigs on a thread of its own: the mapping is there at once and waits for the reader the first time it is
     looked into.  The pileup's first act is the BAM decode -- native code that does not hold the interpreter -- so the
     genomes are read while the alignments are inflated instead of in front of them.  What the reader raises (a missing
-    genome ends the run, midas/run/snps.py:57) is raised where the mapping is first used."""
+    genome ends the run, midas/run/snps.py:57) is raised where the mapping is first used.
+    deal = (rank, ranks): this rank reads its run of the genome files only; wait() then hands out a DealtContigs."""
 
-    def __init__(self, species, start=True):
+    def __init__(self, species, start=True, deal=None):
         self._out, self._err, self._thread, self._species = None, None, None, species
+        self._deal = deal if deal and deal[1] > 1 else None
         if start:
             self.start()
 
@@ -178,7 +246,11 @@ class ContigsInBackground(Mapping):
 
         def work():
             try:
-                self._out = initialize_contigs(self._species)
+                if self._deal is not None:
+                    run = deal_species(self._species, *self._deal)
+                    self._out = DealtContigs(self._species, initialize_contigs({sp: self._species[sp] for sp in run}))
+                else:
+                    self._out = initialize_contigs(self._species)
             except BaseException as e:       # (SystemExit included: it must end the main thread's run, not this thread)
                 self._err = e
         self._thread = threading.Thread(target=work, name="read-genomes", daemon=True)
@@ -369,6 +441,31 @@ def _whole(order, contigs):
 
 
 PHASES = None       # a list: every lap of the stage is appended as (name, seconds) -- bench.py's stage_e2e block sets it
+_T_END = [0.0]      # when _count_alleles reached its last line (what follows is the release of its locals)
+
+
+class BamInBackground:
+    """One rank, a device that will decode: the BAM is opened -- mapped, its pages touched by several threads, its BGZF block
+    table walked, its header parsed (midas_bam_open_share with one share: the whole file) -- on a thread of its own while the
+    main thread brings the device context up (the library's code objects, the HIP runtime: 0.15-0.2 s that need no file).
+    wait() hands the handle out, or None when anything went wrong (the ordinary decode then says what)."""
+
+    def __init__(self, path):
+        import threading
+        self._share, self._path = None, path
+        self._thread = threading.Thread(target=self._open, daemon=True)
+        self._thread.start()
+
+    def _open(self):
+        try:
+            self._share = abi.BamShare(self._path, 0, 1)
+        except Exception:
+            self._share = None
+
+    def wait(self):
+        self._thread.join()
+        share, self._share = self._share, None
+        return share
 
 
 def _lap(name, t0):
@@ -768,7 +865,9 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
         try:
             return _count_alleles(args, species, contigs, ctx)
         finally:
-            t_lap = time()
+            # (between _count_alleles' last line and here its locals went: the decoded BAM's handle -- the file's mapping, the
+            # device arena with the inflated stream and the records -- and the batch's results)
+            t_lap = _lap("the rank's reads and results released", _T_END[0] if _T_END[0] else time())
             dist.detach_context()
             stack.close()
             _lap("device context closed", t_lap)
@@ -826,6 +925,7 @@ def _count_alleles(args, species, contigs, ctx):
             try:
                 refid, reads = share[0].load_ranges([(share[1], share[2])], inflater, resident=True)
                 decoded = (share[0].ref_names, share[0].ref_lens, refid, reads)
+                share[0].release_file()      # (the share's bytes are on the device / decoded: the mapping goes while the records are piled up)
             except abi.MidasSnpsError as e:
                 if e.status == abi.ERR_BAD_LAYOUT:
                     # a guessed border that is no record border -- this rank's end, or its own start (then the decode meets
@@ -872,7 +972,16 @@ def _count_alleles(args, species, contigs, ctx):
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
             try:
                 # ... in the pileup kernel's own layout, every column included (abi.ResidentReads): ONE pass from the file to the tallies
-                decoded = abi.read_bam(bampath, inflater, resident=inflater is not None and ws == 1)
+                opened = args.pop('_bam_opener').wait() if args.get('_bam_opener') is not None else None
+                if opened is not None and inflater is not None and ws == 1 and 0 <= opened.first < opened.total:
+                    # (the file was mapped and its block table walked while the device context came up)
+                    refid, rr = opened.load_ranges([(opened.first, opened.total)], inflater, resident=True)
+                    opened.release_file()        # (its bytes are on the device: the mapping goes while the records are piled up)
+                    decoded = (opened.ref_names, opened.ref_lens, refid, rr)
+                else:
+                    if opened is not None:
+                        opened.close()
+                    decoded = abi.read_bam(bampath, inflater, resident=inflater is not None and ws == 1)
             except abi.MidasSnpsError as e:
                 # 'auto' chose the device and the device could not (its memory, a HIP error): the host's threads can
                 if inflater is None or args.get('device_inflate', 'auto') != 'auto' or e.status not in (abi.ERR_OUT_OF_MEMORY, abi.ERR_HIP):
@@ -905,6 +1014,8 @@ def _count_alleles(args, species, contigs, ctx):
     except Exception as e:
         error = "\nError: %s: %s\n" % (type(e).__name__, e)
     dist.agree_or_exit(error)
+    if isinstance(contigs, DealtContigs):
+        contigs.exchange()          # (every rank read its run of the genome files: now every rank knows every contig)
     by_species = _species_contig_order(all_ids, contigs)
     ref_index = {n: i for i, n in enumerate(ref_names)}
     piece_len = pieces.piece_length(int(args.get('split_length', SPLIT_LENGTH))) if plan is not None and plan['pos_sorted'] else 0
@@ -959,6 +1070,10 @@ def _count_alleles(args, species, contigs, ctx):
     t_lap = _lap("decode, plan, genomes, work items", start)
     local = {}
     try:
+        if isinstance(contigs, DealtContigs):
+            late = contigs.need({cid for cid, _ in mine})
+            if late and args.get('log') is not None:
+                args['log'].write("genomes: %d species of this rank's contigs were in another rank's run of the files: read now\n" % late)
         local = _pileup_contigs(args, all_ids, mine, order, owner, decoded, ctx, span, contigs, halo)
         t_lap = _lap("pileup of the rank's contigs (all batches)", t_lap)
     except abi.MidasSnpsError as e:
@@ -995,6 +1110,7 @@ def _count_alleles(args, species, contigs, ctx):
     if rank == 0:
         print("  %s minutes" % round((time() - start) / 60, 2))
         print("  %s Gb maximum memory" % utility.max_mem_usage())
+    _T_END[0] = time()
 
 
 def snps_summary(args, species):
@@ -1032,7 +1148,8 @@ def run_pipeline(args):
     species = initialize_species(args)
     # (the genomes are read on a thread of their own and waited for where the pileup first needs them)
     # (with --build_db / --align in front of the pileup the reader starts behind them: rank 0 reads the same files there)
-    contigs = (ContigsInBackground(species, start=not (args['build_db'] or args['align'])) if args['call']
+    # (N ranks: the genome files are dealt to the ranks -- DealtContigs)
+    contigs = (ContigsInBackground(species, start=not (args['build_db'] or args['align']), deal=(rank, ws)) if args['call']
                else initialize_contigs(species))
     print("  %s minutes" % round((time() - start) / 60, 2))
     print("  %s Gb maximum memory" % utility.max_mem_usage())
@@ -1069,6 +1186,8 @@ def run_pipeline(args):
             contigs.start()
         if rank == 0:
             index_bam(args)
+        if ws == 1 and args.get('device_inflate', 'auto') not in (False, 'off') and '_bam_opener' not in args:
+            args['_bam_opener'] = BamInBackground('%s/snps/temp/genomes.bam' % args['outdir'])
         t_lap = _lap("species, genome reader started, index_bam", t_lap)
         pysam_pileup(args, species, contigs)
         t_lap = time()

@@ -225,7 +225,8 @@ if os.environ.get("SNPS_SPLIT_LENGTH"):
 if os.environ.get("SNPS_DEVICE_INFLATE"):
     args['device_inflate'] = os.environ["SNPS_DEVICE_INFLATE"]
 species = msnps.initialize_species(args)
-contigs = msnps.initialize_contigs(species)
+# (run_pipeline's way at N ranks: the genome files dealt to the ranks, DealtContigs; SNPS_ALL_GENOMES=1: every rank reads them all)
+contigs = msnps.initialize_contigs(species) if os.environ.get("SNPS_ALL_GENOMES") or ws == 1 else msnps.ContigsInBackground(species, deal=(rank, ws))
 if os.environ.get("SNPS_REAL_DEVICE"):       # (tests/test_gpu_dist.py: the ranks share GPU 0)
     os.environ["LOCAL_RANK"] = "0"
     msnps.pysam_pileup(args, species, contigs)

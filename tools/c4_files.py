@@ -46,17 +46,20 @@ def main():
         contigs.n_species, contigs.n_contigs, contigs.n_sites, reads.n_reads, t1 - t0, time.time() - t1, os.path.getsize(bam) / 1e9,
         utility.cpu_budget()), flush=True)
     runs = []
-    for how in ('auto', 'auto', 'off'):
+    for how in ('auto', 'auto', 'auto', 'off'):
         shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)
+        env = dict(os.environ, MIDAS_SNPS_TRACE='1')
+        if how.endswith('fast-exit'):
+            env['MIDAS_SNPS_EXIT'] = 'fast'
         t = time.perf_counter()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, MIDAS_SNPS_TRACE='1'))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how.split()[0]],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         dt = time.perf_counter() - t
         if r.returncode != 0:
             print("run_midas.py failed:", r.stderr[-3000:])
             sys.exit(1)
         sz = sum(os.path.getsize(os.path.join(out, 'snps/output', f)) for f in os.listdir(os.path.join(out, 'snps/output')))
-        print("run_midas.py snps --pileup --device_inflate %-4s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
+        print("run_midas.py snps --pileup --device_inflate %-14s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
             how, dt, contigs.n_sites / dt, len(os.listdir(os.path.join(out, 'snps/output'))), sz / 1e9), flush=True)
         top = 0.0
         for line in r.stderr.splitlines():
@@ -66,7 +69,7 @@ def main():
                 top += float(line.split()[-2])
         print("    the stage's un-indented phases add up to %.3f s of the %.3f s wall (the rest: interpreter exit, the launcher)" % (top / 1e3, dt), flush=True)
         runs.append(dt)
-        if how == 'auto':
+        if how.startswith('auto'):
             keep = {f: text_crc(os.path.join(out, 'snps/output', f)) for f in sorted(os.listdir(os.path.join(out, 'snps/output')))} if len(runs) == 1 else keep
     # ---- the oracle: counts by the C restatement (all cores), text by the host's row writer, CRC-32 of the text ----
     thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)

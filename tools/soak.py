@@ -1,7 +1,8 @@
 """Developer soak (GPU box): random dataset shapes against the C oracle, every batch run three times (the self-resetting
 device counters -- split tickets, dynamic work items -- must leave no state behind), on the path the batch chooses and on the
 other one; the same work cut into pieces (midas_snps_contigs.origin); the rows from the device's coder against the host
-formatter's text; the columns' bytes through zlib and back through the device inflater.
+formatter's text; the columns' bytes through zlib and back through the device inflater; the reads as a BAM decoded resident on the
+device and batched in place (round 6).
 usage: python tools/soak.py [seconds] [seed] [big]"""
 import gzip
 import os
@@ -38,7 +39,7 @@ def main():
     ctx = abi.Context(0)
     t_end = time.time() + budget
     n = bad = 0
-    tally = {'rows': 0, 'pieces': 0, 'inflate': 0}
+    tally = {'rows': 0, 'pieces': 0, 'inflate': 0, 'resident': 0}
     while time.time() < t_end:
         read_len = int(rng.choice([36, 75, 100, 125, 150, 151, 250]))
         big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # > 1024 tiles: the dynamic work-item path
@@ -55,6 +56,23 @@ def main():
             moved = hot_spot(contigs, reads, rng, float(rng.choice([0.3, 0.9])))
             if moved is not None:
                 reads, tag = moved, ' hot'
+        if 200 < reads.n_reads <= 150000 and not tag and rng.random() < 0.35:
+            # outliers: a few reads get a long deletion / skip in the middle (their span leaves the overhang, or several tiles)
+            cig, coff = reads.cigar.copy(), reads.cigar_off
+            pick = rng.choice(reads.n_reads, size=min(40, reads.n_reads // 50 + 1), replace=False)
+            new_cig, new_off = [], [0]
+            chosen = set(int(x) for x in pick)
+            for i in range(reads.n_reads):
+                ops = cig[coff[i]:coff[i + 1]]
+                if i in chosen and ops.size == 1 and (ops[0] & 15) == 0 and (ops[0] >> 4) >= 20:
+                    l = int(ops[0] >> 4)
+                    a_ = int(rng.integers(5, l - 5))
+                    gap = int(rng.choice([12, 40, 300, 2100, 5000]))
+                    ops = np.array([(a_ << 4) | 0, (gap << 4) | int(rng.choice([2, 3])), ((l - a_) << 4) | 0], np.uint32)
+                new_cig.append(ops)
+                new_off.append(new_off[-1] + ops.size)
+            reads = abi.ReadsSoA(**{**reads.as_dict(), "cigar": np.concatenate(new_cig) if new_cig else cig, "cigar_off": np.array(new_off, np.int64)})
+            tag = ' outliers'
         args = dict(abi.DEFAULT_ARGS)
         if rng.random() < 0.3:
             args.update(baseq=int(rng.choice([0, 20, 41])), mapq=int(rng.choice([0, 30])), mapid=float(rng.choice([90.0, 97.5])),
@@ -124,6 +142,30 @@ def main():
             if bytes(got) != blob:
                 ok = False; extra.append("inflate")
             tally['inflate'] += 1
+        if st == 0 and ok and reads.n_reads > 0 and reads.n_reads <= 600000 and rng.random() < 0.5:
+            # ONE pass from the BAM's bytes: the same reads written as a BAM, decoded on the device into the kernel's own layout,
+            # batched where they lie (midas_snps_batch_create_resident) -- the direct path, then the packed or the long one
+            # (their columns cut out of the handle's stream)
+            with tempfile.TemporaryDirectory() as td:
+                path = td + "/s.bam"
+                refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+                abi.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=int(rng.choice([1, 6])))
+                _, _, rid, res = abi.read_bam(path, ctx, resident=True)
+                rb = ctx.batch(contigs, res)
+                for pth in (None, abi.PATH_PACKED if rng.random() < 0.5 else abi.PATH_LONG):
+                    try:
+                        if pth is not None:
+                            rb.select_path(pth)
+                        rb.run(thr)
+                        c5, a5, s5 = rb.fetch()
+                        if not (np.array_equal(c5, oc) and np.array_equal(a5, oa) and np.array_equal(s5, os_)):
+                            ok = False; extra.append("resident %s" % abi.PATH_NAMES[rb.info().path])
+                    except abi.MidasSnpsError as e:
+                        if pth is None:
+                            ok = False; extra.append("resident: %s" % e.message)
+                rb.close()
+                del res, rid
+            tally['resident'] += 1
         n += 1
         if not ok:
             bad += 1
