@@ -54,6 +54,34 @@ def write_bam(path, ref_names, ref_lengths, refid, reads, read_names=None, heade
         f.write(_EOF_BLOCK)
 
 
+def read_header(path):
+    """(reference names, reference lengths) of a BAM's header, from its first BGZF blocks alone (gzip members: the standard
+    library reads them) -- what a rank needs before it decides how the file is dealt, without mapping or walking the file."""
+    import gzip
+    with gzip.open(path, 'rb') as f:
+        def need(n):
+            out = b""
+            while len(out) < n:
+                piece = f.read(n - len(out))
+                if not piece:
+                    raise ValueError("%s: truncated BAM header" % path)
+                out += piece
+            return out
+        head = need(12)
+        if head[:4] != b"BAM\1":
+            raise ValueError("%s: missing BAM magic" % path)
+        l_text, = struct.unpack("<i", head[4:8])
+        rest = head[8:]                       # (the first four bytes of the text, or of n_ref when there is none)
+        body = rest + need(l_text + 4 - len(rest)) if l_text + 4 > len(rest) else rest
+        n_ref, = struct.unpack("<i", body[l_text:l_text + 4])
+        names, lens = [], []
+        for _ in range(n_ref):
+            l_name, = struct.unpack("<i", need(4))
+            names.append(need(l_name)[:-1].decode('latin-1'))
+            lens.append(struct.unpack("<i", need(4))[0])
+    return names, lens
+
+
 def group_by_contig(ref_names, refid, reads, contig_ids, fetch=None):
     """Records of a decoded BAM -> (ReadsSoA in contig-table order, read_begin) for the given contig ids.
     A coordinate-sorted BAM is already grouped by refID; anything else -- records of contigs that are not wanted among

@@ -589,7 +589,7 @@ void run_pool(int nt, size_t n_tasks, F&& fn) {
 }
 
 // ---- rank-local BAM decode: block table, slice walk with verified record-boundary guessing, range loads -------------------
-int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256) {
+int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool touch = true) {
   m.fd = open(path.c_str(), O_RDONLY);
   if (m.fd < 0) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
   struct stat st;
@@ -599,8 +599,9 @@ int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256) {
   void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
   if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   m.base = static_cast<const uint8_t*>(a);
-  {   // the pages are mapped in by several threads (one read per page: the kernel maps a run of cached pages per fault) -- the
-      // block table's walk below and the decoders' copies then find them there
+  if (touch) {   // the pages are mapped in by several threads (one read per page: the kernel maps a run of cached pages per fault)
+      // -- the block table's walk below and the decoders' copies then find them there.  (Only for a caller that will read the WHOLE
+      // file: a rank of N that takes 1 / N of it maps what it walks and what it decodes, on the CPUs a rank of N has.)
     (void)madvise(a, m.size, MADV_WILLNEED);
     const size_t piece = (size_t)8 << 20, n_pieces = (m.size + piece - 1) / piece;
     const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
@@ -1468,7 +1469,7 @@ int32_t midas::bam_open_slice_with(const char* path, int32_t slice, int32_t n_sl
   if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   b->path = path;
   b->map.reset(new BgzfMap());
-  int32_t st = bgzf_map_file(b->path, *b->map, err256);
+  int32_t st = bgzf_map_file(b->path, *b->map, err256, n_slices == 1);
   if (st != MIDAS_SNPS_OK) return st;
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();
@@ -1616,7 +1617,7 @@ int32_t midas::bam_open_share(const char* path, int32_t slice, int32_t n_slices,
   if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
   b->path = path;
   b->map.reset(new BgzfMap());
-  int32_t st = bgzf_map_file(b->path, *b->map, err256);
+  int32_t st = bgzf_map_file(b->path, *b->map, err256, n_slices == 1);
   if (st != MIDAS_SNPS_OK) return st;
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();

@@ -450,7 +450,10 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       const uint32_t nc = rd_cur.l_nc >> 16;
       const int nb = l - q0 < LB ? (l - q0 < 0 ? 0 : l - q0) : LB;     // bases of the read in this lane
       const bool has = nb > 0;
-      uint32_t qsum = (kDebug & 64) ? 0x00FFFFFFu : read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
+      // (developer timing variant, bit 512: ALL per-read work off -- no quality sum, no CIGAR shape, no filter tables: every read is
+      // one match run of its length and kept; the tallies and the stream stay.  What a scheme that does the per-read work once
+      // per read instead of on each of its lanes could save AT MOST: profiles/r06_kernel_experiments.txt section 3)
+      uint32_t qsum = (kDebug & (64 | 512)) ? 0x00FFFFFFu : read_sum(has ? lane_qsum(dat_cur.q, nb) : 0u);
       const bool t_noqual = (qsum >> 31) != 0u;
       qsum &= 0x7FFFFFFFu;
       const uint32_t nm16 = rd_cur.nmq & 0xFFFFu;
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       ReadShape sh;
       sh.lead = 0u; sh.m1 = (uint32_t)l; sh.ins = 0u; sh.del = 0u; sh.alen = (uint32_t)l;
       bool shaped = nc == 1u && op_is_match(dat_cur.cg[0] & 15u) && (dat_cur.cg[0] >> 4) == (uint32_t)l && l >= 1;
+      if (kDebug & 512) shaped = true;
       if (__ballot(act && !shaped) != 0ull) {
         ReadShape s2;
         const bool ok = decode_shape(dat_cur.cg[0], dat_cur.cg[1], dat_cur.cg[2], dat_cur.cg[3], nc, (uint32_t)l, &s2);
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
       uint32_t err;
       {
         // ---- keep_read (midas/run/snps.py:141-162): such a read has SEQ, NM and a non-empty aligned part -----------------------
-        const int min_match = s_tables[align_len < p.table_len ? align_len : 0];
-        const int min_align = s_tables[p.table_len + (l < p.table_len ? l : 0)];
+        const int min_match = (kDebug & 512) ? 0 : s_tables[align_len < p.table_len ? align_len : 0];
+        const int min_align = (kDebug & 512) ? 0 : s_tables[p.table_len + (l < p.table_len ? l : 0)];
         const bool t_pid = align_len - nm < min_match;                                                       // pid < mapid
         const bool t_drop = ((int)qsum < rq * l) | (mapq < p.mapq_min) | (align_len < min_align);             // readq, mapq, aln_cov
         err = (fast && !t_pid && t_noqual) ? (uint32_t)E_NO_QUAL : 0u;

@@ -4,7 +4,7 @@
 # bench command for configs[2] and configs[1].  Text summaries only land in gpurun_out/evidence/ (the rocpd databases are
 # tens of MiB each and are deleted here).   usage: tools/evidence.sh [tag]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV
@@ -33,7 +33,8 @@ prof c3
 prof c2 --config c2
 # the stage end to end at configs[1] (configs[2] takes three minutes of set-up: tools/e2e_stage.py c3, run by hand) and the
 # row coder's kernel under rocprofv3
-E2E_REPS=3 timeout 900 python tools/e2e_stage.py c2 /tmp/e2e_c2 > $EV/e2e_stage_c2.txt 2>&1
+E2E_REPS=3 E2E_DEVICE_DECODE=1 timeout 900 python tools/e2e_stage.py c2 /tmp/e2e_c2 > $EV/e2e_stage_c2.txt 2>&1
+MIDAS_SNPS_TRACE=1 E2E_REPS=2 E2E_DEVICE_DECODE=1 timeout 900 python tools/e2e_stage.py c3 /tmp/e2e_c3 2>&1 | grep -v "write rows\]\|rows on device\]\|write coded" > $EV/e2e_stage_c3.txt
 ( cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_rows -o rows -- python $REPO/tools/rows_probe.py c2 > $EV/rows_probe_c2.log 2>&1 )
 { echo "# rocprofv3 --kernel-trace --stats -- python tools/rows_probe.py c2   (three device-coded and three host-coded writes of the 15 M rows of configs[1])"

@@ -51,6 +51,8 @@ wrap(abi.BamSlice, 'load_ranges', "decode of its share (resident)", turn=True)
 wrap(msnps, '_pileup_contigs', "contig table, batch, pileup, rows + write", turn=True)
 wrap(msnps, '_one_pass_shares', "share offsets (host walk + exchange)")
 wrap(msnps.DealtContigs, 'need', "genomes read late")
+wrap(msnps.ContigsInBackground, 'wait', "genomes waited for")
+wrap(msnps, '_header_lengths', "BAM header")
 wrap(msnps, '_join_parts', "parts joined")
 for name in ('agree_or_exit', 'all_gather_i64', 'all_gather_blob', 'all_gather_summary', 'barrier', 'attach_context'):
     wrap(dist, name, "the other ranks at an exchange", waiting=True)
