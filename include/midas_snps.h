@@ -440,6 +440,16 @@ int32_t midas_bam_load_resident(const char* path, midas_snps_ctx* ctx, midas_bam
 int32_t midas_bam_load_ranges_resident(midas_bam* bam, midas_snps_ctx* ctx, int32_t n_ranges, const int64_t* range_begin,
                                        const int64_t* range_end, int64_t* n_reads, int64_t* sum_l_seq, char* err256);
 int32_t midas_bam_is_resident(const midas_bam* bam);
+/* midas_bam_open_share with a LOCAL block table (round 6): a rank of N walks the BGZF chain over its own 1 / N of the file's bytes
+ * only -- eight ranks that each walk, and page in the block headers of, the whole of a 9 GB file spend a third of a second each on
+ * it.  _open_share_local: out4 = {file offset of the share's first block (a guess: a header from which eight headers follow one
+ * another), where the rank's walk ended, uncompressed bytes of its blocks, file size}.  The ranks exchange these and believe them
+ * only if they CHAIN (rank 0 starts at 0, every walk ends where the next begins, the last at the file's end); then
+ * _share_locate(bam, slice, upos_base = the uncompressed bytes of the ranks in front, total = of all ranks, max_walk, out3) puts the
+ * table in its place and finds the share's first record: out3 as midas_bam_open_share's.  midas_bam_load_ranges* walk the chain on
+ * as far as a range reaches.  Ranks whose walks do not chain open their shares with midas_bam_open_share.                          */
+int32_t midas_bam_open_share_local(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, int64_t* out4, char* err256);
+int32_t midas_bam_share_locate(midas_bam* bam, int32_t slice, int64_t upos_base, int64_t total, int64_t max_walk, int64_t* out3, char* err256);
 int32_t midas_bam_resident_to_columns(midas_bam* bam, midas_snps_ctx* ctx, int64_t* seq_bytes, int64_t* qual_bytes, int64_t* n_cigar, char* err256);
 int32_t midas_snps_batch_create_resident(midas_snps_ctx* ctx, const midas_snps_contigs* contigs, const midas_bam* bam, int64_t first_read,
                                          midas_snps_batch** out_batch);

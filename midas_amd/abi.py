@@ -288,6 +288,8 @@ def load_library(build_if_missing: bool = True):
         'midas_bam_load_resident': (i32, [C.c_char_p, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_load_ranges_resident': (i32, [vp, vp, i32, vp, vp, C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_bam_is_resident': (i32, [vp]),
+        'midas_bam_open_share_local': (i32, [C.c_char_p, i32, i32, C.POINTER(vp), vp, C.c_char_p]),
+        'midas_bam_share_locate': (i32, [vp, i32, i64, i64, i64, vp, C.c_char_p]),
         'midas_bam_resident_to_columns': (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.c_char_p]),
         'midas_snps_batch_create_resident': (i32, [vp, C.POINTER(_Contigs), vp, i64, C.POINTER(vp)]),
         'midas_snps_copy_from_device': (i32, [vp, vp, vp, i64]),
@@ -355,7 +357,7 @@ EXPORTED_SYMBOLS = [
     'midas_bam_open_device', 'midas_bam_open_slice_device', 'midas_bam_load_ranges_device', 'midas_snps_inflate_blocks', 'midas_bam_load_device',
     'midas_bam_payload_on_device', 'midas_snps_copy_from_device', 'midas_bam_release_file',
     'midas_bam_load_resident', 'midas_bam_load_ranges_resident', 'midas_bam_is_resident', 'midas_bam_resident_to_columns',
-    'midas_snps_batch_create_resident',
+    'midas_snps_batch_create_resident', 'midas_bam_open_share_local', 'midas_bam_share_locate',
     'midas_snps_write_rows', 'midas_snps_write_table', 'midas_snps_write_part', 'midas_snps_write_pieces', 'midas_snps_deflate_rows',
     'midas_snps_tableset_open', 'midas_snps_tableset_read_counts', 'midas_snps_tableset_close', 'midas_snps_batch_write_part',
     'midas_fasta_load', 'midas_fasta_n_records', 'midas_fasta_columns', 'midas_fasta_close',
@@ -805,6 +807,36 @@ class BamShare(BamSlice):
         self._h = h
         self.ref_names, self.ref_lens = _bam_refs(self._lib, h)
         self.first, self.total, self.rec_begin = (int(x) for x in out3)
+
+    @classmethod
+    def open_local(cls, path: str, slice_index: int, n_slices: int):
+        """The share with a LOCAL block table (midas_bam_open_share_local): the rank walks the BGZF chain over its own 1 / N of the
+        file only.  `walk` = (first block's file offset, where the walk ended, uncompressed bytes, file size): the ranks exchange
+        these, check that they chain, and call locate()."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        out4 = np.zeros(4, np.int64)
+        st = self._lib.midas_bam_open_share_local(path.encode(), int(slice_index), int(n_slices), C.byref(h),
+                                                  out4.ctypes.data_as(C.c_void_p), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        self._h, self._slice = h, int(slice_index)
+        self.ref_names, self.ref_lens = _bam_refs(self._lib, h)
+        self.walk = tuple(int(x) for x in out4)
+        self.first = self.total = self.rec_begin = -1
+        return self
+
+    def locate(self, upos_base: int, total: int, max_walk: int = 256 << 20):
+        out3 = np.zeros(3, np.int64)
+        err = C.create_string_buffer(256)
+        st = self._lib.midas_bam_share_locate(self._h, self._slice, int(upos_base), int(total), int(max_walk),
+                                              out3.ctypes.data_as(C.c_void_p), err)
+        if st != 0:
+            raise MidasSnpsError(st, err.value.decode())
+        self.first, self.total, self.rec_begin = (int(x) for x in out3)
+        return self
 
 
 class PinnedPool:

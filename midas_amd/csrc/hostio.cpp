@@ -75,6 +75,11 @@ struct BgzfMap {
   struct Blk { size_t cpos, clen; uint64_t upos; uint32_t ulen; size_t fpos; };
   std::vector<Blk> blocks;
   uint64_t total = 0;          // uncompressed bytes
+  // A rank's LOCAL table (midas_bam_open_share_local): `blocks` begins at the first block of the rank's share of the file's
+  // bytes, not at the file's; the chain goes on at next_fpos when somebody asks beyond it (grow).  A whole table: next_fpos == size.
+  size_t next_fpos = 0;
+  bool local = false;
+  // (bgzf_grow(map, n): walk n blocks further along the chain)
   ~BgzfMap() {
     if (base && size) munmap(const_cast<uint8_t*>(base), size);
     if (fd >= 0) close(fd);
@@ -589,6 +594,54 @@ void run_pool(int nt, size_t n_tasks, F&& fn) {
 }
 
 // ---- rank-local BAM decode: block table, slice walk with verified record-boundary guessing, range loads -------------------
+// A BGZF block header at file offset p (an extra field with the BC subfield, as htslib and this library write it)?
+static bool bgzf_header_at(const uint8_t* c, size_t size, size_t p, size_t* xlen_out, size_t* bsize_out) {
+  if (p + 18 > size || c[p] != 0x1f || c[p + 1] != 0x8b || c[p + 2] != 8 || !(c[p + 3] & 4)) return false;
+  const size_t xlen = rd16(&c[p + 10]);
+  size_t q = p + 12, xend = p + 12 + xlen, bsize = 0;
+  while (q + 4 <= xend && xend <= size) {
+    const uint16_t slen = rd16(&c[q + 2]);
+    if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&c[q + 4]) + 1;
+    q += 4 + slen;
+  }
+  if (bsize == 0 || p + bsize > size || bsize < xlen + 20) return false;
+  *xlen_out = xlen;
+  *bsize_out = bsize;
+  return true;
+}
+// walk n_more blocks further along a local table's chain; false: the end of the file, or no block header where one must be
+static bool bgzf_grow(BgzfMap& m, size_t n_more) {     // (true: at least one block was added)
+  const size_t before = m.blocks.size();
+  for (size_t k = 0; k < n_more; ++k) {
+    if (m.next_fpos >= m.size) break;
+    size_t xlen = 0, bsize = 0;
+    if (!bgzf_header_at(m.base, m.size, m.next_fpos, &xlen, &bsize)) break;
+    const uint32_t isize = rd32(&m.base[m.next_fpos + bsize - 4]);
+    const uint64_t upos = m.blocks.empty() ? 0 : m.blocks.back().upos + m.blocks.back().ulen;
+    m.blocks.push_back({m.next_fpos + 12 + xlen, bsize - xlen - 20, upos, isize, m.next_fpos});
+    m.next_fpos += bsize;
+  }
+  return m.blocks.size() > before;
+}
+// The first block start at or behind `from`: a header from which `chain` headers in a row follow one another (or the file ends
+// behind fewer).  `size` when there is none.  (A guess: the caller's ranks compare their walks -- a rank's walk must END on the
+// next rank's guess -- before any of them believes it.)
+static size_t bgzf_find_block(const uint8_t* c, size_t size, size_t from, int chain) {
+  for (size_t p = from; p + 18 <= size && p < from + ((size_t)1 << 17); ++p) {
+    if (c[p] != 0x1f || c[p + 1] != 0x8b) continue;
+    size_t q = p;
+    int ok = 0;
+    while (ok < chain && q < size) {
+      size_t xlen = 0, bsize = 0;
+      if (!bgzf_header_at(c, size, q, &xlen, &bsize)) { ok = -1; break; }
+      q += bsize;
+      ++ok;
+    }
+    if (ok > 0) return p;
+  }
+  return size;
+}
+
 int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool touch = true) {
   m.fd = open(path.c_str(), O_RDONLY);
   if (m.fd < 0) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
@@ -645,17 +698,20 @@ int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool to
     p += bsize;
   }
   m.total = upos;
+  m.next_fpos = m.size;
   return MIDAS_SNPS_OK;
 }
 
 // Inflated bytes of the consecutive blocks [b_lo, b_hi) of a mapped BAM; grows at the far end on demand.
 struct BamWindow {
   const BgzfMap* m = nullptr;
+  BgzfMap* growable = nullptr;      // (a rank's local table: the window walks the chain on when it needs blocks behind the table's last)
   size_t b_lo = 0, b_hi = 0;
   std::vector<uint8_t> buf;
   uint64_t u_lo() const { return b_lo < m->blocks.size() ? m->blocks[b_lo].upos : m->total; }
   uint64_t u_hi() const { return u_lo() + buf.size(); }
   bool extend(size_t new_hi) {   // inflate blocks [b_hi, new_hi) behind what is there
+    if (growable && new_hi > m->blocks.size()) (void)bgzf_grow(*growable, new_hi - m->blocks.size());
     if (new_hi > m->blocks.size()) new_hi = m->blocks.size();
     if (new_hi <= b_hi) return true;
     size_t add = 0;
@@ -677,7 +733,7 @@ struct BamWindow {
   // make bytes [u, u + n) available (n bytes from uncompressed offset u >= u_lo()); false at end of file / bad data
   bool need(uint64_t u, size_t n) {
     while (u + n > u_hi()) {
-      if (b_hi >= m->blocks.size()) return false;
+      if (b_hi >= m->blocks.size() && !(growable && bgzf_grow(*growable, 4))) return false;
       if (!extend(b_hi + 4)) return false;
     }
     return true;
@@ -1602,6 +1658,50 @@ int32_t midas::bam_open_slice_with(const char* path, int32_t slice, int32_t n_sl
   return MIDAS_SNPS_OK;
 }
 
+// Where a share begins: the first record of the first reference that BEGINS at or behind the share's first block (index `lo` of the
+// handle's table; slice 0: the header's end).  -1: no reference border within max_walk.  The table may be a rank's local one (it
+// grows along the chain as the walk needs blocks).
+static int32_t share_first_record(midas_bam* b, int32_t slice, size_t lo, int64_t max_walk, int64_t* out_first, char* err256) {
+  BgzfMap& m = *b->map;
+  const uint64_t rec_begin = b->rec_begin;
+  int64_t first = -1;
+  if (slice == 0) {
+    first = (int64_t)rec_begin;
+  } else {
+    const size_t nb = m.blocks.size();
+    const uint64_t u_lo = std::max<uint64_t>(lo < nb ? m.blocks[lo].upos : m.total, rec_begin);
+    if (u_lo >= m.total) {
+      first = (int64_t)m.total;
+    } else {
+      BamWindow w;
+      w.m = &m;
+      w.growable = m.local ? &m : nullptr;
+      {
+        size_t a = 0, z = nb;
+        while (a < z) { const size_t mid = (a + z) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u_lo) a = mid + 1; else z = mid; }
+        w.b_lo = w.b_hi = a;
+      }
+      if (!w.extend(w.b_lo + 2)) { set_err(err256, "%s: corrupt deflate data", b->path.c_str()); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      const int64_t g = u_lo == rec_begin ? (int64_t)rec_begin : guess_record_start(w, u_lo, b->ref_lens, 32);
+      if (g >= 0) {
+        uint64_t u = (uint64_t)g;
+        int32_t prev = 0x7fffffff;
+        while (u < m.total && u - (uint64_t)g <= (uint64_t)max_walk) {
+          uint32_t bs = 0;
+          if (!plausible_record(w, u, b->ref_lens, &bs) || !w.need(u, 4ull + bs)) break;      // (a wrong guess runs into this: no boundary)
+          const int32_t refid = (int32_t)rd32(w.at(u) + 4);
+          if (prev != 0x7fffffff && refid != prev) { first = (int64_t)u; break; }
+          prev = refid;
+          u += 4ull + bs;
+        }
+        if (first < 0 && u >= m.total) first = (int64_t)m.total;        // the file's last reference runs to the end: an empty share
+      }
+    }
+  }
+  *out_first = first;
+  return MIDAS_SNPS_OK;
+}
+
 // A rank's CONTIGUOUS share of a coordinate-sorted BAM, for the one-pass rank-local decode: the file is cut where slice
 // `slice` of `n_slices` equal byte shares begins, moved FORWARD to the first record of the next reference (contig) -- found by
 // inflating a few blocks on the host: a record start is guessed (32 plausible records in a row) and the records walked until the
@@ -1645,39 +1745,12 @@ int32_t midas::bam_open_share(const char* path, int32_t slice, int32_t n_slices,
   out3[1] = (int64_t)m.total;
   out3[2] = (int64_t)rec_begin;
   int64_t first = -1;
-  if (slice == 0) {
-    first = (int64_t)rec_begin;
-  } else {
+  {
     size_t lo = 0, hi = nb;
     const size_t fpos = (size_t)((unsigned __int128)m.size * slice / n_slices);
     while (lo < hi) { const size_t mid = (lo + hi) / 2; if (m.blocks[mid].fpos < fpos) lo = mid + 1; else hi = mid; }
-    const uint64_t u_lo = std::max<uint64_t>(lo < nb ? m.blocks[lo].upos : m.total, rec_begin);
-    if (u_lo >= m.total) {
-      first = (int64_t)m.total;
-    } else {
-      BamWindow w;
-      w.m = &m;
-      {
-        size_t a = 0, z = nb;
-        while (a < z) { const size_t mid = (a + z) / 2; if (m.blocks[mid].upos + m.blocks[mid].ulen <= u_lo) a = mid + 1; else z = mid; }
-        w.b_lo = w.b_hi = a;
-      }
-      if (!w.extend(std::min(nb, w.b_lo + 2))) { set_err(err256, "%s: corrupt deflate data", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
-      const int64_t g = u_lo == rec_begin ? (int64_t)rec_begin : guess_record_start(w, u_lo, b->ref_lens, 32);
-      if (g >= 0) {
-        uint64_t u = (uint64_t)g;
-        int32_t prev = 0x7fffffff;
-        while (u < m.total && u - (uint64_t)g <= (uint64_t)max_walk) {
-          uint32_t bs = 0;
-          if (!plausible_record(w, u, b->ref_lens, &bs) || !w.need(u, 4ull + bs)) break;      // (a wrong guess runs into this: no boundary)
-          const int32_t refid = (int32_t)rd32(w.at(u) + 4);
-          if (prev != 0x7fffffff && refid != prev) { first = (int64_t)u; break; }
-          prev = refid;
-          u += 4ull + bs;
-        }
-        if (first < 0 && u >= m.total) first = (int64_t)m.total;        // the file's last reference runs to the end: an empty share
-      }
-    }
+    const int32_t fst = share_first_record(b.get(), slice, lo, max_walk, &first, err256);
+    if (fst != MIDAS_SNPS_OK) return fst;
   }
   out3[0] = first;
   b->slice_first = first;
@@ -1689,6 +1762,90 @@ int32_t midas::bam_open_share(const char* path, int32_t slice, int32_t n_slices,
 extern "C" {
 int32_t midas_bam_open_share(const char* path, int32_t slice, int32_t n_slices, int64_t max_walk, midas_bam** out, int64_t* out3, char* err256) {
   return midas::bam_open_share(path, slice, n_slices, max_walk, out, out3, err256);
+}
+
+// The same share with a LOCAL block table: a rank of N walks the BGZF chain over ITS 1 / N of the file's bytes only (eight ranks
+// that each walk -- and page in the headers of -- the whole of a 9 GB file spend a third of a second each on it, more than on
+// decoding their share).  The rank finds the first block start at or behind size * slice / n (a header from which eight headers in
+// a row follow one another: a GUESS), walks the chain to the first block start at or behind size * (slice + 1) / n, and reports
+//   out4 = {first block's file offset, where its walk ended, uncompressed bytes of its blocks, file size}.
+// The caller exchanges these between the ranks and believes them only if they CHAIN (rank 0 starts at 0, every rank ends where the
+// next one starts, the last ends at the file's end): then midas_bam_share_locate gives the table its place in the uncompressed stream
+// (upos_base = the bytes of the ranks in front, total = all of them) and finds the share's first record as midas_bam_open_share does.
+int32_t midas_bam_open_share_local(const char* path, int32_t slice, int32_t n_slices, midas_bam** out, int64_t* out4, char* err256) {
+  if (!path || !out || !out4 || n_slices < 1 || slice < 0 || slice >= n_slices) return MIDAS_SNPS_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unique_ptr<midas_bam> b(new (std::nothrow) midas_bam());
+  if (!b) return MIDAS_SNPS_ERR_OUT_OF_MEMORY;
+  b->path = path;
+  b->map.reset(new BgzfMap());
+  BgzfMap& m = *b->map;
+  m.fd = open(path, O_RDONLY);
+  if (m.fd < 0) { set_err(err256, "cannot open %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  struct stat sb;
+  if (fstat(m.fd, &sb) != 0) { set_err(err256, "cannot stat %s", path); return MIDAS_SNPS_ERR_INVALID_ARG; }
+  m.size = (size_t)sb.st_size;
+  if (m.size == 0) { set_err(err256, "%s is empty", path); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
+  if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  m.base = static_cast<const uint8_t*>(a);
+  m.local = true;
+  {   // the BAM header: the file's first blocks (a table of its own, from offset 0, as far as the header reaches)
+    BgzfMap head;
+    head.base = m.base; head.size = m.size; head.local = true;
+    BamWindow w;
+    w.m = &head;
+    w.growable = &head;
+    size_t k = 1;
+    int32_t hst = MIDAS_SNPS_OK;
+    for (;;) {
+      if (!w.extend(k) || head.blocks.empty()) { set_err(err256, "%s: not a BGZF file, or corrupt deflate data", path); hst = MIDAS_SNPS_ERR_BAD_LAYOUT; break; }
+      bool bad_magic = false;
+      const size_t rec_begin = parse_bam_header(w.buf.data(), w.buf.size(), b.get(), &bad_magic);
+      if (bad_magic) { set_err(err256, "%s: missing BAM magic", path); hst = MIDAS_SNPS_ERR_BAD_LAYOUT; break; }
+      if (rec_begin) { b->rec_begin = rec_begin; break; }
+      if (head.next_fpos >= head.size) { set_err(err256, "%s: truncated BAM header", path); hst = MIDAS_SNPS_ERR_BAD_LAYOUT; break; }
+      k *= 2;
+    }
+    head.base = nullptr; head.size = 0;      // (the mapping is m's)
+    if (hst != MIDAS_SNPS_OK) return hst;
+  }
+  const size_t n_ref = b->ref_lens.size();
+  b->ref_reads.assign(n_ref, 0);
+  b->ref_bases.assign(n_ref, 0);
+  b->ref_first.assign(n_ref, -1);
+  b->ref_span.assign(n_ref, 0);
+  const size_t lo = (size_t)((unsigned __int128)m.size * slice / n_slices);
+  const size_t hi = slice + 1 == n_slices ? m.size : (size_t)((unsigned __int128)m.size * (slice + 1) / n_slices);
+  const size_t start = slice == 0 ? 0 : bgzf_find_block(m.base, m.size, lo, 8);
+  m.next_fpos = start;
+  while (m.next_fpos < m.size && m.next_fpos < hi) {
+    if (!bgzf_grow(m, 1)) { set_err(err256, "%s: not a BGZF block at offset %lld", path, (long long)m.next_fpos); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  }
+  uint64_t sum = 0;
+  for (const BgzfMap::Blk& q : m.blocks) sum += q.ulen;
+  out4[0] = (int64_t)start; out4[1] = (int64_t)m.next_fpos; out4[2] = (int64_t)sum; out4[3] = (int64_t)m.size;
+  b->slice_first = b->slice_end = -1;
+  *out = b.release();
+  return MIDAS_SNPS_OK;
+}
+
+int32_t midas_bam_share_locate(midas_bam* b, int32_t slice, int64_t upos_base, int64_t total, int64_t max_walk, int64_t* out3, char* err256) {
+  if (!b || !b->map || !b->map->local || !out3 || upos_base < 0 || total < upos_base || max_walk < 0 || slice < 0) return MIDAS_SNPS_ERR_INVALID_ARG;
+  BgzfMap& m = *b->map;
+  if (m.total != 0) return MIDAS_SNPS_ERR_INVALID_ARG;       // (located once)
+  for (BgzfMap::Blk& q : m.blocks) q.upos += (uint64_t)upos_base;
+  if (m.blocks.empty()) {        // (an empty share: its walk goes on from where it would have begun, at the base it was given)
+    // grow() continues behind the last block; with none it starts at 0 -- the first one it finds is put at the base
+    if (bgzf_grow(m, 1)) m.blocks.back().upos = (uint64_t)upos_base;
+  }
+  m.total = (uint64_t)total;
+  int64_t first = -1;
+  const int32_t st = share_first_record(b, slice, 0, max_walk, &first, err256);
+  if (st != MIDAS_SNPS_OK) return st;
+  out3[0] = first; out3[1] = total; out3[2] = (int64_t)b->rec_begin;
+  b->slice_first = b->slice_end = first;
+  return MIDAS_SNPS_OK;
 }
 }
 
@@ -1729,6 +1886,17 @@ int32_t midas::bam_load_ranges_on_device(midas_bam* b, const midas::DeviceDecode
                                          const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                          int64_t* n_cigar, char* err256, int payload) {
   if (!b || !b->map || !dec || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (b->map->local) {      // a rank's local table: walk the chain on until it covers the ranges' ends; nothing in front of its first block
+    uint64_t far = 0;
+    for (int32_t k = 0; k < n_ranges; ++k) far = std::max<uint64_t>(far, (uint64_t)std::max<int64_t>(0, range_end[k]));
+    BgzfMap& gm = *b->map;
+    while ((gm.blocks.empty() || gm.blocks.back().upos + gm.blocks.back().ulen < far) && bgzf_grow(gm, 64)) {}
+    for (int32_t k = 0; k < n_ranges; ++k)
+      if (range_end[k] > range_begin[k] && (gm.blocks.empty() || (uint64_t)range_begin[k] < gm.blocks[0].upos)) {
+        set_err(err256, "%s: record range %lld begins in front of this rank's share of the file", b->path.c_str(), (long long)k);
+        return MIDAS_SNPS_ERR_INVALID_ARG;
+      }
+  }
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();
   auto block_of = [&](uint64_t u) {   // the block holding uncompressed offset u (u < total)
@@ -1811,6 +1979,17 @@ int32_t midas::bam_load_ranges_with(midas_bam* b, const midas::BlockInflater* in
                                     const int64_t* range_end, int64_t* n_reads, int64_t* seq_bytes, int64_t* qual_bytes,
                                     int64_t* n_cigar, char* err256) {
   if (!b || !b->map || n_ranges < 0 || (n_ranges > 0 && (!range_begin || !range_end))) return MIDAS_SNPS_ERR_INVALID_ARG;
+  if (b->map->local) {      // a rank's local table: walk the chain on until it covers the ranges' ends; nothing in front of its first block
+    uint64_t far = 0;
+    for (int32_t k = 0; k < n_ranges; ++k) far = std::max<uint64_t>(far, (uint64_t)std::max<int64_t>(0, range_end[k]));
+    BgzfMap& gm = *b->map;
+    while ((gm.blocks.empty() || gm.blocks.back().upos + gm.blocks.back().ulen < far) && bgzf_grow(gm, 64)) {}
+    for (int32_t k = 0; k < n_ranges; ++k)
+      if (range_end[k] > range_begin[k] && (gm.blocks.empty() || (uint64_t)range_begin[k] < gm.blocks[0].upos)) {
+        set_err(err256, "%s: record range %lld begins in front of this rank's share of the file", b->path.c_str(), (long long)k);
+        return MIDAS_SNPS_ERR_INVALID_ARG;
+      }
+  }
   const BgzfMap& m = *b->map;
   const size_t nb = m.blocks.size();
   auto block_of = [&](uint64_t u) {   // the block holding uncompressed offset u (u < total)

@@ -97,3 +97,43 @@ def test_range_that_cuts_a_record_is_an_error(sample):
     assert ei.value.status == abi.ERR_BAD_LAYOUT
     with pytest.raises(abi.MidasSnpsError):
         s.load_ranges([(s.rec_begin - 4, s.rec_begin)])
+
+
+def test_local_block_tables_of_the_ranks_chain_and_find_the_shares_of_the_full_walk(tmp_path):
+    """midas_bam_open_share_local / _share_locate: every rank walks the BGZF chain over its own 1 / N of the file only.  The
+    walks must chain (rank 0 from 0, each ending where the next begins, the last at the file's end), and with the bases that
+    follows from them every rank finds the share -- first record, total, header -- that the walk of the whole file finds, and
+    decodes the same records from it (the table growing along the chain where a share reaches into the next rank's bytes)."""
+    from midas_amd import abi, synth
+    contigs, reads = synth.make_dataset(n_species=3, contigs_per_species=5, contig_len=30000, n_reads=60000, seed=33, var_len=True)
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+    path = str(tmp_path / "s.bam")
+    abi.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads)
+    size = os.path.getsize(path)
+    for n in (1, 2, 3, 5, 8, 64):
+        local = [abi.BamShare.open_local(path, k, n) for k in range(n)]
+        walks = np.array([s.walk for s in local])
+        assert walks[0, 0] == 0 and (walks[:-1, 1] == walks[1:, 0]).all() and walks[-1, 1] == size and (walks[:, 3] == size).all()
+        full = [abi.BamShare(path, k, n) for k in range(n)]
+        assert int(walks[:, 2].sum()) == full[0].total
+        for k in range(n):
+            local[k].locate(int(walks[:k, 2].sum()), int(walks[:, 2].sum()))
+            assert (local[k].first, local[k].total, local[k].rec_begin) == (full[k].first, full[k].total, full[k].rec_begin), (n, k)
+            assert local[k].ref_names == full[k].ref_names and local[k].ref_lens == full[k].ref_lens
+        firsts = [s.first for s in full] + [full[0].total]
+        if all(f >= 0 for f in firsts) and all(a <= b for a, b in zip(firsts[:-1], firsts[1:])):
+            for k in range(n):
+                if firsts[k] == firsts[k + 1]:
+                    continue
+                want_refid, want = full[k].load_ranges([(firsts[k], firsts[k + 1])])
+                got_refid, got = local[k].load_ranges([(firsts[k], firsts[k + 1])])
+                np.testing.assert_array_equal(want_refid, got_refid)
+                for c in abi._SOA_DTYPES:
+                    np.testing.assert_array_equal(getattr(want, c), getattr(got, c), err_msg=c)
+        # a range in front of a rank's own blocks is refused, not misread
+        if n >= 3 and firsts[1] > firsts[0] >= 0:
+            with pytest.raises(abi.MidasSnpsError) as ei:
+                abi.BamShare.open_local(path, n - 1, n).locate(int(walks[:n - 1, 2].sum()), int(walks[:, 2].sum())).load_ranges([(firsts[0], firsts[1])])
+            assert ei.value.status == abi.ERR_INVALID_ARG
+        for s in local + full:
+            s.close()
