@@ -29,6 +29,29 @@
 #include <thread>
 #include <vector>
 
+namespace {
+struct MappedFile { const uint8_t* base; size_t size; int fd; };
+std::mutex g_map_lock;
+std::vector<MappedFile> g_maps;
+}  // namespace
+void midas::register_file_mapping(const void* base, size_t size, int fd) {
+  std::lock_guard<std::mutex> g(g_map_lock);
+  g_maps.push_back({static_cast<const uint8_t*>(base), size, fd});
+}
+void midas::unregister_file_mapping(const void* base) {
+  std::lock_guard<std::mutex> g(g_map_lock);
+  for (size_t k = 0; k < g_maps.size(); ++k)
+    if (g_maps[k].base == base) { g_maps.erase(g_maps.begin() + (long)k); return; }
+}
+bool midas::file_of_mapping(const void* p, size_t n, int* fd, size_t* file_off) {
+  const uint8_t* q = static_cast<const uint8_t*>(p);
+  std::lock_guard<std::mutex> g(g_map_lock);
+  for (const MappedFile& m : g_maps)
+    if (q >= m.base && n <= m.size && (size_t)(q - m.base) <= m.size - n) { *fd = m.fd; *file_off = (size_t)(q - m.base); return true; }
+  return false;
+}
+
+
 // A byte/word buffer that is NOT zero-filled when it grows: the BAM stream, its inflated form and the decoded SEQ / QUAL /
 // CIGAR columns are hundreds of MB that get overwritten in full right away (std::vector::resize would memset them on one
 // core first: a third of the decode time).
@@ -81,7 +104,7 @@ struct BgzfMap {
   bool local = false;
   // (bgzf_grow(map, n): walk n blocks further along the chain)
   ~BgzfMap() {
-    if (base && size) munmap(const_cast<uint8_t*>(base), size);
+    if (base && size) { midas::unregister_file_mapping(base); munmap(const_cast<uint8_t*>(base), size); }
     if (fd >= 0) close(fd);
   }
 };
@@ -272,6 +295,50 @@ bool bgzf_block_inflate(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_o
 
 // Inflate every BGZF block of a file into one buffer.  Blocks are independent raw-deflate members, so they
 // are inflated in parallel once the block boundaries are known (BSIZE in the 'BC' extra field).
+// A BGZF block header in h[0, avail) (an extra field with the BC subfield, as htslib and this library write it): its XLEN and BSIZE.
+static bool bgzf_parse_header(const uint8_t* h, size_t avail, size_t* xlen_out, size_t* bsize_out) {
+  if (avail < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+  const size_t xlen = rd16(&h[10]);
+  if (12 + xlen > avail) return false;
+  size_t q = 12, xend = 12 + xlen, bsize = 0;
+  while (q + 4 <= xend) {
+    const uint16_t slen = rd16(&h[q + 2]);
+    if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)rd16(&h[q + 4]) + 1;
+    q += 4 + slen;
+  }
+  if (bsize == 0 || bsize < xlen + 20) return false;
+  *xlen_out = xlen;
+  *bsize_out = bsize;
+  return true;
+}
+// The block table of a BGZF file walked with pread: ONE read of a few dozen bytes per block -- the last four bytes of block k
+// (ISIZE) and the header of block k + 1 lie next to each other -- and not a page of the file mapped for it.  emit(cpos, clen,
+// upos, ulen, fpos) per block from file offset `from` on, until `until` (a block that STARTS at or behind it ends the walk) or
+// the end of the file; *end = where the walk stopped.  false: no block header where one must be (*end says where).
+template <class Emit>
+static bool bgzf_walk_pread(int fd, size_t size, size_t from, size_t until, uint64_t upos, size_t max_blocks, size_t* end, Emit emit) {
+  uint8_t h[4 + 256];
+  size_t p = from, n = 0;
+  if (p >= size || p >= until) { *end = p; return true; }
+  ssize_t got = pread(fd, h + 4, 256, (off_t)p);
+  while (true) {
+    size_t xlen = 0, bsize = 0;
+    if (got < 18 || !bgzf_parse_header(h + 4, (size_t)got, &xlen, &bsize) || p + bsize > size) { *end = p; return false; }
+    // ISIZE of this block + the header of the next one
+    got = pread(fd, h, 4 + 256, (off_t)(p + bsize - 4));
+    if (got < 4) { *end = p; return false; }
+    const uint32_t isize = rd32(h);
+    emit(p + 12 + xlen, bsize - xlen - 20, upos, isize, p);
+    upos += isize;
+    p += bsize;
+    ++n;
+    got -= 4;
+    if (p >= size || p >= until || n >= max_blocks) break;
+  }
+  *end = p;
+  return true;
+}
+
 struct FileBlk { size_t cpos, clen, upos, ulen, fpos; };
 // A BGZF file read whole (by several threads) and its block table: where every block's DEFLATE stream lies, what it inflates to.
 // A whole file's bytes for reading: the file MAPPED where that works (a BAM of a gigabyte is in the page cache when the pileup
@@ -281,11 +348,15 @@ struct FileImage {
   const uint8_t* p = nullptr;
   size_t n = 0;
   void* map = nullptr;
+  int fd = -1;
   RawBuf<uint8_t> buf;
   FileImage() = default;
   FileImage(const FileImage&) = delete;
   FileImage& operator=(const FileImage&) = delete;
-  ~FileImage() { if (map) munmap(map, n); }
+  ~FileImage() {
+    if (map) { midas::unregister_file_mapping(map); munmap(map, n); }
+    if (fd >= 0) close(fd);
+  }
   const uint8_t* data() const { return p; }
   size_t size() const { return n; }
   const uint8_t& operator[](size_t i) const { return p[i]; }
@@ -301,25 +372,16 @@ int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<Fil
   const size_t piece = (size_t)8 << 20, n_pieces = (fsz + piece - 1) / piece;
   const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
   void* m = fsz > 0 && !getenv("MIDAS_SNPS_NO_MMAP") ? mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+  bool mapped = false;
   if (m != MAP_FAILED) {
-    (void)madvise(m, fsz, MADV_WILLNEED);
+    // mapped for whoever looks INTO it (the header's blocks, the host's inflater); the block table below and the device
+    // upload read the file with pread: no page of it is mapped on their account (hostio.h, register_file_mapping)
     comp.map = m;
     comp.p = static_cast<const uint8_t*>(m);
     comp.n = fsz;
-    // the pages are mapped in by several threads (one read per page; the kernel maps a run of cached pages per fault)
-    std::atomic<size_t> nextp{0};
-    std::atomic<unsigned> sink{0};
-    Workers::run(n_workers, [&] {
-      unsigned acc = 0;
-      for (;;) {
-        const size_t k = nextp.fetch_add(1);
-        if (k >= n_pieces) break;
-        const size_t end = std::min(fsz, (k + 1) * piece);
-        for (size_t off = k * piece; off < end; off += 4096) acc += comp.p[off];
-      }
-      sink += acc;
-    });
-    close(fd);
+    comp.fd = fd;
+    midas::register_file_mapping(m, fsz, fd);
+    mapped = true;
     lap("map file");
   } else {
     if (!comp.buf.resize(fsz)) { close(fd); set_err(err256, "out of memory reading %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
@@ -346,7 +408,16 @@ int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<Fil
     comp.n = fsz;
     lap("read file");
   }
-  size_t p = 0, upos = 0;
+  size_t upos = 0;
+  if (mapped) {
+    size_t end = 0;
+    const bool ok = bgzf_walk_pread(comp.fd, fsz, 0, fsz, 0, ~(size_t)0, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+      blocks.push_back({cpos, clen, (size_t)u, (size_t)ulen, fpos});
+      upos = (size_t)u + ulen;
+    });
+    if (!ok || end != fsz) { set_err(err256, "%s: not a BGZF block (or a truncated one) at offset %lld", path.c_str(), (long long)end); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  } else {
+  size_t p = 0;
   while (p < comp.size()) {
     if (p + 18 > comp.size() || comp[p] != 0x1f || comp[p + 1] != 0x8b || comp[p + 2] != 8 || !(comp[p + 3] & 4)) {
       set_err(err256, "%s: not a BGZF block at offset %lld", path.c_str(), (long long)p);
@@ -368,6 +439,7 @@ int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<Fil
     blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize, p});
     upos += isize;
     p += bsize;
+  }
   }
   *total = upos;
   lap("block table");
@@ -612,15 +684,12 @@ static bool bgzf_header_at(const uint8_t* c, size_t size, size_t p, size_t* xlen
 // walk n_more blocks further along a local table's chain; false: the end of the file, or no block header where one must be
 static bool bgzf_grow(BgzfMap& m, size_t n_more) {     // (true: at least one block was added)
   const size_t before = m.blocks.size();
-  for (size_t k = 0; k < n_more; ++k) {
-    if (m.next_fpos >= m.size) break;
-    size_t xlen = 0, bsize = 0;
-    if (!bgzf_header_at(m.base, m.size, m.next_fpos, &xlen, &bsize)) break;
-    const uint32_t isize = rd32(&m.base[m.next_fpos + bsize - 4]);
-    const uint64_t upos = m.blocks.empty() ? 0 : m.blocks.back().upos + m.blocks.back().ulen;
-    m.blocks.push_back({m.next_fpos + 12 + xlen, bsize - xlen - 20, upos, isize, m.next_fpos});
-    m.next_fpos += bsize;
-  }
+  size_t end = m.next_fpos;
+  const uint64_t upos = m.blocks.empty() ? 0 : m.blocks.back().upos + m.blocks.back().ulen;
+  (void)bgzf_walk_pread(m.fd, m.size, m.next_fpos, m.size, upos, n_more, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+    m.blocks.push_back({cpos, clen, u, ulen, fpos});
+  });
+  m.next_fpos = end;
   return m.blocks.size() > before;
 }
 // The first block start at or behind `from`: a header from which `chain` headers in a row follow one another (or the file ends
@@ -652,50 +721,17 @@ int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool to
   void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
   if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   m.base = static_cast<const uint8_t*>(a);
-  if (touch) {   // the pages are mapped in by several threads (one read per page: the kernel maps a run of cached pages per fault)
-      // -- the block table's walk below and the decoders' copies then find them there.  (Only for a caller that will read the WHOLE
-      // file: a rank of N that takes 1 / N of it maps what it walks and what it decodes, on the CPUs a rank of N has.)
-    (void)madvise(a, m.size, MADV_WILLNEED);
-    const size_t piece = (size_t)8 << 20, n_pieces = (m.size + piece - 1) / piece;
-    const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
-    std::atomic<size_t> nextp{0};
-    std::atomic<unsigned> sink{0};
-    const uint8_t* base = m.base;
-    const size_t fsz = m.size;
-    Workers::run(n_workers, [&] {
-      unsigned acc = 0;
-      for (;;) {
-        const size_t k = nextp.fetch_add(1);
-        if (k >= n_pieces) break;
-        const size_t end = std::min(fsz, (k + 1) * piece);
-        for (size_t off = k * piece; off < end; off += 4096) acc += base[off];
-      }
-      sink += acc;
-    });
-  }
-  size_t p = 0;
+  midas::register_file_mapping(a, m.size, m.fd);
+  (void)touch;      // (nobody reads the file's bulk through the mapping any more: nothing to page in ahead of time)
+  size_t end = 0;
   uint64_t upos = 0;
-  while (p < m.size) {
-    const uint8_t* c = m.base;
-    if (p + 18 > m.size || c[p] != 0x1f || c[p + 1] != 0x8b || c[p + 2] != 8 || !(c[p + 3] & 4)) {
-      set_err(err256, "%s: not a BGZF block at offset %lld", path.c_str(), (long long)p);
-      return MIDAS_SNPS_ERR_BAD_LAYOUT;
-    }
-    const size_t xlen = rd16(&c[p + 10]);
-    size_t q = p + 12, xend = p + 12 + xlen, bsize = 0;
-    while (q + 4 <= xend && xend <= m.size) {
-      const uint16_t slen = rd16(&c[q + 2]);
-      if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&c[q + 4]) + 1;
-      q += 4 + slen;
-    }
-    if (bsize == 0 || p + bsize > m.size || bsize < xlen + 20) {
-      set_err(err256, "%s: truncated BGZF block at offset %lld", path.c_str(), (long long)p);
-      return MIDAS_SNPS_ERR_BAD_LAYOUT;
-    }
-    const uint32_t isize = rd32(&c[p + bsize - 4]);
-    m.blocks.push_back({p + 12 + xlen, bsize - xlen - 20, upos, isize, p});
-    upos += isize;
-    p += bsize;
+  const bool ok = bgzf_walk_pread(m.fd, m.size, 0, m.size, 0, ~(size_t)0, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+    m.blocks.push_back({cpos, clen, u, ulen, fpos});
+    upos = u + ulen;
+  });
+  if (!ok || end != m.size) {
+    set_err(err256, "%s: not a BGZF block (or a truncated one) at offset %lld", path.c_str(), (long long)end);
+    return MIDAS_SNPS_ERR_BAD_LAYOUT;
   }
   m.total = upos;
   m.next_fpos = m.size;
@@ -1790,9 +1826,10 @@ int32_t midas_bam_open_share_local(const char* path, int32_t slice, int32_t n_sl
   if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   m.base = static_cast<const uint8_t*>(a);
   m.local = true;
+  midas::register_file_mapping(a, m.size, m.fd);
   {   // the BAM header: the file's first blocks (a table of its own, from offset 0, as far as the header reaches)
     BgzfMap head;
-    head.base = m.base; head.size = m.size; head.local = true;
+    head.base = m.base; head.size = m.size; head.local = true; head.fd = m.fd;
     BamWindow w;
     w.m = &head;
     w.growable = &head;
@@ -1807,7 +1844,7 @@ int32_t midas_bam_open_share_local(const char* path, int32_t slice, int32_t n_sl
       if (head.next_fpos >= head.size) { set_err(err256, "%s: truncated BAM header", path); hst = MIDAS_SNPS_ERR_BAD_LAYOUT; break; }
       k *= 2;
     }
-    head.base = nullptr; head.size = 0;      // (the mapping is m's)
+    head.base = nullptr; head.size = 0; head.fd = -1;      // (the mapping and the descriptor are m's)
     if (hst != MIDAS_SNPS_OK) return hst;
   }
   const size_t n_ref = b->ref_lens.size();
@@ -1819,8 +1856,13 @@ int32_t midas_bam_open_share_local(const char* path, int32_t slice, int32_t n_sl
   const size_t hi = slice + 1 == n_slices ? m.size : (size_t)((unsigned __int128)m.size * (slice + 1) / n_slices);
   const size_t start = slice == 0 ? 0 : bgzf_find_block(m.base, m.size, lo, 8);
   m.next_fpos = start;
-  while (m.next_fpos < m.size && m.next_fpos < hi) {
-    if (!bgzf_grow(m, 1)) { set_err(err256, "%s: not a BGZF block at offset %lld", path, (long long)m.next_fpos); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+  {
+    size_t end = start;
+    const bool ok = bgzf_walk_pread(m.fd, m.size, start, hi, 0, ~(size_t)0, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+      m.blocks.push_back({cpos, clen, u, ulen, fpos});
+    });
+    m.next_fpos = end;
+    if (!ok) { set_err(err256, "%s: not a BGZF block at offset %lld", path, (long long)end); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   }
   uint64_t sum = 0;
   for (const BgzfMap::Blk& q : m.blocks) sum += q.ulen;

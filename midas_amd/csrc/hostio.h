@@ -34,6 +34,13 @@ struct BlockInflater {
 }  // namespace midas
 struct midas_bam;
 namespace midas {
+// A BAM's bytes are MAPPED for the few places that look into them (the header's blocks, the search for a share's first record),
+// but bulk readers do not go through the mapping: every page read through it costs a page-table entry to set up and ~0.1 us to
+// tear down again (unmapping a 9 GB BAM that had been read through its mapping: 0.18-0.33 s).  The mappings are registered
+// here; a reader that is handed a pointer into one (the device upload's staging copy) asks for the file behind it and preads.
+void register_file_mapping(const void* base, size_t size, int fd);
+void unregister_file_mapping(const void* base);
+bool file_of_mapping(const void* p, size_t n, int* fd, size_t* file_off);
 // midas_bam_open / midas_bam_load_ranges with the BGZF blocks inflated by `inflater` (nullptr: the host's threads)
 int32_t bam_open_with(const char* path, const BlockInflater* inflater, midas_bam** out, char* err256);
 int32_t bam_load_ranges_with(midas_bam* bam, const BlockInflater* inflater, int32_t n_ranges, const int64_t* range_begin,

@@ -307,9 +307,41 @@ int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t byt
 // Host bytes that are NOT page-locked (a mapped file, a malloc'd buffer) to the device through the context's pinned ring:
 // several threads copy a chunk into a slot while the slot before it crosses the link.  The runtime's own pageable path
 // stages through one thread: 14 GB/s out of a file mapping where this reaches the threads' copy rate.
+// n bytes of a file into dst (a slot of the pinned ring) by several threads: the page cache's bytes, without a page of the
+// file mapped for them (hostio.h, register_file_mapping)
+bool parallel_pread(uint8_t* dst, int fd, size_t file_off, size_t n) {
+  const unsigned hw = (unsigned)midas::cpu_budget();
+  size_t nt = hw >= 32 ? 12 : (hw >= 8 ? 4 : 1);
+  if (n < ((size_t)4 << 20)) nt = 1;
+  const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+  std::atomic<int> bad{0};
+  auto piece = [&](size_t k) {
+    size_t off = k * per;
+    const size_t end = std::min(n, off + per);
+    while (off < end) {
+      const ssize_t got = pread(fd, dst + off, end - off, (off_t)(file_off + off));
+      if (got <= 0) { bad = 1; return; }
+      off += (size_t)got;
+    }
+  };
+  if (nt == 1) { piece(0); return bad == 0; }
+  std::atomic<size_t> next{0};
+  midas::Workers::run((int)nt, [&] {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= nt) return;
+      piece(k);
+    }
+  });
+  return bad == 0;
+}
+
 int32_t copy_to_device_staged(midas_snps_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
-  if (bytes < 2 * kChunk) {
+  int src_fd = -1;
+  size_t src_off = 0;
+  const bool from_file = midas::file_of_mapping(src, bytes, &src_fd, &src_off);      // (a mapped BAM: read with pread, not through the mapping)
+  if (bytes < 2 * kChunk && !from_file) {
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
     return MIDAS_SNPS_OK;
   }
@@ -323,7 +355,11 @@ int32_t copy_to_device_staged(midas_snps_ctx* ctx, void* dst, const void* src, s
     const int slot = (int)(k % midas_snps_ctx::kStageSlots);
     if (k >= (size_t)midas_snps_ctx::kStageSlots) HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[slot]));      // the slot's last chunk is over
     const size_t off = k * kChunk, n = std::min(kChunk, bytes - off);
-    parallel_copy(static_cast<uint8_t*>(ctx->stage[slot]), static_cast<const uint8_t*>(src) + off, n);
+    if (from_file) {
+      if (!parallel_pread(static_cast<uint8_t*>(ctx->stage[slot]), src_fd, src_off + off, n)) return fail(ctx, MIDAS_SNPS_ERR_BAD_LAYOUT, "short read on the BAM file");
+    } else {
+      parallel_copy(static_cast<uint8_t*>(ctx->stage[slot]), static_cast<const uint8_t*>(src) + off, n);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t*>(dst) + off, ctx->stage[slot], n, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[slot], s));
   }
