@@ -91,6 +91,7 @@ struct RawBuf {
 };
 
 // A BAM file mapped read-only with its BGZF block table (rank-local decode: a rank inflates only the blocks it needs).
+void midas_hostio_unmap(const void* base, size_t size);      // (a file mapping taken down by several threads: defined below)
 struct BgzfMap {
   const uint8_t* base = nullptr;
   size_t size = 0;
@@ -104,7 +105,7 @@ struct BgzfMap {
   bool local = false;
   // (bgzf_grow(map, n): walk n blocks further along the chain)
   ~BgzfMap() {
-    if (base && size) { midas::unregister_file_mapping(base); munmap(const_cast<uint8_t*>(base), size); }
+    if (base && size) { midas::unregister_file_mapping(base); midas_hostio_unmap(base, size); }
     if (fd >= 0) close(fd);
   }
 };
@@ -339,6 +340,143 @@ static bool bgzf_walk_pread(int fd, size_t size, size_t from, size_t until, uint
   return true;
 }
 
+static bool bgzf_header_at(const uint8_t* c, size_t size, size_t p, size_t* xlen_out, size_t* bsize_out) {
+  if (p + 18 > size || c[p] != 0x1f || c[p + 1] != 0x8b || c[p + 2] != 8 || !(c[p + 3] & 4)) return false;
+  const size_t xlen = rd16(&c[p + 10]);
+  size_t q = p + 12, xend = p + 12 + xlen, bsize = 0;
+  while (q + 4 <= xend && xend <= size) {
+    const uint16_t slen = rd16(&c[q + 2]);
+    if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&c[q + 4]) + 1;
+    q += 4 + slen;
+  }
+  if (bsize == 0 || p + bsize > size || bsize < xlen + 20) return false;
+  *xlen_out = xlen;
+  *bsize_out = bsize;
+  return true;
+}
+// The first block start at or behind `from`: a header from which `chain` headers in a row follow one another (or the file ends
+// behind fewer).  `size` when there is none.  (A guess: the caller's ranks compare their walks -- a rank's walk must END on the
+// next rank's guess -- before any of them believes it.)
+static size_t bgzf_find_block(const uint8_t* c, size_t size, size_t from, int chain) {
+  for (size_t p = from; p + 18 <= size && p < from + ((size_t)1 << 17); ++p) {
+    if (c[p] != 0x1f || c[p + 1] != 0x8b) continue;
+    size_t q = p;
+    int ok = 0;
+    while (ok < chain && q < size) {
+      size_t xlen = 0, bsize = 0;
+      if (!bgzf_header_at(c, size, q, &xlen, &bsize)) { ok = -1; break; }
+      q += bsize;
+      ++ok;
+    }
+    if (ok > 0) return p;
+  }
+  return size;
+}
+
+// A whole file's block table by several threads: thread k guesses the first block start behind k / T of the file (bgzf_find_block on
+// the mapping: a few pages), walks with pread to thread k + 1's guess, and the pieces are believed only if every walk ENDS on the
+// next one's guess -- else (a guess inside compressed bytes that looked like eight headers in a row) one thread walks it all.
+// One thread spends 0.7 us a block on the two system calls: 0.25 s for a 9 GB BAM's 340 k blocks.
+template <class Emit>
+static bool bgzf_walk_file(int fd, const uint8_t* mapped, size_t size, size_t* end, uint64_t* total, Emit emit) {
+  struct B { size_t cpos, clen; uint64_t upos; uint32_t ulen; size_t fpos; };
+  const int budget = midas::cpu_budget();
+  size_t least = (size_t)64 << 20;
+  if (const char* e = getenv("MIDAS_SNPS_PARALLEL_WALK_MIN")) least = (size_t)strtoull(e, nullptr, 10);      // (tests: small files walked in pieces too)
+  const int T = size < least || !mapped ? 1 : std::min(16, std::max(getenv("MIDAS_SNPS_PARALLEL_WALK_MIN") ? 4 : 1, budget));
+  if (T > 1) {
+    std::vector<size_t> start(T + 1, size);
+    start[0] = 0;
+    for (int k = 1; k < T; ++k) start[k] = bgzf_find_block(mapped, size, (size_t)((unsigned __int128)size * k / T), 8);
+    bool sane = true;
+    for (int k = 1; k <= T; ++k) sane = sane && start[k] > start[k - 1];
+    if (sane) {
+      std::vector<std::vector<B>> part(T);
+      std::vector<size_t> stop(T, 0);
+      std::vector<char> ok(T, 0);
+      std::atomic<int> next{0};
+      Workers::run(T, [&] {
+        for (;;) {
+          const int k = next.fetch_add(1);
+          if (k >= T) return;
+          part[k].reserve((start[k + 1] - start[k]) / 20000 + 16);
+          size_t e = 0;
+          ok[k] = bgzf_walk_pread(fd, size, start[k], start[k + 1], 0, ~(size_t)0, &e, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+            part[k].push_back(B{cpos, clen, u, ulen, fpos});
+          });
+          stop[k] = e;
+        }
+      });
+      bool chained = true;
+      for (int k = 0; k < T; ++k) chained = chained && ok[k] && stop[k] == start[k + 1];
+      if (getenv("MIDAS_SNPS_TRACE")) fprintf(stderr, "[bam inflate] block table walked in %d pieces: %s\n", T, chained ? "they chain" : "they do NOT chain (one thread walks it again)");
+      if (chained) {
+        uint64_t upos = 0;
+        for (int k = 0; k < T; ++k) {
+          for (const B& b : part[k]) emit(b.cpos, b.clen, upos + b.upos, b.ulen, b.fpos);
+          if (!part[k].empty()) upos += part[k].back().upos + part[k].back().ulen;
+        }
+        *end = size;
+        *total = upos;
+        return true;
+      }
+    }
+  }
+  uint64_t upos = 0;
+  const bool ok1 = bgzf_walk_pread(fd, size, 0, size, 0, ~(size_t)0, end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+    emit(cpos, clen, u, ulen, fpos);
+    upos = u + ulen;
+  });
+  *total = upos;
+  return ok1;
+}
+
+// A file mapping whose pages were touched goes in two steps: its pages are dropped piece by piece by several threads
+// (MADV_DONTNEED takes the address space's lock SHARED: the pieces' page tables are emptied side by side, and the threads that
+// are faulting elsewhere meanwhile -- the table writers, the genome reader -- are not held up as they are behind munmap's
+// exclusive lock), then the empty range is unmapped.  munmap alone walks a 9 GB BAM's 2.2 M page-table entries on one core:
+// 0.18 - 0.33 s on the GPU box.
+static void pretouch_mapping(const uint8_t* base, size_t size) {
+  (void)madvise(const_cast<uint8_t*>(base), size, MADV_WILLNEED);
+  const size_t piece = (size_t)8 << 20, n_pieces = (size + piece - 1) / piece;
+  const int n_workers = (int)std::min<size_t>(std::max<size_t>(n_pieces, 1), 16);
+  std::atomic<size_t> nextp{0};
+  std::atomic<unsigned> sink{0};
+  Workers::run(n_workers, [&] {
+    unsigned acc = 0;
+    for (;;) {
+      const size_t k = nextp.fetch_add(1);
+      if (k >= n_pieces) break;
+      const size_t end = std::min(size, (k + 1) * piece);
+      for (size_t off = k * piece; off < end; off += 4096) acc += base[off];
+    }
+    sink += acc;
+  });
+}
+static void unmap_file(const void* base, size_t size) {
+  if (!base || !size) return;
+  uint8_t* const b = static_cast<uint8_t*>(const_cast<void*>(base));
+  const int budget = midas::cpu_budget();
+  if (size >= ((size_t)256 << 20) && budget >= 2) {
+    const size_t piece = (size_t)64 << 20, n_pieces = (size + piece - 1) / piece;
+    const int nt = (int)std::min<size_t>(n_pieces, (size_t)std::min(budget, 16));
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;       // (threads of its own: the pool may be busy with the pileup's table writers)
+    auto work = [&] {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= n_pieces) return;
+        const size_t lo = k * piece, hi = std::min(size, lo + piece);
+        (void)madvise(b + lo, hi - lo, MADV_DONTNEED);
+      }
+    };
+    for (int k = 1; k < nt; ++k) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+  }
+  munmap(b, size);
+}
+
 struct FileBlk { size_t cpos, clen, upos, ulen, fpos; };
 // A BGZF file read whole (by several threads) and its block table: where every block's DEFLATE stream lies, what it inflates to.
 // A whole file's bytes for reading: the file MAPPED where that works (a BAM of a gigabyte is in the page cache when the pileup
@@ -354,7 +492,7 @@ struct FileImage {
   FileImage(const FileImage&) = delete;
   FileImage& operator=(const FileImage&) = delete;
   ~FileImage() {
-    if (map) { midas::unregister_file_mapping(map); munmap(map, n); }
+    if (map) { midas::unregister_file_mapping(map); unmap_file(map, n); }
     if (fd >= 0) close(fd);
   }
   const uint8_t* data() const { return p; }
@@ -374,13 +512,14 @@ int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<Fil
   void* m = fsz > 0 && !getenv("MIDAS_SNPS_NO_MMAP") ? mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
   bool mapped = false;
   if (m != MAP_FAILED) {
-    // mapped for whoever looks INTO it (the header's blocks, the host's inflater); the block table below and the device
-    // upload read the file with pread: no page of it is mapped on their account (hostio.h, register_file_mapping)
+    // the WHOLE file is about to be read by this process (the host's inflater, or the upload's copy threads): its pages are
+    // mapped in by several threads (one read per page: the kernel maps a run of cached pages per fault), the readers then find
+    // them there.  The block table below is walked with pread all the same (bgzf_walk_file).
     comp.map = m;
     comp.p = static_cast<const uint8_t*>(m);
     comp.n = fsz;
     comp.fd = fd;
-    midas::register_file_mapping(m, fsz, fd);
+    pretouch_mapping(comp.p, fsz);
     mapped = true;
     lap("map file");
   } else {
@@ -411,10 +550,11 @@ int32_t read_bgzf_file(const std::string& path, FileImage& comp, std::vector<Fil
   size_t upos = 0;
   if (mapped) {
     size_t end = 0;
-    const bool ok = bgzf_walk_pread(comp.fd, fsz, 0, fsz, 0, ~(size_t)0, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+    uint64_t tot = 0;
+    const bool ok = bgzf_walk_file(comp.fd, comp.p, fsz, &end, &tot, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
       blocks.push_back({cpos, clen, (size_t)u, (size_t)ulen, fpos});
-      upos = (size_t)u + ulen;
     });
+    upos = (size_t)tot;
     if (!ok || end != fsz) { set_err(err256, "%s: not a BGZF block (or a truncated one) at offset %lld", path.c_str(), (long long)end); return MIDAS_SNPS_ERR_BAD_LAYOUT; }
   } else {
   size_t p = 0;
@@ -667,20 +807,6 @@ void run_pool(int nt, size_t n_tasks, F&& fn) {
 
 // ---- rank-local BAM decode: block table, slice walk with verified record-boundary guessing, range loads -------------------
 // A BGZF block header at file offset p (an extra field with the BC subfield, as htslib and this library write it)?
-static bool bgzf_header_at(const uint8_t* c, size_t size, size_t p, size_t* xlen_out, size_t* bsize_out) {
-  if (p + 18 > size || c[p] != 0x1f || c[p + 1] != 0x8b || c[p + 2] != 8 || !(c[p + 3] & 4)) return false;
-  const size_t xlen = rd16(&c[p + 10]);
-  size_t q = p + 12, xend = p + 12 + xlen, bsize = 0;
-  while (q + 4 <= xend && xend <= size) {
-    const uint16_t slen = rd16(&c[q + 2]);
-    if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) bsize = (size_t)rd16(&c[q + 4]) + 1;
-    q += 4 + slen;
-  }
-  if (bsize == 0 || p + bsize > size || bsize < xlen + 20) return false;
-  *xlen_out = xlen;
-  *bsize_out = bsize;
-  return true;
-}
 // walk n_more blocks further along a local table's chain; false: the end of the file, or no block header where one must be
 static bool bgzf_grow(BgzfMap& m, size_t n_more) {     // (true: at least one block was added)
   const size_t before = m.blocks.size();
@@ -692,25 +818,6 @@ static bool bgzf_grow(BgzfMap& m, size_t n_more) {     // (true: at least one bl
   m.next_fpos = end;
   return m.blocks.size() > before;
 }
-// The first block start at or behind `from`: a header from which `chain` headers in a row follow one another (or the file ends
-// behind fewer).  `size` when there is none.  (A guess: the caller's ranks compare their walks -- a rank's walk must END on the
-// next rank's guess -- before any of them believes it.)
-static size_t bgzf_find_block(const uint8_t* c, size_t size, size_t from, int chain) {
-  for (size_t p = from; p + 18 <= size && p < from + ((size_t)1 << 17); ++p) {
-    if (c[p] != 0x1f || c[p + 1] != 0x8b) continue;
-    size_t q = p;
-    int ok = 0;
-    while (ok < chain && q < size) {
-      size_t xlen = 0, bsize = 0;
-      if (!bgzf_header_at(c, size, q, &xlen, &bsize)) { ok = -1; break; }
-      q += bsize;
-      ++ok;
-    }
-    if (ok > 0) return p;
-  }
-  return size;
-}
-
 int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool touch = true) {
   m.fd = open(path.c_str(), O_RDONLY);
   if (m.fd < 0) { set_err(err256, "cannot open %s", path.c_str()); return MIDAS_SNPS_ERR_INVALID_ARG; }
@@ -721,13 +828,16 @@ int32_t bgzf_map_file(const std::string& path, BgzfMap& m, char* err256, bool to
   void* a = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, m.fd, 0);
   if (a == MAP_FAILED) { set_err(err256, "cannot map %s", path.c_str()); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
   m.base = static_cast<const uint8_t*>(a);
-  midas::register_file_mapping(a, m.size, m.fd);
-  (void)touch;      // (nobody reads the file's bulk through the mapping any more: nothing to page in ahead of time)
+  // One caller that will read the WHOLE file (16 CPUs, one GPU): the pages are mapped in now, by several threads, and the
+  // upload's threads copy out of the mapping (51 GB/s into the pinned ring on the GPU box; pread by as many threads: 33 GB/s).
+  // A rank of N that takes 1 / N of the file, on the few CPUs a rank of N has: nothing is mapped in for it -- its upload reads
+  // its share with pread (hostio.h, register_file_mapping), and there is no page table to take down afterwards.
+  if (touch) pretouch_mapping(m.base, m.size);
+  else midas::register_file_mapping(a, m.size, m.fd);
   size_t end = 0;
   uint64_t upos = 0;
-  const bool ok = bgzf_walk_pread(m.fd, m.size, 0, m.size, 0, ~(size_t)0, &end, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
+  const bool ok = bgzf_walk_file(m.fd, m.base, m.size, &end, &upos, [&](size_t cpos, size_t clen, uint64_t u, uint32_t ulen, size_t fpos) {
     m.blocks.push_back({cpos, clen, u, ulen, fpos});
-    upos = u + ulen;
   });
   if (!ok || end != m.size) {
     set_err(err256, "%s: not a BGZF block (or a truncated one) at offset %lld", path.c_str(), (long long)end);
@@ -1091,6 +1201,8 @@ size_t parse_bam_header(const uint8_t* d, size_t n, midas_bam* b, bool* bad_magi
 }
 
 }  // namespace
+void midas_hostio_unmap(const void* base, size_t size) { unmap_file(base, size); }
+
 
 extern "C" {
 

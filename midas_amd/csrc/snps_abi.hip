@@ -311,7 +311,9 @@ int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t byt
 // file mapped for them (hostio.h, register_file_mapping)
 bool parallel_pread(uint8_t* dst, int fd, size_t file_off, size_t n) {
   const unsigned hw = (unsigned)midas::cpu_budget();
-  size_t nt = hw >= 32 ? 12 : (hw >= 8 ? 4 : 1);
+  size_t nt = hw >= 32 ? 12 : (hw >= 16 ? 8 : (hw >= 8 ? 4 : (hw >= 2 ? 2 : 1)));
+  static const int forced = [] { const char* e = getenv("MIDAS_SNPS_UPLOAD_THREADS"); return e ? atoi(e) : 0; }();
+  if (forced > 0) nt = (size_t)std::min(forced, 64);
   if (n < ((size_t)4 << 20)) nt = 1;
   const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
   std::atomic<int> bad{0};

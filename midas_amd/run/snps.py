@@ -985,11 +985,15 @@ def _count_alleles(args, species, contigs, ctx):
             # (one rank, every contig its own: SEQ / QUAL / CIGAR can stay on the device the blocks were inflated on)
             try:
                 # ... in the pileup kernel's own layout, every column included (abi.ResidentReads): ONE pass from the file to the tallies
+                t_in = time()
                 opened = args.pop('_bam_opener').wait() if args.get('_bam_opener') is not None else None
+                t_in = _lap("  BAM opened: its block table waited for", t_in)
                 if opened is not None and inflater is not None and ws == 1 and 0 <= opened.first < opened.total:
                     # (the file was mapped and its block table walked while the device context came up)
                     refid, rr = opened.load_ranges([(opened.first, opened.total)], inflater, resident=True)
+                    t_in = _lap("  decode on the device (resident)", t_in)
                     opened.release_file()        # (its bytes are on the device: the mapping goes while the records are piled up)
+                    _lap("  file released", t_in)
                     decoded = (opened.ref_names, opened.ref_lens, refid, rr)
                 else:
                     if opened is not None:
@@ -1018,10 +1022,12 @@ def _count_alleles(args, species, contigs, ctx):
     # An item is a contig -- the unit count_coverage is called on -- or, for a contig longer than the split length in a BAM
     # whose positions are sorted, a piece of it (midas_amd/pieces.py): one 20 Mb chromosome must not pin the job to one GPU.
     all_ids = sorted(species)
+    t_in = time()
     # first use of the genomes: what their reader raised (a missing genome's sys.exit, an OSError) ends every rank together
     try:
         if isinstance(contigs, ContigsInBackground):
             contigs = contigs.wait()
+            t_in = _lap("  genomes waited for", t_in)
     except SystemExit as e:
         error = dist.exit_message(e)
     except Exception as e:
@@ -1080,6 +1086,7 @@ def _count_alleles(args, species, contigs, ctx):
                 args['log'].write("long contigs: %d cut into pieces of %d positions; records decoded per rank: %s of %d\n"
                                   % (n_cut, piece_len, ' '.join(str(int(x)) for x in per_rank), int(plan['ref_reads'].sum())))
 
+    _lap("  work items", t_in)
     t_lap = _lap("decode, plan, genomes, work items", start)
     local = {}
     try:

@@ -64,6 +64,79 @@ def test_large_bam_goes_through_the_parallel_record_walk(tmp_path):
     assert "truncated or malformed alignment record" in e.value.message
 
 
+def test_block_table_walked_in_pieces_is_the_serial_walk(tmp_path, monkeypatch):
+    """A large BAM's BGZF block table is walked by several threads, each from a GUESSED block start (hostio.cpp bgzf_walk_file):
+    believed only if every piece's walk ends on the next piece's guess.  Forced on for a small file here: the decode must be
+    what was written -- also when the guess lands in a block whose payload holds bytes that look like a block header (a stored
+    block carrying a copy of a real header: the guess starts a chain there that does not hit the next piece's start, and one
+    thread walks the file again) -- and a truncated file is refused as before."""
+    import struct
+    import zlib
+    contigs, reads = synth.make_dataset(n_species=2, contigs_per_species=3, contig_len=40000, n_reads=30000, seed=22, var_len=True)
+    refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
+    path = str(tmp_path / "p.bam")
+    bam.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads)
+    want = abi.read_bam(path)
+    monkeypatch.setenv("MIDAS_SNPS_PARALLEL_WALK_MIN", "1000")
+    for use in (abi.read_bam,):
+        got = use(path)
+        assert got[0] == want[0] and got[1] == want[1]
+        np.testing.assert_array_equal(got[2], want[2])
+        for k in abi._SOA_DTYPES:
+            np.testing.assert_array_equal(getattr(got[3], k), getattr(want[3], k), err_msg=k)
+
+    # the same records in STORED blocks whose bytes are full of real-looking headers: every guess is at risk
+    raw = gzip.open(path, 'rb').read()
+    fake = bam._bgzf_block(b"x" * 300)[:18]
+    stuffed = str(tmp_path / "stuffed.bam")
+    with open(stuffed, 'wb') as f:
+        for lo in range(0, len(raw), 20000):
+            piece = raw[lo:lo + 20000]
+            body = b"\x01" + struct.pack('<HH', len(piece), len(piece) ^ 0xFFFF) + piece           # one stored DEFLATE block
+            bsize = 18 + len(body) + 8
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack('<H', 6) + b"BC" + struct.pack('<HH', 2, bsize - 1) + body
+                    + struct.pack('<II', zlib.crc32(piece), len(piece)))
+        f.write(bam._bgzf_block(b""))
+    got = abi.read_bam(stuffed)
+    np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_array_equal(got[3].seq4, want[3].seq4)
+    # ... and with decoy headers INSIDE the stored bytes (the qualities of a read replaced by copies of a header)
+    rawb = bytearray(raw)
+    at = len(rawb) // 2
+    for k in range(0, 4000, 18):
+        rawb[at + k:at + k + 18] = fake
+    decoy = str(tmp_path / "decoy.bam")
+    with open(decoy, 'wb') as f:
+        for lo in range(0, len(rawb), 20000):
+            piece = bytes(rawb[lo:lo + 20000])
+            body = b"\x01" + struct.pack('<HH', len(piece), len(piece) ^ 0xFFFF) + piece
+            bsize = 18 + len(body) + 8
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack('<H', 6) + b"BC" + struct.pack('<HH', 2, bsize - 1) + body
+                    + struct.pack('<II', zlib.crc32(piece), len(piece)))
+        f.write(bam._bgzf_block(b""))
+    monkeypatch.delenv("MIDAS_SNPS_PARALLEL_WALK_MIN")
+    try:
+        serial = abi.read_bam(decoy)
+        serial_err = None
+    except abi.MidasSnpsError as e:
+        serial, serial_err = None, e.message
+    monkeypatch.setenv("MIDAS_SNPS_PARALLEL_WALK_MIN", "1000")
+    try:
+        pieces = abi.read_bam(decoy)
+        pieces_err = None
+    except abi.MidasSnpsError as e:
+        pieces, pieces_err = None, e.message
+    assert (serial is None) == (pieces is None) and serial_err == pieces_err      # (the records are damaged: both refuse, the same way -- or both read)
+    if serial is not None:
+        np.testing.assert_array_equal(pieces[2], serial[2])
+
+    cut = str(tmp_path / "cutfile.bam")
+    blob = open(path, 'rb').read()
+    open(cut, 'wb').write(blob[:len(blob) - 40])
+    with pytest.raises(abi.MidasSnpsError):
+        abi.read_bam(cut)
+
+
 def test_record_walk_is_not_fooled_by_bytes_that_look_like_records(tmp_path):
     """White box: walk_records cuts the inflated stream into min(4 x threads, MiB) pieces and scans forward from every cut
     for eight plausible records in a row.  Here the QUAL bytes of the reads that straddle those cuts spell eight

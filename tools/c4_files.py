@@ -46,13 +46,13 @@ def main():
         contigs.n_species, contigs.n_contigs, contigs.n_sites, reads.n_reads, t1 - t0, time.time() - t1, os.path.getsize(bam) / 1e9,
         utility.cpu_budget()), flush=True)
     runs = []
-    for how in ('auto', 'auto', 'auto', 'off'):
+    for how in os.environ.get('C4_RUNS', 'auto,auto,auto,off').split(','):        # ('auto@8': the upload's pread by 8 threads)
         shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)
         env = dict(os.environ, MIDAS_SNPS_TRACE='1')
-        if how.endswith('fast-exit'):
-            env['MIDAS_SNPS_EXIT'] = 'fast'
+        if '@' in how:
+            env['MIDAS_SNPS_UPLOAD_THREADS'] = how.split('@')[1]
         t = time.perf_counter()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how.split()[0]],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how.split('@')[0]],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         dt = time.perf_counter() - t
         if r.returncode != 0:
