@@ -173,7 +173,7 @@ __device__ int32_t find_nm(const uint8_t* a, const uint8_t* end) {
 
 __global__ __launch_bounds__(256) void bam_columns_kernel(BamColumnsParams p) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) { p.seq_off[0] = 0; p.qual_off[0] = 0; p.cigar_off[0] = 0; if (p.unit_off) p.unit_off[0] = 0; }
+  if (i == 0) { p.seq_off[0] = p.base[0]; p.qual_off[0] = p.base[1]; p.cigar_off[0] = p.base[2]; if (p.unit_off) p.unit_off[0] = p.base[3]; }
   if (i >= p.n) return;
   const uint8_t* r = p.d + p.rec_off[i];
   const uint32_t bs = rd32(r);

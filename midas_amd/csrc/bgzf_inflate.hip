@@ -814,11 +814,19 @@ __global__ __launch_bounds__(256) void bam_payload_kernel(PayloadParams p) {
   const uint32_t lane = threadIdx.x & 63u, sub = lane >> 5, sl = lane & 31u;
   const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub, n_slots = (long long)gridDim.x * 8;
   for (long long i = slot; i < p.n_records; i += n_slots) {
-    const uint8_t* r = p.stream + p.rec_off[i];
-    const uint32_t l_name = r[12];
-    const uint32_t n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
-    const uint32_t l = (uint32_t)r[20] | ((uint32_t)r[21] << 8) | ((uint32_t)r[22] << 16) | ((uint32_t)r[23] << 24);
-    const uint8_t* q = r + 36 + l_name;
+    uint32_t n_cig, l;
+    const uint8_t* q;
+    if (p.drec) {        // out of the direct layout: the same run of bytes, found by the read's record
+      n_cig = (uint32_t)(p.cigar_off[i + 1] - p.cigar_off[i]);
+      l = (uint32_t)(p.qual_off[i + 1] - p.qual_off[i]);
+      q = p.stream + ((unsigned long long)p.drec[i].off8 << 3);
+    } else {
+      const uint8_t* r = p.stream + p.rec_off[i];
+      const uint32_t l_name = r[12];
+      n_cig = (uint32_t)r[16] | ((uint32_t)r[17] << 8);
+      l = (uint32_t)r[20] | ((uint32_t)r[21] << 8) | ((uint32_t)r[22] << 16) | ((uint32_t)r[23] << 24);
+      q = r + 36 + l_name;
+    }
     copy_run32(reinterpret_cast<uint8_t*>(p.cigar + p.cigar_off[i]), q, 4u * n_cig, sl);
     q += 4ull * n_cig;
     const uint32_t ns = (l + 1u) / 2u;
@@ -864,6 +872,15 @@ hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream
   if (g > cap) g = cap;
   hipLaunchKernelGGL(bam_payload_kernel, dim3((unsigned)g), dim3(256), 0, s, p);
   return hipGetLastError();
+}
+
+// How many BGZF blocks fill the device ONCE with the decoder's workgroups (a lane a block, kW lanes a workgroup, as many
+// workgroups a CU as its LDS holds): the decoder is latency-bound, a launch takes about as long for one such wave of blocks as
+// for a tenth of it -- what a streamed decode's groups are sized by (snps_abi.hip device_decode_stream).
+long long bgzf_inflate_wave_blocks(int n_cu) {
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, w64::bgzf_decode_kernel, w64::kW, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
+  return (long long)occ * (n_cu > 0 ? n_cu : 256) * w64::kW;
 }
 
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases) {

@@ -298,12 +298,16 @@ struct InflateParams {
   const uint32_t* want_crc;        // per stream: the CRC-32 its inflated bytes must have (BGZF footer); nullptr: not checked
 };
 hipError_t launch_bgzf_inflate(const InflateParams& p, hipStream_t s, int phases = 3);
+long long bgzf_inflate_wave_blocks(int n_cu);      // blocks that fill the device once with the decoder's workgroups
 struct PayloadParams {
   const uint8_t* stream;                   // the inflated BAM
   const unsigned long long* rec_off;       // where every record starts in it
   long long n_records;
   const long long* seq_off; const long long* qual_off; const long long* cigar_off;     // [n_records + 1], elements
   uint8_t* seq4; uint8_t* qual; uint32_t* cigar;
+  // (a streamed decode keeps no inflated stream: the records' runs are cut out of the DIRECT layout then -- `stream` is its payload,
+  // drec[i].off8 where record i's [cigar][seq][qual] run starts in it, the lengths from the offset columns)
+  const DirectRec* drec = nullptr;
 };
 hipError_t launch_bam_payload(const PayloadParams& p, int grid_blocks, hipStream_t s);    // 1: decode, 2: resolve the matches
 
@@ -334,6 +338,9 @@ struct BamColumnsParams {
   int32_t* span;                                    // (nullable) reference span: the lengths of the record's M / D / N / = / X ops
   unsigned long long* bad_record;                   // min index of a record whose variable parts overrun its block_size or whose
                                                     // refID names no reference of the header (~0: none)
+  // A GROUP of a streamed decode (snps_abi.hip device_decode_stream): the records continue the columns of the groups before it --
+  // the offsets' scans start at what those came to (entry [0] of this group = the last entry of the one before).
+  long long base[4] = {0, 0, 0, 0};                 // seq_off, qual_off, cigar_off, unit_off
 };
 // the records of an inflated stream as the direct layout (layout.h): DirectRec[n + 1] + payload, one copy of every record's
 // [cigar][seq][qual] run; pos / nm: the columns bam_columns_kernel decoded, unit_off: its scanned payload units

@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <thread>
 
 #include <cmath>
@@ -822,6 +823,578 @@ void arena_loan_free(void* v) {
   if (l) { l->pool->drop_twins(l->p); l->pool->give(l->p); delete l; }
 }
 
+// The streams of a decode whose matches did not fit their room (status kInflateMatchRoom): again, with the bound's room (a match
+// is at least three bytes), into the same output; their statuses replace the first pass's.
+hipError_t inflate_again(const InflateParams& ip, const std::vector<InflateBlock>& blocks, const std::vector<uint32_t>& want, std::vector<uint32_t>& status,
+                         hipStream_t s, bool* ran) {
+  *ran = false;
+  std::vector<size_t> again;
+  for (size_t k = 0; k < status.size(); ++k)
+    if (status[k] == kInflateMatchRoom) again.push_back(k);
+  if (again.empty()) return hipSuccess;
+  *ran = true;
+  std::vector<InflateBlock> b2(again.size());
+  std::vector<uint32_t> want2(again.size());
+  unsigned long long room2 = 0;
+  for (size_t j = 0; j < again.size(); ++j) {
+    const InflateBlock& q = blocks[again[j]];
+    const uint32_t cap = q.ulen / 3u + 1u;
+    b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
+    want2[j] = want[again[j]];
+    room2 += cap;
+  }
+  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_b2, d_s2, d_m2, d_c2;
+  hipError_t e;
+#define AG_TRY(call) do { e = (call); if (e != hipSuccess) return e; } while (0)
+  AG_TRY(hipMalloc(&d_b2.p, b2.size() * sizeof(InflateBlock)));
+  AG_TRY(hipMalloc(&d_s2.p, b2.size() * 8));
+  AG_TRY(hipMalloc(&d_m2.p, (size_t)room2 * 8));
+  AG_TRY(hipMalloc(&d_c2.p, b2.size() * 4));
+  AG_TRY(hipMemcpyAsync(d_b2.p, b2.data(), b2.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+  AG_TRY(hipMemcpyAsync(d_c2.p, want2.data(), b2.size() * 4, hipMemcpyHostToDevice, s));
+  InflateParams ip2 = ip;
+  ip2.blocks = static_cast<const InflateBlock*>(d_b2.p);
+  ip2.n_blocks = (long long)b2.size();
+  ip2.status = static_cast<uint32_t*>(d_s2.p);
+  ip2.n_matches = static_cast<uint32_t*>(d_s2.p) + b2.size();
+  ip2.matches = static_cast<unsigned long long*>(d_m2.p);
+  ip2.want_crc = static_cast<const uint32_t*>(d_c2.p);
+  AG_TRY(launch_bgzf_inflate(ip2, s));
+  std::vector<uint32_t> st2(b2.size());
+  AG_TRY(hipMemcpyAsync(st2.data(), d_s2.p, b2.size() * 4, hipMemcpyDeviceToHost, s));
+  AG_TRY(hipStreamSynchronize(s));
+#undef AG_TRY
+  for (size_t j = 0; j < again.size(); ++j) status[again[j]] = st2[j];
+  return hipSuccess;
+}
+
+// ---- the streamed decode ------------------------------------------------------------------------------------------------------
+// A BAM of several device-fills of blocks (bgzf_inflate_wave_blocks), decoded RESIDENT group by group: the reference's loop over the
+// file (midas/run/snps.py:186-199 iterates the alignments as htslib inflates them, a block at a time) at the device's granularity.
+//   * a GROUP is a run of whole BGZF blocks -- one wave of the decoder's workgroups by default -- plus a few blocks behind it for
+//     the record that straddles its end; it wants the records that START inside it.  Where the chain of group g ends (the first
+//     record start at or behind its last wanted byte) is the exact first record of group g + 1: nothing is guessed behind group 0.
+//   * a group lives in a SLOT (inflated bytes | compressed bytes | block tables | match lists, the walk's tables over the dead
+//     ones); an uploader thread fills slot (g + 1) % S through the pinned ring on a stream of its own while the kernels of group g
+//     run on the context's -- the link and the decoder work at the same time.
+//   * what STAYS is written where it stays: every group's columns continue the ones before it (BamColumnsParams::base: the offset
+//     scans start at what the earlier groups came to), its records and their [cigar][seq][qual] runs go straight behind theirs
+//     in the direct layout.  Those arrays are sized from the first group's records per inflated byte (+ 3 %) and grown (a copy on
+//     the device) if a later group proves the estimate short.
+// Device memory: S slots of ~2.5 x a group's inflated bytes + the result (~1.1 x the file's inflated bytes), against ~2.3 x the
+// file's inflated bytes in one arena -- bounded by the group, not by the file, in everything but the result itself.
+// No inflated stream is kept: a handle decoded this way cuts its raw columns, if somebody asks for them, out of the direct layout
+// (PayloadParams::drec).  kStreamFallback: this BAM is not for the streamed decode (a record longer than the blocks a group
+// keeps behind its end) -- the caller decodes it in one arena.
+constexpr int32_t kStreamFallback = -1000;
+struct TwoBuffers { void* a; void* b; };
+void two_buffers_free(void* v) {
+  TwoBuffers* t = static_cast<TwoBuffers*>(v);
+  if (t->a) (void)hipFree(t->a);
+  if (t->b) (void)hipFree(t->b);
+  delete t;
+}
+struct StreamColumns {       // the result's record arrays in ONE allocation, for `cap` records (+ 2: the offsets' last entry, the sentinel record)
+  uint8_t* p = nullptr;
+  size_t cap = 0, bytes = 0;
+  size_t at[11] = {0};        // rec, refid, pos, nm, l_seq, mapq, flag, seq_off, qual_off, cigar_off, unit_off
+  static constexpr size_t width(int k) { return k == 0 ? 16 : (k <= 4 ? 4 : (k == 5 ? 1 : (k == 6 ? 2 : 8))); }
+  void lay(size_t cap_records) {
+    cap = cap_records;
+    size_t o = 0;
+    for (int k = 0; k < 11; ++k) { at[k] = o; o += ((cap + 2) * width(k) + 255) & ~(size_t)255; }
+    bytes = o;
+  }
+  uint8_t* colp(int k) const { return p + at[k]; }
+};
+
+int32_t device_decode_stream(midas_snps_ctx* ctx, const uint8_t* comp_base, const InflateJob* jobs, DecodeSegment& sg, size_t group_blocks, int n_slots,
+                             const int64_t* ref_lens, int32_t n_ref, HostColumns (*alloc)(void*, int64_t), void* sink, DeviceDecodeResult* res,
+                             int64_t* bad_job, int64_t* bad_record, char* err256) {
+  auto hip_err = [&](hipError_t e, const char* what) {
+    if (err256) snprintf(err256, 256, "device decode (streamed): %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP;
+  };
+#define DS_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_err(e__, #call); } while (0)
+  const bool trace = getenv("MIDAS_SNPS_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto t_last = t_begin;
+  double laps[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // waited for the upload, inflate, walk, stitch, columns, direct, grow, tables
+  auto lap = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    laps[k] += std::chrono::duration<double, std::milli>(t - t_last).count();
+    t_last = t;
+  };
+  hipStream_t s = ctx->stream;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  constexpr size_t kTail = 8;                    // blocks kept behind a group's last: the record that straddles its end lies in them
+  const size_t j_lo = sg.job_lo, j_hi = sg.job_hi;
+  const size_t K = (j_hi - j_lo + group_blocks - 1) / group_blocks;
+  const uint64_t seg_limit = jobs[j_hi - 1].upos + jobs[j_hi - 1].ulen;
+  const uint64_t seg_stop = sg.stop < seg_limit ? sg.stop : seg_limit;
+  struct Group { size_t b_lo, b_hi, b_ext; uint64_t u_lo, stop; size_t comp, infl, room; };
+  std::vector<Group> groups(K);
+  size_t slot_bytes = 0;
+  for (size_t g = 0; g < K; ++g) {
+    Group& G = groups[g];
+    G.b_lo = j_lo + g * group_blocks;
+    G.b_hi = std::min(j_hi, G.b_lo + group_blocks);
+    G.b_ext = std::min(j_hi, G.b_hi + kTail);
+    G.u_lo = jobs[G.b_lo].upos;
+    G.stop = G.b_hi == j_hi ? seg_stop : std::min<uint64_t>(seg_stop, jobs[G.b_hi].upos);
+    G.comp = (size_t)(jobs[G.b_ext - 1].cpos + jobs[G.b_ext - 1].clen + 8 - jobs[G.b_lo].cpos);
+    G.infl = (size_t)(jobs[G.b_ext - 1].upos + jobs[G.b_ext - 1].ulen - G.u_lo);
+    G.room = 0;
+    for (size_t j = G.b_lo; j < G.b_ext; ++j) {
+      if (jobs[j].cpos < jobs[G.b_lo].cpos || jobs[j].upos < G.u_lo) { if (err256) snprintf(err256, 256, "device decode: block %lld lies outside the buffers", (long long)j); return MIDAS_SNPS_ERR_INVALID_ARG; }
+      G.room += jobs[j].ulen / 8u + 16u;
+    }
+    const size_t nj = G.b_ext - G.b_lo;
+    // (behind the inflated bytes: the dead compressed bytes, tables and match lists hold the walk's tables and the record offsets --
+    // 8 bytes a record of >= 36: a quarter of the inflated bytes at most)
+    const size_t behind = std::max(up(G.comp + 512) + up(nj * sizeof(InflateBlock)) + up(nj * 12) + up(G.room * 8), G.infl / 3 + ((size_t)4 << 20));
+    slot_bytes = std::max(slot_bytes, up(G.infl + 64) + behind);
+  }
+  if (n_slots > (int)K) n_slots = (int)K;
+  bool pooled = false;
+  void* arena_p = ctx->arena->take(slot_bytes * (size_t)n_slots, &pooled);
+  if (!arena_p) { if (err256) snprintf(err256, 256, "device decode (streamed): out of device memory (%.1f GB of slots)", (double)(slot_bytes * (size_t)n_slots) / 1e9); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+  struct Loan { std::shared_ptr<midas_arena_pool> pool; void* p; ~Loan() { if (p) pool->give(p); } } loan{ctx->arena, arena_p};
+  uint8_t* const arena = static_cast<uint8_t*>(arena_p);
+  const double slots_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (trace) fprintf(stderr, "[device decode] streamed: %zu groups of <= %zu blocks, %d slots of %.2f GB (allocated in %.1f ms)\n", K, group_blocks, n_slots,
+                     (double)slot_bytes / 1e9, slots_ms);
+  t_last = std::chrono::steady_clock::now();
+
+  // ---- the uploader: a group's bytes and tables up on its own stream, then the group's decoder / resolver / CRC kernels on one of
+  // two streams (groups alternate: the decoder is latency-bound -- ~25 ms a launch however few blocks -- and the next group's
+  // workgroups fill the CUs that this group's stragglers leave idle), its statuses down into pinned memory, an event behind them --
+  struct Pipe {
+    std::mutex m;
+    std::condition_variable cv;
+    long long launched = 0, decoded = 0;
+    bool abort = false;
+    int32_t status = MIDAS_SNPS_OK;
+    hipError_t hip = hipSuccess;
+    double busy_ms = 0;
+  } pipe;
+  struct GroupHost { std::vector<InflateBlock> blocks; std::vector<uint32_t> want; };
+  std::vector<GroupHost> host(K);
+  struct Streams {
+    hipStream_t up = nullptr, inf[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev;
+    uint32_t* status = nullptr;       // pinned: every group's block statuses
+    ~Streams() {
+      for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+      if (up) (void)hipStreamDestroy(up);
+      for (hipStream_t q : inf) if (q) (void)hipStreamDestroy(q);
+      if (status) (void)hipHostFree(status);
+    }
+  } st;
+  DS_TRY(hipStreamCreateWithFlags(&st.up, hipStreamNonBlocking));
+  DS_TRY(hipStreamCreateWithFlags(&st.inf[0], hipStreamNonBlocking));
+  DS_TRY(hipStreamCreateWithFlags(&st.inf[1], hipStreamNonBlocking));
+  st.ev.assign(K, nullptr);
+  for (size_t g = 0; g < K; ++g) DS_TRY(hipEventCreateWithFlags(&st.ev[g], hipEventDisableTiming));
+  std::vector<size_t> status_at(K + 1, 0);
+  for (size_t g = 0; g < K; ++g) status_at[g + 1] = status_at[g] + (groups[g].b_ext - groups[g].b_lo);
+  DS_TRY(hipHostMalloc(reinterpret_cast<void**>(&st.status), status_at[K] * 4 + 64, kHostAllocFlags));
+  auto slot_layout = [&](const Group& G, size_t* at_comp, size_t* at_blocks, size_t* at_status, size_t* at_crc, size_t* at_matches) {
+    const size_t nj = G.b_ext - G.b_lo;
+    *at_comp = up(G.infl + 64); *at_blocks = *at_comp + up(G.comp + 512); *at_status = *at_blocks + up(nj * sizeof(InflateBlock));
+    *at_crc = *at_status + up(nj * 8); *at_matches = *at_crc + up(nj * 4);
+  };
+  auto inflate_params = [&](const Group& G, uint8_t* slot) {
+    size_t at_comp, at_blocks, at_status, at_crc, at_matches;
+    slot_layout(G, &at_comp, &at_blocks, &at_status, &at_crc, &at_matches);
+    const size_t nj = G.b_ext - G.b_lo;
+    InflateParams ip;
+    ip.comp = slot + at_comp;
+    ip.blocks = reinterpret_cast<const InflateBlock*>(slot + at_blocks);
+    ip.n_blocks = (long long)nj;
+    ip.out = slot;
+    ip.status = reinterpret_cast<uint32_t*>(slot + at_status);
+    ip.n_matches = reinterpret_cast<uint32_t*>(slot + at_status) + nj;
+    ip.matches = reinterpret_cast<unsigned long long*>(slot + at_matches);
+    ip.want_crc = reinterpret_cast<const uint32_t*>(slot + at_crc);
+    return ip;
+  };
+  std::thread uploader([&] {
+    (void)hipSetDevice(ctx->device);
+    for (size_t g = 0; g < K; ++g) {
+      {
+        std::unique_lock<std::mutex> lk(pipe.m);
+        pipe.cv.wait(lk, [&] { return pipe.abort || (long long)g < pipe.decoded + n_slots; });
+        if (pipe.abort) return;
+      }
+      const Group& G = groups[g];
+      uint8_t* slot = arena + (g % (size_t)n_slots) * slot_bytes;
+      const auto t0 = std::chrono::steady_clock::now();
+      const size_t nj = G.b_ext - G.b_lo;
+      GroupHost& H = host[g];
+      H.blocks.resize(nj);
+      H.want.resize(nj);
+      {
+        unsigned long long room = 0;
+        const uint64_t c0 = jobs[G.b_lo].cpos;
+        for (size_t j = 0; j < nj; ++j) {
+          const InflateJob& q = jobs[G.b_lo + j];
+          const uint32_t cap = q.ulen / 8u + 16u;
+          H.blocks[j] = InflateBlock{(unsigned long long)(q.cpos - c0), (unsigned long long)(q.upos - G.u_lo), room, q.clen, q.ulen, cap, 0u};
+          H.want[j] = q.crc;
+          room += cap;
+        }
+      }
+      size_t at_comp, at_blocks, at_status, at_crc, at_matches;
+      slot_layout(G, &at_comp, &at_blocks, &at_status, &at_crc, &at_matches);
+      int32_t ust = copy_to_device_staged(ctx, slot + at_comp, comp_base + jobs[G.b_lo].cpos, G.comp, st.up);
+      hipError_t e = hipSuccess;
+      if (ust == MIDAS_SNPS_OK) {
+        e = hipMemcpyAsync(slot + at_blocks, H.blocks.data(), nj * sizeof(InflateBlock), hipMemcpyHostToDevice, st.up);
+        if (e == hipSuccess) e = hipMemcpyAsync(slot + at_crc, H.want.data(), nj * 4, hipMemcpyHostToDevice, st.up);
+        if (e == hipSuccess) e = hipMemsetAsync(slot + at_comp + G.comp, 0, 512, st.up);
+        if (e == hipSuccess) e = hipStreamSynchronize(st.up);
+        if (e == hipSuccess) {
+          hipStream_t q = st.inf[g & 1];
+          const InflateParams ip = inflate_params(G, slot);
+          e = launch_bgzf_inflate(ip, q);
+          if (e == hipSuccess) e = hipMemcpyAsync(st.status + status_at[g], ip.status, nj * 4, hipMemcpyDeviceToHost, q);
+          if (e == hipSuccess) e = hipEventRecord(st.ev[g], q);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); ust = e == hipErrorOutOfMemory ? MIDAS_SNPS_ERR_OUT_OF_MEMORY : MIDAS_SNPS_ERR_HIP; }
+      }
+      {
+        std::lock_guard<std::mutex> lk(pipe.m);
+        pipe.busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ust != MIDAS_SNPS_OK) { pipe.status = ust; pipe.hip = e; pipe.abort = true; }
+        else pipe.launched = (long long)g + 1;
+      }
+      pipe.cv.notify_all();
+      if (ust != MIDAS_SNPS_OK) return;
+    }
+  });
+  struct Join {       // (every way out: the uploader is told to stop and waited for, the streams' work too)
+    Pipe& pipe; std::thread& t; Streams& st;
+    ~Join() {
+      { std::lock_guard<std::mutex> lk(pipe.m); pipe.abort = true; }
+      pipe.cv.notify_all();
+      if (t.joinable()) t.join();
+      for (hipStream_t q : st.inf) if (q) (void)hipStreamSynchronize(q);
+      (void)hipGetLastError();
+    }
+  } join{pipe, uploader, st};
+
+  // ---- the result's arrays ----------------------------------------------------------------------------------------------------------
+  StreamColumns cols;
+  struct Pay { uint8_t* p = nullptr; size_t cap_units = 0; } pay;
+  struct Owned { StreamColumns& c; Pay& y; bool keep = false; ~Owned() { if (!keep) { if (c.p) (void)hipFree(c.p); if (y.p) (void)hipFree(y.p); } } } owned{cols, pay};
+  long long N = 0;                                  // records so far
+  long long base[4] = {0, 0, 0, 0};                 // what the offset columns came to so far: SEQ bytes, QUAL bytes, CIGAR ops, payload units
+  const double span_total = (double)(seg_stop > sg.from ? seg_stop - sg.from : 1);
+  auto grow_columns = [&](size_t need) -> int32_t {       // room for `need` records
+    if (cols.p && need <= cols.cap) return MIDAS_SNPS_OK;
+    StreamColumns nc;
+    nc.lay(need);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nc.p), nc.bytes);
+    if (e != hipSuccess) return hip_err(e, "the records' arrays");
+    if (cols.p) {
+      for (int k = 0; k < 11; ++k) {
+        const size_t n = (size_t)N + (k == 0 || k >= 7 ? 1 : 0);
+        e = hipMemcpyAsync(nc.p + nc.at[k], cols.p + cols.at[k], n * StreamColumns::width(k), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { (void)hipFree(nc.p); return hip_err(e, "the records' arrays moved"); }
+      }
+      e = hipStreamSynchronize(s);
+      (void)hipFree(cols.p);
+      if (e != hipSuccess) { (void)hipFree(nc.p); return hip_err(e, "the records' arrays moved"); }
+    }
+    cols = nc;
+    return MIDAS_SNPS_OK;
+  };
+  auto grow_payload = [&](size_t need_units) -> int32_t {
+    if (pay.p && need_units <= pay.cap_units) return MIDAS_SNPS_OK;
+    uint8_t* q = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), need_units * 8 + 64);
+    if (e != hipSuccess) return hip_err(e, "the reads' payload");
+    if (pay.p) {
+      e = base[3] > 0 ? hipMemcpyAsync(q, pay.p, (size_t)base[3] * 8, hipMemcpyDeviceToDevice, s) : hipSuccess;
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      (void)hipFree(pay.p);
+      if (e != hipSuccess) { (void)hipFree(q); return hip_err(e, "the reads' payload moved"); }
+    }
+    pay.p = q;
+    pay.cap_units = need_units;
+    return MIDAS_SNPS_OK;
+  };
+
+  // ---- group by group -----------------------------------------------------------------------------------------------------------------
+  sg.first = ~0ull; sg.n_records = 0; sg.n_unmapped = 0; sg.first_unmapped = ~0ull; sg.end = seg_stop;
+  unsigned long long cur = sg.exact ? sg.from : ~0ull;       // GLOBAL buffer offset of the next record (~0: group 0 guesses it)
+  int regrown = 0, rounds_total = 0;
+  const unsigned long long kChunk = 32768ull;
+  for (size_t g = 0; g < K; ++g) {
+    const Group& G = groups[g];
+    uint8_t* const slot = arena + (g % (size_t)n_slots) * slot_bytes;
+    const size_t nj = G.b_ext - G.b_lo;
+    size_t at_comp, at_blocks, at_status, at_crc, at_matches;
+    slot_layout(G, &at_comp, &at_blocks, &at_status, &at_crc, &at_matches);
+    lap(7);
+    {
+      std::unique_lock<std::mutex> lk(pipe.m);
+      pipe.cv.wait(lk, [&] { return pipe.abort || pipe.launched > (long long)g; });
+      if (pipe.launched <= (long long)g) {
+        if (pipe.hip != hipSuccess) return hip_err(pipe.hip, "a group's blocks to the device and its decoder's launch");
+        if (err256) snprintf(err256, 256, "device decode (streamed): blocks to the device: %s", ctx->error_text().c_str());
+        return pipe.status != MIDAS_SNPS_OK ? pipe.status : MIDAS_SNPS_ERR_HIP;
+      }
+    }
+    lap(0);
+    DS_TRY(hipEventSynchronize(st.ev[g]));        // the group is inflated, resolved, checked; its statuses are down
+    const InflateParams ip = inflate_params(G, slot);
+    const std::vector<InflateBlock>& blocks = host[g].blocks;
+    const std::vector<uint32_t>& want = host[g].want;
+    std::vector<uint32_t> status(st.status + status_at[g], st.status + status_at[g] + nj);
+    {
+      bool again = false;
+      const hipError_t ae = inflate_again(ip, blocks, want, status, s, &again);
+      if (ae != hipSuccess) return hip_err(ae, "streams decoded again");
+    }
+    for (size_t k = 0; k < nj; ++k) {
+      if (status[k] != 0u) {
+        *bad_job = (int64_t)(G.b_lo + k);
+        if (err256) snprintf(err256, 256, "corrupt BGZF block %lld (code %u)", (long long)(G.b_lo + k), status[k]);
+        return MIDAS_SNPS_ERR_BAD_LAYOUT;
+      }
+    }
+    lap(1);
+    // ---- the record walk of the group: chunks over [from, stop) in the slot's own offsets -----------------------------------------
+    const unsigned long long l_limit = G.infl;
+    const unsigned long long l_stop = G.stop > G.u_lo ? (unsigned long long)(G.stop - G.u_lo) : 0ull;
+    unsigned long long l_from;
+    bool exact;
+    if (cur != ~0ull) { exact = true; l_from = cur >= G.u_lo ? cur - G.u_lo : 0ull; }
+    else { exact = false; l_from = g == 0 && sg.from >= G.u_lo ? (unsigned long long)(sg.from - G.u_lo) : 0ull; }
+    if (cur != ~0ull && cur < G.u_lo) {        // (cannot be: the chain of the group before ended at or behind this group's first byte)
+      if (err256) snprintf(err256, 256, "device decode (streamed): the record chain fell behind group %zu", g);
+      return MIDAS_SNPS_ERR_UNSUPPORTED;
+    }
+    std::vector<unsigned long long> h_lo, h_hi, h_stop, h_limit, h_start;
+    std::vector<uint8_t> h_forced;
+    for (unsigned long long lo = l_from; lo < l_stop; lo += kChunk) {
+      h_lo.push_back(lo); h_hi.push_back(lo + kChunk < l_stop ? lo + kChunk : l_stop); h_stop.push_back(l_stop); h_limit.push_back(l_limit);
+      const bool first = lo == l_from;
+      h_forced.push_back(first && exact ? 1 : 0);
+      h_start.push_back(first && exact ? l_from : ~0ull);
+    }
+    const long long n_chunks = (long long)h_lo.size();
+    uint8_t* const scratch = slot + at_comp;
+    const size_t scratch_bytes = slot_bytes - at_comp;
+    size_t at = 0;
+    auto take = [&](size_t bytes) -> uint8_t* { uint8_t* q = scratch + at; at += up(bytes); return at <= scratch_bytes ? q : nullptr; };
+    const size_t nc1 = (size_t)(n_chunks > 0 ? n_chunks : 1);
+    BamWalkParams wp;
+    wp.d = slot; wp.n_ref = n_ref; wp.n_chunks = n_chunks;
+    long long* d_ref_lens = reinterpret_cast<long long*>(take((size_t)(n_ref > 0 ? n_ref : 1) * 8));
+    unsigned long long* d_lo = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    unsigned long long* d_hi = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    unsigned long long* d_stop = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    unsigned long long* d_limit = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    uint8_t* d_forced = take(nc1);
+    wp.start = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    wp.end = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    wp.kept = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+    wp.unmapped = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+    wp.first_unmapped = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    wp.bad = reinterpret_cast<uint32_t*>(take(nc1 * 4));
+    unsigned long long* d_base = reinterpret_cast<unsigned long long*>(take(nc1 * 8));
+    long long* d_list = reinterpret_cast<long long*>(take(4096 * 8));
+    if (!d_list) { if (err256) snprintf(err256, 256, "device decode (streamed): a slot is too small for the walk"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+    wp.lo = d_lo; wp.hi = d_hi; wp.stop = d_stop; wp.limit = d_limit; wp.forced = d_forced; wp.ref_lens = d_ref_lens;
+    if (n_ref > 0) DS_TRY(hipMemcpyAsync(d_ref_lens, ref_lens, (size_t)n_ref * 8, hipMemcpyHostToDevice, s));
+    std::vector<unsigned long long> h_end(nc1), h_base(nc1), h_fu(nc1);
+    std::vector<uint32_t> h_kept(nc1), h_bad(nc1), h_unm(nc1);
+    if (n_chunks > 0) {
+      DS_TRY(hipMemcpyAsync(d_lo, h_lo.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_hi, h_hi.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_stop, h_stop.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_limit, h_limit.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_forced, h_forced.data(), (size_t)n_chunks, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(launch_bam_walk(wp, nullptr, 0, s));
+      DS_TRY(hipMemcpyAsync(h_start.data(), wp.start, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(h_end.data(), wp.end, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(h_kept.data(), wp.kept, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(h_unm.data(), wp.unmapped, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(h_fu.data(), wp.first_unmapped, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(h_bad.data(), wp.bad, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipStreamSynchronize(s));
+    }
+    lap(2);
+    // stitch in order (device_decode_run's loop, one segment); a record that overruns the bytes the group keeps behind its end: not for
+    // this decode
+    unsigned long long lcur = exact ? l_from : ~0ull;
+    unsigned long long g_first = ~0ull;
+    long long g_records = 0;
+    for (size_t c = 0; c < (size_t)n_chunks;) {
+      if (lcur == ~0ull) {
+        if (h_start[c] == ~0ull) { h_kept[c] = 0u; h_unm[c] = 0u; ++c; continue; }
+        lcur = h_start[c];
+      }
+      if (lcur >= h_hi[c] || lcur + 4 > h_limit[c]) { h_kept[c] = 0u; h_unm[c] = 0u; h_start[c] = ~0ull; ++c; continue; }
+      if (h_start[c] == lcur) {
+        if (h_bad[c]) {
+          if (G.b_ext < j_hi) return kStreamFallback;       // (the group's own bytes end where the record goes on: the one-arena decode holds it whole)
+          *bad_record = -2;
+          return MIDAS_SNPS_ERR_BAD_LAYOUT;
+        }
+        if (g_first == ~0ull) g_first = lcur;
+        g_records += h_kept[c];
+        if (h_unm[c] && sg.first_unmapped == ~0ull) sg.first_unmapped = h_fu[c] + G.u_lo;
+        sg.n_unmapped += h_unm[c];
+        lcur = h_end[c];
+        ++c;
+        continue;
+      }
+      if (++rounds_total > 4096) {
+        if (err256) snprintf(err256, 256, "device decode: the record boundaries did not settle");
+        return MIDAS_SNPS_ERR_UNSUPPORTED;
+      }
+      const long long one = (long long)c;
+      DS_TRY(hipMemcpyAsync(wp.start + c, &lcur, 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_list, &one, 8, hipMemcpyHostToDevice, s));
+      DS_TRY(launch_bam_walk(wp, d_list, 1, s));
+      DS_TRY(hipMemcpyAsync(&h_end[c], wp.end + c, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&h_kept[c], wp.kept + c, 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&h_unm[c], wp.unmapped + c, 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&h_fu[c], wp.first_unmapped + c, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&h_bad[c], wp.bad + c, 4, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipStreamSynchronize(s));
+      h_start[c] = lcur;
+    }
+    if (lcur != ~0ull) {      // (else: a group that had to guess found no record boundary: the next one guesses too)
+      cur = lcur + G.u_lo;
+      sg.end = cur;
+    }
+    if (g_first != ~0ull && sg.first == ~0ull) sg.first = g_first + G.u_lo;
+    unsigned long long n_rec = 0;
+    for (long long c = 0; c < n_chunks; ++c) { h_base[(size_t)c] = n_rec; n_rec += h_kept[(size_t)c]; }
+    lap(3);
+    const long long n = (long long)n_rec;
+    if (n > 0) {
+      DS_TRY(hipMemcpyAsync(wp.start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(wp.kept, h_kept.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, s));
+      DS_TRY(hipMemcpyAsync(d_base, h_base.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+      // room in the result: from the records per inflated byte so far, + 3 %
+      if (!cols.p || (size_t)(N + n) > cols.cap) {
+        const double done = (double)(cur != ~0ull && cur > sg.from ? cur - sg.from : 1);
+        const double est = (double)(N + n) * std::max(1.0, span_total / done) * 1.03 + 4096.0;
+        if (cols.p) ++regrown;
+        const int32_t gst = grow_columns(std::max((size_t)(N + n), (size_t)est));
+        if (gst != MIDAS_SNPS_OK) return gst;
+        lap(6);
+      }
+      const size_t n1 = (size_t)n + 1;
+      unsigned long long* d_rec = reinterpret_cast<unsigned long long*>(take(n1 * 8));
+      unsigned long long* d_badrec = reinterpret_cast<unsigned long long*>(take(8));
+      long long* d_scan = reinterpret_cast<long long*>(take(bam_scan_scratch_bytes(n)));
+      if (!d_scan) { if (err256) snprintf(err256, 256, "device decode (streamed): a slot is too small for the record offsets"); return MIDAS_SNPS_ERR_OUT_OF_MEMORY; }
+      BamColumnsParams cp;
+      cp.d = slot; cp.rec_off = d_rec; cp.n = n; cp.n_ref = n_ref;
+      cp.refid = reinterpret_cast<int32_t*>(cols.colp(1)) + N; cp.pos = reinterpret_cast<int32_t*>(cols.colp(2)) + N; cp.nm = reinterpret_cast<int32_t*>(cols.colp(3)) + N; cp.l_seq = reinterpret_cast<int32_t*>(cols.colp(4)) + N;
+      cp.mapq = reinterpret_cast<uint8_t*>(cols.colp(5)) + N; cp.flag = reinterpret_cast<uint16_t*>(cols.colp(6)) + N;
+      cp.seq_off = reinterpret_cast<long long*>(cols.colp(7)) + N; cp.qual_off = reinterpret_cast<long long*>(cols.colp(8)) + N; cp.cigar_off = reinterpret_cast<long long*>(cols.colp(9)) + N;
+      cp.unit_off = reinterpret_cast<long long*>(cols.colp(10)) + N;
+      cp.span = nullptr;
+      cp.bad_record = d_badrec;
+      for (int k = 0; k < 4; ++k) cp.base[k] = base[k];
+      DS_TRY(hipMemsetAsync(cp.bad_record, 0xFF, 8, s));
+      DS_TRY(launch_bam_offsets(wp, d_base, d_rec, s));
+      DS_TRY(launch_bam_columns(cp, d_scan, s));
+      unsigned long long h_bad_record = ~0ull;
+      long long ends[4] = {0, 0, 0, 0};
+      DS_TRY(hipMemcpyAsync(&h_bad_record, cp.bad_record, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&ends[0], cp.seq_off + n, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&ends[1], cp.qual_off + n, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&ends[2], cp.cigar_off + n, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipMemcpyAsync(&ends[3], cp.unit_off + n, 8, hipMemcpyDeviceToHost, s));
+      DS_TRY(hipStreamSynchronize(s));
+      lap(4);
+      if (h_bad_record != ~0ull) { *bad_record = (int64_t)h_bad_record + N; return MIDAS_SNPS_ERR_BAD_LAYOUT; }
+      if ((unsigned long long)ends[3] > kMaxDirectPayloadUnits) {
+        if (err256) snprintf(err256, 256, "device decode: %llu bytes of read payload exceed the 32 GiB the direct layout addresses", (unsigned long long)ends[3] * 8ull);
+        return MIDAS_SNPS_ERR_UNSUPPORTED;
+      }
+      if (!pay.p || (size_t)ends[3] > pay.cap_units) {
+        const double done = (double)(cur != ~0ull && cur > sg.from ? cur - sg.from : 1);
+        const double est = (double)ends[3] * std::max(1.0, span_total / done) * 1.03 + 65536.0;
+        if (pay.p) ++regrown;
+        const int32_t gst = grow_payload(std::max((size_t)ends[3], (size_t)std::min(est, (double)kMaxDirectPayloadUnits)));
+        if (gst != MIDAS_SNPS_OK) return gst;
+        lap(6);
+      }
+      BamDirectParams dp;
+      dp.stream = slot; dp.rec_off = d_rec; dp.n_records = n;
+      dp.pos = cp.pos; dp.nm = cp.nm; dp.unit_off = cp.unit_off;
+      dp.rec = reinterpret_cast<DirectRec*>(cols.colp(0)) + N; dp.payload = pay.p;
+      DS_TRY(launch_bam_direct(dp, ctx->prop.multiProcessorCount, s));
+      DS_TRY(hipStreamSynchronize(s));
+      lap(5);
+      N += n;
+      for (int k = 0; k < 4; ++k) base[k] = ends[k];
+    }
+    {
+      std::lock_guard<std::mutex> lk(pipe.m);
+      pipe.decoded = (long long)g + 1;
+    }
+    pipe.cv.notify_all();
+    if (cur != ~0ull && cur >= seg_stop) break;       // (the wanted records end here: nothing of the groups behind is needed)
+  }
+  sg.n_records = N;
+  if (N == 0) {        // (no record at all: the caller's columns are empty; nothing stays on the device)
+    const HostColumns hc = alloc(sink, 0);
+    (void)hc;
+    res->n_records = 0; res->seq_bytes = 0; res->qual_bytes = 0; res->n_cigar = 0;
+    const int32_t g0 = grow_columns(1);
+    if (g0 != MIDAS_SNPS_OK) return g0;
+    const int32_t g1 = grow_payload(8);
+    if (g1 != MIDAS_SNPS_OK) return g1;
+    DS_TRY(hipMemsetAsync(cols.p, 0, cols.bytes, s));
+  }
+  DS_TRY(hipMemsetAsync(pay.p + (size_t)base[3] * 8, 0, 64, s));      // (a lane's 16-byte loads may overhang the last read)
+  {       // the uploader has nothing left to do: the ring is the copy-down's again
+    { std::lock_guard<std::mutex> lk(pipe.m); pipe.abort = true; }
+    pipe.cv.notify_all();
+    if (uploader.joinable()) uploader.join();
+    for (hipStream_t q : st.inf) DS_TRY(hipStreamSynchronize(q));
+  }
+  if (N > 0) {
+    const HostColumns hc = alloc(sink, N);
+    if (!hc.refid) { DS_TRY(hipStreamSynchronize(s)); return MIDAS_SNPS_OK; }
+    const int32_t dst = copy_to_host(ctx, hc.refid, reinterpret_cast<int32_t*>(cols.colp(1)), (size_t)N * 4);
+    if (dst != MIDAS_SNPS_OK) { if (err256) snprintf(err256, 256, "device decode: columns to host: %s", ctx->error_text().c_str()); return dst; }
+  }
+  DS_TRY(hipStreamSynchronize(s));
+  if (trace) {
+    const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    fprintf(stderr, "[device decode] streamed: %lld records in %.1f ms: waited for a group's launch %.1f (the uploader worked %.1f), for its decoder %.1f, walk %.1f, stitch %.1f, "
+                    "columns %.1f, direct layout %.1f, result grown %.1f (%d times), tables %.1f ms; %d chunk(s) walked again; result %.2f GB\n",
+            N, total_ms, laps[0], pipe.busy_ms, laps[1], laps[2], laps[3], laps[4], laps[5], laps[6], regrown, laps[7], rounds_total,
+            (double)(cols.bytes + pay.cap_units * 8) / 1e9);
+  }
+  res->n_records = N; res->seq_bytes = base[0]; res->qual_bytes = base[1]; res->n_cigar = base[2];
+  ResidentReads& rr = res->resident;
+  rr.rec = reinterpret_cast<DirectRec*>(cols.colp(0)); rr.payload = pay.p; rr.refid = reinterpret_cast<int32_t*>(cols.colp(1)); rr.pos = reinterpret_cast<int32_t*>(cols.colp(2)); rr.nm = reinterpret_cast<int32_t*>(cols.colp(3));
+  rr.l_seq = reinterpret_cast<int32_t*>(cols.colp(4)); rr.mapq = reinterpret_cast<uint8_t*>(cols.colp(5)); rr.flag = reinterpret_cast<uint16_t*>(cols.colp(6));
+  rr.seq_off = reinterpret_cast<int64_t*>(cols.colp(7)); rr.qual_off = reinterpret_cast<int64_t*>(cols.colp(8)); rr.cigar_off = reinterpret_cast<int64_t*>(cols.colp(9)); rr.unit_off = reinterpret_cast<int64_t*>(cols.colp(10));
+  rr.stream = nullptr; rr.rec_off = nullptr;       // (no inflated stream is kept: raw columns come out of the direct layout)
+  rr.payload_units = base[3];
+  res->dev_owner = new TwoBuffers{cols.p, pay.p};
+  res->dev_free = two_buffers_free;
+  owned.keep = true;
+#undef DS_TRY
+  return MIDAS_SNPS_OK;
+}
+
 // DeviceDecoder::run (hostio.h): BGZF blocks of a BAM -- the whole file's, a rank's slice, or the runs that hold a rank's contigs --
 // decoded on the device: up, inflated, resolved and CRC-checked (bgzf_inflate.hip), records found and decoded (bam_walk.hip), SEQ /
 // QUAL / CIGAR cut out where the stream lies; the small columns are all that comes down.
@@ -849,6 +1422,32 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   DEC_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // ---- a resident decode of ONE run of blocks that fills the device several times over: group by group (device_decode_stream) ----
+  if (payload == 2 && !extra && n_segs == 1 && segs[0].job_lo < segs[0].job_hi && segs[0].job_hi <= n_jobs) {
+    const size_t nb = segs[0].job_hi - segs[0].job_lo;
+    size_t group = 0;
+    int slots = 3;
+    const char* on = getenv("MIDAS_SNPS_DECODE_STREAM");
+    if (!on || atoi(on) != 0) {
+      // (half a device-fill of the decoder's workgroups a group: two groups' kernels run side by side, on alternating streams)
+      group = (size_t)std::max(64ll, bgzf_inflate_wave_blocks(ctx->prop.multiProcessorCount) / 2);
+      if (const char* e = getenv("MIDAS_SNPS_DECODE_GROUP_BLOCKS")) group = (size_t)std::max(1ll, atoll(e));
+      if (const char* e = getenv("MIDAS_SNPS_DECODE_SLOT_MB")) {        // a slot is ~2.5 x its blocks' inflated bytes (<= 64 KiB each)
+        const size_t cap_blocks = (size_t)std::max(16ll, atoll(e) * (1ll << 20) / (160ll << 10));
+        group = std::min(group, cap_blocks);
+      }
+      if (const char* e = getenv("MIDAS_SNPS_DECODE_SLOTS")) slots = std::max(1, std::min(4, atoi(e)));
+    }
+    if (group && nb > group + group / 4) {
+      const size_t K = (nb + group - 1) / group;
+      group = (nb + K - 1) / K;        // (equal groups, none above a wave)
+      const int32_t sst = device_decode_stream(ctx, comp_base, jobs, segs[0], group, slots, ref_lens, n_ref, alloc, sink, res, bad_job, bad_record, err256);
+      if (sst != kStreamFallback) return sst;
+      if (trace) fprintf(stderr, "[device decode] streamed decode gave up (a record longer than what a group keeps behind its end): one arena\n");
+      *bad_job = -1;
+      *bad_record = -1;
+    }
+  }
   // ---- the compressed bytes: every segment's blocks are consecutive in the file, the segments go up back to back ----------
   std::vector<size_t> seg_at(n_segs + 1, 0);      // where segment k's bytes start in the device's copy
   for (size_t k = 0; k < n_segs; ++k) {
@@ -931,41 +1530,10 @@ int32_t device_decode_run(void* user, const uint8_t* comp_base, const InflateJob
   DEC_TRY(hipStreamSynchronize(s));
   lap("blocks up, inflate, resolve, crc");
   {   // the streams whose matches did not fit: again, with the bound's room
-    std::vector<size_t> again;
-    for (size_t k = 0; k < n_jobs; ++k)
-      if (status[k] == kInflateMatchRoom) again.push_back(k);
-    if (!again.empty()) {
-      std::vector<InflateBlock> b2(again.size());
-      std::vector<uint32_t> want2(again.size());
-      unsigned long long room2 = 0;
-      for (size_t j = 0; j < again.size(); ++j) {
-        const InflateBlock& q = blocks[again[j]];
-        const uint32_t cap = q.ulen / 3u + 1u;
-        b2[j] = InflateBlock{q.cpos, q.upos, room2, q.clen, q.ulen, cap, 0u};
-        want2[j] = want[again[j]];
-        room2 += cap;
-      }
-      struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_b2, d_s2, d_m2, d_c2;
-      DEC_TRY(hipMalloc(&d_b2.p, b2.size() * sizeof(InflateBlock)));
-      DEC_TRY(hipMalloc(&d_s2.p, b2.size() * 8));
-      DEC_TRY(hipMalloc(&d_m2.p, (size_t)room2 * 8));
-      DEC_TRY(hipMalloc(&d_c2.p, b2.size() * 4));
-      DEC_TRY(hipMemcpyAsync(d_b2.p, b2.data(), b2.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
-      DEC_TRY(hipMemcpyAsync(d_c2.p, want2.data(), b2.size() * 4, hipMemcpyHostToDevice, s));
-      InflateParams ip2 = ip;
-      ip2.blocks = static_cast<const InflateBlock*>(d_b2.p);
-      ip2.n_blocks = (long long)b2.size();
-      ip2.status = static_cast<uint32_t*>(d_s2.p);
-      ip2.n_matches = static_cast<uint32_t*>(d_s2.p) + b2.size();
-      ip2.matches = static_cast<unsigned long long*>(d_m2.p);
-      ip2.want_crc = static_cast<const uint32_t*>(d_c2.p);
-      DEC_TRY(launch_bgzf_inflate(ip2, s));
-      std::vector<uint32_t> st2(b2.size());
-      DEC_TRY(hipMemcpyAsync(st2.data(), d_s2.p, b2.size() * 4, hipMemcpyDeviceToHost, s));
-      DEC_TRY(hipStreamSynchronize(s));
-      for (size_t j = 0; j < again.size(); ++j) status[again[j]] = st2[j];
-      lap("streams decoded again");
-    }
+    bool again = false;
+    const hipError_t ae = inflate_again(ip, blocks, want, status, s, &again);
+    if (ae != hipSuccess) return hip_err(ae, "streams decoded again");
+    if (again) lap("streams decoded again");
   }
   for (size_t k = 0; k < n_jobs; ++k) {
     if (status[k] != 0u) {
@@ -1274,6 +1842,7 @@ int32_t midas_bam_resident_to_columns(midas_bam* bam, midas_snps_ctx* ctx, int64
   PayloadParams pp;
   pp.stream = rr->stream;
   pp.rec_off = reinterpret_cast<const unsigned long long*>(rr->rec_off);
+  if (!rr->stream) { pp.stream = rr->payload; pp.drec = static_cast<const DirectRec*>(rr->rec); }      // (a streamed decode: out of the direct layout)
   pp.n_records = n;
   pp.seq_off = reinterpret_cast<const long long*>(rr->seq_off); pp.qual_off = reinterpret_cast<const long long*>(rr->qual_off);
   pp.cigar_off = reinterpret_cast<const long long*>(rr->cigar_off);
@@ -1543,10 +2112,14 @@ int32_t ensure_raw_payload(midas_snps_batch* b) {
   PayloadParams pp;
   pp.stream = b->rr.stream;
   pp.rec_off = reinterpret_cast<const unsigned long long*>(b->rr.rec_off) + b->rr_first;
+  if (!b->rr.stream) { pp.stream = b->rr.payload; pp.rec_off = nullptr; pp.drec = b->d_drec; }      // (a streamed decode: out of the direct layout)
   pp.n_records = b->n_reads;
   pp.seq_off = reinterpret_cast<const long long*>(b->d_seq_off); pp.qual_off = reinterpret_cast<const long long*>(b->d_qual_off);
   pp.cigar_off = reinterpret_cast<const long long*>(b->d_cigar_off);
   pp.seq4 = b->d_seq4; pp.qual = b->d_qual; pp.cigar = b->d_cigar;
+  if (getenv("MIDAS_SNPS_TRACE"))
+    fprintf(stderr, "[batch] raw columns cut out of %s: %lld reads, %zu + %zu + %zu bytes\n", pp.drec ? "the direct layout" : "the handle's inflated stream",
+            (long long)b->n_reads, sb, qb, cb);
   HIP_TRY(ctx, launch_bam_payload(pp, ctx->prop.multiProcessorCount, s));
   return MIDAS_SNPS_OK;
 }

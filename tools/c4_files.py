@@ -46,20 +46,20 @@ def main():
         contigs.n_species, contigs.n_contigs, contigs.n_sites, reads.n_reads, t1 - t0, time.time() - t1, os.path.getsize(bam) / 1e9,
         utility.cpu_budget()), flush=True)
     runs = []
-    for how in os.environ.get('C4_RUNS', 'auto,auto,auto,off').split(','):        # ('auto@8': the upload's pread by 8 threads)
+    for how in os.environ.get('C4_RUNS', 'auto,auto,auto,off').split(','):        # ('auto+KEY=VALUE': with that in the run's environment)
         shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)
         env = dict(os.environ, MIDAS_SNPS_TRACE='1')
-        if '@' in how:
-            env['MIDAS_SNPS_UPLOAD_THREADS'] = how.split('@')[1]
+        for kv in how.split('+')[1:]:       # ('auto+MIDAS_SNPS_DECODE_STREAM=0': the run's environment)
+            env[kv.split('=')[0]] = kv.split('=')[1]
         t = time.perf_counter()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how.split('@')[0]],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_midas.py'), 'snps', out, '--pileup', '-d', db, '--device_inflate', how.split('+')[0]],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         dt = time.perf_counter() - t
         if r.returncode != 0:
             print("run_midas.py failed:", r.stderr[-3000:])
             sys.exit(1)
         sz = sum(os.path.getsize(os.path.join(out, 'snps/output', f)) for f in os.listdir(os.path.join(out, 'snps/output')))
-        print("run_midas.py snps --pileup --device_inflate %-14s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
+        print("run_midas.py snps --pileup --device_inflate %-40s: %.2f s wall (process start to exit) -> %.3e sites/s end to end; %d tables, %.2f GB gz" % (
             how, dt, contigs.n_sites / dt, len(os.listdir(os.path.join(out, 'snps/output'))), sz / 1e9), flush=True)
         top = 0.0
         for line in r.stderr.splitlines():
