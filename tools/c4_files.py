@@ -48,6 +48,7 @@ def main():
     runs = []
     for how in os.environ.get('C4_RUNS', 'auto,auto,auto,off').split(','):        # ('auto+KEY=VALUE': with that in the run's environment)
         shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)
+        time.sleep(float(os.environ.get('C4_PAUSE', '0')))       # (the driver wipes what the run before released: an allocation that lands on it waits -- tools/alloc_probe.py)
         env = dict(os.environ, MIDAS_SNPS_TRACE='1')
         for kv in how.split('+')[1:]:       # ('auto+MIDAS_SNPS_DECODE_STREAM=0': the run's environment)
             env[kv.split('=')[0]] = kv.split('=')[1]
@@ -71,6 +72,17 @@ def main():
         runs.append(dt)
         if how.startswith('auto'):
             keep = {f: text_crc(os.path.join(out, 'snps/output', f)) for f in sorted(os.listdir(os.path.join(out, 'snps/output')))} if len(runs) == 1 else keep
+            if len(runs) > 1 and ('+' in how or os.environ.get('C4_VERIFY_ALL')):        # (a variant run: its text against the first run's, which is held to the oracle below)
+                t = time.perf_counter()
+                now = {f: text_crc(os.path.join(out, 'snps/output', f)) for f in sorted(os.listdir(os.path.join(out, 'snps/output')))}
+                summ = open(os.path.join(out, 'snps', 'summary.txt')).read()
+                print("    this run's %d tables: %s the first run's (CRC-32 + length of the decompressed rows, %.0f s); summary.txt %s" % (
+                    len(now), "the same text as" if now == keep else "DIFFERENT FROM", time.perf_counter() - t,
+                    "the same" if summ == first_summary else "DIFFERENT"), flush=True)
+                if now != keep or summ != first_summary:
+                    sys.exit(1)
+            elif len(runs) == 1:
+                first_summary = open(os.path.join(out, 'snps', 'summary.txt')).read()
     # ---- the oracle: counts by the C restatement (all cores), text by the host's row writer, CRC-32 of the text ----
     thr = abi.Thresholds.from_args(abi.DEFAULT_ARGS)
     t = time.perf_counter()
