@@ -889,8 +889,11 @@ def pysam_pileup(args, species, contigs, make_context=_device_context):
 def _inflate_on_device(args, ctx, bampath, ws):
     """args['device_inflate']: 'on' / True, 'off' / False, or 'auto' (the default) -- on where the measurements of DESIGN.md
     3.4 have the device ahead and its one-call arena (about eight times the compressed bytes) fits beside everything else:
-      * one rank and a BAM of at least 0.5 GB whose decode + batch fit the device's memory (configs[2]: stage 0.21-0.23 s
-        against 0.83-0.91 s with the host's threads inflating; smaller files: the host's threads are as fast);
+      * one rank and a BAM of at least 0.5 GB whose decode + batch fit the device's memory (configs[2]: stage 0.17-0.18 s
+        against 0.83-0.91 s with the host's threads inflating; smaller files: the host's threads are as fast).  A file of
+        several device-fills of blocks is decoded group by group (snps_abi.hip device_decode_stream: ~2 x the compressed bytes
+        of slots + the resident records, ~3 x): the rule below is the one-arena decode's, which a record longer than a
+        group's tail, or a payload beyond the direct layout's 32 GiB, still falls back to;
       * a rank with few CPUs -- eight ranks share a node's cores under torchrun -- and a share of the BAM of 32 MB-8 GB (a
         1.26 GB BAM with the 2 CPUs of an 8-rank node's rank: decode 0.87 s against 3.0 s)."""
     want = args.get('device_inflate', 'auto')

@@ -39,7 +39,7 @@ def main():
     ctx = abi.Context(0)
     t_end = time.time() + budget
     n = bad = 0
-    tally = {'rows': 0, 'pieces': 0, 'inflate': 0, 'resident': 0}
+    tally = {'rows': 0, 'pieces': 0, 'inflate': 0, 'resident': 0, 'streamed': 0}
     while time.time() < t_end:
         read_len = int(rng.choice([36, 75, 100, 125, 150, 151, 250]))
         big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # > 1024 tiles: the dynamic work-item path
@@ -150,7 +150,24 @@ def main():
                 path = td + "/s.bam"
                 refid = np.repeat(np.arange(contigs.n_contigs, dtype=np.int32), np.diff(contigs.read_begin))
                 abi.write_bam(path, contigs.ids, [int(x) for x in contigs.length], refid, reads, level=int(rng.choice([1, 6])))
-                _, _, rid, res = abi.read_bam(path, ctx, resident=True)
+                # ... half of them through the STREAMED decode (groups of a few blocks, one to three slots: records straddle every
+                # group's end, the raw columns of the packed / long path are cut out of the direct layout)
+                streamed = rng.random() < 0.5
+                if streamed:
+                    os.environ["MIDAS_SNPS_DECODE_GROUP_BLOCKS"] = str(max(int(rng.integers(1, 40)), os.path.getsize(path) // (20000 * 24)))     # (<= ~30 groups: a group's decoder takes 25 ms however small)
+                    os.environ["MIDAS_SNPS_DECODE_SLOTS"] = str(int(rng.integers(1, 4)))
+                    tally['streamed'] += 1
+                else:
+                    os.environ["MIDAS_SNPS_DECODE_STREAM"] = "0"
+                try:
+                    _, _, rid, res = abi.read_bam(path, ctx, resident=True)
+                except abi.MidasSnpsError as e:
+                    print("DECODE FAILED", {k: os.environ.get(k) for k in ("MIDAS_SNPS_DECODE_GROUP_BLOCKS", "MIDAS_SNPS_DECODE_SLOTS", "MIDAS_SNPS_DECODE_STREAM")},
+                          os.path.getsize(path), e.message, flush=True)
+                    raise
+                finally:
+                    for k in ("MIDAS_SNPS_DECODE_GROUP_BLOCKS", "MIDAS_SNPS_DECODE_SLOTS", "MIDAS_SNPS_DECODE_STREAM"):
+                        os.environ.pop(k, None)
                 rb = ctx.batch(contigs, res)
                 for pth in (None, abi.PATH_PACKED if rng.random() < 0.5 else abi.PATH_LONG):
                     try:
