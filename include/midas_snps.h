@@ -429,11 +429,18 @@ int32_t midas_bam_load_ranges_device(midas_bam* bam, midas_snps_ctx* ctx, int32_
  *                                      batch's facts pass validates them as it validates a caller's arrays.  The batch borrows the
  *                                      handle's device memory: midas_bam_close comes AFTER midas_snps_batch_destroy.  The packed and the
  *                                      long path (unsorted positions, coverage hot spots, reads beyond the fast paths' limits) cut
- *                                      their three payload columns out of the handle's inflated stream when first asked for.
+ *                                      their three payload columns out of the handle's inflated stream (or, after a streamed
+ *                                      decode, out of the direct layout) when first asked for.
  *   midas_bam_resident_to_columns    the fall-back for a host that must regroup or slice the records (contigs it does not
  *                                      want among them, pieces of long contigs): the small columns come down, SEQ / QUAL /
  *                                      CIGAR are cut into device columns -- the handle then answers as after midas_bam_load_device
  *                                      (and stays resident as well).
+ * A resident decode of ONE run of blocks that fills the device's decoder several times over (> ~51 000 BGZF blocks on MI355X: a BAM
+ * of more than ~1.3 GB) is STREAMED: groups of blocks go up on a thread of their own while the groups before them are inflated,
+ * walked and written behind one another into the resident layout; device memory is a few slots of ~2.5 x a group's inflated bytes
+ * + the result instead of ~2.3 x the file's inflated bytes, and no inflated stream is kept.  Same records, same statuses (a corrupt
+ * block is named by its index in the file).  Environment (read at every call): MIDAS_SNPS_DECODE_STREAM=0 switches it off,
+ * MIDAS_SNPS_DECODE_GROUP_BLOCKS / _SLOTS (1-4) / _SLOT_MB size the groups, their number in flight and a slot's cap.
  * MIDAS_SNPS_ERR_UNSUPPORTED: more than 32 GiB of read payload in one decode (the record's offset is 32 bits of 8-byte units):
  * decode with midas_bam_load_device instead.                                                                                    */
 int32_t midas_bam_load_resident(const char* path, midas_snps_ctx* ctx, midas_bam** out, int64_t* n_reads, int64_t* sum_l_seq, char* err256);

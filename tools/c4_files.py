@@ -45,6 +45,10 @@ def main():
     print("sample: %d species, %d contigs, %d sites, %d reads; generated in %.0f s, written in %.0f s; BAM %.2f GB; host CPUs %d" % (
         contigs.n_species, contigs.n_contigs, contigs.n_sites, reads.n_reads, t1 - t0, time.time() - t1, os.path.getsize(bam) / 1e9,
         utility.cpu_budget()), flush=True)
+    if os.environ.get('C4_PRELUDE', '1') != '0':
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import vram_prelude
+        vram_prelude.run()
     runs = []
     for how in os.environ.get('C4_RUNS', 'auto,auto,auto,off').split(','):        # ('auto+KEY=VALUE': with that in the run's environment)
         shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)

@@ -18,6 +18,9 @@ contigs, reads = synth.make_dataset(**synth.CONFIGS[cfg])
 out, db = os.path.join(work, 'sample'), os.path.join(work, 'db')
 synth.write_sample(out, db, contigs, reads)
 print("sample: %d sites, %d reads, BAM %.0f MB" % (contigs.n_sites, reads.n_reads, os.path.getsize(os.path.join(out, 'snps/temp/genomes.bam')) / 1e6), flush=True)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import vram_prelude  # noqa: E402
+vram_prelude.run()
 for how in ('auto', 'off', 'auto', 'off'):
     shutil.rmtree(os.path.join(out, 'snps', 'output'), ignore_errors=True)
     t = time.perf_counter()

@@ -104,6 +104,9 @@ def main():
     synth.write_sample(out, db, contigs, reads)
     print("sample %s: %d species, %d sites, %d reads, BAM %.2f GB" % (cfg, contigs.n_species, contigs.n_sites, reads.n_reads,
                                                                    os.path.getsize(os.path.join(out, 'snps/temp/genomes.bam')) / 1e9), flush=True)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import vram_prelude
+    vram_prelude.run()
     script = os.path.join(work, 'worker.py')
     open(script, 'w').write(WORKER % {"root": os.path.abspath(ROOT)})
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
