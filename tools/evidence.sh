@@ -9,6 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 EV=$REPO/gpurun_out/evidence
 mkdir -p $EV
 cd $REPO
+timeout 300 python tools/vram_prelude.py > $EV/vram_prelude.log 2>&1      # (a fresh box clears never-used VRAM at first allocation: not what the files below are about)
 timeout 2400 python -m pytest tests -m gpu -x -q > $EV/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $EV/pytest_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $EV/smoke.log 2>&1
 timeout 1200 python bench.py --steps 20 --warmup 5 > $EV/bench_n1_c3.json 2> $EV/bench_n1_c3.err
