@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MIDAS_SNPS_ABI_VERSION 3
+#define MIDAS_SNPS_ABI_VERSION 4      /* 4: midas_snps_batch_info grew by direct_chunk_tiles, direct_overhang */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -301,6 +301,10 @@ typedef struct midas_snps_batch_info {
   int64_t direct_reach;           /* longest reference span of a read: how far back a tile's read range reaches */
   int64_t direct_stream_reads;    /* sum over tiles of the reads their streams hold: n_reads + straddlers when sorted */
   int64_t direct_max_tile_reads;
+  int32_t direct_chunk_tiles;     /* the direct path's work items: chunks of this many consecutive tiles, a read visited once per chunk and a
+                                     tile's overhang carried on (4), or 1: every tile by itself (unsorted positions, reads longer than the
+                                     longest overhang, more outlier reads than their list holds)                                              */
+  int32_t direct_overhang;        /* sites behind a tile's last that its tallies hold: 160, or 288 for a batch whose longest read asks for it */
 } midas_snps_batch_info;
 int32_t midas_snps_batch_get_info(const midas_snps_batch* batch, midas_snps_batch_info* out);
 /* Device-side durations from HIP events recorded on the run's stream.  enable_timing(batch, n_slots)

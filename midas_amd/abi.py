@@ -15,7 +15,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STAT_ALIGNED_READS, STAT_MAPPED_READS, STAT_COVERED_BASES, STAT_TOTAL_DEPTH = range(4)
 NUM_STATS = 4
@@ -86,7 +86,8 @@ class BatchInfo(C.Structure):
                 ("tile_sites", C.c_int32), ("lanes_per_read", C.c_int32), ("n_work_items", C.c_int64),
                 ("path", C.c_int32), ("path_auto", C.c_int32), ("lane_bases", C.c_int32), ("layout_build_us", C.c_int32),
                 ("direct_general_reads", C.c_int64), ("direct_reach", C.c_int64),
-                ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64)]
+                ("direct_stream_reads", C.c_int64), ("direct_max_tile_reads", C.c_int64),
+                ("direct_chunk_tiles", C.c_int32), ("direct_overhang", C.c_int32)]
 
 
 ROWS_DEVICE, ROWS_HOST = 0, 1    # who formats and deflates a batch's rows (midas_snps_set_row_coder)

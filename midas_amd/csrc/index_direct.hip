@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
     });
     span = span > 0x3FFFFFFFull ? 0x3FFFFFFFull : span;
     maxspan = (uint32_t)span > maxspan ? (uint32_t)span : maxspan;
-    if (span > (unsigned long long)kDirectOverhang) {
+    if (span > (unsigned long long)p.overhang) {
       // an outlier (a long deletion, an N skip): listed with the tiles behind its own that it reaches, so that the ranges pass
       // can keep to the common span; where it leaves its tile's overhang -- or reaches into tiles beyond the next -- the chunks
       // of those tiles are dealt tile by tile (tile_flag)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kIdxBlock) void direct_facts_kernel(DirectIndexPara
           if (slot < p.outlier_cap) p.outliers[slot] = DirectOutlier{(uint32_t)i, ka + 1u, kb, 0u};
         }
         const long long tile_start = (pc >> p.tile_shift) << p.tile_shift;
-        if (e - tile_start >= (long long)(1 << p.tile_shift) + kDirectOverhang)
+        if (e - tile_start >= (long long)(1 << p.tile_shift) + p.overhang)
           for (uint32_t t = ka; t <= kb; ++t) p.tile_flag[t] = 1;
       }
     } else {

@@ -177,6 +177,9 @@ constexpr int kDirectChunkTiles = MIDAS_DIRECT_CHUNK;
 #endif
 constexpr int kDirectTailDiv = MIDAS_DIRECT_TAIL_DIV;      // the last 1 / kDirectTailDiv of the tiles are dealt one by one
 constexpr int kDirectOverhang = 160;
+// ... and for batches whose reads are longer than that (250 bp reads): a second instantiation of the kernel with this overhang --
+// 2 KiB more LDS a workgroup, three workgroups a CU instead of four -- chosen per batch from its longest read (DirectParams::overhang)
+constexpr int kDirectOverhangLong = 288;
 
 constexpr int kDirectFactSlots = 64;
 struct alignas(128) DirectFacts {                 // per-slot partial results of the facts pass (batch_create), added up by the host
@@ -211,6 +214,7 @@ struct DirectIndexParams {
   uint32_t* tbegin_next; uint32_t* tend_next;     // the other parity, reset here for the next run
   int32_t sorted;                                 // the facts pass found every contig's reads in position order
   int32_t reach;                                  // the longest reference span of the batch's reads: no read touches a site further from its start
+  int32_t overhang = kDirectOverhang;             // facts pass: a read that spans more is an outlier (the batch's: kDirectOverhang or kDirectOverhangLong)
   DirectFacts* facts;                             // [kDirectFactSlots] (facts pass only)
   DirectBlockCursor* block_contig;                // [direct_index_blocks(n_reads)] the contig of a workgroup's first read and that contig's
                                                   // row of the contig tables: found by the facts pass (one binary search per workgroup), ONE
@@ -250,6 +254,7 @@ struct DirectParams {
   int32_t baseq, mapq_min, readq;
   int32_t pad_advances;                           // the CIGAR op P advances the query position (MIDAS_SNPS_PAD_PYSAM)
   int32_t chunk_tiles, n_chunked_tiles;           // tiles [0, n_chunked_tiles) are dealt in chunks of chunk_tiles (1: every tile by itself)
+  int32_t overhang = kDirectOverhang;             // which instantiation: the sites behind a tile's last that the tallies hold
   const uint8_t* chunk_ok;                        // nullptr, or per chunk: 0 = its tiles are piled up one by one (an outlier read), no overhang carried
 };
 

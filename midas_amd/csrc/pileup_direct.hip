@@ -158,12 +158,12 @@ static_assert(kDirectBlock % 64 == 0 && kDirectBlock >= 128 && kDirectBlock <= 1
 constexpr int kDirectWavesPerSimd = (kWorkgroupsPerCU * kDirectBlock / 64 + 3) / 4;      // four workgroups per CU
 
 
-template <int LB, bool BQ0>
+template <int LB, bool BQ0, int OV = kDirectOverhang>
 __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_direct_kernel(DirectParams p) {
   constexpr int TILE = kTileSites;
   constexpr int NWAVES = kDirectBlock / 64;
   constexpr int OUT_IT = (TILE + kDirectBlock - 1) / kDirectBlock;
-  constexpr int OV = kDirectOverhang;       // sites behind the tile's last that the tallies also hold (see "chunks" below)
+  // OV: sites behind the tile's last that the tallies also hold (see "chunks" below); kDirectOverhangLong for batches of longer reads
   static_assert(OV <= TILE, "the overhang is moved by the write-out's first rounds");
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * (TILE + OV)];
   __shared__ __attribute__((aligned(16))) uint32_t s_khi[33 * 4];   // [h][w]: 0xF in the nibbles of the bases j <  h of a lane's four SEQ words
@@ -801,7 +801,15 @@ hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream
   const int n_items = k > 1 ? p.n_chunked_tiles / k + (p.n_tiles - p.n_chunked_tiles) : p.n_tiles;      // (every workgroup of the grid has work)
   const int grid = n_items < p.grid_blocks ? n_items : p.grid_blocks;
   const bool bq0 = p.baseq <= 0;
-  if (lane_bases == 32) {
+  if (p.overhang > kDirectOverhang) {      // (a batch of reads longer than the common overhang: the instantiation with the long one)
+    if (lane_bases == 32) {
+      if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true, kDirectOverhangLong>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+      else hipLaunchKernelGGL((pileup_direct_kernel<32, false, kDirectOverhangLong>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    } else {
+      if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<30, true, kDirectOverhangLong>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+      else hipLaunchKernelGGL((pileup_direct_kernel<30, false, kDirectOverhangLong>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
+    }
+  } else if (lane_bases == 32) {
     if (bq0) hipLaunchKernelGGL((pileup_direct_kernel<32, true>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
     else hipLaunchKernelGGL((pileup_direct_kernel<32, false>), dim3(grid), dim3(kDirectBlock), dyn_lds, stream, p);
   } else {

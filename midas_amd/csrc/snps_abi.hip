@@ -125,6 +125,7 @@ struct midas_snps_batch {
   uint32_t outlier_cap = 0, n_outliers_listed = 0;
   int64_t n_outliers = 0;
   int32_t direct_reach_ranges = 1;     // what the ranges pass reaches back over: the common span when the outliers are listed, else direct_reach
+  int32_t direct_overhang = kDirectOverhang;     // the batch's overhang: kDirectOverhangLong when its longest read asks for it (direct_prepare)
   bool direct_chunks = false;          // chunked tiles (position-sorted reads, outliers listed)
   unsigned long long* d_probe = nullptr;   // developer builds only (MIDAS_SNPS_DEBUG_BITS & 256)
   int64_t direct_general = 0;   // reads the pileup kernel walks op by op (facts pass)
@@ -2139,6 +2140,7 @@ void fill_direct_index(midas_snps_batch* b, DirectIndexParams* ip) {
   ip->tbegin_next = trange_begin(b, par ^ 1); ip->tend_next = trange_end(b, par ^ 1);
   ip->sorted = b->direct_sorted ? 1 : 0;
   ip->reach = b->direct_reach_ranges;
+  ip->overhang = b->direct_overhang;
   ip->outliers = b->d_outliers; ip->n_outliers_listed = b->d_n_outliers; ip->outlier_cap = b->outlier_cap;
   ip->tile_flag = b->d_tile_flag;
   ip->facts = b->d_dfacts;
@@ -2170,25 +2172,51 @@ int32_t direct_prepare(midas_snps_batch* b) {
   HIP_TRY(ctx, hipMemsetAsync(b->d_n_outliers, 0, 4, s));
   HIP_TRY(ctx, hipMemsetAsync(b->d_tile_flag, 0, nt, s));
   DirectIndexParams ip;
-  fill_direct_index(b, &ip);
   std::vector<DirectFacts> facts(kDirectFactSlots);
-  if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_facts(ip, s));
-  HIP_TRY(ctx, hipMemcpyAsync(facts.data(), b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipStreamSynchronize(s));
   unsigned long long status = kNoError, alg = 0, n_general = 0, n_long = 0, n_outliers = 0;
   uint32_t max_l = 0, max_span = 0, unsorted = 0, max_common = 0;
-  for (const DirectFacts& f : facts) {
-    n_outliers += f.n_outliers;
-    max_common = std::max(max_common, f.max_span_common);
-    status = std::min(status, f.status);
-    alg += f.alg_bytes;
-    n_general += f.n_general;
-    n_long += f.n_long;
-    max_l = std::max(max_l, f.max_l);
-    max_span = std::max(max_span, f.max_span);
-    unsorted |= f.unsorted;
+  auto facts_pass = [&]() -> int32_t {
+    fill_direct_index(b, &ip);
+    if (b->n_reads > 0) HIP_TRY(ctx, launch_direct_facts(ip, s));
+    HIP_TRY(ctx, hipMemcpyAsync(facts.data(), b->d_dfacts, sizeof(DirectFacts) * kDirectFactSlots, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    status = kNoError; alg = 0; n_general = 0; n_long = 0; n_outliers = 0;
+    max_l = 0; max_span = 0; unsorted = 0; max_common = 0;
+    for (const DirectFacts& f : facts) {
+      n_outliers += f.n_outliers;
+      max_common = std::max(max_common, f.max_span_common);
+      status = std::min(status, f.status);
+      alg += f.alg_bytes;
+      n_general += f.n_general;
+      n_long += f.n_long;
+      max_l = std::max(max_l, f.max_l);
+      max_span = std::max(max_span, f.max_span);
+      unsorted |= f.unsorted;
+    }
+    return MIDAS_SNPS_OK;
+  };
+  b->direct_overhang = kDirectOverhang;
+  {
+    const int32_t fst = facts_pass();
+    if (fst != MIDAS_SNPS_OK) return fst;
   }
   if (status != kNoError) return pack_status_to_error(ctx, status);
+  // Reads longer than the common overhang (250 bp reads), position-sorted: the batch takes the kernel's instantiation with the
+  // long overhang -- and which reads are OUTLIERS is a question of that overhang: the facts pass again (once per batch, a few ms).
+  static const int overhang_max = [] { const char* e = getenv("MIDAS_SNPS_OVERHANG_MAX"); return e ? atoi(e) : kDirectOverhangLong; }();
+  if (kDirectChunkTiles > 1 && unsorted == 0 && n_long == 0 && max_l > (uint32_t)kDirectOverhang && max_l <= (uint32_t)kDirectOverhangLong &&
+      overhang_max >= kDirectOverhangLong) {
+    b->direct_overhang = kDirectOverhangLong;
+    const size_t nt2 = (size_t)(b->n_tiles > 0 ? b->n_tiles : 1);
+    HIP_TRY(ctx, hipMemsetAsync(b->d_block_contig, 0, (size_t)direct_index_blocks(b->n_reads) * sizeof(DirectBlockCursor), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_dfacts, 0, sizeof(DirectFacts) * kDirectFactSlots, s));
+    for (int k = 0; k < kDirectFactSlots; ++k) HIP_TRY(ctx, hipMemsetAsync(&b->d_dfacts[k].status, 0xFF, 8, s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_n_outliers, 0, 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_tile_flag, 0, nt2, s));
+    const int32_t fst = facts_pass();
+    if (fst != MIDAS_SNPS_OK) return fst;
+    if (status != kNoError) return pack_status_to_error(ctx, status);
+  }
   b->max_l_seq = (int32_t)max_l;
   b->direct_sorted = unsorted == 0;
   b->direct_general = (int64_t)n_general;
@@ -2201,7 +2229,7 @@ int32_t direct_prepare(midas_snps_batch* b) {
   // chunks they touch are dealt tile by tile.  Too many of them for the list (reads longer than the overhang, say): as before
   // round 6 -- the full reach, no chunks.
   b->direct_chunks = false;
-  if (kDirectChunkTiles > 1 && unsorted == 0 && max_l <= (uint32_t)kDirectOverhang) {
+  if (kDirectChunkTiles > 1 && unsorted == 0 && max_l <= (uint32_t)b->direct_overhang) {
     uint32_t listed = 0;
     HIP_TRY(ctx, hipMemcpy(&listed, b->d_n_outliers, 4, hipMemcpyDeviceToHost));
     if (listed <= b->outlier_cap) {
@@ -2829,7 +2857,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.stats = work_stats(b); dp.err = work_err(b);
     dp.sched = b->d_ticket + b->n_tiles;
     dp.n_tiles = (int32_t)b->n_tiles; dp.n_reads = (int32_t)b->n_reads;
-    dp.grid_blocks = ctx->prop.multiProcessorCount * kWorkgroupsPerCU;
+    dp.overhang = b->direct_chunks ? b->direct_overhang : kDirectOverhang;      // (no chunks: nothing is carried, the common instantiation)
+    // (the long overhang's tallies are 2 KiB more LDS a workgroup: three of them fit a CU)
+    dp.grid_blocks = ctx->prop.multiProcessorCount * (dp.overhang > kDirectOverhang ? kWorkgroupsPerCU - 1 : kWorkgroupsPerCU);
 #ifdef MIDAS_SNPS_GRID_BLOCKS
     dp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
 #endif
@@ -3191,6 +3221,8 @@ int32_t midas_snps_batch_get_info(const midas_snps_batch* b, midas_snps_batch_in
   out->direct_reach = b->direct_reach;
   out->direct_stream_reads = b->direct_stream_reads;
   out->direct_max_tile_reads = b->direct_max_tile_reads;
+  out->direct_chunk_tiles = b->direct_chunks ? kDirectChunkTiles : 1;
+  out->direct_overhang = b->direct_chunks ? b->direct_overhang : kDirectOverhang;
   return MIDAS_SNPS_OK;
 }
 

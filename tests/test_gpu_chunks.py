@@ -79,7 +79,8 @@ def test_chunked_tiles_hand_their_overhang_over_exactly(hip_ctx, seed):
         assert st == 0, (st, er)
         b = hip_ctx.batch(table, soa)
         info = b.info()
-        assert info.path == abi.PATH_DIRECT and info.direct_reach <= 160 and info.n_tiles >= 80      # (the chunks are on)
+        assert info.path == abi.PATH_DIRECT and info.direct_reach <= 160 and info.n_tiles >= 80
+        assert info.direct_chunk_tiles == 4 and info.direct_overhang == 160                           # (the chunks are on)
         for _ in range(2):
             b.run(thr)
             counts, allele, stats = b.fetch()
@@ -142,6 +143,7 @@ def test_a_few_long_spans_do_not_switch_the_chunks_off(hip_ctx):
     b = hip_ctx.batch(table, soa)
     info = b.info()
     assert info.path == abi.PATH_DIRECT and info.direct_reach > 3 * TILE
+    assert info.direct_chunk_tiles == 4 and info.direct_overhang == 160          # (chunks on, the outliers listed)
     # the streams are those of the common span -- the reads plus the straddlers (half of these reads sit on tile borders) -- not
     # every read within 6 000 sites of a tile, which would be four tiles' worth per tile
     assert info.direct_stream_reads < 2.5 * info.n_reads, (info.direct_stream_reads, info.n_reads)
@@ -155,4 +157,105 @@ def test_a_few_long_spans_do_not_switch_the_chunks_off(hip_ctx):
     b.run(thr)
     c2, _, s2 = b.fetch()
     assert np.array_equal(c2, oc) and np.array_equal(s2, os_)
+    b.close()
+
+
+def _long_reads_for(rng, length, n, lens, max_span):
+    """as _reads_for, for reads of `lens` bases whose reference spans stay within max_span: dense on tile borders, deletions that
+    stretch a read to exactly max_span, insertions, clips, general CIGARs"""
+    out = []
+    borders = [b for b in range(TILE, length, TILE)]
+    for _ in range(n):
+        l = rng.choice(lens)
+        kind = rng.random()
+        if kind < 0.55:
+            cigar, span = [(0, l)], l
+        elif kind < 0.70:
+            a = rng.randint(1, l - 2)
+            d = rng.randint(1, max_span - l) if l < max_span - 1 else 1
+            cigar, span = [(0, a), (2, d), (0, l - a)], l + d
+        elif kind < 0.80:
+            a, i = rng.randint(1, l - 10), rng.randint(1, 5)
+            cigar, span = [(0, a), (1, i), (0, l - a - i)], l - i
+        elif kind < 0.92:
+            s_, t = rng.randint(0, min(20, (l - 6) // 2)), rng.randint(0, min(20, (l - 6) // 2))
+            m = l - s_ - t
+            cigar = ([(4, s_)] if s_ else []) + [(0, m)] + ([(4, t)] if t else [])
+            span = m
+        else:
+            a = rng.randint(5, l - 30)
+            cigar, span = [(0, a), (3, 7), (7, 10), (8, 2), (0, l - a - 12)], l + 7
+        if borders and rng.random() < 0.5:
+            b = rng.choice(borders)
+            pos = b - rng.randint(0, span + 3) + rng.choice([0, 0, 1, -1, 2])
+        else:
+            pos = rng.randint(-3, length - 1)
+        pos = max(-2, min(length - 1, pos))
+        out.append(dict(pos=pos, cigar=cigar, seq="".join(rng.choice("ACGTACGTACGTN") for _ in range(l)),
+                        qual=[rng.choice([40, 38, 31, 30, 29, 12]) for _ in range(l)], nm=rng.choice([0, 1, 2, 3]),
+                        mapq=rng.choice([42, 42, 30, 19])))
+    out.sort(key=lambda r: r["pos"])
+    return out
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_250_bp_reads_are_chunked_with_the_long_overhang(hip_ctx, seed):
+    """Reads longer than the common overhang of 160 sites (2 x 250 MiSeq): the batch takes the kernel's instantiation whose tallies
+    hold 288 sites behind a tile (three workgroups a CU), chunks stay on -- batch_get_info says so -- and the table is the
+    oracle's: reads on every tile and chunk border, deletions that stretch a read to exactly 288 sites, one read with a 500 bp
+    deletion among them (an outlier: only the chunks it touches fall back), and 150 bp batches beside it keep the common overhang."""
+    rng = random.Random(seed)
+    lengths = [TILE * 4, TILE * 8 + 1, TILE * 3 - 1, TILE, 5, TILE + 288, TILE * 2, 700, TILE * 12, TILE * 5 + 289, TILE * 40]
+    rng.shuffle(lengths)
+    reads, begin, ref = [], [0], []
+    for n in lengths:
+        rs = _long_reads_for(rng, n, max(40, n // 20), [250, 250, 251, 200, 150, 36], 288) if n > 300 else []
+        if n >= TILE * 12:        # outliers: a 500 bp deletion, an N skip over two tiles
+            for gap, op in ((500, 2), (2 * TILE + 9, 3)):
+                a = rng.randint(10, 240)
+                rs.append(dict(pos=rng.choice([TILE * 3 - 100, TILE * 7 + 5]), cigar=[(0, a), (op, gap), (0, 250 - a)],
+                               seq="".join(rng.choice("ACGT") for _ in range(250)), qual=[40] * 250, nm=gap if op == 2 else 0, mapq=42))
+            rs.sort(key=lambda r: r["pos"])
+        reads += rs
+        begin.append(len(reads))
+        ref.append("".join(rng.choice("ACGTacgtN") for _ in range(n)))
+    soa = H.reads_from_dicts(reads)
+    table = abi.ContigTable(length=lengths, species=[k % 3 for k in range(len(lengths))], read_begin=begin,
+                            ref=np.frombuffer("".join(ref).encode(), np.uint8), n_species=3,
+                            ids=["c%d" % k for k in range(len(lengths))], species_ids=["s0", "s1", "s2"])
+    for args in (dict(abi.DEFAULT_ARGS, mapid=0.0), dict(abi.DEFAULT_ARGS, baseq=0, mapid=0.0, aln_cov=0.2, readq=0, mapq=0)):
+        thr = abi.Thresholds.from_args(args)
+        st, er, oc, oa, os_ = c_oracle.pileup(thr, table, soa)
+        assert st == 0, (st, er)
+        b = hip_ctx.batch(table, soa)
+        info = b.info()
+        assert info.path == abi.PATH_DIRECT and info.direct_chunk_tiles == 4 and info.direct_overhang == 288, (info.direct_chunk_tiles, info.direct_overhang)
+        assert info.direct_reach > 2 * TILE           # (the N skip: listed, not reached over by every tile)
+        for _ in range(2):
+            b.run(thr)
+            counts, allele, stats = b.fetch()
+            bad = np.nonzero((counts != oc).any(axis=1))[0]
+            assert bad.size == 0, "counts differ at %d sites, first %s" % (bad.size, bad[:8])
+            assert np.array_equal(allele, oa) and np.array_equal(stats, os_)
+        b.select_path(abi.PATH_PACKED)
+        b.run(thr)
+        c2, _, s2 = b.fetch()
+        assert np.array_equal(c2, oc) and np.array_equal(s2, os_)
+        b.close()
+    # reads of 300 bases: beyond the long overhang too -- no chunks, still the oracle's table
+    rng = random.Random(seed + 100)
+    n = TILE * 20
+    rs = _long_reads_for(rng, n, 2500, [300, 290, 150], 330)
+    soa = H.reads_from_dicts(rs)
+    table = abi.ContigTable(length=[n], species=[0], read_begin=[0, len(rs)], ref=np.frombuffer("".join(rng.choice("ACGT") for _ in range(n)).encode(), np.uint8),
+                            n_species=1, ids=["c0"], species_ids=["s0"])
+    thr = abi.Thresholds.from_args(dict(abi.DEFAULT_ARGS, mapid=0.0))
+    st, er, oc, oa, os_ = c_oracle.pileup(thr, table, soa)
+    assert st == 0
+    b = hip_ctx.batch(table, soa)
+    info = b.info()
+    assert info.direct_chunk_tiles == 1 and info.direct_overhang == 160
+    b.run(thr)
+    counts, allele, stats = b.fetch()
+    assert np.array_equal(counts, oc) and np.array_equal(allele, oa) and np.array_equal(stats, os_)
     b.close()
