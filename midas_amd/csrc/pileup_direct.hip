@@ -171,7 +171,11 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
   __shared__ uint32_t s_qsum[NWAVES * 64];                           // per wave and read slot: sum of a read's quality bytes
   __shared__ unsigned long long s_stats[MIDAS_STATS];
   __shared__ uint32_t s_next_ticket;
-  extern __shared__ __attribute__((aligned(16))) int32_t s_tables[];   // [min_match table_len][min_align table_len]
+  // [min_match table_len][min_align table_len]; 16-bit entries in the long-overhang instantiation (its reads are <= 288 bases, the
+  // thresholds at most that): the kilobyte this saves is what lets FOUR workgroups of it share a CU's 160 KiB
+  using table_t = typename std::conditional<(OV > kDirectOverhang), int16_t, int32_t>::type;
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_tables_raw[];
+  table_t* const s_tables = reinterpret_cast<table_t*>(s_tables_raw);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(kDirectBlock, kDirectWavesPerSimd) void pileup_dire
     uint4* z = reinterpret_cast<uint4*>(lds);
     for (int i = tid; i < TILE + OV; i += kDirectBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < p.table_len; i += kDirectBlock) {
-      s_tables[i] = p.filt->min_match[i];
-      s_tables[p.table_len + i] = p.filt->min_align[i];
+      s_tables[i] = (table_t)p.filt->min_match[i];
+      s_tables[p.table_len + i] = (table_t)p.filt->min_align[i];
     }
     for (int i = tid; i < 33 * 4; i += kDirectBlock) {
       const int h = i >> 2, wd = i & 3;
@@ -796,7 +800,7 @@ int direct_lane_bases(int32_t max_l_seq) {
 
 hipError_t launch_pileup_direct(const DirectParams& p, int lane_bases, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
-  const size_t dyn_lds = (size_t)p.table_len * 2 * sizeof(int32_t);
+  const size_t dyn_lds = (size_t)p.table_len * 2 * (p.overhang > kDirectOverhang ? sizeof(int16_t) : sizeof(int32_t));
   const int k = p.chunk_tiles > 1 ? p.chunk_tiles : 1;
   const int n_items = k > 1 ? p.n_chunked_tiles / k + (p.n_tiles - p.n_chunked_tiles) : p.n_tiles;      // (every workgroup of the grid has work)
   const int grid = n_items < p.grid_blocks ? n_items : p.grid_blocks;

@@ -80,6 +80,7 @@ struct midas_snps_batch {
   int32_t* d_contig_len = nullptr;
   uint8_t* d_work = nullptr;  // [rbinv n_tiles][rend n_tiles][stats n_species*4 u64][err u64]
   FilterTables* d_filt = nullptr;
+  bool filt_fits16 = true;       // every entry of the tables fits 16 bits (the long-overhang instantiation of the direct kernel)
   uint32_t* d_orig = nullptr;   // device record -> input index (for error reports)
   uint32_t* d_key = nullptr;    // device record -> tile << 7 | reach << 2 | class (input of the index kernel)
   uint32_t* d_items = nullptr;  // [n_items][4] work items {tile, part, n_parts, 0} of the pileup kernel
@@ -2805,6 +2806,10 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     b->filt_mapid = thr->mapid;
     b->filt_aln_cov = thr->aln_cov;
     b->filt_valid = true;
+    // (the long-overhang instantiation of the direct kernel keeps these tables in 16 bits: an identity threshold so negative that a
+    // table entry lies below -32768 -- mapid < -11 000 -- sends such a batch through the common instantiation, tile by tile)
+    b->filt_fits16 = true;
+    for (int32_t a = 0; a <= b->max_l_seq && a <= kMaxLSeq; ++a) b->filt_fits16 = b->filt_fits16 && b->h_filt.min_match[a] >= -32768 && b->h_filt.min_align[a] <= 32767;
   }
 
   if (run_path == MIDAS_SNPS_PATH_LONG) {
@@ -2857,9 +2862,9 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     dp.stats = work_stats(b); dp.err = work_err(b);
     dp.sched = b->d_ticket + b->n_tiles;
     dp.n_tiles = (int32_t)b->n_tiles; dp.n_reads = (int32_t)b->n_reads;
-    dp.overhang = b->direct_chunks ? b->direct_overhang : kDirectOverhang;      // (no chunks: nothing is carried, the common instantiation)
-    // (the long overhang's tallies are 2 KiB more LDS a workgroup: three of them fit a CU)
-    dp.grid_blocks = ctx->prop.multiProcessorCount * (dp.overhang > kDirectOverhang ? kWorkgroupsPerCU - 1 : kWorkgroupsPerCU);
+    const bool chunks = b->direct_chunks && (b->direct_overhang == kDirectOverhang || b->filt_fits16);
+    dp.overhang = chunks ? b->direct_overhang : kDirectOverhang;      // (no chunks: nothing is carried, the common instantiation)
+    dp.grid_blocks = ctx->prop.multiProcessorCount * kWorkgroupsPerCU;      // (the long overhang's instantiation keeps its tables in 16 bits: four workgroups a CU as well)
 #ifdef MIDAS_SNPS_GRID_BLOCKS
     dp.grid_blocks = MIDAS_SNPS_GRID_BLOCKS;
 #endif
@@ -2872,7 +2877,7 @@ int32_t midas_snps_batch_run(midas_snps_batch* b, const midas_snps_thresholds* t
     // than the overhang; the last eighth of the tiles one by one, so that the workgroups finish together
     dp.chunk_tiles = 1; dp.n_chunked_tiles = 0;
     dp.chunk_ok = b->d_chunk_ok;
-    if (b->direct_chunks) {
+    if (chunks) {
       dp.chunk_tiles = kDirectChunkTiles;
       dp.n_chunked_tiles = (int32_t)((b->n_tiles - b->n_tiles / kDirectTailDiv) / kDirectChunkTiles * kDirectChunkTiles);
     }

@@ -223,7 +223,10 @@ def test_250_bp_reads_are_chunked_with_the_long_overhang(hip_ctx, seed):
     table = abi.ContigTable(length=lengths, species=[k % 3 for k in range(len(lengths))], read_begin=begin,
                             ref=np.frombuffer("".join(ref).encode(), np.uint8), n_species=3,
                             ids=["c%d" % k for k in range(len(lengths))], species_ids=["s0", "s1", "s2"])
-    for args in (dict(abi.DEFAULT_ARGS, mapid=0.0), dict(abi.DEFAULT_ARGS, baseq=0, mapid=0.0, aln_cov=0.2, readq=0, mapq=0)):
+    # (the third set: an identity threshold so negative that the 16-bit tables of the long-overhang instantiation cannot hold it --
+    # that run goes tile by tile through the common instantiation)
+    for args in (dict(abi.DEFAULT_ARGS, mapid=0.0), dict(abi.DEFAULT_ARGS, baseq=0, mapid=0.0, aln_cov=0.2, readq=0, mapq=0),
+                 dict(abi.DEFAULT_ARGS, mapid=-1.0e6)):
         thr = abi.Thresholds.from_args(args)
         st, er, oc, oa, os_ = c_oracle.pileup(thr, table, soa)
         assert st == 0, (st, er)
