@@ -102,6 +102,10 @@ struct midas_snps_ctx {
   // (pinning and unpinning a quarter of a gigabyte per batch costs more than the copy it would speed up)
   static constexpr int kStageSlots = 2;
   static constexpr size_t kStageBytes = (size_t)32 << 20;
+  // (the ring has ONE user at a time -- copy_mutex: a decode's uploader, a fetch, and the table writers' copies, which run on
+  // copy_stream beside the next table's row kernel on the context's stream; taken AFTER device_mutex by whoever holds both)
+  std::mutex copy_mutex;
+  hipStream_t copy_stream = nullptr;
   void* stage[kStageSlots] = {nullptr, nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr};
   // Page-locking the ring costs ~0.2 ms a megabyte -- 14 ms that the first BAM decode of a process used to pay in front of its

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(256) void copy_out_kernel(copy_u32x4* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(src[i], &dst[i]);
 }
 
-int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t bytes) {
+int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t on = nullptr) {
   if (bytes == 0) return MIDAS_SNPS_OK;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = on ? on : ctx->stream;
   hipPointerAttribute_t at;
   const bool pinned = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
   (void)hipGetLastError();   // (an unregistered pointer is reported as an error: that is the pageable case)
@@ -270,6 +270,7 @@ int32_t copy_to_host(midas_snps_ctx* ctx, void* dst, const void* src, size_t byt
     return MIDAS_SNPS_OK;
   }
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
+  std::lock_guard<std::mutex> ring(ctx->copy_mutex);
   ctx->stage_join();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
@@ -350,6 +351,7 @@ int32_t copy_to_device_staged(midas_snps_ctx* ctx, void* dst, const void* src, s
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
     return MIDAS_SNPS_OK;
   }
+  std::lock_guard<std::mutex> ring(ctx->copy_mutex);
   ctx->stage_join();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (!ctx->stage[k]) HIP_TRY(ctx, hipHostMalloc(&ctx->stage[k], kChunk, kHostAllocFlags));
@@ -459,6 +461,7 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
   ctx->stage_join();
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->arena) ctx->arena->close();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
@@ -3102,17 +3105,22 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   const unsigned long long arena_bytes = (unsigned long long)rows * 10ull + (unsigned long long)n_members * 1024ull + 4096ull;
   std::vector<RowsResult> results((size_t)n_members);
   struct HostBuf { uint8_t* p = nullptr; ~HostBuf() { free(p); } } host;     // (malloc: no zero fill)
+  // Several host threads write one table each.  What they share is taken in turn, and as briefly as it can be: the context's
+  // stream for the row kernel (device_mutex), then the pinned ring + the copy stream for the streams' way down (copy_mutex) --
+  // table k's bytes cross the link while table k + 1 is formatted and deflated.  The allocations are nobody's turn.
+  HIP_TRY(ctx, hipSetDevice(ctx->device));       // (the calling thread may never have talked to the device)
+  DeviceBuf d_arena;      // one allocation: | arena | members | results | cursor | ids |
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t at_members = up256((size_t)arena_bytes), at_results = at_members + up256((size_t)n_members * sizeof(RowsMember)),
+               at_cursor = at_results + up256((size_t)n_members * sizeof(RowsResult)), at_ids = at_cursor + 256;
+  HIP_TRY(ctx, hipMalloc(&d_arena.p, at_ids + ids.size() + 16));
+  uint8_t* const d_base = static_cast<uint8_t*>(d_arena.p);
+  struct Part { void* p; } d_members{d_base + at_members}, d_results{d_base + at_results}, d_cursor{d_base + at_cursor}, d_ids{d_base + at_ids};
+  lap("members + hipMalloc");
+  unsigned long long used = 0;
   {
   std::lock_guard<std::mutex> device_part(ctx->device_mutex);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));       // (the calling thread may never have talked to the device)
-  DeviceBuf d_members, d_ids, d_results, d_arena, d_cursor;
-  HIP_TRY(ctx, hipMalloc(&d_members.p, (size_t)n_members * sizeof(RowsMember)));
-  HIP_TRY(ctx, hipMalloc(&d_ids.p, ids.size() + 16));
-  HIP_TRY(ctx, hipMalloc(&d_results.p, (size_t)n_members * sizeof(RowsResult)));
-  HIP_TRY(ctx, hipMalloc(&d_arena.p, (size_t)arena_bytes));
-  HIP_TRY(ctx, hipMalloc(&d_cursor.p, 8));
   hipStream_t s = ctx->stream;
-  lap("members + hipMalloc");
   HIP_TRY(ctx, hipMemcpyAsync(d_members.p, members.data(), (size_t)n_members * sizeof(RowsMember), hipMemcpyHostToDevice, s));
   if (!ids.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ids.p, ids.data(), ids.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0, (size_t)arena_bytes, s));
@@ -3126,20 +3134,30 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   rp.cursor = static_cast<unsigned long long*>(d_cursor.p);
   rp.results = static_cast<RowsResult*>(d_results.p);
   HIP_TRY(ctx, launch_rows_deflate(rp, ctx->prop.multiProcessorCount, s));
-  unsigned long long used = 0;
   HIP_TRY(ctx, hipMemcpyAsync(results.data(), d_results.p, (size_t)n_members * sizeof(RowsResult), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(&used, d_cursor.p, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  lap("memset + kernel");
+  lap("its turn, memset + kernel");
+  }
   for (const RowsResult& r : results)
     if (r.status != 0u) return MIDAS_SNPS_OK;
   if (used > arena_bytes) return MIDAS_SNPS_OK;
   host.p = static_cast<uint8_t*>(malloc((size_t)used + 16));
   if (!host.p) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "batch_write_part: out of host memory");
-  const int32_t cst = copy_to_host(ctx, host.p, d_arena.p, (size_t)used);
-  if (cst != MIDAS_SNPS_OK) return cst;
-  lap("streams to host");
+  {
+    hipStream_t cs = nullptr;
+    {
+      std::lock_guard<std::mutex> g(ctx->copy_mutex);
+      if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; }
+      cs = ctx->copy_stream;
+    }
+    // (the row kernel is over -- the stream was waited for above: the copy depends on nothing that is still running)
+    const int32_t cst = copy_to_host(ctx, host.p, d_arena.p, (size_t)used, cs);
+    if (cst != MIDAS_SNPS_OK) return cst;
   }
+  lap("streams to host");
+  (void)hipFree(d_arena.p);       // (before the file is written: the next tables want the memory)
+  d_arena.p = nullptr;
   std::vector<CodedMember> coded((size_t)n_members);
   for (int64_t k = 0; k < n_members; ++k) {
     const RowsResult& r = results[(size_t)k];
@@ -3183,6 +3201,7 @@ int32_t midas_snps_batch_write_part(midas_snps_batch* b, const char* path, int32
     if (st != MIDAS_SNPS_OK || done) return st;
   }
   std::lock_guard<std::mutex> host_path(ctx->device_mutex);      // (the host's formatter owns the staging ring for the whole call)
+  std::lock_guard<std::mutex> host_ring(ctx->copy_mutex);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   constexpr size_t kChunk = midas_snps_ctx::kStageBytes;
   ctx->stage_join();
