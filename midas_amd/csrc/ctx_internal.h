@@ -106,6 +106,57 @@ struct midas_snps_ctx {
   // copy_stream beside the next table's row kernel on the context's stream; taken AFTER device_mutex by whoever holds both)
   std::mutex copy_mutex;
   hipStream_t copy_stream = nullptr;
+  // device buffers of the table writers (one a table: its coded streams + the members' tables), kept between tables: a hipMalloc /
+  // hipFree pair per table is 2-3 ms of which the free waits for whatever the device is running
+  struct RowBuffers {
+    std::mutex m;
+    std::vector<std::pair<void*, size_t>> idle;
+    void* take(size_t bytes, size_t* got) {
+      {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = idle.size();
+        for (size_t k = 0; k < idle.size(); ++k)
+          if (idle[k].second >= bytes && (best == idle.size() || idle[k].second < idle[best].second)) best = k;
+        if (best < idle.size()) {
+          void* p = idle[best].first;
+          *got = idle[best].second;
+          idle.erase(idle.begin() + (long)best);
+          return p;
+        }
+      }
+      void* p = nullptr;
+      const size_t want = bytes + bytes / 8;       // (the next table of about this size fits too)
+      if (hipMalloc(&p, want) != hipSuccess) {      // (out of memory: what lies idle goes, then exactly what was asked for)
+        (void)hipGetLastError();
+        clear();
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *got = bytes;
+        return p;
+      }
+      *got = want;
+      return p;
+    }
+    void give(void* p, size_t bytes) {
+      std::vector<void*> drop;
+      {
+        std::lock_guard<std::mutex> g(m);
+        idle.emplace_back(p, bytes);
+        while (idle.size() > 16) {        // (more than any number of writers: the smallest go)
+          size_t least = 0;
+          for (size_t k = 1; k < idle.size(); ++k)
+            if (idle[k].second < idle[least].second) least = k;
+          drop.push_back(idle[least].first);
+          idle.erase(idle.begin() + (long)least);
+        }
+      }
+      for (void* q : drop) (void)hipFree(q);
+    }
+    void clear() {
+      std::lock_guard<std::mutex> g(m);
+      for (auto& e : idle) (void)hipFree(e.first);
+      idle.clear();
+    }
+  } row_buffers;
   void* stage[kStageSlots] = {nullptr, nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr};
   // Page-locking the ring costs ~0.2 ms a megabyte -- 14 ms that the first BAM decode of a process used to pay in front of its

@@ -462,6 +462,7 @@ void midas_snps_destroy(midas_snps_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  ctx->row_buffers.clear();
   if (ctx->arena) ctx->arena->close();
   for (int k = 0; k < midas_snps_ctx::kStageSlots; ++k) {
     if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
@@ -3109,11 +3110,15 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
   // stream for the row kernel (device_mutex), then the pinned ring + the copy stream for the streams' way down (copy_mutex) --
   // table k's bytes cross the link while table k + 1 is formatted and deflated.  The allocations are nobody's turn.
   HIP_TRY(ctx, hipSetDevice(ctx->device));       // (the calling thread may never have talked to the device)
-  DeviceBuf d_arena;      // one allocation: | arena | members | results | cursor | ids |
+  struct PooledBuf {      // one buffer (the context keeps a few between tables): | arena | members | results | cursor | ids |
+    midas_snps_ctx* ctx; void* p = nullptr; size_t bytes = 0;
+    ~PooledBuf() { if (p) ctx->row_buffers.give(p, bytes); }
+  } d_arena{ctx};
   auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t at_members = up256((size_t)arena_bytes), at_results = at_members + up256((size_t)n_members * sizeof(RowsMember)),
                at_cursor = at_results + up256((size_t)n_members * sizeof(RowsResult)), at_ids = at_cursor + 256;
-  HIP_TRY(ctx, hipMalloc(&d_arena.p, at_ids + ids.size() + 16));
+  d_arena.p = ctx->row_buffers.take(at_ids + ids.size() + 16, &d_arena.bytes);
+  if (!d_arena.p) return fail(ctx, MIDAS_SNPS_ERR_OUT_OF_MEMORY, "batch_write_part: out of device memory for a table's coded rows");
   uint8_t* const d_base = static_cast<uint8_t*>(d_arena.p);
   struct Part { void* p; } d_members{d_base + at_members}, d_results{d_base + at_results}, d_cursor{d_base + at_cursor}, d_ids{d_base + at_ids};
   lap("members + hipMalloc");
@@ -3156,7 +3161,7 @@ int32_t write_part_on_device(midas_snps_batch* b, const char* path, bool with_he
     if (cst != MIDAS_SNPS_OK) return cst;
   }
   lap("streams to host");
-  (void)hipFree(d_arena.p);       // (before the file is written: the next tables want the memory)
+  ctx->row_buffers.give(d_arena.p, d_arena.bytes);       // (before the file is written: the next table takes it)
   d_arena.p = nullptr;
   std::vector<CodedMember> coded((size_t)n_members);
   for (int64_t k = 0; k < n_members; ++k) {

@@ -36,7 +36,7 @@ from midas_amd import abi, bam, dist, fasta, pieces, utility
 # writer thread: level 9 0.2, 6 0.5, 4 1.7, 1 2.5 M rows/s for 28.5 / 29.0 / 30.4 / 34.5 MB -- 4 costs 5 % of file size and
 # takes the formatter from the largest to the second smallest item of the stage.
 GZ_LEVEL = 4
-WRITERS = 6                  # tables written side by side from a batch (_write_jobs)
+WRITERS = int(os.environ.get('MIDAS_SNPS_WRITERS', '6') or 6)      # tables written side by side from a batch (_write_jobs)
 MAX_BATCH_READS = 1 << 30   # a rank's work items go to the device in batches of at most this many reads (args['max_batch_reads']) ...
 MAX_BATCH_PAYLOAD = 24 << 30   # ... and about this many bytes of SEQ / QUAL / CIGAR (the library's own limits: 2 * 10^9 reads, 32 GiB)
 SPLIT_LENGTH = 8 << 20      # contigs longer than this are dealt to the ranks in pieces (args['split_length']; 0: never)
