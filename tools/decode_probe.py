@@ -26,7 +26,7 @@ print("%s: %d reads, BAM %.2f GB" % (cfg, reads.n_reads, os.path.getsize(path) /
 del reads
 KEYS = ("MIDAS_SNPS_DECODE_STREAM", "MIDAS_SNPS_DECODE_GROUP_BLOCKS", "MIDAS_SNPS_DECODE_SLOTS")
 variants = [("one arena", {"MIDAS_SNPS_DECODE_STREAM": "0"}), ("streamed, the default groups", {})]
-for blocks in (40960, 24000, 16000, 12000, 8000):
+for blocks in (() if os.environ.get("DECODE_PROBE_BRIEF") else (40960, 24000, 16000, 12000, 8000)):      # (DECODE_PROBE_BRIEF=1: the two decodes only, e.g. under rocprofv3)
     for slots in (2, 3):
         variants.append(("streamed, groups of %d blocks, %d slots" % (blocks, slots), {"MIDAS_SNPS_DECODE_GROUP_BLOCKS": str(blocks), "MIDAS_SNPS_DECODE_SLOTS": str(slots)}))
 with abi.Context(0) as ctx:
@@ -37,7 +37,7 @@ with abi.Context(0) as ctx:
             os.environ.pop(k, None)
         os.environ.update(env)
         best = 1e9
-        for _ in range(4):
+        for _ in range(2 if os.environ.get("DECODE_PROBE_BRIEF") else 4):
             t = time.perf_counter()
             _, _, rid, res = abi.read_bam(path, ctx, resident=True)
             best = min(best, time.perf_counter() - t)
