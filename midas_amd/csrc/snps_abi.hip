@@ -959,7 +959,7 @@ int32_t device_decode_stream(midas_snps_ctx* ctx, const uint8_t* comp_base, cons
     const size_t nj = G.b_ext - G.b_lo;
     // (behind the inflated bytes: the dead compressed bytes, tables and match lists hold the walk's tables and the record offsets --
     // 8 bytes a record of >= 36: a quarter of the inflated bytes at most)
-    const size_t behind = std::max(up(G.comp + 512) + up(nj * sizeof(InflateBlock)) + up(nj * 8) + up(nj * 4) + up(G.room * 8) + 256, G.infl / 3 + ((size_t)4 << 20));      // (slot_layout's regions, each rounded up by itself)
+    const size_t behind = std::max(up(G.comp + 512) + up(nj * sizeof(InflateBlock)) + up(nj * 8) + up(nj * 4) + up(G.room * 8) + 256, G.infl / 3 + ((size_t)4 << 20) + up((size_t)(n_ref > 0 ? n_ref : 1) * 8));      // (slot_layout's regions, each rounded up by itself)
     slot_bytes = std::max(slot_bytes, up(G.infl + 64) + behind);
   }
   if (n_slots > (int)K) n_slots = (int)K;
